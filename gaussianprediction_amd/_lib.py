@@ -1,0 +1,149 @@
+"""ctypes binding of libgp_hip.so (C ABI declared in include/gp_hip.h).
+
+The HIP library is the product; there is NO CPU or eager-PyTorch fallback.  If the shared library is
+missing or cannot be loaded this module raises immediately and loudly.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+
+import torch  # noqa: F401  (must be imported first: libgp_hip.so binds to the HIP runtime torch loaded)
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "libgp_hip.so")
+
+GP_BUF_GEOM, GP_BUF_BINNING, GP_BUF_IMAGE, GP_BUF_TEMP = 0, 1, 2, 3
+
+ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_int, C.c_size_t)
+
+_f = C.POINTER(C.c_float)
+
+
+class RasterSettingsC(C.Structure):
+    _fields_ = [("image_height", C.c_int32), ("image_width", C.c_int32), ("tanfovx", C.c_float),
+                ("tanfovy", C.c_float), ("scale_modifier", C.c_float), ("sh_degree", C.c_int32),
+                ("sh_coeffs", C.c_int32), ("prefiltered", C.c_int32), ("debug", C.c_int32),
+                ("bg", C.c_void_p), ("viewmatrix", C.c_void_p), ("projmatrix", C.c_void_p), ("campos", C.c_void_p)]
+
+
+class RasterInputsC(C.Structure):
+    _fields_ = [("num_gaussians", C.c_int64), ("means3D", C.c_void_p), ("shs", C.c_void_p),
+                ("colors_precomp", C.c_void_p), ("opacities", C.c_void_p), ("scales", C.c_void_p),
+                ("rotations", C.c_void_p), ("cov3D_precomp", C.c_void_p)]
+
+
+class RasterOutputsC(C.Structure):
+    _fields_ = [("color", C.c_void_p), ("radii", C.c_void_p), ("depth", C.c_void_p), ("tidx", C.c_void_p)]
+
+
+class RasterSavedC(C.Structure):
+    _fields_ = [("geom", C.c_void_p), ("geom_bytes", C.c_size_t), ("binning", C.c_void_p),
+                ("binning_bytes", C.c_size_t), ("image", C.c_void_p), ("image_bytes", C.c_size_t),
+                ("num_rendered", C.c_int64)]
+
+
+class RasterGradsC(C.Structure):
+    _fields_ = [("dL_dmeans3D", C.c_void_p), ("dL_dmeans2D", C.c_void_p), ("dL_dshs", C.c_void_p),
+                ("dL_dcolors_precomp", C.c_void_p), ("dL_dopacities", C.c_void_p), ("dL_dscales", C.c_void_p),
+                ("dL_drotations", C.c_void_p), ("dL_dcov3D_precomp", C.c_void_p)]
+
+
+class MlpParamsC(C.Structure):
+    _fields_ = [("in_dim", C.c_int32), ("width", C.c_int32), ("depth", C.c_int32), ("out_dim", C.c_int32),
+                ("w", C.c_void_p * 5), ("b", C.c_void_p * 5)]
+
+
+class MlpGradsC(C.Structure):
+    _fields_ = [("dw", C.c_void_p * 5), ("db", C.c_void_p * 5)]
+
+
+class MlpInputC(C.Structure):
+    _fields_ = [("rows", C.c_int64), ("feature_dim", C.c_int32), ("xyz_freq", C.c_int32), ("time_freq", C.c_int32),
+                ("feature", C.c_void_p), ("xyz", C.c_void_p), ("t", C.c_void_p)]
+
+
+class BlendArgsC(C.Structure):
+    _fields_ = [("num_gaussians", C.c_int64), ("num_keypoints", C.c_int64), ("nearest_num", C.c_int32),
+                ("out_dim", C.c_int32), ("norm_rotation", C.c_int32), ("delta", C.c_void_p), ("raw_w", C.c_void_p),
+                ("knn_idx", C.c_void_p), ("xyz", C.c_void_p), ("rot", C.c_void_p)]
+
+
+EXPORTS = [
+    "gp_raster_forward", "gp_raster_backward", "gp_raster_mark_visible", "gp_raster_debug_binning",
+    "gp_mlp_forward", "gp_mlp_backward", "gp_blend_forward", "gp_blend_backward",
+    "gp_activations_forward", "gp_activations_backward", "gp_last_error", "gp_version",
+]
+
+_lib = None
+_lock = threading.Lock()
+
+
+class GpHipError(RuntimeError):
+    pass
+
+
+def lib() -> C.CDLL:
+    """Load libgp_hip.so once.  Raises (never falls back) if it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise GpHipError(
+                f"{LIB_PATH} not found: the HIP extension is the only implementation of this path (no CPU/eager "
+                "fallback). Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950).")
+        l = C.CDLL(LIB_PATH)
+        for name in EXPORTS:
+            if not hasattr(l, name):
+                raise GpHipError(f"{LIB_PATH} does not export {name}")
+        l.gp_last_error.restype = C.c_char_p
+        l.gp_version.restype = C.c_char_p
+        for name in EXPORTS:
+            if name not in ("gp_last_error", "gp_version"):
+                getattr(l, name).restype = C.c_int
+        _lib = l
+        return _lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        raise GpHipError(f"{what}: {lib().gp_last_error().decode(errors='replace')}")
+
+
+def ptr(t):
+    """device pointer of a tensor (None -> NULL)."""
+    if t is None:
+        return None
+    return C.c_void_p(t.data_ptr())
+
+
+def stream_ptr(device=None):
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+class TorchAllocator:
+    """Backs gp_alloc_fn with torch's caching allocator; keeps buffers alive per class."""
+
+    def __init__(self, device):
+        self.device = device
+        self.bufs = {GP_BUF_GEOM: [], GP_BUF_BINNING: [], GP_BUF_IMAGE: [], GP_BUF_TEMP: []}
+        self.error = None
+        self.cb = ALLOC_FN(self._alloc)
+
+    def _alloc(self, _ctx, which, nbytes):
+        try:
+            t = torch.empty(max(int(nbytes), 1), dtype=torch.uint8, device=self.device)
+            self.bufs[which].append(t)
+            return t.data_ptr()
+        except Exception as e:  # never let an exception cross the C boundary
+            self.error = e
+            return 0
+
+    def first(self, which):
+        b = self.bufs[which]
+        return b[0] if b else None

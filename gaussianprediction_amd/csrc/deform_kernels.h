@@ -1,0 +1,50 @@
+// deform_kernels.h -- device-side argument structs + kernel declarations (definitions in deform_kernels.hip)
+#pragma once
+#include "gp_common.h"
+
+struct MlpDev {
+    long rows;
+    int in_dim, in_pad, out_dim;
+    int feature_dim, xyz_freq, time_freq;
+    const float* w[5];
+    const float* b[5];
+    const float* feature;
+    const float* xyz;
+    const float* t;
+};
+
+struct BlendDev {
+    long N, K;
+    int nn, out_dim, norm_rotation;
+    const float* delta;
+    const float* raw_w;
+    const int64_t* knn;
+    const float* xyz;
+    const float* rot;
+};
+
+__global__ __launch_bounds__(512) void gp_mlp_fwd_kernel(MlpDev p, float* __restrict__ out, float* __restrict__ saved_x,
+                                                         float* __restrict__ saved_h);
+__global__ __launch_bounds__(512) void gp_mlp_bwd_data_kernel(MlpDev p, const float* __restrict__ saved_h,
+                                                              const float* __restrict__ dL_dout, float* __restrict__ dz,
+                                                              float* __restrict__ dfeature, float* __restrict__ dxyz);
+__global__ __launch_bounds__(512) void gp_mlp_bwd_weight_kernel(const float* __restrict__ dZ, int n_out,
+                                                                const float* __restrict__ H, int ldh, int n_in, long rows,
+                                                                long rows_per_block, float* __restrict__ dW, int lddw,
+                                                                float* __restrict__ db);
+__global__ __launch_bounds__(256) void gp_blend_fwd_kernel(BlendDev a, float* __restrict__ xyz_t, float* __restrict__ q_t);
+__global__ __launch_bounds__(256) void gp_blend_bwd_kernel(BlendDev a, const float* __restrict__ g_xyz_t,
+                                                           const float* __restrict__ g_q_t, float* __restrict__ g_delta,
+                                                           float* __restrict__ g_raw_w, float* __restrict__ g_xyz,
+                                                           float* __restrict__ g_rot);
+__global__ __launch_bounds__(256) void gp_act_fwd_kernel(long n, const float* __restrict__ scaling_raw,
+                                                         const float* __restrict__ opacity_raw,
+                                                         const float* __restrict__ delta_o, int stride, float beta,
+                                                         float* __restrict__ scale, float* __restrict__ opacity);
+__global__ __launch_bounds__(256) void gp_act_bwd_kernel(long n, const float* __restrict__ scaling_raw,
+                                                         const float* __restrict__ opacity_raw,
+                                                         const float* __restrict__ delta_o, int stride, float beta,
+                                                         const float* __restrict__ g_scale,
+                                                         const float* __restrict__ g_opacity,
+                                                         float* __restrict__ g_scaling_raw, float* __restrict__ g_opacity_raw,
+                                                         float* __restrict__ g_delta_o);

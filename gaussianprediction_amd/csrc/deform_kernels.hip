@@ -1,0 +1,488 @@
+// deform_kernels.hip -- the per-frame deformation step of GaussianModel.forward on gfx950:
+//   * fused positional-encoding + Deformable_Field MLP, forward and backward, on the exact-fp32
+//     matrix cores (v_mfma_f32_32x32x2_f32: bitwise an fmaf chain, so RGB parity at 1e-4 holds)
+//   * keypoint blend (two softmaxes + SPARSE nn-neighbour gather instead of the reference's dense
+//     [N,K] scatter + matmul), quaternion compose / normalise, forward and backward
+//   * exp / sigmoid activations with the optional lifecycle-opacity factor
+// Reference: scene/gaussian_model.py:180-189, 214-229, 231-304, 314-315; scene/deformable_field.py:63-72,
+// 102-127; utils/camera_utils.py:158-170.
+//
+// MLP data layout.  A workgroup (8 waves) owns 32 rows.  Activations live TRANSPOSED in LDS,
+// act[feature][row], XOR-swizzled (row ^ (feature & 31)) so both the coalesced staging writes and the
+// MFMA operand reads are bank-conflict free.  Each layer computes H_out^T = W . H_in^T: the weight
+// matrix is the MFMA A operand (read straight from L2, nn.Linear's [out,in] row-major layout gives
+// each lane one float4 = 4 consecutive k), the activations are the B operand (LDS), and wave w
+// produces output features [32w, 32w+32).  No activation ever goes through HBM in inference mode.
+#include "gp_common.h"
+#include "deform_kernels.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define MLP_ROWS 32
+#define MLP_THREADS 512
+#define MLP_W 256
+
+__device__ __forceinline__ int act_idx(int f, int j) { return f * MLP_ROWS + (j ^ (f & 31)); }
+// C/D layout of v_mfma_f32_32x32x2_f32: lane l, reg r -> row (r&3) + 8*(r>>2) + 4*(l>>5), col l&31
+__device__ __forceinline__ int cd_row(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
+
+// Builds X^T (input features) for the 32 rows of this workgroup into `buf` (swizzled), zero-padded to
+// in_pad features.  Row layout [feature(fd) | PE(xyz) 6*xf | PE(t) 2*tf]
+// [REF scene/gaussian_model.py:180-184; scene/deformable_field.py:63-72: (sin,cos) interleaved per
+// (coordinate, frequency), coordinate-major, frequencies 2^j, no pi factor].
+__device__ __forceinline__ void build_input(float* buf, const MlpDev& p, long row0, int tid) {
+    const int fd = p.feature_dim, xf = p.xyz_freq, tf = p.time_freq;
+    for (int e = tid; e < fd * MLP_ROWS; e += MLP_THREADS) {
+        const int jj = e / fd, f = e - jj * fd;
+        const long row = row0 + jj;
+        buf[act_idx(f, jj)] = row < p.rows ? p.feature[row * fd + f] : 0.f;
+    }
+    for (int e = tid; e < 3 * xf * MLP_ROWS; e += MLP_THREADS) {
+        const int jj = e % MLP_ROWS, cf = e / MLP_ROWS;  // cf = c*xf + fr
+        const int c = cf / xf, fr = cf - c * xf;
+        const long row = row0 + jj;
+        float sv = 0.f, cv = 0.f;
+        if (row < p.rows) {
+            const float a = p.xyz[row * 3 + c] * (float)(1u << fr);
+            sincosf(a, &sv, &cv);
+        }
+        const int f = fd + 2 * cf;
+        buf[act_idx(f, jj)] = sv;
+        buf[act_idx(f + 1, jj)] = cv;
+    }
+    const float tv = tf > 0 ? p.t[0] : 0.f;
+    for (int e = tid; e < tf * MLP_ROWS; e += MLP_THREADS) {
+        const int jj = e % MLP_ROWS, fr = e / MLP_ROWS;
+        float sv, cv;
+        sincosf(tv * (float)(1u << fr), &sv, &cv);
+        const bool ok = row0 + jj < p.rows;
+        const int f = fd + 6 * xf + 2 * fr;
+        buf[act_idx(f, jj)] = ok ? sv : 0.f;
+        buf[act_idx(f + 1, jj)] = ok ? cv : 0.f;
+    }
+    for (int e = tid; e < (p.in_pad - p.in_dim) * MLP_ROWS; e += MLP_THREADS) {
+        const int jj = e % MLP_ROWS, f = p.in_dim + e / MLP_ROWS;
+        buf[act_idx(f, jj)] = 0.f;
+    }
+}
+
+// coalesced copy LDS act^T[0:nf][32] -> global dst[(row0+jj)*ld + f]
+__device__ __forceinline__ void store_rows(const float* buf, float* dst, int nf, int ld, long row0, long rows, int tid) {
+    for (int e = tid; e < nf * MLP_ROWS; e += MLP_THREADS) {
+        const int jj = e / nf, f = e - jj * nf;
+        if (row0 + jj < rows) dst[(row0 + jj) * (long)ld + f] = buf[act_idx(f, jj)];
+    }
+}
+
+// one dense layer on the matrix cores: out^T[32*wave .. +32][32 rows] = W[., 0:K] . cur^T + bias
+__device__ __forceinline__ f32x16 layer_mfma(const float* __restrict__ W, int ldw, int K, int out_rows,
+                                             const float* __restrict__ bias, const float* cur, int wave, int lane) {
+    const int half = lane >> 5, j = lane & 31;
+    const int i_row = 32 * wave + j;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int f = 32 * wave + cd_row(r, half);
+        acc[r] = (bias && f < out_rows) ? bias[f] : 0.f;
+    }
+    const bool row_ok = i_row < out_rows;
+    const float* wrow = W + (size_t)i_row * ldw;
+    for (int kq = 0; kq < K / 8; ++kq) {
+        const int kbase = 8 * kq + 4 * half;
+        float4 wv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (row_ok && kbase < ldw) wv = *(const float4*)(wrow + kbase);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.x, cur[act_idx(kbase + 0, j)], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.y, cur[act_idx(kbase + 1, j)], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.z, cur[act_idx(kbase + 2, j)], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.w, cur[act_idx(kbase + 3, j)], acc, 0, 0, 0);
+    }
+    return acc;
+}
+
+// transposed layer for backward: out^T[i][row] = sum_k W[k][i] * cur^T[k][row]  (W is [Kout, ldw])
+__device__ __forceinline__ f32x16 layer_mfma_T(const float* __restrict__ W, int ldw, int K, int k_valid, int out_rows,
+                                               const float* cur, int wave, int lane) {
+    const int half = lane >> 5, j = lane & 31;
+    const int i_row = 32 * wave + j;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const bool row_ok = i_row < out_rows;
+    for (int kq = 0; kq < K / 8; ++kq) {
+        const int kbase = 8 * kq + 4 * half;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int k = kbase + u;
+            const float a = (row_ok && k < k_valid) ? W[(size_t)k * ldw + i_row] : 0.f;
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, cur[act_idx(k, j)], acc, 0, 0, 0);
+        }
+    }
+    return acc;
+}
+
+// ------------------------------------------------------------------------------------------------
+// MLP forward
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(MLP_THREADS) void gp_mlp_fwd_kernel(MlpDev p, float* __restrict__ out,
+                                                                 float* __restrict__ saved_x, float* __restrict__ saved_h) {
+    __shared__ float smem[2][MLP_W * MLP_ROWS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, j = lane & 31;
+    const long row0 = (long)blockIdx.x * MLP_ROWS;
+    float* cur = smem[0];
+    float* nxt = smem[1];
+    build_input(cur, p, row0, tid);
+    __syncthreads();
+    if (saved_x) store_rows(cur, saved_x, p.in_pad, p.in_pad, row0, p.rows, tid);
+    for (int l = 0; l < 4; ++l) {
+        const int K = l == 0 ? p.in_pad : MLP_W, ldw = l == 0 ? p.in_dim : MLP_W;
+        f32x16 acc = layer_mfma(p.w[l], ldw, K, MLP_W, p.b[l], cur, wave, lane);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) nxt[act_idx(32 * wave + cd_row(r, half), j)] = fmaxf(acc[r], 0.f);
+        __syncthreads();
+        if (saved_h) store_rows(nxt, saved_h + (size_t)l * p.rows * MLP_W, MLP_W, MLP_W, row0, p.rows, tid);
+        float* t = cur; cur = nxt; nxt = t;
+    }
+    // output layer: out_dim <= 8 rows of W4; split K over the 8 waves, reduce through LDS
+    {
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        const bool row_ok = j < p.out_dim;
+        const float* wrow = p.w[4] + (size_t)j * MLP_W;
+        for (int kq = 4 * wave; kq < 4 * wave + 4; ++kq) {
+            const int kbase = 8 * kq + 4 * half;
+            float4 wv = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row_ok) wv = *(const float4*)(wrow + kbase);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.x, cur[act_idx(kbase + 0, j)], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.y, cur[act_idx(kbase + 1, j)], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.z, cur[act_idx(kbase + 2, j)], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.w, cur[act_idx(kbase + 3, j)], acc, 0, 0, 0);
+        }
+        // features 0..3 sit in regs 0..3 of half 0, features 4..7 in regs 0..3 of half 1
+#pragma unroll
+        for (int r = 0; r < 4; ++r) nxt[(wave * 8 + r + 4 * half) * MLP_ROWS + j] = acc[r];
+        __syncthreads();
+        if (tid < 8 * MLP_ROWS) {
+            const int jj = tid / 8, f = tid % 8;
+            if (f < p.out_dim && row0 + jj < p.rows) {
+                float v = p.b[4][f];
+#pragma unroll
+                for (int w = 0; w < 8; ++w) v += nxt[(w * 8 + f) * MLP_ROWS + jj];
+                out[(row0 + jj) * p.out_dim + f] = v;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// MLP backward, data chain: dZ_l for l = 4..1 (written to dz[l-1]), dX -> d feature, d xyz
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(MLP_THREADS) void gp_mlp_bwd_data_kernel(MlpDev p, const float* __restrict__ saved_h,
+                                                                      const float* __restrict__ dL_dout,
+                                                                      float* __restrict__ dz, float* __restrict__ dfeature,
+                                                                      float* __restrict__ dxyz) {
+    __shared__ float smem[2][MLP_W * MLP_ROWS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, j = lane & 31;
+    const long row0 = (long)blockIdx.x * MLP_ROWS;
+    float* cur = smem[0];
+    float* nxt = smem[1];
+    // dZ5^T [8][32] (zero-padded)
+    for (int e = tid; e < 8 * MLP_ROWS; e += MLP_THREADS) {
+        const int jj = e / 8, f = e % 8;
+        const long row = row0 + jj;
+        cur[act_idx(f, jj)] = (f < p.out_dim && row < p.rows) ? dL_dout[row * p.out_dim + f] : 0.f;
+    }
+    __syncthreads();
+    for (int l = 4; l >= 1; --l) {
+        // dH_l^T = W_l^T dZ_{l+1}^T ; W_l = p.w[l] is [Kout, 256]
+        const int K = l == 4 ? 8 : MLP_W, kv = l == 4 ? p.out_dim : MLP_W;
+        f32x16 acc = layer_mfma_T(p.w[l], MLP_W, K, kv, MLP_W, cur, wave, lane);
+        const float* h = saved_h + (size_t)(l - 1) * p.rows * MLP_W;
+        const long row = row0 + j;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int f = 32 * wave + cd_row(r, half);
+            const float hv = row < p.rows ? h[row * MLP_W + f] : 0.f;
+            nxt[act_idx(f, j)] = hv > 0.f ? acc[r] : 0.f;
+        }
+        __syncthreads();
+        store_rows(nxt, dz + (size_t)(l - 1) * p.rows * MLP_W, MLP_W, MLP_W, row0, p.rows, tid);
+        float* t = cur; cur = nxt; nxt = t;
+    }
+    // dX^T [in_pad][32] = W_0^T dZ_1^T ; W_0 is [256, in_dim]
+    if (dfeature || dxyz) {
+        if (wave * 32 < p.in_pad) {
+            f32x16 acc = layer_mfma_T(p.w[0], p.in_dim, MLP_W, MLP_W, p.in_dim, cur, wave, lane);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) nxt[act_idx(32 * wave + cd_row(r, half), j)] = acc[r];
+        }
+        __syncthreads();
+        if (dfeature) store_rows(nxt, dfeature, p.feature_dim, p.feature_dim, row0, p.rows, tid);
+        if (dxyz) {
+            // d/dx sin(x 2^f) = 2^f cos, d/dx cos(x 2^f) = -2^f sin
+            if (tid < 3 * MLP_ROWS) {
+                const int jj = tid / 3, c = tid % 3;
+                const long row = row0 + jj;
+                if (row < p.rows) {
+                    const float x = p.xyz[row * 3 + c];
+                    float g = 0.f;
+                    for (int fr = 0; fr < p.xyz_freq; ++fr) {
+                        const float sc = (float)(1u << fr);
+                        float sv, cv;
+                        sincosf(x * sc, &sv, &cv);
+                        const int f = p.feature_dim + 2 * (c * p.xyz_freq + fr);
+                        g += sc * (cv * nxt[act_idx(f, jj)] - sv * nxt[act_idx(f + 1, jj)]);
+                    }
+                    dxyz[row * 3 + c] = g;
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// MLP backward, weight grads: dW[o][i] += sum_rows dZ[row][o] * H[row][i]   (A = dZ^T, B = H)
+// grid = (row chunks, i-tiles of 32); wave w of the 8 owns o-tile w.  K (= rows) is walked two rows
+// per MFMA; operands come straight from global memory (each 32-lane half reads 128 contiguous bytes).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(MLP_THREADS) void gp_mlp_bwd_weight_kernel(const float* __restrict__ dZ, int n_out,
+                                                                        const float* __restrict__ H, int ldh, int n_in,
+                                                                        long rows, long rows_per_block,
+                                                                        float* __restrict__ dW, int lddw,
+                                                                        float* __restrict__ db) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, j = lane & 31;
+    const int o = 32 * wave + j;       // A row (output feature)
+    const int i = 32 * blockIdx.y + j; // B col (input feature)
+    const long r_begin = (long)blockIdx.x * rows_per_block;
+    long r_end = r_begin + rows_per_block;
+    if (r_end > rows) r_end = rows;
+    if (32 * wave >= n_out) return;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    float bsum = 0.f;
+    const bool o_ok = o < n_out, i_ok = i < n_in;
+    for (long rb = r_begin; rb < r_end; rb += 2) {  // uniform trip count: MFMA needs the whole wave
+        const long r = rb + half;
+        float a = 0.f, b = 0.f;
+        if (r < r_end) {
+            if (o_ok) a = dZ[r * n_out + o];
+            if (i_ok) b = H[r * (long)ldh + i];
+        }
+        bsum += a;
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int oo = 32 * wave + cd_row(r, half);
+        if (oo < n_out && i_ok) atomicAdd(&dW[(size_t)oo * lddw + i], acc[r]);
+    }
+    if (db && blockIdx.y == 0) {
+        bsum += __shfl_xor(bsum, 32);
+        if (half == 0 && o_ok) atomicAdd(&db[o], bsum);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// keypoint blend + pose composition
+// ------------------------------------------------------------------------------------------------
+#define GP_MAX_NN 16
+
+__device__ __forceinline__ void quat_mul(const float* q, const float* r, float* p) {  // p = q (x) r, (w,x,y,z)
+    p[0] = r[0] * q[0] - r[1] * q[1] - r[2] * q[2] - r[3] * q[3];
+    p[1] = r[1] * q[0] + r[0] * q[1] + r[3] * q[2] - r[2] * q[3];
+    p[2] = r[2] * q[0] - r[3] * q[1] + r[0] * q[2] + r[1] * q[3];
+    p[3] = r[3] * q[0] + r[2] * q[1] - r[1] * q[2] + r[0] * q[3];
+}
+__device__ __forceinline__ float norm4(const float* v) {
+    return fmaxf(sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3]), 1e-12f);  // F.normalize eps
+}
+__device__ __forceinline__ void softmax_n(const float* __restrict__ raw, int n, float* w) {
+    float m = raw[0];
+    for (int k = 1; k < n; ++k) m = fmaxf(m, raw[k]);
+    float s = 0.f;
+    for (int k = 0; k < n; ++k) { w[k] = expf(raw[k] - m); s += w[k]; }
+    const float inv = 1.f / s;
+    for (int k = 0; k < n; ++k) w[k] *= inv;
+}
+
+__global__ __launch_bounds__(256) void gp_blend_fwd_kernel(BlendDev a, float* __restrict__ xyz_t, float* __restrict__ q_t) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= a.N) return;
+    float dxyz[3] = {0.f, 0.f, 0.f}, dq[4] = {0.f, 0.f, 0.f, 0.f};
+    const int od = a.out_dim, nn = a.nn;
+    if (nn > 0) {
+        float wx[GP_MAX_NN], wr[GP_MAX_NN];
+        softmax_n(a.raw_w + i * 2 * nn, nn, wx);
+        softmax_n(a.raw_w + i * 2 * nn + nn, nn, wr);
+        for (int k = 0; k < nn; ++k) {
+            const long kp = a.knn[i * nn + k];
+            const float* dl = a.delta + kp * od;
+            dxyz[0] = fmaf(wx[k], dl[0], dxyz[0]);
+            dxyz[1] = fmaf(wx[k], dl[1], dxyz[1]);
+            dxyz[2] = fmaf(wx[k], dl[2], dxyz[2]);
+            float v[4] = {dl[3], dl[4], dl[5], dl[6]};
+            if (a.norm_rotation) { const float inv = 1.f / norm4(v); v[0] *= inv; v[1] *= inv; v[2] *= inv; v[3] *= inv; }
+            dq[0] = fmaf(wr[k], v[0], dq[0]); dq[1] = fmaf(wr[k], v[1], dq[1]);
+            dq[2] = fmaf(wr[k], v[2], dq[2]); dq[3] = fmaf(wr[k], v[3], dq[3]);
+        }
+    } else {
+        const float* dl = a.delta + i * od;
+        dxyz[0] = dl[0]; dxyz[1] = dl[1]; dxyz[2] = dl[2];
+        dq[0] = dl[3]; dq[1] = dl[4]; dq[2] = dl[5]; dq[3] = dl[6];
+        if (a.norm_rotation) { const float inv = 1.f / norm4(dq); dq[0] *= inv; dq[1] *= inv; dq[2] *= inv; dq[3] *= inv; }
+    }
+    xyz_t[3 * i] = a.xyz[3 * i] + dxyz[0];
+    xyz_t[3 * i + 1] = a.xyz[3 * i + 1] + dxyz[1];
+    xyz_t[3 * i + 2] = a.xyz[3 * i + 2] + dxyz[2];
+    const float invq = 1.f / norm4(dq);
+    const float q[4] = {dq[0] * invq, dq[1] * invq, dq[2] * invq, dq[3] * invq};
+    const float r[4] = {a.rot[4 * i], a.rot[4 * i + 1], a.rot[4 * i + 2], a.rot[4 * i + 3]};
+    float pq[4];
+    quat_mul(q, r, pq);
+    const float invp = 1.f / norm4(pq);
+    q_t[4 * i] = pq[0] * invp; q_t[4 * i + 1] = pq[1] * invp; q_t[4 * i + 2] = pq[2] * invp; q_t[4 * i + 3] = pq[3] * invp;
+}
+
+// gradient through y = v / max(|v|, eps):  dv = (g - y (y.g)) / |v|
+__device__ __forceinline__ void normalize_bwd(const float* v, const float* g, float* dv) {
+    const float n = norm4(v), inv = 1.f / n;
+    const float y[4] = {v[0] * inv, v[1] * inv, v[2] * inv, v[3] * inv};
+    const float dot = y[0] * g[0] + y[1] * g[1] + y[2] * g[2] + y[3] * g[3];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) dv[k] = (g[k] - y[k] * dot) * inv;
+}
+
+// Keypoint gradients are first accumulated per workgroup in LDS ([K, 7]) and flushed with one
+// global atomic per (workgroup, keypoint, component): K is a few hundred, N is 10^6.
+__global__ __launch_bounds__(256) void gp_blend_bwd_kernel(BlendDev a, const float* __restrict__ g_xyz_t,
+                                                          const float* __restrict__ g_q_t, float* __restrict__ g_delta,
+                                                          float* __restrict__ g_raw_w, float* __restrict__ g_xyz,
+                                                          float* __restrict__ g_rot) {
+    extern __shared__ float s_acc[];  // [K*7] when nn > 0
+    const int od = a.out_dim, nn = a.nn;
+    const int KA = nn > 0 ? (int)a.K * 7 : 0;
+    for (int e = threadIdx.x; e < KA; e += 256) s_acc[e] = 0.f;
+    if (nn > 0) __syncthreads();
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < a.N; i += (long)gridDim.x * 256) {
+        const float gx[3] = {g_xyz_t[3 * i], g_xyz_t[3 * i + 1], g_xyz_t[3 * i + 2]};
+        const float gq[4] = {g_q_t[4 * i], g_q_t[4 * i + 1], g_q_t[4 * i + 2], g_q_t[4 * i + 3]};
+        g_xyz[3 * i] = gx[0]; g_xyz[3 * i + 1] = gx[1]; g_xyz[3 * i + 2] = gx[2];
+        // recompute forward
+        float wx[GP_MAX_NN], wr[GP_MAX_NN];
+        float dq[4] = {0.f, 0.f, 0.f, 0.f};
+        if (nn > 0) {
+            softmax_n(a.raw_w + i * 2 * nn, nn, wx);
+            softmax_n(a.raw_w + i * 2 * nn + nn, nn, wr);
+            for (int k = 0; k < nn; ++k) {
+                const float* dl = a.delta + (long)a.knn[i * nn + k] * od;
+                float v[4] = {dl[3], dl[4], dl[5], dl[6]};
+                if (a.norm_rotation) { const float inv = 1.f / norm4(v); v[0] *= inv; v[1] *= inv; v[2] *= inv; v[3] *= inv; }
+                dq[0] = fmaf(wr[k], v[0], dq[0]); dq[1] = fmaf(wr[k], v[1], dq[1]);
+                dq[2] = fmaf(wr[k], v[2], dq[2]); dq[3] = fmaf(wr[k], v[3], dq[3]);
+            }
+        } else {
+            const float* dl = a.delta + i * od;
+            dq[0] = dl[3]; dq[1] = dl[4]; dq[2] = dl[5]; dq[3] = dl[6];
+            if (a.norm_rotation) { const float inv = 1.f / norm4(dq); dq[0] *= inv; dq[1] *= inv; dq[2] *= inv; dq[3] *= inv; }
+        }
+        const float invq = 1.f / norm4(dq);
+        const float q[4] = {dq[0] * invq, dq[1] * invq, dq[2] * invq, dq[3] * invq};
+        const float r[4] = {a.rot[4 * i], a.rot[4 * i + 1], a.rot[4 * i + 2], a.rot[4 * i + 3]};
+        float pq[4];
+        quat_mul(q, r, pq);
+        float gp[4];
+        normalize_bwd(pq, gq, gp);
+        // p = q (x) r : bilinear
+        const float gqn[4] = {gp[0] * r[0] + gp[1] * r[1] + gp[2] * r[2] + gp[3] * r[3],
+                              -gp[0] * r[1] + gp[1] * r[0] - gp[2] * r[3] + gp[3] * r[2],
+                              -gp[0] * r[2] + gp[1] * r[3] + gp[2] * r[0] - gp[3] * r[1],
+                              -gp[0] * r[3] - gp[1] * r[2] + gp[2] * r[1] + gp[3] * r[0]};
+        g_rot[4 * i + 0] = gp[0] * q[0] + gp[1] * q[1] + gp[2] * q[2] + gp[3] * q[3];
+        g_rot[4 * i + 1] = -gp[0] * q[1] + gp[1] * q[0] + gp[2] * q[3] - gp[3] * q[2];
+        g_rot[4 * i + 2] = -gp[0] * q[2] - gp[1] * q[3] + gp[2] * q[0] + gp[3] * q[1];
+        g_rot[4 * i + 3] = -gp[0] * q[3] + gp[1] * q[2] - gp[2] * q[1] + gp[3] * q[0];
+        float gdq[4];
+        normalize_bwd(dq, gqn, gdq);  // grad wrt blended (or per-Gaussian normalised) dq
+        if (nn > 0) {
+            float gwx[GP_MAX_NN], gwr[GP_MAX_NN];
+            float sx = 0.f, sr = 0.f;
+            for (int k = 0; k < nn; ++k) {
+                const long kp = a.knn[i * nn + k];
+                const float* dl = a.delta + kp * od;
+                gwx[k] = dl[0] * gx[0] + dl[1] * gx[1] + dl[2] * gx[2];
+                float v[4] = {dl[3], dl[4], dl[5], dl[6]};
+                float vn[4] = {v[0], v[1], v[2], v[3]};
+                if (a.norm_rotation) { const float inv = 1.f / norm4(v); vn[0] *= inv; vn[1] *= inv; vn[2] *= inv; vn[3] *= inv; }
+                gwr[k] = vn[0] * gdq[0] + vn[1] * gdq[1] + vn[2] * gdq[2] + vn[3] * gdq[3];
+                sx += wx[k] * gwx[k];
+                sr += wr[k] * gwr[k];
+                float c[4] = {wr[k] * gdq[0], wr[k] * gdq[1], wr[k] * gdq[2], wr[k] * gdq[3]};
+                float gv[4] = {c[0], c[1], c[2], c[3]};
+                if (a.norm_rotation) normalize_bwd(v, c, gv);
+                float* acc = s_acc + kp * 7;
+                atomicAdd(acc + 0, wx[k] * gx[0]); atomicAdd(acc + 1, wx[k] * gx[1]); atomicAdd(acc + 2, wx[k] * gx[2]);
+                atomicAdd(acc + 3, gv[0]); atomicAdd(acc + 4, gv[1]); atomicAdd(acc + 5, gv[2]); atomicAdd(acc + 6, gv[3]);
+            }
+            for (int k = 0; k < nn; ++k) {
+                g_raw_w[i * 2 * nn + k] = wx[k] * (gwx[k] - sx);
+                g_raw_w[i * 2 * nn + nn + k] = wr[k] * (gwr[k] - sr);
+            }
+        } else {
+            const float* dl = a.delta + i * od;
+            float gv[4] = {gdq[0], gdq[1], gdq[2], gdq[3]};
+            // here dq is already the normalised per-Gaussian delta when norm_rotation: chain once more
+            if (a.norm_rotation) { const float v[4] = {dl[3], dl[4], dl[5], dl[6]}; normalize_bwd(v, gdq, gv); }
+            float* gd = g_delta + i * od;
+            gd[0] = gx[0]; gd[1] = gx[1]; gd[2] = gx[2];
+            gd[3] = gv[0]; gd[4] = gv[1]; gd[5] = gv[2]; gd[6] = gv[3];
+            for (int k = 7; k < od; ++k) gd[k] = 0.f;
+        }
+    }
+    if (nn > 0) {
+        __syncthreads();
+        for (int e = threadIdx.x; e < KA; e += 256) {
+            const float v = s_acc[e];
+            if (v != 0.f) atomicAdd(&g_delta[(size_t)(e / 7) * od + (e % 7)], v);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// activations
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float sigmoidf(float x) { return 1.f / (1.f + expf(-x)); }
+
+__global__ __launch_bounds__(256) void gp_act_fwd_kernel(long n, const float* __restrict__ scaling_raw,
+                                                        const float* __restrict__ opacity_raw,
+                                                        const float* __restrict__ delta_o, int stride, float beta,
+                                                        float* __restrict__ scale, float* __restrict__ opacity) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    scale[3 * i] = expf(scaling_raw[3 * i]);
+    scale[3 * i + 1] = expf(scaling_raw[3 * i + 1]);
+    scale[3 * i + 2] = expf(scaling_raw[3 * i + 2]);
+    float o = sigmoidf(opacity_raw[i]);
+    if (delta_o) o *= 1.f / (1.f + expf(-delta_o[i * stride] / beta));  // sharp_sigmoid [REF gaussian_model.py:51]
+    opacity[i] = o;
+}
+__global__ __launch_bounds__(256) void gp_act_bwd_kernel(long n, const float* __restrict__ scaling_raw,
+                                                        const float* __restrict__ opacity_raw,
+                                                        const float* __restrict__ delta_o, int stride, float beta,
+                                                        const float* __restrict__ g_scale, const float* __restrict__ g_opacity,
+                                                        float* __restrict__ g_scaling_raw, float* __restrict__ g_opacity_raw,
+                                                        float* __restrict__ g_delta_o) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    if (g_scaling_raw) {
+        g_scaling_raw[3 * i] = g_scale ? g_scale[3 * i] * expf(scaling_raw[3 * i]) : 0.f;
+        g_scaling_raw[3 * i + 1] = g_scale ? g_scale[3 * i + 1] * expf(scaling_raw[3 * i + 1]) : 0.f;
+        g_scaling_raw[3 * i + 2] = g_scale ? g_scale[3 * i + 2] * expf(scaling_raw[3 * i + 2]) : 0.f;
+    }
+    const float so = sigmoidf(opacity_raw[i]);
+    const float go = g_opacity ? g_opacity[i] : 0.f;
+    float life = 1.f;
+    if (delta_o) life = 1.f / (1.f + expf(-delta_o[i * stride] / beta));
+    if (g_opacity_raw) g_opacity_raw[i] = go * life * so * (1.f - so);
+    if (delta_o && g_delta_o) g_delta_o[i * stride] = go * so * life * (1.f - life) / beta;
+}

@@ -1,0 +1,135 @@
+// gp_capi_deform.hip -- extern "C" entry points of the deformation path (see include/gp_hip.h).
+#include "gp_common.h"
+#include "deform_kernels.h"
+
+static int make_mlp(const gp_mlp_params* p, const gp_mlp_input* x, MlpDev& m) {
+    if (!p || !x) GP_FAIL("null mlp params/input");
+    if (p->width != 256 || p->depth != 4) GP_FAIL("Deformable_Field: only d=4, w=256 is implemented (got d=%d w=%d)", p->depth, p->width);
+    if (p->out_dim < 7 || p->out_dim > 8) GP_FAIL("out_dim must be 7 or 8 (got %d)", p->out_dim);
+    if (x->feature_dim <= 0 || x->feature_dim % 4 || x->xyz_freq < 0 || x->xyz_freq > 16 || x->time_freq < 0 || x->time_freq > 16)
+        GP_FAIL("bad input encoding dims");
+    const int in_dim = x->feature_dim + 6 * x->xyz_freq + 2 * x->time_freq;
+    if (in_dim != p->in_dim) GP_FAIL("in_dim %d != feature_dim + 6*xyz_freq + 2*time_freq = %d", p->in_dim, in_dim);
+    if (in_dim % 4 || in_dim > 256) GP_FAIL("in_dim %d must be a multiple of 4 and <= 256", in_dim);
+    if (x->rows < 0) GP_FAIL("negative rows");
+    for (int l = 0; l < 5; ++l)
+        if (!p->w[l] || !p->b[l]) GP_FAIL("null weight pointer (layer %d)", l);
+    if (x->rows > 0 && (!x->feature || (x->xyz_freq > 0 && !x->xyz) || (x->time_freq > 0 && !x->t))) GP_FAIL("null input pointer");
+    m.rows = x->rows; m.in_dim = in_dim; m.in_pad = (in_dim + 7) / 8 * 8; m.out_dim = p->out_dim;
+    m.feature_dim = x->feature_dim; m.xyz_freq = x->xyz_freq; m.time_freq = x->time_freq;
+    for (int l = 0; l < 5; ++l) { m.w[l] = p->w[l]; m.b[l] = p->b[l]; }
+    m.feature = x->feature; m.xyz = x->xyz; m.t = x->t;
+    return 0;
+}
+
+// layout of the activation record: [X: rows x in_pad][H1..H4: 4 x rows x 256]
+static inline size_t acts_x_floats(const MlpDev& m) { return (size_t)m.rows * m.in_pad; }
+
+extern "C" int gp_mlp_forward(const gp_mlp_params* p, const gp_mlp_input* x, float* out, float* acts, gp_stream_t stream_) {
+    MlpDev m;
+    if (make_mlp(p, x, m)) return 1;
+    if (m.rows == 0) return 0;
+    if (!out) GP_FAIL("null output");
+    float* sx = acts;
+    float* sh = acts ? acts + gp_align_up(acts_x_floats(m), 64) : nullptr;
+    hipLaunchKernelGGL(gp_mlp_fwd_kernel, dim3(gp_blocks((size_t)m.rows, 32)), dim3(512), 0, (hipStream_t)stream_, m, out, sx, sh);
+    GP_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int gp_mlp_backward(const gp_mlp_params* p, const gp_mlp_input* x, const float* acts, const float* dL_dout,
+                               gp_mlp_grads* g, float* dL_dfeature, float* dL_dxyz, gp_alloc_fn alloc, void* alloc_ctx,
+                               gp_stream_t stream_) {
+    hipStream_t s = (hipStream_t)stream_;
+    MlpDev m;
+    if (make_mlp(p, x, m)) return 1;
+    if (m.rows == 0) return 0;
+    if (!acts || !dL_dout || !g || !alloc) GP_FAIL("null argument");
+    for (int l = 0; l < 5; ++l)
+        if (!g->dw[l] || !g->db[l]) GP_FAIL("null weight-grad pointer (layer %d)", l);
+    const float* sx = acts;
+    const float* sh = acts + gp_align_up(acts_x_floats(m), 64);
+    const size_t dz_bytes = gp_align_up((size_t)4 * m.rows * 256 * sizeof(float), 256);
+    float* dz = (float*)alloc(alloc_ctx, GP_BUF_TEMP, dz_bytes);
+    if (!dz) GP_FAIL("allocator returned NULL for TEMP (%zu B)", dz_bytes);
+    hipLaunchKernelGGL(gp_mlp_bwd_data_kernel, dim3(gp_blocks((size_t)m.rows, 32)), dim3(512), 0, s, m, sh, dL_dout, dz,
+                       dL_dfeature, dL_dxyz);
+    GP_LAUNCH_CHECK();
+    // weight grads: dW_l = dZ_{l+1}^T H_l,  H_0 = X
+    long rpb = 2048;
+    while (rpb < 65536 && (m.rows + rpb - 1) / rpb > 512) rpb *= 2;
+    const unsigned nrb = (unsigned)((m.rows + rpb - 1) / rpb);
+    for (int l = 0; l < 5; ++l) {
+        const float* dZl = l < 4 ? dz + (size_t)l * m.rows * 256 : dL_dout;
+        const int n_out = l < 4 ? 256 : m.out_dim;
+        const float* H = l == 0 ? sx : sh + (size_t)(l - 1) * m.rows * 256;
+        const int ldh = l == 0 ? m.in_pad : 256;
+        const int n_in = l == 0 ? m.in_dim : 256;
+        hipLaunchKernelGGL(gp_mlp_bwd_weight_kernel, dim3(nrb, (unsigned)((n_in + 31) / 32)), dim3(512), 0, s, dZl, n_out, H,
+                           ldh, n_in, m.rows, rpb, g->dw[l], n_in, g->db[l]);
+        GP_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
+static int make_blend(const gp_blend_args* a, BlendDev& b) {
+    if (!a) GP_FAIL("null blend args");
+    if (a->num_gaussians < 0) GP_FAIL("negative num_gaussians");
+    if (a->out_dim < 7 || a->out_dim > 8) GP_FAIL("out_dim must be 7 or 8");
+    if (a->nearest_num < 0 || a->nearest_num > 16) GP_FAIL("nearest_num %d unsupported (0..16)", a->nearest_num);
+    if (a->nearest_num > 0 && (a->num_keypoints <= 0 || !a->raw_w || !a->knn_idx)) GP_FAIL("stage-2 blend needs keypoints, raw_w and knn_idx");
+    if (a->nearest_num > 0 && a->num_keypoints * 7 * sizeof(float) > 60000) GP_FAIL("too many keypoints (%ld) for the LDS accumulator", (long)a->num_keypoints);
+    if (a->num_gaussians > 0 && (!a->delta || !a->xyz || !a->rot)) GP_FAIL("null blend input");
+    b.N = a->num_gaussians; b.K = a->num_keypoints; b.nn = a->nearest_num; b.out_dim = a->out_dim;
+    b.norm_rotation = a->norm_rotation; b.delta = a->delta; b.raw_w = a->raw_w; b.knn = a->knn_idx; b.xyz = a->xyz; b.rot = a->rot;
+    return 0;
+}
+
+extern "C" int gp_blend_forward(const gp_blend_args* a, float* xyz_t, float* q_t, gp_stream_t stream_) {
+    BlendDev b;
+    if (make_blend(a, b)) return 1;
+    if (b.N == 0) return 0;
+    if (!xyz_t || !q_t) GP_FAIL("null output");
+    hipLaunchKernelGGL(gp_blend_fwd_kernel, dim3(gp_blocks((size_t)b.N, 256)), dim3(256), 0, (hipStream_t)stream_, b, xyz_t, q_t);
+    GP_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int gp_blend_backward(const gp_blend_args* a, const float* dL_dxyz_t, const float* dL_dq_t, float* dL_ddelta,
+                                 float* dL_draw_w, float* dL_dxyz, float* dL_drot, gp_stream_t stream_) {
+    BlendDev b;
+    if (make_blend(a, b)) return 1;
+    if (b.N == 0) return 0;
+    if (!dL_dxyz_t || !dL_dq_t || !dL_ddelta || !dL_dxyz || !dL_drot || (b.nn > 0 && !dL_draw_w)) GP_FAIL("null argument");
+    unsigned blocks = gp_blocks((size_t)b.N, 256);
+    if (b.nn > 0 && blocks > 512) blocks = 512;
+    const size_t lds = b.nn > 0 ? (size_t)b.K * 7 * sizeof(float) : 0;
+    hipLaunchKernelGGL(gp_blend_bwd_kernel, dim3(blocks), dim3(256), lds, (hipStream_t)stream_, b, dL_dxyz_t, dL_dq_t, dL_ddelta,
+                       dL_draw_w, dL_dxyz, dL_drot);
+    GP_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int gp_activations_forward(int64_t n, const float* scaling_raw, const float* opacity_raw, const float* delta_o,
+                                      int32_t stride, float beta, float* scale, float* opacity, gp_stream_t stream_) {
+    if (n < 0) GP_FAIL("negative n");
+    if (n == 0) return 0;
+    if (!scaling_raw || !opacity_raw || !scale || !opacity) GP_FAIL("null argument");
+    if (delta_o && (stride <= 0 || !(beta > 0.f))) GP_FAIL("bad delta_o stride/beta");
+    hipLaunchKernelGGL(gp_act_fwd_kernel, dim3(gp_blocks((size_t)n, 256)), dim3(256), 0, (hipStream_t)stream_, (long)n, scaling_raw,
+                       opacity_raw, delta_o, stride, beta, scale, opacity);
+    GP_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int gp_activations_backward(int64_t n, const float* scaling_raw, const float* opacity_raw, const float* delta_o,
+                                       int32_t stride, float beta, const float* dL_dscale, const float* dL_dopacity,
+                                       float* dL_dscaling_raw, float* dL_dopacity_raw, float* dL_ddelta_o, gp_stream_t stream_) {
+    if (n < 0) GP_FAIL("negative n");
+    if (n == 0) return 0;
+    if (!scaling_raw || !opacity_raw) GP_FAIL("null argument");
+    hipLaunchKernelGGL(gp_act_bwd_kernel, dim3(gp_blocks((size_t)n, 256)), dim3(256), 0, (hipStream_t)stream_, (long)n, scaling_raw,
+                       opacity_raw, delta_o, stride, beta, dL_dscale, dL_dopacity, dL_dscaling_raw, dL_dopacity_raw, dL_ddelta_o);
+    GP_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,241 @@
+// gp_capi_raster.hip -- extern "C" entry points of the rasterizer (see include/gp_hip.h).
+// Host orchestration only: sizes buffers, asks the caller's allocator for scratch, enqueues the
+// kernels of raster_kernels.hip / sort_scan.hip on the caller's stream.
+#include "gp_common.h"
+#include "raster_kernels.h"
+
+thread_local char gp_err_buf[512] = "";
+
+extern "C" const char* gp_last_error(void) { return gp_err_buf; }
+extern "C" const char* gp_version(void) { return "gaussianprediction_amd 0.1 (gfx950)"; }
+
+static int tile_bits_for(int T) {
+    int b = 1;
+    while ((1 << b) < T) ++b;
+    return b;
+}
+
+static int make_dims(const gp_raster_settings* st, const gp_raster_inputs* in, RasterDims& d) {
+    if (!st || !in) GP_FAIL("null settings/inputs");
+    if (st->image_width <= 0 || st->image_height <= 0) GP_FAIL("bad image size %dx%d", st->image_width, st->image_height);
+    if (in->num_gaussians < 0 || in->num_gaussians > 0x7FFFFFF0LL) GP_FAIL("num_gaussians out of range");
+    if (st->sh_degree < 0 || st->sh_degree > 3) GP_FAIL("sh_degree %d unsupported (0..3)", st->sh_degree);
+    if ((in->shs == nullptr) == (in->colors_precomp == nullptr)) GP_FAIL("Please provide exactly one of either SHs or precomputed colors!");
+    const bool has_sr = in->scales != nullptr || in->rotations != nullptr;
+    if (has_sr == (in->cov3D_precomp != nullptr) || (has_sr && (!in->scales || !in->rotations)))
+        GP_FAIL("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!");
+    if (in->shs && st->sh_coeffs < (st->sh_degree + 1) * (st->sh_degree + 1)) GP_FAIL("shs has %d coeffs, degree %d needs more", st->sh_coeffs, st->sh_degree);
+    if (in->shs && st->sh_coeffs > 16) GP_FAIL("sh_coeffs %d > 16 unsupported", st->sh_coeffs);
+    if (!st->bg || !st->viewmatrix || !st->projmatrix || !st->campos) GP_FAIL("null camera pointers");
+    if (in->num_gaussians > 0 && (!in->means3D || !in->opacities)) GP_FAIL("null means3D/opacities");
+    d.N = (int)in->num_gaussians;
+    d.M = in->shs ? st->sh_coeffs : 0;
+    d.D = st->sh_degree;
+    d.W = st->image_width;
+    d.H = st->image_height;
+    d.gx = (d.W + GP_TILE - 1) / GP_TILE;
+    d.gy = (d.H + GP_TILE - 1) / GP_TILE;
+    d.tanfovx = st->tanfovx;
+    d.tanfovy = st->tanfovy;
+    d.fx = (float)d.W / (2.f * st->tanfovx);
+    d.fy = (float)d.H / (2.f * st->tanfovy);
+    d.scale_mod = st->scale_modifier;
+    return 0;
+}
+
+// saved-state layouts (recomputed identically in forward and backward)
+struct GeomLayout {
+    float4* rec;
+    uint8_t* clamped;
+    size_t bytes;
+    GeomLayout(void* base, size_t N) {
+        GpCarver c(base);
+        rec = c.take<float4>(3 * N + 1);
+        clamped = c.take<uint8_t>(N + 1);
+        bytes = c.bytes();
+    }
+};
+struct ImageLayout {
+    int2* ranges;
+    float* final_T;
+    int32_t* n_contrib;
+    size_t bytes;
+    ImageLayout(void* base, size_t T, size_t P) {
+        GpCarver c(base);
+        ranges = c.take<int2>(T);
+        final_T = c.take<float>(P);
+        n_contrib = c.take<int32_t>(P);
+        bytes = c.bytes();
+    }
+};
+
+extern "C" int gp_raster_forward(const gp_raster_settings* st, const gp_raster_inputs* in, gp_raster_outputs* out,
+                                 gp_raster_saved* saved, gp_alloc_fn alloc, void* alloc_ctx, gp_stream_t stream_) {
+    hipStream_t s = (hipStream_t)stream_;
+    RasterDims d;
+    if (make_dims(st, in, d)) return 1;
+    if (!out || !out->color || !out->depth || !out->tidx || (d.N > 0 && !out->radii)) GP_FAIL("null output pointers");
+    if (!saved || !alloc) GP_FAIL("null saved/alloc");
+    const size_t N = (size_t)d.N, T = (size_t)d.gx * d.gy, P = (size_t)d.W * d.H;
+
+    ImageLayout il0(nullptr, T, P);
+    void* img = alloc(alloc_ctx, GP_BUF_IMAGE, il0.bytes);
+    if (!img) GP_FAIL("allocator returned NULL for IMAGE (%zu B)", il0.bytes);
+    ImageLayout il(img, T, P);
+    GeomLayout gl0(nullptr, N);
+    void* geom = alloc(alloc_ctx, GP_BUF_GEOM, gl0.bytes);
+    if (!geom) GP_FAIL("allocator returned NULL for GEOM (%zu B)", gl0.bytes);
+    GeomLayout gl(geom, N);
+    saved->geom = geom; saved->geom_bytes = gl.bytes;
+    saved->image = img; saved->image_bytes = il.bytes;
+    saved->binning = nullptr; saved->binning_bytes = 0; saved->num_rendered = 0;
+
+    GP_HIP_CHECK(hipMemsetAsync(il.ranges, 0, T * sizeof(int2), s));
+    uint32_t R = 0;
+    uint32_t* point_list = nullptr;
+    if (N > 0) {
+        // ---- per-Gaussian temporaries -----------------------------------------------------------
+        GpCarver tc0(nullptr);
+        const size_t hist_elems = gp_sort_hist_elems(N);
+        const size_t scan_elems = gp_scan_tmp_elems(256 * ((N + 4095) / 4096) > N + 1 ? 256 * ((N + 4095) / 4096) : N + 1);
+        auto carve_tmp = [&](GpCarver& c, uint32_t*& k0, uint32_t*& k1, uint32_t*& v0, uint32_t*& v1, uint32_t*& tiles,
+                             uint32_t*& tt, uint32_t*& hist, uint32_t*& scan_tmp) {
+            k0 = c.take<uint32_t>(N); k1 = c.take<uint32_t>(N); v0 = c.take<uint32_t>(N); v1 = c.take<uint32_t>(N);
+            tiles = c.take<uint32_t>(N); tt = c.take<uint32_t>(N + 1);
+            hist = c.take<uint32_t>(hist_elems); scan_tmp = c.take<uint32_t>(scan_elems);
+        };
+        uint32_t *k0, *k1, *v0, *v1, *tiles, *tt, *hist, *scan_tmp;
+        carve_tmp(tc0, k0, k1, v0, v1, tiles, tt, hist, scan_tmp);
+        void* tmp = alloc(alloc_ctx, GP_BUF_TEMP, tc0.bytes());
+        if (!tmp) GP_FAIL("allocator returned NULL for TEMP (%zu B)", tc0.bytes());
+        GpCarver tc(tmp);
+        carve_tmp(tc, k0, k1, v0, v1, tiles, tt, hist, scan_tmp);
+
+        hipLaunchKernelGGL(gp_preprocess_fwd_kernel, dim3(gp_blocks(N, 256)), dim3(256), 0, s, d, in->means3D, in->scales,
+                           in->rotations, in->opacities, in->shs, in->colors_precomp, in->cov3D_precomp, st->viewmatrix,
+                           st->projmatrix, st->campos, out->radii, gl.rec, k0, tiles, gl.clamped);
+        GP_LAUNCH_CHECK();
+        hipLaunchKernelGGL(gp_iota_kernel, dim3(gp_blocks(N, 256)), dim3(256), 0, s, v0, d.N);
+        GP_LAUNCH_CHECK();
+        GpSortBufs sb;
+        sb.k[0] = k0; sb.k[1] = k1; sb.v[0] = v0; sb.v[1] = v1; sb.hist = hist; sb.scan_tmp = scan_tmp; sb.scan_tmp_elems = scan_elems;
+        const int r1 = gp_radix_sort_pairs(sb, N, 32, s);
+        if (r1 < 0) return 1;
+        const uint32_t* sorted_ids = sb.v[r1];
+        hipLaunchKernelGGL(gp_gather_tiles_kernel, dim3(gp_blocks(N + 1, 256)), dim3(256), 0, s, sorted_ids, tiles, tt, d.N);
+        GP_LAUNCH_CHECK();
+        if (gp_scan_exclusive_u32(tt, N + 1, scan_tmp, scan_elems, s)) return 1;
+        GP_HIP_CHECK(hipMemcpyAsync(&R, tt + N, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        GP_HIP_CHECK(hipStreamSynchronize(s));
+        if (R > 0x7FFFFF00u) GP_FAIL("too many tile-splat instances (%u)", R);
+
+        if (R > 0) {
+            const int tbits = tile_bits_for((int)T);
+            const int passes = (tbits + 7) / 8;
+            const int res = passes & 1;  // buffer pair holding the sorted result
+            void* bin = alloc(alloc_ctx, GP_BUF_BINNING, gp_align_up((size_t)R * 4, 256));
+            if (!bin) GP_FAIL("allocator returned NULL for BINNING");
+            point_list = (uint32_t*)bin;
+            saved->binning = bin; saved->binning_bytes = gp_align_up((size_t)R * 4, 256);
+            const size_t bh = gp_sort_hist_elems(R), bs = gp_scan_tmp_elems(256 * (((size_t)R + 4095) / 4096));
+            auto carve_bin = [&](GpCarver& c, uint32_t*& bk0, uint32_t*& bk1, uint32_t*& bvo, uint32_t*& bhist, uint32_t*& bscan) {
+                bk0 = c.take<uint32_t>(R); bk1 = c.take<uint32_t>(R); bvo = c.take<uint32_t>(R);
+                bhist = c.take<uint32_t>(bh); bscan = c.take<uint32_t>(bs);
+            };
+            uint32_t *bk0, *bk1, *bvo, *bhist, *bscan;
+            GpCarver bc0(nullptr);
+            carve_bin(bc0, bk0, bk1, bvo, bhist, bscan);
+            void* btmp = alloc(alloc_ctx, GP_BUF_TEMP, bc0.bytes());
+            if (!btmp) GP_FAIL("allocator returned NULL for TEMP (%zu B)", bc0.bytes());
+            GpCarver bc(btmp);
+            carve_bin(bc, bk0, bk1, bvo, bhist, bscan);
+            GpSortBufs tb;
+            tb.k[0] = bk0; tb.k[1] = bk1;
+            tb.v[res] = point_list; tb.v[res ^ 1] = bvo;
+            tb.hist = bhist; tb.scan_tmp = bscan; tb.scan_tmp_elems = bs;
+            hipLaunchKernelGGL(gp_duplicate_kernel, dim3(gp_blocks(N, 256)), dim3(256), 0, s, d, sorted_ids, tt, tiles,
+                               out->radii, gl.rec, tb.k[0], tb.v[0]);
+            GP_LAUNCH_CHECK();
+            const int r2 = gp_radix_sort_pairs(tb, R, tbits, s);
+            if (r2 < 0) return 1;
+            if (r2 != res) GP_FAIL("internal: sort parity mismatch");
+            hipLaunchKernelGGL(gp_tile_ranges_kernel, dim3(gp_blocks(R, 256)), dim3(256), 0, s, tb.k[r2], R, il.ranges);
+            GP_LAUNCH_CHECK();
+        }
+    }
+    saved->num_rendered = (int64_t)R;
+    hipLaunchKernelGGL(gp_composite_fwd_kernel, dim3((unsigned)T), dim3(128), 0, s, d, il.ranges, point_list, gl.rec, st->bg,
+                       out->color, out->depth, out->tidx, il.final_T, il.n_contrib);
+    GP_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int gp_raster_backward(const gp_raster_settings* st, const gp_raster_inputs* in, const gp_raster_outputs* fwd,
+                                  const gp_raster_saved* saved, const float* dL_dcolor, const float* dL_ddepth,
+                                  gp_raster_grads* g, gp_alloc_fn alloc, void* alloc_ctx, gp_stream_t stream_) {
+    hipStream_t s = (hipStream_t)stream_;
+    RasterDims d;
+    if (make_dims(st, in, d)) return 1;
+    if (!fwd || !saved || !g || !alloc || !dL_dcolor) GP_FAIL("null argument");
+    const size_t N = (size_t)d.N, T = (size_t)d.gx * d.gy, P = (size_t)d.W * d.H;
+    if (N == 0) return 0;
+    if (!g->dL_dmeans3D || !g->dL_dmeans2D || !g->dL_dopacities) GP_FAIL("null gradient outputs");
+    if (in->shs ? !g->dL_dshs : !g->dL_dcolors_precomp) GP_FAIL("missing colour gradient output");
+    if (in->cov3D_precomp ? !g->dL_dcov3D_precomp : (!g->dL_dscales || !g->dL_drotations)) GP_FAIL("missing covariance gradient output");
+    if (!saved->geom || !saved->image) GP_FAIL("saved state missing");
+    GeomLayout gl(saved->geom, N);
+    ImageLayout il(saved->image, T, P);
+    const uint32_t R = (uint32_t)saved->num_rendered;
+    const uint32_t* point_list = (const uint32_t*)saved->binning;
+    if (R > 0 && !point_list) GP_FAIL("saved binning state missing");
+
+    const size_t acc_floats = 10 * N;
+    float* acc = (float*)alloc(alloc_ctx, GP_BUF_TEMP, gp_align_up(acc_floats * 4, 256));
+    if (!acc) GP_FAIL("allocator returned NULL for TEMP");
+    GP_HIP_CHECK(hipMemsetAsync(acc, 0, acc_floats * 4, s));
+    float* g_mean2D = acc;
+    float* g_conic = acc + 2 * N;
+    float* g_opacity = acc + 5 * N;
+    float* g_color = acc + 6 * N;
+    float* g_depth = acc + 9 * N;
+    if (R > 0) {
+        const unsigned parts = GP_TILE / 8;
+        hipLaunchKernelGGL(gp_composite_bwd_kernel, dim3((unsigned)T * parts), dim3(64), 0, s, d, il.ranges, point_list,
+                           gl.rec, st->bg, fwd->color, fwd->depth, il.final_T, il.n_contrib, dL_dcolor, dL_ddepth, g_mean2D,
+                           g_conic, g_opacity, g_color, g_depth);
+        GP_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(gp_preprocess_bwd_kernel, dim3(gp_blocks(N, 256)), dim3(256), 0, s, d, in->means3D, in->scales,
+                       in->rotations, in->shs, in->cov3D_precomp, st->viewmatrix, st->projmatrix, st->campos, fwd->radii,
+                       gl.clamped, g_mean2D, g_conic, g_opacity, g_color, g_depth, g->dL_dmeans3D, g->dL_dmeans2D, g->dL_dshs,
+                       in->shs ? nullptr : g->dL_dcolors_precomp, g->dL_dopacities, g->dL_dscales, g->dL_drotations,
+                       g->dL_dcov3D_precomp);
+    GP_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int gp_raster_mark_visible(int64_t n, const float* means3D, const float* viewmatrix, uint8_t* present,
+                                      gp_stream_t stream_) {
+    if (n < 0 || n > 0x7FFFFFF0LL) GP_FAIL("n out of range");
+    if (n == 0) return 0;
+    if (!means3D || !viewmatrix || !present) GP_FAIL("null argument");
+    hipLaunchKernelGGL(gp_mark_visible_kernel, dim3(gp_blocks((size_t)n, 256)), dim3(256), 0, (hipStream_t)stream_, (int)n,
+                       means3D, viewmatrix, present);
+    GP_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int gp_raster_debug_binning(const gp_raster_settings* st, const gp_raster_saved* saved, uint32_t* point_list,
+                                       int32_t* ranges, gp_stream_t stream_) {
+    hipStream_t s = (hipStream_t)stream_;
+    if (!st || !saved || !ranges) GP_FAIL("null argument");
+    const int gx = (st->image_width + GP_TILE - 1) / GP_TILE, gy = (st->image_height + GP_TILE - 1) / GP_TILE;
+    const size_t T = (size_t)gx * gy, P = (size_t)st->image_width * st->image_height;
+    ImageLayout il(saved->image, T, P);
+    GP_HIP_CHECK(hipMemcpyAsync(ranges, il.ranges, T * sizeof(int2), hipMemcpyDeviceToDevice, s));
+    if (saved->num_rendered > 0) {
+        if (!point_list) GP_FAIL("null point_list");
+        GP_HIP_CHECK(hipMemcpyAsync(point_list, saved->binning, (size_t)saved->num_rendered * 4, hipMemcpyDeviceToDevice, s));
+    }
+    return 0;
+}

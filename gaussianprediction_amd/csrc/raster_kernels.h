@@ -1,0 +1,76 @@
+// raster_kernels.h -- declarations of the rasterizer kernels (definitions in raster_kernels.hip)
+#pragma once
+#include "gp_common.h"
+
+struct RasterDims {
+    int N, M, D;       // gaussians, sh coeffs per channel, active sh degree
+    int W, H, gx, gy;  // image and tile grid
+    float tanfovx, tanfovy, fx, fy, scale_mod;
+};
+
+__global__ __launch_bounds__(256) void gp_preprocess_fwd_kernel(RasterDims d, const float* __restrict__ means3D,
+                                                               const float* __restrict__ scales,
+                                                               const float* __restrict__ rotations,
+                                                               const float* __restrict__ opacities,
+                                                               const float* __restrict__ shs,
+                                                               const float* __restrict__ colors_precomp,
+                                                               const float* __restrict__ cov3D_precomp,
+                                                               const float* __restrict__ view, const float* __restrict__ proj,
+                                                               const float* __restrict__ campos, int32_t* __restrict__ radii,
+                                                               float4* __restrict__ rec, uint32_t* __restrict__ depth_key,
+                                                               uint32_t* __restrict__ tiles_touched,
+                                                               uint8_t* __restrict__ clamped);
+
+__global__ __launch_bounds__(256) void gp_mark_visible_kernel(int n, const float* __restrict__ means3D,
+                                                             const float* __restrict__ view, uint8_t* __restrict__ present);
+
+__global__ __launch_bounds__(256) void gp_iota_kernel(uint32_t* __restrict__ v, int n);
+
+__global__ __launch_bounds__(256) void gp_gather_tiles_kernel(const uint32_t* __restrict__ sorted_ids,
+                                                             const uint32_t* __restrict__ tiles_touched,
+                                                             uint32_t* __restrict__ out, int n);
+
+__global__ __launch_bounds__(256) void gp_duplicate_kernel(RasterDims d, const uint32_t* __restrict__ sorted_ids,
+                                                          const uint32_t* __restrict__ offsets,
+                                                          const uint32_t* __restrict__ tiles_touched,
+                                                          const int32_t* __restrict__ radii, const float4* __restrict__ rec,
+                                                          uint32_t* __restrict__ keys, uint32_t* __restrict__ vals);
+
+__global__ __launch_bounds__(256) void gp_tile_ranges_kernel(const uint32_t* __restrict__ keys, uint32_t R,
+                                                            int2* __restrict__ ranges);
+
+__global__ __launch_bounds__(128) void gp_composite_fwd_kernel(RasterDims d, const int2* __restrict__ ranges,
+                                                                      const uint32_t* __restrict__ point_list,
+                                                                      const float4* __restrict__ rec,
+                                                                      const float* __restrict__ bg,
+                                                                      float* __restrict__ out_color,
+                                                                      float* __restrict__ out_depth,
+                                                                      int32_t* __restrict__ out_tidx,
+                                                                      float* __restrict__ final_T,
+                                                                      int32_t* __restrict__ n_contrib);
+
+__global__ __launch_bounds__(64) void gp_composite_bwd_kernel(RasterDims d, const int2* __restrict__ ranges,
+                                                              const uint32_t* __restrict__ point_list,
+                                                              const float4* __restrict__ rec, const float* __restrict__ bg,
+                                                              const float* __restrict__ out_color,
+                                                              const float* __restrict__ out_depth,
+                                                              const float* __restrict__ final_T,
+                                                              const int32_t* __restrict__ n_contrib,
+                                                              const float* __restrict__ dL_dpix,
+                                                              const float* __restrict__ dL_dpixdepth,
+                                                              float* __restrict__ g_mean2D /*N,2*/,
+                                                              float* __restrict__ g_conic /*N,3*/,
+                                                              float* __restrict__ g_opacity /*N*/,
+                                                              float* __restrict__ g_color /*N,3*/,
+                                                              float* __restrict__ g_depth /*N*/);
+
+__global__ __launch_bounds__(256) void gp_preprocess_bwd_kernel(
+    RasterDims d, const float* __restrict__ means3D, const float* __restrict__ scales, const float* __restrict__ rotations,
+    const float* __restrict__ shs, const float* __restrict__ cov3D_precomp, const float* __restrict__ view,
+    const float* __restrict__ proj, const float* __restrict__ campos, const int32_t* __restrict__ radii,
+    const uint8_t* __restrict__ clamped, const float* __restrict__ g_mean2D, const float* __restrict__ g_conic,
+    const float* __restrict__ g_opacity, const float* __restrict__ g_color, const float* __restrict__ g_depth,
+    float* __restrict__ dL_dmeans3D, float* __restrict__ dL_dmeans2D, float* __restrict__ dL_dshs,
+    float* __restrict__ dL_dcolors, float* __restrict__ dL_dopacities, float* __restrict__ dL_dscales,
+    float* __restrict__ dL_drots, float* __restrict__ dL_dcov3D);
+

@@ -1,0 +1,772 @@
+// raster_kernels.hip -- the rasterizer kernels for gfx950 (wave64), hand-written:
+//   preprocess fwd/bwd  (per Gaussian: projection, EWA cov2D, conic, radius, SH->RGB)
+//   binning helpers     (depth keys, per-tile duplication, tile ranges)
+//   composite forward   (per 16x16 tile; 2 waves x 64 lanes x 2 pixels; LDS-staged splat batches;
+//                        per-wave exact culling by ballot; front-to-back alpha blend + depth + tidx)
+//   composite backward  (SPLAT-parallel: lanes own splats, pixels are walked uniformly; transmittance
+//                        and suffix sums come from wave scans -> no per-pair atomics or reductions)
+// Arithmetic mirrors oracle/gp_oracle.c expression-for-expression (explicit fmaf, built with
+// -ffp-contract=off) so the discrete results (radii, tile rects, depth keys, per-tile order) are
+// bit-identical to the float32 oracle.  Replaces the CUDA kernels of the reference's absent
+// submodule `diff-gaussian-rasterization-w-depth` [/root/reference/.gitmodules:4-6]; call sites
+// gaussian_renderer/__init__.py:98-106.
+#include "gp_common.h"
+#include "raster_kernels.h"
+
+// SH constants [REF utils/sh_utils.py:26-44]
+__device__ static const float SH_C0 = 0.28209479177387814f;
+__device__ static const float SH_C1 = 0.4886025119029199f;
+__device__ static const float SH_C2[5] = {1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f,
+                                          -1.0925484305920792f, 0.5462742152960396f};
+__device__ static const float SH_C3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f,
+                                          0.3731763325901154f, -0.4570457994644658f, 1.445305721320277f,
+                                          -0.5900435899266435f};
+
+// ------------------------------------------------------------------------------------------------
+// shared per-Gaussian math
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float3 xform4x3(const float* __restrict__ m, float x, float y, float z) {
+    float3 o;
+    o.x = fmaf(m[0], x, fmaf(m[4], y, fmaf(m[8], z, m[12])));
+    o.y = fmaf(m[1], x, fmaf(m[5], y, fmaf(m[9], z, m[13])));
+    o.z = fmaf(m[2], x, fmaf(m[6], y, fmaf(m[10], z, m[14])));
+    return o;
+}
+__device__ __forceinline__ float4 xform4x4(const float* __restrict__ m, float x, float y, float z) {
+    float4 o;
+    o.x = fmaf(m[0], x, fmaf(m[4], y, fmaf(m[8], z, m[12])));
+    o.y = fmaf(m[1], x, fmaf(m[5], y, fmaf(m[9], z, m[13])));
+    o.z = fmaf(m[2], x, fmaf(m[6], y, fmaf(m[10], z, m[14])));
+    o.w = fmaf(m[3], x, fmaf(m[7], y, fmaf(m[11], z, m[15])));
+    return o;
+}
+__device__ __forceinline__ void quat_to_R(float r, float x, float y, float z, float* Rm) {
+    Rm[0] = 1.f - 2.f * (y * y + z * z);
+    Rm[1] = 2.f * (x * y - r * z);
+    Rm[2] = 2.f * (x * z + r * y);
+    Rm[3] = 2.f * (x * y + r * z);
+    Rm[4] = 1.f - 2.f * (x * x + z * z);
+    Rm[5] = 2.f * (y * z - r * x);
+    Rm[6] = 2.f * (x * z - r * y);
+    Rm[7] = 2.f * (y * z + r * x);
+    Rm[8] = 1.f - 2.f * (x * x + y * y);
+}
+// cov3D = (R S)(R S)^T  [REF scene/gaussian_model.py:35-39, utils/general_utils.py:101-110]
+__device__ __forceinline__ void compute_cov3D(const float* __restrict__ scale, float mod, const float* __restrict__ q,
+                                              float* c6) {
+    float Rm[9];
+    quat_to_R(q[0], q[1], q[2], q[3], Rm);
+    const float s0 = mod * scale[0], s1 = mod * scale[1], s2 = mod * scale[2];
+    float L[9];
+    L[0] = Rm[0] * s0; L[1] = Rm[1] * s1; L[2] = Rm[2] * s2;
+    L[3] = Rm[3] * s0; L[4] = Rm[4] * s1; L[5] = Rm[5] * s2;
+    L[6] = Rm[6] * s0; L[7] = Rm[7] * s1; L[8] = Rm[8] * s2;
+    c6[0] = fmaf(L[0], L[0], fmaf(L[1], L[1], L[2] * L[2]));
+    c6[1] = fmaf(L[0], L[3], fmaf(L[1], L[4], L[2] * L[5]));
+    c6[2] = fmaf(L[0], L[6], fmaf(L[1], L[7], L[2] * L[8]));
+    c6[3] = fmaf(L[3], L[3], fmaf(L[4], L[4], L[5] * L[5]));
+    c6[4] = fmaf(L[3], L[6], fmaf(L[4], L[7], L[5] * L[8]));
+    c6[5] = fmaf(L[6], L[6], fmaf(L[7], L[7], L[8] * L[8]));
+}
+
+struct ProjCtx {
+    float T0[3], T1[3];
+    float tx, ty, tz, gx, gy;
+};
+__device__ __forceinline__ void compute_cov2D(float3 pv, float fx, float fy, float tanfovx, float tanfovy,
+                                              const float* c6, const float* __restrict__ view, float* abc,
+                                              ProjCtx* ctx) {
+    const float tz = pv.z;
+    const float limx = 1.3f * tanfovx, limy = 1.3f * tanfovy;
+    const float txtz = pv.x / tz, tytz = pv.y / tz;
+    const float cx = fminf(limx, fmaxf(-limx, txtz));
+    const float cy = fminf(limy, fmaxf(-limy, tytz));
+    const float tx = cx * tz, ty = cy * tz;
+    const float itz = 1.f / tz;
+    const float itz2 = itz * itz;
+    const float J00 = fx * itz;
+    const float J02 = -(fx * tx) * itz2;
+    const float J11 = fy * itz;
+    const float J12 = -(fy * ty) * itz2;
+    const float W0[3] = {view[0], view[4], view[8]};
+    const float W1[3] = {view[1], view[5], view[9]};
+    const float W2[3] = {view[2], view[6], view[10]};
+    float T0[3], T1[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        T0[k] = fmaf(J00, W0[k], J02 * W2[k]);
+        T1[k] = fmaf(J11, W1[k], J12 * W2[k]);
+    }
+    const float S0[3] = {c6[0], c6[1], c6[2]};
+    const float S1[3] = {c6[1], c6[3], c6[4]};
+    const float S2[3] = {c6[2], c6[4], c6[5]};
+    float u0[3], u1[3];
+    u0[0] = fmaf(S0[0], T0[0], fmaf(S0[1], T0[1], S0[2] * T0[2]));
+    u0[1] = fmaf(S1[0], T0[0], fmaf(S1[1], T0[1], S1[2] * T0[2]));
+    u0[2] = fmaf(S2[0], T0[0], fmaf(S2[1], T0[1], S2[2] * T0[2]));
+    u1[0] = fmaf(S0[0], T1[0], fmaf(S0[1], T1[1], S0[2] * T1[2]));
+    u1[1] = fmaf(S1[0], T1[0], fmaf(S1[1], T1[1], S1[2] * T1[2]));
+    u1[2] = fmaf(S2[0], T1[0], fmaf(S2[1], T1[1], S2[2] * T1[2]));
+    abc[0] = fmaf(T0[0], u0[0], fmaf(T0[1], u0[1], T0[2] * u0[2]));
+    abc[1] = fmaf(T0[0], u1[0], fmaf(T0[1], u1[1], T0[2] * u1[2]));
+    abc[2] = fmaf(T1[0], u1[0], fmaf(T1[1], u1[1], T1[2] * u1[2]));
+    if (ctx) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { ctx->T0[k] = T0[k]; ctx->T1[k] = T1[k]; }
+        ctx->tx = tx; ctx->ty = ty; ctx->tz = tz;
+        ctx->gx = (txtz < -limx || txtz > limx) ? 0.f : 1.f;
+        ctx->gy = (tytz < -limy || tytz > limy) ? 0.f : 1.f;
+    }
+}
+
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+__device__ __forceinline__ int f2i_sat(float v) { return (int)fminf(1e9f, fmaxf(-1e9f, v)); }
+
+__device__ __forceinline__ void tile_rect(float pix, float piy, float rad_f, int gx, int gy, int& minx, int& miny,
+                                          int& maxx, int& maxy) {
+    minx = clampi(f2i_sat((pix - rad_f) / (float)GP_TILE), 0, gx);
+    miny = clampi(f2i_sat((piy - rad_f) / (float)GP_TILE), 0, gy);
+    maxx = clampi(f2i_sat((pix + rad_f + (float)(GP_TILE - 1)) / (float)GP_TILE), 0, gx);
+    maxy = clampi(f2i_sat((piy + rad_f + (float)(GP_TILE - 1)) / (float)GP_TILE), 0, gy);
+}
+
+// [REF utils/sh_utils.py:57-112], shs layout [M][3]
+__device__ __forceinline__ void sh_to_rgb(int deg, const float* __restrict__ sh, float x, float y, float z, float* out3) {
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+        float res = SH_C0 * sh[0 * 3 + ch];
+        if (deg > 0) {
+            res = res - SH_C1 * y * sh[1 * 3 + ch] + SH_C1 * z * sh[2 * 3 + ch] - SH_C1 * x * sh[3 * 3 + ch];
+            if (deg > 1) {
+                const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+                res = res + SH_C2[0] * xy * sh[4 * 3 + ch] + SH_C2[1] * yz * sh[5 * 3 + ch] +
+                      SH_C2[2] * (2.f * zz - xx - yy) * sh[6 * 3 + ch] + SH_C2[3] * xz * sh[7 * 3 + ch] +
+                      SH_C2[4] * (xx - yy) * sh[8 * 3 + ch];
+                if (deg > 2) {
+                    res = res + SH_C3[0] * y * (3.f * xx - yy) * sh[9 * 3 + ch] + SH_C3[1] * xy * z * sh[10 * 3 + ch] +
+                          SH_C3[2] * y * (4.f * zz - xx - yy) * sh[11 * 3 + ch] +
+                          SH_C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy) * sh[12 * 3 + ch] +
+                          SH_C3[4] * x * (4.f * zz - xx - yy) * sh[13 * 3 + ch] + SH_C3[5] * z * (xx - yy) * sh[14 * 3 + ch] +
+                          SH_C3[6] * x * (xx - 3.f * yy) * sh[15 * 3 + ch];
+                }
+            }
+        }
+        out3[ch] = res;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// preprocess forward
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gp_preprocess_fwd_kernel(RasterDims d, const float* __restrict__ means3D,
+                                                               const float* __restrict__ scales,
+                                                               const float* __restrict__ rotations,
+                                                               const float* __restrict__ opacities,
+                                                               const float* __restrict__ shs,
+                                                               const float* __restrict__ colors_precomp,
+                                                               const float* __restrict__ cov3D_precomp,
+                                                               const float* __restrict__ view, const float* __restrict__ proj,
+                                                               const float* __restrict__ campos, int32_t* __restrict__ radii,
+                                                               float4* __restrict__ rec, uint32_t* __restrict__ depth_key,
+                                                               uint32_t* __restrict__ tiles_touched,
+                                                               uint8_t* __restrict__ clamped) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= d.N) return;
+    radii[i] = 0;
+    tiles_touched[i] = 0;
+    depth_key[i] = 0xFFFFFFFFu;
+    clamped[i] = 0;
+    const float px = means3D[3 * i], py = means3D[3 * i + 1], pz = means3D[3 * i + 2];
+    const float3 pv = xform4x3(view, px, py, pz);
+    if (!(pv.z > 0.2f)) return;
+    const float4 ph = xform4x4(proj, px, py, pz);
+    const float pw = 1.f / (ph.w + 0.0000001f);
+    const float ndcx = ph.x * pw, ndcy = ph.y * pw;
+    float c6[6];
+    if (cov3D_precomp) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) c6[k] = cov3D_precomp[6 * i + k];
+    } else {
+        compute_cov3D(scales + 3 * i, d.scale_mod, rotations + 4 * i, c6);
+    }
+    float abc[3];
+    compute_cov2D(pv, d.fx, d.fy, d.tanfovx, d.tanfovy, c6, view, abc, nullptr);
+    const float a = abc[0] + 0.3f, b = abc[1], c = abc[2] + 0.3f;
+    const float det = a * c - b * b;
+    if (det == 0.f) return;
+    const float det_inv = 1.f / det;
+    const float conx = c * det_inv, cony = -b * det_inv, conz = a * det_inv;
+    const float mid = 0.5f * (a + c);
+    const float sq = sqrtf(fmaxf(0.1f, mid * mid - det));
+    const float l1 = mid + sq, l2 = mid - sq;
+    const float rad_f = ceilf(3.f * sqrtf(fmaxf(l1, l2)));
+    const float pix = ((ndcx + 1.f) * (float)d.W - 1.f) * 0.5f;
+    const float piy = ((ndcy + 1.f) * (float)d.H - 1.f) * 0.5f;
+    int minx, miny, maxx, maxy;
+    tile_rect(pix, piy, rad_f, d.gx, d.gy, minx, miny, maxx, maxy);
+    if ((maxx - minx) * (maxy - miny) == 0) return;
+    float col[3];
+    uint8_t cl = 0;
+    if (colors_precomp) {
+        col[0] = colors_precomp[3 * i]; col[1] = colors_precomp[3 * i + 1]; col[2] = colors_precomp[3 * i + 2];
+    } else {
+        const float dx = px - campos[0], dy = py - campos[1], dz = pz - campos[2];
+        const float len = sqrtf(fmaf(dx, dx, fmaf(dy, dy, dz * dz)));
+        const float inv = 1.f / len;
+        float raw[3];
+        sh_to_rgb(d.D, shs + (size_t)i * d.M * 3, dx * inv, dy * inv, dz * inv, raw);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float v = raw[k] + 0.5f;
+            if (v < 0.f) cl |= (uint8_t)(1u << k);
+            col[k] = fmaxf(v, 0.f);
+        }
+    }
+    radii[i] = f2i_sat(rad_f);
+    clamped[i] = cl;
+    depth_key[i] = __float_as_uint(pv.z);
+    tiles_touched[i] = (uint32_t)((maxx - minx) * (maxy - miny));
+    rec[3 * (size_t)i + 0] = make_float4(pix, piy, -0.5f * conx, -cony);
+    rec[3 * (size_t)i + 1] = make_float4(-0.5f * conz, opacities[i], pv.z, __int_as_float(i));
+    rec[3 * (size_t)i + 2] = make_float4(col[0], col[1], col[2], 0.f);
+}
+
+__global__ __launch_bounds__(256) void gp_mark_visible_kernel(int n, const float* __restrict__ means3D,
+                                                             const float* __restrict__ view, uint8_t* __restrict__ present) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float3 pv = xform4x3(view, means3D[3 * i], means3D[3 * i + 1], means3D[3 * i + 2]);
+    present[i] = pv.z > 0.2f ? 1 : 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// binning helpers
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gp_iota_kernel(uint32_t* __restrict__ v, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) v[i] = (uint32_t)i;
+}
+// tiles touched, in depth order (n+1 entries, last = 0 so the exclusive scan yields the total)
+__global__ __launch_bounds__(256) void gp_gather_tiles_kernel(const uint32_t* __restrict__ sorted_ids,
+                                                             const uint32_t* __restrict__ tiles_touched,
+                                                             uint32_t* __restrict__ out, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = tiles_touched[sorted_ids[i]];
+    else if (i == n) out[i] = 0;
+}
+__global__ __launch_bounds__(256) void gp_duplicate_kernel(RasterDims d, const uint32_t* __restrict__ sorted_ids,
+                                                          const uint32_t* __restrict__ offsets,
+                                                          const uint32_t* __restrict__ tiles_touched,
+                                                          const int32_t* __restrict__ radii, const float4* __restrict__ rec,
+                                                          uint32_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= d.N) return;
+    const uint32_t id = sorted_ids[i];
+    if (tiles_touched[id] == 0) return;
+    uint32_t off = offsets[i];
+    const float4 q0 = rec[3 * (size_t)id];
+    int minx, miny, maxx, maxy;
+    tile_rect(q0.x, q0.y, (float)radii[id], d.gx, d.gy, minx, miny, maxx, maxy);
+    for (int y = miny; y < maxy; ++y)
+        for (int x = minx; x < maxx; ++x) {
+            keys[off] = (uint32_t)(y * d.gx + x);
+            vals[off] = id;
+            ++off;
+        }
+}
+__global__ __launch_bounds__(256) void gp_tile_ranges_kernel(const uint32_t* __restrict__ keys, uint32_t R,
+                                                            int2* __restrict__ ranges) {
+    const uint32_t k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= R) return;
+    const uint32_t t = keys[k];
+    if (k == 0 || keys[k - 1] != t) ranges[t].x = (int)k;
+    if (k == R - 1 || keys[k + 1] != t) ranges[t].y = (int)(k + 1);
+}
+
+// ------------------------------------------------------------------------------------------------
+// composite forward.  One 128-thread workgroup (2 waves) per 16x16 tile.  Wave w owns rows
+// [8w, 8w+8); lane l owns column (l & 15) and the two rows 2*(l >> 4) + {0,1} of that half.
+// Splat records (48 B) are gathered once per tile into LDS in batches of 128; each staging lane also
+// decides, with a conservative alpha >= 1/255 bounding box, whether its splat can touch half-tile 0/1;
+// the ballots of those decisions let each consumer wave walk only the splats that matter to it.
+// ------------------------------------------------------------------------------------------------
+#define CF_THREADS 128
+
+struct PixAcc {
+    float T, C0, C1, C2, Dp, best;
+    int best_id, last;
+    bool done;
+};
+
+__device__ __forceinline__ void blend_px(PixAcc& p, float pxf, float pyf, const float4& q0, const float4& q1,
+                                         const float4& q2, int contributor) {
+    const float dx = q0.x - pxf, dy = q0.y - pyf;
+    const float power = fmaf(dx, fmaf(q0.z, dx, q0.w * dy), (q1.x * dy) * dy);
+    if (p.done || power > 0.f) return;
+    const float alpha = fminf(0.99f, q1.y * gp_exp(power));
+    if (alpha < 1.f / 255.f) return;
+    const float test_T = p.T * (1.f - alpha);
+    if (test_T < 0.0001f) { p.done = true; return; }
+    const float w = alpha * p.T;
+    p.C0 = fmaf(q2.x, w, p.C0);
+    p.C1 = fmaf(q2.y, w, p.C1);
+    p.C2 = fmaf(q2.z, w, p.C2);
+    p.Dp = fmaf(q1.z, w, p.Dp);
+    if (w > p.best) { p.best = w; p.best_id = __float_as_int(q1.w); }
+    p.T = test_T;
+    p.last = contributor;
+}
+
+__global__ __launch_bounds__(CF_THREADS) void gp_composite_fwd_kernel(RasterDims d, const int2* __restrict__ ranges,
+                                                                      const uint32_t* __restrict__ point_list,
+                                                                      const float4* __restrict__ rec,
+                                                                      const float* __restrict__ bg,
+                                                                      float* __restrict__ out_color,
+                                                                      float* __restrict__ out_depth,
+                                                                      int32_t* __restrict__ out_tidx,
+                                                                      float* __restrict__ final_T,
+                                                                      int32_t* __restrict__ n_contrib) {
+    __shared__ float4 s_q0[CF_THREADS], s_q1[CF_THREADS], s_q2[CF_THREADS];
+    __shared__ unsigned long long s_mask[2][2];
+    __shared__ int s_done[2];
+    const int tile = blockIdx.x;
+    const int tx = tile % d.gx, ty = tile / d.gx;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int px = tx * GP_TILE + (lane & 15);
+    const int py0 = ty * GP_TILE + wave * 8 + 2 * (lane >> 4);
+    const int py1 = py0 + 1;
+    const float pxf = (float)px, py0f = (float)py0, py1f = (float)py1;
+    const int2 range = ranges[tile];
+    PixAcc a0, a1;
+    a0.T = a1.T = 1.f;
+    a0.C0 = a0.C1 = a0.C2 = a0.Dp = a0.best = 0.f;
+    a1.C0 = a1.C1 = a1.C2 = a1.Dp = a1.best = 0.f;
+    a0.best_id = a1.best_id = -1;
+    a0.last = a1.last = 0;
+    const bool in0 = px < d.W && py0 < d.H, in1 = px < d.W && py1 < d.H;
+    a0.done = !in0;
+    a1.done = !in1;
+    bool wave_done = false;
+    if (tid < 2) s_done[tid] = 0;
+    // half-tile pixel-centre rectangles for culling
+    const float X0 = (float)(tx * GP_TILE), X1 = X0 + 15.f;
+    const float Y0a = (float)(ty * GP_TILE), Y1a = Y0a + 7.f, Y0b = Y0a + 8.f, Y1b = Y0a + 15.f;
+
+    for (int base = range.x; base < range.y; base += CF_THREADS) {
+        __syncthreads();
+        if (s_done[0] && s_done[1]) break;
+        const int k = base + tid;
+        bool rel0 = false, rel1 = false;
+        if (k < range.y) {
+            const uint32_t id = point_list[k];
+            const float4 q0 = rec[3 * (size_t)id], q1 = rec[3 * (size_t)id + 1], q2 = rec[3 * (size_t)id + 2];
+            s_q0[tid] = q0; s_q1[tid] = q1; s_q2[tid] = q2;
+            // alpha >= 1/255  <=>  0.5 d^T conic d <= ln(255 o) =: tau ; its bbox is sqrt(2 tau cov_xx/yy)
+            const float cx = -2.f * q0.z, cy = -q0.w, cz = -2.f * q1.x;
+            const float detc = cx * cz - cy * cy;
+            const float tau = __logf(255.f * q1.y);
+            if (tau > 0.f && detc > 0.f) {
+                const float e2 = 2.f * tau * 1.004f / detc;
+                const float ex = sqrtf(e2 * cz) + 0.01f, ey = sqrtf(e2 * cx) + 0.01f;
+                const bool inx = (q0.x + ex >= X0) && (q0.x - ex <= X1);
+                rel0 = inx && (q0.y + ey >= Y0a) && (q0.y - ey <= Y1a);
+                rel1 = inx && (q0.y + ey >= Y0b) && (q0.y - ey <= Y1b);
+            } else if (!(detc > 0.f) && tau > 0.f) {
+                rel0 = rel1 = true;  // degenerate conic: do not cull
+            }
+        }
+        const unsigned long long m0 = __ballot(rel0), m1 = __ballot(rel1);
+        if (lane == 0) { s_mask[0][wave] = m0; s_mask[1][wave] = m1; }
+        __syncthreads();
+        if (!wave_done) {
+#pragma unroll 1
+            for (int sw = 0; sw < 2 && !wave_done; ++sw) {
+                unsigned long long mask = gp_readfirstlane64(s_mask[wave][sw]);
+                while (mask) {
+                    const int j = __builtin_ctzll(mask);
+                    mask &= mask - 1;
+                    const int slot = sw * 64 + j;
+                    const float4 q0 = s_q0[slot], q1 = s_q1[slot], q2 = s_q2[slot];
+                    const int contributor = base - range.x + slot + 1;
+                    blend_px(a0, pxf, py0f, q0, q1, q2, contributor);
+                    blend_px(a1, pxf, py1f, q0, q1, q2, contributor);
+                    if (__all(a0.done && a1.done)) { wave_done = true; break; }
+                }
+            }
+            if (wave_done && lane == 0) s_done[wave] = 1;
+        }
+    }
+    const size_t HW = (size_t)d.H * d.W;
+    if (in0) {
+        const size_t pix = (size_t)py0 * d.W + px;
+        out_color[pix] = fmaf(a0.T, bg[0], a0.C0);
+        out_color[HW + pix] = fmaf(a0.T, bg[1], a0.C1);
+        out_color[2 * HW + pix] = fmaf(a0.T, bg[2], a0.C2);
+        out_depth[pix] = a0.Dp;
+        out_tidx[pix] = a0.best_id;
+        final_T[pix] = a0.T;
+        n_contrib[pix] = a0.last;
+    }
+    if (in1) {
+        const size_t pix = (size_t)py1 * d.W + px;
+        out_color[pix] = fmaf(a1.T, bg[0], a1.C0);
+        out_color[HW + pix] = fmaf(a1.T, bg[1], a1.C1);
+        out_color[2 * HW + pix] = fmaf(a1.T, bg[2], a1.C2);
+        out_depth[pix] = a1.Dp;
+        out_tidx[pix] = a1.best_id;
+        final_T[pix] = a1.T;
+        n_contrib[pix] = a1.last;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// composite backward, splat-parallel.  One wave per (tile, group of CB_ROWS pixel rows).  Lanes own
+// the 64 splats of the current batch (record in registers); the wave walks the group's pixels
+// uniformly.  For pixel p:  T_j(p) = T_in(p) * exclusive_prod_{k<j}(1-alpha_k)   (wave scan)
+//                           suffix_j(p) = Tot(p) - P_in(p) - inclusive_sum_{k<=j} s_k (wave scan)
+// with s_k = alpha_k T_k (c_k . dL_dpix + z_k dL_ddepth) and Tot(p) = (C(p) - T_final bg) . dL_dpix
+// + D(p) dL_ddepth from the forward outputs.  dL/dalpha_j = T_j (c_j.dLp + z_j dLd)
+// - (suffix_j + T_final bg.dLp) / (1 - alpha_j).  Each lane accumulates its splat's 10 gradient sums
+// in registers and issues 10 atomics per (splat, tile part) -- not per (splat, pixel).
+// ------------------------------------------------------------------------------------------------
+#define CB_ROWS 8
+#define CB_PIX (CB_ROWS * GP_TILE)
+
+__device__ __forceinline__ float wave_incl_prod(float x, int lane) {
+#pragma unroll
+    for (int dd = 1; dd < 64; dd <<= 1) {
+        const float t = __shfl_up(x, dd);
+        if (lane >= dd) x *= t;
+    }
+    return x;
+}
+__device__ __forceinline__ float wave_incl_sum(float x, int lane) {
+#pragma unroll
+    for (int dd = 1; dd < 64; dd <<= 1) {
+        const float t = __shfl_up(x, dd);
+        if (lane >= dd) x += t;
+    }
+    return x;
+}
+
+__global__ __launch_bounds__(64) void gp_composite_bwd_kernel(RasterDims d, const int2* __restrict__ ranges,
+                                                              const uint32_t* __restrict__ point_list,
+                                                              const float4* __restrict__ rec, const float* __restrict__ bg,
+                                                              const float* __restrict__ out_color,
+                                                              const float* __restrict__ out_depth,
+                                                              const float* __restrict__ final_T,
+                                                              const int32_t* __restrict__ n_contrib,
+                                                              const float* __restrict__ dL_dpix,
+                                                              const float* __restrict__ dL_dpixdepth,
+                                                              float* __restrict__ g_mean2D /*N,2*/,
+                                                              float* __restrict__ g_conic /*N,3*/,
+                                                              float* __restrict__ g_opacity /*N*/,
+                                                              float* __restrict__ g_color /*N,3*/,
+                                                              float* __restrict__ g_depth /*N*/) {
+    // per-pixel uniform data: {dLr, dLg, dLb, dLd}, {Tot, Tfinal*bgdot, T_in, P_in}, n_contrib
+    __shared__ float4 s_pa[CB_PIX];
+    __shared__ float4 s_pb[CB_PIX];
+    __shared__ int s_nc[CB_PIX];
+    const int parts = GP_TILE / CB_ROWS;
+    const int tile = blockIdx.x / parts, part = blockIdx.x % parts;
+    const int tx = tile % d.gx, ty = tile / d.gx;
+    const int lane = threadIdx.x;
+    const int2 range = ranges[tile];
+    const size_t HW = (size_t)d.H * d.W;
+    const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
+    int max_nc = 0;
+    for (int p = lane; p < CB_PIX; p += 64) {
+        const int px = tx * GP_TILE + (p & 15), py = ty * GP_TILE + part * CB_ROWS + (p >> 4);
+        float4 pa = make_float4(0.f, 0.f, 0.f, 0.f), pb = make_float4(0.f, 0.f, 1.f, 0.f);
+        int nc = 0;
+        if (px < d.W && py < d.H) {
+            const size_t pix = (size_t)py * d.W + px;
+            pa.x = dL_dpix[pix]; pa.y = dL_dpix[HW + pix]; pa.z = dL_dpix[2 * HW + pix];
+            pa.w = dL_dpixdepth ? dL_dpixdepth[pix] : 0.f;
+            const float Tf = final_T[pix];
+            const float bgdot = bg0 * pa.x + bg1 * pa.y + bg2 * pa.z;
+            pb.y = Tf * bgdot;
+            pb.x = out_color[pix] * pa.x + out_color[HW + pix] * pa.y + out_color[2 * HW + pix] * pa.z - pb.y +
+                   out_depth[pix] * pa.w;
+            nc = n_contrib[pix];
+        }
+        s_pa[p] = pa; s_pb[p] = pb; s_nc[p] = nc;
+        max_nc = max(max_nc, nc);
+    }
+#pragma unroll
+    for (int dd = 32; dd >= 1; dd >>= 1) max_nc = max(max_nc, __shfl_xor(max_nc, dd));
+    __syncthreads();
+    const float halfW = 0.5f * (float)d.W, halfH = 0.5f * (float)d.H;
+    const int count = min(range.y - range.x, max_nc);
+    for (int b0 = 0; b0 < count; b0 += 64) {
+        const int pos = b0 + lane;  // 0-based position in the tile list
+        const bool have = pos < count;
+        uint32_t id = 0;
+        float4 q0 = make_float4(0.f, 0.f, 0.f, 0.f), q1 = q0, q2 = q0;
+        if (have) {
+            id = point_list[range.x + pos];
+            q0 = rec[3 * (size_t)id]; q1 = rec[3 * (size_t)id + 1]; q2 = rec[3 * (size_t)id + 2];
+        }
+        const float cx = -2.f * q0.z, cy = -q0.w, cz = -2.f * q1.x;
+        float a_mx = 0.f, a_my = 0.f, a_ca = 0.f, a_cb = 0.f, a_cc = 0.f, a_op = 0.f, a_r = 0.f, a_g = 0.f, a_b = 0.f,
+              a_d = 0.f;
+#pragma unroll 1
+        for (int p = 0; p < CB_PIX; ++p) {
+            const int nc = s_nc[p];
+            if (nc <= b0) continue;  // uniform: pixel finished before this batch
+            const float4 pa = s_pa[p];
+            float4 pb = s_pb[p];
+            const float pxf = (float)(tx * GP_TILE + (p & 15));
+            const float pyf = (float)(ty * GP_TILE + part * CB_ROWS + (p >> 4));
+            const float dx = q0.x - pxf, dy = q0.y - pyf;
+            const float power = fmaf(dx, fmaf(q0.z, dx, q0.w * dy), (q1.x * dy) * dy);
+            const float G = gp_exp(fminf(power, 0.f));
+            const float alpha = fminf(0.99f, q1.y * G);
+            const bool contrib = have && (pos < nc) && !(power > 0.f) && !(alpha < 1.f / 255.f);
+            const float om = contrib ? (1.f - alpha) : 1.f;
+            const float incl = wave_incl_prod(om, lane);
+            float excl = __shfl_up(incl, 1);
+            if (lane == 0) excl = 1.f;
+            const float Tj = pb.z * excl;
+            const float cdot = fmaf(q2.x, pa.x, fmaf(q2.y, pa.y, fmaf(q2.z, pa.z, q1.z * pa.w)));
+            const float w = contrib ? alpha * Tj : 0.f;
+            const float s = w * cdot;
+            const float psum = wave_incl_sum(s, lane);
+            if (contrib) {
+                const float suffix = pb.x - pb.w - psum;
+                const float dL_dalpha = fmaf(Tj, cdot, -(suffix + pb.y) * __builtin_amdgcn_rcpf(om));
+                a_r = fmaf(w, pa.x, a_r);
+                a_g = fmaf(w, pa.y, a_g);
+                a_b = fmaf(w, pa.z, a_b);
+                a_d = fmaf(w, pa.w, a_d);
+                a_op = fmaf(G, dL_dalpha, a_op);
+                const float dL_dG = q1.y * dL_dalpha;
+                const float gdx = G * dx, gdy = G * dy;
+                a_mx = fmaf(dL_dG, -gdx * cx - gdy * cy, a_mx);
+                a_my = fmaf(dL_dG, -gdy * cz - gdx * cy, a_my);
+                a_ca = fmaf(gdx * dx, dL_dG, a_ca);
+                a_cb = fmaf(gdx * dy, dL_dG, a_cb);
+                a_cc = fmaf(gdy * dy, dL_dG, a_cc);
+            }
+            // carry to the next batch (uniform values from lane 63)
+            const float tot_prod = __shfl(incl, 63);
+            const float tot_sum = __shfl(psum, 63);
+            if (lane == 0) {
+                pb.z *= tot_prod;
+                pb.w += tot_sum;
+                s_pb[p] = pb;
+            }
+        }
+        if (have) {
+            atomicAdd(&g_mean2D[2 * (size_t)id], a_mx * halfW);
+            atomicAdd(&g_mean2D[2 * (size_t)id + 1], a_my * halfH);
+            atomicAdd(&g_conic[3 * (size_t)id], -0.5f * a_ca);
+            atomicAdd(&g_conic[3 * (size_t)id + 1], -a_cb);
+            atomicAdd(&g_conic[3 * (size_t)id + 2], -0.5f * a_cc);
+            atomicAdd(&g_opacity[id], a_op);
+            atomicAdd(&g_color[3 * (size_t)id], a_r);
+            atomicAdd(&g_color[3 * (size_t)id + 1], a_g);
+            atomicAdd(&g_color[3 * (size_t)id + 2], a_b);
+            atomicAdd(&g_depth[id], a_d);
+        }
+        __syncthreads();  // single wave: orders the s_pb updates before the next batch reads them
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// preprocess backward (per Gaussian) -- mirrors gpo_preprocess_bwd of the oracle
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gp_preprocess_bwd_kernel(
+    RasterDims d, const float* __restrict__ means3D, const float* __restrict__ scales, const float* __restrict__ rotations,
+    const float* __restrict__ shs, const float* __restrict__ cov3D_precomp, const float* __restrict__ view,
+    const float* __restrict__ proj, const float* __restrict__ campos, const int32_t* __restrict__ radii,
+    const uint8_t* __restrict__ clamped, const float* __restrict__ g_mean2D, const float* __restrict__ g_conic,
+    const float* __restrict__ g_opacity, const float* __restrict__ g_color, const float* __restrict__ g_depth,
+    float* __restrict__ dL_dmeans3D, float* __restrict__ dL_dmeans2D, float* __restrict__ dL_dshs,
+    float* __restrict__ dL_dcolors, float* __restrict__ dL_dopacities, float* __restrict__ dL_dscales,
+    float* __restrict__ dL_drots, float* __restrict__ dL_dcov3D) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= d.N) return;
+    const bool vis = radii[i] > 0;
+    dL_dmeans2D[3 * i] = vis ? g_mean2D[2 * i] : 0.f;
+    dL_dmeans2D[3 * i + 1] = vis ? g_mean2D[2 * i + 1] : 0.f;
+    dL_dmeans2D[3 * i + 2] = 0.f;
+    dL_dopacities[i] = vis ? g_opacity[i] : 0.f;
+    if (!vis) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) dL_dmeans3D[3 * i + k] = 0.f;
+        if (dL_dscales) { dL_dscales[3 * i] = dL_dscales[3 * i + 1] = dL_dscales[3 * i + 2] = 0.f; }
+        if (dL_drots) { dL_drots[4 * i] = dL_drots[4 * i + 1] = dL_drots[4 * i + 2] = dL_drots[4 * i + 3] = 0.f; }
+        if (dL_dcov3D) for (int k = 0; k < 6; ++k) dL_dcov3D[6 * i + k] = 0.f;
+        if (dL_dcolors) { dL_dcolors[3 * i] = dL_dcolors[3 * i + 1] = dL_dcolors[3 * i + 2] = 0.f; }
+        if (dL_dshs) for (int k = 0; k < d.M * 3; ++k) dL_dshs[(size_t)i * d.M * 3 + k] = 0.f;
+        return;
+    }
+    const float px = means3D[3 * i], py = means3D[3 * i + 1], pz = means3D[3 * i + 2];
+    const float3 pv = xform4x3(view, px, py, pz);
+    float c6[6];
+    if (cov3D_precomp) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) c6[k] = cov3D_precomp[6 * i + k];
+    } else {
+        compute_cov3D(scales + 3 * i, d.scale_mod, rotations + 4 * i, c6);
+    }
+    float abc[3];
+    ProjCtx cx;
+    compute_cov2D(pv, d.fx, d.fy, d.tanfovx, d.tanfovy, c6, view, abc, &cx);
+    const float a = abc[0] + 0.3f, b = abc[1], c = abc[2] + 0.3f;
+    const float det = a * c - b * b;
+    const float gA = g_conic[3 * i], gB = g_conic[3 * i + 1], gC = g_conic[3 * i + 2];
+    float gm0 = 0.f, gm1 = 0.f, gm2 = 0.f;
+    float g6[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const float W0[3] = {view[0], view[4], view[8]};
+    const float W1[3] = {view[1], view[5], view[9]};
+    const float W2[3] = {view[2], view[6], view[10]};
+    if (det != 0.f) {
+        const float d2 = 1.f / (det * det);
+        const float dL_da = d2 * (-c * c * gA + b * c * gB - b * b * gC);
+        const float dL_db = d2 * (2.f * b * c * gA - (a * c + b * b) * gB + 2.f * a * b * gC);
+        const float dL_dc = d2 * (-b * b * gA + a * b * gB - a * a * gC);
+        const float* T0 = cx.T0;
+        const float* T1 = cx.T1;
+        g6[0] = dL_da * T0[0] * T0[0] + dL_db * T0[0] * T1[0] + dL_dc * T1[0] * T1[0];
+        g6[3] = dL_da * T0[1] * T0[1] + dL_db * T0[1] * T1[1] + dL_dc * T1[1] * T1[1];
+        g6[5] = dL_da * T0[2] * T0[2] + dL_db * T0[2] * T1[2] + dL_dc * T1[2] * T1[2];
+        g6[1] = 2.f * dL_da * T0[0] * T0[1] + dL_db * (T0[0] * T1[1] + T0[1] * T1[0]) + 2.f * dL_dc * T1[0] * T1[1];
+        g6[2] = 2.f * dL_da * T0[0] * T0[2] + dL_db * (T0[0] * T1[2] + T0[2] * T1[0]) + 2.f * dL_dc * T1[0] * T1[2];
+        g6[4] = 2.f * dL_da * T0[1] * T0[2] + dL_db * (T0[1] * T1[2] + T0[2] * T1[1]) + 2.f * dL_dc * T1[1] * T1[2];
+        const float S[9] = {c6[0], c6[1], c6[2], c6[1], c6[3], c6[4], c6[2], c6[4], c6[5]};
+        float dT0[3], dT1[3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const float st0 = S[3 * r] * T0[0] + S[3 * r + 1] * T0[1] + S[3 * r + 2] * T0[2];
+            const float st1 = S[3 * r] * T1[0] + S[3 * r + 1] * T1[1] + S[3 * r + 2] * T1[2];
+            dT0[r] = 2.f * dL_da * st0 + dL_db * st1;
+            dT1[r] = 2.f * dL_dc * st1 + dL_db * st0;
+        }
+        const float dJ00 = dT0[0] * W0[0] + dT0[1] * W0[1] + dT0[2] * W0[2];
+        const float dJ02 = dT0[0] * W2[0] + dT0[1] * W2[1] + dT0[2] * W2[2];
+        const float dJ11 = dT1[0] * W1[0] + dT1[1] * W1[1] + dT1[2] * W1[2];
+        const float dJ12 = dT1[0] * W2[0] + dT1[1] * W2[1] + dT1[2] * W2[2];
+        const float itz = 1.f / cx.tz, itz2 = itz * itz, itz3 = itz2 * itz;
+        const float dtx = cx.gx * (-d.fx * itz2) * dJ02;
+        const float dty = cx.gy * (-d.fy * itz2) * dJ12;
+        const float dtz = -d.fx * itz2 * dJ00 - d.fy * itz2 * dJ11 + (2.f * d.fx * cx.tx) * itz3 * dJ02 +
+                          (2.f * d.fy * cx.ty) * itz3 * dJ12;
+        gm0 += W0[0] * dtx + W1[0] * dty + W2[0] * dtz;
+        gm1 += W0[1] * dtx + W1[1] * dty + W2[1] * dtz;
+        gm2 += W0[2] * dtx + W1[2] * dty + W2[2] * dtz;
+    }
+    {   // depth
+        const float gd = g_depth[i];
+        gm0 += view[2] * gd; gm1 += view[6] * gd; gm2 += view[10] * gd;
+    }
+    {   // mean2D (NDC) -> mean3D
+        const float4 ph = xform4x4(proj, px, py, pz);
+        const float mw = 1.f / (ph.w + 0.0000001f);
+        const float mul1 = ph.x * mw * mw, mul2 = ph.y * mw * mw;
+        const float g2x = g_mean2D[2 * i], g2y = g_mean2D[2 * i + 1];
+        gm0 += (proj[0] * mw - proj[3] * mul1) * g2x + (proj[1] * mw - proj[3] * mul2) * g2y;
+        gm1 += (proj[4] * mw - proj[7] * mul1) * g2x + (proj[5] * mw - proj[7] * mul2) * g2y;
+        gm2 += (proj[8] * mw - proj[11] * mul1) * g2x + (proj[9] * mw - proj[11] * mul2) * g2y;
+    }
+    if (dL_dcolors) {
+        dL_dcolors[3 * i] = g_color[3 * i]; dL_dcolors[3 * i + 1] = g_color[3 * i + 1]; dL_dcolors[3 * i + 2] = g_color[3 * i + 2];
+    } else {
+        const float ddx0 = px - campos[0], ddy0 = py - campos[1], ddz0 = pz - campos[2];
+        const float len = sqrtf(fmaf(ddx0, ddx0, fmaf(ddy0, ddy0, ddz0 * ddz0)));
+        const float inv = 1.f / len;
+        const float x = ddx0 * inv, y = ddy0 * inv, z = ddz0 * inv;
+        const float* sh = shs + (size_t)i * d.M * 3;
+        float* dsh = dL_dshs + (size_t)i * d.M * 3;
+        const uint8_t cl = clamped[i];
+        float ddir0 = 0.f, ddir1 = 0.f, ddir2 = 0.f;
+        const int D = d.D;
+        const int used = (D + 1) * (D + 1);
+        for (int k = used; k < d.M; ++k) { dsh[3 * k] = 0.f; dsh[3 * k + 1] = 0.f; dsh[3 * k + 2] = 0.f; }
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) {
+            const float g = ((cl >> ch) & 1) ? 0.f : g_color[3 * i + ch];
+            dsh[0 * 3 + ch] = SH_C0 * g;
+            if (D > 0) {
+                dsh[1 * 3 + ch] = -SH_C1 * y * g;
+                dsh[2 * 3 + ch] = SH_C1 * z * g;
+                dsh[3 * 3 + ch] = -SH_C1 * x * g;
+                float ddx = -SH_C1 * sh[3 * 3 + ch];
+                float ddy = -SH_C1 * sh[1 * 3 + ch];
+                float ddz = SH_C1 * sh[2 * 3 + ch];
+                if (D > 1) {
+                    const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+                    dsh[4 * 3 + ch] = SH_C2[0] * xy * g;
+                    dsh[5 * 3 + ch] = SH_C2[1] * yz * g;
+                    dsh[6 * 3 + ch] = SH_C2[2] * (2.f * zz - xx - yy) * g;
+                    dsh[7 * 3 + ch] = SH_C2[3] * xz * g;
+                    dsh[8 * 3 + ch] = SH_C2[4] * (xx - yy) * g;
+                    ddx += SH_C2[0] * y * sh[4 * 3 + ch] + SH_C2[2] * 2.f * -x * sh[6 * 3 + ch] + SH_C2[3] * z * sh[7 * 3 + ch] +
+                           SH_C2[4] * 2.f * x * sh[8 * 3 + ch];
+                    ddy += SH_C2[0] * x * sh[4 * 3 + ch] + SH_C2[1] * z * sh[5 * 3 + ch] + SH_C2[2] * 2.f * -y * sh[6 * 3 + ch] +
+                           SH_C2[4] * 2.f * -y * sh[8 * 3 + ch];
+                    ddz += SH_C2[1] * y * sh[5 * 3 + ch] + SH_C2[2] * 4.f * z * sh[6 * 3 + ch] + SH_C2[3] * x * sh[7 * 3 + ch];
+                    if (D > 2) {
+                        dsh[9 * 3 + ch] = SH_C3[0] * y * (3.f * xx - yy) * g;
+                        dsh[10 * 3 + ch] = SH_C3[1] * xy * z * g;
+                        dsh[11 * 3 + ch] = SH_C3[2] * y * (4.f * zz - xx - yy) * g;
+                        dsh[12 * 3 + ch] = SH_C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy) * g;
+                        dsh[13 * 3 + ch] = SH_C3[4] * x * (4.f * zz - xx - yy) * g;
+                        dsh[14 * 3 + ch] = SH_C3[5] * z * (xx - yy) * g;
+                        dsh[15 * 3 + ch] = SH_C3[6] * x * (xx - 3.f * yy) * g;
+                        ddx += SH_C3[0] * sh[9 * 3 + ch] * 6.f * xy + SH_C3[1] * sh[10 * 3 + ch] * yz +
+                               SH_C3[2] * sh[11 * 3 + ch] * -2.f * xy + SH_C3[3] * sh[12 * 3 + ch] * -6.f * xz +
+                               SH_C3[4] * sh[13 * 3 + ch] * (4.f * zz - 3.f * xx - yy) + SH_C3[5] * sh[14 * 3 + ch] * 2.f * xz +
+                               SH_C3[6] * sh[15 * 3 + ch] * 3.f * (xx - yy);
+                        ddy += SH_C3[0] * sh[9 * 3 + ch] * 3.f * (xx - yy) + SH_C3[1] * sh[10 * 3 + ch] * xz +
+                               SH_C3[2] * sh[11 * 3 + ch] * (4.f * zz - xx - 3.f * yy) + SH_C3[3] * sh[12 * 3 + ch] * -6.f * yz +
+                               SH_C3[4] * sh[13 * 3 + ch] * -2.f * xy + SH_C3[5] * sh[14 * 3 + ch] * -2.f * yz +
+                               SH_C3[6] * sh[15 * 3 + ch] * -6.f * xy;
+                        ddz += SH_C3[1] * sh[10 * 3 + ch] * xy + SH_C3[2] * sh[11 * 3 + ch] * 8.f * yz +
+                               SH_C3[3] * sh[12 * 3 + ch] * 3.f * (2.f * zz - xx - yy) + SH_C3[4] * sh[13 * 3 + ch] * 8.f * xz +
+                               SH_C3[5] * sh[14 * 3 + ch] * (xx - yy);
+                    }
+                }
+                ddir0 += ddx * g; ddir1 += ddy * g; ddir2 += ddz * g;
+            }
+        }
+        const float dot = x * ddir0 + y * ddir1 + z * ddir2;
+        gm0 += (ddir0 - x * dot) * inv;
+        gm1 += (ddir1 - y * dot) * inv;
+        gm2 += (ddir2 - z * dot) * inv;
+    }
+    dL_dmeans3D[3 * i] = gm0; dL_dmeans3D[3 * i + 1] = gm1; dL_dmeans3D[3 * i + 2] = gm2;
+    if (cov3D_precomp) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) dL_dcov3D[6 * i + k] = g6[k];
+    } else {
+        const float Gs[9] = {g6[0], 0.5f * g6[1], 0.5f * g6[2], 0.5f * g6[1], g6[3], 0.5f * g6[4], 0.5f * g6[2], 0.5f * g6[4], g6[5]};
+        const float* q = rotations + 4 * i;
+        float Rm[9];
+        quat_to_R(q[0], q[1], q[2], q[3], Rm);
+        const float s[3] = {d.scale_mod * scales[3 * i], d.scale_mod * scales[3 * i + 1], d.scale_mod * scales[3 * i + 2]};
+        float L[9], dLm[9], dR[9];
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) L[3 * r + k] = Rm[3 * r + k] * s[k];
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+                dLm[3 * r + k] = 2.f * (Gs[3 * r] * L[k] + Gs[3 * r + 1] * L[3 + k] + Gs[3 * r + 2] * L[6 + k]);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            float acc = 0.f;
+#pragma unroll
+            for (int r = 0; r < 3; ++r) { acc += dLm[3 * r + k] * Rm[3 * r + k]; dR[3 * r + k] = dLm[3 * r + k] * s[k]; }
+            dL_dscales[3 * i + k] = acc * d.scale_mod;
+        }
+        const float r = q[0], x = q[1], y = q[2], z = q[3];
+        dL_drots[4 * i + 0] = 2.f * (-z * dR[1] + y * dR[2] + z * dR[3] - x * dR[5] - y * dR[6] + x * dR[7]);
+        dL_drots[4 * i + 1] = 2.f * (y * dR[1] + z * dR[2] + y * dR[3] - 2.f * x * dR[4] - r * dR[5] + z * dR[6] + r * dR[7] - 2.f * x * dR[8]);
+        dL_drots[4 * i + 2] = 2.f * (-2.f * y * dR[0] + x * dR[1] + r * dR[2] + x * dR[3] + z * dR[5] - r * dR[6] + z * dR[7] - 2.f * y * dR[8]);
+        dL_drots[4 * i + 3] = 2.f * (-2.f * z * dR[0] - r * dR[1] + x * dR[2] + r * dR[3] - 2.f * z * dR[4] + y * dR[5] + x * dR[6] + y * dR[7]);
+    }
+}

@@ -1,0 +1,195 @@
+"""torch.autograd.Function wrappers over the deformation entry points of libgp_hip.so.
+
+These are the HIP replacements of the PyTorch-composed ops on the reference's per-frame path
+(SURVEY.md section 2.2(c)): positional encoding + concat + MLP [REF scene/gaussian_model.py:180-189,
+scene/deformable_field.py:63-72,102-127], keypoint blend + quaternion compose
+[REF scene/gaussian_model.py:214-229,266-273,285-286,314-315], activations
+[REF scene/gaussian_model.py:41-51,291-298].  No CPU fallback: inputs must live on a HIP device.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib
+
+
+def _need_cuda(t: torch.Tensor, what: str):
+    if not t.is_cuda:
+        raise RuntimeError(f"{what}: tensor on {t.device}; the deformation path only exists as HIP kernels (no CPU fallback)")
+
+
+def _c(t):
+    return t.detach().to(torch.float32).contiguous()
+
+
+class FusedMlp(torch.autograd.Function):
+    """out = Deformable_Field(cat[feature, PE(xyz, xyz_freq), PE(t, time_freq)])  (d=4, w=256)."""
+
+    @staticmethod
+    def forward(ctx, feature, xyz, t, xyz_freq, time_freq, *wb):
+        _need_cuda(feature, "FusedMlp")
+        dev = feature.device
+        ws = [_c(w) for w in wb[0::2]]
+        bs = [_c(b) for b in wb[1::2]]
+        feature_c = _c(feature)
+        xyz_c = _c(xyz) if xyz is not None else None
+        t_c = _c(t).reshape(-1)[:1] if t is not None else None
+        rows, fd = feature_c.shape
+        in_dim, out_dim = ws[0].shape[1], ws[4].shape[0]
+        in_pad = (in_dim + 7) // 8 * 8
+        need_grad = any(x is not None and torch.is_tensor(x) and x.requires_grad for x in (feature, xyz) + tuple(wb))
+        out = torch.empty(rows, out_dim, device=dev)
+        x_floats = (rows * in_pad + 63) // 64 * 64
+        acts = torch.empty(x_floats + 4 * rows * 256, device=dev) if need_grad else None
+        params = _lib.MlpParamsC(in_dim, 256, 4, out_dim)
+        for l in range(5):
+            params.w[l] = ws[l].data_ptr()
+            params.b[l] = bs[l].data_ptr()
+        inp = _lib.MlpInputC(rows, fd, int(xyz_freq), int(time_freq), feature_c.data_ptr(),
+                             xyz_c.data_ptr() if xyz_c is not None else None, t_c.data_ptr() if t_c is not None else None)
+        with torch.cuda.device(dev):
+            rc = _lib.lib().gp_mlp_forward(C.byref(params), C.byref(inp), _lib.ptr(out), _lib.ptr(acts), _lib.stream_ptr(dev))
+            _lib.check(rc, "gp_mlp_forward")
+        if need_grad:
+            ctx.save_for_backward(feature_c, xyz_c if xyz_c is not None else torch.empty(0, device=dev),
+                                  t_c if t_c is not None else torch.empty(0, device=dev), acts, *ws, *bs)
+            ctx.meta = (int(xyz_freq), int(time_freq), xyz_c is not None, t_c is not None)
+            ctx.needs = (feature.requires_grad, xyz is not None and xyz.requires_grad)
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        saved = ctx.saved_tensors
+        feature_c, xyz_c, t_c, acts = saved[:4]
+        ws, bs = saved[4:9], saved[9:14]
+        xyz_freq, time_freq, has_xyz, has_t = ctx.meta
+        dev = feature_c.device
+        rows, fd = feature_c.shape
+        in_dim, out_dim = ws[0].shape[1], ws[4].shape[0]
+        g = g_out.to(torch.float32).contiguous()
+        params = _lib.MlpParamsC(in_dim, 256, 4, out_dim)
+        grads = _lib.MlpGradsC()
+        dws = [torch.zeros_like(w) for w in ws]
+        dbs = [torch.zeros_like(b) for b in bs]
+        for l in range(5):
+            params.w[l] = ws[l].data_ptr()
+            params.b[l] = bs[l].data_ptr()
+            grads.dw[l] = dws[l].data_ptr()
+            grads.db[l] = dbs[l].data_ptr()
+        inp = _lib.MlpInputC(rows, fd, xyz_freq, time_freq, feature_c.data_ptr(), xyz_c.data_ptr() if has_xyz else None,
+                             t_c.data_ptr() if has_t else None)
+        need_f, need_x = ctx.needs
+        g_feat = torch.empty(rows, fd, device=dev) if need_f else None
+        g_xyz = torch.empty(rows, 3, device=dev) if (need_x and has_xyz and xyz_freq > 0) else None
+        alloc = _lib.TorchAllocator(dev)
+        with torch.cuda.device(dev):
+            rc = _lib.lib().gp_mlp_backward(C.byref(params), C.byref(inp), _lib.ptr(acts), _lib.ptr(g), C.byref(grads),
+                                            _lib.ptr(g_feat), _lib.ptr(g_xyz), alloc.cb, None, _lib.stream_ptr(dev))
+            if alloc.error is not None:
+                raise alloc.error
+            _lib.check(rc, "gp_mlp_backward")
+        wb_grads = []
+        for l in range(5):
+            wb_grads += [dws[l], dbs[l]]
+        return (g_feat, g_xyz, None, None, None, *wb_grads)
+
+
+class KeypointBlend(torch.autograd.Function):
+    """(xyz_t, q_t) from per-keypoint (nn>0) or per-Gaussian (raw_w is None) deltas."""
+
+    @staticmethod
+    def forward(ctx, delta, raw_w, knn_idx, xyz, rot, norm_rotation):
+        _need_cuda(xyz, "KeypointBlend")
+        dev = xyz.device
+        delta_c, xyz_c, rot_c = _c(delta), _c(xyz), _c(rot)
+        N = xyz_c.shape[0]
+        if raw_w is not None:
+            raw_c = _c(raw_w)
+            idx_c = knn_idx.detach().to(torch.int64).contiguous()
+            nn_ = idx_c.shape[1]
+            K = delta_c.shape[0]
+            if raw_c.shape != (N, 2 * nn_):
+                raise RuntimeError("raw_w must be [N, 2*nearest_num]")
+        else:
+            raw_c, idx_c, nn_, K = None, None, 0, 0
+        args = _lib.BlendArgsC(N, K, nn_, delta_c.shape[1], int(bool(norm_rotation)), delta_c.data_ptr(),
+                               raw_c.data_ptr() if raw_c is not None else None,
+                               idx_c.data_ptr() if idx_c is not None else None, xyz_c.data_ptr(), rot_c.data_ptr())
+        xyz_t = torch.empty(N, 3, device=dev)
+        q_t = torch.empty(N, 4, device=dev)
+        with torch.cuda.device(dev):
+            rc = _lib.lib().gp_blend_forward(C.byref(args), _lib.ptr(xyz_t), _lib.ptr(q_t), _lib.stream_ptr(dev))
+            _lib.check(rc, "gp_blend_forward")
+        e = torch.empty(0, device=dev)
+        ctx.save_for_backward(delta_c, raw_c if raw_c is not None else e,
+                              idx_c if idx_c is not None else torch.empty(0, dtype=torch.int64, device=dev), xyz_c, rot_c)
+        ctx.meta = (nn_, K, int(bool(norm_rotation)))
+        return xyz_t, q_t
+
+    @staticmethod
+    def backward(ctx, g_xyz_t, g_q_t):
+        delta_c, raw_c, idx_c, xyz_c, rot_c = ctx.saved_tensors
+        nn_, K, norm_rotation = ctx.meta
+        dev = xyz_c.device
+        N = xyz_c.shape[0]
+        gx = g_xyz_t.to(torch.float32).contiguous() if g_xyz_t is not None else torch.zeros(N, 3, device=dev)
+        gq = g_q_t.to(torch.float32).contiguous() if g_q_t is not None else torch.zeros(N, 4, device=dev)
+        args = _lib.BlendArgsC(N, K, nn_, delta_c.shape[1], norm_rotation, delta_c.data_ptr(),
+                               raw_c.data_ptr() if nn_ else None, idx_c.data_ptr() if nn_ else None, xyz_c.data_ptr(),
+                               rot_c.data_ptr())
+        g_delta = torch.zeros_like(delta_c)
+        g_raw = torch.empty_like(raw_c) if nn_ else None
+        g_xyz = torch.empty(N, 3, device=dev)
+        g_rot = torch.empty(N, 4, device=dev)
+        with torch.cuda.device(dev):
+            rc = _lib.lib().gp_blend_backward(C.byref(args), _lib.ptr(gx), _lib.ptr(gq), _lib.ptr(g_delta), _lib.ptr(g_raw),
+                                              _lib.ptr(g_xyz), _lib.ptr(g_rot), _lib.stream_ptr(dev))
+            _lib.check(rc, "gp_blend_backward")
+        return g_delta, g_raw, None, g_xyz, g_rot, None
+
+
+class Activations(torch.autograd.Function):
+    """scale = exp(_scaling); opacity = sigmoid(_opacity) [* sigmoid(delta[:, col] / beta)]."""
+
+    @staticmethod
+    def forward(ctx, scaling_raw, opacity_raw, delta, col, beta):
+        _need_cuda(scaling_raw, "Activations")
+        dev = scaling_raw.device
+        s_c, o_c = _c(scaling_raw), _c(opacity_raw)
+        N = s_c.shape[0]
+        d_c = _c(delta) if delta is not None else None
+        stride = d_c.shape[1] if d_c is not None else 0
+        scale = torch.empty(N, 3, device=dev)
+        opacity = torch.empty(N, 1, device=dev)
+        dptr = C.c_void_p(d_c.data_ptr() + 4 * int(col)) if d_c is not None else None
+        with torch.cuda.device(dev):
+            rc = _lib.lib().gp_activations_forward(C.c_int64(N), _lib.ptr(s_c), _lib.ptr(o_c), dptr, C.c_int32(stride),
+                                                   C.c_float(float(beta)), _lib.ptr(scale), _lib.ptr(opacity),
+                                                   _lib.stream_ptr(dev))
+            _lib.check(rc, "gp_activations_forward")
+        ctx.save_for_backward(s_c, o_c, d_c if d_c is not None else torch.empty(0, device=dev))
+        ctx.meta = (int(col), float(beta), d_c is not None)
+        return scale, opacity
+
+    @staticmethod
+    def backward(ctx, g_scale, g_opacity):
+        s_c, o_c, d_c = ctx.saved_tensors
+        col, beta, has_d = ctx.meta
+        dev = s_c.device
+        N = s_c.shape[0]
+        gs = g_scale.to(torch.float32).contiguous() if g_scale is not None else None
+        go = g_opacity.to(torch.float32).contiguous() if g_opacity is not None else None
+        g_sraw = torch.empty(N, 3, device=dev)
+        g_oraw = torch.empty(N, 1, device=dev)
+        g_delta = torch.zeros_like(d_c) if has_d else None
+        stride = d_c.shape[1] if has_d else 0
+        dptr = C.c_void_p(d_c.data_ptr() + 4 * col) if has_d else None
+        gdptr = C.c_void_p(g_delta.data_ptr() + 4 * col) if has_d else None
+        with torch.cuda.device(dev):
+            rc = _lib.lib().gp_activations_backward(C.c_int64(N), _lib.ptr(s_c), _lib.ptr(o_c), dptr, C.c_int32(stride),
+                                                    C.c_float(beta), _lib.ptr(gs), _lib.ptr(go), _lib.ptr(g_sraw),
+                                                    _lib.ptr(g_oraw), gdptr, _lib.stream_ptr(dev))
+            _lib.check(rc, "gp_activations_backward")
+        return g_sraw, g_oraw, g_delta, None, None

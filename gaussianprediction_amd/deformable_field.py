@@ -1,0 +1,49 @@
+"""Deformable_Field: same constructor, parameter names and state_dict keys as the reference module
+[REF scene/deformable_field.py:74-127] (`mlp.{0,2,4,6}.{weight,bias}`, `feature_to_deformation.0.*`), so
+reference checkpoints (`gaussians.state_dict()`, [REF train.py:199-201]) load unchanged and
+`self.df_model.parameters()` feeds the same optimizer group "df_mlp" [REF scene/gaussian_model.py:406].
+The forward is the fused HIP kernel over those same Parameters (fp32 matrix cores); only the live
+configuration of the reference is implemented (d=4, w=256, split_xyz=False, use_softmax=False).
+"""
+from __future__ import annotations
+
+import torch
+from torch import nn
+
+from .deform_ops import FusedMlp
+
+
+class Deformable_Field(nn.Module):
+    def __init__(self, input_dim, output_dim=10, d=8, w=256, use_softmax=False, split_xyz=False):
+        super().__init__()
+        if split_xyz or use_softmax:
+            raise NotImplementedError("split_xyz / use_softmax are dead branches in the reference "
+                                      "(scene/gaussian_model.py:79) and are not implemented")
+        if d != 4 or w != 256:
+            raise NotImplementedError("the HIP kernel implements the reference's operating point d=4, w=256 "
+                                      "(options/gaussian_option.py:54-55)")
+        self.input_dim, self.output_dim, self.d, self.w = input_dim, output_dim, d, w
+        self.use_softmax, self.split_xyz = use_softmax, split_xyz
+        layers = []
+        for i in range(d):
+            layers.append(nn.Linear(input_dim if i == 0 else w, w))
+            layers.append(nn.ReLU())
+        self.mlp = nn.Sequential(*layers)
+        self.feature_to_deformation = nn.Sequential(nn.Linear(w, output_dim))
+
+    def _wb(self):
+        wb = []
+        for i in range(self.d):
+            wb += [self.mlp[2 * i].weight, self.mlp[2 * i].bias]
+        wb += [self.feature_to_deformation[0].weight, self.feature_to_deformation[0].bias]
+        return wb
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        """x: [M, input_dim] already-concatenated input (the reference's call form)."""
+        return FusedMlp.apply(x, None, None, 0, 0, *self._wb())
+
+    def forward_fused(self, feature, xyz, t, xyz_freq, time_freq) -> torch.Tensor:
+        """Fused form used by GaussianModel: builds [feature | PE(xyz) | PE(t)] inside the kernel
+        (get_motion_delta, REF scene/gaussian_model.py:180-184) -- the [M, input_dim] input and the
+        [M,256] activations never touch HBM in inference."""
+        return FusedMlp.apply(feature, xyz, t, xyz_freq, time_freq, *self._wb())

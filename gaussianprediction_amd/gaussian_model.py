@@ -1,0 +1,132 @@
+"""The per-frame part of the reference's GaussianModel [REF scene/gaussian_model.py:32-321]:
+parameters, activations and `forward(t, iteration) -> (xyz_t, q_t, scale, opacity_t)` with its three
+stages, on the HIP kernels of this package.  Training bookkeeping (optimizer surgery, densify/prune,
+k-means keypoint init, PLY I/O) is out of scope for this round.
+
+Two stage-2/3 inputs come from un-vendored CUDA dependencies of the reference that are not part of
+the hot path and are therefore supplied by the caller:
+  * `knn_idx` [N, nearest_num]  -- frnn kNN of Gaussians vs keypoints  [REF :110-125]
+  * `raw_weights` [N, 2*nearest_num] -- output of the tcnn hash-grid weights model [REF :257]
+"""
+from __future__ import annotations
+
+import torch
+from torch import nn
+
+from .deform_ops import Activations, KeypointBlend
+from .deformable_field import Deformable_Field
+
+
+class GaussianModel(nn.Module):
+    def __init__(self, sh_degree: int, args):
+        super().__init__()
+        self.active_sh_degree = 0
+        self.max_sh_degree = sh_degree
+        self.args = args
+        self.beta = args.beta
+        self.d, self.w = args.d, args.w
+        self.motion_feature_dim = args.feature_dim
+        self.second_stage_iter = args.second_stage_iteration
+        self.third_stage_iter = args.third_stage_iteration
+        self.time_input_dim = None
+        self.xyz_input_dim = None
+        self.knn_idx = None
+        self.raw_weights = None
+        self.lifecycle_opacity = None
+
+    def set_inputDim(self, time_input_dim, xyz_input_dim):   # [REF scene/gaussian_model.py:106-108]
+        self.time_input_dim = time_input_dim
+        self.xyz_input_dim = xyz_input_dim
+
+    # ---- construction from raw tensors (stand-in for create_from_pcd, REF :327-392) ---------------
+    def create_from_tensors(self, xyz, features_dc, features_rest, scaling, rotation, opacity, motion_feature,
+                            keypoints=None, keypoint_features=None):
+        self._xyz = nn.Parameter(xyz.clone().requires_grad_(True))
+        self._features_dc = nn.Parameter(features_dc.clone().requires_grad_(True))
+        self._features_rest = nn.Parameter(features_rest.clone().requires_grad_(True))
+        self._scaling = nn.Parameter(scaling.clone().requires_grad_(True))
+        self._rotation = nn.Parameter(rotation.clone().requires_grad_(True))
+        self._opacity = nn.Parameter(opacity.clone().requires_grad_(True))
+        self.motion_feature = nn.Parameter(motion_feature.clone().requires_grad_(True))
+        delta_dim = 8 if self.args.step_opacity else 7
+        in_dim = self.time_input_dim + self.xyz_input_dim + self.motion_feature_dim
+        self.df_model = Deformable_Field(in_dim, d=self.d, w=self.w, output_dim=delta_dim, split_xyz=False).to(xyz.device)
+        if keypoints is not None:
+            self.super_gaussians = nn.Parameter(keypoints.clone().requires_grad_(True))
+            self.super_gaussians_feature = nn.Parameter(keypoint_features.clone().requires_grad_(True))
+        self.active_sh_degree = self.max_sh_degree
+        return self
+
+    def set_keypoint_weights(self, raw_weights, knn_idx):
+        self.raw_weights, self.knn_idx = raw_weights, knn_idx
+
+    # ---- accessors [REF scene/gaussian_model.py:138-172] -----------------------------------------
+    @property
+    def get_xyz(self):
+        return self._xyz
+
+    @property
+    def get_features(self):
+        return torch.cat((self._features_dc, self._features_rest), dim=1)
+
+    @property
+    def get_scaling(self):
+        return Activations.apply(self._scaling, self._opacity, None, 0, 1.0)[0]
+
+    @property
+    def get_opacity(self):
+        return Activations.apply(self._scaling, self._opacity, None, 0, 1.0)[1]
+
+    @property
+    def get_rotation(self):
+        return torch.nn.functional.normalize(self._rotation)
+
+    @property
+    def get_superGaussians(self):
+        return self.super_gaussians
+
+    def get_loss(self, iteration):                 # [REF scene/gaussian_model.py:174-178]
+        if iteration < self.args.jointly_iteration:
+            return 0.0
+        feat = self.super_gaussians_feature if iteration > self.second_stage_iter else self.motion_feature
+        return 1.0e-5 * torch.mean(torch.abs(feat))
+
+    # ---- the hot path [REF scene/gaussian_model.py:231-304] ---------------------------------------
+    def forward(self, t, iteration):
+        if torch.is_tensor(iteration):
+            iteration = iteration.item()
+        a = self.args
+        xyz_freq, time_freq = int(self.xyz_input_dim / 6), self.time_input_dim // 2
+        if iteration < a.jointly_iteration:          # warm-up: static Gaussians
+            s, o = Activations.apply(self._scaling, self._opacity, None, 0, 1.0)
+            return self._xyz, self.get_rotation, s, o
+        t_dev = t.to(self._xyz.device, torch.float32).reshape(-1)[:1]
+        if iteration <= self.second_stage_iter:      # stage 1: MLP over all N Gaussians, xyz detached
+            noise = getattr(a, "xyz_noise_iteration", 0)
+            xyz_in = self._xyz.detach()
+            if noise and iteration < noise:
+                xyz_in = xyz_in + torch.randn_like(xyz_in) * 0.1 * (1 - min(1, iteration / noise))
+            delta = self.df_model.forward_fused(self.motion_feature, xyz_in, t_dev, xyz_freq, time_freq)
+            xyz_t, q_t = KeypointBlend.apply(delta, None, None, self._xyz, self._rotation, a.norm_rotation)
+        else:                                        # stage 2/3: MLP over K keypoints + sparse blend
+            noise = getattr(a, "xyz_noise_iteration", 0)
+            kp = self.super_gaussians
+            if noise and (iteration - self.second_stage_iter) < noise:
+                kp = kp + torch.randn_like(kp) * 0.1 * (1 - min(1, (iteration - self.second_stage_iter) / noise))
+            if self.raw_weights is None or self.knn_idx is None:
+                raise RuntimeError("stage 2/3 needs set_keypoint_weights(raw_weights, knn_idx)")
+            delta = self.df_model.forward_fused(self.super_gaussians_feature, kp, t_dev, xyz_freq, time_freq)
+            self.kpts_xyz_motion = delta[:, 0:3]
+            xyz_t, q_t = KeypointBlend.apply(delta, self.raw_weights, self.knn_idx, self._xyz, self._rotation,
+                                             a.norm_rotation)
+        self.lifecycle_opacity = None
+        if a.step_opacity and iteration > a.step_opacity_iteration:
+            if a.opacity_type != "implicit":
+                raise NotImplementedError("opacity_type 'explicit' is not on any shipped script's path")
+            # second MLP pass over all N Gaussians with the per-Gaussian motion feature [REF :291-298]
+            delta2 = self.df_model.forward_fused(self.motion_feature, self._xyz, t_dev, xyz_freq, time_freq)
+            s, o = Activations.apply(self._scaling, self._opacity, delta2, 7, self.beta)
+            self.lifecycle_opacity = o
+        else:
+            s, o = Activations.apply(self._scaling, self._opacity, None, 0, 1.0)
+        return xyz_t, q_t, s, o

@@ -1,0 +1,217 @@
+"""Drop-in for the reference's `diff_gaussian_rasterization` package, backed by libgp_hip.so.
+
+Same names, argument meaning and error behaviour as the interface the reference imports and calls
+[REF gaussian_renderer/__init__.py:14, 37-52, 98-106]:
+
+    GaussianRasterizationSettings(image_height, image_width, tanfovx, tanfovy, bg, scale_modifier,
+                                  viewmatrix, projmatrix, sh_degree, campos, prefiltered[, debug])
+    GaussianRasterizer(raster_settings)(means3D=, means2D=, shs=, colors_precomp=, opacities=,
+                                        scales=, rotations=, cov3D_precomp=)
+        -> (rendered_image[3,H,W], radii[N] int32, depth[1,H,W], tidx[H,W] int32)
+
+`loss.backward()` populates .grad on means3D, shs/colors_precomp, opacities, scales, rotations
+(or cov3D_precomp) and on means2D (the retained `screenspace_points`, [:, :2] = NDC-space gradient
+of the projected centre, read at [REF scene/gaussian_model.py:757]).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import NamedTuple, Optional
+
+import torch
+from torch import nn
+
+from . import _lib
+
+
+class GaussianRasterizationSettings(NamedTuple):
+    image_height: int
+    image_width: int
+    tanfovx: float
+    tanfovy: float
+    bg: torch.Tensor
+    scale_modifier: float
+    viewmatrix: torch.Tensor
+    projmatrix: torch.Tensor
+    sh_degree: int
+    campos: torch.Tensor
+    prefiltered: bool
+    debug: bool = False  # the reference does not pass it [REF gaussian_renderer/__init__.py:49]
+
+
+def _f32c(t: Optional[torch.Tensor], device) -> Optional[torch.Tensor]:
+    if t is None or t.numel() == 0 and t.dim() <= 1:
+        return None
+    if t.device != device:
+        raise RuntimeError(f"rasterizer input on {t.device}, expected {device}")
+    return t.detach().to(torch.float32).contiguous()
+
+
+def _settings_c(rs: GaussianRasterizationSettings, device, sh_coeffs: int):
+    keep = [_f32c(rs.bg, device), _f32c(rs.viewmatrix, device), _f32c(rs.projmatrix, device), _f32c(rs.campos, device)]
+    if keep[0] is None or keep[0].numel() != 3 or keep[1].numel() != 16 or keep[2].numel() != 16 or keep[3].numel() != 3:
+        raise RuntimeError("bg[3], viewmatrix[4,4], projmatrix[4,4], campos[3] expected")
+    st = _lib.RasterSettingsC(int(rs.image_height), int(rs.image_width), float(rs.tanfovx), float(rs.tanfovy),
+                              float(rs.scale_modifier), int(rs.sh_degree), int(sh_coeffs), int(bool(rs.prefiltered)),
+                              int(bool(rs.debug)), keep[0].data_ptr(), keep[1].data_ptr(), keep[2].data_ptr(),
+                              keep[3].data_ptr())
+    return st, keep
+
+
+class _RasterizeGaussians(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings):
+        if not means3D.is_cuda:
+            raise RuntimeError("gaussianprediction_amd rasterizer needs tensors on a HIP device (no CPU fallback)")
+        device = means3D.device
+        L = _lib.lib()
+        m3 = _f32c(means3D, device)
+        N = means3D.shape[0]
+        if m3 is None:
+            m3 = torch.empty(0, 3, device=device)
+        shs = _f32c(sh, device)
+        cols = _f32c(colors_precomp, device)
+        ops = _f32c(opacities, device)
+        scl = _f32c(scales, device)
+        rot = _f32c(rotations, device)
+        cov = _f32c(cov3Ds_precomp, device)
+        sh_coeffs = int(shs.shape[1]) if shs is not None else 0
+        rs = raster_settings
+        H, W = int(rs.image_height), int(rs.image_width)
+        with torch.cuda.device(device):
+            st, keep = _settings_c(rs, device, sh_coeffs)
+            inp = _lib.RasterInputsC(N, _lib.ptr(m3), _lib.ptr(shs), _lib.ptr(cols), _lib.ptr(ops), _lib.ptr(scl),
+                                     _lib.ptr(rot), _lib.ptr(cov))
+            color = torch.empty(3, H, W, device=device, dtype=torch.float32)
+            radii = torch.empty(N, device=device, dtype=torch.int32)
+            depth = torch.empty(1, H, W, device=device, dtype=torch.float32)
+            tidx = torch.empty(H, W, device=device, dtype=torch.int32)
+            out = _lib.RasterOutputsC(_lib.ptr(color), _lib.ptr(radii), _lib.ptr(depth), _lib.ptr(tidx))
+            saved = _lib.RasterSavedC()
+            alloc = _lib.TorchAllocator(device)
+            rc = L.gp_raster_forward(C.byref(st), C.byref(inp), C.byref(out), C.byref(saved), alloc.cb, None,
+                                     _lib.stream_ptr(device))
+            if alloc.error is not None:
+                raise alloc.error
+            _lib.check(rc, "gp_raster_forward")
+        ctx.raster_settings = rs
+        ctx.num_rendered = int(saved.num_rendered)
+        ctx.sh_coeffs = sh_coeffs
+        ctx.flags = (shs is not None, cols is not None, scl is not None, cov is not None)
+        geom, binning, image = alloc.first(_lib.GP_BUF_GEOM), alloc.first(_lib.GP_BUF_BINNING), alloc.first(_lib.GP_BUF_IMAGE)
+        empty = torch.empty(0, device=device)
+        ctx.save_for_backward(m3, shs if shs is not None else empty, cols if cols is not None else empty, ops,
+                              scl if scl is not None else empty, rot if rot is not None else empty,
+                              cov if cov is not None else empty, color, radii, depth, tidx, geom,
+                              binning if binning is not None else torch.empty(0, dtype=torch.uint8, device=device), image)
+        ctx.mark_non_differentiable(radii, tidx)
+        return color, radii, depth, tidx
+
+    @staticmethod
+    def backward(ctx, grad_color, grad_radii, grad_depth, grad_tidx):
+        (m3, shs, cols, ops, scl, rot, cov, color, radii, depth, tidx, geom, binning, image) = ctx.saved_tensors
+        has_sh, has_col, has_sr, has_cov = ctx.flags
+        device = m3.device
+        N = m3.shape[0]
+        rs = ctx.raster_settings
+        L = _lib.lib()
+        gc = grad_color.to(torch.float32).contiguous() if grad_color is not None else torch.zeros_like(color)
+        gd = grad_depth.to(torch.float32).contiguous() if grad_depth is not None else None
+        with torch.cuda.device(device):
+            st, keep = _settings_c(rs, device, ctx.sh_coeffs)
+            inp = _lib.RasterInputsC(N, _lib.ptr(m3), _lib.ptr(shs) if has_sh else None, _lib.ptr(cols) if has_col else None,
+                                     _lib.ptr(ops), _lib.ptr(scl) if has_sr else None, _lib.ptr(rot) if has_sr else None,
+                                     _lib.ptr(cov) if has_cov else None)
+            out = _lib.RasterOutputsC(_lib.ptr(color), _lib.ptr(radii), _lib.ptr(depth), _lib.ptr(tidx))
+            saved = _lib.RasterSavedC(geom.data_ptr(), geom.numel(), binning.data_ptr() if binning.numel() else None,
+                                      binning.numel(), image.data_ptr(), image.numel(), ctx.num_rendered)
+            g_m3 = torch.empty(N, 3, device=device)
+            g_m2 = torch.empty(N, 3, device=device)
+            g_sh = torch.empty(N, ctx.sh_coeffs, 3, device=device) if has_sh else None
+            g_col = torch.empty(N, 3, device=device) if has_col else None
+            g_op = torch.empty(N, 1, device=device)
+            g_scl = torch.empty(N, 3, device=device) if has_sr else None
+            g_rot = torch.empty(N, 4, device=device) if has_sr else None
+            g_cov = torch.empty(N, 6, device=device) if has_cov else None
+            grads = _lib.RasterGradsC(_lib.ptr(g_m3), _lib.ptr(g_m2), _lib.ptr(g_sh), _lib.ptr(g_col), _lib.ptr(g_op),
+                                      _lib.ptr(g_scl), _lib.ptr(g_rot), _lib.ptr(g_cov))
+            alloc = _lib.TorchAllocator(device)
+            rc = L.gp_raster_backward(C.byref(st), C.byref(inp), C.byref(out), C.byref(saved), _lib.ptr(gc), _lib.ptr(gd),
+                                      C.byref(grads), alloc.cb, None, _lib.stream_ptr(device))
+            if alloc.error is not None:
+                raise alloc.error
+            _lib.check(rc, "gp_raster_backward")
+        return g_m3, g_m2, g_sh, g_col, g_op, g_scl, g_rot, g_cov, None
+
+
+def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings):
+    return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
+                                     raster_settings)
+
+
+class GaussianRasterizer(nn.Module):
+    def __init__(self, raster_settings: GaussianRasterizationSettings):
+        super().__init__()
+        self.raster_settings = raster_settings
+
+    def markVisible(self, positions: torch.Tensor) -> torch.Tensor:
+        """Boolean mask of the Gaussians that pass the near-plane test of this camera."""
+        with torch.no_grad():
+            p = positions.detach().to(torch.float32).contiguous()
+            vm = self.raster_settings.viewmatrix.detach().to(torch.float32).contiguous()
+            present = torch.empty(p.shape[0], dtype=torch.uint8, device=p.device)
+            with torch.cuda.device(p.device):
+                rc = _lib.lib().gp_raster_mark_visible(C.c_int64(p.shape[0]), _lib.ptr(p), _lib.ptr(vm), _lib.ptr(present),
+                                                      _lib.stream_ptr(p.device))
+                _lib.check(rc, "gp_raster_mark_visible")
+        return present.bool()
+
+    def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
+                cov3D_precomp=None):
+        rs = self.raster_settings
+        if (shs is None and colors_precomp is None) or (shs is not None and colors_precomp is not None):
+            raise Exception('Please provide excatly one of either SHs or precomputed colors!')
+        if ((scales is None or rotations is None) and cov3D_precomp is None) or \
+                ((scales is not None or rotations is not None) and cov3D_precomp is not None):
+            raise Exception('Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!')
+        return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, rs)
+
+
+def debug_binning(ctx_like_saved, raster_settings):  # pragma: no cover - used by GPU tests
+    raise NotImplementedError
+
+
+def raster_forward_debug(raster_settings, means3D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
+                         cov3D_precomp=None):
+    """Test/diagnostic helper: forward pass that also returns the binning result
+    (point_list[R] in composite order, ranges[T,2]) via gp_raster_debug_binning."""
+    device = means3D.device
+    L = _lib.lib()
+    rs = raster_settings
+    N = means3D.shape[0]
+    m3 = _f32c(means3D, device)
+    shs_c, cols, ops = _f32c(shs, device), _f32c(colors_precomp, device), _f32c(opacities, device)
+    scl, rot, cov = _f32c(scales, device), _f32c(rotations, device), _f32c(cov3D_precomp, device)
+    sh_coeffs = int(shs_c.shape[1]) if shs_c is not None else 0
+    H, W = int(rs.image_height), int(rs.image_width)
+    with torch.cuda.device(device):
+        st, keep = _settings_c(rs, device, sh_coeffs)
+        inp = _lib.RasterInputsC(N, _lib.ptr(m3), _lib.ptr(shs_c), _lib.ptr(cols), _lib.ptr(ops), _lib.ptr(scl),
+                                 _lib.ptr(rot), _lib.ptr(cov))
+        color = torch.empty(3, H, W, device=device)
+        radii = torch.empty(N, device=device, dtype=torch.int32)
+        depth = torch.empty(1, H, W, device=device)
+        tidx = torch.empty(H, W, device=device, dtype=torch.int32)
+        out = _lib.RasterOutputsC(_lib.ptr(color), _lib.ptr(radii), _lib.ptr(depth), _lib.ptr(tidx))
+        saved = _lib.RasterSavedC()
+        alloc = _lib.TorchAllocator(device)
+        _lib.check(L.gp_raster_forward(C.byref(st), C.byref(inp), C.byref(out), C.byref(saved), alloc.cb, None,
+                                       _lib.stream_ptr(device)), "gp_raster_forward")
+        R = int(saved.num_rendered)
+        T = ((W + 15) // 16) * ((H + 15) // 16)
+        point_list = torch.empty(max(R, 1), dtype=torch.int32, device=device)
+        ranges = torch.empty(T, 2, dtype=torch.int32, device=device)
+        _lib.check(L.gp_raster_debug_binning(C.byref(st), C.byref(saved), _lib.ptr(point_list), _lib.ptr(ranges),
+                                             _lib.stream_ptr(device)), "gp_raster_debug_binning")
+        torch.cuda.synchronize(device)
+    return dict(color=color, radii=radii, depth=depth, tidx=tidx, R=R, point_list=point_list[:R], ranges=ranges)

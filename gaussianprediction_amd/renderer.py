@@ -1,0 +1,77 @@
+"""render() / render_motion(): the reference's L1 boundary [REF gaussian_renderer/__init__.py:18-191],
+same signature and result dict, on this package's rasterizer and GaussianModel."""
+from __future__ import annotations
+
+import math
+
+import torch
+
+from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer
+
+
+def _settings(viewpoint_camera, pc, bg_color, scaling_modifier):
+    return GaussianRasterizationSettings(
+        image_height=int(viewpoint_camera.image_height),
+        image_width=int(viewpoint_camera.image_width),
+        tanfovx=math.tan(viewpoint_camera.FoVx * 0.5),
+        tanfovy=math.tan(viewpoint_camera.FoVy * 0.5),
+        bg=bg_color,
+        scale_modifier=scaling_modifier,
+        viewmatrix=viewpoint_camera.world_view_transform,
+        projmatrix=viewpoint_camera.full_proj_transform,
+        sh_degree=pc.active_sh_degree,
+        campos=viewpoint_camera.camera_center,
+        prefiltered=False,
+    )
+
+
+def _screenspace_points(pc):
+    # zero tensor whose .grad receives the 2D (screen-space) mean gradients [REF :27-31]
+    p = torch.zeros_like(pc.get_xyz, dtype=pc.get_xyz.dtype, requires_grad=True, device=pc.get_xyz.device) + 0
+    try:
+        p.retain_grad()
+    except Exception:
+        pass
+    return p
+
+
+def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=1.0, override_color=None, delta=None,
+           time=None, it=1):
+    """Render the scene.  Background tensor (bg_color) must be on the GPU."""
+    screenspace_points = _screenspace_points(pc)
+    rasterizer = GaussianRasterizer(raster_settings=_settings(viewpoint_camera, pc, bg_color, scaling_modifier))
+    cov3D_precomp = None
+    if time is None:
+        means3D = pc.get_xyz + delta if delta is not None else pc.get_xyz
+        opacity = pc.get_opacity
+        if getattr(pipe, "compute_cov3D_python", False):
+            raise NotImplementedError("compute_cov3D_python: the covariance is computed in the preprocess kernel")
+        scales, rotations = pc.get_scaling, pc.get_rotation
+    else:
+        means3D, rotations, scales, opacity = pc(time, it)
+    shs, colors_precomp = None, None
+    if override_color is None:
+        if getattr(pipe, "convert_SHs_python", False):
+            raise NotImplementedError("convert_SHs_python: SH->RGB is evaluated in the preprocess kernel")
+        shs = pc.get_features
+    else:
+        colors_precomp = override_color
+    rendered_image, radii, depth, tidx = rasterizer(means3D=means3D, means2D=screenspace_points, shs=shs,
+                                                    colors_precomp=colors_precomp, opacities=opacity, scales=scales,
+                                                    rotations=rotations, cov3D_precomp=cov3D_precomp)
+    return {"render": rendered_image, "viewspace_points": screenspace_points, "visibility_filter": radii > 0,
+            "radii": radii, "depth": depth, "tidx": tidx}
+
+
+def render_motion(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=1.0, override_color=None,
+                  xyz_t=None, r_t=None, opacity=None):
+    """Render externally supplied per-frame positions/rotations [REF gaussian_renderer/__init__.py:117-191]."""
+    screenspace_points = _screenspace_points(pc)
+    rasterizer = GaussianRasterizer(raster_settings=_settings(viewpoint_camera, pc, bg_color, scaling_modifier))
+    opacity = pc.get_opacity if opacity is None else opacity
+    shs, colors_precomp = (pc.get_features, None) if override_color is None else (None, override_color)
+    rendered_image, radii, depth, tidx = rasterizer(means3D=xyz_t, means2D=screenspace_points, shs=shs,
+                                                    colors_precomp=colors_precomp, opacities=opacity,
+                                                    scales=pc.get_scaling, rotations=r_t, cov3D_precomp=None)
+    return {"render": rendered_image, "viewspace_points": screenspace_points, "visibility_filter": radii > 0,
+            "radii": radii}

@@ -1,0 +1,200 @@
+/*
+ * gp_hip.h -- C ABI of libgp_hip.so, the MI355X (gfx950) implementation of the dynamic-Gaussian
+ * render hot path of BoMingZhao/GaussianPrediction.
+ *
+ * Drop-in boundary.  The reference binds this path through the pybind module
+ * `diff_gaussian_rasterization._C` of an (absent, un-vendored) CUDA submodule
+ * [/root/reference/.gitmodules:4-6]; its Python-visible contract is the only thing in the tree:
+ *     GaussianRasterizationSettings(...) kwargs      gaussian_renderer/__init__.py:37-50
+ *     GaussianRasterizer(...)(means3D, means2D, shs, colors_precomp, opacities, scales, rotations,
+ *                             cov3D_precomp) -> (image, radii, depth, tidx)
+ *                                                    gaussian_renderer/__init__.py:98-106
+ *     GaussianModel.forward(t, it) -> xyz,q,s,o      scene/gaussian_model.py:231-304
+ *     Deformable_Field.forward(x)                    scene/deformable_field.py:112-127
+ * Each entry point below names the reference interface it replaces.
+ *
+ * Conventions: plain device pointers + sizes, no torch types.  Every function enqueues on the
+ * hipStream_t it is given (the caller's current stream) and returns 0 on success; on failure it
+ * returns non-zero, nothing is thrown across the ABI, and gp_last_error() holds the message.
+ * All float tensors are fp32, dense, row-major.  Matrices are the reference's row-vector
+ * (transposed) 4x4s [scene/cameras.py:59-61], i.e. column-major in memory.
+ */
+#ifndef GP_HIP_H
+#define GP_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* gp_stream_t; /* hipStream_t */
+
+/* scratch classes handed to the allocator callback */
+enum { GP_BUF_GEOM = 0, GP_BUF_BINNING = 1, GP_BUF_IMAGE = 2, GP_BUF_TEMP = 3 };
+
+/* Allocator callback: return a device pointer to `bytes` bytes (256-B aligned) that stays valid
+ * until the caller frees it; `which` is one of GP_BUF_*.  The Python host backs this with torch's
+ * caching allocator and keeps GEOM/BINNING/IMAGE alive for backward (ctx.save_for_backward). */
+typedef void* (*gp_alloc_fn)(void* ctx, int which, size_t bytes);
+
+/* mirrors GaussianRasterizationSettings [REF gaussian_renderer/__init__.py:37-50] */
+typedef struct gp_raster_settings {
+    int32_t image_height;
+    int32_t image_width;
+    float tanfovx;
+    float tanfovy;
+    float scale_modifier;
+    int32_t sh_degree;   /* active degree 0..3 */
+    int32_t sh_coeffs;   /* coefficients per channel present in `shs` (16 for max degree 3) */
+    int32_t prefiltered; /* accepted for API parity; unused (as in the public rasterizer) */
+    int32_t debug;
+    const float* bg;         /* device [3] */
+    const float* viewmatrix; /* device [16] */
+    const float* projmatrix; /* device [16] */
+    const float* campos;     /* device [3] */
+} gp_raster_settings;
+
+/* inputs of GaussianRasterizer.forward [REF gaussian_renderer/__init__.py:98-106] */
+typedef struct gp_raster_inputs {
+    int64_t num_gaussians;
+    const float* means3D;        /* [N,3] */
+    const float* shs;            /* [N,sh_coeffs,3] or NULL */
+    const float* colors_precomp; /* [N,3] or NULL (exactly one of shs/colors_precomp) */
+    const float* opacities;      /* [N,1] */
+    const float* scales;         /* [N,3] or NULL */
+    const float* rotations;      /* [N,4] or NULL */
+    const float* cov3D_precomp;  /* [N,6] or NULL (exactly one of (scales,rotations)/cov3D_precomp) */
+} gp_raster_inputs;
+
+typedef struct gp_raster_outputs {
+    float* color;   /* [3,H,W] */
+    int32_t* radii; /* [N] */
+    float* depth;   /* [1,H,W]  sum_i z_i alpha_i T_i */
+    int32_t* tidx;  /* [H,W]    id of the Gaussian with the largest blend weight, -1 if none */
+} gp_raster_outputs;
+
+/* opaque state saved between forward and backward */
+typedef struct gp_raster_saved {
+    void* geom;    size_t geom_bytes;
+    void* binning; size_t binning_bytes;
+    void* image;   size_t image_bytes;
+    int64_t num_rendered; /* R = sum of tiles touched */
+} gp_raster_saved;
+
+typedef struct gp_raster_grads {
+    float* dL_dmeans3D;        /* [N,3] */
+    float* dL_dmeans2D;        /* [N,3] (x,y in NDC units, z = 0): the screenspace_points grad sink
+                                  [REF gaussian_renderer/__init__.py:27-31, scene/gaussian_model.py:757] */
+    float* dL_dshs;            /* [N,sh_coeffs,3] or NULL */
+    float* dL_dcolors_precomp; /* [N,3] or NULL */
+    float* dL_dopacities;      /* [N,1] */
+    float* dL_dscales;         /* [N,3] or NULL */
+    float* dL_drotations;      /* [N,4] or NULL */
+    float* dL_dcov3D_precomp;  /* [N,6] or NULL */
+} gp_raster_grads;
+
+/* replaces _C.rasterize_gaussians (the forward of GaussianRasterizer). One host sync (reads R). */
+int gp_raster_forward(const gp_raster_settings* st, const gp_raster_inputs* in, gp_raster_outputs* out,
+                      gp_raster_saved* saved, gp_alloc_fn alloc, void* alloc_ctx, gp_stream_t stream);
+
+/* replaces _C.rasterize_gaussians_backward.  dL_ddepth may be NULL.  No host sync. */
+int gp_raster_backward(const gp_raster_settings* st, const gp_raster_inputs* in, const gp_raster_outputs* fwd_out,
+                       const gp_raster_saved* saved, const float* dL_dcolor /*[3,H,W]*/,
+                       const float* dL_ddepth /*[1,H,W] or NULL*/, gp_raster_grads* grads, gp_alloc_fn alloc,
+                       void* alloc_ctx, gp_stream_t stream);
+
+/* replaces _C.mark_visible: present[i] = 1 iff Gaussian i passes the near-plane test. */
+int gp_raster_mark_visible(int64_t n, const float* means3D, const float* viewmatrix, uint8_t* present,
+                           gp_stream_t stream);
+
+/* test/diagnostic accessor: copies the binning result of a forward call to host-visible device
+ * buffers: point_list[R] (Gaussian ids in composite order) and ranges[T*2]. */
+int gp_raster_debug_binning(const gp_raster_settings* st, const gp_raster_saved* saved, uint32_t* point_list,
+                            int32_t* ranges, gp_stream_t stream);
+
+/* ---- deformation path ----------------------------------------------------------------------- */
+
+/* Parameters of Deformable_Field(d=4, w=256) [REF scene/deformable_field.py:102-110]: weights are
+ * nn.Linear layout [out,in] row-major: mlp.{0,2,4,6}.{weight,bias}, feature_to_deformation.0.* */
+typedef struct gp_mlp_params {
+    int32_t in_dim;     /* feature_dim + 6*xyz_freq + 2*time_freq */
+    int32_t width;      /* 256 */
+    int32_t depth;      /* 4 hidden layers */
+    int32_t out_dim;    /* 7 or 8 */
+    const float* w[5];  /* w[0]:[width,in_dim]  w[1..3]:[width,width]  w[4]:[out_dim,width] */
+    const float* b[5];
+} gp_mlp_params;
+
+typedef struct gp_mlp_grads {
+    float* dw[5]; /* accumulated INTO (+=), caller zeroes */
+    float* db[5];
+} gp_mlp_grads;
+
+/* input row i = [ feature[i, 0:feature_dim] | PE(xyz[i], xyz_freq) | PE(t, time_freq) ]
+ * [REF scene/gaussian_model.py:180-189, scene/deformable_field.py:63-72] */
+typedef struct gp_mlp_input {
+    int64_t rows;
+    int32_t feature_dim; /* 32 */
+    int32_t xyz_freq;    /* 10 */
+    int32_t time_freq;   /* 6 / 8 / 10 */
+    const float* feature; /* [rows, feature_dim] */
+    const float* xyz;     /* [rows, 3] */
+    const float* t;       /* device [1] */
+} gp_mlp_input;
+
+/* replaces Deformable_Field.forward on the concatenated input (get_motion_delta).
+ * `acts` (optional, training): [depth, rows, width] post-ReLU activations saved for backward. */
+int gp_mlp_forward(const gp_mlp_params* p, const gp_mlp_input* x, float* out /*[rows,out_dim]*/,
+                   float* acts, gp_stream_t stream);
+
+/* backward of gp_mlp_forward: weight/bias grads (+=), d feature [rows,feature_dim] (=, may be NULL),
+ * d xyz [rows,3] through the positional encoding (=, may be NULL). */
+int gp_mlp_backward(const gp_mlp_params* p, const gp_mlp_input* x, const float* acts, const float* dL_dout,
+                    gp_mlp_grads* g, float* dL_dfeature, float* dL_dxyz, gp_alloc_fn alloc, void* alloc_ctx,
+                    gp_stream_t stream);
+
+/* keypoint blend + pose composition  [REF scene/gaussian_model.py:214-229,266-273,285-286,314-315;
+ * utils/camera_utils.py:158-170]:
+ *   stage 1 (nn == 0): delta is per Gaussian [N,out_dim]
+ *   stage 2/3 (nn > 0): delta is per keypoint [K,out_dim]; w = softmax(raw_w[:, :nn]) and
+ *   softmax(raw_w[:, nn:2nn]) gathered at knn_idx [N,nn]
+ *   xyz_t = xyz + blend(delta[:, 0:3]);  q_t = normalize(quat_mul(normalize(blend(dq)), rot))
+ *   where dq = normalize(delta[:, 3:7]) if norm_rotation else delta[:, 3:7]. */
+typedef struct gp_blend_args {
+    int64_t num_gaussians;
+    int64_t num_keypoints;   /* 0 in stage 1 */
+    int32_t nearest_num;     /* 0 in stage 1 */
+    int32_t out_dim;         /* 7 or 8 */
+    int32_t norm_rotation;
+    const float* delta;      /* [N or K, out_dim] */
+    const float* raw_w;      /* [N, 2*nn] or NULL */
+    const int64_t* knn_idx;  /* [N, nn] or NULL */
+    const float* xyz;        /* [N,3] */
+    const float* rot;        /* [N,4] raw (un-normalised) _rotation */
+} gp_blend_args;
+
+int gp_blend_forward(const gp_blend_args* a, float* xyz_t /*[N,3]*/, float* q_t /*[N,4]*/, gp_stream_t stream);
+
+/* grads: d delta (+= via atomics when nn>0, = otherwise; caller zeroes), d raw_w (=), d xyz (=), d rot (=) */
+int gp_blend_backward(const gp_blend_args* a, const float* dL_dxyz_t, const float* dL_dq_t, float* dL_ddelta,
+                      float* dL_draw_w, float* dL_dxyz, float* dL_drot, gp_stream_t stream);
+
+/* activations [REF scene/gaussian_model.py:41-51,138-162,291-298]:
+ *   scale = exp(_scaling); opacity = sigmoid(_opacity) [* sigmoid(delta_o / beta) if delta_o] */
+int gp_activations_forward(int64_t n, const float* scaling_raw /*[N,3]*/, const float* opacity_raw /*[N,1]*/,
+                           const float* delta_o /*[N, stride] or NULL*/, int32_t delta_o_stride, float beta,
+                           float* scale /*[N,3]*/, float* opacity /*[N,1]*/, gp_stream_t stream);
+int gp_activations_backward(int64_t n, const float* scaling_raw, const float* opacity_raw, const float* delta_o,
+                            int32_t delta_o_stride, float beta, const float* dL_dscale, const float* dL_dopacity,
+                            float* dL_dscaling_raw, float* dL_dopacity_raw, float* dL_ddelta_o /*[N,stride] col 0*/,
+                            gp_stream_t stream);
+
+const char* gp_last_error(void);
+const char* gp_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GP_HIP_H */
