@@ -1,0 +1,215 @@
+#!/usr/bin/env python
+"""bench.py -- headline benchmark of the dynamic-Gaussian render hot path on MI355X.
+
+Workload (BASELINE.json metric "train-step ms & rendered views/s @1M Gaussians 1352x1014", i.e.
+configs[2]: HyperNeRF-like, 1M Gaussians, 1352x1014, full train step on one GPU): one STEP = one pass
+of the hot path over one camera view per GPU --
+    GaussianModel.forward (stage 3: fused PE+MLP over K=250 keypoints, sparse blend over N, quaternion
+    compose, activations) -> preprocess -> depth sort -> tile binning -> composite forward -> loss
+    (0.8 L1 + 0.2 (1-SSIM)) -> composite backward -> preprocess backward -> deformation backward ->
+    Adam step.
+Synthetic seed-fixed scene + cameras (datasets are not available offline), random-init MLP weights.
+N>1: one process per GPU, view-parallel, RCCL all-reduce(SUM) of the flat gradient bucket ("weak"
+scaling: one view per GPU per step).  value = views/s of full train steps over the whole job.
+
+Contract: python bench.py --gpus N --steps K --warmup W  ->  ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+from types import SimpleNamespace
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s achievable
+
+
+def build_workload(args, device):
+    import gaussianprediction_amd as gpa
+    from gaussianprediction_amd.cameras import orbit_cameras
+    from gaussianprediction_amd.scene_synth import SceneSpec, make_gaussians, make_keypoints
+    margs = SimpleNamespace(beta=0.1, d=4, w=256, feature_dim=32, second_stage_iteration=30000, third_stage_iteration=40000,
+                            jointly_iteration=1000, nearest_num=args.nearest_num, norm_rotation=True, step_opacity=False,
+                            step_opacity_iteration=5000, opacity_type="implicit", xyz_noise_iteration=0)
+    time_freq = args.time_freq
+    raw = make_gaussians(SceneSpec(n_gaussians=args.gaussians, extent=(1.5, 1.5, 0.5), scale_lo=args.scale_lo,
+                                   scale_hi=args.scale_hi, seed=2024), device=device)
+    kp, kpf, idx, raw_w = make_keypoints(raw["xyz"], raw["motion_feature"], args.keypoints, margs.nearest_num)
+    torch.manual_seed(2024)
+    pc = gpa.GaussianModel(3, margs)
+    pc.set_inputDim(2 * time_freq, 60)
+    pc.create_from_tensors(raw["xyz"], raw["features_dc"], raw["features_rest"], raw["scaling"], raw["rotation"], raw["opacity"],
+                           raw["motion_feature"], kp, kpf)
+    pc.set_keypoint_weights(raw_w, idx)
+    fovx = 2 * math.atan(1.0 / (2 * 0.9))           # focal ~ 0.9 W
+    cams = orbit_cameras(8, 4.0, fovx, args.width, args.height, arc_deg=40.0, elevation_deg=5.0, device=device)
+    g = torch.Generator().manual_seed(7)
+    gts = [torch.rand(3, args.height, args.width, generator=g).to(device) for _ in range(2)]
+    return pc, cams, gts, margs
+
+
+def cpu_baseline(args, pc, cams, seconds_budget=30.0):
+    """The oracle (a CPU port of the same path) timed on this box's host cores, on a bounded sample:
+    ONE view, rasterizer forward + backward (C oracle, OpenMP) fed by the deformed Gaussians."""
+    from oracle.oracle import RasterOracle, RasterSettings
+    cam = cams[0]
+    with torch.no_grad():
+        t = torch.from_numpy(cam.time).float().to(pc.get_xyz.device)
+        xyz, q, s, o = pc(t, args.iteration)
+        shs = pc.get_features
+    n64 = lambda x: x.detach().float().cpu().numpy().astype(np.float64)
+    st = RasterSettings(image_height=cam.image_height, image_width=cam.image_width, tanfovx=math.tan(cam.FoVx * 0.5),
+                        tanfovy=math.tan(cam.FoVy * 0.5), bg=np.zeros(3), scale_modifier=1.0,
+                        viewmatrix=n64(cam.world_view_transform), projmatrix=n64(cam.full_proj_transform), sh_degree=3,
+                        campos=n64(cam.camera_center))
+    cores = os.cpu_count() or 1
+    orc = RasterOracle("f32", threads=cores)
+    A = dict(means3D=n64(xyz), opacities=n64(o), shs=n64(shs), scales=n64(s), rotations=n64(q))
+    t0 = time.perf_counter()
+    sres = orc.forward(st, A["means3D"], A["opacities"], shs=A["shs"], scales=A["scales"], rotations=A["rotations"])
+    t_fwd = time.perf_counter() - t0
+    sample = "1 view: C oracle raster forward"
+    t_total = t_fwd
+    if t_fwd < seconds_budget / 3:
+        g = np.random.default_rng(0).normal(size=sres["out_color"].shape)
+        t0 = time.perf_counter()
+        orc.backward(sres, g)
+        t_total += time.perf_counter() - t0
+        sample = "1 view: C oracle raster forward+backward"
+    return {"value": 1.0 / t_total, "unit": "views/s", "cores": cores, "kind": "port",
+            "sample": f"{sample} (OpenMP, {cores} threads), same scene/camera, {t_total:.2f} s; "
+                      "deformation/loss/Adam not included"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--gaussians", type=int, default=1_000_000)
+    ap.add_argument("--width", type=int, default=1352)
+    ap.add_argument("--height", type=int, default=1014)
+    ap.add_argument("--keypoints", type=int, default=250)
+    ap.add_argument("--nearest_num", type=int, default=6)
+    ap.add_argument("--time_freq", type=int, default=8)
+    ap.add_argument("--iteration", type=int, default=50000)
+    ap.add_argument("--scale_lo", type=float, default=0.003)
+    ap.add_argument("--scale_hi", type=float, default=0.012)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--render-only", action="store_true", help="time eval-style forward renders instead of train steps")
+    args = ap.parse_args()
+
+    from gaussianprediction_amd import _lib
+    from gaussianprediction_amd.dist import init_from_env
+    from gaussianprediction_amd.train_step import TrainStep
+    rank, local, world = init_from_env()
+    assert world == args.gpus or world == 1, f"WORLD_SIZE={world} but --gpus {args.gpus}"
+    assert torch.cuda.is_available(), "bench.py needs a HIP device (no CPU fallback)"
+    device = torch.device("cuda", local)
+    torch.cuda.set_device(device)
+    pc, cams, gts, margs = build_workload(args, device)
+    ts = TrainStep(pc, cams, gts, args.iteration)
+
+    def one_step(i):
+        view = i * world + rank            # rank r renders view world*i + r
+        if args.render_only:
+            with torch.no_grad():
+                cam = cams[view % len(cams)]
+                t = torch.from_numpy(cam.time).float().to(device)
+                from gaussianprediction_amd.renderer import render
+                return render(cam, pc, ts.pipe, ts.bg, time=t, it=args.iteration)
+        return ts.step(view)
+
+    for i in range(args.warmup):
+        one_step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    _lib.profile_enable(True)
+    _lib.profile_collect()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    pkg = None
+    for i in range(args.steps):
+        out = one_step(args.warmup + i)
+        pkg = out if args.render_only else out[1]
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    prof = _lib.profile_collect()
+    _lib.profile_enable(False)
+    if world > 1:
+        tmax = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    if rank == 0:
+        ms_per_step = 1000.0 * elapsed / args.steps
+        views_per_s = world * args.steps / elapsed
+        # algorithmic bytes of the composite forward pass: 44 R + 8 T + 28 P
+        W, H = args.width, args.height
+        T = ((W + 15) // 16) * ((H + 15) // 16)
+        P = W * H
+        # R of the last rendered view (re-render to read it)
+        from gaussianprediction_amd.rasterizer import raster_forward_debug
+        from gaussianprediction_amd.renderer import _settings
+        with torch.no_grad():
+            cam = cams[((args.warmup + args.steps - 1) * world) % len(cams)]
+            t = torch.from_numpy(cam.time).float().to(device)
+            xyz, q, s, o = pc(t, args.iteration)
+            dbg = raster_forward_debug(_settings(cam, pc, ts.bg, 1.0), xyz, o, shs=pc.get_features, scales=s, rotations=q)
+        R, n_vis = dbg["R"], int((dbg["radii"] > 0).sum())
+        kern = {k: {"launches": v[0], "avg_ms": v[1] / max(v[0], 1)} for k, v in sorted(prof.items())}
+        roof = None
+        if "composite_fwd" in prof:
+            avg_ms = prof["composite_fwd"][1] / prof["composite_fwd"][0]
+            bytes_alg = 44 * R + 8 * T + 28 * P
+            ach = bytes_alg / (avg_ms * 1e-3) / 1e9
+            roof = {"kernel": "composite_fwd", "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                    "algorithmic_bytes": bytes_alg, "avg_ms": round(avg_ms, 4)}
+            tf = os.path.join(ROOT, "profiles", "composite_fwd_traffic.json")
+            if os.path.exists(tf):
+                try:
+                    roof["traffic"] = json.load(open(tf)).get("hbm_bytes_per_launch")
+                except Exception:
+                    pass
+        result = {
+            "metric": "rendered views/s (full train step) @1M Gaussians 1352x1014" if not args.render_only else
+                      "rendered views/s (eval render) @1M Gaussians 1352x1014",
+            "value": round(views_per_s, 3), "unit": "views/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "configs[2]: HyperNeRF-like 1M Gaussians, 1352x1014, stage-3 full train step "
+                                   "(deform fwd/bwd + raster fwd/bwd on HIP kernels; L1+SSIM loss and Adam in torch)"
+                       if not args.render_only else "configs[2] eval render (forward only)",
+                       "gaussians": args.gaussians, "width": W, "height": H, "keypoints": args.keypoints,
+                       "nearest_num": args.nearest_num, "time_freq": args.time_freq, "iteration": args.iteration,
+                       "tiles": T, "pixels": P, "R": R, "R_per_gaussian": round(R / max(args.gaussians, 1), 3),
+                       "visible": n_vis, "parallelism": f"view-parallel x{world}"},
+            "roofline": roof,
+            "kernels_ms": kern,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            try:
+                result["cpu_baseline"] = cpu_baseline(args, pc, cams)
+            except Exception as e:  # the baseline must never kill the bench line
+                result["cpu_baseline"] = {"value": None, "unit": "views/s", "cores": os.cpu_count(), "kind": "port",
+                                          "sample": f"failed: {e}"}
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

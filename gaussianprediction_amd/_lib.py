@@ -70,10 +70,15 @@ class BlendArgsC(C.Structure):
                 ("knn_idx", C.c_void_p), ("xyz", C.c_void_p), ("rot", C.c_void_p)]
 
 
+class ProfileEntryC(C.Structure):
+    _fields_ = [("name", C.c_char * 48), ("launches", C.c_int32), ("total_ms", C.c_float)]
+
+
 EXPORTS = [
     "gp_raster_forward", "gp_raster_backward", "gp_raster_mark_visible", "gp_raster_debug_binning",
     "gp_mlp_forward", "gp_mlp_backward", "gp_blend_forward", "gp_blend_backward",
-    "gp_activations_forward", "gp_activations_backward", "gp_last_error", "gp_version",
+    "gp_activations_forward", "gp_activations_backward", "gp_profile_enable", "gp_profile_collect",
+    "gp_last_error", "gp_version",
 ]
 
 _lib = None
@@ -147,3 +152,15 @@ class TorchAllocator:
     def first(self, which):
         b = self.bufs[which]
         return b[0] if b else None
+
+
+def profile_enable(on: bool) -> None:
+    check(lib().gp_profile_enable(C.c_int(1 if on else 0)), "gp_profile_enable")
+
+
+def profile_collect() -> dict:
+    """{kernel name: (launches, total_ms)} since the previous collect (waits for the recorded events)."""
+    arr = (ProfileEntryC * 64)()
+    n = C.c_int(0)
+    check(lib().gp_profile_collect(arr, C.c_int(64), C.byref(n)), "gp_profile_collect")
+    return {arr[i].name.decode(): (int(arr[i].launches), float(arr[i].total_ms)) for i in range(n.value)}

@@ -32,8 +32,9 @@ extern "C" int gp_mlp_forward(const gp_mlp_params* p, const gp_mlp_input* x, flo
     if (!out) GP_FAIL("null output");
     float* sx = acts;
     float* sh = acts ? acts + gp_align_up(acts_x_floats(m), 64) : nullptr;
-    hipLaunchKernelGGL(gp_mlp_fwd_kernel, dim3(gp_blocks((size_t)m.rows, 32)), dim3(512), 0, (hipStream_t)stream_, m, out, sx, sh);
-    GP_LAUNCH_CHECK();
+    { GpProfScope _p("mlp_fwd", (hipStream_t)stream_);
+        hipLaunchKernelGGL(gp_mlp_fwd_kernel, dim3(gp_blocks((size_t)m.rows, 32)), dim3(512), 0, (hipStream_t)stream_, m, out, sx, sh);
+    GP_LAUNCH_CHECK(); }
     return 0;
 }
 
@@ -52,9 +53,10 @@ extern "C" int gp_mlp_backward(const gp_mlp_params* p, const gp_mlp_input* x, co
     const size_t dz_bytes = gp_align_up((size_t)4 * m.rows * 256 * sizeof(float), 256);
     float* dz = (float*)alloc(alloc_ctx, GP_BUF_TEMP, dz_bytes);
     if (!dz) GP_FAIL("allocator returned NULL for TEMP (%zu B)", dz_bytes);
-    hipLaunchKernelGGL(gp_mlp_bwd_data_kernel, dim3(gp_blocks((size_t)m.rows, 32)), dim3(512), 0, s, m, sh, dL_dout, dz,
+    { GpProfScope _p("mlp_bwd_data", s);
+        hipLaunchKernelGGL(gp_mlp_bwd_data_kernel, dim3(gp_blocks((size_t)m.rows, 32)), dim3(512), 0, s, m, sh, dL_dout, dz,
                        dL_dfeature, dL_dxyz);
-    GP_LAUNCH_CHECK();
+    GP_LAUNCH_CHECK(); }
     // weight grads: dW_l = dZ_{l+1}^T H_l,  H_0 = X
     long rpb = 2048;
     while (rpb < 65536 && (m.rows + rpb - 1) / rpb > 512) rpb *= 2;
@@ -65,9 +67,10 @@ extern "C" int gp_mlp_backward(const gp_mlp_params* p, const gp_mlp_input* x, co
         const float* H = l == 0 ? sx : sh + (size_t)(l - 1) * m.rows * 256;
         const int ldh = l == 0 ? m.in_pad : 256;
         const int n_in = l == 0 ? m.in_dim : 256;
+        { GpProfScope _p("mlp_bwd_weight", s);
         hipLaunchKernelGGL(gp_mlp_bwd_weight_kernel, dim3(nrb, (unsigned)((n_in + 31) / 32)), dim3(512), 0, s, dZl, n_out, H,
                            ldh, n_in, m.rows, rpb, g->dw[l], n_in, g->db[l]);
-        GP_LAUNCH_CHECK();
+        GP_LAUNCH_CHECK(); }
     }
     return 0;
 }
@@ -90,8 +93,9 @@ extern "C" int gp_blend_forward(const gp_blend_args* a, float* xyz_t, float* q_t
     if (make_blend(a, b)) return 1;
     if (b.N == 0) return 0;
     if (!xyz_t || !q_t) GP_FAIL("null output");
-    hipLaunchKernelGGL(gp_blend_fwd_kernel, dim3(gp_blocks((size_t)b.N, 256)), dim3(256), 0, (hipStream_t)stream_, b, xyz_t, q_t);
-    GP_LAUNCH_CHECK();
+    { GpProfScope _p("blend_fwd", (hipStream_t)stream_);
+        hipLaunchKernelGGL(gp_blend_fwd_kernel, dim3(gp_blocks((size_t)b.N, 256)), dim3(256), 0, (hipStream_t)stream_, b, xyz_t, q_t);
+    GP_LAUNCH_CHECK(); }
     return 0;
 }
 
@@ -104,9 +108,10 @@ extern "C" int gp_blend_backward(const gp_blend_args* a, const float* dL_dxyz_t,
     unsigned blocks = gp_blocks((size_t)b.N, 256);
     if (b.nn > 0 && blocks > 512) blocks = 512;
     const size_t lds = b.nn > 0 ? (size_t)b.K * 7 * sizeof(float) : 0;
-    hipLaunchKernelGGL(gp_blend_bwd_kernel, dim3(blocks), dim3(256), lds, (hipStream_t)stream_, b, dL_dxyz_t, dL_dq_t, dL_ddelta,
+    { GpProfScope _p("blend_bwd", (hipStream_t)stream_);
+        hipLaunchKernelGGL(gp_blend_bwd_kernel, dim3(blocks), dim3(256), lds, (hipStream_t)stream_, b, dL_dxyz_t, dL_dq_t, dL_ddelta,
                        dL_draw_w, dL_dxyz, dL_drot);
-    GP_LAUNCH_CHECK();
+    GP_LAUNCH_CHECK(); }
     return 0;
 }
 

@@ -20,10 +20,12 @@ static int make_dims(const gp_raster_settings* st, const gp_raster_inputs* in, R
     if (st->image_width <= 0 || st->image_height <= 0) GP_FAIL("bad image size %dx%d", st->image_width, st->image_height);
     if (in->num_gaussians < 0 || in->num_gaussians > 0x7FFFFFF0LL) GP_FAIL("num_gaussians out of range");
     if (st->sh_degree < 0 || st->sh_degree > 3) GP_FAIL("sh_degree %d unsupported (0..3)", st->sh_degree);
-    if ((in->shs == nullptr) == (in->colors_precomp == nullptr)) GP_FAIL("Please provide exactly one of either SHs or precomputed colors!");
     const bool has_sr = in->scales != nullptr || in->rotations != nullptr;
-    if (has_sr == (in->cov3D_precomp != nullptr) || (has_sr && (!in->scales || !in->rotations)))
-        GP_FAIL("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!");
+    if (in->num_gaussians > 0) {  // (an empty tensor has a NULL data pointer: nothing to check then)
+        if ((in->shs == nullptr) == (in->colors_precomp == nullptr)) GP_FAIL("Please provide exactly one of either SHs or precomputed colors!");
+        if (has_sr == (in->cov3D_precomp != nullptr) || (has_sr && (!in->scales || !in->rotations)))
+            GP_FAIL("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!");
+    }
     if (in->shs && st->sh_coeffs < (st->sh_degree + 1) * (st->sh_degree + 1)) GP_FAIL("shs has %d coeffs, degree %d needs more", st->sh_coeffs, st->sh_degree);
     if (in->shs && st->sh_coeffs > 16) GP_FAIL("sh_coeffs %d > 16 unsupported", st->sh_coeffs);
     if (!st->bg || !st->viewmatrix || !st->projmatrix || !st->campos) GP_FAIL("null camera pointers");
@@ -111,15 +113,17 @@ extern "C" int gp_raster_forward(const gp_raster_settings* st, const gp_raster_i
         GpCarver tc(tmp);
         carve_tmp(tc, k0, k1, v0, v1, tiles, tt, hist, scan_tmp);
 
+        { GpProfScope _p("preprocess_fwd", s);
         hipLaunchKernelGGL(gp_preprocess_fwd_kernel, dim3(gp_blocks(N, 256)), dim3(256), 0, s, d, in->means3D, in->scales,
                            in->rotations, in->opacities, in->shs, in->colors_precomp, in->cov3D_precomp, st->viewmatrix,
                            st->projmatrix, st->campos, out->radii, gl.rec, k0, tiles, gl.clamped);
-        GP_LAUNCH_CHECK();
+        GP_LAUNCH_CHECK(); }
         hipLaunchKernelGGL(gp_iota_kernel, dim3(gp_blocks(N, 256)), dim3(256), 0, s, v0, d.N);
         GP_LAUNCH_CHECK();
         GpSortBufs sb;
         sb.k[0] = k0; sb.k[1] = k1; sb.v[0] = v0; sb.v[1] = v1; sb.hist = hist; sb.scan_tmp = scan_tmp; sb.scan_tmp_elems = scan_elems;
-        const int r1 = gp_radix_sort_pairs(sb, N, 32, s);
+        int r1;
+        { GpProfScope _p("depth_sort", s); r1 = gp_radix_sort_pairs(sb, N, 32, s); }
         if (r1 < 0) return 1;
         const uint32_t* sorted_ids = sb.v[r1];
         hipLaunchKernelGGL(gp_gather_tiles_kernel, dim3(gp_blocks(N + 1, 256)), dim3(256), 0, s, sorted_ids, tiles, tt, d.N);
@@ -153,20 +157,24 @@ extern "C" int gp_raster_forward(const gp_raster_settings* st, const gp_raster_i
             tb.k[0] = bk0; tb.k[1] = bk1;
             tb.v[res] = point_list; tb.v[res ^ 1] = bvo;
             tb.hist = bhist; tb.scan_tmp = bscan; tb.scan_tmp_elems = bs;
-            hipLaunchKernelGGL(gp_duplicate_kernel, dim3(gp_blocks(N, 256)), dim3(256), 0, s, d, sorted_ids, tt, tiles,
+            { GpProfScope _p("duplicate", s);
+        hipLaunchKernelGGL(gp_duplicate_kernel, dim3(gp_blocks(N, 256)), dim3(256), 0, s, d, sorted_ids, tt, tiles,
                                out->radii, gl.rec, tb.k[0], tb.v[0]);
-            GP_LAUNCH_CHECK();
-            const int r2 = gp_radix_sort_pairs(tb, R, tbits, s);
+            GP_LAUNCH_CHECK(); }
+            int r2;
+            { GpProfScope _p("tile_sort", s); r2 = gp_radix_sort_pairs(tb, R, tbits, s); }
             if (r2 < 0) return 1;
             if (r2 != res) GP_FAIL("internal: sort parity mismatch");
-            hipLaunchKernelGGL(gp_tile_ranges_kernel, dim3(gp_blocks(R, 256)), dim3(256), 0, s, tb.k[r2], R, il.ranges);
-            GP_LAUNCH_CHECK();
+            { GpProfScope _p("tile_ranges", s);
+        hipLaunchKernelGGL(gp_tile_ranges_kernel, dim3(gp_blocks(R, 256)), dim3(256), 0, s, tb.k[r2], R, il.ranges);
+            GP_LAUNCH_CHECK(); }
         }
     }
     saved->num_rendered = (int64_t)R;
-    hipLaunchKernelGGL(gp_composite_fwd_kernel, dim3((unsigned)T), dim3(128), 0, s, d, il.ranges, point_list, gl.rec, st->bg,
+    { GpProfScope _p("composite_fwd", s);
+        hipLaunchKernelGGL(gp_composite_fwd_kernel, dim3((unsigned)T), dim3(128), 0, s, d, il.ranges, point_list, gl.rec, st->bg,
                        out->color, out->depth, out->tidx, il.final_T, il.n_contrib);
-    GP_LAUNCH_CHECK();
+    GP_LAUNCH_CHECK(); }
     return 0;
 }
 
@@ -200,17 +208,19 @@ extern "C" int gp_raster_backward(const gp_raster_settings* st, const gp_raster_
     float* g_depth = acc + 9 * N;
     if (R > 0) {
         const unsigned parts = GP_TILE / 8;
+        { GpProfScope _p("composite_bwd", s);
         hipLaunchKernelGGL(gp_composite_bwd_kernel, dim3((unsigned)T * parts), dim3(64), 0, s, d, il.ranges, point_list,
                            gl.rec, st->bg, fwd->color, fwd->depth, il.final_T, il.n_contrib, dL_dcolor, dL_ddepth, g_mean2D,
                            g_conic, g_opacity, g_color, g_depth);
-        GP_LAUNCH_CHECK();
+        GP_LAUNCH_CHECK(); }
     }
-    hipLaunchKernelGGL(gp_preprocess_bwd_kernel, dim3(gp_blocks(N, 256)), dim3(256), 0, s, d, in->means3D, in->scales,
+    { GpProfScope _p("preprocess_bwd", s);
+        hipLaunchKernelGGL(gp_preprocess_bwd_kernel, dim3(gp_blocks(N, 256)), dim3(256), 0, s, d, in->means3D, in->scales,
                        in->rotations, in->shs, in->cov3D_precomp, st->viewmatrix, st->projmatrix, st->campos, fwd->radii,
                        gl.clamped, g_mean2D, g_conic, g_opacity, g_color, g_depth, g->dL_dmeans3D, g->dL_dmeans2D, g->dL_dshs,
                        in->shs ? nullptr : g->dL_dcolors_precomp, g->dL_dopacities, g->dL_dscales, g->dL_drotations,
                        g->dL_dcov3D_precomp);
-    GP_LAUNCH_CHECK();
+    GP_LAUNCH_CHECK(); }
     return 0;
 }
 

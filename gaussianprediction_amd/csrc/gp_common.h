@@ -58,6 +58,16 @@ __device__ __forceinline__ unsigned long long gp_readfirstlane64(unsigned long l
 // exp(x) for x <= 0 via the hardware exp2 (v_exp_f32, ~1 ulp)
 __device__ __forceinline__ float gp_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
 
+// ---- optional kernel timing (gp_profile.hip) ----------------------------------------------------
+bool gp_prof_on();
+void* gp_prof_begin(const char* name, hipStream_t s);
+void gp_prof_end(void* h, hipStream_t s);
+struct GpProfScope {
+    void* h; hipStream_t s;
+    GpProfScope(const char* name, hipStream_t st) : h(gp_prof_begin(name, st)), s(st) {}
+    ~GpProfScope() { gp_prof_end(h, s); }
+};
+
 // ---- sub-module entry points (host side, defined in the .hip files) -----------------------------
 int gp_scan_exclusive_u32(uint32_t* data, size_t n, uint32_t* tmp, size_t tmp_elems, hipStream_t s);
 size_t gp_scan_tmp_elems(size_t n);

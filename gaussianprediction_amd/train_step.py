@@ -1,0 +1,90 @@
+"""Train-step harness: what the reference's loop does around the hot
+path for one iteration [REF train.py:101-133, 196-197]:
+    render -> 0.8*L1 + 0.2*(1-SSIM_11x11) + 1e-5*mean|motion feature| -> backward -> Adam(eps=1e-15).
+The render + deformation forward/backward are this package's HIP kernels.  The loss and the optimizer
+are plain torch ops here: they are the "next" rows of SURVEY section 8(f) (fused L1+SSIM, fused Adam),
+not yet hot-path rows.
+"""
+from __future__ import annotations
+
+from types import SimpleNamespace
+
+import torch
+import torch.nn.functional as F
+
+from .dist import FlatGradBucket
+from .renderer import render
+
+
+def _gauss_window(channels, device, size=11, sigma=1.5):
+    import math
+    g = torch.tensor([math.exp(-(x - size // 2) ** 2 / float(2 * sigma ** 2)) for x in range(size)], device=device)
+    g = (g / g.sum()).unsqueeze(1)
+    return (g @ g.t()).unsqueeze(0).unsqueeze(0).expand(channels, 1, size, size).contiguous()
+
+
+def l1_loss(a, b):                       # [REF utils/loss_utils.py:54-55]
+    return torch.abs(a - b).mean()
+
+
+def ssim(img1, img2, window):            # [REF utils/loss_utils.py:70-100]
+    C = img1.shape[-3]
+    i1, i2 = img1.unsqueeze(0), img2.unsqueeze(0)
+    pad = window.shape[-1] // 2
+    mu1 = F.conv2d(i1, window, padding=pad, groups=C)
+    mu2 = F.conv2d(i2, window, padding=pad, groups=C)
+    mu1_sq, mu2_sq, mu12 = mu1 * mu1, mu2 * mu2, mu1 * mu2
+    s1 = F.conv2d(i1 * i1, window, padding=pad, groups=C) - mu1_sq
+    s2 = F.conv2d(i2 * i2, window, padding=pad, groups=C) - mu2_sq
+    s12 = F.conv2d(i1 * i2, window, padding=pad, groups=C) - mu12
+    C1, C2 = 0.01 ** 2, 0.03 ** 2
+    return (((2 * mu12 + C1) * (2 * s12 + C2)) / ((mu1_sq + mu2_sq + C1) * (s1 + s2 + C2))).mean()
+
+
+class TrainStep:
+    """One optimisation step over one view per rank (view-parallel when world_size > 1)."""
+
+    def __init__(self, pc, cameras, gt_images, iteration, lambda_dssim=0.2, lrs=None, group=None):
+        self.pc, self.cameras, self.gt, self.iteration = pc, cameras, gt_images, iteration
+        self.lambda_dssim = lambda_dssim
+        self.group = group
+        dev = pc.get_xyz.device
+        self.bg = torch.zeros(3, device=dev)          # black background [REF train.py:59]
+        self.pipe = SimpleNamespace(convert_SHs_python=False, compute_cov3D_python=False, debug=False)
+        self.window = _gauss_window(3, dev)
+        lr = dict(xyz=1.6e-4, f_dc=2.5e-3, f_rest=2.5e-3 / 20, opacity=0.05, scaling=5e-3, rotation=1e-3, mfeature=8e-4,
+                  kpts=8e-4, mlp=8e-4)              # [REF arguments/__init__.py:74-90]
+        if lrs:
+            lr.update(lrs)
+        groups = [
+            {"params": [pc._xyz], "lr": lr["xyz"], "name": "xyz"},
+            {"params": [pc._features_dc], "lr": lr["f_dc"], "name": "f_dc"},
+            {"params": [pc._features_rest], "lr": lr["f_rest"], "name": "f_rest"},
+            {"params": [pc._opacity], "lr": lr["opacity"], "name": "opacity"},
+            {"params": [pc._scaling], "lr": lr["scaling"], "name": "scaling"},
+            {"params": [pc._rotation], "lr": lr["rotation"], "name": "rotation"},
+            {"params": [pc.motion_feature], "lr": lr["mfeature"], "name": "motion_feature"},
+            {"params": list(pc.df_model.parameters()), "lr": lr["mlp"], "name": "df_mlp"},
+        ]
+        if hasattr(pc, "super_gaussians"):
+            groups += [{"params": [pc.super_gaussians], "lr": lr["kpts"], "name": "s_xyz"},
+                       {"params": [pc.super_gaussians_feature], "lr": lr["mfeature"], "name": "s_motion_feature"}]
+        self.optimizer = torch.optim.Adam(groups, lr=0.0, eps=1e-15, foreach=True)   # [REF scene/gaussian_model.py:472]
+        self.bucket = FlatGradBucket([p for g in groups for p in g["params"]])
+
+    def loss_of(self, image, gt):
+        Ll1 = l1_loss(image, gt)
+        loss = (1.0 - self.lambda_dssim) * Ll1 + self.lambda_dssim * (1.0 - ssim(image, gt, self.window))
+        return loss + self.pc.get_loss(self.iteration)
+
+    def step(self, view_index: int):
+        cam = self.cameras[view_index % len(self.cameras)]
+        gt = self.gt[view_index % len(self.gt)]
+        time = torch.from_numpy(cam.time).to(torch.float32).to(self.bg.device)
+        pkg = render(cam, self.pc, self.pipe, self.bg, time=time, it=self.iteration)
+        loss = self.loss_of(pkg["render"], gt)
+        loss.backward()
+        self.bucket.all_reduce_sum(self.group)       # SUM over views == the reference's --batch semantics
+        self.optimizer.step()
+        self.bucket.zero()
+        return loss.detach(), pkg

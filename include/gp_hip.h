@@ -191,6 +191,18 @@ int gp_activations_backward(int64_t n, const float* scaling_raw, const float* op
                             float* dL_dscaling_raw, float* dL_dopacity_raw, float* dL_ddelta_o /*[N,stride] col 0*/,
                             gp_stream_t stream);
 
+/* ---- measurement ----------------------------------------------------------------------------- */
+/* When enabled, the library brackets its kernels with hipEvent pairs recorded on the launch stream.
+ * gp_profile_collect() waits for the recorded events and returns per-kernel launch counts and summed
+ * durations since the previous collect (used by bench.py for the roofline figures). */
+typedef struct gp_profile_entry {
+    char name[48];
+    int32_t launches;
+    float total_ms;
+} gp_profile_entry;
+int gp_profile_enable(int on);
+int gp_profile_collect(gp_profile_entry* out, int max_entries, int* n_out);
+
 const char* gp_last_error(void);
 const char* gp_version(void);
 

@@ -383,10 +383,10 @@ int gpo_composite_fwd(int W, int H, const int32_t* ranges, const uint32_t* point
                     if (FABSR(power) < R(1e-6)) amb |= 1;
                     if (power > R(0)) continue;
                     real alpha = FMINR(R(0.99), co[3] * EXPR(power));
-                    if (FABSR(alpha * R(255) - R(1)) < R(1e-4)) amb |= 1;
+                    if (FABSR(alpha * R(255) - R(1)) < R(2e-5)) amb |= 1;
                     if (alpha < R(1) / R(255)) continue;
                     real test_T = T * (R(1) - alpha);
-                    if (FABSR(test_T * R(1e4) - R(1)) < R(1e-3)) amb |= 1;
+                    if (FABSR(test_T * R(1e4) - R(1)) < R(1e-4)) amb |= 1;
                     if (test_T < R(0.0001)) break;
                     real w = alpha * T;
                     C0 = FMA(rgb[3 * id], w, C0);

@@ -1,0 +1,149 @@
+"""-m gpu: deformation kernels (fused PE+MLP on the fp32 matrix cores, keypoint blend, activations)
+against the torch oracle (oracle/deform_oracle.py, itself pinned to the reference by golden vectors)
+and directly against the golden vectors."""
+import os
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+import gaussianprediction_amd as gpa
+from gaussianprediction_amd.deform_ops import Activations, FusedMlp, KeypointBlend
+from golden.make_golden import mlp_state
+from oracle import deform_oracle as do
+from util import rel_l2
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _net(seed, d_in, d_out, device="cuda"):
+    net = gpa.Deformable_Field(d_in, output_dim=d_out, d=4, w=256).to(device)
+    sd = mlp_state(seed, d_in, d_out)
+    net.load_state_dict({k: torch.tensor(v) for k, v in sd.items()})
+    return net, sd
+
+
+def test_mlp_matches_reference_golden_vectors():
+    g = np.load(os.path.join(G, "deformable_field.npz"))
+    for tag in ("a", "b", "c"):
+        d_in, d_out, M, seed = [int(v) for v in g[f"{tag}_meta"]]
+        net, _ = _net(seed, d_in, d_out)
+        x = torch.tensor(np.random.default_rng(seed + 100).uniform(-1, 1, size=(M, d_in)).astype(np.float32), device="cuda", requires_grad=True)
+        gy = torch.tensor(np.random.default_rng(seed + 200).normal(size=(M, d_out)).astype(np.float32), device="cuda")
+        y = net(x)
+        (y * gy).sum().backward()
+        np.testing.assert_allclose(y.detach().cpu().numpy(), g[f"{tag}_y"], rtol=1e-4, atol=2e-6)
+        np.testing.assert_allclose(x.grad.cpu().numpy(), g[f"{tag}_dx"], rtol=1e-3, atol=2e-6)
+        for k, p in net.named_parameters():
+            if tag == "a":
+                assert rel_l2(p.grad.cpu().numpy(), g[f"a_grad_{k}"]) < 1e-5, k
+            else:
+                gs = g[f"{tag}_gradsum_{k}"]
+                assert abs(p.grad.double().sum().item() - gs[0]) <= 1e-3 * max(1.0, gs[1]), k
+
+
+@pytest.mark.parametrize("rows,F,out_dim", [(1, 6, 7), (33, 8, 7), (250, 8, 7), (300, 10, 8), (5000, 6, 7)])
+def test_fused_pe_mlp_forward_backward(rows, F, out_dim):
+    d_in = 32 + 60 + 2 * F
+    net, sd = _net(40 + rows, d_in, out_dim)
+    rng = np.random.default_rng(rows)
+    feat = torch.tensor(rng.uniform(-1e-1, 1e-1, size=(rows, 32)).astype(np.float32))
+    xyz = torch.tensor(rng.uniform(-1.3, 1.3, size=(rows, 3)).astype(np.float32))
+    t = torch.tensor([0.37], dtype=torch.float32)
+    gy = torch.tensor(rng.normal(size=(rows, out_dim)).astype(np.float32))
+    # oracle (float64 autograd)
+    sd64 = {k: torch.tensor(v, dtype=torch.float64, requires_grad=True) for k, v in sd.items()}
+    f64, x64 = feat.double().requires_grad_(True), xyz.double().requires_grad_(True)
+    X = torch.cat([f64, do.positional_encoding(x64, 10), do.positional_encoding(t.double(), F).unsqueeze(0).repeat(rows, 1)], -1)
+    y64 = do.mlp_forward(sd64, X)
+    (y64 * gy.double()).sum().backward()
+    # rows with a hidden pre-activation within float32 rounding of 0 have an ill-defined ReLU mask
+    with torch.no_grad():
+        h, zmin = X, torch.full((rows,), 1e9, dtype=torch.float64)
+        for i in range(4):
+            z = torch.nn.functional.linear(h, sd64[f"mlp.{2 * i}.weight"], sd64[f"mlp.{2 * i}.bias"])
+            zmin = torch.minimum(zmin, z.abs().min(dim=1).values)
+            h = torch.relu(z)
+        ok = (zmin > 2e-6).numpy()
+    assert ok.mean() > 0.99
+    # HIP
+    fd, xd = feat.cuda().requires_grad_(True), xyz.cuda().requires_grad_(True)
+    y = net.forward_fused(fd, xd, t.cuda(), 10, F)
+    (y * gy.cuda()).sum().backward()
+    assert np.abs(y.detach().cpu().numpy() - y64.detach().numpy()).max() < 2e-5
+    assert rel_l2(fd.grad.cpu().numpy()[ok], f64.grad.numpy()[ok]) < 1e-4
+    assert rel_l2(xd.grad.cpu().numpy()[ok], x64.grad.numpy()[ok]) < 1e-4
+    wtol = 1e-4 if ok.all() else 1e-3
+    for k, p in net.named_parameters():
+        assert rel_l2(p.grad.cpu().numpy(), sd64[k].grad.numpy()) < wtol, k
+
+
+def _blend_inputs(N, K, nn_, out_dim, seed):
+    rng = np.random.default_rng(seed)
+    delta = torch.tensor(rng.normal(size=(K if nn_ else N, out_dim)).astype(np.float32) * 0.3)
+    raw_w = torch.tensor(rng.normal(size=(N, 2 * nn_)).astype(np.float32)) if nn_ else None
+    idx = torch.stack([torch.tensor(rng.permutation(K)[:nn_]) for _ in range(N)]).long() if nn_ else None
+    xyz = torch.tensor(rng.uniform(-1, 1, size=(N, 3)).astype(np.float32))
+    rot = torch.tensor(rng.normal(size=(N, 4)).astype(np.float32))
+    return delta, raw_w, idx, xyz, rot
+
+
+@pytest.mark.parametrize("N,K,nn_,out_dim,norm", [(500, 0, 0, 7, True), (500, 0, 0, 8, False), (3000, 250, 6, 7, True),
+                                                   (3000, 512, 8, 8, True), (777, 100, 6, 7, False)])
+def test_blend_forward_backward(N, K, nn_, out_dim, norm):
+    delta, raw_w, idx, xyz, rot = _blend_inputs(N, K, nn_, out_dim, N + K)
+    gx = torch.tensor(np.random.default_rng(1).normal(size=(N, 3)).astype(np.float32))
+    gq = torch.tensor(np.random.default_rng(2).normal(size=(N, 4)).astype(np.float32))
+    # oracle: dense scatter + matmul as the reference does (float64)
+    d64 = delta.double().requires_grad_(True)
+    x64, r64 = xyz.double().requires_grad_(True), rot.double().requires_grad_(True)
+    dq = d64[:, 3:7]
+    dxyz = d64[:, 0:3]
+    if norm:
+        dq = torch.nn.functional.normalize(dq)
+    if nn_:
+        w64 = raw_w.double().requires_grad_(True)
+        wx, wr = do.fill_nearest(w64, idx, K, nn_)
+        dq, dxyz = wr @ dq, wx @ dxyz
+    xt = x64 + dxyz
+    qt = torch.nn.functional.normalize(do.quat_mul(torch.nn.functional.normalize(dq), r64))
+    ((xt * gx.double()).sum() + (qt * gq.double()).sum()).backward()
+    # HIP
+    dd = delta.cuda().requires_grad_(True)
+    xd, rd = xyz.cuda().requires_grad_(True), rot.cuda().requires_grad_(True)
+    wd = raw_w.cuda().requires_grad_(True) if nn_ else None
+    xt_h, qt_h = KeypointBlend.apply(dd, wd, idx.cuda() if nn_ else None, xd, rd, norm)
+    ((xt_h * gx.cuda()).sum() + (qt_h * gq.cuda()).sum()).backward()
+    assert np.abs(xt_h.detach().cpu().numpy() - xt.detach().numpy()).max() < 1e-5
+    assert np.abs(qt_h.detach().cpu().numpy() - qt.detach().numpy()).max() < 1e-5
+    assert rel_l2(dd.grad.cpu().numpy(), d64.grad.numpy()) < 1e-4
+    assert rel_l2(xd.grad.cpu().numpy(), x64.grad.numpy()) < 1e-5
+    assert rel_l2(rd.grad.cpu().numpy(), r64.grad.numpy()) < 1e-4
+    if nn_:
+        assert rel_l2(wd.grad.cpu().numpy(), w64.grad.numpy()) < 1e-4
+
+
+def test_activations_forward_backward():
+    rng = np.random.default_rng(5)
+    N = 1000
+    s = torch.tensor(rng.uniform(-5, -1, size=(N, 3)).astype(np.float32))
+    o = torch.tensor(rng.normal(size=(N, 1)).astype(np.float32))
+    d = torch.tensor(rng.normal(size=(N, 8)).astype(np.float32) * 0.2)
+    gs = torch.tensor(rng.normal(size=(N, 3)).astype(np.float32))
+    go = torch.tensor(rng.normal(size=(N, 1)).astype(np.float32))
+    for use_d in (False, True):
+        s64, o64, d64 = s.double().requires_grad_(True), o.double().requires_grad_(True), d.double().requires_grad_(True)
+        sc = torch.exp(s64)
+        op = torch.sigmoid(o64) * (1 / (1 + torch.exp(-d64[:, 7:8] / 0.1)) if use_d else 1.0)
+        ((sc * gs.double()).sum() + (op * go.double()).sum()).backward()
+        sd_, od_, dd_ = s.cuda().requires_grad_(True), o.cuda().requires_grad_(True), d.cuda().requires_grad_(True)
+        sc_h, op_h = Activations.apply(sd_, od_, dd_ if use_d else None, 7, 0.1)
+        ((sc_h * gs.cuda()).sum() + (op_h * go.cuda()).sum()).backward()
+        assert np.abs(sc_h.detach().cpu().numpy() - sc.detach().numpy()).max() < 1e-6
+        assert np.abs(op_h.detach().cpu().numpy() - op.detach().numpy()).max() < 1e-6
+        assert rel_l2(sd_.grad.cpu().numpy(), s64.grad.numpy()) < 1e-5
+        assert rel_l2(od_.grad.cpu().numpy(), o64.grad.numpy()) < 1e-5
+        if use_d:
+            assert rel_l2(dd_.grad.cpu().numpy(), d64.grad.numpy()) < 1e-5

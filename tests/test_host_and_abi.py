@@ -43,6 +43,7 @@ def test_abi_validation_errors_are_reported_not_thrown():
     rc = l.gp_raster_forward(C.byref(st), C.byref(inp), C.byref(out), C.byref(saved), alloc.cb, None, None)
     assert rc != 0 and b"image size" in l.gp_last_error()
     st.image_height, st.image_width = 16, 16
+    inp.num_gaussians = 4
     rc = l.gp_raster_forward(C.byref(st), C.byref(inp), C.byref(out), C.byref(saved), alloc.cb, None, None)
     assert rc != 0 and b"exactly one of either SHs" in l.gp_last_error()
     p = _lib.MlpParamsC(104, 128, 4, 7)
