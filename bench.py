@@ -51,8 +51,18 @@ def build_workload(args, device):
     pc.set_keypoint_weights(raw_w, idx)
     fovx = 2 * math.atan(1.0 / (2 * 0.9))           # focal ~ 0.9 W
     cams = orbit_cameras(8, 4.0, fovx, args.width, args.height, arc_deg=40.0, elevation_deg=5.0, device=device)
+    # ground truth = the scene itself rendered at a slightly later time + pixel noise: a small, realistic
+    # residual (a pure-noise target would make Adam fling the Gaussians out of view within a few steps and
+    # the workload R would not be stationary over the timed region)
+    from gaussianprediction_amd.renderer import render
+    pipe = SimpleNamespace(convert_SHs_python=False, compute_cov3D_python=False, debug=False)
     g = torch.Generator().manual_seed(7)
-    gts = [torch.rand(3, args.height, args.width, generator=g).to(device) for _ in range(2)]
+    gts = []
+    with torch.no_grad():
+        for cam in cams:
+            t = torch.from_numpy(cam.time).float().to(device) + 0.02
+            img = render(cam, pc, pipe, torch.zeros(3, device=device), time=t, it=args.iteration)["render"]
+            gts.append((img + 0.02 * torch.randn(img.shape, generator=g).to(device)).clamp(0, 1))
     return pc, cams, gts, margs
 
 
@@ -116,7 +126,9 @@ def main():
     device = torch.device("cuda", local)
     torch.cuda.set_device(device)
     pc, cams, gts, margs = build_workload(args, device)
-    ts = TrainStep(pc, cams, gts, args.iteration)
+    # learning rates of the reference at iteration 50000 (position lr has decayed to position_lr_final,
+    # [REF arguments/__init__.py:75-76, scene/gaussian_model.py:474-491])
+    ts = TrainStep(pc, cams, gts, args.iteration, lrs=dict(xyz=1.6e-6 * 5.0))
 
     def one_step(i):
         view = i * world + rank            # rank r renders view world*i + r
@@ -131,6 +143,14 @@ def main():
     for i in range(args.warmup):
         one_step(i)
     torch.cuda.synchronize()
+    if rank == 0:
+        from gaussianprediction_amd.rasterizer import raster_forward_debug as _rfd
+        from gaussianprediction_amd.renderer import _settings as _st
+        with torch.no_grad():
+            cam0 = cams[(args.warmup * world) % len(cams)]
+            x0, q0, s0, o0 = pc(torch.from_numpy(cam0.time).float().to(device), args.iteration)
+            main._R0 = _rfd(_st(cam0, pc, ts.bg, 1.0), x0, o0, shs=pc.get_features, scales=s0, rotations=q0)["R"]
+        torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     _lib.profile_enable(True)
@@ -168,6 +188,7 @@ def main():
             xyz, q, s, o = pc(t, args.iteration)
             dbg = raster_forward_debug(_settings(cam, pc, ts.bg, 1.0), xyz, o, shs=pc.get_features, scales=s, rotations=q)
         R, n_vis = dbg["R"], int((dbg["radii"] > 0).sum())
+        R0 = getattr(main, "_R0", None)
         kern = {k: {"launches": v[0], "avg_ms": v[1] / max(v[0], 1)} for k, v in sorted(prof.items())}
         roof = None
         if "composite_fwd" in prof:
@@ -190,11 +211,11 @@ def main():
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "configs[2]: HyperNeRF-like 1M Gaussians, 1352x1014, stage-3 full train step "
-                                   "(deform fwd/bwd + raster fwd/bwd on HIP kernels; L1+SSIM loss and Adam in torch)"
+                                   "(deform, raster, L1+SSIM loss, Adam: all HIP kernels)"
                        if not args.render_only else "configs[2] eval render (forward only)",
                        "gaussians": args.gaussians, "width": W, "height": H, "keypoints": args.keypoints,
                        "nearest_num": args.nearest_num, "time_freq": args.time_freq, "iteration": args.iteration,
-                       "tiles": T, "pixels": P, "R": R, "R_per_gaussian": round(R / max(args.gaussians, 1), 3),
+                       "tiles": T, "pixels": P, "R": R, "R_before_timed_region": R0, "R_per_gaussian": round(R / max(args.gaussians, 1), 3),
                        "visible": n_vis, "parallelism": f"view-parallel x{world}"},
             "roofline": roof,
             "kernels_ms": kern,

@@ -78,6 +78,7 @@ EXPORTS = [
     "gp_raster_forward", "gp_raster_backward", "gp_raster_mark_visible", "gp_raster_debug_binning",
     "gp_mlp_forward", "gp_mlp_backward", "gp_blend_forward", "gp_blend_backward",
     "gp_activations_forward", "gp_activations_backward", "gp_profile_enable", "gp_profile_collect",
+    "gp_loss_l1_ssim_forward", "gp_loss_l1_ssim_backward", "gp_adam_step",
     "gp_last_error", "gp_version",
 ]
 
@@ -132,17 +133,39 @@ def stream_ptr(device=None):
 
 
 class TorchAllocator:
-    """Backs gp_alloc_fn with torch's caching allocator; keeps buffers alive per class."""
+    """Backs gp_alloc_fn with torch's caching allocator.
+
+    GEOM / BINNING / IMAGE buffers outlive the call (they are saved for backward) and are rounded up to a
+    coarse granule so the caching allocator re-uses blocks although R changes from view to view.
+    TEMP buffers are only touched by kernels enqueued during the call, on the calling stream, so a
+    per-(device, stream, slot) arena that only ever grows is re-used across calls without any
+    allocator traffic (stream order makes the re-use safe)."""
+
+    _temp_arena: dict = {}
+    GRANULE = 8 << 20
 
     def __init__(self, device):
-        self.device = device
+        self.device = torch.device(device) if not isinstance(device, torch.device) else device
         self.bufs = {GP_BUF_GEOM: [], GP_BUF_BINNING: [], GP_BUF_IMAGE: [], GP_BUF_TEMP: []}
         self.error = None
         self.cb = ALLOC_FN(self._alloc)
+        self._temp_slot = 0
+        self._stream = torch.cuda.current_stream(self.device).cuda_stream if self.device.type == "cuda" else 0
 
     def _alloc(self, _ctx, which, nbytes):
         try:
-            t = torch.empty(max(int(nbytes), 1), dtype=torch.uint8, device=self.device)
+            nbytes = max(int(nbytes), 1)
+            if which == GP_BUF_TEMP and self.device.type == "cuda":
+                key = (self.device.index, self._stream, self._temp_slot)
+                self._temp_slot += 1
+                t = TorchAllocator._temp_arena.get(key)
+                if t is None or t.numel() < nbytes:
+                    t = torch.empty(int(nbytes * 1.25) + 256, dtype=torch.uint8, device=self.device)
+                    TorchAllocator._temp_arena[key] = t
+            else:
+                g = TorchAllocator.GRANULE
+                size = nbytes if nbytes < g // 8 else (nbytes + g - 1) // g * g
+                t = torch.empty(size, dtype=torch.uint8, device=self.device)
             self.bufs[which].append(t)
             return t.data_ptr()
         except Exception as e:  # never let an exception cross the C boundary

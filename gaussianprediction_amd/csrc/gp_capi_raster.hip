@@ -3,6 +3,7 @@
 // kernels of raster_kernels.hip / sort_scan.hip on the caller's stream.
 #include "gp_common.h"
 #include "raster_kernels.h"
+#include <stdlib.h>
 
 thread_local char gp_err_buf[512] = "";
 
@@ -208,8 +209,11 @@ extern "C" int gp_raster_backward(const gp_raster_settings* st, const gp_raster_
     float* g_depth = acc + 9 * N;
     if (R > 0) {
         const unsigned parts = GP_TILE / 8;
+        static const bool noatomic = getenv("GP_EXP_BWD_NOATOMIC") != nullptr;   // timing experiment only
         { GpProfScope _p("composite_bwd", s);
-        hipLaunchKernelGGL(gp_composite_bwd_kernel, dim3((unsigned)T * parts), dim3(64), 0, s, d, il.ranges, point_list,
+        static const bool use_v1 = getenv("GP_EXP_BWD_V1") != nullptr;               // A/B against the first design
+        hipLaunchKernelGGL(noatomic ? gp_composite_bwd_noatomic_kernel : use_v1 ? gp_composite_bwd_kernel :
+                           dL_ddepth ? gp_composite_bwd2_depth_kernel : gp_composite_bwd2_kernel, dim3((unsigned)T * parts), dim3(64), 0, s, d, il.ranges, point_list,
                            gl.rec, st->bg, fwd->color, fwd->depth, il.final_T, il.n_contrib, dL_dcolor, dL_ddepth, g_mean2D,
                            g_conic, g_opacity, g_color, g_depth);
         GP_LAUNCH_CHECK(); }

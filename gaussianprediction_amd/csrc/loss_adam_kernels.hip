@@ -1,0 +1,234 @@
+// loss_adam_kernels.hip -- the two steps that follow the render in every training iteration
+// (SURVEY.md section 8f rows 2 and 3), fused for gfx950:
+//   * L1 + SSIM(11x11 Gaussian window, sigma 1.5, zero padding) loss, forward and backward
+//     [REF utils/loss_utils.py:54-100, train.py:105-108].  One workgroup = one 32x32 tile of one
+//     channel: halo staged in LDS once, separable 11-tap horizontal then vertical pass, all five
+//     (forward) / three (backward) filtered maps produced from that one staging -- instead of five
+//     depthwise conv2d launches each round-tripping [3,H,W] through HBM.
+//   * Adam step [REF scene/gaussian_model.py:472 (eps=1e-15), train.py:196-197] that also zeroes the
+//     gradient it consumed (the flat gradient bucket is reused by the next step).
+#include "gp_common.h"
+#include "loss_adam_kernels.h"
+
+#define LT 32              // output tile edge
+#define LH 5               // window half width
+#define LE (LT + 2 * LH)   // staged tile edge (42)
+#define LP (LE + 1)        // padded LDS row
+
+struct Win11 { float w[11]; };
+
+__device__ __forceinline__ float block_sum_256(float v, float* s_red) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) s_red[wave] = v;
+    __syncthreads();
+    return s_red[0] + s_red[1] + s_red[2] + s_red[3];
+}
+
+// forward: sums[0] += sum |a-b| ; sums[1] += sum ssim_map ; optional derivative maps
+// dmap[0] = d ssim / d conv(a), dmap[1] = d ssim / d conv(a^2), dmap[2] = d ssim / d conv(a b)
+__global__ __launch_bounds__(256) void gp_l1_ssim_fwd_kernel(const float* __restrict__ img, const float* __restrict__ gt,
+                                                            int H, int W, Win11 win, double* __restrict__ sums,
+                                                            float* __restrict__ dmap) {
+    __shared__ float s_a[LE][LP], s_b[LE][LP];
+    __shared__ float s_h[5][LE][LT];
+    __shared__ float s_red[4];
+    const int tid = threadIdx.x;
+    const int tx0 = blockIdx.x * LT, ty0 = blockIdx.y * LT, ch = blockIdx.z;
+    const size_t HW = (size_t)H * W;
+    const float* a_img = img + ch * HW;
+    const float* b_img = gt + ch * HW;
+    for (int i = tid; i < LE * LE; i += 256) {
+        const int y = i / LE, x = i - y * LE;
+        const int gy = ty0 - LH + y, gx = tx0 - LH + x;
+        const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
+        s_a[y][x] = in ? a_img[(size_t)gy * W + gx] : 0.f;
+        s_b[y][x] = in ? b_img[(size_t)gy * W + gx] : 0.f;
+    }
+    __syncthreads();
+    for (int i = tid; i < LE * LT; i += 256) {
+        const int y = i / LT, x = i - y * LT;
+        float m1 = 0.f, m2 = 0.f, aa = 0.f, bb = 0.f, ab = 0.f;
+#pragma unroll
+        for (int k = 0; k < 11; ++k) {
+            const float a = s_a[y][x + k], b = s_b[y][x + k], w = win.w[k];
+            m1 = fmaf(w, a, m1); m2 = fmaf(w, b, m2);
+            aa = fmaf(w, a * a, aa); bb = fmaf(w, b * b, bb); ab = fmaf(w, a * b, ab);
+        }
+        s_h[0][y][x] = m1; s_h[1][y][x] = m2; s_h[2][y][x] = aa; s_h[3][y][x] = bb; s_h[4][y][x] = ab;
+    }
+    __syncthreads();
+    float l1 = 0.f, ss = 0.f;
+    const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
+    for (int i = tid; i < LT * LT; i += 256) {
+        const int y = i / LT, x = i - y * LT;
+        const int gy = ty0 + y, gx = tx0 + x;
+        if (gy >= H || gx >= W) continue;
+        float mu1 = 0.f, mu2 = 0.f, aa = 0.f, bb = 0.f, ab = 0.f;
+#pragma unroll
+        for (int k = 0; k < 11; ++k) {
+            const float w = win.w[k];
+            mu1 = fmaf(w, s_h[0][y + k][x], mu1); mu2 = fmaf(w, s_h[1][y + k][x], mu2);
+            aa = fmaf(w, s_h[2][y + k][x], aa); bb = fmaf(w, s_h[3][y + k][x], bb); ab = fmaf(w, s_h[4][y + k][x], ab);
+        }
+        const float mu1s = mu1 * mu1, mu2s = mu2 * mu2, mu12 = mu1 * mu2;
+        const float s11 = aa - mu1s, s22 = bb - mu2s, s12 = ab - mu12;
+        const float N1 = 2.f * mu12 + C1, N2 = 2.f * s12 + C2, D1 = mu1s + mu2s + C1, D2 = s11 + s22 + C2;
+        const float inv = 1.f / (D1 * D2);
+        const float ssim = N1 * N2 * inv;
+        ss += ssim;
+        l1 += fabsf(s_a[y + LH][x + LH] - s_b[y + LH][x + LH]);
+        if (dmap) {
+            const size_t o = ch * HW + (size_t)gy * W + gx;
+            // d/dmu1 (total, through s11 = aa - mu1^2 and s12 = ab - mu1 mu2)
+            const float dmu1 = (2.f * mu2 * N2 - 2.f * mu2 * N1) * inv - ssim * (2.f * mu1 * D2 - 2.f * mu1 * D1) * inv;
+            dmap[o] = dmu1;
+            dmap[3 * HW + o] = -ssim / D2;        // d/d conv(a^2)
+            dmap[6 * HW + o] = 2.f * N1 * inv;    // d/d conv(a b)
+        }
+    }
+    const float l1_tot = block_sum_256(l1, s_red);
+    __syncthreads();
+    const float ss_tot = block_sum_256(ss, s_red);
+    if (tid == 0) {
+        atomicAdd(&sums[0], (double)l1_tot);
+        atomicAdd(&sums[1], (double)ss_tot);
+    }
+}
+
+// backward: dimg = g * [ (1-lam)/n sign(a-b) - lam/n ( conv(dA) + 2 a conv(dB) + b conv(dC) ) ]
+__global__ __launch_bounds__(256) void gp_l1_ssim_bwd_kernel(const float* __restrict__ img, const float* __restrict__ gt,
+                                                            const float* __restrict__ dmap, int H, int W, Win11 win,
+                                                            float lambda, const float* __restrict__ upstream,
+                                                            float* __restrict__ dimg) {
+    __shared__ float s_m[3][LE][LP];
+    __shared__ float s_h[3][LE][LT];
+    const int tid = threadIdx.x;
+    const int tx0 = blockIdx.x * LT, ty0 = blockIdx.y * LT, ch = blockIdx.z;
+    const size_t HW = (size_t)H * W;
+    for (int i = tid; i < LE * LE; i += 256) {
+        const int y = i / LE, x = i - y * LE;
+        const int gy = ty0 - LH + y, gx = tx0 - LH + x;
+        const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
+        const size_t o = ch * HW + (size_t)(in ? gy : 0) * W + (in ? gx : 0);
+        s_m[0][y][x] = in ? dmap[o] : 0.f;
+        s_m[1][y][x] = in ? dmap[3 * HW + o] : 0.f;
+        s_m[2][y][x] = in ? dmap[6 * HW + o] : 0.f;
+    }
+    __syncthreads();
+    for (int i = tid; i < LE * LT; i += 256) {
+        const int y = i / LT, x = i - y * LT;
+        float h0 = 0.f, h1 = 0.f, h2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < 11; ++k) {
+            const float w = win.w[k];
+            h0 = fmaf(w, s_m[0][y][x + k], h0); h1 = fmaf(w, s_m[1][y][x + k], h1); h2 = fmaf(w, s_m[2][y][x + k], h2);
+        }
+        s_h[0][y][x] = h0; s_h[1][y][x] = h1; s_h[2][y][x] = h2;
+    }
+    __syncthreads();
+    const float g = upstream ? upstream[0] : 1.f;
+    const float inv_n = 1.f / (3.f * (float)HW);
+    for (int i = tid; i < LT * LT; i += 256) {
+        const int y = i / LT, x = i - y * LT;
+        const int gy = ty0 + y, gx = tx0 + x;
+        if (gy >= H || gx >= W) continue;
+        float c0 = 0.f, c1 = 0.f, c2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < 11; ++k) {
+            const float w = win.w[k];
+            c0 = fmaf(w, s_h[0][y + k][x], c0); c1 = fmaf(w, s_h[1][y + k][x], c1); c2 = fmaf(w, s_h[2][y + k][x], c2);
+        }
+        const size_t o = ch * HW + (size_t)gy * W + gx;
+        const float a = img[o], b = gt[o];
+        const float d = a - b;
+        const float sgn = (d > 0.f) ? 1.f : ((d < 0.f) ? -1.f : 0.f);
+        dimg[o] = g * inv_n * ((1.f - lambda) * sgn - lambda * (c0 + 2.f * a * c1 + b * c2));
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Adam (torch.optim.Adam semantics, amsgrad=False, weight_decay=0) + gradient zeroing
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gp_adam_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
+                                                     float* __restrict__ v, size_t n, float lr, float b1, float b2, float eps,
+                                                     float bc1, float bc2_sqrt, int zero_grad) {
+    size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i + 3 < n) {
+        float4 pv = *(float4*)(p + i), gv = *(float4*)(g + i), mv = *(float4*)(m + i), vv = *(float4*)(v + i);
+        float* pp = (float*)&pv; float* gg = (float*)&gv; float* mm = (float*)&mv; float* vq = (float*)&vv;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            mm[k] = b1 * mm[k] + (1.f - b1) * gg[k];
+            vq[k] = b2 * vq[k] + (1.f - b2) * gg[k] * gg[k];
+            const float denom = sqrtf(vq[k]) / bc2_sqrt + eps;
+            pp[k] -= (lr / bc1) * (mm[k] / denom);
+        }
+        *(float4*)(p + i) = pv; *(float4*)(m + i) = mv; *(float4*)(v + i) = vv;
+        if (zero_grad) *(float4*)(g + i) = make_float4(0.f, 0.f, 0.f, 0.f);
+    } else {
+        for (; i < n; ++i) {
+            const float gk = g[i];
+            const float mk = b1 * m[i] + (1.f - b1) * gk;
+            const float vk = b2 * v[i] + (1.f - b2) * gk * gk;
+            const float denom = sqrtf(vk) / bc2_sqrt + eps;
+            p[i] -= (lr / bc1) * (mk / denom);
+            m[i] = mk; v[i] = vk;
+            if (zero_grad) g[i] = 0.f;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------------
+static Win11 make_window() {
+    // [REF utils/loss_utils.py:60-62]: exp(-(x - 5)^2 / (2 * 1.5^2)), normalised
+    Win11 w;
+    double s = 0.0, t[11];
+    for (int x = 0; x < 11; ++x) { t[x] = exp(-(double)((x - 5) * (x - 5)) / (2.0 * 1.5 * 1.5)); s += (float)t[x]; }
+    for (int x = 0; x < 11; ++x) w.w[x] = (float)((float)t[x] / (float)s);
+    return w;
+}
+
+extern "C" int gp_loss_l1_ssim_forward(const float* img, const float* gt, int32_t channels, int32_t H, int32_t W, double* sums,
+                                       float* dmaps, gp_stream_t stream_) {
+    hipStream_t s = (hipStream_t)stream_;
+    if (!img || !gt || !sums) GP_FAIL("null argument");
+    if (channels != 3 || H <= 0 || W <= 0) GP_FAIL("expects a [3,H,W] image (got C=%d H=%d W=%d)", channels, H, W);
+    GP_HIP_CHECK(hipMemsetAsync(sums, 0, 2 * sizeof(double), s));
+    GpProfScope _p("l1_ssim_fwd", s);
+    hipLaunchKernelGGL(gp_l1_ssim_fwd_kernel, dim3((W + LT - 1) / LT, (H + LT - 1) / LT, 3), dim3(256), 0, s, img, gt, H, W,
+                       make_window(), sums, dmaps);
+    GP_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int gp_loss_l1_ssim_backward(const float* img, const float* gt, const float* dmaps, int32_t channels, int32_t H,
+                                        int32_t W, float lambda_dssim, const float* upstream, float* dimg, gp_stream_t stream_) {
+    hipStream_t s = (hipStream_t)stream_;
+    if (!img || !gt || !dmaps || !dimg) GP_FAIL("null argument");
+    if (channels != 3 || H <= 0 || W <= 0) GP_FAIL("expects a [3,H,W] image");
+    GpProfScope _p("l1_ssim_bwd", s);
+    hipLaunchKernelGGL(gp_l1_ssim_bwd_kernel, dim3((W + LT - 1) / LT, (H + LT - 1) / LT, 3), dim3(256), 0, s, img, gt, dmaps, H, W,
+                       make_window(), lambda_dssim, upstream, dimg);
+    GP_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int gp_adam_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
+                            float beta2, float eps, int64_t step, int32_t zero_grad, gp_stream_t stream_) {
+    hipStream_t s = (hipStream_t)stream_;
+    if (n < 0 || step < 1) GP_FAIL("bad n/step");
+    if (n == 0) return 0;
+    if (!param || !grad || !exp_avg || !exp_avg_sq) GP_FAIL("null argument");
+    if ((((uintptr_t)param | (uintptr_t)grad | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) != 0) GP_FAIL("adam: pointers must be 16-byte aligned");
+    const float bc1 = 1.f - powf(beta1, (float)step);
+    const float bc2_sqrt = sqrtf(1.f - powf(beta2, (float)step));
+    GpProfScope _p("adam", s);
+    hipLaunchKernelGGL(gp_adam_kernel, dim3(gp_blocks(((size_t)n + 3) / 4, 256)), dim3(256), 0, s, param, grad, exp_avg, exp_avg_sq,
+                       (size_t)n, lr, beta1, beta2, eps, bc1, bc2_sqrt, zero_grad);
+    GP_LAUNCH_CHECK();
+    return 0;
+}

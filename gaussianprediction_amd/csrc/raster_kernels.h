@@ -63,6 +63,48 @@ __global__ __launch_bounds__(64) void gp_composite_bwd_kernel(RasterDims d, cons
                                                               float* __restrict__ g_opacity /*N*/,
                                                               float* __restrict__ g_color /*N,3*/,
                                                               float* __restrict__ g_depth /*N*/);
+__global__ __launch_bounds__(64) void gp_composite_bwd2_kernel(RasterDims d, const int2* __restrict__ ranges,
+                                                              const uint32_t* __restrict__ point_list,
+                                                              const float4* __restrict__ rec, const float* __restrict__ bg,
+                                                              const float* __restrict__ out_color,
+                                                              const float* __restrict__ out_depth,
+                                                              const float* __restrict__ final_T,
+                                                              const int32_t* __restrict__ n_contrib,
+                                                              const float* __restrict__ dL_dpix,
+                                                              const float* __restrict__ dL_dpixdepth,
+                                                              float* __restrict__ g_mean2D /*N,2*/,
+                                                              float* __restrict__ g_conic /*N,3*/,
+                                                              float* __restrict__ g_opacity /*N*/,
+                                                              float* __restrict__ g_color /*N,3*/,
+                                                              float* __restrict__ g_depth /*N*/);
+__global__ __launch_bounds__(64) void gp_composite_bwd2_depth_kernel(RasterDims d, const int2* __restrict__ ranges,
+                                                              const uint32_t* __restrict__ point_list,
+                                                              const float4* __restrict__ rec, const float* __restrict__ bg,
+                                                              const float* __restrict__ out_color,
+                                                              const float* __restrict__ out_depth,
+                                                              const float* __restrict__ final_T,
+                                                              const int32_t* __restrict__ n_contrib,
+                                                              const float* __restrict__ dL_dpix,
+                                                              const float* __restrict__ dL_dpixdepth,
+                                                              float* __restrict__ g_mean2D /*N,2*/,
+                                                              float* __restrict__ g_conic /*N,3*/,
+                                                              float* __restrict__ g_opacity /*N*/,
+                                                              float* __restrict__ g_color /*N,3*/,
+                                                              float* __restrict__ g_depth /*N*/);
+__global__ __launch_bounds__(64) void gp_composite_bwd_noatomic_kernel(RasterDims d, const int2* __restrict__ ranges,
+                                                              const uint32_t* __restrict__ point_list,
+                                                              const float4* __restrict__ rec, const float* __restrict__ bg,
+                                                              const float* __restrict__ out_color,
+                                                              const float* __restrict__ out_depth,
+                                                              const float* __restrict__ final_T,
+                                                              const int32_t* __restrict__ n_contrib,
+                                                              const float* __restrict__ dL_dpix,
+                                                              const float* __restrict__ dL_dpixdepth,
+                                                              float* __restrict__ g_mean2D /*N,2*/,
+                                                              float* __restrict__ g_conic /*N,3*/,
+                                                              float* __restrict__ g_opacity /*N*/,
+                                                              float* __restrict__ g_color /*N,3*/,
+                                                              float* __restrict__ g_depth /*N*/);
 
 __global__ __launch_bounds__(256) void gp_preprocess_bwd_kernel(
     RasterDims d, const float* __restrict__ means3D, const float* __restrict__ scales, const float* __restrict__ rotations,

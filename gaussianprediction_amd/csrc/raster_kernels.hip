@@ -449,7 +449,8 @@ __device__ __forceinline__ float wave_incl_sum(float x, int lane) {
     return x;
 }
 
-__global__ __launch_bounds__(64) void gp_composite_bwd_kernel(RasterDims d, const int2* __restrict__ ranges,
+template <bool NOATOMIC>
+__device__ __forceinline__ void gp_composite_bwd_kernel_t(RasterDims d, const int2* __restrict__ ranges,
                                                               const uint32_t* __restrict__ point_list,
                                                               const float4* __restrict__ rec, const float* __restrict__ bg,
                                                               const float* __restrict__ out_color,
@@ -557,7 +558,9 @@ __global__ __launch_bounds__(64) void gp_composite_bwd_kernel(RasterDims d, cons
                 s_pb[p] = pb;
             }
         }
-        if (have) {
+        if (NOATOMIC) {
+            if (have && a_mx == 123.456f) g_depth[id] = a_mx + a_my + a_ca + a_cb + a_cc + a_op + a_r + a_g + a_b + a_d;
+        } else if (have) {
             atomicAdd(&g_mean2D[2 * (size_t)id], a_mx * halfW);
             atomicAdd(&g_mean2D[2 * (size_t)id + 1], a_my * halfH);
             atomicAdd(&g_conic[3 * (size_t)id], -0.5f * a_ca);
@@ -572,6 +575,187 @@ __global__ __launch_bounds__(64) void gp_composite_bwd_kernel(RasterDims d, cons
         __syncthreads();  // single wave: orders the s_pb updates before the next batch reads them
     }
 }
+
+
+// ---- v2: DPP wave scans (no LDS round trips), two horizontally adjacent pixels per iteration with
+// 2-wide vector arithmetic (v_pk_*_f32), all-idle pixel pairs skipped, atomics only for splats that
+// contributed inside this tile part, depth-gradient path compiled out when dL_ddepth is NULL.
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef int v2i __attribute__((ext_vector_type(2)));
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_move(float old, float src) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(src), CTRL, ROW_MASK, 0xF, false));
+}
+// inclusive wave64 scans, the gfx9 DPP sequence: row_shr 1,2,4,8 then row_bcast15 (rows 1,3), row_bcast31 (rows 2,3)
+__device__ __forceinline__ float dpp_incl_prod(float v) {
+    v *= dpp_move<0x111, 0xF>(1.f, v);
+    v *= dpp_move<0x112, 0xF>(1.f, v);
+    v *= dpp_move<0x114, 0xF>(1.f, v);
+    v *= dpp_move<0x118, 0xF>(1.f, v);
+    v *= dpp_move<0x142, 0xA>(1.f, v);
+    v *= dpp_move<0x143, 0xC>(1.f, v);
+    return v;
+}
+__device__ __forceinline__ float dpp_incl_sum(float v) {
+    v += dpp_move<0x111, 0xF>(0.f, v);
+    v += dpp_move<0x112, 0xF>(0.f, v);
+    v += dpp_move<0x114, 0xF>(0.f, v);
+    v += dpp_move<0x118, 0xF>(0.f, v);
+    v += dpp_move<0x142, 0xA>(0.f, v);
+    v += dpp_move<0x143, 0xC>(0.f, v);
+    return v;
+}
+__device__ __forceinline__ float dpp_shift_right1(float v, float fill) { return dpp_move<0x138, 0xF>(fill, v); }  // wave_shr:1
+__device__ __forceinline__ float lane63(float v) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63)); }
+
+template <bool HAS_DEPTH>
+__device__ __forceinline__ void gp_composite_bwd2_body(RasterDims d, const int2* __restrict__ ranges,
+                                                       const uint32_t* __restrict__ point_list, const float4* __restrict__ rec,
+                                                       const float* __restrict__ bg, const float* __restrict__ out_color,
+                                                       const float* __restrict__ out_depth, const float* __restrict__ final_T,
+                                                       const int32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpix,
+                                                       const float* __restrict__ dL_dpixdepth, float* __restrict__ g_mean2D,
+                                                       float* __restrict__ g_conic, float* __restrict__ g_opacity,
+                                                       float* __restrict__ g_color, float* __restrict__ g_depth) {
+    __shared__ float4 s_pa[CB_PIX];   // dLr, dLg, dLb, dLd
+    __shared__ float4 s_pb[CB_PIX];   // Tot, Tfinal*bg.dLp, T_in, P_in
+    __shared__ int s_nc[CB_PIX];
+    const int parts = GP_TILE / CB_ROWS;
+    const int tile = blockIdx.x / parts, part = blockIdx.x % parts;
+    const int tx = tile % d.gx, ty = tile / d.gx;
+    const int lane = threadIdx.x;
+    const int2 range = ranges[tile];
+    const size_t HW = (size_t)d.H * d.W;
+    const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
+    int max_nc = 0;
+    for (int p = lane; p < CB_PIX; p += 64) {
+        const int px = tx * GP_TILE + (p & 15), py = ty * GP_TILE + part * CB_ROWS + (p >> 4);
+        float4 pa = make_float4(0.f, 0.f, 0.f, 0.f), pb = make_float4(0.f, 0.f, 1.f, 0.f);
+        int nc = 0;
+        if (px < d.W && py < d.H) {
+            const size_t pix = (size_t)py * d.W + px;
+            pa.x = dL_dpix[pix]; pa.y = dL_dpix[HW + pix]; pa.z = dL_dpix[2 * HW + pix];
+            pa.w = HAS_DEPTH ? dL_dpixdepth[pix] : 0.f;
+            const float Tf = final_T[pix];
+            pb.y = Tf * (bg0 * pa.x + bg1 * pa.y + bg2 * pa.z);
+            pb.x = out_color[pix] * pa.x + out_color[HW + pix] * pa.y + out_color[2 * HW + pix] * pa.z - pb.y;
+            if (HAS_DEPTH) pb.x += out_depth[pix] * pa.w;
+            nc = n_contrib[pix];
+        }
+        s_pa[p] = pa; s_pb[p] = pb; s_nc[p] = nc;
+        max_nc = max(max_nc, nc);
+    }
+#pragma unroll
+    for (int dd = 32; dd >= 1; dd >>= 1) max_nc = max(max_nc, __shfl_xor(max_nc, dd));
+    __syncthreads();
+    const float halfW = 0.5f * (float)d.W, halfH = 0.5f * (float)d.H;
+    const int count = min(range.y - range.x, max_nc);
+    const float px_base = (float)(tx * GP_TILE), py_base = (float)(ty * GP_TILE + part * CB_ROWS);
+    for (int b0 = 0; b0 < count; b0 += 64) {
+        const int pos = b0 + lane;
+        const bool have = pos < count;
+        uint32_t id = 0;
+        float4 q0 = make_float4(0.f, 0.f, 0.f, 0.f), q1 = q0, q2 = q0;
+        if (have) {
+            id = point_list[range.x + pos];
+            q0 = rec[3 * (size_t)id]; q1 = rec[3 * (size_t)id + 1]; q2 = rec[3 * (size_t)id + 2];
+        }
+        const float sx = q0.x - px_base, sy = q0.y - py_base;
+        const float A = q0.z, B = q0.w, Cq = q1.x, op = q1.y, zdep = q1.z;
+        const float cxx = -2.f * A, cxy = -B, cyy = -2.f * Cq;
+        v2f a_mx = {0.f, 0.f}, a_my = {0.f, 0.f}, a_ca = {0.f, 0.f}, a_cb = {0.f, 0.f}, a_cc = {0.f, 0.f}, a_op = {0.f, 0.f},
+            a_r = {0.f, 0.f}, a_g = {0.f, 0.f}, a_b = {0.f, 0.f}, a_d = {0.f, 0.f};
+        bool any_c = false;
+#pragma unroll 1
+        for (int row = 0; row < CB_ROWS; ++row) {
+            const float dy = sy - (float)row;
+            const float tB = B * dy, uC = (Cq * dy) * dy;
+#pragma unroll 1
+            for (int col = 0; col < GP_TILE; col += 2) {
+                const int p = row * GP_TILE + col;
+                const int nc0 = s_nc[p], nc1 = s_nc[p + 1];
+                if (max(nc0, nc1) <= b0) continue;   // uniform: both pixels finished before this batch
+                const float dx0 = sx - (float)col;
+                const v2f dx = {dx0, dx0 - 1.f};
+                v2f power;
+                power.x = fmaf(dx.x, fmaf(A, dx.x, tB), uC);
+                power.y = fmaf(dx.y, fmaf(A, dx.y, tB), uC);
+                v2f G;
+                G.x = gp_exp(fminf(power.x, 0.f));
+                G.y = gp_exp(fminf(power.y, 0.f));
+                const v2f alpha = {fminf(0.99f, op * G.x), fminf(0.99f, op * G.y)};
+                const bool c0 = have && (pos < nc0) && !(power.x > 0.f) && !(alpha.x < 1.f / 255.f);
+                const bool c1 = have && (pos < nc1) && !(power.y > 0.f) && !(alpha.y < 1.f / 255.f);
+                if (!__any(c0 || c1)) continue;      // nobody in the wave touches either pixel
+                any_c = any_c || c0 || c1;
+                const v2f om = {c0 ? 1.f - alpha.x : 1.f, c1 ? 1.f - alpha.y : 1.f};
+                const float4 pa0 = s_pa[p], pa1 = s_pa[p + 1];
+                float4 pb0 = s_pb[p], pb1 = s_pb[p + 1];
+                v2f incl = {dpp_incl_prod(om.x), dpp_incl_prod(om.y)};
+                const v2f Tin = {pb0.z, pb1.z};
+                const v2f Tj = {Tin.x * dpp_shift_right1(incl.x, 1.f), Tin.y * dpp_shift_right1(incl.y, 1.f)};
+                v2f cdot;
+                cdot.x = fmaf(q2.x, pa0.x, fmaf(q2.y, pa0.y, q2.z * pa0.z));
+                cdot.y = fmaf(q2.x, pa1.x, fmaf(q2.y, pa1.y, q2.z * pa1.z));
+                if (HAS_DEPTH) { cdot.x = fmaf(zdep, pa0.w, cdot.x); cdot.y = fmaf(zdep, pa1.w, cdot.y); }
+                const v2f w = {c0 ? alpha.x * Tj.x : 0.f, c1 ? alpha.y * Tj.y : 0.f};
+                const v2f sv = w * cdot;
+                const v2f psum = {dpp_incl_sum(sv.x), dpp_incl_sum(sv.y)};
+                // masked lanes have w = 0 and om = 1: every product below vanishes without branching
+                const v2f tot = {pb0.x - pb0.w, pb1.x - pb1.w};
+                const v2f tb = {pb0.y, pb1.y};
+                const v2f rom = {__builtin_amdgcn_rcpf(om.x), __builtin_amdgcn_rcpf(om.y)};
+                const v2f suffix = tot - psum;
+                v2f dL_dalpha = Tj * cdot - (suffix + tb) * rom;
+                dL_dalpha.x = c0 ? dL_dalpha.x : 0.f;
+                dL_dalpha.y = c1 ? dL_dalpha.y : 0.f;
+                const v2f dLr = {pa0.x, pa1.x}, dLg = {pa0.y, pa1.y}, dLb = {pa0.z, pa1.z};
+                a_r += w * dLr; a_g += w * dLg; a_b += w * dLb;
+                if (HAS_DEPTH) { const v2f dLd = {pa0.w, pa1.w}; a_d += w * dLd; }
+                a_op += G * dL_dalpha;
+                const v2f dL_dG = op * dL_dalpha;
+                const v2f gdx = G * dx, gdy = G * dy;
+                a_mx += dL_dG * (-gdx * cxx - gdy * cxy);
+                a_my += dL_dG * (-gdy * cyy - gdx * cxy);
+                a_ca += (gdx * dx) * dL_dG;
+                a_cb += (gdx * dy) * dL_dG;
+                a_cc += (gdy * dy) * dL_dG;
+                // carry to the next batch
+                const float tp0 = lane63(incl.x), tp1 = lane63(incl.y), ts0 = lane63(psum.x), ts1 = lane63(psum.y);
+                if (lane == 0) {
+                    pb0.z *= tp0; pb0.w += ts0; pb1.z *= tp1; pb1.w += ts1;
+                    s_pb[p] = pb0; s_pb[p + 1] = pb1;
+                }
+            }
+        }
+        if (have && any_c) {
+            atomicAdd(&g_mean2D[2 * (size_t)id], (a_mx.x + a_mx.y) * halfW);
+            atomicAdd(&g_mean2D[2 * (size_t)id + 1], (a_my.x + a_my.y) * halfH);
+            atomicAdd(&g_conic[3 * (size_t)id], -0.5f * (a_ca.x + a_ca.y));
+            atomicAdd(&g_conic[3 * (size_t)id + 1], -(a_cb.x + a_cb.y));
+            atomicAdd(&g_conic[3 * (size_t)id + 2], -0.5f * (a_cc.x + a_cc.y));
+            atomicAdd(&g_opacity[id], a_op.x + a_op.y);
+            atomicAdd(&g_color[3 * (size_t)id], a_r.x + a_r.y);
+            atomicAdd(&g_color[3 * (size_t)id + 1], a_g.x + a_g.y);
+            atomicAdd(&g_color[3 * (size_t)id + 2], a_b.x + a_b.y);
+            if (HAS_DEPTH) atomicAdd(&g_depth[id], a_d.x + a_d.y);
+        }
+        __syncthreads();
+    }
+}
+
+#define CB_ARGS RasterDims d, const int2* __restrict__ ranges, const uint32_t* __restrict__ point_list, \
+    const float4* __restrict__ rec, const float* __restrict__ bg, const float* __restrict__ out_color, \
+    const float* __restrict__ out_depth, const float* __restrict__ final_T, const int32_t* __restrict__ n_contrib, \
+    const float* __restrict__ dL_dpix, const float* __restrict__ dL_dpixdepth, float* __restrict__ g_mean2D, \
+    float* __restrict__ g_conic, float* __restrict__ g_opacity, float* __restrict__ g_color, float* __restrict__ g_depth
+#define CB_PASS d, ranges, point_list, rec, bg, out_color, out_depth, final_T, n_contrib, dL_dpix, dL_dpixdepth, g_mean2D, \
+    g_conic, g_opacity, g_color, g_depth
+__global__ __launch_bounds__(64) void gp_composite_bwd_kernel(CB_ARGS) { gp_composite_bwd_kernel_t<false>(CB_PASS); }
+__global__ __launch_bounds__(64) void gp_composite_bwd_noatomic_kernel(CB_ARGS) { gp_composite_bwd_kernel_t<true>(CB_PASS); }
+__global__ __launch_bounds__(64) void gp_composite_bwd2_kernel(CB_ARGS) { gp_composite_bwd2_body<false>(CB_PASS); }
+__global__ __launch_bounds__(64) void gp_composite_bwd2_depth_kernel(CB_ARGS) { gp_composite_bwd2_body<true>(CB_PASS); }
 
 // ------------------------------------------------------------------------------------------------
 // preprocess backward (per Gaussian) -- mirrors gpo_preprocess_bwd of the oracle

@@ -16,24 +16,24 @@ class FlatGradBucket:
 
     def __init__(self, params):
         self.params = [p for p in params if p.requires_grad]
-        n = sum(p.numel() for p in self.params)
+        self.offsets = []
+        n = 0
+        for p in self.params:                       # 64-element (256 B) aligned segments
+            self.offsets.append(n)
+            n += (p.numel() + 63) // 64 * 64
         dev = self.params[0].device
         self.flat = torch.zeros(n, dtype=torch.float32, device=dev)
-        off = 0
-        for p in self.params:
+        for p, off in zip(self.params, self.offsets):
             p.grad = self.flat[off:off + p.numel()].view_as(p)
-            off += p.numel()
 
     def zero(self):
         self.flat.zero_()
 
     def rebind(self):
         """Re-attach views (needed if something replaced .grad, e.g. zero_grad(set_to_none=True))."""
-        off = 0
-        for p in self.params:
+        for p, off in zip(self.params, self.offsets):
             if p.grad is None or p.grad.data_ptr() != self.flat[off:off + 1].data_ptr():
                 p.grad = self.flat[off:off + p.numel()].view_as(p)
-            off += p.numel()
 
     def all_reduce_sum(self, group=None, async_op=False):
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:

@@ -1,0 +1,93 @@
+"""Fused L1 + SSIM loss and Adam step on libgp_hip.so.
+
+  loss = (1 - lambda) * L1(image, gt) + lambda * (1 - SSIM(image, gt))        [REF train.py:105-108]
+with the reference's 11x11 Gaussian-window SSIM [REF utils/loss_utils.py:54-100], and
+torch.optim.Adam(eps=1e-15) semantics per parameter group [REF scene/gaussian_model.py:394-472].
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib
+
+
+class L1SSIMLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, image, gt, lambda_dssim):
+        if not image.is_cuda:
+            raise RuntimeError("L1SSIMLoss: HIP kernels only (no CPU fallback)")
+        dev = image.device
+        img = image.detach().to(torch.float32).contiguous()
+        g = gt.detach().to(torch.float32).contiguous()
+        if img.dim() != 3 or img.shape[0] != 3 or g.shape != img.shape:
+            raise RuntimeError("L1SSIMLoss expects two [3,H,W] images")
+        _, H, W = img.shape
+        sums = torch.empty(2, dtype=torch.float64, device=dev)
+        need = image.requires_grad
+        dmaps = torch.empty(3, 3, H, W, device=dev) if need else None
+        with torch.cuda.device(dev):
+            rc = _lib.lib().gp_loss_l1_ssim_forward(_lib.ptr(img), _lib.ptr(g), C.c_int32(3), C.c_int32(H), C.c_int32(W),
+                                                    _lib.ptr(sums), _lib.ptr(dmaps), _lib.stream_ptr(dev))
+            _lib.check(rc, "gp_loss_l1_ssim_forward")
+        n = 3.0 * H * W
+        lam = float(lambda_dssim)
+        loss = ((1.0 - lam) * sums[0] / n + lam * (1.0 - sums[1] / n)).to(torch.float32)
+        if need:
+            ctx.save_for_backward(img, g, dmaps)
+            ctx.lam = lam
+        return loss
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        img, g, dmaps = ctx.saved_tensors
+        dev = img.device
+        _, H, W = img.shape
+        up = grad_out.detach().to(torch.float32).reshape(1).contiguous()
+        dimg = torch.empty_like(img)
+        with torch.cuda.device(dev):
+            rc = _lib.lib().gp_loss_l1_ssim_backward(_lib.ptr(img), _lib.ptr(g), _lib.ptr(dmaps), C.c_int32(3), C.c_int32(H),
+                                                     C.c_int32(W), C.c_float(ctx.lam), _lib.ptr(up), _lib.ptr(dimg),
+                                                     _lib.stream_ptr(dev))
+            _lib.check(rc, "gp_loss_l1_ssim_backward")
+        return dimg, None, None
+
+
+def l1_ssim_loss(image, gt, lambda_dssim=0.2):
+    return L1SSIMLoss.apply(image, gt, lambda_dssim)
+
+
+class FusedAdam:
+    """Adam over the segments of a FlatGradBucket: one HIP launch per parameter tensor, gradient zeroed
+    in the same pass.  State layout mirrors torch.optim.Adam (exp_avg, exp_avg_sq, step)."""
+
+    def __init__(self, param_groups, bucket, betas=(0.9, 0.999), eps=1e-15):
+        self.param_groups = param_groups
+        self.bucket = bucket
+        self.betas, self.eps = betas, eps
+        self.step_count = 0
+        off_of = {id(p): off for p, off in zip(bucket.params, bucket.offsets)}
+        self.items = []
+        for g in param_groups:
+            for p in g["params"]:
+                if not p.requires_grad:
+                    continue
+                if not p.is_contiguous():
+                    raise RuntimeError("FusedAdam needs contiguous parameters")
+                self.items.append((g, p, off_of[id(p)], torch.zeros_like(p), torch.zeros_like(p)))
+
+    def step(self, zero_grad=True):
+        self.step_count += 1
+        L = _lib.lib()
+        b1, b2 = self.betas
+        flat = self.bucket.flat
+        dev = flat.device
+        with torch.cuda.device(dev):
+            st = _lib.stream_ptr(dev)
+            for g, p, off, m, v in self.items:
+                gptr = C.c_void_p(flat.data_ptr() + 4 * off)
+                rc = L.gp_adam_step(C.c_void_p(p.data_ptr()), gptr, _lib.ptr(m), _lib.ptr(v), C.c_int64(p.numel()),
+                                    C.c_float(g["lr"]), C.c_float(b1), C.c_float(b2), C.c_float(self.eps),
+                                    C.c_int64(self.step_count), C.c_int32(1 if zero_grad else 0), st)
+                _lib.check(rc, "gp_adam_step")

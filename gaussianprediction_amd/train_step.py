@@ -1,9 +1,9 @@
 """Train-step harness: what the reference's loop does around the hot
 path for one iteration [REF train.py:101-133, 196-197]:
     render -> 0.8*L1 + 0.2*(1-SSIM_11x11) + 1e-5*mean|motion feature| -> backward -> Adam(eps=1e-15).
-The render + deformation forward/backward are this package's HIP kernels.  The loss and the optimizer
-are plain torch ops here: they are the "next" rows of SURVEY section 8(f) (fused L1+SSIM, fused Adam),
-not yet hot-path rows.
+Render, deformation, loss (fused L1+SSIM) and optimizer (fused Adam + gradient zeroing) all run on
+this package's HIP kernels; `fused=False` switches loss and optimizer to the plain-torch restatement of
+the reference (used by the tests as the checker).
 """
 from __future__ import annotations
 
@@ -13,6 +13,7 @@ import torch
 import torch.nn.functional as F
 
 from .dist import FlatGradBucket
+from .loss_ops import FusedAdam, l1_ssim_loss
 from .renderer import render
 
 
@@ -44,14 +45,17 @@ def ssim(img1, img2, window):            # [REF utils/loss_utils.py:70-100]
 class TrainStep:
     """One optimisation step over one view per rank (view-parallel when world_size > 1)."""
 
-    def __init__(self, pc, cameras, gt_images, iteration, lambda_dssim=0.2, lrs=None, group=None):
+    def __init__(self, pc, cameras, gt_images, iteration, lambda_dssim=0.2, lrs=None, group=None, fused=True):
         self.pc, self.cameras, self.gt, self.iteration = pc, cameras, gt_images, iteration
         self.lambda_dssim = lambda_dssim
         self.group = group
+        self.fused = fused
         dev = pc.get_xyz.device
         self.bg = torch.zeros(3, device=dev)          # black background [REF train.py:59]
         self.pipe = SimpleNamespace(convert_SHs_python=False, compute_cov3D_python=False, debug=False)
         self.window = _gauss_window(3, dev)
+        # camera times live on the device: a per-step H2D copy from pageable memory would be a host sync
+        self.times = [torch.from_numpy(c.time).to(torch.float32).to(dev) for c in cameras]
         lr = dict(xyz=1.6e-4, f_dc=2.5e-3, f_rest=2.5e-3 / 20, opacity=0.05, scaling=5e-3, rotation=1e-3, mfeature=8e-4,
                   kpts=8e-4, mlp=8e-4)              # [REF arguments/__init__.py:74-90]
         if lrs:
@@ -69,22 +73,31 @@ class TrainStep:
         if hasattr(pc, "super_gaussians"):
             groups += [{"params": [pc.super_gaussians], "lr": lr["kpts"], "name": "s_xyz"},
                        {"params": [pc.super_gaussians_feature], "lr": lr["mfeature"], "name": "s_motion_feature"}]
-        self.optimizer = torch.optim.Adam(groups, lr=0.0, eps=1e-15, foreach=True)   # [REF scene/gaussian_model.py:472]
         self.bucket = FlatGradBucket([p for g in groups for p in g["params"]])
+        if fused:
+            self.optimizer = FusedAdam(groups, self.bucket, eps=1e-15)
+        else:
+            self.optimizer = torch.optim.Adam(groups, lr=0.0, eps=1e-15, foreach=True)   # [REF scene/gaussian_model.py:472]
 
     def loss_of(self, image, gt):
-        Ll1 = l1_loss(image, gt)
-        loss = (1.0 - self.lambda_dssim) * Ll1 + self.lambda_dssim * (1.0 - ssim(image, gt, self.window))
+        if self.fused:
+            loss = l1_ssim_loss(image, gt, self.lambda_dssim)
+        else:
+            Ll1 = l1_loss(image, gt)
+            loss = (1.0 - self.lambda_dssim) * Ll1 + self.lambda_dssim * (1.0 - ssim(image, gt, self.window))
         return loss + self.pc.get_loss(self.iteration)
 
     def step(self, view_index: int):
         cam = self.cameras[view_index % len(self.cameras)]
         gt = self.gt[view_index % len(self.gt)]
-        time = torch.from_numpy(cam.time).to(torch.float32).to(self.bg.device)
+        time = self.times[view_index % len(self.cameras)]
         pkg = render(cam, self.pc, self.pipe, self.bg, time=time, it=self.iteration)
         loss = self.loss_of(pkg["render"], gt)
         loss.backward()
         self.bucket.all_reduce_sum(self.group)       # SUM over views == the reference's --batch semantics
-        self.optimizer.step()
-        self.bucket.zero()
+        if self.fused:
+            self.optimizer.step(zero_grad=True)
+        else:
+            self.optimizer.step()
+            self.bucket.zero()
         return loss.detach(), pkg

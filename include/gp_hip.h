@@ -191,6 +191,23 @@ int gp_activations_backward(int64_t n, const float* scaling_raw, const float* op
                             float* dL_dscaling_raw, float* dL_dopacity_raw, float* dL_ddelta_o /*[N,stride] col 0*/,
                             gp_stream_t stream);
 
+/* ---- loss + optimizer (the steps right after the render in every training iteration) ---------- */
+
+/* sums[0] = sum |img - gt|, sums[1] = sum of the SSIM map (11x11 Gaussian window, sigma 1.5, zero
+ * padding) over a [3,H,W] image pair [REF utils/loss_utils.py:54-100]; the caller forms
+ * (1-l) * sums[0]/n + l * (1 - sums[1]/n) [REF train.py:108].  dmaps (optional, [3,3,H,W]) receives the
+ * SSIM partial-derivative maps the backward needs. */
+int gp_loss_l1_ssim_forward(const float* img, const float* gt, int32_t channels, int32_t H, int32_t W, double* sums,
+                            float* dmaps, gp_stream_t stream);
+/* dimg = upstream[0] * d loss / d img  (upstream: device scalar, NULL = 1). */
+int gp_loss_l1_ssim_backward(const float* img, const float* gt, const float* dmaps, int32_t channels, int32_t H, int32_t W,
+                             float lambda_dssim, const float* upstream, float* dimg, gp_stream_t stream);
+
+/* torch.optim.Adam step (amsgrad off, no weight decay) on one flat tensor; optionally zeroes `grad`
+ * [REF scene/gaussian_model.py:472, train.py:196-197].  `step` is the 1-based step count. */
+int gp_adam_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1, float beta2,
+                 float eps, int64_t step, int32_t zero_grad, gp_stream_t stream);
+
 /* ---- measurement ----------------------------------------------------------------------------- */
 /* When enabled, the library brackets its kernels with hipEvent pairs recorded on the launch stream.
  * gp_profile_collect() waits for the recorded events and returns per-kernel launch counts and summed

@@ -57,17 +57,20 @@ def test_fused_pe_mlp_forward_backward(rows, F, out_dim):
     sd64 = {k: torch.tensor(v, dtype=torch.float64, requires_grad=True) for k, v in sd.items()}
     f64, x64 = feat.double().requires_grad_(True), xyz.double().requires_grad_(True)
     X = torch.cat([f64, do.positional_encoding(x64, 10), do.positional_encoding(t.double(), F).unsqueeze(0).repeat(rows, 1)], -1)
-    y64 = do.mlp_forward(sd64, X)
-    (y64 * gy.double()).sum().backward()
-    # rows with a hidden pre-activation within float32 rounding of 0 have an ill-defined ReLU mask
+    # rows with a hidden pre-activation within float32 rounding of 0 have an ill-defined ReLU mask:
+    # give them zero upstream gradient so they influence neither side
     with torch.no_grad():
         h, zmin = X, torch.full((rows,), 1e9, dtype=torch.float64)
         for i in range(4):
             z = torch.nn.functional.linear(h, sd64[f"mlp.{2 * i}.weight"], sd64[f"mlp.{2 * i}.bias"])
             zmin = torch.minimum(zmin, z.abs().min(dim=1).values)
             h = torch.relu(z)
-        ok = (zmin > 2e-6).numpy()
-    assert ok.mean() > 0.99
+        ok = (zmin > 1e-6)
+    assert ok.double().mean() > 0.95
+    gy = gy * ok[:, None].float()
+    ok = ok.numpy()
+    y64 = do.mlp_forward(sd64, X)
+    (y64 * gy.double()).sum().backward()
     # HIP
     fd, xd = feat.cuda().requires_grad_(True), xyz.cuda().requires_grad_(True)
     y = net.forward_fused(fd, xd, t.cuda(), 10, F)
@@ -75,9 +78,8 @@ def test_fused_pe_mlp_forward_backward(rows, F, out_dim):
     assert np.abs(y.detach().cpu().numpy() - y64.detach().numpy()).max() < 2e-5
     assert rel_l2(fd.grad.cpu().numpy()[ok], f64.grad.numpy()[ok]) < 1e-4
     assert rel_l2(xd.grad.cpu().numpy()[ok], x64.grad.numpy()[ok]) < 1e-4
-    wtol = 1e-4 if ok.all() else 1e-3
     for k, p in net.named_parameters():
-        assert rel_l2(p.grad.cpu().numpy(), sd64[k].grad.numpy()) < wtol, k
+        assert rel_l2(p.grad.cpu().numpy(), sd64[k].grad.numpy()) < 1e-4, k
 
 
 def _blend_inputs(N, K, nn_, out_dim, seed):
