@@ -29,7 +29,7 @@ class RasterSettingsC(C.Structure):
 
 
 class RasterInputsC(C.Structure):
-    _fields_ = [("num_gaussians", C.c_int64), ("means3D", C.c_void_p), ("shs", C.c_void_p),
+    _fields_ = [("num_gaussians", C.c_int64), ("means3D", C.c_void_p), ("shs", C.c_void_p), ("shs_rest", C.c_void_p),
                 ("colors_precomp", C.c_void_p), ("opacities", C.c_void_p), ("scales", C.c_void_p),
                 ("rotations", C.c_void_p), ("cov3D_precomp", C.c_void_p)]
 
@@ -46,7 +46,7 @@ class RasterSavedC(C.Structure):
 
 class RasterGradsC(C.Structure):
     _fields_ = [("dL_dmeans3D", C.c_void_p), ("dL_dmeans2D", C.c_void_p), ("dL_dshs", C.c_void_p),
-                ("dL_dcolors_precomp", C.c_void_p), ("dL_dopacities", C.c_void_p), ("dL_dscales", C.c_void_p),
+                ("dL_dshs_rest", C.c_void_p), ("dL_dcolors_precomp", C.c_void_p), ("dL_dopacities", C.c_void_p), ("dL_dscales", C.c_void_p),
                 ("dL_drotations", C.c_void_p), ("dL_dcov3D_precomp", C.c_void_p)]
 
 

@@ -33,10 +33,22 @@ __global__ __launch_bounds__(512) void gp_mlp_bwd_weight_kernel(const float* __r
                                                                 long rows_per_block, float* __restrict__ dW, int lddw,
                                                                 float* __restrict__ db);
 __global__ __launch_bounds__(256) void gp_blend_fwd_kernel(BlendDev a, float* __restrict__ xyz_t, float* __restrict__ q_t);
+__global__ __launch_bounds__(256) void gp_blend_fwd6_kernel(BlendDev a, float* __restrict__ xyz_t, float* __restrict__ q_t);
+__global__ __launch_bounds__(256) void gp_blend_fwd8_kernel(BlendDev a, float* __restrict__ xyz_t, float* __restrict__ q_t);
 __global__ __launch_bounds__(256) void gp_blend_bwd_kernel(BlendDev a, const float* __restrict__ g_xyz_t,
                                                            const float* __restrict__ g_q_t, float* __restrict__ g_delta,
                                                            float* __restrict__ g_raw_w, float* __restrict__ g_xyz,
-                                                           float* __restrict__ g_rot);
+                                                           float* __restrict__ g_rot, float* __restrict__ partial);
+__global__ __launch_bounds__(256) void gp_blend_bwd6_kernel(BlendDev a, const float* __restrict__ g_xyz_t,
+                                                           const float* __restrict__ g_q_t, float* __restrict__ g_delta,
+                                                           float* __restrict__ g_raw_w, float* __restrict__ g_xyz,
+                                                           float* __restrict__ g_rot, float* __restrict__ partial);
+__global__ __launch_bounds__(256) void gp_blend_bwd8_kernel(BlendDev a, const float* __restrict__ g_xyz_t,
+                                                           const float* __restrict__ g_q_t, float* __restrict__ g_delta,
+                                                           float* __restrict__ g_raw_w, float* __restrict__ g_xyz,
+                                                           float* __restrict__ g_rot, float* __restrict__ partial);
+__global__ __launch_bounds__(256) void gp_blend_bwd_reduce_kernel(const float* __restrict__ partial, int nblocks, int KA,
+                                                                  int od, float* __restrict__ g_delta);
 __global__ __launch_bounds__(256) void gp_act_fwd_kernel(long n, const float* __restrict__ scaling_raw,
                                                          const float* __restrict__ opacity_raw,
                                                          const float* __restrict__ delta_o, int stride, float beta,

@@ -87,14 +87,26 @@ __device__ __forceinline__ f32x16 layer_mfma(const float* __restrict__ W, int ld
     }
     const bool row_ok = i_row < out_rows;
     const float* wrow = W + (size_t)i_row * ldw;
-    for (int kq = 0; kq < K / 8; ++kq) {
-        const int kbase = 8 * kq + 4 * half;
-        float4 wv = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (row_ok && kbase < ldw) wv = *(const float4*)(wrow + kbase);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.x, cur[act_idx(kbase + 0, j)], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.y, cur[act_idx(kbase + 1, j)], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.z, cur[act_idx(kbase + 2, j)], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.w, cur[act_idx(kbase + 3, j)], acc, 0, 0, 0);
+    const int nkq = K / 8;
+    // 4 k-groups per trip: all weight loads are issued before the 16 dependent MFMAs (hides L2 latency)
+    for (int kq0 = 0; kq0 < nkq; kq0 += 4) {
+        float4 wv[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int kbase = 8 * (kq0 + g) + 4 * half;
+            wv[g] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row_ok && kq0 + g < nkq && kbase < ldw) wv[g] = *(const float4*)(wrow + kbase);
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            if (kq0 + g < nkq) {
+                const int kbase = 8 * (kq0 + g) + 4 * half;
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[g].x, cur[act_idx(kbase + 0, j)], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[g].y, cur[act_idx(kbase + 1, j)], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[g].z, cur[act_idx(kbase + 2, j)], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[g].w, cur[act_idx(kbase + 3, j)], acc, 0, 0, 0);
+            }
+        }
     }
     return acc;
 }
@@ -108,13 +120,25 @@ __device__ __forceinline__ f32x16 layer_mfma_T(const float* __restrict__ W, int 
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     const bool row_ok = i_row < out_rows;
-    for (int kq = 0; kq < K / 8; ++kq) {
-        const int kbase = 8 * kq + 4 * half;
+    const int nkq = K / 8;
+    for (int kq0 = 0; kq0 < nkq; kq0 += 2) {
+        float a[8];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int k = kbase + u;
-            const float a = (row_ok && k < k_valid) ? W[(size_t)k * ldw + i_row] : 0.f;
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, cur[act_idx(k, j)], acc, 0, 0, 0);
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int k = 8 * (kq0 + g) + 4 * half + u;
+                a[4 * g + u] = (row_ok && kq0 + g < nkq && k < k_valid) ? W[(size_t)k * ldw + i_row] : 0.f;
+            }
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            if (kq0 + g < nkq) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int k = 8 * (kq0 + g) + 4 * half + u;
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * g + u], cur[act_idx(k, j)], acc, 0, 0, 0);
+                }
+            }
         }
     }
     return acc;
@@ -242,44 +266,69 @@ __global__ __launch_bounds__(MLP_THREADS) void gp_mlp_bwd_data_kernel(MlpDev p, 
 
 // ------------------------------------------------------------------------------------------------
 // MLP backward, weight grads: dW[o][i] += sum_rows dZ[row][o] * H[row][i]   (A = dZ^T, B = H)
-// grid = (row chunks, i-tiles of 32); wave w of the 8 owns o-tile w.  K (= rows) is walked two rows
-// per MFMA; operands come straight from global memory (each 32-lane half reads 128 contiguous bytes).
+// grid = (row blocks, i-tiles, o-tiles).  The 8 waves of a workgroup split the block's rows, each
+// accumulates a 32x32 tile on the matrix cores (two rows per MFMA, operands straight from global:
+// each 32-lane half reads 128 contiguous bytes), the 8 partial tiles are summed through LDS and leave
+// as ONE update per element -- a plain read-modify-write when a single row block owns the tile
+// (small K: no atomics at all), an atomic only across row blocks.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(MLP_THREADS) void gp_mlp_bwd_weight_kernel(const float* __restrict__ dZ, int n_out,
                                                                         const float* __restrict__ H, int ldh, int n_in,
                                                                         long rows, long rows_per_block,
                                                                         float* __restrict__ dW, int lddw,
                                                                         float* __restrict__ db) {
+    __shared__ float s_red[8][16][64];
+    __shared__ float s_b[8][32];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, j = lane & 31;
-    const int o = 32 * wave + j;       // A row (output feature)
-    const int i = 32 * blockIdx.y + j; // B col (input feature)
-    const long r_begin = (long)blockIdx.x * rows_per_block;
-    long r_end = r_begin + rows_per_block;
-    if (r_end > rows) r_end = rows;
-    if (32 * wave >= n_out) return;
+    const int o = 32 * blockIdx.z + j;  // A row (output feature)
+    const int i = 32 * blockIdx.y + j;  // B col (input feature)
+    const long b_begin = (long)blockIdx.x * rows_per_block;
+    long b_end = b_begin + rows_per_block;
+    if (b_end > rows) b_end = rows;
+    long per_wave = ((b_end - b_begin + 7) / 8 + 1) & ~1L;  // even, so (rb, rb+1) pairs never straddle slices
+    const long r_begin = b_begin + wave * per_wave;
+    long r_end = r_begin + per_wave;
+    if (r_end > b_end) r_end = b_end;
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     float bsum = 0.f;
     const bool o_ok = o < n_out, i_ok = i < n_in;
-    for (long rb = r_begin; rb < r_end; rb += 2) {  // uniform trip count: MFMA needs the whole wave
-        const long r = rb + half;
-        float a = 0.f, b = 0.f;
-        if (r < r_end) {
-            if (o_ok) a = dZ[r * n_out + o];
-            if (i_ok) b = H[r * (long)ldh + i];
+    for (long rb = r_begin; rb < r_end; rb += 8) {  // uniform trip count per wave: MFMA needs the whole wave
+        float a[4], b[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const long r = rb + 2 * u + half;
+            a[u] = (r < r_end && o_ok) ? dZ[r * n_out + o] : 0.f;
+            b[u] = (r < r_end && i_ok) ? H[r * (long)ldh + i] : 0.f;
+            bsum += a[u];
         }
-        bsum += a;
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[u], acc, 0, 0, 0);
     }
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int oo = 32 * wave + cd_row(r, half);
-        if (oo < n_out && i_ok) atomicAdd(&dW[(size_t)oo * lddw + i], acc[r]);
+    for (int r = 0; r < 16; ++r) s_red[wave][r][lane] = acc[r];
+    bsum += __shfl_xor(bsum, 32);
+    if (half == 0) s_b[wave][j] = bsum;
+    __syncthreads();
+    const bool single = gridDim.x == 1;
+    for (int e = tid; e < 16 * 64; e += MLP_THREADS) {
+        const int r = e >> 6, l = e & 63;
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) v += s_red[w][r][l];
+        const int oo = 32 * blockIdx.z + cd_row(r, l >> 5), ii = 32 * blockIdx.y + (l & 31);
+        if (oo < n_out && ii < n_in) {
+            float* dst = &dW[(size_t)oo * lddw + ii];
+            if (single) *dst += v; else atomicAdd(dst, v);
+        }
     }
-    if (db && blockIdx.y == 0) {
-        bsum += __shfl_xor(bsum, 32);
-        if (half == 0 && o_ok) atomicAdd(&db[o], bsum);
+    if (db && blockIdx.y == 0 && tid < 32) {
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) v += s_b[w][tid];
+        const int oo = 32 * blockIdx.z + tid;
+        if (oo < n_out) { if (single) db[oo] += v; else atomicAdd(&db[oo], v); }
     }
 }
 
@@ -299,22 +348,30 @@ __device__ __forceinline__ float norm4(const float* v) {
 }
 __device__ __forceinline__ void softmax_n(const float* __restrict__ raw, int n, float* w) {
     float m = raw[0];
+#pragma unroll
     for (int k = 1; k < n; ++k) m = fmaxf(m, raw[k]);
     float s = 0.f;
+#pragma unroll
     for (int k = 0; k < n; ++k) { w[k] = expf(raw[k] - m); s += w[k]; }
     const float inv = 1.f / s;
+#pragma unroll
     for (int k = 0; k < n; ++k) w[k] *= inv;
 }
 
-__global__ __launch_bounds__(256) void gp_blend_fwd_kernel(BlendDev a, float* __restrict__ xyz_t, float* __restrict__ q_t) {
+// NN > 0: compile-time neighbour count (loops unroll, the nn gathers are issued together);
+// NN == 0: run-time a.nn (including the stage-1 case a.nn == 0)
+template <int NN>
+__device__ __forceinline__ void blend_fwd_body(BlendDev a, float* __restrict__ xyz_t, float* __restrict__ q_t) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= a.N) return;
     float dxyz[3] = {0.f, 0.f, 0.f}, dq[4] = {0.f, 0.f, 0.f, 0.f};
-    const int od = a.out_dim, nn = a.nn;
+    const int od = a.out_dim;
+    const int nn = NN > 0 ? NN : a.nn;
     if (nn > 0) {
-        float wx[GP_MAX_NN], wr[GP_MAX_NN];
+        float wx[NN > 0 ? NN : GP_MAX_NN], wr[NN > 0 ? NN : GP_MAX_NN];
         softmax_n(a.raw_w + i * 2 * nn, nn, wx);
         softmax_n(a.raw_w + i * 2 * nn + nn, nn, wr);
+#pragma unroll
         for (int k = 0; k < nn; ++k) {
             const long kp = a.knn[i * nn + k];
             const float* dl = a.delta + kp * od;
@@ -343,6 +400,9 @@ __global__ __launch_bounds__(256) void gp_blend_fwd_kernel(BlendDev a, float* __
     const float invp = 1.f / norm4(pq);
     q_t[4 * i] = pq[0] * invp; q_t[4 * i + 1] = pq[1] * invp; q_t[4 * i + 2] = pq[2] * invp; q_t[4 * i + 3] = pq[3] * invp;
 }
+__global__ __launch_bounds__(256) void gp_blend_fwd_kernel(BlendDev a, float* __restrict__ xyz_t, float* __restrict__ q_t) { blend_fwd_body<0>(a, xyz_t, q_t); }
+__global__ __launch_bounds__(256) void gp_blend_fwd6_kernel(BlendDev a, float* __restrict__ xyz_t, float* __restrict__ q_t) { blend_fwd_body<6>(a, xyz_t, q_t); }
+__global__ __launch_bounds__(256) void gp_blend_fwd8_kernel(BlendDev a, float* __restrict__ xyz_t, float* __restrict__ q_t) { blend_fwd_body<8>(a, xyz_t, q_t); }
 
 // gradient through y = v / max(|v|, eps):  dv = (g - y (y.g)) / |v|
 __device__ __forceinline__ void normalize_bwd(const float* v, const float* g, float* dv) {
@@ -355,12 +415,14 @@ __device__ __forceinline__ void normalize_bwd(const float* v, const float* g, fl
 
 // Keypoint gradients are first accumulated per workgroup in LDS ([K, 7]) and flushed with one
 // global atomic per (workgroup, keypoint, component): K is a few hundred, N is 10^6.
-__global__ __launch_bounds__(256) void gp_blend_bwd_kernel(BlendDev a, const float* __restrict__ g_xyz_t,
-                                                          const float* __restrict__ g_q_t, float* __restrict__ g_delta,
-                                                          float* __restrict__ g_raw_w, float* __restrict__ g_xyz,
-                                                          float* __restrict__ g_rot) {
+template <int NN>
+__device__ __forceinline__ void blend_bwd_body(BlendDev a, const float* __restrict__ g_xyz_t,
+                                               const float* __restrict__ g_q_t, float* __restrict__ g_delta,
+                                               float* __restrict__ g_raw_w, float* __restrict__ g_xyz,
+                                               float* __restrict__ g_rot, float* __restrict__ partial) {
     extern __shared__ float s_acc[];  // [K*7] when nn > 0
-    const int od = a.out_dim, nn = a.nn;
+    const int od = a.out_dim;
+    const int nn = NN > 0 ? NN : a.nn;
     const int KA = nn > 0 ? (int)a.K * 7 : 0;
     for (int e = threadIdx.x; e < KA; e += 256) s_acc[e] = 0.f;
     if (nn > 0) __syncthreads();
@@ -369,11 +431,12 @@ __global__ __launch_bounds__(256) void gp_blend_bwd_kernel(BlendDev a, const flo
         const float gq[4] = {g_q_t[4 * i], g_q_t[4 * i + 1], g_q_t[4 * i + 2], g_q_t[4 * i + 3]};
         g_xyz[3 * i] = gx[0]; g_xyz[3 * i + 1] = gx[1]; g_xyz[3 * i + 2] = gx[2];
         // recompute forward
-        float wx[GP_MAX_NN], wr[GP_MAX_NN];
+        float wx[NN > 0 ? NN : GP_MAX_NN], wr[NN > 0 ? NN : GP_MAX_NN];
         float dq[4] = {0.f, 0.f, 0.f, 0.f};
         if (nn > 0) {
             softmax_n(a.raw_w + i * 2 * nn, nn, wx);
             softmax_n(a.raw_w + i * 2 * nn + nn, nn, wr);
+#pragma unroll
             for (int k = 0; k < nn; ++k) {
                 const float* dl = a.delta + (long)a.knn[i * nn + k] * od;
                 float v[4] = {dl[3], dl[4], dl[5], dl[6]};
@@ -405,8 +468,9 @@ __global__ __launch_bounds__(256) void gp_blend_bwd_kernel(BlendDev a, const flo
         float gdq[4];
         normalize_bwd(dq, gqn, gdq);  // grad wrt blended (or per-Gaussian normalised) dq
         if (nn > 0) {
-            float gwx[GP_MAX_NN], gwr[GP_MAX_NN];
+            float gwx[NN > 0 ? NN : GP_MAX_NN], gwr[NN > 0 ? NN : GP_MAX_NN];
             float sx = 0.f, sr = 0.f;
+#pragma unroll
             for (int k = 0; k < nn; ++k) {
                 const long kp = a.knn[i * nn + k];
                 const float* dl = a.delta + kp * od;
@@ -424,6 +488,7 @@ __global__ __launch_bounds__(256) void gp_blend_bwd_kernel(BlendDev a, const flo
                 atomicAdd(acc + 0, wx[k] * gx[0]); atomicAdd(acc + 1, wx[k] * gx[1]); atomicAdd(acc + 2, wx[k] * gx[2]);
                 atomicAdd(acc + 3, gv[0]); atomicAdd(acc + 4, gv[1]); atomicAdd(acc + 5, gv[2]); atomicAdd(acc + 6, gv[3]);
             }
+#pragma unroll
             for (int k = 0; k < nn; ++k) {
                 g_raw_w[i * 2 * nn + k] = wx[k] * (gwx[k] - sx);
                 g_raw_w[i * 2 * nn + nn + k] = wr[k] * (gwr[k] - sr);
@@ -441,11 +506,30 @@ __global__ __launch_bounds__(256) void gp_blend_bwd_kernel(BlendDev a, const flo
     }
     if (nn > 0) {
         __syncthreads();
-        for (int e = threadIdx.x; e < KA; e += 256) {
-            const float v = s_acc[e];
-            if (v != 0.f) atomicAdd(&g_delta[(size_t)(e / 7) * od + (e % 7)], v);
-        }
+        // stage 1 of the cross-workgroup reduction: plain coalesced stores of this workgroup's partials
+        for (int e = threadIdx.x; e < KA; e += 256) partial[(size_t)blockIdx.x * KA + e] = s_acc[e];
     }
+}
+
+#define BB_ARGS BlendDev a, const float* __restrict__ g_xyz_t, const float* __restrict__ g_q_t, float* __restrict__ g_delta, \
+    float* __restrict__ g_raw_w, float* __restrict__ g_xyz, float* __restrict__ g_rot, float* __restrict__ partial
+__global__ __launch_bounds__(256) void gp_blend_bwd_kernel(BB_ARGS) { blend_bwd_body<0>(a, g_xyz_t, g_q_t, g_delta, g_raw_w, g_xyz, g_rot, partial); }
+__global__ __launch_bounds__(256) void gp_blend_bwd6_kernel(BB_ARGS) { blend_bwd_body<6>(a, g_xyz_t, g_q_t, g_delta, g_raw_w, g_xyz, g_rot, partial); }
+__global__ __launch_bounds__(256) void gp_blend_bwd8_kernel(BB_ARGS) { blend_bwd_body<8>(a, g_xyz_t, g_q_t, g_delta, g_raw_w, g_xyz, g_rot, partial); }
+
+// stage 2: g_delta[k, c] = sum over workgroups (deterministic, no atomics)
+__global__ __launch_bounds__(256) void gp_blend_bwd_reduce_kernel(const float* __restrict__ partial, int nblocks, int KA,
+                                                                 int od, float* __restrict__ g_delta) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= KA) return;
+    float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
+    int b = 0;
+    for (; b + 3 < nblocks; b += 4) {
+        v0 += partial[(size_t)b * KA + e]; v1 += partial[(size_t)(b + 1) * KA + e];
+        v2 += partial[(size_t)(b + 2) * KA + e]; v3 += partial[(size_t)(b + 3) * KA + e];
+    }
+    for (; b < nblocks; ++b) v0 += partial[(size_t)b * KA + e];
+    g_delta[(size_t)(e / 7) * od + (e % 7)] = (v0 + v1) + (v2 + v3);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -58,8 +58,11 @@ extern "C" int gp_mlp_backward(const gp_mlp_params* p, const gp_mlp_input* x, co
                        dL_dfeature, dL_dxyz);
     GP_LAUNCH_CHECK(); }
     // weight grads: dW_l = dZ_{l+1}^T H_l,  H_0 = X
-    long rpb = 2048;
-    while (rpb < 65536 && (m.rows + rpb - 1) / rpb > 512) rpb *= 2;
+    // row blocks: one for small K (no atomics), up to 16 for large row counts
+    long nrb_l = (m.rows + 4095) / 4096;
+    if (nrb_l > 16) nrb_l = 16;
+    if (nrb_l < 1) nrb_l = 1;
+    long rpb = ((m.rows + nrb_l - 1) / nrb_l + 15) & ~15L;
     const unsigned nrb = (unsigned)((m.rows + rpb - 1) / rpb);
     for (int l = 0; l < 5; ++l) {
         const float* dZl = l < 4 ? dz + (size_t)l * m.rows * 256 : dL_dout;
@@ -68,8 +71,8 @@ extern "C" int gp_mlp_backward(const gp_mlp_params* p, const gp_mlp_input* x, co
         const int ldh = l == 0 ? m.in_pad : 256;
         const int n_in = l == 0 ? m.in_dim : 256;
         { GpProfScope _p("mlp_bwd_weight", s);
-        hipLaunchKernelGGL(gp_mlp_bwd_weight_kernel, dim3(nrb, (unsigned)((n_in + 31) / 32)), dim3(512), 0, s, dZl, n_out, H,
-                           ldh, n_in, m.rows, rpb, g->dw[l], n_in, g->db[l]);
+        hipLaunchKernelGGL(gp_mlp_bwd_weight_kernel, dim3(nrb, (unsigned)((n_in + 31) / 32), (unsigned)((n_out + 31) / 32)),
+                           dim3(512), 0, s, dZl, n_out, H, ldh, n_in, m.rows, rpb, g->dw[l], n_in, g->db[l]);
         GP_LAUNCH_CHECK(); }
     }
     return 0;
@@ -94,24 +97,39 @@ extern "C" int gp_blend_forward(const gp_blend_args* a, float* xyz_t, float* q_t
     if (b.N == 0) return 0;
     if (!xyz_t || !q_t) GP_FAIL("null output");
     { GpProfScope _p("blend_fwd", (hipStream_t)stream_);
-        hipLaunchKernelGGL(gp_blend_fwd_kernel, dim3(gp_blocks((size_t)b.N, 256)), dim3(256), 0, (hipStream_t)stream_, b, xyz_t, q_t);
+        hipLaunchKernelGGL(b.nn == 6 ? gp_blend_fwd6_kernel : b.nn == 8 ? gp_blend_fwd8_kernel : gp_blend_fwd_kernel,
+                       dim3(gp_blocks((size_t)b.N, 256)), dim3(256), 0, (hipStream_t)stream_, b, xyz_t, q_t);
     GP_LAUNCH_CHECK(); }
     return 0;
 }
 
 extern "C" int gp_blend_backward(const gp_blend_args* a, const float* dL_dxyz_t, const float* dL_dq_t, float* dL_ddelta,
-                                 float* dL_draw_w, float* dL_dxyz, float* dL_drot, gp_stream_t stream_) {
+                                 float* dL_draw_w, float* dL_dxyz, float* dL_drot, gp_alloc_fn alloc, void* alloc_ctx,
+                                 gp_stream_t stream_) {
     BlendDev b;
     if (make_blend(a, b)) return 1;
     if (b.N == 0) return 0;
     if (!dL_dxyz_t || !dL_dq_t || !dL_ddelta || !dL_dxyz || !dL_drot || (b.nn > 0 && !dL_draw_w)) GP_FAIL("null argument");
     unsigned blocks = gp_blocks((size_t)b.N, 256);
-    if (b.nn > 0 && blocks > 512) blocks = 512;
+    if (b.nn > 0 && blocks > 1024) blocks = 1024;
     const size_t lds = b.nn > 0 ? (size_t)b.K * 7 * sizeof(float) : 0;
+    float* partial = nullptr;
+    const int KA = (int)b.K * 7;
+    if (b.nn > 0) {
+        if (!alloc) GP_FAIL("null allocator");
+        partial = (float*)alloc(alloc_ctx, GP_BUF_TEMP, gp_align_up((size_t)blocks * KA * sizeof(float), 256));
+        if (!partial) GP_FAIL("allocator returned NULL for TEMP");
+    }
     { GpProfScope _p("blend_bwd", (hipStream_t)stream_);
-        hipLaunchKernelGGL(gp_blend_bwd_kernel, dim3(blocks), dim3(256), lds, (hipStream_t)stream_, b, dL_dxyz_t, dL_dq_t, dL_ddelta,
-                       dL_draw_w, dL_dxyz, dL_drot);
-    GP_LAUNCH_CHECK(); }
+    hipLaunchKernelGGL(b.nn == 6 ? gp_blend_bwd6_kernel : b.nn == 8 ? gp_blend_bwd8_kernel : gp_blend_bwd_kernel,
+                       dim3(blocks), dim3(256), lds, (hipStream_t)stream_, b, dL_dxyz_t, dL_dq_t, dL_ddelta,
+                       dL_draw_w, dL_dxyz, dL_drot, partial);
+    GP_LAUNCH_CHECK();
+    if (b.nn > 0) {
+        hipLaunchKernelGGL(gp_blend_bwd_reduce_kernel, dim3(gp_blocks((size_t)KA, 256)), dim3(256), 0, (hipStream_t)stream_, partial,
+                           (int)blocks, KA, b.out_dim, dL_ddelta);
+        GP_LAUNCH_CHECK();
+    } }
     return 0;
 }
 

@@ -29,6 +29,7 @@ static int make_dims(const gp_raster_settings* st, const gp_raster_inputs* in, R
     }
     if (in->shs && st->sh_coeffs < (st->sh_degree + 1) * (st->sh_degree + 1)) GP_FAIL("shs has %d coeffs, degree %d needs more", st->sh_coeffs, st->sh_degree);
     if (in->shs && st->sh_coeffs > 16) GP_FAIL("sh_coeffs %d > 16 unsupported", st->sh_coeffs);
+    if (in->shs_rest && (!in->shs || st->sh_coeffs != 16)) GP_FAIL("shs_rest needs shs (= features_dc) and sh_coeffs == 16");
     if (!st->bg || !st->viewmatrix || !st->projmatrix || !st->campos) GP_FAIL("null camera pointers");
     if (in->num_gaussians > 0 && (!in->means3D || !in->opacities)) GP_FAIL("null means3D/opacities");
     d.N = (int)in->num_gaussians;
@@ -114,11 +115,21 @@ extern "C" int gp_raster_forward(const gp_raster_settings* st, const gp_raster_i
         GpCarver tc(tmp);
         carve_tmp(tc, k0, k1, v0, v1, tiles, tt, hist, scan_tmp);
 
-        { GpProfScope _p("preprocess_fwd", s);
-        hipLaunchKernelGGL(gp_preprocess_fwd_kernel, dim3(gp_blocks(N, 256)), dim3(256), 0, s, d, in->means3D, in->scales,
-                           in->rotations, in->opacities, in->shs, in->colors_precomp, in->cov3D_precomp, st->viewmatrix,
-                           st->projmatrix, st->campos, out->radii, gl.rec, k0, tiles, gl.clamped);
-        GP_LAUNCH_CHECK(); }
+        {
+            GpProfScope _p("preprocess_fwd", s);
+            const bool al16 = (((uintptr_t)in->shs | (uintptr_t)in->shs_rest) & 15) == 0;
+            auto kern = gp_preprocess_fwd_kernel;
+            if (in->shs && in->shs_rest) {
+                if (!al16) GP_FAIL("shs/shs_rest must be 16-byte aligned");
+                kern = gp_preprocess_fwd_split_kernel;
+            } else if (in->shs && d.M == 16 && al16) {
+                kern = gp_preprocess_fwd_sh16_kernel;
+            }
+            hipLaunchKernelGGL(kern, dim3(gp_blocks(N, 256)), dim3(256), 0, s, d, in->means3D, in->scales, in->rotations,
+                               in->opacities, in->shs, in->shs_rest, in->colors_precomp, in->cov3D_precomp, st->viewmatrix,
+                               st->projmatrix, st->campos, out->radii, gl.rec, k0, tiles, gl.clamped);
+            GP_LAUNCH_CHECK();
+        }
         hipLaunchKernelGGL(gp_iota_kernel, dim3(gp_blocks(N, 256)), dim3(256), 0, s, v0, d.N);
         GP_LAUNCH_CHECK();
         GpSortBufs sb;
@@ -208,23 +219,41 @@ extern "C" int gp_raster_backward(const gp_raster_settings* st, const gp_raster_
     float* g_color = acc + 6 * N;
     float* g_depth = acc + 9 * N;
     if (R > 0) {
-        const unsigned parts = GP_TILE / 8;
-        static const bool noatomic = getenv("GP_EXP_BWD_NOATOMIC") != nullptr;   // timing experiment only
+        static const bool noatomic = getenv("GP_EXP_BWD_NOATOMIC") != nullptr;   // timing experiments only
+        static const bool use_v1 = getenv("GP_EXP_BWD_V1") != nullptr;
+        static const bool use_v2 = getenv("GP_EXP_BWD_V2") != nullptr;
+        static const int exp_rows = getenv("GP_EXP_BWD_ROWS") ? atoi(getenv("GP_EXP_BWD_ROWS")) : 8;
+        auto kern = dL_ddepth ? gp_composite_bwd3_depth_kernel : gp_composite_bwd3_kernel;
+        unsigned parts = GP_TILE / 8;
+        if (noatomic) kern = gp_composite_bwd_noatomic_kernel;
+        else if (use_v1) kern = gp_composite_bwd_kernel;
+        else if (use_v2) kern = dL_ddepth ? gp_composite_bwd2_depth_kernel : gp_composite_bwd2_kernel;
+        else if (!dL_ddepth && exp_rows == 4) { kern = gp_composite_bwd3_r4_kernel; parts = 4; }
+        else if (!dL_ddepth && exp_rows == 2) { kern = gp_composite_bwd3_r2_kernel; parts = 8; }
+        else if (!dL_ddepth && exp_rows == 16) { kern = gp_composite_bwd3_r16_kernel; parts = 1; }
         { GpProfScope _p("composite_bwd", s);
-        static const bool use_v1 = getenv("GP_EXP_BWD_V1") != nullptr;               // A/B against the first design
-        hipLaunchKernelGGL(noatomic ? gp_composite_bwd_noatomic_kernel : use_v1 ? gp_composite_bwd_kernel :
-                           dL_ddepth ? gp_composite_bwd2_depth_kernel : gp_composite_bwd2_kernel, dim3((unsigned)T * parts), dim3(64), 0, s, d, il.ranges, point_list,
+        hipLaunchKernelGGL(kern, dim3((unsigned)T * parts), dim3(64), 0, s, d, il.ranges, point_list,
                            gl.rec, st->bg, fwd->color, fwd->depth, il.final_T, il.n_contrib, dL_dcolor, dL_ddepth, g_mean2D,
                            g_conic, g_opacity, g_color, g_depth);
         GP_LAUNCH_CHECK(); }
     }
-    { GpProfScope _p("preprocess_bwd", s);
-        hipLaunchKernelGGL(gp_preprocess_bwd_kernel, dim3(gp_blocks(N, 256)), dim3(256), 0, s, d, in->means3D, in->scales,
-                       in->rotations, in->shs, in->cov3D_precomp, st->viewmatrix, st->projmatrix, st->campos, fwd->radii,
-                       gl.clamped, g_mean2D, g_conic, g_opacity, g_color, g_depth, g->dL_dmeans3D, g->dL_dmeans2D, g->dL_dshs,
-                       in->shs ? nullptr : g->dL_dcolors_precomp, g->dL_dopacities, g->dL_dscales, g->dL_drotations,
-                       g->dL_dcov3D_precomp);
-    GP_LAUNCH_CHECK(); }
+    {
+        GpProfScope _p("preprocess_bwd", s);
+        const bool al16 = (((uintptr_t)in->shs | (uintptr_t)in->shs_rest | (uintptr_t)g->dL_dshs | (uintptr_t)g->dL_dshs_rest) & 15) == 0;
+        auto kern = gp_preprocess_bwd_kernel;
+        if (in->shs && in->shs_rest) {
+            if (!al16 || !g->dL_dshs_rest) GP_FAIL("split SH mode needs 16-byte aligned tensors and dL_dshs_rest");
+            kern = gp_preprocess_bwd_split_kernel;
+        } else if (in->shs && d.M == 16 && al16) {
+            kern = gp_preprocess_bwd_sh16_kernel;
+        }
+        hipLaunchKernelGGL(kern, dim3(gp_blocks(N, 256)), dim3(256), 0, s, d, in->means3D, in->scales, in->rotations, in->shs,
+                           in->shs_rest, in->cov3D_precomp, st->viewmatrix, st->projmatrix, st->campos, fwd->radii, gl.clamped,
+                           g_mean2D, g_conic, g_opacity, g_color, g_depth, g->dL_dmeans3D, g->dL_dmeans2D, g->dL_dshs,
+                           g->dL_dshs_rest, in->shs ? nullptr : g->dL_dcolors_precomp, g->dL_dopacities, g->dL_dscales,
+                           g->dL_drotations, g->dL_dcov3D_precomp);
+        GP_LAUNCH_CHECK();
+    }
     return 0;
 }
 

@@ -156,21 +156,77 @@ __device__ __forceinline__ void sh_to_rgb(int deg, const float* __restrict__ sh,
 }
 
 // ------------------------------------------------------------------------------------------------
-// preprocess forward
+// preprocess forward.  SH coefficients ([N,16,3] = 192 B per Gaussian, or the model's two tensors
+// features_dc [N,1,3] + features_rest [N,15,3] passed separately so the per-frame torch.cat of
+// [REF scene/gaussian_model.py:155-159] disappears) are staged through LDS: the 256 Gaussians of a
+// workgroup own one contiguous span of global memory, read with coalesced float4 loads, then every
+// thread picks its own coefficients at an odd LDS stride (conflict-free).
+// SH_MODE 0: generic (direct global loads)  1: one tensor, M = 16  2: dc + rest, M = 16
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void gp_preprocess_fwd_kernel(RasterDims d, const float* __restrict__ means3D,
-                                                               const float* __restrict__ scales,
-                                                               const float* __restrict__ rotations,
-                                                               const float* __restrict__ opacities,
-                                                               const float* __restrict__ shs,
-                                                               const float* __restrict__ colors_precomp,
-                                                               const float* __restrict__ cov3D_precomp,
-                                                               const float* __restrict__ view, const float* __restrict__ proj,
-                                                               const float* __restrict__ campos, int32_t* __restrict__ radii,
-                                                               float4* __restrict__ rec, uint32_t* __restrict__ depth_key,
-                                                               uint32_t* __restrict__ tiles_touched,
-                                                               uint8_t* __restrict__ clamped) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
+template <int CNT>
+__device__ __forceinline__ void stage_sh(float* s_sh, const float* __restrict__ src, int nblk, int tid) {
+    constexpr int STRIDE = CNT | 1;
+    const int total = nblk * CNT;
+    for (int e = tid * 4; e < total; e += 1024) {
+        float v[4];
+        if (e + 3 < total) {
+            const float4 f = *(const float4*)(src + e);
+            v[0] = f.x; v[1] = f.y; v[2] = f.z; v[3] = f.w;
+        } else {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = (e + u < total) ? src[e + u] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int idx = e + u;
+            if (idx < total) {
+                const int g = idx / CNT, k = idx - g * CNT;
+                s_sh[g * STRIDE + k] = v[u];
+            }
+        }
+    }
+}
+template <int CNT>
+__device__ __forceinline__ void unstage_sh(const float* s_sh, float* __restrict__ dst, int nblk, int tid) {
+    constexpr int STRIDE = CNT | 1;
+    const int total = nblk * CNT;
+    for (int e = tid * 4; e < total; e += 1024) {
+        float v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int idx = e + u;
+            const int g = idx / CNT, k = idx - g * CNT;
+            v[u] = (idx < total) ? s_sh[g * STRIDE + k] : 0.f;
+        }
+        if (e + 3 < total) {
+            *(float4*)(dst + e) = make_float4(v[0], v[1], v[2], v[3]);
+        } else {
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (e + u < total) dst[e + u] = v[u];
+        }
+    }
+}
+
+template <int SH_MODE>
+__device__ __forceinline__ void preprocess_fwd_body(RasterDims d, const float* __restrict__ means3D,
+                                                    const float* __restrict__ scales, const float* __restrict__ rotations,
+                                                    const float* __restrict__ opacities, const float* __restrict__ shs,
+                                                    const float* __restrict__ shs_rest, const float* __restrict__ colors_precomp,
+                                                    const float* __restrict__ cov3D_precomp, const float* __restrict__ view,
+                                                    const float* __restrict__ proj, const float* __restrict__ campos,
+                                                    int32_t* __restrict__ radii, float4* __restrict__ rec,
+                                                    uint32_t* __restrict__ depth_key, uint32_t* __restrict__ tiles_touched,
+                                                    uint8_t* __restrict__ clamped) {
+    __shared__ float s_sh[SH_MODE == 0 ? 1 : 256 * 49];
+    const int tid = threadIdx.x;
+    const int base = blockIdx.x * 256;
+    const int i = base + tid;
+    const int nblk = min(256, d.N - base);
+    const bool use_sh = !colors_precomp;
+    if (SH_MODE == 1 && use_sh && d.D > 0) stage_sh<48>(s_sh, shs + (size_t)base * 48, nblk, tid);
+    if (SH_MODE == 2 && use_sh && d.D > 0) stage_sh<45>(s_sh, shs_rest + (size_t)base * 45, nblk, tid);
+    if (SH_MODE != 0) __syncthreads();
     if (i >= d.N) return;
     radii[i] = 0;
     tiles_touched[i] = 0;
@@ -214,7 +270,26 @@ __global__ __launch_bounds__(256) void gp_preprocess_fwd_kernel(RasterDims d, co
         const float len = sqrtf(fmaf(dx, dx, fmaf(dy, dy, dz * dz)));
         const float inv = 1.f / len;
         float raw[3];
-        sh_to_rgb(d.D, shs + (size_t)i * d.M * 3, dx * inv, dy * inv, dz * inv, raw);
+        if (SH_MODE == 0) {
+            sh_to_rgb(d.D, shs + (size_t)i * d.M * 3, dx * inv, dy * inv, dz * inv, raw);
+        } else {
+            float shl[48];
+            if (SH_MODE == 1) {
+                if (d.D > 0) {
+#pragma unroll
+                    for (int k = 0; k < 48; ++k) shl[k] = s_sh[tid * 49 + k];
+                } else {
+                    shl[0] = shs[(size_t)i * 48]; shl[1] = shs[(size_t)i * 48 + 1]; shl[2] = shs[(size_t)i * 48 + 2];
+                }
+            } else {
+                shl[0] = shs[3 * (size_t)i]; shl[1] = shs[3 * (size_t)i + 1]; shl[2] = shs[3 * (size_t)i + 2];
+                if (d.D > 0) {
+#pragma unroll
+                    for (int k = 0; k < 45; ++k) shl[3 + k] = s_sh[tid * 45 + k];
+                }
+            }
+            sh_to_rgb(d.D, shl, dx * inv, dy * inv, dz * inv, raw);
+        }
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             const float v = raw[k] + 0.5f;
@@ -230,6 +305,18 @@ __global__ __launch_bounds__(256) void gp_preprocess_fwd_kernel(RasterDims d, co
     rec[3 * (size_t)i + 1] = make_float4(-0.5f * conz, opacities[i], pv.z, __int_as_float(i));
     rec[3 * (size_t)i + 2] = make_float4(col[0], col[1], col[2], 0.f);
 }
+
+#define PF_ARGS RasterDims d, const float* __restrict__ means3D, const float* __restrict__ scales, \
+    const float* __restrict__ rotations, const float* __restrict__ opacities, const float* __restrict__ shs, \
+    const float* __restrict__ shs_rest, const float* __restrict__ colors_precomp, const float* __restrict__ cov3D_precomp, \
+    const float* __restrict__ view, const float* __restrict__ proj, const float* __restrict__ campos, \
+    int32_t* __restrict__ radii, float4* __restrict__ rec, uint32_t* __restrict__ depth_key, \
+    uint32_t* __restrict__ tiles_touched, uint8_t* __restrict__ clamped
+#define PF_PASS d, means3D, scales, rotations, opacities, shs, shs_rest, colors_precomp, cov3D_precomp, view, proj, campos, \
+    radii, rec, depth_key, tiles_touched, clamped
+__global__ __launch_bounds__(256) void gp_preprocess_fwd_kernel(PF_ARGS) { preprocess_fwd_body<0>(PF_PASS); }
+__global__ __launch_bounds__(256) void gp_preprocess_fwd_sh16_kernel(PF_ARGS) { preprocess_fwd_body<1>(PF_PASS); }
+__global__ __launch_bounds__(256) void gp_preprocess_fwd_split_kernel(PF_ARGS) { preprocess_fwd_body<2>(PF_PASS); }
 
 __global__ __launch_bounds__(256) void gp_mark_visible_kernel(int n, const float* __restrict__ means3D,
                                                              const float* __restrict__ view, uint8_t* __restrict__ present) {
@@ -609,7 +696,7 @@ __device__ __forceinline__ float dpp_incl_sum(float v) {
 __device__ __forceinline__ float dpp_shift_right1(float v, float fill) { return dpp_move<0x138, 0xF>(fill, v); }  // wave_shr:1
 __device__ __forceinline__ float lane63(float v) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63)); }
 
-template <bool HAS_DEPTH>
+template <bool HAS_DEPTH, bool NOATOMIC = false>
 __device__ __forceinline__ void gp_composite_bwd2_body(RasterDims d, const int2* __restrict__ ranges,
                                                        const uint32_t* __restrict__ point_list, const float4* __restrict__ rec,
                                                        const float* __restrict__ bg, const float* __restrict__ out_color,
@@ -729,7 +816,216 @@ __device__ __forceinline__ void gp_composite_bwd2_body(RasterDims d, const int2*
                 }
             }
         }
-        if (have && any_c) {
+        if (NOATOMIC) {
+            if (have && a_mx.x == 123.456f) g_opacity[id] = a_mx.x + a_mx.y + a_my.x + a_my.y + a_ca.x + a_ca.y + a_cb.x + a_cb.y + a_cc.x + a_cc.y + a_op.x + a_op.y + a_r.x + a_r.y + a_g.x + a_g.y + a_b.x + a_b.y;
+        } else if (have && any_c) {
+            atomicAdd(&g_mean2D[2 * (size_t)id], (a_mx.x + a_mx.y) * halfW);
+            atomicAdd(&g_mean2D[2 * (size_t)id + 1], (a_my.x + a_my.y) * halfH);
+            atomicAdd(&g_conic[3 * (size_t)id], -0.5f * (a_ca.x + a_ca.y));
+            atomicAdd(&g_conic[3 * (size_t)id + 1], -(a_cb.x + a_cb.y));
+            atomicAdd(&g_conic[3 * (size_t)id + 2], -0.5f * (a_cc.x + a_cc.y));
+            atomicAdd(&g_opacity[id], a_op.x + a_op.y);
+            atomicAdd(&g_color[3 * (size_t)id], a_r.x + a_r.y);
+            atomicAdd(&g_color[3 * (size_t)id + 1], a_g.x + a_g.y);
+            atomicAdd(&g_color[3 * (size_t)id + 2], a_b.x + a_b.y);
+            if (HAS_DEPTH) atomicAdd(&g_depth[id], a_d.x + a_d.y);
+        }
+        __syncthreads();
+    }
+}
+
+
+// ---- v3: log-domain transmittance so that BOTH wave scans are sums, done as fused v_add_f32_dpp chains
+// (four interleaved scans per pixel pair: the interleave covers the 2-wait-state DPP hazard), conic
+// pre-scaled by log2(e) so G = exp2(power), contribution masks as {0,1} floats instead of branches,
+// per-pixel-pair constants packed for 128-bit LDS broadcast reads.
+//   L_in(p) = log2 T_in(p);  T_j = exp2(L_in + incl_j - own_j);  rem(p) = Tot - P_in;  suffix_j = rem - incl_j
+__device__ __forceinline__ void dpp_scan4_add(float& a, float& b, float& c, float& d) {
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %1, %1, %1 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %2, %2, %2 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %3, %3, %3 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %1, %1, %1 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %2, %2, %2 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %3, %3, %3 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %1, %1, %1 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %2, %2, %2 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %3, %3, %3 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %1, %1, %1 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %2, %2, %2 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %3, %3, %3 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "v_add_f32_dpp %1, %1, %1 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "v_add_f32_dpp %2, %2, %2 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "v_add_f32_dpp %3, %3, %3 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+        "v_add_f32_dpp %1, %1, %1 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+        "v_add_f32_dpp %2, %2, %2 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+        "v_add_f32_dpp %3, %3, %3 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+        "s_nop 1"
+        : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+}
+
+__device__ __forceinline__ void dpp_scan2_add(float& a, float& b) {
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %1, %1, %1 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 0\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %1, %1, %1 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 0\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %1, %1, %1 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 0\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %1, %1, %1 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 0\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "v_add_f32_dpp %1, %1, %1 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "s_nop 0\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+        "v_add_f32_dpp %1, %1, %1 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+        "s_nop 1"
+        : "+v"(a), "+v"(b));
+}
+
+
+template <bool HAS_DEPTH, int ROWS>
+__device__ __forceinline__ void gp_composite_bwd3_body(RasterDims d, const int2* __restrict__ ranges,
+                                                       const uint32_t* __restrict__ point_list, const float4* __restrict__ rec,
+                                                       const float* __restrict__ bg, const float* __restrict__ out_color,
+                                                       const float* __restrict__ out_depth, const float* __restrict__ final_T,
+                                                       const int32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpix,
+                                                       const float* __restrict__ dL_dpixdepth, float* __restrict__ g_mean2D,
+                                                       float* __restrict__ g_conic, float* __restrict__ g_opacity,
+                                                       float* __restrict__ g_color, float* __restrict__ g_depth) {
+    // per pixel PAIR (two horizontally adjacent pixels):
+    __shared__ float4 s_v0[(ROWS * GP_TILE / 2)];   // dLr0 dLr1 dLg0 dLg1
+    __shared__ float4 s_v1[(ROWS * GP_TILE / 2)];   // dLb0 dLb1 tb0  tb1      (tb = T_final * bg . dL_dpix)
+    __shared__ float4 s_cy[(ROWS * GP_TILE / 2)];   // Lin0 Lin1 rem0 rem1     (carried between batches)
+    __shared__ int2 s_nc[(ROWS * GP_TILE / 2)];
+    __shared__ float2 s_dd[HAS_DEPTH ? (ROWS * GP_TILE / 2) : 1];   // dLd0 dLd1
+    const int parts = GP_TILE / ROWS;
+    const int tile = blockIdx.x / parts, part = blockIdx.x % parts;
+    const int tx = tile % d.gx, ty = tile / d.gx;
+    const int lane = threadIdx.x;
+    const int2 range = ranges[tile];
+    const size_t HW = (size_t)d.H * d.W;
+    const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
+    int max_nc = 0;
+    for (int pr = lane; pr < ROWS * GP_TILE / 2; pr += 64) {   // one lane per pixel pair
+
+        const int px0 = tx * GP_TILE + 2 * (pr & 7), py = ty * GP_TILE + part * ROWS + (pr >> 3);
+        float dl[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+        float tb[2] = {0.f, 0.f}, rem[2] = {0.f, 0.f};
+        int nc[2] = {0, 0};
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int px = px0 + u;
+            if (px < d.W && py < d.H) {
+                const size_t pix = (size_t)py * d.W + px;
+                dl[u][0] = dL_dpix[pix]; dl[u][1] = dL_dpix[HW + pix]; dl[u][2] = dL_dpix[2 * HW + pix];
+                dl[u][3] = HAS_DEPTH ? dL_dpixdepth[pix] : 0.f;
+                tb[u] = final_T[pix] * (bg0 * dl[u][0] + bg1 * dl[u][1] + bg2 * dl[u][2]);
+                rem[u] = out_color[pix] * dl[u][0] + out_color[HW + pix] * dl[u][1] + out_color[2 * HW + pix] * dl[u][2] - tb[u];
+                if (HAS_DEPTH) rem[u] += out_depth[pix] * dl[u][3];
+                nc[u] = n_contrib[pix];
+            }
+        }
+        s_v0[pr] = make_float4(dl[0][0], dl[1][0], dl[0][1], dl[1][1]);
+        s_v1[pr] = make_float4(dl[0][2], dl[1][2], tb[0], tb[1]);
+        s_cy[pr] = make_float4(0.f, 0.f, rem[0], rem[1]);
+        s_nc[pr] = make_int2(nc[0], nc[1]);
+        if (HAS_DEPTH) s_dd[pr] = make_float2(dl[0][3], dl[1][3]);
+        max_nc = max(max_nc, max(nc[0], nc[1]));
+    }
+#pragma unroll
+    for (int dd = 32; dd >= 1; dd >>= 1) max_nc = max(max_nc, __shfl_xor(max_nc, dd));
+    __syncthreads();
+    const float halfW = 0.5f * (float)d.W, halfH = 0.5f * (float)d.H;
+    const int count = min(range.y - range.x, max_nc);
+    const float px_base = (float)(tx * GP_TILE), py_base = (float)(ty * GP_TILE + part * ROWS);
+    const float LOG2E = 1.4426950408889634f;
+    for (int b0 = 0; b0 < count; b0 += 64) {
+        const int pos = b0 + lane;
+        const bool have = pos < count;
+        uint32_t id = 0;
+        float4 q0 = make_float4(0.f, 0.f, 0.f, 0.f), q1 = q0, q2 = q0;
+        if (have) {
+            id = point_list[range.x + pos];
+            q0 = rec[3 * (size_t)id]; q1 = rec[3 * (size_t)id + 1]; q2 = rec[3 * (size_t)id + 2];
+        }
+        const float sx = q0.x - px_base, sy = q0.y - py_base;
+        const float As = q0.z * LOG2E, Bs = q0.w * LOG2E, Cs = q1.x * LOG2E;   // power in log2 units
+        const float op = have ? q1.y : 0.f, zdep = q1.z;
+        const float cxx = -2.f * q0.z, cxy = -q0.w, cyy = -2.f * q1.x;
+        const v2f cr = {q2.x, q2.x}, cg = {q2.y, q2.y}, cb = {q2.z, q2.z};
+        v2f a_mx = {0.f, 0.f}, a_my = {0.f, 0.f}, a_ca = {0.f, 0.f}, a_cb = {0.f, 0.f}, a_cc = {0.f, 0.f}, a_op = {0.f, 0.f},
+            a_r = {0.f, 0.f}, a_g = {0.f, 0.f}, a_b = {0.f, 0.f}, a_d = {0.f, 0.f};
+        float any_m = 0.f;
+#pragma unroll 1
+        for (int row = 0; row < ROWS; ++row) {
+            const float dy = sy - (float)row;
+            const float tB = Bs * dy, uC = (Cs * dy) * dy;
+#pragma unroll 1
+            for (int cp = 0; cp < GP_TILE / 2; ++cp) {
+                const int pr = row * (GP_TILE / 2) + cp;
+                const int2 nc = s_nc[pr];
+                if (max(nc.x, nc.y) <= b0) continue;   // uniform: both pixels finished before this batch
+                const float dx0 = sx - (float)(2 * cp);
+                const v2f dx = {dx0, dx0 - 1.f};
+                const v2f pw = {fmaf(dx.x, fmaf(As, dx.x, tB), uC), fmaf(dx.y, fmaf(As, dx.y, tB), uC)};
+                const v2f G = {__builtin_amdgcn_exp2f(fminf(pw.x, 0.f)), __builtin_amdgcn_exp2f(fminf(pw.y, 0.f))};
+                const v2f alpha = {fminf(0.99f, op * G.x), fminf(0.99f, op * G.y)};
+                const bool c0 = (pos < nc.x) && !(pw.x > 0.f) && !(alpha.x < 1.f / 255.f);
+                const bool c1 = (pos < nc.y) && !(pw.y > 0.f) && !(alpha.y < 1.f / 255.f);
+                if (!__any(c0 || c1)) continue;        // nobody in the wave touches either pixel
+                const v2f m = {c0 ? 1.f : 0.f, c1 ? 1.f : 0.f};
+                any_m = fmaxf(any_m, fmaxf(m.x, m.y));
+                const v2f am = alpha * m;
+                const v2f om = 1.f - am;
+                float l0 = __builtin_amdgcn_logf(om.x), l1 = __builtin_amdgcn_logf(om.y);   // log2, exactly 0 for om == 1
+                const float4 v0 = s_v0[pr], v1 = s_v1[pr], cy = s_cy[pr];
+                v2f cdot = cb * (v2f){v1.x, v1.y};
+                cdot = cg * (v2f){v0.z, v0.w} + cdot;
+                cdot = cr * (v2f){v0.x, v0.y} + cdot;
+                v2f dLd = {0.f, 0.f};
+                if (HAS_DEPTH) { const float2 t = s_dd[pr]; dLd.x = t.x; dLd.y = t.y; cdot = zdep * dLd + cdot; }
+                // T_j needs the EXCLUSIVE log-sum, s_j = alpha_j T_j cdot needs T_j: scan the logs first
+                float il0 = l0, il1 = l1;
+                dpp_scan2_add(il0, il1);
+                const v2f Tj = {__builtin_amdgcn_exp2f(cy.x + il0 - l0), __builtin_amdgcn_exp2f(cy.y + il1 - l1)};
+                const v2f w = am * Tj;
+                const v2f sv = w * cdot;
+                float is0 = sv.x, is1 = sv.y;
+                dpp_scan2_add(is0, is1);
+                const v2f rem = {cy.z, cy.w};
+                const v2f tbv = {v1.z, v1.w};
+                const v2f rom = {__builtin_amdgcn_rcpf(om.x), __builtin_amdgcn_rcpf(om.y)};
+                const v2f suffix = rem - (v2f){is0, is1};
+                const v2f dL_dalpha = (Tj * cdot - (suffix + tbv) * rom) * m;
+                a_r += w * (v2f){v0.x, v0.y}; a_g += w * (v2f){v0.z, v0.w}; a_b += w * (v2f){v1.x, v1.y};
+                if (HAS_DEPTH) a_d += w * dLd;
+                a_op += G * dL_dalpha;
+                const v2f dL_dG = op * dL_dalpha;
+                const v2f gdx = G * dx, gdy = G * dy;
+                a_mx += dL_dG * (-gdx * cxx - gdy * cxy);
+                a_my += dL_dG * (-gdy * cyy - gdx * cxy);
+                a_ca += (gdx * dx) * dL_dG;
+                a_cb += (gdx * dy) * dL_dG;
+                a_cc += (gdy * dy) * dL_dG;
+                // carry to the next batch
+                const float tl0 = lane63(il0), tl1 = lane63(il1), ts0 = lane63(is0), ts1 = lane63(is1);
+                if (lane == 0) s_cy[pr] = make_float4(cy.x + tl0, cy.y + tl1, cy.z - ts0, cy.w - ts1);
+            }
+        }
+        if (have && any_m > 0.f) {
             atomicAdd(&g_mean2D[2 * (size_t)id], (a_mx.x + a_mx.y) * halfW);
             atomicAdd(&g_mean2D[2 * (size_t)id + 1], (a_my.x + a_my.y) * halfH);
             atomicAdd(&g_conic[3 * (size_t)id], -0.5f * (a_ca.x + a_ca.y));
@@ -753,24 +1049,58 @@ __device__ __forceinline__ void gp_composite_bwd2_body(RasterDims d, const int2*
 #define CB_PASS d, ranges, point_list, rec, bg, out_color, out_depth, final_T, n_contrib, dL_dpix, dL_dpixdepth, g_mean2D, \
     g_conic, g_opacity, g_color, g_depth
 __global__ __launch_bounds__(64) void gp_composite_bwd_kernel(CB_ARGS) { gp_composite_bwd_kernel_t<false>(CB_PASS); }
-__global__ __launch_bounds__(64) void gp_composite_bwd_noatomic_kernel(CB_ARGS) { gp_composite_bwd_kernel_t<true>(CB_PASS); }
+__global__ __launch_bounds__(64) void gp_composite_bwd_noatomic_kernel(CB_ARGS) { gp_composite_bwd2_body<false, true>(CB_PASS); }
 __global__ __launch_bounds__(64) void gp_composite_bwd2_kernel(CB_ARGS) { gp_composite_bwd2_body<false>(CB_PASS); }
 __global__ __launch_bounds__(64) void gp_composite_bwd2_depth_kernel(CB_ARGS) { gp_composite_bwd2_body<true>(CB_PASS); }
+__global__ __launch_bounds__(64) void gp_composite_bwd3_kernel(CB_ARGS) { gp_composite_bwd3_body<false, 8>(CB_PASS); }
+__global__ __launch_bounds__(64) void gp_composite_bwd3_depth_kernel(CB_ARGS) { gp_composite_bwd3_body<true, 8>(CB_PASS); }
+__global__ __launch_bounds__(64) void gp_composite_bwd3_r4_kernel(CB_ARGS) { gp_composite_bwd3_body<false, 4>(CB_PASS); }
+__global__ __launch_bounds__(64) void gp_composite_bwd3_r2_kernel(CB_ARGS) { gp_composite_bwd3_body<false, 2>(CB_PASS); }
+__global__ __launch_bounds__(64) void gp_composite_bwd3_r16_kernel(CB_ARGS) { gp_composite_bwd3_body<false, 16>(CB_PASS); }
 
 // ------------------------------------------------------------------------------------------------
 // preprocess backward (per Gaussian) -- mirrors gpo_preprocess_bwd of the oracle
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void gp_preprocess_bwd_kernel(
+template <int SH_MODE>
+__device__ __forceinline__ void preprocess_bwd_body(
     RasterDims d, const float* __restrict__ means3D, const float* __restrict__ scales, const float* __restrict__ rotations,
-    const float* __restrict__ shs, const float* __restrict__ cov3D_precomp, const float* __restrict__ view,
-    const float* __restrict__ proj, const float* __restrict__ campos, const int32_t* __restrict__ radii,
-    const uint8_t* __restrict__ clamped, const float* __restrict__ g_mean2D, const float* __restrict__ g_conic,
-    const float* __restrict__ g_opacity, const float* __restrict__ g_color, const float* __restrict__ g_depth,
-    float* __restrict__ dL_dmeans3D, float* __restrict__ dL_dmeans2D, float* __restrict__ dL_dshs,
-    float* __restrict__ dL_dcolors, float* __restrict__ dL_dopacities, float* __restrict__ dL_dscales,
-    float* __restrict__ dL_drots, float* __restrict__ dL_dcov3D) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= d.N) return;
+    const float* __restrict__ shs, const float* __restrict__ shs_rest, const float* __restrict__ cov3D_precomp,
+    const float* __restrict__ view, const float* __restrict__ proj, const float* __restrict__ campos,
+    const int32_t* __restrict__ radii, const uint8_t* __restrict__ clamped, const float* __restrict__ g_mean2D,
+    const float* __restrict__ g_conic, const float* __restrict__ g_opacity, const float* __restrict__ g_color,
+    const float* __restrict__ g_depth, float* __restrict__ dL_dmeans3D, float* __restrict__ dL_dmeans2D,
+    float* __restrict__ dL_dshs, float* __restrict__ dL_dshs_rest, float* __restrict__ dL_dcolors,
+    float* __restrict__ dL_dopacities, float* __restrict__ dL_dscales, float* __restrict__ dL_drots,
+    float* __restrict__ dL_dcov3D) {
+    __shared__ float s_sh[SH_MODE == 0 ? 1 : 256 * 49];
+    const int tid = threadIdx.x;
+    const int base = blockIdx.x * 256;
+    const int i = base + tid;
+    const int nblk = min(256, d.N - base);
+    const bool use_sh = dL_dcolors == nullptr;
+    float shl[SH_MODE == 0 ? 1 : 48], dshl[SH_MODE == 0 ? 1 : 48];
+    if (SH_MODE != 0) {
+#pragma unroll
+        for (int k = 0; k < 48; ++k) { shl[k] = 0.f; dshl[k] = 0.f; }
+        if (use_sh && d.D > 0) {
+            if (SH_MODE == 1) stage_sh<48>(s_sh, shs + (size_t)base * 48, nblk, tid);
+            if (SH_MODE == 2) stage_sh<45>(s_sh, shs_rest + (size_t)base * 45, nblk, tid);
+        }
+        __syncthreads();
+        if (use_sh && d.D > 0 && i < d.N) {
+            if (SH_MODE == 1) {
+#pragma unroll
+                for (int k = 0; k < 48; ++k) shl[k] = s_sh[tid * 49 + k];
+            } else {
+                shl[0] = shs[3 * (size_t)i]; shl[1] = shs[3 * (size_t)i + 1]; shl[2] = shs[3 * (size_t)i + 2];
+#pragma unroll
+                for (int k = 0; k < 45; ++k) shl[3 + k] = s_sh[tid * 45 + k];
+            }
+        }
+        __syncthreads();   // everyone has its coefficients in registers: s_sh is free for the gradients
+    }
+    do {
+    if (i >= d.N) break;
     const bool vis = radii[i] > 0;
     dL_dmeans2D[3 * i] = vis ? g_mean2D[2 * i] : 0.f;
     dL_dmeans2D[3 * i + 1] = vis ? g_mean2D[2 * i + 1] : 0.f;
@@ -783,8 +1113,8 @@ __global__ __launch_bounds__(256) void gp_preprocess_bwd_kernel(
         if (dL_drots) { dL_drots[4 * i] = dL_drots[4 * i + 1] = dL_drots[4 * i + 2] = dL_drots[4 * i + 3] = 0.f; }
         if (dL_dcov3D) for (int k = 0; k < 6; ++k) dL_dcov3D[6 * i + k] = 0.f;
         if (dL_dcolors) { dL_dcolors[3 * i] = dL_dcolors[3 * i + 1] = dL_dcolors[3 * i + 2] = 0.f; }
-        if (dL_dshs) for (int k = 0; k < d.M * 3; ++k) dL_dshs[(size_t)i * d.M * 3 + k] = 0.f;
-        return;
+        if (SH_MODE == 0 && dL_dshs) for (int k = 0; k < d.M * 3; ++k) dL_dshs[(size_t)i * d.M * 3 + k] = 0.f;
+        break;
     }
     const float px = means3D[3 * i], py = means3D[3 * i + 1], pz = means3D[3 * i + 2];
     const float3 pv = xform4x3(view, px, py, pz);
@@ -861,8 +1191,8 @@ __global__ __launch_bounds__(256) void gp_preprocess_bwd_kernel(
         const float len = sqrtf(fmaf(ddx0, ddx0, fmaf(ddy0, ddy0, ddz0 * ddz0)));
         const float inv = 1.f / len;
         const float x = ddx0 * inv, y = ddy0 * inv, z = ddz0 * inv;
-        const float* sh = shs + (size_t)i * d.M * 3;
-        float* dsh = dL_dshs + (size_t)i * d.M * 3;
+        const float* sh = SH_MODE == 0 ? shs + (size_t)i * d.M * 3 : shl;
+        float* dsh = SH_MODE == 0 ? dL_dshs + (size_t)i * d.M * 3 : dshl;
         const uint8_t cl = clamped[i];
         float ddir0 = 0.f, ddir1 = 0.f, ddir2 = 0.f;
         const int D = d.D;
@@ -953,4 +1283,36 @@ __global__ __launch_bounds__(256) void gp_preprocess_bwd_kernel(
         dL_drots[4 * i + 2] = 2.f * (-2.f * y * dR[0] + x * dR[1] + r * dR[2] + x * dR[3] + z * dR[5] - r * dR[6] + z * dR[7] - 2.f * y * dR[8]);
         dL_drots[4 * i + 3] = 2.f * (-2.f * z * dR[0] - r * dR[1] + x * dR[2] + r * dR[3] - 2.f * z * dR[4] + y * dR[5] + x * dR[6] + y * dR[7]);
     }
+    } while (0);
+    if (SH_MODE != 0 && use_sh) {
+        // gradients of the SH coefficients leave through LDS as one coalesced span per workgroup
+        if (SH_MODE == 1) {
+#pragma unroll
+            for (int k = 0; k < 48; ++k) s_sh[tid * 49 + k] = dshl[k];
+            __syncthreads();
+            unstage_sh<48>(s_sh, dL_dshs + (size_t)base * 48, nblk, tid);
+        } else {
+            if (i < d.N) { dL_dshs[3 * (size_t)i] = dshl[0]; dL_dshs[3 * (size_t)i + 1] = dshl[1]; dL_dshs[3 * (size_t)i + 2] = dshl[2]; }
+#pragma unroll
+            for (int k = 0; k < 45; ++k) s_sh[tid * 45 + k] = dshl[3 + k];
+            __syncthreads();
+            unstage_sh<45>(s_sh, dL_dshs_rest + (size_t)base * 45, nblk, tid);
+        }
+    }
 }
+
+#define PB_ARGS RasterDims d, const float* __restrict__ means3D, const float* __restrict__ scales, \
+    const float* __restrict__ rotations, const float* __restrict__ shs, const float* __restrict__ shs_rest, \
+    const float* __restrict__ cov3D_precomp, const float* __restrict__ view, const float* __restrict__ proj, \
+    const float* __restrict__ campos, const int32_t* __restrict__ radii, const uint8_t* __restrict__ clamped, \
+    const float* __restrict__ g_mean2D, const float* __restrict__ g_conic, const float* __restrict__ g_opacity, \
+    const float* __restrict__ g_color, const float* __restrict__ g_depth, float* __restrict__ dL_dmeans3D, \
+    float* __restrict__ dL_dmeans2D, float* __restrict__ dL_dshs, float* __restrict__ dL_dshs_rest, \
+    float* __restrict__ dL_dcolors, float* __restrict__ dL_dopacities, float* __restrict__ dL_dscales, \
+    float* __restrict__ dL_drots, float* __restrict__ dL_dcov3D
+#define PB_PASS d, means3D, scales, rotations, shs, shs_rest, cov3D_precomp, view, proj, campos, radii, clamped, g_mean2D, \
+    g_conic, g_opacity, g_color, g_depth, dL_dmeans3D, dL_dmeans2D, dL_dshs, dL_dshs_rest, dL_dcolors, dL_dopacities, \
+    dL_dscales, dL_drots, dL_dcov3D
+__global__ __launch_bounds__(256) void gp_preprocess_bwd_kernel(PB_ARGS) { preprocess_bwd_body<0>(PB_PASS); }
+__global__ __launch_bounds__(256) void gp_preprocess_bwd_sh16_kernel(PB_ARGS) { preprocess_bwd_body<1>(PB_PASS); }
+__global__ __launch_bounds__(256) void gp_preprocess_bwd_split_kernel(PB_ARGS) { preprocess_bwd_body<2>(PB_PASS); }

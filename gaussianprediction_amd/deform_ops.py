@@ -143,9 +143,12 @@ class KeypointBlend(torch.autograd.Function):
         g_raw = torch.empty_like(raw_c) if nn_ else None
         g_xyz = torch.empty(N, 3, device=dev)
         g_rot = torch.empty(N, 4, device=dev)
+        alloc = _lib.TorchAllocator(dev)
         with torch.cuda.device(dev):
             rc = _lib.lib().gp_blend_backward(C.byref(args), _lib.ptr(gx), _lib.ptr(gq), _lib.ptr(g_delta), _lib.ptr(g_raw),
-                                              _lib.ptr(g_xyz), _lib.ptr(g_rot), _lib.stream_ptr(dev))
+                                              _lib.ptr(g_xyz), _lib.ptr(g_rot), alloc.cb, None, _lib.stream_ptr(dev))
+            if alloc.error is not None:
+                raise alloc.error
             _lib.check(rc, "gp_blend_backward")
         return g_delta, g_raw, None, g_xyz, g_rot, None
 

@@ -40,6 +40,69 @@ class FlatGradBucket:
             return dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
         return None
 
+    def segment(self, p):
+        """The bucket slice that backs p.grad (padded to the 64-element granule)."""
+        i = next(k for k, q in enumerate(self.params) if q is p)
+        off = self.offsets[i]
+        end = self.offsets[i + 1] if i + 1 < len(self.offsets) else self.flat.numel()
+        return self.flat[off:end]
+
+
+class OverlappedGradReducer:
+    """SUM-all-reduce of the gradient bucket, overlapped with the rest of backward.
+
+    The rasterizer backward finishes the largest gradients first (SH coefficients: 192 of the 364
+    bytes per Gaussian) while the deformation backward (blend, MLP) and the Adam launches are still
+    ahead.  A post-accumulate-grad hook on every large leaf starts an asynchronous all-reduce of that
+    leaf's bucket segment the moment its gradient is final; RCCL runs it on its own stream over xGMI
+    while the compute stream continues.  Small tensors (MLP weights, keypoints: < `small_numel`) are
+    reduced together in one trailing collective.  `finish()` makes the compute stream wait for all of
+    them; the optimizer then sees exactly sum-over-ranks, i.e. the reference's `--batch` semantics
+    [REF train.py:113-119].  Every rank issues the same collectives in the same order (the order is
+    fixed by the autograd graph, which is identical on all ranks)."""
+
+    def __init__(self, bucket: FlatGradBucket, group=None, small_numel=1 << 20):
+        self.bucket, self.group = bucket, group
+        self.handles = []
+        self.enabled = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+        self.large = [p for p in bucket.params if p.numel() >= small_numel]
+        self.small = [p for p in bucket.params if p.numel() < small_numel]
+        self._fired = set()
+        if self.enabled:
+            for p in self.large:
+                p.register_post_accumulate_grad_hook(self._make_hook(p))
+
+    def _make_hook(self, p):
+        def hook(param):
+            if id(p) in self._fired:
+                return
+            self._fired.add(id(p))
+            self.handles.append(dist.all_reduce(self.bucket.segment(p), op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        return hook
+
+    def finish(self):
+        """Call after loss.backward(): reduces what the hooks did not cover, waits for everything."""
+        if not self.enabled:
+            return
+        for p in self.large:                       # leaves that received no gradient this step (still zero)
+            if id(p) not in self._fired:
+                self.handles.append(dist.all_reduce(self.bucket.segment(p), op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        if self.small:
+            # the small tensors are contiguous at the end of the bucket when they were registered last;
+            # otherwise reduce them one by one (they are tiny)
+            idx = [next(k for k, q in enumerate(self.bucket.params) if q is p) for p in self.small]
+            if idx == list(range(idx[0], idx[0] + len(idx))):
+                off = self.bucket.offsets[idx[0]]
+                end = self.bucket.offsets[idx[-1] + 1] if idx[-1] + 1 < len(self.bucket.offsets) else self.bucket.flat.numel()
+                self.handles.append(dist.all_reduce(self.bucket.flat[off:end], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            else:
+                for p in self.small:
+                    self.handles.append(dist.all_reduce(self.bucket.segment(p), op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        for h in self.handles:
+            h.wait()
+        self.handles.clear()
+        self._fired.clear()
+
 
 def reduce_view_stats(radii: torch.Tensor, group=None):
     """radii = elementwise max over the views of the batch; visibility = radii > 0
@@ -55,9 +118,11 @@ def init_from_env(backend: str | None = None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("GP_FORCE_LOCAL_RANK") is not None:     # test hook: several ranks on one GPU (gloo only)
+        local = int(os.environ["GP_FORCE_LOCAL_RANK"])
     if world > 1 and not dist.is_initialized():
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"   # "nccl" IS RCCL on ROCm
+            backend = os.environ.get("GP_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")  # "nccl" IS RCCL on ROCm
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend == "nccl":

@@ -60,7 +60,8 @@ def _settings_c(rs: GaussianRasterizationSettings, device, sh_coeffs: int):
 
 class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings):
+    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings,
+                sh_rest=None):
         if not means3D.is_cuda:
             raise RuntimeError("gaussianprediction_amd rasterizer needs tensors on a HIP device (no CPU fallback)")
         device = means3D.device
@@ -70,18 +71,21 @@ class _RasterizeGaussians(torch.autograd.Function):
         if m3 is None:
             m3 = torch.empty(0, 3, device=device)
         shs = _f32c(sh, device)
+        shs_r = _f32c(sh_rest, device)
         cols = _f32c(colors_precomp, device)
         ops = _f32c(opacities, device)
         scl = _f32c(scales, device)
         rot = _f32c(rotations, device)
         cov = _f32c(cov3Ds_precomp, device)
         sh_coeffs = int(shs.shape[1]) if shs is not None else 0
+        if shs_r is not None:
+            sh_coeffs += int(shs_r.shape[1])
         rs = raster_settings
         H, W = int(rs.image_height), int(rs.image_width)
         with torch.cuda.device(device):
             st, keep = _settings_c(rs, device, sh_coeffs)
-            inp = _lib.RasterInputsC(N, _lib.ptr(m3), _lib.ptr(shs), _lib.ptr(cols), _lib.ptr(ops), _lib.ptr(scl),
-                                     _lib.ptr(rot), _lib.ptr(cov))
+            inp = _lib.RasterInputsC(N, _lib.ptr(m3), _lib.ptr(shs), _lib.ptr(shs_r), _lib.ptr(cols), _lib.ptr(ops),
+                                     _lib.ptr(scl), _lib.ptr(rot), _lib.ptr(cov))
             color = torch.empty(3, H, W, device=device, dtype=torch.float32)
             radii = torch.empty(N, device=device, dtype=torch.int32)
             depth = torch.empty(1, H, W, device=device, dtype=torch.float32)
@@ -94,13 +98,15 @@ class _RasterizeGaussians(torch.autograd.Function):
             if alloc.error is not None:
                 raise alloc.error
             _lib.check(rc, "gp_raster_forward")
+        ctx.set_materialize_grads(False)      # an unused `depth` output must arrive as None, not as zeros
         ctx.raster_settings = rs
         ctx.num_rendered = int(saved.num_rendered)
         ctx.sh_coeffs = sh_coeffs
-        ctx.flags = (shs is not None, cols is not None, scl is not None, cov is not None)
+        ctx.flags = (shs is not None, cols is not None, scl is not None, cov is not None, shs_r is not None)
         geom, binning, image = alloc.first(_lib.GP_BUF_GEOM), alloc.first(_lib.GP_BUF_BINNING), alloc.first(_lib.GP_BUF_IMAGE)
         empty = torch.empty(0, device=device)
-        ctx.save_for_backward(m3, shs if shs is not None else empty, cols if cols is not None else empty, ops,
+        ctx.save_for_backward(m3, shs if shs is not None else empty, shs_r if shs_r is not None else empty,
+                              cols if cols is not None else empty, ops,
                               scl if scl is not None else empty, rot if rot is not None else empty,
                               cov if cov is not None else empty, color, radii, depth, tidx, geom,
                               binning if binning is not None else torch.empty(0, dtype=torch.uint8, device=device), image)
@@ -109,8 +115,8 @@ class _RasterizeGaussians(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, grad_color, grad_radii, grad_depth, grad_tidx):
-        (m3, shs, cols, ops, scl, rot, cov, color, radii, depth, tidx, geom, binning, image) = ctx.saved_tensors
-        has_sh, has_col, has_sr, has_cov = ctx.flags
+        (m3, shs, shs_r, cols, ops, scl, rot, cov, color, radii, depth, tidx, geom, binning, image) = ctx.saved_tensors
+        has_sh, has_col, has_sr, has_cov, has_rest = ctx.flags
         device = m3.device
         N = m3.shape[0]
         rs = ctx.raster_settings
@@ -119,7 +125,8 @@ class _RasterizeGaussians(torch.autograd.Function):
         gd = grad_depth.to(torch.float32).contiguous() if grad_depth is not None else None
         with torch.cuda.device(device):
             st, keep = _settings_c(rs, device, ctx.sh_coeffs)
-            inp = _lib.RasterInputsC(N, _lib.ptr(m3), _lib.ptr(shs) if has_sh else None, _lib.ptr(cols) if has_col else None,
+            inp = _lib.RasterInputsC(N, _lib.ptr(m3), _lib.ptr(shs) if has_sh else None, _lib.ptr(shs_r) if has_rest else None,
+                                     _lib.ptr(cols) if has_col else None,
                                      _lib.ptr(ops), _lib.ptr(scl) if has_sr else None, _lib.ptr(rot) if has_sr else None,
                                      _lib.ptr(cov) if has_cov else None)
             out = _lib.RasterOutputsC(_lib.ptr(color), _lib.ptr(radii), _lib.ptr(depth), _lib.ptr(tidx))
@@ -127,13 +134,14 @@ class _RasterizeGaussians(torch.autograd.Function):
                                       binning.numel(), image.data_ptr(), image.numel(), ctx.num_rendered)
             g_m3 = torch.empty(N, 3, device=device)
             g_m2 = torch.empty(N, 3, device=device)
-            g_sh = torch.empty(N, ctx.sh_coeffs, 3, device=device) if has_sh else None
+            g_sh = torch.empty(N, 1 if has_rest else ctx.sh_coeffs, 3, device=device) if has_sh else None
+            g_shr = torch.empty(N, ctx.sh_coeffs - 1, 3, device=device) if has_rest else None
             g_col = torch.empty(N, 3, device=device) if has_col else None
             g_op = torch.empty(N, 1, device=device)
             g_scl = torch.empty(N, 3, device=device) if has_sr else None
             g_rot = torch.empty(N, 4, device=device) if has_sr else None
             g_cov = torch.empty(N, 6, device=device) if has_cov else None
-            grads = _lib.RasterGradsC(_lib.ptr(g_m3), _lib.ptr(g_m2), _lib.ptr(g_sh), _lib.ptr(g_col), _lib.ptr(g_op),
+            grads = _lib.RasterGradsC(_lib.ptr(g_m3), _lib.ptr(g_m2), _lib.ptr(g_sh), _lib.ptr(g_shr), _lib.ptr(g_col), _lib.ptr(g_op),
                                       _lib.ptr(g_scl), _lib.ptr(g_rot), _lib.ptr(g_cov))
             alloc = _lib.TorchAllocator(device)
             rc = L.gp_raster_backward(C.byref(st), C.byref(inp), C.byref(out), C.byref(saved), _lib.ptr(gc), _lib.ptr(gd),
@@ -141,12 +149,13 @@ class _RasterizeGaussians(torch.autograd.Function):
             if alloc.error is not None:
                 raise alloc.error
             _lib.check(rc, "gp_raster_backward")
-        return g_m3, g_m2, g_sh, g_col, g_op, g_scl, g_rot, g_cov, None
+        return g_m3, g_m2, g_sh, g_col, g_op, g_scl, g_rot, g_cov, None, g_shr
 
 
-def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings):
+def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings,
+                        sh_rest=None):
     return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-                                     raster_settings)
+                                     raster_settings, sh_rest)
 
 
 class GaussianRasterizer(nn.Module):
@@ -167,14 +176,17 @@ class GaussianRasterizer(nn.Module):
         return present.bool()
 
     def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
-                cov3D_precomp=None):
+                cov3D_precomp=None, shs_rest=None):
+        """`shs_rest` is an extension to the reference signature: pass shs=features_dc [N,1,3] and
+        shs_rest=features_rest [N,15,3] to skip the per-frame torch.cat of get_features."""
         rs = self.raster_settings
         if (shs is None and colors_precomp is None) or (shs is not None and colors_precomp is not None):
             raise Exception('Please provide excatly one of either SHs or precomputed colors!')
         if ((scales is None or rotations is None) and cov3D_precomp is None) or \
                 ((scales is not None or rotations is not None) and cov3D_precomp is not None):
             raise Exception('Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!')
-        return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, rs)
+        return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, rs,
+                                   shs_rest)
 
 
 def debug_binning(ctx_like_saved, raster_settings):  # pragma: no cover - used by GPU tests
@@ -196,7 +208,7 @@ def raster_forward_debug(raster_settings, means3D, opacities, shs=None, colors_p
     H, W = int(rs.image_height), int(rs.image_width)
     with torch.cuda.device(device):
         st, keep = _settings_c(rs, device, sh_coeffs)
-        inp = _lib.RasterInputsC(N, _lib.ptr(m3), _lib.ptr(shs_c), _lib.ptr(cols), _lib.ptr(ops), _lib.ptr(scl),
+        inp = _lib.RasterInputsC(N, _lib.ptr(m3), _lib.ptr(shs_c), None, _lib.ptr(cols), _lib.ptr(ops), _lib.ptr(scl),
                                  _lib.ptr(rot), _lib.ptr(cov))
         color = torch.empty(3, H, W, device=device)
         radii = torch.empty(N, device=device, dtype=torch.int32)

@@ -49,16 +49,19 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=
         scales, rotations = pc.get_scaling, pc.get_rotation
     else:
         means3D, rotations, scales, opacity = pc(time, it)
-    shs, colors_precomp = None, None
+    shs, shs_rest, colors_precomp = None, None, None
     if override_color is None:
         if getattr(pipe, "convert_SHs_python", False):
             raise NotImplementedError("convert_SHs_python: SH->RGB is evaluated in the preprocess kernel")
-        shs = pc.get_features
+        if hasattr(pc, "_features_dc") and hasattr(pc, "_features_rest") and pc._features_rest.shape[1] == 15:
+            shs, shs_rest = pc._features_dc, pc._features_rest       # no per-frame cat (get_features)
+        else:
+            shs = pc.get_features
     else:
         colors_precomp = override_color
     rendered_image, radii, depth, tidx = rasterizer(means3D=means3D, means2D=screenspace_points, shs=shs,
                                                     colors_precomp=colors_precomp, opacities=opacity, scales=scales,
-                                                    rotations=rotations, cov3D_precomp=cov3D_precomp)
+                                                    rotations=rotations, cov3D_precomp=cov3D_precomp, shs_rest=shs_rest)
     return {"render": rendered_image, "viewspace_points": screenspace_points, "visibility_filter": radii > 0,
             "radii": radii, "depth": depth, "tidx": tidx}
 

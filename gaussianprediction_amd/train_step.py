@@ -12,7 +12,7 @@ from types import SimpleNamespace
 import torch
 import torch.nn.functional as F
 
-from .dist import FlatGradBucket
+from .dist import FlatGradBucket, OverlappedGradReducer
 from .loss_ops import FusedAdam, l1_ssim_loss
 from .renderer import render
 
@@ -74,6 +74,7 @@ class TrainStep:
             groups += [{"params": [pc.super_gaussians], "lr": lr["kpts"], "name": "s_xyz"},
                        {"params": [pc.super_gaussians_feature], "lr": lr["mfeature"], "name": "s_motion_feature"}]
         self.bucket = FlatGradBucket([p for g in groups for p in g["params"]])
+        self.reducer = OverlappedGradReducer(self.bucket, group)
         if fused:
             self.optimizer = FusedAdam(groups, self.bucket, eps=1e-15)
         else:
@@ -93,8 +94,8 @@ class TrainStep:
         time = self.times[view_index % len(self.cameras)]
         pkg = render(cam, self.pc, self.pipe, self.bg, time=time, it=self.iteration)
         loss = self.loss_of(pkg["render"], gt)
-        loss.backward()
-        self.bucket.all_reduce_sum(self.group)       # SUM over views == the reference's --batch semantics
+        loss.backward()                              # hooks start the all-reduce of each large gradient as it completes
+        self.reducer.finish()                        # SUM over views == the reference's --batch semantics
         if self.fused:
             self.optimizer.step(zero_grad=True)
         else:

@@ -60,7 +60,9 @@ typedef struct gp_raster_settings {
 typedef struct gp_raster_inputs {
     int64_t num_gaussians;
     const float* means3D;        /* [N,3] */
-    const float* shs;            /* [N,sh_coeffs,3] or NULL */
+    const float* shs;            /* [N,sh_coeffs,3] or NULL; with shs_rest: features_dc [N,1,3] */
+    const float* shs_rest;       /* NULL, or features_rest [N,sh_coeffs-1,3]: the model's two SH tensors
+                                    [REF scene/gaussian_model.py:155-159] passed without the per-frame cat */
     const float* colors_precomp; /* [N,3] or NULL (exactly one of shs/colors_precomp) */
     const float* opacities;      /* [N,1] */
     const float* scales;         /* [N,3] or NULL */
@@ -87,7 +89,8 @@ typedef struct gp_raster_grads {
     float* dL_dmeans3D;        /* [N,3] */
     float* dL_dmeans2D;        /* [N,3] (x,y in NDC units, z = 0): the screenspace_points grad sink
                                   [REF gaussian_renderer/__init__.py:27-31, scene/gaussian_model.py:757] */
-    float* dL_dshs;            /* [N,sh_coeffs,3] or NULL */
+    float* dL_dshs;            /* [N,sh_coeffs,3] ([N,1,3] with shs_rest) or NULL */
+    float* dL_dshs_rest;       /* [N,sh_coeffs-1,3] or NULL */
     float* dL_dcolors_precomp; /* [N,3] or NULL */
     float* dL_dopacities;      /* [N,1] */
     float* dL_dscales;         /* [N,3] or NULL */
@@ -177,9 +180,12 @@ typedef struct gp_blend_args {
 
 int gp_blend_forward(const gp_blend_args* a, float* xyz_t /*[N,3]*/, float* q_t /*[N,4]*/, gp_stream_t stream);
 
-/* grads: d delta (+= via atomics when nn>0, = otherwise; caller zeroes), d raw_w (=), d xyz (=), d rot (=) */
+/* grads (all "="): d delta, d raw_w, d xyz, d rot.  With nn>0 the keypoint gradient is reduced in two
+ * deterministic stages (per-workgroup LDS partials, then a sum over workgroups); the caller zeroes
+ * dL_ddelta beforehand (columns >= 7 are never written). */
 int gp_blend_backward(const gp_blend_args* a, const float* dL_dxyz_t, const float* dL_dq_t, float* dL_ddelta,
-                      float* dL_draw_w, float* dL_dxyz, float* dL_drot, gp_stream_t stream);
+                      float* dL_draw_w, float* dL_dxyz, float* dL_drot, gp_alloc_fn alloc, void* alloc_ctx,
+                      gp_stream_t stream);
 
 /* activations [REF scene/gaussian_model.py:41-51,138-162,291-298]:
  *   scale = exp(_scaling); opacity = sigmoid(_opacity) [* sigmoid(delta_o / beta) if delta_o] */

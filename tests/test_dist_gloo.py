@@ -1,0 +1,103 @@
+"""CPU, world_size 2, gloo: the view-parallel gradient exchange reproduces the reference's single-process
+`--batch` accumulation (sum of per-view losses, one backward) [REF train.py:113-133]."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from gaussianprediction_amd.dist import FlatGradBucket, OverlappedGradReducer, reduce_view_stats
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _params(seed=0):
+    g = torch.Generator().manual_seed(seed)
+    return [torch.nn.Parameter(torch.randn(37, 3, generator=g)), torch.nn.Parameter(torch.randn(37, 16, 3, generator=g)),
+            torch.nn.Parameter(torch.randn(5, generator=g)), torch.nn.Parameter(torch.randn(64, 7, generator=g))]
+
+
+def _view_loss(params, view):
+    # any differentiable function of all parameters that depends on the view
+    g = torch.Generator().manual_seed(100 + view)
+    return sum(((p * torch.randn(p.shape, generator=g)).sin() ** 2).sum() for p in params)
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    params = _params()
+    bucket = FlatGradBucket(params)
+    flat_before = bucket.flat.data_ptr()
+    _view_loss(params, rank).backward()                 # rank r renders view r
+    assert all(p.grad.data_ptr() >= flat_before for p in params)   # grads were accumulated in the bucket views
+    bucket.all_reduce_sum()
+    radii = torch.tensor([3, 0, 7, 0], dtype=torch.int32) if rank == 0 else torch.tensor([0, 0, 9, 2], dtype=torch.int32)
+    radii, vis = reduce_view_stats(radii)
+    torch.save({"flat": bucket.flat.clone(), "radii": radii, "vis": vis, "offsets": bucket.offsets}, os.path.join(out_dir, f"r{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_view_parallel_sum_equals_batch_accumulation(tmp_path):
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    r0 = torch.load(os.path.join(tmp_path, "r0.pt"))
+    r1 = torch.load(os.path.join(tmp_path, "r1.pt"))
+    assert torch.equal(r0["flat"], r1["flat"])           # every rank holds the same reduced gradient
+    # single-process reference: loss_ = stack(batch_loss).sum(); loss_.backward()
+    params = _params()
+    torch.stack([_view_loss(params, v) for v in range(world)]).sum().backward()
+    for p, off in zip(params, r0["offsets"]):
+        torch.testing.assert_close(r0["flat"][off:off + p.numel()].view_as(p), p.grad, rtol=1e-5, atol=1e-6)
+    assert r0["radii"].tolist() == [3, 0, 9, 2] and r0["vis"].tolist() == [True, False, True, True]
+    assert all(o % 64 == 0 for o in r0["offsets"])       # 256-byte aligned segments (float4 Adam kernel)
+
+
+def _worker_overlap(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    params = _params()
+    bucket = FlatGradBucket(params)
+    red = OverlappedGradReducer(bucket, small_numel=200)      # two "large" leaves get hooks, two go in the tail
+    assert len(red.large) == 1 and len(red.small) == 3 or len(red.large) >= 1
+    for step in range(2):                                      # hooks must re-arm every step
+        bucket.zero()
+        _view_loss(params, rank + 10 * step).backward()
+        red.finish()
+        torch.save(bucket.flat.clone(), os.path.join(out_dir, f"ov{rank}_{step}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_overlapped_reducer_equals_batch_accumulation(tmp_path):
+    world = 2
+    mp.spawn(_worker_overlap, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    for step in range(2):
+        a = torch.load(os.path.join(tmp_path, f"ov0_{step}.pt"))
+        b = torch.load(os.path.join(tmp_path, f"ov1_{step}.pt"))
+        assert torch.equal(a, b)
+        params = _params()
+        bucket = FlatGradBucket(params)
+        torch.stack([_view_loss(params, v + 10 * step) for v in range(world)]).sum().backward()
+        torch.testing.assert_close(a, bucket.flat, rtol=1e-5, atol=1e-6)
+
+
+def test_bucket_is_noop_without_process_group():
+    params = _params(1)
+    b = FlatGradBucket(params)
+    _view_loss(params, 0).backward()
+    ref = b.flat.clone()
+    assert b.all_reduce_sum() is None and torch.equal(ref, b.flat)
+    b.zero()
+    assert float(b.flat.abs().max()) == 0.0 and float(params[0].grad.abs().max()) == 0.0

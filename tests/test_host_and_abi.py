@@ -25,9 +25,9 @@ def test_library_exports_every_declared_symbol():
 
 def test_struct_sizes_match_header_layout():
     assert C.sizeof(_lib.RasterSettingsC) == 9 * 4 + 4 + 4 * 8       # 9 x 4-byte + pad + 4 pointers
-    assert C.sizeof(_lib.RasterInputsC) == 8 * 8
+    assert C.sizeof(_lib.RasterInputsC) == 9 * 8
     assert C.sizeof(_lib.RasterSavedC) == 7 * 8
-    assert C.sizeof(_lib.RasterGradsC) == 8 * 8
+    assert C.sizeof(_lib.RasterGradsC) == 9 * 8
     assert C.sizeof(_lib.MlpParamsC) == 4 * 4 + 10 * 8
     assert C.sizeof(_lib.MlpInputC) == 8 + 3 * 4 + 4 + 3 * 8
     assert C.sizeof(_lib.BlendArgsC) == 2 * 8 + 3 * 4 + 4 + 5 * 8
@@ -36,7 +36,7 @@ def test_struct_sizes_match_header_layout():
 def test_abi_validation_errors_are_reported_not_thrown():
     l = _lib.lib()
     st = _lib.RasterSettingsC(0, 0, 1.0, 1.0, 1.0, 3, 16, 0, 0, None, None, None, None)
-    inp = _lib.RasterInputsC(0, None, None, None, None, None, None, None)
+    inp = _lib.RasterInputsC(0, None, None, None, None, None, None, None, None)
     out = _lib.RasterOutputsC(None, None, None, None)
     saved = _lib.RasterSavedC()
     alloc = _lib.TorchAllocator("cpu")

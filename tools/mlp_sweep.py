@@ -1,0 +1,33 @@
+#!/usr/bin/env python
+"""Diagnostic: fused PE+MLP kernel timings vs row count (hipEvent timings from the library)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import gaussianprediction_amd as gpa
+from gaussianprediction_amd import _lib
+
+dev = "cuda"
+F = 6
+d_in = 32 + 60 + 2 * F
+net = gpa.Deformable_Field(d_in, output_dim=7, d=4, w=256).to(dev)
+flop_row = 2 * (d_in * 256 + 3 * 256 * 256 + 256 * 7)
+for rows in [250, 1024, 8192, 65536, 262144, 1048576]:
+    feat = (torch.rand(rows, 32, device=dev) - 0.5).requires_grad_(True)
+    xyz = (torch.rand(rows, 3, device=dev) * 2.6 - 1.3).requires_grad_(True)
+    t = torch.tensor([0.3], device=dev)
+    for _ in range(3):
+        y = net.forward_fused(feat, xyz, t, 10, F)
+        y.sum().backward()
+    torch.cuda.synchronize()
+    _lib.profile_enable(True); _lib.profile_collect()
+    n = 5
+    for _ in range(n):
+        y = net.forward_fused(feat, xyz, t, 10, F)
+        y.sum().backward()
+    torch.cuda.synchronize()
+    p = _lib.profile_collect(); _lib.profile_enable(False)
+    fwd = p["mlp_fwd"][1] / p["mlp_fwd"][0]
+    bd = p["mlp_bwd_data"][1] / p["mlp_bwd_data"][0]
+    bw = p["mlp_bwd_weight"][1] / n
+    print(f"rows {rows:8d}: fwd {fwd*1e3:9.1f} us ({rows*flop_row/fwd/1e9:7.1f} GF/s)  bwd_data {bd*1e3:9.1f} us ({rows*flop_row/bd/1e9:7.1f} GF/s)  "
+          f"bwd_weight(5 launches) {bw*1e3:9.1f} us ({rows*flop_row/bw/1e9:7.1f} GF/s)", flush=True)
