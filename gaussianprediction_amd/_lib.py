@@ -47,7 +47,7 @@ class RasterSavedC(C.Structure):
 class RasterGradsC(C.Structure):
     _fields_ = [("dL_dmeans3D", C.c_void_p), ("dL_dmeans2D", C.c_void_p), ("dL_dshs", C.c_void_p),
                 ("dL_dshs_rest", C.c_void_p), ("dL_dcolors_precomp", C.c_void_p), ("dL_dopacities", C.c_void_p), ("dL_dscales", C.c_void_p),
-                ("dL_drotations", C.c_void_p), ("dL_dcov3D_precomp", C.c_void_p)]
+                ("dL_drotations", C.c_void_p), ("dL_dcov3D_precomp", C.c_void_p), ("accumulate_shs", C.c_int32)]
 
 
 class MlpParamsC(C.Structure):
@@ -78,7 +78,8 @@ EXPORTS = [
     "gp_raster_forward", "gp_raster_backward", "gp_raster_mark_visible", "gp_raster_debug_binning",
     "gp_mlp_forward", "gp_mlp_backward", "gp_blend_forward", "gp_blend_backward",
     "gp_activations_forward", "gp_activations_backward", "gp_profile_enable", "gp_profile_collect",
-    "gp_loss_l1_ssim_forward", "gp_loss_l1_ssim_backward", "gp_adam_step",
+    "gp_loss_l1_ssim_forward", "gp_loss_l1_ssim_finalize", "gp_loss_l1_ssim_backward", "gp_adam_step",
+    "gp_adam_step_multi",
     "gp_last_error", "gp_version",
 ]
 
@@ -177,8 +178,10 @@ class TorchAllocator:
         return b[0] if b else None
 
 
-def profile_enable(on: bool) -> None:
-    check(lib().gp_profile_enable(C.c_int(1 if on else 0)), "gp_profile_enable")
+def profile_enable(level) -> None:
+    """0/False = off, 1 = only the roofline kernel (composite forward), 2/True = every kernel."""
+    level = 2 if level is True else int(level)
+    check(lib().gp_profile_enable(C.c_int(level)), "gp_profile_enable")
 
 
 def profile_collect() -> dict:

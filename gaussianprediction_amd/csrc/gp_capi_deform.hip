@@ -1,6 +1,7 @@
 // gp_capi_deform.hip -- extern "C" entry points of the deformation path (see include/gp_hip.h).
 #include "gp_common.h"
 #include "deform_kernels.h"
+#include <stdlib.h>
 
 static int make_mlp(const gp_mlp_params* p, const gp_mlp_input* x, MlpDev& m) {
     if (!p || !x) GP_FAIL("null mlp params/input");
@@ -64,13 +65,14 @@ extern "C" int gp_mlp_backward(const gp_mlp_params* p, const gp_mlp_input* x, co
     if (nrb_l < 1) nrb_l = 1;
     long rpb = ((m.rows + nrb_l - 1) / nrb_l + 15) & ~15L;
     const unsigned nrb = (unsigned)((m.rows + rpb - 1) / rpb);
+    GpProfScope _pw("mlp_bwd_weight", s);
     for (int l = 0; l < 5; ++l) {
         const float* dZl = l < 4 ? dz + (size_t)l * m.rows * 256 : dL_dout;
         const int n_out = l < 4 ? 256 : m.out_dim;
         const float* H = l == 0 ? sx : sh + (size_t)(l - 1) * m.rows * 256;
         const int ldh = l == 0 ? m.in_pad : 256;
         const int n_in = l == 0 ? m.in_dim : 256;
-        { GpProfScope _p("mlp_bwd_weight", s);
+        {
         hipLaunchKernelGGL(gp_mlp_bwd_weight_kernel, dim3(nrb, (unsigned)((n_in + 31) / 32), (unsigned)((n_out + 31) / 32)),
                            dim3(512), 0, s, dZl, n_out, H, ldh, n_in, m.rows, rpb, g->dw[l], n_in, g->db[l]);
         GP_LAUNCH_CHECK(); }
@@ -111,7 +113,8 @@ extern "C" int gp_blend_backward(const gp_blend_args* a, const float* dL_dxyz_t,
     if (b.N == 0) return 0;
     if (!dL_dxyz_t || !dL_dq_t || !dL_ddelta || !dL_dxyz || !dL_drot || (b.nn > 0 && !dL_draw_w)) GP_FAIL("null argument");
     unsigned blocks = gp_blocks((size_t)b.N, 256);
-    if (b.nn > 0 && blocks > 1024) blocks = 1024;
+    static const unsigned exp_blocks = getenv("GP_EXP_BLEND_BLOCKS") ? (unsigned)atoi(getenv("GP_EXP_BLEND_BLOCKS")) : 512u;
+    if (b.nn > 0 && blocks > exp_blocks) blocks = exp_blocks;
     const size_t lds = b.nn > 0 ? (size_t)b.K * 7 * sizeof(float) : 0;
     float* partial = nullptr;
     const int KA = (int)b.K * 7;
@@ -121,7 +124,8 @@ extern "C" int gp_blend_backward(const gp_blend_args* a, const float* dL_dxyz_t,
         if (!partial) GP_FAIL("allocator returned NULL for TEMP");
     }
     { GpProfScope _p("blend_bwd", (hipStream_t)stream_);
-    hipLaunchKernelGGL(b.nn == 6 ? gp_blend_bwd6_kernel : b.nn == 8 ? gp_blend_bwd8_kernel : gp_blend_bwd_kernel,
+    static const bool nolds = getenv("GP_EXP_BLEND_NOLDS") != nullptr;   // timing experiment only
+    hipLaunchKernelGGL((nolds && b.nn == 6) ? gp_blend_bwd6_nolds_kernel : b.nn == 6 ? gp_blend_bwd6_kernel : b.nn == 8 ? gp_blend_bwd8_kernel : gp_blend_bwd_kernel,
                        dim3(blocks), dim3(256), lds, (hipStream_t)stream_, b, dL_dxyz_t, dL_dq_t, dL_ddelta,
                        dL_draw_w, dL_dxyz, dL_drot, partial);
     GP_LAUNCH_CHECK();

@@ -183,7 +183,7 @@ extern "C" int gp_raster_forward(const gp_raster_settings* st, const gp_raster_i
         }
     }
     saved->num_rendered = (int64_t)R;
-    { GpProfScope _p("composite_fwd", s);
+    { GpProfScope _p("composite_fwd", s, 1);
         hipLaunchKernelGGL(gp_composite_fwd_kernel, dim3((unsigned)T), dim3(128), 0, s, d, il.ranges, point_list, gl.rec, st->bg,
                        out->color, out->depth, out->tidx, il.final_T, il.n_contrib);
     GP_LAUNCH_CHECK(); }
@@ -251,7 +251,8 @@ extern "C" int gp_raster_backward(const gp_raster_settings* st, const gp_raster_
                            in->shs_rest, in->cov3D_precomp, st->viewmatrix, st->projmatrix, st->campos, fwd->radii, gl.clamped,
                            g_mean2D, g_conic, g_opacity, g_color, g_depth, g->dL_dmeans3D, g->dL_dmeans2D, g->dL_dshs,
                            g->dL_dshs_rest, in->shs ? nullptr : g->dL_dcolors_precomp, g->dL_dopacities, g->dL_dscales,
-                           g->dL_drotations, g->dL_dcov3D_precomp);
+                           g->dL_drotations, g->dL_dcov3D_precomp, (kern != gp_preprocess_bwd_kernel) ? g->accumulate_shs : 0);
+        if (g->accumulate_shs && kern == gp_preprocess_bwd_kernel) GP_FAIL("accumulate_shs needs the staged SH kernels (16 coeffs, 16-byte aligned)");
         GP_LAUNCH_CHECK();
     }
     return 0;

@@ -60,11 +60,11 @@ __device__ __forceinline__ float gp_exp(float x) { return __builtin_amdgcn_exp2f
 
 // ---- optional kernel timing (gp_profile.hip) ----------------------------------------------------
 bool gp_prof_on();
-void* gp_prof_begin(const char* name, hipStream_t s);
+void* gp_prof_begin(const char* name, hipStream_t s, int level);
 void gp_prof_end(void* h, hipStream_t s);
 struct GpProfScope {
     void* h; hipStream_t s;
-    GpProfScope(const char* name, hipStream_t st) : h(gp_prof_begin(name, st)), s(st) {}
+    GpProfScope(const char* name, hipStream_t st, int level = 2) : h(gp_prof_begin(name, st, level)), s(st) {}
     ~GpProfScope() { gp_prof_end(h, s); }
 };
 

@@ -8,7 +8,7 @@
 
 struct ProfRec { const char* name; hipEvent_t a, b; };
 static std::mutex g_mu;
-static bool g_on = false;
+static int g_level = 0;   // 0 off, 1 = only the kernels tagged level 1 (roofline kernel), 2 = every kernel
 static std::vector<ProfRec> g_recs;
 static std::vector<hipEvent_t> g_pool;
 
@@ -19,10 +19,10 @@ static hipEvent_t take_event() {
     return e;
 }
 
-bool gp_prof_on() { return g_on; }
+bool gp_prof_on() { return g_level > 0; }
 
-void* gp_prof_begin(const char* name, hipStream_t s) {
-    if (!g_on) return nullptr;
+void* gp_prof_begin(const char* name, hipStream_t s, int level) {
+    if (g_level < level) return nullptr;
     std::lock_guard<std::mutex> lk(g_mu);
     ProfRec r{name, take_event(), take_event()};
     if (!r.a || !r.b) return nullptr;
@@ -39,7 +39,7 @@ void gp_prof_end(void* h, hipStream_t s) {
 
 extern "C" int gp_profile_enable(int on) {
     std::lock_guard<std::mutex> lk(g_mu);
-    g_on = on != 0;
+    g_level = on < 0 ? 0 : on;
     return 0;
 }
 

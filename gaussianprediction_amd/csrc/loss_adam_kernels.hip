@@ -180,6 +180,58 @@ __global__ __launch_bounds__(256) void gp_adam_kernel(float* __restrict__ p, flo
     }
 }
 
+// multi-tensor form: ONE launch walks every parameter tensor (chunk table built by the host)
+#define ADAM_MAX_TENSORS 32
+#define ADAM_CHUNK 65536   // elements per workgroup-chunk
+struct AdamTable {
+    float* p[ADAM_MAX_TENSORS];
+    float* g[ADAM_MAX_TENSORS];
+    float* m[ADAM_MAX_TENSORS];
+    float* v[ADAM_MAX_TENSORS];
+    unsigned long long n[ADAM_MAX_TENSORS];
+    float lr[ADAM_MAX_TENSORS];
+    unsigned chunk_begin[ADAM_MAX_TENSORS + 1];   // prefix of chunk counts
+    int count;
+};
+__global__ __launch_bounds__(256) void gp_adam_multi_kernel(AdamTable t, float b1, float b2, float eps, float bc1, float bc2_sqrt,
+                                                           int zero_grad) {
+    const unsigned chunk = blockIdx.x;
+    int k = 0;
+    while (k + 1 < t.count && chunk >= t.chunk_begin[k + 1]) ++k;
+    const size_t base = (size_t)(chunk - t.chunk_begin[k]) * ADAM_CHUNK;
+    const size_t n = t.n[k];
+    float* __restrict__ p = t.p[k]; float* __restrict__ g = t.g[k]; float* __restrict__ m = t.m[k]; float* __restrict__ v = t.v[k];
+    const float step_size = t.lr[k] / bc1;
+    const size_t end = base + ADAM_CHUNK < n ? base + ADAM_CHUNK : n;
+    for (size_t i = base + (size_t)threadIdx.x * 4; i < end; i += 1024) {
+        if (i + 3 < n) {
+            float4 pv = *(float4*)(p + i), gv = *(float4*)(g + i), mv = *(float4*)(m + i), vv = *(float4*)(v + i);
+            float* pp = (float*)&pv; float* gg = (float*)&gv; float* mm = (float*)&mv; float* vq = (float*)&vv;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                mm[u] = b1 * mm[u] + (1.f - b1) * gg[u];
+                vq[u] = b2 * vq[u] + (1.f - b2) * gg[u] * gg[u];
+                pp[u] -= step_size * (mm[u] / (sqrtf(vq[u]) / bc2_sqrt + eps));
+            }
+            *(float4*)(p + i) = pv; *(float4*)(m + i) = mv; *(float4*)(v + i) = vv;
+            if (zero_grad) *(float4*)(g + i) = make_float4(0.f, 0.f, 0.f, 0.f);
+        } else {
+            for (size_t j = i; j < n; ++j) {
+                const float gk = g[j];
+                const float mk = b1 * m[j] + (1.f - b1) * gk, vk = b2 * v[j] + (1.f - b2) * gk * gk;
+                p[j] -= step_size * (mk / (sqrtf(vk) / bc2_sqrt + eps));
+                m[j] = mk; v[j] = vk;
+                if (zero_grad) g[j] = 0.f;
+            }
+        }
+    }
+}
+
+// loss = (1-lam) * sums[0]/n + lam * (1 - sums[1]/n)   (one thread; keeps the scalar on the device)
+__global__ void gp_loss_finalize_kernel(const double* __restrict__ sums, double n, float lambda, float* __restrict__ loss) {
+    loss[0] = (float)((1.0 - (double)lambda) * sums[0] / n + (double)lambda * (1.0 - sums[1] / n));
+}
+
 // ------------------------------------------------------------------------------------------------
 // C ABI
 // ------------------------------------------------------------------------------------------------
@@ -201,6 +253,14 @@ extern "C" int gp_loss_l1_ssim_forward(const float* img, const float* gt, int32_
     GpProfScope _p("l1_ssim_fwd", s);
     hipLaunchKernelGGL(gp_l1_ssim_fwd_kernel, dim3((W + LT - 1) / LT, (H + LT - 1) / LT, 3), dim3(256), 0, s, img, gt, H, W,
                        make_window(), sums, dmaps);
+    GP_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int gp_loss_l1_ssim_finalize(const double* sums, int32_t channels, int32_t H, int32_t W, float lambda_dssim, float* loss,
+                                        gp_stream_t stream_) {
+    if (!sums || !loss) GP_FAIL("null argument");
+    hipLaunchKernelGGL(gp_loss_finalize_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream_, sums, (double)channels * H * W, lambda_dssim, loss);
     GP_LAUNCH_CHECK();
     return 0;
 }
@@ -229,6 +289,37 @@ extern "C" int gp_adam_step(float* param, float* grad, float* exp_avg, float* ex
     GpProfScope _p("adam", s);
     hipLaunchKernelGGL(gp_adam_kernel, dim3(gp_blocks(((size_t)n + 3) / 4, 256)), dim3(256), 0, s, param, grad, exp_avg, exp_avg_sq,
                        (size_t)n, lr, beta1, beta2, eps, bc1, bc2_sqrt, zero_grad);
+    GP_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int gp_adam_step_multi(int32_t count, float* const* params, float* const* grads, float* const* exp_avgs,
+                                  float* const* exp_avg_sqs, const int64_t* numels, const float* lrs, float beta1, float beta2,
+                                  float eps, int64_t step, int32_t zero_grad, gp_stream_t stream_) {
+    hipStream_t s = (hipStream_t)stream_;
+    if (count < 0 || count > ADAM_MAX_TENSORS) GP_FAIL("adam: at most %d tensors per call (got %d)", ADAM_MAX_TENSORS, count);
+    if (step < 1) GP_FAIL("bad step");
+    if (count == 0) return 0;
+    if (!params || !grads || !exp_avgs || !exp_avg_sqs || !numels || !lrs) GP_FAIL("null argument");
+    AdamTable t;
+    t.count = 0;
+    unsigned chunks = 0;
+    for (int k = 0; k < count; ++k) {
+        if (numels[k] <= 0) continue;
+        if ((((uintptr_t)params[k] | (uintptr_t)grads[k] | (uintptr_t)exp_avgs[k] | (uintptr_t)exp_avg_sqs[k]) & 15) != 0)
+            GP_FAIL("adam: pointers must be 16-byte aligned (tensor %d)", k);
+        const int j = t.count++;
+        t.p[j] = params[k]; t.g[j] = grads[k]; t.m[j] = exp_avgs[k]; t.v[j] = exp_avg_sqs[k];
+        t.n[j] = (unsigned long long)numels[k]; t.lr[j] = lrs[k];
+        t.chunk_begin[j] = chunks;
+        chunks += (unsigned)((numels[k] + ADAM_CHUNK - 1) / ADAM_CHUNK);
+    }
+    t.chunk_begin[t.count] = chunks;
+    if (chunks == 0) return 0;
+    const float bc1 = 1.f - powf(beta1, (float)step);
+    const float bc2_sqrt = sqrtf(1.f - powf(beta2, (float)step));
+    GpProfScope _p("adam", s);
+    hipLaunchKernelGGL(gp_adam_multi_kernel, dim3(chunks), dim3(256), 0, s, t, beta1, beta2, eps, bc1, bc2_sqrt, zero_grad);
     GP_LAUNCH_CHECK();
     return 0;
 }

@@ -187,7 +187,7 @@ __device__ __forceinline__ void stage_sh(float* s_sh, const float* __restrict__ 
     }
 }
 template <int CNT>
-__device__ __forceinline__ void unstage_sh(const float* s_sh, float* __restrict__ dst, int nblk, int tid) {
+__device__ __forceinline__ void unstage_sh(const float* s_sh, float* __restrict__ dst, int nblk, int tid, bool accumulate) {
     constexpr int STRIDE = CNT | 1;
     const int total = nblk * CNT;
     for (int e = tid * 4; e < total; e += 1024) {
@@ -199,11 +199,13 @@ __device__ __forceinline__ void unstage_sh(const float* s_sh, float* __restrict_
             v[u] = (idx < total) ? s_sh[g * STRIDE + k] : 0.f;
         }
         if (e + 3 < total) {
-            *(float4*)(dst + e) = make_float4(v[0], v[1], v[2], v[3]);
+            float4 o = make_float4(v[0], v[1], v[2], v[3]);
+            if (accumulate) { const float4 c = *(const float4*)(dst + e); o.x += c.x; o.y += c.y; o.z += c.z; o.w += c.w; }
+            *(float4*)(dst + e) = o;
         } else {
 #pragma unroll
             for (int u = 0; u < 4; ++u)
-                if (e + u < total) dst[e + u] = v[u];
+                if (e + u < total) dst[e + u] = accumulate ? dst[e + u] + v[u] : v[u];
         }
     }
 }
@@ -1071,7 +1073,7 @@ __device__ __forceinline__ void preprocess_bwd_body(
     const float* __restrict__ g_depth, float* __restrict__ dL_dmeans3D, float* __restrict__ dL_dmeans2D,
     float* __restrict__ dL_dshs, float* __restrict__ dL_dshs_rest, float* __restrict__ dL_dcolors,
     float* __restrict__ dL_dopacities, float* __restrict__ dL_dscales, float* __restrict__ dL_drots,
-    float* __restrict__ dL_dcov3D) {
+    float* __restrict__ dL_dcov3D, int accumulate_shs) {
     __shared__ float s_sh[SH_MODE == 0 ? 1 : 256 * 49];
     const int tid = threadIdx.x;
     const int base = blockIdx.x * 256;
@@ -1290,13 +1292,16 @@ __device__ __forceinline__ void preprocess_bwd_body(
 #pragma unroll
             for (int k = 0; k < 48; ++k) s_sh[tid * 49 + k] = dshl[k];
             __syncthreads();
-            unstage_sh<48>(s_sh, dL_dshs + (size_t)base * 48, nblk, tid);
+            unstage_sh<48>(s_sh, dL_dshs + (size_t)base * 48, nblk, tid, accumulate_shs != 0);
         } else {
-            if (i < d.N) { dL_dshs[3 * (size_t)i] = dshl[0]; dL_dshs[3 * (size_t)i + 1] = dshl[1]; dL_dshs[3 * (size_t)i + 2] = dshl[2]; }
+            if (i < d.N) {
+                if (accumulate_shs) { dL_dshs[3 * (size_t)i] += dshl[0]; dL_dshs[3 * (size_t)i + 1] += dshl[1]; dL_dshs[3 * (size_t)i + 2] += dshl[2]; }
+                else { dL_dshs[3 * (size_t)i] = dshl[0]; dL_dshs[3 * (size_t)i + 1] = dshl[1]; dL_dshs[3 * (size_t)i + 2] = dshl[2]; }
+            }
 #pragma unroll
             for (int k = 0; k < 45; ++k) s_sh[tid * 45 + k] = dshl[3 + k];
             __syncthreads();
-            unstage_sh<45>(s_sh, dL_dshs_rest + (size_t)base * 45, nblk, tid);
+            unstage_sh<45>(s_sh, dL_dshs_rest + (size_t)base * 45, nblk, tid, accumulate_shs != 0);
         }
     }
 }
@@ -1309,10 +1314,10 @@ __device__ __forceinline__ void preprocess_bwd_body(
     const float* __restrict__ g_color, const float* __restrict__ g_depth, float* __restrict__ dL_dmeans3D, \
     float* __restrict__ dL_dmeans2D, float* __restrict__ dL_dshs, float* __restrict__ dL_dshs_rest, \
     float* __restrict__ dL_dcolors, float* __restrict__ dL_dopacities, float* __restrict__ dL_dscales, \
-    float* __restrict__ dL_drots, float* __restrict__ dL_dcov3D
+    float* __restrict__ dL_drots, float* __restrict__ dL_dcov3D, int accumulate_shs
 #define PB_PASS d, means3D, scales, rotations, shs, shs_rest, cov3D_precomp, view, proj, campos, radii, clamped, g_mean2D, \
     g_conic, g_opacity, g_color, g_depth, dL_dmeans3D, dL_dmeans2D, dL_dshs, dL_dshs_rest, dL_dcolors, dL_dopacities, \
-    dL_dscales, dL_drots, dL_dcov3D
+    dL_dscales, dL_drots, dL_dcov3D, accumulate_shs
 __global__ __launch_bounds__(256) void gp_preprocess_bwd_kernel(PB_ARGS) { preprocess_bwd_body<0>(PB_PASS); }
 __global__ __launch_bounds__(256) void gp_preprocess_bwd_sh16_kernel(PB_ARGS) { preprocess_bwd_body<1>(PB_PASS); }
 __global__ __launch_bounds__(256) void gp_preprocess_bwd_split_kernel(PB_ARGS) { preprocess_bwd_body<2>(PB_PASS); }

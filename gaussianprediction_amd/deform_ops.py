@@ -12,7 +12,7 @@ import ctypes as C
 
 import torch
 
-from . import _lib
+from . import _lib, grad_sink
 
 
 def _need_cuda(t: torch.Tensor, what: str):
@@ -57,6 +57,7 @@ class FusedMlp(torch.autograd.Function):
                                   t_c if t_c is not None else torch.empty(0, device=dev), acts, *ws, *bs)
             ctx.meta = (int(xyz_freq), int(time_freq), xyz_c is not None, t_c is not None)
             ctx.needs = (feature.requires_grad, xyz is not None and xyz.requires_grad)
+            ctx.wb_leaves = tuple(wb)
         return out
 
     @staticmethod
@@ -71,8 +72,15 @@ class FusedMlp(torch.autograd.Function):
         g = g_out.to(torch.float32).contiguous()
         params = _lib.MlpParamsC(in_dim, 256, 4, out_dim)
         grads = _lib.MlpGradsC()
-        dws = [torch.zeros_like(w) for w in ws]
-        dbs = [torch.zeros_like(b) for b in bs]
+        # the kernels "+=" into dW/db: when every weight owns an allocated .grad, use it directly
+        leaves = ctx.wb_leaves
+        sinks = [grad_sink.sink_of(t) for t in leaves]
+        use_sink = all(s_ is not None for s_ in sinks)
+        if use_sink:
+            dws, dbs = list(sinks[0::2]), list(sinks[1::2])
+        else:
+            dws = [torch.zeros_like(w) for w in ws]
+            dbs = [torch.zeros_like(b) for b in bs]
         for l in range(5):
             params.w[l] = ws[l].data_ptr()
             params.b[l] = bs[l].data_ptr()
@@ -92,7 +100,10 @@ class FusedMlp(torch.autograd.Function):
             _lib.check(rc, "gp_mlp_backward")
         wb_grads = []
         for l in range(5):
-            wb_grads += [dws[l], dbs[l]]
+            wb_grads += [None, None] if use_sink else [dws[l], dbs[l]]
+        if use_sink:
+            for t in leaves:
+                grad_sink.notify(t)
         return (g_feat, g_xyz, None, None, None, *wb_grads)
 
 

@@ -69,8 +69,13 @@ class OverlappedGradReducer:
         self.small = [p for p in bucket.params if p.numel() < small_numel]
         self._fired = set()
         if self.enabled:
+            from . import grad_sink
+            hooks = {id(p): self._make_hook(p) for p in self.large}
             for p in self.large:
-                p.register_post_accumulate_grad_hook(self._make_hook(p))
+                p.register_post_accumulate_grad_hook(hooks[id(p)])
+            # leaves whose gradient is written directly by a kernel (grad_sink) never run AccumulateGrad:
+            # they announce completion through the sink registry instead
+            self._sink_cb = grad_sink.register_callback(lambda p: hooks[id(p)](p) if id(p) in hooks else None)
 
     def _make_hook(self, p):
         def hook(param):

@@ -31,9 +31,13 @@ class L1SSIMLoss(torch.autograd.Function):
             rc = _lib.lib().gp_loss_l1_ssim_forward(_lib.ptr(img), _lib.ptr(g), C.c_int32(3), C.c_int32(H), C.c_int32(W),
                                                     _lib.ptr(sums), _lib.ptr(dmaps), _lib.stream_ptr(dev))
             _lib.check(rc, "gp_loss_l1_ssim_forward")
-        n = 3.0 * H * W
         lam = float(lambda_dssim)
-        loss = ((1.0 - lam) * sums[0] / n + lam * (1.0 - sums[1] / n)).to(torch.float32)
+        loss_t = torch.empty(1, dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            rc = _lib.lib().gp_loss_l1_ssim_finalize(_lib.ptr(sums), C.c_int32(3), C.c_int32(H), C.c_int32(W), C.c_float(lam),
+                                                     _lib.ptr(loss_t), _lib.stream_ptr(dev))
+            _lib.check(rc, "gp_loss_l1_ssim_finalize")
+        loss = loss_t.reshape(())
         if need:
             ctx.save_for_backward(img, g, dmaps)
             ctx.lam = lam
@@ -78,16 +82,21 @@ class FusedAdam:
                 self.items.append((g, p, off_of[id(p)], torch.zeros_like(p), torch.zeros_like(p)))
 
     def step(self, zero_grad=True):
+        """One launch for all parameter tensors (gp_adam_step_multi)."""
         self.step_count += 1
-        L = _lib.lib()
+        n = len(self.items)
+        if not hasattr(self, "_tab"):
+            P = (C.c_void_p * n)(*[p.data_ptr() for _, p, _, _, _ in self.items])
+            G = (C.c_void_p * n)(*[self.bucket.flat.data_ptr() + 4 * off for _, _, off, _, _ in self.items])
+            M = (C.c_void_p * n)(*[m.data_ptr() for _, _, _, m, _ in self.items])
+            V = (C.c_void_p * n)(*[v.data_ptr() for _, _, _, _, v in self.items])
+            NUM = (C.c_int64 * n)(*[p.numel() for _, p, _, _, _ in self.items])
+            self._tab = (P, G, M, V, NUM)
+        P, G, M, V, NUM = self._tab
+        LR = (C.c_float * n)(*[float(g["lr"]) for g, _, _, _, _ in self.items])
         b1, b2 = self.betas
-        flat = self.bucket.flat
-        dev = flat.device
+        dev = self.bucket.flat.device
         with torch.cuda.device(dev):
-            st = _lib.stream_ptr(dev)
-            for g, p, off, m, v in self.items:
-                gptr = C.c_void_p(flat.data_ptr() + 4 * off)
-                rc = L.gp_adam_step(C.c_void_p(p.data_ptr()), gptr, _lib.ptr(m), _lib.ptr(v), C.c_int64(p.numel()),
-                                    C.c_float(g["lr"]), C.c_float(b1), C.c_float(b2), C.c_float(self.eps),
-                                    C.c_int64(self.step_count), C.c_int32(1 if zero_grad else 0), st)
-                _lib.check(rc, "gp_adam_step")
+            rc = _lib.lib().gp_adam_step_multi(C.c_int32(n), P, G, M, V, NUM, LR, C.c_float(b1), C.c_float(b2), C.c_float(self.eps),
+                                               C.c_int64(self.step_count), C.c_int32(1 if zero_grad else 0), _lib.stream_ptr(dev))
+            _lib.check(rc, "gp_adam_step_multi")

@@ -21,7 +21,7 @@ from typing import NamedTuple, Optional
 import torch
 from torch import nn
 
-from . import _lib
+from . import _lib, grad_sink
 
 
 class GaussianRasterizationSettings(NamedTuple):
@@ -99,6 +99,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                 raise alloc.error
             _lib.check(rc, "gp_raster_forward")
         ctx.set_materialize_grads(False)      # an unused `depth` output must arrive as None, not as zeros
+        ctx.sh_leaves = (sh, sh_rest)         # (leaf Parameters: candidates for direct gradient sinks)
         ctx.raster_settings = rs
         ctx.num_rendered = int(saved.num_rendered)
         ctx.sh_coeffs = sh_coeffs
@@ -134,21 +135,36 @@ class _RasterizeGaussians(torch.autograd.Function):
                                       binning.numel(), image.data_ptr(), image.numel(), ctx.num_rendered)
             g_m3 = torch.empty(N, 3, device=device)
             g_m2 = torch.empty(N, 3, device=device)
-            g_sh = torch.empty(N, 1 if has_rest else ctx.sh_coeffs, 3, device=device) if has_sh else None
-            g_shr = torch.empty(N, ctx.sh_coeffs - 1, 3, device=device) if has_rest else None
+            # direct sinks: accumulate SH gradients straight into the parameters' pre-allocated .grad
+            leaf_sh, leaf_rest = ctx.sh_leaves
+            sink_sh = grad_sink.sink_of(leaf_sh) if has_sh else None
+            sink_rest = grad_sink.sink_of(leaf_rest) if has_rest else None
+            m16 = ctx.sh_coeffs == 16 and (shs.data_ptr() % 16 == 0)
+            use_sink = has_sh and m16 and sink_sh is not None and (not has_rest or sink_rest is not None) and \
+                sink_sh.shape == shs.shape and (not has_rest or sink_rest.shape == shs_r.shape)
+            if use_sink:
+                g_sh, g_shr = sink_sh, (sink_rest if has_rest else None)
+            else:
+                g_sh = torch.empty(N, 1 if has_rest else ctx.sh_coeffs, 3, device=device) if has_sh else None
+                g_shr = torch.empty(N, ctx.sh_coeffs - 1, 3, device=device) if has_rest else None
             g_col = torch.empty(N, 3, device=device) if has_col else None
             g_op = torch.empty(N, 1, device=device)
             g_scl = torch.empty(N, 3, device=device) if has_sr else None
             g_rot = torch.empty(N, 4, device=device) if has_sr else None
             g_cov = torch.empty(N, 6, device=device) if has_cov else None
             grads = _lib.RasterGradsC(_lib.ptr(g_m3), _lib.ptr(g_m2), _lib.ptr(g_sh), _lib.ptr(g_shr), _lib.ptr(g_col), _lib.ptr(g_op),
-                                      _lib.ptr(g_scl), _lib.ptr(g_rot), _lib.ptr(g_cov))
+                                      _lib.ptr(g_scl), _lib.ptr(g_rot), _lib.ptr(g_cov), 1 if use_sink else 0)
             alloc = _lib.TorchAllocator(device)
             rc = L.gp_raster_backward(C.byref(st), C.byref(inp), C.byref(out), C.byref(saved), _lib.ptr(gc), _lib.ptr(gd),
                                       C.byref(grads), alloc.cb, None, _lib.stream_ptr(device))
             if alloc.error is not None:
                 raise alloc.error
             _lib.check(rc, "gp_raster_backward")
+        if use_sink:
+            grad_sink.notify(leaf_sh)
+            if has_rest:
+                grad_sink.notify(leaf_rest)
+            g_sh, g_shr = None, None
         return g_m3, g_m2, g_sh, g_col, g_op, g_scl, g_rot, g_cov, None, g_shr
 
 

@@ -96,6 +96,8 @@ typedef struct gp_raster_grads {
     float* dL_dscales;         /* [N,3] or NULL */
     float* dL_drotations;      /* [N,4] or NULL */
     float* dL_dcov3D_precomp;  /* [N,6] or NULL */
+    int32_t accumulate_shs;    /* 1: dL_dshs / dL_dshs_rest are "+=" targets (the parameters' own .grad buffers:
+                                  no temporary, no separate accumulate pass over 192 B/Gaussian); 0: "=" */
 } gp_raster_grads;
 
 /* replaces _C.rasterize_gaussians (the forward of GaussianRasterizer). One host sync (reads R). */
@@ -205,6 +207,9 @@ int gp_activations_backward(int64_t n, const float* scaling_raw, const float* op
  * SSIM partial-derivative maps the backward needs. */
 int gp_loss_l1_ssim_forward(const float* img, const float* gt, int32_t channels, int32_t H, int32_t W, double* sums,
                             float* dmaps, gp_stream_t stream);
+/* loss[0] = (1-l) * sums[0]/n + l * (1 - sums[1]/n), n = channels*H*W: keeps the scalar on the device. */
+int gp_loss_l1_ssim_finalize(const double* sums, int32_t channels, int32_t H, int32_t W, float lambda_dssim, float* loss,
+                             gp_stream_t stream);
 /* dimg = upstream[0] * d loss / d img  (upstream: device scalar, NULL = 1). */
 int gp_loss_l1_ssim_backward(const float* img, const float* gt, const float* dmaps, int32_t channels, int32_t H, int32_t W,
                              float lambda_dssim, const float* upstream, float* dimg, gp_stream_t stream);
@@ -214,8 +219,14 @@ int gp_loss_l1_ssim_backward(const float* img, const float* gt, const float* dma
 int gp_adam_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1, float beta2,
                  float eps, int64_t step, int32_t zero_grad, gp_stream_t stream);
 
+/* the same for up to 32 tensors in ONE launch (host arrays of device pointers / sizes / learning rates) */
+int gp_adam_step_multi(int32_t count, float* const* params, float* const* grads, float* const* exp_avgs,
+                       float* const* exp_avg_sqs, const int64_t* numels, const float* lrs, float beta1, float beta2, float eps,
+                       int64_t step, int32_t zero_grad, gp_stream_t stream);
+
 /* ---- measurement ----------------------------------------------------------------------------- */
-/* When enabled, the library brackets its kernels with hipEvent pairs recorded on the launch stream.
+/* gp_profile_enable(level): 0 = off, 1 = bracket only the roofline kernel (composite forward), 2 = every
+ * kernel.  When enabled, the library brackets kernels with hipEvent pairs recorded on the launch stream.
  * gp_profile_collect() waits for the recorded events and returns per-kernel launch counts and summed
  * durations since the previous collect (used by bench.py for the roofline figures). */
 typedef struct gp_profile_entry {
