@@ -177,6 +177,12 @@ class TorchAllocator:
         b = self.bufs[which]
         return b[0] if b else None
 
+    def release(self):
+        """Break the self -> callback -> bound method -> self cycle so the buffers are freed by
+        reference counting right away (not at the next cyclic GC, seconds and gigabytes later)."""
+        self.cb = None
+        self.bufs = None
+
 
 def profile_enable(level) -> None:
     """0/False = off, 1 = only the roofline kernel (composite forward), 2/True = every kernel."""

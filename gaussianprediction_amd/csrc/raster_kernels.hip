@@ -954,14 +954,21 @@ __device__ __forceinline__ void gp_composite_bwd3_body(RasterDims d, const int2*
     const int count = min(range.y - range.x, max_nc);
     const float px_base = (float)(tx * GP_TILE), py_base = (float)(ty * GP_TILE + part * ROWS);
     const float LOG2E = 1.4426950408889634f;
+    // software pipeline: the record gather of batch b+1 is issued before the pixel walk of batch b
+    uint32_t id_n = 0;
+    float4 q0_n = make_float4(0.f, 0.f, 0.f, 0.f), q1_n = q0_n, q2_n = q0_n;
+    if (lane < count) {
+        id_n = point_list[range.x + lane];
+        q0_n = rec[3 * (size_t)id_n]; q1_n = rec[3 * (size_t)id_n + 1]; q2_n = rec[3 * (size_t)id_n + 2];
+    }
     for (int b0 = 0; b0 < count; b0 += 64) {
         const int pos = b0 + lane;
         const bool have = pos < count;
-        uint32_t id = 0;
-        float4 q0 = make_float4(0.f, 0.f, 0.f, 0.f), q1 = q0, q2 = q0;
-        if (have) {
-            id = point_list[range.x + pos];
-            q0 = rec[3 * (size_t)id]; q1 = rec[3 * (size_t)id + 1]; q2 = rec[3 * (size_t)id + 2];
+        const uint32_t id = id_n;
+        const float4 q0 = q0_n, q1 = q1_n, q2 = q2_n;
+        if (pos + 64 < count) {
+            id_n = point_list[range.x + pos + 64];
+            q0_n = rec[3 * (size_t)id_n]; q1_n = rec[3 * (size_t)id_n + 1]; q2_n = rec[3 * (size_t)id_n + 2];
         }
         const float sx = q0.x - px_base, sy = q0.y - py_base;
         const float As = q0.z * LOG2E, Bs = q0.w * LOG2E, Cs = q1.x * LOG2E;   // power in log2 units

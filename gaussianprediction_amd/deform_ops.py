@@ -96,7 +96,10 @@ class FusedMlp(torch.autograd.Function):
             rc = _lib.lib().gp_mlp_backward(C.byref(params), C.byref(inp), _lib.ptr(acts), _lib.ptr(g), C.byref(grads),
                                             _lib.ptr(g_feat), _lib.ptr(g_xyz), alloc.cb, None, _lib.stream_ptr(dev))
             if alloc.error is not None:
-                raise alloc.error
+                err = alloc.error
+                alloc.release()
+                raise err
+            alloc.release()
             _lib.check(rc, "gp_mlp_backward")
         wb_grads = []
         for l in range(5):
@@ -159,7 +162,10 @@ class KeypointBlend(torch.autograd.Function):
             rc = _lib.lib().gp_blend_backward(C.byref(args), _lib.ptr(gx), _lib.ptr(gq), _lib.ptr(g_delta), _lib.ptr(g_raw),
                                               _lib.ptr(g_xyz), _lib.ptr(g_rot), alloc.cb, None, _lib.stream_ptr(dev))
             if alloc.error is not None:
-                raise alloc.error
+                err = alloc.error
+                alloc.release()
+                raise err
+            alloc.release()
             _lib.check(rc, "gp_blend_backward")
         return g_delta, g_raw, None, g_xyz, g_rot, None
 

@@ -96,7 +96,9 @@ class _RasterizeGaussians(torch.autograd.Function):
             rc = L.gp_raster_forward(C.byref(st), C.byref(inp), C.byref(out), C.byref(saved), alloc.cb, None,
                                      _lib.stream_ptr(device))
             if alloc.error is not None:
-                raise alloc.error
+                err = alloc.error
+                alloc.release()
+                raise err
             _lib.check(rc, "gp_raster_forward")
         ctx.set_materialize_grads(False)      # an unused `depth` output must arrive as None, not as zeros
         ctx.sh_leaves = (sh, sh_rest)         # (leaf Parameters: candidates for direct gradient sinks)
@@ -105,6 +107,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         ctx.sh_coeffs = sh_coeffs
         ctx.flags = (shs is not None, cols is not None, scl is not None, cov is not None, shs_r is not None)
         geom, binning, image = alloc.first(_lib.GP_BUF_GEOM), alloc.first(_lib.GP_BUF_BINNING), alloc.first(_lib.GP_BUF_IMAGE)
+        alloc.release()
         empty = torch.empty(0, device=device)
         ctx.save_for_backward(m3, shs if shs is not None else empty, shs_r if shs_r is not None else empty,
                               cols if cols is not None else empty, ops,
@@ -158,7 +161,10 @@ class _RasterizeGaussians(torch.autograd.Function):
             rc = L.gp_raster_backward(C.byref(st), C.byref(inp), C.byref(out), C.byref(saved), _lib.ptr(gc), _lib.ptr(gd),
                                       C.byref(grads), alloc.cb, None, _lib.stream_ptr(device))
             if alloc.error is not None:
-                raise alloc.error
+                err = alloc.error
+                alloc.release()
+                raise err
+            alloc.release()
             _lib.check(rc, "gp_raster_backward")
         if use_sink:
             grad_sink.notify(leaf_sh)
@@ -242,4 +248,5 @@ def raster_forward_debug(raster_settings, means3D, opacities, shs=None, colors_p
         _lib.check(L.gp_raster_debug_binning(C.byref(st), C.byref(saved), _lib.ptr(point_list), _lib.ptr(ranges),
                                              _lib.stream_ptr(device)), "gp_raster_debug_binning")
         torch.cuda.synchronize(device)
+        alloc.release()
     return dict(color=color, radii=radii, depth=depth, tidx=tidx, R=R, point_list=point_list[:R], ranges=ranges)

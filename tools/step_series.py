@@ -15,6 +15,8 @@ pc, cams, gts, margs = bench.build_workload(args, dev)
 torch.cuda.synchronize()
 print(f"setup {time.perf_counter() - t0:.2f}s", flush=True)
 ts = TrainStep(pc, cams, gts, 50000, lrs=dict(xyz=8e-6))
+import gc
+if os.environ.get('NOGC'): gc.disable()
 ser = []
 for i in range(int(sys.argv[1]) if len(sys.argv) > 1 else 60):
     torch.cuda.synchronize()
@@ -23,3 +25,4 @@ for i in range(int(sys.argv[1]) if len(sys.argv) > 1 else 60):
     torch.cuda.synchronize()
     ser.append((time.perf_counter() - a) * 1e3)
 print(" ".join(f"{x:.2f}" for x in ser))
+print('outliers', [(i, round(x,1)) for i,x in enumerate(ser) if x > 5], 'gc counts', gc.get_count(), 'mem reserved MB', torch.cuda.memory_reserved()/2**20)
