@@ -168,6 +168,23 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     prof = _lib.profile_collect()
+    _lib.profile_enable(0)
+    # eval-style forward renders (the "rendered views/s" half of the metric, [REF eval.py:208-224]); separate
+    # timed loop, reported as an extra field
+    eval_fps = None
+    if not args.render_only:
+        from gaussianprediction_amd.renderer import render as _render
+        n_eval = max(10, min(args.steps, 50))
+        with torch.no_grad():
+            for i in range(3):
+                _render(cams[i % len(cams)], pc, ts.pipe, ts.bg, time=ts.times[i % len(cams)], it=args.iteration)
+            torch.cuda.synchronize()
+            te = time.perf_counter()
+            for i in range(n_eval):
+                _render(cams[(i * world + rank) % len(cams)], pc, ts.pipe, ts.bg, time=ts.times[(i * world + rank) % len(cams)],
+                        it=args.iteration)
+            torch.cuda.synchronize()
+            eval_fps = n_eval / (time.perf_counter() - te)
     _lib.profile_enable(2)                      # untimed pass for the per-kernel table
     for i in range(min(args.steps, 5)):
         one_step(args.warmup + args.steps + i)
@@ -226,6 +243,7 @@ def main():
                        "tiles": T, "pixels": P, "R": R, "R_before_timed_region": R0, "R_per_gaussian": round(R / max(args.gaussians, 1), 3),
                        "visible": n_vis, "parallelism": f"view-parallel x{world}"},
             "roofline": roof,
+            "eval_render_views_per_s_per_gpu": None if eval_fps is None else round(eval_fps, 2),
             "kernels_ms": kern,
         }
         if not args.no_cpu_baseline and world == 1:

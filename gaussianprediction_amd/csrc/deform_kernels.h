@@ -43,10 +43,6 @@ __global__ __launch_bounds__(256) void gp_blend_bwd6_kernel(BlendDev a, const fl
                                                            const float* __restrict__ g_q_t, float* __restrict__ g_delta,
                                                            float* __restrict__ g_raw_w, float* __restrict__ g_xyz,
                                                            float* __restrict__ g_rot, float* __restrict__ partial);
-__global__ __launch_bounds__(256) void gp_blend_bwd6_nolds_kernel(BlendDev a, const float* __restrict__ g_xyz_t,
-                                                           const float* __restrict__ g_q_t, float* __restrict__ g_delta,
-                                                           float* __restrict__ g_raw_w, float* __restrict__ g_xyz,
-                                                           float* __restrict__ g_rot, float* __restrict__ partial);
 __global__ __launch_bounds__(256) void gp_blend_bwd8_kernel(BlendDev a, const float* __restrict__ g_xyz_t,
                                                            const float* __restrict__ g_q_t, float* __restrict__ g_delta,
                                                            float* __restrict__ g_raw_w, float* __restrict__ g_xyz,

@@ -415,7 +415,7 @@ __device__ __forceinline__ void normalize_bwd(const float* v, const float* g, fl
 
 // Keypoint gradients are first accumulated per workgroup in LDS ([K, 7]) and flushed with one
 // global atomic per (workgroup, keypoint, component): K is a few hundred, N is 10^6.
-template <int NN, bool NOLDS = false>
+template <int NN>
 __device__ __forceinline__ void blend_bwd_body(BlendDev a, const float* __restrict__ g_xyz_t,
                                                const float* __restrict__ g_q_t, float* __restrict__ g_delta,
                                                float* __restrict__ g_raw_w, float* __restrict__ g_xyz,
@@ -485,7 +485,6 @@ __device__ __forceinline__ void blend_bwd_body(BlendDev a, const float* __restri
                 float gv[4] = {c[0], c[1], c[2], c[3]};
                 if (a.norm_rotation) normalize_bwd(v, c, gv);
                 float* acc = s_acc + kp * 7;
-                if (NOLDS) { if (gv[0] == 123.456f) acc[0] = gv[1] + gv[2] + gv[3] + wx[k]; continue; }
                 atomicAdd(acc + 0, wx[k] * gx[0]); atomicAdd(acc + 1, wx[k] * gx[1]); atomicAdd(acc + 2, wx[k] * gx[2]);
                 atomicAdd(acc + 3, gv[0]); atomicAdd(acc + 4, gv[1]); atomicAdd(acc + 5, gv[2]); atomicAdd(acc + 6, gv[3]);
             }
@@ -516,7 +515,6 @@ __device__ __forceinline__ void blend_bwd_body(BlendDev a, const float* __restri
     float* __restrict__ g_raw_w, float* __restrict__ g_xyz, float* __restrict__ g_rot, float* __restrict__ partial
 __global__ __launch_bounds__(256) void gp_blend_bwd_kernel(BB_ARGS) { blend_bwd_body<0>(a, g_xyz_t, g_q_t, g_delta, g_raw_w, g_xyz, g_rot, partial); }
 __global__ __launch_bounds__(256) void gp_blend_bwd6_kernel(BB_ARGS) { blend_bwd_body<6>(a, g_xyz_t, g_q_t, g_delta, g_raw_w, g_xyz, g_rot, partial); }
-__global__ __launch_bounds__(256) void gp_blend_bwd6_nolds_kernel(BB_ARGS) { blend_bwd_body<6, true>(a, g_xyz_t, g_q_t, g_delta, g_raw_w, g_xyz, g_rot, partial); }
 __global__ __launch_bounds__(256) void gp_blend_bwd8_kernel(BB_ARGS) { blend_bwd_body<8>(a, g_xyz_t, g_q_t, g_delta, g_raw_w, g_xyz, g_rot, partial); }
 
 // stage 2: g_delta[k, c] = sum over workgroups (deterministic, no atomics)

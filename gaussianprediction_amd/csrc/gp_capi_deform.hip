@@ -113,8 +113,7 @@ extern "C" int gp_blend_backward(const gp_blend_args* a, const float* dL_dxyz_t,
     if (b.N == 0) return 0;
     if (!dL_dxyz_t || !dL_dq_t || !dL_ddelta || !dL_dxyz || !dL_drot || (b.nn > 0 && !dL_draw_w)) GP_FAIL("null argument");
     unsigned blocks = gp_blocks((size_t)b.N, 256);
-    static const unsigned exp_blocks = getenv("GP_EXP_BLEND_BLOCKS") ? (unsigned)atoi(getenv("GP_EXP_BLEND_BLOCKS")) : 512u;
-    if (b.nn > 0 && blocks > exp_blocks) blocks = exp_blocks;
+    if (b.nn > 0 && blocks > 512) blocks = 512;   // measured: 256-512 workgroups minimise partial-buffer traffic
     const size_t lds = b.nn > 0 ? (size_t)b.K * 7 * sizeof(float) : 0;
     float* partial = nullptr;
     const int KA = (int)b.K * 7;
@@ -124,8 +123,7 @@ extern "C" int gp_blend_backward(const gp_blend_args* a, const float* dL_dxyz_t,
         if (!partial) GP_FAIL("allocator returned NULL for TEMP");
     }
     { GpProfScope _p("blend_bwd", (hipStream_t)stream_);
-    static const bool nolds = getenv("GP_EXP_BLEND_NOLDS") != nullptr;   // timing experiment only
-    hipLaunchKernelGGL((nolds && b.nn == 6) ? gp_blend_bwd6_nolds_kernel : b.nn == 6 ? gp_blend_bwd6_kernel : b.nn == 8 ? gp_blend_bwd8_kernel : gp_blend_bwd_kernel,
+    hipLaunchKernelGGL(b.nn == 6 ? gp_blend_bwd6_kernel : b.nn == 8 ? gp_blend_bwd8_kernel : gp_blend_bwd_kernel,
                        dim3(blocks), dim3(256), lds, (hipStream_t)stream_, b, dL_dxyz_t, dL_dq_t, dL_ddelta,
                        dL_draw_w, dL_dxyz, dL_drot, partial);
     GP_LAUNCH_CHECK();

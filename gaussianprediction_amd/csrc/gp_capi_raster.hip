@@ -219,18 +219,11 @@ extern "C" int gp_raster_backward(const gp_raster_settings* st, const gp_raster_
     float* g_color = acc + 6 * N;
     float* g_depth = acc + 9 * N;
     if (R > 0) {
-        static const bool noatomic = getenv("GP_EXP_BWD_NOATOMIC") != nullptr;   // timing experiments only
-        static const bool use_v1 = getenv("GP_EXP_BWD_V1") != nullptr;
-        static const bool use_v2 = getenv("GP_EXP_BWD_V2") != nullptr;
-        static const int exp_rows = getenv("GP_EXP_BWD_ROWS") ? atoi(getenv("GP_EXP_BWD_ROWS")) : 8;
-        auto kern = dL_ddepth ? gp_composite_bwd3_depth_kernel : gp_composite_bwd3_kernel;
-        unsigned parts = GP_TILE / 8;
-        if (noatomic) kern = gp_composite_bwd_noatomic_kernel;
-        else if (use_v1) kern = gp_composite_bwd_kernel;
-        else if (use_v2) kern = dL_ddepth ? gp_composite_bwd2_depth_kernel : gp_composite_bwd2_kernel;
-        else if (!dL_ddepth && exp_rows == 4) { kern = gp_composite_bwd3_r4_kernel; parts = 4; }
-        else if (!dL_ddepth && exp_rows == 2) { kern = gp_composite_bwd3_r2_kernel; parts = 8; }
-        else if (!dL_ddepth && exp_rows == 16) { kern = gp_composite_bwd3_r16_kernel; parts = 1; }
+        // v4 (compacted batches) is the default; GP_EXP_BWD_V3=1 selects the un-compacted variant for A/B timing
+        static const bool use_v3 = getenv("GP_EXP_BWD_V3") != nullptr;
+        auto kern = use_v3 ? (dL_ddepth ? gp_composite_bwd3_depth_kernel : gp_composite_bwd3_kernel)
+                           : (dL_ddepth ? gp_composite_bwd4_depth_kernel : gp_composite_bwd4_kernel);
+        const unsigned parts = GP_TILE / 8;
         { GpProfScope _p("composite_bwd", s);
         hipLaunchKernelGGL(kern, dim3((unsigned)T * parts), dim3(64), 0, s, d, il.ranges, point_list,
                            gl.rec, st->bg, fwd->color, fwd->depth, il.final_T, il.n_contrib, dL_dcolor, dL_ddepth, g_mean2D,

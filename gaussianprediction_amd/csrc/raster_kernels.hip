@@ -509,7 +509,7 @@ __global__ __launch_bounds__(CF_THREADS) void gp_composite_fwd_kernel(RasterDims
 }
 
 // ------------------------------------------------------------------------------------------------
-// composite backward, splat-parallel.  One wave per (tile, group of CB_ROWS pixel rows).  Lanes own
+// composite backward, splat-parallel.  One wave per (tile, group of 8 pixel rows).  Lanes own
 // the 64 splats of the current batch (record in registers); the wave walks the group's pixels
 // uniformly.  For pixel p:  T_j(p) = T_in(p) * exclusive_prod_{k<j}(1-alpha_k)   (wave scan)
 //                           suffix_j(p) = Tot(p) - P_in(p) - inclusive_sum_{k<=j} s_k (wave scan)
@@ -518,361 +518,15 @@ __global__ __launch_bounds__(CF_THREADS) void gp_composite_fwd_kernel(RasterDims
 // - (suffix_j + T_final bg.dLp) / (1 - alpha_j).  Each lane accumulates its splat's 10 gradient sums
 // in registers and issues 10 atomics per (splat, tile part) -- not per (splat, pixel).
 // ------------------------------------------------------------------------------------------------
-#define CB_ROWS 8
-#define CB_PIX (CB_ROWS * GP_TILE)
-
-__device__ __forceinline__ float wave_incl_prod(float x, int lane) {
-#pragma unroll
-    for (int dd = 1; dd < 64; dd <<= 1) {
-        const float t = __shfl_up(x, dd);
-        if (lane >= dd) x *= t;
-    }
-    return x;
-}
-__device__ __forceinline__ float wave_incl_sum(float x, int lane) {
-#pragma unroll
-    for (int dd = 1; dd < 64; dd <<= 1) {
-        const float t = __shfl_up(x, dd);
-        if (lane >= dd) x += t;
-    }
-    return x;
-}
-
-template <bool NOATOMIC>
-__device__ __forceinline__ void gp_composite_bwd_kernel_t(RasterDims d, const int2* __restrict__ ranges,
-                                                              const uint32_t* __restrict__ point_list,
-                                                              const float4* __restrict__ rec, const float* __restrict__ bg,
-                                                              const float* __restrict__ out_color,
-                                                              const float* __restrict__ out_depth,
-                                                              const float* __restrict__ final_T,
-                                                              const int32_t* __restrict__ n_contrib,
-                                                              const float* __restrict__ dL_dpix,
-                                                              const float* __restrict__ dL_dpixdepth,
-                                                              float* __restrict__ g_mean2D /*N,2*/,
-                                                              float* __restrict__ g_conic /*N,3*/,
-                                                              float* __restrict__ g_opacity /*N*/,
-                                                              float* __restrict__ g_color /*N,3*/,
-                                                              float* __restrict__ g_depth /*N*/) {
-    // per-pixel uniform data: {dLr, dLg, dLb, dLd}, {Tot, Tfinal*bgdot, T_in, P_in}, n_contrib
-    __shared__ float4 s_pa[CB_PIX];
-    __shared__ float4 s_pb[CB_PIX];
-    __shared__ int s_nc[CB_PIX];
-    const int parts = GP_TILE / CB_ROWS;
-    const int tile = blockIdx.x / parts, part = blockIdx.x % parts;
-    const int tx = tile % d.gx, ty = tile / d.gx;
-    const int lane = threadIdx.x;
-    const int2 range = ranges[tile];
-    const size_t HW = (size_t)d.H * d.W;
-    const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
-    int max_nc = 0;
-    for (int p = lane; p < CB_PIX; p += 64) {
-        const int px = tx * GP_TILE + (p & 15), py = ty * GP_TILE + part * CB_ROWS + (p >> 4);
-        float4 pa = make_float4(0.f, 0.f, 0.f, 0.f), pb = make_float4(0.f, 0.f, 1.f, 0.f);
-        int nc = 0;
-        if (px < d.W && py < d.H) {
-            const size_t pix = (size_t)py * d.W + px;
-            pa.x = dL_dpix[pix]; pa.y = dL_dpix[HW + pix]; pa.z = dL_dpix[2 * HW + pix];
-            pa.w = dL_dpixdepth ? dL_dpixdepth[pix] : 0.f;
-            const float Tf = final_T[pix];
-            const float bgdot = bg0 * pa.x + bg1 * pa.y + bg2 * pa.z;
-            pb.y = Tf * bgdot;
-            pb.x = out_color[pix] * pa.x + out_color[HW + pix] * pa.y + out_color[2 * HW + pix] * pa.z - pb.y +
-                   out_depth[pix] * pa.w;
-            nc = n_contrib[pix];
-        }
-        s_pa[p] = pa; s_pb[p] = pb; s_nc[p] = nc;
-        max_nc = max(max_nc, nc);
-    }
-#pragma unroll
-    for (int dd = 32; dd >= 1; dd >>= 1) max_nc = max(max_nc, __shfl_xor(max_nc, dd));
-    __syncthreads();
-    const float halfW = 0.5f * (float)d.W, halfH = 0.5f * (float)d.H;
-    const int count = min(range.y - range.x, max_nc);
-    for (int b0 = 0; b0 < count; b0 += 64) {
-        const int pos = b0 + lane;  // 0-based position in the tile list
-        const bool have = pos < count;
-        uint32_t id = 0;
-        float4 q0 = make_float4(0.f, 0.f, 0.f, 0.f), q1 = q0, q2 = q0;
-        if (have) {
-            id = point_list[range.x + pos];
-            q0 = rec[3 * (size_t)id]; q1 = rec[3 * (size_t)id + 1]; q2 = rec[3 * (size_t)id + 2];
-        }
-        const float cx = -2.f * q0.z, cy = -q0.w, cz = -2.f * q1.x;
-        float a_mx = 0.f, a_my = 0.f, a_ca = 0.f, a_cb = 0.f, a_cc = 0.f, a_op = 0.f, a_r = 0.f, a_g = 0.f, a_b = 0.f,
-              a_d = 0.f;
-#pragma unroll 1
-        for (int p = 0; p < CB_PIX; ++p) {
-            const int nc = s_nc[p];
-            if (nc <= b0) continue;  // uniform: pixel finished before this batch
-            const float4 pa = s_pa[p];
-            float4 pb = s_pb[p];
-            const float pxf = (float)(tx * GP_TILE + (p & 15));
-            const float pyf = (float)(ty * GP_TILE + part * CB_ROWS + (p >> 4));
-            const float dx = q0.x - pxf, dy = q0.y - pyf;
-            const float power = fmaf(dx, fmaf(q0.z, dx, q0.w * dy), (q1.x * dy) * dy);
-            const float G = gp_exp(fminf(power, 0.f));
-            const float alpha = fminf(0.99f, q1.y * G);
-            const bool contrib = have && (pos < nc) && !(power > 0.f) && !(alpha < 1.f / 255.f);
-            const float om = contrib ? (1.f - alpha) : 1.f;
-            const float incl = wave_incl_prod(om, lane);
-            float excl = __shfl_up(incl, 1);
-            if (lane == 0) excl = 1.f;
-            const float Tj = pb.z * excl;
-            const float cdot = fmaf(q2.x, pa.x, fmaf(q2.y, pa.y, fmaf(q2.z, pa.z, q1.z * pa.w)));
-            const float w = contrib ? alpha * Tj : 0.f;
-            const float s = w * cdot;
-            const float psum = wave_incl_sum(s, lane);
-            if (contrib) {
-                const float suffix = pb.x - pb.w - psum;
-                const float dL_dalpha = fmaf(Tj, cdot, -(suffix + pb.y) * __builtin_amdgcn_rcpf(om));
-                a_r = fmaf(w, pa.x, a_r);
-                a_g = fmaf(w, pa.y, a_g);
-                a_b = fmaf(w, pa.z, a_b);
-                a_d = fmaf(w, pa.w, a_d);
-                a_op = fmaf(G, dL_dalpha, a_op);
-                const float dL_dG = q1.y * dL_dalpha;
-                const float gdx = G * dx, gdy = G * dy;
-                a_mx = fmaf(dL_dG, -gdx * cx - gdy * cy, a_mx);
-                a_my = fmaf(dL_dG, -gdy * cz - gdx * cy, a_my);
-                a_ca = fmaf(gdx * dx, dL_dG, a_ca);
-                a_cb = fmaf(gdx * dy, dL_dG, a_cb);
-                a_cc = fmaf(gdy * dy, dL_dG, a_cc);
-            }
-            // carry to the next batch (uniform values from lane 63)
-            const float tot_prod = __shfl(incl, 63);
-            const float tot_sum = __shfl(psum, 63);
-            if (lane == 0) {
-                pb.z *= tot_prod;
-                pb.w += tot_sum;
-                s_pb[p] = pb;
-            }
-        }
-        if (NOATOMIC) {
-            if (have && a_mx == 123.456f) g_depth[id] = a_mx + a_my + a_ca + a_cb + a_cc + a_op + a_r + a_g + a_b + a_d;
-        } else if (have) {
-            atomicAdd(&g_mean2D[2 * (size_t)id], a_mx * halfW);
-            atomicAdd(&g_mean2D[2 * (size_t)id + 1], a_my * halfH);
-            atomicAdd(&g_conic[3 * (size_t)id], -0.5f * a_ca);
-            atomicAdd(&g_conic[3 * (size_t)id + 1], -a_cb);
-            atomicAdd(&g_conic[3 * (size_t)id + 2], -0.5f * a_cc);
-            atomicAdd(&g_opacity[id], a_op);
-            atomicAdd(&g_color[3 * (size_t)id], a_r);
-            atomicAdd(&g_color[3 * (size_t)id + 1], a_g);
-            atomicAdd(&g_color[3 * (size_t)id + 2], a_b);
-            atomicAdd(&g_depth[id], a_d);
-        }
-        __syncthreads();  // single wave: orders the s_pb updates before the next batch reads them
-    }
-}
-
-
-// ---- v2: DPP wave scans (no LDS round trips), two horizontally adjacent pixels per iteration with
-// 2-wide vector arithmetic (v_pk_*_f32), all-idle pixel pairs skipped, atomics only for splats that
-// contributed inside this tile part, depth-gradient path compiled out when dL_ddepth is NULL.
 typedef float v2f __attribute__((ext_vector_type(2)));
 typedef int v2i __attribute__((ext_vector_type(2)));
-
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ float dpp_move(float old, float src) {
-    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(src), CTRL, ROW_MASK, 0xF, false));
-}
-// inclusive wave64 scans, the gfx9 DPP sequence: row_shr 1,2,4,8 then row_bcast15 (rows 1,3), row_bcast31 (rows 2,3)
-__device__ __forceinline__ float dpp_incl_prod(float v) {
-    v *= dpp_move<0x111, 0xF>(1.f, v);
-    v *= dpp_move<0x112, 0xF>(1.f, v);
-    v *= dpp_move<0x114, 0xF>(1.f, v);
-    v *= dpp_move<0x118, 0xF>(1.f, v);
-    v *= dpp_move<0x142, 0xA>(1.f, v);
-    v *= dpp_move<0x143, 0xC>(1.f, v);
-    return v;
-}
-__device__ __forceinline__ float dpp_incl_sum(float v) {
-    v += dpp_move<0x111, 0xF>(0.f, v);
-    v += dpp_move<0x112, 0xF>(0.f, v);
-    v += dpp_move<0x114, 0xF>(0.f, v);
-    v += dpp_move<0x118, 0xF>(0.f, v);
-    v += dpp_move<0x142, 0xA>(0.f, v);
-    v += dpp_move<0x143, 0xC>(0.f, v);
-    return v;
-}
-__device__ __forceinline__ float dpp_shift_right1(float v, float fill) { return dpp_move<0x138, 0xF>(fill, v); }  // wave_shr:1
 __device__ __forceinline__ float lane63(float v) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63)); }
-
-template <bool HAS_DEPTH, bool NOATOMIC = false>
-__device__ __forceinline__ void gp_composite_bwd2_body(RasterDims d, const int2* __restrict__ ranges,
-                                                       const uint32_t* __restrict__ point_list, const float4* __restrict__ rec,
-                                                       const float* __restrict__ bg, const float* __restrict__ out_color,
-                                                       const float* __restrict__ out_depth, const float* __restrict__ final_T,
-                                                       const int32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpix,
-                                                       const float* __restrict__ dL_dpixdepth, float* __restrict__ g_mean2D,
-                                                       float* __restrict__ g_conic, float* __restrict__ g_opacity,
-                                                       float* __restrict__ g_color, float* __restrict__ g_depth) {
-    __shared__ float4 s_pa[CB_PIX];   // dLr, dLg, dLb, dLd
-    __shared__ float4 s_pb[CB_PIX];   // Tot, Tfinal*bg.dLp, T_in, P_in
-    __shared__ int s_nc[CB_PIX];
-    const int parts = GP_TILE / CB_ROWS;
-    const int tile = blockIdx.x / parts, part = blockIdx.x % parts;
-    const int tx = tile % d.gx, ty = tile / d.gx;
-    const int lane = threadIdx.x;
-    const int2 range = ranges[tile];
-    const size_t HW = (size_t)d.H * d.W;
-    const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
-    int max_nc = 0;
-    for (int p = lane; p < CB_PIX; p += 64) {
-        const int px = tx * GP_TILE + (p & 15), py = ty * GP_TILE + part * CB_ROWS + (p >> 4);
-        float4 pa = make_float4(0.f, 0.f, 0.f, 0.f), pb = make_float4(0.f, 0.f, 1.f, 0.f);
-        int nc = 0;
-        if (px < d.W && py < d.H) {
-            const size_t pix = (size_t)py * d.W + px;
-            pa.x = dL_dpix[pix]; pa.y = dL_dpix[HW + pix]; pa.z = dL_dpix[2 * HW + pix];
-            pa.w = HAS_DEPTH ? dL_dpixdepth[pix] : 0.f;
-            const float Tf = final_T[pix];
-            pb.y = Tf * (bg0 * pa.x + bg1 * pa.y + bg2 * pa.z);
-            pb.x = out_color[pix] * pa.x + out_color[HW + pix] * pa.y + out_color[2 * HW + pix] * pa.z - pb.y;
-            if (HAS_DEPTH) pb.x += out_depth[pix] * pa.w;
-            nc = n_contrib[pix];
-        }
-        s_pa[p] = pa; s_pb[p] = pb; s_nc[p] = nc;
-        max_nc = max(max_nc, nc);
-    }
-#pragma unroll
-    for (int dd = 32; dd >= 1; dd >>= 1) max_nc = max(max_nc, __shfl_xor(max_nc, dd));
-    __syncthreads();
-    const float halfW = 0.5f * (float)d.W, halfH = 0.5f * (float)d.H;
-    const int count = min(range.y - range.x, max_nc);
-    const float px_base = (float)(tx * GP_TILE), py_base = (float)(ty * GP_TILE + part * CB_ROWS);
-    for (int b0 = 0; b0 < count; b0 += 64) {
-        const int pos = b0 + lane;
-        const bool have = pos < count;
-        uint32_t id = 0;
-        float4 q0 = make_float4(0.f, 0.f, 0.f, 0.f), q1 = q0, q2 = q0;
-        if (have) {
-            id = point_list[range.x + pos];
-            q0 = rec[3 * (size_t)id]; q1 = rec[3 * (size_t)id + 1]; q2 = rec[3 * (size_t)id + 2];
-        }
-        const float sx = q0.x - px_base, sy = q0.y - py_base;
-        const float A = q0.z, B = q0.w, Cq = q1.x, op = q1.y, zdep = q1.z;
-        const float cxx = -2.f * A, cxy = -B, cyy = -2.f * Cq;
-        v2f a_mx = {0.f, 0.f}, a_my = {0.f, 0.f}, a_ca = {0.f, 0.f}, a_cb = {0.f, 0.f}, a_cc = {0.f, 0.f}, a_op = {0.f, 0.f},
-            a_r = {0.f, 0.f}, a_g = {0.f, 0.f}, a_b = {0.f, 0.f}, a_d = {0.f, 0.f};
-        bool any_c = false;
-#pragma unroll 1
-        for (int row = 0; row < CB_ROWS; ++row) {
-            const float dy = sy - (float)row;
-            const float tB = B * dy, uC = (Cq * dy) * dy;
-#pragma unroll 1
-            for (int col = 0; col < GP_TILE; col += 2) {
-                const int p = row * GP_TILE + col;
-                const int nc0 = s_nc[p], nc1 = s_nc[p + 1];
-                if (max(nc0, nc1) <= b0) continue;   // uniform: both pixels finished before this batch
-                const float dx0 = sx - (float)col;
-                const v2f dx = {dx0, dx0 - 1.f};
-                v2f power;
-                power.x = fmaf(dx.x, fmaf(A, dx.x, tB), uC);
-                power.y = fmaf(dx.y, fmaf(A, dx.y, tB), uC);
-                v2f G;
-                G.x = gp_exp(fminf(power.x, 0.f));
-                G.y = gp_exp(fminf(power.y, 0.f));
-                const v2f alpha = {fminf(0.99f, op * G.x), fminf(0.99f, op * G.y)};
-                const bool c0 = have && (pos < nc0) && !(power.x > 0.f) && !(alpha.x < 1.f / 255.f);
-                const bool c1 = have && (pos < nc1) && !(power.y > 0.f) && !(alpha.y < 1.f / 255.f);
-                if (!__any(c0 || c1)) continue;      // nobody in the wave touches either pixel
-                any_c = any_c || c0 || c1;
-                const v2f om = {c0 ? 1.f - alpha.x : 1.f, c1 ? 1.f - alpha.y : 1.f};
-                const float4 pa0 = s_pa[p], pa1 = s_pa[p + 1];
-                float4 pb0 = s_pb[p], pb1 = s_pb[p + 1];
-                v2f incl = {dpp_incl_prod(om.x), dpp_incl_prod(om.y)};
-                const v2f Tin = {pb0.z, pb1.z};
-                const v2f Tj = {Tin.x * dpp_shift_right1(incl.x, 1.f), Tin.y * dpp_shift_right1(incl.y, 1.f)};
-                v2f cdot;
-                cdot.x = fmaf(q2.x, pa0.x, fmaf(q2.y, pa0.y, q2.z * pa0.z));
-                cdot.y = fmaf(q2.x, pa1.x, fmaf(q2.y, pa1.y, q2.z * pa1.z));
-                if (HAS_DEPTH) { cdot.x = fmaf(zdep, pa0.w, cdot.x); cdot.y = fmaf(zdep, pa1.w, cdot.y); }
-                const v2f w = {c0 ? alpha.x * Tj.x : 0.f, c1 ? alpha.y * Tj.y : 0.f};
-                const v2f sv = w * cdot;
-                const v2f psum = {dpp_incl_sum(sv.x), dpp_incl_sum(sv.y)};
-                // masked lanes have w = 0 and om = 1: every product below vanishes without branching
-                const v2f tot = {pb0.x - pb0.w, pb1.x - pb1.w};
-                const v2f tb = {pb0.y, pb1.y};
-                const v2f rom = {__builtin_amdgcn_rcpf(om.x), __builtin_amdgcn_rcpf(om.y)};
-                const v2f suffix = tot - psum;
-                v2f dL_dalpha = Tj * cdot - (suffix + tb) * rom;
-                dL_dalpha.x = c0 ? dL_dalpha.x : 0.f;
-                dL_dalpha.y = c1 ? dL_dalpha.y : 0.f;
-                const v2f dLr = {pa0.x, pa1.x}, dLg = {pa0.y, pa1.y}, dLb = {pa0.z, pa1.z};
-                a_r += w * dLr; a_g += w * dLg; a_b += w * dLb;
-                if (HAS_DEPTH) { const v2f dLd = {pa0.w, pa1.w}; a_d += w * dLd; }
-                a_op += G * dL_dalpha;
-                const v2f dL_dG = op * dL_dalpha;
-                const v2f gdx = G * dx, gdy = G * dy;
-                a_mx += dL_dG * (-gdx * cxx - gdy * cxy);
-                a_my += dL_dG * (-gdy * cyy - gdx * cxy);
-                a_ca += (gdx * dx) * dL_dG;
-                a_cb += (gdx * dy) * dL_dG;
-                a_cc += (gdy * dy) * dL_dG;
-                // carry to the next batch
-                const float tp0 = lane63(incl.x), tp1 = lane63(incl.y), ts0 = lane63(psum.x), ts1 = lane63(psum.y);
-                if (lane == 0) {
-                    pb0.z *= tp0; pb0.w += ts0; pb1.z *= tp1; pb1.w += ts1;
-                    s_pb[p] = pb0; s_pb[p + 1] = pb1;
-                }
-            }
-        }
-        if (NOATOMIC) {
-            if (have && a_mx.x == 123.456f) g_opacity[id] = a_mx.x + a_mx.y + a_my.x + a_my.y + a_ca.x + a_ca.y + a_cb.x + a_cb.y + a_cc.x + a_cc.y + a_op.x + a_op.y + a_r.x + a_r.y + a_g.x + a_g.y + a_b.x + a_b.y;
-        } else if (have && any_c) {
-            atomicAdd(&g_mean2D[2 * (size_t)id], (a_mx.x + a_mx.y) * halfW);
-            atomicAdd(&g_mean2D[2 * (size_t)id + 1], (a_my.x + a_my.y) * halfH);
-            atomicAdd(&g_conic[3 * (size_t)id], -0.5f * (a_ca.x + a_ca.y));
-            atomicAdd(&g_conic[3 * (size_t)id + 1], -(a_cb.x + a_cb.y));
-            atomicAdd(&g_conic[3 * (size_t)id + 2], -0.5f * (a_cc.x + a_cc.y));
-            atomicAdd(&g_opacity[id], a_op.x + a_op.y);
-            atomicAdd(&g_color[3 * (size_t)id], a_r.x + a_r.y);
-            atomicAdd(&g_color[3 * (size_t)id + 1], a_g.x + a_g.y);
-            atomicAdd(&g_color[3 * (size_t)id + 2], a_b.x + a_b.y);
-            if (HAS_DEPTH) atomicAdd(&g_depth[id], a_d.x + a_d.y);
-        }
-        __syncthreads();
-    }
-}
-
 
 // ---- v3: log-domain transmittance so that BOTH wave scans are sums, done as fused v_add_f32_dpp chains
 // (four interleaved scans per pixel pair: the interleave covers the 2-wait-state DPP hazard), conic
 // pre-scaled by log2(e) so G = exp2(power), contribution masks as {0,1} floats instead of branches,
 // per-pixel-pair constants packed for 128-bit LDS broadcast reads.
 //   L_in(p) = log2 T_in(p);  T_j = exp2(L_in + incl_j - own_j);  rem(p) = Tot - P_in;  suffix_j = rem - incl_j
-__device__ __forceinline__ void dpp_scan4_add(float& a, float& b, float& c, float& d) {
-    asm volatile(
-        "s_nop 1\n\t"
-        "v_add_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %1, %1, %1 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %2, %2, %2 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %3, %3, %3 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %1, %1, %1 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %2, %2, %2 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %3, %3, %3 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %1, %1, %1 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %2, %2, %2 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %3, %3, %3 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %1, %1, %1 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %2, %2, %2 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %3, %3, %3 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
-        "v_add_f32_dpp %1, %1, %1 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
-        "v_add_f32_dpp %2, %2, %2 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
-        "v_add_f32_dpp %3, %3, %3 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
-        "v_add_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
-        "v_add_f32_dpp %1, %1, %1 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
-        "v_add_f32_dpp %2, %2, %2 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
-        "v_add_f32_dpp %3, %3, %3 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
-        "s_nop 1"
-        : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
-}
-
 __device__ __forceinline__ void dpp_scan2_add(float& a, float& b) {
     asm volatile(
         "s_nop 1\n\t"
@@ -1050,6 +704,201 @@ __device__ __forceinline__ void gp_composite_bwd3_body(RasterDims d, const int2*
     }
 }
 
+template <bool HAS_DEPTH, int ROWS>
+__device__ __forceinline__ void gp_composite_bwd4_body(RasterDims d, const int2* __restrict__ ranges,
+                                                       const uint32_t* __restrict__ point_list, const float4* __restrict__ rec,
+                                                       const float* __restrict__ bg, const float* __restrict__ out_color,
+                                                       const float* __restrict__ out_depth, const float* __restrict__ final_T,
+                                                       const int32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpix,
+                                                       const float* __restrict__ dL_dpixdepth, float* __restrict__ g_mean2D,
+                                                       float* __restrict__ g_conic, float* __restrict__ g_opacity,
+                                                       float* __restrict__ g_color, float* __restrict__ g_depth) {
+    // per pixel PAIR (two horizontally adjacent pixels):
+    __shared__ float4 s_v0[(ROWS * GP_TILE / 2)];   // dLr0 dLr1 dLg0 dLg1
+    __shared__ float4 s_v1[(ROWS * GP_TILE / 2)];   // dLb0 dLb1 tb0  tb1      (tb = T_final * bg . dL_dpix)
+    __shared__ float4 s_cy[(ROWS * GP_TILE / 2)];   // Lin0 Lin1 rem0 rem1     (carried between batches)
+    __shared__ int2 s_nc[(ROWS * GP_TILE / 2)];
+    __shared__ float2 s_dd[HAS_DEPTH ? (ROWS * GP_TILE / 2) : 1];   // dLd0 dLd1
+    const int parts = GP_TILE / ROWS;
+    const int tile = blockIdx.x / parts, part = blockIdx.x % parts;
+    const int tx = tile % d.gx, ty = tile / d.gx;
+    const int lane = threadIdx.x;
+    const int2 range = ranges[tile];
+    const size_t HW = (size_t)d.H * d.W;
+    const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
+    int max_nc = 0;
+    for (int pr = lane; pr < ROWS * GP_TILE / 2; pr += 64) {   // one lane per pixel pair
+
+        const int px0 = tx * GP_TILE + 2 * (pr & 7), py = ty * GP_TILE + part * ROWS + (pr >> 3);
+        float dl[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+        float tb[2] = {0.f, 0.f}, rem[2] = {0.f, 0.f};
+        int nc[2] = {0, 0};
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int px = px0 + u;
+            if (px < d.W && py < d.H) {
+                const size_t pix = (size_t)py * d.W + px;
+                dl[u][0] = dL_dpix[pix]; dl[u][1] = dL_dpix[HW + pix]; dl[u][2] = dL_dpix[2 * HW + pix];
+                dl[u][3] = HAS_DEPTH ? dL_dpixdepth[pix] : 0.f;
+                tb[u] = final_T[pix] * (bg0 * dl[u][0] + bg1 * dl[u][1] + bg2 * dl[u][2]);
+                rem[u] = out_color[pix] * dl[u][0] + out_color[HW + pix] * dl[u][1] + out_color[2 * HW + pix] * dl[u][2] - tb[u];
+                if (HAS_DEPTH) rem[u] += out_depth[pix] * dl[u][3];
+                nc[u] = n_contrib[pix];
+            }
+        }
+        s_v0[pr] = make_float4(dl[0][0], dl[1][0], dl[0][1], dl[1][1]);
+        s_v1[pr] = make_float4(dl[0][2], dl[1][2], tb[0], tb[1]);
+        s_cy[pr] = make_float4(0.f, 0.f, rem[0], rem[1]);
+        s_nc[pr] = make_int2(nc[0], nc[1]);
+        if (HAS_DEPTH) s_dd[pr] = make_float2(dl[0][3], dl[1][3]);
+        max_nc = max(max_nc, max(nc[0], nc[1]));
+    }
+#pragma unroll
+    for (int dd = 32; dd >= 1; dd >>= 1) max_nc = max(max_nc, __shfl_xor(max_nc, dd));
+    __syncthreads();
+    const float halfW = 0.5f * (float)d.W, halfH = 0.5f * (float)d.H;
+    const int count = min(range.y - range.x, max_nc);
+    const float px_base = (float)(tx * GP_TILE), py_base = (float)(ty * GP_TILE + part * ROWS);
+    const float LOG2E = 1.4426950408889634f;
+    // ---- compaction: only splats whose alpha >= 1/255 bounding box intersects THIS tile part enter a batch
+    // (stable, so depth order is kept); candidates are fetched 64 at a time, one fetch ahead of the pixel walk.
+    __shared__ float4 s_e0[128], s_e1[128], s_e2[128];
+    __shared__ int s_epos[128];
+    __shared__ uint32_t s_eid[128];
+    const float RX0 = px_base, RX1 = px_base + 15.f, RY0 = py_base, RY1 = py_base + (float)(ROWS - 1);
+    int qn = 0, src = 0;
+    uint32_t c_id = 0;
+    float4 k0 = make_float4(0.f, 0.f, 0.f, 0.f), k1 = k0, k2 = k0;
+    bool c_have = lane < count;
+    if (c_have) {
+        c_id = point_list[range.x + lane];
+        k0 = rec[3 * (size_t)c_id]; k1 = rec[3 * (size_t)c_id + 1]; k2 = rec[3 * (size_t)c_id + 2];
+    }
+    bool pending = count > 0;
+    while (true) {
+        while (qn < 64 && pending) {
+            bool relevant = false;
+            if (c_have) {
+                const float cx_ = -2.f * k0.z, cy_ = -k0.w, cz_ = -2.f * k1.x;
+                const float detc = cx_ * cz_ - cy_ * cy_;
+                const float tau = __logf(255.f * k1.y);
+                if (tau > 0.f && detc > 0.f) {
+                    const float e2 = 2.f * tau * 1.004f / detc;
+                    const float ex = sqrtf(e2 * cz_) + 0.01f, ey = sqrtf(e2 * cx_) + 0.01f;
+                    relevant = (k0.x + ex >= RX0) && (k0.x - ex <= RX1) && (k0.y + ey >= RY0) && (k0.y - ey <= RY1);
+                } else if (!(detc > 0.f) && tau > 0.f) {
+                    relevant = true;
+                }
+            }
+            const unsigned long long mk = __ballot(relevant);
+            const int slot = qn + (int)gp_mbcnt(mk);
+            if (relevant) { s_e0[slot] = k0; s_e1[slot] = k1; s_e2[slot] = k2; s_epos[slot] = src + lane; s_eid[slot] = c_id; }
+            qn += (int)__popcll(mk);
+            src += 64;
+            pending = src < count;
+            c_have = src + lane < count;
+            if (c_have) {
+                c_id = point_list[range.x + src + lane];
+                k0 = rec[3 * (size_t)c_id]; k1 = rec[3 * (size_t)c_id + 1]; k2 = rec[3 * (size_t)c_id + 2];
+            }
+        }
+        if (qn == 0) break;
+        __syncthreads();
+        const int nb = min(64, qn);
+        const bool have = lane < nb;
+        const int b0 = s_epos[0];                       // smallest list position in this batch (uniform)
+        const int pos = have ? s_epos[lane] : 0x7fffffff;
+        const uint32_t id = have ? s_eid[lane] : 0u;
+        float4 q0 = make_float4(0.f, 0.f, 0.f, 0.f), q1 = q0, q2 = q0;
+        if (have) { q0 = s_e0[lane]; q1 = s_e1[lane]; q2 = s_e2[lane]; }
+        {   // pop the batch: entries [64, qn) move to the front
+            float4 m0 = q0, m1 = q1, m2 = q2; int mp = 0; uint32_t mi = 0;
+            const bool mv = lane + 64 < qn;
+            if (mv) { m0 = s_e0[lane + 64]; m1 = s_e1[lane + 64]; m2 = s_e2[lane + 64]; mp = s_epos[lane + 64]; mi = s_eid[lane + 64]; }
+            __syncthreads();
+            if (mv) { s_e0[lane] = m0; s_e1[lane] = m1; s_e2[lane] = m2; s_epos[lane] = mp; s_eid[lane] = mi; }
+            qn -= nb;
+        }
+        const float sx = q0.x - px_base, sy = q0.y - py_base;
+        const float As = q0.z * LOG2E, Bs = q0.w * LOG2E, Cs = q1.x * LOG2E;   // power in log2 units
+        const float op = have ? q1.y : 0.f, zdep = q1.z;
+        const float cxx = -2.f * q0.z, cxy = -q0.w, cyy = -2.f * q1.x;
+        const v2f cr = {q2.x, q2.x}, cg = {q2.y, q2.y}, cb = {q2.z, q2.z};
+        v2f a_mx = {0.f, 0.f}, a_my = {0.f, 0.f}, a_ca = {0.f, 0.f}, a_cb = {0.f, 0.f}, a_cc = {0.f, 0.f}, a_op = {0.f, 0.f},
+            a_r = {0.f, 0.f}, a_g = {0.f, 0.f}, a_b = {0.f, 0.f}, a_d = {0.f, 0.f};
+        float any_m = 0.f;
+#pragma unroll 1
+        for (int row = 0; row < ROWS; ++row) {
+            const float dy = sy - (float)row;
+            const float tB = Bs * dy, uC = (Cs * dy) * dy;
+#pragma unroll 1
+            for (int cp = 0; cp < GP_TILE / 2; ++cp) {
+                const int pr = row * (GP_TILE / 2) + cp;
+                const int2 nc = s_nc[pr];
+                if (max(nc.x, nc.y) <= b0) continue;   // uniform: both pixels finished before this batch
+                const float dx0 = sx - (float)(2 * cp);
+                const v2f dx = {dx0, dx0 - 1.f};
+                const v2f pw = {fmaf(dx.x, fmaf(As, dx.x, tB), uC), fmaf(dx.y, fmaf(As, dx.y, tB), uC)};
+                const v2f G = {__builtin_amdgcn_exp2f(fminf(pw.x, 0.f)), __builtin_amdgcn_exp2f(fminf(pw.y, 0.f))};
+                const v2f alpha = {fminf(0.99f, op * G.x), fminf(0.99f, op * G.y)};
+                const bool c0 = (pos < nc.x) && !(pw.x > 0.f) && !(alpha.x < 1.f / 255.f);
+                const bool c1 = (pos < nc.y) && !(pw.y > 0.f) && !(alpha.y < 1.f / 255.f);
+                if (!__any(c0 || c1)) continue;        // nobody in the wave touches either pixel
+                const v2f m = {c0 ? 1.f : 0.f, c1 ? 1.f : 0.f};
+                any_m = fmaxf(any_m, fmaxf(m.x, m.y));
+                const v2f am = alpha * m;
+                const v2f om = 1.f - am;
+                float l0 = __builtin_amdgcn_logf(om.x), l1 = __builtin_amdgcn_logf(om.y);   // log2, exactly 0 for om == 1
+                const float4 v0 = s_v0[pr], v1 = s_v1[pr], cy = s_cy[pr];
+                v2f cdot = cb * (v2f){v1.x, v1.y};
+                cdot = cg * (v2f){v0.z, v0.w} + cdot;
+                cdot = cr * (v2f){v0.x, v0.y} + cdot;
+                v2f dLd = {0.f, 0.f};
+                if (HAS_DEPTH) { const float2 t = s_dd[pr]; dLd.x = t.x; dLd.y = t.y; cdot = zdep * dLd + cdot; }
+                // T_j needs the EXCLUSIVE log-sum, s_j = alpha_j T_j cdot needs T_j: scan the logs first
+                float il0 = l0, il1 = l1;
+                dpp_scan2_add(il0, il1);
+                const v2f Tj = {__builtin_amdgcn_exp2f(cy.x + il0 - l0), __builtin_amdgcn_exp2f(cy.y + il1 - l1)};
+                const v2f w = am * Tj;
+                const v2f sv = w * cdot;
+                float is0 = sv.x, is1 = sv.y;
+                dpp_scan2_add(is0, is1);
+                const v2f rem = {cy.z, cy.w};
+                const v2f tbv = {v1.z, v1.w};
+                const v2f rom = {__builtin_amdgcn_rcpf(om.x), __builtin_amdgcn_rcpf(om.y)};
+                const v2f suffix = rem - (v2f){is0, is1};
+                const v2f dL_dalpha = (Tj * cdot - (suffix + tbv) * rom) * m;
+                a_r += w * (v2f){v0.x, v0.y}; a_g += w * (v2f){v0.z, v0.w}; a_b += w * (v2f){v1.x, v1.y};
+                if (HAS_DEPTH) a_d += w * dLd;
+                a_op += G * dL_dalpha;
+                const v2f dL_dG = op * dL_dalpha;
+                const v2f gdx = G * dx, gdy = G * dy;
+                a_mx += dL_dG * (-gdx * cxx - gdy * cxy);
+                a_my += dL_dG * (-gdy * cyy - gdx * cxy);
+                a_ca += (gdx * dx) * dL_dG;
+                a_cb += (gdx * dy) * dL_dG;
+                a_cc += (gdy * dy) * dL_dG;
+                // carry to the next batch
+                const float tl0 = lane63(il0), tl1 = lane63(il1), ts0 = lane63(is0), ts1 = lane63(is1);
+                if (lane == 0) s_cy[pr] = make_float4(cy.x + tl0, cy.y + tl1, cy.z - ts0, cy.w - ts1);
+            }
+        }
+        if (have && any_m > 0.f) {
+            atomicAdd(&g_mean2D[2 * (size_t)id], (a_mx.x + a_mx.y) * halfW);
+            atomicAdd(&g_mean2D[2 * (size_t)id + 1], (a_my.x + a_my.y) * halfH);
+            atomicAdd(&g_conic[3 * (size_t)id], -0.5f * (a_ca.x + a_ca.y));
+            atomicAdd(&g_conic[3 * (size_t)id + 1], -(a_cb.x + a_cb.y));
+            atomicAdd(&g_conic[3 * (size_t)id + 2], -0.5f * (a_cc.x + a_cc.y));
+            atomicAdd(&g_opacity[id], a_op.x + a_op.y);
+            atomicAdd(&g_color[3 * (size_t)id], a_r.x + a_r.y);
+            atomicAdd(&g_color[3 * (size_t)id + 1], a_g.x + a_g.y);
+            atomicAdd(&g_color[3 * (size_t)id + 2], a_b.x + a_b.y);
+            if (HAS_DEPTH) atomicAdd(&g_depth[id], a_d.x + a_d.y);
+        }
+        __syncthreads();
+    }
+}
+
 #define CB_ARGS RasterDims d, const int2* __restrict__ ranges, const uint32_t* __restrict__ point_list, \
     const float4* __restrict__ rec, const float* __restrict__ bg, const float* __restrict__ out_color, \
     const float* __restrict__ out_depth, const float* __restrict__ final_T, const int32_t* __restrict__ n_contrib, \
@@ -1057,15 +906,10 @@ __device__ __forceinline__ void gp_composite_bwd3_body(RasterDims d, const int2*
     float* __restrict__ g_conic, float* __restrict__ g_opacity, float* __restrict__ g_color, float* __restrict__ g_depth
 #define CB_PASS d, ranges, point_list, rec, bg, out_color, out_depth, final_T, n_contrib, dL_dpix, dL_dpixdepth, g_mean2D, \
     g_conic, g_opacity, g_color, g_depth
-__global__ __launch_bounds__(64) void gp_composite_bwd_kernel(CB_ARGS) { gp_composite_bwd_kernel_t<false>(CB_PASS); }
-__global__ __launch_bounds__(64) void gp_composite_bwd_noatomic_kernel(CB_ARGS) { gp_composite_bwd2_body<false, true>(CB_PASS); }
-__global__ __launch_bounds__(64) void gp_composite_bwd2_kernel(CB_ARGS) { gp_composite_bwd2_body<false>(CB_PASS); }
-__global__ __launch_bounds__(64) void gp_composite_bwd2_depth_kernel(CB_ARGS) { gp_composite_bwd2_body<true>(CB_PASS); }
 __global__ __launch_bounds__(64) void gp_composite_bwd3_kernel(CB_ARGS) { gp_composite_bwd3_body<false, 8>(CB_PASS); }
 __global__ __launch_bounds__(64) void gp_composite_bwd3_depth_kernel(CB_ARGS) { gp_composite_bwd3_body<true, 8>(CB_PASS); }
-__global__ __launch_bounds__(64) void gp_composite_bwd3_r4_kernel(CB_ARGS) { gp_composite_bwd3_body<false, 4>(CB_PASS); }
-__global__ __launch_bounds__(64) void gp_composite_bwd3_r2_kernel(CB_ARGS) { gp_composite_bwd3_body<false, 2>(CB_PASS); }
-__global__ __launch_bounds__(64) void gp_composite_bwd3_r16_kernel(CB_ARGS) { gp_composite_bwd3_body<false, 16>(CB_PASS); }
+__global__ __launch_bounds__(64) void gp_composite_bwd4_kernel(CB_ARGS) { gp_composite_bwd4_body<false, 8>(CB_PASS); }
+__global__ __launch_bounds__(64) void gp_composite_bwd4_depth_kernel(CB_ARGS) { gp_composite_bwd4_body<true, 8>(CB_PASS); }
 
 // ------------------------------------------------------------------------------------------------
 // preprocess backward (per Gaussian) -- mirrors gpo_preprocess_bwd of the oracle

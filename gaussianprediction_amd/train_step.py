@@ -60,19 +60,31 @@ class TrainStep:
                   kpts=8e-4, mlp=8e-4)              # [REF arguments/__init__.py:74-90]
         if lrs:
             lr.update(lrs)
-        groups = [
+        # parameter groups per training stage, as the reference builds them
+        # [REF scene/gaussian_model.py:394-411 (stage 3), 413-430 (stage 2), 432-451 (stage 1)]
+        g_gauss = [
             {"params": [pc._xyz], "lr": lr["xyz"], "name": "xyz"},
             {"params": [pc._features_dc], "lr": lr["f_dc"], "name": "f_dc"},
             {"params": [pc._features_rest], "lr": lr["f_rest"], "name": "f_rest"},
             {"params": [pc._opacity], "lr": lr["opacity"], "name": "opacity"},
             {"params": [pc._scaling], "lr": lr["scaling"], "name": "scaling"},
             {"params": [pc._rotation], "lr": lr["rotation"], "name": "rotation"},
-            {"params": [pc.motion_feature], "lr": lr["mfeature"], "name": "motion_feature"},
-            {"params": list(pc.df_model.parameters()), "lr": lr["mlp"], "name": "df_mlp"},
         ]
+        g_mlp = [{"params": list(pc.df_model.parameters()), "lr": lr["mlp"], "name": "df_mlp"}]
+        g_kp = []
         if hasattr(pc, "super_gaussians"):
-            groups += [{"params": [pc.super_gaussians], "lr": lr["kpts"], "name": "s_xyz"},
-                       {"params": [pc.super_gaussians_feature], "lr": lr["mfeature"], "name": "s_motion_feature"}]
+            g_kp = [{"params": [pc.super_gaussians], "lr": lr["kpts"], "name": "s_xyz"},
+                    {"params": [pc.super_gaussians_feature], "lr": lr["kpts"], "name": "s_motion_feature"}]
+        if iteration <= pc.second_stage_iter:                      # stage 1
+            groups = g_gauss + g_mlp + [{"params": [pc.motion_feature], "lr": lr["mfeature"], "name": "motion_feature"}]
+        elif iteration <= pc.third_stage_iter:                     # stage 2: keypoints + MLP only
+            groups = g_kp + g_mlp
+        else:                                                      # stage 3: everything except the per-Gaussian feature
+            groups = g_gauss + g_kp + g_mlp
+        optimized = {id(p) for g in groups for p in g["params"]}
+        for p in pc.parameters():                                  # the reference computes (and ignores) these grads
+            if id(p) not in optimized:
+                p.requires_grad_(False)
         self.bucket = FlatGradBucket([p for g in groups for p in g["params"]])
         self.reducer = OverlappedGradReducer(self.bucket, group)
         if fused:
