@@ -37,10 +37,12 @@ def build_workload(args, device):
     from gaussianprediction_amd.cameras import orbit_cameras
     from gaussianprediction_amd.scene_synth import SceneSpec, make_gaussians, make_keypoints
     margs = SimpleNamespace(beta=0.1, d=4, w=256, feature_dim=32, second_stage_iteration=30000, third_stage_iteration=40000,
-                            jointly_iteration=1000, nearest_num=args.nearest_num, norm_rotation=True, step_opacity=False,
-                            step_opacity_iteration=5000, opacity_type="implicit", xyz_noise_iteration=0)
+                            jointly_iteration=1000, nearest_num=args.nearest_num, norm_rotation=True,
+                            step_opacity=bool(getattr(args, "step_opacity", False)), step_opacity_iteration=5000,
+                            opacity_type="implicit", xyz_noise_iteration=0)
     time_freq = args.time_freq
-    raw = make_gaussians(SceneSpec(n_gaussians=args.gaussians, extent=(1.5, 1.5, 0.5), scale_lo=args.scale_lo,
+    extent = getattr(args, "extent", (1.5, 1.5, 0.5))
+    raw = make_gaussians(SceneSpec(n_gaussians=args.gaussians, extent=extent, scale_lo=args.scale_lo,
                                    scale_hi=args.scale_hi, seed=2024), device=device)
     kp, kpf, idx, raw_w = make_keypoints(raw["xyz"], raw["motion_feature"], args.keypoints, margs.nearest_num)
     torch.manual_seed(2024)
@@ -49,8 +51,9 @@ def build_workload(args, device):
     pc.create_from_tensors(raw["xyz"], raw["features_dc"], raw["features_rest"], raw["scaling"], raw["rotation"], raw["opacity"],
                            raw["motion_feature"], kp, kpf)
     pc.set_keypoint_weights(raw_w, idx)
-    fovx = 2 * math.atan(1.0 / (2 * 0.9))           # focal ~ 0.9 W
-    cams = orbit_cameras(8, 4.0, fovx, args.width, args.height, arc_deg=40.0, elevation_deg=5.0, device=device)
+    fovx = getattr(args, "fovx", None) or 2 * math.atan(1.0 / (2 * 0.9))           # focal ~ 0.9 W
+    cams = orbit_cameras(8, 4.0, fovx, args.width, args.height, arc_deg=getattr(args, "arc_deg", 40.0),
+                         elevation_deg=getattr(args, "elevation_deg", 5.0), device=device)
     # ground truth = the scene itself rendered at a slightly later time + pixel noise: a small, realistic
     # residual (a pure-noise target would make Adam fling the Gaussians out of view within a few steps and
     # the workload R would not be stationary over the timed region)

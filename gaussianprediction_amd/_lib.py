@@ -55,6 +55,14 @@ class MlpParamsC(C.Structure):
                 ("w", C.c_void_p * 5), ("b", C.c_void_p * 5)]
 
 
+class Mlp16ParamsC(C.Structure):
+    _fields_ = [("dtype", C.c_int32), ("in_dim", C.c_int32), ("width", C.c_int32), ("depth", C.c_int32), ("out_dim", C.c_int32),
+                ("w16", C.c_void_p * 5), ("b", C.c_void_p * 5)]
+
+
+GP_DTYPE_F16, GP_DTYPE_BF16 = 1, 2
+
+
 class MlpGradsC(C.Structure):
     _fields_ = [("dw", C.c_void_p * 5), ("db", C.c_void_p * 5)]
 
@@ -76,7 +84,7 @@ class ProfileEntryC(C.Structure):
 
 EXPORTS = [
     "gp_raster_forward", "gp_raster_backward", "gp_raster_mark_visible", "gp_raster_debug_binning",
-    "gp_mlp_forward", "gp_mlp_backward", "gp_blend_forward", "gp_blend_backward",
+    "gp_mlp_forward", "gp_mlp_backward", "gp_mlp16_forward", "gp_mlp16_backward", "gp_blend_forward", "gp_blend_backward",
     "gp_activations_forward", "gp_activations_backward", "gp_profile_enable", "gp_profile_collect",
     "gp_loss_l1_ssim_forward", "gp_loss_l1_ssim_finalize", "gp_loss_l1_ssim_backward", "gp_adam_step",
     "gp_adam_step_multi",

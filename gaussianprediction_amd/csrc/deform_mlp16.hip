@@ -1,0 +1,590 @@
+// deform_mlp16.hip -- fused PE + Deformable_Field MLP with 16-bit operands (fp16 or bf16) and fp32
+// accumulation on the gfx950 matrix cores (v_mfma_f32_32x32x16_{f16,bf16}: 16x the fp32-MFMA rate).
+// BASELINE config 5 ("deformation MLP on MFMA fp16"); opt-in via Deformable_Field(precision=...),
+// the default stays exact fp32 (deform_kernels.hip) because the 1e-4 RGB parity bar covers the chain.
+//
+// Orientation (differs from the fp32 kernel on purpose): D[row][feature] = sum_k X[row][k] W[feature][k].
+//   A operand = activations from LDS: act[row][k] row-major, 16-byte XOR swizzle ((row & 15) << 4 bytes),
+//               one ds_read_b128 = the lane's 8 consecutive k
+//   B operand = nn.Linear weights [out][in] row-major (16-bit copy), one 16-byte global load per lane
+// Both operands use the same lane -> k-slice assumption, so the contraction is correct for any
+// hardware k-permutation.  A workgroup = 4 waves = 64 rows; wave w owns output features [64w, 64w+64).
+// Saved for backward (training): H_l TRANSPOSED ([256][rows], so the weight-gradient GEMM reads 8
+// consecutive rows per lane as one 16-byte load) and a ReLU sign bitmask (32 B per row per layer).
+// fp16 backward runs the whole dZ chain scaled by a power of two picked on the device from max|dL_dout|.
+#include "gp_common.h"
+#include "deform_kernels.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef __bf16 b8 __attribute__((ext_vector_type(8)));
+
+template <typename T> struct Vec8;
+template <> struct Vec8<_Float16> { typedef h8 type; };
+template <> struct Vec8<__bf16> { typedef b8 type; };
+// fp16 backward: the dZ chain is scaled by a power of two chosen on the device from max|dL_dout| so that
+// the largest entry lands near 2^12 (no overflow at 65504, small gradients stay normal); bf16 needs none.
+template <typename T> struct UsesScale;
+template <> struct UsesScale<_Float16> { static constexpr bool v = true; };
+template <> struct UsesScale<__bf16> { static constexpr bool v = false; };
+__device__ __forceinline__ float grad_scale_from(const uint32_t* absmax_bits) {
+    const float mx = __uint_as_float(absmax_bits[0]);
+    if (!(mx > 0.f)) return 1.f;
+    float e = floorf(12.f - log2f(mx));
+    e = fminf(fmaxf(e, -60.f), 60.f);
+    return exp2f(e);
+}
+__global__ __launch_bounds__(256) void gp_absmax_kernel(const float* __restrict__ x, size_t n, uint32_t* __restrict__ out) {
+    float m = 0.f;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) m = fmaxf(m, fabsf(x[i]));
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) m = fmaxf(m, __shfl_xor(m, d));
+    if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(out, __float_as_uint(m));   // non-negative floats order like their bits
+}
+
+__device__ __forceinline__ f32x16 mfma16(h8 a, h8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ f32x16 mfma16(b8 a, b8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+
+#define M16_ROWS 64
+#define M16_THREADS 256
+#define M16_W 256
+
+// element index of (row, feature) in the swizzled [64][256] tile (16-byte granules XORed by row & 15)
+__device__ __forceinline__ int a16_idx(int row, int f) { return row * M16_W + (f ^ ((row & 15) << 3)); }
+__device__ __forceinline__ int cd_row16(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
+
+struct Mlp16Dev {
+    long rows;
+    int in_dim, in_pad, out_dim;       // in_pad = in_dim rounded up to 16
+    int feature_dim, xyz_freq, time_freq;
+    const void* w[5];                  // 16-bit copies: [256][in_pad], 3 x [256][256], [32][256] (rows >= out_dim zero)
+    const float* b[5];                 // fp32 biases
+    const float* feature;
+    const float* xyz;
+    const float* t;
+};
+
+// hardware sin/cos (v_sin_f32 / v_cos_f32 take revolutions and reduce the range themselves, |x| < 256 rev):
+// ~1e-5 absolute error, far below 16-bit operand precision; 4 instructions instead of ~150 for ocml sincosf
+__device__ __forceinline__ void fast_sincos(float a, float* s, float* c) {
+    const float rev = a * 0.15915494309189535f;
+    *s = __builtin_amdgcn_sinf(rev);
+    *c = __builtin_amdgcn_cosf(rev);
+}
+
+template <typename T>
+__device__ __forceinline__ void build_input16(T* buf, const Mlp16Dev& p, long row0, int tid) {
+    const int fd = p.feature_dim, xf = p.xyz_freq, tf = p.time_freq;
+    for (int e = tid; e < fd * M16_ROWS; e += M16_THREADS) {
+        const int jj = e / fd, f = e - jj * fd;
+        const long row = row0 + jj;
+        buf[a16_idx(jj, f)] = (T)(row < p.rows ? p.feature[row * fd + f] : 0.f);
+    }
+    for (int e = tid; e < 3 * xf * M16_ROWS; e += M16_THREADS) {
+        const int jj = e % M16_ROWS, cf = e / M16_ROWS;
+        const int c = cf / xf, fr = cf - c * xf;
+        const long row = row0 + jj;
+        float sv = 0.f, cv = 0.f;
+        if (row < p.rows) fast_sincos(p.xyz[row * 3 + c] * (float)(1u << fr), &sv, &cv);
+        const int f = fd + 2 * cf;
+        buf[a16_idx(jj, f)] = (T)sv;
+        buf[a16_idx(jj, f + 1)] = (T)cv;
+    }
+    const float tv = tf > 0 ? p.t[0] : 0.f;
+    for (int e = tid; e < tf * M16_ROWS; e += M16_THREADS) {
+        const int jj = e % M16_ROWS, fr = e / M16_ROWS;
+        float sv, cv;
+        fast_sincos(tv * (float)(1u << fr), &sv, &cv);
+        const bool ok = row0 + jj < p.rows;
+        const int f = fd + 6 * xf + 2 * fr;
+        buf[a16_idx(jj, f)] = (T)(ok ? sv : 0.f);
+        buf[a16_idx(jj, f + 1)] = (T)(ok ? cv : 0.f);
+    }
+    for (int e = tid; e < (p.in_pad - p.in_dim) * M16_ROWS; e += M16_THREADS) {
+        const int jj = e % M16_ROWS, f = p.in_dim + e / M16_ROWS;
+        buf[a16_idx(jj, f)] = (T)0.f;
+    }
+}
+
+// acc[rt][nt] += X[64 x K] . W[feature tile][K]^T for this wave's two feature tiles.
+// The weight fragments (straight from L2) are software-pipelined in groups of four k-steps: the 8 loads
+// of group g+1 are in flight while the 16 MFMAs (512 matrix-pipe cycles) of group g execute.
+template <typename T>
+__device__ __forceinline__ void gemm16(const T* cur, const T* __restrict__ W, int ldk, int K, int n_feat, int wave, int lane,
+                                       f32x16 acc[2][2]) {
+    typedef typename Vec8<T>::type V8;
+    const int half = lane >> 5, j = lane & 31;
+    const int f0 = (2 * wave) * 32 + j, f1 = f0 + 32;
+    const T* w0 = W + (size_t)f0 * ldk + 8 * half;
+    const T* w1 = W + (size_t)f1 * ldk + 8 * half;
+    const bool ok0 = f0 < n_feat, ok1 = f1 < n_feat;
+    const int nks = K / 16;
+    V8 zero;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) zero[e] = (T)0.f;
+    // A-fragment base for row j; the swizzled column of k-step ks is ((ks*16 + 8*half) ^ ((j & 15) << 3)):
+    // bits 3..6 only, so it is computed with one XOR on a per-lane constant
+    const T* arow = cur + j * M16_W;
+    const int swz = ((j & 15) << 3) ^ (8 * half);
+    V8 bn[4][2];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        bn[u][0] = (ok0 && u < nks) ? *(const V8*)(w0 + u * 16) : zero;
+        bn[u][1] = (ok1 && u < nks) ? *(const V8*)(w1 + u * 16) : zero;
+    }
+    for (int ks = 0; ks < nks; ks += 4) {
+        V8 bc[4][2];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { bc[u][0] = bn[u][0]; bc[u][1] = bn[u][1]; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {   // prefetch the next group
+            const int kn = ks + 4 + u;
+            bn[u][0] = (ok0 && kn < nks) ? *(const V8*)(w0 + kn * 16) : zero;
+            bn[u][1] = (ok1 && kn < nks) ? *(const V8*)(w1 + kn * 16) : zero;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (ks + u < nks) {
+                const int col = ((ks + u) * 16) ^ swz;
+                const V8 a0 = *(const V8*)(arow + col);
+                const V8 a1 = *(const V8*)(arow + 32 * M16_W + col);
+                acc[0][0] = mfma16(a0, bc[u][0], acc[0][0]);
+                acc[0][1] = mfma16(a0, bc[u][1], acc[0][1]);
+                acc[1][0] = mfma16(a1, bc[u][0], acc[1][0]);
+                acc[1][1] = mfma16(a1, bc[u][1], acc[1][1]);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ void mlp16_fwd_body(Mlp16Dev p, float* __restrict__ out, T* __restrict__ saved_xT /*[in_pad][rows]*/,
+                                               T* __restrict__ saved_hT /*[4][256][rows]*/,
+                                               uint32_t* __restrict__ masks /*[4][rows][8]*/) {
+    __shared__ T smem[2][M16_ROWS * M16_W];
+    typedef typename Vec8<T>::type V8;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, j = lane & 31;
+    const long row0 = (long)blockIdx.x * M16_ROWS;
+    T* cur = smem[0];
+    T* nxt = smem[1];
+    build_input16<T>(cur, p, row0, tid);
+    __syncthreads();
+    // transposed copy-out of a tile: dst[f][row0 + r] for f < nf  (64 consecutive rows = 128 B per feature)
+    auto store_T = [&](const T* buf, T* dst, int nf) {
+        for (int e = tid; e < nf * M16_ROWS; e += M16_THREADS) {
+            const int f = e / M16_ROWS, r = e - f * M16_ROWS;
+            if (row0 + r < p.rows) dst[(size_t)f * p.rows + row0 + r] = buf[a16_idx(r, f)];
+        }
+    };
+    if (saved_xT) store_T(cur, saved_xT, p.in_pad);
+    // epilogue write offsets, computed once: wbase[nt][c] = 4*half*256 + (f_nt ^ (((c&3) + 8*(c>>2) + 4*half) << 3))
+    int wbase[2][8];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+            wbase[nt][c] = 4 * half * M16_W + (((2 * wave + nt) * 32 + j) ^ ((((c & 3) + 8 * (c >> 2)) | (4 * half)) << 3));
+    for (int l = 0; l < 4; ++l) {
+        const int K = l == 0 ? p.in_pad : M16_W;
+        f32x16 acc[2][2];
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                const float bv = p.b[l][(2 * wave + nt) * 32 + j];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[rt][nt][r] = bv;
+            }
+        gemm16<T>(cur, (const T*)p.w[l], K, K, M16_W, wave, lane, acc);
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float v = fmaxf(acc[rt][nt][r], 0.f);
+                    const int row = rt * 32 + cd_row16(r, half);
+                    // == a16_idx(row, f): (row & 15) = cr | 4*half with cr = (r&3) + 8*((r>>2)&1) known at compile time
+                    nxt[(rt * 32 + (r & 3) + 8 * (r >> 2)) * M16_W + wbase[nt][(r & 3) + 4 * ((r >> 2) & 1)]] = (T)v;
+                    if (masks) {   // sign bits of this (row, 32-feature tile): low word = half 0's row, high word = half 1's row
+                        const unsigned long long bal = __ballot(v > 0.f);
+                        const long grow = row0 + row;
+                        if (j == 0 && grow < p.rows)
+                            masks[((size_t)l * p.rows + grow) * 8 + (2 * wave + nt)] = half ? (uint32_t)(bal >> 32) : (uint32_t)bal;
+                    }
+                }
+            }
+        __syncthreads();
+        if (saved_hT) store_T(nxt, saved_hT + (size_t)l * M16_W * p.rows, M16_W);
+        T* t = cur; cur = nxt; nxt = t;
+    }
+    {   // output layer: W4 padded to [32][256]; the 4 waves split K, reduce through LDS (fp32)
+        f32x16 acc[2];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc[0][r] = 0.f; acc[1][r] = 0.f; }
+        const T* w4 = (const T*)p.w[4] + (size_t)j * M16_W + 8 * half;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int ks = 4 * wave + u;
+            const V8 b = *(const V8*)(w4 + ks * 16);
+            const V8 a0 = *(const V8*)(cur + a16_idx(j, ks * 16 + 8 * half));
+            const V8 a1 = *(const V8*)(cur + a16_idx(32 + j, ks * 16 + 8 * half));
+            acc[0] = mfma16(a0, b, acc[0]);
+            acc[1] = mfma16(a1, b, acc[1]);
+        }
+        float* red = (float*)nxt;   // [4 waves][64 rows][8]
+        if (j < 8) {
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) red[(wave * M16_ROWS + rt * 32 + cd_row16(r, half)) * 8 + j] = acc[rt][r];
+        }
+        __syncthreads();
+        for (int e = tid; e < M16_ROWS * 8; e += M16_THREADS) {
+            const int r = e / 8, f = e % 8;
+            if (f < p.out_dim && row0 + r < p.rows) {
+                float v = p.b[4][f];
+#pragma unroll
+                for (int w = 0; w < 4; ++w) v += red[(w * M16_ROWS + r) * 8 + f];
+                out[(row0 + r) * p.out_dim + f] = v;
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(M16_THREADS) void gp_mlp16_fwd_f16_kernel(Mlp16Dev p, float* out, void* sx, void* sh, uint32_t* masks) {
+    mlp16_fwd_body<_Float16>(p, out, (_Float16*)sx, (_Float16*)sh, masks);
+}
+__global__ __launch_bounds__(M16_THREADS) void gp_mlp16_fwd_bf16_kernel(Mlp16Dev p, float* out, void* sx, void* sh, uint32_t* masks) {
+    mlp16_fwd_body<__bf16>(p, out, (__bf16*)sx, (__bf16*)sh, masks);
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward, data chain.  wt[l] = TRANSPOSED 16-bit weights: wt[4]: [256][16] (k >= out_dim zero),
+// wt[1..3]: [256][256] (= W_l^T), wt[0]: [in_pad][256] (= W_0^T, rows >= in_dim zero).
+// Writes dZ_l TRANSPOSED ([4][256][rows], scaled) for the weight-gradient GEMM.
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ void mlp16_bwd_data_body(Mlp16Dev p, const uint32_t* __restrict__ masks,
+                                                    const float* __restrict__ dL_dout, T* __restrict__ dzT,
+                                                    float* __restrict__ dfeature, float* __restrict__ dxyz,
+                                                    const uint32_t* __restrict__ absmax_bits) {
+    __shared__ T smem[2][M16_ROWS * M16_W];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, j = lane & 31;
+    const long row0 = (long)blockIdx.x * M16_ROWS;
+    const float S = UsesScale<T>::v ? grad_scale_from(absmax_bits) : 1.f;
+    T* cur = smem[0];
+    T* nxt = smem[1];
+    for (int e = tid; e < 16 * M16_ROWS; e += M16_THREADS) {
+        const int r = e / 16, f = e % 16;
+        const long row = row0 + r;
+        cur[a16_idx(r, f)] = (T)((f < p.out_dim && row < p.rows) ? dL_dout[row * p.out_dim + f] * S : 0.f);
+    }
+    __syncthreads();
+    int wbase[2][8];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+            wbase[nt][c] = 4 * half * M16_W + (((2 * wave + nt) * 32 + j) ^ ((((c & 3) + 8 * (c >> 2)) | (4 * half)) << 3));
+    for (int l = 4; l >= 1; --l) {
+        const int K = l == 4 ? 16 : M16_W;
+        f32x16 acc[2][2];
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[rt][nt][r] = 0.f;
+        gemm16<T>(cur, (const T*)p.w[l], K, K, M16_W, wave, lane, acc);
+        const uint32_t* mk = masks + (size_t)(l - 1) * p.rows * 8;
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = rt * 32 + cd_row16(r, half);
+                    const long grow = row0 + row;
+                    const uint32_t m = grow < p.rows ? mk[grow * 8 + (2 * wave + nt)] : 0u;
+                    nxt[(rt * 32 + (r & 3) + 8 * (r >> 2)) * M16_W + wbase[nt][(r & 3) + 4 * ((r >> 2) & 1)]] =
+                        (T)(((m >> j) & 1u) ? acc[rt][nt][r] : 0.f);
+                }
+            }
+        __syncthreads();
+        {   // dZ_l^T -> global [256][rows]
+            T* dst = dzT + (size_t)(l - 1) * M16_W * p.rows;
+            for (int e = tid; e < M16_W * M16_ROWS; e += M16_THREADS) {
+                const int f = e / M16_ROWS, r = e - f * M16_ROWS;
+                if (row0 + r < p.rows) dst[(size_t)f * p.rows + row0 + r] = nxt[a16_idx(r, f)];
+            }
+        }
+        T* t = cur; cur = nxt; nxt = t;
+    }
+    if (dfeature || dxyz) {
+        // dX[64][in_pad] = dZ_1 . W_0 ; feature tiles beyond in_pad are skipped; result kept in fp32 in LDS
+        f32x16 acc[2][2];
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[rt][nt][r] = 0.f;
+        if (wave * 64 < p.in_pad) gemm16<T>(cur, (const T*)p.w[0], M16_W, M16_W, p.in_pad, wave, lane, acc);
+        float* dX = (float*)nxt;   // [64][128] fp32 = 32 KB
+        const float inv = 1.f / S;
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                const int f = (2 * wave + nt) * 32 + j;
+                if (f < 128) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) dX[(rt * 32 + cd_row16(r, half)) * 128 + f] = acc[rt][nt][r] * inv;
+                }
+            }
+        __syncthreads();
+        if (dfeature) {
+            const int fd = p.feature_dim;
+            for (int e = tid; e < fd * M16_ROWS; e += M16_THREADS) {
+                const int r = e / fd, f = e - r * fd;
+                if (row0 + r < p.rows) dfeature[(row0 + r) * fd + f] = dX[r * 128 + f];
+            }
+        }
+        if (dxyz && tid < 3 * M16_ROWS) {
+            const int r = tid / 3, c = tid % 3;
+            const long row = row0 + r;
+            if (row < p.rows) {
+                const float x = p.xyz[row * 3 + c];
+                float g = 0.f;
+                for (int fr = 0; fr < p.xyz_freq; ++fr) {
+                    const float sc = (float)(1u << fr);
+                    float sv, cv;
+                    sincosf(x * sc, &sv, &cv);
+                    const int f = p.feature_dim + 2 * (c * p.xyz_freq + fr);
+                    g += sc * (cv * dX[r * 128 + f] - sv * dX[r * 128 + f + 1]);
+                }
+                dxyz[row * 3 + c] = g;
+            }
+        }
+    }
+}
+__global__ __launch_bounds__(M16_THREADS) void gp_mlp16_bwd_data_f16_kernel(Mlp16Dev p, const uint32_t* masks, const float* dL_dout,
+                                                                             void* dzT, float* dfeature, float* dxyz, const uint32_t* absmax_bits) {
+    mlp16_bwd_data_body<_Float16>(p, masks, dL_dout, (_Float16*)dzT, dfeature, dxyz, absmax_bits);
+}
+__global__ __launch_bounds__(M16_THREADS) void gp_mlp16_bwd_data_bf16_kernel(Mlp16Dev p, const uint32_t* masks, const float* dL_dout,
+                                                                              void* dzT, float* dfeature, float* dxyz, const uint32_t* absmax_bits) {
+    mlp16_bwd_data_body<__bf16>(p, masks, dL_dout, (__bf16*)dzT, dfeature, dxyz, absmax_bits);
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward, weight grads: dW[o][i] += (1/S) sum_rows dZ^T[o][row] H^T[i][row]
+// Both operands are stored feature-major, so a lane's 8 consecutive rows are one 16-byte load.
+// grid = (row blocks, i-tile pairs, o-tile pairs); a wave owns a 64x64 output block (2x2 MFMA tiles),
+// the 4 waves of a workgroup split the block's rows and are summed through LDS.
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ void mlp16_bwd_weight_body(const T* __restrict__ dzT, int n_out, const T* __restrict__ hT, int n_in,
+                                                      long rows, long rows_per_block, float* __restrict__ dW, int lddw,
+                                                      float* __restrict__ db, const uint32_t* __restrict__ absmax_bits) {
+    typedef typename Vec8<T>::type V8;
+    const float inv_scale = UsesScale<T>::v ? 1.f / grad_scale_from(absmax_bits) : 1.f;
+    __shared__ float s_red[4][4][16][64];   // 64 KB
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, j = lane & 31;
+    const int o0 = 64 * blockIdx.z, i0 = 64 * blockIdx.y;
+    const long b_begin = (long)blockIdx.x * rows_per_block;
+    long b_end = b_begin + rows_per_block;
+    if (b_end > rows) b_end = rows;
+    const long per_wave = ((b_end - b_begin + 3) / 4 + 15) & ~15L;
+    const long r_begin = b_begin + wave * per_wave;
+    long r_end = r_begin + per_wave;
+    if (r_end > b_end) r_end = b_end;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    V8 zero;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) zero[e] = (T)0.f;
+    float bsum[2] = {0.f, 0.f};
+    const bool full_rows = (rows % 8) == 0;
+    for (long rb = r_begin; rb < r_end; rb += 16) {
+        const long r8 = rb + 8 * half;
+        V8 av[2], bv[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int o = o0 + 32 * u + j, i = i0 + 32 * u + j;
+            av[u] = zero; bv[u] = zero;
+            if (full_rows && r8 + 8 <= r_end) {
+                if (o < n_out) av[u] = *(const V8*)(dzT + (size_t)o * rows + r8);
+                if (i < n_in) bv[u] = *(const V8*)(hT + (size_t)i * rows + r8);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    if (r8 + e < r_end) {
+                        if (o < n_out) av[u][e] = dzT[(size_t)o * rows + r8 + e];
+                        if (i < n_in) bv[u][e] = hT[(size_t)i * rows + r8 + e];
+                    }
+                }
+            }
+        }
+        if (db && blockIdx.y == 0) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) bsum[u] += (float)av[u][e];
+        }
+        acc[0][0] = mfma16(av[0], bv[0], acc[0][0]);
+        acc[0][1] = mfma16(av[0], bv[1], acc[0][1]);
+        acc[1][0] = mfma16(av[1], bv[0], acc[1][0]);
+        acc[1][1] = mfma16(av[1], bv[1], acc[1][1]);
+    }
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s_red[wave][2 * a + b][r][lane] = acc[a][b][r];
+    __syncthreads();
+    const bool single = gridDim.x == 1;
+    for (int e = tid; e < 4 * 16 * 64; e += M16_THREADS) {
+        const int tl = e >> 10, r = (e >> 6) & 15, l = e & 63;
+        float v = s_red[0][tl][r][l] + s_red[1][tl][r][l] + s_red[2][tl][r][l] + s_red[3][tl][r][l];
+        const int oo = o0 + 32 * (tl >> 1) + cd_row16(r, l >> 5), ii = i0 + 32 * (tl & 1) + (l & 31);
+        if (oo < n_out && ii < n_in) {
+            float* dst = &dW[(size_t)oo * lddw + ii];
+            v *= inv_scale;
+            if (single) *dst += v; else atomicAdd(dst, v);
+        }
+    }
+    if (db && blockIdx.y == 0) {
+        __syncthreads();
+        float* sb = &s_red[0][0][0][0];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            float v = bsum[u] + __shfl_xor(bsum[u], 32);
+            if (half == 0) sb[(wave * 2 + u) * 32 + j] = v;
+        }
+        __syncthreads();
+        if (tid < 64) {
+            const int u = tid >> 5, jj = tid & 31;
+            const float v = (sb[(0 * 2 + u) * 32 + jj] + sb[(1 * 2 + u) * 32 + jj] + sb[(2 * 2 + u) * 32 + jj] + sb[(3 * 2 + u) * 32 + jj]) * inv_scale;
+            const int oo = o0 + 32 * u + jj;
+            if (oo < n_out) { if (single) db[oo] += v; else atomicAdd(&db[oo], v); }
+        }
+    }
+}
+__global__ __launch_bounds__(M16_THREADS) void gp_mlp16_bwd_weight_f16_kernel(const void* dzT, int n_out, const void* hT, int n_in, long rows,
+                                                                               long rpb, float* dW, int lddw, float* db, const uint32_t* absmax_bits) {
+    mlp16_bwd_weight_body<_Float16>((const _Float16*)dzT, n_out, (const _Float16*)hT, n_in, rows, rpb, dW, lddw, db, absmax_bits);
+}
+__global__ __launch_bounds__(M16_THREADS) void gp_mlp16_bwd_weight_bf16_kernel(const void* dzT, int n_out, const void* hT, int n_in, long rows,
+                                                                                long rpb, float* dW, int lddw, float* db, const uint32_t* absmax_bits) {
+    mlp16_bwd_weight_body<__bf16>((const __bf16*)dzT, n_out, (const __bf16*)hT, n_in, rows, rpb, dW, lddw, db, absmax_bits);
+}
+
+// dL_dout^T in 16 bits, scaled: [16][rows] (rows >= out_dim zero) -- A operand of the last layer's weight gradient
+template <typename T>
+__global__ __launch_bounds__(256) void gp_mlp16_pack_dout_kernel(const float* __restrict__ dL_dout, int out_dim, long rows,
+                                                                T* __restrict__ dst, const uint32_t* __restrict__ absmax_bits) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= rows) return;
+    const float scale = UsesScale<T>::v ? grad_scale_from(absmax_bits) : 1.f;
+#pragma unroll
+    for (int f = 0; f < 16; ++f) dst[(size_t)f * rows + i] = (T)(f < out_dim ? dL_dout[i * out_dim + f] * scale : 0.f);
+}
+
+// ------------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------------
+static int make16(const gp_mlp16_params* p, const gp_mlp_input* x, Mlp16Dev& m) {
+    if (!p || !x) GP_FAIL("null mlp16 params/input");
+    if (p->dtype != GP_DTYPE_F16 && p->dtype != GP_DTYPE_BF16) GP_FAIL("mlp16: dtype must be GP_DTYPE_F16 or GP_DTYPE_BF16");
+    if (p->width != 256 || p->depth != 4) GP_FAIL("Deformable_Field: only d=4, w=256 is implemented");
+    if (p->out_dim < 7 || p->out_dim > 8) GP_FAIL("out_dim must be 7 or 8");
+    const int in_dim = x->feature_dim + 6 * x->xyz_freq + 2 * x->time_freq;
+    if (in_dim != p->in_dim || in_dim > 128 || in_dim <= 0) GP_FAIL("in_dim mismatch or > 128 (%d)", in_dim);
+    if (x->rows < 0) GP_FAIL("negative rows");
+    for (int l = 0; l < 5; ++l)
+        if (!p->w16[l] || !p->b[l]) GP_FAIL("null weight pointer (layer %d)", l);
+    if (x->rows > 0 && (!x->feature || (x->xyz_freq > 0 && !x->xyz) || (x->time_freq > 0 && !x->t))) GP_FAIL("null input pointer");
+    m.rows = x->rows; m.in_dim = in_dim; m.in_pad = (in_dim + 15) / 16 * 16; m.out_dim = p->out_dim;
+    m.feature_dim = x->feature_dim; m.xyz_freq = x->xyz_freq; m.time_freq = x->time_freq;
+    for (int l = 0; l < 5; ++l) { m.w[l] = p->w16[l]; m.b[l] = p->b[l]; }
+    m.feature = x->feature; m.xyz = x->xyz; m.t = x->t;
+    return 0;
+}
+
+extern "C" int gp_mlp16_forward(const gp_mlp16_params* p, const gp_mlp_input* x, float* out, void* saved_xT, void* saved_hT,
+                                uint32_t* masks, gp_stream_t stream_) {
+    Mlp16Dev m;
+    if (make16(p, x, m)) return 1;
+    if (m.rows == 0) return 0;
+    if (!out) GP_FAIL("null output");
+    hipStream_t s = (hipStream_t)stream_;
+    GpProfScope _p("mlp16_fwd", s);
+    const dim3 grid(gp_blocks((size_t)m.rows, M16_ROWS));
+    if (p->dtype == GP_DTYPE_F16) hipLaunchKernelGGL(gp_mlp16_fwd_f16_kernel, grid, dim3(M16_THREADS), 0, s, m, out, saved_xT, saved_hT, masks);
+    else hipLaunchKernelGGL(gp_mlp16_fwd_bf16_kernel, grid, dim3(M16_THREADS), 0, s, m, out, saved_xT, saved_hT, masks);
+    GP_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int gp_mlp16_backward(const gp_mlp16_params* p /* w16 = TRANSPOSED copies */, const gp_mlp_input* x, const void* saved_xT,
+                                 const void* saved_hT, const uint32_t* masks, const float* dL_dout, gp_mlp_grads* g,
+                                 float* dL_dfeature, float* dL_dxyz, gp_alloc_fn alloc, void* alloc_ctx, gp_stream_t stream_) {
+    hipStream_t s = (hipStream_t)stream_;
+    Mlp16Dev m;
+    if (make16(p, x, m)) return 1;
+    if (m.rows == 0) return 0;
+    if (!saved_xT || !saved_hT || !masks || !dL_dout || !g || !alloc) GP_FAIL("null argument");
+    for (int l = 0; l < 5; ++l)
+        if (!g->dw[l] || !g->db[l]) GP_FAIL("null weight-grad pointer (layer %d)", l);
+    const bool f16 = p->dtype == GP_DTYPE_F16;
+    const size_t dz_elems = (size_t)4 * 256 * m.rows + (size_t)16 * m.rows;
+    char* dz = (char*)alloc(alloc_ctx, GP_BUF_TEMP, gp_align_up(dz_elems * 2, 256) + 256);
+    if (!dz) GP_FAIL("allocator returned NULL for TEMP");
+    char* dout16 = dz + (size_t)4 * 256 * m.rows * 2;
+    uint32_t* absmax = (uint32_t*)(dz + gp_align_up(dz_elems * 2, 256));
+    GP_HIP_CHECK(hipMemsetAsync(absmax, 0, 4, s));
+    if (f16) {
+        hipLaunchKernelGGL(gp_absmax_kernel, dim3(256), dim3(256), 0, s, dL_dout, (size_t)m.rows * m.out_dim, absmax);
+        GP_LAUNCH_CHECK();
+    }
+    {
+        GpProfScope _p("mlp16_bwd_data", s);
+        const dim3 grid(gp_blocks((size_t)m.rows, M16_ROWS));
+        if (f16) {
+            hipLaunchKernelGGL(gp_mlp16_bwd_data_f16_kernel, grid, dim3(M16_THREADS), 0, s, m, masks, dL_dout, (void*)dz, dL_dfeature, dL_dxyz, absmax);
+            hipLaunchKernelGGL((gp_mlp16_pack_dout_kernel<_Float16>), dim3(gp_blocks((size_t)m.rows, 256)), dim3(256), 0, s, dL_dout, m.out_dim, m.rows, (_Float16*)dout16, absmax);
+        } else {
+            hipLaunchKernelGGL(gp_mlp16_bwd_data_bf16_kernel, grid, dim3(M16_THREADS), 0, s, m, masks, dL_dout, (void*)dz, dL_dfeature, dL_dxyz, absmax);
+            hipLaunchKernelGGL((gp_mlp16_pack_dout_kernel<__bf16>), dim3(gp_blocks((size_t)m.rows, 256)), dim3(256), 0, s, dL_dout, m.out_dim, m.rows, (__bf16*)dout16, absmax);
+        }
+        GP_LAUNCH_CHECK();
+    }
+    long nrb_l = (m.rows + 8191) / 8192;
+    if (nrb_l > 32) nrb_l = 32;
+    if (nrb_l < 1) nrb_l = 1;
+    const long rpb = ((m.rows + nrb_l - 1) / nrb_l + 63) & ~63L;
+    const unsigned nrb = (unsigned)((m.rows + rpb - 1) / rpb);
+    GpProfScope _pw("mlp16_bwd_weight", s);
+    for (int l = 0; l < 5; ++l) {
+        const void* dZl = l < 4 ? (const void*)(dz + (size_t)l * 256 * m.rows * 2) : (const void*)dout16;
+        const int n_out = l < 4 ? 256 : m.out_dim;
+        const void* H = l == 0 ? saved_xT : (const void*)((const char*)saved_hT + (size_t)(l - 1) * 256 * m.rows * 2);
+        const int n_in = l == 0 ? m.in_dim : 256;
+        const dim3 grid(nrb, (unsigned)((n_in + 63) / 64), (unsigned)((n_out + 63) / 64));
+        if (f16) hipLaunchKernelGGL(gp_mlp16_bwd_weight_f16_kernel, grid, dim3(M16_THREADS), 0, s, dZl, n_out, H, n_in, m.rows, rpb, g->dw[l], n_in, g->db[l], absmax);
+        else hipLaunchKernelGGL(gp_mlp16_bwd_weight_bf16_kernel, grid, dim3(M16_THREADS), 0, s, dZl, n_out, H, n_in, m.rows, rpb, g->dw[l], n_in, g->db[l], absmax);
+        GP_LAUNCH_CHECK();
+    }
+    return 0;
+}

@@ -110,6 +110,105 @@ class FusedMlp(torch.autograd.Function):
         return (g_feat, g_xyz, None, None, None, *wb_grads)
 
 
+class FusedMlp16(torch.autograd.Function):
+    """FusedMlp with 16-bit operands on the matrix cores (fp16 or bf16, fp32 accumulate).  Opt-in."""
+
+    @staticmethod
+    def forward(ctx, feature, xyz, t, xyz_freq, time_freq, precision, *wb):
+        _need_cuda(feature, "FusedMlp16")
+        dev = feature.device
+        tdt = {"fp16": torch.float16, "bf16": torch.bfloat16}[precision]
+        cdt = {"fp16": _lib.GP_DTYPE_F16, "bf16": _lib.GP_DTYPE_BF16}[precision]
+        ws = [_c(w) for w in wb[0::2]]
+        bs = [_c(b) for b in wb[1::2]]
+        feature_c = _c(feature)
+        xyz_c = _c(xyz) if xyz is not None else None
+        t_c = _c(t).reshape(-1)[:1] if t is not None else None
+        rows, fd = feature_c.shape
+        in_dim, out_dim = ws[0].shape[1], ws[4].shape[0]
+        in_pad = (in_dim + 15) // 16 * 16
+        w0p = torch.zeros(256, in_pad, device=dev, dtype=tdt)
+        w0p[:, :in_dim] = ws[0]
+        w4p = torch.zeros(32, 256, device=dev, dtype=tdt)
+        w4p[:out_dim] = ws[4]
+        w16 = [w0p, ws[1].to(tdt), ws[2].to(tdt), ws[3].to(tdt), w4p]
+        need_grad = any(x is not None and torch.is_tensor(x) and x.requires_grad for x in (feature, xyz) + tuple(wb))
+        out = torch.empty(rows, out_dim, device=dev)
+        xT = torch.empty(in_pad, rows, device=dev, dtype=tdt) if need_grad else None
+        hT = torch.empty(4, 256, rows, device=dev, dtype=tdt) if need_grad else None
+        masks = torch.empty(4, rows, 8, device=dev, dtype=torch.int32) if need_grad else None
+        params = _lib.Mlp16ParamsC(cdt, in_dim, 256, 4, out_dim)
+        for l in range(5):
+            params.w16[l] = w16[l].data_ptr()
+            params.b[l] = bs[l].data_ptr()
+        inp = _lib.MlpInputC(rows, fd, int(xyz_freq), int(time_freq), feature_c.data_ptr(),
+                             xyz_c.data_ptr() if xyz_c is not None else None, t_c.data_ptr() if t_c is not None else None)
+        with torch.cuda.device(dev):
+            rc = _lib.lib().gp_mlp16_forward(C.byref(params), C.byref(inp), _lib.ptr(out), _lib.ptr(xT), _lib.ptr(hT), _lib.ptr(masks),
+                                             _lib.stream_ptr(dev))
+            _lib.check(rc, "gp_mlp16_forward")
+        if need_grad:
+            e = torch.empty(0, device=dev)
+            ctx.save_for_backward(feature_c, xyz_c if xyz_c is not None else e, t_c if t_c is not None else e, xT, hT, masks, *ws, *bs)
+            ctx.meta = (int(xyz_freq), int(time_freq), xyz_c is not None, t_c is not None, tdt, cdt, in_pad)
+            ctx.needs = (feature.requires_grad, xyz is not None and xyz.requires_grad)
+            ctx.wb_leaves = tuple(wb)
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        saved = ctx.saved_tensors
+        feature_c, xyz_c, t_c, xT, hT, masks = saved[:6]
+        ws, bs = saved[6:11], saved[11:16]
+        xyz_freq, time_freq, has_xyz, has_t, tdt, cdt, in_pad = ctx.meta
+        dev = feature_c.device
+        rows, fd = feature_c.shape
+        in_dim, out_dim = ws[0].shape[1], ws[4].shape[0]
+        g = g_out.to(torch.float32).contiguous()
+        wt0 = torch.zeros(in_pad, 256, device=dev, dtype=tdt)
+        wt0[:in_dim] = ws[0].t()
+        wt4 = torch.zeros(256, 16, device=dev, dtype=tdt)
+        wt4[:, :out_dim] = ws[4].t()
+        wt = [wt0, ws[1].t().contiguous().to(tdt), ws[2].t().contiguous().to(tdt), ws[3].t().contiguous().to(tdt), wt4]
+        params = _lib.Mlp16ParamsC(cdt, in_dim, 256, 4, out_dim)
+        grads = _lib.MlpGradsC()
+        leaves = ctx.wb_leaves
+        sinks = [grad_sink.sink_of(t_) for t_ in leaves]
+        use_sink = all(s_ is not None for s_ in sinks)
+        if use_sink:
+            dws, dbs = list(sinks[0::2]), list(sinks[1::2])
+        else:
+            dws = [torch.zeros_like(w) for w in ws]
+            dbs = [torch.zeros_like(b) for b in bs]
+        for l in range(5):
+            params.w16[l] = wt[l].data_ptr()
+            params.b[l] = bs[l].data_ptr()
+            grads.dw[l] = dws[l].data_ptr()
+            grads.db[l] = dbs[l].data_ptr()
+        inp = _lib.MlpInputC(rows, fd, xyz_freq, time_freq, feature_c.data_ptr(), xyz_c.data_ptr() if has_xyz else None,
+                             t_c.data_ptr() if has_t else None)
+        need_f, need_x = ctx.needs
+        g_feat = torch.empty(rows, fd, device=dev) if need_f else None
+        g_xyz = torch.empty(rows, 3, device=dev) if (need_x and has_xyz and xyz_freq > 0) else None
+        alloc = _lib.TorchAllocator(dev)
+        with torch.cuda.device(dev):
+            rc = _lib.lib().gp_mlp16_backward(C.byref(params), C.byref(inp), _lib.ptr(xT), _lib.ptr(hT), _lib.ptr(masks), _lib.ptr(g),
+                                              C.byref(grads), _lib.ptr(g_feat), _lib.ptr(g_xyz), alloc.cb, None, _lib.stream_ptr(dev))
+            if alloc.error is not None:
+                err = alloc.error
+                alloc.release()
+                raise err
+            alloc.release()
+            _lib.check(rc, "gp_mlp16_backward")
+        wb_grads = []
+        for l in range(5):
+            wb_grads += [None, None] if use_sink else [dws[l], dbs[l]]
+        if use_sink:
+            for t_ in leaves:
+                grad_sink.notify(t_)
+        return (g_feat, g_xyz, None, None, None, None, *wb_grads)
+
+
 class KeypointBlend(torch.autograd.Function):
     """(xyz_t, q_t) from per-keypoint (nn>0) or per-Gaussian (raw_w is None) deltas."""
 

@@ -10,12 +10,17 @@ from __future__ import annotations
 import torch
 from torch import nn
 
-from .deform_ops import FusedMlp
+from .deform_ops import FusedMlp, FusedMlp16
 
 
 class Deformable_Field(nn.Module):
-    def __init__(self, input_dim, output_dim=10, d=8, w=256, use_softmax=False, split_xyz=False):
+    def __init__(self, input_dim, output_dim=10, d=8, w=256, use_softmax=False, split_xyz=False, precision="fp32"):
+        """`precision` (extension): "fp32" = exact-fp32 matrix cores (default, parity-grade); "fp16" / "bf16" =
+        16-bit operands with fp32 accumulation, ~16x the MFMA rate (BASELINE config 5)."""
         super().__init__()
+        if precision not in ("fp32", "fp16", "bf16"):
+            raise ValueError("precision must be fp32, fp16 or bf16")
+        self.precision = precision
         if split_xyz or use_softmax:
             raise NotImplementedError("split_xyz / use_softmax are dead branches in the reference "
                                       "(scene/gaussian_model.py:79) and are not implemented")
@@ -46,4 +51,6 @@ class Deformable_Field(nn.Module):
         """Fused form used by GaussianModel: builds [feature | PE(xyz) | PE(t)] inside the kernel
         (get_motion_delta, REF scene/gaussian_model.py:180-184) -- the [M, input_dim] input and the
         [M,256] activations never touch HBM in inference."""
+        if self.precision != "fp32":
+            return FusedMlp16.apply(feature, xyz, t, xyz_freq, time_freq, self.precision, *self._wb())
         return FusedMlp.apply(feature, xyz, t, xyz_freq, time_freq, *self._wb())

@@ -81,6 +81,19 @@ class GaussianModel(nn.Module):
     def get_rotation(self):
         return torch.nn.functional.normalize(self._rotation)
 
+    def get_covariance(self, scaling_modifier=1):
+        """Packed world-space covariance [N,6] (xx,xy,xz,yy,yz,zz) = (R S)(R S)^T, with the *raw*
+        `_rotation` normalised inside, as the reference's python fallback does
+        [REF scene/gaussian_model.py:35-39,320-321; utils/general_utils.py:64-110]."""
+        q = torch.nn.functional.normalize(self._rotation)
+        r, x, y, z = q.unbind(-1)
+        R = torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - r * z), 2 * (x * z + r * y),
+                         2 * (x * y + r * z), 1 - 2 * (x * x + z * z), 2 * (y * z - r * x),
+                         2 * (x * z - r * y), 2 * (y * z + r * x), 1 - 2 * (x * x + y * y)], dim=-1).reshape(-1, 3, 3)
+        L = R * (scaling_modifier * self.get_scaling)[:, None, :]
+        S = L @ L.transpose(1, 2)
+        return torch.stack([S[:, 0, 0], S[:, 0, 1], S[:, 0, 2], S[:, 1, 1], S[:, 1, 2], S[:, 2, 2]], dim=-1)
+
     @property
     def get_superGaussians(self):
         return self.super_gaussians

@@ -8,6 +8,30 @@ import torch
 
 from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer
 
+_C0, _C1 = 0.28209479177387814, 0.4886025119029199
+_C2 = (1.0925484305920792, -1.0925484305920792, 0.31539156525252005, -1.0925484305920792, 0.5462742152960396)
+_C3 = (-0.5900435899266435, 2.890611442640554, -0.4570457994644658, 0.3731763325901154, -0.4570457994644658,
+       1.445305721320277, -0.5900435899266435)
+
+
+def _sh_to_rgb_python(deg, feats, dirs):
+    """`pipe.convert_SHs_python` fallback: SH -> RGB in torch (feats [N,16,3], unit dirs [N,3]);
+    same basis/constants as [REF utils/sh_utils.py:57-112], + 0.5 and clamp as [REF gaussian_renderer/__init__.py:86-91]."""
+    x, y, z = dirs[:, 0:1], dirs[:, 1:2], dirs[:, 2:3]
+    res = _C0 * feats[:, 0]
+    if deg > 0:
+        res = res - _C1 * y * feats[:, 1] + _C1 * z * feats[:, 2] - _C1 * x * feats[:, 3]
+    if deg > 1:
+        xx, yy, zz, xy, yz, xz = x * x, y * y, z * z, x * y, y * z, x * z
+        res = res + _C2[0] * xy * feats[:, 4] + _C2[1] * yz * feats[:, 5] + _C2[2] * (2 * zz - xx - yy) * feats[:, 6] + \
+            _C2[3] * xz * feats[:, 7] + _C2[4] * (xx - yy) * feats[:, 8]
+    if deg > 2:
+        res = res + _C3[0] * y * (3 * xx - yy) * feats[:, 9] + _C3[1] * xy * z * feats[:, 10] + \
+            _C3[2] * y * (4 * zz - xx - yy) * feats[:, 11] + _C3[3] * z * (2 * zz - 3 * xx - 3 * yy) * feats[:, 12] + \
+            _C3[4] * x * (4 * zz - xx - yy) * feats[:, 13] + _C3[5] * z * (xx - yy) * feats[:, 14] + \
+            _C3[6] * x * (xx - 3 * yy) * feats[:, 15]
+    return torch.clamp_min(res + 0.5, 0.0)
+
 
 def _settings(viewpoint_camera, pc, bg_color, scaling_modifier):
     return GaussianRasterizationSettings(
@@ -45,15 +69,18 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=
         means3D = pc.get_xyz + delta if delta is not None else pc.get_xyz
         opacity = pc.get_opacity
         if getattr(pipe, "compute_cov3D_python", False):
-            raise NotImplementedError("compute_cov3D_python: the covariance is computed in the preprocess kernel")
-        scales, rotations = pc.get_scaling, pc.get_rotation
+            cov3D_precomp, scales, rotations = pc.get_covariance(scaling_modifier), None, None
+        else:
+            scales, rotations = pc.get_scaling, pc.get_rotation
     else:
         means3D, rotations, scales, opacity = pc(time, it)
     shs, shs_rest, colors_precomp = None, None, None
     if override_color is None:
         if getattr(pipe, "convert_SHs_python", False):
-            raise NotImplementedError("convert_SHs_python: SH->RGB is evaluated in the preprocess kernel")
-        if hasattr(pc, "_features_dc") and hasattr(pc, "_features_rest") and pc._features_rest.shape[1] == 15:
+            base = means3D.detach() if time is not None else pc.get_xyz + (delta if delta is not None else 0)
+            d = base - viewpoint_camera.camera_center[None]
+            colors_precomp = _sh_to_rgb_python(pc.active_sh_degree, pc.get_features, d / d.norm(dim=1, keepdim=True))
+        elif hasattr(pc, "_features_dc") and hasattr(pc, "_features_rest") and pc._features_rest.shape[1] == 15:
             shs, shs_rest = pc._features_dc, pc._features_rest       # no per-frame cat (get_features)
         else:
             shs = pc.get_features

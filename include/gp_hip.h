@@ -160,6 +160,25 @@ int gp_mlp_backward(const gp_mlp_params* p, const gp_mlp_input* x, const float* 
                     gp_mlp_grads* g, float* dL_dfeature, float* dL_dxyz, gp_alloc_fn alloc, void* alloc_ctx,
                     gp_stream_t stream);
 
+/* ---- 16-bit-operand variant (fp16 or bf16 inputs, fp32 accumulate; BASELINE config 5).  Opt-in: results
+ * differ from the fp32 path at the 1e-3 (fp16) / 1e-2 (bf16) relative level.  Weights are passed as 16-bit
+ * copies prepared by the host (zero-padded): forward  w16[0]:[256,in_pad16] w16[1..3]:[256,256] w16[4]:[32,256];
+ * backward takes the TRANSPOSED copies  w16[0]:[in_pad16,256] w16[1..3]:[256,256]^T w16[4]:[256,16]. */
+enum { GP_DTYPE_F16 = 1, GP_DTYPE_BF16 = 2 };
+typedef struct gp_mlp16_params {
+    int32_t dtype;
+    int32_t in_dim, width, depth, out_dim;
+    const void* w16[5];
+    const float* b[5];
+} gp_mlp16_params;
+/* saved (training, all optional together): xT [in_pad16, rows] and hT [4,256,rows] 16-bit, feature-major;
+ * masks [4, rows, 8] u32 = ReLU sign bits. */
+int gp_mlp16_forward(const gp_mlp16_params* p, const gp_mlp_input* x, float* out, void* saved_xT, void* saved_hT,
+                     uint32_t* masks, gp_stream_t stream);
+int gp_mlp16_backward(const gp_mlp16_params* p_transposed, const gp_mlp_input* x, const void* saved_xT, const void* saved_hT,
+                      const uint32_t* masks, const float* dL_dout, gp_mlp_grads* g, float* dL_dfeature, float* dL_dxyz,
+                      gp_alloc_fn alloc, void* alloc_ctx, gp_stream_t stream);
+
 /* keypoint blend + pose composition  [REF scene/gaussian_model.py:214-229,266-273,285-286,314-315;
  * utils/camera_utils.py:158-170]:
  *   stage 1 (nn == 0): delta is per Gaussian [N,out_dim]

@@ -149,3 +149,36 @@ def test_activations_forward_backward():
         assert rel_l2(od_.grad.cpu().numpy(), o64.grad.numpy()) < 1e-5
         if use_d:
             assert rel_l2(dd_.grad.cpu().numpy(), d64.grad.numpy()) < 1e-5
+
+
+@pytest.mark.parametrize("precision,tol_y,tol_g", [("fp16", 3e-3, 3e-2), ("bf16", 3e-2, 1e-1)])
+@pytest.mark.parametrize("rows,F,out_dim", [(1, 6, 7), (100, 8, 7), (4100, 10, 8)])
+def test_fused_mlp16_close_to_fp32(precision, tol_y, tol_g, rows, F, out_dim):
+    """16-bit-operand matrix-core MLP (BASELINE config 5): not bit-parity with the reference -- the test
+    states its tolerance: forward within tol_y of the float64 oracle relative to the output scale, gradients
+    within tol_g relative L2."""
+    d_in = 32 + 60 + 2 * F
+    net = gpa.Deformable_Field(d_in, output_dim=out_dim, d=4, w=256, precision=precision).cuda()
+    sd = mlp_state(90 + rows, d_in, out_dim)
+    net.load_state_dict({k: torch.tensor(v) for k, v in sd.items()})
+    rng = np.random.default_rng(rows + 1)
+    feat = torch.tensor(rng.uniform(-1e-1, 1e-1, size=(rows, 32)).astype(np.float32))
+    xyz = torch.tensor(rng.uniform(-1.3, 1.3, size=(rows, 3)).astype(np.float32))
+    t = torch.tensor([0.61], dtype=torch.float32)
+    gy = torch.tensor(rng.normal(size=(rows, out_dim)).astype(np.float32))
+    sd64 = {k: torch.tensor(v, dtype=torch.float64, requires_grad=True) for k, v in sd.items()}
+    f64, x64 = feat.double().requires_grad_(True), xyz.double().requires_grad_(True)
+    X = torch.cat([f64, do.positional_encoding(x64, 10), do.positional_encoding(t.double(), F).unsqueeze(0).repeat(rows, 1)], -1)
+    y64 = do.mlp_forward(sd64, X)
+    (y64 * gy.double()).sum().backward()
+    fd, xd = feat.cuda().requires_grad_(True), xyz.cuda().requires_grad_(True)
+    y = net.forward_fused(fd, xd, t.cuda(), 10, F)
+    (y * gy.cuda()).sum().backward()
+    scale = float(y64.detach().abs().max())
+    assert np.abs(y.detach().cpu().numpy() - y64.detach().numpy()).max() < tol_y * max(scale, 1e-3)
+    if rows < 8:
+        tol_g *= 8          # a single row: one 16-bit ReLU sign flip is a visible fraction of the gradient
+    assert rel_l2(fd.grad.cpu().numpy(), f64.grad.numpy()) < tol_g
+    assert rel_l2(xd.grad.cpu().numpy(), x64.grad.numpy()) < tol_g
+    for k, p in net.named_parameters():
+        assert rel_l2(p.grad.cpu().numpy(), sd64[k].grad.numpy()) < tol_g, k

@@ -118,3 +118,24 @@ def test_render_backward_populates_all_grads_and_matches_oracle():
     assert rel_l2(pc._rotation.grad.cpu().numpy(), P64["rotation"].grad.numpy()) < 1e-4
     for k, p in pc.df_model.named_parameters():
         assert rel_l2(p.grad.cpu().numpy(), sd64[k].grad.numpy()) < 1e-3, k
+
+
+def test_render_motion_and_python_fallback_flags():
+    """render_motion (4-key dict, external xyz_t/r_t) and the pipe.convert_SHs_python / compute_cov3D_python
+    fallbacks [REF gaussian_renderer/__init__.py:54-72, 84-93, 117-191] agree with the kernel paths."""
+    pc, cam, P, sd, raw, raw_w, idx, args = build(N=2000, K=40, W=96, H=72)
+    bg = torch.zeros(3, device="cuda")
+    pipe = SimpleNamespace(convert_SHs_python=False, compute_cov3D_python=False, debug=False)
+    t = torch.tensor([0.4], device="cuda")
+    with torch.no_grad():
+        ref = gpa.render(cam, pc, pipe, bg, time=t, it=50000)
+        xyz_t, q_t, s, o = pc(t, 50000)
+        rm = gpa.render_motion(cam, pc, pipe, bg, xyz_t=xyz_t, r_t=q_t, opacity=o)
+        assert set(rm) == {"render", "viewspace_points", "visibility_filter", "radii"}
+        assert float((rm["render"] - ref["render"]).abs().max()) < 1e-6
+        # static branch (time=None) with the python fallbacks vs the in-kernel SH / covariance
+        a = gpa.render(cam, pc, pipe, bg)
+        b = gpa.render(cam, pc, SimpleNamespace(convert_SHs_python=True, compute_cov3D_python=True, debug=False), bg)
+        err = (a["render"] - b["render"]).abs()
+        assert float(err.median()) < 1e-6 and float((err > 1e-4).float().mean()) < 1e-3
+        assert (a["radii"] != b["radii"]).float().mean() < 1e-3

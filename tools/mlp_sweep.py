@@ -9,7 +9,10 @@ from gaussianprediction_amd import _lib
 dev = "cuda"
 F = 6
 d_in = 32 + 60 + 2 * F
-net = gpa.Deformable_Field(d_in, output_dim=7, d=4, w=256).to(dev)
+prec = sys.argv[1] if len(sys.argv) > 1 else "fp32"
+net = gpa.Deformable_Field(d_in, output_dim=7, d=4, w=256, precision=prec).to(dev)
+pre = "mlp16" if prec != "fp32" else "mlp"
+print("precision", prec)
 flop_row = 2 * (d_in * 256 + 3 * 256 * 256 + 256 * 7)
 for rows in [250, 1024, 8192, 65536, 262144, 1048576]:
     feat = (torch.rand(rows, 32, device=dev) - 0.5).requires_grad_(True)
@@ -26,8 +29,8 @@ for rows in [250, 1024, 8192, 65536, 262144, 1048576]:
         y.sum().backward()
     torch.cuda.synchronize()
     p = _lib.profile_collect(); _lib.profile_enable(False)
-    fwd = p["mlp_fwd"][1] / p["mlp_fwd"][0]
-    bd = p["mlp_bwd_data"][1] / p["mlp_bwd_data"][0]
-    bw = p["mlp_bwd_weight"][1] / n
-    print(f"rows {rows:8d}: fwd {fwd*1e3:9.1f} us ({rows*flop_row/fwd/1e9:7.1f} GF/s)  bwd_data {bd*1e3:9.1f} us ({rows*flop_row/bd/1e9:7.1f} GF/s)  "
-          f"bwd_weight(5 launches) {bw*1e3:9.1f} us ({rows*flop_row/bw/1e9:7.1f} GF/s)", flush=True)
+    fwd = p[pre + "_fwd"][1] / p[pre + "_fwd"][0]
+    bd = p[pre + "_bwd_data"][1] / p[pre + "_bwd_data"][0]
+    bw = p[pre + "_bwd_weight"][1] / n
+    print(f"rows {rows:8d}: fwd {fwd*1e3:9.1f} us ({rows*flop_row/fwd/1e9:7.1f} TF/s)  bwd_data {bd*1e3:9.1f} us ({rows*flop_row/bd/1e9:7.1f} TF/s)  "
+          f"bwd_weight(5 launches) {bw*1e3:9.1f} us ({rows*flop_row/bw/1e9:7.1f} TF/s)", flush=True)
