@@ -63,12 +63,16 @@ struct ImageLayout {
     int2* ranges;
     float* final_T;
     int32_t* n_contrib;
+    int32_t* tile_work;    // per tile: largest list position consumed by the forward (backward work estimate)
+    uint32_t* order;       // heavy-first launch order of the forward
     size_t bytes;
     ImageLayout(void* base, size_t T, size_t P) {
         GpCarver c(base);
         ranges = c.take<int2>(T);
         final_T = c.take<float>(P);
         n_contrib = c.take<int32_t>(P);
+        tile_work = c.take<int32_t>(T);
+        order = c.take<uint32_t>(T);
         bytes = c.bytes();
     }
 };
@@ -183,9 +187,11 @@ extern "C" int gp_raster_forward(const gp_raster_settings* st, const gp_raster_i
         }
     }
     saved->num_rendered = (int64_t)R;
+    hipLaunchKernelGGL(gp_tile_order_kernel, dim3(1), dim3(1024), 0, s, il.ranges, (const int32_t*)nullptr, (int)T, il.order);
+    GP_LAUNCH_CHECK();
     { GpProfScope _p("composite_fwd", s, 1);
         hipLaunchKernelGGL(gp_composite_fwd_kernel, dim3((unsigned)T), dim3(128), 0, s, d, il.ranges, point_list, gl.rec, st->bg,
-                       out->color, out->depth, out->tidx, il.final_T, il.n_contrib);
+                       out->color, out->depth, out->tidx, il.final_T, il.n_contrib, il.order, il.tile_work);
     GP_LAUNCH_CHECK(); }
     return 0;
 }
@@ -209,25 +215,39 @@ extern "C" int gp_raster_backward(const gp_raster_settings* st, const gp_raster_
     const uint32_t* point_list = (const uint32_t*)saved->binning;
     if (R > 0 && !point_list) GP_FAIL("saved binning state missing");
 
-    const size_t acc_floats = 10 * N;
-    float* acc = (float*)alloc(alloc_ctx, GP_BUF_TEMP, gp_align_up(acc_floats * 4, 256));
+    const size_t acc_floats = (size_t)GP_ACC_STRIDE * N;
+    const size_t pp_bytes = T * 2 * 64 * 64;   // (tile, 8-row part) x 64 pixel pairs x 64 B
+    float* acc = (float*)alloc(alloc_ctx, GP_BUF_TEMP, gp_align_up(acc_floats * 4, 256) + gp_align_up(T * 4, 256) + pp_bytes);
     if (!acc) GP_FAIL("allocator returned NULL for TEMP");
+    uint32_t* order_bwd = (uint32_t*)((char*)acc + gp_align_up(acc_floats * 4, 256));
+    GpPixPair* pp = (GpPixPair*)((char*)order_bwd + gp_align_up(T * 4, 256));
     GP_HIP_CHECK(hipMemsetAsync(acc, 0, acc_floats * 4, s));
-    float* g_mean2D = acc;
-    float* g_conic = acc + 2 * N;
-    float* g_opacity = acc + 5 * N;
-    float* g_color = acc + 6 * N;
-    float* g_depth = acc + 9 * N;
+    float* g_mean2D = acc;   // AoS, stride GP_ACC_STRIDE
+    float* g_conic = acc + 2;
+    float* g_opacity = acc + 5;
+    float* g_color = acc + 6;
+    float* g_depth = acc + 9;
     if (R > 0) {
         // v4 (compacted batches) is the default; GP_EXP_BWD_V3=1 selects the un-compacted variant for A/B timing
         static const bool use_v3 = getenv("GP_EXP_BWD_V3") != nullptr;
         auto kern = use_v3 ? (dL_ddepth ? gp_composite_bwd3_depth_kernel : gp_composite_bwd3_kernel)
                            : (dL_ddepth ? gp_composite_bwd4_depth_kernel : gp_composite_bwd4_kernel);
         const unsigned parts = GP_TILE / 8;
-        { GpProfScope _p("composite_bwd", s);
+        hipLaunchKernelGGL(gp_tile_order_kernel, dim3(1), dim3(1024), 0, s, il.ranges, il.tile_work, (int)T, order_bwd);
+        GP_LAUNCH_CHECK();
+        static const bool use_v5 = getenv("GP_EXP_BWD_V4") == nullptr && !use_v3;
+        if (use_v5) {
+            GpProfScope _p("composite_bwd", s);
+            hipLaunchKernelGGL(gp_bwd_pixprep_kernel, dim3(gp_blocks(T * parts * 64, 256)), dim3(256), 0, s, d, st->bg, fwd->color,
+                               fwd->depth, il.final_T, il.n_contrib, dL_dcolor, dL_ddepth, pp);
+            hipLaunchKernelGGL(dL_ddepth ? gp_composite_bwd5_depth_kernel : gp_composite_bwd5_kernel, dim3((unsigned)T * parts),
+                               dim3(64), 0, s, d, il.ranges, point_list, gl.rec, (const GpPixPair*)pp, g_mean2D, g_conic, g_opacity,
+                               g_color, g_depth, order_bwd);
+            GP_LAUNCH_CHECK();
+        } else { GpProfScope _p("composite_bwd", s);
         hipLaunchKernelGGL(kern, dim3((unsigned)T * parts), dim3(64), 0, s, d, il.ranges, point_list,
                            gl.rec, st->bg, fwd->color, fwd->depth, il.final_T, il.n_contrib, dL_dcolor, dL_ddepth, g_mean2D,
-                           g_conic, g_opacity, g_color, g_depth);
+                           g_conic, g_opacity, g_color, g_depth, order_bwd);
         GP_LAUNCH_CHECK(); }
     }
     {

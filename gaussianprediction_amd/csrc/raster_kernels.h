@@ -2,6 +2,9 @@
 #pragma once
 #include "gp_common.h"
 
+// backward accumulators: one 64-byte line per Gaussian  [0,1] mean2D  [2..4] conic  [5] opacity  [6..8] colour  [9] depth
+#define GP_ACC_STRIDE 16
+
 struct RasterDims {
     int N, M, D;       // gaussians, sh coeffs per channel, active sh degree
     int W, H, gx, gy;  // image and tile grid
@@ -32,6 +35,7 @@ __global__ __launch_bounds__(256) void gp_duplicate_kernel(RasterDims d, const u
 __global__ __launch_bounds__(256) void gp_tile_ranges_kernel(const uint32_t* __restrict__ keys, uint32_t R,
                                                             int2* __restrict__ ranges);
 
+__global__ __launch_bounds__(1024) void gp_tile_order_kernel(const int2* __restrict__ ranges, const int32_t* __restrict__ work_hint, int T, uint32_t* __restrict__ order);
 __global__ __launch_bounds__(128) void gp_composite_fwd_kernel(RasterDims d, const int2* __restrict__ ranges,
                                                                       const uint32_t* __restrict__ point_list,
                                                                       const float4* __restrict__ rec,
@@ -40,12 +44,12 @@ __global__ __launch_bounds__(128) void gp_composite_fwd_kernel(RasterDims d, con
                                                                       float* __restrict__ out_depth,
                                                                       int32_t* __restrict__ out_tidx,
                                                                       float* __restrict__ final_T,
-                                                                      int32_t* __restrict__ n_contrib);
+                                                                      int32_t* __restrict__ n_contrib, const uint32_t* __restrict__ order, int32_t* __restrict__ tile_work);
 
-__global__ __launch_bounds__(64) void gp_composite_bwd3_kernel(RasterDims d, const int2* __restrict__ ranges, const uint32_t* __restrict__ point_list,      const float4* __restrict__ rec, const float* __restrict__ bg, const float* __restrict__ out_color,      const float* __restrict__ out_depth, const float* __restrict__ final_T, const int32_t* __restrict__ n_contrib,      const float* __restrict__ dL_dpix, const float* __restrict__ dL_dpixdepth, float* __restrict__ g_mean2D,      float* __restrict__ g_conic, float* __restrict__ g_opacity, float* __restrict__ g_color, float* __restrict__ g_depth);
-__global__ __launch_bounds__(64) void gp_composite_bwd4_kernel(RasterDims d, const int2* __restrict__ ranges, const uint32_t* __restrict__ point_list,      const float4* __restrict__ rec, const float* __restrict__ bg, const float* __restrict__ out_color,      const float* __restrict__ out_depth, const float* __restrict__ final_T, const int32_t* __restrict__ n_contrib,      const float* __restrict__ dL_dpix, const float* __restrict__ dL_dpixdepth, float* __restrict__ g_mean2D,      float* __restrict__ g_conic, float* __restrict__ g_opacity, float* __restrict__ g_color, float* __restrict__ g_depth);
-__global__ __launch_bounds__(64) void gp_composite_bwd4_depth_kernel(RasterDims d, const int2* __restrict__ ranges, const uint32_t* __restrict__ point_list,      const float4* __restrict__ rec, const float* __restrict__ bg, const float* __restrict__ out_color,      const float* __restrict__ out_depth, const float* __restrict__ final_T, const int32_t* __restrict__ n_contrib,      const float* __restrict__ dL_dpix, const float* __restrict__ dL_dpixdepth, float* __restrict__ g_mean2D,      float* __restrict__ g_conic, float* __restrict__ g_opacity, float* __restrict__ g_color, float* __restrict__ g_depth);
-__global__ __launch_bounds__(64) void gp_composite_bwd3_depth_kernel(RasterDims d, const int2* __restrict__ ranges, const uint32_t* __restrict__ point_list,      const float4* __restrict__ rec, const float* __restrict__ bg, const float* __restrict__ out_color,      const float* __restrict__ out_depth, const float* __restrict__ final_T, const int32_t* __restrict__ n_contrib,      const float* __restrict__ dL_dpix, const float* __restrict__ dL_dpixdepth, float* __restrict__ g_mean2D,      float* __restrict__ g_conic, float* __restrict__ g_opacity, float* __restrict__ g_color, float* __restrict__ g_depth);
+__global__ __launch_bounds__(64) void gp_composite_bwd3_kernel(RasterDims d, const int2* __restrict__ ranges, const uint32_t* __restrict__ point_list,      const float4* __restrict__ rec, const float* __restrict__ bg, const float* __restrict__ out_color,      const float* __restrict__ out_depth, const float* __restrict__ final_T, const int32_t* __restrict__ n_contrib,      const float* __restrict__ dL_dpix, const float* __restrict__ dL_dpixdepth, float* __restrict__ g_mean2D,      float* __restrict__ g_conic, float* __restrict__ g_opacity, float* __restrict__ g_color, float* __restrict__ g_depth, const uint32_t* __restrict__ order);
+__global__ __launch_bounds__(64) void gp_composite_bwd4_kernel(RasterDims d, const int2* __restrict__ ranges, const uint32_t* __restrict__ point_list,      const float4* __restrict__ rec, const float* __restrict__ bg, const float* __restrict__ out_color,      const float* __restrict__ out_depth, const float* __restrict__ final_T, const int32_t* __restrict__ n_contrib,      const float* __restrict__ dL_dpix, const float* __restrict__ dL_dpixdepth, float* __restrict__ g_mean2D,      float* __restrict__ g_conic, float* __restrict__ g_opacity, float* __restrict__ g_color, float* __restrict__ g_depth, const uint32_t* __restrict__ order);
+__global__ __launch_bounds__(64) void gp_composite_bwd4_depth_kernel(RasterDims d, const int2* __restrict__ ranges, const uint32_t* __restrict__ point_list,      const float4* __restrict__ rec, const float* __restrict__ bg, const float* __restrict__ out_color,      const float* __restrict__ out_depth, const float* __restrict__ final_T, const int32_t* __restrict__ n_contrib,      const float* __restrict__ dL_dpix, const float* __restrict__ dL_dpixdepth, float* __restrict__ g_mean2D,      float* __restrict__ g_conic, float* __restrict__ g_opacity, float* __restrict__ g_color, float* __restrict__ g_depth, const uint32_t* __restrict__ order);
+__global__ __launch_bounds__(64) void gp_composite_bwd3_depth_kernel(RasterDims d, const int2* __restrict__ ranges, const uint32_t* __restrict__ point_list,      const float4* __restrict__ rec, const float* __restrict__ bg, const float* __restrict__ out_color,      const float* __restrict__ out_depth, const float* __restrict__ final_T, const int32_t* __restrict__ n_contrib,      const float* __restrict__ dL_dpix, const float* __restrict__ dL_dpixdepth, float* __restrict__ g_mean2D,      float* __restrict__ g_conic, float* __restrict__ g_opacity, float* __restrict__ g_color, float* __restrict__ g_depth, const uint32_t* __restrict__ order);
 
 __global__ __launch_bounds__(256) void gp_preprocess_bwd_kernel(RasterDims d, const float* __restrict__ means3D, const float* __restrict__ scales,      const float* __restrict__ rotations, const float* __restrict__ shs, const float* __restrict__ shs_rest,      const float* __restrict__ cov3D_precomp, const float* __restrict__ view, const float* __restrict__ proj,      const float* __restrict__ campos, const int32_t* __restrict__ radii, const uint8_t* __restrict__ clamped,      const float* __restrict__ g_mean2D, const float* __restrict__ g_conic, const float* __restrict__ g_opacity,      const float* __restrict__ g_color, const float* __restrict__ g_depth, float* __restrict__ dL_dmeans3D,      float* __restrict__ dL_dmeans2D, float* __restrict__ dL_dshs, float* __restrict__ dL_dshs_rest,      float* __restrict__ dL_dcolors, float* __restrict__ dL_dopacities, float* __restrict__ dL_dscales,      float* __restrict__ dL_drots, float* __restrict__ dL_dcov3D, int accumulate_shs);
 
@@ -53,3 +57,15 @@ __global__ __launch_bounds__(256) void gp_preprocess_bwd_sh16_kernel(RasterDims 
 
 __global__ __launch_bounds__(256) void gp_preprocess_bwd_split_kernel(RasterDims d, const float* __restrict__ means3D, const float* __restrict__ scales,      const float* __restrict__ rotations, const float* __restrict__ shs, const float* __restrict__ shs_rest,      const float* __restrict__ cov3D_precomp, const float* __restrict__ view, const float* __restrict__ proj,      const float* __restrict__ campos, const int32_t* __restrict__ radii, const uint8_t* __restrict__ clamped,      const float* __restrict__ g_mean2D, const float* __restrict__ g_conic, const float* __restrict__ g_opacity,      const float* __restrict__ g_color, const float* __restrict__ g_depth, float* __restrict__ dL_dmeans3D,      float* __restrict__ dL_dmeans2D, float* __restrict__ dL_dshs, float* __restrict__ dL_dshs_rest,      float* __restrict__ dL_dcolors, float* __restrict__ dL_dopacities, float* __restrict__ dL_dscales,      float* __restrict__ dL_drots, float* __restrict__ dL_dcov3D, int accumulate_shs);
 
+
+struct GpPixPair;
+__global__ __launch_bounds__(256) void gp_bwd_pixprep_kernel(RasterDims d, const float* __restrict__ bg, const float* __restrict__ out_color,
+                                                             const float* __restrict__ out_depth, const float* __restrict__ final_T,
+                                                             const int32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpix,
+                                                             const float* __restrict__ dL_dpixdepth, GpPixPair* __restrict__ pp);
+__global__ __launch_bounds__(64) void gp_composite_bwd5_kernel(RasterDims d, const int2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
+    const float4* __restrict__ rec, const GpPixPair* __restrict__ pp, float* __restrict__ g_mean2D, float* __restrict__ g_conic,
+    float* __restrict__ g_opacity, float* __restrict__ g_color, float* __restrict__ g_depth, const uint32_t* __restrict__ order);
+__global__ __launch_bounds__(64) void gp_composite_bwd5_depth_kernel(RasterDims d, const int2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
+    const float4* __restrict__ rec, const GpPixPair* __restrict__ pp, float* __restrict__ g_mean2D, float* __restrict__ g_conic,
+    float* __restrict__ g_opacity, float* __restrict__ g_color, float* __restrict__ g_depth, const uint32_t* __restrict__ order);

@@ -372,6 +372,74 @@ __global__ __launch_bounds__(256) void gp_tile_ranges_kernel(const uint32_t* __r
     if (k == R - 1 || keys[k + 1] != t) ranges[t].y = (int)(k + 1);
 }
 
+// Heavy-first launch order.  Per-tile work varies by >10x; the hardware dispatches workgroups in blockIdx order, so
+// with natural order the last wave of workgroups contains a few very long tiles and the chip idles behind them.
+// One workgroup buckets the tiles by a 2-mantissa-bit logarithm of their work estimate (counting sort, descending);
+// order within a bucket is arbitrary (it only affects scheduling, never results).
+// work = ranges length, or min(length, work_hint) when the forward's per-tile "last contributor" is known.
+__global__ __launch_bounds__(1024) void gp_tile_order_kernel(const int2* __restrict__ ranges, const int32_t* __restrict__ work_hint,
+                                                             int T, uint32_t* __restrict__ order) {
+    __shared__ uint32_t s_cnt[128], s_base[128];
+    const int tid = threadIdx.x;
+    if (tid < 128) s_cnt[tid] = 0;
+    __syncthreads();
+    auto bucket_of = [&](int t) {
+        const int2 r = ranges[t];
+        int w = r.y - r.x;
+        if (work_hint) w = min(w, work_hint[t]);
+        if (w <= 0) return 127;
+        const int lg = 31 - __clz(w);
+        const int sub = lg >= 2 ? ((w >> (lg - 2)) & 3) : 0;
+        return 126 - min(lg * 4 + sub, 126);
+    };
+    for (int t = tid; t < T; t += 1024) atomicAdd(&s_cnt[bucket_of(t)], 1u);
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t run = 0;
+        for (int b = 0; b < 128; ++b) { s_base[b] = run; run += s_cnt[b]; }
+    }
+    __syncthreads();
+    for (int t = tid; t < T; t += 1024) order[atomicAdd(&s_base[bucket_of(t)], 1u)] = (uint32_t)t;
+}
+
+// Can the splat reach alpha >= 1/255 anywhere on the pixel-centre rectangle [X0,X1] x [Y0,Y1]?
+// alpha >= 1/255  <=>  q(d) := cx dx^2 + 2 cy dx dy + cz dy^2 <= 2 ln(255 o) =: two_tau  (d = pixel - centre).
+// First the bounding box of that ellipse, then the exact minimum of the convex q over the rectangle (it lies on
+// an edge when the centre is outside).  Conservative: slack on two_tau and on the box, so a culled splat has
+// no contributing pixel in the rectangle.
+__device__ __forceinline__ bool gp_splat_hits_rect(const float4 q0, const float4 q1, float X0, float X1, float Y0, float Y1) {
+    const float cx = -2.f * q0.z, cy = -q0.w, cz = -2.f * q1.x;
+    const float detc = cx * cz - cy * cy;
+    const float tau = __logf(255.f * q1.y);
+    if (!(tau > 0.f)) return false;
+    if (!(detc > 0.f)) return true;                       // degenerate conic: do not cull
+    const float two_tau = 2.f * tau * 1.004f;
+    const float e2 = two_tau / detc;
+    const float ex = sqrtf(e2 * cz) + 0.01f, ey = sqrtf(e2 * cx) + 0.01f;
+    const float dx0 = X0 - q0.x, dx1 = X1 - q0.x, dy0 = Y0 - q0.y, dy1 = Y1 - q0.y;
+    if (!(dx0 <= ex && dx1 >= -ex && dy0 <= ey && dy1 >= -ey)) return false;
+    if (dx0 <= 0.f && dx1 >= 0.f && dy0 <= 0.f && dy1 >= 0.f) return true;   // centre inside
+    const float ry = -cy / cz, rx = -cy / cx;             // argmin of q along a vertical / horizontal line
+    float qmin;
+    {
+        const float dy = fminf(fmaxf(ry * dx0, dy0), dy1);
+        qmin = cx * dx0 * dx0 + (2.f * cy * dx0 + cz * dy) * dy;
+    }
+    {
+        const float dy = fminf(fmaxf(ry * dx1, dy0), dy1);
+        qmin = fminf(qmin, cx * dx1 * dx1 + (2.f * cy * dx1 + cz * dy) * dy);
+    }
+    {
+        const float dx = fminf(fmaxf(rx * dy0, dx0), dx1);
+        qmin = fminf(qmin, cz * dy0 * dy0 + (2.f * cy * dy0 + cx * dx) * dx);
+    }
+    {
+        const float dx = fminf(fmaxf(rx * dy1, dx0), dx1);
+        qmin = fminf(qmin, cz * dy1 * dy1 + (2.f * cy * dy1 + cx * dx) * dx);
+    }
+    return qmin <= two_tau + 0.02f;
+}
+
 // ------------------------------------------------------------------------------------------------
 // composite forward.  One 128-thread workgroup (2 waves) per 16x16 tile.  Wave w owns rows
 // [8w, 8w+8); lane l owns column (l & 15) and the two rows 2*(l >> 4) + {0,1} of that half.
@@ -414,11 +482,14 @@ __global__ __launch_bounds__(CF_THREADS) void gp_composite_fwd_kernel(RasterDims
                                                                       float* __restrict__ out_depth,
                                                                       int32_t* __restrict__ out_tidx,
                                                                       float* __restrict__ final_T,
-                                                                      int32_t* __restrict__ n_contrib) {
+                                                                      int32_t* __restrict__ n_contrib,
+                                                                      const uint32_t* __restrict__ order,
+                                                                      int32_t* __restrict__ tile_work) {
     __shared__ float4 s_q0[CF_THREADS], s_q1[CF_THREADS], s_q2[CF_THREADS];
     __shared__ unsigned long long s_mask[2][2];
     __shared__ int s_done[2];
-    const int tile = blockIdx.x;
+    __shared__ int s_last[2];
+    const int tile = order ? (int)order[blockIdx.x] : (int)blockIdx.x;
     const int tx = tile % d.gx, ty = tile / d.gx;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int px = tx * GP_TILE + (lane & 15);
@@ -450,19 +521,8 @@ __global__ __launch_bounds__(CF_THREADS) void gp_composite_fwd_kernel(RasterDims
             const uint32_t id = point_list[k];
             const float4 q0 = rec[3 * (size_t)id], q1 = rec[3 * (size_t)id + 1], q2 = rec[3 * (size_t)id + 2];
             s_q0[tid] = q0; s_q1[tid] = q1; s_q2[tid] = q2;
-            // alpha >= 1/255  <=>  0.5 d^T conic d <= ln(255 o) =: tau ; its bbox is sqrt(2 tau cov_xx/yy)
-            const float cx = -2.f * q0.z, cy = -q0.w, cz = -2.f * q1.x;
-            const float detc = cx * cz - cy * cy;
-            const float tau = __logf(255.f * q1.y);
-            if (tau > 0.f && detc > 0.f) {
-                const float e2 = 2.f * tau * 1.004f / detc;
-                const float ex = sqrtf(e2 * cz) + 0.01f, ey = sqrtf(e2 * cx) + 0.01f;
-                const bool inx = (q0.x + ex >= X0) && (q0.x - ex <= X1);
-                rel0 = inx && (q0.y + ey >= Y0a) && (q0.y - ey <= Y1a);
-                rel1 = inx && (q0.y + ey >= Y0b) && (q0.y - ey <= Y1b);
-            } else if (!(detc > 0.f) && tau > 0.f) {
-                rel0 = rel1 = true;  // degenerate conic: do not cull
-            }
+            rel0 = gp_splat_hits_rect(q0, q1, X0, X1, Y0a, Y1a);
+            rel1 = gp_splat_hits_rect(q0, q1, X0, X1, Y0b, Y1b);
         }
         const unsigned long long m0 = __ballot(rel0), m1 = __ballot(rel1);
         if (lane == 0) { s_mask[0][wave] = m0; s_mask[1][wave] = m1; }
@@ -505,6 +565,14 @@ __global__ __launch_bounds__(CF_THREADS) void gp_composite_fwd_kernel(RasterDims
         out_tidx[pix] = a1.best_id;
         final_T[pix] = a1.T;
         n_contrib[pix] = a1.last;
+    }
+    if (tile_work) {   // largest list position any pixel of the tile consumed: the backward's work estimate
+        int mx = max(in0 ? a0.last : 0, in1 ? a1.last : 0);
+#pragma unroll
+        for (int dd = 32; dd >= 1; dd >>= 1) mx = max(mx, __shfl_xor(mx, dd));
+        if (lane == 0) s_last[wave] = mx;
+        __syncthreads();
+        if (tid == 0) tile_work[tile] = max(s_last[0], s_last[1]);
     }
 }
 
@@ -560,7 +628,8 @@ __device__ __forceinline__ void gp_composite_bwd3_body(RasterDims d, const int2*
                                                        const int32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpix,
                                                        const float* __restrict__ dL_dpixdepth, float* __restrict__ g_mean2D,
                                                        float* __restrict__ g_conic, float* __restrict__ g_opacity,
-                                                       float* __restrict__ g_color, float* __restrict__ g_depth) {
+                                                       float* __restrict__ g_color, float* __restrict__ g_depth,
+                                                       const uint32_t* __restrict__ order) {
     // per pixel PAIR (two horizontally adjacent pixels):
     __shared__ float4 s_v0[(ROWS * GP_TILE / 2)];   // dLr0 dLr1 dLg0 dLg1
     __shared__ float4 s_v1[(ROWS * GP_TILE / 2)];   // dLb0 dLb1 tb0  tb1      (tb = T_final * bg . dL_dpix)
@@ -568,7 +637,8 @@ __device__ __forceinline__ void gp_composite_bwd3_body(RasterDims d, const int2*
     __shared__ int2 s_nc[(ROWS * GP_TILE / 2)];
     __shared__ float2 s_dd[HAS_DEPTH ? (ROWS * GP_TILE / 2) : 1];   // dLd0 dLd1
     const int parts = GP_TILE / ROWS;
-    const int tile = blockIdx.x / parts, part = blockIdx.x % parts;
+    const int part = blockIdx.x % parts;
+    const int tile = order ? (int)order[blockIdx.x / parts] : (int)(blockIdx.x / parts);
     const int tx = tile % d.gx, ty = tile / d.gx;
     const int lane = threadIdx.x;
     const int2 range = ranges[tile];
@@ -689,16 +759,16 @@ __device__ __forceinline__ void gp_composite_bwd3_body(RasterDims d, const int2*
             }
         }
         if (have && any_m > 0.f) {
-            atomicAdd(&g_mean2D[2 * (size_t)id], (a_mx.x + a_mx.y) * halfW);
-            atomicAdd(&g_mean2D[2 * (size_t)id + 1], (a_my.x + a_my.y) * halfH);
-            atomicAdd(&g_conic[3 * (size_t)id], -0.5f * (a_ca.x + a_ca.y));
-            atomicAdd(&g_conic[3 * (size_t)id + 1], -(a_cb.x + a_cb.y));
-            atomicAdd(&g_conic[3 * (size_t)id + 2], -0.5f * (a_cc.x + a_cc.y));
-            atomicAdd(&g_opacity[id], a_op.x + a_op.y);
-            atomicAdd(&g_color[3 * (size_t)id], a_r.x + a_r.y);
-            atomicAdd(&g_color[3 * (size_t)id + 1], a_g.x + a_g.y);
-            atomicAdd(&g_color[3 * (size_t)id + 2], a_b.x + a_b.y);
-            if (HAS_DEPTH) atomicAdd(&g_depth[id], a_d.x + a_d.y);
+            atomicAdd(&g_mean2D[GP_ACC_STRIDE * (size_t)id], (a_mx.x + a_mx.y) * halfW);
+            atomicAdd(&g_mean2D[GP_ACC_STRIDE * (size_t)id + 1], (a_my.x + a_my.y) * halfH);
+            atomicAdd(&g_conic[GP_ACC_STRIDE * (size_t)id], -0.5f * (a_ca.x + a_ca.y));
+            atomicAdd(&g_conic[GP_ACC_STRIDE * (size_t)id + 1], -(a_cb.x + a_cb.y));
+            atomicAdd(&g_conic[GP_ACC_STRIDE * (size_t)id + 2], -0.5f * (a_cc.x + a_cc.y));
+            atomicAdd(&g_opacity[GP_ACC_STRIDE * (size_t)id], a_op.x + a_op.y);
+            atomicAdd(&g_color[GP_ACC_STRIDE * (size_t)id], a_r.x + a_r.y);
+            atomicAdd(&g_color[GP_ACC_STRIDE * (size_t)id + 1], a_g.x + a_g.y);
+            atomicAdd(&g_color[GP_ACC_STRIDE * (size_t)id + 2], a_b.x + a_b.y);
+            if (HAS_DEPTH) atomicAdd(&g_depth[GP_ACC_STRIDE * (size_t)id], a_d.x + a_d.y);
         }
         __syncthreads();
     }
@@ -712,7 +782,8 @@ __device__ __forceinline__ void gp_composite_bwd4_body(RasterDims d, const int2*
                                                        const int32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpix,
                                                        const float* __restrict__ dL_dpixdepth, float* __restrict__ g_mean2D,
                                                        float* __restrict__ g_conic, float* __restrict__ g_opacity,
-                                                       float* __restrict__ g_color, float* __restrict__ g_depth) {
+                                                       float* __restrict__ g_color, float* __restrict__ g_depth,
+                                                       const uint32_t* __restrict__ order) {
     // per pixel PAIR (two horizontally adjacent pixels):
     __shared__ float4 s_v0[(ROWS * GP_TILE / 2)];   // dLr0 dLr1 dLg0 dLg1
     __shared__ float4 s_v1[(ROWS * GP_TILE / 2)];   // dLb0 dLb1 tb0  tb1      (tb = T_final * bg . dL_dpix)
@@ -720,7 +791,8 @@ __device__ __forceinline__ void gp_composite_bwd4_body(RasterDims d, const int2*
     __shared__ int2 s_nc[(ROWS * GP_TILE / 2)];
     __shared__ float2 s_dd[HAS_DEPTH ? (ROWS * GP_TILE / 2) : 1];   // dLd0 dLd1
     const int parts = GP_TILE / ROWS;
-    const int tile = blockIdx.x / parts, part = blockIdx.x % parts;
+    const int part = blockIdx.x % parts;
+    const int tile = order ? (int)order[blockIdx.x / parts] : (int)(blockIdx.x / parts);
     const int tx = tile % d.gx, ty = tile / d.gx;
     const int lane = threadIdx.x;
     const int2 range = ranges[tile];
@@ -779,16 +851,7 @@ __device__ __forceinline__ void gp_composite_bwd4_body(RasterDims d, const int2*
         while (qn < 64 && pending) {
             bool relevant = false;
             if (c_have) {
-                const float cx_ = -2.f * k0.z, cy_ = -k0.w, cz_ = -2.f * k1.x;
-                const float detc = cx_ * cz_ - cy_ * cy_;
-                const float tau = __logf(255.f * k1.y);
-                if (tau > 0.f && detc > 0.f) {
-                    const float e2 = 2.f * tau * 1.004f / detc;
-                    const float ex = sqrtf(e2 * cz_) + 0.01f, ey = sqrtf(e2 * cx_) + 0.01f;
-                    relevant = (k0.x + ex >= RX0) && (k0.x - ex <= RX1) && (k0.y + ey >= RY0) && (k0.y - ey <= RY1);
-                } else if (!(detc > 0.f) && tau > 0.f) {
-                    relevant = true;
-                }
+                relevant = gp_splat_hits_rect(k0, k1, RX0, RX1, RY0, RY1);
             }
             const unsigned long long mk = __ballot(relevant);
             const int slot = qn + (int)gp_mbcnt(mk);
@@ -884,16 +947,16 @@ __device__ __forceinline__ void gp_composite_bwd4_body(RasterDims d, const int2*
             }
         }
         if (have && any_m > 0.f) {
-            atomicAdd(&g_mean2D[2 * (size_t)id], (a_mx.x + a_mx.y) * halfW);
-            atomicAdd(&g_mean2D[2 * (size_t)id + 1], (a_my.x + a_my.y) * halfH);
-            atomicAdd(&g_conic[3 * (size_t)id], -0.5f * (a_ca.x + a_ca.y));
-            atomicAdd(&g_conic[3 * (size_t)id + 1], -(a_cb.x + a_cb.y));
-            atomicAdd(&g_conic[3 * (size_t)id + 2], -0.5f * (a_cc.x + a_cc.y));
-            atomicAdd(&g_opacity[id], a_op.x + a_op.y);
-            atomicAdd(&g_color[3 * (size_t)id], a_r.x + a_r.y);
-            atomicAdd(&g_color[3 * (size_t)id + 1], a_g.x + a_g.y);
-            atomicAdd(&g_color[3 * (size_t)id + 2], a_b.x + a_b.y);
-            if (HAS_DEPTH) atomicAdd(&g_depth[id], a_d.x + a_d.y);
+            atomicAdd(&g_mean2D[GP_ACC_STRIDE * (size_t)id], (a_mx.x + a_mx.y) * halfW);
+            atomicAdd(&g_mean2D[GP_ACC_STRIDE * (size_t)id + 1], (a_my.x + a_my.y) * halfH);
+            atomicAdd(&g_conic[GP_ACC_STRIDE * (size_t)id], -0.5f * (a_ca.x + a_ca.y));
+            atomicAdd(&g_conic[GP_ACC_STRIDE * (size_t)id + 1], -(a_cb.x + a_cb.y));
+            atomicAdd(&g_conic[GP_ACC_STRIDE * (size_t)id + 2], -0.5f * (a_cc.x + a_cc.y));
+            atomicAdd(&g_opacity[GP_ACC_STRIDE * (size_t)id], a_op.x + a_op.y);
+            atomicAdd(&g_color[GP_ACC_STRIDE * (size_t)id], a_r.x + a_r.y);
+            atomicAdd(&g_color[GP_ACC_STRIDE * (size_t)id + 1], a_g.x + a_g.y);
+            atomicAdd(&g_color[GP_ACC_STRIDE * (size_t)id + 2], a_b.x + a_b.y);
+            if (HAS_DEPTH) atomicAdd(&g_depth[GP_ACC_STRIDE * (size_t)id], a_d.x + a_d.y);
         }
         __syncthreads();
     }
@@ -903,13 +966,265 @@ __device__ __forceinline__ void gp_composite_bwd4_body(RasterDims d, const int2*
     const float4* __restrict__ rec, const float* __restrict__ bg, const float* __restrict__ out_color, \
     const float* __restrict__ out_depth, const float* __restrict__ final_T, const int32_t* __restrict__ n_contrib, \
     const float* __restrict__ dL_dpix, const float* __restrict__ dL_dpixdepth, float* __restrict__ g_mean2D, \
-    float* __restrict__ g_conic, float* __restrict__ g_opacity, float* __restrict__ g_color, float* __restrict__ g_depth
+    float* __restrict__ g_conic, float* __restrict__ g_opacity, float* __restrict__ g_color, float* __restrict__ g_depth, \
+    const uint32_t* __restrict__ order
 #define CB_PASS d, ranges, point_list, rec, bg, out_color, out_depth, final_T, n_contrib, dL_dpix, dL_dpixdepth, g_mean2D, \
-    g_conic, g_opacity, g_color, g_depth
+    g_conic, g_opacity, g_color, g_depth, order
 __global__ __launch_bounds__(64) void gp_composite_bwd3_kernel(CB_ARGS) { gp_composite_bwd3_body<false, 8>(CB_PASS); }
 __global__ __launch_bounds__(64) void gp_composite_bwd3_depth_kernel(CB_ARGS) { gp_composite_bwd3_body<true, 8>(CB_PASS); }
 __global__ __launch_bounds__(64) void gp_composite_bwd4_kernel(CB_ARGS) { gp_composite_bwd4_body<false, 8>(CB_PASS); }
 __global__ __launch_bounds__(64) void gp_composite_bwd4_depth_kernel(CB_ARGS) { gp_composite_bwd4_body<true, 8>(CB_PASS); }
+
+// ---- v5: v4 + the per-pixel-pair constants come from a prepared, read-only buffer through the SCALAR cache.
+// Every lane of the wave needs the same 14 values per pixel pair (dL/dpixel of both pixels, the background term,
+// n_contrib, dL/ddepth): as LDS broadcast reads they cost 4 LDS round trips per step and 14 VGPRs; as
+// s_load_dwordx8/x4 (prefetched one step ahead) they cost none of either and feed v_pk_* directly as SGPR pairs.
+// gp_bwd_pixprep_kernel writes the buffer: per (tile, part) 64 pairs x 16 dwords
+//   [0..3] dLr0 dLr1 dLg0 dLg1  [4..7] dLb0 dLb1 tb0 tb1  [8,9] nc0 nc1  [10,11] rem0 rem1  [12,13] dLd0 dLd1
+// Only the running (log2 T, remaining suffix) pair stays in LDS: it is carried from batch to batch.
+struct GpPixPair { float v[16]; };
+
+template <int ROWS>
+__device__ __forceinline__ void gp_bwd_pixprep_body(RasterDims d, const float* __restrict__ bg, const float* __restrict__ out_color,
+                                                    const float* __restrict__ out_depth, const float* __restrict__ final_T,
+                                                    const int32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpix,
+                                                    const float* __restrict__ dL_dpixdepth, GpPixPair* __restrict__ pp) {
+    const int parts = GP_TILE / ROWS;
+    const int PAIRS = ROWS * GP_TILE / 2;
+    const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t total = (size_t)d.gx * d.gy * parts * PAIRS;
+    if (gid >= total) return;
+    const int pr = (int)(gid % PAIRS);
+    const int tp = (int)(gid / PAIRS);
+    const int tile = tp / parts, part = tp % parts;
+    const int tx = tile % d.gx, ty = tile / d.gx;
+    const size_t HW = (size_t)d.H * d.W;
+    const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
+    const int px0 = tx * GP_TILE + 2 * (pr & 7), py = ty * GP_TILE + part * ROWS + (pr >> 3);
+    float dl[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    float tb[2] = {0.f, 0.f}, rem[2] = {0.f, 0.f};
+    int nc[2] = {0, 0};
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int px = px0 + u;
+        if (px < d.W && py < d.H) {
+            const size_t pix = (size_t)py * d.W + px;
+            dl[u][0] = dL_dpix[pix]; dl[u][1] = dL_dpix[HW + pix]; dl[u][2] = dL_dpix[2 * HW + pix];
+            dl[u][3] = dL_dpixdepth ? dL_dpixdepth[pix] : 0.f;
+            tb[u] = final_T[pix] * (bg0 * dl[u][0] + bg1 * dl[u][1] + bg2 * dl[u][2]);
+            rem[u] = out_color[pix] * dl[u][0] + out_color[HW + pix] * dl[u][1] + out_color[2 * HW + pix] * dl[u][2] - tb[u];
+            if (dL_dpixdepth) rem[u] += out_depth[pix] * dl[u][3];
+            nc[u] = n_contrib[pix];
+        }
+    }
+    float4* o = (float4*)&pp[gid];
+    o[0] = make_float4(dl[0][0], dl[1][0], dl[0][1], dl[1][1]);
+    o[1] = make_float4(dl[0][2], dl[1][2], tb[0], tb[1]);
+    o[2] = make_float4(__int_as_float(nc[0]), __int_as_float(nc[1]), rem[0], rem[1]);
+    o[3] = make_float4(dl[0][3], dl[1][3], 0.f, 0.f);
+}
+__global__ __launch_bounds__(256) void gp_bwd_pixprep_kernel(RasterDims d, const float* __restrict__ bg, const float* __restrict__ out_color,
+                                                             const float* __restrict__ out_depth, const float* __restrict__ final_T,
+                                                             const int32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpix,
+                                                             const float* __restrict__ dL_dpixdepth, GpPixPair* __restrict__ pp) {
+    gp_bwd_pixprep_body<8>(d, bg, out_color, out_depth, final_T, n_contrib, dL_dpix, dL_dpixdepth, pp);
+}
+
+__device__ int g_abl = 0;
+extern "C" void gp_set_abl(int v) { hipMemcpyToSymbol(HIP_SYMBOL(g_abl), &v, sizeof(int)); }
+template <bool HAS_DEPTH, int ROWS>
+__device__ __forceinline__ void gp_composite_bwd5_body(RasterDims d, const int2* __restrict__ ranges,
+                                                       const uint32_t* __restrict__ point_list, const float4* __restrict__ rec,
+                                                       const GpPixPair* __restrict__ pp, float* __restrict__ g_mean2D,
+                                                       float* __restrict__ g_conic, float* __restrict__ g_opacity,
+                                                       float* __restrict__ g_color, float* __restrict__ g_depth,
+                                                       const uint32_t* __restrict__ order) {
+    const int abl = g_abl;
+    constexpr int PAIRS = ROWS * GP_TILE / 2;
+    static_assert(PAIRS == 64, "one lane per pixel pair in the prologue");
+    __shared__ float4 s_cy[PAIRS];   // Lin0 Lin1 rem0 rem1     (carried between batches)
+    __shared__ float4 s_fl[64][3];
+    __shared__ uint32_t s_flid[64];
+    const int parts = GP_TILE / ROWS;
+    const int part = blockIdx.x % parts;
+    const int tile = __builtin_amdgcn_readfirstlane(order ? (int)order[blockIdx.x / parts] : (int)(blockIdx.x / parts));
+    const int tx = tile % d.gx, ty = tile / d.gx;
+    const int lane = threadIdx.x;
+    const int2 range = ranges[tile];
+    const GpPixPair* __restrict__ mypp = pp + ((size_t)tile * parts + part) * PAIRS;   // uniform base
+    int max_nc;
+    {
+        const float4 t = ((const float4*)&mypp[lane])[2];
+        s_cy[lane] = make_float4(0.f, 0.f, t.z, t.w);
+        max_nc = max(__float_as_int(t.x), __float_as_int(t.y));
+    }
+#pragma unroll
+    for (int dd = 32; dd >= 1; dd >>= 1) max_nc = max(max_nc, __shfl_xor(max_nc, dd));
+    __builtin_amdgcn_wave_barrier();
+    const float halfW = 0.5f * (float)d.W, halfH = 0.5f * (float)d.H;
+    const int count = min(range.y - range.x, max_nc);
+    const float px_base = (float)(tx * GP_TILE), py_base = (float)(ty * GP_TILE + part * ROWS);
+    const float LOG2E = 1.4426950408889634f;
+    // ---- compaction: only splats whose alpha >= 1/255 footprint intersects THIS tile part enter a batch
+    // (stable, so depth order is kept); candidates are fetched 64 at a time, one fetch ahead of the pixel walk.
+    __shared__ float4 s_e0[128], s_e1[128], s_e2[128];
+    __shared__ int s_epos[128];
+    __shared__ uint32_t s_eid[128];
+    const float RX0 = px_base, RX1 = px_base + 15.f, RY0 = py_base, RY1 = py_base + (float)(ROWS - 1);
+    int qn = 0, src = 0;
+    uint32_t c_id = 0;
+    float4 k0 = make_float4(0.f, 0.f, 0.f, 0.f), k1 = k0, k2 = k0;
+    bool c_have = lane < count;
+    if (c_have) {
+        c_id = point_list[range.x + lane];
+        k0 = rec[3 * (size_t)c_id]; k1 = rec[3 * (size_t)c_id + 1]; k2 = rec[3 * (size_t)c_id + 2];
+    }
+    bool pending = count > 0;
+    while (true) {
+        while (qn < 64 && pending) {
+            bool relevant = false;
+            if (c_have) relevant = gp_splat_hits_rect(k0, k1, RX0, RX1, RY0, RY1);
+            const unsigned long long mk = __ballot(relevant);
+            const int slot = qn + (int)gp_mbcnt(mk);
+            if (relevant) { s_e0[slot] = k0; s_e1[slot] = k1; s_e2[slot] = k2; s_epos[slot] = src + lane; s_eid[slot] = c_id; }
+            qn += (int)__popcll(mk);
+            src += 64;
+            pending = src < count;
+            c_have = src + lane < count;
+            if (c_have) {
+                c_id = point_list[range.x + src + lane];
+                k0 = rec[3 * (size_t)c_id]; k1 = rec[3 * (size_t)c_id + 1]; k2 = rec[3 * (size_t)c_id + 2];
+            }
+        }
+        if (qn == 0) break;
+        __builtin_amdgcn_wave_barrier();
+        const int nb = min(64, qn);
+        const bool have = lane < nb;
+        const int b0 = __builtin_amdgcn_readfirstlane(s_epos[0]);   // smallest list position in this batch (uniform)
+        const int pos = have ? s_epos[lane] : 0x7fffffff;
+        const uint32_t id = have ? s_eid[lane] : 0u;
+        float4 q0 = make_float4(0.f, 0.f, 0.f, 0.f), q1 = q0, q2 = q0;
+        if (have) { q0 = s_e0[lane]; q1 = s_e1[lane]; q2 = s_e2[lane]; }
+        {   // pop the batch: entries [64, qn) move to the front
+            float4 m0 = q0, m1 = q1, m2 = q2; int mp = 0; uint32_t mi = 0;
+            const bool mv = lane + 64 < qn;
+            if (mv) { m0 = s_e0[lane + 64]; m1 = s_e1[lane + 64]; m2 = s_e2[lane + 64]; mp = s_epos[lane + 64]; mi = s_eid[lane + 64]; }
+            __builtin_amdgcn_wave_barrier();
+            if (mv) { s_e0[lane] = m0; s_e1[lane] = m1; s_e2[lane] = m2; s_epos[lane] = mp; s_eid[lane] = mi; }
+            qn -= nb;
+        }
+        const float sx = q0.x - px_base, sy = q0.y - py_base;
+        const float As = q0.z * LOG2E, Bs = q0.w * LOG2E, Cs = q1.x * LOG2E;   // power in log2 units
+        const float op = have ? q1.y : 0.f, zdep = q1.z;
+        const float cxx = -2.f * q0.z, cxy = -q0.w, cyy = -2.f * q1.x;
+        const v2f cr = {q2.x, q2.x}, cg = {q2.y, q2.y}, cb = {q2.z, q2.z};
+        v2f a_mx = {0.f, 0.f}, a_my = {0.f, 0.f}, a_ca = {0.f, 0.f}, a_cb = {0.f, 0.f}, a_cc = {0.f, 0.f}, a_op = {0.f, 0.f},
+            a_r = {0.f, 0.f}, a_g = {0.f, 0.f}, a_b = {0.f, 0.f}, a_d = {0.f, 0.f};
+        float any_m = 0.f;
+        // scalar-cache prefetch, one pixel pair ahead
+        const float4* __restrict__ ppq = (const float4*)mypp;
+        float4 n0 = ppq[0], n1 = ppq[1], n2 = ppq[2], n3 = HAS_DEPTH ? ppq[3] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 1
+        for (int row = 0; row < ((abl & 32) ? 0 : ROWS); ++row) {
+            const float dy = sy - (float)row;
+            const float tB = Bs * dy, uC = (Cs * dy) * dy;
+#pragma unroll 1
+            for (int cp = 0; cp < GP_TILE / 2; ++cp) {
+                const int pr = row * (GP_TILE / 2) + cp;
+                const float4 v0 = n0, v1 = n1, v2 = n2, v3 = n3;
+                {
+                    const int nx = min(pr + 1, PAIRS - 1) * 4;
+                    n0 = ppq[nx]; n1 = ppq[nx + 1]; n2 = ppq[nx + 2];
+                    if (HAS_DEPTH) n3 = ppq[nx + 3];
+                }
+                const int ncx = __float_as_int(v2.x), ncy = __float_as_int(v2.y);
+                if (max(ncx, ncy) > b0) {   // uniform: otherwise both pixels finished before this batch
+                    const float4 cy = s_cy[pr];
+                    const float dx0 = sx - (float)(2 * cp);
+                    const v2f dx = {dx0, dx0 - 1.f};
+                    const v2f pw = {fmaf(dx.x, fmaf(As, dx.x, tB), uC), fmaf(dx.y, fmaf(As, dx.y, tB), uC)};
+                    const v2f G = {__builtin_amdgcn_exp2f(fminf(pw.x, 0.f)), __builtin_amdgcn_exp2f(fminf(pw.y, 0.f))};
+                    const v2f alpha = {fminf(0.99f, op * G.x), fminf(0.99f, op * G.y)};
+                    const bool c0 = (pos < ncx) && !(pw.x > 0.f) && !(alpha.x < 1.f / 255.f);
+                    const bool c1 = (pos < ncy) && !(pw.y > 0.f) && !(alpha.y < 1.f / 255.f);
+                    if (__any(c0 || c1)) {   // otherwise nobody in the wave touches either pixel
+                        const v2f m = {c0 ? 1.f : 0.f, c1 ? 1.f : 0.f};
+                        any_m = fmaxf(any_m, fmaxf(m.x, m.y));
+                        const v2f am = alpha * m;
+                        const v2f om = 1.f - am;
+                        float l0 = __builtin_amdgcn_logf(om.x), l1 = __builtin_amdgcn_logf(om.y);   // log2, exactly 0 for om == 1
+                        v2f cdot = cb * (v2f){v1.x, v1.y};
+                        cdot = cg * (v2f){v0.z, v0.w} + cdot;
+                        cdot = cr * (v2f){v0.x, v0.y} + cdot;
+                        v2f dLd = {0.f, 0.f};
+                        if (HAS_DEPTH) { dLd.x = v3.x; dLd.y = v3.y; cdot = zdep * dLd + cdot; }
+                        // T_j needs the EXCLUSIVE log-sum, s_j = alpha_j T_j cdot needs T_j: scan the logs first
+                        float il0 = l0, il1 = l1;
+                        if (!(abl & 1)) dpp_scan2_add(il0, il1);
+                        const v2f Tj = {__builtin_amdgcn_exp2f(cy.x + il0 - l0), __builtin_amdgcn_exp2f(cy.y + il1 - l1)};
+                        const v2f w = am * Tj;
+                        const v2f sv = w * cdot;
+                        float is0 = sv.x, is1 = sv.y;
+                        if (!(abl & 2)) dpp_scan2_add(is0, is1);
+                        const v2f rem = {cy.z, cy.w};
+                        const v2f tbv = {v1.z, v1.w};
+                        const v2f rom = {__builtin_amdgcn_rcpf(om.x), __builtin_amdgcn_rcpf(om.y)};
+                        const v2f suffix = rem - (v2f){is0, is1};
+                        const v2f dL_dalpha = (Tj * cdot - (suffix + tbv) * rom) * m;
+                        if (!(abl & 8)) {
+                        a_r += w * (v2f){v0.x, v0.y}; a_g += w * (v2f){v0.z, v0.w}; a_b += w * (v2f){v1.x, v1.y};
+                        if (HAS_DEPTH) a_d += w * dLd;
+                        a_op += G * dL_dalpha;
+                        const v2f dL_dG = op * dL_dalpha;
+                        const v2f gdx = G * dx, gdy = G * dy;
+                        a_mx += dL_dG * (-gdx * cxx - gdy * cxy);
+                        a_my += dL_dG * (-gdy * cyy - gdx * cxy);
+                        a_ca += (gdx * dx) * dL_dG;
+                        a_cb += (gdx * dy) * dL_dG;
+                        a_cc += (gdy * dy) * dL_dG;
+                        } else { a_r += dL_dalpha; }
+                        // carry to the next batch
+                        if (!(abl & 4)) {
+                        const float tl0 = lane63(il0), tl1 = lane63(il1), ts0 = lane63(is0), ts1 = lane63(is1);
+                        if (lane == 0) s_cy[pr] = make_float4(cy.x + tl0, cy.y + tl1, cy.z - ts0, cy.w - ts1);
+                        }
+                    }
+                }
+            }
+        }
+        // flush: transpose through LDS so that 16 consecutive lanes add to the 16 consecutive floats of ONE
+        // Gaussian's accumulator line -- an atomic instruction then touches 4 cache lines instead of 64.
+        if (!(abl & 16)) {
+            const bool mine = have && any_m > 0.f;
+            s_fl[lane][0] = make_float4((a_mx.x + a_mx.y) * halfW, (a_my.x + a_my.y) * halfH, -0.5f * (a_ca.x + a_ca.y), -(a_cb.x + a_cb.y));
+            s_fl[lane][1] = make_float4(-0.5f * (a_cc.x + a_cc.y), a_op.x + a_op.y, a_r.x + a_r.y, a_g.x + a_g.y);
+            s_fl[lane][2] = make_float4(a_b.x + a_b.y, HAS_DEPTH ? a_d.x + a_d.y : 0.f, 0.f, 0.f);
+            s_flid[lane] = mine ? id : 0xffffffffu;
+            __builtin_amdgcn_wave_barrier();
+            const int comp = lane & 15, sub = lane >> 4;
+            const float* fl = (const float*)&s_fl[0][0];
+            if (comp < (HAS_DEPTH ? 10 : 9)) {
+#pragma unroll 4
+                for (int r = 0; r < 16; ++r) {
+                    const int sp = r * 4 + sub;
+                    const uint32_t gid = s_flid[sp];
+                    if (gid != 0xffffffffu) atomicAdd(&g_mean2D[GP_ACC_STRIDE * (size_t)gid + comp], fl[sp * 12 + comp]);
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+#define CB5_ARGS RasterDims d, const int2* __restrict__ ranges, const uint32_t* __restrict__ point_list, \
+    const float4* __restrict__ rec, const GpPixPair* __restrict__ pp, float* __restrict__ g_mean2D, \
+    float* __restrict__ g_conic, float* __restrict__ g_opacity, float* __restrict__ g_color, float* __restrict__ g_depth, \
+    const uint32_t* __restrict__ order
+__global__ __launch_bounds__(64) void gp_composite_bwd5_kernel(CB5_ARGS) {
+    gp_composite_bwd5_body<false, 8>(d, ranges, point_list, rec, pp, g_mean2D, g_conic, g_opacity, g_color, g_depth, order);
+}
+__global__ __launch_bounds__(64) void gp_composite_bwd5_depth_kernel(CB5_ARGS) {
+    gp_composite_bwd5_body<true, 8>(d, ranges, point_list, rec, pp, g_mean2D, g_conic, g_opacity, g_color, g_depth, order);
+}
 
 // ------------------------------------------------------------------------------------------------
 // preprocess backward (per Gaussian) -- mirrors gpo_preprocess_bwd of the oracle
@@ -955,10 +1270,10 @@ __device__ __forceinline__ void preprocess_bwd_body(
     do {
     if (i >= d.N) break;
     const bool vis = radii[i] > 0;
-    dL_dmeans2D[3 * i] = vis ? g_mean2D[2 * i] : 0.f;
-    dL_dmeans2D[3 * i + 1] = vis ? g_mean2D[2 * i + 1] : 0.f;
+    dL_dmeans2D[3 * i] = vis ? g_mean2D[GP_ACC_STRIDE * (size_t)i] : 0.f;
+    dL_dmeans2D[3 * i + 1] = vis ? g_mean2D[GP_ACC_STRIDE * (size_t)i + 1] : 0.f;
     dL_dmeans2D[3 * i + 2] = 0.f;
-    dL_dopacities[i] = vis ? g_opacity[i] : 0.f;
+    dL_dopacities[i] = vis ? g_opacity[GP_ACC_STRIDE * (size_t)i] : 0.f;
     if (!vis) {
 #pragma unroll
         for (int k = 0; k < 3; ++k) dL_dmeans3D[3 * i + k] = 0.f;
@@ -983,7 +1298,7 @@ __device__ __forceinline__ void preprocess_bwd_body(
     compute_cov2D(pv, d.fx, d.fy, d.tanfovx, d.tanfovy, c6, view, abc, &cx);
     const float a = abc[0] + 0.3f, b = abc[1], c = abc[2] + 0.3f;
     const float det = a * c - b * b;
-    const float gA = g_conic[3 * i], gB = g_conic[3 * i + 1], gC = g_conic[3 * i + 2];
+    const float gA = g_conic[GP_ACC_STRIDE * (size_t)i], gB = g_conic[GP_ACC_STRIDE * (size_t)i + 1], gC = g_conic[GP_ACC_STRIDE * (size_t)i + 2];
     float gm0 = 0.f, gm1 = 0.f, gm2 = 0.f;
     float g6[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     const float W0[3] = {view[0], view[4], view[8]};
@@ -1025,20 +1340,20 @@ __device__ __forceinline__ void preprocess_bwd_body(
         gm2 += W0[2] * dtx + W1[2] * dty + W2[2] * dtz;
     }
     {   // depth
-        const float gd = g_depth[i];
+        const float gd = g_depth[GP_ACC_STRIDE * (size_t)i];
         gm0 += view[2] * gd; gm1 += view[6] * gd; gm2 += view[10] * gd;
     }
     {   // mean2D (NDC) -> mean3D
         const float4 ph = xform4x4(proj, px, py, pz);
         const float mw = 1.f / (ph.w + 0.0000001f);
         const float mul1 = ph.x * mw * mw, mul2 = ph.y * mw * mw;
-        const float g2x = g_mean2D[2 * i], g2y = g_mean2D[2 * i + 1];
+        const float g2x = g_mean2D[GP_ACC_STRIDE * (size_t)i], g2y = g_mean2D[GP_ACC_STRIDE * (size_t)i + 1];
         gm0 += (proj[0] * mw - proj[3] * mul1) * g2x + (proj[1] * mw - proj[3] * mul2) * g2y;
         gm1 += (proj[4] * mw - proj[7] * mul1) * g2x + (proj[5] * mw - proj[7] * mul2) * g2y;
         gm2 += (proj[8] * mw - proj[11] * mul1) * g2x + (proj[9] * mw - proj[11] * mul2) * g2y;
     }
     if (dL_dcolors) {
-        dL_dcolors[3 * i] = g_color[3 * i]; dL_dcolors[3 * i + 1] = g_color[3 * i + 1]; dL_dcolors[3 * i + 2] = g_color[3 * i + 2];
+        dL_dcolors[3 * i] = g_color[GP_ACC_STRIDE * (size_t)i]; dL_dcolors[3 * i + 1] = g_color[GP_ACC_STRIDE * (size_t)i + 1]; dL_dcolors[3 * i + 2] = g_color[GP_ACC_STRIDE * (size_t)i + 2];
     } else {
         const float ddx0 = px - campos[0], ddy0 = py - campos[1], ddz0 = pz - campos[2];
         const float len = sqrtf(fmaf(ddx0, ddx0, fmaf(ddy0, ddy0, ddz0 * ddz0)));
@@ -1053,7 +1368,7 @@ __device__ __forceinline__ void preprocess_bwd_body(
         for (int k = used; k < d.M; ++k) { dsh[3 * k] = 0.f; dsh[3 * k + 1] = 0.f; dsh[3 * k + 2] = 0.f; }
 #pragma unroll
         for (int ch = 0; ch < 3; ++ch) {
-            const float g = ((cl >> ch) & 1) ? 0.f : g_color[3 * i + ch];
+            const float g = ((cl >> ch) & 1) ? 0.f : g_color[GP_ACC_STRIDE * (size_t)i + ch];
             dsh[0 * 3 + ch] = SH_C0 * g;
             if (D > 0) {
                 dsh[1 * 3 + ch] = -SH_C1 * y * g;

@@ -248,5 +248,10 @@ def raster_forward_debug(raster_settings, means3D, opacities, shs=None, colors_p
         _lib.check(L.gp_raster_debug_binning(C.byref(st), C.byref(saved), _lib.ptr(point_list), _lib.ptr(ranges),
                                              _lib.stream_ptr(device)), "gp_raster_debug_binning")
         torch.cuda.synchronize(device)
+        geom = alloc.first(_lib.GP_BUF_GEOM)
+        rec = geom[:48 * N].view(torch.float32).view(N, 12).clone() if (geom is not None and N > 0) else None
+        img = alloc.first(_lib.GP_BUF_IMAGE)
+        n_contrib = img[8 * T + 4 * H * W:8 * T + 8 * H * W].view(torch.int32).view(H, W).clone() if img is not None else None
         alloc.release()
-    return dict(color=color, radii=radii, depth=depth, tidx=tidx, R=R, point_list=point_list[:R], ranges=ranges)
+    return dict(color=color, radii=radii, depth=depth, tidx=tidx, R=R, point_list=point_list[:R], ranges=ranges, rec=rec,
+                n_contrib=n_contrib)
