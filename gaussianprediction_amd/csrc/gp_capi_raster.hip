@@ -216,7 +216,7 @@ extern "C" int gp_raster_backward(const gp_raster_settings* st, const gp_raster_
     if (R > 0 && !point_list) GP_FAIL("saved binning state missing");
 
     const size_t acc_floats = (size_t)GP_ACC_STRIDE * N;
-    const size_t pp_bytes = T * 2 * 64 * 64;   // (tile, 8-row part) x 64 pixel pairs x 64 B
+    const size_t pp_bytes = T * GP_BWD_PARTS * GP_BWD_PAIRS * 64;   // (tile, part) x pixel pairs x 64 B
     float* acc = (float*)alloc(alloc_ctx, GP_BUF_TEMP, gp_align_up(acc_floats * 4, 256) + gp_align_up(T * 4, 256) + pp_bytes);
     if (!acc) GP_FAIL("allocator returned NULL for TEMP");
     uint32_t* order_bwd = (uint32_t*)((char*)acc + gp_align_up(acc_floats * 4, 256));
@@ -237,10 +237,14 @@ extern "C" int gp_raster_backward(const gp_raster_settings* st, const gp_raster_
         GP_LAUNCH_CHECK();
         static const bool use_v5 = getenv("GP_EXP_BWD_V4") == nullptr && !use_v3;
         if (use_v5) {
+            {
+                GpProfScope _p("bwd_pixprep", s);
+                hipLaunchKernelGGL(gp_bwd_pixprep_kernel, dim3(gp_blocks(T * GP_BWD_PARTS * GP_BWD_PAIRS, 256)), dim3(256), 0, s, d, st->bg,
+                                   fwd->color, fwd->depth, il.final_T, il.n_contrib, dL_dcolor, dL_ddepth, pp);
+                GP_LAUNCH_CHECK();
+            }
             GpProfScope _p("composite_bwd", s);
-            hipLaunchKernelGGL(gp_bwd_pixprep_kernel, dim3(gp_blocks(T * parts * 64, 256)), dim3(256), 0, s, d, st->bg, fwd->color,
-                               fwd->depth, il.final_T, il.n_contrib, dL_dcolor, dL_ddepth, pp);
-            hipLaunchKernelGGL(dL_ddepth ? gp_composite_bwd5_depth_kernel : gp_composite_bwd5_kernel, dim3((unsigned)T * parts),
+            hipLaunchKernelGGL(dL_ddepth ? gp_composite_bwd5_depth_kernel : gp_composite_bwd5_kernel, dim3((unsigned)T * GP_BWD_PARTS),
                                dim3(64), 0, s, d, il.ranges, point_list, gl.rec, (const GpPixPair*)pp, g_mean2D, g_conic, g_opacity,
                                g_color, g_depth, order_bwd);
             GP_LAUNCH_CHECK();

@@ -4,6 +4,13 @@
 
 // backward accumulators: one 64-byte line per Gaussian  [0,1] mean2D  [2..4] conic  [5] opacity  [6..8] colour  [9] depth
 #define GP_ACC_STRIDE 16
+// the backward walks the image in parts of GP_BWD_ROWS x GP_BWD_COLS pixels, one wave each
+#ifndef GP_BWD_ROWS
+#define GP_BWD_ROWS 8
+#define GP_BWD_COLS 8
+#endif
+#define GP_BWD_PARTS ((16 / GP_BWD_ROWS) * (16 / GP_BWD_COLS))
+#define GP_BWD_PAIRS (GP_BWD_ROWS * GP_BWD_COLS / 2)
 
 struct RasterDims {
     int N, M, D;       // gaussians, sh coeffs per channel, active sh degree

@@ -448,6 +448,8 @@ __device__ __forceinline__ bool gp_splat_hits_rect(const float4 q0, const float4
 // the ballots of those decisions let each consumer wave walk only the splats that matter to it.
 // ------------------------------------------------------------------------------------------------
 #define CF_THREADS 128
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef int v2i __attribute__((ext_vector_type(2)));
 
 struct PixAcc {
     float T, C0, C1, C2, Dp, best;
@@ -586,8 +588,6 @@ __global__ __launch_bounds__(CF_THREADS) void gp_composite_fwd_kernel(RasterDims
 // - (suffix_j + T_final bg.dLp) / (1 - alpha_j).  Each lane accumulates its splat's 10 gradient sums
 // in registers and issues 10 atomics per (splat, tile part) -- not per (splat, pixel).
 // ------------------------------------------------------------------------------------------------
-typedef float v2f __attribute__((ext_vector_type(2)));
-typedef int v2i __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float lane63(float v) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63)); }
 
 // ---- v3: log-domain transmittance so that BOTH wave scans are sums, done as fused v_add_f32_dpp chains
@@ -615,6 +615,30 @@ __device__ __forceinline__ void dpp_scan2_add(float& a, float& b) {
         "s_nop 0\n\t"
         "v_add_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
         "v_add_f32_dpp %1, %1, %1 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+        "s_nop 1"
+        : "+v"(a), "+v"(b));
+}
+// inclusive wave PRODUCT scan of two values (same DPP ladder; lanes without a source keep their value)
+__device__ __forceinline__ void dpp_scan2_mul(float& a, float& b) {
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_mul_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+        "v_mul_f32_dpp %1, %1, %1 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 0\n\t"
+        "v_mul_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+        "v_mul_f32_dpp %1, %1, %1 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 0\n\t"
+        "v_mul_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+        "v_mul_f32_dpp %1, %1, %1 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 0\n\t"
+        "v_mul_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_mul_f32_dpp %1, %1, %1 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 0\n\t"
+        "v_mul_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "v_mul_f32_dpp %1, %1, %1 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "s_nop 0\n\t"
+        "v_mul_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+        "v_mul_f32_dpp %1, %1, %1 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
         "s_nop 1"
         : "+v"(a), "+v"(b));
 }
@@ -984,13 +1008,13 @@ __global__ __launch_bounds__(64) void gp_composite_bwd4_depth_kernel(CB_ARGS) { 
 // Only the running (log2 T, remaining suffix) pair stays in LDS: it is carried from batch to batch.
 struct GpPixPair { float v[16]; };
 
-template <int ROWS>
+template <int ROWS, int COLS>
 __device__ __forceinline__ void gp_bwd_pixprep_body(RasterDims d, const float* __restrict__ bg, const float* __restrict__ out_color,
                                                     const float* __restrict__ out_depth, const float* __restrict__ final_T,
                                                     const int32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpix,
                                                     const float* __restrict__ dL_dpixdepth, GpPixPair* __restrict__ pp) {
-    const int parts = GP_TILE / ROWS;
-    const int PAIRS = ROWS * GP_TILE / 2;
+    const int parts_x = GP_TILE / COLS, parts = (GP_TILE / ROWS) * parts_x;
+    const int PAIRS = ROWS * COLS / 2;
     const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
     const size_t total = (size_t)d.gx * d.gy * parts * PAIRS;
     if (gid >= total) return;
@@ -1000,7 +1024,8 @@ __device__ __forceinline__ void gp_bwd_pixprep_body(RasterDims d, const float* _
     const int tx = tile % d.gx, ty = tile / d.gx;
     const size_t HW = (size_t)d.H * d.W;
     const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
-    const int px0 = tx * GP_TILE + 2 * (pr & 7), py = ty * GP_TILE + part * ROWS + (pr >> 3);
+    const int px0 = tx * GP_TILE + (part % parts_x) * COLS + 2 * (pr % (COLS / 2));
+    const int py = ty * GP_TILE + (part / parts_x) * ROWS + pr / (COLS / 2);
     float dl[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
     float tb[2] = {0.f, 0.f}, rem[2] = {0.f, 0.f};
     int nc[2] = {0, 0};
@@ -1027,12 +1052,12 @@ __global__ __launch_bounds__(256) void gp_bwd_pixprep_kernel(RasterDims d, const
                                                              const float* __restrict__ out_depth, const float* __restrict__ final_T,
                                                              const int32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpix,
                                                              const float* __restrict__ dL_dpixdepth, GpPixPair* __restrict__ pp) {
-    gp_bwd_pixprep_body<8>(d, bg, out_color, out_depth, final_T, n_contrib, dL_dpix, dL_dpixdepth, pp);
+    gp_bwd_pixprep_body<GP_BWD_ROWS, GP_BWD_COLS>(d, bg, out_color, out_depth, final_T, n_contrib, dL_dpix, dL_dpixdepth, pp);
 }
 
 __device__ int g_abl = 0;
 extern "C" void gp_set_abl(int v) { hipMemcpyToSymbol(HIP_SYMBOL(g_abl), &v, sizeof(int)); }
-template <bool HAS_DEPTH, int ROWS>
+template <bool HAS_DEPTH, int ROWS, int COLS>
 __device__ __forceinline__ void gp_composite_bwd5_body(RasterDims d, const int2* __restrict__ ranges,
                                                        const uint32_t* __restrict__ point_list, const float4* __restrict__ rec,
                                                        const GpPixPair* __restrict__ pp, float* __restrict__ g_mean2D,
@@ -1040,12 +1065,14 @@ __device__ __forceinline__ void gp_composite_bwd5_body(RasterDims d, const int2*
                                                        float* __restrict__ g_color, float* __restrict__ g_depth,
                                                        const uint32_t* __restrict__ order) {
     const int abl = g_abl;
-    constexpr int PAIRS = ROWS * GP_TILE / 2;
-    static_assert(PAIRS == 64, "one lane per pixel pair in the prologue");
-    __shared__ float4 s_cy[PAIRS];   // Lin0 Lin1 rem0 rem1     (carried between batches)
-    __shared__ float4 s_fl[64][3];
-    __shared__ uint32_t s_flid[64];
-    const int parts = GP_TILE / ROWS;
+    constexpr int PAIRS = ROWS * COLS / 2;
+    static_assert(PAIRS <= 64, "one lane per pixel pair in the prologue");
+    __shared__ float4 s_cy[PAIRS];   // Tin0 Tin1 rem0 rem1     (carried between batches)
+    __shared__ float4 s_v0[PAIRS];   // dLr0 dLr1 dLg0 dLg1
+    __shared__ float4 s_v1[PAIRS];   // dLb0 dLb1 tb0  tb1      (tb = T_final * bg . dL_dpix)
+    __shared__ int2 s_nc[PAIRS];
+    __shared__ float2 s_dd[HAS_DEPTH ? PAIRS : 1];   // dLd0 dLd1
+    constexpr int parts_x = GP_TILE / COLS, parts = (GP_TILE / ROWS) * parts_x;
     const int part = blockIdx.x % parts;
     const int tile = __builtin_amdgcn_readfirstlane(order ? (int)order[blockIdx.x / parts] : (int)(blockIdx.x / parts));
     const int tx = tile % d.gx, ty = tile / d.gx;
@@ -1054,23 +1081,30 @@ __device__ __forceinline__ void gp_composite_bwd5_body(RasterDims d, const int2*
     const GpPixPair* __restrict__ mypp = pp + ((size_t)tile * parts + part) * PAIRS;   // uniform base
     int max_nc;
     {
-        const float4 t = ((const float4*)&mypp[lane])[2];
-        s_cy[lane] = make_float4(0.f, 0.f, t.z, t.w);
-        max_nc = max(__float_as_int(t.x), __float_as_int(t.y));
+        max_nc = 0;
+        if (lane < PAIRS) {
+            const float4* me = (const float4*)&mypp[lane];
+            const float4 t0 = me[0], t1 = me[1], t = me[2];
+            s_v0[lane] = t0; s_v1[lane] = t1;
+            s_nc[lane] = make_int2(__float_as_int(t.x), __float_as_int(t.y));
+            if (HAS_DEPTH) { const float4 t3 = me[3]; s_dd[lane] = make_float2(t3.x, t3.y); }
+            s_cy[lane] = make_float4(1.f, 1.f, t.z, t.w);
+            max_nc = max(__float_as_int(t.x), __float_as_int(t.y));
+        }
     }
 #pragma unroll
     for (int dd = 32; dd >= 1; dd >>= 1) max_nc = max(max_nc, __shfl_xor(max_nc, dd));
     __builtin_amdgcn_wave_barrier();
     const float halfW = 0.5f * (float)d.W, halfH = 0.5f * (float)d.H;
     const int count = min(range.y - range.x, max_nc);
-    const float px_base = (float)(tx * GP_TILE), py_base = (float)(ty * GP_TILE + part * ROWS);
+    const float px_base = (float)(tx * GP_TILE + (part % parts_x) * COLS), py_base = (float)(ty * GP_TILE + (part / parts_x) * ROWS);
     const float LOG2E = 1.4426950408889634f;
     // ---- compaction: only splats whose alpha >= 1/255 footprint intersects THIS tile part enter a batch
     // (stable, so depth order is kept); candidates are fetched 64 at a time, one fetch ahead of the pixel walk.
     __shared__ float4 s_e0[128], s_e1[128], s_e2[128];
     __shared__ int s_epos[128];
     __shared__ uint32_t s_eid[128];
-    const float RX0 = px_base, RX1 = px_base + 15.f, RY0 = py_base, RY1 = py_base + (float)(ROWS - 1);
+    const float RX0 = px_base, RX1 = px_base + (float)(COLS - 1), RY0 = py_base, RY1 = py_base + (float)(ROWS - 1);
     int qn = 0, src = 0;
     uint32_t c_id = 0;
     float4 k0 = make_float4(0.f, 0.f, 0.f, 0.f), k1 = k0, k2 = k0;
@@ -1118,97 +1152,109 @@ __device__ __forceinline__ void gp_composite_bwd5_body(RasterDims d, const int2*
         const float op = have ? q1.y : 0.f, zdep = q1.z;
         const float cxx = -2.f * q0.z, cxy = -q0.w, cyy = -2.f * q1.x;
         const v2f cr = {q2.x, q2.x}, cg = {q2.y, q2.y}, cb = {q2.z, q2.z};
-        v2f a_mx = {0.f, 0.f}, a_my = {0.f, 0.f}, a_ca = {0.f, 0.f}, a_cb = {0.f, 0.f}, a_cc = {0.f, 0.f}, a_op = {0.f, 0.f},
-            a_r = {0.f, 0.f}, a_g = {0.f, 0.f}, a_b = {0.f, 0.f}, a_d = {0.f, 0.f};
+        // h := dL/dG * G per (splat, pixel).  The geometric gradients are moments of h:
+        //   S_x = sum h dx, S_y = sum h dy, S_xx = sum h dx^2, S_xy = sum h dx dy, S_yy = sum h dy^2
+        // dy is constant along a row, so only sum h, sum h dx and S_xx are accumulated per step; the row totals
+        // are folded in at the end of each row.
+        v2f a_op = {0.f, 0.f}, a_r = {0.f, 0.f}, a_g = {0.f, 0.f}, a_b = {0.f, 0.f}, a_d = {0.f, 0.f}, s_xx = {0.f, 0.f};
+        float S_x = 0.f, S_y = 0.f, S_xy = 0.f, S_yy = 0.f;
         float any_m = 0.f;
-        // scalar-cache prefetch, one pixel pair ahead
-        const float4* __restrict__ ppq = (const float4*)mypp;
-        float4 n0 = ppq[0], n1 = ppq[1], n2 = ppq[2], n3 = HAS_DEPTH ? ppq[3] : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll 1
         for (int row = 0; row < ((abl & 32) ? 0 : ROWS); ++row) {
             const float dy = sy - (float)row;
             const float tB = Bs * dy, uC = (Cs * dy) * dy;
+            v2f r_h = {0.f, 0.f}, r_hx = {0.f, 0.f};
 #pragma unroll 1
-            for (int cp = 0; cp < GP_TILE / 2; ++cp) {
-                const int pr = row * (GP_TILE / 2) + cp;
-                const float4 v0 = n0, v1 = n1, v2 = n2, v3 = n3;
-                {
-                    const int nx = min(pr + 1, PAIRS - 1) * 4;
-                    n0 = ppq[nx]; n1 = ppq[nx + 1]; n2 = ppq[nx + 2];
-                    if (HAS_DEPTH) n3 = ppq[nx + 3];
-                }
-                const int ncx = __float_as_int(v2.x), ncy = __float_as_int(v2.y);
-                if (max(ncx, ncy) > b0) {   // uniform: otherwise both pixels finished before this batch
-                    const float4 cy = s_cy[pr];
-                    const float dx0 = sx - (float)(2 * cp);
-                    const v2f dx = {dx0, dx0 - 1.f};
-                    const v2f pw = {fmaf(dx.x, fmaf(As, dx.x, tB), uC), fmaf(dx.y, fmaf(As, dx.y, tB), uC)};
-                    const v2f G = {__builtin_amdgcn_exp2f(fminf(pw.x, 0.f)), __builtin_amdgcn_exp2f(fminf(pw.y, 0.f))};
-                    const v2f alpha = {fminf(0.99f, op * G.x), fminf(0.99f, op * G.y)};
+            for (int cp = 0; cp < COLS / 2; ++cp) {
+                const int pr = row * (COLS / 2) + cp;
+                // all four broadcast reads are issued up front; the alpha math below covers their latency
+                const int2 nc = s_nc[pr];
+                const float4 v0 = s_v0[pr], v1 = s_v1[pr], cy = s_cy[pr];
+                float2 v3 = make_float2(0.f, 0.f);
+                if (HAS_DEPTH) v3 = s_dd[pr];
+                const float dx0 = sx - (float)(2 * cp);
+                const v2f dx = {dx0, dx0 - 1.f};
+                const v2f pw = {fmaf(dx.x, fmaf(As, dx.x, tB), uC), fmaf(dx.y, fmaf(As, dx.y, tB), uC)};
+                const v2f G = {__builtin_amdgcn_exp2f(fminf(pw.x, 0.f)), __builtin_amdgcn_exp2f(fminf(pw.y, 0.f))};
+                const v2f alpha = {fminf(0.99f, op * G.x), fminf(0.99f, op * G.y)};
+                const int ncx = nc.x, ncy = nc.y;
+                if (max(ncx, ncy) > b0 && !(abl & 64)) {   // uniform: otherwise both pixels finished before this batch
                     const bool c0 = (pos < ncx) && !(pw.x > 0.f) && !(alpha.x < 1.f / 255.f);
                     const bool c1 = (pos < ncy) && !(pw.y > 0.f) && !(alpha.y < 1.f / 255.f);
-                    if (__any(c0 || c1)) {   // otherwise nobody in the wave touches either pixel
+                    if (__any(c0 || c1) && !(abl & 128)) {   // otherwise nobody in the wave touches either pixel
                         const v2f m = {c0 ? 1.f : 0.f, c1 ? 1.f : 0.f};
                         any_m = fmaxf(any_m, fmaxf(m.x, m.y));
                         const v2f am = alpha * m;
                         const v2f om = 1.f - am;
-                        float l0 = __builtin_amdgcn_logf(om.x), l1 = __builtin_amdgcn_logf(om.y);   // log2, exactly 0 for om == 1
                         v2f cdot = cb * (v2f){v1.x, v1.y};
                         cdot = cg * (v2f){v0.z, v0.w} + cdot;
                         cdot = cr * (v2f){v0.x, v0.y} + cdot;
                         v2f dLd = {0.f, 0.f};
                         if (HAS_DEPTH) { dLd.x = v3.x; dLd.y = v3.y; cdot = zdep * dLd + cdot; }
-                        // T_j needs the EXCLUSIVE log-sum, s_j = alpha_j T_j cdot needs T_j: scan the logs first
-                        float il0 = l0, il1 = l1;
-                        if (!(abl & 1)) dpp_scan2_add(il0, il1);
-                        const v2f Tj = {__builtin_amdgcn_exp2f(cy.x + il0 - l0), __builtin_amdgcn_exp2f(cy.y + il1 - l1)};
+                        // T_j = T_in * prod_{k<j} (1 - alpha_k): inclusive product scan, then divide the own factor out
+                        const v2f rom = {__builtin_amdgcn_rcpf(om.x), __builtin_amdgcn_rcpf(om.y)};
+                        float il0 = om.x, il1 = om.y;
+                        if (!(abl & 1)) dpp_scan2_mul(il0, il1);
+                        const v2f Tnext = (v2f){cy.x, cy.y} * (v2f){il0, il1};    // transmittance AFTER splat j
+                        const v2f Tj = Tnext * rom;
                         const v2f w = am * Tj;
                         const v2f sv = w * cdot;
                         float is0 = sv.x, is1 = sv.y;
                         if (!(abl & 2)) dpp_scan2_add(is0, is1);
                         const v2f rem = {cy.z, cy.w};
                         const v2f tbv = {v1.z, v1.w};
-                        const v2f rom = {__builtin_amdgcn_rcpf(om.x), __builtin_amdgcn_rcpf(om.y)};
                         const v2f suffix = rem - (v2f){is0, is1};
                         const v2f dL_dalpha = (Tj * cdot - (suffix + tbv) * rom) * m;
                         if (!(abl & 8)) {
                         a_r += w * (v2f){v0.x, v0.y}; a_g += w * (v2f){v0.z, v0.w}; a_b += w * (v2f){v1.x, v1.y};
                         if (HAS_DEPTH) a_d += w * dLd;
-                        a_op += G * dL_dalpha;
-                        const v2f dL_dG = op * dL_dalpha;
-                        const v2f gdx = G * dx, gdy = G * dy;
-                        a_mx += dL_dG * (-gdx * cxx - gdy * cxy);
-                        a_my += dL_dG * (-gdy * cyy - gdx * cxy);
-                        a_ca += (gdx * dx) * dL_dG;
-                        a_cb += (gdx * dy) * dL_dG;
-                        a_cc += (gdy * dy) * dL_dG;
+                        const v2f gda = G * dL_dalpha;
+                        a_op += gda;
+                        const v2f h = op * gda;
+                        const v2f hx = h * dx;
+                        r_h += h;
+                        r_hx += hx;
+                        s_xx += hx * dx;
                         } else { a_r += dL_dalpha; }
                         // carry to the next batch
                         if (!(abl & 4)) {
-                        const float tl0 = lane63(il0), tl1 = lane63(il1), ts0 = lane63(is0), ts1 = lane63(is1);
-                        if (lane == 0) s_cy[pr] = make_float4(cy.x + tl0, cy.y + tl1, cy.z - ts0, cy.w - ts1);
+                        if (lane == 63) s_cy[pr] = make_float4(Tnext.x, Tnext.y, cy.z - is0, cy.w - is1);
                         }
                     }
                 }
+            }
+            {   // fold the row:  sum h dy = dy sum h, sum h dx dy = dy sum h dx, sum h dy^2 = dy^2 sum h
+                const float rh = r_h.x + r_h.y, rhx = r_hx.x + r_hx.y;
+                S_x += rhx;
+                S_y = fmaf(dy, rh, S_y);
+                S_xy = fmaf(dy, rhx, S_xy);
+                S_yy = fmaf(dy * dy, rh, S_yy);
             }
         }
         // flush: transpose through LDS so that 16 consecutive lanes add to the 16 consecutive floats of ONE
         // Gaussian's accumulator line -- an atomic instruction then touches 4 cache lines instead of 64.
         if (!(abl & 16)) {
             const bool mine = have && any_m > 0.f;
-            s_fl[lane][0] = make_float4((a_mx.x + a_mx.y) * halfW, (a_my.x + a_my.y) * halfH, -0.5f * (a_ca.x + a_ca.y), -(a_cb.x + a_cb.y));
-            s_fl[lane][1] = make_float4(-0.5f * (a_cc.x + a_cc.y), a_op.x + a_op.y, a_r.x + a_r.y, a_g.x + a_g.y);
-            s_fl[lane][2] = make_float4(a_b.x + a_b.y, HAS_DEPTH ? a_d.x + a_d.y : 0.f, 0.f, 0.f);
-            s_flid[lane] = mine ? id : 0xffffffffu;
+            // staging: the upper halves of the queue arrays are free here (at most 63 entries are left after the pop)
+            float* fl = (float*)&s_e0[64];          // [64 splats][4]: comps 0..3
+            float* fm = (float*)&s_e1[64];          //                 comps 4..7
+            float* fh = (float*)&s_e2[64];          //                 comps 8..11
+            // dG/dmean = -G (conic d),  dG/d(conic) = -0.5 G (dx^2, 2 dx dy, dy^2)
+            const float S_xx = s_xx.x + s_xx.y;
+            const float g_mx = -(cxx * S_x + cxy * S_y), g_my = -(cyy * S_y + cxy * S_x);
+            ((float4*)fl)[lane] = make_float4(g_mx * halfW, g_my * halfH, -0.5f * S_xx, -S_xy);
+            ((float4*)fm)[lane] = make_float4(-0.5f * S_yy, a_op.x + a_op.y, a_r.x + a_r.y, a_g.x + a_g.y);
+            ((float4*)fh)[lane] = make_float4(a_b.x + a_b.y, HAS_DEPTH ? a_d.x + a_d.y : 0.f, 0.f, 0.f);
+            s_eid[64 + lane] = mine ? id : 0xffffffffu;
             __builtin_amdgcn_wave_barrier();
             const int comp = lane & 15, sub = lane >> 4;
-            const float* fl = (const float*)&s_fl[0][0];
+            const float* src_c = comp < 4 ? fl : (comp < 8 ? fm : fh);
             if (comp < (HAS_DEPTH ? 10 : 9)) {
 #pragma unroll 4
                 for (int r = 0; r < 16; ++r) {
                     const int sp = r * 4 + sub;
-                    const uint32_t gid = s_flid[sp];
-                    if (gid != 0xffffffffu) atomicAdd(&g_mean2D[GP_ACC_STRIDE * (size_t)gid + comp], fl[sp * 12 + comp]);
+                    const uint32_t gid = s_eid[64 + sp];
+                    if (gid != 0xffffffffu) atomicAdd(&g_mean2D[GP_ACC_STRIDE * (size_t)gid + comp], src_c[sp * 4 + (comp & 3)]);
                 }
             }
         }
@@ -1220,10 +1266,10 @@ __device__ __forceinline__ void gp_composite_bwd5_body(RasterDims d, const int2*
     float* __restrict__ g_conic, float* __restrict__ g_opacity, float* __restrict__ g_color, float* __restrict__ g_depth, \
     const uint32_t* __restrict__ order
 __global__ __launch_bounds__(64) void gp_composite_bwd5_kernel(CB5_ARGS) {
-    gp_composite_bwd5_body<false, 8>(d, ranges, point_list, rec, pp, g_mean2D, g_conic, g_opacity, g_color, g_depth, order);
+    gp_composite_bwd5_body<false, GP_BWD_ROWS, GP_BWD_COLS>(d, ranges, point_list, rec, pp, g_mean2D, g_conic, g_opacity, g_color, g_depth, order);
 }
 __global__ __launch_bounds__(64) void gp_composite_bwd5_depth_kernel(CB5_ARGS) {
-    gp_composite_bwd5_body<true, 8>(d, ranges, point_list, rec, pp, g_mean2D, g_conic, g_opacity, g_color, g_depth, order);
+    gp_composite_bwd5_body<true, GP_BWD_ROWS, GP_BWD_COLS>(d, ranges, point_list, rec, pp, g_mean2D, g_conic, g_opacity, g_color, g_depth, order);
 }
 
 // ------------------------------------------------------------------------------------------------
