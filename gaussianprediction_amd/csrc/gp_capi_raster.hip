@@ -153,10 +153,12 @@ extern "C" int gp_raster_forward(const gp_raster_settings* st, const gp_raster_i
             const int tbits = tile_bits_for((int)T);
             const int passes = (tbits + 7) / 8;
             const int res = passes & 1;  // buffer pair holding the sorted result
-            void* bin = alloc(alloc_ctx, GP_BUF_BINNING, gp_align_up((size_t)R * 4, 256));
+            // BINNING = point_list[R] (u32) followed by qmask[R] (u8: which 8x8 quadrants of its tile an instance can touch)
+            const size_t bin_bytes = gp_align_up((size_t)R * 4, 256) + gp_align_up((size_t)R + 4, 256);
+            void* bin = alloc(alloc_ctx, GP_BUF_BINNING, bin_bytes);
             if (!bin) GP_FAIL("allocator returned NULL for BINNING");
             point_list = (uint32_t*)bin;
-            saved->binning = bin; saved->binning_bytes = gp_align_up((size_t)R * 4, 256);
+            saved->binning = bin; saved->binning_bytes = bin_bytes;
             const size_t bh = gp_sort_hist_elems(R), bs = gp_scan_tmp_elems(256 * (((size_t)R + 4095) / 4096));
             auto carve_bin = [&](GpCarver& c, uint32_t*& bk0, uint32_t*& bk1, uint32_t*& bvo, uint32_t*& bhist, uint32_t*& bscan) {
                 bk0 = c.take<uint32_t>(R); bk1 = c.take<uint32_t>(R); bvo = c.take<uint32_t>(R);
@@ -190,8 +192,9 @@ extern "C" int gp_raster_forward(const gp_raster_settings* st, const gp_raster_i
     hipLaunchKernelGGL(gp_tile_order_kernel, dim3(1), dim3(1024), 0, s, il.ranges, (const int32_t*)nullptr, (int)T, il.order);
     GP_LAUNCH_CHECK();
     { GpProfScope _p("composite_fwd", s, 1);
-        hipLaunchKernelGGL(gp_composite_fwd_kernel, dim3((unsigned)T), dim3(128), 0, s, d, il.ranges, point_list, gl.rec, st->bg,
-                       out->color, out->depth, out->tidx, il.final_T, il.n_contrib, il.order, il.tile_work);
+        hipLaunchKernelGGL(gp_composite_fwd_kernel, dim3((unsigned)T), dim3(256), 0, s, d, il.ranges, point_list, gl.rec, st->bg,
+                       out->color, out->depth, out->tidx, il.final_T, il.n_contrib, il.order, il.tile_work,
+                       point_list ? (uint8_t*)point_list + gp_align_up((size_t)R * 4, 256) : (uint8_t*)nullptr);
     GP_LAUNCH_CHECK(); }
     return 0;
 }
@@ -245,8 +248,8 @@ extern "C" int gp_raster_backward(const gp_raster_settings* st, const gp_raster_
             }
             GpProfScope _p("composite_bwd", s);
             hipLaunchKernelGGL(dL_ddepth ? gp_composite_bwd5_depth_kernel : gp_composite_bwd5_kernel, dim3((unsigned)T * GP_BWD_PARTS),
-                               dim3(64), 0, s, d, il.ranges, point_list, gl.rec, (const GpPixPair*)pp, g_mean2D, g_conic, g_opacity,
-                               g_color, g_depth, order_bwd);
+                               dim3(64), 0, s, d, il.ranges, point_list, (const uint8_t*)point_list + gp_align_up((size_t)R * 4, 256), gl.rec,
+                               (const GpPixPair*)pp, g_mean2D, g_conic, g_opacity, g_color, g_depth, order_bwd);
             GP_LAUNCH_CHECK();
         } else { GpProfScope _p("composite_bwd", s);
         hipLaunchKernelGGL(kern, dim3((unsigned)T * parts), dim3(64), 0, s, d, il.ranges, point_list,

@@ -43,7 +43,7 @@ __global__ __launch_bounds__(256) void gp_tile_ranges_kernel(const uint32_t* __r
                                                             int2* __restrict__ ranges);
 
 __global__ __launch_bounds__(1024) void gp_tile_order_kernel(const int2* __restrict__ ranges, const int32_t* __restrict__ work_hint, int T, uint32_t* __restrict__ order);
-__global__ __launch_bounds__(128) void gp_composite_fwd_kernel(RasterDims d, const int2* __restrict__ ranges,
+__global__ __launch_bounds__(256) void gp_composite_fwd_kernel(RasterDims d, const int2* __restrict__ ranges,
                                                                       const uint32_t* __restrict__ point_list,
                                                                       const float4* __restrict__ rec,
                                                                       const float* __restrict__ bg,
@@ -51,7 +51,7 @@ __global__ __launch_bounds__(128) void gp_composite_fwd_kernel(RasterDims d, con
                                                                       float* __restrict__ out_depth,
                                                                       int32_t* __restrict__ out_tidx,
                                                                       float* __restrict__ final_T,
-                                                                      int32_t* __restrict__ n_contrib, const uint32_t* __restrict__ order, int32_t* __restrict__ tile_work);
+                                                                      int32_t* __restrict__ n_contrib, const uint32_t* __restrict__ order, int32_t* __restrict__ tile_work, uint8_t* __restrict__ qmask);
 
 __global__ __launch_bounds__(64) void gp_composite_bwd3_kernel(RasterDims d, const int2* __restrict__ ranges, const uint32_t* __restrict__ point_list,      const float4* __restrict__ rec, const float* __restrict__ bg, const float* __restrict__ out_color,      const float* __restrict__ out_depth, const float* __restrict__ final_T, const int32_t* __restrict__ n_contrib,      const float* __restrict__ dL_dpix, const float* __restrict__ dL_dpixdepth, float* __restrict__ g_mean2D,      float* __restrict__ g_conic, float* __restrict__ g_opacity, float* __restrict__ g_color, float* __restrict__ g_depth, const uint32_t* __restrict__ order);
 __global__ __launch_bounds__(64) void gp_composite_bwd4_kernel(RasterDims d, const int2* __restrict__ ranges, const uint32_t* __restrict__ point_list,      const float4* __restrict__ rec, const float* __restrict__ bg, const float* __restrict__ out_color,      const float* __restrict__ out_depth, const float* __restrict__ final_T, const int32_t* __restrict__ n_contrib,      const float* __restrict__ dL_dpix, const float* __restrict__ dL_dpixdepth, float* __restrict__ g_mean2D,      float* __restrict__ g_conic, float* __restrict__ g_opacity, float* __restrict__ g_color, float* __restrict__ g_depth, const uint32_t* __restrict__ order);
@@ -71,8 +71,8 @@ __global__ __launch_bounds__(256) void gp_bwd_pixprep_kernel(RasterDims d, const
                                                              const int32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpix,
                                                              const float* __restrict__ dL_dpixdepth, GpPixPair* __restrict__ pp);
 __global__ __launch_bounds__(64) void gp_composite_bwd5_kernel(RasterDims d, const int2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
-    const float4* __restrict__ rec, const GpPixPair* __restrict__ pp, float* __restrict__ g_mean2D, float* __restrict__ g_conic,
+    const uint8_t* __restrict__ qmask, const float4* __restrict__ rec, const GpPixPair* __restrict__ pp, float* __restrict__ g_mean2D, float* __restrict__ g_conic,
     float* __restrict__ g_opacity, float* __restrict__ g_color, float* __restrict__ g_depth, const uint32_t* __restrict__ order);
 __global__ __launch_bounds__(64) void gp_composite_bwd5_depth_kernel(RasterDims d, const int2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
-    const float4* __restrict__ rec, const GpPixPair* __restrict__ pp, float* __restrict__ g_mean2D, float* __restrict__ g_conic,
+    const uint8_t* __restrict__ qmask, const float4* __restrict__ rec, const GpPixPair* __restrict__ pp, float* __restrict__ g_mean2D, float* __restrict__ g_conic,
     float* __restrict__ g_opacity, float* __restrict__ g_color, float* __restrict__ g_depth, const uint32_t* __restrict__ order);

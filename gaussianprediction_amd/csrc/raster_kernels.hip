@@ -407,47 +407,58 @@ __global__ __launch_bounds__(1024) void gp_tile_order_kernel(const int2* __restr
 // First the bounding box of that ellipse, then the exact minimum of the convex q over the rectangle (it lies on
 // an edge when the centre is outside).  Conservative: slack on two_tau and on the box, so a culled splat has
 // no contributing pixel in the rectangle.
+struct GpFootprint {
+    float mx, my, cx, cy, cz, two_tau, ex, ey, rx, ry;
+    int state;   // 0: never contributes, 1: degenerate conic (do not cull), 2: regular
+    __device__ __forceinline__ GpFootprint(const float4 q0, const float4 q1) {
+        mx = q0.x; my = q0.y;
+        cx = -2.f * q0.z; cy = -q0.w; cz = -2.f * q1.x;
+        const float detc = cx * cz - cy * cy;
+        const float tau = __logf(255.f * q1.y);
+        two_tau = 2.f * tau * 1.004f;
+        state = !(tau > 0.f) ? 0 : (!(detc > 0.f) ? 1 : 2);
+        const float e2 = two_tau / detc;
+        ex = sqrtf(e2 * cz) + 0.01f; ey = sqrtf(e2 * cx) + 0.01f;
+        ry = -cy / cz; rx = -cy / cx;                      // argmin of q along a vertical / horizontal line
+    }
+    __device__ __forceinline__ bool hits(float X0, float X1, float Y0, float Y1) const {
+        if (state < 2) return state == 1;
+        const float dx0 = X0 - mx, dx1 = X1 - mx, dy0 = Y0 - my, dy1 = Y1 - my;
+        if (!(dx0 <= ex && dx1 >= -ex && dy0 <= ey && dy1 >= -ey)) return false;
+        if (dx0 <= 0.f && dx1 >= 0.f && dy0 <= 0.f && dy1 >= 0.f) return true;   // centre inside
+        float qmin;
+        {
+            const float dy = fminf(fmaxf(ry * dx0, dy0), dy1);
+            qmin = cx * dx0 * dx0 + (2.f * cy * dx0 + cz * dy) * dy;
+        }
+        {
+            const float dy = fminf(fmaxf(ry * dx1, dy0), dy1);
+            qmin = fminf(qmin, cx * dx1 * dx1 + (2.f * cy * dx1 + cz * dy) * dy);
+        }
+        {
+            const float dx = fminf(fmaxf(rx * dy0, dx0), dx1);
+            qmin = fminf(qmin, cz * dy0 * dy0 + (2.f * cy * dy0 + cx * dx) * dx);
+        }
+        {
+            const float dx = fminf(fmaxf(rx * dy1, dx0), dx1);
+            qmin = fminf(qmin, cz * dy1 * dy1 + (2.f * cy * dy1 + cx * dx) * dx);
+        }
+        return qmin <= two_tau + 0.02f;
+    }
+};
 __device__ __forceinline__ bool gp_splat_hits_rect(const float4 q0, const float4 q1, float X0, float X1, float Y0, float Y1) {
-    const float cx = -2.f * q0.z, cy = -q0.w, cz = -2.f * q1.x;
-    const float detc = cx * cz - cy * cy;
-    const float tau = __logf(255.f * q1.y);
-    if (!(tau > 0.f)) return false;
-    if (!(detc > 0.f)) return true;                       // degenerate conic: do not cull
-    const float two_tau = 2.f * tau * 1.004f;
-    const float e2 = two_tau / detc;
-    const float ex = sqrtf(e2 * cz) + 0.01f, ey = sqrtf(e2 * cx) + 0.01f;
-    const float dx0 = X0 - q0.x, dx1 = X1 - q0.x, dy0 = Y0 - q0.y, dy1 = Y1 - q0.y;
-    if (!(dx0 <= ex && dx1 >= -ex && dy0 <= ey && dy1 >= -ey)) return false;
-    if (dx0 <= 0.f && dx1 >= 0.f && dy0 <= 0.f && dy1 >= 0.f) return true;   // centre inside
-    const float ry = -cy / cz, rx = -cy / cx;             // argmin of q along a vertical / horizontal line
-    float qmin;
-    {
-        const float dy = fminf(fmaxf(ry * dx0, dy0), dy1);
-        qmin = cx * dx0 * dx0 + (2.f * cy * dx0 + cz * dy) * dy;
-    }
-    {
-        const float dy = fminf(fmaxf(ry * dx1, dy0), dy1);
-        qmin = fminf(qmin, cx * dx1 * dx1 + (2.f * cy * dx1 + cz * dy) * dy);
-    }
-    {
-        const float dx = fminf(fmaxf(rx * dy0, dx0), dx1);
-        qmin = fminf(qmin, cz * dy0 * dy0 + (2.f * cy * dy0 + cx * dx) * dx);
-    }
-    {
-        const float dx = fminf(fmaxf(rx * dy1, dx0), dx1);
-        qmin = fminf(qmin, cz * dy1 * dy1 + (2.f * cy * dy1 + cx * dx) * dx);
-    }
-    return qmin <= two_tau + 0.02f;
+    return GpFootprint(q0, q1).hits(X0, X1, Y0, Y1);
 }
 
 // ------------------------------------------------------------------------------------------------
-// composite forward.  One 128-thread workgroup (2 waves) per 16x16 tile.  Wave w owns rows
-// [8w, 8w+8); lane l owns column (l & 15) and the two rows 2*(l >> 4) + {0,1} of that half.
-// Splat records (48 B) are gathered once per tile into LDS in batches of 128; each staging lane also
-// decides, with a conservative alpha >= 1/255 bounding box, whether its splat can touch half-tile 0/1;
-// the ballots of those decisions let each consumer wave walk only the splats that matter to it.
+// composite forward.  One 256-thread workgroup (4 waves) per 16x16 tile; wave w owns the 8x8 quadrant
+// (w & 1, w >> 1), one pixel per lane.  Splat records (48 B) are gathered once per tile into LDS in batches
+// of 256; each staging lane also decides -- exactly, ellipse against rectangle -- which of the four quadrants
+// its splat's alpha >= 1/255 footprint can touch.  The ballots of those decisions let each consumer wave walk
+// only the splats that matter to it, and the 4-bit masks are saved per tile-splat instance (qmask) so that
+// the backward never repeats the test or fetches records it does not need.
 // ------------------------------------------------------------------------------------------------
-#define CF_THREADS 128
+#define CF_THREADS 256
 typedef float v2f __attribute__((ext_vector_type(2)));
 typedef int v2i __attribute__((ext_vector_type(2)));
 
@@ -486,52 +497,51 @@ __global__ __launch_bounds__(CF_THREADS) void gp_composite_fwd_kernel(RasterDims
                                                                       float* __restrict__ final_T,
                                                                       int32_t* __restrict__ n_contrib,
                                                                       const uint32_t* __restrict__ order,
-                                                                      int32_t* __restrict__ tile_work) {
+                                                                      int32_t* __restrict__ tile_work,
+                                                                      uint8_t* __restrict__ qmask) {
     __shared__ float4 s_q0[CF_THREADS], s_q1[CF_THREADS], s_q2[CF_THREADS];
-    __shared__ unsigned long long s_mask[2][2];
-    __shared__ int s_done[2];
-    __shared__ int s_last[2];
+    __shared__ unsigned long long s_mask[4][4];   // [quadrant][staging wave]
+    __shared__ int s_done[4];
+    __shared__ int s_last[4];
     const int tile = order ? (int)order[blockIdx.x] : (int)blockIdx.x;
     const int tx = tile % d.gx, ty = tile / d.gx;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int px = tx * GP_TILE + (lane & 15);
-    const int py0 = ty * GP_TILE + wave * 8 + 2 * (lane >> 4);
-    const int py1 = py0 + 1;
-    const float pxf = (float)px, py0f = (float)py0, py1f = (float)py1;
+    const int px = tx * GP_TILE + (wave & 1) * 8 + (lane & 7);
+    const int py = ty * GP_TILE + (wave >> 1) * 8 + (lane >> 3);
+    const float pxf = (float)px, pyf = (float)py;
     const int2 range = ranges[tile];
-    PixAcc a0, a1;
-    a0.T = a1.T = 1.f;
-    a0.C0 = a0.C1 = a0.C2 = a0.Dp = a0.best = 0.f;
-    a1.C0 = a1.C1 = a1.C2 = a1.Dp = a1.best = 0.f;
-    a0.best_id = a1.best_id = -1;
-    a0.last = a1.last = 0;
-    const bool in0 = px < d.W && py0 < d.H, in1 = px < d.W && py1 < d.H;
-    a0.done = !in0;
-    a1.done = !in1;
+    PixAcc a;
+    a.T = 1.f;
+    a.C0 = a.C1 = a.C2 = a.Dp = a.best = 0.f;
+    a.best_id = -1;
+    a.last = 0;
+    const bool inside = px < d.W && py < d.H;
+    a.done = !inside;
     bool wave_done = false;
-    if (tid < 2) s_done[tid] = 0;
-    // half-tile pixel-centre rectangles for culling
-    const float X0 = (float)(tx * GP_TILE), X1 = X0 + 15.f;
-    const float Y0a = (float)(ty * GP_TILE), Y1a = Y0a + 7.f, Y0b = Y0a + 8.f, Y1b = Y0a + 15.f;
+    if (tid < 4) s_done[tid] = 0;
+    // quadrant pixel-centre rectangles for culling
+    const float X0 = (float)(tx * GP_TILE), Y0 = (float)(ty * GP_TILE);
 
     for (int base = range.x; base < range.y; base += CF_THREADS) {
         __syncthreads();
-        if (s_done[0] && s_done[1]) break;
+        if (s_done[0] && s_done[1] && s_done[2] && s_done[3]) break;
         const int k = base + tid;
-        bool rel0 = false, rel1 = false;
+        unsigned rel = 0;
         if (k < range.y) {
             const uint32_t id = point_list[k];
             const float4 q0 = rec[3 * (size_t)id], q1 = rec[3 * (size_t)id + 1], q2 = rec[3 * (size_t)id + 2];
             s_q0[tid] = q0; s_q1[tid] = q1; s_q2[tid] = q2;
-            rel0 = gp_splat_hits_rect(q0, q1, X0, X1, Y0a, Y1a);
-            rel1 = gp_splat_hits_rect(q0, q1, X0, X1, Y0b, Y1b);
+            const GpFootprint f(q0, q1);
+            rel = (f.hits(X0, X0 + 7.f, Y0, Y0 + 7.f) ? 1u : 0u) | (f.hits(X0 + 8.f, X0 + 15.f, Y0, Y0 + 7.f) ? 2u : 0u) |
+                  (f.hits(X0, X0 + 7.f, Y0 + 8.f, Y0 + 15.f) ? 4u : 0u) | (f.hits(X0 + 8.f, X0 + 15.f, Y0 + 8.f, Y0 + 15.f) ? 8u : 0u);
+            qmask[k] = (uint8_t)rel;
         }
-        const unsigned long long m0 = __ballot(rel0), m1 = __ballot(rel1);
-        if (lane == 0) { s_mask[0][wave] = m0; s_mask[1][wave] = m1; }
+        const unsigned long long m0 = __ballot(rel & 1u), m1 = __ballot(rel & 2u), m2 = __ballot(rel & 4u), m3 = __ballot(rel & 8u);
+        if (lane == 0) { s_mask[0][wave] = m0; s_mask[1][wave] = m1; s_mask[2][wave] = m2; s_mask[3][wave] = m3; }
         __syncthreads();
         if (!wave_done) {
 #pragma unroll 1
-            for (int sw = 0; sw < 2 && !wave_done; ++sw) {
+            for (int sw = 0; sw < 4 && !wave_done; ++sw) {
                 unsigned long long mask = gp_readfirstlane64(s_mask[wave][sw]);
                 while (mask) {
                     const int j = __builtin_ctzll(mask);
@@ -539,42 +549,31 @@ __global__ __launch_bounds__(CF_THREADS) void gp_composite_fwd_kernel(RasterDims
                     const int slot = sw * 64 + j;
                     const float4 q0 = s_q0[slot], q1 = s_q1[slot], q2 = s_q2[slot];
                     const int contributor = base - range.x + slot + 1;
-                    blend_px(a0, pxf, py0f, q0, q1, q2, contributor);
-                    blend_px(a1, pxf, py1f, q0, q1, q2, contributor);
-                    if (__all(a0.done && a1.done)) { wave_done = true; break; }
+                    blend_px(a, pxf, pyf, q0, q1, q2, contributor);
+                    if (__all(a.done)) { wave_done = true; break; }
                 }
             }
             if (wave_done && lane == 0) s_done[wave] = 1;
         }
     }
     const size_t HW = (size_t)d.H * d.W;
-    if (in0) {
-        const size_t pix = (size_t)py0 * d.W + px;
-        out_color[pix] = fmaf(a0.T, bg[0], a0.C0);
-        out_color[HW + pix] = fmaf(a0.T, bg[1], a0.C1);
-        out_color[2 * HW + pix] = fmaf(a0.T, bg[2], a0.C2);
-        out_depth[pix] = a0.Dp;
-        out_tidx[pix] = a0.best_id;
-        final_T[pix] = a0.T;
-        n_contrib[pix] = a0.last;
-    }
-    if (in1) {
-        const size_t pix = (size_t)py1 * d.W + px;
-        out_color[pix] = fmaf(a1.T, bg[0], a1.C0);
-        out_color[HW + pix] = fmaf(a1.T, bg[1], a1.C1);
-        out_color[2 * HW + pix] = fmaf(a1.T, bg[2], a1.C2);
-        out_depth[pix] = a1.Dp;
-        out_tidx[pix] = a1.best_id;
-        final_T[pix] = a1.T;
-        n_contrib[pix] = a1.last;
+    if (inside) {
+        const size_t pix = (size_t)py * d.W + px;
+        out_color[pix] = fmaf(a.T, bg[0], a.C0);
+        out_color[HW + pix] = fmaf(a.T, bg[1], a.C1);
+        out_color[2 * HW + pix] = fmaf(a.T, bg[2], a.C2);
+        out_depth[pix] = a.Dp;
+        out_tidx[pix] = a.best_id;
+        final_T[pix] = a.T;
+        n_contrib[pix] = a.last;
     }
     if (tile_work) {   // largest list position any pixel of the tile consumed: the backward's work estimate
-        int mx = max(in0 ? a0.last : 0, in1 ? a1.last : 0);
+        int mx = inside ? a.last : 0;
 #pragma unroll
         for (int dd = 32; dd >= 1; dd >>= 1) mx = max(mx, __shfl_xor(mx, dd));
         if (lane == 0) s_last[wave] = mx;
         __syncthreads();
-        if (tid == 0) tile_work[tile] = max(s_last[0], s_last[1]);
+        if (tid == 0) tile_work[tile] = max(max(s_last[0], s_last[1]), max(s_last[2], s_last[3]));
     }
 }
 
@@ -1059,8 +1058,8 @@ __device__ int g_abl = 0;
 extern "C" void gp_set_abl(int v) { hipMemcpyToSymbol(HIP_SYMBOL(g_abl), &v, sizeof(int)); }
 template <bool HAS_DEPTH, int ROWS, int COLS>
 __device__ __forceinline__ void gp_composite_bwd5_body(RasterDims d, const int2* __restrict__ ranges,
-                                                       const uint32_t* __restrict__ point_list, const float4* __restrict__ rec,
-                                                       const GpPixPair* __restrict__ pp, float* __restrict__ g_mean2D,
+                                                       const uint32_t* __restrict__ point_list, const uint8_t* __restrict__ qmask,
+                                                       const float4* __restrict__ rec, const GpPixPair* __restrict__ pp, float* __restrict__ g_mean2D,
                                                        float* __restrict__ g_conic, float* __restrict__ g_opacity,
                                                        float* __restrict__ g_color, float* __restrict__ g_depth,
                                                        const uint32_t* __restrict__ order) {
@@ -1099,53 +1098,69 @@ __device__ __forceinline__ void gp_composite_bwd5_body(RasterDims d, const int2*
     const int count = min(range.y - range.x, max_nc);
     const float px_base = (float)(tx * GP_TILE + (part % parts_x) * COLS), py_base = (float)(ty * GP_TILE + (part / parts_x) * ROWS);
     const float LOG2E = 1.4426950408889634f;
-    // ---- compaction: only splats whose alpha >= 1/255 footprint intersects THIS tile part enter a batch
-    // (stable, so depth order is kept); candidates are fetched 64 at a time, one fetch ahead of the pixel walk.
-    __shared__ float4 s_e0[128], s_e1[128], s_e2[128];
-    __shared__ int s_epos[128];
-    __shared__ uint32_t s_eid[128];
-    const float RX0 = px_base, RX1 = px_base + (float)(COLS - 1), RY0 = py_base, RY1 = py_base + (float)(ROWS - 1);
+    // ---- compaction.  The forward saved, per tile-splat instance, which quadrants its footprint touches
+    // (qmask): a refill reads 256 mask bytes + ids with two coalesced loads, keeps the instances of THIS part
+    // (stable, so depth order is kept) and appends (list position, id) to a queue.  Records are gathered only
+    // for queued instances, one batch ahead of the pixel walk.
+    static_assert(ROWS == 8 && COLS == 8, "qmask bits are 8x8 quadrants");
+    constexpr int QCAP = 448;
+    __shared__ int2 s_q[QCAP];            // (list position, gaussian id)
+    __shared__ float4 s_fl[3][64];        // flush staging
+    __shared__ uint32_t s_flid[64];
     int qn = 0, src = 0;
-    uint32_t c_id = 0;
-    float4 k0 = make_float4(0.f, 0.f, 0.f, 0.f), k1 = k0, k2 = k0;
-    bool c_have = lane < count;
-    if (c_have) {
-        c_id = point_list[range.x + lane];
-        k0 = rec[3 * (size_t)c_id]; k1 = rec[3 * (size_t)c_id + 1]; k2 = rec[3 * (size_t)c_id + 2];
-    }
-    bool pending = count > 0;
-    while (true) {
-        while (qn < 64 && pending) {
-            bool relevant = false;
-            if (c_have) relevant = gp_splat_hits_rect(k0, k1, RX0, RX1, RY0, RY1);
-            const unsigned long long mk = __ballot(relevant);
-            const int slot = qn + (int)gp_mbcnt(mk);
-            if (relevant) { s_e0[slot] = k0; s_e1[slot] = k1; s_e2[slot] = k2; s_epos[slot] = src + lane; s_eid[slot] = c_id; }
-            qn += (int)__popcll(mk);
-            src += 64;
-            pending = src < count;
-            c_have = src + lane < count;
-            if (c_have) {
-                c_id = point_list[range.x + src + lane];
-                k0 = rec[3 * (size_t)c_id]; k1 = rec[3 * (size_t)c_id + 1]; k2 = rec[3 * (size_t)c_id + 2];
+    auto refill = [&]() {   // candidates src + 64 e + lane, e = 0..3: coalesced byte / dword loads
+        bool r[4];
+        uint32_t ids[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int k = src + 64 * e + lane;
+            r[e] = false; ids[e] = 0u;
+            if (k < count) {
+                r[e] = (qmask[range.x + k] >> part) & 1u;
+                ids[e] = point_list[range.x + k];
             }
         }
-        if (qn == 0) break;
-        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const unsigned long long bal = __ballot(r[e]);
+            if (r[e]) s_q[qn + (int)gp_mbcnt(bal)] = make_int2(src + 64 * e + lane, (int)ids[e]);
+            qn += (int)__popcll(bal);
+        }
+        src += 256;
+    };
+    while (qn < 128 && src < count) refill();
+    __builtin_amdgcn_wave_barrier();
+    // records of the first batch
+    float4 n0 = make_float4(0.f, 0.f, 0.f, 0.f), n1 = n0, n2 = n0;
+    int2 ne = make_int2(0x7fffffff, 0);
+    if (lane < qn) {
+        ne = s_q[lane];
+        n0 = rec[3 * (size_t)ne.y]; n1 = rec[3 * (size_t)ne.y + 1]; n2 = rec[3 * (size_t)ne.y + 2];
+    }
+    while (qn > 0) {
         const int nb = min(64, qn);
         const bool have = lane < nb;
-        const int b0 = __builtin_amdgcn_readfirstlane(s_epos[0]);   // smallest list position in this batch (uniform)
-        const int pos = have ? s_epos[lane] : 0x7fffffff;
-        const uint32_t id = have ? s_eid[lane] : 0u;
-        float4 q0 = make_float4(0.f, 0.f, 0.f, 0.f), q1 = q0, q2 = q0;
-        if (have) { q0 = s_e0[lane]; q1 = s_e1[lane]; q2 = s_e2[lane]; }
-        {   // pop the batch: entries [64, qn) move to the front
-            float4 m0 = q0, m1 = q1, m2 = q2; int mp = 0; uint32_t mi = 0;
-            const bool mv = lane + 64 < qn;
-            if (mv) { m0 = s_e0[lane + 64]; m1 = s_e1[lane + 64]; m2 = s_e2[lane + 64]; mp = s_epos[lane + 64]; mi = s_eid[lane + 64]; }
+        const int b0 = __builtin_amdgcn_readfirstlane(ne.x);        // smallest list position in this batch (uniform)
+        const int pos = have ? ne.x : 0x7fffffff;
+        const uint32_t id = (uint32_t)ne.y;
+        const float4 q0 = n0, q1 = n1, q2 = n2;
+        {   // pop the batch, top the queue up, and start fetching the next batch's records
+            int2 mv[6];
+#pragma unroll
+            for (int e = 0; e < 6; ++e) mv[e] = (64 + e * 64 + lane < qn) ? s_q[64 + e * 64 + lane] : make_int2(0, 0);
             __builtin_amdgcn_wave_barrier();
-            if (mv) { s_e0[lane] = m0; s_e1[lane] = m1; s_e2[lane] = m2; s_epos[lane] = mp; s_eid[lane] = mi; }
+#pragma unroll
+            for (int e = 0; e < 6; ++e) if (64 + e * 64 + lane < qn) s_q[e * 64 + lane] = mv[e];
             qn -= nb;
+            __builtin_amdgcn_wave_barrier();
+            while (qn < 128 && src < count) refill();
+            __builtin_amdgcn_wave_barrier();
+            n0 = make_float4(0.f, 0.f, 0.f, 0.f); n1 = n0; n2 = n0;
+            ne = make_int2(0x7fffffff, 0);
+            if (lane < qn) {
+                ne = s_q[lane];
+                n0 = rec[3 * (size_t)ne.y]; n1 = rec[3 * (size_t)ne.y + 1]; n2 = rec[3 * (size_t)ne.y + 2];
+            }
         }
         const float sx = q0.x - px_base, sy = q0.y - py_base;
         const float As = q0.z * LOG2E, Bs = q0.w * LOG2E, Cs = q1.x * LOG2E;   // power in log2 units
@@ -1235,17 +1250,16 @@ __device__ __forceinline__ void gp_composite_bwd5_body(RasterDims d, const int2*
         // Gaussian's accumulator line -- an atomic instruction then touches 4 cache lines instead of 64.
         if (!(abl & 16)) {
             const bool mine = have && any_m > 0.f;
-            // staging: the upper halves of the queue arrays are free here (at most 63 entries are left after the pop)
-            float* fl = (float*)&s_e0[64];          // [64 splats][4]: comps 0..3
-            float* fm = (float*)&s_e1[64];          //                 comps 4..7
-            float* fh = (float*)&s_e2[64];          //                 comps 8..11
+            float* fl = (float*)&s_fl[0][0];        // [64 splats][4]: comps 0..3
+            float* fm = (float*)&s_fl[1][0];        //                 comps 4..7
+            float* fh = (float*)&s_fl[2][0];        //                 comps 8..11
             // dG/dmean = -G (conic d),  dG/d(conic) = -0.5 G (dx^2, 2 dx dy, dy^2)
             const float S_xx = s_xx.x + s_xx.y;
             const float g_mx = -(cxx * S_x + cxy * S_y), g_my = -(cyy * S_y + cxy * S_x);
             ((float4*)fl)[lane] = make_float4(g_mx * halfW, g_my * halfH, -0.5f * S_xx, -S_xy);
             ((float4*)fm)[lane] = make_float4(-0.5f * S_yy, a_op.x + a_op.y, a_r.x + a_r.y, a_g.x + a_g.y);
             ((float4*)fh)[lane] = make_float4(a_b.x + a_b.y, HAS_DEPTH ? a_d.x + a_d.y : 0.f, 0.f, 0.f);
-            s_eid[64 + lane] = mine ? id : 0xffffffffu;
+            s_flid[lane] = mine ? id : 0xffffffffu;
             __builtin_amdgcn_wave_barrier();
             const int comp = lane & 15, sub = lane >> 4;
             const float* src_c = comp < 4 ? fl : (comp < 8 ? fm : fh);
@@ -1253,7 +1267,7 @@ __device__ __forceinline__ void gp_composite_bwd5_body(RasterDims d, const int2*
 #pragma unroll 4
                 for (int r = 0; r < 16; ++r) {
                     const int sp = r * 4 + sub;
-                    const uint32_t gid = s_eid[64 + sp];
+                    const uint32_t gid = s_flid[sp];
                     if (gid != 0xffffffffu) atomicAdd(&g_mean2D[GP_ACC_STRIDE * (size_t)gid + comp], src_c[sp * 4 + (comp & 3)]);
                 }
             }
@@ -1262,14 +1276,14 @@ __device__ __forceinline__ void gp_composite_bwd5_body(RasterDims d, const int2*
     }
 }
 #define CB5_ARGS RasterDims d, const int2* __restrict__ ranges, const uint32_t* __restrict__ point_list, \
-    const float4* __restrict__ rec, const GpPixPair* __restrict__ pp, float* __restrict__ g_mean2D, \
+    const uint8_t* __restrict__ qmask, const float4* __restrict__ rec, const GpPixPair* __restrict__ pp, float* __restrict__ g_mean2D, \
     float* __restrict__ g_conic, float* __restrict__ g_opacity, float* __restrict__ g_color, float* __restrict__ g_depth, \
     const uint32_t* __restrict__ order
 __global__ __launch_bounds__(64) void gp_composite_bwd5_kernel(CB5_ARGS) {
-    gp_composite_bwd5_body<false, GP_BWD_ROWS, GP_BWD_COLS>(d, ranges, point_list, rec, pp, g_mean2D, g_conic, g_opacity, g_color, g_depth, order);
+    gp_composite_bwd5_body<false, GP_BWD_ROWS, GP_BWD_COLS>(d, ranges, point_list, qmask, rec, pp, g_mean2D, g_conic, g_opacity, g_color, g_depth, order);
 }
 __global__ __launch_bounds__(64) void gp_composite_bwd5_depth_kernel(CB5_ARGS) {
-    gp_composite_bwd5_body<true, GP_BWD_ROWS, GP_BWD_COLS>(d, ranges, point_list, rec, pp, g_mean2D, g_conic, g_opacity, g_color, g_depth, order);
+    gp_composite_bwd5_body<true, GP_BWD_ROWS, GP_BWD_COLS>(d, ranges, point_list, qmask, rec, pp, g_mean2D, g_conic, g_opacity, g_color, g_depth, order);
 }
 
 // ------------------------------------------------------------------------------------------------
