@@ -413,101 +413,180 @@ __device__ __forceinline__ void normalize_bwd(const float* v, const float* g, fl
     for (int k = 0; k < 4; ++k) dv[k] = (g[k] - y[k] * dot) * inv;
 }
 
-// Keypoint gradients are first accumulated per workgroup in LDS ([K, 7]) and flushed with one
-// global atomic per (workgroup, keypoint, component): K is a few hundred, N is 10^6.
+// Keypoint gradients  dDelta[kp] = sum_i w_i,kp g_i  are a sparse-transpose product.  LDS float atomics run at
+// about one lane per clock, so instead of 7 atomics per (Gaussian, neighbour) each 256-Gaussian chunk is
+// COUNTING-SORTED by keypoint in LDS (integer atomics only, for the ranks) and every keypoint's owner thread sums
+// its own contiguous list into a plain LDS accumulator: no floating-point atomics, deterministic per workgroup.
+// The normalisation Jacobian of a keypoint's quaternion is linear in the incoming gradient, so it is applied once
+// per (workgroup, keypoint) after the sum.  Workgroup partials go to `partial`; gp_blend_bwd_reduce_kernel adds them.
+//
+// dynamic LDS: acc[K*7] | delta[K*od] | cnt[K] | base[K+1] | g[256*8] | w[256*2*nn] | sorted u16 [256*nn]
 template <int NN>
 __device__ __forceinline__ void blend_bwd_body(BlendDev a, const float* __restrict__ g_xyz_t,
                                                const float* __restrict__ g_q_t, float* __restrict__ g_delta,
                                                float* __restrict__ g_raw_w, float* __restrict__ g_xyz,
                                                float* __restrict__ g_rot, float* __restrict__ partial) {
-    extern __shared__ float s_acc[];  // [K*7] when nn > 0
+    extern __shared__ float s_dyn[];
     const int od = a.out_dim;
     const int nn = NN > 0 ? NN : a.nn;
-    const int KA = nn > 0 ? (int)a.K * 7 : 0;
-    for (int e = threadIdx.x; e < KA; e += 256) s_acc[e] = 0.f;
-    if (nn > 0) __syncthreads();
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < a.N; i += (long)gridDim.x * 256) {
-        const float gx[3] = {g_xyz_t[3 * i], g_xyz_t[3 * i + 1], g_xyz_t[3 * i + 2]};
-        const float gq[4] = {g_q_t[4 * i], g_q_t[4 * i + 1], g_q_t[4 * i + 2], g_q_t[4 * i + 3]};
-        g_xyz[3 * i] = gx[0]; g_xyz[3 * i + 1] = gx[1]; g_xyz[3 * i + 2] = gx[2];
-        // recompute forward
-        float wx[NN > 0 ? NN : GP_MAX_NN], wr[NN > 0 ? NN : GP_MAX_NN];
-        float dq[4] = {0.f, 0.f, 0.f, 0.f};
+    const int K = (int)a.K;
+    const int tid = threadIdx.x;
+    float* s_acc = s_dyn;                               // [K*7]
+    float* s_delta = s_acc + (nn > 0 ? K * 7 : 0);      // [K*od]
+    int* s_cnt = (int*)(s_delta + (nn > 0 ? K * od : 0));   // [K]
+    int* s_base = s_cnt + (nn > 0 ? K : 0);             // [K+1]
+    float* s_g = (float*)(s_base + (nn > 0 ? K + 1 : 0));   // [256][8]
+    float* s_w = s_g + 256 * 8;                         // [256][2*nn]
+    unsigned short* s_sorted = (unsigned short*)(s_w + 256 * 2 * nn);   // [256*nn]
+    __shared__ int s_wsum[4];
+    if (nn > 0) {
+        for (int e = tid; e < K * 7; e += 256) s_acc[e] = 0.f;
+        for (int e = tid; e < K * od; e += 256) s_delta[e] = a.delta[e];
+    }
+    const long chunks = (a.N + 255) / 256;
+    for (long c = blockIdx.x; c < chunks; c += gridDim.x) {
+        const long i = c * 256 + tid;
+        const bool live = i < a.N;
         if (nn > 0) {
-            softmax_n(a.raw_w + i * 2 * nn, nn, wx);
-            softmax_n(a.raw_w + i * 2 * nn + nn, nn, wr);
-#pragma unroll
-            for (int k = 0; k < nn; ++k) {
-                const float* dl = a.delta + (long)a.knn[i * nn + k] * od;
-                float v[4] = {dl[3], dl[4], dl[5], dl[6]};
-                if (a.norm_rotation) { const float inv = 1.f / norm4(v); v[0] *= inv; v[1] *= inv; v[2] *= inv; v[3] *= inv; }
-                dq[0] = fmaf(wr[k], v[0], dq[0]); dq[1] = fmaf(wr[k], v[1], dq[1]);
-                dq[2] = fmaf(wr[k], v[2], dq[2]); dq[3] = fmaf(wr[k], v[3], dq[3]);
-            }
-        } else {
-            const float* dl = a.delta + i * od;
-            dq[0] = dl[3]; dq[1] = dl[4]; dq[2] = dl[5]; dq[3] = dl[6];
-            if (a.norm_rotation) { const float inv = 1.f / norm4(dq); dq[0] *= inv; dq[1] *= inv; dq[2] *= inv; dq[3] *= inv; }
+            for (int e = tid; e < K; e += 256) s_cnt[e] = 0;
+            __syncthreads();
         }
-        const float invq = 1.f / norm4(dq);
-        const float q[4] = {dq[0] * invq, dq[1] * invq, dq[2] * invq, dq[3] * invq};
-        const float r[4] = {a.rot[4 * i], a.rot[4 * i + 1], a.rot[4 * i + 2], a.rot[4 * i + 3]};
-        float pq[4];
-        quat_mul(q, r, pq);
-        float gp[4];
-        normalize_bwd(pq, gq, gp);
-        // p = q (x) r : bilinear
-        const float gqn[4] = {gp[0] * r[0] + gp[1] * r[1] + gp[2] * r[2] + gp[3] * r[3],
-                              -gp[0] * r[1] + gp[1] * r[0] - gp[2] * r[3] + gp[3] * r[2],
-                              -gp[0] * r[2] + gp[1] * r[3] + gp[2] * r[0] - gp[3] * r[1],
-                              -gp[0] * r[3] - gp[1] * r[2] + gp[2] * r[1] + gp[3] * r[0]};
-        g_rot[4 * i + 0] = gp[0] * q[0] + gp[1] * q[1] + gp[2] * q[2] + gp[3] * q[3];
-        g_rot[4 * i + 1] = -gp[0] * q[1] + gp[1] * q[0] + gp[2] * q[3] - gp[3] * q[2];
-        g_rot[4 * i + 2] = -gp[0] * q[2] - gp[1] * q[3] + gp[2] * q[0] + gp[3] * q[1];
-        g_rot[4 * i + 3] = -gp[0] * q[3] + gp[1] * q[2] - gp[2] * q[1] + gp[3] * q[0];
-        float gdq[4];
-        normalize_bwd(dq, gqn, gdq);  // grad wrt blended (or per-Gaussian normalised) dq
+        int kps[NN > 0 ? NN : GP_MAX_NN], rk[NN > 0 ? NN : GP_MAX_NN];
+        if (live) {
+            const float gx[3] = {g_xyz_t[3 * i], g_xyz_t[3 * i + 1], g_xyz_t[3 * i + 2]};
+            const float gq[4] = {g_q_t[4 * i], g_q_t[4 * i + 1], g_q_t[4 * i + 2], g_q_t[4 * i + 3]};
+            g_xyz[3 * i] = gx[0]; g_xyz[3 * i + 1] = gx[1]; g_xyz[3 * i + 2] = gx[2];
+            // recompute forward
+            float wx[NN > 0 ? NN : GP_MAX_NN], wr[NN > 0 ? NN : GP_MAX_NN];
+            float dq[4] = {0.f, 0.f, 0.f, 0.f};
+            if (nn > 0) {
+                softmax_n(a.raw_w + i * 2 * nn, nn, wx);
+                softmax_n(a.raw_w + i * 2 * nn + nn, nn, wr);
+#pragma unroll
+                for (int k = 0; k < nn; ++k) {
+                    kps[k] = (int)a.knn[i * nn + k];
+                    const float* dl = s_delta + kps[k] * od;
+                    float v[4] = {dl[3], dl[4], dl[5], dl[6]};
+                    if (a.norm_rotation) { const float inv = 1.f / norm4(v); v[0] *= inv; v[1] *= inv; v[2] *= inv; v[3] *= inv; }
+                    dq[0] = fmaf(wr[k], v[0], dq[0]); dq[1] = fmaf(wr[k], v[1], dq[1]);
+                    dq[2] = fmaf(wr[k], v[2], dq[2]); dq[3] = fmaf(wr[k], v[3], dq[3]);
+                }
+            } else {
+                const float* dl = a.delta + i * od;
+                dq[0] = dl[3]; dq[1] = dl[4]; dq[2] = dl[5]; dq[3] = dl[6];
+                if (a.norm_rotation) { const float inv = 1.f / norm4(dq); dq[0] *= inv; dq[1] *= inv; dq[2] *= inv; dq[3] *= inv; }
+            }
+            const float invq = 1.f / norm4(dq);
+            const float q[4] = {dq[0] * invq, dq[1] * invq, dq[2] * invq, dq[3] * invq};
+            const float r[4] = {a.rot[4 * i], a.rot[4 * i + 1], a.rot[4 * i + 2], a.rot[4 * i + 3]};
+            float pq[4];
+            quat_mul(q, r, pq);
+            float gp[4];
+            normalize_bwd(pq, gq, gp);
+            // p = q (x) r : bilinear
+            const float gqn[4] = {gp[0] * r[0] + gp[1] * r[1] + gp[2] * r[2] + gp[3] * r[3],
+                                  -gp[0] * r[1] + gp[1] * r[0] - gp[2] * r[3] + gp[3] * r[2],
+                                  -gp[0] * r[2] + gp[1] * r[3] + gp[2] * r[0] - gp[3] * r[1],
+                                  -gp[0] * r[3] - gp[1] * r[2] + gp[2] * r[1] + gp[3] * r[0]};
+            g_rot[4 * i + 0] = gp[0] * q[0] + gp[1] * q[1] + gp[2] * q[2] + gp[3] * q[3];
+            g_rot[4 * i + 1] = -gp[0] * q[1] + gp[1] * q[0] + gp[2] * q[3] - gp[3] * q[2];
+            g_rot[4 * i + 2] = -gp[0] * q[2] - gp[1] * q[3] + gp[2] * q[0] + gp[3] * q[1];
+            g_rot[4 * i + 3] = -gp[0] * q[3] + gp[1] * q[2] - gp[2] * q[1] + gp[3] * q[0];
+            float gdq[4];
+            normalize_bwd(dq, gqn, gdq);  // grad wrt blended (or per-Gaussian normalised) dq
+            if (nn > 0) {
+                float gwx[NN > 0 ? NN : GP_MAX_NN], gwr[NN > 0 ? NN : GP_MAX_NN];
+                float sx = 0.f, sr = 0.f;
+#pragma unroll
+                for (int k = 0; k < nn; ++k) {
+                    const float* dl = s_delta + kps[k] * od;
+                    gwx[k] = dl[0] * gx[0] + dl[1] * gx[1] + dl[2] * gx[2];
+                    float vn[4] = {dl[3], dl[4], dl[5], dl[6]};
+                    if (a.norm_rotation) { const float inv = 1.f / norm4(vn); vn[0] *= inv; vn[1] *= inv; vn[2] *= inv; vn[3] *= inv; }
+                    gwr[k] = vn[0] * gdq[0] + vn[1] * gdq[1] + vn[2] * gdq[2] + vn[3] * gdq[3];
+                    sx += wx[k] * gwx[k];
+                    sr += wr[k] * gwr[k];
+                    s_w[tid * 2 * nn + k] = wx[k];
+                    s_w[tid * 2 * nn + nn + k] = wr[k];
+                    rk[k] = atomicAdd(&s_cnt[kps[k]], 1);          // rank of this entry within its keypoint
+                }
+#pragma unroll
+                for (int k = 0; k < nn; ++k) {
+                    g_raw_w[i * 2 * nn + k] = wx[k] * (gwx[k] - sx);
+                    g_raw_w[i * 2 * nn + nn + k] = wr[k] * (gwr[k] - sr);
+                }
+                float* sg = s_g + tid * 8;
+                sg[0] = gx[0]; sg[1] = gx[1]; sg[2] = gx[2]; sg[3] = gdq[0]; sg[4] = gdq[1]; sg[5] = gdq[2]; sg[6] = gdq[3];
+            } else {
+                const float* dl = a.delta + i * od;
+                float gv[4] = {gdq[0], gdq[1], gdq[2], gdq[3]};
+                // here dq is already the normalised per-Gaussian delta when norm_rotation: chain once more
+                if (a.norm_rotation) { const float v[4] = {dl[3], dl[4], dl[5], dl[6]}; normalize_bwd(v, gdq, gv); }
+                float* gd = g_delta + i * od;
+                gd[0] = gx[0]; gd[1] = gx[1]; gd[2] = gx[2];
+                gd[3] = gv[0]; gd[4] = gv[1]; gd[5] = gv[2]; gd[6] = gv[3];
+                for (int k = 7; k < od; ++k) gd[k] = 0.f;
+            }
+        }
         if (nn > 0) {
-            float gwx[NN > 0 ? NN : GP_MAX_NN], gwr[NN > 0 ? NN : GP_MAX_NN];
-            float sx = 0.f, sr = 0.f;
+            __syncthreads();
+            {   // exclusive scan of cnt[0..K) -> base[0..K]: each thread owns ceil(K/256) consecutive bins
+                const int per = (K + 255) / 256;
+                const int b0 = tid * per;
+                int loc = 0;
+                for (int e = 0; e < per; ++e) if (b0 + e < K) loc += s_cnt[b0 + e];
+                int inc = loc;
 #pragma unroll
-            for (int k = 0; k < nn; ++k) {
-                const long kp = a.knn[i * nn + k];
-                const float* dl = a.delta + kp * od;
-                gwx[k] = dl[0] * gx[0] + dl[1] * gx[1] + dl[2] * gx[2];
-                float v[4] = {dl[3], dl[4], dl[5], dl[6]};
-                float vn[4] = {v[0], v[1], v[2], v[3]};
-                if (a.norm_rotation) { const float inv = 1.f / norm4(v); vn[0] *= inv; vn[1] *= inv; vn[2] *= inv; vn[3] *= inv; }
-                gwr[k] = vn[0] * gdq[0] + vn[1] * gdq[1] + vn[2] * gdq[2] + vn[3] * gdq[3];
-                sx += wx[k] * gwx[k];
-                sr += wr[k] * gwr[k];
-                float c[4] = {wr[k] * gdq[0], wr[k] * gdq[1], wr[k] * gdq[2], wr[k] * gdq[3]};
-                float gv[4] = {c[0], c[1], c[2], c[3]};
-                if (a.norm_rotation) normalize_bwd(v, c, gv);
+                for (int dd = 1; dd < 64; dd <<= 1) { const int t = __shfl_up(inc, dd); if ((tid & 63) >= dd) inc += t; }
+                if ((tid & 63) == 63) s_wsum[tid >> 6] = inc;
+                __syncthreads();
+                int woff = 0;
+                for (int w = 0; w < (tid >> 6); ++w) woff += s_wsum[w];
+                int run = woff + inc - loc;
+                for (int e = 0; e < per; ++e) if (b0 + e < K) { s_base[b0 + e] = run; run += s_cnt[b0 + e]; }
+                if (tid == 255) s_base[K] = run;
+            }
+            __syncthreads();
+            if (live) {
+#pragma unroll
+                for (int k = 0; k < nn; ++k) s_sorted[s_base[kps[k]] + rk[k]] = (unsigned short)(tid * nn + k);
+            }
+            __syncthreads();
+            for (int kp = tid; kp < K; kp += 256) {
+                float sacc[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                const int pe = s_base[kp + 1];
+                for (int pp = s_base[kp]; pp < pe; ++pp) {
+                    const int e = s_sorted[pp];
+                    const int t = e / nn, k = e - t * nn;
+                    const float wxk = s_w[t * 2 * nn + k], wrk = s_w[t * 2 * nn + nn + k];
+                    const float* sg = s_g + t * 8;
+                    sacc[0] = fmaf(wxk, sg[0], sacc[0]); sacc[1] = fmaf(wxk, sg[1], sacc[1]); sacc[2] = fmaf(wxk, sg[2], sacc[2]);
+                    sacc[3] = fmaf(wrk, sg[3], sacc[3]); sacc[4] = fmaf(wrk, sg[4], sacc[4]);
+                    sacc[5] = fmaf(wrk, sg[5], sacc[5]); sacc[6] = fmaf(wrk, sg[6], sacc[6]);
+                }
                 float* acc = s_acc + kp * 7;
-                atomicAdd(acc + 0, wx[k] * gx[0]); atomicAdd(acc + 1, wx[k] * gx[1]); atomicAdd(acc + 2, wx[k] * gx[2]);
-                atomicAdd(acc + 3, gv[0]); atomicAdd(acc + 4, gv[1]); atomicAdd(acc + 5, gv[2]); atomicAdd(acc + 6, gv[3]);
-            }
 #pragma unroll
-            for (int k = 0; k < nn; ++k) {
-                g_raw_w[i * 2 * nn + k] = wx[k] * (gwx[k] - sx);
-                g_raw_w[i * 2 * nn + nn + k] = wr[k] * (gwr[k] - sr);
+                for (int cc = 0; cc < 7; ++cc) acc[cc] += sacc[cc];
             }
-        } else {
-            const float* dl = a.delta + i * od;
-            float gv[4] = {gdq[0], gdq[1], gdq[2], gdq[3]};
-            // here dq is already the normalised per-Gaussian delta when norm_rotation: chain once more
-            if (a.norm_rotation) { const float v[4] = {dl[3], dl[4], dl[5], dl[6]}; normalize_bwd(v, gdq, gv); }
-            float* gd = g_delta + i * od;
-            gd[0] = gx[0]; gd[1] = gx[1]; gd[2] = gx[2];
-            gd[3] = gv[0]; gd[4] = gv[1]; gd[5] = gv[2]; gd[6] = gv[3];
-            for (int k = 7; k < od; ++k) gd[k] = 0.f;
+            __syncthreads();
         }
     }
     if (nn > 0) {
-        __syncthreads();
         // stage 1 of the cross-workgroup reduction: plain coalesced stores of this workgroup's partials
-        for (int e = threadIdx.x; e < KA; e += 256) partial[(size_t)blockIdx.x * KA + e] = s_acc[e];
+        const int KA = K * 7;
+        for (int kp = tid; kp < K; kp += 256) {
+            float* acc = s_acc + kp * 7;
+            if (a.norm_rotation) {
+                const float* dl = s_delta + kp * od;
+                const float v[4] = {dl[3], dl[4], dl[5], dl[6]};
+                const float cq[4] = {acc[3], acc[4], acc[5], acc[6]};
+                float gv[4];
+                normalize_bwd(v, cq, gv);
+                acc[3] = gv[0]; acc[4] = gv[1]; acc[5] = gv[2]; acc[6] = gv[3];
+            }
+        }
+        __syncthreads();
+        for (int e = tid; e < KA; e += 256) partial[(size_t)blockIdx.x * KA + e] = s_acc[e];
     }
 }
 
@@ -517,19 +596,25 @@ __global__ __launch_bounds__(256) void gp_blend_bwd_kernel(BB_ARGS) { blend_bwd_
 __global__ __launch_bounds__(256) void gp_blend_bwd6_kernel(BB_ARGS) { blend_bwd_body<6>(a, g_xyz_t, g_q_t, g_delta, g_raw_w, g_xyz, g_rot, partial); }
 __global__ __launch_bounds__(256) void gp_blend_bwd8_kernel(BB_ARGS) { blend_bwd_body<8>(a, g_xyz_t, g_q_t, g_delta, g_raw_w, g_xyz, g_rot, partial); }
 
-// stage 2: g_delta[k, c] = sum over workgroups (deterministic, no atomics)
+// stage 2: g_delta[k, c] = sum over workgroups (deterministic, no atomics).  64 elements per workgroup, the
+// workgroup's 4 waves split the partials and meet in LDS.
 __global__ __launch_bounds__(256) void gp_blend_bwd_reduce_kernel(const float* __restrict__ partial, int nblocks, int KA,
                                                                  int od, float* __restrict__ g_delta) {
-    const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= KA) return;
+    __shared__ float s_r[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int e = blockIdx.x * 64 + lane;
     float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
-    int b = 0;
-    for (; b + 3 < nblocks; b += 4) {
-        v0 += partial[(size_t)b * KA + e]; v1 += partial[(size_t)(b + 1) * KA + e];
-        v2 += partial[(size_t)(b + 2) * KA + e]; v3 += partial[(size_t)(b + 3) * KA + e];
+    if (e < KA) {
+        int b = wave;
+        for (; b + 12 < nblocks; b += 16) {
+            v0 += partial[(size_t)b * KA + e]; v1 += partial[(size_t)(b + 4) * KA + e];
+            v2 += partial[(size_t)(b + 8) * KA + e]; v3 += partial[(size_t)(b + 12) * KA + e];
+        }
+        for (; b < nblocks; b += 4) v0 += partial[(size_t)b * KA + e];
     }
-    for (; b < nblocks; ++b) v0 += partial[(size_t)b * KA + e];
-    g_delta[(size_t)(e / 7) * od + (e % 7)] = (v0 + v1) + (v2 + v3);
+    s_r[wave][lane] = (v0 + v1) + (v2 + v3);
+    __syncthreads();
+    if (wave == 0 && e < KA) g_delta[(size_t)(e / 7) * od + (e % 7)] = (s_r[0][lane] + s_r[1][lane]) + (s_r[2][lane] + s_r[3][lane]);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -114,7 +114,9 @@ extern "C" int gp_blend_backward(const gp_blend_args* a, const float* dL_dxyz_t,
     if (!dL_dxyz_t || !dL_dq_t || !dL_ddelta || !dL_dxyz || !dL_drot || (b.nn > 0 && !dL_draw_w)) GP_FAIL("null argument");
     unsigned blocks = gp_blocks((size_t)b.N, 256);
     if (b.nn > 0 && blocks > 512) blocks = 512;   // measured: 256-512 workgroups minimise partial-buffer traffic
-    const size_t lds = b.nn > 0 ? (size_t)b.K * 7 * sizeof(float) : 0;
+    // acc[K*7] | delta[K*od] | cnt[K] | base[K+1] | g[256*8] | w[256*2*nn] | sorted u16 [256*nn]
+    const size_t lds = b.nn > 0 ? ((size_t)b.K * (7 + b.out_dim + 2) + 1 + 256 * 8 + 256 * 2 * (size_t)b.nn) * 4 + 256 * (size_t)b.nn * 2 + 16 : 256 * 8 * 4;
+    if (lds > 64 * 1024) GP_FAIL("keypoint blend backward: K = %ld, nn = %d needs %zu B of LDS (> 64 KiB)", (long)b.K, b.nn, lds);
     float* partial = nullptr;
     const int KA = (int)b.K * 7;
     if (b.nn > 0) {
@@ -128,7 +130,7 @@ extern "C" int gp_blend_backward(const gp_blend_args* a, const float* dL_dxyz_t,
                        dL_draw_w, dL_dxyz, dL_drot, partial);
     GP_LAUNCH_CHECK();
     if (b.nn > 0) {
-        hipLaunchKernelGGL(gp_blend_bwd_reduce_kernel, dim3(gp_blocks((size_t)KA, 256)), dim3(256), 0, (hipStream_t)stream_, partial,
+        hipLaunchKernelGGL(gp_blend_bwd_reduce_kernel, dim3(gp_blocks((size_t)KA, 64)), dim3(256), 0, (hipStream_t)stream_, partial,
                            (int)blocks, KA, b.out_dim, dL_ddelta);
         GP_LAUNCH_CHECK();
     } }
