@@ -1306,27 +1306,24 @@ __device__ __forceinline__ void preprocess_bwd_body(
     const int i = base + tid;
     const int nblk = min(256, d.N - base);
     const bool use_sh = dL_dcolors == nullptr;
-    float shl[SH_MODE == 0 ? 1 : 48], dshl[SH_MODE == 0 ? 1 : 48];
+    // SH_MODE 1/2: coefficients are staged in LDS and their gradients REPLACE them in place (one channel's 16
+    // coefficients are in registers at a time), then leave as one coalesced span per workgroup.
+    constexpr int SROW = SH_MODE == 1 ? 49 : 45;        // LDS row stride (odd: conflict-free)
+    constexpr int SOFF = SH_MODE == 1 ? 0 : 3;          // first coefficient float held in the row
+    float dsh_dc[3] = {0.f, 0.f, 0.f};                  // SH_MODE 2: gradient of the dc coefficient (separate tensor)
     if (SH_MODE != 0) {
-#pragma unroll
-        for (int k = 0; k < 48; ++k) { shl[k] = 0.f; dshl[k] = 0.f; }
         if (use_sh && d.D > 0) {
             if (SH_MODE == 1) stage_sh<48>(s_sh, shs + (size_t)base * 48, nblk, tid);
             if (SH_MODE == 2) stage_sh<45>(s_sh, shs_rest + (size_t)base * 45, nblk, tid);
         }
         __syncthreads();
-        if (use_sh && d.D > 0 && i < d.N) {
-            if (SH_MODE == 1) {
-#pragma unroll
-                for (int k = 0; k < 48; ++k) shl[k] = s_sh[tid * 49 + k];
-            } else {
-                shl[0] = shs[3 * (size_t)i]; shl[1] = shs[3 * (size_t)i + 1]; shl[2] = shs[3 * (size_t)i + 2];
-#pragma unroll
-                for (int k = 0; k < 45; ++k) shl[3 + k] = s_sh[tid * 45 + k];
-            }
-        }
-        __syncthreads();   // everyone has its coefficients in registers: s_sh is free for the gradients
     }
+    auto zero_row = [&]() {
+        if (SH_MODE != 0 && use_sh) {
+#pragma unroll
+            for (int k = 0; k < (SH_MODE == 1 ? 48 : 45); ++k) s_sh[tid * SROW + k] = 0.f;
+        }
+    };
     do {
     if (i >= d.N) break;
     const bool vis = radii[i] > 0;
@@ -1342,6 +1339,7 @@ __device__ __forceinline__ void preprocess_bwd_body(
         if (dL_dcov3D) for (int k = 0; k < 6; ++k) dL_dcov3D[6 * i + k] = 0.f;
         if (dL_dcolors) { dL_dcolors[3 * i] = dL_dcolors[3 * i + 1] = dL_dcolors[3 * i + 2] = 0.f; }
         if (SH_MODE == 0 && dL_dshs) for (int k = 0; k < d.M * 3; ++k) dL_dshs[(size_t)i * d.M * 3 + k] = 0.f;
+        zero_row();
         break;
     }
     const float px = means3D[3 * i], py = means3D[3 * i + 1], pz = means3D[3 * i + 2];
@@ -1419,58 +1417,74 @@ __device__ __forceinline__ void preprocess_bwd_body(
         const float len = sqrtf(fmaf(ddx0, ddx0, fmaf(ddy0, ddy0, ddz0 * ddz0)));
         const float inv = 1.f / len;
         const float x = ddx0 * inv, y = ddy0 * inv, z = ddz0 * inv;
-        const float* sh = SH_MODE == 0 ? shs + (size_t)i * d.M * 3 : shl;
-        float* dsh = SH_MODE == 0 ? dL_dshs + (size_t)i * d.M * 3 : dshl;
         const uint8_t cl = clamped[i];
         float ddir0 = 0.f, ddir1 = 0.f, ddir2 = 0.f;
         const int D = d.D;
         const int used = (D + 1) * (D + 1);
-        for (int k = used; k < d.M; ++k) { dsh[3 * k] = 0.f; dsh[3 * k + 1] = 0.f; dsh[3 * k + 2] = 0.f; }
+        const float* sh_g = shs + (size_t)i * d.M * 3;          // SH_MODE 0
+        float* dsh_g = dL_dshs + (size_t)i * d.M * 3;           // SH_MODE 0
+        float* row = s_sh + tid * SROW - SOFF;                  // SH_MODE 1/2: row[3 k + ch], k >= SOFF / 3
 #pragma unroll
         for (int ch = 0; ch < 3; ++ch) {
             const float g = ((cl >> ch) & 1) ? 0.f : g_color[GP_ACC_STRIDE * (size_t)i + ch];
-            dsh[0 * 3 + ch] = SH_C0 * g;
+            // this channel's coefficients first (their slots are about to be overwritten by the gradients)
+            float sh[16];
+#pragma unroll
+            for (int k = 1; k < 16; ++k) sh[k] = (k < used) ? (SH_MODE == 0 ? sh_g[3 * k + ch] : row[3 * k + ch]) : 0.f;
+            float dsh[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) dsh[k] = 0.f;
+            dsh[0] = SH_C0 * g;
             if (D > 0) {
-                dsh[1 * 3 + ch] = -SH_C1 * y * g;
-                dsh[2 * 3 + ch] = SH_C1 * z * g;
-                dsh[3 * 3 + ch] = -SH_C1 * x * g;
-                float ddx = -SH_C1 * sh[3 * 3 + ch];
-                float ddy = -SH_C1 * sh[1 * 3 + ch];
-                float ddz = SH_C1 * sh[2 * 3 + ch];
+                dsh[1] = -SH_C1 * y * g;
+                dsh[2] = SH_C1 * z * g;
+                dsh[3] = -SH_C1 * x * g;
+                float ddx = -SH_C1 * sh[3];
+                float ddy = -SH_C1 * sh[1];
+                float ddz = SH_C1 * sh[2];
                 if (D > 1) {
                     const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
-                    dsh[4 * 3 + ch] = SH_C2[0] * xy * g;
-                    dsh[5 * 3 + ch] = SH_C2[1] * yz * g;
-                    dsh[6 * 3 + ch] = SH_C2[2] * (2.f * zz - xx - yy) * g;
-                    dsh[7 * 3 + ch] = SH_C2[3] * xz * g;
-                    dsh[8 * 3 + ch] = SH_C2[4] * (xx - yy) * g;
-                    ddx += SH_C2[0] * y * sh[4 * 3 + ch] + SH_C2[2] * 2.f * -x * sh[6 * 3 + ch] + SH_C2[3] * z * sh[7 * 3 + ch] +
-                           SH_C2[4] * 2.f * x * sh[8 * 3 + ch];
-                    ddy += SH_C2[0] * x * sh[4 * 3 + ch] + SH_C2[1] * z * sh[5 * 3 + ch] + SH_C2[2] * 2.f * -y * sh[6 * 3 + ch] +
-                           SH_C2[4] * 2.f * -y * sh[8 * 3 + ch];
-                    ddz += SH_C2[1] * y * sh[5 * 3 + ch] + SH_C2[2] * 4.f * z * sh[6 * 3 + ch] + SH_C2[3] * x * sh[7 * 3 + ch];
+                    dsh[4] = SH_C2[0] * xy * g;
+                    dsh[5] = SH_C2[1] * yz * g;
+                    dsh[6] = SH_C2[2] * (2.f * zz - xx - yy) * g;
+                    dsh[7] = SH_C2[3] * xz * g;
+                    dsh[8] = SH_C2[4] * (xx - yy) * g;
+                    ddx += SH_C2[0] * y * sh[4] + SH_C2[2] * 2.f * -x * sh[6] + SH_C2[3] * z * sh[7] +
+                           SH_C2[4] * 2.f * x * sh[8];
+                    ddy += SH_C2[0] * x * sh[4] + SH_C2[1] * z * sh[5] + SH_C2[2] * 2.f * -y * sh[6] +
+                           SH_C2[4] * 2.f * -y * sh[8];
+                    ddz += SH_C2[1] * y * sh[5] + SH_C2[2] * 4.f * z * sh[6] + SH_C2[3] * x * sh[7];
                     if (D > 2) {
-                        dsh[9 * 3 + ch] = SH_C3[0] * y * (3.f * xx - yy) * g;
-                        dsh[10 * 3 + ch] = SH_C3[1] * xy * z * g;
-                        dsh[11 * 3 + ch] = SH_C3[2] * y * (4.f * zz - xx - yy) * g;
-                        dsh[12 * 3 + ch] = SH_C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy) * g;
-                        dsh[13 * 3 + ch] = SH_C3[4] * x * (4.f * zz - xx - yy) * g;
-                        dsh[14 * 3 + ch] = SH_C3[5] * z * (xx - yy) * g;
-                        dsh[15 * 3 + ch] = SH_C3[6] * x * (xx - 3.f * yy) * g;
-                        ddx += SH_C3[0] * sh[9 * 3 + ch] * 6.f * xy + SH_C3[1] * sh[10 * 3 + ch] * yz +
-                               SH_C3[2] * sh[11 * 3 + ch] * -2.f * xy + SH_C3[3] * sh[12 * 3 + ch] * -6.f * xz +
-                               SH_C3[4] * sh[13 * 3 + ch] * (4.f * zz - 3.f * xx - yy) + SH_C3[5] * sh[14 * 3 + ch] * 2.f * xz +
-                               SH_C3[6] * sh[15 * 3 + ch] * 3.f * (xx - yy);
-                        ddy += SH_C3[0] * sh[9 * 3 + ch] * 3.f * (xx - yy) + SH_C3[1] * sh[10 * 3 + ch] * xz +
-                               SH_C3[2] * sh[11 * 3 + ch] * (4.f * zz - xx - 3.f * yy) + SH_C3[3] * sh[12 * 3 + ch] * -6.f * yz +
-                               SH_C3[4] * sh[13 * 3 + ch] * -2.f * xy + SH_C3[5] * sh[14 * 3 + ch] * -2.f * yz +
-                               SH_C3[6] * sh[15 * 3 + ch] * -6.f * xy;
-                        ddz += SH_C3[1] * sh[10 * 3 + ch] * xy + SH_C3[2] * sh[11 * 3 + ch] * 8.f * yz +
-                               SH_C3[3] * sh[12 * 3 + ch] * 3.f * (2.f * zz - xx - yy) + SH_C3[4] * sh[13 * 3 + ch] * 8.f * xz +
-                               SH_C3[5] * sh[14 * 3 + ch] * (xx - yy);
+                        dsh[9] = SH_C3[0] * y * (3.f * xx - yy) * g;
+                        dsh[10] = SH_C3[1] * xy * z * g;
+                        dsh[11] = SH_C3[2] * y * (4.f * zz - xx - yy) * g;
+                        dsh[12] = SH_C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy) * g;
+                        dsh[13] = SH_C3[4] * x * (4.f * zz - xx - yy) * g;
+                        dsh[14] = SH_C3[5] * z * (xx - yy) * g;
+                        dsh[15] = SH_C3[6] * x * (xx - 3.f * yy) * g;
+                        ddx += SH_C3[0] * sh[9] * 6.f * xy + SH_C3[1] * sh[10] * yz +
+                               SH_C3[2] * sh[11] * -2.f * xy + SH_C3[3] * sh[12] * -6.f * xz +
+                               SH_C3[4] * sh[13] * (4.f * zz - 3.f * xx - yy) + SH_C3[5] * sh[14] * 2.f * xz +
+                               SH_C3[6] * sh[15] * 3.f * (xx - yy);
+                        ddy += SH_C3[0] * sh[9] * 3.f * (xx - yy) + SH_C3[1] * sh[10] * xz +
+                               SH_C3[2] * sh[11] * (4.f * zz - xx - 3.f * yy) + SH_C3[3] * sh[12] * -6.f * yz +
+                               SH_C3[4] * sh[13] * -2.f * xy + SH_C3[5] * sh[14] * -2.f * yz +
+                               SH_C3[6] * sh[15] * -6.f * xy;
+                        ddz += SH_C3[1] * sh[10] * xy + SH_C3[2] * sh[11] * 8.f * yz +
+                               SH_C3[3] * sh[12] * 3.f * (2.f * zz - xx - yy) + SH_C3[4] * sh[13] * 8.f * xz +
+                               SH_C3[5] * sh[14] * (xx - yy);
                     }
                 }
                 ddir0 += ddx * g; ddir1 += ddy * g; ddir2 += ddz * g;
+            }
+            if (SH_MODE == 0) {
+#pragma unroll
+                for (int k = 0; k < 16; ++k) if (k < d.M) dsh_g[3 * k + ch] = dsh[k];
+                for (int k = 16; k < d.M; ++k) dsh_g[3 * k + ch] = 0.f;
+            } else {
+                if (SH_MODE == 2) dsh_dc[ch] = dsh[0]; else row[ch] = dsh[0];
+#pragma unroll
+                for (int k = 1; k < 16; ++k) row[3 * k + ch] = dsh[k];
             }
         }
         const float dot = x * ddir0 + y * ddir1 + z * ddir2;
@@ -1514,19 +1528,14 @@ __device__ __forceinline__ void preprocess_bwd_body(
     } while (0);
     if (SH_MODE != 0 && use_sh) {
         // gradients of the SH coefficients leave through LDS as one coalesced span per workgroup
+        __syncthreads();
         if (SH_MODE == 1) {
-#pragma unroll
-            for (int k = 0; k < 48; ++k) s_sh[tid * 49 + k] = dshl[k];
-            __syncthreads();
             unstage_sh<48>(s_sh, dL_dshs + (size_t)base * 48, nblk, tid, accumulate_shs != 0);
         } else {
             if (i < d.N) {
-                if (accumulate_shs) { dL_dshs[3 * (size_t)i] += dshl[0]; dL_dshs[3 * (size_t)i + 1] += dshl[1]; dL_dshs[3 * (size_t)i + 2] += dshl[2]; }
-                else { dL_dshs[3 * (size_t)i] = dshl[0]; dL_dshs[3 * (size_t)i + 1] = dshl[1]; dL_dshs[3 * (size_t)i + 2] = dshl[2]; }
+                if (accumulate_shs) { dL_dshs[3 * (size_t)i] += dsh_dc[0]; dL_dshs[3 * (size_t)i + 1] += dsh_dc[1]; dL_dshs[3 * (size_t)i + 2] += dsh_dc[2]; }
+                else { dL_dshs[3 * (size_t)i] = dsh_dc[0]; dL_dshs[3 * (size_t)i + 1] = dsh_dc[1]; dL_dshs[3 * (size_t)i + 2] = dsh_dc[2]; }
             }
-#pragma unroll
-            for (int k = 0; k < 45; ++k) s_sh[tid * 45 + k] = dshl[3 + k];
-            __syncthreads();
             unstage_sh<45>(s_sh, dL_dshs_rest + (size_t)base * 45, nblk, tid, accumulate_shs != 0);
         }
     }
