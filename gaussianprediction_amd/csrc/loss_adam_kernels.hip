@@ -182,7 +182,7 @@ __global__ __launch_bounds__(256) void gp_adam_kernel(float* __restrict__ p, flo
 
 // multi-tensor form: ONE launch walks every parameter tensor (chunk table built by the host)
 #define ADAM_MAX_TENSORS 32
-#define ADAM_CHUNK 65536   // elements per workgroup-chunk
+#define ADAM_CHUNK 16384   // elements per workgroup-chunk
 struct AdamTable {
     float* p[ADAM_MAX_TENSORS];
     float* g[ADAM_MAX_TENSORS];
@@ -203,18 +203,34 @@ __global__ __launch_bounds__(256) void gp_adam_multi_kernel(AdamTable t, float b
     float* __restrict__ p = t.p[k]; float* __restrict__ g = t.g[k]; float* __restrict__ m = t.m[k]; float* __restrict__ v = t.v[k];
     const float step_size = t.lr[k] / bc1;
     const size_t end = base + ADAM_CHUNK < n ? base + ADAM_CHUNK : n;
-    for (size_t i = base + (size_t)threadIdx.x * 4; i < end; i += 1024) {
+    auto upd = [&](float4& pv, const float4& gv, float4& mv, float4& vv) {
+        float* pp = (float*)&pv; const float* gg = (const float*)&gv; float* mm = (float*)&mv; float* vq = (float*)&vv;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            mm[u] = b1 * mm[u] + (1.f - b1) * gg[u];
+            vq[u] = b2 * vq[u] + (1.f - b2) * gg[u] * gg[u];
+            pp[u] -= step_size * (mm[u] / (sqrtf(vq[u]) / bc2_sqrt + eps));
+        }
+    };
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    size_t i = base + (size_t)threadIdx.x * 4;
+    // two independent 16-byte streams per thread and iteration: 8 loads in flight per lane
+    for (; i + 1024 + 3 < end; i += 2048) {
+        const size_t j = i + 1024;
+        float4 pa = *(float4*)(p + i), ga = *(float4*)(g + i), ma = *(float4*)(m + i), va = *(float4*)(v + i);
+        float4 pb = *(float4*)(p + j), gb = *(float4*)(g + j), mb = *(float4*)(m + j), vb = *(float4*)(v + j);
+        upd(pa, ga, ma, va);
+        upd(pb, gb, mb, vb);
+        *(float4*)(p + i) = pa; *(float4*)(m + i) = ma; *(float4*)(v + i) = va;
+        *(float4*)(p + j) = pb; *(float4*)(m + j) = mb; *(float4*)(v + j) = vb;
+        if (zero_grad) { *(float4*)(g + i) = zero4; *(float4*)(g + j) = zero4; }
+    }
+    for (; i < end; i += 1024) {
         if (i + 3 < n) {
             float4 pv = *(float4*)(p + i), gv = *(float4*)(g + i), mv = *(float4*)(m + i), vv = *(float4*)(v + i);
-            float* pp = (float*)&pv; float* gg = (float*)&gv; float* mm = (float*)&mv; float* vq = (float*)&vv;
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                mm[u] = b1 * mm[u] + (1.f - b1) * gg[u];
-                vq[u] = b2 * vq[u] + (1.f - b2) * gg[u] * gg[u];
-                pp[u] -= step_size * (mm[u] / (sqrtf(vq[u]) / bc2_sqrt + eps));
-            }
+            upd(pv, gv, mv, vv);
             *(float4*)(p + i) = pv; *(float4*)(m + i) = mv; *(float4*)(v + i) = vv;
-            if (zero_grad) *(float4*)(g + i) = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (zero_grad) *(float4*)(g + i) = zero4;
         } else {
             for (size_t j = i; j < n; ++j) {
                 const float gk = g[j];
