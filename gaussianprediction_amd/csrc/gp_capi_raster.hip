@@ -231,31 +231,19 @@ extern "C" int gp_raster_backward(const gp_raster_settings* st, const gp_raster_
     float* g_color = acc + 6;
     float* g_depth = acc + 9;
     if (R > 0) {
-        // v4 (compacted batches) is the default; GP_EXP_BWD_V3=1 selects the un-compacted variant for A/B timing
-        static const bool use_v3 = getenv("GP_EXP_BWD_V3") != nullptr;
-        auto kern = use_v3 ? (dL_ddepth ? gp_composite_bwd3_depth_kernel : gp_composite_bwd3_kernel)
-                           : (dL_ddepth ? gp_composite_bwd4_depth_kernel : gp_composite_bwd4_kernel);
-        const unsigned parts = GP_TILE / 8;
         hipLaunchKernelGGL(gp_tile_order_kernel, dim3(1), dim3(1024), 0, s, il.ranges, il.tile_work, (int)T, order_bwd);
         GP_LAUNCH_CHECK();
-        static const bool use_v5 = getenv("GP_EXP_BWD_V4") == nullptr && !use_v3;
-        if (use_v5) {
-            {
-                GpProfScope _p("bwd_pixprep", s);
-                hipLaunchKernelGGL(gp_bwd_pixprep_kernel, dim3(gp_blocks(T * GP_BWD_PARTS * GP_BWD_PAIRS, 256)), dim3(256), 0, s, d, st->bg,
-                                   fwd->color, fwd->depth, il.final_T, il.n_contrib, dL_dcolor, dL_ddepth, pp);
-                GP_LAUNCH_CHECK();
-            }
-            GpProfScope _p("composite_bwd", s);
-            hipLaunchKernelGGL(dL_ddepth ? gp_composite_bwd5_depth_kernel : gp_composite_bwd5_kernel, dim3((unsigned)T * GP_BWD_PARTS),
-                               dim3(64), 0, s, d, il.ranges, point_list, (const uint8_t*)point_list + gp_align_up((size_t)R * 4, 256), gl.rec,
-                               (const GpPixPair*)pp, g_mean2D, g_conic, g_opacity, g_color, g_depth, order_bwd);
+        {
+            GpProfScope _p("bwd_pixprep", s);
+            hipLaunchKernelGGL(gp_bwd_pixprep_kernel, dim3(gp_blocks(T * GP_BWD_PARTS * GP_BWD_PAIRS, 256)), dim3(256), 0, s, d, st->bg,
+                               fwd->color, fwd->depth, il.final_T, il.n_contrib, dL_dcolor, dL_ddepth, pp);
             GP_LAUNCH_CHECK();
-        } else { GpProfScope _p("composite_bwd", s);
-        hipLaunchKernelGGL(kern, dim3((unsigned)T * parts), dim3(64), 0, s, d, il.ranges, point_list,
-                           gl.rec, st->bg, fwd->color, fwd->depth, il.final_T, il.n_contrib, dL_dcolor, dL_ddepth, g_mean2D,
-                           g_conic, g_opacity, g_color, g_depth, order_bwd);
-        GP_LAUNCH_CHECK(); }
+        }
+        GpProfScope _p("composite_bwd", s);
+        hipLaunchKernelGGL(dL_ddepth ? gp_composite_bwd_depth_kernel : gp_composite_bwd_kernel, dim3((unsigned)T * GP_BWD_PARTS),
+                           dim3(64), 0, s, d, il.ranges, point_list, (const uint8_t*)point_list + gp_align_up((size_t)R * 4, 256), gl.rec,
+                           (const GpPixPair*)pp, g_mean2D, g_conic, g_opacity, g_color, g_depth, order_bwd);
+        GP_LAUNCH_CHECK();
     }
     {
         GpProfScope _p("preprocess_bwd", s);

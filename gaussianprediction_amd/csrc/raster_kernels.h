@@ -53,10 +53,6 @@ __global__ __launch_bounds__(256) void gp_composite_fwd_kernel(RasterDims d, con
                                                                       float* __restrict__ final_T,
                                                                       int32_t* __restrict__ n_contrib, const uint32_t* __restrict__ order, int32_t* __restrict__ tile_work, uint8_t* __restrict__ qmask);
 
-__global__ __launch_bounds__(64) void gp_composite_bwd3_kernel(RasterDims d, const int2* __restrict__ ranges, const uint32_t* __restrict__ point_list,      const float4* __restrict__ rec, const float* __restrict__ bg, const float* __restrict__ out_color,      const float* __restrict__ out_depth, const float* __restrict__ final_T, const int32_t* __restrict__ n_contrib,      const float* __restrict__ dL_dpix, const float* __restrict__ dL_dpixdepth, float* __restrict__ g_mean2D,      float* __restrict__ g_conic, float* __restrict__ g_opacity, float* __restrict__ g_color, float* __restrict__ g_depth, const uint32_t* __restrict__ order);
-__global__ __launch_bounds__(64) void gp_composite_bwd4_kernel(RasterDims d, const int2* __restrict__ ranges, const uint32_t* __restrict__ point_list,      const float4* __restrict__ rec, const float* __restrict__ bg, const float* __restrict__ out_color,      const float* __restrict__ out_depth, const float* __restrict__ final_T, const int32_t* __restrict__ n_contrib,      const float* __restrict__ dL_dpix, const float* __restrict__ dL_dpixdepth, float* __restrict__ g_mean2D,      float* __restrict__ g_conic, float* __restrict__ g_opacity, float* __restrict__ g_color, float* __restrict__ g_depth, const uint32_t* __restrict__ order);
-__global__ __launch_bounds__(64) void gp_composite_bwd4_depth_kernel(RasterDims d, const int2* __restrict__ ranges, const uint32_t* __restrict__ point_list,      const float4* __restrict__ rec, const float* __restrict__ bg, const float* __restrict__ out_color,      const float* __restrict__ out_depth, const float* __restrict__ final_T, const int32_t* __restrict__ n_contrib,      const float* __restrict__ dL_dpix, const float* __restrict__ dL_dpixdepth, float* __restrict__ g_mean2D,      float* __restrict__ g_conic, float* __restrict__ g_opacity, float* __restrict__ g_color, float* __restrict__ g_depth, const uint32_t* __restrict__ order);
-__global__ __launch_bounds__(64) void gp_composite_bwd3_depth_kernel(RasterDims d, const int2* __restrict__ ranges, const uint32_t* __restrict__ point_list,      const float4* __restrict__ rec, const float* __restrict__ bg, const float* __restrict__ out_color,      const float* __restrict__ out_depth, const float* __restrict__ final_T, const int32_t* __restrict__ n_contrib,      const float* __restrict__ dL_dpix, const float* __restrict__ dL_dpixdepth, float* __restrict__ g_mean2D,      float* __restrict__ g_conic, float* __restrict__ g_opacity, float* __restrict__ g_color, float* __restrict__ g_depth, const uint32_t* __restrict__ order);
 
 __global__ __launch_bounds__(256) void gp_preprocess_bwd_kernel(RasterDims d, const float* __restrict__ means3D, const float* __restrict__ scales,      const float* __restrict__ rotations, const float* __restrict__ shs, const float* __restrict__ shs_rest,      const float* __restrict__ cov3D_precomp, const float* __restrict__ view, const float* __restrict__ proj,      const float* __restrict__ campos, const int32_t* __restrict__ radii, const uint8_t* __restrict__ clamped,      const float* __restrict__ g_mean2D, const float* __restrict__ g_conic, const float* __restrict__ g_opacity,      const float* __restrict__ g_color, const float* __restrict__ g_depth, float* __restrict__ dL_dmeans3D,      float* __restrict__ dL_dmeans2D, float* __restrict__ dL_dshs, float* __restrict__ dL_dshs_rest,      float* __restrict__ dL_dcolors, float* __restrict__ dL_dopacities, float* __restrict__ dL_dscales,      float* __restrict__ dL_drots, float* __restrict__ dL_dcov3D, int accumulate_shs);
 
@@ -70,9 +66,9 @@ __global__ __launch_bounds__(256) void gp_bwd_pixprep_kernel(RasterDims d, const
                                                              const float* __restrict__ out_depth, const float* __restrict__ final_T,
                                                              const int32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpix,
                                                              const float* __restrict__ dL_dpixdepth, GpPixPair* __restrict__ pp);
-__global__ __launch_bounds__(64) void gp_composite_bwd5_kernel(RasterDims d, const int2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
+__global__ __launch_bounds__(64) void gp_composite_bwd_kernel(RasterDims d, const int2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
     const uint8_t* __restrict__ qmask, const float4* __restrict__ rec, const GpPixPair* __restrict__ pp, float* __restrict__ g_mean2D, float* __restrict__ g_conic,
     float* __restrict__ g_opacity, float* __restrict__ g_color, float* __restrict__ g_depth, const uint32_t* __restrict__ order);
-__global__ __launch_bounds__(64) void gp_composite_bwd5_depth_kernel(RasterDims d, const int2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
+__global__ __launch_bounds__(64) void gp_composite_bwd_depth_kernel(RasterDims d, const int2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
     const uint8_t* __restrict__ qmask, const float4* __restrict__ rec, const GpPixPair* __restrict__ pp, float* __restrict__ g_mean2D, float* __restrict__ g_conic,
     float* __restrict__ g_opacity, float* __restrict__ g_color, float* __restrict__ g_depth, const uint32_t* __restrict__ order);

@@ -578,22 +578,26 @@ __global__ __launch_bounds__(CF_THREADS) void gp_composite_fwd_kernel(RasterDims
 }
 
 // ------------------------------------------------------------------------------------------------
-// composite backward, splat-parallel.  One wave per (tile, group of 8 pixel rows).  Lanes own
-// the 64 splats of the current batch (record in registers); the wave walks the group's pixels
-// uniformly.  For pixel p:  T_j(p) = T_in(p) * exclusive_prod_{k<j}(1-alpha_k)   (wave scan)
-//                           suffix_j(p) = Tot(p) - P_in(p) - inclusive_sum_{k<=j} s_k (wave scan)
-// with s_k = alpha_k T_k (c_k . dL_dpix + z_k dL_ddepth) and Tot(p) = (C(p) - T_final bg) . dL_dpix
-// + D(p) dL_ddepth from the forward outputs.  dL/dalpha_j = T_j (c_j.dLp + z_j dLd)
-// - (suffix_j + T_final bg.dLp) / (1 - alpha_j).  Each lane accumulates its splat's 10 gradient sums
-// in registers and issues 10 atomics per (splat, tile part) -- not per (splat, pixel).
+// composite backward, SPLAT-parallel.  One wave per (tile, 8x8 quadrant).  Lanes own the 64 splats of the
+// current batch (record in registers) and the wave walks the quadrant's pixels uniformly, two at a time with
+// v_pk_*_f32.  For pixel p and the batch's splats j (front to back):
+//     T_j(p)      = T_in(p) * prod_{k<j} (1 - alpha_k)                 (wave PRODUCT scan, v_mul_f32_dpp ladder)
+//     suffix_j(p) = rem_in(p) - sum_{k<=j} s_k,   s_k = alpha_k T_k (c_k . dL_dpix + z_k dL_ddepth)
+//                                                                      (wave SUM scan, v_add_f32_dpp ladder)
+//     dL/dalpha_j = T_j (c_j . dLp + z_j dLd) - (suffix_j + T_final bg . dLp) / (1 - alpha_j)
+// with rem_in(p) initialised from the forward outputs, (C(p) - T_final bg) . dLp + D(p) dLd, and (T_in, rem_in)
+// carried from batch to batch in LDS.  Each lane accumulates its splat's sums in registers:
+//   * colour / depth / opacity directly;
+//   * the geometric gradients as MOMENTS of h = dL/dG * G (sum h, sum h dx, sum h dx^2 per step; dy is constant
+//     along a pixel row, so the dy moments are folded in once per row) -- 5 packed ops per step instead of 14.
+// Batches are built from the forward's per-instance quadrant masks (qmask), so only splats whose alpha >= 1/255
+// footprint meets THIS quadrant are fetched, and lanes are always full.
+// Flush: scattered float atomics are the slowest thing this kernel could do (one L2 transaction per lane); the
+// wave transposes its 64 x 10 sums through LDS so that 16 consecutive lanes add to the 16 consecutive floats of ONE
+// Gaussian's 64-byte accumulator line -- an atomic instruction then touches 4 cache lines instead of 64.
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float lane63(float v) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63)); }
-
-// ---- v3: log-domain transmittance so that BOTH wave scans are sums, done as fused v_add_f32_dpp chains
-// (four interleaved scans per pixel pair: the interleave covers the 2-wait-state DPP hazard), conic
-// pre-scaled by log2(e) so G = exp2(power), contribution masks as {0,1} floats instead of branches,
-// per-pixel-pair constants packed for 128-bit LDS broadcast reads.
-//   L_in(p) = log2 T_in(p);  T_j = exp2(L_in + incl_j - own_j);  rem(p) = Tot - P_in;  suffix_j = rem - incl_j
+// inclusive wave SUM scan of two values: row_shr 1/2/4/8 inside each row of 16 lanes, then row_bcast 15 / 31 across
+// rows; the two chains are interleaved so each covers the other's DPP wait states.
 __device__ __forceinline__ void dpp_scan2_add(float& a, float& b) {
     asm volatile(
         "s_nop 1\n\t"
@@ -643,368 +647,12 @@ __device__ __forceinline__ void dpp_scan2_mul(float& a, float& b) {
 }
 
 
-template <bool HAS_DEPTH, int ROWS>
-__device__ __forceinline__ void gp_composite_bwd3_body(RasterDims d, const int2* __restrict__ ranges,
-                                                       const uint32_t* __restrict__ point_list, const float4* __restrict__ rec,
-                                                       const float* __restrict__ bg, const float* __restrict__ out_color,
-                                                       const float* __restrict__ out_depth, const float* __restrict__ final_T,
-                                                       const int32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpix,
-                                                       const float* __restrict__ dL_dpixdepth, float* __restrict__ g_mean2D,
-                                                       float* __restrict__ g_conic, float* __restrict__ g_opacity,
-                                                       float* __restrict__ g_color, float* __restrict__ g_depth,
-                                                       const uint32_t* __restrict__ order) {
-    // per pixel PAIR (two horizontally adjacent pixels):
-    __shared__ float4 s_v0[(ROWS * GP_TILE / 2)];   // dLr0 dLr1 dLg0 dLg1
-    __shared__ float4 s_v1[(ROWS * GP_TILE / 2)];   // dLb0 dLb1 tb0  tb1      (tb = T_final * bg . dL_dpix)
-    __shared__ float4 s_cy[(ROWS * GP_TILE / 2)];   // Lin0 Lin1 rem0 rem1     (carried between batches)
-    __shared__ int2 s_nc[(ROWS * GP_TILE / 2)];
-    __shared__ float2 s_dd[HAS_DEPTH ? (ROWS * GP_TILE / 2) : 1];   // dLd0 dLd1
-    const int parts = GP_TILE / ROWS;
-    const int part = blockIdx.x % parts;
-    const int tile = order ? (int)order[blockIdx.x / parts] : (int)(blockIdx.x / parts);
-    const int tx = tile % d.gx, ty = tile / d.gx;
-    const int lane = threadIdx.x;
-    const int2 range = ranges[tile];
-    const size_t HW = (size_t)d.H * d.W;
-    const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
-    int max_nc = 0;
-    for (int pr = lane; pr < ROWS * GP_TILE / 2; pr += 64) {   // one lane per pixel pair
 
-        const int px0 = tx * GP_TILE + 2 * (pr & 7), py = ty * GP_TILE + part * ROWS + (pr >> 3);
-        float dl[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-        float tb[2] = {0.f, 0.f}, rem[2] = {0.f, 0.f};
-        int nc[2] = {0, 0};
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int px = px0 + u;
-            if (px < d.W && py < d.H) {
-                const size_t pix = (size_t)py * d.W + px;
-                dl[u][0] = dL_dpix[pix]; dl[u][1] = dL_dpix[HW + pix]; dl[u][2] = dL_dpix[2 * HW + pix];
-                dl[u][3] = HAS_DEPTH ? dL_dpixdepth[pix] : 0.f;
-                tb[u] = final_T[pix] * (bg0 * dl[u][0] + bg1 * dl[u][1] + bg2 * dl[u][2]);
-                rem[u] = out_color[pix] * dl[u][0] + out_color[HW + pix] * dl[u][1] + out_color[2 * HW + pix] * dl[u][2] - tb[u];
-                if (HAS_DEPTH) rem[u] += out_depth[pix] * dl[u][3];
-                nc[u] = n_contrib[pix];
-            }
-        }
-        s_v0[pr] = make_float4(dl[0][0], dl[1][0], dl[0][1], dl[1][1]);
-        s_v1[pr] = make_float4(dl[0][2], dl[1][2], tb[0], tb[1]);
-        s_cy[pr] = make_float4(0.f, 0.f, rem[0], rem[1]);
-        s_nc[pr] = make_int2(nc[0], nc[1]);
-        if (HAS_DEPTH) s_dd[pr] = make_float2(dl[0][3], dl[1][3]);
-        max_nc = max(max_nc, max(nc[0], nc[1]));
-    }
-#pragma unroll
-    for (int dd = 32; dd >= 1; dd >>= 1) max_nc = max(max_nc, __shfl_xor(max_nc, dd));
-    __syncthreads();
-    const float halfW = 0.5f * (float)d.W, halfH = 0.5f * (float)d.H;
-    const int count = min(range.y - range.x, max_nc);
-    const float px_base = (float)(tx * GP_TILE), py_base = (float)(ty * GP_TILE + part * ROWS);
-    const float LOG2E = 1.4426950408889634f;
-    // software pipeline: the record gather of batch b+1 is issued before the pixel walk of batch b
-    uint32_t id_n = 0;
-    float4 q0_n = make_float4(0.f, 0.f, 0.f, 0.f), q1_n = q0_n, q2_n = q0_n;
-    if (lane < count) {
-        id_n = point_list[range.x + lane];
-        q0_n = rec[3 * (size_t)id_n]; q1_n = rec[3 * (size_t)id_n + 1]; q2_n = rec[3 * (size_t)id_n + 2];
-    }
-    for (int b0 = 0; b0 < count; b0 += 64) {
-        const int pos = b0 + lane;
-        const bool have = pos < count;
-        const uint32_t id = id_n;
-        const float4 q0 = q0_n, q1 = q1_n, q2 = q2_n;
-        if (pos + 64 < count) {
-            id_n = point_list[range.x + pos + 64];
-            q0_n = rec[3 * (size_t)id_n]; q1_n = rec[3 * (size_t)id_n + 1]; q2_n = rec[3 * (size_t)id_n + 2];
-        }
-        const float sx = q0.x - px_base, sy = q0.y - py_base;
-        const float As = q0.z * LOG2E, Bs = q0.w * LOG2E, Cs = q1.x * LOG2E;   // power in log2 units
-        const float op = have ? q1.y : 0.f, zdep = q1.z;
-        const float cxx = -2.f * q0.z, cxy = -q0.w, cyy = -2.f * q1.x;
-        const v2f cr = {q2.x, q2.x}, cg = {q2.y, q2.y}, cb = {q2.z, q2.z};
-        v2f a_mx = {0.f, 0.f}, a_my = {0.f, 0.f}, a_ca = {0.f, 0.f}, a_cb = {0.f, 0.f}, a_cc = {0.f, 0.f}, a_op = {0.f, 0.f},
-            a_r = {0.f, 0.f}, a_g = {0.f, 0.f}, a_b = {0.f, 0.f}, a_d = {0.f, 0.f};
-        float any_m = 0.f;
-#pragma unroll 1
-        for (int row = 0; row < ROWS; ++row) {
-            const float dy = sy - (float)row;
-            const float tB = Bs * dy, uC = (Cs * dy) * dy;
-#pragma unroll 1
-            for (int cp = 0; cp < GP_TILE / 2; ++cp) {
-                const int pr = row * (GP_TILE / 2) + cp;
-                const int2 nc = s_nc[pr];
-                if (max(nc.x, nc.y) <= b0) continue;   // uniform: both pixels finished before this batch
-                const float dx0 = sx - (float)(2 * cp);
-                const v2f dx = {dx0, dx0 - 1.f};
-                const v2f pw = {fmaf(dx.x, fmaf(As, dx.x, tB), uC), fmaf(dx.y, fmaf(As, dx.y, tB), uC)};
-                const v2f G = {__builtin_amdgcn_exp2f(fminf(pw.x, 0.f)), __builtin_amdgcn_exp2f(fminf(pw.y, 0.f))};
-                const v2f alpha = {fminf(0.99f, op * G.x), fminf(0.99f, op * G.y)};
-                const bool c0 = (pos < nc.x) && !(pw.x > 0.f) && !(alpha.x < 1.f / 255.f);
-                const bool c1 = (pos < nc.y) && !(pw.y > 0.f) && !(alpha.y < 1.f / 255.f);
-                if (!__any(c0 || c1)) continue;        // nobody in the wave touches either pixel
-                const v2f m = {c0 ? 1.f : 0.f, c1 ? 1.f : 0.f};
-                any_m = fmaxf(any_m, fmaxf(m.x, m.y));
-                const v2f am = alpha * m;
-                const v2f om = 1.f - am;
-                float l0 = __builtin_amdgcn_logf(om.x), l1 = __builtin_amdgcn_logf(om.y);   // log2, exactly 0 for om == 1
-                const float4 v0 = s_v0[pr], v1 = s_v1[pr], cy = s_cy[pr];
-                v2f cdot = cb * (v2f){v1.x, v1.y};
-                cdot = cg * (v2f){v0.z, v0.w} + cdot;
-                cdot = cr * (v2f){v0.x, v0.y} + cdot;
-                v2f dLd = {0.f, 0.f};
-                if (HAS_DEPTH) { const float2 t = s_dd[pr]; dLd.x = t.x; dLd.y = t.y; cdot = zdep * dLd + cdot; }
-                // T_j needs the EXCLUSIVE log-sum, s_j = alpha_j T_j cdot needs T_j: scan the logs first
-                float il0 = l0, il1 = l1;
-                dpp_scan2_add(il0, il1);
-                const v2f Tj = {__builtin_amdgcn_exp2f(cy.x + il0 - l0), __builtin_amdgcn_exp2f(cy.y + il1 - l1)};
-                const v2f w = am * Tj;
-                const v2f sv = w * cdot;
-                float is0 = sv.x, is1 = sv.y;
-                dpp_scan2_add(is0, is1);
-                const v2f rem = {cy.z, cy.w};
-                const v2f tbv = {v1.z, v1.w};
-                const v2f rom = {__builtin_amdgcn_rcpf(om.x), __builtin_amdgcn_rcpf(om.y)};
-                const v2f suffix = rem - (v2f){is0, is1};
-                const v2f dL_dalpha = (Tj * cdot - (suffix + tbv) * rom) * m;
-                a_r += w * (v2f){v0.x, v0.y}; a_g += w * (v2f){v0.z, v0.w}; a_b += w * (v2f){v1.x, v1.y};
-                if (HAS_DEPTH) a_d += w * dLd;
-                a_op += G * dL_dalpha;
-                const v2f dL_dG = op * dL_dalpha;
-                const v2f gdx = G * dx, gdy = G * dy;
-                a_mx += dL_dG * (-gdx * cxx - gdy * cxy);
-                a_my += dL_dG * (-gdy * cyy - gdx * cxy);
-                a_ca += (gdx * dx) * dL_dG;
-                a_cb += (gdx * dy) * dL_dG;
-                a_cc += (gdy * dy) * dL_dG;
-                // carry to the next batch
-                const float tl0 = lane63(il0), tl1 = lane63(il1), ts0 = lane63(is0), ts1 = lane63(is1);
-                if (lane == 0) s_cy[pr] = make_float4(cy.x + tl0, cy.y + tl1, cy.z - ts0, cy.w - ts1);
-            }
-        }
-        if (have && any_m > 0.f) {
-            atomicAdd(&g_mean2D[GP_ACC_STRIDE * (size_t)id], (a_mx.x + a_mx.y) * halfW);
-            atomicAdd(&g_mean2D[GP_ACC_STRIDE * (size_t)id + 1], (a_my.x + a_my.y) * halfH);
-            atomicAdd(&g_conic[GP_ACC_STRIDE * (size_t)id], -0.5f * (a_ca.x + a_ca.y));
-            atomicAdd(&g_conic[GP_ACC_STRIDE * (size_t)id + 1], -(a_cb.x + a_cb.y));
-            atomicAdd(&g_conic[GP_ACC_STRIDE * (size_t)id + 2], -0.5f * (a_cc.x + a_cc.y));
-            atomicAdd(&g_opacity[GP_ACC_STRIDE * (size_t)id], a_op.x + a_op.y);
-            atomicAdd(&g_color[GP_ACC_STRIDE * (size_t)id], a_r.x + a_r.y);
-            atomicAdd(&g_color[GP_ACC_STRIDE * (size_t)id + 1], a_g.x + a_g.y);
-            atomicAdd(&g_color[GP_ACC_STRIDE * (size_t)id + 2], a_b.x + a_b.y);
-            if (HAS_DEPTH) atomicAdd(&g_depth[GP_ACC_STRIDE * (size_t)id], a_d.x + a_d.y);
-        }
-        __syncthreads();
-    }
-}
-
-template <bool HAS_DEPTH, int ROWS>
-__device__ __forceinline__ void gp_composite_bwd4_body(RasterDims d, const int2* __restrict__ ranges,
-                                                       const uint32_t* __restrict__ point_list, const float4* __restrict__ rec,
-                                                       const float* __restrict__ bg, const float* __restrict__ out_color,
-                                                       const float* __restrict__ out_depth, const float* __restrict__ final_T,
-                                                       const int32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpix,
-                                                       const float* __restrict__ dL_dpixdepth, float* __restrict__ g_mean2D,
-                                                       float* __restrict__ g_conic, float* __restrict__ g_opacity,
-                                                       float* __restrict__ g_color, float* __restrict__ g_depth,
-                                                       const uint32_t* __restrict__ order) {
-    // per pixel PAIR (two horizontally adjacent pixels):
-    __shared__ float4 s_v0[(ROWS * GP_TILE / 2)];   // dLr0 dLr1 dLg0 dLg1
-    __shared__ float4 s_v1[(ROWS * GP_TILE / 2)];   // dLb0 dLb1 tb0  tb1      (tb = T_final * bg . dL_dpix)
-    __shared__ float4 s_cy[(ROWS * GP_TILE / 2)];   // Lin0 Lin1 rem0 rem1     (carried between batches)
-    __shared__ int2 s_nc[(ROWS * GP_TILE / 2)];
-    __shared__ float2 s_dd[HAS_DEPTH ? (ROWS * GP_TILE / 2) : 1];   // dLd0 dLd1
-    const int parts = GP_TILE / ROWS;
-    const int part = blockIdx.x % parts;
-    const int tile = order ? (int)order[blockIdx.x / parts] : (int)(blockIdx.x / parts);
-    const int tx = tile % d.gx, ty = tile / d.gx;
-    const int lane = threadIdx.x;
-    const int2 range = ranges[tile];
-    const size_t HW = (size_t)d.H * d.W;
-    const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
-    int max_nc = 0;
-    for (int pr = lane; pr < ROWS * GP_TILE / 2; pr += 64) {   // one lane per pixel pair
-
-        const int px0 = tx * GP_TILE + 2 * (pr & 7), py = ty * GP_TILE + part * ROWS + (pr >> 3);
-        float dl[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-        float tb[2] = {0.f, 0.f}, rem[2] = {0.f, 0.f};
-        int nc[2] = {0, 0};
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int px = px0 + u;
-            if (px < d.W && py < d.H) {
-                const size_t pix = (size_t)py * d.W + px;
-                dl[u][0] = dL_dpix[pix]; dl[u][1] = dL_dpix[HW + pix]; dl[u][2] = dL_dpix[2 * HW + pix];
-                dl[u][3] = HAS_DEPTH ? dL_dpixdepth[pix] : 0.f;
-                tb[u] = final_T[pix] * (bg0 * dl[u][0] + bg1 * dl[u][1] + bg2 * dl[u][2]);
-                rem[u] = out_color[pix] * dl[u][0] + out_color[HW + pix] * dl[u][1] + out_color[2 * HW + pix] * dl[u][2] - tb[u];
-                if (HAS_DEPTH) rem[u] += out_depth[pix] * dl[u][3];
-                nc[u] = n_contrib[pix];
-            }
-        }
-        s_v0[pr] = make_float4(dl[0][0], dl[1][0], dl[0][1], dl[1][1]);
-        s_v1[pr] = make_float4(dl[0][2], dl[1][2], tb[0], tb[1]);
-        s_cy[pr] = make_float4(0.f, 0.f, rem[0], rem[1]);
-        s_nc[pr] = make_int2(nc[0], nc[1]);
-        if (HAS_DEPTH) s_dd[pr] = make_float2(dl[0][3], dl[1][3]);
-        max_nc = max(max_nc, max(nc[0], nc[1]));
-    }
-#pragma unroll
-    for (int dd = 32; dd >= 1; dd >>= 1) max_nc = max(max_nc, __shfl_xor(max_nc, dd));
-    __syncthreads();
-    const float halfW = 0.5f * (float)d.W, halfH = 0.5f * (float)d.H;
-    const int count = min(range.y - range.x, max_nc);
-    const float px_base = (float)(tx * GP_TILE), py_base = (float)(ty * GP_TILE + part * ROWS);
-    const float LOG2E = 1.4426950408889634f;
-    // ---- compaction: only splats whose alpha >= 1/255 bounding box intersects THIS tile part enter a batch
-    // (stable, so depth order is kept); candidates are fetched 64 at a time, one fetch ahead of the pixel walk.
-    __shared__ float4 s_e0[128], s_e1[128], s_e2[128];
-    __shared__ int s_epos[128];
-    __shared__ uint32_t s_eid[128];
-    const float RX0 = px_base, RX1 = px_base + 15.f, RY0 = py_base, RY1 = py_base + (float)(ROWS - 1);
-    int qn = 0, src = 0;
-    uint32_t c_id = 0;
-    float4 k0 = make_float4(0.f, 0.f, 0.f, 0.f), k1 = k0, k2 = k0;
-    bool c_have = lane < count;
-    if (c_have) {
-        c_id = point_list[range.x + lane];
-        k0 = rec[3 * (size_t)c_id]; k1 = rec[3 * (size_t)c_id + 1]; k2 = rec[3 * (size_t)c_id + 2];
-    }
-    bool pending = count > 0;
-    while (true) {
-        while (qn < 64 && pending) {
-            bool relevant = false;
-            if (c_have) {
-                relevant = gp_splat_hits_rect(k0, k1, RX0, RX1, RY0, RY1);
-            }
-            const unsigned long long mk = __ballot(relevant);
-            const int slot = qn + (int)gp_mbcnt(mk);
-            if (relevant) { s_e0[slot] = k0; s_e1[slot] = k1; s_e2[slot] = k2; s_epos[slot] = src + lane; s_eid[slot] = c_id; }
-            qn += (int)__popcll(mk);
-            src += 64;
-            pending = src < count;
-            c_have = src + lane < count;
-            if (c_have) {
-                c_id = point_list[range.x + src + lane];
-                k0 = rec[3 * (size_t)c_id]; k1 = rec[3 * (size_t)c_id + 1]; k2 = rec[3 * (size_t)c_id + 2];
-            }
-        }
-        if (qn == 0) break;
-        __syncthreads();
-        const int nb = min(64, qn);
-        const bool have = lane < nb;
-        const int b0 = s_epos[0];                       // smallest list position in this batch (uniform)
-        const int pos = have ? s_epos[lane] : 0x7fffffff;
-        const uint32_t id = have ? s_eid[lane] : 0u;
-        float4 q0 = make_float4(0.f, 0.f, 0.f, 0.f), q1 = q0, q2 = q0;
-        if (have) { q0 = s_e0[lane]; q1 = s_e1[lane]; q2 = s_e2[lane]; }
-        {   // pop the batch: entries [64, qn) move to the front
-            float4 m0 = q0, m1 = q1, m2 = q2; int mp = 0; uint32_t mi = 0;
-            const bool mv = lane + 64 < qn;
-            if (mv) { m0 = s_e0[lane + 64]; m1 = s_e1[lane + 64]; m2 = s_e2[lane + 64]; mp = s_epos[lane + 64]; mi = s_eid[lane + 64]; }
-            __syncthreads();
-            if (mv) { s_e0[lane] = m0; s_e1[lane] = m1; s_e2[lane] = m2; s_epos[lane] = mp; s_eid[lane] = mi; }
-            qn -= nb;
-        }
-        const float sx = q0.x - px_base, sy = q0.y - py_base;
-        const float As = q0.z * LOG2E, Bs = q0.w * LOG2E, Cs = q1.x * LOG2E;   // power in log2 units
-        const float op = have ? q1.y : 0.f, zdep = q1.z;
-        const float cxx = -2.f * q0.z, cxy = -q0.w, cyy = -2.f * q1.x;
-        const v2f cr = {q2.x, q2.x}, cg = {q2.y, q2.y}, cb = {q2.z, q2.z};
-        v2f a_mx = {0.f, 0.f}, a_my = {0.f, 0.f}, a_ca = {0.f, 0.f}, a_cb = {0.f, 0.f}, a_cc = {0.f, 0.f}, a_op = {0.f, 0.f},
-            a_r = {0.f, 0.f}, a_g = {0.f, 0.f}, a_b = {0.f, 0.f}, a_d = {0.f, 0.f};
-        float any_m = 0.f;
-#pragma unroll 1
-        for (int row = 0; row < ROWS; ++row) {
-            const float dy = sy - (float)row;
-            const float tB = Bs * dy, uC = (Cs * dy) * dy;
-#pragma unroll 1
-            for (int cp = 0; cp < GP_TILE / 2; ++cp) {
-                const int pr = row * (GP_TILE / 2) + cp;
-                const int2 nc = s_nc[pr];
-                if (max(nc.x, nc.y) <= b0) continue;   // uniform: both pixels finished before this batch
-                const float dx0 = sx - (float)(2 * cp);
-                const v2f dx = {dx0, dx0 - 1.f};
-                const v2f pw = {fmaf(dx.x, fmaf(As, dx.x, tB), uC), fmaf(dx.y, fmaf(As, dx.y, tB), uC)};
-                const v2f G = {__builtin_amdgcn_exp2f(fminf(pw.x, 0.f)), __builtin_amdgcn_exp2f(fminf(pw.y, 0.f))};
-                const v2f alpha = {fminf(0.99f, op * G.x), fminf(0.99f, op * G.y)};
-                const bool c0 = (pos < nc.x) && !(pw.x > 0.f) && !(alpha.x < 1.f / 255.f);
-                const bool c1 = (pos < nc.y) && !(pw.y > 0.f) && !(alpha.y < 1.f / 255.f);
-                if (!__any(c0 || c1)) continue;        // nobody in the wave touches either pixel
-                const v2f m = {c0 ? 1.f : 0.f, c1 ? 1.f : 0.f};
-                any_m = fmaxf(any_m, fmaxf(m.x, m.y));
-                const v2f am = alpha * m;
-                const v2f om = 1.f - am;
-                float l0 = __builtin_amdgcn_logf(om.x), l1 = __builtin_amdgcn_logf(om.y);   // log2, exactly 0 for om == 1
-                const float4 v0 = s_v0[pr], v1 = s_v1[pr], cy = s_cy[pr];
-                v2f cdot = cb * (v2f){v1.x, v1.y};
-                cdot = cg * (v2f){v0.z, v0.w} + cdot;
-                cdot = cr * (v2f){v0.x, v0.y} + cdot;
-                v2f dLd = {0.f, 0.f};
-                if (HAS_DEPTH) { const float2 t = s_dd[pr]; dLd.x = t.x; dLd.y = t.y; cdot = zdep * dLd + cdot; }
-                // T_j needs the EXCLUSIVE log-sum, s_j = alpha_j T_j cdot needs T_j: scan the logs first
-                float il0 = l0, il1 = l1;
-                dpp_scan2_add(il0, il1);
-                const v2f Tj = {__builtin_amdgcn_exp2f(cy.x + il0 - l0), __builtin_amdgcn_exp2f(cy.y + il1 - l1)};
-                const v2f w = am * Tj;
-                const v2f sv = w * cdot;
-                float is0 = sv.x, is1 = sv.y;
-                dpp_scan2_add(is0, is1);
-                const v2f rem = {cy.z, cy.w};
-                const v2f tbv = {v1.z, v1.w};
-                const v2f rom = {__builtin_amdgcn_rcpf(om.x), __builtin_amdgcn_rcpf(om.y)};
-                const v2f suffix = rem - (v2f){is0, is1};
-                const v2f dL_dalpha = (Tj * cdot - (suffix + tbv) * rom) * m;
-                a_r += w * (v2f){v0.x, v0.y}; a_g += w * (v2f){v0.z, v0.w}; a_b += w * (v2f){v1.x, v1.y};
-                if (HAS_DEPTH) a_d += w * dLd;
-                a_op += G * dL_dalpha;
-                const v2f dL_dG = op * dL_dalpha;
-                const v2f gdx = G * dx, gdy = G * dy;
-                a_mx += dL_dG * (-gdx * cxx - gdy * cxy);
-                a_my += dL_dG * (-gdy * cyy - gdx * cxy);
-                a_ca += (gdx * dx) * dL_dG;
-                a_cb += (gdx * dy) * dL_dG;
-                a_cc += (gdy * dy) * dL_dG;
-                // carry to the next batch
-                const float tl0 = lane63(il0), tl1 = lane63(il1), ts0 = lane63(is0), ts1 = lane63(is1);
-                if (lane == 0) s_cy[pr] = make_float4(cy.x + tl0, cy.y + tl1, cy.z - ts0, cy.w - ts1);
-            }
-        }
-        if (have && any_m > 0.f) {
-            atomicAdd(&g_mean2D[GP_ACC_STRIDE * (size_t)id], (a_mx.x + a_mx.y) * halfW);
-            atomicAdd(&g_mean2D[GP_ACC_STRIDE * (size_t)id + 1], (a_my.x + a_my.y) * halfH);
-            atomicAdd(&g_conic[GP_ACC_STRIDE * (size_t)id], -0.5f * (a_ca.x + a_ca.y));
-            atomicAdd(&g_conic[GP_ACC_STRIDE * (size_t)id + 1], -(a_cb.x + a_cb.y));
-            atomicAdd(&g_conic[GP_ACC_STRIDE * (size_t)id + 2], -0.5f * (a_cc.x + a_cc.y));
-            atomicAdd(&g_opacity[GP_ACC_STRIDE * (size_t)id], a_op.x + a_op.y);
-            atomicAdd(&g_color[GP_ACC_STRIDE * (size_t)id], a_r.x + a_r.y);
-            atomicAdd(&g_color[GP_ACC_STRIDE * (size_t)id + 1], a_g.x + a_g.y);
-            atomicAdd(&g_color[GP_ACC_STRIDE * (size_t)id + 2], a_b.x + a_b.y);
-            if (HAS_DEPTH) atomicAdd(&g_depth[GP_ACC_STRIDE * (size_t)id], a_d.x + a_d.y);
-        }
-        __syncthreads();
-    }
-}
-
-#define CB_ARGS RasterDims d, const int2* __restrict__ ranges, const uint32_t* __restrict__ point_list, \
-    const float4* __restrict__ rec, const float* __restrict__ bg, const float* __restrict__ out_color, \
-    const float* __restrict__ out_depth, const float* __restrict__ final_T, const int32_t* __restrict__ n_contrib, \
-    const float* __restrict__ dL_dpix, const float* __restrict__ dL_dpixdepth, float* __restrict__ g_mean2D, \
-    float* __restrict__ g_conic, float* __restrict__ g_opacity, float* __restrict__ g_color, float* __restrict__ g_depth, \
-    const uint32_t* __restrict__ order
-#define CB_PASS d, ranges, point_list, rec, bg, out_color, out_depth, final_T, n_contrib, dL_dpix, dL_dpixdepth, g_mean2D, \
-    g_conic, g_opacity, g_color, g_depth, order
-__global__ __launch_bounds__(64) void gp_composite_bwd3_kernel(CB_ARGS) { gp_composite_bwd3_body<false, 8>(CB_PASS); }
-__global__ __launch_bounds__(64) void gp_composite_bwd3_depth_kernel(CB_ARGS) { gp_composite_bwd3_body<true, 8>(CB_PASS); }
-__global__ __launch_bounds__(64) void gp_composite_bwd4_kernel(CB_ARGS) { gp_composite_bwd4_body<false, 8>(CB_PASS); }
-__global__ __launch_bounds__(64) void gp_composite_bwd4_depth_kernel(CB_ARGS) { gp_composite_bwd4_body<true, 8>(CB_PASS); }
-
-// ---- v5: v4 + the per-pixel-pair constants come from a prepared, read-only buffer through the SCALAR cache.
-// Every lane of the wave needs the same 14 values per pixel pair (dL/dpixel of both pixels, the background term,
-// n_contrib, dL/ddepth): as LDS broadcast reads they cost 4 LDS round trips per step and 14 VGPRs; as
-// s_load_dwordx8/x4 (prefetched one step ahead) they cost none of either and feed v_pk_* directly as SGPR pairs.
-// gp_bwd_pixprep_kernel writes the buffer: per (tile, part) 64 pairs x 16 dwords
+// Per-pixel-pair constants, prepared once per backward by gp_bwd_pixprep_kernel (coalesced, ~0.03 ms) so that the
+// composite waves start with one 64-byte load per lane instead of 14 strided ones:
+// per (tile, quadrant) GP_BWD_PAIRS pairs x 16 dwords
 //   [0..3] dLr0 dLr1 dLg0 dLg1  [4..7] dLb0 dLb1 tb0 tb1  [8,9] nc0 nc1  [10,11] rem0 rem1  [12,13] dLd0 dLd1
-// Only the running (log2 T, remaining suffix) pair stays in LDS: it is carried from batch to batch.
+// (tb = T_final * bg . dL_dpix, nc = n_contrib, rem = initial remaining suffix)
 struct GpPixPair { float v[16]; };
 
 template <int ROWS, int COLS>
@@ -1054,16 +702,13 @@ __global__ __launch_bounds__(256) void gp_bwd_pixprep_kernel(RasterDims d, const
     gp_bwd_pixprep_body<GP_BWD_ROWS, GP_BWD_COLS>(d, bg, out_color, out_depth, final_T, n_contrib, dL_dpix, dL_dpixdepth, pp);
 }
 
-__device__ int g_abl = 0;
-extern "C" void gp_set_abl(int v) { hipMemcpyToSymbol(HIP_SYMBOL(g_abl), &v, sizeof(int)); }
 template <bool HAS_DEPTH, int ROWS, int COLS>
-__device__ __forceinline__ void gp_composite_bwd5_body(RasterDims d, const int2* __restrict__ ranges,
+__device__ __forceinline__ void gp_composite_bwd_body(RasterDims d, const int2* __restrict__ ranges,
                                                        const uint32_t* __restrict__ point_list, const uint8_t* __restrict__ qmask,
                                                        const float4* __restrict__ rec, const GpPixPair* __restrict__ pp, float* __restrict__ g_mean2D,
                                                        float* __restrict__ g_conic, float* __restrict__ g_opacity,
                                                        float* __restrict__ g_color, float* __restrict__ g_depth,
                                                        const uint32_t* __restrict__ order) {
-    const int abl = g_abl;
     constexpr int PAIRS = ROWS * COLS / 2;
     static_assert(PAIRS <= 64, "one lane per pixel pair in the prologue");
     __shared__ float4 s_cy[PAIRS];   // Tin0 Tin1 rem0 rem1     (carried between batches)
@@ -1175,7 +820,7 @@ __device__ __forceinline__ void gp_composite_bwd5_body(RasterDims d, const int2*
         float S_x = 0.f, S_y = 0.f, S_xy = 0.f, S_yy = 0.f;
         float any_m = 0.f;
 #pragma unroll 1
-        for (int row = 0; row < ((abl & 32) ? 0 : ROWS); ++row) {
+        for (int row = 0; row < ROWS; ++row) {
             const float dy = sy - (float)row;
             const float tB = Bs * dy, uC = (Cs * dy) * dy;
             v2f r_h = {0.f, 0.f}, r_hx = {0.f, 0.f};
@@ -1193,10 +838,10 @@ __device__ __forceinline__ void gp_composite_bwd5_body(RasterDims d, const int2*
                 const v2f G = {__builtin_amdgcn_exp2f(fminf(pw.x, 0.f)), __builtin_amdgcn_exp2f(fminf(pw.y, 0.f))};
                 const v2f alpha = {fminf(0.99f, op * G.x), fminf(0.99f, op * G.y)};
                 const int ncx = nc.x, ncy = nc.y;
-                if (max(ncx, ncy) > b0 && !(abl & 64)) {   // uniform: otherwise both pixels finished before this batch
+                if (max(ncx, ncy) > b0) {   // uniform: otherwise both pixels finished before this batch
                     const bool c0 = (pos < ncx) && !(pw.x > 0.f) && !(alpha.x < 1.f / 255.f);
                     const bool c1 = (pos < ncy) && !(pw.y > 0.f) && !(alpha.y < 1.f / 255.f);
-                    if (__any(c0 || c1) && !(abl & 128)) {   // otherwise nobody in the wave touches either pixel
+                    if (__any(c0 || c1)) {   // otherwise nobody in the wave touches either pixel
                         const v2f m = {c0 ? 1.f : 0.f, c1 ? 1.f : 0.f};
                         any_m = fmaxf(any_m, fmaxf(m.x, m.y));
                         const v2f am = alpha * m;
@@ -1209,18 +854,17 @@ __device__ __forceinline__ void gp_composite_bwd5_body(RasterDims d, const int2*
                         // T_j = T_in * prod_{k<j} (1 - alpha_k): inclusive product scan, then divide the own factor out
                         const v2f rom = {__builtin_amdgcn_rcpf(om.x), __builtin_amdgcn_rcpf(om.y)};
                         float il0 = om.x, il1 = om.y;
-                        if (!(abl & 1)) dpp_scan2_mul(il0, il1);
+                        dpp_scan2_mul(il0, il1);
                         const v2f Tnext = (v2f){cy.x, cy.y} * (v2f){il0, il1};    // transmittance AFTER splat j
                         const v2f Tj = Tnext * rom;
                         const v2f w = am * Tj;
                         const v2f sv = w * cdot;
                         float is0 = sv.x, is1 = sv.y;
-                        if (!(abl & 2)) dpp_scan2_add(is0, is1);
+                        dpp_scan2_add(is0, is1);
                         const v2f rem = {cy.z, cy.w};
                         const v2f tbv = {v1.z, v1.w};
                         const v2f suffix = rem - (v2f){is0, is1};
                         const v2f dL_dalpha = (Tj * cdot - (suffix + tbv) * rom) * m;
-                        if (!(abl & 8)) {
                         a_r += w * (v2f){v0.x, v0.y}; a_g += w * (v2f){v0.z, v0.w}; a_b += w * (v2f){v1.x, v1.y};
                         if (HAS_DEPTH) a_d += w * dLd;
                         const v2f gda = G * dL_dalpha;
@@ -1230,11 +874,8 @@ __device__ __forceinline__ void gp_composite_bwd5_body(RasterDims d, const int2*
                         r_h += h;
                         r_hx += hx;
                         s_xx += hx * dx;
-                        } else { a_r += dL_dalpha; }
                         // carry to the next batch
-                        if (!(abl & 4)) {
                         if (lane == 63) s_cy[pr] = make_float4(Tnext.x, Tnext.y, cy.z - is0, cy.w - is1);
-                        }
                     }
                 }
             }
@@ -1248,7 +889,7 @@ __device__ __forceinline__ void gp_composite_bwd5_body(RasterDims d, const int2*
         }
         // flush: transpose through LDS so that 16 consecutive lanes add to the 16 consecutive floats of ONE
         // Gaussian's accumulator line -- an atomic instruction then touches 4 cache lines instead of 64.
-        if (!(abl & 16)) {
+        {
             const bool mine = have && any_m > 0.f;
             float* fl = (float*)&s_fl[0][0];        // [64 splats][4]: comps 0..3
             float* fm = (float*)&s_fl[1][0];        //                 comps 4..7
@@ -1275,15 +916,15 @@ __device__ __forceinline__ void gp_composite_bwd5_body(RasterDims d, const int2*
         __builtin_amdgcn_wave_barrier();
     }
 }
-#define CB5_ARGS RasterDims d, const int2* __restrict__ ranges, const uint32_t* __restrict__ point_list, \
+#define CB_ARGS RasterDims d, const int2* __restrict__ ranges, const uint32_t* __restrict__ point_list, \
     const uint8_t* __restrict__ qmask, const float4* __restrict__ rec, const GpPixPair* __restrict__ pp, float* __restrict__ g_mean2D, \
     float* __restrict__ g_conic, float* __restrict__ g_opacity, float* __restrict__ g_color, float* __restrict__ g_depth, \
     const uint32_t* __restrict__ order
-__global__ __launch_bounds__(64) void gp_composite_bwd5_kernel(CB5_ARGS) {
-    gp_composite_bwd5_body<false, GP_BWD_ROWS, GP_BWD_COLS>(d, ranges, point_list, qmask, rec, pp, g_mean2D, g_conic, g_opacity, g_color, g_depth, order);
+__global__ __launch_bounds__(64) void gp_composite_bwd_kernel(CB_ARGS) {
+    gp_composite_bwd_body<false, GP_BWD_ROWS, GP_BWD_COLS>(d, ranges, point_list, qmask, rec, pp, g_mean2D, g_conic, g_opacity, g_color, g_depth, order);
 }
-__global__ __launch_bounds__(64) void gp_composite_bwd5_depth_kernel(CB5_ARGS) {
-    gp_composite_bwd5_body<true, GP_BWD_ROWS, GP_BWD_COLS>(d, ranges, point_list, qmask, rec, pp, g_mean2D, g_conic, g_opacity, g_color, g_depth, order);
+__global__ __launch_bounds__(64) void gp_composite_bwd_depth_kernel(CB_ARGS) {
+    gp_composite_bwd_body<true, GP_BWD_ROWS, GP_BWD_COLS>(d, ranges, point_list, qmask, rec, pp, g_mean2D, g_conic, g_opacity, g_color, g_depth, order);
 }
 
 // ------------------------------------------------------------------------------------------------
