@@ -14,6 +14,7 @@ import torch  # noqa: F401  (must be imported first: libgp_hip.so binds to the H
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libgp_hip.so")
 
+GP_LOSS_SUM_SLOTS = 256   # include/gp_hip.h
 GP_BUF_GEOM, GP_BUF_BINNING, GP_BUF_IMAGE, GP_BUF_TEMP = 0, 1, 2, 3
 
 ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_int, C.c_size_t)

@@ -14,6 +14,7 @@
 #define LH 5               // window half width
 #define LE (LT + 2 * LH)   // staged tile edge (42)
 #define LP (LE + 1)        // padded LDS row
+#define LHP (LT + 1)       // padded row of the horizontally filtered maps
 
 struct Win11 { float w[11]; };
 
@@ -32,7 +33,7 @@ __global__ __launch_bounds__(256) void gp_l1_ssim_fwd_kernel(const float* __rest
                                                             int H, int W, Win11 win, double* __restrict__ sums,
                                                             float* __restrict__ dmap) {
     __shared__ float s_a[LE][LP], s_b[LE][LP];
-    __shared__ float s_h[5][LE][LT];
+    __shared__ float s_h[5][LE][LHP];
     __shared__ float s_red[4];
     const int tid = threadIdx.x;
     const int tx0 = blockIdx.x * LT, ty0 = blockIdx.y * LT, ch = blockIdx.z;
@@ -47,53 +48,78 @@ __global__ __launch_bounds__(256) void gp_l1_ssim_fwd_kernel(const float* __rest
         s_b[y][x] = in ? b_img[(size_t)gy * W + gx] : 0.f;
     }
     __syncthreads();
-    for (int i = tid; i < LE * LT; i += 256) {
-        const int y = i / LT, x = i - y * LT;
-        float m1 = 0.f, m2 = 0.f, aa = 0.f, bb = 0.f, ab = 0.f;
+    // horizontal pass: a thread owns 8 consecutive outputs of one staged row -- 18 + 18 LDS reads feed 8 x 5 outputs
+    // (a sliding window in registers instead of 22 reads per output).  Row strides 43 / 33 keep every access conflict-free.
+    if (tid < LE * 4) {
+        const int y = tid >> 2, x0 = (tid & 3) * 8;
+        float a[18], b[18], aa[18], bb[18], ab[18];
 #pragma unroll
-        for (int k = 0; k < 11; ++k) {
-            const float a = s_a[y][x + k], b = s_b[y][x + k], w = win.w[k];
-            m1 = fmaf(w, a, m1); m2 = fmaf(w, b, m2);
-            aa = fmaf(w, a * a, aa); bb = fmaf(w, b * b, bb); ab = fmaf(w, a * b, ab);
+        for (int j = 0; j < 18; ++j) {
+            a[j] = s_a[y][x0 + j]; b[j] = s_b[y][x0 + j];
+            aa[j] = a[j] * a[j]; bb[j] = b[j] * b[j]; ab[j] = a[j] * b[j];
         }
-        s_h[0][y][x] = m1; s_h[1][y][x] = m2; s_h[2][y][x] = aa; s_h[3][y][x] = bb; s_h[4][y][x] = ab;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float m1 = 0.f, m2 = 0.f, saa = 0.f, sbb = 0.f, sab = 0.f;
+#pragma unroll
+            for (int k = 0; k < 11; ++k) {
+                const float w = win.w[k];
+                m1 = fmaf(w, a[e + k], m1); m2 = fmaf(w, b[e + k], m2);
+                saa = fmaf(w, aa[e + k], saa); sbb = fmaf(w, bb[e + k], sbb); sab = fmaf(w, ab[e + k], sab);
+            }
+            s_h[0][y][x0 + e] = m1; s_h[1][y][x0 + e] = m2; s_h[2][y][x0 + e] = saa; s_h[3][y][x0 + e] = sbb; s_h[4][y][x0 + e] = sab;
+        }
     }
     __syncthreads();
+    // vertical pass: a thread owns 4 consecutive outputs of one column (14 reads per map feed 4 outputs)
     float l1 = 0.f, ss = 0.f;
     const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
-    for (int i = tid; i < LT * LT; i += 256) {
-        const int y = i / LT, x = i - y * LT;
-        const int gy = ty0 + y, gx = tx0 + x;
-        if (gy >= H || gx >= W) continue;
-        float mu1 = 0.f, mu2 = 0.f, aa = 0.f, bb = 0.f, ab = 0.f;
+    {
+        const int x = tid & 31, y0 = (tid >> 5) * 4;
+        float o[5][4];
 #pragma unroll
-        for (int k = 0; k < 11; ++k) {
-            const float w = win.w[k];
-            mu1 = fmaf(w, s_h[0][y + k][x], mu1); mu2 = fmaf(w, s_h[1][y + k][x], mu2);
-            aa = fmaf(w, s_h[2][y + k][x], aa); bb = fmaf(w, s_h[3][y + k][x], bb); ab = fmaf(w, s_h[4][y + k][x], ab);
+        for (int q = 0; q < 5; ++q) {
+            float v[14];
+#pragma unroll
+            for (int j = 0; j < 14; ++j) v[j] = s_h[q][y0 + j][x];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float acc = 0.f;
+#pragma unroll
+                for (int k = 0; k < 11; ++k) acc = fmaf(win.w[k], v[e + k], acc);
+                o[q][e] = acc;
+            }
         }
-        const float mu1s = mu1 * mu1, mu2s = mu2 * mu2, mu12 = mu1 * mu2;
-        const float s11 = aa - mu1s, s22 = bb - mu2s, s12 = ab - mu12;
-        const float N1 = 2.f * mu12 + C1, N2 = 2.f * s12 + C2, D1 = mu1s + mu2s + C1, D2 = s11 + s22 + C2;
-        const float inv = 1.f / (D1 * D2);
-        const float ssim = N1 * N2 * inv;
-        ss += ssim;
-        l1 += fabsf(s_a[y + LH][x + LH] - s_b[y + LH][x + LH]);
-        if (dmap) {
-            const size_t o = ch * HW + (size_t)gy * W + gx;
-            // d/dmu1 (total, through s11 = aa - mu1^2 and s12 = ab - mu1 mu2)
-            const float dmu1 = (2.f * mu2 * N2 - 2.f * mu2 * N1) * inv - ssim * (2.f * mu1 * D2 - 2.f * mu1 * D1) * inv;
-            dmap[o] = dmu1;
-            dmap[3 * HW + o] = -ssim / D2;        // d/d conv(a^2)
-            dmap[6 * HW + o] = 2.f * N1 * inv;    // d/d conv(a b)
+        const int gx = tx0 + x;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int y = y0 + e, gy = ty0 + y;
+            if (gy >= H || gx >= W) continue;
+            const float mu1 = o[0][e], mu2 = o[1][e], aa = o[2][e], bb = o[3][e], ab = o[4][e];
+            const float mu1s = mu1 * mu1, mu2s = mu2 * mu2, mu12 = mu1 * mu2;
+            const float s11 = aa - mu1s, s22 = bb - mu2s, s12 = ab - mu12;
+            const float N1 = 2.f * mu12 + C1, N2 = 2.f * s12 + C2, D1 = mu1s + mu2s + C1, D2 = s11 + s22 + C2;
+            const float inv = 1.f / (D1 * D2);
+            const float ssim = N1 * N2 * inv;
+            ss += ssim;
+            l1 += fabsf(s_a[y + LH][x + LH] - s_b[y + LH][x + LH]);
+            if (dmap) {
+                const size_t oo = ch * HW + (size_t)gy * W + gx;
+                // d/dmu1 (total, through s11 = aa - mu1^2 and s12 = ab - mu1 mu2)
+                const float dmu1 = (2.f * mu2 * N2 - 2.f * mu2 * N1) * inv - ssim * (2.f * mu1 * D2 - 2.f * mu1 * D1) * inv;
+                dmap[oo] = dmu1;
+                dmap[3 * HW + oo] = -ssim / D2;        // d/d conv(a^2)
+                dmap[6 * HW + oo] = 2.f * N1 * inv;    // d/d conv(a b)
+            }
         }
     }
     const float l1_tot = block_sum_256(l1, s_red);
     __syncthreads();
     const float ss_tot = block_sum_256(ss, s_red);
     if (tid == 0) {
-        atomicAdd(&sums[0], (double)l1_tot);
-        atomicAdd(&sums[1], (double)ss_tot);
+        const unsigned slot = (blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) % GP_LOSS_SUM_SLOTS;
+        atomicAdd(&sums[2 * slot], (double)l1_tot);
+        atomicAdd(&sums[2 * slot + 1], (double)ss_tot);
     }
 }
 
@@ -103,7 +129,7 @@ __global__ __launch_bounds__(256) void gp_l1_ssim_bwd_kernel(const float* __rest
                                                             float lambda, const float* __restrict__ upstream,
                                                             float* __restrict__ dimg) {
     __shared__ float s_m[3][LE][LP];
-    __shared__ float s_h[3][LE][LT];
+    __shared__ float s_h[3][LE][LHP];
     const int tid = threadIdx.x;
     const int tx0 = blockIdx.x * LT, ty0 = blockIdx.y * LT, ch = blockIdx.z;
     const size_t HW = (size_t)H * W;
@@ -117,34 +143,52 @@ __global__ __launch_bounds__(256) void gp_l1_ssim_bwd_kernel(const float* __rest
         s_m[2][y][x] = in ? dmap[6 * HW + o] : 0.f;
     }
     __syncthreads();
-    for (int i = tid; i < LE * LT; i += 256) {
-        const int y = i / LT, x = i - y * LT;
-        float h0 = 0.f, h1 = 0.f, h2 = 0.f;
+    if (tid < LE * 4) {   // horizontal pass, 8 outputs per thread (see the forward kernel)
+        const int y = tid >> 2, x0 = (tid & 3) * 8;
 #pragma unroll
-        for (int k = 0; k < 11; ++k) {
-            const float w = win.w[k];
-            h0 = fmaf(w, s_m[0][y][x + k], h0); h1 = fmaf(w, s_m[1][y][x + k], h1); h2 = fmaf(w, s_m[2][y][x + k], h2);
+        for (int q = 0; q < 3; ++q) {
+            float v[18];
+#pragma unroll
+            for (int j = 0; j < 18; ++j) v[j] = s_m[q][y][x0 + j];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float acc = 0.f;
+#pragma unroll
+                for (int k = 0; k < 11; ++k) acc = fmaf(win.w[k], v[e + k], acc);
+                s_h[q][y][x0 + e] = acc;
+            }
         }
-        s_h[0][y][x] = h0; s_h[1][y][x] = h1; s_h[2][y][x] = h2;
     }
     __syncthreads();
     const float g = upstream ? upstream[0] : 1.f;
     const float inv_n = 1.f / (3.f * (float)HW);
-    for (int i = tid; i < LT * LT; i += 256) {
-        const int y = i / LT, x = i - y * LT;
-        const int gy = ty0 + y, gx = tx0 + x;
-        if (gy >= H || gx >= W) continue;
-        float c0 = 0.f, c1 = 0.f, c2 = 0.f;
+    {   // vertical pass, 4 outputs per thread
+        const int x = tid & 31, y0 = (tid >> 5) * 4;
+        float o[3][4];
 #pragma unroll
-        for (int k = 0; k < 11; ++k) {
-            const float w = win.w[k];
-            c0 = fmaf(w, s_h[0][y + k][x], c0); c1 = fmaf(w, s_h[1][y + k][x], c1); c2 = fmaf(w, s_h[2][y + k][x], c2);
+        for (int q = 0; q < 3; ++q) {
+            float v[14];
+#pragma unroll
+            for (int j = 0; j < 14; ++j) v[j] = s_h[q][y0 + j][x];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float acc = 0.f;
+#pragma unroll
+                for (int k = 0; k < 11; ++k) acc = fmaf(win.w[k], v[e + k], acc);
+                o[q][e] = acc;
+            }
         }
-        const size_t o = ch * HW + (size_t)gy * W + gx;
-        const float a = img[o], b = gt[o];
-        const float d = a - b;
-        const float sgn = (d > 0.f) ? 1.f : ((d < 0.f) ? -1.f : 0.f);
-        dimg[o] = g * inv_n * ((1.f - lambda) * sgn - lambda * (c0 + 2.f * a * c1 + b * c2));
+        const int gx = tx0 + x;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int gy = ty0 + y0 + e;
+            if (gy >= H || gx >= W) continue;
+            const size_t oo = ch * HW + (size_t)gy * W + gx;
+            const float a = img[oo], b = gt[oo];
+            const float d = a - b;
+            const float sgn = (d > 0.f) ? 1.f : ((d < 0.f) ? -1.f : 0.f);
+            dimg[oo] = g * inv_n * ((1.f - lambda) * sgn - lambda * (o[0][e] + 2.f * a * o[1][e] + b * o[2][e]));
+        }
     }
 }
 
@@ -245,7 +289,9 @@ __global__ __launch_bounds__(256) void gp_adam_multi_kernel(AdamTable t, float b
 
 // loss = (1-lam) * sums[0]/n + lam * (1 - sums[1]/n)   (one thread; keeps the scalar on the device)
 __global__ void gp_loss_finalize_kernel(const double* __restrict__ sums, double n, float lambda, float* __restrict__ loss) {
-    loss[0] = (float)((1.0 - (double)lambda) * sums[0] / n + (double)lambda * (1.0 - sums[1] / n));
+    double s0 = 0.0, s1 = 0.0;
+    for (int k = 0; k < GP_LOSS_SUM_SLOTS; ++k) { s0 += sums[2 * k]; s1 += sums[2 * k + 1]; }   // fixed order
+    loss[0] = (float)((1.0 - (double)lambda) * s0 / n + (double)lambda * (1.0 - s1 / n));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -265,7 +311,7 @@ extern "C" int gp_loss_l1_ssim_forward(const float* img, const float* gt, int32_
     hipStream_t s = (hipStream_t)stream_;
     if (!img || !gt || !sums) GP_FAIL("null argument");
     if (channels != 3 || H <= 0 || W <= 0) GP_FAIL("expects a [3,H,W] image (got C=%d H=%d W=%d)", channels, H, W);
-    GP_HIP_CHECK(hipMemsetAsync(sums, 0, 2 * sizeof(double), s));
+    GP_HIP_CHECK(hipMemsetAsync(sums, 0, 2 * GP_LOSS_SUM_SLOTS * sizeof(double), s));
     GpProfScope _p("l1_ssim_fwd", s);
     hipLaunchKernelGGL(gp_l1_ssim_fwd_kernel, dim3((W + LT - 1) / LT, (H + LT - 1) / LT, 3), dim3(256), 0, s, img, gt, H, W,
                        make_window(), sums, dmaps);

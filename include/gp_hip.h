@@ -220,13 +220,16 @@ int gp_activations_backward(int64_t n, const float* scaling_raw, const float* op
 
 /* ---- loss + optimizer (the steps right after the render in every training iteration) ---------- */
 
-/* sums[0] = sum |img - gt|, sums[1] = sum of the SSIM map (11x11 Gaussian window, sigma 1.5, zero
- * padding) over a [3,H,W] image pair [REF utils/loss_utils.py:54-100]; the caller forms
- * (1-l) * sums[0]/n + l * (1 - sums[1]/n) [REF train.py:108].  dmaps (optional, [3,3,H,W]) receives the
- * SSIM partial-derivative maps the backward needs. */
+/* sum |img - gt| and the sum of the SSIM map (11x11 Gaussian window, sigma 1.5, zero padding) over a [3,H,W]
+ * image pair [REF utils/loss_utils.py:54-100].  `sums` has 2 * GP_LOSS_SUM_SLOTS doubles: workgroups add into
+ * slot (id % GP_LOSS_SUM_SLOTS) -- (sums[2s], sums[2s+1]) -- because thousands of atomics on ONE address serialise
+ * in L2; the totals are the sums over the slots.  gp_loss_l1_ssim_finalize forms
+ * (1-l) * S0/n + l * (1 - S1/n) [REF train.py:108].  dmaps (optional, [3,3,H,W]) receives the SSIM
+ * partial-derivative maps the backward needs. */
+#define GP_LOSS_SUM_SLOTS 256
 int gp_loss_l1_ssim_forward(const float* img, const float* gt, int32_t channels, int32_t H, int32_t W, double* sums,
                             float* dmaps, gp_stream_t stream);
-/* loss[0] = (1-l) * sums[0]/n + l * (1 - sums[1]/n), n = channels*H*W: keeps the scalar on the device. */
+/* loss[0] = (1-l) * S0/n + l * (1 - S1/n), n = channels*H*W, S = slot totals: keeps the scalar on the device. */
 int gp_loss_l1_ssim_finalize(const double* sums, int32_t channels, int32_t H, int32_t W, float lambda_dssim, float* loss,
                              gp_stream_t stream);
 /* dimg = upstream[0] * d loss / d img  (upstream: device scalar, NULL = 1). */
