@@ -13,6 +13,14 @@ struct MlpDev {
     const float* t;
 };
 
+struct MlpWeightJobs {
+    const float* dZ[5];
+    const float* H[5];
+    float* dW[5];
+    float* db[5];
+    int n_out[5], n_in[5], ldh[5];
+};
+
 struct BlendDev {
     long N, K;
     int nn, out_dim, norm_rotation;
@@ -60,3 +68,10 @@ __global__ __launch_bounds__(256) void gp_act_bwd_kernel(long n, const float* __
                                                          const float* __restrict__ g_opacity,
                                                          float* __restrict__ g_scaling_raw, float* __restrict__ g_opacity_raw,
                                                          float* __restrict__ g_delta_o);
+
+__global__ __launch_bounds__(512) void gp_mlp_bwd_weight5_kernel(MlpWeightJobs t, long rows);
+__global__ __launch_bounds__(512) void gp_mlp_fwd_small_kernel(MlpDev p, float* __restrict__ out, float* __restrict__ saved_x,
+                                                               float* __restrict__ saved_h);
+__global__ __launch_bounds__(512) void gp_mlp_bwd_data_small_kernel(MlpDev p, const float* __restrict__ saved_h,
+                                                                    const float* __restrict__ dL_dout, float* __restrict__ dz,
+                                                                    float* __restrict__ dfeature, float* __restrict__ dxyz);

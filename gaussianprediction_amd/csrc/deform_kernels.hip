@@ -272,17 +272,15 @@ __global__ __launch_bounds__(MLP_THREADS) void gp_mlp_bwd_data_kernel(MlpDev p, 
 // as ONE update per element -- a plain read-modify-write when a single row block owns the tile
 // (small K: no atomics at all), an atomic only across row blocks.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(MLP_THREADS) void gp_mlp_bwd_weight_kernel(const float* __restrict__ dZ, int n_out,
-                                                                        const float* __restrict__ H, int ldh, int n_in,
-                                                                        long rows, long rows_per_block,
-                                                                        float* __restrict__ dW, int lddw,
-                                                                        float* __restrict__ db) {
+__device__ __forceinline__ void mlp_bwd_weight_body(const float* __restrict__ dZ, int n_out, const float* __restrict__ H, int ldh,
+                                                    int n_in, long rows, long rows_per_block, float* __restrict__ dW, int lddw,
+                                                    float* __restrict__ db, int row_block, int n_row_blocks, int bz, int by) {
     __shared__ float s_red[8][16][64];
     __shared__ float s_b[8][32];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, j = lane & 31;
-    const int o = 32 * blockIdx.z + j;  // A row (output feature)
-    const int i = 32 * blockIdx.y + j;  // B col (input feature)
-    const long b_begin = (long)blockIdx.x * rows_per_block;
+    const int o = 32 * bz + j;  // A row (output feature)
+    const int i = 32 * by + j;  // B col (input feature)
+    const long b_begin = (long)row_block * rows_per_block;
     long b_end = b_begin + rows_per_block;
     if (b_end > rows) b_end = rows;
     long per_wave = ((b_end - b_begin + 7) / 8 + 1) & ~1L;  // even, so (rb, rb+1) pairs never straddle slices
@@ -311,25 +309,40 @@ __global__ __launch_bounds__(MLP_THREADS) void gp_mlp_bwd_weight_kernel(const fl
     bsum += __shfl_xor(bsum, 32);
     if (half == 0) s_b[wave][j] = bsum;
     __syncthreads();
-    const bool single = gridDim.x == 1;
+    const bool single = n_row_blocks == 1;
     for (int e = tid; e < 16 * 64; e += MLP_THREADS) {
         const int r = e >> 6, l = e & 63;
         float v = 0.f;
 #pragma unroll
         for (int w = 0; w < 8; ++w) v += s_red[w][r][l];
-        const int oo = 32 * blockIdx.z + cd_row(r, l >> 5), ii = 32 * blockIdx.y + (l & 31);
+        const int oo = 32 * bz + cd_row(r, l >> 5), ii = 32 * by + (l & 31);
         if (oo < n_out && ii < n_in) {
             float* dst = &dW[(size_t)oo * lddw + ii];
             if (single) *dst += v; else atomicAdd(dst, v);
         }
     }
-    if (db && blockIdx.y == 0 && tid < 32) {
+    if (db && by == 0 && tid < 32) {
         float v = 0.f;
 #pragma unroll
         for (int w = 0; w < 8; ++w) v += s_b[w][tid];
-        const int oo = 32 * blockIdx.z + tid;
+        const int oo = 32 * bz + tid;
         if (oo < n_out) { if (single) db[oo] += v; else atomicAdd(&db[oo], v); }
     }
+}
+
+__global__ __launch_bounds__(MLP_THREADS) void gp_mlp_bwd_weight_kernel(const float* __restrict__ dZ, int n_out,
+                                                                        const float* __restrict__ H, int ldh, int n_in,
+                                                                        long rows, long rows_per_block,
+                                                                        float* __restrict__ dW, int lddw,
+                                                                        float* __restrict__ db) {
+    mlp_bwd_weight_body(dZ, n_out, H, ldh, n_in, rows, rows_per_block, dW, lddw, db, blockIdx.x, gridDim.x, blockIdx.z, blockIdx.y);
+}
+// all five layers in ONE launch (small row counts: one row block per tile, no atomics): blockIdx.x = layer
+__global__ __launch_bounds__(MLP_THREADS) void gp_mlp_bwd_weight5_kernel(MlpWeightJobs t, long rows) {
+    const int l = blockIdx.x;
+    if ((int)blockIdx.y * 32 >= t.n_in[l] || (int)blockIdx.z * 32 >= t.n_out[l]) return;
+    mlp_bwd_weight_body(t.dZ[l], t.n_out[l], t.H[l], t.ldh[l], t.n_in[l], rows, rows, t.dW[l], t.n_in[l], t.db[l], 0, 1, blockIdx.z,
+                        blockIdx.y);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -1,0 +1,310 @@
+// deform_mlp_small.hip -- the Deformable_Field MLP for SMALL row counts (stage 2/3: the rows are the K <= 512
+// keypoints [REF scene/gaussian_model.py:262-270]).  The 32-row kernels of deform_kernels.hip would occupy only
+// K/32 = 8..16 of the 256 CUs, and each of those CUs is matrix-core-bound on its 32 x 256 x 256 layer.  Here a
+// workgroup owns 16 rows and uses v_mfma_f32_16x16x4_f32 (still exact fp32), so twice as many CUs share the work
+// and each does half of it.  Same fusion as the large kernels: positional encoding + concat + 5 layers, activations
+// transposed in LDS, weights straight from L2 as the A operand, saved activations in the same row-major layout
+// (the weight-gradient kernel is shared).
+//
+// LDS layout: act[pi(f)][16 rows] with pi(16 q + 4 a + b) = 16 q + 4 b + a.  MFMA step (q, u) needs k = 16 q + 4 kg + u
+// from lane group kg (so that a lane's four A values are one float4 of a weight row); those four k sit in the four
+// CONSECUTIVE LDS rows 16 q + 4 u + kg -- 64 consecutive floats per instruction, bank-conflict free -- and the C/D
+// layout (lane group kg' holds features 4 kg' + r) writes back as 64 consecutive floats per register r as well.
+#include "gp_common.h"
+#include "deform_kernels.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define SR 16
+#define ST 512
+#define SW 256
+
+__device__ __forceinline__ int pi16(int f) { return (f & ~15) | ((f & 3) << 2) | ((f >> 2) & 3); }
+__device__ __forceinline__ int sidx(int f, int n) { return pi16(f) * SR + n; }
+
+__device__ __forceinline__ void build_input_s(float* buf, const MlpDev& p, long row0, int tid, int k16) {
+    const int fd = p.feature_dim, xf = p.xyz_freq, tf = p.time_freq;
+    for (int e = tid; e < fd * SR; e += ST) {
+        const int jj = e / fd, f = e - jj * fd;
+        const long row = row0 + jj;
+        buf[sidx(f, jj)] = row < p.rows ? p.feature[row * fd + f] : 0.f;
+    }
+    for (int e = tid; e < 3 * xf * SR; e += ST) {
+        const int jj = e % SR, cf = e / SR;  // cf = c*xf + fr
+        const int c = cf / xf, fr = cf - c * xf;
+        const long row = row0 + jj;
+        float sv = 0.f, cv = 0.f;
+        if (row < p.rows) sincosf(p.xyz[row * 3 + c] * (float)(1u << fr), &sv, &cv);
+        const int f = fd + 2 * cf;
+        buf[sidx(f, jj)] = sv;
+        buf[sidx(f + 1, jj)] = cv;
+    }
+    const float tv = tf > 0 ? p.t[0] : 0.f;
+    for (int e = tid; e < tf * SR; e += ST) {
+        const int jj = e % SR, fr = e / SR;
+        float sv, cv;
+        sincosf(tv * (float)(1u << fr), &sv, &cv);
+        const bool ok = row0 + jj < p.rows;
+        const int f = fd + 6 * xf + 2 * fr;
+        buf[sidx(f, jj)] = ok ? sv : 0.f;
+        buf[sidx(f + 1, jj)] = ok ? cv : 0.f;
+    }
+    for (int e = tid; e < (k16 - p.in_dim) * SR; e += ST) buf[sidx(p.in_dim + e / SR, e % SR)] = 0.f;
+}
+
+// coalesced copy LDS act^T[0:nf][16] -> global dst[(row0+jj)*ld + f]
+__device__ __forceinline__ void store_rows_s(const float* buf, float* dst, int nf, int nf_valid, int ld, long row0, long rows, int tid) {
+    for (int e = tid; e < nf * SR; e += ST) {
+        const int jj = e / nf, f = e - jj * nf;
+        if (row0 + jj < rows) dst[(row0 + jj) * (long)ld + f] = f < nf_valid ? buf[sidx(f, jj)] : 0.f;
+    }
+}
+
+// two 16-feature tiles (t0, t0+1) of  out^T = W[., 0:k_valid] . cur^T.  K16 = k range walked (multiple of 16; LDS rows
+// beyond k_valid must hold finite values, the A operand is zero there).
+__device__ __forceinline__ void tiles_mfma(const float* __restrict__ W, int ldw, int k_valid, int K16, int out_rows, int t0,
+                                           const float* cur, int lane, f32x4& acc0, f32x4& acc1) {
+    const int i = lane & 15, kg = lane >> 4;
+    const int r0 = 16 * t0 + i, r1 = r0 + 16;
+    const bool ok0 = r0 < out_rows, ok1 = r1 < out_rows;
+    const float* w0 = W + (size_t)r0 * ldw;
+    const float* w1 = W + (size_t)r1 * ldw;
+    const bool vec = (ldw & 3) == 0;
+    const int nq = K16 / 16;
+    for (int q0 = 0; q0 < nq; q0 += 2) {
+        float4 a0[2], a1[2];
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            const int kb = 16 * (q0 + g) + 4 * kg;
+            a0[g] = make_float4(0.f, 0.f, 0.f, 0.f); a1[g] = a0[g];
+            if (q0 + g < nq) {
+                if (vec && kb + 3 < k_valid) {
+                    if (ok0) a0[g] = *(const float4*)(w0 + kb);
+                    if (ok1) a1[g] = *(const float4*)(w1 + kb);
+                } else {
+                    float* p0 = (float*)&a0[g]; float* p1 = (float*)&a1[g];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        if (ok0 && kb + u < k_valid) p0[u] = w0[kb + u];
+                        if (ok1 && kb + u < k_valid) p1[u] = w1[kb + u];
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            if (q0 + g < nq) {
+                const float* b = cur + (16 * (q0 + g) + kg) * SR + i;   // row pi(16 q + 4 kg + u) = 16 q + 4 u + kg
+                const float b0 = b[0], b1 = b[4 * SR], b2 = b[8 * SR], b3 = b[12 * SR];
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[g].x, b0, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[g].x, b0, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[g].y, b1, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[g].y, b1, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[g].z, b2, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[g].z, b2, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[g].w, b3, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[g].w, b3, acc1, 0, 0, 0);
+            }
+        }
+    }
+}
+
+// transposed: out^T[i][row] = sum_k W[k][i] cur^T[k][row], W is [k_valid, ldw]
+__device__ __forceinline__ void tiles_mfma_T(const float* __restrict__ W, int ldw, int k_valid, int K16, int out_rows, int t0,
+                                             const float* cur, int lane, f32x4& acc0, f32x4& acc1) {
+    const int i = lane & 15, kg = lane >> 4;
+    const int r0 = 16 * t0 + i, r1 = r0 + 16;
+    const bool ok0 = r0 < out_rows, ok1 = r1 < out_rows;
+    const int nq = K16 / 16;
+    for (int q = 0; q < nq; ++q) {
+        float a0[4], a1[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int k = 16 * q + 4 * kg + u;
+            a0[u] = (ok0 && k < k_valid) ? W[(size_t)k * ldw + r0] : 0.f;
+            a1[u] = (ok1 && k < k_valid) ? W[(size_t)k * ldw + r1] : 0.f;
+        }
+        const float* b = cur + (16 * q + kg) * SR + i;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float bv = b[4 * u * SR];
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[u], bv, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[u], bv, acc1, 0, 0, 0);
+        }
+    }
+}
+
+// K = 256 variants: with so few workgroups per CU nothing hides L2 latency, so a wave fetches its whole slice of the
+// weight matrix (2 tiles x 16 k-steps x float4 = 128 VGPRs) in one burst before the 128 dependent MFMAs.
+__device__ __forceinline__ void tiles_mfma_256(const float* __restrict__ W, int out_rows, int t0, const float* cur, int lane,
+                                               f32x4& acc0, f32x4& acc1) {
+    const int i = lane & 15, kg = lane >> 4;
+    const int r0 = 16 * t0 + i, r1 = r0 + 16;
+    const bool ok0 = r0 < out_rows, ok1 = r1 < out_rows;
+    const float4* w0 = (const float4*)(W + (size_t)r0 * SW) + kg;
+    const float4* w1 = (const float4*)(W + (size_t)r1 * SW) + kg;
+    float4 a0[16], a1[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        a0[q] = ok0 ? w0[4 * q] : make_float4(0.f, 0.f, 0.f, 0.f);
+        a1[q] = ok1 ? w1[4 * q] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const float* b = cur + (16 * q + kg) * SR + i;
+        const float b0 = b[0], b1 = b[4 * SR], b2 = b[8 * SR], b3 = b[12 * SR];
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[q].x, b0, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[q].x, b0, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[q].y, b1, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[q].y, b1, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[q].z, b2, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[q].z, b2, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[q].w, b3, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[q].w, b3, acc1, 0, 0, 0);
+    }
+}
+__device__ __forceinline__ void tiles_mfma_T_256(const float* __restrict__ W, int ldw, int out_rows, int t0, const float* cur, int lane,
+                                                 f32x4& acc0, f32x4& acc1) {
+    const int i = lane & 15, kg = lane >> 4;
+    const int r0 = 16 * t0 + i, r1 = r0 + 16;
+    const bool ok0 = r0 < out_rows, ok1 = r1 < out_rows;
+    float a0[64], a1[64];
+#pragma unroll
+    for (int q = 0; q < 16; ++q)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int k = 16 * q + 4 * kg + u;
+            a0[4 * q + u] = ok0 ? W[(size_t)k * ldw + r0] : 0.f;
+            a1[4 * q + u] = ok1 ? W[(size_t)k * ldw + r1] : 0.f;
+        }
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const float* b = cur + (16 * q + kg) * SR + i;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float bv = b[4 * u * SR];
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[4 * q + u], bv, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[4 * q + u], bv, acc1, 0, 0, 0);
+        }
+    }
+}
+
+__global__ __launch_bounds__(ST) void gp_mlp_fwd_small_kernel(MlpDev p, float* __restrict__ out, float* __restrict__ saved_x,
+                                                              float* __restrict__ saved_h) {
+    __shared__ float smem[2][SW * SR];
+    __shared__ float s_out[8][16][SR];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, kg = lane >> 4, n = lane & 15;
+    const long row0 = (long)blockIdx.x * SR;
+    float* cur = smem[0];
+    float* nxt = smem[1];
+    const int k16 = (p.in_dim + 15) & ~15;
+    build_input_s(cur, p, row0, tid, k16);
+    __syncthreads();
+    if (saved_x) store_rows_s(cur, saved_x, p.in_pad, p.in_dim, p.in_pad, row0, p.rows, tid);
+    for (int l = 0; l < 4; ++l) {
+        const int kv = l == 0 ? p.in_dim : SW, K16 = l == 0 ? k16 : SW, ldw = l == 0 ? p.in_dim : SW;
+        f32x4 acc0, acc1;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            acc0[r] = p.b[l][32 * wave + 4 * kg + r];
+            acc1[r] = p.b[l][32 * wave + 16 + 4 * kg + r];
+        }
+        if (l == 0) tiles_mfma(p.w[l], ldw, kv, K16, SW, 2 * wave, cur, lane, acc0, acc1);
+        else tiles_mfma_256(p.w[l], SW, 2 * wave, cur, lane, acc0, acc1);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            nxt[sidx(32 * wave + 4 * kg + r, n)] = fmaxf(acc0[r], 0.f);
+            nxt[sidx(32 * wave + 16 + 4 * kg + r, n)] = fmaxf(acc1[r], 0.f);
+        }
+        __syncthreads();
+        if (saved_h) store_rows_s(nxt, saved_h + (size_t)l * p.rows * SW, SW, SW, SW, row0, p.rows, tid);
+        float* t = cur; cur = nxt; nxt = t;
+    }
+    // output layer: out_dim <= 8 rows of W4 (one 16-feature tile); K split over the 8 waves, reduced through LDS
+    {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f}, dummy = {0.f, 0.f, 0.f, 0.f};
+        // wave w walks k in [32 w, 32 w + 32): shift the weight / activation windows accordingly
+        tiles_mfma(p.w[4] + 32 * wave, SW, 32, 32, p.out_dim, 0, cur + 32 * wave * SR, lane, acc, dummy);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s_out[wave][4 * kg + r][n] = acc[r];
+        __syncthreads();
+        if (tid < 8 * SR) {
+            const int jj = tid / 8, f = tid % 8;
+            if (f < p.out_dim && row0 + jj < p.rows) {
+                float v = p.b[4][f];
+#pragma unroll
+                for (int w = 0; w < 8; ++w) v += s_out[w][f][jj];
+                out[(row0 + jj) * p.out_dim + f] = v;
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(ST) void gp_mlp_bwd_data_small_kernel(MlpDev p, const float* __restrict__ saved_h,
+                                                                   const float* __restrict__ dL_dout, float* __restrict__ dz,
+                                                                   float* __restrict__ dfeature, float* __restrict__ dxyz) {
+    __shared__ float smem[2][SW * SR];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, kg = lane >> 4, n = lane & 15;
+    const long row0 = (long)blockIdx.x * SR;
+    float* cur = smem[0];
+    float* nxt = smem[1];
+    // dZ5^T [16][16] (zero-padded beyond out_dim)
+    for (int e = tid; e < 16 * SR; e += ST) {
+        const int jj = e / 16, f = e % 16;
+        const long row = row0 + jj;
+        cur[sidx(f, jj)] = (f < p.out_dim && row < p.rows) ? dL_dout[row * p.out_dim + f] : 0.f;
+    }
+    __syncthreads();
+    for (int l = 4; l >= 1; --l) {
+        // dH_l^T = W_l^T dZ_{l+1}^T ; W_l = p.w[l] is [Kout, 256]
+        const int K16 = l == 4 ? 16 : SW, kv = l == 4 ? p.out_dim : SW;
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+        if (l == 4) tiles_mfma_T(p.w[l], SW, kv, K16, SW, 2 * wave, cur, lane, acc0, acc1);
+        else tiles_mfma_T_256(p.w[l], SW, SW, 2 * wave, cur, lane, acc0, acc1);
+        const float* h = saved_h + (size_t)(l - 1) * p.rows * SW;
+        const long row = row0 + n;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int f0 = 32 * wave + 4 * kg + r, f1 = f0 + 16;
+            const float h0 = row < p.rows ? h[row * SW + f0] : 0.f, h1 = row < p.rows ? h[row * SW + f1] : 0.f;
+            nxt[sidx(f0, n)] = h0 > 0.f ? acc0[r] : 0.f;
+            nxt[sidx(f1, n)] = h1 > 0.f ? acc1[r] : 0.f;
+        }
+        __syncthreads();
+        store_rows_s(nxt, dz + (size_t)(l - 1) * p.rows * SW, SW, SW, SW, row0, p.rows, tid);
+        float* t = cur; cur = nxt; nxt = t;
+    }
+    // dX^T [in_dim][16] = W_0^T dZ_1^T ; W_0 is [256, in_dim]
+    if (dfeature || dxyz) {
+        if (32 * wave < p.in_dim) {
+            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+            tiles_mfma_T_256(p.w[0], p.in_dim, p.in_dim, 2 * wave, cur, lane, acc0, acc1);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                nxt[sidx(32 * wave + 4 * kg + r, n)] = acc0[r];
+                nxt[sidx(32 * wave + 16 + 4 * kg + r, n)] = acc1[r];
+            }
+        }
+        __syncthreads();
+        if (dfeature) store_rows_s(nxt, dfeature, p.feature_dim, p.feature_dim, p.feature_dim, row0, p.rows, tid);
+        if (dxyz) {
+            // d/dx sin(x 2^f) = 2^f cos, d/dx cos(x 2^f) = -2^f sin
+            if (tid < 3 * SR) {
+                const int jj = tid / 3, c = tid % 3;
+                const long row = row0 + jj;
+                if (row < p.rows) {
+                    const float x = p.xyz[row * 3 + c];
+                    float g = 0.f;
+                    for (int fr = 0; fr < p.xyz_freq; ++fr) {
+                        const float sc = (float)(1u << fr);
+                        float sv, cv;
+                        sincosf(x * sc, &sv, &cv);
+                        const int f = p.feature_dim + 2 * (c * p.xyz_freq + fr);
+                        g += sc * (cv * nxt[sidx(f, jj)] - sv * nxt[sidx(f + 1, jj)]);
+                    }
+                    dxyz[row * 3 + c] = g;
+                }
+            }
+        }
+    }
+}

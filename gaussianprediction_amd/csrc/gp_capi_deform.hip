@@ -26,6 +26,8 @@ static int make_mlp(const gp_mlp_params* p, const gp_mlp_input* x, MlpDev& m) {
 // layout of the activation record: [X: rows x in_pad][H1..H4: 4 x rows x 256]
 static inline size_t acts_x_floats(const MlpDev& m) { return (size_t)m.rows * m.in_pad; }
 
+#define GP_MLP_SMALL_ROWS 2048
+
 extern "C" int gp_mlp_forward(const gp_mlp_params* p, const gp_mlp_input* x, float* out, float* acts, gp_stream_t stream_) {
     MlpDev m;
     if (make_mlp(p, x, m)) return 1;
@@ -34,7 +36,11 @@ extern "C" int gp_mlp_forward(const gp_mlp_params* p, const gp_mlp_input* x, flo
     float* sx = acts;
     float* sh = acts ? acts + gp_align_up(acts_x_floats(m), 64) : nullptr;
     { GpProfScope _p("mlp_fwd", (hipStream_t)stream_);
-        hipLaunchKernelGGL(gp_mlp_fwd_kernel, dim3(gp_blocks((size_t)m.rows, 32)), dim3(512), 0, (hipStream_t)stream_, m, out, sx, sh);
+        // few rows (stage 2/3: the keypoints): 16-row workgroups on v_mfma_f32_16x16x4_f32 spread the work over twice the CUs
+        if (m.rows <= GP_MLP_SMALL_ROWS)
+            hipLaunchKernelGGL(gp_mlp_fwd_small_kernel, dim3(gp_blocks((size_t)m.rows, 16)), dim3(512), 0, (hipStream_t)stream_, m, out, sx, sh);
+        else
+            hipLaunchKernelGGL(gp_mlp_fwd_kernel, dim3(gp_blocks((size_t)m.rows, 32)), dim3(512), 0, (hipStream_t)stream_, m, out, sx, sh);
     GP_LAUNCH_CHECK(); }
     return 0;
 }
@@ -55,7 +61,11 @@ extern "C" int gp_mlp_backward(const gp_mlp_params* p, const gp_mlp_input* x, co
     float* dz = (float*)alloc(alloc_ctx, GP_BUF_TEMP, dz_bytes);
     if (!dz) GP_FAIL("allocator returned NULL for TEMP (%zu B)", dz_bytes);
     { GpProfScope _p("mlp_bwd_data", s);
-        hipLaunchKernelGGL(gp_mlp_bwd_data_kernel, dim3(gp_blocks((size_t)m.rows, 32)), dim3(512), 0, s, m, sh, dL_dout, dz,
+        if (m.rows <= GP_MLP_SMALL_ROWS)
+            hipLaunchKernelGGL(gp_mlp_bwd_data_small_kernel, dim3(gp_blocks((size_t)m.rows, 16)), dim3(512), 0, s, m, sh, dL_dout, dz,
+                               dL_dfeature, dL_dxyz);
+        else
+            hipLaunchKernelGGL(gp_mlp_bwd_data_kernel, dim3(gp_blocks((size_t)m.rows, 32)), dim3(512), 0, s, m, sh, dL_dout, dz,
                        dL_dfeature, dL_dxyz);
     GP_LAUNCH_CHECK(); }
     // weight grads: dW_l = dZ_{l+1}^T H_l,  H_0 = X
@@ -66,6 +76,20 @@ extern "C" int gp_mlp_backward(const gp_mlp_params* p, const gp_mlp_input* x, co
     long rpb = ((m.rows + nrb_l - 1) / nrb_l + 15) & ~15L;
     const unsigned nrb = (unsigned)((m.rows + rpb - 1) / rpb);
     GpProfScope _pw("mlp_bwd_weight", s);
+    if (nrb == 1) {   // one launch for all five layers
+        MlpWeightJobs jobs;
+        for (int l = 0; l < 5; ++l) {
+            jobs.dZ[l] = l < 4 ? dz + (size_t)l * m.rows * 256 : dL_dout;
+            jobs.n_out[l] = l < 4 ? 256 : m.out_dim;
+            jobs.H[l] = l == 0 ? sx : sh + (size_t)(l - 1) * m.rows * 256;
+            jobs.ldh[l] = l == 0 ? m.in_pad : 256;
+            jobs.n_in[l] = l == 0 ? m.in_dim : 256;
+            jobs.dW[l] = g->dw[l]; jobs.db[l] = g->db[l];
+        }
+        hipLaunchKernelGGL(gp_mlp_bwd_weight5_kernel, dim3(5, 8, 8), dim3(512), 0, s, jobs, m.rows);
+        GP_LAUNCH_CHECK();
+        return 0;
+    }
     for (int l = 0; l < 5; ++l) {
         const float* dZl = l < 4 ? dz + (size_t)l * m.rows * 256 : dL_dout;
         const int n_out = l < 4 ? 256 : m.out_dim;
