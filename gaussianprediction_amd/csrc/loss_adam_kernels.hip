@@ -234,6 +234,7 @@ struct AdamTable {
     float* v[ADAM_MAX_TENSORS];
     unsigned long long n[ADAM_MAX_TENSORS];
     float lr[ADAM_MAX_TENSORS];
+    unsigned keep_grad_mask;                     // bit k: leave tensor k's gradient as it is
     unsigned chunk_begin[ADAM_MAX_TENSORS + 1];   // prefix of chunk counts
     int count;
 };
@@ -246,6 +247,7 @@ __global__ __launch_bounds__(256) void gp_adam_multi_kernel(AdamTable t, float b
     const size_t n = t.n[k];
     float* __restrict__ p = t.p[k]; float* __restrict__ g = t.g[k]; float* __restrict__ m = t.m[k]; float* __restrict__ v = t.v[k];
     const float step_size = t.lr[k] / bc1;
+    if ((t.keep_grad_mask >> k) & 1u) zero_grad = 0;
     const size_t end = base + ADAM_CHUNK < n ? base + ADAM_CHUNK : n;
     auto upd = [&](float4& pv, const float4& gv, float4& mv, float4& vv) {
         float* pp = (float*)&pv; const float* gg = (const float*)&gv; float* mm = (float*)&mv; float* vq = (float*)&vv;
@@ -357,7 +359,7 @@ extern "C" int gp_adam_step(float* param, float* grad, float* exp_avg, float* ex
 
 extern "C" int gp_adam_step_multi(int32_t count, float* const* params, float* const* grads, float* const* exp_avgs,
                                   float* const* exp_avg_sqs, const int64_t* numels, const float* lrs, float beta1, float beta2,
-                                  float eps, int64_t step, int32_t zero_grad, gp_stream_t stream_) {
+                                  float eps, int64_t step, int32_t zero_grad, uint32_t keep_grad_mask, gp_stream_t stream_) {
     hipStream_t s = (hipStream_t)stream_;
     if (count < 0 || count > ADAM_MAX_TENSORS) GP_FAIL("adam: at most %d tensors per call (got %d)", ADAM_MAX_TENSORS, count);
     if (step < 1) GP_FAIL("bad step");
@@ -365,12 +367,14 @@ extern "C" int gp_adam_step_multi(int32_t count, float* const* params, float* co
     if (!params || !grads || !exp_avgs || !exp_avg_sqs || !numels || !lrs) GP_FAIL("null argument");
     AdamTable t;
     t.count = 0;
+    t.keep_grad_mask = 0;
     unsigned chunks = 0;
     for (int k = 0; k < count; ++k) {
         if (numels[k] <= 0) continue;
         if ((((uintptr_t)params[k] | (uintptr_t)grads[k] | (uintptr_t)exp_avgs[k] | (uintptr_t)exp_avg_sqs[k]) & 15) != 0)
             GP_FAIL("adam: pointers must be 16-byte aligned (tensor %d)", k);
         const int j = t.count++;
+        if ((keep_grad_mask >> k) & 1u) t.keep_grad_mask |= 1u << j;
         t.p[j] = params[k]; t.g[j] = grads[k]; t.m[j] = exp_avgs[k]; t.v[j] = exp_avg_sqs[k];
         t.n[j] = (unsigned long long)numels[k]; t.lr[j] = lrs[k];
         t.chunk_begin[j] = chunks;

@@ -28,6 +28,29 @@ def sink_of(t):
     return g
 
 
+# Gradient buffers whose CONTENTS are stale: the optimizer consumed them and skipped the zeroing pass because the next
+# producer is known to overwrite the whole tensor (the rasterizer's SH gradients: 192 B per Gaussian that would
+# otherwise be zero-written by Adam and read back by the next backward).  Keyed by data_ptr.
+_stale = set()
+
+
+def mark_stale(g):
+    _stale.add(g.data_ptr())
+
+
+def take_stale(g):
+    """True (and forget it) if `g` must be overwritten rather than accumulated into."""
+    k = g.data_ptr()
+    if k in _stale:
+        _stale.discard(k)
+        return True
+    return False
+
+
+def is_stale(g):
+    return g.data_ptr() in _stale
+
+
 def register_callback(fn):
     _callbacks.append(fn)
     return fn

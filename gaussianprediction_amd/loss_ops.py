@@ -81,8 +81,9 @@ class FusedAdam:
                     raise RuntimeError("FusedAdam needs contiguous parameters")
                 self.items.append((g, p, off_of[id(p)], torch.zeros_like(p), torch.zeros_like(p)))
 
-    def step(self, zero_grad=True):
-        """One launch for all parameter tensors (gp_adam_step_multi)."""
+    def step(self, zero_grad=True, keep_grad=()):
+        """One launch for all parameter tensors (gp_adam_step_multi).  Parameters listed in `keep_grad` are not
+        zeroed: their gradient buffers are marked stale (grad_sink.mark_stale) and the next backward overwrites them."""
         self.step_count += 1
         n = len(self.items)
         if not hasattr(self, "_tab"):
@@ -94,9 +95,20 @@ class FusedAdam:
             self._tab = (P, G, M, V, NUM)
         P, G, M, V, NUM = self._tab
         LR = (C.c_float * n)(*[float(g["lr"]) for g, _, _, _, _ in self.items])
+        keep_ids = {id(p) for p in keep_grad}
+        mask = 0
+        if zero_grad:
+            for k, (_, p, _, _, _) in enumerate(self.items):
+                if id(p) in keep_ids:
+                    mask |= 1 << k
         b1, b2 = self.betas
         dev = self.bucket.flat.device
         with torch.cuda.device(dev):
             rc = _lib.lib().gp_adam_step_multi(C.c_int32(n), P, G, M, V, NUM, LR, C.c_float(b1), C.c_float(b2), C.c_float(self.eps),
-                                               C.c_int64(self.step_count), C.c_int32(1 if zero_grad else 0), _lib.stream_ptr(dev))
+                                               C.c_int64(self.step_count), C.c_int32(1 if zero_grad else 0), C.c_uint32(mask), _lib.stream_ptr(dev))
             _lib.check(rc, "gp_adam_step_multi")
+        if mask:
+            from . import grad_sink
+            for k, (_, p, _, _, _) in enumerate(self.items):
+                if (mask >> k) & 1:
+                    grad_sink.mark_stale(p.grad)

@@ -145,9 +145,24 @@ class _RasterizeGaussians(torch.autograd.Function):
             m16 = ctx.sh_coeffs == 16 and (shs.data_ptr() % 16 == 0)
             use_sink = has_sh and m16 and sink_sh is not None and (not has_rest or sink_rest is not None) and \
                 sink_sh.shape == shs.shape and (not has_rest or sink_rest.shape == shs_r.shape)
+            accumulate = 0
             if use_sink:
                 g_sh, g_shr = sink_sh, (sink_rest if has_rest else None)
+                # a sink the optimizer left un-zeroed (grad_sink.mark_stale) is overwritten; mixed states are normalised first
+                st_sh = grad_sink.take_stale(g_sh)
+                st_r = grad_sink.take_stale(g_shr) if has_rest else st_sh
+                if st_sh and st_r:
+                    accumulate = 0
+                else:
+                    if st_sh:
+                        g_sh.zero_()
+                    if st_r and has_rest:
+                        g_shr.zero_()
+                    accumulate = 1
             else:
+                for leaf in (leaf_sh, leaf_rest):   # autograd will ACCUMULATE into these: stale contents must not survive
+                    if isinstance(leaf, torch.Tensor) and leaf.grad is not None and grad_sink.take_stale(leaf.grad):
+                        leaf.grad.zero_()
                 g_sh = torch.empty(N, 1 if has_rest else ctx.sh_coeffs, 3, device=device) if has_sh else None
                 g_shr = torch.empty(N, ctx.sh_coeffs - 1, 3, device=device) if has_rest else None
             g_col = torch.empty(N, 3, device=device) if has_col else None
@@ -156,7 +171,7 @@ class _RasterizeGaussians(torch.autograd.Function):
             g_rot = torch.empty(N, 4, device=device) if has_sr else None
             g_cov = torch.empty(N, 6, device=device) if has_cov else None
             grads = _lib.RasterGradsC(_lib.ptr(g_m3), _lib.ptr(g_m2), _lib.ptr(g_sh), _lib.ptr(g_shr), _lib.ptr(g_col), _lib.ptr(g_op),
-                                      _lib.ptr(g_scl), _lib.ptr(g_rot), _lib.ptr(g_cov), 1 if use_sink else 0)
+                                      _lib.ptr(g_scl), _lib.ptr(g_rot), _lib.ptr(g_cov), accumulate)
             alloc = _lib.TorchAllocator(device)
             rc = L.gp_raster_backward(C.byref(st), C.byref(inp), C.byref(out), C.byref(saved), _lib.ptr(gc), _lib.ptr(gd),
                                       C.byref(grads), alloc.cb, None, _lib.stream_ptr(device))

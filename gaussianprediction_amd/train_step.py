@@ -109,7 +109,12 @@ class TrainStep:
         loss.backward()                              # hooks start the all-reduce of each large gradient as it completes
         self.reducer.finish()                        # SUM over views == the reference's --batch semantics
         if self.fused:
-            self.optimizer.step(zero_grad=True)
+            # the SH gradients (48 of the 59 floats per Gaussian) are written by the rasterizer backward in full: skip
+            # their zeroing pass here and let the next backward overwrite instead of accumulate
+            keep = ()
+            if not self.pipe.convert_SHs_python and self.iteration > self.pc.third_stage_iter:
+                keep = (self.pc._features_dc, self.pc._features_rest)
+            self.optimizer.step(zero_grad=True, keep_grad=keep)
         else:
             self.optimizer.step()
             self.bucket.zero()

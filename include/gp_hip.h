@@ -241,10 +241,11 @@ int gp_loss_l1_ssim_backward(const float* img, const float* gt, const float* dma
 int gp_adam_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1, float beta2,
                  float eps, int64_t step, int32_t zero_grad, gp_stream_t stream);
 
-/* the same for up to 32 tensors in ONE launch (host arrays of device pointers / sizes / learning rates) */
+/* the same for up to 32 tensors in ONE launch (host arrays of device pointers / sizes / learning rates).
+ * keep_grad_mask: bit k set = do NOT zero tensor k's gradient even when zero_grad != 0 (its next producer overwrites it). */
 int gp_adam_step_multi(int32_t count, float* const* params, float* const* grads, float* const* exp_avgs,
                        float* const* exp_avg_sqs, const int64_t* numels, const float* lrs, float beta1, float beta2, float eps,
-                       int64_t step, int32_t zero_grad, gp_stream_t stream);
+                       int64_t step, int32_t zero_grad, uint32_t keep_grad_mask, gp_stream_t stream);
 
 /* ---- measurement ----------------------------------------------------------------------------- */
 /* gp_profile_enable(level): 0 = off, 1 = bracket only the roofline kernel (composite forward), 2 = every
