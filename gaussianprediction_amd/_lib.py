@@ -89,6 +89,7 @@ EXPORTS = [
     "gp_activations_forward", "gp_activations_backward", "gp_profile_enable", "gp_profile_collect",
     "gp_loss_l1_ssim_forward", "gp_loss_l1_ssim_finalize", "gp_loss_l1_ssim_backward", "gp_adam_step",
     "gp_adam_step_multi",
+    "gp_hashgrid_table_entries", "gp_hashgrid_forward", "gp_hashgrid_backward", "gp_knn_keypoints",
     "gp_last_error", "gp_version",
 ]
 
@@ -122,6 +123,7 @@ def lib() -> C.CDLL:
         for name in EXPORTS:
             if name not in ("gp_last_error", "gp_version"):
                 getattr(l, name).restype = C.c_int
+        l.gp_hashgrid_table_entries.restype = C.c_int64
         _lib = l
         return _lib
 

@@ -3,10 +3,12 @@ parameters, activations and `forward(t, iteration) -> (xyz_t, q_t, scale, opacit
 stages, on the HIP kernels of this package.  Training bookkeeping (optimizer surgery, densify/prune,
 k-means keypoint init, PLY I/O) is out of scope for this round.
 
-Two stage-2/3 inputs come from un-vendored CUDA dependencies of the reference that are not part of
-the hot path and are therefore supplied by the caller:
+Two stage-2/3 quantities come from un-vendored CUDA dependencies of the reference:
   * `knn_idx` [N, nearest_num]  -- frnn kNN of Gaussians vs keypoints  [REF :110-125]
   * `raw_weights` [N, 2*nearest_num] -- output of the tcnn hash-grid weights model [REF :257]
+They are the hot path's *inputs* (BASELINE.json north_star): `set_keypoint_weights` supplies them directly (what the
+bench does).  When they are not supplied, `forward` computes them per frame as the reference does, with this
+package's own `WeightsModel` / `knn_keypoints` (weights_ops.py; SURVEY.md section 8f rank 1, parity unpinned).
 """
 from __future__ import annotations
 
@@ -15,6 +17,7 @@ from torch import nn
 
 from .deform_ops import Activations, KeypointBlend
 from .deformable_field import Deformable_Field
+from .weights_ops import WeightsModel, knn_keypoints
 
 
 class GaussianModel(nn.Module):
@@ -40,7 +43,7 @@ class GaussianModel(nn.Module):
 
     # ---- construction from raw tensors (stand-in for create_from_pcd, REF :327-392) ---------------
     def create_from_tensors(self, xyz, features_dc, features_rest, scaling, rotation, opacity, motion_feature,
-                            keypoints=None, keypoint_features=None):
+                            keypoints=None, keypoint_features=None, with_weights_model=False):
         self._xyz = nn.Parameter(xyz.clone().requires_grad_(True))
         self._features_dc = nn.Parameter(features_dc.clone().requires_grad_(True))
         self._features_rest = nn.Parameter(features_rest.clone().requires_grad_(True))
@@ -54,11 +57,23 @@ class GaussianModel(nn.Module):
         if keypoints is not None:
             self.super_gaussians = nn.Parameter(keypoints.clone().requires_grad_(True))
             self.super_gaussians_feature = nn.Parameter(keypoint_features.clone().requires_grad_(True))
+        self.weights_model = None
+        if with_weights_model:                       # [REF scene/gaussian_model.py:370-392]
+            self.weights_model = WeightsModel(2 * self.args.nearest_num, device=xyz.device)
         self.active_sh_degree = self.max_sh_degree
         return self
 
     def set_keypoint_weights(self, raw_weights, knn_idx):
         self.raw_weights, self.knn_idx = raw_weights, knn_idx
+
+    @torch.no_grad()
+    def get_nearest_mask(self, keepshape=False):     # [REF scene/gaussian_model.py:110-125]
+        a = self.args
+        nearest = knn_keypoints(self._xyz, self.super_gaussians, a.nearest_num, self.motion_feature,
+                                self.super_gaussians_feature, getattr(a, "feature_amplify", 5.0),
+                                getattr(a, "knn_type", "hybird"))
+        self.nearest_mask = nearest if keepshape else nearest.view([-1])
+        return self.nearest_mask
 
     # ---- accessors [REF scene/gaussian_model.py:138-172] -----------------------------------------
     @property
@@ -126,12 +141,16 @@ class GaussianModel(nn.Module):
             kp = self.super_gaussians
             if noise and (iteration - self.second_stage_iter) < noise:
                 kp = kp + torch.randn_like(kp) * 0.1 * (1 - min(1, (iteration - self.second_stage_iter) / noise))
-            if self.raw_weights is None or self.knn_idx is None:
-                raise RuntimeError("stage 2/3 needs set_keypoint_weights(raw_weights, knn_idx)")
+            raw_weights, knn_idx = self.raw_weights, self.knn_idx
+            if raw_weights is None or knn_idx is None:
+                if getattr(self, "weights_model", None) is None:
+                    raise RuntimeError("stage 2/3 needs set_keypoint_weights(raw_weights, knn_idx) or a weights_model "
+                                       "(create_from_tensors(..., with_weights_model=True))")
+                raw_weights = self.weights_model(self.get_xyz.detach())          # [REF :257]
+                knn_idx = self.get_nearest_mask(keepshape=True)                  # [REF :260]
             delta = self.df_model.forward_fused(self.super_gaussians_feature, kp, t_dev, xyz_freq, time_freq)
             self.kpts_xyz_motion = delta[:, 0:3]
-            xyz_t, q_t = KeypointBlend.apply(delta, self.raw_weights, self.knn_idx, self._xyz, self._rotation,
-                                             a.norm_rotation)
+            xyz_t, q_t = KeypointBlend.apply(delta, raw_weights, knn_idx, self._xyz, self._rotation, a.norm_rotation)
         self.lifecycle_opacity = None
         if a.step_opacity and iteration > a.step_opacity_iteration:
             if a.opacity_type != "implicit":

@@ -247,6 +247,34 @@ int gp_adam_step_multi(int32_t count, float* const* params, float* const* grads,
                        float* const* exp_avg_sqs, const int64_t* numels, const float* lrs, float beta1, float beta2, float eps,
                        int64_t step, int32_t zero_grad, uint32_t keep_grad_mask, gp_stream_t stream);
 
+/* ---- keypoint weights (parity unpinned: tinycudann / frnn are absent from the reference tree) --- */
+
+/* the Grid/Hash encoding of weights_model = tcnn.NetworkWithInputEncoding(...) [REF scene/gaussian_model.py:370-392] */
+typedef struct gp_hashgrid_config {
+    int32_t n_levels;               /* 16 */
+    int32_t n_features_per_level;   /* 4 (only value implemented) */
+    int32_t log2_hashmap_size;      /* 19 */
+    int32_t base_resolution;        /* 16 */
+    float per_level_scale;          /* exp(ln(2048/16)/15) */
+} gp_hashgrid_config;
+
+/* number of table entries (n_features_per_level floats each) over all levels; -1 on a bad configuration */
+int64_t gp_hashgrid_table_entries(const gp_hashgrid_config* cfg);
+/* out[n, n_levels*4] = trilinear multiresolution hash encoding of xyz[n,3] (used as given: the reference does not
+ * normalise positions) -- the encoding half of weights_model(self.get_xyz.detach()) [REF scene/gaussian_model.py:257].
+ * perm (optional, int32[n]): a permutation of the points in a spatially coherent order (e.g. Morton); it only changes
+ * which points share a wavefront -- neighbouring lanes then read neighbouring table entries -- never the result. */
+int gp_hashgrid_forward(const gp_hashgrid_config* cfg, int64_t n, const float* xyz, const int32_t* perm, const float* table,
+                        float* out, gp_stream_t stream);
+/* dtable += d out / d table applied to dL_dout[n, n_levels*4] (xyz is detached in the reference: no position gradient) */
+int gp_hashgrid_backward(const gp_hashgrid_config* cfg, int64_t n, const float* xyz, const int32_t* perm, const float* dL_dout,
+                         float* dtable, gp_stream_t stream);
+/* idx_out[n, nn] (int64, ascending squared distance; ties to the lower index) = the nn nearest of the K keypoints, in 3-D
+ * (feat_dim = 0: knn_type "3D") or in [xyz | amplify * feature] (feat_dim = 32: "hybird")
+ * [REF scene/gaussian_model.py:110-125, frnn.frnn_grid_points].  d2_out (optional) receives the squared distances. */
+int gp_knn_keypoints(int64_t n, const float* xyz, const float* feat, int32_t feat_dim, float amplify, int64_t K,
+                     const float* kp_xyz, const float* kp_feat, int32_t nn, int64_t* idx_out, float* d2_out, gp_stream_t stream);
+
 /* ---- measurement ----------------------------------------------------------------------------- */
 /* gp_profile_enable(level): 0 = off, 1 = bracket only the roofline kernel (composite forward), 2 = every
  * kernel.  When enabled, the library brackets kernels with hipEvent pairs recorded on the launch stream.
