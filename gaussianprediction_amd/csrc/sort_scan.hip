@@ -53,7 +53,7 @@ __global__ __launch_bounds__(256) void gp_scan_add_kernel(uint32_t* __restrict__
 }
 
 size_t gp_scan_tmp_elems(size_t n) {
-    size_t total = 64;
+    size_t total = 256 + 64;   // the radix sort keeps its 256 digit totals here
     while (n > 1) {
         size_t nb = (n + SCAN_TILE - 1) / SCAN_TILE;
         total += gp_align_up(nb, 64);
@@ -105,15 +105,49 @@ __global__ __launch_bounds__(RS_BLOCK) void gp_radix_hist_kernel(const uint32_t*
     hist[(size_t)tid * nblocks + blockIdx.x] = s_hist[tid];
 }
 
+// exclusive scan of every digit's row  hist[digit][0..nblocks)  in place (one workgroup per digit) + the row totals.
+// Together with a 256-entry scan of the totals inside the scatter kernel this replaces a generic three-launch device
+// scan of the whole 256 x nblocks array: 3 launches per radix pass instead of 5.
+__global__ __launch_bounds__(256) void gp_radix_rowscan_kernel(uint32_t* __restrict__ hist, uint32_t nblocks,
+                                                               uint32_t* __restrict__ totals) {
+    __shared__ uint32_t s_wave[4];
+    __shared__ uint32_t s_carry;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    uint32_t* row = hist + (size_t)blockIdx.x * nblocks;
+    if (tid == 0) s_carry = 0;
+    __syncthreads();
+    for (uint32_t b0 = 0; b0 < nblocks; b0 += 256) {
+        const uint32_t b = b0 + tid;
+        const uint32_t v = b < nblocks ? row[b] : 0u;
+        uint32_t x = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t t = __shfl_up(x, d);
+            if (lane >= d) x += t;
+        }
+        if (lane == 63) s_wave[wave] = x;
+        __syncthreads();
+        uint32_t off = s_carry;
+        for (int w = 0; w < wave; ++w) off += s_wave[w];
+        if (b < nblocks) row[b] = off + x - v;
+        __syncthreads();
+        if (tid == 255) s_carry = off + x;
+        __syncthreads();
+    }
+    if (tid == 0) totals[blockIdx.x] = s_carry;
+}
+
 // stable scatter.  Element order inside a block: (wave, iteration, lane); wave w owns the
 // contiguous sub-chunk [w*1024, (w+1)*1024) of the block's 4096 elements.
 __global__ __launch_bounds__(RS_BLOCK) void gp_radix_scatter_kernel(const uint32_t* __restrict__ keys_in,
                                                                     const uint32_t* __restrict__ vals_in,
                                                                     uint32_t* __restrict__ keys_out,
                                                                     uint32_t* __restrict__ vals_out,
-                                                                    const uint32_t* __restrict__ hist_scanned, size_t n,
+                                                                    const uint32_t* __restrict__ hist_scanned,
+                                                                    const uint32_t* __restrict__ totals, size_t n,
                                                                     int shift, uint32_t mask, uint32_t nblocks) {
     __shared__ uint32_t s_cnt[RS_BLOCK / GP_WAVE][256];
+    __shared__ uint32_t s_dbase[256], s_dw[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 #pragma unroll
     for (int w = 0; w < RS_BLOCK / GP_WAVE; ++w) s_cnt[w][tid] = 0;
@@ -147,8 +181,22 @@ __global__ __launch_bounds__(RS_BLOCK) void gp_radix_scatter_kernel(const uint32
         r[it] = old + below;
     }
     __syncthreads();
+    {   // global base of digit `tid` = exclusive scan of the 256 row totals
+        const uint32_t tv = totals[tid];
+        uint32_t x = tv;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t t = __shfl_up(x, d);
+            if (lane >= d) x += t;
+        }
+        if (lane == 63) s_dw[wave] = x;
+        __syncthreads();
+        uint32_t off = 0;
+        for (int w = 0; w < wave; ++w) off += s_dw[w];
+        s_dbase[tid] = off + x - tv;
+    }
     {   // per-digit exclusive prefix over the 4 waves, plus the global base of (digit, block)
-        uint32_t run = hist_scanned[(size_t)tid * nblocks + blockIdx.x];
+        uint32_t run = s_dbase[tid] + hist_scanned[(size_t)tid * nblocks + blockIdx.x];
 #pragma unroll
         for (int w = 0; w < RS_BLOCK / GP_WAVE; ++w) {
             uint32_t c = s_cnt[w][tid];
@@ -181,9 +229,10 @@ int gp_radix_sort_pairs(GpSortBufs& b, size_t n, int nbits, hipStream_t s) {
         hipLaunchKernelGGL(gp_radix_hist_kernel, dim3(nblocks), dim3(RS_BLOCK), 0, s, b.k[cur], n, shift, mask, b.hist,
                            nblocks);
         if (hipGetLastError() != hipSuccess) { snprintf(gp_err_buf, sizeof(gp_err_buf), "radix hist launch failed"); return -1; }
-        if (gp_scan_exclusive_u32(b.hist, (size_t)256 * nblocks, b.scan_tmp, b.scan_tmp_elems, s)) return -1;
+        if (b.scan_tmp_elems < 256) { snprintf(gp_err_buf, sizeof(gp_err_buf), "radix sort: temp storage too small"); return -1; }
+        hipLaunchKernelGGL(gp_radix_rowscan_kernel, dim3(256), dim3(256), 0, s, b.hist, nblocks, b.scan_tmp);
         hipLaunchKernelGGL(gp_radix_scatter_kernel, dim3(nblocks), dim3(RS_BLOCK), 0, s, b.k[cur], b.v[cur], b.k[cur ^ 1],
-                           b.v[cur ^ 1], b.hist, n, shift, mask, nblocks);
+                           b.v[cur ^ 1], b.hist, b.scan_tmp, n, shift, mask, nblocks);
         if (hipGetLastError() != hipSuccess) { snprintf(gp_err_buf, sizeof(gp_err_buf), "radix scatter launch failed"); return -1; }
         cur ^= 1;
     }
