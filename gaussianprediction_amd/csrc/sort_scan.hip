@@ -148,6 +148,7 @@ __global__ __launch_bounds__(RS_BLOCK) void gp_radix_scatter_kernel(const uint32
                                                                     int shift, uint32_t mask, uint32_t nblocks) {
     __shared__ uint32_t s_cnt[RS_BLOCK / GP_WAVE][256];
     __shared__ uint32_t s_dbase[256], s_dw[4];
+    __shared__ uint32_t s_k[RS_TILE], s_v[RS_TILE];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 #pragma unroll
     for (int w = 0; w < RS_BLOCK / GP_WAVE; ++w) s_cnt[w][tid] = 0;
@@ -195,25 +196,50 @@ __global__ __launch_bounds__(RS_BLOCK) void gp_radix_scatter_kernel(const uint32
         for (int w = 0; w < wave; ++w) off += s_dw[w];
         s_dbase[tid] = off + x - tv;
     }
-    {   // per-digit exclusive prefix over the 4 waves, plus the global base of (digit, block)
-        uint32_t run = s_dbase[tid] + hist_scanned[(size_t)tid * nblocks + blockIdx.x];
+    {   // per-digit: exclusive prefix over the 4 waves (block-local), block-local digit base, global base of (digit, block)
+        uint32_t c[RS_BLOCK / GP_WAVE], bc = 0;
 #pragma unroll
-        for (int w = 0; w < RS_BLOCK / GP_WAVE; ++w) {
-            uint32_t c = s_cnt[w][tid];
-            s_cnt[w][tid] = run;
-            run += c;
+        for (int w = 0; w < RS_BLOCK / GP_WAVE; ++w) { c[w] = s_cnt[w][tid]; bc += c[w]; }
+        // block-local exclusive scan of the 256 digit counts
+        uint32_t x = bc;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t t = __shfl_up(x, d);
+            if (lane >= d) x += t;
         }
+        __syncthreads();                 // s_dw is reused
+        if (lane == 63) s_dw[wave] = x;
+        __syncthreads();
+        uint32_t off = 0;
+        for (int w = 0; w < wave; ++w) off += s_dw[w];
+        const uint32_t lbase = off + x - bc;
+        uint32_t run = lbase;
+#pragma unroll
+        for (int w = 0; w < RS_BLOCK / GP_WAVE; ++w) { s_cnt[w][tid] = run; run += c[w]; }
+        // element at block-local sorted position p with this digit goes to global  p + s_dbase[digit]
+        s_dbase[tid] = s_dbase[tid] + hist_scanned[(size_t)tid * nblocks + blockIdx.x] - lbase;
     }
     __syncthreads();
+    // stage the block's pairs in sorted order in LDS, then write them out: consecutive threads -> consecutive addresses
+    // inside each digit run (instead of every lane scattering 4 bytes on its own)
 #pragma unroll
     for (int it = 0; it < RS_ITEMS; ++it) {
         const size_t idx = base + (size_t)it * GP_WAVE + lane;
         if (idx < n) {
             const uint32_t digit = (k[it] >> shift) & mask;
-            const uint32_t pos = s_cnt[wave][digit] + r[it];
-            keys_out[pos] = k[it];
-            vals_out[pos] = v[it];
+            const uint32_t lp = s_cnt[wave][digit] + r[it];
+            s_k[lp] = k[it];
+            s_v[lp] = v[it];
         }
+    }
+    __syncthreads();
+    const size_t bbase = (size_t)blockIdx.x * RS_TILE;
+    const uint32_t bn = (uint32_t)(n - bbase < RS_TILE ? n - bbase : RS_TILE);
+    for (uint32_t p = tid; p < bn; p += RS_BLOCK) {
+        const uint32_t kk = s_k[p];
+        const uint32_t pos = p + s_dbase[(kk >> shift) & mask];
+        keys_out[pos] = kk;
+        vals_out[pos] = s_v[p];
     }
 }
 
