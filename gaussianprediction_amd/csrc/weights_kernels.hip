@@ -276,3 +276,345 @@ extern "C" int gp_knn_keypoints(int64_t n, const float* xyz, const float* feat, 
     GP_LAUNCH_CHECK();
     return 0;
 }
+
+// ------------------------------------------------------------------------------------------------
+// Fused weights model: hash-grid encoding + the 64-wide bias-free MLP (64 -> 64 -> 64 -> 16, ReLU) on the exact-fp32
+// matrix cores, persistent workgroups.  A workgroup walks blocks of 64 points (in `perm` order); per block the
+// activations live transposed in LDS, T[f][p] at f*64 + (p & 32) + ((p & 31) ^ (f & 31)) -- conflict-free both for the
+// layer products (lanes = points) and for the weight-gradient products (lanes = features).  The weight matrices stay in
+// registers as MFMA A operands for the whole kernel.
+//   forward : out[i][0..n_out) and (training) the encoded features, saved slot-major ([slot][64], slot = position in perm)
+//   backward: recomputes the two hidden layers from the saved features, back-propagates, accumulates the three weight
+//             gradients in MFMA accumulators across all of the workgroup's blocks (flushed once, as full cache lines)
+//             and writes dL/d(features) slot-major for the table-gradient kernel.
+// ------------------------------------------------------------------------------------------------
+typedef float wf32x16 __attribute__((ext_vector_type(16)));
+#define WM_THREADS 256
+__device__ __forceinline__ int wm_ti(int f, int p) { return f * 64 + (p & 32) + ((p & 31) ^ (f & 31)); }
+__device__ __forceinline__ int wm_row(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
+
+// acc[32 x 32] += A[32 x 64] . T[64 x 32 points of tile tj], A rows in registers (a[s] = A[i][2 s + half])
+__device__ __forceinline__ wf32x16 wm_layer(const float (&a)[32], const float* T, int tj, int lane) {
+    const int j = lane & 31, half = lane >> 5;
+    wf32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int s = 0; s < 32; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], T[wm_ti(2 * s + half, 32 * tj + j)], acc, 0, 0, 0);
+    return acc;
+}
+// acc[32 features ta x 32 features tb] += sum over the block's 64 points of  TA[32 ta + i][p] * TB[32 tb + j][p]
+__device__ __forceinline__ void wm_outer(wf32x16& acc, const float* TA, int ta, const float* TB, int tb, int lane) {
+    const int j = lane & 31, half = lane >> 5;
+#pragma unroll 8
+    for (int s = 0; s < 32; ++s) {
+        const int p = 2 * s + half;
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(TA[wm_ti(32 * ta + j, p)], TB[wm_ti(32 * tb + j, p)], acc, 0, 0, 0);
+    }
+}
+
+__device__ __forceinline__ void wm_encode_block(const HashGridDev& g, long n, long slot0, const float* __restrict__ xyz,
+                                                const int32_t* __restrict__ perm, const float4* __restrict__ table, float* T,
+                                                int tid) {
+    const int p = tid & 63;
+    const long slot = slot0 + p;
+    const bool live = slot < n;
+    const long i = live ? (perm ? (long)perm[slot] : slot) : 0;
+    for (int l = tid >> 6; l < HG_MAX_LEVELS; l += 4) {
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (live && l < g.L) {
+            float w[3];
+            uint32_t c[3];
+            hg_cell(g, l, xyz, i, w, c);
+            const float4* tl = table + g.off[l];
+#pragma unroll
+            for (int corner = 0; corner < 8; ++corner) {
+                const int bx = corner & 1, by = (corner >> 1) & 1, bz = corner >> 2;
+                float cw = (bx ? w[0] : 1.f - w[0]);
+                cw = cw * (by ? w[1] : 1.f - w[1]);
+                cw = cw * (bz ? w[2] : 1.f - w[2]);
+                const float4 v = tl[hg_index(g, l, c[0] + bx, c[1] + by, c[2] + bz)];
+                acc.x = acc.x + cw * v.x; acc.y = acc.y + cw * v.y; acc.z = acc.z + cw * v.z; acc.w = acc.w + cw * v.w;
+            }
+        }
+        T[wm_ti(4 * l + 0, p)] = acc.x; T[wm_ti(4 * l + 1, p)] = acc.y; T[wm_ti(4 * l + 2, p)] = acc.z; T[wm_ti(4 * l + 3, p)] = acc.w;
+    }
+}
+
+// A operand rows of W (row-major [rows, 64]): a[s] = W[32 ti + i][2 s + half]   (rows >= valid_rows read as 0)
+__device__ __forceinline__ void wm_load_rows(float (&a)[32], const float* __restrict__ W, int ti, int valid_rows, int lane) {
+    const int i = lane & 31, half = lane >> 5;
+    const int row = 32 * ti + i;
+#pragma unroll
+    for (int s = 0; s < 32; ++s) a[s] = row < valid_rows ? W[row * 64 + 2 * s + half] : 0.f;
+}
+// A operand rows of W^T: a[s] = W[2 s + half][32 ti + i]   (W is [k_valid, 64]; rows >= k_valid read as 0)
+__device__ __forceinline__ void wm_load_cols(float (&a)[32], const float* __restrict__ W, int ti, int k_valid, int lane) {
+    const int i = lane & 31, half = lane >> 5;
+#pragma unroll
+    for (int s = 0; s < 32; ++s) a[s] = (2 * s + half) < k_valid ? W[(2 * s + half) * 64 + 32 * ti + i] : 0.f;
+}
+
+__global__ __launch_bounds__(WM_THREADS) void gp_wm_fwd_kernel(HashGridDev g, long n, const float* __restrict__ xyz,
+                                                              const int32_t* __restrict__ perm, const float* __restrict__ params,
+                                                              int n_out, float* __restrict__ out, float* __restrict__ saved_feat) {
+    __shared__ float sA[64 * 64], sB[64 * 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, half = lane >> 5;
+    const int ti = wave & 1, tj = wave >> 1;
+    const float* W1 = params;
+    const float* W2 = params + 4096;
+    const float* W3 = params + 8192;
+    const float4* table = (const float4*)(params + 9216);
+    float w1[32], w2[32], w3[32];
+    wm_load_rows(w1, W1, ti, 64, lane);
+    wm_load_rows(w2, W2, ti, 64, lane);
+    wm_load_rows(w3, W3, 0, 16, lane);
+    const long nblocks = (n + 63) / 64;
+    for (long b = blockIdx.x; b < nblocks; b += gridDim.x) {
+        const long slot0 = b * 64;
+        __syncthreads();
+        wm_encode_block(g, n, slot0, xyz, perm, table, sA, tid);
+        __syncthreads();
+        if (saved_feat) {   // slot-major rows of 64 floats
+            for (int e = tid; e < 64 * 64; e += WM_THREADS) {
+                const int p = e >> 6, f = e & 63;
+                if (slot0 + p < n) saved_feat[(slot0 + p) * 64 + f] = sA[wm_ti(f, p)];
+            }
+        }
+        wf32x16 acc = wm_layer(w1, sA, tj, lane);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sB[wm_ti(32 * ti + wm_row(r, half), 32 * tj + j)] = fmaxf(acc[r], 0.f);
+        __syncthreads();
+        acc = wm_layer(w2, sB, tj, lane);
+        __syncthreads();                        // everyone is done reading sA (features) before it is overwritten
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sA[wm_ti(32 * ti + wm_row(r, half), 32 * tj + j)] = fmaxf(acc[r], 0.f);
+        __syncthreads();
+        if (ti == 0) {                          // output layer: rows 0..15 of a 32-row tile, one tile per point half
+            acc = wm_layer(w3, sA, tj, lane);
+            const long slot = slot0 + 32 * tj + j;
+            if (slot < n) {
+                const long i = perm ? (long)perm[slot] : slot;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int f = wm_row(r, half);
+                    if (f < n_out) out[i * n_out + f] = acc[r];
+                }
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(WM_THREADS) void gp_wm_bwd_kernel(long n, const int32_t* __restrict__ perm,
+                                                              const float* __restrict__ params, int n_out,
+                                                              const float* __restrict__ saved_feat, const float* __restrict__ dL_dout,
+                                                              float* __restrict__ dparams, float* __restrict__ dfeat) {
+    __shared__ float sA[64 * 64], sB[64 * 64], sC[64 * 64], sD[32 * 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, half = lane >> 5;
+    const int ti = wave & 1, tj = wave >> 1;
+    const float* W1 = params;
+    const float* W2 = params + 4096;
+    const float* W3 = params + 8192;
+    float w1[32], w2[32], w1t[32], w2t[32], w3t[8];
+    wm_load_rows(w1, W1, ti, 64, lane);
+    wm_load_rows(w2, W2, ti, 64, lane);
+    wm_load_cols(w1t, W1, ti, 64, lane);
+    wm_load_cols(w2t, W2, ti, 64, lane);
+    {
+        const int i = lane & 31;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) w3t[s] = W3[(2 * s + half) * 64 + 32 * ti + i];   // W3^T, k = 2 s + half < 16
+    }
+    wf32x16 g1, g2, g3;   // dW1 / dW2 tile (ti = output rows, tj = input columns), dW3 tile (rows 0..31, columns 32 tj ..) on ti == 0
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { g1[r] = 0.f; g2[r] = 0.f; g3[r] = 0.f; }
+    const long nblocks = (n + 63) / 64;
+    for (long b = blockIdx.x; b < nblocks; b += gridDim.x) {
+        const long slot0 = b * 64;
+        __syncthreads();
+        for (int e = tid; e < 64 * 64; e += WM_THREADS) {            // X^T
+            const int p = e >> 6, f = e & 63;
+            sA[wm_ti(f, p)] = slot0 + p < n ? saved_feat[(slot0 + p) * 64 + f] : 0.f;
+        }
+        for (int e = tid; e < 32 * 64; e += WM_THREADS) {            // dZ3^T, rows >= n_out zero
+            const int p = e >> 5, f = e & 31;
+            float v = 0.f;
+            if (f < n_out && slot0 + p < n) v = dL_dout[(perm ? (long)perm[slot0 + p] : slot0 + p) * n_out + f];
+            sD[wm_ti(f, p)] = v;
+        }
+        __syncthreads();
+        wf32x16 acc = wm_layer(w1, sA, tj, lane);                    // H1^T -> sB
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sB[wm_ti(32 * ti + wm_row(r, half), 32 * tj + j)] = fmaxf(acc[r], 0.f);
+        __syncthreads();
+        acc = wm_layer(w2, sB, tj, lane);                            // H2^T -> sC
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sC[wm_ti(32 * ti + wm_row(r, half), 32 * tj + j)] = fmaxf(acc[r], 0.f);
+        __syncthreads();
+        if (ti == 0) wm_outer(g3, sD, 0, sC, tj, lane);              // dW3[o][i] += dZ3^T[o][p] H2^T[i][p]
+        {   // dH2^T = W3^T dZ3^T (K = 16), masked by H2 > 0, in place over sC
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+            for (int s = 0; s < 8; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w3t[s], sD[wm_ti(2 * s + half, 32 * tj + j)], acc, 0, 0, 0);
+            __syncthreads();                                         // dW3 products have read sC
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int idx = wm_ti(32 * ti + wm_row(r, half), 32 * tj + j);
+                sC[idx] = sC[idx] > 0.f ? acc[r] : 0.f;
+            }
+        }
+        __syncthreads();
+        wm_outer(g2, sC, ti, sB, tj, lane);                          // dW2[o][i] += dZ2^T[o][p] H1^T[i][p]
+        acc = wm_layer(w2t, sC, tj, lane);                           // dH1^T = W2^T dZ2^T
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int idx = wm_ti(32 * ti + wm_row(r, half), 32 * tj + j);
+            sB[idx] = sB[idx] > 0.f ? acc[r] : 0.f;                  // dZ1^T in place over H1^T
+        }
+        __syncthreads();
+        wm_outer(g1, sB, ti, sA, tj, lane);                          // dW1[o][i] += dZ1^T[o][p] X^T[i][p]
+        acc = wm_layer(w1t, sB, tj, lane);                           // dX^T = W1^T dZ1^T -> sC
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sC[wm_ti(32 * ti + wm_row(r, half), 32 * tj + j)] = acc[r];
+        __syncthreads();
+        for (int e = tid; e < 64 * 64; e += WM_THREADS) {            // slot-major rows for the table-gradient kernel
+            const int p = e >> 6, f = e & 63;
+            if (slot0 + p < n) dfeat[(slot0 + p) * 64 + f] = sC[wm_ti(f, p)];
+        }
+    }
+    // flush the weight gradients: for a fixed register the 32 lanes of a half write 128 contiguous bytes
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = 32 * ti + wm_row(r, half);
+        atomicAdd(&dparams[row * 64 + 32 * tj + j], g1[r]);
+        atomicAdd(&dparams[4096 + row * 64 + 32 * tj + j], g2[r]);
+        if (ti == 0 && wm_row(r, half) < 16) atomicAdd(&dparams[8192 + wm_row(r, half) * 64 + 32 * tj + j], g3[r]);
+    }
+}
+
+// table gradient from slot-major feature gradients (the fused backward's output).
+// Measured cost model on this part: an atomic instruction costs ~29 CU-cycles per DISTINCT cache line it touches.
+// EIGHT lanes per (point, level): (x-corner bit, component).  The two x-neighbours of a corner pair are adjacent table
+// entries on dense levels and -- because the x prime of the spatial hash is 1 -- within the same aligned group of four
+// entries (one 64-byte line) three times out of four on hashed levels, so the eight lanes usually share ONE line:
+// ~5 line-operations per (point, level) instead of 8.
+#define HG_BOX_CAP 1024   // LDS box entries (x 4 floats) for the dense levels
+__global__ __launch_bounds__(256) void gp_hashgrid_bwd_slots_kernel(HashGridDev g, long n, const float* __restrict__ xyz,
+                                                                   const int32_t* __restrict__ perm, const float* __restrict__ dfeat,
+                                                                   float* __restrict__ dtable) {
+    __shared__ float s_box[HG_BOX_CAP * 4];
+    __shared__ int s_lo[3], s_hi[3];
+    const int tid = threadIdx.x;
+    const int comp = tid & 3, bx = (tid >> 2) & 1, pl = tid >> 3;
+    const long slot = (long)blockIdx.x * 32 + pl;
+    const bool live = slot < n;
+    const long i = live ? (perm ? (long)perm[slot] : slot) : 0;
+    for (int l = 0; l < g.L; ++l) {
+        const float go = live ? dfeat[slot * 64 + 4 * l + comp] : 0.f;
+        float w[3];
+        uint32_t c[3];
+        hg_cell(g, l, xyz, i, w, c);
+        float* tl = dtable + 4 * (size_t)g.off[l];
+        const float wx = bx ? w[0] : 1.f - w[0];
+        bool boxed = false;
+        int ex = 0, ey = 0;
+        if (g.dense[l]) {
+            // Dense (coarse) level: the workgroup's 32 spatially adjacent points fall into a handful of cells, i.e. they
+            // would all hammer the same few entries.  Accumulate in an LDS box spanning their cells and flush each entry
+            // once, as whole cache lines (consecutive x entries x 4 components from consecutive lanes).
+            if (tid < 3) { s_lo[tid] = 0x7fffffff; s_hi[tid] = -0x7fffffff; }
+            __syncthreads();
+            if (live && bx == 0 && comp < 3) { atomicMin(&s_lo[comp], (int)c[comp]); atomicMax(&s_hi[comp], (int)c[comp]); }
+            __syncthreads();
+            const int lo0 = s_lo[0], lo1 = s_lo[1], lo2 = s_lo[2];
+            ex = s_hi[0] - lo0 + 2; ey = s_hi[1] - lo1 + 2;
+            const int ez = s_hi[2] - lo2 + 2;
+            const long vol = (long)ex * ey * ez;
+            boxed = s_hi[0] >= lo0 && vol <= HG_BOX_CAP;            // uniform
+            if (boxed) {
+                for (int e = tid; e < (int)vol * 4; e += 256) s_box[e] = 0.f;
+                __syncthreads();
+                if (live) {
+#pragma unroll
+                    for (int cyz = 0; cyz < 4; ++cyz) {
+                        const int by = cyz & 1, bz = cyz >> 1;
+                        float cw = wx * (by ? w[1] : 1.f - w[1]);
+                        cw = cw * (bz ? w[2] : 1.f - w[2]);
+                        const float v = cw * go;
+                        const int bi = (((int)c[2] - lo2 + bz) * ey + ((int)c[1] - lo1 + by)) * ex + ((int)c[0] - lo0 + bx);
+                        if (v != 0.f) atomicAdd(&s_box[4 * bi + comp], v);
+                    }
+                }
+                __syncthreads();
+                for (int e = tid; e < (int)vol * 4; e += 256) {
+                    const float v = s_box[e];
+                    if (v != 0.f) {
+                        const int bi = e >> 2, x = bi % ex, y = (bi / ex) % ey, z = bi / (ex * ey);
+                        atomicAdd(tl + 4 * (size_t)hg_index(g, l, (uint32_t)(lo0 + x), (uint32_t)(lo1 + y), (uint32_t)(lo2 + z)) + (e & 3), v);
+                    }
+                }
+                __syncthreads();
+            }
+        }
+        if (!boxed && live) {
+#pragma unroll
+            for (int cyz = 0; cyz < 4; ++cyz) {
+                const int by = cyz & 1, bz = cyz >> 1;
+                float cw = wx * (by ? w[1] : 1.f - w[1]);
+                cw = cw * (bz ? w[2] : 1.f - w[2]);
+                const float v = cw * go;
+                if (v != 0.f) atomicAdd(tl + 4 * (size_t)hg_index(g, l, c[0] + bx, c[1] + by, c[2] + bz) + comp, v);
+            }
+        }
+    }
+}
+
+static int wm_check(const gp_hashgrid_config* cfg, HashGridDev& g, int64_t n, int32_t n_out) {
+    if (make_grid(cfg, g, nullptr)) return 1;
+    if (g.L != 16) GP_FAIL("fused weights model: n_levels must be 16 (64 encoded features)");
+    if (n < 0) GP_FAIL("negative n");
+    if (n_out < 1 || n_out > 16) GP_FAIL("fused weights model: n_out must be 1..16");
+    return 0;
+}
+
+extern "C" int gp_weights_forward(const gp_hashgrid_config* cfg, int64_t n, const float* xyz, const int32_t* perm, const float* params,
+                                  int32_t n_out, float* out, float* saved_feat, gp_stream_t stream_) {
+    HashGridDev g;
+    if (wm_check(cfg, g, n, n_out)) return 1;
+    if (n == 0) return 0;
+    if (!xyz || !params || !out) GP_FAIL("null argument");
+    if (((uintptr_t)params & 15) != 0) GP_FAIL("weights model: params must be 16-byte aligned");
+    hipStream_t s = (hipStream_t)stream_;
+    GpProfScope _p("weights_fwd", s);
+    const unsigned nb = (unsigned)((n + 63) / 64);
+    hipLaunchKernelGGL(gp_wm_fwd_kernel, dim3(nb < 1024u ? nb : 1024u), dim3(WM_THREADS), 0, s, g, (long)n, xyz, perm, params, n_out, out,
+                       saved_feat);
+    GP_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int gp_weights_backward(const gp_hashgrid_config* cfg, int64_t n, const float* xyz, const int32_t* perm, const float* params,
+                                   int32_t n_out, const float* saved_feat, const float* dL_dout, float* dparams, gp_alloc_fn alloc,
+                                   void* alloc_ctx, gp_stream_t stream_) {
+    HashGridDev g;
+    if (wm_check(cfg, g, n, n_out)) return 1;
+    if (n == 0) return 0;
+    if (!xyz || !params || !saved_feat || !dL_dout || !dparams || !alloc) GP_FAIL("null argument");
+    hipStream_t s = (hipStream_t)stream_;
+    float* dfeat = (float*)alloc(alloc_ctx, GP_BUF_TEMP, gp_align_up((size_t)n * 64 * sizeof(float), 256));
+    if (!dfeat) GP_FAIL("allocator returned NULL for TEMP");
+    const unsigned nb = (unsigned)((n + 63) / 64);
+    {
+        GpProfScope _p("weights_bwd_mlp", s);
+        hipLaunchKernelGGL(gp_wm_bwd_kernel, dim3(nb < 512u ? nb : 512u), dim3(WM_THREADS), 0, s, (long)n, perm, params, n_out, saved_feat,
+                           dL_dout, dparams, dfeat);
+        GP_LAUNCH_CHECK();
+    }
+    GpProfScope _p("weights_bwd_table", s);
+    hipLaunchKernelGGL(gp_hashgrid_bwd_slots_kernel, dim3((unsigned)((n + 31) / 32)), dim3(256), 0, s, g, (long)n, xyz, perm,
+                       (const float*)dfeat, dparams + 9216);
+    GP_LAUNCH_CHECK();
+    return 0;
+}

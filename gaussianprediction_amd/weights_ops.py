@@ -76,6 +76,52 @@ class _HashGridEncode(torch.autograd.Function):
         return None, dtable, None, None
 
 
+class _WeightsModelFused(torch.autograd.Function):
+    """encode + MLP in one HIP kernel each way (gp_weights_forward / gp_weights_backward)."""
+
+    @staticmethod
+    def forward(ctx, xyz, params, cfg, n_out, perm):
+        _need_cuda(xyz, "weights model")
+        x = xyz.detach().to(torch.float32).contiguous()
+        p = params.detach().contiguous()
+        n = x.shape[0]
+        need = params.requires_grad
+        out = torch.empty(n, n_out, device=x.device)
+        feat = torch.empty(n, 64, device=x.device) if need else None
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.lib().gp_weights_forward(C.byref(cfg), C.c_int64(n), _lib.ptr(x), _lib.ptr(perm), _lib.ptr(p),
+                                                     C.c_int32(n_out), _lib.ptr(out), _lib.ptr(feat), _lib.stream_ptr(x.device)),
+                       "gp_weights_forward")
+        if need:
+            ctx.save_for_backward(x, p, feat)
+            ctx.cfg, ctx.n_out, ctx.perm, ctx.leaf = cfg, n_out, perm, params
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        from . import grad_sink
+        x, p, feat = ctx.saved_tensors
+        g = g.to(torch.float32).contiguous()
+        sink = grad_sink.sink_of(ctx.leaf)
+        if sink is not None and grad_sink.take_stale(sink):
+            sink.zero_()
+        dparams = sink if sink is not None else torch.zeros_like(p)
+        alloc = _lib.TorchAllocator(x.device)
+        with torch.cuda.device(x.device):
+            rc = _lib.lib().gp_weights_backward(C.byref(ctx.cfg), C.c_int64(x.shape[0]), _lib.ptr(x), _lib.ptr(ctx.perm), _lib.ptr(p),
+                                                C.c_int32(ctx.n_out), _lib.ptr(feat), _lib.ptr(g), _lib.ptr(dparams), alloc.cb, None,
+                                                _lib.stream_ptr(x.device))
+        err = alloc.error
+        alloc.release()
+        if err is not None:
+            raise err
+        _lib.check(rc, "gp_weights_backward")
+        if sink is not None:
+            grad_sink.notify(ctx.leaf)
+            return None, None, None, None, None
+        return None, dparams, None, None, None
+
+
 class WeightsModel(nn.Module):
     """Drop-in for the reference's `tcnn.NetworkWithInputEncoding(n_input_dims=3, n_output_dims=2*nearest_num, Grid/Hash
     encoding, FullyFusedMLP 64 x 2 hidden, ReLU)`.  One flat parameter `params` (as tcnn exposes it): the three
@@ -105,6 +151,7 @@ class WeightsModel(nn.Module):
         grid = (torch.rand(entries * 4, generator=gen) * 2 - 1) * 1e-4     # tcnn's grid initialisation range
         self.params = nn.Parameter(torch.cat([mlp, grid]).to(device))
         self._perm, self._perm_age = None, 0
+        self.fused = True
         self.perm_refresh = 200          # frames between refreshes of the spatial order (Gaussians move slowly)
 
     def spatial_order(self, xyz):
@@ -114,10 +161,17 @@ class WeightsModel(nn.Module):
         return self._perm
 
     def forward(self, xyz):
+        perm = self.spatial_order(xyz) if xyz.shape[0] > 4096 else None
+        if self.cfg.n_levels == 16 and self.fused:
+            return _WeightsModelFused.apply(xyz, self.params, self.cfg, self.n_output_dims, perm)
+        return self.forward_unfused(xyz, perm)
+
+    def forward_unfused(self, xyz, perm=None):
+        """Encoding kernel + three library GEMMs (any n_levels; also the cross-check of the fused path)."""
         p = self.params
         w1, w2, w3 = p[0:4096].view(64, 64), p[4096:8192].view(64, 64), p[8192:MLP_FLOATS].view(16, 64)
         table = p[MLP_FLOATS:].view(-1, 4)
-        feat = _HashGridEncode.apply(xyz, table, self.cfg, self.spatial_order(xyz) if xyz.shape[0] > 4096 else None)
+        feat = _HashGridEncode.apply(xyz, table, self.cfg, perm)
         h = torch.relu(feat @ w1.t())
         h = torch.relu(h @ w2.t())
         return (h @ w3.t())[:, :self.n_output_dims]

@@ -269,6 +269,16 @@ int gp_hashgrid_forward(const gp_hashgrid_config* cfg, int64_t n, const float* x
 /* dtable += d out / d table applied to dL_dout[n, n_levels*4] (xyz is detached in the reference: no position gradient) */
 int gp_hashgrid_backward(const gp_hashgrid_config* cfg, int64_t n, const float* xyz, const int32_t* perm, const float* dL_dout,
                          float* dtable, gp_stream_t stream);
+/* the whole weights model fused: hash-grid encoding + the 64-wide bias-free MLP (64 -> 64 -> 64 -> 16 padded, ReLU) on
+ * the fp32 matrix cores.  params = [W1 64x64 | W2 64x64 | W3 16x64 | table entries x 4] (one flat tensor, as tcnn exposes
+ * it); out[n, n_out] = first n_out columns.  saved_feat (optional, [n,64], slot-major: row k belongs to point perm[k]) is
+ * what the backward needs.  n_levels must be 16. */
+int gp_weights_forward(const gp_hashgrid_config* cfg, int64_t n, const float* xyz, const int32_t* perm, const float* params,
+                       int32_t n_out, float* out, float* saved_feat, gp_stream_t stream);
+/* dparams (same layout as params) += gradient of sum(out * dL_dout) */
+int gp_weights_backward(const gp_hashgrid_config* cfg, int64_t n, const float* xyz, const int32_t* perm, const float* params,
+                        int32_t n_out, const float* saved_feat, const float* dL_dout, float* dparams, gp_alloc_fn alloc,
+                        void* alloc_ctx, gp_stream_t stream);
 /* idx_out[n, nn] (int64, ascending squared distance; ties to the lower index) = the nn nearest of the K keypoints, in 3-D
  * (feat_dim = 0: knn_type "3D") or in [xyz | amplify * feature] (feat_dim = 32: "hybird")
  * [REF scene/gaussian_model.py:110-125, frnn.frnn_grid_points].  d2_out (optional) receives the squared distances. */

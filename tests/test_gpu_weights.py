@@ -69,8 +69,30 @@ def test_spatial_order_changes_nothing():
     assert np.linalg.norm(grads[0] - grads[1]) <= 1e-5 * np.linalg.norm(grads[0])
 
 
-def test_hashgrid_backward_matches_autograd():
+def test_fused_matches_unfused_with_spatial_order():
+    """n > 4096: Morton order + persistent fused kernels vs the encode kernel + library GEMMs."""
+    m = _small_model(log2_T=13)
+    rng = np.random.default_rng(21)
+    xyz = torch.tensor(rng.uniform(-1.5, 1.5, size=(9001, 3)).astype(np.float32)).cuda()
+    gy = torch.tensor(rng.normal(size=(9001, 12)).astype(np.float32)).cuda()
+    with torch.no_grad():
+        m.params[wo_mlp():] = torch.tensor(rng.normal(size=m.params.numel() - wo_mlp()).astype(np.float32)).cuda()
+    res = []
+    for fused in (True, False):
+        m.fused = fused
+        m.params.grad = None
+        o = m(xyz)
+        (o * gy).sum().backward()
+        res.append((o.detach().cpu().numpy(), m.params.grad.cpu().numpy()))
+    assert np.abs(res[0][0] - res[1][0]).max() < 2e-4 * max(1.0, np.abs(res[1][0]).max())
+    rel = np.linalg.norm(res[0][1] - res[1][1]) / np.linalg.norm(res[1][1])
+    assert rel < 1e-4, rel
+
+
+@pytest.mark.parametrize("fused", [True, False])
+def test_hashgrid_backward_matches_autograd(fused):
     m = _small_model(log2_T=9)
+    m.fused = fused
     meta = wo.grid_meta(16, 4, 9, 16)
     rng = np.random.default_rng(5)
     xyz = torch.tensor(rng.uniform(-1.2, 1.2, size=(300, 3)).astype(np.float32))
