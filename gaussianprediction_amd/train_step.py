@@ -57,7 +57,7 @@ class TrainStep:
         # camera times live on the device: a per-step H2D copy from pageable memory would be a host sync
         self.times = [torch.from_numpy(c.time).to(torch.float32).to(dev) for c in cameras]
         lr = dict(xyz=1.6e-4, f_dc=2.5e-3, f_rest=2.5e-3 / 20, opacity=0.05, scaling=5e-3, rotation=1e-3, mfeature=8e-4,
-                  kpts=8e-4, mlp=8e-4)              # [REF arguments/__init__.py:74-90]
+                  kpts=8e-4, mlp=8e-4, hash=1e-3)   # [REF arguments/__init__.py:74-90]
         if lrs:
             lr.update(lrs)
         # parameter groups per training stage, as the reference builds them
@@ -75,6 +75,8 @@ class TrainStep:
         if hasattr(pc, "super_gaussians"):
             g_kp = [{"params": [pc.super_gaussians], "lr": lr["kpts"], "name": "s_xyz"},
                     {"params": [pc.super_gaussians_feature], "lr": lr["kpts"], "name": "s_motion_feature"}]
+            if getattr(pc, "weights_model", None) is not None and pc.raw_weights is None:   # [REF :402,421 "weight_mlp"]
+                g_kp.append({"params": list(pc.weights_model.parameters()), "lr": lr["hash"], "name": "weight_mlp"})
         if iteration <= pc.second_stage_iter:                      # stage 1
             groups = g_gauss + g_mlp + [{"params": [pc.motion_feature], "lr": lr["mfeature"], "name": "motion_feature"}]
         elif iteration <= pc.third_stage_iter:                     # stage 2: keypoints + MLP only

@@ -38,3 +38,26 @@ for _ in range(5): fwdbwd()
 torch.cuda.synchronize()
 for k, (n_, ms) in sorted(_lib.profile_collect().items()):
     print(f"  {k:16s} {ms / n_:8.3f} ms")
+
+# ---- full stage-3 train step with the model computing its own weights + kNN per frame (what the reference's step does)
+import bench
+from types import SimpleNamespace
+from gaussianprediction_amd.train_step import TrainStep
+from gaussianprediction_amd.weights_ops import WeightsModel as WM
+args = SimpleNamespace(gaussians=N, width=1352, height=1014, keypoints=250, nearest_num=6, time_freq=8, iteration=50000,
+                       scale_lo=0.003, scale_hi=0.012)
+pc, cams, gts, margs = bench.build_workload(args, dev)
+margs.knn_type, margs.feature_amplify = "hybird", 5.0
+pc.weights_model = WM(12, device=dev)
+pc.set_keypoint_weights(None, None)
+ts = TrainStep(pc, cams, gts, 50000, lrs=dict(xyz=8e-6))
+for i in range(10): ts.step(i)
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for i in range(50): ts.step(i)
+torch.cuda.synchronize()
+print(f"stage-3 train step incl. weights model + kNN: {1e3 * (time.perf_counter() - t0) / 50:.3f} ms")
+_lib.profile_enable(2); _lib.profile_collect()
+for i in range(10): ts.step(i)
+torch.cuda.synchronize()
+for k, (n_, ms) in sorted(_lib.profile_collect().items(), key=lambda kv: -kv[1][1]):
+    print(f"  {k:18s} {ms / n_:8.3f} ms")
