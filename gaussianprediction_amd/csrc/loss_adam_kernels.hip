@@ -296,6 +296,26 @@ __global__ void gp_loss_finalize_kernel(const double* __restrict__ sums, double 
     loss[0] = (float)((1.0 - (double)lambda) * s0 / n + (double)lambda * (1.0 - s1 / n));
 }
 
+// out[0] = base[0] + scale * mean|x|   [REF scene/gaussian_model.py:174-178: 1e-5 * mean(|motion feature|)]
+// (multi-block: out is initialised by block 0's thread 0 through the host-side memset + base add)
+__global__ __launch_bounds__(256) void gp_l1_mean_fwd_kernel(const float* __restrict__ x, long n, float scale_over_n,
+                                                            const float* __restrict__ base, float* __restrict__ out) {
+    __shared__ float s_red[4];
+    float acc = 0.f;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) acc += fabsf(x[i]);
+    const float tot = block_sum_256(acc, s_red);
+    if (threadIdx.x == 0) atomicAdd(out, tot * scale_over_n + (blockIdx.x == 0 ? base[0] : 0.f));
+}
+// g[i] = upstream[0] * scale/n * sign(x[i])
+__global__ __launch_bounds__(256) void gp_l1_mean_bwd_kernel(const float* __restrict__ x, long n, float scale_over_n,
+                                                            const float* __restrict__ upstream, float* __restrict__ g) {
+    const float c = upstream[0] * scale_over_n;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const float v = x[i];
+        g[i] = v > 0.f ? c : (v < 0.f ? -c : 0.f);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // C ABI
 // ------------------------------------------------------------------------------------------------
@@ -386,6 +406,28 @@ extern "C" int gp_adam_step_multi(int32_t count, float* const* params, float* co
     const float bc2_sqrt = sqrtf(1.f - powf(beta2, (float)step));
     GpProfScope _p("adam", s);
     hipLaunchKernelGGL(gp_adam_multi_kernel, dim3(chunks), dim3(256), 0, s, t, beta1, beta2, eps, bc1, bc2_sqrt, zero_grad);
+    GP_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int gp_l1_mean_forward(const float* x, int64_t n, float scale, const float* base, float* out, gp_stream_t stream_) {
+    if (n <= 0) GP_FAIL("l1 mean: empty input");
+    if (!x || !base || !out) GP_FAIL("null argument");
+    hipStream_t s = (hipStream_t)stream_;
+    GP_HIP_CHECK(hipMemsetAsync(out, 0, sizeof(float), s));
+    unsigned blocks = gp_blocks((size_t)n, 4096);
+    if (blocks > 256) blocks = 256;
+    hipLaunchKernelGGL(gp_l1_mean_fwd_kernel, dim3(blocks), dim3(256), 0, s, x, (long)n, scale / (float)n, base, out);
+    GP_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int gp_l1_mean_backward(const float* x, int64_t n, float scale, const float* upstream, float* g, gp_stream_t stream_) {
+    if (n <= 0) GP_FAIL("l1 mean: empty input");
+    if (!x || !upstream || !g) GP_FAIL("null argument");
+    unsigned blocks = gp_blocks((size_t)n, 1024);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(gp_l1_mean_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream_, x, (long)n, scale / (float)n, upstream, g);
     GP_LAUNCH_CHECK();
     return 0;
 }

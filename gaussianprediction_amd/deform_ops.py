@@ -209,6 +209,15 @@ class FusedMlp16(torch.autograd.Function):
         return (g_feat, g_xyz, None, None, None, None, *wb_grads)
 
 
+def _overwrite_sink(leaf):
+    """`leaf.grad` if it is a direct-sink buffer marked stale (grad_sink.mark_stale): the kernel then writes the gradient
+    straight into it; None otherwise (the usual temporary + autograd accumulation)."""
+    sk = grad_sink.sink_of(leaf)
+    if sk is not None and grad_sink.take_stale(sk):
+        return sk
+    return None
+
+
 class KeypointBlend(torch.autograd.Function):
     """(xyz_t, q_t) from per-keypoint (nn>0) or per-Gaussian (raw_w is None) deltas."""
 
@@ -239,6 +248,7 @@ class KeypointBlend(torch.autograd.Function):
         ctx.save_for_backward(delta_c, raw_c if raw_c is not None else e,
                               idx_c if idx_c is not None else torch.empty(0, dtype=torch.int64, device=dev), xyz_c, rot_c)
         ctx.meta = (nn_, K, int(bool(norm_rotation)))
+        ctx.leaves = (xyz, rot)
         return xyz_t, q_t
 
     @staticmethod
@@ -254,8 +264,10 @@ class KeypointBlend(torch.autograd.Function):
                                rot_c.data_ptr())
         g_delta = torch.zeros_like(delta_c)
         g_raw = torch.empty_like(raw_c) if nn_ else None
-        g_xyz = torch.empty(N, 3, device=dev)
-        g_rot = torch.empty(N, 4, device=dev)
+        # a leaf whose gradient buffer the optimizer left stale is OVERWRITTEN in place (no temporary + AccumulateGrad pass)
+        sinks = [_overwrite_sink(t_) for t_ in ctx.leaves]
+        g_xyz = sinks[0] if sinks[0] is not None else torch.empty(N, 3, device=dev)
+        g_rot = sinks[1] if sinks[1] is not None else torch.empty(N, 4, device=dev)
         alloc = _lib.TorchAllocator(dev)
         with torch.cuda.device(dev):
             rc = _lib.lib().gp_blend_backward(C.byref(args), _lib.ptr(gx), _lib.ptr(gq), _lib.ptr(g_delta), _lib.ptr(g_raw),
@@ -266,7 +278,10 @@ class KeypointBlend(torch.autograd.Function):
                 raise err
             alloc.release()
             _lib.check(rc, "gp_blend_backward")
-        return g_delta, g_raw, None, g_xyz, g_rot, None
+        for t_, sk in zip(ctx.leaves, sinks):
+            if sk is not None:
+                grad_sink.notify(t_)
+        return g_delta, g_raw, None, (None if sinks[0] is not None else g_xyz), (None if sinks[1] is not None else g_rot), None
 
 
 class Activations(torch.autograd.Function):
@@ -290,6 +305,7 @@ class Activations(torch.autograd.Function):
             _lib.check(rc, "gp_activations_forward")
         ctx.save_for_backward(s_c, o_c, d_c if d_c is not None else torch.empty(0, device=dev))
         ctx.meta = (int(col), float(beta), d_c is not None)
+        ctx.leaves = (scaling_raw, opacity_raw)
         return scale, opacity
 
     @staticmethod
@@ -300,8 +316,9 @@ class Activations(torch.autograd.Function):
         N = s_c.shape[0]
         gs = g_scale.to(torch.float32).contiguous() if g_scale is not None else None
         go = g_opacity.to(torch.float32).contiguous() if g_opacity is not None else None
-        g_sraw = torch.empty(N, 3, device=dev)
-        g_oraw = torch.empty(N, 1, device=dev)
+        sinks = [_overwrite_sink(t_) for t_ in ctx.leaves]
+        g_sraw = sinks[0] if sinks[0] is not None else torch.empty(N, 3, device=dev)
+        g_oraw = sinks[1] if sinks[1] is not None else torch.empty(N, 1, device=dev)
         g_delta = torch.zeros_like(d_c) if has_d else None
         stride = d_c.shape[1] if has_d else 0
         dptr = C.c_void_p(d_c.data_ptr() + 4 * col) if has_d else None
@@ -311,4 +328,7 @@ class Activations(torch.autograd.Function):
                                                     C.c_float(beta), _lib.ptr(gs), _lib.ptr(go), _lib.ptr(g_sraw),
                                                     _lib.ptr(g_oraw), gdptr, _lib.stream_ptr(dev))
             _lib.check(rc, "gp_activations_backward")
-        return g_sraw, g_oraw, g_delta, None, None
+        for t_, sk in zip(ctx.leaves, sinks):
+            if sk is not None:
+                grad_sink.notify(t_)
+        return (None if sinks[0] is not None else g_sraw), (None if sinks[1] is not None else g_oraw), g_delta, None, None

@@ -58,6 +58,39 @@ class L1SSIMLoss(torch.autograd.Function):
         return dimg, None, None
 
 
+class _AddL1Mean(torch.autograd.Function):
+    """loss + scale * mean(|x|) in one kernel each way (the reference composes abs / mean / mul / add: ten launches on a
+    tensor of a few thousand elements)."""
+
+    @staticmethod
+    def forward(ctx, loss, x, scale):
+        if not x.is_cuda:
+            raise RuntimeError("add_l1_mean: HIP kernels only (no CPU fallback)")
+        xc = x.detach().to(torch.float32).contiguous()
+        base = loss.detach().to(torch.float32).reshape(1).contiguous()
+        out = torch.empty(1, device=xc.device)
+        with torch.cuda.device(xc.device):
+            _lib.check(_lib.lib().gp_l1_mean_forward(_lib.ptr(xc), C.c_int64(xc.numel()), C.c_float(scale), _lib.ptr(base),
+                                                     _lib.ptr(out), _lib.stream_ptr(xc.device)), "gp_l1_mean_forward")
+        ctx.save_for_backward(xc)
+        ctx.scale, ctx.shape = float(scale), x.shape
+        return out.reshape(loss.shape)
+
+    @staticmethod
+    def backward(ctx, g):
+        (xc,) = ctx.saved_tensors
+        up = g.detach().to(torch.float32).reshape(1).contiguous()
+        gx = torch.empty_like(xc)
+        with torch.cuda.device(xc.device):
+            _lib.check(_lib.lib().gp_l1_mean_backward(_lib.ptr(xc), C.c_int64(xc.numel()), C.c_float(ctx.scale), _lib.ptr(up),
+                                                      _lib.ptr(gx), _lib.stream_ptr(xc.device)), "gp_l1_mean_backward")
+        return g, gx.reshape(ctx.shape), None
+
+
+def add_l1_mean(loss, x, scale):
+    return _AddL1Mean.apply(loss, x, scale)
+
+
 def l1_ssim_loss(image, gt, lambda_dssim=0.2):
     return L1SSIMLoss.apply(image, gt, lambda_dssim)
 

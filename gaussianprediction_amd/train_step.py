@@ -13,7 +13,7 @@ import torch
 import torch.nn.functional as F
 
 from .dist import FlatGradBucket, OverlappedGradReducer
-from .loss_ops import FusedAdam, l1_ssim_loss
+from .loss_ops import FusedAdam, add_l1_mean, l1_ssim_loss
 from .renderer import render
 
 
@@ -97,6 +97,10 @@ class TrainStep:
     def loss_of(self, image, gt):
         if self.fused:
             loss = l1_ssim_loss(image, gt, self.lambda_dssim)
+            if self.iteration >= self.pc.args.jointly_iteration:            # [REF scene/gaussian_model.py:174-178]
+                feat = self.pc.super_gaussians_feature if self.iteration > self.pc.second_stage_iter else self.pc.motion_feature
+                return add_l1_mean(loss, feat, 1.0e-5)
+            return loss
         else:
             Ll1 = l1_loss(image, gt)
             loss = (1.0 - self.lambda_dssim) * Ll1 + self.lambda_dssim * (1.0 - ssim(image, gt, self.window))
@@ -111,11 +115,13 @@ class TrainStep:
         loss.backward()                              # hooks start the all-reduce of each large gradient as it completes
         self.reducer.finish()                        # SUM over views == the reference's --batch semantics
         if self.fused:
-            # the SH gradients (48 of the 59 floats per Gaussian) are written by the rasterizer backward in full: skip
-            # their zeroing pass here and let the next backward overwrite instead of accumulate
+            # the per-Gaussian gradients each have exactly one producer kernel that writes the whole tensor (SH: rasterizer
+            # backward; xyz / rotation: blend backward; scaling / opacity: activation backward): skip their zeroing pass
+            # here and let the next backward overwrite instead of accumulate
             keep = ()
             if not self.pipe.convert_SHs_python and self.iteration > self.pc.third_stage_iter:
-                keep = (self.pc._features_dc, self.pc._features_rest)
+                keep = (self.pc._features_dc, self.pc._features_rest, self.pc._xyz, self.pc._rotation, self.pc._scaling,
+                        self.pc._opacity)
             self.optimizer.step(zero_grad=True, keep_grad=keep)
         else:
             self.optimizer.step()

@@ -236,6 +236,11 @@ int gp_loss_l1_ssim_finalize(const double* sums, int32_t channels, int32_t H, in
 int gp_loss_l1_ssim_backward(const float* img, const float* gt, const float* dmaps, int32_t channels, int32_t H, int32_t W,
                              float lambda_dssim, const float* upstream, float* dimg, gp_stream_t stream);
 
+/* out[0] = base[0] + scale * mean(|x|): the motion-feature regulariser added to the loss
+ * [REF scene/gaussian_model.py:174-178, train.py:108-109]; g = upstream[0] * scale/n * sign(x). */
+int gp_l1_mean_forward(const float* x, int64_t n, float scale, const float* base, float* out, gp_stream_t stream);
+int gp_l1_mean_backward(const float* x, int64_t n, float scale, const float* upstream, float* g, gp_stream_t stream);
+
 /* torch.optim.Adam step (amsgrad off, no weight decay) on one flat tensor; optionally zeroes `grad`
  * [REF scene/gaussian_model.py:472, train.py:196-197].  `step` is the 1-based step count. */
 int gp_adam_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1, float beta2,
