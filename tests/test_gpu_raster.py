@@ -195,3 +195,45 @@ def test_full_size_properties():
     assert float((diff[1] - Tf * 0.6).abs().max()) < 1e-5 and float((diff[2] - Tf * 0.9).abs().max()) < 1e-5
     assert torch.equal(h0["tidx"], h1["tidx"]) and torch.equal(h0["radii"], h1["radii"])
     print(f"[full-size] N={N} R={R} R/N={R / N:.2f} visible={int((h0['radii'] > 0).sum())} mean_T={float(Tf.mean()):.3f}")
+
+
+def test_full_size_backward_is_linear_in_the_upstream_gradient():
+    """BASELINE config 3 size: the backward is a vector-Jacobian product, so bwd(a G1 + b G2) = a bwd(G1) + b bwd(G2)
+    (up to fp32 summation order: the accumulation uses atomics) -- a size-independent property of the whole
+    backward chain (composite backward with its compaction / scans / line atomics, preprocess backward)."""
+    from gaussianprediction_amd.scene_synth import SceneSpec, make_gaussians
+    from gaussianprediction_amd.cameras import orbit_cameras
+    import math
+    N, W, H = 1_000_000, 1352, 1014
+    raw = make_gaussians(SceneSpec(n_gaussians=N, extent=(1.5, 1.5, 0.5), scale_lo=0.003, scale_hi=0.012), device="cuda")
+    cam = orbit_cameras(8, 4.0, 2 * math.atan(1 / 1.8), W, H, arc_deg=40.0, elevation_deg=5.0, device="cuda")[5]
+    st = gpa.GaussianRasterizationSettings(
+        image_height=H, image_width=W, tanfovx=math.tan(cam.FoVx * 0.5), tanfovy=math.tan(cam.FoVy * 0.5),
+        bg=torch.tensor([0.1, 0.2, 0.3], device="cuda"), scale_modifier=1.0, viewmatrix=cam.world_view_transform,
+        projmatrix=cam.full_proj_transform, sh_degree=3, campos=cam.camera_center, prefiltered=False)
+    leaves = dict(means3D=raw["xyz"].clone().requires_grad_(True), opacities=torch.sigmoid(raw["opacity"]).requires_grad_(True),
+                  shs=torch.cat([raw["features_dc"], raw["features_rest"]], 1).requires_grad_(True),
+                  scales=torch.exp(raw["scaling"]).requires_grad_(True),
+                  rotations=torch.nn.functional.normalize(raw["rotation"]).requires_grad_(True))
+    m2 = torch.zeros(N, 3, device="cuda", requires_grad=True)
+    g = torch.Generator(device="cuda").manual_seed(5)
+    G1 = torch.randn(3, H, W, device="cuda", generator=g)
+    G2 = torch.randn(3, H, W, device="cuda", generator=g)
+    D1 = torch.randn(1, H, W, device="cuda", generator=g)
+    a, b = 0.7, -1.9
+
+    def vjp(gc, gd):
+        for t in list(leaves.values()) + [m2]:
+            t.grad = None
+        img, radii, depth, tidx = gpa.GaussianRasterizer(st)(means3D=leaves["means3D"], means2D=m2, shs=leaves["shs"],
+                                                            colors_precomp=None, opacities=leaves["opacities"],
+                                                            scales=leaves["scales"], rotations=leaves["rotations"], cov3D_precomp=None)
+        torch.autograd.backward([img, depth], [gc, gd])
+        return {k: v.grad.clone() for k, v in leaves.items()} | {"means2D": m2.grad.clone()}
+
+    r1, r2, r12 = vjp(G1, D1), vjp(G2, torch.zeros_like(D1)), vjp(a * G1 + b * G2, a * D1)
+    for k in r1:
+        lin = a * r1[k] + b * r2[k]
+        err = float((r12[k] - lin).norm() / lin.norm().clamp_min(1e-30))
+        assert err < 2e-4, (k, err)
+        assert torch.isfinite(r12[k]).all()
