@@ -68,6 +68,7 @@ class OverlappedGradReducer:
         self.large = [p for p in bucket.params if p.numel() >= small_numel]
         self.small = [p for p in bucket.params if p.numel() < small_numel]
         self._fired = set()
+        self._sink_cb = None
         if self.enabled:
             from . import grad_sink
             hooks = {id(p): self._make_hook(p) for p in self.large}
@@ -76,6 +77,14 @@ class OverlappedGradReducer:
             # leaves whose gradient is written directly by a kernel (grad_sink) never run AccumulateGrad:
             # they announce completion through the sink registry instead
             self._sink_cb = grad_sink.register_callback(lambda p: hooks[id(p)](p) if id(p) in hooks else None)
+
+    def close(self):
+        """Detach from the gradient-sink registry (call before the bucket is rebuilt)."""
+        if getattr(self, "_sink_cb", None) is not None:
+            from . import grad_sink
+            grad_sink.unregister_callback(self._sink_cb)
+            self._sink_cb = None
+        self.enabled = False
 
     def _make_hook(self, p):
         def hook(param):

@@ -47,6 +47,11 @@ def take_stale(g):
     return False
 
 
+def forget_all():
+    """Drop every stale mark (the gradient buffers were re-allocated)."""
+    _stale.clear()
+
+
 def is_stale(g):
     return g.data_ptr() in _stale
 

@@ -13,6 +13,7 @@ import torch
 import torch.nn.functional as F
 
 from .dist import FlatGradBucket, OverlappedGradReducer
+from . import grad_sink
 from .loss_ops import FusedAdam, add_l1_mean, l1_ssim_loss
 from .renderer import render
 
@@ -57,11 +58,16 @@ class TrainStep:
         # camera times live on the device: a per-step H2D copy from pageable memory would be a host sync
         self.times = [torch.from_numpy(c.time).to(torch.float32).to(dev) for c in cameras]
         lr = dict(xyz=1.6e-4, f_dc=2.5e-3, f_rest=2.5e-3 / 20, opacity=0.05, scaling=5e-3, rotation=1e-3, mfeature=8e-4,
-                  kpts=8e-4, mlp=8e-4, hash=1e-3)   # [REF arguments/__init__.py:74-90]
+                  kpts=8e-4, mlp=8e-4, hash=5e-3)   # [REF arguments/__init__.py:74-90]
         if lrs:
             lr.update(lrs)
-        # parameter groups per training stage, as the reference builds them
-        # [REF scene/gaussian_model.py:394-411 (stage 3), 413-430 (stage 2), 432-451 (stage 1)]
+        self.lr = lr
+        self._build_optimizer()
+
+    def _groups(self):
+        """Parameter groups per training stage, as the reference builds them
+        [REF scene/gaussian_model.py:394-411 (stage 3), 413-430 (stage 2), 432-451 (stage 1)]."""
+        pc, lr, iteration = self.pc, self.lr, self.iteration
         g_gauss = [
             {"params": [pc._xyz], "lr": lr["xyz"], "name": "xyz"},
             {"params": [pc._features_dc], "lr": lr["f_dc"], "name": "f_dc"},
@@ -78,21 +84,54 @@ class TrainStep:
             if getattr(pc, "weights_model", None) is not None and pc.raw_weights is None:   # [REF :402,421 "weight_mlp"]
                 g_kp.append({"params": list(pc.weights_model.parameters()), "lr": lr["hash"], "name": "weight_mlp"})
         if iteration <= pc.second_stage_iter:                      # stage 1
-            groups = g_gauss + g_mlp + [{"params": [pc.motion_feature], "lr": lr["mfeature"], "name": "motion_feature"}]
-        elif iteration <= pc.third_stage_iter:                     # stage 2: keypoints + MLP only
-            groups = g_kp + g_mlp
-        else:                                                      # stage 3: everything except the per-Gaussian feature
-            groups = g_gauss + g_kp + g_mlp
+            return g_gauss + g_mlp + [{"params": [pc.motion_feature], "lr": lr["mfeature"], "name": "motion_feature"}]
+        if iteration <= pc.third_stage_iter:                       # stage 2: keypoints + MLP only
+            return g_kp + g_mlp
+        return g_gauss + g_kp + g_mlp                              # stage 3: everything except the per-Gaussian feature
+
+    def _build_optimizer(self):
+        pc = self.pc
+        groups = self._groups()
         optimized = {id(p) for g in groups for p in g["params"]}
         for p in pc.parameters():                                  # the reference computes (and ignores) these grads
-            if id(p) not in optimized:
-                p.requires_grad_(False)
+            p.requires_grad_(id(p) in optimized)
         self.bucket = FlatGradBucket([p for g in groups for p in g["params"]])
-        self.reducer = OverlappedGradReducer(self.bucket, group)
-        if fused:
+        self.reducer = OverlappedGradReducer(self.bucket, self.group)
+        if self.fused:
             self.optimizer = FusedAdam(groups, self.bucket, eps=1e-15)
         else:
             self.optimizer = torch.optim.Adam(groups, lr=0.0, eps=1e-15, foreach=True)   # [REF scene/gaussian_model.py:472]
+
+    # ---- optimizer-state surgery (densify / prune, gaussianprediction_amd/densify.py) ---------------------------
+    def adam_moments(self):
+        """{id(param): (exp_avg, exp_avg_sq)} of the current optimizer."""
+        if self.fused:
+            return {id(p): (m, v) for _, p, _, m, v in self.optimizer.items}
+        return {id(p): (st["exp_avg"], st["exp_avg_sq"]) for p, st in self.optimizer.state.items() if "exp_avg" in st}
+
+    def rebuild_optimizer(self, carried):
+        """After the model's per-Gaussian Parameters were replaced: new bucket + optimizer; `carried` maps id(new param)
+        to its (exp_avg, exp_avg_sq); everything else keeps its moments; the step count is preserved."""
+        old = self.adam_moments()
+        old_steps = self.optimizer.step_count if self.fused else None
+        old_torch_state = None if self.fused else {id(p): st for p, st in self.optimizer.state.items()}
+        self.reducer.close()
+        grad_sink.forget_all()
+        self._build_optimizer()
+        if self.fused:
+            self.optimizer.step_count = old_steps
+            for _, p, _, m, v in self.optimizer.items:
+                src = carried.get(id(p)) or old.get(id(p))
+                if src is not None and src[0].shape == m.shape:
+                    m.copy_(src[0]); v.copy_(src[1])
+        else:
+            for g in self.optimizer.param_groups:
+                for p in g["params"]:
+                    src = carried.get(id(p))
+                    if src is not None:
+                        self.optimizer.state[p] = {"step": torch.tensor(0.0), "exp_avg": src[0].clone(), "exp_avg_sq": src[1].clone()}
+                    elif id(p) in old_torch_state:
+                        self.optimizer.state[p] = old_torch_state[id(p)]
 
     def loss_of(self, image, gt):
         if self.fused:
