@@ -501,6 +501,7 @@ __global__ __launch_bounds__(CF_THREADS) void gp_composite_fwd_kernel(RasterDims
                                                                       uint8_t* __restrict__ qmask) {
     __shared__ float4 s_q0[CF_THREADS], s_q1[CF_THREADS], s_q2[CF_THREADS];
     __shared__ unsigned long long s_mask[4][4];   // [quadrant][staging wave]
+    __shared__ __attribute__((aligned(4))) unsigned char s_list[4][CF_THREADS];   // per quadrant: batch slots in order
     __shared__ int s_done[4];
     __shared__ int s_last[4];
     const int tile = order ? (int)order[blockIdx.x] : (int)blockIdx.x;
@@ -539,18 +540,34 @@ __global__ __launch_bounds__(CF_THREADS) void gp_composite_fwd_kernel(RasterDims
         const unsigned long long m0 = __ballot(rel & 1u), m1 = __ballot(rel & 2u), m2 = __ballot(rel & 4u), m3 = __ballot(rel & 8u);
         if (lane == 0) { s_mask[0][wave] = m0; s_mask[1][wave] = m1; s_mask[2][wave] = m2; s_mask[3][wave] = m3; }
         __syncthreads();
+        // compact the batch into one slot list per quadrant (depth order kept: staging waves in order, lanes in order).
+        // A consumer then runs a plain counted loop over bytes instead of peeling bits off 64-bit masks with the scalar
+        // unit -- that walk cost as much as the blending itself.
+        {
+            const unsigned long long own[4] = {m0, m1, m2, m3};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                int off = 0;
+                for (int w = 0; w < wave; ++w) off += __popcll(s_mask[q][w]);
+                if ((rel >> q) & 1u) s_list[q][off + (int)gp_mbcnt(own[q])] = (unsigned char)tid;
+            }
+        }
+        __syncthreads();
         if (!wave_done) {
+            const int cnt = __builtin_amdgcn_readfirstlane(__popcll(s_mask[wave][0]) + __popcll(s_mask[wave][1]) +
+                                                           __popcll(s_mask[wave][2]) + __popcll(s_mask[wave][3]));
+            const unsigned char* lst = s_list[wave];
 #pragma unroll 1
-            for (int sw = 0; sw < 4 && !wave_done; ++sw) {
-                unsigned long long mask = gp_readfirstlane64(s_mask[wave][sw]);
-                while (mask) {
-                    const int j = __builtin_ctzll(mask);
-                    mask &= mask - 1;
-                    const int slot = sw * 64 + j;
-                    const float4 q0 = s_q0[slot], q1 = s_q1[slot], q2 = s_q2[slot];
-                    const int contributor = base - range.x + slot + 1;
-                    blend_px(a, pxf, pyf, q0, q1, q2, contributor);
-                    if (__all(a.done)) { wave_done = true; break; }
+            for (int i = 0; i < cnt && !wave_done; i += 4) {
+                const uint32_t four = *(const uint32_t*)(lst + i);       // four slots per LDS read
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (i + u < cnt) {
+                        const int slot = (int)((four >> (8 * u)) & 255u);
+                        const float4 q0 = s_q0[slot], q1 = s_q1[slot], q2 = s_q2[slot];
+                        blend_px(a, pxf, pyf, q0, q1, q2, base - range.x + slot + 1);
+                        if (__all(a.done)) { wave_done = true; break; }
+                    }
                 }
             }
             if (wave_done && lane == 0) s_done[wave] = 1;
