@@ -81,16 +81,25 @@ int gp_scan_exclusive_u32(uint32_t* data, size_t n, uint32_t* tmp, size_t tmp_el
 // ------------------------------------------------------------------------------------------------
 // radix sort, 8-bit digits, 256 threads x 16 items per block
 // ------------------------------------------------------------------------------------------------
-#define RS_ITEMS 16
 #define RS_BLOCK 256
-#define RS_TILE (RS_ITEMS * RS_BLOCK)
+// keys per workgroup = ITEMS * 256.  16 items amortise the per-block prologue on large inputs; small inputs (the depth
+// sort of ~1M Gaussians) use 4 so that the grid still covers every CU several times.
+#define RS_ITEMS_LARGE 16
+#define RS_ITEMS_SMALL 4
+#define RS_SMALL_N (2u << 20)
+static inline int rs_items_for(size_t n) { return n <= RS_SMALL_N ? RS_ITEMS_SMALL : RS_ITEMS_LARGE; }
 
-size_t gp_sort_hist_elems(size_t n) { return 256 * ((n + RS_TILE - 1) / RS_TILE) + 64; }
+size_t gp_sort_hist_elems(size_t n) {
+    const size_t tile = (size_t)rs_items_for(n) * RS_BLOCK;
+    return 256 * ((n + tile - 1) / tile) + 64;
+}
 
 // per-block digit histogram, written digit-major: hist[digit * nblocks + block]
+template <int RS_ITEMS>
 __global__ __launch_bounds__(RS_BLOCK) void gp_radix_hist_kernel(const uint32_t* __restrict__ keys, size_t n, int shift,
                                                                  uint32_t mask, uint32_t* __restrict__ hist,
                                                                  uint32_t nblocks) {
+    constexpr int RS_TILE = RS_ITEMS * RS_BLOCK;
     __shared__ uint32_t s_hist[256];
     const int tid = threadIdx.x;
     s_hist[tid] = 0;
@@ -139,6 +148,7 @@ __global__ __launch_bounds__(256) void gp_radix_rowscan_kernel(uint32_t* __restr
 
 // stable scatter.  Element order inside a block: (wave, iteration, lane); wave w owns the
 // contiguous sub-chunk [w*1024, (w+1)*1024) of the block's 4096 elements.
+template <int RS_ITEMS>
 __global__ __launch_bounds__(RS_BLOCK) void gp_radix_scatter_kernel(const uint32_t* __restrict__ keys_in,
                                                                     const uint32_t* __restrict__ vals_in,
                                                                     uint32_t* __restrict__ keys_out,
@@ -146,6 +156,7 @@ __global__ __launch_bounds__(RS_BLOCK) void gp_radix_scatter_kernel(const uint32
                                                                     const uint32_t* __restrict__ hist_scanned,
                                                                     const uint32_t* __restrict__ totals, size_t n,
                                                                     int shift, uint32_t mask, uint32_t nblocks) {
+    constexpr int RS_TILE = RS_ITEMS * RS_BLOCK;
     __shared__ uint32_t s_cnt[RS_BLOCK / GP_WAVE][256];
     __shared__ uint32_t s_dbase[256], s_dw[4];
     __shared__ uint32_t s_k[RS_TILE], s_v[RS_TILE];
@@ -247,18 +258,28 @@ __global__ __launch_bounds__(RS_BLOCK) void gp_radix_scatter_kernel(const uint32
 // counts), the scatter kernel uses the same block partition [b*4096, (b+1)*4096).
 int gp_radix_sort_pairs(GpSortBufs& b, size_t n, int nbits, hipStream_t s) {
     if (n == 0 || nbits <= 0) return 0;
-    const uint32_t nblocks = (uint32_t)((n + RS_TILE - 1) / RS_TILE);
+    const int items = rs_items_for(n);
+    const size_t tile = (size_t)items * RS_BLOCK;
+    const uint32_t nblocks = (uint32_t)((n + tile - 1) / tile);
     int cur = 0;
     for (int shift = 0; shift < nbits; shift += 8) {
         const int bits = (nbits - shift) < 8 ? (nbits - shift) : 8;
         const uint32_t mask = (1u << bits) - 1u;
-        hipLaunchKernelGGL(gp_radix_hist_kernel, dim3(nblocks), dim3(RS_BLOCK), 0, s, b.k[cur], n, shift, mask, b.hist,
-                           nblocks);
+        if (items == RS_ITEMS_SMALL)
+            hipLaunchKernelGGL((gp_radix_hist_kernel<RS_ITEMS_SMALL>), dim3(nblocks), dim3(RS_BLOCK), 0, s, b.k[cur], n, shift, mask,
+                               b.hist, nblocks);
+        else
+            hipLaunchKernelGGL((gp_radix_hist_kernel<RS_ITEMS_LARGE>), dim3(nblocks), dim3(RS_BLOCK), 0, s, b.k[cur], n, shift, mask,
+                               b.hist, nblocks);
         if (hipGetLastError() != hipSuccess) { snprintf(gp_err_buf, sizeof(gp_err_buf), "radix hist launch failed"); return -1; }
         if (b.scan_tmp_elems < 256) { snprintf(gp_err_buf, sizeof(gp_err_buf), "radix sort: temp storage too small"); return -1; }
         hipLaunchKernelGGL(gp_radix_rowscan_kernel, dim3(256), dim3(256), 0, s, b.hist, nblocks, b.scan_tmp);
-        hipLaunchKernelGGL(gp_radix_scatter_kernel, dim3(nblocks), dim3(RS_BLOCK), 0, s, b.k[cur], b.v[cur], b.k[cur ^ 1],
-                           b.v[cur ^ 1], b.hist, b.scan_tmp, n, shift, mask, nblocks);
+        if (items == RS_ITEMS_SMALL)
+            hipLaunchKernelGGL((gp_radix_scatter_kernel<RS_ITEMS_SMALL>), dim3(nblocks), dim3(RS_BLOCK), 0, s, b.k[cur], b.v[cur],
+                               b.k[cur ^ 1], b.v[cur ^ 1], b.hist, b.scan_tmp, n, shift, mask, nblocks);
+        else
+            hipLaunchKernelGGL((gp_radix_scatter_kernel<RS_ITEMS_LARGE>), dim3(nblocks), dim3(RS_BLOCK), 0, s, b.k[cur], b.v[cur],
+                               b.k[cur ^ 1], b.v[cur ^ 1], b.hist, b.scan_tmp, n, shift, mask, nblocks);
         if (hipGetLastError() != hipSuccess) { snprintf(gp_err_buf, sizeof(gp_err_buf), "radix scatter launch failed"); return -1; }
         cur ^= 1;
     }
