@@ -51,6 +51,8 @@ class Deformable_Field(nn.Module):
         """Fused form used by GaussianModel: builds [feature | PE(xyz) | PE(t)] inside the kernel
         (get_motion_delta, REF scene/gaussian_model.py:180-184) -- the [M, input_dim] input and the
         [M,256] activations never touch HBM in inference."""
-        if self.precision != "fp32":
+        # 16-bit operands pay off for the per-Gaussian passes (10^5..10^6 rows).  A few hundred rows (the keypoints of
+        # stage 2/3) are a latency problem, for which the 16-row fp32 kernels are both faster and exact.
+        if self.precision != "fp32" and feature.shape[0] > 2048:
             return FusedMlp16.apply(feature, xyz, t, xyz_freq, time_freq, self.precision, *self._wb())
         return FusedMlp.apply(feature, xyz, t, xyz_freq, time_freq, *self._wb())

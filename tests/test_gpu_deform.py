@@ -172,7 +172,8 @@ def test_fused_mlp16_close_to_fp32(precision, tol_y, tol_g, rows, F, out_dim):
     y64 = do.mlp_forward(sd64, X)
     (y64 * gy.double()).sum().backward()
     fd, xd = feat.cuda().requires_grad_(True), xyz.cuda().requires_grad_(True)
-    y = net.forward_fused(fd, xd, t.cuda(), 10, F)
+    from gaussianprediction_amd.deform_ops import FusedMlp16
+    y = FusedMlp16.apply(fd, xd, t.cuda(), 10, F, precision, *net._wb())      # the 16-bit kernels at every row count
     (y * gy.cuda()).sum().backward()
     scale = float(y64.detach().abs().max())
     assert np.abs(y.detach().cpu().numpy() - y64.detach().numpy()).max() < tol_y * max(scale, 1e-3)
