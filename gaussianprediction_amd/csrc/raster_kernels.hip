@@ -1,10 +1,11 @@
 // raster_kernels.hip -- the rasterizer kernels for gfx950 (wave64), hand-written:
 //   preprocess fwd/bwd  (per Gaussian: projection, EWA cov2D, conic, radius, SH->RGB)
-//   binning helpers     (depth keys, per-tile duplication, tile ranges)
-//   composite forward   (per 16x16 tile; 2 waves x 64 lanes x 2 pixels; LDS-staged splat batches;
-//                        per-wave exact culling by ballot; front-to-back alpha blend + depth + tidx)
-//   composite backward  (SPLAT-parallel: lanes own splats, pixels are walked uniformly; transmittance
-//                        and suffix sums come from wave scans -> no per-pair atomics or reductions)
+//   binning helpers     (depth keys, per-tile duplication, tile ranges, heavy-first launch order)
+//   composite forward   (per 16x16 tile; 4 waves = 4 quadrants of 8x8, one pixel per lane; LDS-staged splat
+//                        batches; exact per-quadrant culling, compacted slot lists; front-to-back alpha blend +
+//                        depth + tidx; saves the per-instance quadrant masks)
+//   composite backward  (SPLAT-parallel per (tile, quadrant): lanes own splats, pixels are walked uniformly;
+//                        transmittance and suffix sums come from wave scans; gradients flushed as whole lines)
 // Arithmetic mirrors oracle/gp_oracle.c expression-for-expression (explicit fmaf, built with
 // -ffp-contract=off) so the discrete results (radii, tile rects, depth keys, per-tile order) are
 // bit-identical to the float32 oracle.  Replaces the CUDA kernels of the reference's absent
@@ -460,7 +461,6 @@ __device__ __forceinline__ bool gp_splat_hits_rect(const float4 q0, const float4
 // ------------------------------------------------------------------------------------------------
 #define CF_THREADS 256
 typedef float v2f __attribute__((ext_vector_type(2)));
-typedef int v2i __attribute__((ext_vector_type(2)));
 
 struct PixAcc {
     float T, C0, C1, C2, Dp, best;
