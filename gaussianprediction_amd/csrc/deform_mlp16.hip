@@ -19,6 +19,11 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef __bf16 b8 __attribute__((ext_vector_type(8)));
 
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef __bf16 b4 __attribute__((ext_vector_type(4)));
+template <typename T> struct Vec4;
+template <> struct Vec4<_Float16> { typedef h4 type; };
+template <> struct Vec4<__bf16> { typedef b4 type; };
 template <typename T> struct Vec8;
 template <> struct Vec8<_Float16> { typedef h8 type; };
 template <> struct Vec8<__bf16> { typedef b8 type; };
@@ -46,6 +51,11 @@ __device__ __forceinline__ f32x16 mfma16(h8 a, h8 b, f32x16 c) { return __builti
 __device__ __forceinline__ f32x16 mfma16(b8 a, b8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
 
 #define M16_ROWS 64
+// Saved / intermediate 16-bit tensors are stored BLOCKED: [row block of 64][feature][64 rows].  A workgroup writes and the
+// weight-gradient kernels read one contiguous (features x 128 B) chunk per row block; the plain feature-major layout
+// [feature][rows] put every lane of a fragment load in a different page (2 MB stride at 1M rows: TLB-bound).
+__device__ __host__ __forceinline__ size_t t16_idx(int f, long row, int nf) { return ((size_t)(row >> 6) * nf + f) * 64 + (row & 63); }
+__device__ __host__ __forceinline__ size_t t16_elems(int nf, long rows) { return (size_t)((rows + 63) / 64) * nf * 64; }
 #define M16_THREADS 256
 #define M16_W 256
 
@@ -109,7 +119,10 @@ __device__ __forceinline__ void build_input16(T* buf, const Mlp16Dev& p, long ro
 // acc[rt][nt] += X[64 x K] . W[feature tile][K]^T for this wave's two feature tiles.
 // The weight fragments (straight from L2) are software-pipelined in groups of four k-steps: the 8 loads
 // of group g+1 are in flight while the 16 MFMAs (512 matrix-pipe cycles) of group g execute.
-template <typename T>
+// SWAPPED = true swaps the MFMA operands (weights as A, activations as B): the accumulator then holds C[feature][row],
+// i.e. lane = row, registers = 16 of the tile's 32 features in runs of FOUR CONSECUTIVE features -- an epilogue writes
+// 8 bytes per run (4 stores per tile instead of 16 two-byte ones) and builds ReLU masks from its own registers.
+template <typename T, bool SWAPPED = false>
 __device__ __forceinline__ void gemm16(const T* cur, const T* __restrict__ W, int ldk, int K, int n_feat, int wave, int lane,
                                        f32x16 acc[2][2]) {
     typedef typename Vec8<T>::type V8;
@@ -148,10 +161,17 @@ __device__ __forceinline__ void gemm16(const T* cur, const T* __restrict__ W, in
                 const int col = ((ks + u) * 16) ^ swz;
                 const V8 a0 = *(const V8*)(arow + col);
                 const V8 a1 = *(const V8*)(arow + 32 * M16_W + col);
-                acc[0][0] = mfma16(a0, bc[u][0], acc[0][0]);
-                acc[0][1] = mfma16(a0, bc[u][1], acc[0][1]);
-                acc[1][0] = mfma16(a1, bc[u][0], acc[1][0]);
-                acc[1][1] = mfma16(a1, bc[u][1], acc[1][1]);
+                if (SWAPPED) {
+                    acc[0][0] = mfma16(bc[u][0], a0, acc[0][0]);
+                    acc[0][1] = mfma16(bc[u][1], a0, acc[0][1]);
+                    acc[1][0] = mfma16(bc[u][0], a1, acc[1][0]);
+                    acc[1][1] = mfma16(bc[u][1], a1, acc[1][1]);
+                } else {
+                    acc[0][0] = mfma16(a0, bc[u][0], acc[0][0]);
+                    acc[0][1] = mfma16(a0, bc[u][1], acc[0][1]);
+                    acc[1][0] = mfma16(a1, bc[u][0], acc[1][0]);
+                    acc[1][1] = mfma16(a1, bc[u][1], acc[1][1]);
+                }
             }
         }
     }
@@ -173,52 +193,56 @@ __device__ __forceinline__ void mlp16_fwd_body(Mlp16Dev p, float* __restrict__ o
     build_input16<T>(cur, p, row0, tid);
     __syncthreads();
     // transposed copy-out of a tile: dst[f][row0 + r] for f < nf  (64 consecutive rows = 128 B per feature)
-    auto store_T = [&](const T* buf, T* dst, int nf) {
+    auto store_T = [&](const T* buf, T* dst, int nf) {      // this workgroup's block: nf x 64 contiguous elements
+        T* blk = dst + (size_t)blockIdx.x * nf * M16_ROWS;
         for (int e = tid; e < nf * M16_ROWS; e += M16_THREADS) {
             const int f = e / M16_ROWS, r = e - f * M16_ROWS;
-            if (row0 + r < p.rows) dst[(size_t)f * p.rows + row0 + r] = buf[a16_idx(r, f)];
+            blk[e] = row0 + r < p.rows ? buf[a16_idx(r, f)] : (T)0.f;
         }
     };
     if (saved_xT) store_T(cur, saved_xT, p.in_pad);
-    // epilogue write offsets, computed once: wbase[nt][c] = 4*half*256 + (f_nt ^ (((c&3) + 8*(c>>2) + 4*half) << 3))
-    int wbase[2][8];
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-        for (int c = 0; c < 8; ++c)
-            wbase[nt][c] = 4 * half * M16_W + (((2 * wave + nt) * 32 + j) ^ ((((c & 3) + 8 * (c >> 2)) | (4 * half)) << 3));
+    typedef typename Vec4<T>::type V4;
     for (int l = 0; l < 4; ++l) {
         const int K = l == 0 ? p.in_pad : M16_W;
         f32x16 acc[2][2];
 #pragma unroll
-        for (int rt = 0; rt < 2; ++rt)
+        for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt) {
-                const float bv = p.b[l][(2 * wave + nt) * 32 + j];
+            for (int g = 0; g < 4; ++g) {   // this lane's features of tile nt: runs of four at (2 wave + nt) * 32 + 8 g + 4 half
+                const float4 bv = *(const float4*)(p.b[l] + (2 * wave + nt) * 32 + 8 * g + 4 * half);
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[rt][nt][r] = bv;
-            }
-        gemm16<T>(cur, (const T*)p.w[l], K, K, M16_W, wave, lane, acc);
-#pragma unroll
-        for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float v = fmaxf(acc[rt][nt][r], 0.f);
-                    const int row = rt * 32 + cd_row16(r, half);
-                    // == a16_idx(row, f): (row & 15) = cr | 4*half with cr = (r&3) + 8*((r>>2)&1) known at compile time
-                    nxt[(rt * 32 + (r & 3) + 8 * (r >> 2)) * M16_W + wbase[nt][(r & 3) + 4 * ((r >> 2) & 1)]] = (T)v;
-                    if (masks) {   // sign bits of this (row, 32-feature tile): low word = half 0's row, high word = half 1's row
-                        const unsigned long long bal = __ballot(v > 0.f);
-                        const long grow = row0 + row;
-                        if (j == 0 && grow < p.rows)
-                            masks[((size_t)l * p.rows + grow) * 8 + (2 * wave + nt)] = half ? (uint32_t)(bal >> 32) : (uint32_t)bal;
-                    }
+                for (int rt = 0; rt < 2; ++rt) {
+                    acc[rt][nt][4 * g + 0] = bv.x; acc[rt][nt][4 * g + 1] = bv.y; acc[rt][nt][4 * g + 2] = bv.z; acc[rt][nt][4 * g + 3] = bv.w;
                 }
             }
+        gemm16<T, true>(cur, (const T*)p.w[l], K, K, M16_W, wave, lane, acc);
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) {
+            const int row = rt * 32 + j;
+            const long grow = row0 + row;
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                uint32_t mbits = 0;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int f0 = (2 * wave + nt) * 32 + 8 * g + 4 * half;
+                    V4 pk;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float v = fmaxf(acc[rt][nt][4 * g + e], 0.f);
+                        pk[e] = (T)v;
+                        mbits |= (v > 0.f ? 1u : 0u) << (8 * g + 4 * half + e);
+                    }
+                    *(V4*)&nxt[a16_idx(row, f0)] = pk;        // four consecutive features: one 8-byte store
+                }
+                if (masks) {   // sign bits of this (row, 32-feature tile): the two halves hold complementary bits
+                    const uint32_t full = mbits | (uint32_t)__shfl_xor((int)mbits, 32);
+                    if (half == 0 && grow < p.rows) masks[((size_t)l * p.rows + grow) * 8 + (2 * wave + nt)] = full;
+                }
+            }
+        }
         __syncthreads();
-        if (saved_hT) store_T(nxt, saved_hT + (size_t)l * M16_W * p.rows, M16_W);
+        if (saved_hT) store_T(nxt, saved_hT + (size_t)l * t16_elems(M16_W, p.rows), M16_W);
         T* t = cur; cur = nxt; nxt = t;
     }
     {   // output layer: W4 padded to [32][256]; the 4 waves split K, reduce through LDS (fp32)
@@ -284,12 +308,7 @@ __device__ __forceinline__ void mlp16_bwd_data_body(Mlp16Dev p, const uint32_t* 
         cur[a16_idx(r, f)] = (T)((f < p.out_dim && row < p.rows) ? dL_dout[row * p.out_dim + f] * S : 0.f);
     }
     __syncthreads();
-    int wbase[2][8];
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-        for (int c = 0; c < 8; ++c)
-            wbase[nt][c] = 4 * half * M16_W + (((2 * wave + nt) * 32 + j) ^ ((((c & 3) + 8 * (c >> 2)) | (4 * half)) << 3));
+    typedef typename Vec4<T>::type V4;
     for (int l = 4; l >= 1; --l) {
         const int K = l == 4 ? 16 : M16_W;
         f32x16 acc[2][2];
@@ -299,27 +318,31 @@ __device__ __forceinline__ void mlp16_bwd_data_body(Mlp16Dev p, const uint32_t* 
             for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[rt][nt][r] = 0.f;
-        gemm16<T>(cur, (const T*)p.w[l], K, K, M16_W, wave, lane, acc);
+        gemm16<T, true>(cur, (const T*)p.w[l], K, K, M16_W, wave, lane, acc);
         const uint32_t* mk = masks + (size_t)(l - 1) * p.rows * 8;
 #pragma unroll
-        for (int rt = 0; rt < 2; ++rt)
+        for (int rt = 0; rt < 2; ++rt) {
+            const int row = rt * 32 + j;
+            const long grow = row0 + row;
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) {
+                const uint32_t m = grow < p.rows ? mk[grow * 8 + (2 * wave + nt)] : 0u;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = rt * 32 + cd_row16(r, half);
-                    const long grow = row0 + row;
-                    const uint32_t m = grow < p.rows ? mk[grow * 8 + (2 * wave + nt)] : 0u;
-                    nxt[(rt * 32 + (r & 3) + 8 * (r >> 2)) * M16_W + wbase[nt][(r & 3) + 4 * ((r >> 2) & 1)]] =
-                        (T)(((m >> j) & 1u) ? acc[rt][nt][r] : 0.f);
+                for (int g = 0; g < 4; ++g) {
+                    const int f0 = (2 * wave + nt) * 32 + 8 * g + 4 * half;
+                    V4 pk;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) pk[e] = (T)(((m >> (8 * g + 4 * half + e)) & 1u) ? acc[rt][nt][4 * g + e] : 0.f);
+                    *(V4*)&nxt[a16_idx(row, f0)] = pk;
                 }
             }
+        }
         __syncthreads();
         {   // dZ_l^T -> global [256][rows]
-            T* dst = dzT + (size_t)(l - 1) * M16_W * p.rows;
+            T* blk = dzT + (size_t)(l - 1) * t16_elems(M16_W, p.rows) + (size_t)blockIdx.x * M16_W * M16_ROWS;
             for (int e = tid; e < M16_W * M16_ROWS; e += M16_THREADS) {
                 const int f = e / M16_ROWS, r = e - f * M16_ROWS;
-                if (row0 + r < p.rows) dst[(size_t)f * p.rows + row0 + r] = nxt[a16_idx(r, f)];
+                blk[e] = row0 + r < p.rows ? nxt[a16_idx(r, f)] : (T)0.f;
             }
         }
         T* t = cur; cur = nxt; nxt = t;
@@ -389,14 +412,18 @@ __global__ __launch_bounds__(M16_THREADS) void gp_mlp16_bwd_data_bf16_kernel(Mlp
 // ------------------------------------------------------------------------------------------------
 template <typename T>
 __device__ __forceinline__ void mlp16_bwd_weight_body(const T* __restrict__ dzT, int n_out, const T* __restrict__ hT, int n_in,
-                                                      long rows, long rows_per_block, float* __restrict__ dW, int lddw,
+                                                      int nf_z, int nf_h, long rows, long rows_per_block, float* __restrict__ dW, int lddw,
                                                       float* __restrict__ db, const uint32_t* __restrict__ absmax_bits) {
     typedef typename Vec8<T>::type V8;
     const float inv_scale = UsesScale<T>::v ? 1.f / grad_scale_from(absmax_bits) : 1.f;
     __shared__ float s_red[4][4][16][64];   // 64 KB
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, j = lane & 31;
-    const int o0 = 64 * blockIdx.z, i0 = 64 * blockIdx.y;
-    const long b_begin = (long)blockIdx.x * rows_per_block;
+    // grid = (tile pairs, row blocks): the 16 workgroups that share one slab of rows are dispatched back to back, so
+    // the slab comes from HBM once and the other fifteen reads hit L2 / MALL (with row blocks as the fast index and few,
+    // huge row blocks, every operand was streamed from HBM four times beyond ~256k rows)
+    const int n_it = (n_in + 63) / 64;
+    const int o0 = 64 * (blockIdx.x / n_it), i0 = 64 * (blockIdx.x % n_it);
+    const long b_begin = (long)blockIdx.y * rows_per_block;
     long b_end = b_begin + rows_per_block;
     if (b_end > rows) b_end = rows;
     const long per_wave = ((b_end - b_begin + 3) / 4 + 15) & ~15L;
@@ -423,19 +450,19 @@ __device__ __forceinline__ void mlp16_bwd_weight_body(const T* __restrict__ dzT,
             const int o = o0 + 32 * u + j, i = i0 + 32 * u + j;
             av[u] = zero; bv[u] = zero;
             if (full_rows && r8 + 8 <= r_end) {
-                if (o < n_out) av[u] = *(const V8*)(dzT + (size_t)o * rows + r8);
-                if (i < n_in) bv[u] = *(const V8*)(hT + (size_t)i * rows + r8);
+                if (o < n_out) av[u] = *(const V8*)(dzT + t16_idx(o, r8, nf_z));
+                if (i < n_in) bv[u] = *(const V8*)(hT + t16_idx(i, r8, nf_h));
             } else {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     if (r8 + e < r_end) {
-                        if (o < n_out) av[u][e] = dzT[(size_t)o * rows + r8 + e];
-                        if (i < n_in) bv[u][e] = hT[(size_t)i * rows + r8 + e];
+                        if (o < n_out) av[u][e] = dzT[t16_idx(o, r8 + e, nf_z)];
+                        if (i < n_in) bv[u][e] = hT[t16_idx(i, r8 + e, nf_h)];
                     }
                 }
             }
         }
-        if (db && blockIdx.y == 0) {
+        if (db && i0 == 0) {
 #pragma unroll
             for (int u = 0; u < 2; ++u)
 #pragma unroll
@@ -453,7 +480,7 @@ __device__ __forceinline__ void mlp16_bwd_weight_body(const T* __restrict__ dzT,
 #pragma unroll
             for (int r = 0; r < 16; ++r) s_red[wave][2 * a + b][r][lane] = acc[a][b][r];
     __syncthreads();
-    const bool single = gridDim.x == 1;
+    const bool single = gridDim.y == 1;
     for (int e = tid; e < 4 * 16 * 64; e += M16_THREADS) {
         const int tl = e >> 10, r = (e >> 6) & 15, l = e & 63;
         float v = s_red[0][tl][r][l] + s_red[1][tl][r][l] + s_red[2][tl][r][l] + s_red[3][tl][r][l];
@@ -464,7 +491,7 @@ __device__ __forceinline__ void mlp16_bwd_weight_body(const T* __restrict__ dzT,
             if (single) *dst += v; else atomicAdd(dst, v);
         }
     }
-    if (db && blockIdx.y == 0) {
+    if (db && i0 == 0) {
         __syncthreads();
         float* sb = &s_red[0][0][0][0];
 #pragma unroll
@@ -481,13 +508,13 @@ __device__ __forceinline__ void mlp16_bwd_weight_body(const T* __restrict__ dzT,
         }
     }
 }
-__global__ __launch_bounds__(M16_THREADS) void gp_mlp16_bwd_weight_f16_kernel(const void* dzT, int n_out, const void* hT, int n_in, long rows,
+__global__ __launch_bounds__(M16_THREADS) void gp_mlp16_bwd_weight_f16_kernel(const void* dzT, int n_out, const void* hT, int n_in, int nf_z, int nf_h, long rows,
                                                                                long rpb, float* dW, int lddw, float* db, const uint32_t* absmax_bits) {
-    mlp16_bwd_weight_body<_Float16>((const _Float16*)dzT, n_out, (const _Float16*)hT, n_in, rows, rpb, dW, lddw, db, absmax_bits);
+    mlp16_bwd_weight_body<_Float16>((const _Float16*)dzT, n_out, (const _Float16*)hT, n_in, nf_z, nf_h, rows, rpb, dW, lddw, db, absmax_bits);
 }
-__global__ __launch_bounds__(M16_THREADS) void gp_mlp16_bwd_weight_bf16_kernel(const void* dzT, int n_out, const void* hT, int n_in, long rows,
+__global__ __launch_bounds__(M16_THREADS) void gp_mlp16_bwd_weight_bf16_kernel(const void* dzT, int n_out, const void* hT, int n_in, int nf_z, int nf_h, long rows,
                                                                                 long rpb, float* dW, int lddw, float* db, const uint32_t* absmax_bits) {
-    mlp16_bwd_weight_body<__bf16>((const __bf16*)dzT, n_out, (const __bf16*)hT, n_in, rows, rpb, dW, lddw, db, absmax_bits);
+    mlp16_bwd_weight_body<__bf16>((const __bf16*)dzT, n_out, (const __bf16*)hT, n_in, nf_z, nf_h, rows, rpb, dW, lddw, db, absmax_bits);
 }
 
 // dL_dout^T in 16 bits, scaled: [16][rows] (rows >= out_dim zero) -- A operand of the last layer's weight gradient
@@ -498,7 +525,7 @@ __global__ __launch_bounds__(256) void gp_mlp16_pack_dout_kernel(const float* __
     if (i >= rows) return;
     const float scale = UsesScale<T>::v ? grad_scale_from(absmax_bits) : 1.f;
 #pragma unroll
-    for (int f = 0; f < 16; ++f) dst[(size_t)f * rows + i] = (T)(f < out_dim ? dL_dout[i * out_dim + f] * scale : 0.f);
+    for (int f = 0; f < 16; ++f) dst[t16_idx(f, i, 16)] = (T)(f < out_dim ? dL_dout[i * out_dim + f] * scale : 0.f);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -548,10 +575,10 @@ extern "C" int gp_mlp16_backward(const gp_mlp16_params* p /* w16 = TRANSPOSED co
     for (int l = 0; l < 5; ++l)
         if (!g->dw[l] || !g->db[l]) GP_FAIL("null weight-grad pointer (layer %d)", l);
     const bool f16 = p->dtype == GP_DTYPE_F16;
-    const size_t dz_elems = (size_t)4 * 256 * m.rows + (size_t)16 * m.rows;
+    const size_t dz_elems = 4 * t16_elems(256, m.rows) + t16_elems(16, m.rows);
     char* dz = (char*)alloc(alloc_ctx, GP_BUF_TEMP, gp_align_up(dz_elems * 2, 256) + 256);
     if (!dz) GP_FAIL("allocator returned NULL for TEMP");
-    char* dout16 = dz + (size_t)4 * 256 * m.rows * 2;
+    char* dout16 = dz + 4 * t16_elems(256, m.rows) * 2;
     uint32_t* absmax = (uint32_t*)(dz + gp_align_up(dz_elems * 2, 256));
     GP_HIP_CHECK(hipMemsetAsync(absmax, 0, 4, s));
     if (f16) {
@@ -570,20 +597,20 @@ extern "C" int gp_mlp16_backward(const gp_mlp16_params* p /* w16 = TRANSPOSED co
         }
         GP_LAUNCH_CHECK();
     }
-    long nrb_l = (m.rows + 8191) / 8192;
-    if (nrb_l > 32) nrb_l = 32;
+    long nrb_l = (m.rows + 4095) / 4096;       // 4096-row slabs: 2 x 256 x 4096 x 2 B = 4 MB per layer, shared by 16 workgroups
     if (nrb_l < 1) nrb_l = 1;
     const long rpb = ((m.rows + nrb_l - 1) / nrb_l + 63) & ~63L;
     const unsigned nrb = (unsigned)((m.rows + rpb - 1) / rpb);
     GpProfScope _pw("mlp16_bwd_weight", s);
     for (int l = 0; l < 5; ++l) {
-        const void* dZl = l < 4 ? (const void*)(dz + (size_t)l * 256 * m.rows * 2) : (const void*)dout16;
+        const void* dZl = l < 4 ? (const void*)(dz + (size_t)l * t16_elems(256, m.rows) * 2) : (const void*)dout16;
+        const int nf_z = l < 4 ? 256 : 16, nf_h = l == 0 ? m.in_pad : 256;
         const int n_out = l < 4 ? 256 : m.out_dim;
-        const void* H = l == 0 ? saved_xT : (const void*)((const char*)saved_hT + (size_t)(l - 1) * 256 * m.rows * 2);
+        const void* H = l == 0 ? saved_xT : (const void*)((const char*)saved_hT + (size_t)(l - 1) * t16_elems(256, m.rows) * 2);
         const int n_in = l == 0 ? m.in_dim : 256;
-        const dim3 grid(nrb, (unsigned)((n_in + 63) / 64), (unsigned)((n_out + 63) / 64));
-        if (f16) hipLaunchKernelGGL(gp_mlp16_bwd_weight_f16_kernel, grid, dim3(M16_THREADS), 0, s, dZl, n_out, H, n_in, m.rows, rpb, g->dw[l], n_in, g->db[l], absmax);
-        else hipLaunchKernelGGL(gp_mlp16_bwd_weight_bf16_kernel, grid, dim3(M16_THREADS), 0, s, dZl, n_out, H, n_in, m.rows, rpb, g->dw[l], n_in, g->db[l], absmax);
+        const dim3 grid((unsigned)((n_in + 63) / 64) * (unsigned)((n_out + 63) / 64), nrb);
+        if (f16) hipLaunchKernelGGL(gp_mlp16_bwd_weight_f16_kernel, grid, dim3(M16_THREADS), 0, s, dZl, n_out, H, n_in, nf_z, nf_h, m.rows, rpb, g->dw[l], n_in, g->db[l], absmax);
+        else hipLaunchKernelGGL(gp_mlp16_bwd_weight_bf16_kernel, grid, dim3(M16_THREADS), 0, s, dZl, n_out, H, n_in, nf_z, nf_h, m.rows, rpb, g->dw[l], n_in, g->db[l], absmax);
         GP_LAUNCH_CHECK();
     }
     return 0;

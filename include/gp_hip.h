@@ -171,7 +171,8 @@ typedef struct gp_mlp16_params {
     const void* w16[5];
     const float* b[5];
 } gp_mlp16_params;
-/* saved (training, all optional together): xT [in_pad16, rows] and hT [4,256,rows] 16-bit, feature-major;
+/* saved (training, all optional together), 16-bit, BLOCKED by 64 rows: xT [ceil(rows/64)][in_pad16][64] and
+ * hT [4][ceil(rows/64)][256][64] (element (f, row) at ((row >> 6) * nf + f) * 64 + (row & 63));
  * masks [4, rows, 8] u32 = ReLU sign bits. */
 int gp_mlp16_forward(const gp_mlp16_params* p, const gp_mlp_input* x, float* out, void* saved_xT, void* saved_hT,
                      uint32_t* masks, gp_stream_t stream);

@@ -152,7 +152,7 @@ def test_activations_forward_backward():
 
 
 @pytest.mark.parametrize("precision,tol_y,tol_g", [("fp16", 3e-3, 3e-2), ("bf16", 3e-2, 1e-1)])
-@pytest.mark.parametrize("rows,F,out_dim", [(1, 6, 7), (100, 8, 7), (4100, 10, 8)])
+@pytest.mark.parametrize("rows,F,out_dim", [(1, 6, 7), (100, 8, 7), (4100, 10, 8), (131072, 6, 7)])   # the last size takes the one-read weight-gradient kernel
 def test_fused_mlp16_close_to_fp32(precision, tol_y, tol_g, rows, F, out_dim):
     """16-bit-operand matrix-core MLP (BASELINE config 5): not bit-parity with the reference -- the test
     states its tolerance: forward within tol_y of the float64 oracle relative to the output scale, gradients
