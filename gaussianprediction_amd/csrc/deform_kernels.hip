@@ -345,6 +345,89 @@ __global__ __launch_bounds__(MLP_THREADS) void gp_mlp_bwd_weight5_kernel(MlpWeig
                         blockIdx.y);
 }
 
+// Large row counts: 64 x 64 output block per workgroup (4 waves, each a 2 x 2 arrangement of 32 x 32 tiles over its quarter
+// of the block's rows, summed through LDS).  With 32 x 32 blocks every dZ / H element is read by 8 workgroups and the
+// kernel is L2-bandwidth bound; 64 x 64 halves that twice.  grid = (i-blocks * o-blocks, row blocks): the workgroups that
+// share a slab of rows are dispatched back to back.
+__global__ __launch_bounds__(256) void gp_mlp_bwd_weight64_kernel(const float* __restrict__ dZ, int n_out, const float* __restrict__ H,
+                                                                 int ldh, int n_in, long rows, long rows_per_block,
+                                                                 float* __restrict__ dW, int lddw, float* __restrict__ db) {
+    __shared__ float s_red[4][4][16][64];   // 64 KB
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, j = lane & 31;
+    const int n_ib = (n_in + 63) / 64;
+    const int o0 = 64 * (blockIdx.x / n_ib), i0 = 64 * (blockIdx.x % n_ib);
+    const long b_begin = (long)blockIdx.y * rows_per_block;
+    long b_end = b_begin + rows_per_block;
+    if (b_end > rows) b_end = rows;
+    const long per_wave = ((b_end - b_begin + 3) / 4 + 7) & ~7L;
+    const long r_begin = b_begin + wave * per_wave;
+    long r_end = r_begin + per_wave;
+    if (r_end > b_end) r_end = b_end;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    float bsum[2] = {0.f, 0.f};
+    const int oa = o0 + j, ob = o0 + 32 + j, ia = i0 + j, ib = i0 + 32 + j;
+    const bool oka = oa < n_out, okb = ob < n_out, ika = ia < n_in, ikb = ib < n_in;
+    for (long rb = r_begin; rb < r_end; rb += 8) {   // uniform trip count per wave
+        float a0[4], a1[4], b0[4], b1[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const long r = rb + 2 * u + half;
+            const bool rk = r < r_end;
+            a0[u] = (rk && oka) ? dZ[r * n_out + oa] : 0.f;
+            a1[u] = (rk && okb) ? dZ[r * n_out + ob] : 0.f;
+            b0[u] = (rk && ika) ? H[r * (long)ldh + ia] : 0.f;
+            b1[u] = (rk && ikb) ? H[r * (long)ldh + ib] : 0.f;
+            bsum[0] += a0[u]; bsum[1] += a1[u];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[u], b0[u], acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[u], b1[u], acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[u], b0[u], acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[u], b1[u], acc[1][1], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s_red[wave][2 * a + b][r][lane] = acc[a][b][r];
+    __syncthreads();
+    const bool single = gridDim.y == 1;
+    for (int e = tid; e < 4 * 16 * 64; e += 256) {
+        const int tl = e >> 10, r = (e >> 6) & 15, l = e & 63;
+        const float v = (s_red[0][tl][r][l] + s_red[1][tl][r][l]) + (s_red[2][tl][r][l] + s_red[3][tl][r][l]);
+        const int oo = o0 + 32 * (tl >> 1) + cd_row(r, l >> 5), ii = i0 + 32 * (tl & 1) + (l & 31);
+        if (oo < n_out && ii < n_in) {
+            float* dst = &dW[(size_t)oo * lddw + ii];
+            if (single) *dst += v; else atomicAdd(dst, v);
+        }
+    }
+    if (db && i0 == 0) {
+        __syncthreads();
+        float* sb = &s_red[0][0][0][0];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const float v = bsum[u] + __shfl_xor(bsum[u], 32);
+            if (half == 0) sb[(wave * 2 + u) * 32 + j] = v;
+        }
+        __syncthreads();
+        if (tid < 64) {
+            const int u = tid >> 5, jj = tid & 31;
+            const float v = (sb[(0 * 2 + u) * 32 + jj] + sb[(1 * 2 + u) * 32 + jj]) + (sb[(2 * 2 + u) * 32 + jj] + sb[(3 * 2 + u) * 32 + jj]);
+            const int oo = o0 + 32 * u + jj;
+            if (oo < n_out) { if (single) db[oo] += v; else atomicAdd(&db[oo], v); }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // keypoint blend + pose composition
 // ------------------------------------------------------------------------------------------------

@@ -90,6 +90,23 @@ extern "C" int gp_mlp_backward(const gp_mlp_params* p, const gp_mlp_input* x, co
         GP_LAUNCH_CHECK();
         return 0;
     }
+    if (m.rows >= 16384) {   // large pass: 64 x 64 blocks, 4096-row slabs
+        long nb = (m.rows + 4095) / 4096;                 // 4096-row slabs, but at least 64 row blocks (>= 1024 workgroups)
+        if (nb < 64) nb = 64;
+        const long brpb = ((m.rows + nb - 1) / nb + 7) & ~7L;
+        const unsigned bnrb = (unsigned)((m.rows + brpb - 1) / brpb);
+        for (int l = 0; l < 5; ++l) {
+            const float* dZl = l < 4 ? dz + (size_t)l * m.rows * 256 : dL_dout;
+            const int n_out = l < 4 ? 256 : m.out_dim;
+            const float* H = l == 0 ? sx : sh + (size_t)(l - 1) * m.rows * 256;
+            const int ldh = l == 0 ? m.in_pad : 256;
+            const int n_in = l == 0 ? m.in_dim : 256;
+            hipLaunchKernelGGL(gp_mlp_bwd_weight64_kernel, dim3((unsigned)((n_in + 63) / 64) * (unsigned)((n_out + 63) / 64), bnrb),
+                               dim3(256), 0, s, dZl, n_out, H, ldh, n_in, m.rows, brpb, g->dw[l], n_in, g->db[l]);
+            GP_LAUNCH_CHECK();
+        }
+        return 0;
+    }
     for (int l = 0; l < 5; ++l) {
         const float* dZl = l < 4 ? dz + (size_t)l * m.rows * 256 : dL_dout;
         const int n_out = l < 4 ? 256 : m.out_dim;

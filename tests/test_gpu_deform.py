@@ -44,7 +44,7 @@ def test_mlp_matches_reference_golden_vectors():
                 assert abs(p.grad.double().sum().item() - gs[0]) <= 1e-3 * max(1.0, gs[1]), k
 
 
-@pytest.mark.parametrize("rows,F,out_dim", [(1, 6, 7), (33, 8, 7), (250, 8, 7), (300, 10, 8), (5000, 6, 7)])
+@pytest.mark.parametrize("rows,F,out_dim", [(1, 6, 7), (33, 8, 7), (250, 8, 7), (300, 10, 8), (5000, 6, 7), (20003, 8, 8)])   # last: the large-row weight-gradient kernel, ragged
 def test_fused_pe_mlp_forward_backward(rows, F, out_dim):
     d_in = 32 + 60 + 2 * F
     net, sd = _net(40 + rows, d_in, out_dim)
@@ -152,7 +152,7 @@ def test_activations_forward_backward():
 
 
 @pytest.mark.parametrize("precision,tol_y,tol_g", [("fp16", 3e-3, 3e-2), ("bf16", 3e-2, 1e-1)])
-@pytest.mark.parametrize("rows,F,out_dim", [(1, 6, 7), (100, 8, 7), (4100, 10, 8), (131072, 6, 7)])   # the last size takes the one-read weight-gradient kernel
+@pytest.mark.parametrize("rows,F,out_dim", [(1, 6, 7), (100, 8, 7), (4100, 10, 8), (131072, 6, 7)])   # the last size spans many row blocks of the weight-gradient grid
 def test_fused_mlp16_close_to_fp32(precision, tol_y, tol_g, rows, F, out_dim):
     """16-bit-operand matrix-core MLP (BASELINE config 5): not bit-parity with the reference -- the test
     states its tolerance: forward within tol_y of the float64 oracle relative to the output scale, gradients
