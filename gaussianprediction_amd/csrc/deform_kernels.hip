@@ -265,6 +265,224 @@ __global__ __launch_bounds__(MLP_THREADS) void gp_mlp_bwd_data_kernel(MlpDev p, 
 }
 
 // ------------------------------------------------------------------------------------------------
+// Large row counts: TWO 32-row tiles per workgroup.  Every workgroup streams all five weight matrices from L2 (0.9 MB);
+// at 32 rows per workgroup that is 8 KB per row and layer and the kernels are L2-bound.  With two tiles a weight fragment
+// is fetched once and used for both (half the L2 traffic); the activations of both tiles are updated IN PLACE
+// (64 KB of LDS, the static limit), which costs one more barrier per layer.
+// ------------------------------------------------------------------------------------------------
+#define MLP_TILE (MLP_W * MLP_ROWS)
+
+__device__ __forceinline__ void layer_mfma2(const float* __restrict__ W, int ldw, int K, int out_rows, const float* __restrict__ bias,
+                                            const float* cur, int wave, int lane, f32x16& acc0, f32x16& acc1) {
+    const int half = lane >> 5, j = lane & 31;
+    const int i_row = 32 * wave + j;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int f = 32 * wave + cd_row(r, half);
+        acc0[r] = (bias && f < out_rows) ? bias[f] : 0.f;
+        acc1[r] = acc0[r];
+    }
+    const bool row_ok = i_row < out_rows;
+    const float* wrow = W + (size_t)i_row * ldw;
+    const int nkq = K / 8;
+    for (int kq0 = 0; kq0 < nkq; kq0 += 4) {
+        float4 wv[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int kbase = 8 * (kq0 + g) + 4 * half;
+            wv[g] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row_ok && kq0 + g < nkq && kbase < ldw) wv[g] = *(const float4*)(wrow + kbase);
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            if (kq0 + g < nkq) {
+                const int kbase = 8 * (kq0 + g) + 4 * half;
+                const float wk[4] = {wv[g].x, wv[g].y, wv[g].z, wv[g].w};
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(wk[u], cur[act_idx(kbase + u, j)], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(wk[u], cur[MLP_TILE + act_idx(kbase + u, j)], acc1, 0, 0, 0);
+                }
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ void layer_mfma_T2(const float* __restrict__ W, int ldw, int K, int k_valid, int out_rows, const float* cur,
+                                              int wave, int lane, f32x16& acc0, f32x16& acc1) {
+    const int half = lane >> 5, j = lane & 31;
+    const int i_row = 32 * wave + j;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+    const bool row_ok = i_row < out_rows;
+    const int nkq = K / 8;
+    for (int kq0 = 0; kq0 < nkq; kq0 += 2) {
+        float a[8];
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int k = 8 * (kq0 + g) + 4 * half + u;
+                a[4 * g + u] = (row_ok && kq0 + g < nkq && k < k_valid) ? W[(size_t)k * ldw + i_row] : 0.f;
+            }
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            if (kq0 + g < nkq) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int k = 8 * (kq0 + g) + 4 * half + u;
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * g + u], cur[act_idx(k, j)], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * g + u], cur[MLP_TILE + act_idx(k, j)], acc1, 0, 0, 0);
+                }
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(MLP_THREADS) void gp_mlp_fwd2_kernel(MlpDev p, float* __restrict__ out, float* __restrict__ saved_x,
+                                                                  float* __restrict__ saved_h) {
+    __shared__ float cur[2 * MLP_TILE];          // 64 KB: two row tiles, in place
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, j = lane & 31;
+    const long row0 = (long)blockIdx.x * (2 * MLP_ROWS);
+    build_input(cur, p, row0, tid);
+    build_input(cur + MLP_TILE, p, row0 + MLP_ROWS, tid);
+    __syncthreads();
+    if (saved_x) {
+        store_rows(cur, saved_x, p.in_pad, p.in_pad, row0, p.rows, tid);
+        store_rows(cur + MLP_TILE, saved_x, p.in_pad, p.in_pad, row0 + MLP_ROWS, p.rows, tid);
+    }
+    for (int l = 0; l < 4; ++l) {
+        const int K = l == 0 ? p.in_pad : MLP_W, ldw = l == 0 ? p.in_dim : MLP_W;
+        f32x16 acc0, acc1;
+        layer_mfma2(p.w[l], ldw, K, MLP_W, p.b[l], cur, wave, lane, acc0, acc1);
+        __syncthreads();                 // every wave has read its operands
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int idx = act_idx(32 * wave + cd_row(r, half), j);
+            cur[idx] = fmaxf(acc0[r], 0.f);
+            cur[MLP_TILE + idx] = fmaxf(acc1[r], 0.f);
+        }
+        __syncthreads();
+        if (saved_h) {
+            store_rows(cur, saved_h + (size_t)l * p.rows * MLP_W, MLP_W, MLP_W, row0, p.rows, tid);
+            store_rows(cur + MLP_TILE, saved_h + (size_t)l * p.rows * MLP_W, MLP_W, MLP_W, row0 + MLP_ROWS, p.rows, tid);
+        }
+    }
+    // output layer: out_dim <= 8 rows of W4; K split over the 8 waves; partials leave through the (now free) tile buffer
+    {
+        f32x16 acc0, acc1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+        const bool row_ok = j < p.out_dim;
+        const float* wrow = p.w[4] + (size_t)j * MLP_W;
+        for (int kq = 4 * wave; kq < 4 * wave + 4; ++kq) {
+            const int kbase = 8 * kq + 4 * half;
+            float4 wv = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row_ok) wv = *(const float4*)(wrow + kbase);
+            const float wk[4] = {wv.x, wv.y, wv.z, wv.w};
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(wk[u], cur[act_idx(kbase + u, j)], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(wk[u], cur[MLP_TILE + act_idx(kbase + u, j)], acc1, 0, 0, 0);
+            }
+        }
+        __syncthreads();                 // all reads of the activations are done: reuse the buffer for the partials
+        // features 0..3 sit in regs 0..3 of half 0, features 4..7 in regs 0..3 of half 1
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            cur[(wave * 8 + r + 4 * half) * MLP_ROWS + j] = acc0[r];
+            cur[MLP_TILE + (wave * 8 + r + 4 * half) * MLP_ROWS + j] = acc1[r];
+        }
+        __syncthreads();
+        if (tid < 2 * 8 * MLP_ROWS) {
+            const int t = tid / (8 * MLP_ROWS), e = tid % (8 * MLP_ROWS);
+            const int jj = e / 8, f = e % 8;
+            const long row = row0 + t * MLP_ROWS + jj;
+            if (f < p.out_dim && row < p.rows) {
+                float v = p.b[4][f];
+#pragma unroll
+                for (int w = 0; w < 8; ++w) v += cur[t * MLP_TILE + (w * 8 + f) * MLP_ROWS + jj];
+                out[row * p.out_dim + f] = v;
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(MLP_THREADS) void gp_mlp_bwd_data2_kernel(MlpDev p, const float* __restrict__ saved_h,
+                                                                       const float* __restrict__ dL_dout, float* __restrict__ dz,
+                                                                       float* __restrict__ dfeature, float* __restrict__ dxyz) {
+    __shared__ float cur[2 * MLP_TILE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, j = lane & 31;
+    const long row0 = (long)blockIdx.x * (2 * MLP_ROWS);
+    // dZ5^T [8][32] per tile (zero-padded)
+    for (int e = tid; e < 2 * 8 * MLP_ROWS; e += MLP_THREADS) {
+        const int t = e / (8 * MLP_ROWS), ee = e % (8 * MLP_ROWS);
+        const int jj = ee / 8, f = ee % 8;
+        const long row = row0 + t * MLP_ROWS + jj;
+        cur[t * MLP_TILE + act_idx(f, jj)] = (f < p.out_dim && row < p.rows) ? dL_dout[row * p.out_dim + f] : 0.f;
+    }
+    __syncthreads();
+    for (int l = 4; l >= 1; --l) {
+        // dH_l^T = W_l^T dZ_{l+1}^T ; W_l = p.w[l] is [Kout, 256]
+        const int K = l == 4 ? 8 : MLP_W, kv = l == 4 ? p.out_dim : MLP_W;
+        f32x16 acc0, acc1;
+        layer_mfma_T2(p.w[l], MLP_W, K, kv, MLP_W, cur, wave, lane, acc0, acc1);
+        const float* h = saved_h + (size_t)(l - 1) * p.rows * MLP_W;
+        const long ra = row0 + j, rb = row0 + MLP_ROWS + j;
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int f = 32 * wave + cd_row(r, half);
+            const float ha = ra < p.rows ? h[ra * MLP_W + f] : 0.f, hb = rb < p.rows ? h[rb * MLP_W + f] : 0.f;
+            cur[act_idx(f, j)] = ha > 0.f ? acc0[r] : 0.f;
+            cur[MLP_TILE + act_idx(f, j)] = hb > 0.f ? acc1[r] : 0.f;
+        }
+        __syncthreads();
+        store_rows(cur, dz + (size_t)(l - 1) * p.rows * MLP_W, MLP_W, MLP_W, row0, p.rows, tid);
+        store_rows(cur + MLP_TILE, dz + (size_t)(l - 1) * p.rows * MLP_W, MLP_W, MLP_W, row0 + MLP_ROWS, p.rows, tid);
+    }
+    // dX^T [in_pad][32] = W_0^T dZ_1^T ; W_0 is [256, in_dim]
+    if (dfeature || dxyz) {
+        f32x16 acc0, acc1;
+        const bool mine = wave * 32 < p.in_pad;
+        if (mine) layer_mfma_T2(p.w[0], p.in_dim, MLP_W, MLP_W, p.in_dim, cur, wave, lane, acc0, acc1);
+        __syncthreads();
+        if (mine) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                cur[act_idx(32 * wave + cd_row(r, half), j)] = acc0[r];
+                cur[MLP_TILE + act_idx(32 * wave + cd_row(r, half), j)] = acc1[r];
+            }
+        }
+        __syncthreads();
+        for (int t = 0; t < 2; ++t) {
+            const float* buf = cur + t * MLP_TILE;
+            const long trow0 = row0 + t * MLP_ROWS;
+            if (dfeature) store_rows(buf, dfeature, p.feature_dim, p.feature_dim, trow0, p.rows, tid);
+            if (dxyz) {
+                // d/dx sin(x 2^f) = 2^f cos, d/dx cos(x 2^f) = -2^f sin
+                if (tid < 3 * MLP_ROWS) {
+                    const int jj = tid / 3, c = tid % 3;
+                    const long row = trow0 + jj;
+                    if (row < p.rows) {
+                        const float x = p.xyz[row * 3 + c];
+                        float g = 0.f;
+                        for (int fr = 0; fr < p.xyz_freq; ++fr) {
+                            const float sc = (float)(1u << fr);
+                            float sv, cv;
+                            sincosf(x * sc, &sv, &cv);
+                            const int f = p.feature_dim + 2 * (c * p.xyz_freq + fr);
+                            g += sc * (cv * buf[act_idx(f, jj)] - sv * buf[act_idx(f + 1, jj)]);
+                        }
+                        dxyz[row * 3 + c] = g;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // MLP backward, weight grads: dW[o][i] += sum_rows dZ[row][o] * H[row][i]   (A = dZ^T, B = H)
 // grid = (row blocks, i-tiles, o-tiles).  The 8 waves of a workgroup split the block's rows, each
 // accumulates a 32x32 tile on the matrix cores (two rows per MFMA, operands straight from global:

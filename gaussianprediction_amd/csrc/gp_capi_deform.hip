@@ -27,6 +27,7 @@ static int make_mlp(const gp_mlp_params* p, const gp_mlp_input* x, MlpDev& m) {
 static inline size_t acts_x_floats(const MlpDev& m) { return (size_t)m.rows * m.in_pad; }
 
 #define GP_MLP_SMALL_ROWS 2048
+#define GP_MLP_LARGE_ROWS 32768
 
 extern "C" int gp_mlp_forward(const gp_mlp_params* p, const gp_mlp_input* x, float* out, float* acts, gp_stream_t stream_) {
     MlpDev m;
@@ -39,6 +40,8 @@ extern "C" int gp_mlp_forward(const gp_mlp_params* p, const gp_mlp_input* x, flo
         // few rows (stage 2/3: the keypoints): 16-row workgroups on v_mfma_f32_16x16x4_f32 spread the work over twice the CUs
         if (m.rows <= GP_MLP_SMALL_ROWS)
             hipLaunchKernelGGL(gp_mlp_fwd_small_kernel, dim3(gp_blocks((size_t)m.rows, 16)), dim3(512), 0, (hipStream_t)stream_, m, out, sx, sh);
+        else if (m.rows >= GP_MLP_LARGE_ROWS)   // two row tiles per workgroup: half the weight traffic from L2
+            hipLaunchKernelGGL(gp_mlp_fwd2_kernel, dim3(gp_blocks((size_t)m.rows, 64)), dim3(512), 0, (hipStream_t)stream_, m, out, sx, sh);
         else
             hipLaunchKernelGGL(gp_mlp_fwd_kernel, dim3(gp_blocks((size_t)m.rows, 32)), dim3(512), 0, (hipStream_t)stream_, m, out, sx, sh);
     GP_LAUNCH_CHECK(); }
@@ -63,6 +66,9 @@ extern "C" int gp_mlp_backward(const gp_mlp_params* p, const gp_mlp_input* x, co
     { GpProfScope _p("mlp_bwd_data", s);
         if (m.rows <= GP_MLP_SMALL_ROWS)
             hipLaunchKernelGGL(gp_mlp_bwd_data_small_kernel, dim3(gp_blocks((size_t)m.rows, 16)), dim3(512), 0, s, m, sh, dL_dout, dz,
+                               dL_dfeature, dL_dxyz);
+        else if (m.rows >= GP_MLP_LARGE_ROWS)
+            hipLaunchKernelGGL(gp_mlp_bwd_data2_kernel, dim3(gp_blocks((size_t)m.rows, 64)), dim3(512), 0, s, m, sh, dL_dout, dz,
                                dL_dfeature, dL_dxyz);
         else
             hipLaunchKernelGGL(gp_mlp_bwd_data_kernel, dim3(gp_blocks((size_t)m.rows, 32)), dim3(512), 0, s, m, sh, dL_dout, dz,

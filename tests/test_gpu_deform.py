@@ -44,7 +44,7 @@ def test_mlp_matches_reference_golden_vectors():
                 assert abs(p.grad.double().sum().item() - gs[0]) <= 1e-3 * max(1.0, gs[1]), k
 
 
-@pytest.mark.parametrize("rows,F,out_dim", [(1, 6, 7), (33, 8, 7), (250, 8, 7), (300, 10, 8), (5000, 6, 7), (20003, 8, 8)])   # last: the large-row weight-gradient kernel, ragged
+@pytest.mark.parametrize("rows,F,out_dim", [(1, 6, 7), (33, 8, 7), (250, 8, 7), (300, 10, 8), (5000, 6, 7), (20003, 8, 8), (40001, 6, 7)])   # last two: large-row weight-gradient kernel; two-tile fwd/bwd kernels (ragged)
 def test_fused_pe_mlp_forward_backward(rows, F, out_dim):
     d_in = 32 + 60 + 2 * F
     net, sd = _net(40 + rows, d_in, out_dim)
