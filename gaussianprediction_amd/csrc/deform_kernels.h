@@ -80,7 +80,7 @@ __global__ __launch_bounds__(256) void gp_mlp_bwd_weight64_kernel(const float* _
                                                                  int ldh, int n_in, long rows, long rows_per_block,
                                                                  float* __restrict__ dW, int lddw, float* __restrict__ db);
 __global__ __launch_bounds__(512) void gp_mlp_fwd2_kernel(MlpDev p, float* __restrict__ out, float* __restrict__ saved_x,
-                                                          float* __restrict__ saved_h);
-__global__ __launch_bounds__(512) void gp_mlp_bwd_data2_kernel(MlpDev p, const float* __restrict__ saved_h,
+                                                          float* __restrict__ saved_h, uint32_t* __restrict__ masks);
+__global__ __launch_bounds__(512) void gp_mlp_bwd_data2_kernel(MlpDev p, const uint32_t* __restrict__ masks,
                                                                const float* __restrict__ dL_dout, float* __restrict__ dz,
                                                                float* __restrict__ dfeature, float* __restrict__ dxyz);

@@ -340,7 +340,7 @@ __device__ __forceinline__ void layer_mfma_T2(const float* __restrict__ W, int l
 }
 
 __global__ __launch_bounds__(MLP_THREADS) void gp_mlp_fwd2_kernel(MlpDev p, float* __restrict__ out, float* __restrict__ saved_x,
-                                                                  float* __restrict__ saved_h) {
+                                                                  float* __restrict__ saved_h, uint32_t* __restrict__ masks) {
     __shared__ float cur[2 * MLP_TILE];          // 64 KB: two row tiles, in place
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, j = lane & 31;
     const long row0 = (long)blockIdx.x * (2 * MLP_ROWS);
@@ -356,11 +356,22 @@ __global__ __launch_bounds__(MLP_THREADS) void gp_mlp_fwd2_kernel(MlpDev p, floa
         f32x16 acc0, acc1;
         layer_mfma2(p.w[l], ldw, K, MLP_W, p.b[l], cur, wave, lane, acc0, acc1);
         __syncthreads();                 // every wave has read its operands
+        uint32_t m0 = 0, m1 = 0;         // ReLU sign bits of this lane's 16 features (bit = feature within the wave's tile)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int idx = act_idx(32 * wave + cd_row(r, half), j);
             cur[idx] = fmaxf(acc0[r], 0.f);
             cur[MLP_TILE + idx] = fmaxf(acc1[r], 0.f);
+            m0 |= (acc0[r] > 0.f ? 1u : 0u) << cd_row(r, half);
+            m1 |= (acc1[r] > 0.f ? 1u : 0u) << cd_row(r, half);
+        }
+        if (masks) {   // [4][rows][8] words: the backward reads 4 bytes per (row, tile) instead of 128 bytes of activations
+            m0 |= (uint32_t)__shfl_xor((int)m0, 32);
+            m1 |= (uint32_t)__shfl_xor((int)m1, 32);
+            if (half == 0) {
+                if (row0 + j < p.rows) masks[((size_t)l * p.rows + row0 + j) * 8 + wave] = m0;
+                if (row0 + MLP_ROWS + j < p.rows) masks[((size_t)l * p.rows + row0 + MLP_ROWS + j) * 8 + wave] = m1;
+            }
         }
         __syncthreads();
         if (saved_h) {
@@ -408,7 +419,7 @@ __global__ __launch_bounds__(MLP_THREADS) void gp_mlp_fwd2_kernel(MlpDev p, floa
     }
 }
 
-__global__ __launch_bounds__(MLP_THREADS) void gp_mlp_bwd_data2_kernel(MlpDev p, const float* __restrict__ saved_h,
+__global__ __launch_bounds__(MLP_THREADS) void gp_mlp_bwd_data2_kernel(MlpDev p, const uint32_t* __restrict__ masks,
                                                                        const float* __restrict__ dL_dout, float* __restrict__ dz,
                                                                        float* __restrict__ dfeature, float* __restrict__ dxyz) {
     __shared__ float cur[2 * MLP_TILE];
@@ -427,15 +438,15 @@ __global__ __launch_bounds__(MLP_THREADS) void gp_mlp_bwd_data2_kernel(MlpDev p,
         const int K = l == 4 ? 8 : MLP_W, kv = l == 4 ? p.out_dim : MLP_W;
         f32x16 acc0, acc1;
         layer_mfma_T2(p.w[l], MLP_W, K, kv, MLP_W, cur, wave, lane, acc0, acc1);
-        const float* h = saved_h + (size_t)(l - 1) * p.rows * MLP_W;
+        const uint32_t* mk = masks + (size_t)(l - 1) * p.rows * 8;
         const long ra = row0 + j, rb = row0 + MLP_ROWS + j;
+        const uint32_t ma = ra < p.rows ? mk[ra * 8 + wave] : 0u, mb = rb < p.rows ? mk[rb * 8 + wave] : 0u;
         __syncthreads();
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int f = 32 * wave + cd_row(r, half);
-            const float ha = ra < p.rows ? h[ra * MLP_W + f] : 0.f, hb = rb < p.rows ? h[rb * MLP_W + f] : 0.f;
-            cur[act_idx(f, j)] = ha > 0.f ? acc0[r] : 0.f;
-            cur[MLP_TILE + act_idx(f, j)] = hb > 0.f ? acc1[r] : 0.f;
+            cur[act_idx(f, j)] = ((ma >> cd_row(r, half)) & 1u) ? acc0[r] : 0.f;
+            cur[MLP_TILE + act_idx(f, j)] = ((mb >> cd_row(r, half)) & 1u) ? acc1[r] : 0.f;
         }
         __syncthreads();
         store_rows(cur, dz + (size_t)(l - 1) * p.rows * MLP_W, MLP_W, MLP_W, row0, p.rows, tid);

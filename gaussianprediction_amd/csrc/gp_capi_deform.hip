@@ -41,7 +41,8 @@ extern "C" int gp_mlp_forward(const gp_mlp_params* p, const gp_mlp_input* x, flo
         if (m.rows <= GP_MLP_SMALL_ROWS)
             hipLaunchKernelGGL(gp_mlp_fwd_small_kernel, dim3(gp_blocks((size_t)m.rows, 16)), dim3(512), 0, (hipStream_t)stream_, m, out, sx, sh);
         else if (m.rows >= GP_MLP_LARGE_ROWS)   // two row tiles per workgroup: half the weight traffic from L2
-            hipLaunchKernelGGL(gp_mlp_fwd2_kernel, dim3(gp_blocks((size_t)m.rows, 64)), dim3(512), 0, (hipStream_t)stream_, m, out, sx, sh);
+            hipLaunchKernelGGL(gp_mlp_fwd2_kernel, dim3(gp_blocks((size_t)m.rows, 64)), dim3(512), 0, (hipStream_t)stream_, m, out, sx, sh,
+                               acts ? (uint32_t*)(sh + (size_t)4 * m.rows * 256) : (uint32_t*)nullptr);
         else
             hipLaunchKernelGGL(gp_mlp_fwd_kernel, dim3(gp_blocks((size_t)m.rows, 32)), dim3(512), 0, (hipStream_t)stream_, m, out, sx, sh);
     GP_LAUNCH_CHECK(); }
@@ -68,7 +69,8 @@ extern "C" int gp_mlp_backward(const gp_mlp_params* p, const gp_mlp_input* x, co
             hipLaunchKernelGGL(gp_mlp_bwd_data_small_kernel, dim3(gp_blocks((size_t)m.rows, 16)), dim3(512), 0, s, m, sh, dL_dout, dz,
                                dL_dfeature, dL_dxyz);
         else if (m.rows >= GP_MLP_LARGE_ROWS)
-            hipLaunchKernelGGL(gp_mlp_bwd_data2_kernel, dim3(gp_blocks((size_t)m.rows, 64)), dim3(512), 0, s, m, sh, dL_dout, dz,
+            hipLaunchKernelGGL(gp_mlp_bwd_data2_kernel, dim3(gp_blocks((size_t)m.rows, 64)), dim3(512), 0, s, m,
+                               (const uint32_t*)(sh + (size_t)4 * m.rows * 256), dL_dout, dz,
                                dL_dfeature, dL_dxyz);
         else
             hipLaunchKernelGGL(gp_mlp_bwd_data_kernel, dim3(gp_blocks((size_t)m.rows, 32)), dim3(512), 0, s, m, sh, dL_dout, dz,

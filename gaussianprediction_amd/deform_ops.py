@@ -42,7 +42,7 @@ class FusedMlp(torch.autograd.Function):
         need_grad = any(x is not None and torch.is_tensor(x) and x.requires_grad for x in (feature, xyz) + tuple(wb))
         out = torch.empty(rows, out_dim, device=dev)
         x_floats = (rows * in_pad + 63) // 64 * 64
-        acts = torch.empty(x_floats + 4 * rows * 256, device=dev) if need_grad else None
+        acts = torch.empty(x_floats + 4 * rows * 256 + 4 * rows * 8, device=dev) if need_grad else None   # x | h | ReLU bit masks
         params = _lib.MlpParamsC(in_dim, 256, 4, out_dim)
         for l in range(5):
             params.w[l] = ws[l].data_ptr()

@@ -150,7 +150,9 @@ typedef struct gp_mlp_input {
 } gp_mlp_input;
 
 /* replaces Deformable_Field.forward on the concatenated input (get_motion_delta).
- * `acts` (optional, training): [depth, rows, width] post-ReLU activations saved for backward. */
+ * `acts` (optional, training): ceil64(rows * in_pad) + depth * rows * width + depth * rows * 8 floats = the kernel input
+ * [rows, in_pad] (in_pad = in_dim rounded up to 8), the [depth, rows, width] post-ReLU activations, and [depth, rows, 8]
+ * 32-bit words of ReLU sign bits (written by the large-row kernels). */
 int gp_mlp_forward(const gp_mlp_params* p, const gp_mlp_input* x, float* out /*[rows,out_dim]*/,
                    float* acts, gp_stream_t stream);
 
