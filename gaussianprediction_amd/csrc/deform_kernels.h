@@ -78,7 +78,8 @@ __global__ __launch_bounds__(512) void gp_mlp_bwd_data_small_kernel(MlpDev p, co
 
 __global__ __launch_bounds__(256) void gp_mlp_bwd_weight64_kernel(const float* __restrict__ dZ, int n_out, const float* __restrict__ H,
                                                                  int ldh, int n_in, long rows, long rows_per_block,
-                                                                 float* __restrict__ dW, int lddw, float* __restrict__ db);
+                                                                 unsigned n_row_blocks, float* __restrict__ dW, int lddw,
+                                                                 float* __restrict__ db);
 __global__ __launch_bounds__(512) void gp_mlp_fwd2_kernel(MlpDev p, float* __restrict__ out, float* __restrict__ saved_x,
                                                           float* __restrict__ saved_h, uint32_t* __restrict__ masks);
 __global__ __launch_bounds__(512) void gp_mlp_bwd_data2_kernel(MlpDev p, const uint32_t* __restrict__ masks,

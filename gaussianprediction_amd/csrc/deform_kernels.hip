@@ -576,16 +576,22 @@ __global__ __launch_bounds__(MLP_THREADS) void gp_mlp_bwd_weight5_kernel(MlpWeig
 
 // Large row counts: 64 x 64 output block per workgroup (4 waves, each a 2 x 2 arrangement of 32 x 32 tiles over its quarter
 // of the block's rows, summed through LDS).  With 32 x 32 blocks every dZ / H element is read by 8 workgroups and the
-// kernel is L2-bandwidth bound; 64 x 64 halves that twice.  grid = (i-blocks * o-blocks, row blocks): the workgroups that
-// share a slab of rows are dispatched back to back.
+// kernel is L2-bandwidth bound; 64 x 64 halves that twice.  1-D grid over (row slab, tile pair), see the mapping below.
 __global__ __launch_bounds__(256) void gp_mlp_bwd_weight64_kernel(const float* __restrict__ dZ, int n_out, const float* __restrict__ H,
                                                                  int ldh, int n_in, long rows, long rows_per_block,
-                                                                 float* __restrict__ dW, int lddw, float* __restrict__ db) {
+                                                                 unsigned n_row_blocks, float* __restrict__ dW, int lddw,
+                                                                 float* __restrict__ db) {
     __shared__ float s_red[4][4][16][64];   // 64 KB
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, j = lane & 31;
+    // XCD-aware mapping: workgroups go to the 8 XCDs round-robin by flat id, and each XCD has its own L2.  All tile pairs
+    // of one row slab get ids that are congruent mod 8, so a slab is fetched into ONE L2 instead of eight.
     const int n_ib = (n_in + 63) / 64;
-    const int o0 = 64 * (blockIdx.x / n_ib), i0 = 64 * (blockIdx.x % n_ib);
-    const long b_begin = (long)blockIdx.y * rows_per_block;
+    const int ntp = n_ib * ((n_out + 63) / 64);
+    const unsigned flat = blockIdx.x, xcd = flat & 7u, seq = flat >> 3;
+    const unsigned slab = (seq / ntp) * 8u + xcd, tp = seq % ntp;
+    if (slab >= n_row_blocks) return;
+    const int o0 = 64 * (tp / n_ib), i0 = 64 * (tp % n_ib);
+    const long b_begin = (long)slab * rows_per_block;
     long b_end = b_begin + rows_per_block;
     if (b_end > rows) b_end = rows;
     const long per_wave = ((b_end - b_begin + 3) / 4 + 7) & ~7L;
@@ -629,7 +635,7 @@ __global__ __launch_bounds__(256) void gp_mlp_bwd_weight64_kernel(const float* _
 #pragma unroll
             for (int r = 0; r < 16; ++r) s_red[wave][2 * a + b][r][lane] = acc[a][b][r];
     __syncthreads();
-    const bool single = gridDim.y == 1;
+    const bool single = n_row_blocks == 1;
     for (int e = tid; e < 4 * 16 * 64; e += 256) {
         const int tl = e >> 10, r = (e >> 6) & 15, l = e & 63;
         const float v = (s_red[0][tl][r][l] + s_red[1][tl][r][l]) + (s_red[2][tl][r][l] + s_red[3][tl][r][l]);

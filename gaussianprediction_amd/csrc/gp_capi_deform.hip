@@ -109,8 +109,9 @@ extern "C" int gp_mlp_backward(const gp_mlp_params* p, const gp_mlp_input* x, co
             const float* H = l == 0 ? sx : sh + (size_t)(l - 1) * m.rows * 256;
             const int ldh = l == 0 ? m.in_pad : 256;
             const int n_in = l == 0 ? m.in_dim : 256;
-            hipLaunchKernelGGL(gp_mlp_bwd_weight64_kernel, dim3((unsigned)((n_in + 63) / 64) * (unsigned)((n_out + 63) / 64), bnrb),
-                               dim3(256), 0, s, dZl, n_out, H, ldh, n_in, m.rows, brpb, g->dw[l], n_in, g->db[l]);
+            const unsigned ntp = (unsigned)((n_in + 63) / 64) * (unsigned)((n_out + 63) / 64);
+            hipLaunchKernelGGL(gp_mlp_bwd_weight64_kernel, dim3(ntp * ((bnrb + 7u) & ~7u)), dim3(256), 0, s, dZl, n_out, H, ldh, n_in,
+                               m.rows, brpb, bnrb, g->dw[l], n_in, g->db[l]);
             GP_LAUNCH_CHECK();
         }
         return 0;
