@@ -249,6 +249,15 @@ def main():
             "eval_render_views_per_s_per_gpu": None if eval_fps is None else round(eval_fps, 2),
             "kernels_ms": kern,
         }
+        if roof is not None and world == 1:
+            try:                                 # measured device peaks beside the vendor number; untimed
+                from gaussianprediction_amd import peaks
+                mp = peaks.measure(device, gib=1.0, reps=5, mfma_iters=2048)
+                roof["peak_measured"] = {"stream_copy": mp["copy_GBps"], "stream_read": mp["read_GBps"], "unit": "GB/s"}
+                roof["frac_of_measured_copy"] = round(roof["achieved"] / mp["copy_GBps"], 4)
+                result["device_peaks_measured"] = mp
+            except Exception as e:
+                roof["peak_measured"] = f"failed: {e}"
         if not args.no_cpu_baseline and world == 1:
             try:
                 result["cpu_baseline"] = cpu_baseline(args, pc, cams)

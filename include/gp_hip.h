@@ -306,6 +306,17 @@ typedef struct gp_profile_entry {
 int gp_profile_enable(int on);
 int gp_profile_collect(gp_profile_entry* out, int max_entries, int* n_out);
 
+/* Peak microbenchmarks (the measured stream-copy and MFMA peaks are reported beside the vendor
+ * numbers).  Each call enqueues ONE kernel on `stream`, bracketed (profile level >= 1) under the names "mb_copy",
+ * "mb_read", "mb_mfma_f32|f16|bf16"; the caller divides bytes / flop by the collected time.
+ *   copy: dst[0..bytes) = src[0..bytes), 16-byte vectors, non-temporal; moves 2*bytes over HBM.
+ *   read: reads src[0..bytes) and discards it (sink is never written for a zero-filled source).
+ *   mfma: 4 independent accumulator chains of `iters` 32x32 MFMAs per wave, 4 waves x 8 workgroups per CU; dtype
+ *         0 = f32 (32x32x2), 1 = f16, 2 = bf16 (32x32x16); *flop_out = total floating-point operations enqueued. */
+int gp_microbench_copy(void* dst, const void* src, size_t bytes, gp_stream_t stream);
+int gp_microbench_read(const void* src, size_t bytes, float* sink, gp_stream_t stream);
+int gp_microbench_mfma(int dtype, int iters, float* sink, double* flop_out, gp_stream_t stream);
+
 const char* gp_last_error(void);
 const char* gp_version(void);
 
