@@ -51,12 +51,16 @@ __device__ __forceinline__ f32x16 mfma16(h8 a, h8 b, f32x16 c) { return __builti
 __device__ __forceinline__ f32x16 mfma16(b8 a, b8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
 
 #define M16_ROWS 64
-// Saved / intermediate 16-bit tensors are stored BLOCKED: [row block of 64][feature][64 rows].  A workgroup writes and the
-// weight-gradient kernels read one contiguous (features x 128 B) chunk per row block; the plain feature-major layout
-// [feature][rows] put every lane of a fragment load in a different page (2 MB stride at 1M rows: TLB-bound).
-__device__ __host__ __forceinline__ size_t t16_idx(int f, long row, int nf) { return ((size_t)(row >> 6) * nf + f) * 64 + (row & 63); }
+// Saved / intermediate 16-bit tensors are stored BLOCKED: [row block of 16][feature][16 rows], rows padded to a multiple of
+// 64 with zeros.  A 32-feature x 16-row MFMA operand fragment of the weight-gradient GEMM (lane = feature, 8 consecutive
+// rows per lane) is then ONE contiguous 1 KB wave load; a forward workgroup (64 rows) still writes one contiguous
+// (features x 128 B) chunk.  The plain feature-major layout [feature][rows] put every lane of a fragment load in a
+// different page (2 MB stride at 1M rows: TLB-bound); 64-row blocks made each load touch 64 separate cache lines.
+#define T16_BLK 16
+__device__ __host__ __forceinline__ size_t t16_idx(int f, long row, int nf) { return ((size_t)(row >> 4) * nf + f) * T16_BLK + (row & 15); }
 __device__ __host__ __forceinline__ size_t t16_elems(int nf, long rows) { return (size_t)((rows + 63) / 64) * nf * 64; }
 #define M16_THREADS 256
+#define GP_MLP16_BIG_ROWS 65536   // from here on the 256x256 layers use the one-workgroup-per-slab weight-gradient kernel
 #define M16_W 256
 
 // element index of (row, feature) in the swizzled [64][256] tile (16-byte granules XORed by row & 15)
@@ -195,10 +199,12 @@ __device__ __forceinline__ void mlp16_fwd_body(Mlp16Dev p, float* __restrict__ o
     // transposed copy-out of a tile: dst[f][row0 + r] for f < nf  (64 consecutive rows = 128 B per feature)
     auto store_T = [&](const T* buf, T* dst, int nf) {      // this workgroup's block: nf x 64 contiguous elements
         T* blk = dst + (size_t)blockIdx.x * nf * M16_ROWS;
-        for (int e = tid; e < nf * M16_ROWS; e += M16_THREADS) {
-            const int f = e / M16_ROWS, r = e - f * M16_ROWS;
-            blk[e] = row0 + r < p.rows ? buf[a16_idx(r, f)] : (T)0.f;
-        }
+#pragma unroll
+        for (int sub = 0; sub < M16_ROWS / T16_BLK; ++sub)
+            for (int e = tid; e < nf * T16_BLK; e += M16_THREADS) {
+                const int f = e >> 4, r = sub * T16_BLK + (e & 15);
+                blk[sub * nf * T16_BLK + e] = row0 + r < p.rows ? buf[a16_idx(r, f)] : (T)0.f;
+            }
     };
     if (saved_xT) store_T(cur, saved_xT, p.in_pad);
     typedef typename Vec4<T>::type V4;
@@ -340,8 +346,8 @@ __device__ __forceinline__ void mlp16_bwd_data_body(Mlp16Dev p, const uint32_t* 
         __syncthreads();
         {   // dZ_l^T -> global [256][rows]
             T* blk = dzT + (size_t)(l - 1) * t16_elems(M16_W, p.rows) + (size_t)blockIdx.x * M16_W * M16_ROWS;
-            for (int e = tid; e < M16_W * M16_ROWS; e += M16_THREADS) {
-                const int f = e / M16_ROWS, r = e - f * M16_ROWS;
+            for (int e = tid; e < M16_W * M16_ROWS; e += M16_THREADS) {      // [4 sub-blocks][256][16 rows]
+                const int f = (e >> 4) & (M16_W - 1), r = (e >> 12) * T16_BLK + (e & 15);
                 blk[e] = row0 + r < p.rows ? nxt[a16_idx(r, f)] : (T)0.f;
             }
         }
@@ -517,6 +523,121 @@ __global__ __launch_bounds__(M16_THREADS) void gp_mlp16_bwd_weight_bf16_kernel(c
     mlp16_bwd_weight_body<__bf16>((const __bf16*)dzT, n_out, (const __bf16*)hT, n_in, nf_z, nf_h, rows, rpb, dW, lddw, db, absmax_bits);
 }
 
+// The three 256x256 layers at large row counts: ONE workgroup owns the whole 256x256 gradient of (layer, row slab), so
+// HBM sees each saved activation / dZ exactly once (the 64x64-per-wave kernel above re-read every slab through L2 sixteen
+// times and ran at 165 TF/s).  The kernel is HBM-bound by design (1 KB of operands per row and layer), so it is built
+// around bytes in flight: per k-step (16 rows) the 8 waves fetch the 16 unique 1 KB fragments (2 each) into registers
+// W16_DEPTH k-steps ahead (64 KB of unique data in flight per CU), pass them through a double-buffered 32 KB LDS stage,
+// and every wave reads the 6 fragments of its 128x64 block (4x2 MFMA tiles, 128 accumulator registers) back from LDS.
+// The barrier waits only for LDS (lgkmcnt); the global prefetches stay in flight across it.
+struct W16BigJob { float* dw[3]; float* db[3]; };
+#define W16_THREADS 512
+#define W16_DEPTH 4
+#define W16_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
+// One group of W16_DEPTH k-steps: write the staged fragments of step k to LDS, re-issue the stage's two loads for step
+// k + W16_DEPTH (the tail re-loads its own step: every k-step issues exactly two loads, in a fixed order, so the
+// compiler's vmcnt before an LDS write leaves the 2 (W16_DEPTH - 1) younger loads in flight), barrier, MFMA from LDS.
+template <typename T, typename V8>
+__device__ __forceinline__ void w16_group(V8 (&gq)[W16_DEPTH][2], f32x16 (&acc)[4][2], float (&bsum)[4], T (*s_st)[2][8][512],
+                                          const T* gz, const T* gh, long k0, long nk, size_t kstride, int wave, int lane,
+                                          int wo, int wi, int frag_off) {
+#pragma unroll
+    for (int d = 0; d < W16_DEPTH; ++d) {
+        const long k = k0 + d;
+        const int buf = d & 1;                              // = k & 1 (W16_DEPTH is even)
+        *(V8*)&s_st[buf][0][wave][lane * 8] = gq[d][0];
+        *(V8*)&s_st[buf][1][wave][lane * 8] = gq[d][1];
+        const long kn = k + W16_DEPTH < nk ? k + W16_DEPTH : k;
+        gq[d][0] = *(const V8*)(gz + kn * kstride);
+        gq[d][1] = *(const V8*)(gh + kn * kstride);
+        W16_LDS_BARRIER();          // one barrier per k-step: a buffer is rewritten two steps later, behind the next barrier
+        V8 a[4], b[2];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) a[u] = *(const V8*)&s_st[buf][0][wo * 4 + u][frag_off];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) b[u] = *(const V8*)&s_st[buf][1][wi * 2 + u][frag_off];
+#pragma unroll
+        for (int uo = 0; uo < 4; ++uo)
+#pragma unroll
+            for (int ui = 0; ui < 2; ++ui) acc[uo][ui] = mfma16(a[uo], b[ui], acc[uo][ui]);
+        if (wi == 0) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) bsum[u] += (float)a[u][e];
+        }
+    }
+}
+
+template <typename T>
+__device__ __forceinline__ void mlp16_bwd_weight_big_body(const T* __restrict__ dz, const T* __restrict__ hT, size_t layer_elems,
+                                                          long n_kb, long kb_per_slab, W16BigJob jobs,
+                                                          const uint32_t* __restrict__ absmax_bits) {
+    typedef typename Vec8<T>::type V8;
+    __shared__ T s_st[2][2][8][512];                           // [buffer][dZ | H][fragment of 32 features][16 rows x 32] = 32 KB
+    const float inv_scale = UsesScale<T>::v ? 1.f / grad_scale_from(absmax_bits) : 1.f;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, j = lane & 31;
+    const int wo = wave >> 2, wi = wave & 3;                   // o block of 128, i block of 64
+    const int l = blockIdx.y;                                  // 0..2 -> layers 1..3: dZ_{l+1} x hidden_l
+    const long kb0 = (long)blockIdx.x * kb_per_slab;
+    long kb1 = kb0 + kb_per_slab;
+    if (kb1 > n_kb) kb1 = n_kb;
+    const long nk = kb1 - kb0;
+    const size_t kstride = (size_t)M16_W * T16_BLK;             // elements per 16-row block (8 KB)
+    // this wave's share of a k-step: fragment `wave` of dZ and of H, lane-linear 16-byte chunks
+    const T* gz = dz + (size_t)(l + 1) * layer_elems + (size_t)kb0 * kstride + wave * 512 + lane * 8;
+    const T* gh = hT + (size_t)l * layer_elems + (size_t)kb0 * kstride + wave * 512 + lane * 8;
+    const int frag_off = (2 * j + half) * 8;                    // (feature j, rows 8 half ..) inside a fragment
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    float bsum[4] = {0.f, 0.f, 0.f, 0.f};
+    // nk is a multiple of W16_DEPTH (the host rounds slabs to 64 rows; the tensors are zero-padded to 64 rows).  The first
+    // group is peeled so that the loop header sees the same load order from both of its predecessors.
+    V8 gq[W16_DEPTH][2];
+#pragma unroll
+    for (int d = 0; d < W16_DEPTH; ++d) { gq[d][0] = *(const V8*)(gz + d * kstride); gq[d][1] = *(const V8*)(gh + d * kstride); }
+    if (nk > 0) w16_group<T, V8>(gq, acc, bsum, s_st, gz, gh, 0, nk, kstride, wave, lane, wo, wi, frag_off);
+    for (long k0 = W16_DEPTH; k0 < nk; k0 += W16_DEPTH)
+        w16_group<T, V8>(gq, acc, bsum, s_st, gz, gh, k0, nk, kstride, wave, lane, wo, wi, frag_off);
+    const bool single = gridDim.x == 1;
+    float* dbase = jobs.dw[l] + (size_t)(wo * 128 + 4 * half) * M16_W + wi * 64 + j;
+#pragma unroll
+    for (int uo = 0; uo < 4; ++uo)
+#pragma unroll
+        for (int ui = 0; ui < 2; ++ui) {
+            __builtin_amdgcn_sched_barrier(0);      // one tile at a time
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float v = acc[uo][ui][r] * inv_scale;
+                float* dst = dbase + (size_t)(uo * 32 + (r & 3) + 8 * (r >> 2)) * M16_W + ui * 32;
+                if (single) *dst += v; else atomicAdd(dst, v);
+            }
+        }
+    __builtin_amdgcn_sched_barrier(0);
+    if (wi == 0) {
+        float* db = jobs.db[l];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float v = (bsum[u] + __shfl_xor(bsum[u], 32)) * inv_scale;
+            if (half == 0) { float* dst = &db[wo * 128 + u * 32 + j]; if (single) *dst += v; else atomicAdd(dst, v); }
+        }
+    }
+}
+__global__ __launch_bounds__(W16_THREADS) void gp_mlp16_bwd_weight_big_f16_kernel(const void* dz, const void* hT, size_t layer_elems, long n_kb,
+                                                                                   long kb_per_slab, W16BigJob jobs, const uint32_t* absmax_bits) {
+    mlp16_bwd_weight_big_body<_Float16>((const _Float16*)dz, (const _Float16*)hT, layer_elems, n_kb, kb_per_slab, jobs, absmax_bits);
+}
+__global__ __launch_bounds__(W16_THREADS) void gp_mlp16_bwd_weight_big_bf16_kernel(const void* dz, const void* hT, size_t layer_elems, long n_kb,
+                                                                                    long kb_per_slab, W16BigJob jobs, const uint32_t* absmax_bits) {
+    mlp16_bwd_weight_big_body<__bf16>((const __bf16*)dz, (const __bf16*)hT, layer_elems, n_kb, kb_per_slab, jobs, absmax_bits);
+}
+
 // dL_dout^T in 16 bits, scaled: [16][rows] (rows >= out_dim zero) -- A operand of the last layer's weight gradient
 template <typename T>
 __global__ __launch_bounds__(256) void gp_mlp16_pack_dout_kernel(const float* __restrict__ dL_dout, int out_dim, long rows,
@@ -602,7 +723,23 @@ extern "C" int gp_mlp16_backward(const gp_mlp16_params* p /* w16 = TRANSPOSED co
     const long rpb = ((m.rows + nrb_l - 1) / nrb_l + 63) & ~63L;
     const unsigned nrb = (unsigned)((m.rows + rpb - 1) / rpb);
     GpProfScope _pw("mlp16_bwd_weight", s);
+    const bool big = m.rows >= GP_MLP16_BIG_ROWS;
+    if (big) {       // layers 1..3 in one launch: grid = (row slabs, 3), slabs of >= 1024 rows, at most 256 per layer
+        const long n_kb = (m.rows + 63) / 64 * (64 / T16_BLK);   // 16-row blocks incl. the zero padding to 64 rows
+        long nslab = n_kb / 64;
+        if (nslab > 256) nslab = 256;
+        if (nslab < 1) nslab = 1;
+        const long kbs = ((n_kb + nslab - 1) / nslab + W16_DEPTH - 1) / W16_DEPTH * W16_DEPTH;
+        const unsigned gx = (unsigned)((n_kb + kbs - 1) / kbs);
+        GpProfScope _pb("mlp16_bwd_weight_big", s);
+        W16BigJob jobs;
+        for (int l = 0; l < 3; ++l) { jobs.dw[l] = g->dw[l + 1]; jobs.db[l] = g->db[l + 1]; }
+        if (f16) hipLaunchKernelGGL(gp_mlp16_bwd_weight_big_f16_kernel, dim3(gx, 3), dim3(W16_THREADS), 0, s, (const void*)dz, saved_hT, t16_elems(256, m.rows), n_kb, kbs, jobs, absmax);
+        else hipLaunchKernelGGL(gp_mlp16_bwd_weight_big_bf16_kernel, dim3(gx, 3), dim3(W16_THREADS), 0, s, (const void*)dz, saved_hT, t16_elems(256, m.rows), n_kb, kbs, jobs, absmax);
+        GP_LAUNCH_CHECK();
+    }
     for (int l = 0; l < 5; ++l) {
+        if (big && l >= 1 && l <= 3) continue;
         const void* dZl = l < 4 ? (const void*)(dz + (size_t)l * t16_elems(256, m.rows) * 2) : (const void*)dout16;
         const int nf_z = l < 4 ? 256 : 16, nf_h = l == 0 ? m.in_pad : 256;
         const int n_out = l < 4 ? 256 : m.out_dim;

@@ -134,7 +134,7 @@ class FusedMlp16(torch.autograd.Function):
         w16 = [w0p, ws[1].to(tdt), ws[2].to(tdt), ws[3].to(tdt), w4p]
         need_grad = any(x is not None and torch.is_tensor(x) and x.requires_grad for x in (feature, xyz) + tuple(wb))
         out = torch.empty(rows, out_dim, device=dev)
-        rows64 = (rows + 63) // 64 * 64                     # blocked layout [row block of 64][feature][64]
+        rows64 = (rows + 63) // 64 * 64                     # blocked layout [row block of 16][feature][16], rows padded to 64
         xT = torch.empty(in_pad * rows64, device=dev, dtype=tdt) if need_grad else None
         hT = torch.empty(4 * 256 * rows64, device=dev, dtype=tdt) if need_grad else None
         masks = torch.empty(4, rows, 8, device=dev, dtype=torch.int32) if need_grad else None

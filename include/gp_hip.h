@@ -173,8 +173,9 @@ typedef struct gp_mlp16_params {
     const void* w16[5];
     const float* b[5];
 } gp_mlp16_params;
-/* saved (training, all optional together), 16-bit, BLOCKED by 64 rows: xT [ceil(rows/64)][in_pad16][64] and
- * hT [4][ceil(rows/64)][256][64] (element (f, row) at ((row >> 6) * nf + f) * 64 + (row & 63));
+/* saved (training, all optional together), 16-bit, BLOCKED by 16 rows, rows zero-padded to a multiple of 64:
+ * xT [ceil(rows/64)*4][in_pad16][16] and hT [4][ceil(rows/64)*4][256][16]
+ * (element (f, row) at ((row >> 4) * nf + f) * 16 + (row & 15));
  * masks [4, rows, 8] u32 = ReLU sign bits. */
 int gp_mlp16_forward(const gp_mlp16_params* p, const gp_mlp_input* x, float* out, void* saved_xT, void* saved_hT,
                      uint32_t* masks, gp_stream_t stream);

@@ -14,7 +14,8 @@ net = gpa.Deformable_Field(d_in, output_dim=7, d=4, w=256, precision=prec).to(de
 pre = "mlp16" if prec != "fp32" else "mlp"
 print("precision", prec)
 flop_row = 2 * (d_in * 256 + 3 * 256 * 256 + 256 * 7)
-for rows in ([250, 1024] if prec == "fp32" else []) + [8192, 65536, 262144, 1048576]:   # 16-bit: large inputs only (small ones use the fp32 small-row kernels)
+row_list = [int(a) for a in sys.argv[2:]] or ([250, 1024] if prec == "fp32" else []) + [8192, 65536, 262144, 1048576]
+for rows in row_list:   # 16-bit: large inputs only (small ones use the fp32 small-row kernels)
     feat = (torch.rand(rows, 32, device=dev) - 0.5).requires_grad_(True)
     xyz = (torch.rand(rows, 3, device=dev) * 2.6 - 1.3).requires_grad_(True)
     t = torch.tensor([0.3], device=dev)
@@ -33,4 +34,5 @@ for rows in ([250, 1024] if prec == "fp32" else []) + [8192, 65536, 262144, 1048
     bd = p[pre + "_bwd_data"][1] / p[pre + "_bwd_data"][0]
     bw = p[pre + "_bwd_weight"][1] / n
     print(f"rows {rows:8d}: fwd {fwd*1e3:9.1f} us ({rows*flop_row/fwd/1e9:7.1f} TF/s)  bwd_data {bd*1e3:9.1f} us ({rows*flop_row/bd/1e9:7.1f} TF/s)  "
-          f"bwd_weight(5 launches) {bw*1e3:9.1f} us ({rows*flop_row/bw/1e9:7.1f} TF/s)", flush=True)
+          f"bwd_weight(5 launches) {bw*1e3:9.1f} us ({rows*flop_row/bw/1e9:7.1f} TF/s)"
+          + (f"  [big 3 layers {p[pre + '_bwd_weight_big'][1] / n * 1e3:.1f} us]" if pre + "_bwd_weight_big" in p else ""), flush=True)
