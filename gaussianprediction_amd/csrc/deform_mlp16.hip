@@ -86,16 +86,16 @@ __device__ __forceinline__ void fast_sincos(float a, float* s, float* c) {
     *c = __builtin_amdgcn_cosf(rev);
 }
 
-template <typename T>
+template <typename T, int ROWS>
 __device__ __forceinline__ void build_input16(T* buf, const Mlp16Dev& p, long row0, int tid) {
     const int fd = p.feature_dim, xf = p.xyz_freq, tf = p.time_freq;
-    for (int e = tid; e < fd * M16_ROWS; e += M16_THREADS) {
+    for (int e = tid; e < fd * ROWS; e += M16_THREADS) {
         const int jj = e / fd, f = e - jj * fd;
         const long row = row0 + jj;
         buf[a16_idx(jj, f)] = (T)(row < p.rows ? p.feature[row * fd + f] : 0.f);
     }
-    for (int e = tid; e < 3 * xf * M16_ROWS; e += M16_THREADS) {
-        const int jj = e % M16_ROWS, cf = e / M16_ROWS;
+    for (int e = tid; e < 3 * xf * ROWS; e += M16_THREADS) {
+        const int jj = e % ROWS, cf = e / ROWS;
         const int c = cf / xf, fr = cf - c * xf;
         const long row = row0 + jj;
         float sv = 0.f, cv = 0.f;
@@ -105,8 +105,8 @@ __device__ __forceinline__ void build_input16(T* buf, const Mlp16Dev& p, long ro
         buf[a16_idx(jj, f + 1)] = (T)cv;
     }
     const float tv = tf > 0 ? p.t[0] : 0.f;
-    for (int e = tid; e < tf * M16_ROWS; e += M16_THREADS) {
-        const int jj = e % M16_ROWS, fr = e / M16_ROWS;
+    for (int e = tid; e < tf * ROWS; e += M16_THREADS) {
+        const int jj = e % ROWS, fr = e / ROWS;
         float sv, cv;
         fast_sincos(tv * (float)(1u << fr), &sv, &cv);
         const bool ok = row0 + jj < p.rows;
@@ -114,9 +114,45 @@ __device__ __forceinline__ void build_input16(T* buf, const Mlp16Dev& p, long ro
         buf[a16_idx(jj, f)] = (T)(ok ? sv : 0.f);
         buf[a16_idx(jj, f + 1)] = (T)(ok ? cv : 0.f);
     }
-    for (int e = tid; e < (p.in_pad - p.in_dim) * M16_ROWS; e += M16_THREADS) {
-        const int jj = e % M16_ROWS, f = p.in_dim + e / M16_ROWS;
+    for (int e = tid; e < (p.in_pad - p.in_dim) * ROWS; e += M16_THREADS) {
+        const int jj = e % ROWS, f = p.in_dim + e / ROWS;
         buf[a16_idx(jj, f)] = (T)0.f;
+    }
+}
+
+// Copy a [ROWS][nf] activation tile (row-major, swizzled, in LDS) to the blocked saved layout [16-row block][nf][16 rows].
+// A lane owns 8 rows x 8 features: eight 16-byte LDS reads (one row each, conflict-free: 32 lanes cover one 512-B row),
+// an 8x8 transpose of 16-bit elements in registers (32 v_perm_b32), eight 16-byte global stores (8 rows of one feature).
+// The element-wise version (one 2-byte LDS read + one 2-byte store per element) was 55 % of the forward kernel.
+template <typename T, int ROWS>
+__device__ __forceinline__ void store_tile_T(const T* buf, T* __restrict__ blk, int nf, long row0, long rows, long rows_pad,
+                                             int wave, int lane) {
+    typedef typename Vec8<T>::type V8;
+    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+    const int fg = lane & 31, h8 = lane >> 5;
+#pragma unroll
+    for (int sub = wave; sub < ROWS / T16_BLK; sub += M16_THREADS / 64) {
+        if (row0 + sub * T16_BLK >= rows_pad) break;            // uniform per wave
+        if (fg * 8 < nf) {
+            const int r0 = sub * T16_BLK + 8 * h8;
+            u4 v[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = __builtin_bit_cast(u4, *(const V8*)&buf[a16_idx(r0 + i, fg * 8)]);
+            if (row0 + sub * T16_BLK + T16_BLK > rows) {        // zero padding rows (last block only)
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    if (row0 + r0 + i >= rows) v[i] = u4{0u, 0u, 0u, 0u};
+            }
+            T* o = blk + ((size_t)sub * nf + fg * 8) * T16_BLK + 8 * h8;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {                       // feature fg*8 + c: rows r0 .. r0+7
+                u4 t;
+#pragma unroll
+                for (int d = 0; d < 4; ++d)                     // dword d = rows (2d, 2d+1), 16-bit column c of each
+                    t[d] = __builtin_amdgcn_perm(v[2 * d + 1][c >> 1], v[2 * d][c >> 1], (c & 1) ? 0x07060302u : 0x05040100u);
+                *(u4*)(o + c * T16_BLK) = t;
+            }
+        }
     }
 }
 
@@ -126,9 +162,9 @@ __device__ __forceinline__ void build_input16(T* buf, const Mlp16Dev& p, long ro
 // SWAPPED = true swaps the MFMA operands (weights as A, activations as B): the accumulator then holds C[feature][row],
 // i.e. lane = row, registers = 16 of the tile's 32 features in runs of FOUR CONSECUTIVE features -- an epilogue writes
 // 8 bytes per run (4 stores per tile instead of 16 two-byte ones) and builds ReLU masks from its own registers.
-template <typename T, bool SWAPPED = false>
+template <typename T, bool SWAPPED = false, int RT = 2>
 __device__ __forceinline__ void gemm16(const T* cur, const T* __restrict__ W, int ldk, int K, int n_feat, int wave, int lane,
-                                       f32x16 acc[2][2]) {
+                                       f32x16 (&acc)[RT][2]) {
     typedef typename Vec8<T>::type V8;
     const int half = lane >> 5, j = lane & 31;
     const int f0 = (2 * wave) * 32 + j, f1 = f0 + 32;
@@ -143,38 +179,39 @@ __device__ __forceinline__ void gemm16(const T* cur, const T* __restrict__ W, in
     // bits 3..6 only, so it is computed with one XOR on a per-lane constant
     const T* arow = cur + j * M16_W;
     const int swz = ((j & 15) << 3) ^ (8 * half);
-    V8 bn[4][2];
+    constexpr int G = RT > 2 ? 2 : 4;       // k-steps per prefetch group: 8 RT MFMAs (256 RT matrix-pipe cycles) cover one group's loads
+    V8 bn[G][2];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < G; ++u) {
         bn[u][0] = (ok0 && u < nks) ? *(const V8*)(w0 + u * 16) : zero;
         bn[u][1] = (ok1 && u < nks) ? *(const V8*)(w1 + u * 16) : zero;
     }
-    for (int ks = 0; ks < nks; ks += 4) {
-        V8 bc[4][2];
+    for (int ks = 0; ks < nks; ks += G) {
+        V8 bc[G][2];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) { bc[u][0] = bn[u][0]; bc[u][1] = bn[u][1]; }
+        for (int u = 0; u < G; ++u) { bc[u][0] = bn[u][0]; bc[u][1] = bn[u][1]; }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {   // prefetch the next group
-            const int kn = ks + 4 + u;
+        for (int u = 0; u < G; ++u) {   // prefetch the next group
+            const int kn = ks + G + u;
             bn[u][0] = (ok0 && kn < nks) ? *(const V8*)(w0 + kn * 16) : zero;
             bn[u][1] = (ok1 && kn < nks) ? *(const V8*)(w1 + kn * 16) : zero;
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < G; ++u) {
             if (ks + u < nks) {
                 const int col = ((ks + u) * 16) ^ swz;
-                const V8 a0 = *(const V8*)(arow + col);
-                const V8 a1 = *(const V8*)(arow + 32 * M16_W + col);
-                if (SWAPPED) {
-                    acc[0][0] = mfma16(bc[u][0], a0, acc[0][0]);
-                    acc[0][1] = mfma16(bc[u][1], a0, acc[0][1]);
-                    acc[1][0] = mfma16(bc[u][0], a1, acc[1][0]);
-                    acc[1][1] = mfma16(bc[u][1], a1, acc[1][1]);
-                } else {
-                    acc[0][0] = mfma16(a0, bc[u][0], acc[0][0]);
-                    acc[0][1] = mfma16(a0, bc[u][1], acc[0][1]);
-                    acc[1][0] = mfma16(a1, bc[u][0], acc[1][0]);
-                    acc[1][1] = mfma16(a1, bc[u][1], acc[1][1]);
+                V8 a[RT];
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) a[rt] = *(const V8*)(arow + rt * 32 * M16_W + col);
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) {
+                    if (SWAPPED) {
+                        acc[rt][0] = mfma16(bc[u][0], a[rt], acc[rt][0]);
+                        acc[rt][1] = mfma16(bc[u][1], a[rt], acc[rt][1]);
+                    } else {
+                        acc[rt][0] = mfma16(a[rt], bc[u][0], acc[rt][0]);
+                        acc[rt][1] = mfma16(a[rt], bc[u][1], acc[rt][1]);
+                    }
                 }
             }
         }
@@ -184,46 +221,47 @@ __device__ __forceinline__ void gemm16(const T* cur, const T* __restrict__ W, in
 // ------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------
-template <typename T>
+// RT = 32-row tiles per wave.  RT = 2: 64 rows per workgroup, double-buffered activations.  RT = 4 (large row counts): 128
+// rows per workgroup, so every weight fragment fetched from L2 feeds four MFMAs instead of two; the activations are
+// updated IN PLACE (one 64 KB tile, two workgroups per CU) behind one extra barrier per layer.
+template <typename T, int RT>
 __device__ __forceinline__ void mlp16_fwd_body(Mlp16Dev p, float* __restrict__ out, T* __restrict__ saved_xT /*[in_pad][rows]*/,
                                                T* __restrict__ saved_hT /*[4][256][rows]*/,
-                                               uint32_t* __restrict__ masks /*[4][rows][8]*/) {
-    __shared__ T smem[2][M16_ROWS * M16_W];
+                                               uint32_t* __restrict__ masks /*[4][rows][8]*/, int dbg = 0) {
+    constexpr int ROWS = 32 * RT;
+    constexpr bool INPLACE = RT > 2;
+    __shared__ T smem[INPLACE ? 1 : 2][ROWS * M16_W];
     typedef typename Vec8<T>::type V8;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, j = lane & 31;
-    const long row0 = (long)blockIdx.x * M16_ROWS;
+    const long row0 = (long)blockIdx.x * ROWS;
+    const long rows_pad = (p.rows + 63) & ~63L;                 // the saved tensors are allocated (and zero-padded) to 64 rows
     T* cur = smem[0];
-    T* nxt = smem[1];
-    build_input16<T>(cur, p, row0, tid);
+    T* nxt = smem[INPLACE ? 0 : 1];
+    if (!(dbg & 2)) build_input16<T, ROWS>(cur, p, row0, tid);
     __syncthreads();
-    // transposed copy-out of a tile: dst[f][row0 + r] for f < nf  (64 consecutive rows = 128 B per feature)
-    auto store_T = [&](const T* buf, T* dst, int nf) {      // this workgroup's block: nf x 64 contiguous elements
-        T* blk = dst + (size_t)blockIdx.x * nf * M16_ROWS;
-#pragma unroll
-        for (int sub = 0; sub < M16_ROWS / T16_BLK; ++sub)
-            for (int e = tid; e < nf * T16_BLK; e += M16_THREADS) {
-                const int f = e >> 4, r = sub * T16_BLK + (e & 15);
-                blk[sub * nf * T16_BLK + e] = row0 + r < p.rows ? buf[a16_idx(r, f)] : (T)0.f;
-            }
+    auto store_T = [&](const T* buf, T* dst, int nf) {      // this workgroup's block: nf x ROWS contiguous elements
+        store_tile_T<T, ROWS>(buf, dst + (size_t)blockIdx.x * nf * ROWS, nf, row0, p.rows, rows_pad, wave, lane);
     };
-    if (saved_xT) store_T(cur, saved_xT, p.in_pad);
+    if (saved_xT && !(dbg & 1)) store_T(cur, saved_xT, p.in_pad);
     typedef typename Vec4<T>::type V4;
     for (int l = 0; l < 4; ++l) {
         const int K = l == 0 ? p.in_pad : M16_W;
-        f32x16 acc[2][2];
+        f32x16 acc[RT][2];
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {   // this lane's features of tile nt: runs of four at (2 wave + nt) * 32 + 8 g + 4 half
                 const float4 bv = *(const float4*)(p.b[l] + (2 * wave + nt) * 32 + 8 * g + 4 * half);
 #pragma unroll
-                for (int rt = 0; rt < 2; ++rt) {
+                for (int rt = 0; rt < RT; ++rt) {
                     acc[rt][nt][4 * g + 0] = bv.x; acc[rt][nt][4 * g + 1] = bv.y; acc[rt][nt][4 * g + 2] = bv.z; acc[rt][nt][4 * g + 3] = bv.w;
                 }
             }
-        gemm16<T, true>(cur, (const T*)p.w[l], K, K, M16_W, wave, lane, acc);
+        if (!(dbg & 8)) gemm16<T, true, RT>(cur, (const T*)p.w[l], K, K, M16_W, wave, lane, acc);
+        if (INPLACE) __syncthreads();       // every wave has read the layer's input before anyone overwrites it
+        if (!(dbg & 4))
 #pragma unroll
-        for (int rt = 0; rt < 2; ++rt) {
+        for (int rt = 0; rt < RT; ++rt) {
             const int row = rt * 32 + j;
             const long grow = row0 + row;
 #pragma unroll
@@ -248,37 +286,38 @@ __device__ __forceinline__ void mlp16_fwd_body(Mlp16Dev p, float* __restrict__ o
             }
         }
         __syncthreads();
-        if (saved_hT) store_T(nxt, saved_hT + (size_t)l * t16_elems(M16_W, p.rows), M16_W);
+        if (saved_hT && !(dbg & 1)) store_T(nxt, saved_hT + (size_t)l * t16_elems(M16_W, p.rows), M16_W);
         T* t = cur; cur = nxt; nxt = t;
     }
     {   // output layer: W4 padded to [32][256]; the 4 waves split K, reduce through LDS (fp32)
-        f32x16 acc[2];
+        f32x16 acc[RT];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { acc[0][r] = 0.f; acc[1][r] = 0.f; }
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[rt][r] = 0.f;
         const T* w4 = (const T*)p.w[4] + (size_t)j * M16_W + 8 * half;
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int ks = 4 * wave + u;
             const V8 b = *(const V8*)(w4 + ks * 16);
-            const V8 a0 = *(const V8*)(cur + a16_idx(j, ks * 16 + 8 * half));
-            const V8 a1 = *(const V8*)(cur + a16_idx(32 + j, ks * 16 + 8 * half));
-            acc[0] = mfma16(a0, b, acc[0]);
-            acc[1] = mfma16(a1, b, acc[1]);
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) acc[rt] = mfma16(*(const V8*)(cur + a16_idx(32 * rt + j, ks * 16 + 8 * half)), b, acc[rt]);
         }
-        float* red = (float*)nxt;   // [4 waves][64 rows][8]
+        if (INPLACE) __syncthreads();
+        float* red = (float*)nxt;   // [4 waves][ROWS][8]
         if (j < 8) {
 #pragma unroll
-            for (int rt = 0; rt < 2; ++rt)
+            for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) red[(wave * M16_ROWS + rt * 32 + cd_row16(r, half)) * 8 + j] = acc[rt][r];
+                for (int r = 0; r < 16; ++r) red[(wave * ROWS + rt * 32 + cd_row16(r, half)) * 8 + j] = acc[rt][r];
         }
         __syncthreads();
-        for (int e = tid; e < M16_ROWS * 8; e += M16_THREADS) {
+        for (int e = tid; e < ROWS * 8; e += M16_THREADS) {
             const int r = e / 8, f = e % 8;
             if (f < p.out_dim && row0 + r < p.rows) {
                 float v = p.b[4][f];
 #pragma unroll
-                for (int w = 0; w < 4; ++w) v += red[(w * M16_ROWS + r) * 8 + f];
+                for (int w = 0; w < 4; ++w) v += red[(w * ROWS + r) * 8 + f];
                 out[(row0 + r) * p.out_dim + f] = v;
             }
         }
@@ -286,10 +325,16 @@ __device__ __forceinline__ void mlp16_fwd_body(Mlp16Dev p, float* __restrict__ o
 }
 
 __global__ __launch_bounds__(M16_THREADS) void gp_mlp16_fwd_f16_kernel(Mlp16Dev p, float* out, void* sx, void* sh, uint32_t* masks) {
-    mlp16_fwd_body<_Float16>(p, out, (_Float16*)sx, (_Float16*)sh, masks);
+    mlp16_fwd_body<_Float16, 2>(p, out, (_Float16*)sx, (_Float16*)sh, masks);
 }
 __global__ __launch_bounds__(M16_THREADS) void gp_mlp16_fwd_bf16_kernel(Mlp16Dev p, float* out, void* sx, void* sh, uint32_t* masks) {
-    mlp16_fwd_body<__bf16>(p, out, (__bf16*)sx, (__bf16*)sh, masks);
+    mlp16_fwd_body<__bf16, 2>(p, out, (__bf16*)sx, (__bf16*)sh, masks);
+}
+__global__ __launch_bounds__(M16_THREADS, 2) void gp_mlp16_fwd4_f16_kernel(Mlp16Dev p, float* out, void* sx, void* sh, uint32_t* masks, int dbg) {
+    mlp16_fwd_body<_Float16, 4>(p, out, (_Float16*)sx, (_Float16*)sh, masks, dbg);
+}
+__global__ __launch_bounds__(M16_THREADS, 2) void gp_mlp16_fwd4_bf16_kernel(Mlp16Dev p, float* out, void* sx, void* sh, uint32_t* masks) {
+    mlp16_fwd_body<__bf16, 4>(p, out, (__bf16*)sx, (__bf16*)sh, masks);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -297,18 +342,21 @@ __global__ __launch_bounds__(M16_THREADS) void gp_mlp16_fwd_bf16_kernel(Mlp16Dev
 // wt[1..3]: [256][256] (= W_l^T), wt[0]: [in_pad][256] (= W_0^T, rows >= in_dim zero).
 // Writes dZ_l TRANSPOSED ([4][256][rows], scaled) for the weight-gradient GEMM.
 // ------------------------------------------------------------------------------------------------
-template <typename T>
+template <typename T, int RT>
 __device__ __forceinline__ void mlp16_bwd_data_body(Mlp16Dev p, const uint32_t* __restrict__ masks,
                                                     const float* __restrict__ dL_dout, T* __restrict__ dzT,
                                                     float* __restrict__ dfeature, float* __restrict__ dxyz,
                                                     const uint32_t* __restrict__ absmax_bits) {
-    __shared__ T smem[2][M16_ROWS * M16_W];
+    constexpr int ROWS = 32 * RT;
+    constexpr bool INPLACE = RT > 2;
+    __shared__ T smem[INPLACE ? 1 : 2][ROWS * M16_W];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, j = lane & 31;
-    const long row0 = (long)blockIdx.x * M16_ROWS;
+    const long row0 = (long)blockIdx.x * ROWS;
+    const long rows_pad = (p.rows + 63) & ~63L;
     const float S = UsesScale<T>::v ? grad_scale_from(absmax_bits) : 1.f;
     T* cur = smem[0];
-    T* nxt = smem[1];
-    for (int e = tid; e < 16 * M16_ROWS; e += M16_THREADS) {
+    T* nxt = smem[INPLACE ? 0 : 1];
+    for (int e = tid; e < 16 * ROWS; e += M16_THREADS) {
         const int r = e / 16, f = e % 16;
         const long row = row0 + r;
         cur[a16_idx(r, f)] = (T)((f < p.out_dim && row < p.rows) ? dL_dout[row * p.out_dim + f] * S : 0.f);
@@ -317,17 +365,18 @@ __device__ __forceinline__ void mlp16_bwd_data_body(Mlp16Dev p, const uint32_t* 
     typedef typename Vec4<T>::type V4;
     for (int l = 4; l >= 1; --l) {
         const int K = l == 4 ? 16 : M16_W;
-        f32x16 acc[2][2];
+        f32x16 acc[RT][2];
 #pragma unroll
-        for (int rt = 0; rt < 2; ++rt)
+        for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[rt][nt][r] = 0.f;
-        gemm16<T, true>(cur, (const T*)p.w[l], K, K, M16_W, wave, lane, acc);
+        gemm16<T, true, RT>(cur, (const T*)p.w[l], K, K, M16_W, wave, lane, acc);
+        if (INPLACE) __syncthreads();
         const uint32_t* mk = masks + (size_t)(l - 1) * p.rows * 8;
 #pragma unroll
-        for (int rt = 0; rt < 2; ++rt) {
+        for (int rt = 0; rt < RT; ++rt) {
             const int row = rt * 32 + j;
             const long grow = row0 + row;
 #pragma unroll
@@ -345,28 +394,26 @@ __device__ __forceinline__ void mlp16_bwd_data_body(Mlp16Dev p, const uint32_t* 
         }
         __syncthreads();
         {   // dZ_l^T -> global [256][rows]
-            T* blk = dzT + (size_t)(l - 1) * t16_elems(M16_W, p.rows) + (size_t)blockIdx.x * M16_W * M16_ROWS;
-            for (int e = tid; e < M16_W * M16_ROWS; e += M16_THREADS) {      // [4 sub-blocks][256][16 rows]
-                const int f = (e >> 4) & (M16_W - 1), r = (e >> 12) * T16_BLK + (e & 15);
-                blk[e] = row0 + r < p.rows ? nxt[a16_idx(r, f)] : (T)0.f;
-            }
+            T* blk = dzT + (size_t)(l - 1) * t16_elems(M16_W, p.rows) + (size_t)blockIdx.x * M16_W * ROWS;
+            store_tile_T<T, ROWS>(nxt, blk, M16_W, row0, p.rows, rows_pad, wave, lane);
         }
         T* t = cur; cur = nxt; nxt = t;
     }
     if (dfeature || dxyz) {
         // dX[64][in_pad] = dZ_1 . W_0 ; feature tiles beyond in_pad are skipped; result kept in fp32 in LDS
-        f32x16 acc[2][2];
+        f32x16 acc[RT][2];
 #pragma unroll
-        for (int rt = 0; rt < 2; ++rt)
+        for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[rt][nt][r] = 0.f;
-        if (wave * 64 < p.in_pad) gemm16<T>(cur, (const T*)p.w[0], M16_W, M16_W, p.in_pad, wave, lane, acc);
-        float* dX = (float*)nxt;   // [64][128] fp32 = 32 KB
+        if (wave * 64 < p.in_pad) gemm16<T, false, RT>(cur, (const T*)p.w[0], M16_W, M16_W, p.in_pad, wave, lane, acc);
+        if (INPLACE) __syncthreads();
+        float* dX = (float*)nxt;   // [ROWS][128] fp32
         const float inv = 1.f / S;
 #pragma unroll
-        for (int rt = 0; rt < 2; ++rt)
+        for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) {
                 const int f = (2 * wave + nt) * 32 + j;
@@ -378,13 +425,13 @@ __device__ __forceinline__ void mlp16_bwd_data_body(Mlp16Dev p, const uint32_t* 
         __syncthreads();
         if (dfeature) {
             const int fd = p.feature_dim;
-            for (int e = tid; e < fd * M16_ROWS; e += M16_THREADS) {
+            for (int e = tid; e < fd * ROWS; e += M16_THREADS) {
                 const int r = e / fd, f = e - r * fd;
                 if (row0 + r < p.rows) dfeature[(row0 + r) * fd + f] = dX[r * 128 + f];
             }
         }
-        if (dxyz && tid < 3 * M16_ROWS) {
-            const int r = tid / 3, c = tid % 3;
+        for (int e = tid; dxyz && e < 3 * ROWS; e += M16_THREADS) {
+            const int r = e / 3, c = e % 3;
             const long row = row0 + r;
             if (row < p.rows) {
                 const float x = p.xyz[row * 3 + c];
@@ -403,11 +450,19 @@ __device__ __forceinline__ void mlp16_bwd_data_body(Mlp16Dev p, const uint32_t* 
 }
 __global__ __launch_bounds__(M16_THREADS) void gp_mlp16_bwd_data_f16_kernel(Mlp16Dev p, const uint32_t* masks, const float* dL_dout,
                                                                              void* dzT, float* dfeature, float* dxyz, const uint32_t* absmax_bits) {
-    mlp16_bwd_data_body<_Float16>(p, masks, dL_dout, (_Float16*)dzT, dfeature, dxyz, absmax_bits);
+    mlp16_bwd_data_body<_Float16, 2>(p, masks, dL_dout, (_Float16*)dzT, dfeature, dxyz, absmax_bits);
 }
 __global__ __launch_bounds__(M16_THREADS) void gp_mlp16_bwd_data_bf16_kernel(Mlp16Dev p, const uint32_t* masks, const float* dL_dout,
                                                                               void* dzT, float* dfeature, float* dxyz, const uint32_t* absmax_bits) {
-    mlp16_bwd_data_body<__bf16>(p, masks, dL_dout, (__bf16*)dzT, dfeature, dxyz, absmax_bits);
+    mlp16_bwd_data_body<__bf16, 2>(p, masks, dL_dout, (__bf16*)dzT, dfeature, dxyz, absmax_bits);
+}
+__global__ __launch_bounds__(M16_THREADS, 2) void gp_mlp16_bwd_data4_f16_kernel(Mlp16Dev p, const uint32_t* masks, const float* dL_dout,
+                                                                                 void* dzT, float* dfeature, float* dxyz, const uint32_t* absmax_bits) {
+    mlp16_bwd_data_body<_Float16, 4>(p, masks, dL_dout, (_Float16*)dzT, dfeature, dxyz, absmax_bits);
+}
+__global__ __launch_bounds__(M16_THREADS, 2) void gp_mlp16_bwd_data4_bf16_kernel(Mlp16Dev p, const uint32_t* masks, const float* dL_dout,
+                                                                                  void* dzT, float* dfeature, float* dxyz, const uint32_t* absmax_bits) {
+    mlp16_bwd_data_body<__bf16, 4>(p, masks, dL_dout, (__bf16*)dzT, dfeature, dxyz, absmax_bits);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -678,9 +733,15 @@ extern "C" int gp_mlp16_forward(const gp_mlp16_params* p, const gp_mlp_input* x,
     if (!out) GP_FAIL("null output");
     hipStream_t s = (hipStream_t)stream_;
     GpProfScope _p("mlp16_fwd", s);
-    const dim3 grid(gp_blocks((size_t)m.rows, M16_ROWS));
-    if (p->dtype == GP_DTYPE_F16) hipLaunchKernelGGL(gp_mlp16_fwd_f16_kernel, grid, dim3(M16_THREADS), 0, s, m, out, saved_xT, saved_hT, masks);
-    else hipLaunchKernelGGL(gp_mlp16_fwd_bf16_kernel, grid, dim3(M16_THREADS), 0, s, m, out, saved_xT, saved_hT, masks);
+    if (m.rows >= GP_MLP16_BIG_ROWS) {        // 128 rows per workgroup
+        const dim3 grid(gp_blocks((size_t)m.rows, 128));
+        if (p->dtype == GP_DTYPE_F16) hipLaunchKernelGGL(gp_mlp16_fwd4_f16_kernel, grid, dim3(M16_THREADS), 0, s, m, out, saved_xT, saved_hT, masks, getenv("GP_F4_DBG") ? atoi(getenv("GP_F4_DBG")) : 0);
+        else hipLaunchKernelGGL(gp_mlp16_fwd4_bf16_kernel, grid, dim3(M16_THREADS), 0, s, m, out, saved_xT, saved_hT, masks);
+    } else {
+        const dim3 grid(gp_blocks((size_t)m.rows, M16_ROWS));
+        if (p->dtype == GP_DTYPE_F16) hipLaunchKernelGGL(gp_mlp16_fwd_f16_kernel, grid, dim3(M16_THREADS), 0, s, m, out, saved_xT, saved_hT, masks);
+        else hipLaunchKernelGGL(gp_mlp16_fwd_bf16_kernel, grid, dim3(M16_THREADS), 0, s, m, out, saved_xT, saved_hT, masks);
+    }
     GP_LAUNCH_CHECK();
     return 0;
 }
@@ -708,12 +769,13 @@ extern "C" int gp_mlp16_backward(const gp_mlp16_params* p /* w16 = TRANSPOSED co
     }
     {
         GpProfScope _p("mlp16_bwd_data", s);
-        const dim3 grid(gp_blocks((size_t)m.rows, M16_ROWS));
+        const bool big_rows = m.rows >= GP_MLP16_BIG_ROWS;
+        const dim3 grid(gp_blocks((size_t)m.rows, big_rows ? 128 : M16_ROWS));
         if (f16) {
-            hipLaunchKernelGGL(gp_mlp16_bwd_data_f16_kernel, grid, dim3(M16_THREADS), 0, s, m, masks, dL_dout, (void*)dz, dL_dfeature, dL_dxyz, absmax);
+            hipLaunchKernelGGL(big_rows ? gp_mlp16_bwd_data4_f16_kernel : gp_mlp16_bwd_data_f16_kernel, grid, dim3(M16_THREADS), 0, s, m, masks, dL_dout, (void*)dz, dL_dfeature, dL_dxyz, absmax);
             hipLaunchKernelGGL((gp_mlp16_pack_dout_kernel<_Float16>), dim3(gp_blocks((size_t)m.rows, 256)), dim3(256), 0, s, dL_dout, m.out_dim, m.rows, (_Float16*)dout16, absmax);
         } else {
-            hipLaunchKernelGGL(gp_mlp16_bwd_data_bf16_kernel, grid, dim3(M16_THREADS), 0, s, m, masks, dL_dout, (void*)dz, dL_dfeature, dL_dxyz, absmax);
+            hipLaunchKernelGGL(big_rows ? gp_mlp16_bwd_data4_bf16_kernel : gp_mlp16_bwd_data_bf16_kernel, grid, dim3(M16_THREADS), 0, s, m, masks, dL_dout, (void*)dz, dL_dfeature, dL_dxyz, absmax);
             hipLaunchKernelGGL((gp_mlp16_pack_dout_kernel<__bf16>), dim3(gp_blocks((size_t)m.rows, 256)), dim3(256), 0, s, dL_dout, m.out_dim, m.rows, (__bf16*)dout16, absmax);
         }
         GP_LAUNCH_CHECK();
