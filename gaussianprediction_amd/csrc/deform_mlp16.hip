@@ -60,7 +60,7 @@ __device__ __forceinline__ f32x16 mfma16(b8 a, b8 b, f32x16 c) { return __builti
 __device__ __host__ __forceinline__ size_t t16_idx(int f, long row, int nf) { return ((size_t)(row >> 4) * nf + f) * T16_BLK + (row & 15); }
 __device__ __host__ __forceinline__ size_t t16_elems(int nf, long rows) { return (size_t)((rows + 63) / 64) * nf * 64; }
 #define M16_THREADS 256
-#define GP_MLP16_BIG_ROWS 65536   // from here on the 256x256 layers use the one-workgroup-per-slab weight-gradient kernel
+#define GP_MLP16_BIG_ROWS 65536   // from here on forward / data-backward use 128-row workgroups
 #define M16_W 256
 
 // element index of (row, feature) in the swizzled [64][256] tile (16-byte granules XORed by row & 15)
@@ -86,40 +86,96 @@ __device__ __forceinline__ void fast_sincos(float a, float* s, float* c) {
     *c = __builtin_amdgcn_cosf(rev);
 }
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// four floats -> four 16-bit values with the packed converts (v_cvt_pk_f16_f32 / v_cvt_pk_bf16_f32: one instruction per pair)
+__device__ __forceinline__ h4 pack4(float a, float b, float c, float d, _Float16) {
+    typedef _Float16 hh2 __attribute__((ext_vector_type(2)));
+    const hh2 lo = __builtin_convertvector((f32x2){a, b}, hh2), hi = __builtin_convertvector((f32x2){c, d}, hh2);
+    return (h4){lo[0], lo[1], hi[0], hi[1]};
+}
+__device__ __forceinline__ b4 pack4(float a, float b, float c, float d, __bf16) {
+    typedef __bf16 bb2 __attribute__((ext_vector_type(2)));
+    const bb2 lo = __builtin_convertvector((f32x2){a, b}, bb2), hi = __builtin_convertvector((f32x2){c, d}, bb2);
+    return (b4){lo[0], lo[1], hi[0], hi[1]};
+}
+
+template <typename T> struct Vec2;
+template <> struct Vec2<_Float16> { typedef _Float16 type __attribute__((ext_vector_type(2))); };
+template <> struct Vec2<__bf16> { typedef __bf16 type __attribute__((ext_vector_type(2))); };
+
+// Layer-0 input tile [ROWS][in_pad] = [feature | PE(xyz) | PE(t) | 0] in 16 bits.  Fast path (feature_dim % 4 == 0, the
+// reference's 32): float4 feature loads -> 8-byte LDS stores, one thread per (row, coordinate) computing all its
+// frequencies with (sin, cos) pairs stored as one dword, no run-time divisions (this stage was ~15 % of the forward).
 template <typename T, int ROWS>
 __device__ __forceinline__ void build_input16(T* buf, const Mlp16Dev& p, long row0, int tid) {
+    typedef typename Vec4<T>::type V4;
+    typedef typename Vec2<T>::type V2;
     const int fd = p.feature_dim, xf = p.xyz_freq, tf = p.time_freq;
-    for (int e = tid; e < fd * ROWS; e += M16_THREADS) {
-        const int jj = e / fd, f = e - jj * fd;
-        const long row = row0 + jj;
-        buf[a16_idx(jj, f)] = (T)(row < p.rows ? p.feature[row * fd + f] : 0.f);
-    }
-    for (int e = tid; e < 3 * xf * ROWS; e += M16_THREADS) {
-        const int jj = e % ROWS, cf = e / ROWS;
-        const int c = cf / xf, fr = cf - c * xf;
-        const long row = row0 + jj;
-        float sv = 0.f, cv = 0.f;
-        if (row < p.rows) fast_sincos(p.xyz[row * 3 + c] * (float)(1u << fr), &sv, &cv);
-        const int f = fd + 2 * cf;
-        buf[a16_idx(jj, f)] = (T)sv;
-        buf[a16_idx(jj, f + 1)] = (T)cv;
-    }
     const float tv = tf > 0 ? p.t[0] : 0.f;
-    for (int e = tid; e < tf * ROWS; e += M16_THREADS) {
-        const int jj = e % ROWS, fr = e / ROWS;
-        float sv, cv;
-        fast_sincos(tv * (float)(1u << fr), &sv, &cv);
-        const bool ok = row0 + jj < p.rows;
-        const int f = fd + 6 * xf + 2 * fr;
-        buf[a16_idx(jj, f)] = (T)(ok ? sv : 0.f);
-        buf[a16_idx(jj, f + 1)] = (T)(ok ? cv : 0.f);
+    if ((fd & 3) == 0 && ((uintptr_t)p.feature & 15) == 0) {
+        const int q = fd >> 2;
+        for (int jj = tid >> 3; jj < ROWS; jj += M16_THREADS / 8) {
+            const long row = row0 + jj;
+            for (int f4 = tid & 7; f4 < q; f4 += 8) {
+                const float4 v = row < p.rows ? *(const float4*)(p.feature + row * fd + 4 * f4) : make_float4(0.f, 0.f, 0.f, 0.f);
+                V4 pk;
+                pk[0] = (T)v.x; pk[1] = (T)v.y; pk[2] = (T)v.z; pk[3] = (T)v.w;
+                *(V4*)&buf[a16_idx(jj, 4 * f4)] = pk;
+            }
+        }
+        for (int e = tid; e < 3 * ROWS; e += M16_THREADS) {
+            const int jj = e / 3, c = e - 3 * jj;
+            const long row = row0 + jj;
+            const bool ok = row < p.rows;
+            const float x = ok ? p.xyz[row * 3 + c] : 0.f;
+            for (int fr = 0; fr < xf; ++fr) {
+                float sv, cv;
+                fast_sincos(x * (float)(1u << fr), &sv, &cv);
+                V2 pk;
+                pk[0] = (T)(ok ? sv : 0.f); pk[1] = (T)(ok ? cv : 0.f);
+                *(V2*)&buf[a16_idx(jj, fd + 2 * (c * xf + fr))] = pk;
+            }
+        }
+        for (int e = tid; e < tf * ROWS; e += M16_THREADS) {
+            const int jj = e % ROWS, fr = e / ROWS;
+            float sv, cv;
+            fast_sincos(tv * (float)(1u << fr), &sv, &cv);
+            const bool ok = row0 + jj < p.rows;
+            V2 pk;
+            pk[0] = (T)(ok ? sv : 0.f); pk[1] = (T)(ok ? cv : 0.f);
+            *(V2*)&buf[a16_idx(jj, fd + 6 * xf + 2 * fr)] = pk;
+        }
+    } else {
+        for (int e = tid; e < fd * ROWS; e += M16_THREADS) {
+            const int jj = e / fd, f = e - jj * fd;
+            const long row = row0 + jj;
+            buf[a16_idx(jj, f)] = (T)(row < p.rows ? p.feature[row * fd + f] : 0.f);
+        }
+        for (int e = tid; e < 3 * xf * ROWS; e += M16_THREADS) {
+            const int jj = e % ROWS, cf = e / ROWS;
+            const int c = cf / xf, fr = cf - c * xf;
+            const long row = row0 + jj;
+            float sv = 0.f, cv = 0.f;
+            if (row < p.rows) fast_sincos(p.xyz[row * 3 + c] * (float)(1u << fr), &sv, &cv);
+            const int f = fd + 2 * cf;
+            buf[a16_idx(jj, f)] = (T)sv;
+            buf[a16_idx(jj, f + 1)] = (T)cv;
+        }
+        for (int e = tid; e < tf * ROWS; e += M16_THREADS) {
+            const int jj = e % ROWS, fr = e / ROWS;
+            float sv, cv;
+            fast_sincos(tv * (float)(1u << fr), &sv, &cv);
+            const bool ok = row0 + jj < p.rows;
+            const int f = fd + 6 * xf + 2 * fr;
+            buf[a16_idx(jj, f)] = (T)(ok ? sv : 0.f);
+            buf[a16_idx(jj, f + 1)] = (T)(ok ? cv : 0.f);
+        }
     }
     for (int e = tid; e < (p.in_pad - p.in_dim) * ROWS; e += M16_THREADS) {
         const int jj = e % ROWS, f = p.in_dim + e / ROWS;
         buf[a16_idx(jj, f)] = (T)0.f;
     }
 }
-
 // Copy a [ROWS][nf] activation tile (row-major, swizzled, in LDS) to the blocked saved layout [16-row block][nf][16 rows].
 // A lane owns 8 rows x 8 features: eight 16-byte LDS reads (one row each, conflict-free: 32 lanes cover one 512-B row),
 // an 8x8 transpose of 16-bit elements in registers (32 v_perm_b32), eight 16-byte global stores (8 rows of one feature).
@@ -227,7 +283,7 @@ __device__ __forceinline__ void gemm16(const T* cur, const T* __restrict__ W, in
 template <typename T, int RT>
 __device__ __forceinline__ void mlp16_fwd_body(Mlp16Dev p, float* __restrict__ out, T* __restrict__ saved_xT /*[in_pad][rows]*/,
                                                T* __restrict__ saved_hT /*[4][256][rows]*/,
-                                               uint32_t* __restrict__ masks /*[4][rows][8]*/, int dbg = 0) {
+                                               uint32_t* __restrict__ masks /*[4][rows][8]*/) {
     constexpr int ROWS = 32 * RT;
     constexpr bool INPLACE = RT > 2;
     __shared__ T smem[INPLACE ? 1 : 2][ROWS * M16_W];
@@ -237,12 +293,12 @@ __device__ __forceinline__ void mlp16_fwd_body(Mlp16Dev p, float* __restrict__ o
     const long rows_pad = (p.rows + 63) & ~63L;                 // the saved tensors are allocated (and zero-padded) to 64 rows
     T* cur = smem[0];
     T* nxt = smem[INPLACE ? 0 : 1];
-    if (!(dbg & 2)) build_input16<T, ROWS>(cur, p, row0, tid);
+    build_input16<T, ROWS>(cur, p, row0, tid);
     __syncthreads();
     auto store_T = [&](const T* buf, T* dst, int nf) {      // this workgroup's block: nf x ROWS contiguous elements
         store_tile_T<T, ROWS>(buf, dst + (size_t)blockIdx.x * nf * ROWS, nf, row0, p.rows, rows_pad, wave, lane);
     };
-    if (saved_xT && !(dbg & 1)) store_T(cur, saved_xT, p.in_pad);
+    if (saved_xT) store_T(cur, saved_xT, p.in_pad);
     typedef typename Vec4<T>::type V4;
     for (int l = 0; l < 4; ++l) {
         const int K = l == 0 ? p.in_pad : M16_W;
@@ -257,9 +313,8 @@ __device__ __forceinline__ void mlp16_fwd_body(Mlp16Dev p, float* __restrict__ o
                     acc[rt][nt][4 * g + 0] = bv.x; acc[rt][nt][4 * g + 1] = bv.y; acc[rt][nt][4 * g + 2] = bv.z; acc[rt][nt][4 * g + 3] = bv.w;
                 }
             }
-        if (!(dbg & 8)) gemm16<T, true, RT>(cur, (const T*)p.w[l], K, K, M16_W, wave, lane, acc);
+        gemm16<T, true, RT>(cur, (const T*)p.w[l], K, K, M16_W, wave, lane, acc);
         if (INPLACE) __syncthreads();       // every wave has read the layer's input before anyone overwrites it
-        if (!(dbg & 4))
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
             const int row = rt * 32 + j;
@@ -270,14 +325,13 @@ __device__ __forceinline__ void mlp16_fwd_body(Mlp16Dev p, float* __restrict__ o
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const int f0 = (2 * wave + nt) * 32 + 8 * g + 4 * half;
-                    V4 pk;
+                    float v[4];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        const float v = fmaxf(acc[rt][nt][4 * g + e], 0.f);
-                        pk[e] = (T)v;
-                        mbits |= (v > 0.f ? 1u : 0u) << (8 * g + 4 * half + e);
+                        v[e] = fmaxf(acc[rt][nt][4 * g + e], 0.f);
+                        mbits |= (v[e] > 0.f ? 1u : 0u) << (8 * g + 4 * half + e);
                     }
-                    *(V4*)&nxt[a16_idx(row, f0)] = pk;        // four consecutive features: one 8-byte store
+                    *(V4*)&nxt[a16_idx(row, f0)] = pack4(v[0], v[1], v[2], v[3], T());   // four consecutive features: one 8-byte store
                 }
                 if (masks) {   // sign bits of this (row, 32-feature tile): the two halves hold complementary bits
                     const uint32_t full = mbits | (uint32_t)__shfl_xor((int)mbits, 32);
@@ -286,7 +340,7 @@ __device__ __forceinline__ void mlp16_fwd_body(Mlp16Dev p, float* __restrict__ o
             }
         }
         __syncthreads();
-        if (saved_hT && !(dbg & 1)) store_T(nxt, saved_hT + (size_t)l * t16_elems(M16_W, p.rows), M16_W);
+        if (saved_hT) store_T(nxt, saved_hT + (size_t)l * t16_elems(M16_W, p.rows), M16_W);
         T* t = cur; cur = nxt; nxt = t;
     }
     {   // output layer: W4 padded to [32][256]; the 4 waves split K, reduce through LDS (fp32)
@@ -330,8 +384,8 @@ __global__ __launch_bounds__(M16_THREADS) void gp_mlp16_fwd_f16_kernel(Mlp16Dev 
 __global__ __launch_bounds__(M16_THREADS) void gp_mlp16_fwd_bf16_kernel(Mlp16Dev p, float* out, void* sx, void* sh, uint32_t* masks) {
     mlp16_fwd_body<__bf16, 2>(p, out, (__bf16*)sx, (__bf16*)sh, masks);
 }
-__global__ __launch_bounds__(M16_THREADS, 2) void gp_mlp16_fwd4_f16_kernel(Mlp16Dev p, float* out, void* sx, void* sh, uint32_t* masks, int dbg) {
-    mlp16_fwd_body<_Float16, 4>(p, out, (_Float16*)sx, (_Float16*)sh, masks, dbg);
+__global__ __launch_bounds__(M16_THREADS, 2) void gp_mlp16_fwd4_f16_kernel(Mlp16Dev p, float* out, void* sx, void* sh, uint32_t* masks) {
+    mlp16_fwd_body<_Float16, 4>(p, out, (_Float16*)sx, (_Float16*)sh, masks);
 }
 __global__ __launch_bounds__(M16_THREADS, 2) void gp_mlp16_fwd4_bf16_kernel(Mlp16Dev p, float* out, void* sx, void* sh, uint32_t* masks) {
     mlp16_fwd_body<__bf16, 4>(p, out, (__bf16*)sx, (__bf16*)sh, masks);
@@ -385,15 +439,16 @@ __device__ __forceinline__ void mlp16_bwd_data_body(Mlp16Dev p, const uint32_t* 
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const int f0 = (2 * wave + nt) * 32 + 8 * g + 4 * half;
-                    V4 pk;
+                    float v[4];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) pk[e] = (T)(((m >> (8 * g + 4 * half + e)) & 1u) ? acc[rt][nt][4 * g + e] : 0.f);
-                    *(V4*)&nxt[a16_idx(row, f0)] = pk;
+                    for (int e = 0; e < 4; ++e)     // sign-extended mask bit (v_bfe_i32) AND value bits: two instructions per value
+                        v[e] = __uint_as_float(__float_as_uint(acc[rt][nt][4 * g + e]) & (uint32_t)__builtin_amdgcn_sbfe((int)m, 8 * g + 4 * half + e, 1));
+                    *(V4*)&nxt[a16_idx(row, f0)] = pack4(v[0], v[1], v[2], v[3], T());
                 }
             }
         }
         __syncthreads();
-        {   // dZ_l^T -> global [256][rows]
+        {   // dZ_l^T -> global, blocked
             T* blk = dzT + (size_t)(l - 1) * t16_elems(M16_W, p.rows) + (size_t)blockIdx.x * M16_W * ROWS;
             store_tile_T<T, ROWS>(nxt, blk, M16_W, row0, p.rows, rows_pad, wave, lane);
         }
@@ -439,7 +494,7 @@ __device__ __forceinline__ void mlp16_bwd_data_body(Mlp16Dev p, const uint32_t* 
                 for (int fr = 0; fr < p.xyz_freq; ++fr) {
                     const float sc = (float)(1u << fr);
                     float sv, cv;
-                    sincosf(x * sc, &sv, &cv);
+                    fast_sincos(x * sc, &sv, &cv);      // the same hardware sin/cos the forward encoded with
                     const int f = p.feature_dim + 2 * (c * p.xyz_freq + fr);
                     g += sc * (cv * dX[r * 128 + f] - sv * dX[r * 128 + f + 1]);
                 }
@@ -735,7 +790,7 @@ extern "C" int gp_mlp16_forward(const gp_mlp16_params* p, const gp_mlp_input* x,
     GpProfScope _p("mlp16_fwd", s);
     if (m.rows >= GP_MLP16_BIG_ROWS) {        // 128 rows per workgroup
         const dim3 grid(gp_blocks((size_t)m.rows, 128));
-        if (p->dtype == GP_DTYPE_F16) hipLaunchKernelGGL(gp_mlp16_fwd4_f16_kernel, grid, dim3(M16_THREADS), 0, s, m, out, saved_xT, saved_hT, masks, getenv("GP_F4_DBG") ? atoi(getenv("GP_F4_DBG")) : 0);
+        if (p->dtype == GP_DTYPE_F16) hipLaunchKernelGGL(gp_mlp16_fwd4_f16_kernel, grid, dim3(M16_THREADS), 0, s, m, out, saved_xT, saved_hT, masks);
         else hipLaunchKernelGGL(gp_mlp16_fwd4_bf16_kernel, grid, dim3(M16_THREADS), 0, s, m, out, saved_xT, saved_hT, masks);
     } else {
         const dim3 grid(gp_blocks((size_t)m.rows, M16_ROWS));
@@ -781,14 +836,22 @@ extern "C" int gp_mlp16_backward(const gp_mlp16_params* p /* w16 = TRANSPOSED co
         GP_LAUNCH_CHECK();
     }
     long nrb_l = (m.rows + 4095) / 4096;       // 4096-row slabs: 2 x 256 x 4096 x 2 B = 4 MB per layer, shared by 16 workgroups
+    {   // small row counts: 256-row slabs keep the grid at a few hundred workgroups (two 4096-row slabs at 8k rows left
+        // 32 workgroups walking 256 k-steps each: latency-bound, 5x the forward's time)
+        long small = (m.rows + 255) / 256;
+        if (small > 128) small = 128;
+        if (nrb_l < small) nrb_l = small;
+    }
     if (nrb_l < 1) nrb_l = 1;
     const long rpb = ((m.rows + nrb_l - 1) / nrb_l + 63) & ~63L;
     const unsigned nrb = (unsigned)((m.rows + rpb - 1) / rpb);
     GpProfScope _pw("mlp16_bwd_weight", s);
-    const bool big = m.rows >= GP_MLP16_BIG_ROWS;
-    if (big) {       // layers 1..3 in one launch: grid = (row slabs, 3), slabs of >= 1024 rows, at most 256 per layer
+    const bool big = m.rows >= 4096;
+    if (big) {       // layers 1..3 in one launch: grid = (row slabs, 3), slabs of >= 256 rows, at most 256 per layer
         const long n_kb = (m.rows + 63) / 64 * (64 / T16_BLK);   // 16-row blocks incl. the zero padding to 64 rows
-        long nslab = n_kb / 64;
+        long nslab = n_kb / 64;                                  // 1024-row slabs (every slab ends in 64 k atomic adds) ...
+        const long few = n_kb / 16 < 32 ? n_kb / 16 : 32;        // ... but at least 32 slabs of >= 256 rows at small row counts
+        if (nslab < few) nslab = few;
         if (nslab > 256) nslab = 256;
         if (nslab < 1) nslab = 1;
         const long kbs = ((n_kb + nslab - 1) / nslab + W16_DEPTH - 1) / W16_DEPTH * W16_DEPTH;
