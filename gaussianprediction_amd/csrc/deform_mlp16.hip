@@ -640,112 +640,133 @@ __global__ __launch_bounds__(M16_THREADS) void gp_mlp16_bwd_weight_bf16_kernel(c
 // W16_DEPTH k-steps ahead (64 KB of unique data in flight per CU), pass them through a double-buffered 32 KB LDS stage,
 // and every wave reads the 6 fragments of its 128x64 block (4x2 MFMA tiles, 128 accumulator registers) back from LDS.
 // The barrier waits only for LDS (lgkmcnt); the global prefetches stay in flight across it.
-struct W16BigJob { float* dw[3]; float* db[3]; };
+// The same kernel, shaped by <OT, IT, WI> (32x32 tiles per wave along o and i, waves along i), covers all five layers:
+//   layers 1..3 (256 x 256):  <4, 2, 4>  one launch, blockIdx.y = layer
+//   layer 0     (256 x in_pad <= 128): <2, 2, 2>
+//   layer 4     (out_dim <= 16 x 256, dZ = the packed dL_dout): <1, 1, 8>
+// Fragments beyond a tensor's feature count are loaded from a clamped address and zeroed, so every wave issues exactly
+// two loads per k-step whatever the shape.
+struct W16Job { const void* z; const void* h; float* dw; float* db; };
+struct W16Jobs { W16Job j[3]; };
+struct W16Shape { int nf_z, nf_h, n_out, n_in, lddw; };
 #define W16_THREADS 512
 #define W16_DEPTH 4
 #define W16_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
+template <typename V8>
+__device__ __forceinline__ V8 w16_keep(V8 v, bool ok) {
+    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+    u4 b = __builtin_bit_cast(u4, v);
+    if (!ok) b = u4{0u, 0u, 0u, 0u};
+    return __builtin_bit_cast(V8, b);
+}
+
 // One group of W16_DEPTH k-steps: write the staged fragments of step k to LDS, re-issue the stage's two loads for step
 // k + W16_DEPTH (the tail re-loads its own step: every k-step issues exactly two loads, in a fixed order, so the
 // compiler's vmcnt before an LDS write leaves the 2 (W16_DEPTH - 1) younger loads in flight), barrier, MFMA from LDS.
-template <typename T, typename V8>
-__device__ __forceinline__ void w16_group(V8 (&gq)[W16_DEPTH][2], f32x16 (&acc)[4][2], float (&bsum)[4], T (*s_st)[2][8][512],
-                                          const T* gz, const T* gh, long k0, long nk, size_t kstride, int wave, int lane,
-                                          int wo, int wi, int frag_off) {
+template <typename T, typename V8, int OT, int IT, int WI>
+__device__ __forceinline__ void w16_group(V8 (&gq)[W16_DEPTH][2], f32x16 (&acc)[OT][IT], float (&bsum)[OT], T (*s_st)[2][8][512],
+                                          const T* gz, const T* gh, bool okz, bool okh, long k0, long nk, size_t kstride_z,
+                                          size_t kstride_h, int wave, int lane, int wo, int wi, int frag_off) {
 #pragma unroll
     for (int d = 0; d < W16_DEPTH; ++d) {
         const long k = k0 + d;
         const int buf = d & 1;                              // = k & 1 (W16_DEPTH is even)
-        *(V8*)&s_st[buf][0][wave][lane * 8] = gq[d][0];
-        *(V8*)&s_st[buf][1][wave][lane * 8] = gq[d][1];
+        *(V8*)&s_st[buf][0][wave][lane * 8] = w16_keep(gq[d][0], okz);
+        *(V8*)&s_st[buf][1][wave][lane * 8] = w16_keep(gq[d][1], okh);
         const long kn = k + W16_DEPTH < nk ? k + W16_DEPTH : k;
-        gq[d][0] = *(const V8*)(gz + kn * kstride);
-        gq[d][1] = *(const V8*)(gh + kn * kstride);
+        gq[d][0] = *(const V8*)(gz + kn * kstride_z);
+        gq[d][1] = *(const V8*)(gh + kn * kstride_h);
         W16_LDS_BARRIER();          // one barrier per k-step: a buffer is rewritten two steps later, behind the next barrier
-        V8 a[4], b[2];
+        V8 a[OT], b[IT];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) a[u] = *(const V8*)&s_st[buf][0][wo * 4 + u][frag_off];
+        for (int u = 0; u < OT; ++u) a[u] = *(const V8*)&s_st[buf][0][wo * OT + u][frag_off];
 #pragma unroll
-        for (int u = 0; u < 2; ++u) b[u] = *(const V8*)&s_st[buf][1][wi * 2 + u][frag_off];
+        for (int u = 0; u < IT; ++u) b[u] = *(const V8*)&s_st[buf][1][wi * IT + u][frag_off];
 #pragma unroll
-        for (int uo = 0; uo < 4; ++uo)
+        for (int uo = 0; uo < OT; ++uo)
 #pragma unroll
-            for (int ui = 0; ui < 2; ++ui) acc[uo][ui] = mfma16(a[uo], b[ui], acc[uo][ui]);
+            for (int ui = 0; ui < IT; ++ui) acc[uo][ui] = mfma16(a[uo], b[ui], acc[uo][ui]);
         if (wi == 0) {
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
+            for (int u = 0; u < OT; ++u)
 #pragma unroll
                 for (int e = 0; e < 8; ++e) bsum[u] += (float)a[u][e];
         }
     }
 }
 
-template <typename T>
-__device__ __forceinline__ void mlp16_bwd_weight_big_body(const T* __restrict__ dz, const T* __restrict__ hT, size_t layer_elems,
-                                                          long n_kb, long kb_per_slab, W16BigJob jobs,
+template <typename T, int OT, int IT, int WI>
+__device__ __forceinline__ void mlp16_bwd_weight_lds_body(W16Jobs jobs, W16Shape sh, long n_kb, long kb_per_slab,
                                                           const uint32_t* __restrict__ absmax_bits) {
     typedef typename Vec8<T>::type V8;
+    static_assert((8 / WI) * OT <= 8 && WI * IT <= 8, "eight fragment slots per operand");
     __shared__ T s_st[2][2][8][512];                           // [buffer][dZ | H][fragment of 32 features][16 rows x 32] = 32 KB
     const float inv_scale = UsesScale<T>::v ? 1.f / grad_scale_from(absmax_bits) : 1.f;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, j = lane & 31;
-    const int wo = wave >> 2, wi = wave & 3;                   // o block of 128, i block of 64
-    const int l = blockIdx.y;                                  // 0..2 -> layers 1..3: dZ_{l+1} x hidden_l
+    const int wo = wave / WI, wi = wave % WI;
+    const W16Job job = jobs.j[blockIdx.y];
     const long kb0 = (long)blockIdx.x * kb_per_slab;
     long kb1 = kb0 + kb_per_slab;
     if (kb1 > n_kb) kb1 = n_kb;
     const long nk = kb1 - kb0;
-    const size_t kstride = (size_t)M16_W * T16_BLK;             // elements per 16-row block (8 KB)
-    // this wave's share of a k-step: fragment `wave` of dZ and of H, lane-linear 16-byte chunks
-    const T* gz = dz + (size_t)(l + 1) * layer_elems + (size_t)kb0 * kstride + wave * 512 + lane * 8;
-    const T* gh = hT + (size_t)l * layer_elems + (size_t)kb0 * kstride + wave * 512 + lane * 8;
+    const size_t kstride_z = (size_t)sh.nf_z * T16_BLK, kstride_h = (size_t)sh.nf_h * T16_BLK;   // elements per 16-row block
+    // this wave's share of a k-step: fragment `wave` of dZ and of H in lane-linear 16-byte chunks (chunk = feature, 8 rows)
+    const int nfr_z = (sh.nf_z + 31) / 32, nfr_h = (sh.nf_h + 31) / 32;
+    const int fz = wave < nfr_z ? wave : nfr_z - 1, fh = wave < nfr_h ? wave : nfr_h - 1;
+    const bool okz = wave < nfr_z && fz * 32 + (lane >> 1) < sh.nf_z, okh = wave < nfr_h && fh * 32 + (lane >> 1) < sh.nf_h;
+    const T* gz = (const T*)job.z + (size_t)kb0 * kstride_z + fz * 512 + (okz ? lane * 8 : 0);
+    const T* gh = (const T*)job.h + (size_t)kb0 * kstride_h + fh * 512 + (okh ? lane * 8 : 0);
     const int frag_off = (2 * j + half) * 8;                    // (feature j, rows 8 half ..) inside a fragment
-    f32x16 acc[4][2];
+    f32x16 acc[OT][IT];
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+    for (int a = 0; a < OT; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+        for (int b = 0; b < IT; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-    float bsum[4] = {0.f, 0.f, 0.f, 0.f};
+    float bsum[OT];
+#pragma unroll
+    for (int a = 0; a < OT; ++a) bsum[a] = 0.f;
     // nk is a multiple of W16_DEPTH (the host rounds slabs to 64 rows; the tensors are zero-padded to 64 rows).  The first
     // group is peeled so that the loop header sees the same load order from both of its predecessors.
     V8 gq[W16_DEPTH][2];
 #pragma unroll
-    for (int d = 0; d < W16_DEPTH; ++d) { gq[d][0] = *(const V8*)(gz + d * kstride); gq[d][1] = *(const V8*)(gh + d * kstride); }
-    if (nk > 0) w16_group<T, V8>(gq, acc, bsum, s_st, gz, gh, 0, nk, kstride, wave, lane, wo, wi, frag_off);
+    for (int d = 0; d < W16_DEPTH; ++d) { gq[d][0] = *(const V8*)(gz + d * kstride_z); gq[d][1] = *(const V8*)(gh + d * kstride_h); }
+    if (nk > 0) w16_group<T, V8, OT, IT, WI>(gq, acc, bsum, s_st, gz, gh, okz, okh, 0, nk, kstride_z, kstride_h, wave, lane, wo, wi, frag_off);
     for (long k0 = W16_DEPTH; k0 < nk; k0 += W16_DEPTH)
-        w16_group<T, V8>(gq, acc, bsum, s_st, gz, gh, k0, nk, kstride, wave, lane, wo, wi, frag_off);
+        w16_group<T, V8, OT, IT, WI>(gq, acc, bsum, s_st, gz, gh, okz, okh, k0, nk, kstride_z, kstride_h, wave, lane, wo, wi, frag_off);
     const bool single = gridDim.x == 1;
-    float* dbase = jobs.dw[l] + (size_t)(wo * 128 + 4 * half) * M16_W + wi * 64 + j;
 #pragma unroll
-    for (int uo = 0; uo < 4; ++uo)
+    for (int uo = 0; uo < OT; ++uo)
 #pragma unroll
-        for (int ui = 0; ui < 2; ++ui) {
+        for (int ui = 0; ui < IT; ++ui) {
             __builtin_amdgcn_sched_barrier(0);      // one tile at a time
+            const int i = (wi * IT + ui) * 32 + j;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float v = acc[uo][ui][r] * inv_scale;
-                float* dst = dbase + (size_t)(uo * 32 + (r & 3) + 8 * (r >> 2)) * M16_W + ui * 32;
-                if (single) *dst += v; else atomicAdd(dst, v);
+                const int o = (wo * OT + uo) * 32 + cd_row16(r, half);
+                if (o < sh.n_out && i < sh.n_in) {
+                    const float v = acc[uo][ui][r] * inv_scale;
+                    float* dst = job.dw + (size_t)o * sh.lddw + i;
+                    if (single) *dst += v; else atomicAdd(dst, v);
+                }
             }
         }
     __builtin_amdgcn_sched_barrier(0);
     if (wi == 0) {
-        float* db = jobs.db[l];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < OT; ++u) {
             const float v = (bsum[u] + __shfl_xor(bsum[u], 32)) * inv_scale;
-            if (half == 0) { float* dst = &db[wo * 128 + u * 32 + j]; if (single) *dst += v; else atomicAdd(dst, v); }
+            const int o = (wo * OT + u) * 32 + j;
+            if (half == 0 && o < sh.n_out) { float* dst = &job.db[o]; if (single) *dst += v; else atomicAdd(dst, v); }
         }
     }
 }
-__global__ __launch_bounds__(W16_THREADS) void gp_mlp16_bwd_weight_big_f16_kernel(const void* dz, const void* hT, size_t layer_elems, long n_kb,
-                                                                                   long kb_per_slab, W16BigJob jobs, const uint32_t* absmax_bits) {
-    mlp16_bwd_weight_big_body<_Float16>((const _Float16*)dz, (const _Float16*)hT, layer_elems, n_kb, kb_per_slab, jobs, absmax_bits);
-}
-__global__ __launch_bounds__(W16_THREADS) void gp_mlp16_bwd_weight_big_bf16_kernel(const void* dz, const void* hT, size_t layer_elems, long n_kb,
-                                                                                    long kb_per_slab, W16BigJob jobs, const uint32_t* absmax_bits) {
-    mlp16_bwd_weight_big_body<__bf16>((const __bf16*)dz, (const __bf16*)hT, layer_elems, n_kb, kb_per_slab, jobs, absmax_bits);
+template <typename T, int OT, int IT, int WI>
+__global__ __launch_bounds__(W16_THREADS) void gp_mlp16_bwd_weight_lds_kernel(W16Jobs jobs, W16Shape sh, long n_kb, long kb_per_slab,
+                                                                             const uint32_t* absmax_bits) {
+    mlp16_bwd_weight_lds_body<T, OT, IT, WI>(jobs, sh, n_kb, kb_per_slab, absmax_bits);
 }
 
 // dL_dout^T in 16 bits, scaled: [16][rows] (rows >= out_dim zero) -- A operand of the last layer's weight gradient
@@ -753,10 +774,10 @@ template <typename T>
 __global__ __launch_bounds__(256) void gp_mlp16_pack_dout_kernel(const float* __restrict__ dL_dout, int out_dim, long rows,
                                                                 T* __restrict__ dst, const uint32_t* __restrict__ absmax_bits) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= rows) return;
+    if (i >= ((rows + 63) & ~63L)) return;                      // the padding rows (to 64) are written as zeros
     const float scale = UsesScale<T>::v ? grad_scale_from(absmax_bits) : 1.f;
 #pragma unroll
-    for (int f = 0; f < 16; ++f) dst[t16_idx(f, i, 16)] = (T)(f < out_dim ? dL_dout[i * out_dim + f] * scale : 0.f);
+    for (int f = 0; f < 16; ++f) dst[t16_idx(f, i, 16)] = (T)((f < out_dim && i < rows) ? dL_dout[i * out_dim + f] * scale : 0.f);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -828,10 +849,10 @@ extern "C" int gp_mlp16_backward(const gp_mlp16_params* p /* w16 = TRANSPOSED co
         const dim3 grid(gp_blocks((size_t)m.rows, big_rows ? 128 : M16_ROWS));
         if (f16) {
             hipLaunchKernelGGL(big_rows ? gp_mlp16_bwd_data4_f16_kernel : gp_mlp16_bwd_data_f16_kernel, grid, dim3(M16_THREADS), 0, s, m, masks, dL_dout, (void*)dz, dL_dfeature, dL_dxyz, absmax);
-            hipLaunchKernelGGL((gp_mlp16_pack_dout_kernel<_Float16>), dim3(gp_blocks((size_t)m.rows, 256)), dim3(256), 0, s, dL_dout, m.out_dim, m.rows, (_Float16*)dout16, absmax);
+            hipLaunchKernelGGL((gp_mlp16_pack_dout_kernel<_Float16>), dim3(gp_blocks((size_t)((m.rows + 63) & ~63L), 256)), dim3(256), 0, s, dL_dout, m.out_dim, m.rows, (_Float16*)dout16, absmax);
         } else {
             hipLaunchKernelGGL(big_rows ? gp_mlp16_bwd_data4_bf16_kernel : gp_mlp16_bwd_data_bf16_kernel, grid, dim3(M16_THREADS), 0, s, m, masks, dL_dout, (void*)dz, dL_dfeature, dL_dxyz, absmax);
-            hipLaunchKernelGGL((gp_mlp16_pack_dout_kernel<__bf16>), dim3(gp_blocks((size_t)m.rows, 256)), dim3(256), 0, s, dL_dout, m.out_dim, m.rows, (__bf16*)dout16, absmax);
+            hipLaunchKernelGGL((gp_mlp16_pack_dout_kernel<__bf16>), dim3(gp_blocks((size_t)((m.rows + 63) & ~63L), 256)), dim3(256), 0, s, dL_dout, m.out_dim, m.rows, (__bf16*)dout16, absmax);
         }
         GP_LAUNCH_CHECK();
     }
@@ -846,8 +867,7 @@ extern "C" int gp_mlp16_backward(const gp_mlp16_params* p /* w16 = TRANSPOSED co
     const long rpb = ((m.rows + nrb_l - 1) / nrb_l + 63) & ~63L;
     const unsigned nrb = (unsigned)((m.rows + rpb - 1) / rpb);
     GpProfScope _pw("mlp16_bwd_weight", s);
-    const bool big = m.rows >= 4096;
-    if (big) {       // layers 1..3 in one launch: grid = (row slabs, 3), slabs of >= 256 rows, at most 256 per layer
+    if (m.rows >= 4096) {       // LDS-staged kernel: grid = (row slabs, jobs), three launches cover the five layers
         const long n_kb = (m.rows + 63) / 64 * (64 / T16_BLK);   // 16-row blocks incl. the zero padding to 64 rows
         long nslab = n_kb / 64;                                  // 1024-row slabs (every slab ends in 64 k atomic adds) ...
         const long few = n_kb / 16 < 32 ? n_kb / 16 : 32;        // ... but at least 32 slabs of >= 256 rows at small row counts
@@ -856,15 +876,26 @@ extern "C" int gp_mlp16_backward(const gp_mlp16_params* p /* w16 = TRANSPOSED co
         if (nslab < 1) nslab = 1;
         const long kbs = ((n_kb + nslab - 1) / nslab + W16_DEPTH - 1) / W16_DEPTH * W16_DEPTH;
         const unsigned gx = (unsigned)((n_kb + kbs - 1) / kbs);
-        GpProfScope _pb("mlp16_bwd_weight_big", s);
-        W16BigJob jobs;
-        for (int l = 0; l < 3; ++l) { jobs.dw[l] = g->dw[l + 1]; jobs.db[l] = g->db[l + 1]; }
-        if (f16) hipLaunchKernelGGL(gp_mlp16_bwd_weight_big_f16_kernel, dim3(gx, 3), dim3(W16_THREADS), 0, s, (const void*)dz, saved_hT, t16_elems(256, m.rows), n_kb, kbs, jobs, absmax);
-        else hipLaunchKernelGGL(gp_mlp16_bwd_weight_big_bf16_kernel, dim3(gx, 3), dim3(W16_THREADS), 0, s, (const void*)dz, saved_hT, t16_elems(256, m.rows), n_kb, kbs, jobs, absmax);
+        const size_t le = t16_elems(256, m.rows) * 2;            // bytes per 256-feature layer tensor
+        W16Jobs mid, first, last;
+        for (int l = 1; l <= 3; ++l) mid.j[l - 1] = W16Job{dz + (size_t)l * le, (const char*)saved_hT + (size_t)(l - 1) * le, g->dw[l], g->db[l]};
+        first.j[0] = W16Job{dz, saved_xT, g->dw[0], g->db[0]};
+        last.j[0] = W16Job{dout16, (const char*)saved_hT + (size_t)3 * le, g->dw[4], g->db[4]};
+        first.j[1] = first.j[2] = first.j[0]; last.j[1] = last.j[2] = last.j[0];
+        const W16Shape sh_mid{256, 256, 256, 256, 256}, sh_first{256, m.in_pad, 256, m.in_dim, m.in_dim}, sh_last{16, 256, m.out_dim, 256, 256};
+        if (f16) {
+            hipLaunchKernelGGL((gp_mlp16_bwd_weight_lds_kernel<_Float16, 4, 2, 4>), dim3(gx, 3), dim3(W16_THREADS), 0, s, mid, sh_mid, n_kb, kbs, absmax);
+            hipLaunchKernelGGL((gp_mlp16_bwd_weight_lds_kernel<_Float16, 2, 2, 2>), dim3(gx, 1), dim3(W16_THREADS), 0, s, first, sh_first, n_kb, kbs, absmax);
+            hipLaunchKernelGGL((gp_mlp16_bwd_weight_lds_kernel<_Float16, 1, 1, 8>), dim3(gx, 1), dim3(W16_THREADS), 0, s, last, sh_last, n_kb, kbs, absmax);
+        } else {
+            hipLaunchKernelGGL((gp_mlp16_bwd_weight_lds_kernel<__bf16, 4, 2, 4>), dim3(gx, 3), dim3(W16_THREADS), 0, s, mid, sh_mid, n_kb, kbs, absmax);
+            hipLaunchKernelGGL((gp_mlp16_bwd_weight_lds_kernel<__bf16, 2, 2, 2>), dim3(gx, 1), dim3(W16_THREADS), 0, s, first, sh_first, n_kb, kbs, absmax);
+            hipLaunchKernelGGL((gp_mlp16_bwd_weight_lds_kernel<__bf16, 1, 1, 8>), dim3(gx, 1), dim3(W16_THREADS), 0, s, last, sh_last, n_kb, kbs, absmax);
+        }
         GP_LAUNCH_CHECK();
+        return 0;
     }
     for (int l = 0; l < 5; ++l) {
-        if (big && l >= 1 && l <= 3) continue;
         const void* dZl = l < 4 ? (const void*)(dz + (size_t)l * t16_elems(256, m.rows) * 2) : (const void*)dout16;
         const int nf_z = l < 4 ? 256 : 16, nf_h = l == 0 ? m.in_pad : 256;
         const int n_out = l < 4 ? 256 : m.out_dim;
