@@ -405,6 +405,26 @@ __global__ __launch_bounds__(WM_THREADS) void gp_wm_fwd_kernel(HashGridDev g, lo
     }
 }
 
+// One block's inputs of the backward kernel into registers: 64 points x 64 saved features (float4 per thread x 4) and
+// the upstream gradient rows (gathered through the Morton permutation), issued a whole block ahead of their use.
+__device__ __forceinline__ void wm_bwd_fetch(float4 (&px)[4], float (&pd)[8], long b, long nblocks, long n, const int32_t* __restrict__ perm,
+                                             int n_out, const float* __restrict__ saved_feat, const float* __restrict__ dL_dout, int tid) {
+    if (b >= nblocks) return;
+    const long slot0 = b * 64;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int e4 = tid + WM_THREADS * u, p = e4 >> 4, f = 4 * (e4 & 15);
+        px[u] = slot0 + p < n ? *(const float4*)(saved_feat + (slot0 + p) * 64 + f) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int e = tid + WM_THREADS * u, p = e >> 5, f = e & 31;
+        float v = 0.f;
+        if (f < n_out && slot0 + p < n) v = dL_dout[(perm ? (long)perm[slot0 + p] : slot0 + p) * n_out + f];
+        pd[u] = v;
+    }
+}
+
 __global__ __launch_bounds__(WM_THREADS) void gp_wm_bwd_kernel(long n, const int32_t* __restrict__ perm,
                                                               const float* __restrict__ params, int n_out,
                                                               const float* __restrict__ saved_feat, const float* __restrict__ dL_dout,
@@ -429,19 +449,23 @@ __global__ __launch_bounds__(WM_THREADS) void gp_wm_bwd_kernel(long n, const int
 #pragma unroll
     for (int r = 0; r < 16; ++r) { g1[r] = 0.f; g2[r] = 0.f; g3[r] = 0.f; }
     const long nblocks = (n + 63) / 64;
+    float4 px[4];
+    float pd[8];
+    wm_bwd_fetch(px, pd, blockIdx.x, nblocks, n, perm, n_out, saved_feat, dL_dout, tid);
     for (long b = blockIdx.x; b < nblocks; b += gridDim.x) {
         const long slot0 = b * 64;
         __syncthreads();
-        for (int e = tid; e < 64 * 64; e += WM_THREADS) {            // X^T
-            const int p = e >> 6, f = e & 63;
-            sA[wm_ti(f, p)] = slot0 + p < n ? saved_feat[(slot0 + p) * 64 + f] : 0.f;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {                                // X^T (prefetched one block ahead)
+            const int e4 = tid + WM_THREADS * u, p = e4 >> 4, f = 4 * (e4 & 15);
+            sA[wm_ti(f + 0, p)] = px[u].x; sA[wm_ti(f + 1, p)] = px[u].y; sA[wm_ti(f + 2, p)] = px[u].z; sA[wm_ti(f + 3, p)] = px[u].w;
         }
-        for (int e = tid; e < 32 * 64; e += WM_THREADS) {            // dZ3^T, rows >= n_out zero
-            const int p = e >> 5, f = e & 31;
-            float v = 0.f;
-            if (f < n_out && slot0 + p < n) v = dL_dout[(perm ? (long)perm[slot0 + p] : slot0 + p) * n_out + f];
-            sD[wm_ti(f, p)] = v;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {                                // dZ3^T, rows >= n_out zero
+            const int e = tid + WM_THREADS * u;
+            sD[wm_ti(e & 31, e >> 5)] = pd[u];
         }
+        wm_bwd_fetch(px, pd, b + gridDim.x, nblocks, n, perm, n_out, saved_feat, dL_dout, tid);   // in flight during this block's 7 GEMM phases
         __syncthreads();
         wf32x16 acc = wm_layer(w1, sA, tj, lane);                    // H1^T -> sB
 #pragma unroll

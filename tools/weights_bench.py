@@ -39,6 +39,7 @@ torch.cuda.synchronize()
 for k, (n_, ms) in sorted(_lib.profile_collect().items()):
     print(f"  {k:16s} {ms / n_:8.3f} ms")
 
+if os.environ.get('GP_WB_SHORT'): sys.exit(0)
 # ---- full stage-3 train step with the model computing its own weights + kNN per frame (what the reference's step does)
 import bench
 from types import SimpleNamespace
