@@ -232,6 +232,15 @@ def main():
                     roof["traffic"] = json.load(open(tf)).get("hbm_bytes_per_launch")
                 except Exception:
                     pass
+        # the other HBM-bound kernels of the step against the same roofline (algorithmic bytes: SURVEY.md 8d / DESIGN.md 4;
+        # durations from the untimed per-kernel pass), reported beside the contract's `roofline` object
+        others = {}
+        n_par = int(ts.bucket.flat.numel())
+        alg = {"composite_bwd": 44 * R + 8 * T + 24 * P + 40 * n_vis, "preprocess_fwd": 312 * args.gaussians, "adam": 28 * n_par}
+        for k, nbytes in alg.items():
+            if k in kern and kern[k]["ms_per_step"] > 0:
+                gbs = nbytes / (kern[k]["ms_per_step"] * 1e-3) / 1e9
+                others[k] = {"algorithmic_bytes": nbytes, "achieved": round(gbs, 1), "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4)}
         result = {
             "metric": f"rendered views/s ({'eval render' if args.render_only else 'full train step'}) "
                       f"@{args.gaussians / 1e6:g}M Gaussians {args.width}x{args.height}",
@@ -246,6 +255,7 @@ def main():
                        "tiles": T, "pixels": P, "R": R, "R_before_timed_region": R0, "R_per_gaussian": round(R / max(args.gaussians, 1), 3),
                        "visible": n_vis, "parallelism": f"view-parallel x{world}"},
             "roofline": roof,
+            "roofline_other_kernels": others,
             "eval_render_views_per_s_per_gpu": None if eval_fps is None else round(eval_fps, 2),
             "kernels_ms": kern,
         }
