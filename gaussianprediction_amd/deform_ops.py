@@ -49,7 +49,7 @@ class FusedMlp(torch.autograd.Function):
             params.b[l] = bs[l].data_ptr()
         inp = _lib.MlpInputC(rows, fd, int(xyz_freq), int(time_freq), feature_c.data_ptr(),
                              xyz_c.data_ptr() if xyz_c is not None else None, t_c.data_ptr() if t_c is not None else None)
-        with torch.cuda.device(dev):
+        with _lib.on_device(dev):
             rc = _lib.lib().gp_mlp_forward(C.byref(params), C.byref(inp), _lib.ptr(out), _lib.ptr(acts), _lib.stream_ptr(dev))
             _lib.check(rc, "gp_mlp_forward")
         if need_grad:
@@ -92,7 +92,7 @@ class FusedMlp(torch.autograd.Function):
         g_feat = torch.empty(rows, fd, device=dev) if need_f else None
         g_xyz = torch.empty(rows, 3, device=dev) if (need_x and has_xyz and xyz_freq > 0) else None
         alloc = _lib.TorchAllocator(dev)
-        with torch.cuda.device(dev):
+        with _lib.on_device(dev):
             rc = _lib.lib().gp_mlp_backward(C.byref(params), C.byref(inp), _lib.ptr(acts), _lib.ptr(g), C.byref(grads),
                                             _lib.ptr(g_feat), _lib.ptr(g_xyz), alloc.cb, None, _lib.stream_ptr(dev))
             if alloc.error is not None:
@@ -144,7 +144,7 @@ class FusedMlp16(torch.autograd.Function):
             params.b[l] = bs[l].data_ptr()
         inp = _lib.MlpInputC(rows, fd, int(xyz_freq), int(time_freq), feature_c.data_ptr(),
                              xyz_c.data_ptr() if xyz_c is not None else None, t_c.data_ptr() if t_c is not None else None)
-        with torch.cuda.device(dev):
+        with _lib.on_device(dev):
             rc = _lib.lib().gp_mlp16_forward(C.byref(params), C.byref(inp), _lib.ptr(out), _lib.ptr(xT), _lib.ptr(hT), _lib.ptr(masks),
                                              _lib.stream_ptr(dev))
             _lib.check(rc, "gp_mlp16_forward")
@@ -192,7 +192,7 @@ class FusedMlp16(torch.autograd.Function):
         g_feat = torch.empty(rows, fd, device=dev) if need_f else None
         g_xyz = torch.empty(rows, 3, device=dev) if (need_x and has_xyz and xyz_freq > 0) else None
         alloc = _lib.TorchAllocator(dev)
-        with torch.cuda.device(dev):
+        with _lib.on_device(dev):
             rc = _lib.lib().gp_mlp16_backward(C.byref(params), C.byref(inp), _lib.ptr(xT), _lib.ptr(hT), _lib.ptr(masks), _lib.ptr(g),
                                               C.byref(grads), _lib.ptr(g_feat), _lib.ptr(g_xyz), alloc.cb, None, _lib.stream_ptr(dev))
             if alloc.error is not None:
@@ -242,7 +242,7 @@ class KeypointBlend(torch.autograd.Function):
                                idx_c.data_ptr() if idx_c is not None else None, xyz_c.data_ptr(), rot_c.data_ptr())
         xyz_t = torch.empty(N, 3, device=dev)
         q_t = torch.empty(N, 4, device=dev)
-        with torch.cuda.device(dev):
+        with _lib.on_device(dev):
             rc = _lib.lib().gp_blend_forward(C.byref(args), _lib.ptr(xyz_t), _lib.ptr(q_t), _lib.stream_ptr(dev))
             _lib.check(rc, "gp_blend_forward")
         e = torch.empty(0, device=dev)
@@ -270,7 +270,7 @@ class KeypointBlend(torch.autograd.Function):
         g_xyz = sinks[0] if sinks[0] is not None else torch.empty(N, 3, device=dev)
         g_rot = sinks[1] if sinks[1] is not None else torch.empty(N, 4, device=dev)
         alloc = _lib.TorchAllocator(dev)
-        with torch.cuda.device(dev):
+        with _lib.on_device(dev):
             rc = _lib.lib().gp_blend_backward(C.byref(args), _lib.ptr(gx), _lib.ptr(gq), _lib.ptr(g_delta), _lib.ptr(g_raw),
                                               _lib.ptr(g_xyz), _lib.ptr(g_rot), alloc.cb, None, _lib.stream_ptr(dev))
             if alloc.error is not None:
@@ -299,7 +299,7 @@ class Activations(torch.autograd.Function):
         scale = torch.empty(N, 3, device=dev)
         opacity = torch.empty(N, 1, device=dev)
         dptr = C.c_void_p(d_c.data_ptr() + 4 * int(col)) if d_c is not None else None
-        with torch.cuda.device(dev):
+        with _lib.on_device(dev):
             rc = _lib.lib().gp_activations_forward(C.c_int64(N), _lib.ptr(s_c), _lib.ptr(o_c), dptr, C.c_int32(stride),
                                                    C.c_float(float(beta)), _lib.ptr(scale), _lib.ptr(opacity),
                                                    _lib.stream_ptr(dev))
@@ -324,7 +324,7 @@ class Activations(torch.autograd.Function):
         stride = d_c.shape[1] if has_d else 0
         dptr = C.c_void_p(d_c.data_ptr() + 4 * col) if has_d else None
         gdptr = C.c_void_p(g_delta.data_ptr() + 4 * col) if has_d else None
-        with torch.cuda.device(dev):
+        with _lib.on_device(dev):
             rc = _lib.lib().gp_activations_backward(C.c_int64(N), _lib.ptr(s_c), _lib.ptr(o_c), dptr, C.c_int32(stride),
                                                     C.c_float(beta), _lib.ptr(gs), _lib.ptr(go), _lib.ptr(g_sraw),
                                                     _lib.ptr(g_oraw), gdptr, _lib.stream_ptr(dev))

@@ -27,13 +27,13 @@ class L1SSIMLoss(torch.autograd.Function):
         sums = torch.empty(2 * _lib.GP_LOSS_SUM_SLOTS, dtype=torch.float64, device=dev)
         need = image.requires_grad
         dmaps = torch.empty(3, 3, H, W, device=dev) if need else None
-        with torch.cuda.device(dev):
+        with _lib.on_device(dev):
             rc = _lib.lib().gp_loss_l1_ssim_forward(_lib.ptr(img), _lib.ptr(g), C.c_int32(3), C.c_int32(H), C.c_int32(W),
                                                     _lib.ptr(sums), _lib.ptr(dmaps), _lib.stream_ptr(dev))
             _lib.check(rc, "gp_loss_l1_ssim_forward")
         lam = float(lambda_dssim)
         loss_t = torch.empty(1, dtype=torch.float32, device=dev)
-        with torch.cuda.device(dev):
+        with _lib.on_device(dev):
             rc = _lib.lib().gp_loss_l1_ssim_finalize(_lib.ptr(sums), C.c_int32(3), C.c_int32(H), C.c_int32(W), C.c_float(lam),
                                                      _lib.ptr(loss_t), _lib.stream_ptr(dev))
             _lib.check(rc, "gp_loss_l1_ssim_finalize")
@@ -50,7 +50,7 @@ class L1SSIMLoss(torch.autograd.Function):
         _, H, W = img.shape
         up = grad_out.detach().to(torch.float32).reshape(1).contiguous()
         dimg = torch.empty_like(img)
-        with torch.cuda.device(dev):
+        with _lib.on_device(dev):
             rc = _lib.lib().gp_loss_l1_ssim_backward(_lib.ptr(img), _lib.ptr(g), _lib.ptr(dmaps), C.c_int32(3), C.c_int32(H),
                                                      C.c_int32(W), C.c_float(ctx.lam), _lib.ptr(up), _lib.ptr(dimg),
                                                      _lib.stream_ptr(dev))
@@ -69,7 +69,7 @@ class _AddL1Mean(torch.autograd.Function):
         xc = x.detach().to(torch.float32).contiguous()
         base = loss.detach().to(torch.float32).reshape(1).contiguous()
         out = torch.empty(1, device=xc.device)
-        with torch.cuda.device(xc.device):
+        with _lib.on_device(xc.device):
             _lib.check(_lib.lib().gp_l1_mean_forward(_lib.ptr(xc), C.c_int64(xc.numel()), C.c_float(scale), _lib.ptr(base),
                                                      _lib.ptr(out), _lib.stream_ptr(xc.device)), "gp_l1_mean_forward")
         ctx.save_for_backward(xc)
@@ -81,7 +81,7 @@ class _AddL1Mean(torch.autograd.Function):
         (xc,) = ctx.saved_tensors
         up = g.detach().to(torch.float32).reshape(1).contiguous()
         gx = torch.empty_like(xc)
-        with torch.cuda.device(xc.device):
+        with _lib.on_device(xc.device):
             _lib.check(_lib.lib().gp_l1_mean_backward(_lib.ptr(xc), C.c_int64(xc.numel()), C.c_float(ctx.scale), _lib.ptr(up),
                                                       _lib.ptr(gx), _lib.stream_ptr(xc.device)), "gp_l1_mean_backward")
         return g, gx.reshape(ctx.shape), None
@@ -136,7 +136,7 @@ class FusedAdam:
                     mask |= 1 << k
         b1, b2 = self.betas
         dev = self.bucket.flat.device
-        with torch.cuda.device(dev):
+        with _lib.on_device(dev):
             rc = _lib.lib().gp_adam_step_multi(C.c_int32(n), P, G, M, V, NUM, LR, C.c_float(b1), C.c_float(b2), C.c_float(self.eps),
                                                C.c_int64(self.step_count), C.c_int32(1 if zero_grad else 0), C.c_uint32(mask), _lib.stream_ptr(dev))
             _lib.check(rc, "gp_adam_step_multi")

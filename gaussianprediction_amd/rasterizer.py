@@ -82,7 +82,7 @@ class _RasterizeGaussians(torch.autograd.Function):
             sh_coeffs += int(shs_r.shape[1])
         rs = raster_settings
         H, W = int(rs.image_height), int(rs.image_width)
-        with torch.cuda.device(device):
+        with _lib.on_device(device):
             st, keep = _settings_c(rs, device, sh_coeffs)
             inp = _lib.RasterInputsC(N, _lib.ptr(m3), _lib.ptr(shs), _lib.ptr(shs_r), _lib.ptr(cols), _lib.ptr(ops),
                                      _lib.ptr(scl), _lib.ptr(rot), _lib.ptr(cov))
@@ -127,7 +127,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         L = _lib.lib()
         gc = grad_color.to(torch.float32).contiguous() if grad_color is not None else torch.zeros_like(color)
         gd = grad_depth.to(torch.float32).contiguous() if grad_depth is not None else None
-        with torch.cuda.device(device):
+        with _lib.on_device(device):
             st, keep = _settings_c(rs, device, ctx.sh_coeffs)
             inp = _lib.RasterInputsC(N, _lib.ptr(m3), _lib.ptr(shs) if has_sh else None, _lib.ptr(shs_r) if has_rest else None,
                                      _lib.ptr(cols) if has_col else None,
@@ -206,7 +206,7 @@ class GaussianRasterizer(nn.Module):
             p = positions.detach().to(torch.float32).contiguous()
             vm = self.raster_settings.viewmatrix.detach().to(torch.float32).contiguous()
             present = torch.empty(p.shape[0], dtype=torch.uint8, device=p.device)
-            with torch.cuda.device(p.device):
+            with _lib.on_device(p.device):
                 rc = _lib.lib().gp_raster_mark_visible(C.c_int64(p.shape[0]), _lib.ptr(p), _lib.ptr(vm), _lib.ptr(present),
                                                       _lib.stream_ptr(p.device))
                 _lib.check(rc, "gp_raster_mark_visible")
@@ -243,7 +243,7 @@ def raster_forward_debug(raster_settings, means3D, opacities, shs=None, colors_p
     scl, rot, cov = _f32c(scales, device), _f32c(rotations, device), _f32c(cov3D_precomp, device)
     sh_coeffs = int(shs_c.shape[1]) if shs_c is not None else 0
     H, W = int(rs.image_height), int(rs.image_width)
-    with torch.cuda.device(device):
+    with _lib.on_device(device):
         st, keep = _settings_c(rs, device, sh_coeffs)
         inp = _lib.RasterInputsC(N, _lib.ptr(m3), _lib.ptr(shs_c), None, _lib.ptr(cols), _lib.ptr(ops), _lib.ptr(scl),
                                  _lib.ptr(rot), _lib.ptr(cov))

@@ -56,7 +56,7 @@ class _HashGridEncode(torch.autograd.Function):
         t = table.detach().contiguous()
         n = x.shape[0]
         out = torch.empty(n, cfg.n_levels * 4, device=x.device)
-        with torch.cuda.device(x.device):
+        with _lib.on_device(x.device):
             _lib.check(_lib.lib().gp_hashgrid_forward(C.byref(cfg), C.c_int64(n), _lib.ptr(x), _lib.ptr(perm), _lib.ptr(t),
                                                       _lib.ptr(out), _lib.stream_ptr(x.device)), "gp_hashgrid_forward")
         ctx.save_for_backward(x)
@@ -69,7 +69,7 @@ class _HashGridEncode(torch.autograd.Function):
         (x,) = ctx.saved_tensors
         g = g.to(torch.float32).contiguous()
         dtable = torch.zeros(ctx.table_shape, device=x.device)
-        with torch.cuda.device(x.device):
+        with _lib.on_device(x.device):
             _lib.check(_lib.lib().gp_hashgrid_backward(C.byref(ctx.cfg), C.c_int64(x.shape[0]), _lib.ptr(x), _lib.ptr(ctx.perm),
                                                        _lib.ptr(g), _lib.ptr(dtable), _lib.stream_ptr(x.device)),
                        "gp_hashgrid_backward")
@@ -88,7 +88,7 @@ class _WeightsModelFused(torch.autograd.Function):
         need = params.requires_grad
         out = torch.empty(n, n_out, device=x.device)
         feat = torch.empty(n, 64, device=x.device) if need else None
-        with torch.cuda.device(x.device):
+        with _lib.on_device(x.device):
             _lib.check(_lib.lib().gp_weights_forward(C.byref(cfg), C.c_int64(n), _lib.ptr(x), _lib.ptr(perm), _lib.ptr(p),
                                                      C.c_int32(n_out), _lib.ptr(out), _lib.ptr(feat), _lib.stream_ptr(x.device)),
                        "gp_weights_forward")
@@ -107,7 +107,7 @@ class _WeightsModelFused(torch.autograd.Function):
             sink.zero_()
         dparams = sink if sink is not None else torch.zeros_like(p)
         alloc = _lib.TorchAllocator(x.device)
-        with torch.cuda.device(x.device):
+        with _lib.on_device(x.device):
             rc = _lib.lib().gp_weights_backward(C.byref(ctx.cfg), C.c_int64(x.shape[0]), _lib.ptr(x), _lib.ptr(ctx.perm), _lib.ptr(p),
                                                 C.c_int32(ctx.n_out), _lib.ptr(feat), _lib.ptr(g), _lib.ptr(dparams), alloc.cb, None,
                                                 _lib.stream_ptr(x.device))
@@ -191,7 +191,7 @@ def knn_keypoints(xyz, kp_xyz, nearest_num, feat=None, kp_feat=None, feature_amp
     n, K = x.shape[0], k.shape[0]
     idx = torch.empty(n, nearest_num, dtype=torch.int64, device=x.device)
     d2 = torch.empty(n, nearest_num, device=x.device) if return_dist else None
-    with torch.cuda.device(x.device):
+    with _lib.on_device(x.device):
         rc = _lib.lib().gp_knn_keypoints(C.c_int64(n), _lib.ptr(x), _lib.ptr(f), C.c_int32(f.shape[1] if hybrid else 0),
                                          C.c_float(feature_amplify), C.c_int64(K), _lib.ptr(k), _lib.ptr(kf),
                                          C.c_int32(nearest_num), _lib.ptr(idx), _lib.ptr(d2), _lib.stream_ptr(x.device))
