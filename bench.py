@@ -117,6 +117,9 @@ def main():
     ap.add_argument("--scale_lo", type=float, default=0.003)
     ap.add_argument("--scale_hi", type=float, default=0.012)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--exact-binning", action="store_true",
+                    help="size the binning buffers by reading R back every step (one host sync per step) instead of the "
+                         "capacity mode with the high-water-mark protocol of TrainStep(speculative=True)")
     ap.add_argument("--render-only", action="store_true", help="time eval-style forward renders instead of train steps")
     args = ap.parse_args()
 
@@ -131,7 +134,7 @@ def main():
     pc, cams, gts, margs = build_workload(args, device)
     # learning rates of the reference at iteration 50000 (position lr has decayed to position_lr_final,
     # [REF arguments/__init__.py:75-76, scene/gaussian_model.py:474-491])
-    ts = TrainStep(pc, cams, gts, args.iteration, lrs=dict(xyz=1.6e-6 * 5.0))
+    ts = TrainStep(pc, cams, gts, args.iteration, lrs=dict(xyz=1.6e-6 * 5.0), speculative=not args.exact_binning)
 
     def one_step(i):
         view = i * world + rank            # rank r renders view world*i + r
@@ -253,7 +256,9 @@ def main():
                        "gaussians": args.gaussians, "width": W, "height": H, "keypoints": args.keypoints,
                        "nearest_num": args.nearest_num, "time_freq": args.time_freq, "iteration": args.iteration,
                        "tiles": T, "pixels": P, "R": R, "R_before_timed_region": R0, "R_per_gaussian": round(R / max(args.gaussians, 1), 3),
-                       "visible": n_vis, "parallelism": f"view-parallel x{world}"},
+                       "visible": n_vis, "parallelism": f"view-parallel x{world}",
+                       "binning": "exact (R read back every step)" if args.exact_binning else
+                                  f"capacity mode (no host sync; {getattr(ts, 'redone', 0)} frames repeated after overflow)"},
             "roofline": roof,
             "roofline_other_kernels": others,
             "eval_render_views_per_s_per_gpu": None if eval_fps is None else round(eval_fps, 2),

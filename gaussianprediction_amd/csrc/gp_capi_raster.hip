@@ -145,12 +145,26 @@ extern "C" int gp_raster_forward(const gp_raster_settings* st, const gp_raster_i
         hipLaunchKernelGGL(gp_gather_tiles_kernel, dim3(gp_blocks(N + 1, 256)), dim3(256), 0, s, sorted_ids, tiles, tt, d.N);
         GP_LAUNCH_CHECK();
         if (gp_scan_exclusive_u32(tt, N + 1, scan_tmp, scan_elems, s)) return 1;
-        GP_HIP_CHECK(hipMemcpyAsync(&R, tt + N, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-        GP_HIP_CHECK(hipStreamSynchronize(s));
-        if (R > 0x7FFFFF00u) GP_FAIL("too many tile-splat instances (%u)", R);
+        const bool capacity_mode = st->binning_capacity > 0;
+        if (capacity_mode) {    // no host synchronisation: everything below is sized by the caller's capacity
+            if (!st->binning_status) GP_FAIL("binning_capacity needs binning_status (device, 2 words)");
+            if (st->binning_capacity > 0x7FFFFF00ll) GP_FAIL("binning_capacity too large");
+            R = (uint32_t)st->binning_capacity;
+            hipLaunchKernelGGL(gp_binning_status_kernel, dim3(1), dim3(1), 0, s, tt + N, R, st->binning_status);
+            GP_LAUNCH_CHECK();
+        } else {
+            GP_HIP_CHECK(hipMemcpyAsync(&R, tt + N, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+            GP_HIP_CHECK(hipStreamSynchronize(s));
+            if (R > 0x7FFFFF00u) GP_FAIL("too many tile-splat instances (%u)", R);
+            if (st->binning_status) {   // exact mode reports R too (a caller sizing its capacity reads it from here)
+                hipLaunchKernelGGL(gp_binning_status_kernel, dim3(1), dim3(1), 0, s, tt + N, 0xFFFFFFFFu, st->binning_status);
+                GP_LAUNCH_CHECK();
+            }
+        }
 
         if (R > 0) {
-            const int tbits = tile_bits_for((int)T);
+            // capacity mode pads the keys with 0xFFFFFFFF: its low `tbits` bits must sort behind every real tile id
+            const int tbits = tile_bits_for((int)T + (capacity_mode ? 1 : 0));
             const int passes = (tbits + 7) / 8;
             const int res = passes & 1;  // buffer pair holding the sorted result
             // BINNING = point_list[R] (u32) followed by qmask[R] (u8: which 8x8 quadrants of its tile an instance can touch)
@@ -176,15 +190,19 @@ extern "C" int gp_raster_forward(const gp_raster_settings* st, const gp_raster_i
             tb.v[res] = point_list; tb.v[res ^ 1] = bvo;
             tb.hist = bhist; tb.scan_tmp = bscan; tb.scan_tmp_elems = bs;
             { GpProfScope _p("duplicate", s);
+            if (capacity_mode) {    // sentinel keys behind the real instances
+                hipLaunchKernelGGL(gp_fill_sentinel_kernel, dim3(gp_blocks(R, 256)), dim3(256), 0, s, tb.k[0], tt + N, R);
+                GP_LAUNCH_CHECK();
+            }
         hipLaunchKernelGGL(gp_duplicate_kernel, dim3(gp_blocks(N, 256)), dim3(256), 0, s, d, sorted_ids, tt, tiles,
-                               out->radii, gl.rec, tb.k[0], tb.v[0]);
+                               out->radii, gl.rec, tb.k[0], tb.v[0], R);
             GP_LAUNCH_CHECK(); }
             int r2;
             { GpProfScope _p("tile_sort", s); r2 = gp_radix_sort_pairs(tb, R, tbits, s); }
             if (r2 < 0) return 1;
             if (r2 != res) GP_FAIL("internal: sort parity mismatch");
             { GpProfScope _p("tile_ranges", s);
-        hipLaunchKernelGGL(gp_tile_ranges_kernel, dim3(gp_blocks(R, 256)), dim3(256), 0, s, tb.k[r2], R, il.ranges);
+        hipLaunchKernelGGL(gp_tile_ranges_kernel, dim3(gp_blocks(R, 256)), dim3(256), 0, s, tb.k[r2], R, (uint32_t)T, il.ranges);
             GP_LAUNCH_CHECK(); }
         }
     }

@@ -239,7 +239,8 @@ struct AdamTable {
     int count;
 };
 __global__ __launch_bounds__(256) void gp_adam_multi_kernel(AdamTable t, float b1, float b2, float eps, float bc1, float bc2_sqrt,
-                                                           int zero_grad) {
+                                                           int zero_grad, const uint32_t* __restrict__ skip_flag) {
+    const bool skip = skip_flag && *skip_flag != 0;      // the frame that produced these gradients was invalid: no update
     const unsigned chunk = blockIdx.x;
     int k = 0;
     while (k + 1 < t.count && chunk >= t.chunk_begin[k + 1]) ++k;
@@ -260,6 +261,11 @@ __global__ __launch_bounds__(256) void gp_adam_multi_kernel(AdamTable t, float b
     };
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
     size_t i = base + (size_t)threadIdx.x * 4;
+    if (skip) {             // discard the gradients (where this pass owns their zeroing), leave p / m / v untouched
+        if (zero_grad)
+            for (size_t j = base + threadIdx.x; j < end; j += 256) g[j] = 0.f;
+        return;
+    }
     // two independent 16-byte streams per thread and iteration: 8 loads in flight per lane
     for (; i + 1024 + 3 < end; i += 2048) {
         const size_t j = i + 1024;
@@ -379,7 +385,8 @@ extern "C" int gp_adam_step(float* param, float* grad, float* exp_avg, float* ex
 
 extern "C" int gp_adam_step_multi(int32_t count, float* const* params, float* const* grads, float* const* exp_avgs,
                                   float* const* exp_avg_sqs, const int64_t* numels, const float* lrs, float beta1, float beta2,
-                                  float eps, int64_t step, int32_t zero_grad, uint32_t keep_grad_mask, gp_stream_t stream_) {
+                                  float eps, int64_t step, int32_t zero_grad, uint32_t keep_grad_mask, const uint32_t* skip_flag,
+                                  gp_stream_t stream_) {
     hipStream_t s = (hipStream_t)stream_;
     if (count < 0 || count > ADAM_MAX_TENSORS) GP_FAIL("adam: at most %d tensors per call (got %d)", ADAM_MAX_TENSORS, count);
     if (step < 1) GP_FAIL("bad step");
@@ -405,7 +412,7 @@ extern "C" int gp_adam_step_multi(int32_t count, float* const* params, float* co
     const float bc1 = 1.f - powf(beta1, (float)step);
     const float bc2_sqrt = sqrtf(1.f - powf(beta2, (float)step));
     GpProfScope _p("adam", s);
-    hipLaunchKernelGGL(gp_adam_multi_kernel, dim3(chunks), dim3(256), 0, s, t, beta1, beta2, eps, bc1, bc2_sqrt, zero_grad);
+    hipLaunchKernelGGL(gp_adam_multi_kernel, dim3(chunks), dim3(256), 0, s, t, beta1, beta2, eps, bc1, bc2_sqrt, zero_grad, skip_flag);
     GP_LAUNCH_CHECK();
     return 0;
 }

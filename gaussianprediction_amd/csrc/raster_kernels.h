@@ -37,10 +37,13 @@ __global__ __launch_bounds__(256) void gp_duplicate_kernel(RasterDims d, const u
                                                           const uint32_t* __restrict__ offsets,
                                                           const uint32_t* __restrict__ tiles_touched,
                                                           const int32_t* __restrict__ radii, const float4* __restrict__ rec,
-                                                          uint32_t* __restrict__ keys, uint32_t* __restrict__ vals);
+                                                          uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, uint32_t capacity);
 
-__global__ __launch_bounds__(256) void gp_tile_ranges_kernel(const uint32_t* __restrict__ keys, uint32_t R,
+__global__ __launch_bounds__(256) void gp_tile_ranges_kernel(const uint32_t* __restrict__ keys, uint32_t R, uint32_t n_tiles,
                                                             int2* __restrict__ ranges);
+__global__ __launch_bounds__(256) void gp_fill_sentinel_kernel(uint32_t* __restrict__ keys, const uint32_t* __restrict__ total,
+                                                              uint32_t capacity);
+__global__ void gp_binning_status_kernel(const uint32_t* __restrict__ total, uint32_t capacity, uint32_t* __restrict__ status);
 
 __global__ __launch_bounds__(1024) void gp_tile_order_kernel(const int2* __restrict__ ranges, const int32_t* __restrict__ work_hint, int T, uint32_t* __restrict__ order);
 __global__ __launch_bounds__(256) void gp_composite_fwd_kernel(RasterDims d, const int2* __restrict__ ranges,

@@ -348,12 +348,13 @@ __global__ __launch_bounds__(256) void gp_duplicate_kernel(RasterDims d, const u
                                                           const uint32_t* __restrict__ offsets,
                                                           const uint32_t* __restrict__ tiles_touched,
                                                           const int32_t* __restrict__ radii, const float4* __restrict__ rec,
-                                                          uint32_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+                                                          uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, uint32_t capacity) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= d.N) return;
     const uint32_t id = sorted_ids[i];
     if (tiles_touched[id] == 0) return;
     uint32_t off = offsets[i];
+    if (off + tiles_touched[id] > capacity) return;      // capacity mode overflow: truncated lists, flagged in binning_status
     const float4 q0 = rec[3 * (size_t)id];
     int minx, miny, maxx, maxy;
     tile_rect(q0.x, q0.y, (float)radii[id], d.gx, d.gy, minx, miny, maxx, maxy);
@@ -364,13 +365,26 @@ __global__ __launch_bounds__(256) void gp_duplicate_kernel(RasterDims d, const u
             ++off;
         }
 }
-__global__ __launch_bounds__(256) void gp_tile_ranges_kernel(const uint32_t* __restrict__ keys, uint32_t R,
+__global__ __launch_bounds__(256) void gp_tile_ranges_kernel(const uint32_t* __restrict__ keys, uint32_t R, uint32_t n_tiles,
                                                             int2* __restrict__ ranges) {
     const uint32_t k = blockIdx.x * 256 + threadIdx.x;
     if (k >= R) return;
     const uint32_t t = keys[k];
+    if (t >= n_tiles) return;                            // sentinel padding of the capacity mode (sorted behind every tile)
     if (k == 0 || keys[k - 1] != t) ranges[t].x = (int)k;
     if (k == R - 1 || keys[k + 1] != t) ranges[t].y = (int)(k + 1);
+}
+// capacity mode: sentinel keys behind the R real instances (their values are never read: no tile range covers them)
+__global__ __launch_bounds__(256) void gp_fill_sentinel_kernel(uint32_t* __restrict__ keys, const uint32_t* __restrict__ total,
+                                                              uint32_t capacity) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i < capacity && i >= total[0]) keys[i] = 0xFFFFFFFFu;
+}
+// capacity mode: status = {R, R > capacity}
+__global__ void gp_binning_status_kernel(const uint32_t* __restrict__ total, uint32_t capacity, uint32_t* __restrict__ status) {
+    const uint32_t R = total[0];
+    status[0] = R;
+    status[1] = R > capacity ? 1u : 0u;
 }
 
 // Heavy-first launch order.  Per-tile work varies by >10x; the hardware dispatches workgroups in blockIdx order, so

@@ -114,9 +114,10 @@ class FusedAdam:
                     raise RuntimeError("FusedAdam needs contiguous parameters")
                 self.items.append((g, p, off_of[id(p)], torch.zeros_like(p), torch.zeros_like(p)))
 
-    def step(self, zero_grad=True, keep_grad=()):
+    def step(self, zero_grad=True, keep_grad=(), skip_flag=None):
         """One launch for all parameter tensors (gp_adam_step_multi).  Parameters listed in `keep_grad` are not
-        zeroed: their gradient buffers are marked stale (grad_sink.mark_stale) and the next backward overwrites them."""
+        zeroed: their gradient buffers are marked stale (grad_sink.mark_stale) and the next backward overwrites them.
+        `skip_flag`: optional int32 device word; non-zero = leave parameters and moments untouched (invalid frame)."""
         self.step_count += 1
         n = len(self.items)
         if not hasattr(self, "_tab"):
@@ -138,7 +139,8 @@ class FusedAdam:
         dev = self.bucket.flat.device
         with _lib.on_device(dev):
             rc = _lib.lib().gp_adam_step_multi(C.c_int32(n), P, G, M, V, NUM, LR, C.c_float(b1), C.c_float(b2), C.c_float(self.eps),
-                                               C.c_int64(self.step_count), C.c_int32(1 if zero_grad else 0), C.c_uint32(mask), _lib.stream_ptr(dev))
+                                               C.c_int64(self.step_count), C.c_int32(1 if zero_grad else 0), C.c_uint32(mask),
+                                               _lib.ptr(skip_flag), _lib.stream_ptr(dev))
             _lib.check(rc, "gp_adam_step_multi")
         if mask:
             from . import grad_sink

@@ -37,6 +37,10 @@ class GaussianRasterizationSettings(NamedTuple):
     campos: torch.Tensor
     prefiltered: bool
     debug: bool = False  # the reference does not pass it [REF gaussian_renderer/__init__.py:49]
+    # extension (include/gp_hip.h, gp_raster_settings): capacity mode of the binning stage.  0 / None = exact mode (one
+    # host sync per forward to read R).  capacity > 0 with a 2-word int32 device tensor = no host sync; status = {R, overflow}
+    binning_capacity: int = 0
+    binning_status: Optional[torch.Tensor] = None
 
 
 def _f32c(t: Optional[torch.Tensor], device) -> Optional[torch.Tensor]:
@@ -54,7 +58,16 @@ def _settings_c(rs: GaussianRasterizationSettings, device, sh_coeffs: int):
     st = _lib.RasterSettingsC(int(rs.image_height), int(rs.image_width), float(rs.tanfovx), float(rs.tanfovy),
                               float(rs.scale_modifier), int(rs.sh_degree), int(sh_coeffs), int(bool(rs.prefiltered)),
                               int(bool(rs.debug)), keep[0].data_ptr(), keep[1].data_ptr(), keep[2].data_ptr(),
-                              keep[3].data_ptr())
+                              keep[3].data_ptr(), 0, None)
+    status = getattr(rs, "binning_status", None)
+    if status is not None:
+        if status.device != device or status.dtype != torch.int32 or status.numel() < 2 or not status.is_contiguous():
+            raise RuntimeError("binning_status: contiguous int32 tensor of >= 2 elements on the render device expected")
+        st.binning_capacity = int(getattr(rs, "binning_capacity", 0) or 0)
+        st.binning_status = status.data_ptr()
+        keep.append(status)
+    elif getattr(rs, "binning_capacity", 0):
+        raise RuntimeError("binning_capacity needs binning_status")
     return st, keep
 
 

@@ -33,8 +33,10 @@ def _sh_to_rgb_python(deg, feats, dirs):
     return torch.clamp_min(res + 0.5, 0.0)
 
 
-def _settings(viewpoint_camera, pc, bg_color, scaling_modifier):
+def _settings(viewpoint_camera, pc, bg_color, scaling_modifier, binning=None):
     return GaussianRasterizationSettings(
+        binning_capacity=int(binning[0]) if binning else 0,
+        binning_status=binning[1] if binning else None,
         image_height=int(viewpoint_camera.image_height),
         image_width=int(viewpoint_camera.image_width),
         tanfovx=math.tan(viewpoint_camera.FoVx * 0.5),
@@ -60,10 +62,12 @@ def _screenspace_points(pc):
 
 
 def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=1.0, override_color=None, delta=None,
-           time=None, it=1):
-    """Render the scene.  Background tensor (bg_color) must be on the GPU."""
+           time=None, it=1, binning=None):
+    """Render the scene.  Background tensor (bg_color) must be on the GPU.
+    `binning` (extension, not in the reference signature): (capacity, status) of the rasterizer's capacity mode -- see
+    GaussianRasterizationSettings.binning_capacity."""
     screenspace_points = _screenspace_points(pc)
-    rasterizer = GaussianRasterizer(raster_settings=_settings(viewpoint_camera, pc, bg_color, scaling_modifier))
+    rasterizer = GaussianRasterizer(raster_settings=_settings(viewpoint_camera, pc, bg_color, scaling_modifier, binning))
     cov3D_precomp = None
     if time is None:
         means3D = pc.get_xyz + delta if delta is not None else pc.get_xyz

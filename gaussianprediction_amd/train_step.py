@@ -46,12 +46,31 @@ def ssim(img1, img2, window):            # [REF utils/loss_utils.py:70-100]
 class TrainStep:
     """One optimisation step over one view per rank (view-parallel when world_size > 1)."""
 
-    def __init__(self, pc, cameras, gt_images, iteration, lambda_dssim=0.2, lrs=None, group=None, fused=True):
+    # capacity mode of the rasterizer's binning stage (include/gp_hip.h, gp_raster_settings.binning_capacity): the host
+    # never waits for R.  Protocol: the first `len(cameras)` steps run in exact mode and report R through the status word;
+    # afterwards the capacity is SPEC_MARGIN x the largest R seen, every step writes {R, overflow} into one of SPEC_SLOTS
+    # status slots, Adam takes the overflow word as its skip flag, and the slot is read back (pinned, asynchronous) when it
+    # comes round again SPEC_SLOTS steps later: the high-water mark follows the scene, and a frame that overflowed (its
+    # update was skipped on the device) is repeated in exact mode.
+    SPEC_SLOTS = 4
+    SPEC_MARGIN = 1.1
+    SPEC_PAD = 4096
+
+    def __init__(self, pc, cameras, gt_images, iteration, lambda_dssim=0.2, lrs=None, group=None, fused=True, speculative=False):
         self.pc, self.cameras, self.gt, self.iteration = pc, cameras, gt_images, iteration
         self.lambda_dssim = lambda_dssim
         self.group = group
         self.fused = fused
         dev = pc.get_xyz.device
+        self.speculative = bool(speculative) and fused and dev.type == "cuda"
+        if self.speculative:
+            K = self.SPEC_SLOTS
+            self._status = torch.zeros(K, 2, dtype=torch.int32, device=dev)
+            self._status_host = torch.zeros(K, 2, dtype=torch.int32).pin_memory()
+            self._events = [None] * K
+            self._slot_view = [None] * K            # view rendered by the step that last used the slot
+            self._slot_spec = [False] * K           # ... and whether it ran in capacity mode
+            self._r_max, self._n_steps, self.redone = 0, 0, 0
         self.bg = torch.zeros(3, device=dev)          # black background [REF train.py:59]
         self.pipe = SimpleNamespace(convert_SHs_python=False, compute_cov3D_python=False, debug=False)
         self.window = _gauss_window(3, dev)
@@ -146,13 +165,48 @@ class TrainStep:
         return loss + self.pc.get_loss(self.iteration)
 
     def step(self, view_index: int):
+        if not self.speculative:
+            return self._step(view_index, None, None)
+        K = self.SPEC_SLOTS
+        slot = self._n_steps % K
+        if self._events[slot] is not None:           # the step that used this slot K steps ago: long finished
+            self._events[slot].synchronize()
+            r, overflow = int(self._status_host[slot, 0]), int(self._status_host[slot, 1])
+            self._r_max = max(self._r_max, r)
+            if overflow and self._slot_spec[slot]:   # its Adam update was skipped on the device: repeat the frame, exactly
+                self.redone += 1
+                if self.fused:
+                    self.optimizer.step_count -= 1
+                self._events[slot] = None
+                self._run_slot(slot, self._slot_view[slot], exact=True)
+                self._n_steps += 1
+                return self.step(view_index)
+        exact = self._n_steps < len(self.cameras) + K or self._r_max == 0   # until every view's R has been read back
+        out = self._run_slot(slot, view_index, exact)
+        self._n_steps += 1
+        return out
+
+    def _run_slot(self, slot, view_index, exact):
+        status = self._status[slot]
+        capacity = 0 if exact else (int(self._r_max * self.SPEC_MARGIN) + self.SPEC_PAD)
+        out = self._step(view_index, (capacity, status), None if exact else status[1:2])
+        self._status_host[slot].copy_(status, non_blocking=True)
+        ev = self._events[slot] or torch.cuda.Event()
+        ev.record()
+        self._events[slot], self._slot_view[slot], self._slot_spec[slot] = ev, view_index, not exact
+        return out
+
+    def _step(self, view_index: int, binning, skip_flag):
         cam = self.cameras[view_index % len(self.cameras)]
         gt = self.gt[view_index % len(self.gt)]
         time = self.times[view_index % len(self.cameras)]
-        pkg = render(cam, self.pc, self.pipe, self.bg, time=time, it=self.iteration)
+        pkg = render(cam, self.pc, self.pipe, self.bg, time=time, it=self.iteration, binning=binning)
         loss = self.loss_of(pkg["render"], gt)
         loss.backward()                              # hooks start the all-reduce of each large gradient as it completes
         self.reducer.finish()                        # SUM over views == the reference's --batch semantics
+        if skip_flag is not None and self.reducer.enabled:
+            # one rank's overflow invalidates the summed gradient: every rank must skip (and later repeat) this step
+            torch.distributed.all_reduce(skip_flag, op=torch.distributed.ReduceOp.MAX, group=self.group)
         if self.fused:
             # the per-Gaussian gradients each have exactly one producer kernel that writes the whole tensor (SH: rasterizer
             # backward; xyz / rotation: blend backward; scaling / opacity: activation backward): skip their zeroing pass
@@ -161,7 +215,7 @@ class TrainStep:
             if not self.pipe.convert_SHs_python and self.iteration > self.pc.third_stage_iter:
                 keep = (self.pc._features_dc, self.pc._features_rest, self.pc._xyz, self.pc._rotation, self.pc._scaling,
                         self.pc._opacity)
-            self.optimizer.step(zero_grad=True, keep_grad=keep)
+            self.optimizer.step(zero_grad=True, keep_grad=keep, skip_flag=skip_flag)
         else:
             self.optimizer.step()
             self.bucket.zero()

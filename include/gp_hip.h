@@ -54,6 +54,14 @@ typedef struct gp_raster_settings {
     const float* viewmatrix; /* device [16] */
     const float* projmatrix; /* device [16] */
     const float* campos;     /* device [3] */
+    /* Binning capacity.  0 = exact mode: gp_raster_forward reads R (the number of tile-splat instances) back to size the
+     * binning buffers -- the call's one host synchronisation.  > 0 = the caller promises R <= binning_capacity (e.g. a
+     * high-water mark of earlier frames): buffers are sized by the capacity, the sort is padded with sentinel keys and the
+     * host never waits.  `binning_status` (device, 2 words, required when capacity > 0) receives {R, overflow}: on overflow
+     * (R > capacity) the instance lists are truncated -- every access stays in bounds, the image is NOT valid -- and the
+     * caller must discard the frame (gp_adam_step_multi takes the same word as its skip flag) and retry with more room. */
+    int64_t binning_capacity;
+    uint32_t* binning_status;
 } gp_raster_settings;
 
 /* inputs of GaussianRasterizer.forward [REF gaussian_renderer/__init__.py:98-106] */
@@ -82,7 +90,7 @@ typedef struct gp_raster_saved {
     void* geom;    size_t geom_bytes;
     void* binning; size_t binning_bytes;
     void* image;   size_t image_bytes;
-    int64_t num_rendered; /* R = sum of tiles touched */
+    int64_t num_rendered; /* R = sum of tiles touched (exact mode); the binning capacity in capacity mode */
 } gp_raster_saved;
 
 typedef struct gp_raster_grads {
@@ -251,10 +259,13 @@ int gp_adam_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq, i
                  float eps, int64_t step, int32_t zero_grad, gp_stream_t stream);
 
 /* the same for up to 32 tensors in ONE launch (host arrays of device pointers / sizes / learning rates).
- * keep_grad_mask: bit k set = do NOT zero tensor k's gradient even when zero_grad != 0 (its next producer overwrites it). */
+ * keep_grad_mask: bit k set = do NOT zero tensor k's gradient even when zero_grad != 0 (its next producer overwrites it).
+ * skip_flag: NULL, or a device word read by the kernel: non-zero = the gradients come from an invalid frame (binning
+ * overflow of the rasterizer's capacity mode, gp_raster_settings.binning_status + 1): parameters and moments stay as they
+ * are, the gradients are still zeroed. */
 int gp_adam_step_multi(int32_t count, float* const* params, float* const* grads, float* const* exp_avgs,
                        float* const* exp_avg_sqs, const int64_t* numels, const float* lrs, float beta1, float beta2, float eps,
-                       int64_t step, int32_t zero_grad, uint32_t keep_grad_mask, gp_stream_t stream);
+                       int64_t step, int32_t zero_grad, uint32_t keep_grad_mask, const uint32_t* skip_flag, gp_stream_t stream);
 
 /* ---- keypoint weights (parity unpinned: tinycudann / frnn are absent from the reference tree) --- */
 
