@@ -79,6 +79,8 @@ def densify_and_prune(model, step, stats, max_grad, min_opacity, extent, max_scr
     """`densify` (clone + split) followed by `prune` [REF scene/gaussian_model.py:690-694, 739-747; train.py:171-175].
     Returns (n_cloned, n_split_sources, n_pruned)."""
     dev = model._xyz.device
+    if hasattr(step, "wait_side"):
+        step.wait_side()            # a side-stream parameter update (TrainStep: the SH Adam) must have landed
     P = {k: v.detach() for k, v in _per_gaussian(model).items()}
     N0 = P["xyz"].shape[0]
     grads = stats.xyz_gradient_accum / stats.denom

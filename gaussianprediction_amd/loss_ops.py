@@ -114,11 +114,16 @@ class FusedAdam:
                     raise RuntimeError("FusedAdam needs contiguous parameters")
                 self.items.append((g, p, off_of[id(p)], torch.zeros_like(p), torch.zeros_like(p)))
 
-    def step(self, zero_grad=True, keep_grad=(), skip_flag=None):
+    def step(self, zero_grad=True, keep_grad=(), skip_flag=None, only=None, exclude=None, stream=None, advance=True):
         """One launch for all parameter tensors (gp_adam_step_multi).  Parameters listed in `keep_grad` are not
         zeroed: their gradient buffers are marked stale (grad_sink.mark_stale) and the next backward overwrites them.
-        `skip_flag`: optional int32 device word; non-zero = leave parameters and moments untouched (invalid frame)."""
-        self.step_count += 1
+        `skip_flag`: optional int32 device word; non-zero = leave parameters and moments untouched (invalid frame).
+        `only` / `exclude`: restrict the launch to a subset of the parameter tensors; `stream`: a torch.cuda.Stream other
+        than the current one; `advance=False` uses step number step_count + 1 without committing it (the first of two
+        partial launches of one optimisation step)."""
+        step_no = self.step_count + 1
+        if advance:
+            self.step_count = step_no
         n = len(self.items)
         if not hasattr(self, "_tab"):
             P = (C.c_void_p * n)(*[p.data_ptr() for _, p, _, _, _ in self.items])
@@ -127,20 +132,33 @@ class FusedAdam:
             V = (C.c_void_p * n)(*[v.data_ptr() for _, _, _, _, v in self.items])
             NUM = (C.c_int64 * n)(*[p.numel() for _, p, _, _, _ in self.items])
             self._tab = (P, G, M, V, NUM)
+            self._num_subsets = {}
         P, G, M, V, NUM = self._tab
+        active = None
+        if only is not None or exclude is not None:
+            inc = {id(p) for p in only} if only is not None else None
+            exc = {id(p) for p in exclude} if exclude is not None else set()
+            key = (frozenset(inc) if inc is not None else None, frozenset(exc))
+            sub = self._num_subsets.get(key)
+            if sub is None:     # a tensor with numel 0 is skipped by the library
+                flags = [(inc is None or id(p) in inc) and id(p) not in exc for _, p, _, _, _ in self.items]
+                sub = ((C.c_int64 * n)(*[p.numel() if f else 0 for f, (_, p, _, _, _) in zip(flags, self.items)]), flags)
+                self._num_subsets[key] = sub
+            NUM, active = sub
         LR = (C.c_float * n)(*[float(g["lr"]) for g, _, _, _, _ in self.items])
         keep_ids = {id(p) for p in keep_grad}
         mask = 0
         if zero_grad:
             for k, (_, p, _, _, _) in enumerate(self.items):
-                if id(p) in keep_ids:
+                if id(p) in keep_ids and (active is None or active[k]):
                     mask |= 1 << k
         b1, b2 = self.betas
         dev = self.bucket.flat.device
+        sp = _lib.stream_ptr(dev) if stream is None else C.c_void_p(stream.cuda_stream)
         with _lib.on_device(dev):
             rc = _lib.lib().gp_adam_step_multi(C.c_int32(n), P, G, M, V, NUM, LR, C.c_float(b1), C.c_float(b2), C.c_float(self.eps),
-                                               C.c_int64(self.step_count), C.c_int32(1 if zero_grad else 0), C.c_uint32(mask),
-                                               _lib.ptr(skip_flag), _lib.stream_ptr(dev))
+                                               C.c_int64(step_no), C.c_int32(1 if zero_grad else 0), C.c_uint32(mask),
+                                               _lib.ptr(skip_flag), sp)
             _lib.check(rc, "gp_adam_step_multi")
         if mask:
             from . import grad_sink

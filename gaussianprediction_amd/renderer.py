@@ -51,6 +51,14 @@ def _settings(viewpoint_camera, pc, bg_color, scaling_modifier, binning=None):
     )
 
 
+def _wait_params(pc):
+    """A training harness may update parameters on a second stream (TrainStep: the SH coefficients); the event it leaves on
+    the model orders every render behind that update."""
+    ev = getattr(pc, "_param_ready_event", None)
+    if ev is not None:
+        torch.cuda.current_stream().wait_event(ev)
+
+
 def _screenspace_points(pc):
     # zero tensor whose .grad receives the 2D (screen-space) mean gradients [REF :27-31]
     p = torch.zeros_like(pc.get_xyz, dtype=pc.get_xyz.dtype, requires_grad=True, device=pc.get_xyz.device) + 0
@@ -79,6 +87,7 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=
     else:
         means3D, rotations, scales, opacity = pc(time, it)
     shs, shs_rest, colors_precomp = None, None, None
+    _wait_params(pc)         # (after the deformation was enqueued: it does not read the tensors a harness updates late)
     if override_color is None:
         if getattr(pipe, "convert_SHs_python", False):
             base = means3D.detach() if time is not None else pc.get_xyz + (delta if delta is not None else 0)
@@ -101,6 +110,7 @@ def render_motion(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_mo
                   xyz_t=None, r_t=None, opacity=None):
     """Render externally supplied per-frame positions/rotations [REF gaussian_renderer/__init__.py:117-191]."""
     screenspace_points = _screenspace_points(pc)
+    _wait_params(pc)
     rasterizer = GaussianRasterizer(raster_settings=_settings(viewpoint_camera, pc, bg_color, scaling_modifier))
     opacity = pc.get_opacity if opacity is None else opacity
     shs, colors_precomp = (pc.get_features, None) if override_color is None else (None, override_color)

@@ -92,3 +92,26 @@ def test_speculative_train_step_matches_exact_and_recovers_from_overflow():
     assert rc > 0                                                         # overflows happened, were detected and redone
     assert torch.isfinite(xc).all() and torch.isfinite(fc).all()
     assert lc[-1] < lc[0]                                                 # and the optimisation still progresses
+
+
+def test_side_stream_sh_adam_matches_the_single_stream_step():
+    """TrainStep(overlap_sh_adam=True): the SH tensors are updated on a second stream during the backward; render()
+    orders itself behind that update through the event left on the model."""
+    from test_gpu_render import build, make_args
+    from gaussianprediction_amd.train_step import TrainStep
+    outs = []
+    for overlap in (False, True):
+        pc, cam, *_ = build(N=2000, K=40, W=96, H=80, args=make_args())
+        gt = torch.rand(3, 80, 96, generator=torch.Generator().manual_seed(5)).cuda()
+        ts = TrainStep(pc, [cam], [gt], 50000, overlap_sh_adam=overlap)
+        losses = [float(ts.step(0)[0]) for _ in range(8)]
+        ts.wait_side()
+        torch.cuda.synchronize()
+        outs.append((losses, pc._features_dc.detach().clone(), pc._features_rest.detach().clone(), pc._xyz.detach().clone(),
+                     ts.optimizer.step_count))
+    (la, da, ra, xa, na), (lb, db, rb, xb, nb) = outs
+    assert na == nb == 8
+    assert np.allclose(la, lb, rtol=2e-4, atol=1e-6), (la, lb)
+    assert rel_l2(da.cpu().numpy(), db.cpu().numpy()) < 1e-3
+    assert rel_l2(ra.cpu().numpy(), rb.cpu().numpy()) < 1e-3
+    assert rel_l2(xa.cpu().numpy(), xb.cpu().numpy()) < 1e-4
