@@ -29,7 +29,7 @@ def run(name, steps=15, warmup=5, precision="fp32"):
     dev = torch.device("cuda", 0)
     pc, cams, gts, margs = bench.build_workload(args, dev)
     pc.df_model.precision = precision
-    ts = TrainStep(pc, cams, gts, args.iteration, lrs=dict(xyz=8e-6))
+    ts = TrainStep(pc, cams, gts, args.iteration, lrs=dict(xyz=8e-6), speculative=(mode == "train"))
     out = {"config": name, "mlp_precision": precision, "mode": mode, **{k: v for k, v in cfg.items() if k not in ("extent",)}}
 
     def one(i):
