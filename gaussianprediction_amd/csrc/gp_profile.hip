@@ -26,7 +26,7 @@ void* gp_prof_begin(const char* name, hipStream_t s, int level) {
     std::lock_guard<std::mutex> lk(g_mu);
     ProfRec r{name, take_event(), take_event()};
     if (!r.a || !r.b) return nullptr;
-    hipEventRecord(r.a, s);
+    (void)hipEventRecord(r.a, s);
     g_recs.push_back(r);
     return (void*)(uintptr_t)g_recs.size();  // 1-based index
 }
@@ -34,7 +34,7 @@ void gp_prof_end(void* h, hipStream_t s) {
     if (!h) return;
     std::lock_guard<std::mutex> lk(g_mu);
     size_t i = (size_t)(uintptr_t)h - 1;
-    if (i < g_recs.size()) hipEventRecord(g_recs[i].b, s);
+    if (i < g_recs.size()) (void)hipEventRecord(g_recs[i].b, s);
 }
 
 extern "C" int gp_profile_enable(int on) {
