@@ -354,14 +354,15 @@ __global__ __launch_bounds__(256) void gp_duplicate_kernel(RasterDims d, const u
     const uint32_t id = sorted_ids[i];
     if (tiles_touched[id] == 0) return;
     uint32_t off = offsets[i];
-    if (off + tiles_touched[id] > capacity) return;      // capacity mode overflow: truncated lists, flagged in binning_status
     const float4 q0 = rec[3 * (size_t)id];
     int minx, miny, maxx, maxy;
     tile_rect(q0.x, q0.y, (float)radii[id], d.gx, d.gy, minx, miny, maxx, maxy);
     for (int y = miny; y < maxy; ++y)
         for (int x = minx; x < maxx; ++x) {
-            keys[off] = (uint32_t)(y * d.gx + x);
-            vals[off] = id;
+            if (off < capacity) {       // capacity-mode overflow: the list is cut at the capacity (flagged in binning_status);
+                keys[off] = (uint32_t)(y * d.gx + x);   // every slot below it is still written, so no stale id is ever read
+                vals[off] = id;
+            }
             ++off;
         }
 }

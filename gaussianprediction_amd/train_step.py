@@ -7,6 +7,7 @@ the reference (used by the tests as the checker).
 """
 from __future__ import annotations
 
+import os
 from types import SimpleNamespace
 
 import torch
@@ -72,6 +73,8 @@ class TrainStep:
             self._slot_view = [None] * K            # view rendered by the step that last used the slot
             self._slot_spec = [False] * K           # ... and whether it ran in capacity mode
             self._r_max, self._n_steps, self.redone = 0, 0, 0
+            if os.environ.get("GP_SPEC_MARGIN"):     # test hook: a margin < 1 forces overflows (and the redo protocol)
+                self.SPEC_MARGIN, self.SPEC_PAD = float(os.environ["GP_SPEC_MARGIN"]), 0
         # Optional (off: measured 1.83 -> 1.90 ms on the bench): Adam for the SH coefficients (3/4 of all parameter bytes) on
         # a second stream.  Their gradients are final as soon as the rasterizer backward has run and their values are not
         # read again before the next rasterizer forward, so the update can overlap the deformation backward of this step and
