@@ -89,3 +89,25 @@ def test_product_does_not_import_the_oracle():
             if f.endswith((".py", ".hip", ".h")):
                 src = open(os.path.join(dirpath, f)).read()
                 assert "import oracle" not in src and "from oracle" not in src and "gp_oracle" not in src.replace("oracle/gp_oracle.c", ""), f
+
+
+def test_capacity_mode_settings_are_validated_on_the_host():
+    """GaussianRasterizationSettings.binning_capacity / binning_status (extension): defaults keep the reference's
+    11-kwarg construction working; a capacity without a status word, or a malformed status tensor, is rejected before
+    anything is launched."""
+    import torch
+    from gaussianprediction_amd import rasterizer as R
+    dev = torch.device("cpu")
+    kw = dict(image_height=8, image_width=8, tanfovx=0.5, tanfovy=0.5, bg=torch.zeros(3), scale_modifier=1.0,
+              viewmatrix=torch.eye(4), projmatrix=torch.eye(4), sh_degree=3, campos=torch.zeros(3), prefiltered=False)
+    rs = R.GaussianRasterizationSettings(**kw)
+    assert rs.debug is False and rs.binning_capacity == 0 and rs.binning_status is None
+    st, keep = R._settings_c(rs, dev, 16)
+    assert st.binning_capacity == 0 and not st.binning_status
+    status = torch.zeros(2, dtype=torch.int32)
+    st, keep = R._settings_c(R.GaussianRasterizationSettings(**kw, binning_capacity=1000, binning_status=status), dev, 16)
+    assert st.binning_capacity == 1000 and st.binning_status == status.data_ptr() and any(k is status for k in keep)
+    with pytest.raises(RuntimeError, match="needs binning_status"):
+        R._settings_c(R.GaussianRasterizationSettings(**kw, binning_capacity=1000), dev, 16)
+    with pytest.raises(RuntimeError, match="int32"):
+        R._settings_c(R.GaussianRasterizationSettings(**kw, binning_capacity=1000, binning_status=torch.zeros(2)), dev, 16)
