@@ -106,18 +106,19 @@ extern "C" int gp_raster_forward(const gp_raster_settings* st, const gp_raster_i
         GpCarver tc0(nullptr);
         const size_t hist_elems = gp_sort_hist_elems(N);
         const size_t scan_elems = gp_scan_tmp_elems(256 * ((N + 4095) / 4096) > N + 1 ? 256 * ((N + 4095) / 4096) : N + 1);
-        auto carve_tmp = [&](GpCarver& c, uint32_t*& k0, uint32_t*& k1, uint32_t*& v0, uint32_t*& v1, uint32_t*& tiles,
-                             uint32_t*& tt, uint32_t*& hist, uint32_t*& scan_tmp) {
+        auto carve_tmp = [&](GpCarver& c, uint32_t*& k0, uint32_t*& k1, uint32_t*& v0, uint32_t*& v1, uint2*& tiles,
+                             uint2*& rects, uint32_t*& tt, uint32_t*& hist, uint32_t*& scan_tmp) {
             k0 = c.take<uint32_t>(N); k1 = c.take<uint32_t>(N); v0 = c.take<uint32_t>(N); v1 = c.take<uint32_t>(N);
-            tiles = c.take<uint32_t>(N); tt = c.take<uint32_t>(N + 1);
+            tiles = c.take<uint2>(N); rects = c.take<uint2>(N); tt = c.take<uint32_t>(N + 1);
             hist = c.take<uint32_t>(hist_elems); scan_tmp = c.take<uint32_t>(scan_elems);
         };
-        uint32_t *k0, *k1, *v0, *v1, *tiles, *tt, *hist, *scan_tmp;
-        carve_tmp(tc0, k0, k1, v0, v1, tiles, tt, hist, scan_tmp);
+        uint32_t *k0, *k1, *v0, *v1, *tt, *hist, *scan_tmp;
+        uint2 *tiles, *rects;      // per-Gaussian tile rectangle by id, and the same in depth order
+        carve_tmp(tc0, k0, k1, v0, v1, tiles, rects, tt, hist, scan_tmp);
         void* tmp = alloc(alloc_ctx, GP_BUF_TEMP, tc0.bytes());
         if (!tmp) GP_FAIL("allocator returned NULL for TEMP (%zu B)", tc0.bytes());
         GpCarver tc(tmp);
-        carve_tmp(tc, k0, k1, v0, v1, tiles, tt, hist, scan_tmp);
+        carve_tmp(tc, k0, k1, v0, v1, tiles, rects, tt, hist, scan_tmp);
 
         {
             GpProfScope _p("preprocess_fwd", s);
@@ -142,7 +143,7 @@ extern "C" int gp_raster_forward(const gp_raster_settings* st, const gp_raster_i
         { GpProfScope _p("depth_sort", s); r1 = gp_radix_sort_pairs(sb, N, 32, s); }
         if (r1 < 0) return 1;
         const uint32_t* sorted_ids = sb.v[r1];
-        hipLaunchKernelGGL(gp_gather_tiles_kernel, dim3(gp_blocks(N + 1, 256)), dim3(256), 0, s, sorted_ids, tiles, tt, d.N);
+        hipLaunchKernelGGL(gp_gather_tiles_kernel, dim3(gp_blocks(N + 1, 256)), dim3(256), 0, s, sorted_ids, tiles, tt, rects, d.N);
         GP_LAUNCH_CHECK();
         if (gp_scan_exclusive_u32(tt, N + 1, scan_tmp, scan_elems, s)) return 1;
         const bool capacity_mode = st->binning_capacity > 0;
@@ -194,8 +195,8 @@ extern "C" int gp_raster_forward(const gp_raster_settings* st, const gp_raster_i
                 hipLaunchKernelGGL(gp_fill_sentinel_kernel, dim3(gp_blocks(R, 256)), dim3(256), 0, s, tb.k[0], tt + N, R);
                 GP_LAUNCH_CHECK();
             }
-        hipLaunchKernelGGL(gp_duplicate_kernel, dim3(gp_blocks(N, 256)), dim3(256), 0, s, d, sorted_ids, tt, tiles,
-                               out->radii, gl.rec, tb.k[0], tb.v[0], R);
+        hipLaunchKernelGGL(gp_duplicate_kernel, dim3(gp_blocks(N, 256)), dim3(256), 0, s, d, sorted_ids, tt, rects,
+                               tb.k[0], tb.v[0], R);
             GP_LAUNCH_CHECK(); }
             int r2;
             { GpProfScope _p("tile_sort", s); r2 = gp_radix_sort_pairs(tb, R, tbits, s); }

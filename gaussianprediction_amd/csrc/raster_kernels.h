@@ -18,11 +18,11 @@ struct RasterDims {
     float tanfovx, tanfovy, fx, fy, scale_mod;
 };
 
-__global__ __launch_bounds__(256) void gp_preprocess_fwd_kernel(RasterDims d, const float* __restrict__ means3D, const float* __restrict__ scales,      const float* __restrict__ rotations, const float* __restrict__ opacities, const float* __restrict__ shs,      const float* __restrict__ shs_rest, const float* __restrict__ colors_precomp, const float* __restrict__ cov3D_precomp,      const float* __restrict__ view, const float* __restrict__ proj, const float* __restrict__ campos,      int32_t* __restrict__ radii, float4* __restrict__ rec, uint32_t* __restrict__ depth_key,      uint32_t* __restrict__ tiles_touched, uint8_t* __restrict__ clamped);
+__global__ __launch_bounds__(256) void gp_preprocess_fwd_kernel(RasterDims d, const float* __restrict__ means3D, const float* __restrict__ scales,      const float* __restrict__ rotations, const float* __restrict__ opacities, const float* __restrict__ shs,      const float* __restrict__ shs_rest, const float* __restrict__ colors_precomp, const float* __restrict__ cov3D_precomp,      const float* __restrict__ view, const float* __restrict__ proj, const float* __restrict__ campos,      int32_t* __restrict__ radii, float4* __restrict__ rec, uint32_t* __restrict__ depth_key,      uint2* __restrict__ tiles_touched, uint8_t* __restrict__ clamped);
 
-__global__ __launch_bounds__(256) void gp_preprocess_fwd_sh16_kernel(RasterDims d, const float* __restrict__ means3D, const float* __restrict__ scales,      const float* __restrict__ rotations, const float* __restrict__ opacities, const float* __restrict__ shs,      const float* __restrict__ shs_rest, const float* __restrict__ colors_precomp, const float* __restrict__ cov3D_precomp,      const float* __restrict__ view, const float* __restrict__ proj, const float* __restrict__ campos,      int32_t* __restrict__ radii, float4* __restrict__ rec, uint32_t* __restrict__ depth_key,      uint32_t* __restrict__ tiles_touched, uint8_t* __restrict__ clamped);
+__global__ __launch_bounds__(256) void gp_preprocess_fwd_sh16_kernel(RasterDims d, const float* __restrict__ means3D, const float* __restrict__ scales,      const float* __restrict__ rotations, const float* __restrict__ opacities, const float* __restrict__ shs,      const float* __restrict__ shs_rest, const float* __restrict__ colors_precomp, const float* __restrict__ cov3D_precomp,      const float* __restrict__ view, const float* __restrict__ proj, const float* __restrict__ campos,      int32_t* __restrict__ radii, float4* __restrict__ rec, uint32_t* __restrict__ depth_key,      uint2* __restrict__ tiles_touched, uint8_t* __restrict__ clamped);
 
-__global__ __launch_bounds__(256) void gp_preprocess_fwd_split_kernel(RasterDims d, const float* __restrict__ means3D, const float* __restrict__ scales,      const float* __restrict__ rotations, const float* __restrict__ opacities, const float* __restrict__ shs,      const float* __restrict__ shs_rest, const float* __restrict__ colors_precomp, const float* __restrict__ cov3D_precomp,      const float* __restrict__ view, const float* __restrict__ proj, const float* __restrict__ campos,      int32_t* __restrict__ radii, float4* __restrict__ rec, uint32_t* __restrict__ depth_key,      uint32_t* __restrict__ tiles_touched, uint8_t* __restrict__ clamped);
+__global__ __launch_bounds__(256) void gp_preprocess_fwd_split_kernel(RasterDims d, const float* __restrict__ means3D, const float* __restrict__ scales,      const float* __restrict__ rotations, const float* __restrict__ opacities, const float* __restrict__ shs,      const float* __restrict__ shs_rest, const float* __restrict__ colors_precomp, const float* __restrict__ cov3D_precomp,      const float* __restrict__ view, const float* __restrict__ proj, const float* __restrict__ campos,      int32_t* __restrict__ radii, float4* __restrict__ rec, uint32_t* __restrict__ depth_key,      uint2* __restrict__ tiles_touched, uint8_t* __restrict__ clamped);
 
 __global__ __launch_bounds__(256) void gp_mark_visible_kernel(int n, const float* __restrict__ means3D,
                                                              const float* __restrict__ view, uint8_t* __restrict__ present);
@@ -30,13 +30,12 @@ __global__ __launch_bounds__(256) void gp_mark_visible_kernel(int n, const float
 __global__ __launch_bounds__(256) void gp_iota_kernel(uint32_t* __restrict__ v, int n);
 
 __global__ __launch_bounds__(256) void gp_gather_tiles_kernel(const uint32_t* __restrict__ sorted_ids,
-                                                             const uint32_t* __restrict__ tiles_touched,
-                                                             uint32_t* __restrict__ out, int n);
+                                                             const uint2* __restrict__ tiles_touched,
+                                                             uint32_t* __restrict__ out, uint2* __restrict__ rect_sorted, int n);
 
 __global__ __launch_bounds__(256) void gp_duplicate_kernel(RasterDims d, const uint32_t* __restrict__ sorted_ids,
                                                           const uint32_t* __restrict__ offsets,
-                                                          const uint32_t* __restrict__ tiles_touched,
-                                                          const int32_t* __restrict__ radii, const float4* __restrict__ rec,
+                                                          const uint2* __restrict__ rect_sorted,
                                                           uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, uint32_t capacity);
 
 __global__ __launch_bounds__(256) void gp_tile_ranges_kernel(const uint32_t* __restrict__ keys, uint32_t R, uint32_t n_tiles,

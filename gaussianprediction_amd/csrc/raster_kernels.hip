@@ -219,7 +219,7 @@ __device__ __forceinline__ void preprocess_fwd_body(RasterDims d, const float* _
                                                     const float* __restrict__ cov3D_precomp, const float* __restrict__ view,
                                                     const float* __restrict__ proj, const float* __restrict__ campos,
                                                     int32_t* __restrict__ radii, float4* __restrict__ rec,
-                                                    uint32_t* __restrict__ depth_key, uint32_t* __restrict__ tiles_touched,
+                                                    uint32_t* __restrict__ depth_key, uint2* __restrict__ tiles_touched,
                                                     uint8_t* __restrict__ clamped) {
     __shared__ float s_sh[SH_MODE == 0 ? 1 : 256 * 49];
     const int tid = threadIdx.x;
@@ -232,7 +232,7 @@ __device__ __forceinline__ void preprocess_fwd_body(RasterDims d, const float* _
     if (SH_MODE != 0) __syncthreads();
     if (i >= d.N) return;
     radii[i] = 0;
-    tiles_touched[i] = 0;
+    tiles_touched[i] = make_uint2(0u, 0u);
     depth_key[i] = 0xFFFFFFFFu;
     clamped[i] = 0;
     const float px = means3D[3 * i], py = means3D[3 * i + 1], pz = means3D[3 * i + 2];
@@ -303,7 +303,8 @@ __device__ __forceinline__ void preprocess_fwd_body(RasterDims d, const float* _
     radii[i] = f2i_sat(rad_f);
     clamped[i] = cl;
     depth_key[i] = __float_as_uint(pv.z);
-    tiles_touched[i] = (uint32_t)((maxx - minx) * (maxy - miny));
+    // tile rectangle (first tile | extent, 16 bits each): the binning stage expands it without touching `rec` again
+    tiles_touched[i] = make_uint2((uint32_t)minx | ((uint32_t)miny << 16), (uint32_t)(maxx - minx) | ((uint32_t)(maxy - miny) << 16));
     rec[3 * (size_t)i + 0] = make_float4(pix, piy, -0.5f * conx, -cony);
     rec[3 * (size_t)i + 1] = make_float4(-0.5f * conz, opacities[i], pv.z, __int_as_float(i));
     rec[3 * (size_t)i + 2] = make_float4(col[0], col[1], col[2], 0.f);
@@ -314,7 +315,7 @@ __device__ __forceinline__ void preprocess_fwd_body(RasterDims d, const float* _
     const float* __restrict__ shs_rest, const float* __restrict__ colors_precomp, const float* __restrict__ cov3D_precomp, \
     const float* __restrict__ view, const float* __restrict__ proj, const float* __restrict__ campos, \
     int32_t* __restrict__ radii, float4* __restrict__ rec, uint32_t* __restrict__ depth_key, \
-    uint32_t* __restrict__ tiles_touched, uint8_t* __restrict__ clamped
+    uint2* __restrict__ tiles_touched, uint8_t* __restrict__ clamped
 #define PF_PASS d, means3D, scales, rotations, opacities, shs, shs_rest, colors_precomp, cov3D_precomp, view, proj, campos, \
     radii, rec, depth_key, tiles_touched, clamped
 __global__ __launch_bounds__(256) void gp_preprocess_fwd_kernel(PF_ARGS) { preprocess_fwd_body<0>(PF_PASS); }
@@ -336,35 +337,71 @@ __global__ __launch_bounds__(256) void gp_iota_kernel(uint32_t* __restrict__ v, 
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i < n) v[i] = (uint32_t)i;
 }
-// tiles touched, in depth order (n+1 entries, last = 0 so the exclusive scan yields the total)
+// tiles touched and tile rectangles, in depth order (counts: n+1 entries, last = 0 so the exclusive scan yields the total)
 __global__ __launch_bounds__(256) void gp_gather_tiles_kernel(const uint32_t* __restrict__ sorted_ids,
-                                                             const uint32_t* __restrict__ tiles_touched,
-                                                             uint32_t* __restrict__ out, int n) {
+                                                             const uint2* __restrict__ tiles_touched,
+                                                             uint32_t* __restrict__ out, uint2* __restrict__ rect_sorted, int n) {
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < n) out[i] = tiles_touched[sorted_ids[i]];
-    else if (i == n) out[i] = 0;
+    if (i < n) {
+        const uint2 r = tiles_touched[sorted_ids[i]];
+        rect_sorted[i] = r;
+        out[i] = (r.y & 0xFFFFu) * (r.y >> 16);
+    } else if (i == n) out[i] = 0;
 }
+// Expand every visible Gaussian into its (tile key, id) instances at offsets[i] .. (exclusive prefix sum over the depth order).
+// Wave-cooperative: the 64 Gaussians of a wave own one CONTIGUOUS run of instances, so the wave walks that run 64 entries
+// at a time -- each lane finds its entry's owner by a binary search over the wave's relative offsets (LDS) -- and every
+// store is one coalesced 256-byte line; the tile rectangles arrive in depth order from gp_gather_tiles_kernel, so nothing is
+// gathered here.  (One thread per Gaussian re-deriving its rectangle from `rec[id]` and looping over its own tiles: three
+// random gathers per Gaussian, 64-way scattered stores, and one large footprint serialising its whole wave.)
 __global__ __launch_bounds__(256) void gp_duplicate_kernel(RasterDims d, const uint32_t* __restrict__ sorted_ids,
                                                           const uint32_t* __restrict__ offsets,
-                                                          const uint32_t* __restrict__ tiles_touched,
-                                                          const int32_t* __restrict__ radii, const float4* __restrict__ rec,
+                                                          const uint2* __restrict__ rect_sorted,
                                                           uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, uint32_t capacity) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= d.N) return;
-    const uint32_t id = sorted_ids[i];
-    if (tiles_touched[id] == 0) return;
-    uint32_t off = offsets[i];
-    const float4 q0 = rec[3 * (size_t)id];
-    int minx, miny, maxx, maxy;
-    tile_rect(q0.x, q0.y, (float)radii[id], d.gx, d.gy, minx, miny, maxx, maxy);
-    for (int y = miny; y < maxy; ++y)
-        for (int x = minx; x < maxx; ++x) {
+    __shared__ int4 s_own[4][64];        // (relative offset, first tile x, first tile y, tiles per row)
+    __shared__ uint32_t s_id[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i0 = blockIdx.x * 256 + wave * 64;             // uniform per wave
+    if (i0 >= d.N) return;
+    const int i = i0 + lane;
+    uint32_t id = 0;
+    int cnt = 0, minx = 0, miny = 0, w = 1;
+    if (i < d.N) {                                           // everything is read in depth order: coalesced, no gathers
+        id = sorted_ids[i];
+        const uint2 r = rect_sorted[i];
+        minx = (int)(r.x & 0xFFFFu); miny = (int)(r.x >> 16);
+        w = (int)(r.y & 0xFFFFu);
+        cnt = w * (int)(r.y >> 16);
+        if (w < 1) w = 1;
+    }
+    const uint32_t base = offsets[i0];
+    int incl = cnt;                                          // inclusive scan of the counts over the wave
+#pragma unroll
+    for (int dlt = 1; dlt < 64; dlt <<= 1) {
+        const int t = __shfl_up(incl, dlt);
+        if (lane >= dlt) incl += t;
+    }
+    const int total = __shfl(incl, 63);
+    s_own[wave][lane] = make_int4(incl - cnt, minx, miny, w);
+    s_id[wave][lane] = id;
+    __builtin_amdgcn_wave_barrier();
+    for (int b = 0; b < total; b += 64) {
+        const int j = b + lane;
+        if (j < total) {
+            int lo = 0;                                      // the last lane whose run starts at or before j
+#pragma unroll
+            for (int step = 32; step >= 1; step >>= 1)
+                if (s_own[wave][lo + step].x <= j) lo += step;   // lo + step <= 63 always
+            const int4 o = s_own[wave][lo];
+            const int k = j - o.x;
+            const int yy = k / o.w, xx = k - yy * o.w;
+            const uint32_t off = base + (uint32_t)j;
             if (off < capacity) {       // capacity-mode overflow: the list is cut at the capacity (flagged in binning_status);
-                keys[off] = (uint32_t)(y * d.gx + x);   // every slot below it is still written, so no stale id is ever read
-                vals[off] = id;
+                keys[off] = (uint32_t)((o.z + yy) * d.gx + o.y + xx);   // every slot below it is still written: no stale id
+                vals[off] = s_id[wave][lo];
             }
-            ++off;
         }
+    }
 }
 __global__ __launch_bounds__(256) void gp_tile_ranges_kernel(const uint32_t* __restrict__ keys, uint32_t R, uint32_t n_tiles,
                                                             int2* __restrict__ ranges) {
