@@ -211,7 +211,7 @@ extern "C" int gp_raster_forward(const gp_raster_settings* st, const gp_raster_i
     hipLaunchKernelGGL(gp_tile_order_kernel, dim3(1), dim3(1024), 0, s, il.ranges, (const int32_t*)nullptr, (int)T, il.order);
     GP_LAUNCH_CHECK();
     { GpProfScope _p("composite_fwd", s, 1);
-        hipLaunchKernelGGL(gp_composite_fwd_kernel, dim3((unsigned)T), dim3(256), 0, s, d, il.ranges, point_list, gl.rec, st->bg,
+        hipLaunchKernelGGL(gp_debug_get(0) == 1 ? gp_composite_fwd_kernel : (gp_debug_get(0) == 2 ? gp_composite_fwd_sbc_kernel : gp_composite_fwd_sb_kernel), dim3((unsigned)T), dim3(256), 0, s, d, il.ranges, point_list, gl.rec, st->bg,
                        out->color, out->depth, out->tidx, il.final_T, il.n_contrib, il.order, il.tile_work,
                        point_list ? (uint8_t*)point_list + gp_align_up((size_t)R * 4, 256) : (uint8_t*)nullptr);
     GP_LAUNCH_CHECK(); }

@@ -68,6 +68,8 @@ struct GpProfScope {
     ~GpProfScope() { gp_prof_end(h, s); }
 };
 
+int gp_debug_get(int key);   // diagnostics knobs (gp_profile.hip)
+
 // ---- sub-module entry points (host side, defined in the .hip files) -----------------------------
 int gp_scan_exclusive_u32(uint32_t* data, size_t n, uint32_t* tmp, size_t tmp_elems, hipStream_t s);
 size_t gp_scan_tmp_elems(size_t n);

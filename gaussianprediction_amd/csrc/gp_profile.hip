@@ -190,3 +190,100 @@ extern "C" int gp_microbench_mfma(int dtype, int iters, float* sink, double* flo
     GP_LAUNCH_CHECK();
     return 0;
 }
+
+// ---- instruction-rate microbenchmarks ---------------------------------------------------------------------------
+// The composite kernels are bound by the vector ALU, not by HBM; what a wave64 VALU instruction costs on this part
+// (plain vs packed fp32, transcendental, DPP) decides every design choice there, so it is measured, not assumed.
+// Each kind runs 8 independent dependency chains per lane, `iters` x 8 instructions of the kind under test per chain
+// group, 4 waves per workgroup, 8 workgroups per CU (the same occupancy as the composite kernels).
+typedef float mb_f2 __attribute__((ext_vector_type(2)));
+template <int KIND>
+__global__ __launch_bounds__(256) void gp_mb_valu_kernel(int iters, float* __restrict__ sink) {
+    const float seed = 1.f + (float)(threadIdx.x & 15) * 1e-3f;
+    float r[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) r[k] = seed + (float)k * 1e-4f;
+    mb_f2 p[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) p[k] = (mb_f2){r[k], r[k] * 0.5f};
+    const float m = 0.999f, a = 1e-6f;
+    __shared__ mb_f4 s_lds[64];
+    if (KIND == 6) { if (threadIdx.x < 64) s_lds[threadIdx.x] = (mb_f4){seed, seed, seed, seed}; __syncthreads(); }
+    const uint32_t lp = (uint32_t)(uintptr_t)&s_lds[(blockIdx.x + iters) & 63];    // uniform LDS address: a broadcast read
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            if (KIND == 0) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(r[k]) : "v"(m), "v"(a));
+            if (KIND == 1) asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(p[k]) : "v"((mb_f2){m, m}), "v"((mb_f2){a, a}));
+            if (KIND == 2) asm volatile("v_exp_f32 %0, %0" : "+v"(r[k]));
+            if (KIND == 3) asm volatile("v_cmp_gt_f32 vcc, %0, %1\n\tv_cndmask_b32 %0, %0, %2, vcc" : "+v"(r[k]) : "v"(m), "v"(a) : "vcc");
+            if (KIND == 4) asm volatile("v_rcp_f32 %0, %0" : "+v"(r[k]));
+            if (KIND == 5) asm volatile("v_add_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(r[k]));
+            if (KIND == 6) { mb_f4 t; asm volatile("ds_read_b128 %0, %1" : "=v"(t) : "v"(lp)); asm volatile("s_waitcnt lgkmcnt(8)"); r[k] += 0.f * t.x; }
+            if (KIND == 7) asm volatile("v_min_f32 %0, %0, %1" : "+v"(r[k]) : "v"(m));
+            if (KIND == 8) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(p[k]) : "v"((mb_f2){m, m}));
+            if (KIND == 9) asm volatile("v_sqrt_f32 %0, %0" : "+v"(r[k]));
+        }
+    }
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t += r[k] + p[k].x + p[k].y;
+    if (t == 123456.789f) sink[0] = t;
+}
+
+extern "C" int gp_microbench_valu(int kind, int iters, float* sink, double* instr_out, void* stream) {
+    if (!sink || iters <= 0 || kind < 0 || kind > 9) GP_FAIL("gp_microbench_valu: kind 0..9, iters > 0, sink required");
+    hipStream_t s = (hipStream_t)stream;
+    const int grid = mb_grid();
+    // wave-instructions of the kind under test (kind 3 issues two VALU instructions per slot)
+    if (instr_out) *instr_out = 8.0 * (double)iters * 4.0 /*waves*/ * (double)grid * (kind == 3 ? 2.0 : 1.0);
+    static const char* names[10] = {"mb_valu_fma", "mb_valu_pk_fma", "mb_valu_exp", "mb_valu_cmp_cndmask", "mb_valu_rcp",
+                                    "mb_valu_dpp_add", "mb_lds_read_b128", "mb_valu_min", "mb_valu_pk_mul", "mb_valu_sqrt"};
+    {
+        GpProfScope _p(names[kind], s, 1);
+        switch (kind) {
+#define MBV(K) case K: hipLaunchKernelGGL(gp_mb_valu_kernel<K>, dim3(grid), dim3(256), 0, s, iters, sink); break;
+            MBV(0) MBV(1) MBV(2) MBV(3) MBV(4) MBV(5) MBV(6) MBV(7) MBV(8) MBV(9)
+#undef MBV
+        }
+    }
+    GP_LAUNCH_CHECK();
+    return 0;
+}
+
+// Random gather: every thread reads rec_bytes (16 / 48 / 64) at record idx[i] of `src` -- the access shape of the
+// composite kernels' record fetch.  Run under `rocprofv3 --pmc` it calibrates the FETCH_SIZE correction for gathers
+// (the x2 figure was calibrated on a streaming kernel); bracketed as "mb_gather".
+__global__ __launch_bounds__(256) void gp_mb_gather_kernel(const mb_f4* __restrict__ src, const uint32_t* __restrict__ idx, size_t n_idx,
+                                                           int vecs, int stride_vecs, float* __restrict__ sink) {
+    const size_t stride = (size_t)gridDim.x * 256;
+    mb_f4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n_idx; i += stride) {
+        const mb_f4* p = src + (size_t)idx[i] * stride_vecs;
+        for (int v = 0; v < vecs; ++v) acc += p[v];
+    }
+    const float t = acc.x + acc.y + acc.z + acc.w;
+    if (t == 123456.789f) sink[0] = t;
+}
+extern "C" int gp_microbench_gather(const void* src, int rec_bytes, int stride_bytes, const uint32_t* idx, size_t n_idx, float* sink,
+                                    void* stream) {
+    if (!src || !idx || !sink || (rec_bytes & 15) || rec_bytes <= 0 || (stride_bytes & 15) || stride_bytes < rec_bytes || ((uintptr_t)src & 15))
+        GP_FAIL("gp_microbench_gather: 16-byte multiples and aligned source required");
+    hipStream_t s = (hipStream_t)stream;
+    {
+        GpProfScope _p("mb_gather", s, 1);
+        hipLaunchKernelGGL(gp_mb_gather_kernel, dim3(mb_grid()), dim3(256), 0, s, (const mb_f4*)src, idx, n_idx, rec_bytes / 16,
+                           stride_bytes / 16, sink);
+    }
+    GP_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- diagnostics knobs (A/B selection of kernel variants while profiling; 0 = the shipped default everywhere) -----
+static int g_debug_opt[16] = {0};
+int gp_debug_get(int key) { return (key >= 0 && key < 16) ? g_debug_opt[key] : 0; }
+extern "C" int gp_debug_option(int key, int value) {
+    if (key < 0 || key >= 16) GP_FAIL("gp_debug_option: key 0..15");
+    g_debug_opt[key] = value;
+    return 0;
+}

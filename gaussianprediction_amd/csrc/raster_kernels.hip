@@ -646,6 +646,305 @@ __global__ __launch_bounds__(CF_THREADS) void gp_composite_fwd_kernel(RasterDims
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// composite forward, sub-block lists (the shipped kernel; gp_composite_fwd_kernel above is kept as the A/B baseline
+// behind gp_debug_option(0, 1)).
+//
+// Measured on MI355X the quadrant kernel above is bound by the vector ALU (41 issue slots per wave-visit x 4 cycles
+// x 3.2 M wave-visits = its whole 0.22 ms), with only one lane in three contributing: a splat that touches an 8x8
+// quadrant reaches alpha >= 1/255 on a third of its pixels.  This kernel culls at 4x4 granularity instead:
+//   * a tile is 4 x 4 sub-blocks (SB) of 4 x 4 pixels; wave w still owns quadrant w, but its four 16-lane groups are
+//     the quadrant's four SBs, and EACH GROUP WALKS ITS OWN LIST of the batch's splats (lists in LDS as byte offsets
+//     of the staged records, so a visit is one ds_read_u16 + three record reads at up to four distinct addresses);
+//   * the staging lane derives the exact 16-bit SB mask of its splat from four row strips: over the strip
+//     dy in [d0, d0 + 3] the alpha >= 1/255 ellipse spans x in [c(dl) - h(dl), c(dr) + h(dr)], where dr / dl are the
+//     strip's points nearest to the ellipse's rightmost / leftmost point -- two sqrt per strip, about the cost of the
+//     four rectangle tests it replaces;
+//   * 'done' and 'list exhausted' are ONE per-lane limit (i < lim), so a visit carries one compare for both.
+// Wave-steps per tile drop from 4 x 146 to 4 x 96 (lock-step over four lists costs 14 % against ideal 4x4 culling) and
+// a visit from 41 to 29 VALU slots.  The arithmetic per (pixel, splat) is unchanged, expression for expression, so the
+// outputs are bit-identical to the quadrant kernel's.
+// ------------------------------------------------------------------------------------------------
+#define CF2_REC 48            // bytes per staged record: (x, y, A, B) (C, opacity, r, g) (b, depth, -, -)
+__device__ __forceinline__ uint32_t gp_sb_mask(const float4 q0, const float4 q1, float X0, float Y0) {
+    const float mx = q0.x - X0, my = q0.y - Y0;                  // centre in tile-local pixel coordinates
+    const float cx = -2.f * q0.z, cy = -q0.w, cz = -2.f * q1.x;
+    const float det = cx * cz - cy * cy;
+    const float tau = __logf(255.f * q1.y);
+    if (!(tau > 0.f)) return 0u;                                 // opacity < 1/255: alpha never reaches the threshold
+    if (!(det > 0.f && cx > 0.f && cz > 0.f)) return 0xFFFFu;    // degenerate conic: do not cull
+    const float tt = 2.f * tau * 1.004f + 0.02f;                 // q <= tt, with slack for the rounding of power / exp / log
+    const float ex = sqrtf(tt * cz / det);                       // half extent in x; rightmost point at dy = -(cy / cz) ex
+    if (!(ex <= 1e8f)) return 0xFFFFu;
+    const float inv_cx = 1.f / cx, rxy = -cy * inv_cx;           // centre line of the row spans: c(dy) = rxy dy
+    const float dyr = -(cy / cz) * ex;
+    const float ctt = cx * tt;
+    uint32_t mask = 0u;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const float d0 = (float)(4 * s) - my, d1 = d0 + 3.f;
+        const float dr = fminf(fmaxf(dyr, d0), d1), dl = fminf(fmaxf(-dyr, d0), d1);
+        const float Dr = ctt - det * dr * dr, Dl = ctt - det * dl * dl;
+        if (Dr < 0.f || Dl < 0.f) continue;                      // the strip misses the ellipse's y range
+        const float xr = mx + rxy * dr + sqrtf(Dr) * inv_cx + 0.01f;
+        const float xl = mx + rxy * dl - sqrtf(Dl) * inv_cx - 0.01f;
+        // column k covers pixel centres 4k .. 4k + 3
+        const int k_hi = (int)floorf(fminf(xr, 15.5f) * 0.25f + 8.f) - 8;          // floor(xr / 4), clamped, no negative-int pitfalls
+        const int k_lo = (int)ceilf(fminf(fmaxf(xl - 3.f, 0.f), 16.f) * 0.25f);    // ceil((xl - 3) / 4), clamped to 0 .. 4
+        if (xr >= 0.f && k_lo <= k_hi) mask |= (((2u << k_hi) - 1u) & ~((1u << k_lo) - 1u)) << (4 * s);
+    }
+    return mask;
+}
+
+template <bool ASM>
+__device__ __forceinline__ void gp_composite_fwd_sb_body(RasterDims d, const int2* __restrict__ ranges,
+                                                                         const uint32_t* __restrict__ point_list,
+                                                                         const float4* __restrict__ rec,
+                                                                         const float* __restrict__ bg,
+                                                                         float* __restrict__ out_color,
+                                                                         float* __restrict__ out_depth,
+                                                                         int32_t* __restrict__ out_tidx,
+                                                                         float* __restrict__ final_T,
+                                                                         int32_t* __restrict__ n_contrib,
+                                                                         const uint32_t* __restrict__ order,
+                                                                         int32_t* __restrict__ tile_work,
+                                                                         uint8_t* __restrict__ qmask) {
+    __shared__ __attribute__((aligned(16))) unsigned char s_rec[CF_THREADS * CF2_REC];
+    __shared__ unsigned short s_list[16][CF_THREADS];    // per SB: byte offsets of the batch's records that touch it, in depth order
+    __shared__ int s_cnt[4][16];                         // [staging wave][SB]
+    __shared__ int s_off[4][16];                         // exclusive prefix over the staging waves
+    __shared__ int s_tot[16];
+    __shared__ int s_done[4];
+    __shared__ int s_last[4];
+    const int tile = order ? (int)order[blockIdx.x] : (int)blockIdx.x;
+    const int tx = tile % d.gx, ty = tile / d.gx;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // wave = quadrant, 16-lane group = 4x4 sub-block of the quadrant
+    const int grp = lane >> 4;
+    const int sbx = 2 * (wave & 1) + (grp & 1), sby = 2 * (wave >> 1) + (grp >> 1);
+    const int mysb = sby * 4 + sbx;
+    const int px = tx * GP_TILE + sbx * 4 + (lane & 3);
+    const int py = ty * GP_TILE + sby * 4 + ((lane >> 2) & 3);
+    const float pxf = (float)px, pyf = (float)py;
+    const int2 range = ranges[tile];
+    float T = 1.f, best = 0.f;
+    int best_pos = -1, last = -1;                        // list positions x CF2_REC (tile-relative), -1 = none
+    const bool inside = px < d.W && py < d.H;
+    int lim = inside ? 0 : -1;                           // < 0: this pixel is finished (or outside the image)
+    if (tid < 4) s_done[tid] = 0;
+    {   // every list entry is a valid record offset at all times (lanes past their list's end read them, masked)
+        uint4* z = (uint4*)&s_list[0][0];
+        z[tid] = make_uint4(0u, 0u, 0u, 0u);
+        z[tid + CF_THREADS] = make_uint4(0u, 0u, 0u, 0u);
+    }
+    const float X0 = (float)(tx * GP_TILE), Y0 = (float)(ty * GP_TILE);
+    const unsigned short* lst = s_list[mysb];
+    v2f C01 = {0.f, 0.f}, C2D = {0.f, 0.f};              // (C0, C1), (C2, depth): the packed accumulators of the asm path
+
+    for (int base = range.x; base < range.y; base += CF_THREADS) {
+        __syncthreads();
+        if (s_done[0] && s_done[1] && s_done[2] && s_done[3]) break;
+        const int k = base + tid;
+        uint32_t rel = 0u;
+        if (k < range.y) {
+            const uint32_t id = point_list[k];
+            const float4 q0 = rec[3 * (size_t)id], q1 = rec[3 * (size_t)id + 1], q2 = rec[3 * (size_t)id + 2];
+            float4* dst = (float4*)(s_rec + tid * CF2_REC);
+            dst[0] = q0;
+            dst[1] = make_float4(q1.x, q1.y, q2.x, q2.y);
+            *(float2*)(dst + 2) = make_float2(q2.z, q1.z);
+            rel = gp_sb_mask(q0, q1, X0, Y0);
+            qmask[k] = (uint8_t)(((rel & 0x0033u) ? 1u : 0u) | ((rel & 0x00CCu) ? 2u : 0u) | ((rel & 0x3300u) ? 4u : 0u) | ((rel & 0xCC00u) ? 8u : 0u));
+        }
+        unsigned long long bal[16];
+        int mycnt = 0;
+#pragma unroll
+        for (int sb = 0; sb < 16; ++sb) {
+            bal[sb] = __ballot((rel >> sb) & 1u);
+            const int c = (int)__popcll(bal[sb]);
+            if (lane == sb) mycnt = c;
+        }
+        if (lane < 16) s_cnt[wave][lane] = mycnt;
+        __syncthreads();
+        if (lane < 16) {
+            int off = 0;
+            for (int w = 0; w < wave; ++w) off += s_cnt[w][lane];
+            s_off[wave][lane] = off;
+            if (wave == 3) s_tot[lane] = off + mycnt;
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int sb = 0; sb < 16; ++sb) {
+            if ((rel >> sb) & 1u) s_list[sb][s_off[wave][sb] + (int)gp_mbcnt(bal[sb])] = (unsigned short)(tid * CF2_REC);
+        }
+        __syncthreads();
+        if (__any(lim >= 0)) {
+            const int tot = s_tot[mysb];
+            lim = lim < 0 ? -1 : tot;
+            const int nmax = max(max(__builtin_amdgcn_readlane(tot, 0), __builtin_amdgcn_readlane(tot, 16)),
+                                 max(__builtin_amdgcn_readlane(tot, 32), __builtin_amdgcn_readlane(tot, 48)));
+            const int sbase = (base - range.x) * CF2_REC;
+            if (ASM) {
+                // Four visits per block, hand-scheduled: the compiler's version of this loop carries 37 VALU slots per visit
+                // (flag bytes, moves, duplicated compares); this one carries 29.  Temporaries and the two record buffers are
+                // fixed registers v36 .. v65 (clobbered); LDS returns in order, so `s_waitcnt lgkmcnt(3)` = "the older record
+                // buffer is complete" while the younger one is still in flight.  exec is restored before leaving.
+                uint32_t lp = (uint32_t)(uintptr_t)lst;
+#pragma unroll 1
+                for (int i0 = 0; i0 < nmax; i0 += 4, lp += 8) {
+                    unsigned long long sv, am;
+                    int sk;
+#define CF2_VISIT(K, X, Y, A_, B_, C_, OP, RG, BD, OFF)                                                             \
+    "s_add_i32 %[sk], %[i0], " #K "\n\t"                                                                            \
+    "v_cmp_lt_i32 vcc, %[sk], %[lim]\n\t"                                                                           \
+    "s_and_b64 exec, %[sv], vcc\n\t"                                                                                \
+    "s_cbranch_execz 1" #K "f\n\t"                                                                                  \
+    "v_sub_f32 v60, " X ", %[pxf]\n\t"                                                                              \
+    "v_sub_f32 v61, " Y ", %[pyf]\n\t"                                                                              \
+    "v_mul_f32 v62, " B_ ", v61\n\t"                                                                                \
+    "v_fmac_f32 v62, " A_ ", v60\n\t"                                                                               \
+    "v_mul_f32 v63, " C_ ", v61\n\t"                                                                                \
+    "v_mul_f32 v63, v63, v61\n\t"                                                                                   \
+    "v_fmac_f32 v63, v60, v62\n\t"                                                                                  \
+    "v_cmp_nlt_f32 vcc, 0, v63\n\t"                                                                                 \
+    "s_and_b64 exec, exec, vcc\n\t"                                                                                 \
+    "v_mul_f32 v63, 0x3fb8aa3b, v63\n\t"                                                                            \
+    "v_exp_f32 v63, v63\n\t"                                                                                        \
+    "s_nop 0\n\t"                                                                                                   \
+    "v_mul_f32 v63, " OP ", v63\n\t"                                                                                \
+    "v_min_f32 v63, 0x3f7d70a4, v63\n\t"                                                                            \
+    "v_cmp_ngt_f32 vcc, 0x3b808081, v63\n\t"                                                                        \
+    "s_and_b64 exec, exec, vcc\n\t"                                                                                 \
+    "s_cbranch_execz 1" #K "f\n\t"                                                                                  \
+    "v_sub_f32 v62, 1.0, v63\n\t"                                                                                   \
+    "v_mul_f32 v62, %[T], v62\n\t"                                                                                  \
+    "v_cmp_ngt_f32 vcc, 0x38d1b717, v62\n\t"                                                                        \
+    "v_cndmask_b32 %[lim], -1, %[lim], vcc\n\t"                                                                     \
+    "s_and_b64 exec, exec, vcc\n\t"                                                                                 \
+    "v_mul_f32 v64, v63, %[T]\n\t"                                                                                  \
+    "v_add_u32 %[last], %[sbase], " OFF "\n\t"                                                                      \
+    "v_cmp_gt_f32 vcc, v64, %[best]\n\t"                                                                            \
+    "v_pk_fma_f32 %[C01], " RG ", v[64:65], %[C01] op_sel_hi:[1,0,1]\n\t"                                           \
+    "v_pk_fma_f32 %[C2D], " BD ", v[64:65], %[C2D] op_sel_hi:[1,0,1]\n\t"                                           \
+    "v_cndmask_b32 %[best], %[best], v64, vcc\n\t"                                                                  \
+    "v_cndmask_b32 %[bpos], %[bpos], %[last], vcc\n\t"                                                              \
+    "v_mov_b32 %[T], v62\n\t"                                                                                       \
+    "1" #K ":\n\t"                                                                                                  \
+    "s_mov_b64 exec, %[sv]\n\t"
+#define CF2_VISIT_A(K, OFF) CF2_VISIT(K, "v36", "v37", "v38", "v39", "v40", "v41", "v[42:43]", "v[44:45]", OFF)
+#define CF2_VISIT_B(K, OFF) CF2_VISIT(K, "v46", "v47", "v48", "v49", "v50", "v51", "v[52:53]", "v[54:55]", OFF)
+                    asm volatile(
+                        "s_mov_b64 %[sv], exec\n\t"
+                        "ds_read_u16 v56, %[lp]\n\t"
+                        "ds_read_u16 v57, %[lp] offset:2\n\t"
+                        "ds_read_u16 v58, %[lp] offset:4\n\t"
+                        "ds_read_u16 v59, %[lp] offset:6\n\t"
+                        "s_waitcnt lgkmcnt(2)\n\t"
+                        "ds_read_b128 v[36:39], v56\n\t"
+                        "ds_read_b128 v[40:43], v56 offset:16\n\t"
+                        "ds_read_b64 v[44:45], v56 offset:32\n\t"
+                        "ds_read_b128 v[46:49], v57\n\t"
+                        "ds_read_b128 v[50:53], v57 offset:16\n\t"
+                        "ds_read_b64 v[54:55], v57 offset:32\n\t"
+                        "s_waitcnt lgkmcnt(3)\n\t"
+                        CF2_VISIT_A(0, "v56")
+                        "ds_read_b128 v[36:39], v58\n\t"
+                        "ds_read_b128 v[40:43], v58 offset:16\n\t"
+                        "ds_read_b64 v[44:45], v58 offset:32\n\t"
+                        "s_waitcnt lgkmcnt(3)\n\t"
+                        CF2_VISIT_B(1, "v57")
+                        "ds_read_b128 v[46:49], v59\n\t"
+                        "ds_read_b128 v[50:53], v59 offset:16\n\t"
+                        "ds_read_b64 v[54:55], v59 offset:32\n\t"
+                        "s_waitcnt lgkmcnt(3)\n\t"
+                        CF2_VISIT_A(2, "v58")
+                        "s_waitcnt lgkmcnt(0)\n\t"
+                        CF2_VISIT_B(3, "v59")
+                        "s_add_i32 %[sk], %[i0], 4\n\t"
+                        "v_cmp_lt_i32 vcc, %[sk], %[lim]\n\t"
+                        "s_mov_b64 %[am], vcc\n\t"
+                        : [T] "+v"(T), [C01] "+v"(C01), [C2D] "+v"(C2D), [best] "+v"(best), [bpos] "+v"(best_pos), [last] "+v"(last),
+                          [lim] "+v"(lim), [sv] "=&s"(sv), [am] "=&s"(am), [sk] "=&s"(sk)
+                        : [pxf] "v"(pxf), [pyf] "v"(pyf), [lp] "v"(lp), [i0] "s"(__builtin_amdgcn_readfirstlane(i0)), [sbase] "s"(__builtin_amdgcn_readfirstlane(sbase))
+                        : "vcc", "scc", "memory", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47",
+                          "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63",
+                          "v64", "v65");
+#undef CF2_VISIT_A
+#undef CF2_VISIT_B
+#undef CF2_VISIT
+                    if (am == 0ull) break;
+                }
+            } else {
+#pragma unroll 1
+                for (int i = 0; i < nmax; ++i) {
+                    const bool act = i < lim;
+                    if (!__any(act)) break;
+                    if (act) {
+                        const int off = (int)lst[i];
+                        const float4 q0 = *(const float4*)(s_rec + off);
+                        const float4 q1 = *(const float4*)(s_rec + off + 16);
+                        const float2 q2 = *(const float2*)(s_rec + off + 32);
+                        const float dx = q0.x - pxf, dy = q0.y - pyf;
+                        const float power = fmaf(dx, fmaf(q0.z, dx, q0.w * dy), (q1.x * dy) * dy);
+                        if (!(power > 0.f)) {
+                            const float alpha = fminf(0.99f, q1.y * gp_exp(power));
+                            if (!(alpha < 1.f / 255.f)) {
+                                const float test_T = T * (1.f - alpha);
+                                if (test_T < 0.0001f) {
+                                    lim = -1;
+                                } else {
+                                    const float w = alpha * T;
+                                    const int posv = off + sbase;
+                                    C01.x = fmaf(q1.z, w, C01.x);
+                                    C01.y = fmaf(q1.w, w, C01.y);
+                                    C2D.x = fmaf(q2.x, w, C2D.x);
+                                    C2D.y = fmaf(q2.y, w, C2D.y);
+                                    if (w > best) { best = w; best_pos = posv; }
+                                    T = test_T;
+                                    last = posv;
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+            if (!__any(lim >= 0) && lane == 0) s_done[wave] = 1;
+        }
+    }
+    const float C0 = C01.x, C1 = C01.y, C2 = C2D.x, Dp = C2D.y;
+    const size_t HW = (size_t)d.H * d.W;
+    const int last_n = last < 0 ? 0 : last / CF2_REC + 1;          // 1-based position of the last contributor in the tile list
+    if (inside) {
+        const size_t pix = (size_t)py * d.W + px;
+        out_color[pix] = fmaf(T, bg[0], C0);
+        out_color[HW + pix] = fmaf(T, bg[1], C1);
+        out_color[2 * HW + pix] = fmaf(T, bg[2], C2);
+        out_depth[pix] = Dp;
+        out_tidx[pix] = best_pos < 0 ? -1 : (int32_t)point_list[range.x + best_pos / CF2_REC];
+        final_T[pix] = T;
+        n_contrib[pix] = last_n;
+    }
+    if (tile_work) {   // largest list position any pixel of the tile consumed: the backward's work estimate
+        int mx = inside ? last_n : 0;
+#pragma unroll
+        for (int dd = 32; dd >= 1; dd >>= 1) mx = max(mx, __shfl_xor(mx, dd));
+        if (lane == 0) s_last[wave] = mx;
+        __syncthreads();
+        if (tid == 0) tile_work[tile] = max(max(s_last[0], s_last[1]), max(s_last[2], s_last[3]));
+    }
+}
+#define CF2_ARGS RasterDims d, const int2* __restrict__ ranges, const uint32_t* __restrict__ point_list, const float4* __restrict__ rec, \
+    const float* __restrict__ bg, float* __restrict__ out_color, float* __restrict__ out_depth, int32_t* __restrict__ out_tidx, \
+    float* __restrict__ final_T, int32_t* __restrict__ n_contrib, const uint32_t* __restrict__ order, int32_t* __restrict__ tile_work, \
+    uint8_t* __restrict__ qmask
+__global__ __launch_bounds__(CF_THREADS) void gp_composite_fwd_sb_kernel(CF2_ARGS) {
+    gp_composite_fwd_sb_body<true>(d, ranges, point_list, rec, bg, out_color, out_depth, out_tidx, final_T, n_contrib, order, tile_work, qmask);
+}
+__global__ __launch_bounds__(CF_THREADS) void gp_composite_fwd_sbc_kernel(CF2_ARGS) {   // compiler-scheduled inner loop (A/B reference)
+    gp_composite_fwd_sb_body<false>(d, ranges, point_list, rec, bg, out_color, out_depth, out_tidx, final_T, n_contrib, order, tile_work, qmask);
+}
+
 // ------------------------------------------------------------------------------------------------
 // composite backward, SPLAT-parallel.  One wave per (tile, 8x8 quadrant).  Lanes own the 64 splats of the
 // current batch (record in registers) and the wave walks the quadrant's pixels uniformly, two at a time with

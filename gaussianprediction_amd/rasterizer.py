@@ -279,7 +279,9 @@ def raster_forward_debug(raster_settings, means3D, opacities, shs=None, colors_p
         geom = alloc.first(_lib.GP_BUF_GEOM)
         rec = geom[:48 * N].view(torch.float32).view(N, 12).clone() if (geom is not None and N > 0) else None
         img = alloc.first(_lib.GP_BUF_IMAGE)
-        n_contrib = img[8 * T + 4 * H * W:8 * T + 8 * H * W].view(torch.int32).view(H, W).clone() if img is not None else None
+        al = lambda v: (v + 255) // 256 * 256                     # ImageLayout of gp_capi_raster.hip: 256-byte aligned arrays
+        nc_off = al(al(8 * T) + 4 * H * W)
+        n_contrib = img[nc_off:nc_off + 4 * H * W].view(torch.int32).view(H, W).clone() if img is not None else None
         alloc.release()
     return dict(color=color, radii=radii, depth=depth, tidx=tidx, R=R, point_list=point_list[:R], ranges=ranges, rec=rec,
                 n_contrib=n_contrib)

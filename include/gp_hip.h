@@ -328,6 +328,18 @@ int gp_profile_collect(gp_profile_entry* out, int max_entries, int* n_out);
 int gp_microbench_copy(void* dst, const void* src, size_t bytes, gp_stream_t stream);
 int gp_microbench_read(const void* src, size_t bytes, float* sink, gp_stream_t stream);
 int gp_microbench_mfma(int dtype, int iters, float* sink, double* flop_out, gp_stream_t stream);
+/* Instruction-rate microbenchmarks: 8 independent chains per lane of ONE instruction kind, 4 waves x 8 workgroups per CU
+ * (the occupancy of the composite kernels); *instr_out = wave-instructions of that kind enqueued.  kind: 0 v_fma_f32,
+ * 1 v_pk_fma_f32, 2 v_exp_f32, 3 v_cmp_f32 + v_cndmask_b32 (two instructions), 4 v_rcp_f32, 5 v_add_f32_dpp, 6 broadcast
+ * ds_read_b128, 7 v_min_f32, 8 v_pk_mul_f32, 9 v_sqrt_f32.  Bracketed as "mb_valu_*" / "mb_lds_read_b128". */
+int gp_microbench_valu(int kind, int iters, float* sink, double* instr_out, gp_stream_t stream);
+/* Random gather (the record fetch of the composite kernels): thread i reads rec_bytes at src + idx[i] * stride_bytes.
+ * Bracketed as "mb_gather"; run under `rocprofv3 --pmc FETCH_SIZE` it calibrates the counter for this access shape. */
+int gp_microbench_gather(const void* src, int rec_bytes, int stride_bytes, const uint32_t* idx, size_t n_idx, float* sink,
+                         gp_stream_t stream);
+/* Diagnostics: select a kernel variant for A/B profiling (key 0: composite forward, key 1: composite backward; value 0 =
+ * the shipped default).  Never needed by a caller of the render path. */
+int gp_debug_option(int key, int value);
 
 const char* gp_last_error(void);
 const char* gp_version(void);
