@@ -668,6 +668,8 @@ __global__ __launch_bounds__(CF_THREADS) void gp_composite_fwd_kernel(RasterDims
 // ------------------------------------------------------------------------------------------------
 #define CF2_REC 48            // bytes per staged record: (x, y, A, B) (C, opacity, r, g) (b, depth, -, -)
 __device__ __forceinline__ uint32_t gp_sb_mask(const float4 q0, const float4 q1, float X0, float Y0) {
+    // hardware rcp / sqrt / log (about 1 ulp) instead of the correctly rounded sequences (10 - 15 instructions each): the test
+    // carries 0.4 % + 0.02 of slack on q and 0.01 px on the spans, orders of magnitude above their error
     const float mx = q0.x - X0, my = q0.y - Y0;                  // centre in tile-local pixel coordinates
     const float cx = -2.f * q0.z, cy = -q0.w, cz = -2.f * q1.x;
     const float det = cx * cz - cy * cy;
@@ -675,24 +677,26 @@ __device__ __forceinline__ uint32_t gp_sb_mask(const float4 q0, const float4 q1,
     if (!(tau > 0.f)) return 0u;                                 // opacity < 1/255: alpha never reaches the threshold
     if (!(det > 0.f && cx > 0.f && cz > 0.f)) return 0xFFFFu;    // degenerate conic: do not cull
     const float tt = 2.f * tau * 1.004f + 0.02f;                 // q <= tt, with slack for the rounding of power / exp / log
-    const float ex = sqrtf(tt * cz / det);                       // half extent in x; rightmost point at dy = -(cy / cz) ex
+    const float ex = __builtin_amdgcn_sqrtf(tt * cz * __builtin_amdgcn_rcpf(det));   // half extent in x; rightmost point at dy = -(cy / cz) ex
     if (!(ex <= 1e8f)) return 0xFFFFu;
-    const float inv_cx = 1.f / cx, rxy = -cy * inv_cx;           // centre line of the row spans: c(dy) = rxy dy
-    const float dyr = -(cy / cz) * ex;
+    const float inv_cx = __builtin_amdgcn_rcpf(cx), rxy = -cy * inv_cx;              // centre line of the row spans: c(dy) = rxy dy
+    const float dyr = -(cy * __builtin_amdgcn_rcpf(cz)) * ex;
     const float ctt = cx * tt;
     uint32_t mask = 0u;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
         const float d0 = (float)(4 * s) - my, d1 = d0 + 3.f;
-        const float dr = fminf(fmaxf(dyr, d0), d1), dl = fminf(fmaxf(-dyr, d0), d1);
-        const float Dr = ctt - det * dr * dr, Dl = ctt - det * dl * dl;
-        if (Dr < 0.f || Dl < 0.f) continue;                      // the strip misses the ellipse's y range
-        const float xr = mx + rxy * dr + sqrtf(Dr) * inv_cx + 0.01f;
-        const float xl = mx + rxy * dl - sqrtf(Dl) * inv_cx - 0.01f;
+        const float dr = __builtin_amdgcn_fmed3f(dyr, d0, d1), dl = __builtin_amdgcn_fmed3f(-dyr, d0, d1);
+        const float Dr = fmaf(-det * dr, dr, ctt), Dl = fmaf(-det * dl, dl, ctt);
+        // (either discriminant < 0: the strip misses the ellipse's y range)
+        const float xr = fmaf(__builtin_amdgcn_sqrtf(fmaxf(Dr, 0.f)), inv_cx, fmaf(rxy, dr, mx + 0.01f));
+        const float xl = fmaf(-__builtin_amdgcn_sqrtf(fmaxf(Dl, 0.f)), inv_cx, fmaf(rxy, dl, mx - 0.01f));
         // column k covers pixel centres 4k .. 4k + 3
-        const int k_hi = (int)floorf(fminf(xr, 15.5f) * 0.25f + 8.f) - 8;          // floor(xr / 4), clamped, no negative-int pitfalls
-        const int k_lo = (int)ceilf(fminf(fmaxf(xl - 3.f, 0.f), 16.f) * 0.25f);    // ceil((xl - 3) / 4), clamped to 0 .. 4
-        if (xr >= 0.f && k_lo <= k_hi) mask |= (((2u << k_hi) - 1u) & ~((1u << k_lo) - 1u)) << (4 * s);
+        const float khf = floorf(fminf(xr, 15.5f) * 0.25f);                       // floor(xr / 4) <= 3
+        const float klf = ceilf(__builtin_amdgcn_fmed3f(xl - 3.f, 0.f, 16.f) * 0.25f);   // ceil((xl - 3) / 4) in 0 .. 4
+        const bool hit = fminf(Dr, Dl) >= 0.f && xr >= 0.f && klf <= khf;         // (hit => 0 <= k_lo <= k_hi <= 3)
+        const uint32_t bits = (2u << ((int)khf & 3)) - (1u << ((int)klf & 7));    // bits k_lo .. k_hi
+        if (hit) mask |= bits << (4 * s);
     }
     return mask;
 }
@@ -759,11 +763,14 @@ __device__ __forceinline__ void gp_composite_fwd_sb_body(RasterDims d, const int
         }
         unsigned long long bal[16];
         int mycnt = 0;
-#pragma unroll
-        for (int sb = 0; sb < 16; ++sb) {
-            bal[sb] = __ballot((rel >> sb) & 1u);
-            const int c = (int)__popcll(bal[sb]);
-            if (lane == sb) mycnt = c;
+        {   // ballot of bit sb for all 16 SBs: shifting the mask out through the carry flag costs ONE VALU instruction per ballot
+            uint32_t sh = rel << 16;
+#define CF2_BAL(SB)                                                                                         \
+    asm("v_add_co_u32 %0, %1, %0, %0" : "+v"(sh), "=s"(bal[SB]));                                           \
+    asm("v_writelane_b32 %0, %1, " #SB : "+v"(mycnt) : "s"((int)__popcll(bal[SB])));
+            CF2_BAL(15) CF2_BAL(14) CF2_BAL(13) CF2_BAL(12) CF2_BAL(11) CF2_BAL(10) CF2_BAL(9) CF2_BAL(8)
+            CF2_BAL(7) CF2_BAL(6) CF2_BAL(5) CF2_BAL(4) CF2_BAL(3) CF2_BAL(2) CF2_BAL(1) CF2_BAL(0)
+#undef CF2_BAL
         }
         if (lane < 16) s_cnt[wave][lane] = mycnt;
         __syncthreads();
@@ -788,88 +795,93 @@ __device__ __forceinline__ void gp_composite_fwd_sb_body(RasterDims d, const int
             if (ASM) {
                 // Four visits per block, hand-scheduled: the compiler's version of this loop carries 37 VALU slots per visit
                 // (flag bytes, moves, duplicated compares); this one carries 29.  Temporaries and the two record buffers are
-                // fixed registers v36 .. v65 (clobbered); LDS returns in order, so `s_waitcnt lgkmcnt(3)` = "the older record
+                // fixed registers v24 .. v53 (clobbered); LDS returns in order, so `s_waitcnt lgkmcnt(3)` = "the older record
                 // buffer is complete" while the younger one is still in flight.  exec is restored before leaving.
                 uint32_t lp = (uint32_t)(uintptr_t)lst;
 #pragma unroll 1
                 for (int i0 = 0; i0 < nmax; i0 += 4, lp += 8) {
-                    unsigned long long sv, am;
+                    unsigned long long sv, am, sd;
                     int sk;
 #define CF2_VISIT(K, X, Y, A_, B_, C_, OP, RG, BD, OFF)                                                             \
     "s_add_i32 %[sk], %[i0], " #K "\n\t"                                                                            \
     "v_cmp_lt_i32 vcc, %[sk], %[lim]\n\t"                                                                           \
     "s_and_b64 exec, %[sv], vcc\n\t"                                                                                \
     "s_cbranch_execz 1" #K "f\n\t"                                                                                  \
-    "v_sub_f32 v60, " X ", %[pxf]\n\t"                                                                              \
-    "v_sub_f32 v61, " Y ", %[pyf]\n\t"                                                                              \
-    "v_mul_f32 v62, " B_ ", v61\n\t"                                                                                \
-    "v_fmac_f32 v62, " A_ ", v60\n\t"                                                                               \
-    "v_mul_f32 v63, " C_ ", v61\n\t"                                                                                \
-    "v_mul_f32 v63, v63, v61\n\t"                                                                                   \
-    "v_fmac_f32 v63, v60, v62\n\t"                                                                                  \
-    "v_cmp_nlt_f32 vcc, 0, v63\n\t"                                                                                 \
+    "v_sub_f32 v48, " X ", %[pxf]\n\t"                                                                              \
+    "v_sub_f32 v49, " Y ", %[pyf]\n\t"                                                                              \
+    "v_mul_f32 v50, " B_ ", v49\n\t"                                                                                \
+    "v_fmac_f32 v50, " A_ ", v48\n\t"                                                                               \
+    "v_mul_f32 v51, " C_ ", v49\n\t"                                                                                \
+    "v_mul_f32 v51, v51, v49\n\t"                                                                                   \
+    "v_fmac_f32 v51, v48, v50\n\t"                                                                                  \
+    "v_cmp_nlt_f32 vcc, 0, v51\n\t"                                                                                 \
     "s_and_b64 exec, exec, vcc\n\t"                                                                                 \
-    "v_mul_f32 v63, 0x3fb8aa3b, v63\n\t"                                                                            \
-    "v_exp_f32 v63, v63\n\t"                                                                                        \
+    "v_mul_f32 v51, 0x3fb8aa3b, v51\n\t"                                                                            \
+    "v_exp_f32 v51, v51\n\t"                                                                                        \
     "s_nop 0\n\t"                                                                                                   \
-    "v_mul_f32 v63, " OP ", v63\n\t"                                                                                \
-    "v_min_f32 v63, 0x3f7d70a4, v63\n\t"                                                                            \
-    "v_cmp_ngt_f32 vcc, 0x3b808081, v63\n\t"                                                                        \
+    "v_mul_f32 v51, " OP ", v51\n\t"                                                                                \
+    "v_min_f32 v51, 0x3f7d70a4, v51\n\t"                                                                            \
+    "v_cmp_ngt_f32 vcc, 0x3b808081, v51\n\t"                                                                        \
     "s_and_b64 exec, exec, vcc\n\t"                                                                                 \
     "s_cbranch_execz 1" #K "f\n\t"                                                                                  \
-    "v_sub_f32 v62, 1.0, v63\n\t"                                                                                   \
-    "v_mul_f32 v62, %[T], v62\n\t"                                                                                  \
-    "v_cmp_ngt_f32 vcc, 0x38d1b717, v62\n\t"                                                                        \
-    "v_cndmask_b32 %[lim], -1, %[lim], vcc\n\t"                                                                     \
-    "s_and_b64 exec, exec, vcc\n\t"                                                                                 \
-    "v_mul_f32 v64, v63, %[T]\n\t"                                                                                  \
+    "v_sub_f32 v50, 1.0, v51\n\t"                                                                                   \
+    "v_mul_f32 v50, %[T], v50\n\t"                                                                                  \
+    "v_cmp_ngt_f32 vcc, 0x38d1b717, v50\n\t"                                                                        \
+    "s_andn2_b64 %[sd], exec, vcc\n\t"              /* lanes whose transmittance would drop below 1e-4: finished */ \
+    "s_cbranch_scc0 2" #K "f\n\t"                                                                                   \
+    "s_mov_b64 exec, %[sd]\n\t"                                                                                     \
+    "v_mov_b32 %[lim], -1\n\t"                                                                                      \
+    "2" #K ":\n\t"                                                                                                  \
+    "s_mov_b64 exec, vcc\n\t"                       /* (v_cmp leaves vcc a subset of the lanes it ran on) */        \
+    "v_mul_f32 v52, v51, %[T]\n\t"                                                                                  \
     "v_add_u32 %[last], %[sbase], " OFF "\n\t"                                                                      \
-    "v_cmp_gt_f32 vcc, v64, %[best]\n\t"                                                                            \
-    "v_pk_fma_f32 %[C01], " RG ", v[64:65], %[C01] op_sel_hi:[1,0,1]\n\t"                                           \
-    "v_pk_fma_f32 %[C2D], " BD ", v[64:65], %[C2D] op_sel_hi:[1,0,1]\n\t"                                           \
-    "v_cndmask_b32 %[best], %[best], v64, vcc\n\t"                                                                  \
+    "v_cmp_gt_f32 vcc, v52, %[best]\n\t"                                                                            \
+    "v_pk_fma_f32 %[C01], " RG ", v[52:53], %[C01] op_sel_hi:[1,0,1]\n\t"                                           \
+    "v_pk_fma_f32 %[C2D], " BD ", v[52:53], %[C2D] op_sel_hi:[1,0,1]\n\t"                                           \
+    "v_mov_b32 %[T], v50\n\t"                                                                                       \
+    "s_cbranch_vccz 1" #K "f\n\t"                   /* nobody's blend weight is a new maximum */                    \
+    "v_cndmask_b32 %[best], %[best], v52, vcc\n\t"                                                                  \
     "v_cndmask_b32 %[bpos], %[bpos], %[last], vcc\n\t"                                                              \
-    "v_mov_b32 %[T], v62\n\t"                                                                                       \
     "1" #K ":\n\t"                                                                                                  \
     "s_mov_b64 exec, %[sv]\n\t"
-#define CF2_VISIT_A(K, OFF) CF2_VISIT(K, "v36", "v37", "v38", "v39", "v40", "v41", "v[42:43]", "v[44:45]", OFF)
-#define CF2_VISIT_B(K, OFF) CF2_VISIT(K, "v46", "v47", "v48", "v49", "v50", "v51", "v[52:53]", "v[54:55]", OFF)
+#define CF2_VISIT_A(K, OFF) CF2_VISIT(K, "v24", "v25", "v26", "v27", "v28", "v29", "v[30:31]", "v[32:33]", OFF)
+#define CF2_VISIT_B(K, OFF) CF2_VISIT(K, "v34", "v35", "v36", "v37", "v38", "v39", "v[40:41]", "v[42:43]", OFF)
                     asm volatile(
                         "s_mov_b64 %[sv], exec\n\t"
-                        "ds_read_u16 v56, %[lp]\n\t"
-                        "ds_read_u16 v57, %[lp] offset:2\n\t"
-                        "ds_read_u16 v58, %[lp] offset:4\n\t"
-                        "ds_read_u16 v59, %[lp] offset:6\n\t"
+                        "ds_read_u16 v44, %[lp]\n\t"
+                        "ds_read_u16 v45, %[lp] offset:2\n\t"
+                        "ds_read_u16 v46, %[lp] offset:4\n\t"
+                        "ds_read_u16 v47, %[lp] offset:6\n\t"
                         "s_waitcnt lgkmcnt(2)\n\t"
-                        "ds_read_b128 v[36:39], v56\n\t"
-                        "ds_read_b128 v[40:43], v56 offset:16\n\t"
-                        "ds_read_b64 v[44:45], v56 offset:32\n\t"
-                        "ds_read_b128 v[46:49], v57\n\t"
-                        "ds_read_b128 v[50:53], v57 offset:16\n\t"
-                        "ds_read_b64 v[54:55], v57 offset:32\n\t"
+                        "ds_read_b128 v[24:27], v44\n\t"
+                        "ds_read_b128 v[28:31], v44 offset:16\n\t"
+                        "ds_read_b64 v[32:33], v44 offset:32\n\t"
+                        "ds_read_b128 v[34:37], v45\n\t"
+                        "ds_read_b128 v[38:41], v45 offset:16\n\t"
+                        "ds_read_b64 v[42:43], v45 offset:32\n\t"
                         "s_waitcnt lgkmcnt(3)\n\t"
-                        CF2_VISIT_A(0, "v56")
-                        "ds_read_b128 v[36:39], v58\n\t"
-                        "ds_read_b128 v[40:43], v58 offset:16\n\t"
-                        "ds_read_b64 v[44:45], v58 offset:32\n\t"
+                        CF2_VISIT_A(0, "v44")
+                        "ds_read_b128 v[24:27], v46\n\t"
+                        "ds_read_b128 v[28:31], v46 offset:16\n\t"
+                        "ds_read_b64 v[32:33], v46 offset:32\n\t"
                         "s_waitcnt lgkmcnt(3)\n\t"
-                        CF2_VISIT_B(1, "v57")
-                        "ds_read_b128 v[46:49], v59\n\t"
-                        "ds_read_b128 v[50:53], v59 offset:16\n\t"
-                        "ds_read_b64 v[54:55], v59 offset:32\n\t"
+                        CF2_VISIT_B(1, "v45")
+                        "ds_read_b128 v[34:37], v47\n\t"
+                        "ds_read_b128 v[38:41], v47 offset:16\n\t"
+                        "ds_read_b64 v[42:43], v47 offset:32\n\t"
                         "s_waitcnt lgkmcnt(3)\n\t"
-                        CF2_VISIT_A(2, "v58")
+                        CF2_VISIT_A(2, "v46")
                         "s_waitcnt lgkmcnt(0)\n\t"
-                        CF2_VISIT_B(3, "v59")
+                        CF2_VISIT_B(3, "v47")
                         "s_add_i32 %[sk], %[i0], 4\n\t"
                         "v_cmp_lt_i32 vcc, %[sk], %[lim]\n\t"
                         "s_mov_b64 %[am], vcc\n\t"
                         : [T] "+v"(T), [C01] "+v"(C01), [C2D] "+v"(C2D), [best] "+v"(best), [bpos] "+v"(best_pos), [last] "+v"(last),
-                          [lim] "+v"(lim), [sv] "=&s"(sv), [am] "=&s"(am), [sk] "=&s"(sk)
+                          [lim] "+v"(lim), [sv] "=&s"(sv), [am] "=&s"(am), [sk] "=&s"(sk), [sd] "=&s"(sd)
                         : [pxf] "v"(pxf), [pyf] "v"(pyf), [lp] "v"(lp), [i0] "s"(__builtin_amdgcn_readfirstlane(i0)), [sbase] "s"(__builtin_amdgcn_readfirstlane(sbase))
-                        : "vcc", "scc", "memory", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47",
-                          "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63",
-                          "v64", "v65");
+                        : "vcc", "scc", "memory", "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35",
+                          "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51",
+                          "v52", "v53");
 #undef CF2_VISIT_A
 #undef CF2_VISIT_B
 #undef CF2_VISIT
