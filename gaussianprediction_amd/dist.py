@@ -68,6 +68,7 @@ class OverlappedGradReducer:
         self.large = [p for p in bucket.params if p.numel() >= small_numel]
         self.small = [p for p in bucket.params if p.numel() < small_numel]
         self._fired = set()
+        self._late = set()
         self._sink_cb = None
         if self.enabled:
             from . import grad_sink
@@ -86,9 +87,15 @@ class OverlappedGradReducer:
             self._sink_cb = None
         self.enabled = False
 
+    def set_late(self, params):
+        """Leaves whose gradient has more than one producer in the coming backward (several views per step; the lifecycle
+        opacity's second MLP pass into `_xyz`): a producer's completion notice is not "final" for them, so they are left to
+        finish(), which runs after backward."""
+        self._late = {id(p) for p in params}
+
     def _make_hook(self, p):
         def hook(param):
-            if id(p) in self._fired:
+            if id(p) in self._fired or id(p) in self._late:
                 return
             self._fired.add(id(p))
             self.handles.append(dist.all_reduce(self.bucket.segment(p), op=dist.ReduceOp.SUM, group=self.group, async_op=True))

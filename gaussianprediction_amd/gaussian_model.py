@@ -1,7 +1,8 @@
 """The per-frame part of the reference's GaussianModel [REF scene/gaussian_model.py:32-321]:
-parameters, activations and `forward(t, iteration) -> (xyz_t, q_t, scale, opacity_t)` with its three
-stages, on the HIP kernels of this package.  Training bookkeeping (optimizer surgery, densify/prune,
-k-means keypoint init, PLY I/O) is out of scope for this round.
+parameters, activations and `forward(t, iteration, return_weights=False) -> (xyz_t, q_t, scale, opacity_t[, weights_xyz,
+weights_r])` with its three stages, on the HIP kernels of this package.  The training bookkeeping the reference keeps on
+the same class (optimizer groups per stage, learning-rate schedule, restore, densify / prune, keypoint growth) is in
+training.py (TrainingMixin); PLY / checkpoint I/O in io_formats.py.
 
 Two stage-2/3 quantities come from un-vendored CUDA dependencies of the reference:
   * `knn_idx` [N, nearest_num]  -- frnn kNN of Gaussians vs keypoints  [REF :110-125]
@@ -17,10 +18,11 @@ from torch import nn
 
 from .deform_ops import Activations, KeypointBlend
 from .deformable_field import Deformable_Field
+from .training import TrainingMixin
 from .weights_ops import WeightsModel, knn_keypoints
 
 
-class GaussianModel(nn.Module):
+class GaussianModel(TrainingMixin, nn.Module):
     def __init__(self, sh_degree: int, args):
         super().__init__()
         self.active_sh_degree = 0
@@ -36,6 +38,9 @@ class GaussianModel(nn.Module):
         self.knn_idx = None
         self.raw_weights = None
         self.lifecycle_opacity = None
+        self._last_delta = None
+        self._last_blend = None
+        self._training_init()
 
     def set_inputDim(self, time_input_dim, xyz_input_dim):   # [REF scene/gaussian_model.py:106-108]
         self.time_input_dim = time_input_dim
@@ -51,6 +56,9 @@ class GaussianModel(nn.Module):
         self._rotation = nn.Parameter(rotation.clone().requires_grad_(True))
         self._opacity = nn.Parameter(opacity.clone().requires_grad_(True))
         self.motion_feature = nn.Parameter(motion_feature.clone().requires_grad_(True))
+        self.max_radii2D = torch.zeros(xyz.shape[0], device=xyz.device)
+        if self.args.step_opacity:               # [REF scene/gaussian_model.py:357-360]; read by opacity_type "explicit" only
+            self.opacity_thres = nn.Parameter((-2 * torch.ones_like(opacity)).requires_grad_(True))
         delta_dim = 8 if self.args.step_opacity else 7
         in_dim = self.time_input_dim + self.xyz_input_dim + self.motion_feature_dim
         self.df_model = Deformable_Field(in_dim, d=self.d, w=self.w, output_dim=delta_dim, split_xyz=False).to(xyz.device)
@@ -119,8 +127,47 @@ class GaussianModel(nn.Module):
         feat = self.super_gaussians_feature if iteration > self.second_stage_iter else self.motion_feature
         return 1.0e-5 * torch.mean(torch.abs(feat))
 
+    # ---- side outputs of forward (lazy: none of them is on the train / eval hot path) -----------------------------
+    @property
+    def kpts_xyz_motion(self):                     # [REF :269] the MLP's translation output, before the blend
+        d = self._last_delta
+        return None if d is None else d[:, 0:3]
+
+    @property
+    def kpts_rotation_motion(self):                # [REF :266-270] the MLP's rotation output (normalised if norm_rotation)
+        d = self._last_delta
+        if d is None:
+            return None
+        q = d[:, 3:7]
+        return torch.nn.functional.normalize(q) if self.args.norm_rotation else q
+
+    def dense_weights(self):
+        """The reference's dense [N,K] blend weights (`fill_nearest`: two softmaxes scattered at the kNN indices,
+        [REF scene/gaussian_model.py:214-229]) from the sparse form the kernels use.  1 GB each at N = 1M, K = 250: built
+        only on request (`return_weights=True`, `weights_sum`)."""
+        raw_w, idx, K = self._last_blend
+        nn_ = idx.shape[1]
+        wx = torch.softmax(raw_w[:, :nn_], dim=-1)
+        wr = torch.softmax(raw_w[:, nn_:2 * nn_], dim=-1)
+        fill = torch.zeros(raw_w.shape[0], K, dtype=raw_w.dtype, device=raw_w.device)
+        return torch.scatter(fill, -1, idx, wx), torch.scatter(fill, -1, idx, wr)
+
+    @property
+    def weights_sum(self):                         # [REF :263] |weights_xyz| + |weights_r|, dense
+        if self._last_blend is None:
+            return None
+        wx, wr = self.dense_weights()
+        return torch.abs(wx) + torch.abs(wr)
+
+    @torch.no_grad()
+    def get_teach_motion(self, t, delta_xyz):
+        """Stage-1 "teacher" displacement of every Gaussian vs the blended one [REF scene/gaussian_model.py:306-312]."""
+        xyz_freq, time_freq = int(self.xyz_input_dim / 6), self.time_input_dim // 2
+        teach = self.df_model.forward_fused(self.motion_feature.detach(), self._xyz.detach(), t, xyz_freq, time_freq)
+        self.add_desification_stats_motion(delta_xyz - teach[:, 0:3])
+
     # ---- the hot path [REF scene/gaussian_model.py:231-304] ---------------------------------------
-    def forward(self, t, iteration):
+    def forward(self, t, iteration, return_weights=False):
         if torch.is_tensor(iteration):
             iteration = iteration.item()
         a = self.args
@@ -129,12 +176,21 @@ class GaussianModel(nn.Module):
             s, o = Activations.apply(self._scaling, self._opacity, None, 0, 1.0)
             return self._xyz, self.get_rotation, s, o
         t_dev = t.to(self._xyz.device, torch.float32).reshape(-1)[:1]
+        # stage transitions happen inside forward in the reference [REF :246-250]; they need a training set-up
+        if self.training_args is not None:
+            if iteration == self.third_stage_iter + 1 and not self.third_stage:
+                self.training3stage_setup()
+            if iteration == self.second_stage_iter + 1 and not self.second_stage:
+                self.set_superKeypoints()
+                self.training2stage_setup()
+        self._last_blend = None
         if iteration <= self.second_stage_iter:      # stage 1: MLP over all N Gaussians, xyz detached
             noise = getattr(a, "xyz_noise_iteration", 0)
             xyz_in = self._xyz.detach()
             if noise and iteration < noise:
                 xyz_in = xyz_in + torch.randn_like(xyz_in) * 0.1 * (1 - min(1, iteration / noise))
             delta = self.df_model.forward_fused(self.motion_feature, xyz_in, t_dev, xyz_freq, time_freq)
+            self._last_delta = delta
             xyz_t, q_t = KeypointBlend.apply(delta, None, None, self._xyz, self._rotation, a.norm_rotation)
         else:                                        # stage 2/3: MLP over K keypoints + sparse blend
             noise = getattr(a, "xyz_noise_iteration", 0)
@@ -149,9 +205,19 @@ class GaussianModel(nn.Module):
                 raw_weights = self.weights_model(self.get_xyz.detach())          # [REF :257]
                 knn_idx = self.get_nearest_mask(keepshape=True)                  # [REF :260]
             delta = self.df_model.forward_fused(self.super_gaussians_feature, kp, t_dev, xyz_freq, time_freq)
-            self.kpts_xyz_motion = delta[:, 0:3]
+            self._last_delta = delta
+            self._last_blend = (raw_weights.detach(), knn_idx, self.super_gaussians.shape[0])
             xyz_t, q_t = KeypointBlend.apply(delta, raw_weights, knn_idx, self._xyz, self._rotation, a.norm_rotation)
+            if getattr(a, "densify_from_teaching", False) and self.second_stage:                # [REF :274-283]
+                off = self.second_stage_iter
+                if a.adaptive_from_iter + off <= iteration < a.adaptive_end_iter + off and self._kpts_room() > 0:
+                    self.get_teach_motion(t_dev, (xyz_t - self._xyz).detach())
+                    if iteration % a.adaptive_interval == 0:
+                        self.get_new_kpts(self.xyz_motion_accum_max.squeeze(-1) >= a.teaching_threshold)
         self.lifecycle_opacity = None
+        weights = ()
+        if return_weights and iteration > self.second_stage_iter:
+            weights = self.dense_weights()
         if a.step_opacity and iteration > a.step_opacity_iteration:
             if a.opacity_type != "implicit":
                 raise NotImplementedError("opacity_type 'explicit' is not on any shipped script's path")
@@ -159,6 +225,8 @@ class GaussianModel(nn.Module):
             delta2 = self.df_model.forward_fused(self.motion_feature, self._xyz, t_dev, xyz_freq, time_freq)
             s, o = Activations.apply(self._scaling, self._opacity, delta2, 7, self.beta)
             self.lifecycle_opacity = o
-        else:
-            s, o = Activations.apply(self._scaling, self._opacity, None, 0, 1.0)
-        return xyz_t, q_t, s, o
+            if weights:                              # the reference returns the PLAIN opacity beside the weights [REF :299-300]
+                return (xyz_t, q_t, s, self.get_opacity) + tuple(weights)
+            return xyz_t, q_t, s, o
+        s, o = Activations.apply(self._scaling, self._opacity, None, 0, 1.0)
+        return (xyz_t, q_t, s, o) + tuple(weights)

@@ -114,6 +114,69 @@ class FusedAdam:
                     raise RuntimeError("FusedAdam needs contiguous parameters")
                 self.items.append((g, p, off_of[id(p)], torch.zeros_like(p), torch.zeros_like(p)))
 
+    # ---- the torch.optim.Adam surface train.py and the checkpoint format use ---------------------------------------
+    @property
+    def state(self):
+        """{param: {"step", "exp_avg", "exp_avg_sq"}} (views of the live moments), empty before the first step as in torch."""
+        if self.step_count == 0:
+            return {}
+        return {p: {"step": torch.tensor(float(self.step_count)), "exp_avg": m, "exp_avg_sq": v} for _, p, _, m, v in self.items}
+
+    def zero_grad(self, set_to_none=True):
+        """train.py calls `optimizer.zero_grad(set_to_none=True)` [REF train.py:197]; the gradients here are views into the
+        flat bucket (the all-reduce operand), so they are zeroed in place, never detached."""
+        self.bucket.zero()
+
+    def _group_template(self):
+        probe = torch.optim.Adam([torch.zeros(1, requires_grad=True)], lr=0.0, betas=self.betas, eps=self.eps)
+        return {k: v for k, v in probe.state_dict()["param_groups"][0].items() if k not in ("params", "lr")}
+
+    def state_dict(self):
+        """Same layout as `torch.optim.Adam.state_dict()` for the same groups: `(state_dict(), optimizer.state_dict(),
+        iteration)` checkpoints interchange with the reference's [REF train.py:199-201, scene/gaussian_model.py:96-104]."""
+        tmpl = self._group_template()
+        mom = {id(p): (m, v) for _, p, _, m, v in self.items}
+        groups, state, k = [], {}, 0
+        for g in self.param_groups:
+            entry = dict(tmpl)
+            entry.update({kk: vv for kk, vv in g.items() if kk != "params"})
+            entry["params"] = list(range(k, k + len(g["params"])))
+            for p in g["params"]:
+                if self.step_count > 0 and id(p) in mom:
+                    m, v = mom[id(p)]
+                    state[k] = {"step": torch.tensor(float(self.step_count)), "exp_avg": m.detach().clone(),
+                                "exp_avg_sq": v.detach().clone()}
+                k += 1
+            groups.append(entry)
+        return {"state": state, "param_groups": groups}
+
+    def load_state_dict(self, sd):
+        """Accepts a `torch.optim.Adam.state_dict()` (or this class's) for the same groups."""
+        groups = sd["param_groups"]
+        if len(groups) != len(self.param_groups):
+            raise ValueError(f"loaded state dict has {len(groups)} parameter groups, the optimizer has {len(self.param_groups)}")
+        mom = {id(p): (m, v) for _, p, _, m, v in self.items}
+        steps = []
+        for g, saved in zip(self.param_groups, groups):
+            if len(saved["params"]) != len(g["params"]):
+                raise ValueError(f"group {g.get('name')}: {len(saved['params'])} parameters saved, {len(g['params'])} expected")
+            if "name" in saved and saved["name"] != g.get("name"):
+                raise ValueError(f"group order differs: saved {saved['name']!r}, optimizer {g.get('name')!r}")
+            g["lr"] = float(saved["lr"])
+            for p, idx in zip(g["params"], saved["params"]):
+                st = sd["state"].get(idx)
+                if st is None or id(p) not in mom:
+                    continue
+                m, v = mom[id(p)]
+                if tuple(st["exp_avg"].shape) != tuple(m.shape):
+                    raise ValueError(f"group {g.get('name')}: moment shape {tuple(st['exp_avg'].shape)} vs parameter {tuple(m.shape)}")
+                m.copy_(st["exp_avg"].to(m.device, m.dtype))
+                v.copy_(st["exp_avg_sq"].to(v.device, v.dtype))
+                steps.append(int(float(st["step"])))
+        # one step counter for all tensors: every optimizer of the reference is created whole by a *_setup call, so its
+        # per-parameter steps are equal (densify / prune keep the stored state, step included)
+        self.step_count = max(steps) if steps else 0
+
     def step(self, zero_grad=True, keep_grad=(), skip_flag=None, only=None, exclude=None, stream=None, advance=True):
         """One launch for all parameter tensors (gp_adam_step_multi).  Parameters listed in `keep_grad` are not
         zeroed: their gradient buffers are marked stale (grad_sink.mark_stale) and the next backward overwrites them.

@@ -13,10 +13,11 @@ from types import SimpleNamespace
 import torch
 import torch.nn.functional as F
 
-from .dist import FlatGradBucket, OverlappedGradReducer
+from .dist import OverlappedGradReducer
 from . import grad_sink
-from .loss_ops import FusedAdam, add_l1_mean, l1_ssim_loss
+from .loss_ops import add_l1_mean, l1_ssim_loss
 from .renderer import render
+from .training import default_training_args
 
 
 def _gauss_window(channels, device, size=11, sigma=1.5):
@@ -45,7 +46,10 @@ def ssim(img1, img2, window):            # [REF utils/loss_utils.py:70-100]
 
 
 class TrainStep:
-    """One optimisation step over one view per rank (view-parallel when world_size > 1)."""
+    """One optimisation step: `batch` views per rank rendered, their losses SUMMED, one backward, one Adam step
+    [REF train.py:101-133, 196-197]; view-parallel over the ranks when world_size > 1 (rank r takes the views
+    (step * world + r) * batch + b).  Optimizer, gradient bucket, learning-rate schedule and densification live on the
+    model, as in the reference (training.py)."""
 
     # capacity mode of the rasterizer's binning stage (include/gp_hip.h, gp_raster_settings.binning_capacity): the host
     # never waits for R.  Protocol: the first `len(cameras)` steps run in exact mode and report R through the status word;
@@ -58,11 +62,13 @@ class TrainStep:
     SPEC_PAD = 4096
 
     def __init__(self, pc, cameras, gt_images, iteration, lambda_dssim=0.2, lrs=None, group=None, fused=True, speculative=False,
-                 overlap_sh_adam=False):
+                 overlap_sh_adam=False, batch=1, schedule=False, training_args=None):
         self.pc, self.cameras, self.gt, self.iteration = pc, cameras, gt_images, iteration
         self.lambda_dssim = lambda_dssim
         self.group = group
         self.fused = fused
+        self.batch = int(batch)
+        self.schedule = bool(schedule)      # True: update_learning_rate(iteration) every step, as train.py:79 does
         dev = pc.get_xyz.device
         self.speculative = bool(speculative) and fused and dev.type == "cuda"
         if self.speculative:
@@ -89,86 +95,54 @@ class TrainStep:
         self.window = _gauss_window(3, dev)
         # camera times live on the device: a per-step H2D copy from pageable memory would be a host sync
         self.times = [torch.from_numpy(c.time).to(torch.float32).to(dev) for c in cameras]
-        lr = dict(xyz=1.6e-4, f_dc=2.5e-3, f_rest=2.5e-3 / 20, opacity=0.05, scaling=5e-3, rotation=1e-3, mfeature=8e-4,
-                  kpts=8e-4, mlp=8e-4, hash=5e-3)   # [REF arguments/__init__.py:74-90]
-        if lrs:
-            lr.update(lrs)
-        self.lr = lr
-        self._build_optimizer()
+        # learning rates: the reference's defaults [REF arguments/__init__.py:74-90], overridable per group through `lrs`
+        # (xyz, f_dc, opacity, scaling, rotation, mfeature, kpts, mlp, hash) or wholesale through `training_args`
+        if training_args is None:
+            m = dict(xyz="position_lr_init", f_dc="feature_lr", opacity="opacity_lr", scaling="scaling_lr", rotation="rotation_lr",
+                     mfeature="mfeature_lr", kpts="kpts_lr", mlp="mlp_lr", hash="hash_lr")
+            over = {m[k]: v for k, v in (lrs or {}).items() if k in m}
+            if lrs and "f_rest" in lrs and "f_dc" not in lrs:
+                over["feature_lr"] = 20.0 * lrs["f_rest"]
+            training_args = default_training_args(**over)
+        self.training_args = training_args
+        pc.use_fused_adam = bool(fused)
+        if pc.optimizer is None or getattr(pc, "_stage", None) != self._stage_of(iteration):
+            pc.setup_for_iteration(training_args, iteration)
+        self._epoch = None
+        self._attach()
 
-    def _groups(self):
-        """Parameter groups per training stage, as the reference builds them
-        [REF scene/gaussian_model.py:394-411 (stage 3), 413-430 (stage 2), 432-451 (stage 1)]."""
-        pc, lr, iteration = self.pc, self.lr, self.iteration
-        g_gauss = [
-            {"params": [pc._xyz], "lr": lr["xyz"], "name": "xyz"},
-            {"params": [pc._features_dc], "lr": lr["f_dc"], "name": "f_dc"},
-            {"params": [pc._features_rest], "lr": lr["f_rest"], "name": "f_rest"},
-            {"params": [pc._opacity], "lr": lr["opacity"], "name": "opacity"},
-            {"params": [pc._scaling], "lr": lr["scaling"], "name": "scaling"},
-            {"params": [pc._rotation], "lr": lr["rotation"], "name": "rotation"},
-        ]
-        g_mlp = [{"params": list(pc.df_model.parameters()), "lr": lr["mlp"], "name": "df_mlp"}]
-        g_kp = []
-        if hasattr(pc, "super_gaussians"):
-            g_kp = [{"params": [pc.super_gaussians], "lr": lr["kpts"], "name": "s_xyz"},
-                    {"params": [pc.super_gaussians_feature], "lr": lr["kpts"], "name": "s_motion_feature"}]
-            if getattr(pc, "weights_model", None) is not None and pc.raw_weights is None:   # [REF :402,421 "weight_mlp"]
-                g_kp.append({"params": list(pc.weights_model.parameters()), "lr": lr["hash"], "name": "weight_mlp"})
-        if iteration <= pc.second_stage_iter:                      # stage 1
-            return g_gauss + g_mlp + [{"params": [pc.motion_feature], "lr": lr["mfeature"], "name": "motion_feature"}]
-        if iteration <= pc.third_stage_iter:                       # stage 2: keypoints + MLP only
-            return g_kp + g_mlp
-        return g_gauss + g_kp + g_mlp                              # stage 3: everything except the per-Gaussian feature
+    def _stage_of(self, iteration):
+        return 1 if iteration <= self.pc.second_stage_iter else (2 if iteration <= self.pc.third_stage_iter else 3)
 
-    def _build_optimizer(self):
-        pc = self.pc
-        groups = self._groups()
-        optimized = {id(p) for g in groups for p in g["params"]}
-        for p in pc.parameters():                                  # the reference computes (and ignores) these grads
-            p.requires_grad_(id(p) in optimized)
-        self.bucket = FlatGradBucket([p for g in groups for p in g["params"]])
-        self.reducer = OverlappedGradReducer(self.bucket, self.group)
+    @property
+    def bucket(self):
+        return self.pc.bucket
+
+    @property
+    def optimizer(self):
+        return self.pc.optimizer
+
+    def _attach(self):
+        """(Re-)attach the gradient reducer and the side-stream callback to the model's CURRENT bucket."""
+        if self._epoch == self.pc.optimizer_epoch:
+            return
+        if getattr(self, "reducer", None) is not None:
+            self.reducer.close()
+        self.reducer = OverlappedGradReducer(self.pc.bucket, self.group)
         if getattr(self, "overlap_sh_adam", False) and self._sink_cb is None:
             self._armed = False
             self._ev_bwd, self._ev_sh = torch.cuda.Event(), torch.cuda.Event()
             self._sink_cb = grad_sink.register_callback(self._on_sink)
-        if self.fused:
-            self.optimizer = FusedAdam(groups, self.bucket, eps=1e-15)
-        else:
-            self.optimizer = torch.optim.Adam(groups, lr=0.0, eps=1e-15, foreach=True)   # [REF scene/gaussian_model.py:472]
+        self._epoch = self.pc.optimizer_epoch
 
-    # ---- optimizer-state surgery (densify / prune, gaussianprediction_amd/densify.py) ---------------------------
+    # ---- optimizer-state surgery lives on the model (training.py); kept here for callers of the round-1 interface ------
     def adam_moments(self):
-        """{id(param): (exp_avg, exp_avg_sq)} of the current optimizer."""
         self.wait_side()
-        if self.fused:
-            return {id(p): (m, v) for _, p, _, m, v in self.optimizer.items}
-        return {id(p): (st["exp_avg"], st["exp_avg_sq"]) for p, st in self.optimizer.state.items() if "exp_avg" in st}
+        return self.pc.adam_moments()
 
     def rebuild_optimizer(self, carried):
-        """After the model's per-Gaussian Parameters were replaced: new bucket + optimizer; `carried` maps id(new param)
-        to its (exp_avg, exp_avg_sq); everything else keeps its moments; the step count is preserved."""
-        old = self.adam_moments()
-        old_steps = self.optimizer.step_count if self.fused else None
-        old_torch_state = None if self.fused else {id(p): st for p, st in self.optimizer.state.items()}
-        self.reducer.close()
-        grad_sink.forget_all()
-        self._build_optimizer()
-        if self.fused:
-            self.optimizer.step_count = old_steps
-            for _, p, _, m, v in self.optimizer.items:
-                src = carried.get(id(p)) or old.get(id(p))
-                if src is not None and src[0].shape == m.shape:
-                    m.copy_(src[0]); v.copy_(src[1])
-        else:
-            for g in self.optimizer.param_groups:
-                for p in g["params"]:
-                    src = carried.get(id(p))
-                    if src is not None:
-                        self.optimizer.state[p] = {"step": torch.tensor(0.0), "exp_avg": src[0].clone(), "exp_avg_sq": src[1].clone()}
-                    elif id(p) in old_torch_state:
-                        self.optimizer.state[p] = old_torch_state[id(p)]
+        self.pc._rebuild_optimizer(carried)
+        self._attach()
 
     def wait_side(self):
         """Make the current stream wait for the side-stream SH update (before anything but render() touches the SH
@@ -235,31 +209,55 @@ class TrainStep:
         return out
 
     def _step(self, view_index: int, binning, skip_flag):
-        cam = self.cameras[view_index % len(self.cameras)]
-        gt = self.gt[view_index % len(self.gt)]
-        time = self.times[view_index % len(self.cameras)]
+        pc = self.pc
+        self._attach()                               # (densify / prune / stage changes rebuild bucket + optimizer)
+        if self.schedule:
+            pc.update_learning_rate(self.iteration)  # [REF train.py:79]
+        a = pc.args
+        lifecycle = bool(a.step_opacity and self.iteration > a.step_opacity_iteration)
         keep = ()
-        if self.fused and not self.pipe.convert_SHs_python and self.iteration > self.pc.third_stage_iter:
+        if self.fused and self.batch == 1 and not self.pipe.convert_SHs_python and self.iteration > pc.third_stage_iter:
             # the per-Gaussian gradients each have exactly one producer kernel that writes the whole tensor (SH: rasterizer
             # backward; xyz / rotation: blend backward; scaling / opacity: activation backward): their zeroing pass is
-            # skipped and the next backward overwrites instead of accumulating
-            keep = (self.pc._features_dc, self.pc._features_rest, self.pc._xyz, self.pc._rotation, self.pc._scaling,
-                    self.pc._opacity)
+            # skipped and the next backward overwrites instead of accumulating.  With the lifecycle opacity the second MLP
+            # pass is a second producer of the xyz gradient, so xyz keeps the zero-and-accumulate protocol.
+            keep = (pc._features_dc, pc._features_rest, pc._rotation, pc._scaling, pc._opacity) + (() if lifecycle else (pc._xyz,))
+        # a gradient that has more than one producer in this backward is final only when autograd says so: such leaves are
+        # reduced after backward (finish()), never from a kernel's completion notice
+        self.reducer.set_late(list(self.bucket.params) if self.batch > 1 else ([pc._xyz] if lifecycle else []))
         if self.overlap_sh_adam and keep and not self.reducer.enabled:
             self._armed, self._keep, self._skip_flag = True, keep, skip_flag
-        pkg = render(cam, self.pc, self.pipe, self.bg, time=time, it=self.iteration, binning=binning)
-        loss = self.loss_of(pkg["render"], gt)
+        world = torch.distributed.get_world_size(self.group) if self.reducer.enabled else 1
+        losses, pkgs = [], []
+        for b in range(self.batch):                  # [REF train.py:101-119]
+            v = view_index * self.batch + b
+            cam = self.cameras[v % len(self.cameras)]
+            pkg = render(cam, pc, self.pipe, self.bg, time=self.times[v % len(self.cameras)], it=self.iteration, binning=binning)
+            losses.append(self.loss_of(pkg["render"], self.gt[v % len(self.gt)]))
+            pkgs.append(pkg)
+        loss = losses[0] if self.batch == 1 else torch.stack(losses, dim=0).sum()
         loss.backward()                              # hooks start the all-reduce of each large gradient as it completes
         self._armed = False
         self.reducer.finish()                        # SUM over views == the reference's --batch semantics
         if skip_flag is not None and self.reducer.enabled:
             # one rank's overflow invalidates the summed gradient: every rank must skip (and later repeat) this step
             torch.distributed.all_reduce(skip_flag, op=torch.distributed.ReduceOp.MAX, group=self.group)
+        pkg = pkgs[-1]
+        if self.batch > 1 or world > 1:
+            # densification inputs of a batch [REF train.py:121-127]: radii = max over the views, visibility = any; the summed
+            # screen-space gradient is computed -- and then the reference feeds add_densification_stats the LAST view's
+            # tensor, whose .grad holds that view alone (train.py:167); both are returned
+            from .dist import reduce_view_stats
+            radii = torch.stack([p["radii"] for p in pkgs]).max(dim=0).values
+            radii, vis = reduce_view_stats(radii, self.group)
+            grads = [p["viewspace_points"].grad for p in pkgs if p["viewspace_points"].grad is not None]
+            pkg = dict(pkg, radii=radii, visibility_filter=vis,
+                       viewspace_point_tensor_grad=torch.stack(grads).sum(0) if grads else None)
         if self.fused:
             if self._sh_early:       # the SH tensors were updated on the side stream during the backward
                 self._sh_early = False
                 self.optimizer.step(zero_grad=True, keep_grad=keep, skip_flag=skip_flag,
-                                    exclude=(self.pc._features_dc, self.pc._features_rest))
+                                    exclude=(pc._features_dc, pc._features_rest))
             else:
                 self.optimizer.step(zero_grad=True, keep_grad=keep, skip_flag=skip_flag)
         else:

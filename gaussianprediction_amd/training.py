@@ -1,0 +1,551 @@
+"""Training bookkeeping of the reference's GaussianModel, on this package's flat gradient bucket + fused Adam:
+
+    training_setup / training2stage_setup / training3stage_setup      [REF scene/gaussian_model.py:394-472]
+    update_learning_rate                                              [REF :474-491]
+    restore                                                           [REF :96-104]
+    add_densification_stats, densify, prune, reset_opacity            [REF :526-530, 645-718, 745-760]
+    densify_kpts, get_new_kpts, densification_motion_postfix,
+    get_teach_motion, add_desification_stats_motion                   [REF :196-212, 306-312, 612-630, 720-744, 762-773]
+    set_superKeypoints (k-means keypoint initialisation)              [REF :127-136]
+
+so that `train.py`'s calls on `gaussians` (`update_learning_rate`, `optimizer.step()`, `optimizer.zero_grad(set_to_none=True)`,
+`densify`, `reset_opacity`, `prune`, `densify_kpts`, `optimizer.state_dict()`, `restore`) resolve on this model.
+
+The reference edits `torch.optim.Adam`'s per-parameter state in place (`cat_tensors_to_optimizer`, `_prune_optimizer`,
+`replace_tensor_to_optimizer`).  Here every optimized parameter's `.grad` is a view into ONE flat buffer (the RCCL
+all-reduce operand, dist.FlatGradBucket) and Adam is one multi-tensor HIP launch over it (loss_ops.FusedAdam), so a change
+of the per-Gaussian row count rebuilds bucket + optimizer together: moments of surviving rows are carried over, appended
+rows start at zero (`torch.zeros_like(extension_tensor)` in the reference), step count and learning rates are preserved.
+This is bookkeeping that runs every few hundred iterations: torch tensor ops (plumbing), except furthest-point sampling,
+which is a kernel (gp_furthest_point_sampling; the reference's is pointops' CUDA kernel, utils/fps.py:71-88).
+On CPU tensors (the -m "not gpu" tests of this logic) the optimizer is the plain `torch.optim.Adam` of the reference.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from types import SimpleNamespace
+
+import torch
+from torch import nn
+
+from . import _lib
+from .dist import FlatGradBucket
+
+# (optimizer group name, model attribute) of the per-Gaussian parameters [REF scene/gaussian_model.py:434-451, 632-655]
+PER_GAUSSIAN = (("xyz", "_xyz"), ("f_dc", "_features_dc"), ("f_rest", "_features_rest"), ("opacity", "_opacity"),
+                ("scaling", "_scaling"), ("rotation", "_rotation"), ("motion_feature", "motion_feature"),
+                ("opacity_thres", "opacity_thres"))
+
+
+def default_training_args(**over):
+    """The optimisation defaults of the reference [REF arguments/__init__.py:72-96]."""
+    a = dict(iterations=30_000, position_lr_init=0.00016, position_lr_final=0.0000016, position_lr_delay_mult=0.01,
+             position_lr_max_steps=30_000, feature_lr=0.0025, opacity_lr=0.05, scaling_lr=0.005, rotation_lr=0.001,
+             mfeature_lr=0.0008, mfeature_lr_final=0.00008, kpts_lr=0.0008, kpts_lr_final=0.00008, hash_lr=0.005,
+             hash_lr_final=0.00005, mlp_lr=0.0008, percent_dense=0.01, lambda_dssim=0.2, densification_interval=100,
+             opacity_reset_interval=3000, densify_from_iter=500, densify_until_iter=15_000, densify_grad_threshold=0.0002)
+    a.update(over)
+    return SimpleNamespace(**a)
+
+
+def get_expon_lr_func(lr_init, lr_final, lr_delay_steps=0, lr_delay_mult=1.0, max_steps=1000000):
+    """Log-linear interpolation from lr_init (step 0) to lr_final (step max_steps), optionally eased in over the first
+    lr_delay_steps by lr_delay_mult + (1 - lr_delay_mult) sin(pi/2 * step / lr_delay_steps)
+    [REF utils/general_utils.py:29-62]."""
+    def rate(step):
+        if step < 0 or (lr_init == 0.0 and lr_final == 0.0):
+            return 0.0
+        ease = 1.0
+        if lr_delay_steps > 0:
+            ease = lr_delay_mult + (1 - lr_delay_mult) * math.sin(0.5 * math.pi * min(max(step / lr_delay_steps, 0.0), 1.0))
+        t = min(max(step / max_steps, 0.0), 1.0)
+        return ease * math.exp(math.log(lr_init) * (1 - t) + math.log(lr_final) * t)
+    return rate
+
+
+def build_rotation(r):
+    """[REF utils/general_utils.py:78-99] rotation matrices of (w, x, y, z) quaternions, normalised inside."""
+    q = r / torch.sqrt((r * r).sum(-1, keepdim=True))
+    w, x, y, z = q.unbind(-1)
+    return torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y),
+                        2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x),
+                        2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)], dim=-1).reshape(-1, 3, 3)
+
+
+def furthest_point_sampling(xyz: torch.Tensor, m: int) -> torch.Tensor:
+    """Indices (int64, [m]) of an iterative furthest-point sample of `xyz` [n,3] that starts at point 0 -- the contract of
+    pointops' `furthestsampling` for one batch [REF utils/fps.py:71-88].  HIP kernel on the GPU; torch loop on CPU tensors
+    (test infrastructure for the host logic only)."""
+    n = xyz.shape[0]
+    m = int(min(m, n))
+    if m <= 0:
+        return torch.empty(0, dtype=torch.int64, device=xyz.device)
+    x = xyz.detach().to(torch.float32).contiguous()
+    if x.is_cuda:
+        idx = torch.empty(m, dtype=torch.int32, device=x.device)
+        tmp = torch.empty(n, dtype=torch.float32, device=x.device)
+        with _lib.on_device(x.device):
+            _lib.check(_lib.lib().gp_furthest_point_sampling(C.c_int64(n), _lib.ptr(x), C.c_int64(m), _lib.ptr(idx), _lib.ptr(tmp),
+                                                             _lib.stream_ptr(x.device)), "gp_furthest_point_sampling")
+        return idx.to(torch.int64)
+    idx = torch.zeros(m, dtype=torch.int64)
+    dist = torch.full((n,), 1e10)
+    for j in range(1, m):
+        d = ((x - x[idx[j - 1]]) ** 2).sum(-1)
+        dist = torch.minimum(dist, d)
+        idx[j] = int(torch.argmax(dist))          # first maximum
+    return idx
+
+
+def nearest_index(query: torch.Tensor, base: torch.Tensor, chunk: int = 256) -> torch.Tensor:
+    """Index of the nearest `base` point for every `query` point (pytorch3d knn_points K=1 in the reference, :207)."""
+    out = torch.empty(query.shape[0], dtype=torch.int64, device=query.device)
+    for s in range(0, query.shape[0], chunk):
+        out[s:s + chunk] = torch.cdist(query[s:s + chunk], base).argmin(dim=1)
+    return out
+
+
+def kmeans(features: torch.Tensor, K: int, iters: int = 20, seed: int = 0, chunk: int = 65536):
+    """Lloyd's k-means (cluster ids, centres), centres initialised from a seeded random subset.  Stands in for
+    kmeans_pytorch.kmeans (absent, un-vendored: parity unpinned) in `feature_kmeans` [REF utils/visualizer_utils.py:84-93]."""
+    n = features.shape[0]
+    g = torch.Generator().manual_seed(seed)
+    centres = features[torch.randperm(n, generator=g)[:K].to(features.device)].clone()
+    ids = torch.zeros(n, dtype=torch.int64, device=features.device)
+    for _ in range(iters):
+        for s in range(0, n, chunk):
+            ids[s:s + chunk] = torch.cdist(features[s:s + chunk], centres).argmin(dim=1)
+        sums = torch.zeros_like(centres).index_add_(0, ids, features)
+        cnt = torch.zeros(K, device=features.device).index_add_(0, ids, torch.ones(n, device=features.device))
+        new = torch.where(cnt[:, None] > 0, sums / cnt[:, None].clamp_min(1), centres)
+        if torch.allclose(new, centres, rtol=0, atol=1e-7):
+            centres = new
+            break
+        centres = new
+    return ids, centres
+
+
+class TrainingMixin:
+    """See the module docstring.  Mixed into GaussianModel."""
+
+    No_prune_and_densify = ("s_xyz", "s_motion_feature", "s_weights", "weight_feature", "weight_mlp")   # [REF :88]
+
+    def _training_init(self):
+        self.optimizer = None
+        self.bucket = None
+        self.optimizer_epoch = 0           # bumped whenever bucket + optimizer are rebuilt (harnesses re-attach their hooks)
+        self.spatial_lr_scale = 1.0
+        self.percent_dense = 0.01
+        self.second_stage = False
+        self.third_stage = False
+        self.training_args = None
+        self.max_radii2D = torch.empty(0)
+        self.xyz_gradient_accum = torch.empty(0)
+        self.xyz_gradient_accum_max = torch.empty(0)
+        self.denom = torch.empty(0)
+        self.new_kpts_init()
+
+    # ---- optimizer construction ----------------------------------------------------------------------------------
+    def _per_gaussian(self):
+        return {name: getattr(self, attr) for name, attr in PER_GAUSSIAN if isinstance(getattr(self, attr, None), nn.Parameter)}
+
+    def _install_optimizer(self, groups):
+        optimized = {id(p) for g in groups for p in g["params"]}
+        for p in self.parameters():             # the reference computes (and discards) the other gradients; skipping them
+            p.requires_grad_(id(p) in optimized)   # changes no result
+        params = [p for g in groups for p in g["params"]]
+        self.bucket = FlatGradBucket(params)
+        if params[0].is_cuda and getattr(self, "use_fused_adam", True):
+            from .loss_ops import FusedAdam
+            self.optimizer = FusedAdam(groups, self.bucket, eps=1e-15)
+        else:
+            self.optimizer = torch.optim.Adam(groups, lr=0.0, eps=1e-15)     # [REF :472]
+        self.optimizer_epoch += 1
+
+    def _gaussian_groups(self):
+        a, s = self.training_args, self.spatial_lr_scale
+        return [{"params": [self._xyz], "lr": a.position_lr_init * s, "name": "xyz"},
+                {"params": [self._features_dc], "lr": a.feature_lr, "name": "f_dc"},
+                {"params": [self._features_rest], "lr": a.feature_lr / 20.0, "name": "f_rest"},
+                {"params": [self._opacity], "lr": a.opacity_lr, "name": "opacity"},
+                {"params": [self._scaling], "lr": a.scaling_lr, "name": "scaling"},
+                {"params": [self._rotation], "lr": a.rotation_lr, "name": "rotation"}]
+
+    def _keypoint_groups(self):
+        a = self.training_args
+        g = [{"params": [self.super_gaussians], "lr": a.kpts_lr, "name": "s_xyz"},
+             {"params": [self.super_gaussians_feature], "lr": a.kpts_lr, "name": "s_motion_feature"}]
+        if getattr(self, "weights_model", None) is not None:
+            g.append({"params": list(self.weights_model.parameters()), "lr": a.hash_lr, "name": "weight_mlp"})
+        return g
+
+    def _thres_group(self):
+        if self.args.step_opacity and isinstance(getattr(self, "opacity_thres", None), nn.Parameter):
+            return [{"params": [self.opacity_thres], "lr": self.training_args.opacity_lr, "name": "opacity_thres"}]
+        return []
+
+    def _stage_groups(self, stage):
+        a = self.training_args
+        mlp = [{"params": list(self.df_model.parameters()), "lr": a.mlp_lr, "name": "df_mlp"}]
+        if stage == 1:        # [REF :432-451]
+            return self._gaussian_groups() + mlp + \
+                [{"params": [self.motion_feature], "lr": a.mfeature_lr, "name": "motion_feature"}] + self._thres_group()
+        if stage == 2:        # [REF :413-430]
+            return self._keypoint_groups() + mlp
+        return self._gaussian_groups() + self._keypoint_groups() + mlp + self._thres_group()     # [REF :394-411]
+
+    def _reset_gaussian_stats(self):
+        n, dev = self.get_xyz.shape[0], self.get_xyz.device
+        self.xyz_gradient_accum = torch.zeros((n, 1), device=dev)
+        self.xyz_gradient_accum_max = torch.zeros((n, 1), device=dev)
+        self.denom = torch.zeros((n, 1), device=dev)
+        self.max_radii2D = torch.zeros(n, device=dev)
+
+    def _reset_kpts_stats(self, k=None):
+        dev = self.get_xyz.device
+        k = self.super_gaussians.shape[0] if k is None else k
+        self.kpts_gradient_accum = torch.zeros((k, 1), device=dev)
+        self.kpts_gradient_accum_max = torch.zeros((k, 1), device=dev)
+        self.kpts_denom = torch.zeros((k, 1), device=dev)
+
+    def training_setup(self, training_args):
+        """Stage 1 [REF scene/gaussian_model.py:432-472]."""
+        self.training_args = a = training_args
+        self.percent_dense = a.percent_dense
+        keep_radii = self.max_radii2D if self.max_radii2D.numel() == self.get_xyz.shape[0] else None
+        self._reset_gaussian_stats()
+        if keep_radii is not None:               # the reference allocates max_radii2D in create_from_pcd, not here
+            self.max_radii2D = keep_radii
+        self._reset_kpts_stats(self.args.max_points if hasattr(self.args, "max_points") else None)
+        self._stage = 1
+        self._install_optimizer(self._stage_groups(1))
+        s = self.spatial_lr_scale
+        self.xyz_scheduler_args = get_expon_lr_func(a.position_lr_init * s, a.position_lr_final * s,
+                                                    lr_delay_mult=a.position_lr_delay_mult, max_steps=a.position_lr_max_steps)
+        self.mlp_scheduler_args = get_expon_lr_func(a.mlp_lr, a.position_lr_final, lr_delay_mult=a.position_lr_delay_mult,
+                                                    max_steps=a.position_lr_max_steps)
+        self.weight_mlp_scheduler_args = get_expon_lr_func(a.hash_lr, a.hash_lr_final, lr_delay_steps=a.position_lr_max_steps,
+                                                           max_steps=a.iterations)
+        self.motion_feature_scheduler_args = get_expon_lr_func(a.mfeature_lr, a.mfeature_lr_final,
+                                                               lr_delay_steps=a.position_lr_max_steps,
+                                                               max_steps=a.position_lr_max_steps)
+        self.super_xyz_scheduler_args = get_expon_lr_func(a.kpts_lr, a.kpts_lr_final, lr_delay_steps=a.position_lr_max_steps,
+                                                          max_steps=a.iterations)
+
+    def training2stage_setup(self):
+        """Stage 2: keypoints + MLP only [REF :413-430]."""
+        self.second_stage = True
+        n, dev = self.get_xyz.shape[0], self.get_xyz.device
+        self.xyz_motion_accum = torch.zeros((n, 1), device=dev)
+        self.xyz_motion_accum_max = torch.zeros((n, 1), device=dev)
+        self.motion_denom = torch.zeros((n, 1), device=dev)
+        self._reset_kpts_stats()
+        self._stage = 2
+        self._install_optimizer(self._stage_groups(2))
+
+    def training3stage_setup(self):
+        """Stage 3: everything except the per-Gaussian motion feature [REF :394-411]."""
+        self.third_stage = True
+        self._stage = 3
+        self._install_optimizer(self._stage_groups(3))
+
+    def setup_for_iteration(self, training_args, iteration):
+        """The setup call the reference would have made by `iteration` [REF :96-104 restore, :244-249 forward]."""
+        if self.training_args is None or iteration <= self.second_stage_iter:
+            self.training_setup(training_args)
+        if iteration > self.third_stage_iter:
+            self.second_stage = True
+            self.training3stage_setup()
+        elif iteration > self.second_stage_iter:
+            self.training2stage_setup()
+
+    def restore(self, opt_dict, training_args, iteration=-1):
+        """[REF scene/gaussian_model.py:96-104]"""
+        self.training_args = training_args
+        if iteration <= self.second_stage_iter:
+            self.training_setup(training_args)
+        else:
+            if not hasattr(self, "xyz_scheduler_args"):
+                self.training_setup(training_args)       # schedulers + statistics (the reference keeps them from __init__ time)
+            if iteration > self.third_stage_iter:
+                self.second_stage = True
+                self.training3stage_setup()
+            else:
+                self.training2stage_setup()
+        self.optimizer.load_state_dict(opt_dict)
+
+    def update_learning_rate(self, iteration):
+        """Per-step learning-rate schedule, by group name [REF scene/gaussian_model.py:474-491]."""
+        for g in self.optimizer.param_groups:
+            name = g["name"]
+            if name == "xyz" or "delta" in name or "fourier_weights" in name:
+                g["lr"] = self.xyz_scheduler_args(iteration)
+            elif "mlp" in name and "weight" not in name:
+                g["lr"] = self.mlp_scheduler_args(iteration)
+            elif name == "s_xyz" or name == "weight_feature":
+                g["lr"] = self.super_xyz_scheduler_args(iteration)
+            elif "weight_mlp" in name:
+                g["lr"] = self.weight_mlp_scheduler_args(iteration)
+            elif "motion_feature" in name or "motion_weights" in name or name == "delta_xyz":
+                g["lr"] = self.motion_feature_scheduler_args(iteration)
+
+    def oneupSHdegree(self):                      # [REF :323-325]
+        if self.active_sh_degree < self.max_sh_degree:
+            self.active_sh_degree += 1
+
+    # ---- Adam-moment access (fused or torch) ---------------------------------------------------------------------
+    def adam_moments(self):
+        """{id(param): (exp_avg, exp_avg_sq)} of the current optimizer."""
+        opt = self.optimizer
+        if opt is None:
+            return {}
+        if hasattr(opt, "items"):
+            return {id(p): (m, v) for _, p, _, m, v in opt.items}
+        return {id(p): (st["exp_avg"], st["exp_avg_sq"]) for p, st in opt.state.items() if "exp_avg" in st}
+
+    def _rebuild_optimizer(self, carried):
+        """New bucket + optimizer over the model's CURRENT Parameters.  `carried` maps id(new per-Gaussian Parameter) to its
+        (exp_avg, exp_avg_sq); every other parameter keeps its moments; step count and learning rates are preserved."""
+        old = self.optimizer
+        if old is None:
+            return
+        old_mom = self.adam_moments()
+        fused = hasattr(old, "items")
+        lrs = {g["name"]: g["lr"] for g in old.param_groups}
+        old_step = old.step_count if fused else None
+        old_state = None if fused else {id(p): st for p, st in old.state.items()}
+        from . import grad_sink
+        grad_sink.forget_all()
+        self._install_optimizer(self._stage_groups(self._stage))
+        for g in self.optimizer.param_groups:
+            if g["name"] in lrs:
+                g["lr"] = lrs[g["name"]]
+        if fused:
+            self.optimizer.step_count = old_step
+            for _, p, _, m, v in self.optimizer.items:
+                src = carried.get(id(p)) or old_mom.get(id(p))
+                if src is not None and src[0].shape == m.shape:
+                    m.copy_(src[0]); v.copy_(src[1])
+        else:
+            some = next((st for st in old_state.values() if "step" in st), None)
+            for g in self.optimizer.param_groups:
+                for p in g["params"]:
+                    src = carried.get(id(p))
+                    if src is not None and some is not None:     # the reference keeps the stored state (and its step) [REF :595-598]
+                        self.optimizer.state[p] = {"step": some["step"].clone(), "exp_avg": src[0].clone(), "exp_avg_sq": src[1].clone()}
+                    elif id(p) in old_state:
+                        self.optimizer.state[p] = old_state[id(p)]
+
+    def _resize_per_gaussian(self, new_tensors, keep, n_new):
+        """Install new per-Gaussian tensors (name -> tensor).  `keep` = bool mask over the OLD rows that survive, in order;
+        `n_new` rows follow them with zero moments [REF :551-630 _prune_optimizer / cat_tensors_to_optimizer]."""
+        old = self._per_gaussian()
+        mom = self.adam_moments()
+        carried = {}
+        for name, p in old.items():
+            if id(p) in mom:
+                m, v = mom[id(p)]
+                tail = [n_new] + list(p.shape[1:])
+                carried[name] = (torch.cat([m[keep], torch.zeros(tail, device=m.device)]),
+                                 torch.cat([v[keep], torch.zeros(tail, device=v.device)]))
+        fresh = {}
+        for name, attr in PER_GAUSSIAN:
+            if name in new_tensors and name in old:
+                q = nn.Parameter(new_tensors[name].contiguous().requires_grad_(True))
+                setattr(self, attr, q)
+                fresh[name] = q
+        self._rebuild_optimizer({id(fresh[name]): mv for name, mv in carried.items() if name in fresh})
+
+    def _sync_side_stream(self):
+        ev = getattr(self, "_param_ready_event", None)      # a harness may be updating parameters on a second stream
+        if ev is not None:
+            torch.cuda.current_stream().wait_event(ev)
+
+    # ---- densification statistics ----------------------------------------------------------------------------------
+    def add_densification_stats(self, viewspace_point_tensor, update_filter):
+        """[REF scene/gaussian_model.py:755-760]"""
+        grad = torch.norm(viewspace_point_tensor.grad[update_filter, :2], dim=-1, keepdim=True)
+        self.xyz_gradient_accum[update_filter] += grad
+        self.denom[update_filter] += 1
+        cur = self.xyz_gradient_accum_max[update_filter]
+        self.xyz_gradient_accum_max[update_filter] = torch.where(grad > cur, grad, cur)
+
+    def add_desification_stats_motion(self, viewspace_point_tensor, update_filter=None):
+        """[REF :762-773] (the reference's spelling)"""
+        if update_filter is None:
+            motion = torch.norm(viewspace_point_tensor, dim=-1, keepdim=True)
+            self.xyz_motion_accum_max = torch.where(motion > self.xyz_motion_accum_max, motion, self.xyz_motion_accum_max)
+            self.motion_denom += 1
+        else:
+            grad = torch.norm(viewspace_point_tensor.grad, dim=-1, keepdim=True)
+            self.kpts_gradient_accum += grad
+            self.kpts_gradient_accum_max = torch.where(grad > self.kpts_gradient_accum_max, grad, self.kpts_gradient_accum_max)
+            self.kpts_denom += 1
+
+    # ---- densify / prune --------------------------------------------------------------------------------------------
+    def prune_points(self, mask):
+        """Remove the rows where `mask` is set [REF :566-589]."""
+        self._sync_side_stream()
+        keep = ~mask
+        P = {k: v.detach() for k, v in self._per_gaussian().items()}
+        self._resize_per_gaussian({k: v[keep] for k, v in P.items()}, keep, 0)
+        self.xyz_gradient_accum = self.xyz_gradient_accum[keep]
+        self.xyz_gradient_accum_max = self.xyz_gradient_accum_max[keep]
+        self.denom = self.denom[keep]
+        self.max_radii2D = self.max_radii2D[keep]
+
+    def densification_postfix(self, new):
+        """Append rows (name -> tensor) and reset EVERY per-Gaussian statistic, max_radii2D included [REF :632-661]."""
+        self._sync_side_stream()
+        P = {k: v.detach() for k, v in self._per_gaussian().items()}
+        n_old = P["xyz"].shape[0]
+        n_new = new["xyz"].shape[0]
+        keep = torch.ones(n_old, dtype=torch.bool, device=P["xyz"].device)
+        self._resize_per_gaussian({k: torch.cat([P[k], new[k]]) for k in P}, keep, n_new)
+        self._reset_gaussian_stats()
+
+    def densify_and_clone(self, grads, grad_threshold, scene_extent):
+        """[REF :696-711]"""
+        P = {k: v.detach() for k, v in self._per_gaussian().items()}
+        sel = torch.norm(grads, dim=-1) >= grad_threshold
+        sel = sel & (torch.exp(P["scaling"]).max(dim=1).values <= self.percent_dense * scene_extent)
+        self.densification_postfix({k: v[sel] for k, v in P.items()})
+        return int(sel.sum())
+
+    def densify_and_split(self, grads, grad_threshold, scene_extent, N=2, generator=None):
+        """[REF :663-694]: the gradients are zero-padded for the rows the clone step appended."""
+        P = {k: v.detach() for k, v in self._per_gaussian().items()}
+        n = P["xyz"].shape[0]
+        padded = torch.zeros(n, device=P["xyz"].device)
+        padded[:grads.shape[0]] = grads.squeeze()
+        scaling = torch.exp(P["scaling"])
+        sel = (padded >= grad_threshold) & (scaling.max(dim=1).values > self.percent_dense * scene_extent)
+        stds = scaling[sel].repeat(N, 1)
+        samples = torch.normal(mean=torch.zeros_like(stds), std=stds, generator=generator)
+        rots = build_rotation(P["rotation"][sel]).repeat(N, 1, 1)
+        new = {k: v[sel].repeat(N, *([1] * (v.dim() - 1))) for k, v in P.items()}
+        new["xyz"] = torch.bmm(rots, samples.unsqueeze(-1)).squeeze(-1) + P["xyz"][sel].repeat(N, 1)
+        new["scaling"] = torch.log(scaling[sel].repeat(N, 1) / (0.8 * N))
+        n_src = int(sel.sum())
+        self.densification_postfix(new)
+        self.prune_points(torch.cat([sel, torch.zeros(N * n_src, dtype=torch.bool, device=sel.device)]))
+        return n_src
+
+    def densify(self, max_grad, min_opacity, extent, max_screen_size, generator=None):
+        """Clone + split; NO pruning of transparent / oversized points here [REF :713-718]."""
+        grads = self.xyz_gradient_accum / self.denom
+        grads[grads.isnan()] = 0.0
+        n_clone = self.densify_and_clone(grads, max_grad, extent)
+        n_src = self.densify_and_split(grads, max_grad, extent, generator=generator)
+        return n_clone, n_src
+
+    def prune(self, max_grad, min_opacity, extent, max_screen_size):
+        """[REF :745-753]; runs with the LIVE max_radii2D, which a preceding densify has zeroed [REF :661]."""
+        o = torch.sigmoid(self._opacity.detach())
+        mask = (o < min_opacity).squeeze(-1)
+        if max_screen_size:
+            big_vs = self.max_radii2D > max_screen_size
+            big_ws = torch.exp(self._scaling.detach()).max(dim=1).values > 0.1 * extent
+            mask = mask | big_vs | big_ws
+        self.prune_points(mask)
+        return int(mask.sum())
+
+    def reset_opacity(self):
+        """opacity <- inverse_sigmoid(min(opacity, 0.01)); its Adam moments are zeroed [REF :526-545]."""
+        self._sync_side_stream()
+        o = torch.sigmoid(self._opacity.detach())
+        new = torch.minimum(o, torch.full_like(o, 0.01))
+        new = torch.log(new / (1 - new))
+        with torch.no_grad():
+            self._opacity.copy_(new)
+        mv = self.adam_moments().get(id(self._opacity))
+        if mv is not None:
+            mv[0].zero_(); mv[1].zero_()
+
+    # ---- keypoint growth -----------------------------------------------------------------------------------------------
+    def new_kpts_init(self):                      # [REF :170-172]
+        self.new_xyz = None
+        self.new_motion_feature = None
+
+    def _kpts_room(self):
+        return int(self.args.max_points + self.args.adaptive_points_num - self.super_gaussians.shape[0])
+
+    @torch.no_grad()
+    def get_new_kpts(self, mask, ratio=100):
+        """Furthest-point sample of the masked Gaussians -> candidate keypoints, each with the motion feature of its
+        nearest Gaussian [REF scene/gaussian_model.py:196-212]."""
+        sampling = self.get_xyz.detach()[mask].contiguous()
+        if sampling.shape[0] >= 1:
+            select = sampling.shape[0] // ratio if sampling.shape[0] > ratio else 1
+            clip = self._kpts_room()
+            select = select if select < clip else clip
+            if select <= 0:
+                self.new_xyz, self.new_motion_feature = sampling[:0], self.motion_feature.detach()[:0]
+                return
+            idx = furthest_point_sampling(sampling, select)
+            new_xyz = sampling[idx]
+            nn_idx = nearest_index(new_xyz, self._xyz.detach())
+            self.new_xyz, self.new_motion_feature = new_xyz[:clip], self.motion_feature.detach()[nn_idx][:clip]
+        else:
+            self.new_xyz, self.new_motion_feature = None, None
+
+    def densification_motion_postfix(self, new_xyz, new_motion_feature):
+        """Append keypoints (zero Adam moments) and reset every statistic [REF :612-630]."""
+        mom = self.adam_moments()
+        old_kp, old_kf = self.super_gaussians, self.super_gaussians_feature
+        carried = {}
+        new_kp = nn.Parameter(torch.cat([old_kp.detach(), new_xyz]).contiguous().requires_grad_(True))
+        new_kf = nn.Parameter(torch.cat([old_kf.detach(), new_motion_feature]).contiguous().requires_grad_(True))
+        for old, new, ext in ((old_kp, new_kp, new_xyz), (old_kf, new_kf, new_motion_feature)):
+            if id(old) in mom:
+                m, v = mom[id(old)]
+                carried[id(new)] = (torch.cat([m, torch.zeros_like(ext)]), torch.cat([v, torch.zeros_like(ext)]))
+        self.super_gaussians, self.super_gaussians_feature = new_kp, new_kf
+        self._rebuild_optimizer(carried)
+        n, dev = self.get_xyz.shape[0], self.get_xyz.device
+        self.xyz_motion_accum = torch.zeros((n, 1), device=dev)
+        self.xyz_motion_accum_max = torch.zeros((n, 1), device=dev)
+        self.motion_denom = torch.zeros((n, 1), device=dev)
+        self._reset_kpts_stats()
+        self._reset_gaussian_stats()
+        self.knn_idx = None if getattr(self, "_knn_from_model", False) else self.knn_idx    # stale once K changes
+
+    @torch.no_grad()
+    def densify_kpts(self, max_grad, mode="gaussian_mean", ratio=100):
+        """[REF scene/gaussian_model.py:720-744]"""
+        if mode == "down_sampling":
+            grads = self.xyz_gradient_accum / self.denom
+            grads[grads.isnan()] = 0.0
+            self.get_new_kpts((grads > max_grad).squeeze(-1), ratio=ratio)
+        else:
+            if mode == "gaussian_mean":
+                grads = self.xyz_gradient_accum / self.denom
+                grads[grads.isnan()] = 0.0
+                mask = (grads > max_grad).squeeze(-1)
+                _, index = self.weights_sum[mask, :self.super_gaussians.shape[0]].max(dim=-1)
+                clone_idx = index.unique()
+            else:
+                grads = self.kpts_gradient_accum / self.kpts_denom
+                grads[grads.isnan()] = 0.0
+                clone_idx = (grads >= max_grad).view([-1])
+            clip = self._kpts_room()
+            self.new_xyz = self.super_gaussians.detach()[clone_idx][:clip]
+            self.new_motion_feature = self.super_gaussians_feature.detach()[clone_idx][:clip]
+        if self.new_xyz is not None:
+            self.densification_motion_postfix(self.new_xyz, self.new_motion_feature)
+            self.new_kpts_init()
+
+    @torch.no_grad()
+    def set_superKeypoints(self, seed=0):
+        """k-means of [xyz | motion_feature] -> K = max_points keypoints: positions = per-cluster mean of the Gaussian
+        positions, features = the motion-feature part of the cluster centres [REF scene/gaussian_model.py:127-136]."""
+        xyz = self.get_xyz.detach()
+        feature = torch.cat([xyz, self.motion_feature.detach()], dim=-1)
+        ids, centres = kmeans(feature, int(self.args.max_points), seed=seed)
+        K = centres.shape[0]
+        sums = torch.zeros(K, 3, device=xyz.device).index_add_(0, ids, xyz)
+        cnt = torch.zeros(K, device=xyz.device).index_add_(0, ids, torch.ones(xyz.shape[0], device=xyz.device))
+        means = torch.where(cnt[:, None] > 0, sums / cnt[:, None].clamp_min(1), centres[:, :3])
+        self.super_gaussians_feature = nn.Parameter(centres[:, 3:].contiguous().requires_grad_(True))
+        self.super_gaussians = nn.Parameter(means.contiguous().requires_grad_(True))

@@ -305,6 +305,11 @@ int gp_weights_backward(const gp_hashgrid_config* cfg, int64_t n, const float* x
 int gp_knn_keypoints(int64_t n, const float* xyz, const float* feat, int32_t feat_dim, float amplify, int64_t K,
                      const float* kp_xyz, const float* kp_feat, int32_t nn, int64_t* idx_out, float* d2_out, gp_stream_t stream);
 
+/* Furthest-point sampling of xyz[n,3], starting at point 0: idx_out[m] (int32); idx_out[j] is the point farthest from
+ * {idx_out[0..j)} (first maximum on ties).  tmp_dist: n floats of scratch.  Replaces pointops' furthestsampling_cuda for one
+ * batch [REF utils/fps.py:71-88, scene/gaussian_model.py:196-212 get_new_kpts]. */
+int gp_furthest_point_sampling(int64_t n, const float* xyz, int64_t m, int32_t* idx_out, float* tmp_dist, gp_stream_t stream);
+
 /* ---- measurement ----------------------------------------------------------------------------- */
 /* gp_profile_enable(level): 0 = off, 1 = bracket only the roofline kernel (composite forward), 2 = every
  * kernel.  When enabled, the library brackets kernels with hipEvent pairs recorded on the launch stream.

@@ -137,6 +137,19 @@ class RasterOracle:
         self.composite(s)
         return s
 
+    def forward_with_binning_of(self, ref, st: RasterSettings, means3D, opacities, shs=None, colors_precomp=None, scales=None,
+                                rotations=None, cov3D_precomp=None):
+        """The float64 shadow of a float32 forward `ref` (another precision's state): per-Gaussian quantities and the
+        composite are evaluated in THIS precision, the discrete binning result (visibility, per-tile depth order) is taken
+        from `ref`.  Two Gaussians whose depths coincide in float32 but not in float64 would otherwise be blended in the
+        opposite order by the two precisions -- at 1 M Gaussians a few hundred tiles contain such a pair -- and the
+        gradient "ground truth" would be that of a (slightly) different image."""
+        s = self.preprocess(st, means3D, opacities, shs, colors_precomp, scales, rotations, cov3D_precomp)
+        s["R"], s["point_list"], s["ranges"] = ref["R"], ref["point_list"].copy(), ref["ranges"].copy()
+        s["radii"] = ref["radii"].copy()
+        self.composite(s)
+        return s
+
     def backward(self, s, dL_dcolor, dL_ddepth=None):
         """-> dict of gradients wrt means3D, means2D(NDC), shs|colors_precomp, opacities, scales, rotations,
         cov3D_precomp."""

@@ -1,0 +1,97 @@
+"""The optimizer half of the reference's checkpoint tuple `(gaussians.state_dict(), optimizer.state_dict(), iteration)`
+[REF train.py:199-201] and `GaussianModel.restore` [REF scene/gaussian_model.py:96-104]: FusedAdam speaks
+torch.optim.Adam's state_dict layout with the reference's group names, both ways."""
+from types import SimpleNamespace
+
+import pytest
+import torch
+
+import gaussianprediction_amd as gpa
+from gaussianprediction_amd.dist import FlatGradBucket
+from gaussianprediction_amd.loss_ops import FusedAdam
+from gaussianprediction_amd.scene_synth import SceneSpec, make_gaussians
+from gaussianprediction_amd.training import default_training_args
+
+STAGE_GROUPS = {   # [REF scene/gaussian_model.py:394-451]
+    1: ["xyz", "f_dc", "f_rest", "opacity", "scaling", "rotation", "df_mlp", "motion_feature"],
+    2: ["s_xyz", "s_motion_feature", "df_mlp"],
+    3: ["xyz", "f_dc", "f_rest", "opacity", "scaling", "rotation", "s_xyz", "s_motion_feature", "df_mlp"],
+}
+
+
+def _model(n=30, K=6, device="cpu", **kw):
+    a = dict(beta=0.1, d=4, w=256, feature_dim=32, second_stage_iteration=30000, third_stage_iteration=40000,
+             jointly_iteration=1000, nearest_num=6, norm_rotation=True, step_opacity=False, step_opacity_iteration=5000,
+             opacity_type="implicit", xyz_noise_iteration=0, max_points=K, adaptive_points_num=0)
+    a.update(kw)
+    raw = make_gaussians(SceneSpec(n_gaussians=n, seed=3), device=device)
+    pc = gpa.GaussianModel(3, SimpleNamespace(**a))
+    pc.set_inputDim(12, 60)
+    pc.create_from_tensors(raw["xyz"], raw["features_dc"], raw["features_rest"], raw["scaling"], raw["rotation"], raw["opacity"],
+                           raw["motion_feature"], raw["xyz"][:K].clone(), raw["motion_feature"][:K].clone())
+    return pc
+
+
+def _reference_layout_adam(pc, stage, steps=2):
+    """A plain torch.optim.Adam over the reference's groups for `stage`, stepped a few times: what the reference saves."""
+    pc.training_args = default_training_args()
+    opt = torch.optim.Adam(pc._stage_groups(stage), lr=0.0, eps=1e-15)
+    g = torch.Generator().manual_seed(9)
+    for _ in range(steps):
+        for grp in opt.param_groups:
+            for p in grp["params"]:
+                p.grad = torch.randn(p.shape, generator=g).to(p.device)
+        opt.step()
+    return opt
+
+
+@pytest.mark.parametrize("stage,iteration", [(1, 5000), (2, 35000), (3, 50000)])
+def test_groups_and_restore_from_a_reference_layout_tuple(stage, iteration):
+    src = _model()
+    ref_opt = _reference_layout_adam(src, stage)
+    assert [g["name"] for g in ref_opt.param_groups] == STAGE_GROUPS[stage]
+    sd = ref_opt.state_dict()
+    sd["param_groups"][0]["lr"] = 1.25e-5                     # restore must take the saved learning rates
+    dst = _model()
+    dst.load_state_dict(src.state_dict(), strict=False)
+    dst.restore(sd, default_training_args(), iteration)       # CPU: the optimizer IS torch.optim.Adam
+    assert [g["name"] for g in dst.optimizer.param_groups] == STAGE_GROUPS[stage]
+    assert dst.optimizer.param_groups[0]["lr"] == 1.25e-5
+    for (ga, gb) in zip(ref_opt.param_groups, dst.optimizer.param_groups):
+        for pa, pb in zip(ga["params"], gb["params"]):
+            assert torch.equal(ref_opt.state[pa]["exp_avg"], dst.optimizer.state[pb]["exp_avg"])
+    assert dst.second_stage == (stage >= 2) and dst.third_stage == (stage == 3)
+    # every optimized parameter's gradient is a view of the flat bucket
+    for g in dst.optimizer.param_groups:
+        for p in g["params"]:
+            assert p.grad is not None and p.grad.data_ptr() >= dst.bucket.flat.data_ptr()
+
+
+def test_fused_adam_state_dict_has_torch_adams_layout():
+    pc = _model()
+    pc.training_args = default_training_args()
+    ref = _reference_layout_adam(pc, 3)
+    bucket = FlatGradBucket([p for g in ref.param_groups for p in g["params"]])
+    fused = FusedAdam([{"params": g["params"], "lr": g["lr"], "name": g["name"]} for g in ref.param_groups], bucket, eps=1e-15)
+    assert fused.state_dict()["state"] == {}                   # no state before the first step, as in torch
+    fused.load_state_dict(ref.state_dict())
+    assert fused.step_count == 2
+    out = fused.state_dict()
+    want = ref.state_dict()
+    assert set(out) == set(want) and len(out["param_groups"]) == len(want["param_groups"])
+    for a, b in zip(out["param_groups"], want["param_groups"]):
+        assert set(a) == set(b) and a["params"] == b["params"] and a["name"] == b["name"] and a["eps"] == 1e-15
+    assert set(out["state"]) == set(want["state"])
+    for k in want["state"]:
+        assert torch.equal(out["state"][k]["exp_avg"], want["state"][k]["exp_avg"])
+        assert torch.equal(out["state"][k]["exp_avg_sq"], want["state"][k]["exp_avg_sq"])
+        assert float(out["state"][k]["step"]) == float(want["state"][k]["step"])
+    # ... and plain torch.optim.Adam accepts what FusedAdam wrote
+    fresh = torch.optim.Adam([{"params": [torch.nn.Parameter(p.detach().clone()) for p in g["params"]], "lr": 0.0, "name": g["name"]}
+                              for g in ref.param_groups], lr=0.0, eps=1e-15)
+    fresh.load_state_dict(out)
+    assert float(fresh.state[fresh.param_groups[0]["params"][0]]["step"]) == 2.0
+    with pytest.raises(ValueError, match="parameter groups"):
+        fused.load_state_dict({"state": {}, "param_groups": want["param_groups"][:-1]})
+    st = fused.state
+    assert st[ref.param_groups[0]["params"][0]]["exp_avg"].shape == ref.param_groups[0]["params"][0].shape

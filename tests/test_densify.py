@@ -1,4 +1,6 @@
-"""Densify / prune with optimizer-state surgery [REF scene/gaussian_model.py:532-690, 739-760]."""
+"""Densify / prune / opacity reset / keypoint growth with optimizer-state surgery
+[REF scene/gaussian_model.py:526-754, train.py:164-192].  CPU: the optimizer is the reference's plain
+torch.optim.Adam; the same code drives the fused Adam on the GPU (tests/test_gpu_densify.py)."""
 from types import SimpleNamespace
 
 import numpy as np
@@ -6,86 +8,165 @@ import torch
 
 import gaussianprediction_amd as gpa
 from gaussianprediction_amd import densify as dn
-from gaussianprediction_amd.cameras import orbit_cameras
 from gaussianprediction_amd.scene_synth import SceneSpec, make_gaussians
-from gaussianprediction_amd.train_step import TrainStep
+from gaussianprediction_amd.training import default_training_args, furthest_point_sampling, get_expon_lr_func
 
 
-def _setup(n=40, iteration=5000):
-    margs = SimpleNamespace(beta=0.1, d=4, w=256, feature_dim=32, second_stage_iteration=30000, third_stage_iteration=40000,
-                            jointly_iteration=1000, nearest_num=6, norm_rotation=True, step_opacity=False,
-                            step_opacity_iteration=5000, opacity_type="implicit", xyz_noise_iteration=0)
+def _margs(**kw):
+    a = dict(beta=0.1, d=4, w=256, feature_dim=32, second_stage_iteration=30000, third_stage_iteration=40000,
+             jointly_iteration=1000, nearest_num=6, norm_rotation=True, step_opacity=False, step_opacity_iteration=5000,
+             opacity_type="implicit", xyz_noise_iteration=0, max_points=8, adaptive_points_num=6, adaptive_from_iter=3000,
+             adaptive_end_iter=10000, adaptive_interval=200, densify_from_grad="True", densify_from_teaching=False,
+             teaching_threshold=0.2)
+    a.update(kw)
+    return SimpleNamespace(**a)
+
+
+def _setup(n=40, keypoints=0, **kw):
+    margs = _margs(**kw)
     raw = make_gaussians(SceneSpec(n_gaussians=n, extent=(1.3, 1.3, 1.3), scale_lo=0.01, scale_hi=0.2, seed=5))
     pc = gpa.GaussianModel(3, margs)
     pc.set_inputDim(12, 60)
+    kp = raw["xyz"][:keypoints].clone() if keypoints else None
+    kf = raw["motion_feature"][:keypoints].clone() if keypoints else None
     pc.create_from_tensors(raw["xyz"], raw["features_dc"], raw["features_rest"], raw["scaling"], raw["rotation"], raw["opacity"],
-                           raw["motion_feature"])
-    cams = orbit_cameras(2, 4.0, 0.69, 32, 32)
-    ts = TrainStep(pc, cams, [torch.zeros(3, 32, 32)] * 2, iteration)       # stage 1 (no kernels are launched in this test)
-    return pc, ts
+                           raw["motion_feature"], kp, kf)
+    pc.training_setup(default_training_args())
+    return pc
 
 
-def test_clone_split_prune_and_moment_surgery():
-    pc, ts = _setup()
+def _fake_adam_state(pc, step=17):
+    """Give every optimized parameter a recognisable Adam state (as after `step` optimizer steps)."""
+    for k, g in enumerate(pc.optimizer.param_groups):
+        for p in g["params"]:
+            m = torch.arange(p.numel(), dtype=torch.float32).reshape(p.shape) + 1000 * k
+            pc.optimizer.state[p] = {"step": torch.tensor(float(step)), "exp_avg": m.clone(), "exp_avg_sq": 2 * m}
+
+
+def test_densify_then_prune_as_the_reference_sequences_them():
+    pc = _setup()
     n = pc._xyz.shape[0]
-    mom = ts.adam_moments()
-    for k, p in enumerate([pc._xyz, pc._scaling, pc._features_rest, pc.motion_feature]):
-        m, v = mom[id(p)]
-        m.copy_(torch.arange(m.numel(), dtype=torch.float32).reshape(m.shape) + 1000 * k)
-        v.copy_(2 * m)
-    ts.optimizer.step_count = 17
-    old = {k: v.detach().clone() for k, v in dn._per_gaussian(pc).items()}
-    old_m = mom[id(pc._xyz)][0].clone()
-    stats = dn.DensificationStats(n, "cpu")
-    stats.denom += 1
+    _fake_adam_state(pc)
     hot = torch.zeros(n, dtype=torch.bool); hot[[1, 4, 7, 20, 21]] = True
-    stats.xyz_gradient_accum[hot] = 1.0                       # mean view-space gradient 1.0 >> threshold
+    pc.denom += 1
+    pc.xyz_gradient_accum[hot] = 1.0                       # mean view-space gradient 1.0 >> threshold
     extent = 5.0
     with torch.no_grad():
-        pc._opacity[30:33] = -10.0                            # sigmoid -> ~4.5e-5 < min_opacity: pruned
-        pc._scaling[[1, 4]] = np.log(0.2)                     # > percent_dense*extent = 0.05: split
-        pc._scaling[[7, 20, 21]] = np.log(0.01)               # small: cloned
+        pc._opacity[30:33] = -10.0                         # sigmoid -> ~4.5e-5 < min_opacity: pruned by prune(), not by densify()
+        pc._scaling[[1, 4]] = np.log(0.2)                  # > percent_dense*extent = 0.05: split
+        pc._scaling[[7, 20, 21]] = np.log(0.01)            # small: cloned
         pc._opacity[[1, 4, 7, 20, 21]] = 2.0
-    old = {k: v.detach().clone() for k, v in dn._per_gaussian(pc).items()}
+    pc.max_radii2D[[0, 2, 3]] = 50.0                       # large on screen BEFORE the densify
+    old = {k: v.detach().clone() for k, v in pc._per_gaussian().items()}
+    old_m = pc.adam_moments()[id(pc._xyz)][0].clone()
     g = torch.Generator().manual_seed(0)
-    n_clone, n_src, n_pruned = dn.densify_and_prune(pc, ts, stats, max_grad=0.0002, min_opacity=0.005, extent=extent,
-                                                    max_screen_size=None, generator=g)
-    assert (n_clone, n_src, n_pruned) == (3, 2, 3)
-    N1 = n - 2 - 3 + 3 + 4                                    # - split sources - transparent + clones + 2 children per source
-    for k, p in dn._per_gaussian(pc).items():
-        assert p.shape[0] == N1, k
-    survivors = torch.ones(n, dtype=torch.bool); survivors[[1, 4, 30, 31, 32]] = False
-    assert torch.equal(pc._xyz.detach()[:n - 5], old["xyz"][survivors])
-    # clones are exact copies of their sources, appended after the survivors [REF :668-688]
-    assert torch.equal(pc._xyz.detach()[n - 5:n - 2], old["xyz"][[7, 20, 21]])
-    assert torch.equal(pc._features_rest.detach()[n - 5:n - 2], old["f_rest"][[7, 20, 21]])
-    # split children: scale / (0.8 N) in log space, other attributes repeated [REF :645-662]
-    ch = pc._scaling.detach()[n - 2:]
-    assert torch.allclose(ch, (old["scaling"][[1, 4]].exp() / 1.6).log().repeat(2, 1))
-    assert torch.equal(pc._rotation.detach()[n - 2:], old["rotation"][[1, 4]].repeat(2, 1))
-    assert not torch.equal(pc._xyz.detach()[n - 2:], old["xyz"][[1, 4]].repeat(2, 1))      # sampled around the source
-    # Adam moments: survivors carried, new rows zero, step count kept; gradients are views of the new bucket
-    m, v = ts.adam_moments()[id(pc._xyz)]
-    assert torch.equal(m[:n - 5], old_m[survivors]) and float(m[n - 5:].abs().sum()) == 0.0 and torch.equal(v[:n - 5], 2 * m[:n - 5])
-    assert ts.optimizer.step_count == 17
-    assert pc._xyz.grad is not None and pc._xyz.grad.shape == pc._xyz.shape and pc._xyz.grad.data_ptr() >= ts.bucket.flat.data_ptr()
-    # the MLP kept its parameters and moments
-    assert any(id(p) in ts.adam_moments() for p in pc.df_model.parameters())
-    assert stats.denom.shape[0] == N1 and float(stats.denom.sum()) == 0.0
+    n_clone, n_src = pc.densify(0.0002, 0.005, extent, 20, generator=g)
+    assert (n_clone, n_src) == (3, 2)
+    N1 = n + 3 + 4 - 2                                     # + clones + 2 children per source - the split sources
+    assert all(p.shape[0] == N1 for p in pc._per_gaussian().values())
+    # densification_postfix resets max_radii2D for EVERY row [REF scene/gaussian_model.py:661] ...
+    assert float(pc.max_radii2D.abs().sum()) == 0.0 and pc.max_radii2D.shape[0] == N1
+    assert float(pc.denom.sum()) == 0.0 and float(pc.xyz_gradient_accum.sum()) == 0.0
+    survivors = torch.ones(n, dtype=torch.bool); survivors[[1, 4]] = False
+    assert torch.equal(pc._xyz.detach()[:n - 2], old["xyz"][survivors])
+    # clones are exact copies of their sources, appended after the old rows [REF :696-711]; then the split children
+    assert torch.equal(pc._xyz.detach()[n - 2:n + 1], old["xyz"][[7, 20, 21]])
+    ch = pc._scaling.detach()[n + 1:]
+    assert torch.allclose(ch, (old["scaling"][[1, 4]].exp() / 1.6).log().repeat(2, 1))                # scale / (0.8 N) [REF :677]
+    assert torch.equal(pc._rotation.detach()[n + 1:], old["rotation"][[1, 4]].repeat(2, 1))
+    assert not torch.equal(pc._xyz.detach()[n + 1:], old["xyz"][[1, 4]].repeat(2, 1))                 # sampled around the source
+    # Adam moments: survivors carried, appended rows zero, step kept; gradients are views of the NEW bucket
+    m, v = pc.adam_moments()[id(pc._xyz)]
+    assert torch.equal(m[:n - 2], old_m[survivors]) and float(m[n - 2:].abs().sum()) == 0.0 and torch.equal(v[:n - 2], 2 * m[:n - 2])
+    assert float(pc.optimizer.state[pc._xyz]["step"]) == 17.0
+    assert pc._xyz.grad is not None and pc._xyz.grad.shape == pc._xyz.shape and pc._xyz.grad.data_ptr() >= pc.bucket.flat.data_ptr()
+    assert any(id(p) in pc.adam_moments() for p in pc.df_model.parameters())                          # the MLP kept its state
+    # ... so the screen-size test of the prune that follows can not fire for the rows that were large before
+    # [REF train.py:170-177]: only the three transparent Gaussians go
+    n_pruned = pc.prune(0.0002, 0.005, extent, 20)
+    assert n_pruned == 3 and pc._xyz.shape[0] == N1 - 3
+    # prune on its own (densify skipped because N >= max_gaussian_size) DOES see the live radii [REF train.py:176-177]
+    pc.max_radii2D[[0, 2]] = 50.0
+    assert pc.prune(0.0002, 0.005, extent, 20) == 2
+    assert pc.prune(0.0002, 0.005, extent, None) == 0      # size_threshold None before the first opacity reset [REF train.py:171]
+    with torch.no_grad():
+        pc._scaling[5] = np.log(0.6)                       # > 0.1 * extent: world-space size test [REF :750]
+    assert pc.prune(0.0002, 0.005, extent, 20) == 1
+
+
+def test_loop_driver_prunes_without_densifying_at_the_size_cap():
+    pc = _setup()
+    opt = default_training_args()
+    with torch.no_grad():
+        pc._opacity[:4] = -10.0
+    pc.denom += 1
+    pc.xyz_gradient_accum += 1.0
+    n = pc._xyz.shape[0]
+    out = dn.densification_step(pc, 600, opt, 5.0, max_gaussian_size=n)        # N >= cap: densify skipped, prune runs
+    assert out == (None, None, 4) and pc._xyz.shape[0] == n - 4
+    assert dn.densification_step(pc, 601, opt, 5.0) == (None, None, None)        # not on the interval
+    out = dn.densification_step(pc, 3000, opt, 5.0, max_gaussian_size=10**6)     # interval + opacity reset in between
+    assert out[0] is not None and float(torch.sigmoid(pc._opacity.detach()).max()) <= 0.01 + 1e-6
 
 
 def test_stats_and_reset_opacity():
-    pc, ts = _setup()
+    pc = _setup()
     n = pc._xyz.shape[0]
-    stats = dn.DensificationStats(n, "cpu")
     vs = torch.zeros(n, 3, requires_grad=True)
     vs.grad = torch.zeros(n, 3); vs.grad[:, 0] = 3.0; vs.grad[:, 1] = 4.0
     filt = torch.zeros(n, dtype=torch.bool); filt[::2] = True
     radii = torch.arange(n, dtype=torch.int32)
-    stats.add(vs, filt, radii); stats.add(vs, filt, radii)
-    assert torch.allclose(stats.xyz_gradient_accum[::2], torch.full((n // 2, 1), 10.0)) and float(stats.xyz_gradient_accum[1::2].sum()) == 0
-    assert float(stats.denom[0]) == 2 and float(stats.max_radii2D[2]) == 2.0
-    mom = ts.adam_moments()[id(pc._opacity)]
-    mom[0].fill_(1.0)
-    dn.reset_opacity(pc, ts)
-    assert float(torch.sigmoid(pc._opacity.detach()).max()) <= 0.01 + 1e-6 and float(mom[0].abs().sum()) == 0.0   # [REF :526-530]
+    dn.track_view(pc, vs, filt, radii); dn.track_view(pc, vs, filt, radii)
+    assert torch.allclose(pc.xyz_gradient_accum[::2], torch.full((n // 2, 1), 10.0)) and float(pc.xyz_gradient_accum[1::2].sum()) == 0
+    assert float(pc.denom[0]) == 2 and float(pc.max_radii2D[2]) == 2.0 and float(pc.xyz_gradient_accum_max[0]) == 5.0
+    _fake_adam_state(pc)
+    pc.reset_opacity()
+    mom = pc.adam_moments()[id(pc._opacity)]
+    assert float(torch.sigmoid(pc._opacity.detach()).max()) <= 0.01 + 1e-6 and float(mom[0].abs().sum()) == 0.0   # [REF :526-545]
+
+
+def test_keypoint_growth_by_down_sampling():
+    pc = _setup(n=400, keypoints=8)
+    pc.training2stage_setup()
+    _fake_adam_state(pc)
+    names = [g["name"] for g in pc.optimizer.param_groups]
+    assert names == ["s_xyz", "s_motion_feature", "df_mlp"]
+    pc.denom += 1
+    pc.xyz_gradient_accum[:300] = 1.0                      # 300 hot Gaussians -> 300 // 100 = 3 new keypoints (ratio 100)
+    old_kp = pc.super_gaussians.detach().clone()
+    old_m = pc.adam_moments()[id(pc.super_gaussians)][0].clone()
+    pc.densify_kpts(0.0002, mode="down_sampling")
+    assert pc.super_gaussians.shape == (11, 3) and pc.super_gaussians_feature.shape == (11, 32)
+    assert torch.equal(pc.super_gaussians.detach()[:8], old_kp)
+    # the new keypoints are a furthest-point sample of the hot Gaussians, starting at the first one [REF utils/fps.py:71-88]
+    hot = pc._xyz.detach()[:300]
+    idx = furthest_point_sampling(hot, 3)
+    assert int(idx[0]) == 0 and torch.equal(pc.super_gaussians.detach()[8:], hot[idx])
+    d1 = ((hot - hot[0]) ** 2).sum(-1)
+    assert int(idx[1]) == int(d1.argmax())
+    # each takes the motion feature of its nearest Gaussian (itself) [REF scene/gaussian_model.py:207-208]
+    assert torch.equal(pc.super_gaussians_feature.detach()[8:], pc.motion_feature.detach()[:300][idx])
+    m, v = pc.adam_moments()[id(pc.super_gaussians)]
+    assert torch.equal(m[:8], old_m) and float(m[8:].abs().sum()) == 0.0
+    assert pc.kpts_denom.shape == (11, 1) and float(pc.denom.sum()) == 0.0 and pc.new_xyz is None
+    # the cap max_points + adaptive_points_num = 14 clips the growth [REF :199-201]
+    pc.denom += 1
+    pc.xyz_gradient_accum[:] = 1.0
+    pc.densify_kpts(0.0002, mode="down_sampling", ratio=10)
+    assert pc.super_gaussians.shape[0] == 14
+
+
+def test_learning_rate_schedule_matches_the_reference_formula():
+    f = get_expon_lr_func(1.6e-4, 1.6e-6, lr_delay_mult=0.01, max_steps=30000)
+    assert abs(f(0) - 1.6e-4) < 1e-12 and abs(f(30000) - 1.6e-6) < 1e-12 and abs(f(15000) - 1.6e-5) < 1e-10
+    g = get_expon_lr_func(8e-4, 8e-5, lr_delay_steps=30000, max_steps=30000)       # delay_mult 1.0: no easing
+    assert abs(g(15000) - 8e-4 * 10 ** -0.5) < 1e-9
+    h = get_expon_lr_func(1.0, 1.0, lr_delay_steps=100, lr_delay_mult=0.01)
+    assert abs(h(0) - 0.01) < 1e-12 and abs(h(50) - (0.01 + 0.99 * np.sin(0.25 * np.pi))) < 1e-12 and h(-1) == 0.0
+    pc = _setup(keypoints=8)
+    pc.update_learning_rate(15000)
+    lr = {g["name"]: g["lr"] for g in pc.optimizer.param_groups}
+    assert abs(lr["xyz"] - 1.6e-5) < 1e-10                       # position schedule (spatial_lr_scale 1)
+    assert abs(lr["df_mlp"] - np.exp(0.5 * np.log(8e-4) + 0.5 * np.log(1.6e-6))) < 1e-10        # mlp_lr -> position_lr_final
+    assert lr["f_dc"] == 0.0025 and lr["opacity"] == 0.05        # groups without a schedule keep their rate
+    assert abs(lr["motion_feature"] - g(15000)) < 1e-12          # mfeature_lr -> mfeature_lr_final over position_lr_max_steps

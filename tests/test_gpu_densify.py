@@ -38,19 +38,26 @@ def test_steps_densify_steps(iteration):
     with torch.no_grad():
         gts = [render(c, pc, pipe, torch.zeros(3, device=dev), time=torch.tensor([0.3], device=dev), it=iteration)["render"] * 0.9
                for c in cams]
-    ts = TrainStep(pc, cams, gts, iteration)
-    stats = dn.DensificationStats(pc._xyz.shape[0], dev)
+    ts = TrainStep(pc, cams, gts, iteration, schedule=True)
     losses = []
     for i in range(3):
         loss, pkg = ts.step(i)
-        stats.add(pkg["viewspace_points"], pkg["visibility_filter"], pkg["radii"])
+        dn.track_view(pc, pkg["viewspace_points"], pkg["visibility_filter"], pkg["radii"])
         losses.append(float(loss))
     n0 = pc._xyz.shape[0]
-    if iteration <= 30000:          # the reference densifies in stage 1 [REF train.py:164-175]
-        n_clone, n_src, n_pruned = dn.densify_and_prune(pc, ts, stats, max_grad=1e-7, min_opacity=0.005, extent=4.0, max_screen_size=20)
-        assert n_clone + n_src > 0 and pc._xyz.shape[0] == n0 + n_clone + n_src - n_pruned
+    step0 = pc.optimizer.step_count
+    if iteration <= 30000:          # the reference densifies in stage 1 [REF train.py:164-177]: densify, then prune
+        m_old = pc.adam_moments()[id(pc._xyz)][0].clone()
+        n_clone, n_src = pc.densify(1e-7, 0.005, 4.0, 20)
+        assert n_clone + n_src > 0 and pc._xyz.shape[0] == n0 + n_clone + n_src
+        assert float(pc.max_radii2D.abs().sum()) == 0.0            # reset for every row [REF scene/gaussian_model.py:661]
+        m_new = pc.adam_moments()[id(pc._xyz)][0]
+        assert float(m_new[n0 - n_src:].abs().sum()) == 0.0 and float(m_new[:n0 - n_src].abs().sum()) > 0 and m_old.shape[0] == n0
+        n_pruned = pc.prune(1e-7, 0.005, 4.0, 20)
+        assert pc._xyz.shape[0] == n0 + n_clone + n_src - n_pruned
     else:
-        dn.reset_opacity(pc, ts)
+        pc.reset_opacity()
+    assert pc.optimizer.step_count == step0
     if pc._xyz.shape[0] != n0:
         knn_and_weights()
     for i in range(3):

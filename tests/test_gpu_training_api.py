@@ -1,0 +1,227 @@
+"""-m gpu: the training-side surface of the reference's GaussianModel on the HIP path -- `forward(..., return_weights=True)`
+[REF scene/gaussian_model.py:231,299-303; eval.py:126], checkpoint tuple interchange through the fused Adam
+[REF train.py:199-201, scene/gaussian_model.py:96-104], `--batch` accumulation on one GPU [REF train.py:113-133],
+furthest-point sampling [REF utils/fps.py:71-88] and a 2-rank view-parallel step (RCCL when two GPUs are visible, gloo with
+both ranks on the one GPU otherwise)."""
+import math
+import os
+import socket
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import gaussianprediction_amd as gpa  # noqa: E402
+from gaussianprediction_amd.cameras import orbit_cameras  # noqa: E402
+from gaussianprediction_amd.io_formats import load_checkpoint, save_checkpoint  # noqa: E402
+from gaussianprediction_amd.renderer import render  # noqa: E402
+from gaussianprediction_amd.scene_synth import SceneSpec, make_gaussians, make_keypoints  # noqa: E402
+from gaussianprediction_amd.train_step import TrainStep  # noqa: E402
+from gaussianprediction_amd.training import default_training_args, furthest_point_sampling  # noqa: E402
+from oracle import deform_oracle as do  # noqa: E402
+
+
+def margs(**kw):
+    a = dict(beta=0.1, d=4, w=256, feature_dim=32, second_stage_iteration=30000, third_stage_iteration=40000,
+             jointly_iteration=1000, nearest_num=6, norm_rotation=True, step_opacity=False, step_opacity_iteration=5000,
+             opacity_type="implicit", xyz_noise_iteration=0, max_points=48, adaptive_points_num=0)
+    a.update(kw)
+    return SimpleNamespace(**a)
+
+
+def build(n=4000, K=48, dev="cuda", W=160, H=128, seed=11, **kw):
+    args = margs(**kw)
+    raw = make_gaussians(SceneSpec(n_gaussians=n, extent=(1.3, 1.3, 1.3), scale_lo=0.01, scale_hi=0.08, seed=seed), device=dev)
+    kp, kpf, idx, rw = make_keypoints(raw["xyz"], raw["motion_feature"], K, args.nearest_num)
+    torch.manual_seed(1234)                      # the MLP's default nn.Linear init draws from the global generator
+    pc = gpa.GaussianModel(3, args)
+    tf = 10 if args.step_opacity else 6
+    pc.set_inputDim(2 * tf, 60)
+    pc.create_from_tensors(raw["xyz"], raw["features_dc"], raw["features_rest"], raw["scaling"], raw["rotation"], raw["opacity"],
+                           raw["motion_feature"] * 50, kp, kpf * 50)
+    pc.set_keypoint_weights(rw, idx)
+    cams = orbit_cameras(4, 4.0, 0.69, W, H, device=dev)
+    pipe = SimpleNamespace(convert_SHs_python=False, compute_cov3D_python=False, debug=False)
+    with torch.no_grad():
+        gts = [render(c, pc, pipe, torch.zeros(3, device=dev), time=torch.tensor([0.3], device=dev), it=50000)["render"] * 0.9 for c in cams]
+    return pc, cams, gts, raw, rw, idx, args
+
+
+def test_forward_return_weights_is_the_reference_dense_form():
+    pc, cams, gts, raw, rw, idx, args = build(n=1500, K=40)
+    t = torch.tensor([0.4], device="cuda")
+    with torch.no_grad():
+        out4 = pc(t, 50000)
+        out6 = pc(t, 50000, return_weights=True)
+        assert len(out4) == 4 and len(out6) == 6
+        for a, b in zip(out4, out6[:4]):
+            assert torch.equal(a, b)
+        wx, wr = out6[4], out6[5]
+        ox, orr = do.fill_nearest(rw.cpu(), idx.cpu(), 40, 6)                     # the reference's dense scatter [REF :214-229]
+        assert wx.shape == (1500, 40) and torch.allclose(wx.cpu(), ox, atol=1e-6) and torch.allclose(wr.cpu(), orr, atol=1e-6)
+        assert torch.allclose(pc.weights_sum.cpu(), ox.abs() + orr.abs(), atol=1e-6)
+        assert pc.kpts_xyz_motion.shape == (40, 3) and pc.kpts_rotation_motion.shape == (40, 4)
+        assert torch.allclose(pc.kpts_rotation_motion.norm(dim=-1), torch.ones(40, device="cuda"), atol=1e-5)
+        # the blended displacement equals the dense matmul with those weights [REF :272-273]
+        assert torch.allclose(out4[0] - pc._xyz, wx @ pc.kpts_xyz_motion, atol=1e-5)
+        assert len(pc(t, 20000, return_weights=True)) == 4                        # stage 1: never six [REF :302]
+    pc2, *_ = build(n=1500, K=40, step_opacity=True)
+    with torch.no_grad():
+        o4 = pc2(t, 50000)
+        o6 = pc2(t, 50000, return_weights=True)
+        assert len(o6) == 6 and torch.equal(o6[3], pc2.get_opacity) and not torch.equal(o4[3], o6[3])   # [REF :299-300]
+
+
+def test_furthest_point_sampling_kernel_matches_the_host_restatement():
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(5000, 3, generator=g)
+    ref = furthest_point_sampling(x, 64)            # CPU tensors: the torch restatement
+    out = furthest_point_sampling(x.cuda(), 64)
+    assert out.dtype == torch.int64 and torch.equal(out.cpu(), ref)
+    assert int(out[0]) == 0 and len(set(out.tolist())) == 64
+    assert furthest_point_sampling(x.cuda()[:1], 5).tolist() == [0]
+
+
+def test_checkpoint_tuple_round_trips_through_the_fused_adam(tmp_path):
+    """Load a reference-layout checkpoint (written by plain torch.optim.Adam with the reference's group names), run one
+    step on the HIP path, save, and let torch.optim.Adam load the result."""
+    pc, cams, gts, raw, rw, idx, args = build(n=3000)
+    pc.training_args = default_training_args()
+    ref_opt = torch.optim.Adam(pc._stage_groups(3), lr=0.0, eps=1e-15)
+    g = torch.Generator(device="cuda").manual_seed(2)
+    for _ in range(3):
+        for grp in ref_opt.param_groups:
+            for p in grp["params"]:
+                p.grad = 1e-3 * torch.randn(p.shape, generator=g, device="cuda")
+        ref_opt.step()
+    path = os.path.join(tmp_path, "chkpnt50000.pth")
+    torch.save((pc.state_dict(), ref_opt.state_dict(), 50000), path)               # [REF train.py:199-201]
+    m, opt_state, it = load_checkpoint(path, args, device="cuda")
+    assert it == 50000
+    m.set_keypoint_weights(rw, idx)
+    m.restore(opt_state, default_training_args(), it)                               # [REF train.py:48-57]
+    assert type(m.optimizer).__name__ == "FusedAdam" and m.optimizer.step_count == 3
+    names = [gg["name"] for gg in m.optimizer.param_groups]
+    assert names == ["xyz", "f_dc", "f_rest", "opacity", "scaling", "rotation", "s_xyz", "s_motion_feature", "df_mlp"]
+    ts = TrainStep(m, cams, gts, it)
+    before = m._xyz.detach().clone()
+    loss, pkg = ts.step(0)
+    assert math.isfinite(float(loss)) and m.optimizer.step_count == 4 and not torch.equal(before, m._xyz.detach())
+    out = os.path.join(tmp_path, "chkpnt50001.pth")
+    save_checkpoint(m, m.optimizer.state_dict(), it + 1, out)
+    sd_model, sd_opt, it2 = torch.load(out, weights_only=False)
+    fresh = torch.optim.Adam([{"params": [torch.nn.Parameter(p.detach().clone()) for p in gg["params"]], "lr": 0.0, "name": gg["name"]}
+                              for gg in m.optimizer.param_groups], lr=0.0, eps=1e-15)
+    fresh.load_state_dict(sd_opt)
+    st = fresh.state[fresh.param_groups[0]["params"][0]]
+    assert float(st["step"]) == 4.0 and st["exp_avg"].shape == m._xyz.shape and it2 == 50001
+    assert set(sd_model) == set(pc.state_dict())
+
+
+def test_batch_accumulation_equals_the_sum_of_single_view_losses():
+    """--batch B on one GPU [REF train.py:113-133]: gradients of sum_b loss_b, radii = max, visibility = any, and the
+    last-view quirk of the densification input."""
+    pc, cams, gts, raw, rw, idx, args = build(n=3000)
+    ts = TrainStep(pc, cams, gts, 50000, lrs=dict(xyz=0.0, f_dc=0.0, opacity=0.0, scaling=0.0, rotation=0.0, kpts=0.0, mlp=0.0), batch=2)
+    # reference accumulation by hand, plain autograd
+    for p in pc.parameters():
+        if p.grad is not None:
+            p.grad.zero_()
+    losses, pk = [], []
+    for v in (2, 3):
+        pkg = render(cams[v], pc, ts.pipe, ts.bg, time=ts.times[v], it=50000)
+        losses.append(ts.loss_of(pkg["render"], gts[v])); pk.append(pkg)
+    torch.stack(losses).sum().backward()
+    want = {k: getattr(pc, k).grad.clone() for k in ("_xyz", "_features_rest", "_opacity", "super_gaussians")}
+    want_mlp = [p.grad.clone() for p in pc.df_model.parameters()]
+    ts.bucket.zero()
+    captured = {}
+    orig = ts.optimizer.step
+
+    def spy(*a, **k):                               # the gradients as Adam sees them (it zeroes them in the same launch)
+        captured.update({kk: getattr(pc, kk).grad.clone() for kk in want})
+        captured["mlp"] = [p.grad.clone() for p in pc.df_model.parameters()]
+        return orig(*a, **k)
+    ts.optimizer.step = spy
+    loss, pkg = ts.step(1)                          # step 1 with batch 2 = views 2, 3
+    assert abs(float(loss) - float(torch.stack(losses).sum())) < 1e-5
+    for k in want:
+        e = float((captured[k] - want[k]).norm() / want[k].norm().clamp_min(1e-30))
+        assert e < 1e-5, (k, e)
+    for a, b in zip(captured["mlp"], want_mlp):
+        assert float((a - b).norm() / b.norm().clamp_min(1e-30)) < 1e-4
+    assert torch.equal(pkg["radii"], torch.maximum(pk[0]["radii"], pk[1]["radii"]))
+    assert torch.equal(pkg["visibility_filter"], pk[0]["visibility_filter"] | pk[1]["visibility_filter"])
+    # the tensor handed on is the LAST view's (its .grad holds that view alone); the batch sum is beside it [REF train.py:123-127,167]
+    assert torch.allclose(pkg["viewspace_points"].grad, pk[1]["viewspace_points"].grad, atol=1e-7)
+    assert torch.allclose(pkg["viewspace_point_tensor_grad"], pk[0]["viewspace_points"].grad + pk[1]["viewspace_points"].grad, atol=1e-7)
+
+
+# ---- two ranks ------------------------------------------------------------------------------------------------------------
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def _rank_main(rank, world, port, out_dir, backend, step_opacity):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch.distributed as dist
+    dev = rank if backend == "nccl" else 0
+    torch.cuda.set_device(dev)
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    pc, cams, gts, raw, rw, idx, args = build(n=3000, dev=f"cuda:{dev}", step_opacity=step_opacity)
+    zero = dict(xyz=0.0, f_dc=0.0, opacity=0.0, scaling=0.0, rotation=0.0, kpts=0.0, mlp=0.0)
+    ts = TrainStep(pc, cams, gts, 50000, lrs=zero)
+    assert ts.reducer.enabled
+    got = {}
+    orig = ts.optimizer.step
+
+    def spy(*a, **k):
+        got["flat"] = ts.bucket.flat.clone()
+        return orig(*a, **k)
+    for step in range(2):                            # second step: the overwrite-sink (stale gradient) protocol is live
+        ts.optimizer.step = spy
+        loss, pkg = ts.step(step * world + rank)     # rank r renders view world*step + r
+        torch.save({"flat": got["flat"].cpu(), "radii": pkg["radii"].cpu(), "offsets": ts.bucket.offsets,
+                    "names": [n for n, _ in pc.named_parameters() if _.requires_grad]}, os.path.join(out_dir, f"r{rank}_s{step}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("step_opacity", [False, True])
+def test_two_rank_view_parallel_step_equals_batch_accumulation(tmp_path, step_opacity):
+    """Each rank renders its own view; the gradient Adam sees on every rank is the SUM over ranks == the single-process
+    `--batch 2` gradient.  With the lifecycle opacity `_xyz` has two gradient producers (blend backward + the second MLP
+    pass), the case the reducer must not reduce early."""
+    import torch.multiprocessing as mp
+    backend = "nccl" if torch.cuda.device_count() >= 2 else "gloo"
+    mp.spawn(_rank_main, args=(2, _free_port(), str(tmp_path), backend, step_opacity), nprocs=2, join=True)
+    pc, cams, gts, raw, rw, idx, args = build(n=3000, step_opacity=step_opacity)
+    zero = dict(xyz=0.0, f_dc=0.0, opacity=0.0, scaling=0.0, rotation=0.0, kpts=0.0, mlp=0.0)
+    ts = TrainStep(pc, cams, gts, 50000, lrs=zero, batch=2)
+    for step in range(2):
+        got = {}
+        orig = ts.optimizer.step
+
+        def spy(*a, **k):
+            got["flat"] = ts.bucket.flat.clone()
+            return orig(*a, **k)
+        ts.optimizer.step = spy
+        loss, pkg = ts.step(step)                    # views 2*step, 2*step + 1
+        ts.optimizer.step = orig
+        r0 = torch.load(os.path.join(tmp_path, f"r0_s{step}.pt"))
+        r1 = torch.load(os.path.join(tmp_path, f"r1_s{step}.pt"))
+        assert torch.equal(r0["flat"], r1["flat"])   # every rank holds the same reduced gradient
+        want = got["flat"].cpu()
+        offs = r0["offsets"] + [want.numel()]
+        for k in range(len(offs) - 1):
+            a, b = r0["flat"][offs[k]:offs[k + 1]], want[offs[k]:offs[k + 1]]
+            e = float((a - b).norm() / b.norm().clamp_min(1e-30))
+            assert e < 2e-5, (step, k, e)
+        assert torch.equal(r0["radii"], pkg["radii"].cpu())
