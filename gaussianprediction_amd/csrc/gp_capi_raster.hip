@@ -207,6 +207,8 @@ extern "C" int gp_raster_forward(const gp_raster_settings* st, const gp_raster_i
             GP_LAUNCH_CHECK(); }
         }
     }
+    if (N == 0 && st->binning_status)      // nothing to bin: {R, overflow} = {0, 0} (a stale overflow word would make Adam skip the step)
+        GP_HIP_CHECK(hipMemsetAsync(st->binning_status, 0, 2 * sizeof(uint32_t), s));
     saved->num_rendered = (int64_t)R;
     hipLaunchKernelGGL(gp_tile_order_kernel, dim3(1), dim3(1024), 0, s, il.ranges, (const int32_t*)nullptr, (int)T, il.order);
     GP_LAUNCH_CHECK();
@@ -274,12 +276,13 @@ extern "C" int gp_raster_backward(const gp_raster_settings* st, const gp_raster_
         } else if (in->shs && d.M == 16 && al16) {
             kern = gp_preprocess_bwd_sh16_kernel;
         }
+        if (g->accumulate_shs && kern == gp_preprocess_bwd_kernel)
+            GP_FAIL("accumulate_shs needs the staged SH kernels (16 coeffs, 16-byte aligned)");      // (before anything is written)
         hipLaunchKernelGGL(kern, dim3(gp_blocks(N, 256)), dim3(256), 0, s, d, in->means3D, in->scales, in->rotations, in->shs,
                            in->shs_rest, in->cov3D_precomp, st->viewmatrix, st->projmatrix, st->campos, fwd->radii, gl.clamped,
                            g_mean2D, g_conic, g_opacity, g_color, g_depth, g->dL_dmeans3D, g->dL_dmeans2D, g->dL_dshs,
                            g->dL_dshs_rest, in->shs ? nullptr : g->dL_dcolors_precomp, g->dL_dopacities, g->dL_dscales,
                            g->dL_drotations, g->dL_dcov3D_precomp, (kern != gp_preprocess_bwd_kernel) ? g->accumulate_shs : 0);
-        if (g->accumulate_shs && kern == gp_preprocess_bwd_kernel) GP_FAIL("accumulate_shs needs the staged SH kernels (16 coeffs, 16-byte aligned)");
         GP_LAUNCH_CHECK();
     }
     return 0;

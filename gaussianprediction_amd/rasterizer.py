@@ -106,13 +106,15 @@ class _RasterizeGaussians(torch.autograd.Function):
             out = _lib.RasterOutputsC(_lib.ptr(color), _lib.ptr(radii), _lib.ptr(depth), _lib.ptr(tidx))
             saved = _lib.RasterSavedC()
             alloc = _lib.TorchAllocator(device)
-            rc = L.gp_raster_forward(C.byref(st), C.byref(inp), C.byref(out), C.byref(saved), alloc.cb, None,
-                                     _lib.stream_ptr(device))
-            if alloc.error is not None:
-                err = alloc.error
-                alloc.release()
-                raise err
-            _lib.check(rc, "gp_raster_forward")
+            try:
+                rc = L.gp_raster_forward(C.byref(st), C.byref(inp), C.byref(out), C.byref(saved), alloc.cb, None,
+                                         _lib.stream_ptr(device))
+                if alloc.error is not None:
+                    raise alloc.error
+                _lib.check(rc, "gp_raster_forward")
+            except BaseException:
+                alloc.release()          # (breaks the allocator's self-reference: the buffers are freed now, not at the next GC)
+                raise
         ctx.set_materialize_grads(False)      # an unused `depth` output must arrive as None, not as zeros
         ctx.sh_leaves = (sh, sh_rest)         # (leaf Parameters: candidates for direct gradient sinks)
         ctx.raster_settings = rs
@@ -186,14 +188,14 @@ class _RasterizeGaussians(torch.autograd.Function):
             grads = _lib.RasterGradsC(_lib.ptr(g_m3), _lib.ptr(g_m2), _lib.ptr(g_sh), _lib.ptr(g_shr), _lib.ptr(g_col), _lib.ptr(g_op),
                                       _lib.ptr(g_scl), _lib.ptr(g_rot), _lib.ptr(g_cov), accumulate)
             alloc = _lib.TorchAllocator(device)
-            rc = L.gp_raster_backward(C.byref(st), C.byref(inp), C.byref(out), C.byref(saved), _lib.ptr(gc), _lib.ptr(gd),
-                                      C.byref(grads), alloc.cb, None, _lib.stream_ptr(device))
-            if alloc.error is not None:
-                err = alloc.error
+            try:
+                rc = L.gp_raster_backward(C.byref(st), C.byref(inp), C.byref(out), C.byref(saved), _lib.ptr(gc), _lib.ptr(gd),
+                                          C.byref(grads), alloc.cb, None, _lib.stream_ptr(device))
+                if alloc.error is not None:
+                    raise alloc.error
+                _lib.check(rc, "gp_raster_backward")
+            finally:
                 alloc.release()
-                raise err
-            alloc.release()
-            _lib.check(rc, "gp_raster_backward")
         if use_sink:
             grad_sink.notify(leaf_sh)
             if has_rest:
@@ -239,10 +241,6 @@ class GaussianRasterizer(nn.Module):
                                    shs_rest)
 
 
-def debug_binning(ctx_like_saved, raster_settings):  # pragma: no cover - used by GPU tests
-    raise NotImplementedError
-
-
 def raster_forward_debug(raster_settings, means3D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
                          cov3D_precomp=None):
     """Test/diagnostic helper: forward pass that also returns the binning result
@@ -267,8 +265,12 @@ def raster_forward_debug(raster_settings, means3D, opacities, shs=None, colors_p
         out = _lib.RasterOutputsC(_lib.ptr(color), _lib.ptr(radii), _lib.ptr(depth), _lib.ptr(tidx))
         saved = _lib.RasterSavedC()
         alloc = _lib.TorchAllocator(device)
-        _lib.check(L.gp_raster_forward(C.byref(st), C.byref(inp), C.byref(out), C.byref(saved), alloc.cb, None,
-                                       _lib.stream_ptr(device)), "gp_raster_forward")
+        try:
+            _lib.check(L.gp_raster_forward(C.byref(st), C.byref(inp), C.byref(out), C.byref(saved), alloc.cb, None,
+                                           _lib.stream_ptr(device)), "gp_raster_forward")
+        except BaseException:
+            alloc.release()
+            raise
         R = int(saved.num_rendered)
         T = ((W + 15) // 16) * ((H + 15) // 16)
         point_list = torch.empty(max(R, 1), dtype=torch.int32, device=device)

@@ -294,57 +294,58 @@ int gpo_preprocess_fwd(int N, int D, int M, const real* means3D, const real* sca
 /* ------------------------------------------------------------------------------------------- */
 /* 2. binning: duplicate per touched tile, stable sort by (tile, depth), per-tile ranges        */
 /* ------------------------------------------------------------------------------------------- */
-typedef struct { uint32_t tile; uint32_t id; real depth; } bin_item;
+/* (tile, depth, id) order = what one stable sort of the instances by (tile << 32 | depth bits) gives when the instances
+ * are generated in increasing Gaussian id.  Done as the GPU path does it, in two levels: a counting sort by tile (stable:
+ * ids stay ascending inside a tile), then every tile's segment is sorted by (depth, id) on its own -- independent
+ * segments, one OpenMP task each.  (A single merge sort over all R instances, as this file first had, copies the whole
+ * array once per pass and leaves most cores idle: as a CPU baseline it was a straw man.) */
+typedef struct { real depth; uint32_t id; } bin_item;
 
-static inline int bin_less(const bin_item* a, const bin_item* b) {
-    if (a->tile != b->tile) return a->tile < b->tile;
-    return a->depth < b->depth;
-}
-static void merge_sort(bin_item* a, bin_item* tmp, long n) {
-    /* bottom-up stable merge sort */
-    for (long w = 1; w < n; w *= 2) {
-#pragma omp parallel for schedule(dynamic, 16)
-        for (long lo = 0; lo < n; lo += 2 * w) {
-            long mid = lo + w < n ? lo + w : n, hi = lo + 2 * w < n ? lo + 2 * w : n;
-            long i = lo, j = mid, k = lo;
-            while (i < mid && j < hi) tmp[k++] = bin_less(&a[j], &a[i]) ? a[j++] : a[i++];
-            while (i < mid) tmp[k++] = a[i++];
-            while (j < hi) tmp[k++] = a[j++];
-        }
-        memcpy(a, tmp, (size_t)n * sizeof(bin_item));
-    }
+static int bin_cmp(const void* pa, const void* pb) {
+    const bin_item *a = (const bin_item*)pa, *b = (const bin_item*)pb;
+    if (a->depth < b->depth) return -1;
+    if (a->depth > b->depth) return 1;
+    return (a->id > b->id) - (a->id < b->id);
 }
 
 /* returns R = number of tile-splat instances; call with point_list==NULL to get R only. */
 long gpo_bin(int N, int W, int H, const uint32_t* tiles_touched, const int32_t* rect, const real* depths,
              uint32_t* point_list /*R*/, uint32_t* point_tile /*R or NULL*/, int32_t* ranges /*T*2*/) {
-    const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
+    const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE, T = gx * gy;
     long Rn = 0;
     for (int i = 0; i < N; ++i) Rn += tiles_touched[i];
     if (!point_list) return Rn;
+    long* start = (long*)calloc((size_t)T + 1, sizeof(long));
+    for (int i = 0; i < N; ++i) {
+        if (!tiles_touched[i]) continue;
+        for (int y = rect[4 * i + 1]; y < rect[4 * i + 3]; ++y)
+            for (int x = rect[4 * i]; x < rect[4 * i + 2]; ++x) ++start[y * gx + x + 1];
+    }
+    for (int t = 0; t < T; ++t) start[t + 1] += start[t];
+    long* cursor = (long*)malloc((size_t)T * sizeof(long));
+    memcpy(cursor, start, (size_t)T * sizeof(long));
     bin_item* items = (bin_item*)malloc((size_t)(Rn > 0 ? Rn : 1) * sizeof(bin_item));
-    bin_item* tmp = (bin_item*)malloc((size_t)(Rn > 0 ? Rn : 1) * sizeof(bin_item));
-    long off = 0;
     for (int i = 0; i < N; ++i) {
         if (!tiles_touched[i]) continue;
         for (int y = rect[4 * i + 1]; y < rect[4 * i + 3]; ++y)
             for (int x = rect[4 * i]; x < rect[4 * i + 2]; ++x) {
-                items[off].tile = (uint32_t)(y * gx + x);
-                items[off].id = (uint32_t)i;
-                items[off].depth = depths[i];
-                ++off;
+                bin_item* it = &items[cursor[y * gx + x]++];
+                it->depth = depths[i];
+                it->id = (uint32_t)i;
             }
     }
-    merge_sort(items, tmp, Rn);
-    for (int t = 0; t < gx * gy; ++t) ranges[2 * t] = ranges[2 * t + 1] = 0;
-    for (long k = 0; k < Rn; ++k) {
-        point_list[k] = items[k].id;
-        if (point_tile) point_tile[k] = items[k].tile;
-        uint32_t t = items[k].tile;
-        if (k == 0 || items[k - 1].tile != t) ranges[2 * t] = (int32_t)k;
-        if (k == Rn - 1 || items[k + 1].tile != t) ranges[2 * t + 1] = (int32_t)(k + 1);
+#pragma omp parallel for schedule(dynamic, 8)
+    for (int t = 0; t < T; ++t) {
+        const long lo = start[t], hi = start[t + 1];
+        if (hi - lo > 1) qsort(items + lo, (size_t)(hi - lo), sizeof(bin_item), bin_cmp);
+        ranges[2 * t] = hi > lo ? (int32_t)lo : 0;
+        ranges[2 * t + 1] = hi > lo ? (int32_t)hi : 0;
+        for (long k = lo; k < hi; ++k) {
+            point_list[k] = items[k].id;
+            if (point_tile) point_tile[k] = (uint32_t)t;
+        }
     }
-    free(items); free(tmp);
+    free(items); free(start); free(cursor);
     return Rn;
 }
 
