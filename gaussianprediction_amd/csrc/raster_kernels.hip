@@ -1199,12 +1199,16 @@ __device__ __forceinline__ void gp_composite_bwd_body(RasterDims d, const int2* 
         v2f a_op = {0.f, 0.f}, a_r = {0.f, 0.f}, a_g = {0.f, 0.f}, a_b = {0.f, 0.f}, a_d = {0.f, 0.f}, s_xx = {0.f, 0.f};
         float S_x = 0.f, S_y = 0.f, S_xy = 0.f, S_yy = 0.f;
         float any_m = 0.f;
+        auto fma2 = [](v2f a, v2f b, v2f c) { return (v2f){fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y)}; };   // -> v_pk_fma_f32
+        float dxs[COLS / 2];                   // dx of the even pixel of each pair: the same in every row
+#pragma unroll
+        for (int cp = 0; cp < COLS / 2; ++cp) dxs[cp] = sx - (float)(2 * cp);
 #pragma unroll 1
         for (int row = 0; row < ROWS; ++row) {
             const float dy = sy - (float)row;
             const float tB = Bs * dy, uC = (Cs * dy) * dy;
             v2f r_h = {0.f, 0.f}, r_hx = {0.f, 0.f};
-#pragma unroll 1
+#pragma unroll
             for (int cp = 0; cp < COLS / 2; ++cp) {
                 const int pr = row * (COLS / 2) + cp;
                 // all four broadcast reads are issued up front; the alpha math below covers their latency
@@ -1212,7 +1216,7 @@ __device__ __forceinline__ void gp_composite_bwd_body(RasterDims d, const int2* 
                 const float4 v0 = s_v0[pr], v1 = s_v1[pr], cy = s_cy[pr];
                 float2 v3 = make_float2(0.f, 0.f);
                 if (HAS_DEPTH) v3 = s_dd[pr];
-                const float dx0 = sx - (float)(2 * cp);
+                const float dx0 = dxs[cp];
                 const v2f dx = {dx0, dx0 - 1.f};
                 const v2f pw = {fmaf(dx.x, fmaf(As, dx.x, tB), uC), fmaf(dx.y, fmaf(As, dx.y, tB), uC)};
                 const v2f G = {__builtin_amdgcn_exp2f(fminf(pw.x, 0.f)), __builtin_amdgcn_exp2f(fminf(pw.y, 0.f))};
@@ -1221,16 +1225,18 @@ __device__ __forceinline__ void gp_composite_bwd_body(RasterDims d, const int2* 
                 if (max(ncx, ncy) > b0) {   // uniform: otherwise both pixels finished before this batch
                     const bool c0 = (pos < ncx) && !(pw.x > 0.f) && !(alpha.x < 1.f / 255.f);
                     const bool c1 = (pos < ncy) && !(pw.y > 0.f) && !(alpha.y < 1.f / 255.f);
-                    if (__any(c0 || c1)) {   // otherwise nobody in the wave touches either pixel
-                        const v2f m = {c0 ? 1.f : 0.f, c1 ? 1.f : 0.f};
-                        any_m = fmaxf(any_m, fmaxf(m.x, m.y));
-                        const v2f am = alpha * m;
+                    if (__builtin_amdgcn_ballot_w64(c0 || c1) != 0ull) {   // otherwise nobody in the wave touches either pixel
+                        // a lane that does not contribute to a pixel takes part with G = 0 (alpha = 0, factor 1 in the product scan,
+                        // 0 in the sum scan, zero gradient): one select per pixel instead of mask multiplications
+                        const v2f Gm = {c0 ? G.x : 0.f, c1 ? G.y : 0.f};
+                        const v2f am = {c0 ? alpha.x : 0.f, c1 ? alpha.y : 0.f};
+                        any_m = fmaxf(any_m, fmaxf(am.x, am.y));
                         const v2f om = 1.f - am;
                         v2f cdot = cb * (v2f){v1.x, v1.y};
-                        cdot = cg * (v2f){v0.z, v0.w} + cdot;
-                        cdot = cr * (v2f){v0.x, v0.y} + cdot;
+                        cdot = fma2(cg, (v2f){v0.z, v0.w}, cdot);
+                        cdot = fma2(cr, (v2f){v0.x, v0.y}, cdot);
                         v2f dLd = {0.f, 0.f};
-                        if (HAS_DEPTH) { dLd.x = v3.x; dLd.y = v3.y; cdot = zdep * dLd + cdot; }
+                        if (HAS_DEPTH) { dLd.x = v3.x; dLd.y = v3.y; cdot = fma2((v2f){zdep, zdep}, dLd, cdot); }
                         // T_j = T_in * prod_{k<j} (1 - alpha_k): inclusive product scan, then divide the own factor out
                         const v2f rom = {__builtin_amdgcn_rcpf(om.x), __builtin_amdgcn_rcpf(om.y)};
                         float il0 = om.x, il1 = om.y;
@@ -1244,16 +1250,18 @@ __device__ __forceinline__ void gp_composite_bwd_body(RasterDims d, const int2* 
                         const v2f rem = {cy.z, cy.w};
                         const v2f tbv = {v1.z, v1.w};
                         const v2f suffix = rem - (v2f){is0, is1};
-                        const v2f dL_dalpha = (Tj * cdot - (suffix + tbv) * rom) * m;
-                        a_r += w * (v2f){v0.x, v0.y}; a_g += w * (v2f){v0.z, v0.w}; a_b += w * (v2f){v1.x, v1.y};
-                        if (HAS_DEPTH) a_d += w * dLd;
-                        const v2f gda = G * dL_dalpha;
+                        const v2f dL_dalpha = fma2(Tj, cdot, -((suffix + tbv) * rom));
+                        a_r = fma2(w, (v2f){v0.x, v0.y}, a_r);
+                        a_g = fma2(w, (v2f){v0.z, v0.w}, a_g);
+                        a_b = fma2(w, (v2f){v1.x, v1.y}, a_b);
+                        if (HAS_DEPTH) a_d = fma2(w, dLd, a_d);
+                        const v2f gda = Gm * dL_dalpha;
                         a_op += gda;
                         const v2f h = op * gda;
                         const v2f hx = h * dx;
                         r_h += h;
                         r_hx += hx;
-                        s_xx += hx * dx;
+                        s_xx = fma2(hx, dx, s_xx);
                         // carry to the next batch
                         if (lane == 63) s_cy[pr] = make_float4(Tnext.x, Tnext.y, cy.z - is0, cy.w - is1);
                     }
