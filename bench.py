@@ -137,6 +137,8 @@ def main():
                     help="size the binning buffers by reading R back every step (one host sync per step) instead of the "
                          "capacity mode with the high-water-mark protocol of TrainStep(speculative=True)")
     ap.add_argument("--render-only", action="store_true", help="time eval-style forward renders instead of train steps")
+    ap.add_argument("--replicated-adam", action="store_true",
+                    help="N > 1: all-reduce + replicated Adam (round 1) instead of reduce-scatter -> sharded Adam -> all-gather")
     args = ap.parse_args()
 
     from gaussianprediction_amd import _lib
@@ -150,7 +152,8 @@ def main():
     pc, cams, gts, margs = build_workload(args, device)
     # learning rates of the reference at iteration 50000 (position lr has decayed to position_lr_final,
     # [REF arguments/__init__.py:75-76, scene/gaussian_model.py:474-491])
-    ts = TrainStep(pc, cams, gts, args.iteration, lrs=dict(xyz=1.6e-6 * 5.0), speculative=not args.exact_binning)
+    ts = TrainStep(pc, cams, gts, args.iteration, lrs=dict(xyz=1.6e-6 * 5.0), speculative=not args.exact_binning,
+                   sharded=False if args.replicated_adam else None)
 
     def one_step(i):
         view = i * world + rank            # rank r renders view world*i + r
@@ -193,6 +196,7 @@ def main():
     for i in range(args.steps):
         out = one_step(preroll + args.warmup + i)
         pkg = out if args.render_only else out[1]
+    ts.sync_params()                            # (N > 1: the last step's parameter all-gather belongs to the timed work)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -300,6 +304,11 @@ def main():
                        "nearest_num": args.nearest_num, "time_freq": args.time_freq, "iteration": args.iteration,
                        "tiles": T, "pixels": P, "R": R, "R_before_timed_region": R0, "R_per_gaussian": round(R / max(args.gaussians, 1), 3),
                        "visible": n_vis, "parallelism": f"view-parallel x{world}",
+                       "gradient_exchange": None if world == 1 else (
+                           "all-reduce(SUM) of the flat gradient bucket + replicated Adam" if not ts.sharded else
+                           "reduce-scatter(SUM) per region -> Adam on 1/N of every region -> asynchronous all-gather of the parameters"),
+                       "xgmi_bytes_sent_per_rank_per_step": None if world == 1 else (
+                           getattr(ts.reducer, "bytes_sent_per_step", None) or int(2 * 4 * ts.bucket.flat.numel() * (world - 1) / world)),
                        "binning": "exact (R read back every step)" if args.exact_binning else
                                   f"capacity mode in warm-up and timed steps (no host sync; {preroll} exact-mode set-up steps before the "
                                   f"warm-up; {getattr(ts, 'redone', 0)} frames repeated after overflow)",

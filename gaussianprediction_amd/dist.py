@@ -12,18 +12,56 @@ import torch.distributed as dist
 
 
 class FlatGradBucket:
-    """Makes every parameter's .grad a view into one contiguous buffer."""
+    """Makes every parameter's .grad a view into one contiguous buffer.
 
-    def __init__(self, params):
-        self.params = [p for p in params if p.requires_grad]
-        self.offsets = []
+    `shards` > 1 lays the buffer out for a sharded optimizer (reduce-scatter -> 1/shards of Adam per rank -> all-gather):
+    the buffer is a sequence of REGIONS, each a multiple of 64 * shards elements so that rank r owns the r-th equal slice of
+    every region -- one region per large tensor (its gradient can be exchanged the moment it is final), one region for all
+    the small tensors together (MLP weights, keypoints: one collective instead of twenty).  `flat_params` additionally moves
+    the parameters' storage into a second buffer of the same layout (p.data becomes a view), the all-gather operand."""
+
+    def __init__(self, params, shards=1, flat_params=False, small_numel=1 << 20):
+        params = [p for p in params if p.requires_grad]
+        self.shards = int(shards)
+        if self.shards > 1:                         # large tensors first (in order), then the small ones: two kinds of region
+            params = [p for p in params if p.numel() >= small_numel] + [p for p in params if p.numel() < small_numel]
+        self.params = params
+        self.offsets, self.regions = [], []         # regions: (start, end, [param indices])
+        unit = 64 * self.shards
         n = 0
-        for p in self.params:                       # 64-element (256 B) aligned segments
-            self.offsets.append(n)
-            n += (p.numel() + 63) // 64 * 64
-        dev = self.params[0].device
+        if self.shards > 1:
+            tail = []
+            for k, p in enumerate(params):
+                if p.numel() >= small_numel:
+                    self.offsets.append(n)
+                    end = n + (p.numel() + unit - 1) // unit * unit
+                    self.regions.append((n, end, [k]))
+                    n = end
+                else:
+                    tail.append(k)
+            if tail:
+                start = n
+                for k in tail:                      # 64-element (256 B) aligned segments inside the tail region
+                    self.offsets.append(n)
+                    n += (params[k].numel() + 63) // 64 * 64
+                end = start + (n - start + unit - 1) // unit * unit
+                self.regions.append((start, end, tail))
+                n = end
+        else:
+            for p in params:                        # 64-element (256 B) aligned segments
+                self.offsets.append(n)
+                n += (p.numel() + 63) // 64 * 64
+            self.regions.append((0, n, list(range(len(params)))))
+        dev = params[0].device
         self.flat = torch.zeros(n, dtype=torch.float32, device=dev)
-        for p, off in zip(self.params, self.offsets):
+        self.pflat = None
+        if flat_params:
+            self.pflat = torch.zeros(n, dtype=torch.float32, device=dev)
+            for p, off in zip(params, self.offsets):
+                view = self.pflat[off:off + p.numel()].view_as(p)
+                view.copy_(p.data)
+                p.data = view
+        for p, off in zip(params, self.offsets):
             p.grad = self.flat[off:off + p.numel()].view_as(p)
 
     def zero(self):
@@ -46,6 +84,120 @@ class FlatGradBucket:
         off = self.offsets[i]
         end = self.offsets[i + 1] if i + 1 < len(self.offsets) else self.flat.numel()
         return self.flat[off:end]
+
+    def region_of(self, p):
+        i = next(k for k, q in enumerate(self.params) if q is p)
+        return next(r for r in self.regions if i in r[2])
+
+    def shard_slice(self, region, rank):
+        start, end, _ = region
+        n = (end - start) // self.shards
+        return start + rank * n, start + (rank + 1) * n
+
+
+class ShardedExchange:
+    """The gradient / parameter exchange of the sharded optimizer (ZeRO-1 shaped, sized for xGMI):
+
+        backward  ->  reduce-scatter(SUM) of every region, each large tensor's the moment its gradient is final
+                  ->  Adam on this rank's 1/world slice of every region (loss_ops.FusedAdam(shard=...))
+                  ->  all-gather of the updated parameter slices, asynchronous: the small tensors and the per-Gaussian
+                      geometry are awaited before the next deformation, the SH coefficients (3/4 of the bytes) only in front
+                      of the next rasterizer call (renderer._wait_params), i.e. behind the next step's deformation.
+
+    Against all-reduce + replicated Adam the bytes on the links are the same (an all-reduce IS a reduce-scatter + all-gather),
+    but Adam's 0.32 ms at configs[2] shrinks by the world size and the all-gather half overlaps the next forward.
+    SUM semantics = the reference's --batch accumulation [REF train.py:113-119].  Backends: RCCL ("nccl") uses in-place
+    reduce_scatter_tensor / all_gather_into_tensor; gloo (CPU tests, two ranks on one GPU) has neither, so there the same
+    result is produced with all_reduce / all_gather on the same views."""
+
+    def __init__(self, bucket: FlatGradBucket, group=None):
+        self.bucket, self.group = bucket, group
+        self.enabled = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+        self.world = dist.get_world_size(group) if self.enabled else 1
+        self.rank = dist.get_rank(group) if self.enabled else 0
+        assert bucket.shards == self.world, "bucket layout and process group disagree on the number of shards"
+        self.nccl = self.enabled and dist.get_backend(group) == "nccl"
+        self.handles, self._fired, self._late = [], set(), set()
+        self._gather = []                       # (param ids of the region, handle)
+        self._sink_cb = None
+        self.bytes_sent_per_step = 0
+        if self.enabled:
+            from . import grad_sink
+            self.large = [bucket.params[r[2][0]] for r in bucket.regions if len(r[2]) == 1 and bucket.params[r[2][0]].numel() >= (1 << 20)]
+            hooks = {id(p): self._make_hook(p) for p in self.large}
+            for p in self.large:
+                p.register_post_accumulate_grad_hook(hooks[id(p)])
+            self._sink_cb = grad_sink.register_callback(lambda p: hooks[id(p)](p) if id(p) in hooks else None)
+
+    def close(self):
+        if self._sink_cb is not None:
+            from . import grad_sink
+            grad_sink.unregister_callback(self._sink_cb)
+            self._sink_cb = None
+        self.enabled = False
+
+    def set_late(self, params):
+        self._late = {id(p) for p in params}
+
+    def _reduce_scatter(self, region):
+        start, end, _ = region
+        seg = self.bucket.flat[start:end]
+        if self.nccl:
+            lo, hi = self.bucket.shard_slice(region, self.rank)
+            return dist.reduce_scatter_tensor(self.bucket.flat[lo:hi], seg, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        return dist.all_reduce(seg, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    def _make_hook(self, p):
+        def hook(param):
+            if id(p) in self._fired or id(p) in self._late:
+                return
+            self._fired.add(id(p))
+            self.handles.append(self._reduce_scatter(self.bucket.region_of(p)))
+        return hook
+
+    def finish(self):
+        """After loss.backward(): reduce-scatter what the hooks did not cover; every rank then holds the SUM over ranks in its
+        own slice of every region."""
+        if not self.enabled:
+            return
+        for region in self.bucket.regions:
+            ids = [id(self.bucket.params[k]) for k in region[2]]
+            if len(ids) == 1 and ids[0] in self._fired:
+                continue
+            self.handles.append(self._reduce_scatter(region))
+        for h in self.handles:
+            h.wait()
+        self.handles.clear()
+        self._fired.clear()
+        n = self.bucket.flat.numel()
+        self.bytes_sent_per_step = 2 * 4 * n * (self.world - 1) // self.world     # reduce-scatter + all-gather, per rank
+
+    def gather_params(self):
+        """Start the all-gather of the updated parameter slices (after the optimizer step), small / geometry regions first."""
+        if not self.enabled:
+            return
+        pf = self.bucket.pflat
+        order = sorted(self.bucket.regions, key=lambda r: r[1] - r[0])          # smallest first: the SH regions come last
+        for region in order:
+            start, end, idx = region
+            lo, hi = self.bucket.shard_slice(region, self.rank)
+            if self.nccl:
+                h = dist.all_gather_into_tensor(pf[start:end], pf[lo:hi], group=self.group, async_op=True)
+            else:
+                n = (end - start) // self.world
+                outs = [pf[start + k * n:start + (k + 1) * n] for k in range(self.world)]
+                h = dist.all_gather(outs, pf[lo:hi].clone(), group=self.group, async_op=True)
+            self._gather.append(({id(self.bucket.params[k]) for k in idx}, h))
+
+    def wait_params(self, only=None, exclude=None):
+        """Make the current stream wait for the gathered parameters (`only` / `exclude`: sets of id(param))."""
+        rest = []
+        for ids, h in self._gather:
+            if (only is not None and not (ids & only)) or (exclude is not None and ids <= exclude):
+                rest.append((ids, h))
+            else:
+                h.wait()
+        self._gather = rest
 
 
 class OverlappedGradReducer:

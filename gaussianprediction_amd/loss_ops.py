@@ -96,23 +96,80 @@ def l1_ssim_loss(image, gt, lambda_dssim=0.2):
 
 
 class FusedAdam:
-    """Adam over the segments of a FlatGradBucket: one HIP launch per parameter tensor, gradient zeroed
-    in the same pass.  State layout mirrors torch.optim.Adam (exp_avg, exp_avg_sq, step)."""
+    """Adam over the segments of a FlatGradBucket: ONE multi-tensor HIP launch, gradient zeroed in the same pass.  State
+    layout mirrors torch.optim.Adam (exp_avg, exp_avg_sq, step).
 
-    def __init__(self, param_groups, bucket, betas=(0.9, 0.999), eps=1e-15):
+    `shard=(rank, world)`: the sharded form (dist.ShardedExchange).  This rank holds moments for, and updates, only its
+    1/world slice of every region of the bucket (parameters live in `bucket.pflat`); the launch table is the intersection of
+    every tensor with that slice, so a slice of the small-tensor region that spans several tensors still gets each one's own
+    learning rate."""
+
+    def __init__(self, param_groups, bucket, betas=(0.9, 0.999), eps=1e-15, shard=None):
         self.param_groups = param_groups
         self.bucket = bucket
         self.betas, self.eps = betas, eps
         self.step_count = 0
+        self.shard = shard
         off_of = {id(p): off for p, off in zip(bucket.params, bucket.offsets)}
-        self.items = []
+        self.items = []        # (group, tensor the launch updates, its offset in the flat buffers, exp_avg, exp_avg_sq)
+        self.owner = []        # the Parameter each item belongs to (itself when not sharded)
         for g in param_groups:
             for p in g["params"]:
                 if not p.requires_grad:
                     continue
                 if not p.is_contiguous():
                     raise RuntimeError("FusedAdam needs contiguous parameters")
-                self.items.append((g, p, off_of[id(p)], torch.zeros_like(p), torch.zeros_like(p)))
+                if shard is None:
+                    self.items.append((g, p, off_of[id(p)], torch.zeros_like(p), torch.zeros_like(p)))
+                    self.owner.append(p)
+                    continue
+                if bucket.pflat is None or bucket.shards != shard[1]:
+                    raise RuntimeError("sharded FusedAdam needs FlatGradBucket(shards=world, flat_params=True)")
+                lo, hi = bucket.shard_slice(bucket.region_of(p), shard[0])
+                a, b = max(lo, off_of[id(p)]), min(hi, off_of[id(p)] + p.numel())
+                if a < b:          # this rank owns elements [a, b) of the flat layout, all inside tensor p
+                    view = bucket.pflat[a:b]
+                    self.items.append((g, view, a, torch.zeros_like(view), torch.zeros_like(view)))
+                    self.owner.append(p)
+
+    def full_moments(self):
+        """{id(param): (exp_avg, exp_avg_sq)} as whole tensors.  Sharded: a COLLECTIVE (every rank must call it)."""
+        if self.shard is None:
+            return {id(p): (m, v) for _, p, _, m, v in self.items}
+        import torch.distributed as dist
+        n = self.bucket.flat.numel()
+        full = [torch.zeros(n, device=self.bucket.flat.device) for _ in range(2)]
+        for (_, view, a, m, v) in self.items:
+            full[0][a:a + view.numel()] = m
+            full[1][a:a + view.numel()] = v
+        for f in full:             # every element is owned by exactly one rank, the others hold zero there
+            dist.all_reduce(f, op=dist.ReduceOp.SUM)
+        return {id(p): (full[0][off:off + p.numel()].view_as(p).clone(), full[1][off:off + p.numel()].view_as(p).clone())
+                for p, off in zip(self.bucket.params, self.bucket.offsets)}
+
+    def load_full_moments(self, p, m_full, v_full):
+        """Install whole-tensor moments for parameter `p` (each rank keeps its own slice when sharded)."""
+        off = next(o for q, o in zip(self.bucket.params, self.bucket.offsets) if q is p)
+        for (_, view, a, m, v), owner in zip(self.items, self.owner):
+            if owner is p:
+                if self.shard is None:
+                    m.copy_(m_full.to(m.device, m.dtype)); v.copy_(v_full.to(v.device, v.dtype))
+                else:
+                    m.copy_(m_full.reshape(-1)[a - off:a - off + view.numel()].to(m.device, m.dtype))
+                    v.copy_(v_full.reshape(-1)[a - off:a - off + view.numel()].to(v.device, v.dtype))
+
+    @torch.no_grad()
+    def _step_host(self, step_no, zero_grad, keep_ids):
+        b1, b2 = self.betas
+        bc1, bc2 = 1 - b1 ** step_no, 1 - b2 ** step_no
+        for (g, p, off, m, v), owner in zip(self.items, self.owner):
+            grad = self.bucket.flat[off:off + p.numel()].view_as(p)
+            m.mul_(b1).add_(grad, alpha=1 - b1)
+            v.mul_(b2).addcmul_(grad, grad, value=1 - b2)
+            denom = (v.sqrt() / (bc2 ** 0.5)).add_(self.eps)
+            p.addcdiv_(m, denom, value=-float(g["lr"]) / bc1)
+        if zero_grad:
+            self.bucket.flat.zero_()
 
     # ---- the torch.optim.Adam surface train.py and the checkpoint format use ---------------------------------------
     @property
@@ -120,7 +177,9 @@ class FusedAdam:
         """{param: {"step", "exp_avg", "exp_avg_sq"}} (views of the live moments), empty before the first step as in torch."""
         if self.step_count == 0:
             return {}
-        return {p: {"step": torch.tensor(float(self.step_count)), "exp_avg": m, "exp_avg_sq": v} for _, p, _, m, v in self.items}
+        mom = self.full_moments()
+        return {p: {"step": torch.tensor(float(self.step_count)), "exp_avg": mom[id(p)][0], "exp_avg_sq": mom[id(p)][1]}
+                for p in self.bucket.params if id(p) in mom}
 
     def zero_grad(self, set_to_none=True):
         """train.py calls `optimizer.zero_grad(set_to_none=True)` [REF train.py:197]; the gradients here are views into the
@@ -135,7 +194,7 @@ class FusedAdam:
         """Same layout as `torch.optim.Adam.state_dict()` for the same groups: `(state_dict(), optimizer.state_dict(),
         iteration)` checkpoints interchange with the reference's [REF train.py:199-201, scene/gaussian_model.py:96-104]."""
         tmpl = self._group_template()
-        mom = {id(p): (m, v) for _, p, _, m, v in self.items}
+        mom = self.full_moments()
         groups, state, k = [], {}, 0
         for g in self.param_groups:
             entry = dict(tmpl)
@@ -155,7 +214,7 @@ class FusedAdam:
         groups = sd["param_groups"]
         if len(groups) != len(self.param_groups):
             raise ValueError(f"loaded state dict has {len(groups)} parameter groups, the optimizer has {len(self.param_groups)}")
-        mom = {id(p): (m, v) for _, p, _, m, v in self.items}
+        known = {id(p) for p in self.bucket.params}
         steps = []
         for g, saved in zip(self.param_groups, groups):
             if len(saved["params"]) != len(g["params"]):
@@ -165,13 +224,11 @@ class FusedAdam:
             g["lr"] = float(saved["lr"])
             for p, idx in zip(g["params"], saved["params"]):
                 st = sd["state"].get(idx)
-                if st is None or id(p) not in mom:
+                if st is None or id(p) not in known:
                     continue
-                m, v = mom[id(p)]
-                if tuple(st["exp_avg"].shape) != tuple(m.shape):
-                    raise ValueError(f"group {g.get('name')}: moment shape {tuple(st['exp_avg'].shape)} vs parameter {tuple(m.shape)}")
-                m.copy_(st["exp_avg"].to(m.device, m.dtype))
-                v.copy_(st["exp_avg_sq"].to(v.device, v.dtype))
+                if tuple(st["exp_avg"].shape) != tuple(p.shape):
+                    raise ValueError(f"group {g.get('name')}: moment shape {tuple(st['exp_avg'].shape)} vs parameter {tuple(p.shape)}")
+                self.load_full_moments(p, st["exp_avg"], st["exp_avg_sq"])
                 steps.append(int(float(st["step"])))
         # one step counter for all tensors: every optimizer of the reference is created whole by a *_setup call, so its
         # per-parameter steps are equal (densify / prune keep the stored state, step included)
@@ -188,6 +245,10 @@ class FusedAdam:
         if advance:
             self.step_count = step_no
         n = len(self.items)
+        if not self.bucket.flat.is_cuda:
+            # CPU tensors: the -m "not gpu" tests of the host logic (sharding, checkpoint layout) -- torch.optim.Adam's update
+            # rule in torch ops.  HIP tensors never come here: below is the only implementation the render path has.
+            return self._step_host(step_no, zero_grad, {id(p) for p in keep_grad})
         if not hasattr(self, "_tab"):
             P = (C.c_void_p * n)(*[p.data_ptr() for _, p, _, _, _ in self.items])
             G = (C.c_void_p * n)(*[self.bucket.flat.data_ptr() + 4 * off for _, _, off, _, _ in self.items])
@@ -204,7 +265,7 @@ class FusedAdam:
             key = (frozenset(inc) if inc is not None else None, frozenset(exc))
             sub = self._num_subsets.get(key)
             if sub is None:     # a tensor with numel 0 is skipped by the library
-                flags = [(inc is None or id(p) in inc) and id(p) not in exc for _, p, _, _, _ in self.items]
+                flags = [(inc is None or id(p) in inc) and id(p) not in exc for p in self.owner]
                 sub = ((C.c_int64 * n)(*[p.numel() if f else 0 for f, (_, p, _, _, _) in zip(flags, self.items)]), flags)
                 self._num_subsets[key] = sub
             NUM, active = sub
@@ -212,7 +273,7 @@ class FusedAdam:
         keep_ids = {id(p) for p in keep_grad}
         mask = 0
         if zero_grad:
-            for k, (_, p, _, _, _) in enumerate(self.items):
+            for k, p in enumerate(self.owner):
                 if id(p) in keep_ids and (active is None or active[k]):
                     mask |= 1 << k
         b1, b2 = self.betas
@@ -225,6 +286,16 @@ class FusedAdam:
             _lib.check(rc, "gp_adam_step_multi")
         if mask:
             from . import grad_sink
-            for k, (_, p, _, _, _) in enumerate(self.items):
+            for k, p in enumerate(self.owner):
                 if (mask >> k) & 1:
                     grad_sink.mark_stale(p.grad)
+        if self.shard is not None and zero_grad:
+            # the launch zeroed this rank's slices only; the slices the other ranks own hold this rank's partial sums still
+            kept = set()
+            for region in self.bucket.regions:
+                ps = [self.bucket.params[i] for i in region[2]]
+                if all(id(p) in keep_ids for p in ps):
+                    kept.add(region[0])          # every tensor of the region is overwritten by its producer next step
+            for start, end, _ in self.bucket.regions:
+                if start not in kept:
+                    self.bucket.flat[start:end].zero_()

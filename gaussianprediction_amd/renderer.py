@@ -57,6 +57,9 @@ def _wait_params(pc):
     ev = getattr(pc, "_param_ready_event", None)
     if ev is not None:
         torch.cuda.current_stream().wait_event(ev)
+    wait = getattr(pc, "_param_ready_wait", None)     # (sharded optimizer: the all-gather of the SH coefficients)
+    if wait is not None:
+        wait()
 
 
 def _screenspace_points(pc):

@@ -13,7 +13,7 @@ from types import SimpleNamespace
 import torch
 import torch.nn.functional as F
 
-from .dist import OverlappedGradReducer
+from .dist import OverlappedGradReducer, ShardedExchange
 from . import grad_sink
 from .loss_ops import add_l1_mean, l1_ssim_loss
 from .renderer import render
@@ -62,7 +62,7 @@ class TrainStep:
     SPEC_PAD = 4096
 
     def __init__(self, pc, cameras, gt_images, iteration, lambda_dssim=0.2, lrs=None, group=None, fused=True, speculative=False,
-                 overlap_sh_adam=False, batch=1, schedule=False, training_args=None):
+                 overlap_sh_adam=False, batch=1, schedule=False, training_args=None, sharded=None):
         self.pc, self.cameras, self.gt, self.iteration = pc, cameras, gt_images, iteration
         self.lambda_dssim = lambda_dssim
         self.group = group
@@ -106,7 +106,14 @@ class TrainStep:
             training_args = default_training_args(**over)
         self.training_args = training_args
         pc.use_fused_adam = bool(fused)
-        if pc.optimizer is None or getattr(pc, "_stage", None) != self._stage_of(iteration):
+        # view-parallel: reduce-scatter -> sharded Adam -> all-gather by default (dist.ShardedExchange); sharded=False keeps
+        # the all-reduce + replicated Adam of round 1
+        import torch.distributed as tdist
+        world = tdist.get_world_size(group) if (tdist.is_available() and tdist.is_initialized()) else 1
+        self.sharded = bool(fused and world > 1 and (sharded is None or sharded))
+        shard = (tdist.get_rank(group), world) if self.sharded else None
+        if pc.optimizer is None or getattr(pc, "_stage", None) != self._stage_of(iteration) or getattr(pc, "optimizer_shard", None) != shard:
+            pc.optimizer_shard = shard
             pc.setup_for_iteration(training_args, iteration)
         self._epoch = None
         self._attach()
@@ -128,7 +135,13 @@ class TrainStep:
             return
         if getattr(self, "reducer", None) is not None:
             self.reducer.close()
-        self.reducer = OverlappedGradReducer(self.pc.bucket, self.group)
+        if self.sharded:
+            self.reducer = ShardedExchange(self.pc.bucket, self.group)
+            sh = {id(self.pc._features_dc), id(self.pc._features_rest)}
+            self._early_params = {id(p) for p in self.pc.bucket.params} - sh
+            self.pc._param_ready_wait = self.reducer.wait_params          # render(): right before the rasterizer call
+        else:
+            self.reducer = OverlappedGradReducer(self.pc.bucket, self.group)
         if getattr(self, "overlap_sh_adam", False) and self._sink_cb is None:
             self._armed = False
             self._ev_bwd, self._ev_sh = torch.cuda.Event(), torch.cuda.Event()
@@ -211,6 +224,8 @@ class TrainStep:
     def _step(self, view_index: int, binning, skip_flag):
         pc = self.pc
         self._attach()                               # (densify / prune / stage changes rebuild bucket + optimizer)
+        if self.sharded:                             # parameters the deformation reads: their all-gather must have landed
+            self.reducer.wait_params(only=self._early_params)
         if self.schedule:
             pc.update_learning_rate(self.iteration)  # [REF train.py:79]
         a = pc.args
@@ -263,4 +278,11 @@ class TrainStep:
         else:
             self.optimizer.step()
             self.bucket.zero()
+        if self.sharded:
+            self.reducer.gather_params()             # asynchronous; awaited by the next step / render
         return loss.detach(), pkg
+
+    def sync_params(self):
+        """Wait for every outstanding parameter exchange (before anything outside step() / render() reads the parameters)."""
+        if self.sharded:
+            self.reducer.wait_params()

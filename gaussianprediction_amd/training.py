@@ -155,11 +155,17 @@ class TrainingMixin:
         for p in self.parameters():             # the reference computes (and discards) the other gradients; skipping them
             p.requires_grad_(id(p) in optimized)   # changes no result
         params = [p for g in groups for p in g["params"]]
-        self.bucket = FlatGradBucket(params)
-        if params[0].is_cuda and getattr(self, "use_fused_adam", True):
+        shard = getattr(self, "optimizer_shard", None)       # (rank, world): set by a view-parallel harness (dist.ShardedExchange)
+        if shard is not None and shard[1] > 1:
             from .loss_ops import FusedAdam
+            self.bucket = FlatGradBucket(params, shards=shard[1], flat_params=True)
+            self.optimizer = FusedAdam(groups, self.bucket, eps=1e-15, shard=shard)
+        elif params[0].is_cuda and getattr(self, "use_fused_adam", True):
+            from .loss_ops import FusedAdam
+            self.bucket = FlatGradBucket(params)
             self.optimizer = FusedAdam(groups, self.bucket, eps=1e-15)
         else:
+            self.bucket = FlatGradBucket(params)
             self.optimizer = torch.optim.Adam(groups, lr=0.0, eps=1e-15)     # [REF :472]
         self.optimizer_epoch += 1
 
@@ -301,7 +307,7 @@ class TrainingMixin:
         if opt is None:
             return {}
         if hasattr(opt, "items"):
-            return {id(p): (m, v) for _, p, _, m, v in opt.items}
+            return opt.full_moments()            # (sharded: a collective -- every rank performs the same surgery)
         return {id(p): (st["exp_avg"], st["exp_avg_sq"]) for p, st in opt.state.items() if "exp_avg" in st}
 
     def _rebuild_optimizer(self, carried):
@@ -323,10 +329,10 @@ class TrainingMixin:
                 g["lr"] = lrs[g["name"]]
         if fused:
             self.optimizer.step_count = old_step
-            for _, p, _, m, v in self.optimizer.items:
+            for p in self.bucket.params:
                 src = carried.get(id(p)) or old_mom.get(id(p))
-                if src is not None and src[0].shape == m.shape:
-                    m.copy_(src[0]); v.copy_(src[1])
+                if src is not None and src[0].shape == p.shape:
+                    self.optimizer.load_full_moments(p, src[0], src[1])
         else:
             some = next((st for st in old_state.values() if "step" in st), None)
             for g in self.optimizer.param_groups:

@@ -101,3 +101,62 @@ def test_bucket_is_noop_without_process_group():
     assert b.all_reduce_sum() is None and torch.equal(ref, b.flat)
     b.zero()
     assert float(b.flat.abs().max()) == 0.0 and float(params[0].grad.abs().max()) == 0.0
+
+
+# ---- sharded optimizer: reduce-scatter -> 1/world of Adam per rank -> all-gather ----------------------------------------
+def _named_groups(params):
+    return [{"params": [params[0]], "lr": 1e-2, "name": "xyz"}, {"params": [params[1]], "lr": 5e-3, "name": "f_rest"},
+            {"params": [params[2], params[3]], "lr": 2e-2, "name": "df_mlp"}]
+
+
+def _worker_sharded(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from gaussianprediction_amd.dist import ShardedExchange
+    from gaussianprediction_amd.loss_ops import FusedAdam
+    params = _params()
+    groups = _named_groups(params)
+    # small_numel = 200: the two larger tensors get a region of their own, the two small ones (different learning rates) share the tail
+    bucket = FlatGradBucket([p for g in groups for p in g["params"]], shards=world, flat_params=True, small_numel=200)
+    assert all((e - s) % (64 * world) == 0 for s, e, _ in bucket.regions) and len(bucket.regions) == 3
+    opt = FusedAdam(groups, bucket, eps=1e-15, shard=(rank, world))
+    ex = ShardedExchange(bucket)
+    for step in range(3):
+        _view_loss(params, rank + 10 * step).backward()          # rank r renders view r of this step
+        ex.finish()
+        opt.step()
+        ex.gather_params()
+        ex.wait_params()
+    sd = opt.state_dict()                                         # collective: whole-tensor moments in torch's layout
+    torch.save({"params": [p.detach().clone() for p in params], "sd": sd, "bytes": ex.bytes_sent_per_step, "n": bucket.flat.numel()},
+               os.path.join(out_dir, f"sh{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_adam_equals_replicated_adam(tmp_path, world):
+    mp.spawn(_worker_sharded, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    outs = [torch.load(os.path.join(tmp_path, f"sh{r}.pt"), weights_only=False) for r in range(world)]
+    # single-process reference: torch.optim.Adam on the SUM of the ranks' losses [REF train.py:113-119, scene/gaussian_model.py:472]
+    params = _params()
+    ref = torch.optim.Adam(_named_groups(params), lr=0.0, eps=1e-15)
+    for step in range(3):
+        ref.zero_grad()
+        torch.stack([_view_loss(params, r + 10 * step) for r in range(world)]).sum().backward()
+        ref.step()
+    for r in range(world):
+        for a, b in zip(outs[r]["params"], params):               # every rank holds every updated parameter (all-gather)
+            torch.testing.assert_close(a, b.detach(), rtol=2e-5, atol=2e-6)
+        for a, b in zip(outs[r]["params"], outs[0]["params"]):
+            assert torch.equal(a, b)
+    want = ref.state_dict()
+    got = outs[0]["sd"]
+    assert [g["name"] for g in got["param_groups"]] == ["xyz", "f_rest", "df_mlp"]
+    for k in want["state"]:
+        torch.testing.assert_close(got["state"][k]["exp_avg"], want["state"][k]["exp_avg"], rtol=2e-5, atol=1e-7)
+        torch.testing.assert_close(got["state"][k]["exp_avg_sq"], want["state"][k]["exp_avg_sq"], rtol=2e-5, atol=1e-9)
+        assert float(got["state"][k]["step"]) == 3.0
+    # bytes on the links per rank and step: reduce-scatter + all-gather of the flat buffer, (world - 1) / world of it each
+    assert outs[0]["bytes"] == 2 * 4 * outs[0]["n"] * (world - 1) // world

@@ -177,7 +177,7 @@ def _rank_main(rank, world, port, out_dir, backend, step_opacity):
         dist.init_process_group("gloo", rank=rank, world_size=world)
     pc, cams, gts, raw, rw, idx, args = build(n=3000, dev=f"cuda:{dev}", step_opacity=step_opacity)
     zero = dict(xyz=0.0, f_dc=0.0, opacity=0.0, scaling=0.0, rotation=0.0, kpts=0.0, mlp=0.0)
-    ts = TrainStep(pc, cams, gts, 50000, lrs=zero)
+    ts = TrainStep(pc, cams, gts, 50000, lrs=zero, sharded=False)
     assert ts.reducer.enabled
     got = {}
     orig = ts.optimizer.step
@@ -225,3 +225,49 @@ def test_two_rank_view_parallel_step_equals_batch_accumulation(tmp_path, step_op
             e = float((a - b).norm() / b.norm().clamp_min(1e-30))
             assert e < 2e-5, (step, k, e)
         assert torch.equal(r0["radii"], pkg["radii"].cpu())
+
+
+def _rank_main_params(rank, world, port, out_dir, backend, sharded, step_opacity):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch.distributed as dist
+    dev = rank if backend == "nccl" else 0
+    torch.cuda.set_device(dev)
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    pc, cams, gts, raw, rw, idx, args = build(n=3000, dev=f"cuda:{dev}", step_opacity=step_opacity)
+    ts = TrainStep(pc, cams, gts, 50000, sharded=sharded)
+    assert ts.sharded == sharded and type(ts.reducer).__name__ == ("ShardedExchange" if sharded else "OverlappedGradReducer")
+    for step in range(3):
+        ts.step(step * world + rank)
+    ts.sync_params()
+    sd = pc.optimizer.state_dict()                       # (sharded: a collective)
+    torch.save({"params": {n: p.detach().cpu() for n, p in pc.named_parameters()}, "state": {k: {kk: vv.cpu() for kk, vv in v.items()} for k, v in sd["state"].items()},
+                "bytes": getattr(ts.reducer, "bytes_sent_per_step", None), "n": pc.bucket.flat.numel()}, os.path.join(out_dir, f"p{int(sharded)}_{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("step_opacity", [False, True])
+def test_two_rank_sharded_adam_equals_replicated_adam(tmp_path, step_opacity):
+    """reduce-scatter -> Adam on 1/world of every region -> all-gather leaves every rank with the parameters (and, gathered, the
+    moments) that all-reduce + replicated Adam produce."""
+    import torch.multiprocessing as mp
+    backend = "nccl" if torch.cuda.device_count() >= 2 else "gloo"
+    for sharded in (False, True):
+        mp.spawn(_rank_main_params, args=(2, _free_port(), str(tmp_path), backend, sharded, step_opacity), nprocs=2, join=True)
+    rep = [torch.load(os.path.join(tmp_path, f"p0_{r}.pt")) for r in range(2)]
+    sh = [torch.load(os.path.join(tmp_path, f"p1_{r}.pt")) for r in range(2)]
+    for name in rep[0]["params"]:
+        a, b = rep[0]["params"][name], sh[0]["params"][name]
+        assert torch.equal(sh[0]["params"][name], sh[1]["params"][name]), name          # replicas stay replicas
+        # the backward accumulates with atomics (run-to-run differences in the last bits of a gradient), and Adam with eps = 1e-15
+        # moves an element whose gradient is rounding noise by a full +-lr: a few such elements may differ by a couple of steps
+        diff = (a - b).abs()
+        assert float((diff > 1e-6).float().mean()) < 2e-2 and float(diff.max()) < 0.05 * 3 + 1e-6, (name, float(diff.max()))
+    assert set(rep[0]["state"]) == set(sh[0]["state"]) and len(sh[0]["state"]) > 5
+    for k in rep[0]["state"]:
+        torch.testing.assert_close(sh[0]["state"][k]["exp_avg"], rep[0]["state"][k]["exp_avg"], rtol=1e-3, atol=1e-7)
+        assert float(sh[0]["state"][k]["step"]) == 3.0
+    assert sh[0]["bytes"] == 4 * sh[0]["n"]          # world 2: reduce-scatter + all-gather move half the flat buffer each, per rank
