@@ -133,6 +133,8 @@ def main():
     ap.add_argument("--scale_lo", type=float, default=0.003)
     ap.add_argument("--scale_hi", type=float, default=0.012)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-weights-model-step", action="store_true", help="skip the secondary measurement of the step that also "
+                    "runs the per-frame hash-grid weights model + kNN")
     ap.add_argument("--exact-binning", action="store_true",
                     help="size the binning buffers by reading R back every step (one host sync per step) instead of the "
                          "capacity mode with the high-water-mark protocol of TrainStep(speculative=True)")
@@ -336,6 +338,27 @@ def main():
             except Exception as e:  # the baseline must never kill the bench line
                 result["cpu_baseline"] = {"value": None, "unit": "views/s", "cores": os.cpu_count(), "kind": "port",
                                           "sample": f"failed: {e}"}
+        if world == 1 and not args.render_only and not args.no_weights_model_step:
+            # the step the REFERENCE runs in stage 3 also evaluates the hash-grid weights model and the kNN every frame (and
+            # optimizes the former) [REF scene/gaussian_model.py:257-260,402]; north_star takes their outputs as inputs, so the
+            # headline does not contain them -- this is the same step with them inside, on this package's own kernels
+            try:
+                from gaussianprediction_amd.weights_ops import WeightsModel
+                margs.knn_type, margs.feature_amplify = "hybird", 5.0
+                pc.weights_model = WeightsModel(2 * args.nearest_num, device=device)
+                pc.set_keypoint_weights(None, None)
+                pc.optimizer = None
+                ts2 = TrainStep(pc, cams, gts, args.iteration, lrs=dict(xyz=1.6e-6 * 5.0))
+                for i in range(5):
+                    ts2.step(i)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for i in range(20):
+                    ts2.step(5 + i)
+                torch.cuda.synchronize()
+                result["train_step_with_weights_model_ms"] = round(1000.0 * (time.perf_counter() - t1) / 20, 3)
+            except Exception as e:
+                result["train_step_with_weights_model_ms"] = f"failed: {e}"
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()
