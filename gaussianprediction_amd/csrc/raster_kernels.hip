@@ -701,7 +701,7 @@ __device__ __forceinline__ uint32_t gp_sb_mask(const float4 q0, const float4 q1,
     return mask;
 }
 
-template <bool ASM>
+template <int MODE>   // 0: compiler-scheduled visit loop (the readable statement of the algorithm)  1: hand-scheduled (shipped)
 __device__ __forceinline__ void gp_composite_fwd_sb_body(RasterDims d, const int2* __restrict__ ranges,
                                                                          const uint32_t* __restrict__ point_list,
                                                                          const float4* __restrict__ rec,
@@ -792,7 +792,7 @@ __device__ __forceinline__ void gp_composite_fwd_sb_body(RasterDims d, const int
             const int nmax = max(max(__builtin_amdgcn_readlane(tot, 0), __builtin_amdgcn_readlane(tot, 16)),
                                  max(__builtin_amdgcn_readlane(tot, 32), __builtin_amdgcn_readlane(tot, 48)));
             const int sbase = (base - range.x) * CF2_REC;
-            if (ASM) {
+            if (MODE == 1) {
                 // Four visits per block, hand-scheduled: the compiler's version of this loop carries 37 VALU slots per visit
                 // (flag bytes, moves, duplicated compares); this one carries 29.  Temporaries and the two record buffers are
                 // fixed registers v24 .. v53 (clobbered); LDS returns in order, so `s_waitcnt lgkmcnt(3)` = "the older record
@@ -951,10 +951,10 @@ __device__ __forceinline__ void gp_composite_fwd_sb_body(RasterDims d, const int
     float* __restrict__ final_T, int32_t* __restrict__ n_contrib, const uint32_t* __restrict__ order, int32_t* __restrict__ tile_work, \
     uint8_t* __restrict__ qmask
 __global__ __launch_bounds__(CF_THREADS) void gp_composite_fwd_sb_kernel(CF2_ARGS) {
-    gp_composite_fwd_sb_body<true>(d, ranges, point_list, rec, bg, out_color, out_depth, out_tidx, final_T, n_contrib, order, tile_work, qmask);
+    gp_composite_fwd_sb_body<1>(d, ranges, point_list, rec, bg, out_color, out_depth, out_tidx, final_T, n_contrib, order, tile_work, qmask);
 }
 __global__ __launch_bounds__(CF_THREADS) void gp_composite_fwd_sbc_kernel(CF2_ARGS) {   // compiler-scheduled inner loop (A/B reference)
-    gp_composite_fwd_sb_body<false>(d, ranges, point_list, rec, bg, out_color, out_depth, out_tidx, final_T, n_contrib, order, tile_work, qmask);
+    gp_composite_fwd_sb_body<0>(d, ranges, point_list, rec, bg, out_color, out_depth, out_tidx, final_T, n_contrib, order, tile_work, qmask);
 }
 
 // ------------------------------------------------------------------------------------------------
