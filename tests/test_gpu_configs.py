@@ -225,3 +225,37 @@ def test_c5_single_gpu_form_fp16_operand_mlp():
         loss, pkg = ts.step(1)
         assert math.isfinite(float(loss))
         assert torch.isfinite(pc._xyz).all() and all(torch.isfinite(p).all() for p in pc.df_model.parameters())
+
+
+def test_c4_single_gpu_form_lifecycle_opacity_batch_of_views():
+    """configs[3] on one GPU: 1 M Gaussians, K = 300 keypoints, F = 10, lifecycle opacity (a second MLP pass over all N with its own
+    gradient into `_xyz`), several views per iteration accumulated as `--batch` does [REF train.py:113-133, scripts/train/hyper/lemon.sh]
+    -- the 8-GPU leg runs the same step with one view per rank and the exchange of tests/test_gpu_training_api.py."""
+    from gaussianprediction_amd.train_step import TrainStep
+    N, W, H = 1_000_000, 1352, 1014
+    args = SimpleNamespace(beta=0.1, d=4, w=256, feature_dim=32, second_stage_iteration=30000, third_stage_iteration=40000,
+                           jointly_iteration=1000, nearest_num=6, norm_rotation=True, step_opacity=True, step_opacity_iteration=5000,
+                           opacity_type="implicit", xyz_noise_iteration=0)
+    raw = make_gaussians(SceneSpec(n_gaussians=N, extent=(1.5, 1.5, 0.5), scale_lo=0.003, scale_hi=0.012, seed=2024), device="cuda")
+    kp, kpf, idx, rw = make_keypoints(raw["xyz"], raw["motion_feature"], 300, 6)
+    torch.manual_seed(2024)
+    pc = gpa.GaussianModel(3, args)
+    pc.set_inputDim(20, 60)                                    # F = 10
+    pc.create_from_tensors(raw["xyz"], raw["features_dc"], raw["features_rest"], raw["scaling"], raw["rotation"], raw["opacity"],
+                           raw["motion_feature"], kp, kpf)
+    pc.set_keypoint_weights(rw, idx)
+    assert pc.df_model.feature_to_deformation[0].weight.shape[0] == 8 and isinstance(pc.opacity_thres, torch.nn.Parameter)
+    cams = orbit_cameras(8, 4.0, 2 * math.atan(1 / 1.8), W, H, arc_deg=40.0, elevation_deg=5.0, device="cuda")
+    pipe = SimpleNamespace(convert_SHs_python=False, compute_cov3D_python=False, debug=False)
+    with torch.no_grad():
+        gts = [gpa.render(c, pc, pipe, torch.zeros(3, device="cuda"), time=torch.tensor([0.3], device="cuda"), it=50000)["render"] * 0.9
+               for c in cams[:2]] * 4
+    ts = TrainStep(pc, cams, gts, 50000, batch=2)
+    names = [g["name"] for g in pc.optimizer.param_groups]
+    assert names == ["xyz", "f_dc", "f_rest", "opacity", "scaling", "rotation", "s_xyz", "s_motion_feature", "df_mlp", "opacity_thres"]
+    x0 = pc._xyz.detach().clone()
+    loss, pkg = ts.step(0)
+    assert math.isfinite(float(loss)) and pc.lifecycle_opacity is not None
+    assert pkg["radii"].shape == (N,) and int(pkg["visibility_filter"].sum()) > N // 2
+    assert torch.isfinite(pc._xyz).all() and not torch.equal(pc._xyz.detach(), x0)
+    assert all(torch.isfinite(p).all() for p in pc.df_model.parameters())
