@@ -1091,10 +1091,9 @@ __device__ __forceinline__ void gp_composite_bwd_body(RasterDims d, const int2* 
                                                        const uint32_t* __restrict__ order) {
     constexpr int PAIRS = ROWS * COLS / 2;
     static_assert(PAIRS <= 64, "one lane per pixel pair in the prologue");
-    __shared__ float4 s_cy[PAIRS];   // Tin0 Tin1 rem0 rem1     (carried between batches)
-    __shared__ float4 s_v0[PAIRS];   // dLr0 dLr1 dLg0 dLg1
-    __shared__ float4 s_v1[PAIRS];   // dLb0 dLb1 tb0  tb1      (tb = T_final * bg . dL_dpix)
-    __shared__ int2 s_nc[PAIRS];
+    // per pixel pair, 64 B: [0] n_contrib0 n_contrib1 - -   [1] dLr0 dLr1 dLg0 dLg1   [2] dLb0 dLb1 tb0 tb1 (tb = T_final * bg . dL_dpix)
+    //                       [3] Tin0 Tin1 rem0 rem1 (carried between batches).  One array: a step reaches all four with immediate offsets.
+    __shared__ float4 s_pp[PAIRS][4];
     __shared__ float2 s_dd[HAS_DEPTH ? PAIRS : 1];   // dLd0 dLd1
     constexpr int parts_x = GP_TILE / COLS, parts = (GP_TILE / ROWS) * parts_x;
     const int part = blockIdx.x % parts;
@@ -1109,10 +1108,10 @@ __device__ __forceinline__ void gp_composite_bwd_body(RasterDims d, const int2* 
         if (lane < PAIRS) {
             const float4* me = (const float4*)&mypp[lane];
             const float4 t0 = me[0], t1 = me[1], t = me[2];
-            s_v0[lane] = t0; s_v1[lane] = t1;
-            s_nc[lane] = make_int2(__float_as_int(t.x), __float_as_int(t.y));
+            s_pp[lane][1] = t0; s_pp[lane][2] = t1;
+            s_pp[lane][0] = make_float4(t.x, t.y, 0.f, 0.f);
             if (HAS_DEPTH) { const float4 t3 = me[3]; s_dd[lane] = make_float2(t3.x, t3.y); }
-            s_cy[lane] = make_float4(1.f, 1.f, t.z, t.w);
+            s_pp[lane][3] = make_float4(1.f, 1.f, t.z, t.w);
             max_nc = max(__float_as_int(t.x), __float_as_int(t.y));
         }
     }
@@ -1208,12 +1207,131 @@ __device__ __forceinline__ void gp_composite_bwd_body(RasterDims d, const int2* 
             const float dy = sy - (float)row;
             const float tB = Bs * dy, uC = (Cs * dy) * dy;
             v2f r_h = {0.f, 0.f}, r_hx = {0.f, 0.f};
+            if (!HAS_DEPTH) {
+                // The four pixel-pair steps of a row, hand-scheduled (the compiler's version of the step below carries ~95 issue
+                // slots: phi copies at the merge points, address moves, duplicated selects; this one 80).  Temporaries v64..v97 are
+                // fixed registers (clobbered); exec is restored before leaving.  Same arithmetic as the C++ step (HAS_DEPTH path).
+                const v2f As2 = {As, As}, tB2 = {tB, tB}, uC2 = {uC, uC}, op2 = {op, op};
+                const v2f dx0 = {dxs[0], dxs[0] - 1.f}, dx1 = {dxs[1], dxs[1] - 1.f}, dx2 = {dxs[2], dxs[2] - 1.f}, dx3 = {dxs[3], dxs[3] - 1.f};
+                const uint32_t vpp = (uint32_t)(uintptr_t)&s_pp[row * (COLS / 2)][0];
+                unsigned long long sv, c0, c1, t0;
+#define CB_SCAN2(OPC, R0, R1)                                                                   \
+    "s_nop 1\n\t"                                                                               \
+    OPC " " R0 ", " R0 ", " R0 " row_shr:1 row_mask:0xf bank_mask:0xf\n\t"                       \
+    OPC " " R1 ", " R1 ", " R1 " row_shr:1 row_mask:0xf bank_mask:0xf\n\t"                       \
+    "s_nop 0\n\t"                                                                               \
+    OPC " " R0 ", " R0 ", " R0 " row_shr:2 row_mask:0xf bank_mask:0xf\n\t"                       \
+    OPC " " R1 ", " R1 ", " R1 " row_shr:2 row_mask:0xf bank_mask:0xf\n\t"                       \
+    "s_nop 0\n\t"                                                                               \
+    OPC " " R0 ", " R0 ", " R0 " row_shr:4 row_mask:0xf bank_mask:0xf\n\t"                       \
+    OPC " " R1 ", " R1 ", " R1 " row_shr:4 row_mask:0xf bank_mask:0xf\n\t"                       \
+    "s_nop 0\n\t"                                                                               \
+    OPC " " R0 ", " R0 ", " R0 " row_shr:8 row_mask:0xf bank_mask:0xf\n\t"                       \
+    OPC " " R1 ", " R1 ", " R1 " row_shr:8 row_mask:0xf bank_mask:0xf\n\t"                       \
+    "s_nop 0\n\t"                                                                               \
+    OPC " " R0 ", " R0 ", " R0 " row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"                    \
+    OPC " " R1 ", " R1 ", " R1 " row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"                    \
+    "s_nop 0\n\t"                                                                               \
+    OPC " " R0 ", " R0 ", " R0 " row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"                    \
+    OPC " " R1 ", " R1 ", " R1 " row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"                    \
+    "s_nop 1\n\t"
+#define CB_STEP(CP, O0, O1, O2, O3, DX)                                                                               \
+    "ds_read_b64 v[64:65], %[vpp] offset:" #O0 "\n\t"                                                                \
+    "ds_read_b128 v[66:69], %[vpp] offset:" #O1 "\n\t"                                                               \
+    "ds_read_b128 v[70:73], %[vpp] offset:" #O2 "\n\t"                                                               \
+    "ds_read_b128 v[74:77], %[vpp] offset:" #O3 "\n\t"                                                               \
+    "v_pk_fma_f32 v[78:79], %[As2], " DX ", %[tB2] op_sel_hi:[0,1,0]\n\t"                                             \
+    "s_nop 0\n\t"                                                                                                   \
+    "v_pk_fma_f32 v[78:79], " DX ", v[78:79], %[uC2] op_sel_hi:[1,1,0]\n\t"                                           \
+    "s_waitcnt lgkmcnt(3)\n\t"                                                                                       \
+    "v_max_i32 v80, v64, v65\n\t"                                                                                    \
+    "v_cmp_lt_i32 vcc, %[b0], v80\n\t"                                                                               \
+    "s_cbranch_vccz 9" #CP "f\n\t"                                                                                   \
+    "v_min_f32 v80, 0, v78\n\t"                                                                                      \
+    "v_min_f32 v81, 0, v79\n\t"                                                                                      \
+    "v_exp_f32 v80, v80\n\t"                                                                                         \
+    "v_exp_f32 v81, v81\n\t"                                                                                         \
+    "v_cmp_lt_i32 %[c0], %[pos], v64\n\t"                                                                            \
+    "v_cmp_lt_i32 %[c1], %[pos], v65\n\t"                                                                            \
+    "v_cmp_nlt_f32 %[t0], 0, v78\n\t"                                                                                \
+    "s_and_b64 %[c0], %[c0], %[t0]\n\t"                                                                              \
+    "v_cmp_nlt_f32 %[t0], 0, v79\n\t"                                                                                \
+    "s_and_b64 %[c1], %[c1], %[t0]\n\t"                                                                              \
+    "v_pk_mul_f32 v[82:83], %[op2], v[80:81] op_sel_hi:[0,1]\n\t"                                                     \
+    "s_nop 0\n\t"                                                                                                   \
+    "v_min_f32 v82, 0x3f7d70a4, v82\n\t"                                                                             \
+    "v_min_f32 v83, 0x3f7d70a4, v83\n\t"                                                                             \
+    "v_cmp_ngt_f32 vcc, 0x3b808081, v82\n\t"         /* (a literal needs the VOPC encoding: destination vcc) */      \
+    "s_and_b64 %[c0], %[c0], vcc\n\t"                                                                                \
+    "v_cmp_ngt_f32 vcc, 0x3b808081, v83\n\t"                                                                         \
+    "s_and_b64 %[c1], %[c1], vcc\n\t"                                                                              \
+    "s_or_b64 %[t0], %[c0], %[c1]\n\t"                                                                               \
+    "s_cbranch_scc0 9" #CP "f\n\t"                                                                                   \
+    "v_cndmask_b32 v80, 0, v80, %[c0]\n\t"                                                                           \
+    "v_cndmask_b32 v81, 0, v81, %[c1]\n\t"                                                                           \
+    "v_cndmask_b32 v82, 0, v82, %[c0]\n\t"                                                                           \
+    "v_cndmask_b32 v83, 0, v83, %[c1]\n\t"                                                                           \
+    "v_max3_f32 %[any], %[any], v82, v83\n\t"                                                                        \
+    "v_pk_add_f32 v[84:85], v[82:83], 1.0 op_sel_hi:[1,0] neg_lo:[1,0] neg_hi:[1,0]\n\t"                              \
+    "s_waitcnt lgkmcnt(0)\n\t"                                                                                       \
+    "v_pk_mul_f32 v[86:87], %[cb], v[70:71]\n\t"                                                                     \
+    "v_rcp_f32 v88, v84\n\t"                                                                                         \
+    "v_rcp_f32 v89, v85\n\t"                                                                                         \
+    "v_pk_fma_f32 v[86:87], %[cg], v[68:69], v[86:87]\n\t"                                                           \
+    CB_SCAN2("v_mul_f32_dpp", "v84", "v85")                                                                           \
+    "v_pk_fma_f32 v[86:87], %[cr], v[66:67], v[86:87]\n\t"                                                           \
+    "v_pk_mul_f32 v[90:91], v[74:75], v[84:85]\n\t"                                                                  \
+    "s_nop 0\n\t"                                                                                                   \
+    "v_pk_mul_f32 v[84:85], v[90:91], v[88:89]\n\t"                                                                  \
+    "s_nop 0\n\t"                                                                                                   \
+    "v_pk_mul_f32 v[94:95], v[82:83], v[84:85]\n\t"                                                                  \
+    "s_nop 0\n\t"                                                                                                   \
+    "v_pk_mul_f32 v[96:97], v[94:95], v[86:87]\n\t"                                                                  \
+    CB_SCAN2("v_add_f32_dpp", "v96", "v97")                                                                           \
+    "v_pk_add_f32 v[92:93], v[76:77], v[96:97] neg_lo:[0,1] neg_hi:[0,1]\n\t"                                         \
+    "s_bfm_b64 exec, 1, 63\n\t"                                                                                      \
+    "ds_write_b128 %[vpp], v[90:93] offset:" #O3 "\n\t"                                                              \
+    "s_mov_b64 exec, %[sv]\n\t"                                                                                      \
+    "v_pk_add_f32 v[96:97], v[92:93], v[72:73]\n\t"                                                                  \
+    "v_pk_fma_f32 %[a_r], v[94:95], v[66:67], %[a_r]\n\t"                                                            \
+    "v_pk_mul_f32 v[96:97], v[96:97], v[88:89]\n\t"                                                                  \
+    "v_pk_fma_f32 %[a_g], v[94:95], v[68:69], %[a_g]\n\t"                                                            \
+    "v_pk_fma_f32 v[96:97], v[84:85], v[86:87], v[96:97] neg_lo:[0,0,1] neg_hi:[0,0,1]\n\t"                           \
+    "v_pk_fma_f32 %[a_b], v[94:95], v[70:71], %[a_b]\n\t"                                                            \
+    "v_pk_mul_f32 v[96:97], v[80:81], v[96:97]\n\t"                                                                  \
+    "s_nop 0\n\t"                                                                                                   \
+    "v_pk_add_f32 %[a_op], %[a_op], v[96:97]\n\t"                                                                    \
+    "v_pk_mul_f32 v[96:97], %[op2], v[96:97] op_sel_hi:[0,1]\n\t"                                                     \
+    "s_nop 0\n\t"                                                                                                   \
+    "v_pk_add_f32 %[r_h], %[r_h], v[96:97]\n\t"                                                                      \
+    "v_pk_mul_f32 v[96:97], v[96:97], " DX "\n\t"                                                                    \
+    "s_nop 0\n\t"                                                                                                   \
+    "v_pk_add_f32 %[r_hx], %[r_hx], v[96:97]\n\t"                                                                    \
+    "v_pk_fma_f32 %[s_xx], v[96:97], " DX ", %[s_xx]\n\t"                                                            \
+    "9" #CP ":\n\t"
+                asm volatile(
+                    "s_mov_b64 %[sv], exec\n\t"
+                    CB_STEP(0, 0, 16, 32, 48, "%[dx0]")
+                    CB_STEP(1, 64, 80, 96, 112, "%[dx1]")
+                    CB_STEP(2, 128, 144, 160, 176, "%[dx2]")
+                    CB_STEP(3, 192, 208, 224, 240, "%[dx3]")
+                    : [a_op] "+v"(a_op), [a_r] "+v"(a_r), [a_g] "+v"(a_g), [a_b] "+v"(a_b), [s_xx] "+v"(s_xx), [r_h] "+v"(r_h), [r_hx] "+v"(r_hx),
+                      [any] "+v"(any_m), [sv] "=&s"(sv), [c0] "=&s"(c0), [c1] "=&s"(c1), [t0] "=&s"(t0)
+                    : [As2] "v"(As2), [tB2] "v"(tB2), [uC2] "v"(uC2), [op2] "v"(op2), [cr] "v"(cr), [cg] "v"(cg), [cb] "v"(cb), [dx0] "v"(dx0),
+                      [dx1] "v"(dx1), [dx2] "v"(dx2), [dx3] "v"(dx3), [pos] "v"(pos), [vpp] "v"(vpp), [b0] "s"(b0)
+                    : "vcc", "scc", "memory", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77",
+                      "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94",
+                      "v95", "v96", "v97");
+#undef CB_STEP
+#undef CB_SCAN2
+            } else
 #pragma unroll
             for (int cp = 0; cp < COLS / 2; ++cp) {
                 const int pr = row * (COLS / 2) + cp;
                 // all four broadcast reads are issued up front; the alpha math below covers their latency
-                const int2 nc = s_nc[pr];
-                const float4 v0 = s_v0[pr], v1 = s_v1[pr], cy = s_cy[pr];
+                const float4 ncf = s_pp[pr][0];
+                const int2 nc = make_int2(__float_as_int(ncf.x), __float_as_int(ncf.y));
+                const float4 v0 = s_pp[pr][1], v1 = s_pp[pr][2], cy = s_pp[pr][3];
                 float2 v3 = make_float2(0.f, 0.f);
                 if (HAS_DEPTH) v3 = s_dd[pr];
                 const float dx0 = dxs[cp];
@@ -1263,7 +1381,7 @@ __device__ __forceinline__ void gp_composite_bwd_body(RasterDims d, const int2* 
                         r_hx += hx;
                         s_xx = fma2(hx, dx, s_xx);
                         // carry to the next batch
-                        if (lane == 63) s_cy[pr] = make_float4(Tnext.x, Tnext.y, cy.z - is0, cy.w - is1);
+                        if (lane == 63) s_pp[pr][3] = make_float4(Tnext.x, Tnext.y, cy.z - is0, cy.w - is1);
                     }
                 }
             }
