@@ -1186,8 +1186,9 @@ __device__ __forceinline__ void gp_composite_bwd_body(RasterDims d, const int2* 
                 n0 = rec[3 * (size_t)ne.y]; n1 = rec[3 * (size_t)ne.y + 1]; n2 = rec[3 * (size_t)ne.y + 2];
             }
         }
-        const float sx = q0.x - px_base, sy = q0.y - py_base;
-        const float As = q0.z * LOG2E, Bs = q0.w * LOG2E, Cs = q1.x * LOG2E;   // power in log2 units
+        // alpha is recomputed with the FORWARD's expression tree, bit for bit (dx = x - px, dy = y - py from the same operands, the same
+        // fma nesting, exp2(power * log2e)): the backward's discrete decisions (power > 0, alpha < 1/255) are then the forward's own
+        const float As = q0.z, Bs = q0.w, Cs = q1.x;
         const float op = have ? q1.y : 0.f, zdep = q1.z;
         const float cxx = -2.f * q0.z, cxy = -q0.w, cyy = -2.f * q1.x;
         const v2f cr = {q2.x, q2.x}, cg = {q2.y, q2.y}, cb = {q2.z, q2.z};
@@ -1199,20 +1200,20 @@ __device__ __forceinline__ void gp_composite_bwd_body(RasterDims d, const int2* 
         float S_x = 0.f, S_y = 0.f, S_xy = 0.f, S_yy = 0.f;
         float any_m = 0.f;
         auto fma2 = [](v2f a, v2f b, v2f c) { return (v2f){fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y)}; };   // -> v_pk_fma_f32
-        float dxs[COLS / 2];                   // dx of the even pixel of each pair: the same in every row
+        v2f dxs[COLS / 2];                     // dx of the two pixels of each pair: the same in every row
 #pragma unroll
-        for (int cp = 0; cp < COLS / 2; ++cp) dxs[cp] = sx - (float)(2 * cp);
+        for (int cp = 0; cp < COLS / 2; ++cp) dxs[cp] = (v2f){q0.x - (px_base + (float)(2 * cp)), q0.x - (px_base + (float)(2 * cp + 1))};
 #pragma unroll 1
         for (int row = 0; row < ROWS; ++row) {
-            const float dy = sy - (float)row;
+            const float dy = q0.y - (py_base + (float)row);
             const float tB = Bs * dy, uC = (Cs * dy) * dy;
             v2f r_h = {0.f, 0.f}, r_hx = {0.f, 0.f};
             if (!HAS_DEPTH) {
                 // The four pixel-pair steps of a row, hand-scheduled (the compiler's version of the step below carries ~95 issue
                 // slots: phi copies at the merge points, address moves, duplicated selects; this one 80).  Temporaries v64..v97 are
                 // fixed registers (clobbered); exec is restored before leaving.  Same arithmetic as the C++ step (HAS_DEPTH path).
-                const v2f As2 = {As, As}, tB2 = {tB, tB}, uC2 = {uC, uC}, op2 = {op, op};
-                const v2f dx0 = {dxs[0], dxs[0] - 1.f}, dx1 = {dxs[1], dxs[1] - 1.f}, dx2 = {dxs[2], dxs[2] - 1.f}, dx3 = {dxs[3], dxs[3] - 1.f};
+                const v2f As2 = {As, As}, tB2 = {tB, tB}, uC2 = {uC, uC}, op2 = {op, op}, l2e = {LOG2E, LOG2E};
+                const v2f dx0 = dxs[0], dx1 = dxs[1], dx2 = dxs[2], dx3 = dxs[3];
                 const uint32_t vpp = (uint32_t)(uintptr_t)&s_pp[row * (COLS / 2)][0];
                 unsigned long long sv, c0, c1, t0;
 #define CB_SCAN2(OPC, R0, R1)                                                                   \
@@ -1247,8 +1248,10 @@ __device__ __forceinline__ void gp_composite_bwd_body(RasterDims d, const int2* 
     "v_max_i32 v80, v64, v65\n\t"                                                                                    \
     "v_cmp_lt_i32 vcc, %[b0], v80\n\t"                                                                               \
     "s_cbranch_vccz 9" #CP "f\n\t"                                                                                   \
-    "v_min_f32 v80, 0, v78\n\t"                                                                                      \
-    "v_min_f32 v81, 0, v79\n\t"                                                                                      \
+    "v_pk_mul_f32 v[80:81], v[78:79], %[l2e]\n\t"     /* gp_exp(power) = exp2(power * log2e), as the forward */     \
+    "s_nop 0\n\t"                                                                                                   \
+    "v_min_f32 v80, 0, v80\n\t"                                                                                      \
+    "v_min_f32 v81, 0, v81\n\t"                                                                                      \
     "v_exp_f32 v80, v80\n\t"                                                                                         \
     "v_exp_f32 v81, v81\n\t"                                                                                         \
     "v_cmp_lt_i32 %[c0], %[pos], v64\n\t"                                                                            \
@@ -1318,7 +1321,7 @@ __device__ __forceinline__ void gp_composite_bwd_body(RasterDims d, const int2* 
                     : [a_op] "+v"(a_op), [a_r] "+v"(a_r), [a_g] "+v"(a_g), [a_b] "+v"(a_b), [s_xx] "+v"(s_xx), [r_h] "+v"(r_h), [r_hx] "+v"(r_hx),
                       [any] "+v"(any_m), [sv] "=&s"(sv), [c0] "=&s"(c0), [c1] "=&s"(c1), [t0] "=&s"(t0)
                     : [As2] "v"(As2), [tB2] "v"(tB2), [uC2] "v"(uC2), [op2] "v"(op2), [cr] "v"(cr), [cg] "v"(cg), [cb] "v"(cb), [dx0] "v"(dx0),
-                      [dx1] "v"(dx1), [dx2] "v"(dx2), [dx3] "v"(dx3), [pos] "v"(pos), [vpp] "v"(vpp), [b0] "s"(b0)
+                      [dx1] "v"(dx1), [dx2] "v"(dx2), [dx3] "v"(dx3), [pos] "v"(pos), [vpp] "v"(vpp), [l2e] "v"(l2e), [b0] "s"(b0)
                     : "vcc", "scc", "memory", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77",
                       "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94",
                       "v95", "v96", "v97");
@@ -1334,10 +1337,9 @@ __device__ __forceinline__ void gp_composite_bwd_body(RasterDims d, const int2* 
                 const float4 v0 = s_pp[pr][1], v1 = s_pp[pr][2], cy = s_pp[pr][3];
                 float2 v3 = make_float2(0.f, 0.f);
                 if (HAS_DEPTH) v3 = s_dd[pr];
-                const float dx0 = dxs[cp];
-                const v2f dx = {dx0, dx0 - 1.f};
+                const v2f dx = dxs[cp];
                 const v2f pw = {fmaf(dx.x, fmaf(As, dx.x, tB), uC), fmaf(dx.y, fmaf(As, dx.y, tB), uC)};
-                const v2f G = {__builtin_amdgcn_exp2f(fminf(pw.x, 0.f)), __builtin_amdgcn_exp2f(fminf(pw.y, 0.f))};
+                const v2f G = {__builtin_amdgcn_exp2f(fminf(pw.x * LOG2E, 0.f)), __builtin_amdgcn_exp2f(fminf(pw.y * LOG2E, 0.f))};
                 const v2f alpha = {fminf(0.99f, op * G.x), fminf(0.99f, op * G.y)};
                 const int ncx = nc.x, ncy = nc.y;
                 if (max(ncx, ncy) > b0) {   // uniform: otherwise both pixels finished before this batch
