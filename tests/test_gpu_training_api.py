@@ -271,3 +271,46 @@ def test_two_rank_sharded_adam_equals_replicated_adam(tmp_path, step_opacity):
         torch.testing.assert_close(sh[0]["state"][k]["exp_avg"], rep[0]["state"][k]["exp_avg"], rtol=1e-3, atol=1e-7)
         assert float(sh[0]["state"][k]["step"]) == 3.0
     assert sh[0]["bytes"] == 4 * sh[0]["n"]          # world 2: reduce-scatter + all-gather move half the flat buffer each, per rank
+
+
+def test_stage_transitions_and_teaching_path_inside_forward():
+    """The reference switches stages INSIDE forward [REF scene/gaussian_model.py:246-250]: at second_stage_iter + 1 the keypoints are
+    initialised by k-means and the stage-2 optimizer is built, at third_stage_iter + 1 the stage-3 one; with densify_from_teaching the
+    stage-1 "teacher" motion of every Gaussian is compared with the blended one and proposes new keypoints [REF :274-283, 306-312]."""
+    args = margs(max_points=24, adaptive_points_num=8, densify_from_teaching=True, adaptive_from_iter=3000, adaptive_end_iter=10000,
+                 adaptive_interval=200, teaching_threshold=0.0, knn_type="hybird", feature_amplify=5.0, densify_from_grad="True")
+    raw = make_gaussians(SceneSpec(n_gaussians=4000, extent=(1.3, 1.3, 1.3), scale_lo=0.01, scale_hi=0.08, seed=11), device="cuda")
+    torch.manual_seed(1234)
+    pc = gpa.GaussianModel(3, args)
+    pc.set_inputDim(12, 60)
+    pc.create_from_tensors(raw["xyz"], raw["features_dc"], raw["features_rest"], raw["scaling"], raw["rotation"], raw["opacity"],
+                           raw["motion_feature"] * 50, with_weights_model=True)
+    pc.training_setup(default_training_args())
+    assert [g["name"] for g in pc.optimizer.param_groups][-2:] == ["df_mlp", "motion_feature"] and not pc.second_stage
+    t = torch.tensor([0.4], device="cuda")
+    with torch.no_grad():
+        pc(t, 30000)                                     # still stage 1
+        assert not hasattr(pc, "super_gaussians")
+        out = pc(t, 30001)                               # -> k-means keypoints + training2stage_setup
+    assert pc.second_stage and pc.super_gaussians.shape == (24, 3) and pc.super_gaussians_feature.shape == (24, 32)
+    assert [g["name"] for g in pc.optimizer.param_groups] == ["s_xyz", "s_motion_feature", "weight_mlp", "df_mlp"]
+    assert len(out) == 4 and torch.isfinite(out[0]).all()
+    # every keypoint is the mean position of a non-empty cluster of Gaussians: inside their bounding box
+    lo, hi = raw["xyz"].min(0).values, raw["xyz"].max(0).values
+    assert bool(((pc.super_gaussians.detach() >= lo) & (pc.super_gaussians.detach() <= hi)).all())
+    # teaching window [adaptive_from_iter, adaptive_end_iter) + second_stage_iter: statistics every frame, candidates on the interval
+    with torch.no_grad():
+        pc(t, 33001)
+        assert float(pc.motion_denom.max()) == 1.0 and pc.new_xyz is None
+        pc(t, 33200)                                     # 33200 % 200 == 0, threshold 0: every Gaussian is a candidate
+    assert pc.new_xyz is not None and pc.new_xyz.shape == (8, 3)          # 4000 // 100 = 40, clipped to the 8 free slots
+    from gaussianprediction_amd import densify as dn
+    grown = dn.keypoint_growth_step(pc, 33200, default_training_args(), args)
+    assert grown and pc.super_gaussians.shape == (32, 3) and pc.new_xyz is None
+    assert pc.optimizer.param_groups[0]["params"][0] is pc.super_gaussians
+    with torch.no_grad():
+        out = pc(t, 33201)                               # kNN / weights recomputed for 32 keypoints
+    assert torch.isfinite(out[0]).all()
+    with torch.no_grad():
+        pc(t, 40001)                                     # -> training3stage_setup
+    assert pc.third_stage and [g["name"] for g in pc.optimizer.param_groups][:6] == ["xyz", "f_dc", "f_rest", "opacity", "scaling", "rotation"]
