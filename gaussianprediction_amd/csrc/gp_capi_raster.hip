@@ -135,12 +135,11 @@ extern "C" int gp_raster_forward(const gp_raster_settings* st, const gp_raster_i
                                st->projmatrix, st->campos, out->radii, gl.rec, k0, tiles, gl.clamped);
             GP_LAUNCH_CHECK();
         }
-        hipLaunchKernelGGL(gp_iota_kernel, dim3(gp_blocks(N, 256)), dim3(256), 0, s, v0, d.N);
-        GP_LAUNCH_CHECK();
         GpSortBufs sb;
         sb.k[0] = k0; sb.k[1] = k1; sb.v[0] = v0; sb.v[1] = v1; sb.hist = hist; sb.scan_tmp = scan_tmp; sb.scan_tmp_elems = scan_elems;
         int r1;
-        { GpProfScope _p("depth_sort", s); r1 = gp_radix_sort_pairs(sb, N, 32, s); }
+        // (values = 0 .. N-1, generated by the first pass)
+        { GpProfScope _p("depth_sort", s); r1 = gp_radix_sort_pairs(sb, N, 32, s, true); }
         if (r1 < 0) return 1;
         const uint32_t* sorted_ids = sb.v[r1];
         hipLaunchKernelGGL(gp_gather_tiles_kernel, dim3(gp_blocks(N + 1, 256)), dim3(256), 0, s, sorted_ids, tiles, tt, rects, d.N);
@@ -150,9 +149,7 @@ extern "C" int gp_raster_forward(const gp_raster_settings* st, const gp_raster_i
         if (capacity_mode) {    // no host synchronisation: everything below is sized by the caller's capacity
             if (!st->binning_status) GP_FAIL("binning_capacity needs binning_status (device, 2 words)");
             if (st->binning_capacity > 0x7FFFFF00ll) GP_FAIL("binning_capacity too large");
-            R = (uint32_t)st->binning_capacity;
-            hipLaunchKernelGGL(gp_binning_status_kernel, dim3(1), dim3(1), 0, s, tt + N, R, st->binning_status);
-            GP_LAUNCH_CHECK();
+            R = (uint32_t)st->binning_capacity;          // (the status word and the sentinel keys are written by the duplicate launch)
         } else {
             GP_HIP_CHECK(hipMemcpyAsync(&R, tt + N, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
             GP_HIP_CHECK(hipStreamSynchronize(s));
@@ -191,12 +188,9 @@ extern "C" int gp_raster_forward(const gp_raster_settings* st, const gp_raster_i
             tb.v[res] = point_list; tb.v[res ^ 1] = bvo;
             tb.hist = bhist; tb.scan_tmp = bscan; tb.scan_tmp_elems = bs;
             { GpProfScope _p("duplicate", s);
-            if (capacity_mode) {    // sentinel keys behind the real instances
-                hipLaunchKernelGGL(gp_fill_sentinel_kernel, dim3(gp_blocks(R, 256)), dim3(256), 0, s, tb.k[0], tt + N, R);
-                GP_LAUNCH_CHECK();
-            }
-        hipLaunchKernelGGL(gp_duplicate_kernel, dim3(gp_blocks(N, 256)), dim3(256), 0, s, d, sorted_ids, tt, rects,
-                               tb.k[0], tb.v[0], R);
+            const unsigned ndup = gp_blocks(N, 256);
+            hipLaunchKernelGGL(gp_duplicate_kernel, dim3(ndup + (capacity_mode ? gp_blocks(R, 4096) : 0u)), dim3(256), 0, s, d, sorted_ids, tt,
+                               rects, tb.k[0], tb.v[0], R, st->binning_status, ndup);
             GP_LAUNCH_CHECK(); }
             int r2;
             { GpProfScope _p("tile_sort", s); r2 = gp_radix_sort_pairs(tb, R, tbits, s); }

@@ -27,7 +27,6 @@ __global__ __launch_bounds__(256) void gp_preprocess_fwd_split_kernel(RasterDims
 __global__ __launch_bounds__(256) void gp_mark_visible_kernel(int n, const float* __restrict__ means3D,
                                                              const float* __restrict__ view, uint8_t* __restrict__ present);
 
-__global__ __launch_bounds__(256) void gp_iota_kernel(uint32_t* __restrict__ v, int n);
 
 __global__ __launch_bounds__(256) void gp_gather_tiles_kernel(const uint32_t* __restrict__ sorted_ids,
                                                              const uint2* __restrict__ tiles_touched,
@@ -36,12 +35,11 @@ __global__ __launch_bounds__(256) void gp_gather_tiles_kernel(const uint32_t* __
 __global__ __launch_bounds__(256) void gp_duplicate_kernel(RasterDims d, const uint32_t* __restrict__ sorted_ids,
                                                           const uint32_t* __restrict__ offsets,
                                                           const uint2* __restrict__ rect_sorted,
-                                                          uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, uint32_t capacity);
+                                                          uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, uint32_t capacity,
+                                                          uint32_t* __restrict__ status, uint32_t n_dup_blocks);
 
 __global__ __launch_bounds__(256) void gp_tile_ranges_kernel(const uint32_t* __restrict__ keys, uint32_t R, uint32_t n_tiles,
                                                             int2* __restrict__ ranges);
-__global__ __launch_bounds__(256) void gp_fill_sentinel_kernel(uint32_t* __restrict__ keys, const uint32_t* __restrict__ total,
-                                                              uint32_t capacity);
 __global__ void gp_binning_status_kernel(const uint32_t* __restrict__ total, uint32_t capacity, uint32_t* __restrict__ status);
 
 __global__ __launch_bounds__(1024) void gp_tile_order_kernel(const int2* __restrict__ ranges, const int32_t* __restrict__ work_hint, int T, uint32_t* __restrict__ order);

@@ -333,10 +333,6 @@ __global__ __launch_bounds__(256) void gp_mark_visible_kernel(int n, const float
 // ------------------------------------------------------------------------------------------------
 // binning helpers
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void gp_iota_kernel(uint32_t* __restrict__ v, int n) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < n) v[i] = (uint32_t)i;
-}
 // tiles touched and tile rectangles, in depth order (counts: n+1 entries, last = 0 so the exclusive scan yields the total)
 __global__ __launch_bounds__(256) void gp_gather_tiles_kernel(const uint32_t* __restrict__ sorted_ids,
                                                              const uint2* __restrict__ tiles_touched,
@@ -357,9 +353,20 @@ __global__ __launch_bounds__(256) void gp_gather_tiles_kernel(const uint32_t* __
 __global__ __launch_bounds__(256) void gp_duplicate_kernel(RasterDims d, const uint32_t* __restrict__ sorted_ids,
                                                           const uint32_t* __restrict__ offsets,
                                                           const uint2* __restrict__ rect_sorted,
-                                                          uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, uint32_t capacity) {
+                                                          uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, uint32_t capacity,
+                                                          uint32_t* __restrict__ status, uint32_t n_dup_blocks) {
     __shared__ int4 s_own[4][64];        // (relative offset, first tile x, first tile y, tiles per row)
     __shared__ uint32_t s_id[4][64];
+    if (blockIdx.x >= n_dup_blocks) {
+        // capacity mode, the blocks behind the expansion: status = {R, R > capacity} and sentinel keys behind the R real
+        // instances (their values are never read: no tile range covers them) -- two tiny kernels folded into this launch
+        const uint32_t R = offsets[d.N];
+        if (blockIdx.x == n_dup_blocks && threadIdx.x == 0) { status[0] = R; status[1] = R > capacity ? 1u : 0u; }
+        const uint32_t b0 = (blockIdx.x - n_dup_blocks) * 4096u;
+        for (uint32_t i = b0 + threadIdx.x; i < b0 + 4096u && i < capacity; i += 256u)
+            if (i >= R) keys[i] = 0xFFFFFFFFu;
+        return;
+    }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i0 = blockIdx.x * 256 + wave * 64;             // uniform per wave
     if (i0 >= d.N) return;
@@ -412,13 +419,7 @@ __global__ __launch_bounds__(256) void gp_tile_ranges_kernel(const uint32_t* __r
     if (k == 0 || keys[k - 1] != t) ranges[t].x = (int)k;
     if (k == R - 1 || keys[k + 1] != t) ranges[t].y = (int)(k + 1);
 }
-// capacity mode: sentinel keys behind the R real instances (their values are never read: no tile range covers them)
-__global__ __launch_bounds__(256) void gp_fill_sentinel_kernel(uint32_t* __restrict__ keys, const uint32_t* __restrict__ total,
-                                                              uint32_t capacity) {
-    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    if (i < capacity && i >= total[0]) keys[i] = 0xFFFFFFFFu;
-}
-// capacity mode: status = {R, R > capacity}
+// exact mode with a status word requested: status = {R, 0}  (capacity mode writes it from the duplicate launch)
 __global__ void gp_binning_status_kernel(const uint32_t* __restrict__ total, uint32_t capacity, uint32_t* __restrict__ status) {
     const uint32_t R = total[0];
     status[0] = R;

@@ -171,7 +171,7 @@ __global__ __launch_bounds__(RS_BLOCK) void gp_radix_scatter_kernel(const uint32
         const size_t idx = base + (size_t)it * GP_WAVE + lane;
         const bool valid = idx < n;
         k[it] = valid ? keys_in[idx] : 0xFFFFFFFFu;
-        v[it] = valid ? vals_in[idx] : 0u;
+        v[it] = valid ? (vals_in ? vals_in[idx] : (uint32_t)idx) : 0u;      // vals_in == NULL: the values are the indices (first pass)
         const uint32_t digit = (k[it] >> shift) & mask;
         // peers = lanes of this wave (valid only) holding the same digit
         unsigned long long peers = __ballot(valid);
@@ -256,7 +256,7 @@ __global__ __launch_bounds__(RS_BLOCK) void gp_radix_scatter_kernel(const uint32
 
 // the histogram kernel above partitions by block only (order inside a block is irrelevant for
 // counts), the scatter kernel uses the same block partition [b*4096, (b+1)*4096).
-int gp_radix_sort_pairs(GpSortBufs& b, size_t n, int nbits, hipStream_t s) {
+int gp_radix_sort_pairs(GpSortBufs& b, size_t n, int nbits, hipStream_t s, bool iota_vals) {
     if (n == 0 || nbits <= 0) return 0;
     const int items = rs_items_for(n);
     const size_t tile = (size_t)items * RS_BLOCK;
@@ -265,6 +265,7 @@ int gp_radix_sort_pairs(GpSortBufs& b, size_t n, int nbits, hipStream_t s) {
     for (int shift = 0; shift < nbits; shift += 8) {
         const int bits = (nbits - shift) < 8 ? (nbits - shift) : 8;
         const uint32_t mask = (1u << bits) - 1u;
+        const uint32_t* vin = (shift == 0 && iota_vals) ? nullptr : b.v[cur];
         if (items == RS_ITEMS_SMALL)
             hipLaunchKernelGGL((gp_radix_hist_kernel<RS_ITEMS_SMALL>), dim3(nblocks), dim3(RS_BLOCK), 0, s, b.k[cur], n, shift, mask,
                                b.hist, nblocks);
@@ -275,10 +276,10 @@ int gp_radix_sort_pairs(GpSortBufs& b, size_t n, int nbits, hipStream_t s) {
         if (b.scan_tmp_elems < 256) { snprintf(gp_err_buf, sizeof(gp_err_buf), "radix sort: temp storage too small"); return -1; }
         hipLaunchKernelGGL(gp_radix_rowscan_kernel, dim3(256), dim3(256), 0, s, b.hist, nblocks, b.scan_tmp);
         if (items == RS_ITEMS_SMALL)
-            hipLaunchKernelGGL((gp_radix_scatter_kernel<RS_ITEMS_SMALL>), dim3(nblocks), dim3(RS_BLOCK), 0, s, b.k[cur], b.v[cur],
+            hipLaunchKernelGGL((gp_radix_scatter_kernel<RS_ITEMS_SMALL>), dim3(nblocks), dim3(RS_BLOCK), 0, s, b.k[cur], vin,
                                b.k[cur ^ 1], b.v[cur ^ 1], b.hist, b.scan_tmp, n, shift, mask, nblocks);
         else
-            hipLaunchKernelGGL((gp_radix_scatter_kernel<RS_ITEMS_LARGE>), dim3(nblocks), dim3(RS_BLOCK), 0, s, b.k[cur], b.v[cur],
+            hipLaunchKernelGGL((gp_radix_scatter_kernel<RS_ITEMS_LARGE>), dim3(nblocks), dim3(RS_BLOCK), 0, s, b.k[cur], vin,
                                b.k[cur ^ 1], b.v[cur ^ 1], b.hist, b.scan_tmp, n, shift, mask, nblocks);
         if (hipGetLastError() != hipSuccess) { snprintf(gp_err_buf, sizeof(gp_err_buf), "radix scatter launch failed"); return -1; }
         cur ^= 1;
