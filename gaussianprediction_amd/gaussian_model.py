@@ -190,7 +190,7 @@ class GaussianModel(TrainingMixin, nn.Module):
             if noise and iteration < noise:
                 xyz_in = xyz_in + torch.randn_like(xyz_in) * 0.1 * (1 - min(1, iteration / noise))
             delta = self.df_model.forward_fused(self.motion_feature, xyz_in, t_dev, xyz_freq, time_freq)
-            self._last_delta = delta
+            self._last_delta = delta.detach()        # (side outputs only: holding the graph alive would pin its AccumulateGrad nodes)
             xyz_t, q_t = KeypointBlend.apply(delta, None, None, self._xyz, self._rotation, a.norm_rotation)
         else:                                        # stage 2/3: MLP over K keypoints + sparse blend
             noise = getattr(a, "xyz_noise_iteration", 0)
@@ -205,7 +205,7 @@ class GaussianModel(TrainingMixin, nn.Module):
                 raw_weights = self.weights_model(self.get_xyz.detach())          # [REF :257]
                 knn_idx = self.get_nearest_mask(keepshape=True)                  # [REF :260]
             delta = self.df_model.forward_fused(self.super_gaussians_feature, kp, t_dev, xyz_freq, time_freq)
-            self._last_delta = delta
+            self._last_delta = delta.detach()
             self._last_blend = (raw_weights.detach(), knn_idx, self.super_gaussians.shape[0])
             xyz_t, q_t = KeypointBlend.apply(delta, raw_weights, knn_idx, self._xyz, self._rotation, a.norm_rotation)
             if getattr(a, "densify_from_teaching", False) and self.second_stage:                # [REF :274-283]
