@@ -62,7 +62,7 @@ class Mlp16ParamsC(C.Structure):
                 ("w16", C.c_void_p * 5), ("b", C.c_void_p * 5)]
 
 
-GP_DTYPE_F16, GP_DTYPE_BF16 = 1, 2
+GP_DTYPE_F16, GP_DTYPE_BF16, GP_DTYPE_F16_SPLIT = 1, 2, 3
 
 
 class MlpGradsC(C.Structure):

@@ -12,6 +12,14 @@
 // Saved for backward (training): H_l TRANSPOSED ([256][rows], so the weight-gradient GEMM reads 8
 // consecutive rows per lane as one 16-byte load) and a ReLU sign bitmask (32 B per row per layer).
 // fp16 backward runs the whole dZ chain scaled by a power of two picked on the device from max|dL_dout|.
+//
+// SPLIT mode (GP_DTYPE_F16_SPLIT, precision="fp32s"): fp32-grade results at the 16-bit matrix-core rate.  Every fp32
+// operand x is carried as TWO fp16 numbers, hi = fp16(x) and lo' = fp16((x - hi) * 2^11) (22 significant bits; lo' has
+// hi's magnitude, so neither half lives in the fp16 subnormal range unless |x| < 2^-14, where hi := 0 and lo' carries x),
+// and a product sum becomes three MFMA chains with fp32 accumulation:
+//     sum a b  =  sum ah bh  +  2^-11 (sum ah bl' + sum al' bh)          (the al' bl' term, 2^-22 relative, is dropped)
+// Tiles hold [hi | lo'] side by side (LDS row = 512 halves; saved tensors = 2 nf "features" per row block), the weight
+// arrays are [hi copy][lo' copy].  Positional encoding uses sincosf (as the fp32 kernels), not the hardware sin/cos.
 #include "gp_common.h"
 #include "deform_kernels.h"
 
@@ -64,7 +72,8 @@ __device__ __host__ __forceinline__ size_t t16_elems(int nf, long rows) { return
 #define M16_W 256
 
 // element index of (row, feature) in the swizzled [64][256] tile (16-byte granules XORed by row & 15)
-__device__ __forceinline__ int a16_idx(int row, int f) { return row * M16_W + (f ^ ((row & 15) << 3)); }
+template <int WS = M16_W>
+__device__ __forceinline__ int a16_idx(int row, int f) { return row * WS + (f ^ ((row & 15) << 3)); }
 __device__ __forceinline__ int cd_row16(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
 
 struct Mlp16Dev {
@@ -72,6 +81,7 @@ struct Mlp16Dev {
     int in_dim, in_pad, out_dim;       // in_pad = in_dim rounded up to 16
     int feature_dim, xyz_freq, time_freq;
     const void* w[5];                  // 16-bit copies: [256][in_pad], 3 x [256][256], [32][256] (rows >= out_dim zero)
+    const void* wlo[5];                // split mode: the lo' copies (same shapes), else null
     const float* b[5];                 // fp32 biases
     const float* feature;
     const float* xyz;
@@ -176,12 +186,67 @@ __device__ __forceinline__ void build_input16(T* buf, const Mlp16Dev& p, long ro
         buf[a16_idx(jj, f)] = (T)0.f;
     }
 }
+// ---- split mode helpers --------------------------------------------------------------------------------------------
+#define SP_W 512                 // halves per LDS row: hi at column f, lo' at column 256 + f
+#define SP_LO 2048.f
+#define SP_LO_INV 4.8828125e-4f
+// x -> (hi, lo'): saturated to the fp16 range, hi flushed to zero below the fp16 normal range (lo' then carries x * 2^11)
+__device__ __forceinline__ void split1(float x, _Float16& hi, _Float16& lo) {
+    const float c = __builtin_amdgcn_fmed3f(x, -65504.f, 65504.f);
+    hi = (_Float16)(fabsf(c) < 6.103515625e-05f ? 0.f : c);
+    lo = (_Float16)((c - (float)hi) * SP_LO);
+}
+__device__ __forceinline__ void split4(const float (&v)[4], h4& hi, h4& lo) {
+    float c[4], r[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        c[e] = __builtin_amdgcn_fmed3f(v[e], -65504.f, 65504.f);
+        r[e] = fabsf(c[e]) < 6.103515625e-05f ? 0.f : c[e];
+    }
+    hi = pack4(r[0], r[1], r[2], r[3], _Float16());
+#pragma unroll
+    for (int e = 0; e < 4; ++e) r[e] = (c[e] - (float)hi[e]) * SP_LO;
+    lo = pack4(r[0], r[1], r[2], r[3], _Float16());
+}
+// Layer-0 input tile in split form, [ROWS][SP_W]; the encoding is the fp32 kernels' (sincosf on x * 2^fr)
+template <int ROWS>
+__device__ __forceinline__ void build_input16s(_Float16* buf, const Mlp16Dev& p, long row0, int tid) {
+    const int fd = p.feature_dim, xf = p.xyz_freq, tf = p.time_freq;
+    const float tv = tf > 0 ? p.t[0] : 0.f;
+    auto put = [&](int jj, int f, float v) { split1(v, buf[a16_idx<SP_W>(jj, f)], buf[a16_idx<SP_W>(jj, 256 + f)]); };
+    for (int e = tid; e < fd * ROWS; e += M16_THREADS) {
+        const int jj = e / fd, f = e - jj * fd;
+        const long row = row0 + jj;
+        put(jj, f, row < p.rows ? p.feature[row * fd + f] : 0.f);
+    }
+    for (int e = tid; e < 3 * xf * ROWS; e += M16_THREADS) {
+        const int jj = e % ROWS, cf = e / ROWS;
+        const int c = cf / xf, fr = cf - c * xf;
+        const long row = row0 + jj;
+        float sv = 0.f, cv = 0.f;
+        if (row < p.rows) sincosf(p.xyz[row * 3 + c] * (float)(1u << fr), &sv, &cv);
+        put(jj, fd + 2 * cf, sv);
+        put(jj, fd + 2 * cf + 1, cv);
+    }
+    for (int e = tid; e < tf * ROWS; e += M16_THREADS) {
+        const int jj = e % ROWS, fr = e / ROWS;
+        float sv, cv;
+        sincosf(tv * (float)(1u << fr), &sv, &cv);
+        const bool ok = row0 + jj < p.rows;
+        put(jj, fd + 6 * xf + 2 * fr, ok ? sv : 0.f);
+        put(jj, fd + 6 * xf + 2 * fr + 1, ok ? cv : 0.f);
+    }
+    for (int e = tid; e < (p.in_pad - p.in_dim) * ROWS; e += M16_THREADS) put(e % ROWS, p.in_dim + e / ROWS, 0.f);
+}
+
 // Copy a [ROWS][nf] activation tile (row-major, swizzled, in LDS) to the blocked saved layout [16-row block][nf][16 rows].
 // A lane owns 8 rows x 8 features: eight 16-byte LDS reads (one row each, conflict-free: 32 lanes cover one 512-B row),
 // an 8x8 transpose of 16-bit elements in registers (32 v_perm_b32), eight 16-byte global stores (8 rows of one feature).
 // The element-wise version (one 2-byte LDS read + one 2-byte store per element) was 55 % of the forward kernel.
-template <typename T, int ROWS>
-__device__ __forceinline__ void store_tile_T(const T* buf, T* __restrict__ blk, int nf, long row0, long rows, long rows_pad,
+// `nfs` = features per row block in the destination (= nf, or 2 nf in split mode where `buf` / `blk` are pre-offset to the
+// half being stored); WS = LDS row length.
+template <typename T, int ROWS, int WS = M16_W>
+__device__ __forceinline__ void store_tile_T(const T* buf, T* __restrict__ blk, int nf, int nfs, long row0, long rows, long rows_pad,
                                              int wave, int lane) {
     typedef typename Vec8<T>::type V8;
     typedef uint32_t u4 __attribute__((ext_vector_type(4)));
@@ -193,13 +258,13 @@ __device__ __forceinline__ void store_tile_T(const T* buf, T* __restrict__ blk, 
             const int r0 = sub * T16_BLK + 8 * h8;
             u4 v[8];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) v[i] = __builtin_bit_cast(u4, *(const V8*)&buf[a16_idx(r0 + i, fg * 8)]);
+            for (int i = 0; i < 8; ++i) v[i] = __builtin_bit_cast(u4, *(const V8*)&buf[a16_idx<WS>(r0 + i, fg * 8)]);
             if (row0 + sub * T16_BLK + T16_BLK > rows) {        // zero padding rows (last block only)
 #pragma unroll
                 for (int i = 0; i < 8; ++i)
                     if (row0 + r0 + i >= rows) v[i] = u4{0u, 0u, 0u, 0u};
             }
-            T* o = blk + ((size_t)sub * nf + fg * 8) * T16_BLK + 8 * h8;
+            T* o = blk + ((size_t)sub * nfs + fg * 8) * T16_BLK + 8 * h8;
 #pragma unroll
             for (int c = 0; c < 8; ++c) {                       // feature fg*8 + c: rows r0 .. r0+7
                 u4 t;
@@ -274,35 +339,104 @@ __device__ __forceinline__ void gemm16(const T* cur, const T* __restrict__ W, in
     }
 }
 
+// Split-mode product: am += Xh . Wh^T,  ax += Xh . Wl'^T + Xl' . Wh^T  (result = am + 2^-11 ax).  One pass over K: every
+// fragment (two LDS reads per row tile, four L2 loads) feeds three MFMAs per (row tile, feature tile).
+template <bool SWAPPED, int RT>
+__device__ __forceinline__ void gemm16s(const _Float16* cur, const _Float16* __restrict__ Wh, const _Float16* __restrict__ Wl, int ldk,
+                                        int K, int n_feat, int wave, int lane, f32x16 (&am)[RT][2], f32x16 (&ax)[RT][2]) {
+    const int half = lane >> 5, j = lane & 31;
+    const int f0 = (2 * wave) * 32 + j, f1 = f0 + 32;
+    const size_t o0 = (size_t)f0 * ldk + 8 * half, o1 = (size_t)f1 * ldk + 8 * half;
+    const bool ok0 = f0 < n_feat, ok1 = f1 < n_feat;
+    const int nks = K / 16;
+    h8 zero;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) zero[e] = (_Float16)0.f;
+    const _Float16* arow = cur + j * SP_W;
+    const int swz = ((j & 15) << 3) ^ (8 * half);
+    h8 bn[4];                            // next k-step: Wh tile 0, Wh tile 1, Wl' tile 0, Wl' tile 1
+    bn[0] = (ok0 && nks > 0) ? *(const h8*)(Wh + o0) : zero;
+    bn[1] = (ok1 && nks > 0) ? *(const h8*)(Wh + o1) : zero;
+    bn[2] = (ok0 && nks > 0) ? *(const h8*)(Wl + o0) : zero;
+    bn[3] = (ok1 && nks > 0) ? *(const h8*)(Wl + o1) : zero;
+    for (int ks = 0; ks < nks; ++ks) {
+        h8 bc[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) bc[u] = bn[u];
+        const int kn = ks + 1;
+        bn[0] = (ok0 && kn < nks) ? *(const h8*)(Wh + o0 + kn * 16) : zero;
+        bn[1] = (ok1 && kn < nks) ? *(const h8*)(Wh + o1 + kn * 16) : zero;
+        bn[2] = (ok0 && kn < nks) ? *(const h8*)(Wl + o0 + kn * 16) : zero;
+        bn[3] = (ok1 && kn < nks) ? *(const h8*)(Wl + o1 + kn * 16) : zero;
+        const int col = (ks * 16) ^ swz;
+        h8 ah[RT], al[RT];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            ah[rt] = *(const h8*)(arow + rt * 32 * SP_W + col);
+            al[rt] = *(const h8*)(arow + rt * 32 * SP_W + 256 + col);
+        }
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            if (SWAPPED) {
+                am[rt][0] = mfma16(bc[0], ah[rt], am[rt][0]);
+                am[rt][1] = mfma16(bc[1], ah[rt], am[rt][1]);
+                ax[rt][0] = mfma16(bc[2], ah[rt], ax[rt][0]);
+                ax[rt][1] = mfma16(bc[3], ah[rt], ax[rt][1]);
+            } else {
+                am[rt][0] = mfma16(ah[rt], bc[0], am[rt][0]);
+                am[rt][1] = mfma16(ah[rt], bc[1], am[rt][1]);
+                ax[rt][0] = mfma16(ah[rt], bc[2], ax[rt][0]);
+                ax[rt][1] = mfma16(ah[rt], bc[3], ax[rt][1]);
+            }
+        }
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            if (SWAPPED) {
+                ax[rt][0] = mfma16(bc[0], al[rt], ax[rt][0]);
+                ax[rt][1] = mfma16(bc[1], al[rt], ax[rt][1]);
+            } else {
+                ax[rt][0] = mfma16(al[rt], bc[0], ax[rt][0]);
+                ax[rt][1] = mfma16(al[rt], bc[1], ax[rt][1]);
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------
 // RT = 32-row tiles per wave.  RT = 2: 64 rows per workgroup, double-buffered activations.  RT = 4 (large row counts): 128
 // rows per workgroup, so every weight fragment fetched from L2 feeds four MFMAs instead of two; the activations are
 // updated IN PLACE (one 64 KB tile, two workgroups per CU) behind one extra barrier per layer.
-template <typename T, int RT>
+template <typename T, int RT, bool SP = false>
 __device__ __forceinline__ void mlp16_fwd_body(Mlp16Dev p, float* __restrict__ out, T* __restrict__ saved_xT /*[in_pad][rows]*/,
                                                T* __restrict__ saved_hT /*[4][256][rows]*/,
                                                uint32_t* __restrict__ masks /*[4][rows][8]*/) {
     constexpr int ROWS = 32 * RT;
-    constexpr bool INPLACE = RT > 2;
-    __shared__ T smem[INPLACE ? 1 : 2][ROWS * M16_W];
+    constexpr int WS = SP ? SP_W : M16_W;
+    constexpr int NS = SP ? 2 : 1;                              // saved "features" per real feature
+    constexpr bool INPLACE = RT > 2 || SP;
+    __shared__ T smem[INPLACE ? 1 : 2][ROWS * WS];
     typedef typename Vec8<T>::type V8;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, j = lane & 31;
     const long row0 = (long)blockIdx.x * ROWS;
     const long rows_pad = (p.rows + 63) & ~63L;                 // the saved tensors are allocated (and zero-padded) to 64 rows
     T* cur = smem[0];
     T* nxt = smem[INPLACE ? 0 : 1];
-    build_input16<T, ROWS>(cur, p, row0, tid);
+    if constexpr (SP) build_input16s<ROWS>(cur, p, row0, tid);
+    else build_input16<T, ROWS>(cur, p, row0, tid);
     __syncthreads();
-    auto store_T = [&](const T* buf, T* dst, int nf) {      // this workgroup's block: nf x ROWS contiguous elements
-        store_tile_T<T, ROWS>(buf, dst + (size_t)blockIdx.x * nf * ROWS, nf, row0, p.rows, rows_pad, wave, lane);
+    auto store_T = [&](const T* buf, T* dst, int nf) {      // this workgroup's block: NS x nf x ROWS contiguous elements
+        T* blk = dst + (size_t)blockIdx.x * NS * nf * ROWS;
+        store_tile_T<T, ROWS, WS>(buf, blk, nf, NS * nf, row0, p.rows, rows_pad, wave, lane);
+        if constexpr (SP) store_tile_T<T, ROWS, WS>(buf + 256, blk + (size_t)nf * T16_BLK, nf, NS * nf, row0, p.rows, rows_pad, wave, lane);
     };
     if (saved_xT) store_T(cur, saved_xT, p.in_pad);
     typedef typename Vec4<T>::type V4;
     for (int l = 0; l < 4; ++l) {
         const int K = l == 0 ? p.in_pad : M16_W;
         f32x16 acc[RT][2];
+        f32x16 ax[SP ? RT : 1][2];
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
@@ -313,7 +447,17 @@ __device__ __forceinline__ void mlp16_fwd_body(Mlp16Dev p, float* __restrict__ o
                     acc[rt][nt][4 * g + 0] = bv.x; acc[rt][nt][4 * g + 1] = bv.y; acc[rt][nt][4 * g + 2] = bv.z; acc[rt][nt][4 * g + 3] = bv.w;
                 }
             }
-        gemm16<T, true, RT>(cur, (const T*)p.w[l], K, K, M16_W, wave, lane, acc);
+        if constexpr (SP) {
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) ax[rt][nt][r] = 0.f;
+            gemm16s<true, RT>(cur, (const _Float16*)p.w[l], (const _Float16*)p.wlo[l], K, K, M16_W, wave, lane, acc, ax);
+        } else {
+            gemm16<T, true, RT>(cur, (const T*)p.w[l], K, K, M16_W, wave, lane, acc);
+        }
         if (INPLACE) __syncthreads();       // every wave has read the layer's input before anyone overwrites it
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
@@ -328,10 +472,19 @@ __device__ __forceinline__ void mlp16_fwd_body(Mlp16Dev p, float* __restrict__ o
                     float v[4];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        v[e] = fmaxf(acc[rt][nt][4 * g + e], 0.f);
+                        float z = acc[rt][nt][4 * g + e];
+                        if constexpr (SP) z = fmaf(ax[rt][nt][4 * g + e], SP_LO_INV, z);
+                        v[e] = fmaxf(z, 0.f);
                         mbits |= (v[e] > 0.f ? 1u : 0u) << (8 * g + 4 * half + e);
                     }
-                    *(V4*)&nxt[a16_idx(row, f0)] = pack4(v[0], v[1], v[2], v[3], T());   // four consecutive features: one 8-byte store
+                    if constexpr (SP) {
+                        h4 hi, lo;
+                        split4(v, hi, lo);
+                        *(h4*)&nxt[a16_idx<WS>(row, f0)] = hi;
+                        *(h4*)&nxt[a16_idx<WS>(row, 256 + f0)] = lo;
+                    } else {
+                        *(V4*)&nxt[a16_idx(row, f0)] = pack4(v[0], v[1], v[2], v[3], T());   // four consecutive features: one 8-byte store
+                    }
                 }
                 if (masks) {   // sign bits of this (row, 32-feature tile): the two halves hold complementary bits
                     const uint32_t full = mbits | (uint32_t)__shfl_xor((int)mbits, 32);
@@ -340,22 +493,36 @@ __device__ __forceinline__ void mlp16_fwd_body(Mlp16Dev p, float* __restrict__ o
             }
         }
         __syncthreads();
-        if (saved_hT) store_T(nxt, saved_hT + (size_t)l * t16_elems(M16_W, p.rows), M16_W);
+        if (saved_hT) store_T(nxt, saved_hT + (size_t)l * t16_elems(NS * M16_W, p.rows), M16_W);
         T* t = cur; cur = nxt; nxt = t;
     }
     {   // output layer: W4 padded to [32][256]; the 4 waves split K, reduce through LDS (fp32)
         f32x16 acc[RT];
+        f32x16 ax[SP ? RT : 1];
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[rt][r] = 0.f;
+            for (int r = 0; r < 16; ++r) { acc[rt][r] = 0.f; if (SP) ax[rt][r] = 0.f; }
         const T* w4 = (const T*)p.w[4] + (size_t)j * M16_W + 8 * half;
+        const T* w4l = SP ? (const T*)p.wlo[4] + (size_t)j * M16_W + 8 * half : nullptr;
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int ks = 4 * wave + u;
             const V8 b = *(const V8*)(w4 + ks * 16);
+            if constexpr (SP) {
+                const V8 bl = *(const V8*)(w4l + ks * 16);
 #pragma unroll
-            for (int rt = 0; rt < RT; ++rt) acc[rt] = mfma16(*(const V8*)(cur + a16_idx(32 * rt + j, ks * 16 + 8 * half)), b, acc[rt]);
+                for (int rt = 0; rt < RT; ++rt) {
+                    const V8 ah = *(const V8*)(cur + a16_idx<WS>(32 * rt + j, ks * 16 + 8 * half));
+                    const V8 al = *(const V8*)(cur + a16_idx<WS>(32 * rt + j, 256 + ks * 16 + 8 * half));
+                    acc[rt] = mfma16(ah, b, acc[rt]);
+                    ax[rt] = mfma16(ah, bl, ax[rt]);
+                    ax[rt] = mfma16(al, b, ax[rt]);
+                }
+            } else {
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) acc[rt] = mfma16(*(const V8*)(cur + a16_idx(32 * rt + j, ks * 16 + 8 * half)), b, acc[rt]);
+            }
         }
         if (INPLACE) __syncthreads();
         float* red = (float*)nxt;   // [4 waves][ROWS][8]
@@ -363,7 +530,11 @@ __device__ __forceinline__ void mlp16_fwd_body(Mlp16Dev p, float* __restrict__ o
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) red[(wave * ROWS + rt * 32 + cd_row16(r, half)) * 8 + j] = acc[rt][r];
+                for (int r = 0; r < 16; ++r) {
+                    float v = acc[rt][r];
+                    if constexpr (SP) v = fmaf(ax[rt][r], SP_LO_INV, v);
+                    red[(wave * ROWS + rt * 32 + cd_row16(r, half)) * 8 + j] = v;
+                }
         }
         __syncthreads();
         for (int e = tid; e < ROWS * 8; e += M16_THREADS) {
@@ -384,6 +555,9 @@ __global__ __launch_bounds__(M16_THREADS) void gp_mlp16_fwd_f16_kernel(Mlp16Dev 
 __global__ __launch_bounds__(M16_THREADS) void gp_mlp16_fwd_bf16_kernel(Mlp16Dev p, float* out, void* sx, void* sh, uint32_t* masks) {
     mlp16_fwd_body<__bf16, 2>(p, out, (__bf16*)sx, (__bf16*)sh, masks);
 }
+__global__ __launch_bounds__(M16_THREADS, 2) void gp_mlp16_fwd_split_kernel(Mlp16Dev p, float* out, void* sx, void* sh, uint32_t* masks) {
+    mlp16_fwd_body<_Float16, 2, true>(p, out, (_Float16*)sx, (_Float16*)sh, masks);
+}
 __global__ __launch_bounds__(M16_THREADS, 2) void gp_mlp16_fwd4_f16_kernel(Mlp16Dev p, float* out, void* sx, void* sh, uint32_t* masks) {
     mlp16_fwd_body<_Float16, 4>(p, out, (_Float16*)sx, (_Float16*)sh, masks);
 }
@@ -396,14 +570,16 @@ __global__ __launch_bounds__(M16_THREADS, 2) void gp_mlp16_fwd4_bf16_kernel(Mlp1
 // wt[1..3]: [256][256] (= W_l^T), wt[0]: [in_pad][256] (= W_0^T, rows >= in_dim zero).
 // Writes dZ_l TRANSPOSED ([4][256][rows], scaled) for the weight-gradient GEMM.
 // ------------------------------------------------------------------------------------------------
-template <typename T, int RT>
+template <typename T, int RT, bool SP = false>
 __device__ __forceinline__ void mlp16_bwd_data_body(Mlp16Dev p, const uint32_t* __restrict__ masks,
                                                     const float* __restrict__ dL_dout, T* __restrict__ dzT,
                                                     float* __restrict__ dfeature, float* __restrict__ dxyz,
                                                     const uint32_t* __restrict__ absmax_bits) {
     constexpr int ROWS = 32 * RT;
-    constexpr bool INPLACE = RT > 2;
-    __shared__ T smem[INPLACE ? 1 : 2][ROWS * M16_W];
+    constexpr int WS = SP ? SP_W : M16_W;
+    constexpr int NS = SP ? 2 : 1;
+    constexpr bool INPLACE = RT > 2 || SP;
+    __shared__ T smem[INPLACE ? 1 : 2][ROWS * WS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, j = lane & 31;
     const long row0 = (long)blockIdx.x * ROWS;
     const long rows_pad = (p.rows + 63) & ~63L;
@@ -413,20 +589,24 @@ __device__ __forceinline__ void mlp16_bwd_data_body(Mlp16Dev p, const uint32_t* 
     for (int e = tid; e < 16 * ROWS; e += M16_THREADS) {
         const int r = e / 16, f = e % 16;
         const long row = row0 + r;
-        cur[a16_idx(r, f)] = (T)((f < p.out_dim && row < p.rows) ? dL_dout[row * p.out_dim + f] * S : 0.f);
+        const float v = (f < p.out_dim && row < p.rows) ? dL_dout[row * p.out_dim + f] * S : 0.f;
+        if constexpr (SP) split1(v, cur[a16_idx<WS>(r, f)], cur[a16_idx<WS>(r, 256 + f)]);
+        else cur[a16_idx(r, f)] = (T)v;
     }
     __syncthreads();
     typedef typename Vec4<T>::type V4;
     for (int l = 4; l >= 1; --l) {
         const int K = l == 4 ? 16 : M16_W;
         f32x16 acc[RT][2];
+        f32x16 ax[SP ? RT : 1][2];
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[rt][nt][r] = 0.f;
-        gemm16<T, true, RT>(cur, (const T*)p.w[l], K, K, M16_W, wave, lane, acc);
+                for (int r = 0; r < 16; ++r) { acc[rt][nt][r] = 0.f; if (SP) ax[rt][nt][r] = 0.f; }
+        if constexpr (SP) gemm16s<true, RT>(cur, (const _Float16*)p.w[l], (const _Float16*)p.wlo[l], K, K, M16_W, wave, lane, acc, ax);
+        else gemm16<T, true, RT>(cur, (const T*)p.w[l], K, K, M16_W, wave, lane, acc);
         if (INPLACE) __syncthreads();
         const uint32_t* mk = masks + (size_t)(l - 1) * p.rows * 8;
 #pragma unroll
@@ -441,29 +621,44 @@ __device__ __forceinline__ void mlp16_bwd_data_body(Mlp16Dev p, const uint32_t* 
                     const int f0 = (2 * wave + nt) * 32 + 8 * g + 4 * half;
                     float v[4];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e)     // sign-extended mask bit (v_bfe_i32) AND value bits: two instructions per value
-                        v[e] = __uint_as_float(__float_as_uint(acc[rt][nt][4 * g + e]) & (uint32_t)__builtin_amdgcn_sbfe((int)m, 8 * g + 4 * half + e, 1));
-                    *(V4*)&nxt[a16_idx(row, f0)] = pack4(v[0], v[1], v[2], v[3], T());
+                    for (int e = 0; e < 4; ++e) {   // sign-extended mask bit (v_bfe_i32) AND value bits: two instructions per value
+                        float z = acc[rt][nt][4 * g + e];
+                        if constexpr (SP) z = fmaf(ax[rt][nt][4 * g + e], SP_LO_INV, z);
+                        v[e] = __uint_as_float(__float_as_uint(z) & (uint32_t)__builtin_amdgcn_sbfe((int)m, 8 * g + 4 * half + e, 1));
+                    }
+                    if constexpr (SP) {
+                        h4 hi, lo;
+                        split4(v, hi, lo);
+                        *(h4*)&nxt[a16_idx<WS>(row, f0)] = hi;
+                        *(h4*)&nxt[a16_idx<WS>(row, 256 + f0)] = lo;
+                    } else {
+                        *(V4*)&nxt[a16_idx(row, f0)] = pack4(v[0], v[1], v[2], v[3], T());
+                    }
                 }
             }
         }
         __syncthreads();
         {   // dZ_l^T -> global, blocked
-            T* blk = dzT + (size_t)(l - 1) * t16_elems(M16_W, p.rows) + (size_t)blockIdx.x * M16_W * ROWS;
-            store_tile_T<T, ROWS>(nxt, blk, M16_W, row0, p.rows, rows_pad, wave, lane);
+            T* blk = dzT + (size_t)(l - 1) * t16_elems(NS * M16_W, p.rows) + (size_t)blockIdx.x * NS * M16_W * ROWS;
+            store_tile_T<T, ROWS, WS>(nxt, blk, M16_W, NS * M16_W, row0, p.rows, rows_pad, wave, lane);
+            if constexpr (SP) store_tile_T<T, ROWS, WS>(nxt + 256, blk + (size_t)M16_W * T16_BLK, M16_W, NS * M16_W, row0, p.rows, rows_pad, wave, lane);
         }
         T* t = cur; cur = nxt; nxt = t;
     }
     if (dfeature || dxyz) {
         // dX[64][in_pad] = dZ_1 . W_0 ; feature tiles beyond in_pad are skipped; result kept in fp32 in LDS
         f32x16 acc[RT][2];
+        f32x16 ax[SP ? RT : 1][2];
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[rt][nt][r] = 0.f;
-        if (wave * 64 < p.in_pad) gemm16<T, false, RT>(cur, (const T*)p.w[0], M16_W, M16_W, p.in_pad, wave, lane, acc);
+                for (int r = 0; r < 16; ++r) { acc[rt][nt][r] = 0.f; if (SP) ax[rt][nt][r] = 0.f; }
+        if (wave * 64 < p.in_pad) {
+            if constexpr (SP) gemm16s<false, RT>(cur, (const _Float16*)p.w[0], (const _Float16*)p.wlo[0], M16_W, M16_W, p.in_pad, wave, lane, acc, ax);
+            else gemm16<T, false, RT>(cur, (const T*)p.w[0], M16_W, M16_W, p.in_pad, wave, lane, acc);
+        }
         if (INPLACE) __syncthreads();
         float* dX = (float*)nxt;   // [ROWS][128] fp32
         const float inv = 1.f / S;
@@ -474,7 +669,11 @@ __device__ __forceinline__ void mlp16_bwd_data_body(Mlp16Dev p, const uint32_t* 
                 const int f = (2 * wave + nt) * 32 + j;
                 if (f < 128) {
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) dX[(rt * 32 + cd_row16(r, half)) * 128 + f] = acc[rt][nt][r] * inv;
+                    for (int r = 0; r < 16; ++r) {
+                        float v = acc[rt][nt][r];
+                        if constexpr (SP) v = fmaf(ax[rt][nt][r], SP_LO_INV, v);
+                        dX[(rt * 32 + cd_row16(r, half)) * 128 + f] = v * inv;
+                    }
                 }
             }
         __syncthreads();
@@ -494,7 +693,8 @@ __device__ __forceinline__ void mlp16_bwd_data_body(Mlp16Dev p, const uint32_t* 
                 for (int fr = 0; fr < p.xyz_freq; ++fr) {
                     const float sc = (float)(1u << fr);
                     float sv, cv;
-                    fast_sincos(x * sc, &sv, &cv);      // the same hardware sin/cos the forward encoded with
+                    if constexpr (SP) sincosf(x * sc, &sv, &cv);
+                    else fast_sincos(x * sc, &sv, &cv);      // the same hardware sin/cos the forward encoded with
                     const int f = p.feature_dim + 2 * (c * p.xyz_freq + fr);
                     g += sc * (cv * dX[r * 128 + f] - sv * dX[r * 128 + f + 1]);
                 }
@@ -510,6 +710,10 @@ __global__ __launch_bounds__(M16_THREADS) void gp_mlp16_bwd_data_f16_kernel(Mlp1
 __global__ __launch_bounds__(M16_THREADS) void gp_mlp16_bwd_data_bf16_kernel(Mlp16Dev p, const uint32_t* masks, const float* dL_dout,
                                                                               void* dzT, float* dfeature, float* dxyz, const uint32_t* absmax_bits) {
     mlp16_bwd_data_body<__bf16, 2>(p, masks, dL_dout, (__bf16*)dzT, dfeature, dxyz, absmax_bits);
+}
+__global__ __launch_bounds__(M16_THREADS, 2) void gp_mlp16_bwd_data_split_kernel(Mlp16Dev p, const uint32_t* masks, const float* dL_dout,
+                                                                                  void* dzT, float* dfeature, float* dxyz, const uint32_t* absmax_bits) {
+    mlp16_bwd_data_body<_Float16, 2, true>(p, masks, dL_dout, (_Float16*)dzT, dfeature, dxyz, absmax_bits);
 }
 __global__ __launch_bounds__(M16_THREADS, 2) void gp_mlp16_bwd_data4_f16_kernel(Mlp16Dev p, const uint32_t* masks, const float* dL_dout,
                                                                                  void* dzT, float* dfeature, float* dxyz, const uint32_t* absmax_bits) {
@@ -529,9 +733,10 @@ __global__ __launch_bounds__(M16_THREADS, 2) void gp_mlp16_bwd_data4_bf16_kernel
 template <typename T>
 __device__ __forceinline__ void mlp16_bwd_weight_body(const T* __restrict__ dzT, int n_out, const T* __restrict__ hT, int n_in,
                                                       int nf_z, int nf_h, long rows, long rows_per_block, float* __restrict__ dW, int lddw,
-                                                      float* __restrict__ db, const uint32_t* __restrict__ absmax_bits) {
+                                                      float* __restrict__ db, const uint32_t* __restrict__ absmax_bits, float mul) {
+    // nf_z / nf_h are the blocked layouts' features per row block (strides); split mode passes 2 nf with pre-offset pointers
     typedef typename Vec8<T>::type V8;
-    const float inv_scale = UsesScale<T>::v ? 1.f / grad_scale_from(absmax_bits) : 1.f;
+    const float inv_scale = (UsesScale<T>::v ? 1.f / grad_scale_from(absmax_bits) : 1.f) * mul;
     __shared__ float s_red[4][4][16][64];   // 64 KB
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, j = lane & 31;
     // grid = (tile pairs, row blocks): the 16 workgroups that share one slab of rows are dispatched back to back, so
@@ -625,12 +830,12 @@ __device__ __forceinline__ void mlp16_bwd_weight_body(const T* __restrict__ dzT,
     }
 }
 __global__ __launch_bounds__(M16_THREADS) void gp_mlp16_bwd_weight_f16_kernel(const void* dzT, int n_out, const void* hT, int n_in, int nf_z, int nf_h, long rows,
-                                                                               long rpb, float* dW, int lddw, float* db, const uint32_t* absmax_bits) {
-    mlp16_bwd_weight_body<_Float16>((const _Float16*)dzT, n_out, (const _Float16*)hT, n_in, nf_z, nf_h, rows, rpb, dW, lddw, db, absmax_bits);
+                                                                               long rpb, float* dW, int lddw, float* db, const uint32_t* absmax_bits, float mul) {
+    mlp16_bwd_weight_body<_Float16>((const _Float16*)dzT, n_out, (const _Float16*)hT, n_in, nf_z, nf_h, rows, rpb, dW, lddw, db, absmax_bits, mul);
 }
 __global__ __launch_bounds__(M16_THREADS) void gp_mlp16_bwd_weight_bf16_kernel(const void* dzT, int n_out, const void* hT, int n_in, int nf_z, int nf_h, long rows,
-                                                                                long rpb, float* dW, int lddw, float* db, const uint32_t* absmax_bits) {
-    mlp16_bwd_weight_body<__bf16>((const __bf16*)dzT, n_out, (const __bf16*)hT, n_in, nf_z, nf_h, rows, rpb, dW, lddw, db, absmax_bits);
+                                                                                long rpb, float* dW, int lddw, float* db, const uint32_t* absmax_bits, float mul) {
+    mlp16_bwd_weight_body<__bf16>((const __bf16*)dzT, n_out, (const __bf16*)hT, n_in, nf_z, nf_h, rows, rpb, dW, lddw, db, absmax_bits, mul);
 }
 
 // The three 256x256 layers at large row counts: ONE workgroup owns the whole 256x256 gradient of (layer, row slab), so
@@ -646,9 +851,11 @@ __global__ __launch_bounds__(M16_THREADS) void gp_mlp16_bwd_weight_bf16_kernel(c
 //   layer 4     (out_dim <= 16 x 256, dZ = the packed dL_dout): <1, 1, 8>
 // Fragments beyond a tensor's feature count are loaded from a clamped address and zeroed, so every wave issues exactly
 // two loads per k-step whatever the shape.
-struct W16Job { const void* z; const void* h; float* dw; float* db; };
-struct W16Jobs { W16Job j[3]; };
-struct W16Shape { int nf_z, nf_h, n_out, n_in, lddw; };
+struct W16Job { const void* z; const void* h; float* dw; float* db; float mul; };   // dw += mul * dZ^T H (db may be null)
+struct W16Jobs { W16Job j[9]; };
+// nf_* = features a job reads, ks_* = features per row block of the tensor (= nf, or 2 nf in split mode with pre-offset
+// pointers); shared = several jobs of one launch add into the same dw
+struct W16Shape { int nf_z, nf_h, n_out, n_in, lddw, ks_z, ks_h, shared; };
 #define W16_THREADS 512
 #define W16_DEPTH 4
 #define W16_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
@@ -702,15 +909,15 @@ __device__ __forceinline__ void mlp16_bwd_weight_lds_body(W16Jobs jobs, W16Shape
     typedef typename Vec8<T>::type V8;
     static_assert((8 / WI) * OT <= 8 && WI * IT <= 8, "eight fragment slots per operand");
     __shared__ T s_st[2][2][8][512];                           // [buffer][dZ | H][fragment of 32 features][16 rows x 32] = 32 KB
-    const float inv_scale = UsesScale<T>::v ? 1.f / grad_scale_from(absmax_bits) : 1.f;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, j = lane & 31;
     const int wo = wave / WI, wi = wave % WI;
     const W16Job job = jobs.j[blockIdx.y];
+    const float inv_scale = (UsesScale<T>::v ? 1.f / grad_scale_from(absmax_bits) : 1.f) * job.mul;
     const long kb0 = (long)blockIdx.x * kb_per_slab;
     long kb1 = kb0 + kb_per_slab;
     if (kb1 > n_kb) kb1 = n_kb;
     const long nk = kb1 - kb0;
-    const size_t kstride_z = (size_t)sh.nf_z * T16_BLK, kstride_h = (size_t)sh.nf_h * T16_BLK;   // elements per 16-row block
+    const size_t kstride_z = (size_t)sh.ks_z * T16_BLK, kstride_h = (size_t)sh.ks_h * T16_BLK;   // elements per 16-row block
     // this wave's share of a k-step: fragment `wave` of dZ and of H in lane-linear 16-byte chunks (chunk = feature, 8 rows)
     const int nfr_z = (sh.nf_z + 31) / 32, nfr_h = (sh.nf_h + 31) / 32;
     const int fz = wave < nfr_z ? wave : nfr_z - 1, fh = wave < nfr_h ? wave : nfr_h - 1;
@@ -736,7 +943,7 @@ __device__ __forceinline__ void mlp16_bwd_weight_lds_body(W16Jobs jobs, W16Shape
     if (nk > 0) w16_group<T, V8, OT, IT, WI>(gq, acc, bsum, s_st, gz, gh, okz, okh, 0, nk, kstride_z, kstride_h, wave, lane, wo, wi, frag_off);
     for (long k0 = W16_DEPTH; k0 < nk; k0 += W16_DEPTH)
         w16_group<T, V8, OT, IT, WI>(gq, acc, bsum, s_st, gz, gh, okz, okh, k0, nk, kstride_z, kstride_h, wave, lane, wo, wi, frag_off);
-    const bool single = gridDim.x == 1;
+    const bool single = gridDim.x == 1 && !sh.shared;
 #pragma unroll
     for (int uo = 0; uo < OT; ++uo)
 #pragma unroll
@@ -759,7 +966,7 @@ __device__ __forceinline__ void mlp16_bwd_weight_lds_body(W16Jobs jobs, W16Shape
         for (int u = 0; u < OT; ++u) {
             const float v = (bsum[u] + __shfl_xor(bsum[u], 32)) * inv_scale;
             const int o = (wo * OT + u) * 32 + j;
-            if (half == 0 && o < sh.n_out) { float* dst = &job.db[o]; if (single) *dst += v; else atomicAdd(dst, v); }
+            if (half == 0 && o < sh.n_out && job.db) { float* dst = &job.db[o]; if (single) *dst += v; else atomicAdd(dst, v); }
         }
     }
 }
@@ -780,12 +987,24 @@ __global__ __launch_bounds__(256) void gp_mlp16_pack_dout_kernel(const float* __
     for (int f = 0; f < 16; ++f) dst[t16_idx(f, i, 16)] = (T)((f < out_dim && i < rows) ? dL_dout[i * out_dim + f] * scale : 0.f);
 }
 
+// split mode: [16 hi | 16 lo'] "features"
+__global__ __launch_bounds__(256) void gp_mlp16_pack_dout_split_kernel(const float* __restrict__ dL_dout, int out_dim, long rows,
+                                                                      _Float16* __restrict__ dst, const uint32_t* __restrict__ absmax_bits) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= ((rows + 63) & ~63L)) return;
+    const float scale = grad_scale_from(absmax_bits);
+#pragma unroll
+    for (int f = 0; f < 16; ++f)
+        split1((f < out_dim && i < rows) ? dL_dout[i * out_dim + f] * scale : 0.f, dst[t16_idx(f, i, 32)], dst[t16_idx(16 + f, i, 32)]);
+}
+
 // ------------------------------------------------------------------------------------------------
 // C ABI
 // ------------------------------------------------------------------------------------------------
-static int make16(const gp_mlp16_params* p, const gp_mlp_input* x, Mlp16Dev& m) {
+static int make16(const gp_mlp16_params* p, const gp_mlp_input* x, Mlp16Dev& m, bool transposed) {
     if (!p || !x) GP_FAIL("null mlp16 params/input");
-    if (p->dtype != GP_DTYPE_F16 && p->dtype != GP_DTYPE_BF16) GP_FAIL("mlp16: dtype must be GP_DTYPE_F16 or GP_DTYPE_BF16");
+    if (p->dtype != GP_DTYPE_F16 && p->dtype != GP_DTYPE_BF16 && p->dtype != GP_DTYPE_F16_SPLIT)
+        GP_FAIL("mlp16: dtype must be GP_DTYPE_F16, GP_DTYPE_BF16 or GP_DTYPE_F16_SPLIT");
     if (p->width != 256 || p->depth != 4) GP_FAIL("Deformable_Field: only d=4, w=256 is implemented");
     if (p->out_dim < 7 || p->out_dim > 8) GP_FAIL("out_dim must be 7 or 8");
     const int in_dim = x->feature_dim + 6 * x->xyz_freq + 2 * x->time_freq;
@@ -796,7 +1015,12 @@ static int make16(const gp_mlp16_params* p, const gp_mlp_input* x, Mlp16Dev& m) 
     if (x->rows > 0 && (!x->feature || (x->xyz_freq > 0 && !x->xyz) || (x->time_freq > 0 && !x->t))) GP_FAIL("null input pointer");
     m.rows = x->rows; m.in_dim = in_dim; m.in_pad = (in_dim + 15) / 16 * 16; m.out_dim = p->out_dim;
     m.feature_dim = x->feature_dim; m.xyz_freq = x->xyz_freq; m.time_freq = x->time_freq;
-    for (int l = 0; l < 5; ++l) { m.w[l] = p->w16[l]; m.b[l] = p->b[l]; }
+    for (int l = 0; l < 5; ++l) {
+        m.w[l] = p->w16[l]; m.b[l] = p->b[l];
+        // split mode: each array is [hi copy][lo' copy]
+        const size_t elems = l == 0 ? (size_t)256 * m.in_pad : l < 4 ? (size_t)65536 : (transposed ? (size_t)256 * 16 : (size_t)32 * 256);
+        m.wlo[l] = p->dtype == GP_DTYPE_F16_SPLIT ? (const void*)((const _Float16*)p->w16[l] + elems) : nullptr;
+    }
     m.feature = x->feature; m.xyz = x->xyz; m.t = x->t;
     return 0;
 }
@@ -804,12 +1028,14 @@ static int make16(const gp_mlp16_params* p, const gp_mlp_input* x, Mlp16Dev& m) 
 extern "C" int gp_mlp16_forward(const gp_mlp16_params* p, const gp_mlp_input* x, float* out, void* saved_xT, void* saved_hT,
                                 uint32_t* masks, gp_stream_t stream_) {
     Mlp16Dev m;
-    if (make16(p, x, m)) return 1;
+    if (make16(p, x, m, false)) return 1;
     if (m.rows == 0) return 0;
     if (!out) GP_FAIL("null output");
     hipStream_t s = (hipStream_t)stream_;
     GpProfScope _p("mlp16_fwd", s);
-    if (m.rows >= GP_MLP16_BIG_ROWS) {        // 128 rows per workgroup
+    if (p->dtype == GP_DTYPE_F16_SPLIT) {
+        hipLaunchKernelGGL(gp_mlp16_fwd_split_kernel, dim3(gp_blocks((size_t)m.rows, M16_ROWS)), dim3(M16_THREADS), 0, s, m, out, saved_xT, saved_hT, masks);
+    } else if (m.rows >= GP_MLP16_BIG_ROWS) {        // 128 rows per workgroup
         const dim3 grid(gp_blocks((size_t)m.rows, 128));
         if (p->dtype == GP_DTYPE_F16) hipLaunchKernelGGL(gp_mlp16_fwd4_f16_kernel, grid, dim3(M16_THREADS), 0, s, m, out, saved_xT, saved_hT, masks);
         else hipLaunchKernelGGL(gp_mlp16_fwd4_bf16_kernel, grid, dim3(M16_THREADS), 0, s, m, out, saved_xT, saved_hT, masks);
@@ -827,16 +1053,18 @@ extern "C" int gp_mlp16_backward(const gp_mlp16_params* p /* w16 = TRANSPOSED co
                                  float* dL_dfeature, float* dL_dxyz, gp_alloc_fn alloc, void* alloc_ctx, gp_stream_t stream_) {
     hipStream_t s = (hipStream_t)stream_;
     Mlp16Dev m;
-    if (make16(p, x, m)) return 1;
+    if (make16(p, x, m, true)) return 1;
     if (m.rows == 0) return 0;
     if (!saved_xT || !saved_hT || !masks || !dL_dout || !g || !alloc) GP_FAIL("null argument");
     for (int l = 0; l < 5; ++l)
         if (!g->dw[l] || !g->db[l]) GP_FAIL("null weight-grad pointer (layer %d)", l);
-    const bool f16 = p->dtype == GP_DTYPE_F16;
-    const size_t dz_elems = 4 * t16_elems(256, m.rows) + t16_elems(16, m.rows);
+    const bool split = p->dtype == GP_DTYPE_F16_SPLIT;
+    const bool f16 = p->dtype == GP_DTYPE_F16 || split;
+    const int NS = split ? 2 : 1;
+    const size_t dz_elems = 4 * t16_elems(NS * 256, m.rows) + t16_elems(NS * 16, m.rows);
     char* dz = (char*)alloc(alloc_ctx, GP_BUF_TEMP, gp_align_up(dz_elems * 2, 256) + 256);
     if (!dz) GP_FAIL("allocator returned NULL for TEMP");
-    char* dout16 = dz + 4 * t16_elems(256, m.rows) * 2;
+    char* dout16 = dz + 4 * t16_elems(NS * 256, m.rows) * 2;
     uint32_t* absmax = (uint32_t*)(dz + gp_align_up(dz_elems * 2, 256));
     GP_HIP_CHECK(hipMemsetAsync(absmax, 0, 4, s));
     if (f16) {
@@ -847,7 +1075,10 @@ extern "C" int gp_mlp16_backward(const gp_mlp16_params* p /* w16 = TRANSPOSED co
         GpProfScope _p("mlp16_bwd_data", s);
         const bool big_rows = m.rows >= GP_MLP16_BIG_ROWS;
         const dim3 grid(gp_blocks((size_t)m.rows, big_rows ? 128 : M16_ROWS));
-        if (f16) {
+        if (split) {
+            hipLaunchKernelGGL(gp_mlp16_bwd_data_split_kernel, dim3(gp_blocks((size_t)m.rows, M16_ROWS)), dim3(M16_THREADS), 0, s, m, masks, dL_dout, (void*)dz, dL_dfeature, dL_dxyz, absmax);
+            hipLaunchKernelGGL(gp_mlp16_pack_dout_split_kernel, dim3(gp_blocks((size_t)((m.rows + 63) & ~63L), 256)), dim3(256), 0, s, dL_dout, m.out_dim, m.rows, (_Float16*)dout16, absmax);
+        } else if (f16) {
             hipLaunchKernelGGL(big_rows ? gp_mlp16_bwd_data4_f16_kernel : gp_mlp16_bwd_data_f16_kernel, grid, dim3(M16_THREADS), 0, s, m, masks, dL_dout, (void*)dz, dL_dfeature, dL_dxyz, absmax);
             hipLaunchKernelGGL((gp_mlp16_pack_dout_kernel<_Float16>), dim3(gp_blocks((size_t)((m.rows + 63) & ~63L), 256)), dim3(256), 0, s, dL_dout, m.out_dim, m.rows, (_Float16*)dout16, absmax);
         } else {
@@ -867,6 +1098,26 @@ extern "C" int gp_mlp16_backward(const gp_mlp16_params* p /* w16 = TRANSPOSED co
     const long rpb = ((m.rows + nrb_l - 1) / nrb_l + 63) & ~63L;
     const unsigned nrb = (unsigned)((m.rows + rpb - 1) / rpb);
     GpProfScope _pw("mlp16_bwd_weight", s);
+    // operand tensors of layer l: dZ_l (n_out x rows) and H_l (n_in x rows); nf = features read, ks = features per row block
+    const size_t le = t16_elems(NS * 256, m.rows) * 2;               // bytes per 256-feature layer tensor
+    struct Opnd { const char* z; const char* h; int nf_z, nf_h, n_out, n_in; };
+    auto opnd = [&](int l) {
+        Opnd o;
+        o.z = l < 4 ? dz + (size_t)l * le : dout16;
+        o.h = l == 0 ? (const char*)saved_xT : (const char*)saved_hT + (size_t)(l - 1) * le;
+        o.nf_z = l < 4 ? 256 : 16; o.nf_h = l == 0 ? m.in_pad : 256;
+        o.n_out = l < 4 ? 256 : m.out_dim; o.n_in = l == 0 ? m.in_dim : 256;
+        return o;
+    };
+    // split mode: dW = Zh Hh^T + 2^-11 (Zh Hl'^T + Zl' Hh^T); the lo' half of a tensor starts nf features into each row block
+    const int n_terms = split ? 3 : 1;
+    auto term = [&](const Opnd& o, int t, float* dw, float* db) {
+        W16Job jb;
+        jb.z = o.z + (t == 2 ? (size_t)o.nf_z * T16_BLK * 2 : 0);
+        jb.h = o.h + (t == 1 ? (size_t)o.nf_h * T16_BLK * 2 : 0);
+        jb.dw = dw; jb.db = t == 1 ? nullptr : db; jb.mul = t == 0 ? 1.f : SP_LO_INV;
+        return jb;
+    };
     if (m.rows >= 4096) {       // LDS-staged kernel: grid = (row slabs, jobs), three launches cover the five layers
         const long n_kb = (m.rows + 63) / 64 * (64 / T16_BLK);   // 16-row blocks incl. the zero padding to 64 rows
         long nslab = n_kb / 64;                                  // 1024-row slabs (every slab ends in 64 k atomic adds) ...
@@ -876,17 +1127,18 @@ extern "C" int gp_mlp16_backward(const gp_mlp16_params* p /* w16 = TRANSPOSED co
         if (nslab < 1) nslab = 1;
         const long kbs = ((n_kb + nslab - 1) / nslab + W16_DEPTH - 1) / W16_DEPTH * W16_DEPTH;
         const unsigned gx = (unsigned)((n_kb + kbs - 1) / kbs);
-        const size_t le = t16_elems(256, m.rows) * 2;            // bytes per 256-feature layer tensor
         W16Jobs mid, first, last;
-        for (int l = 1; l <= 3; ++l) mid.j[l - 1] = W16Job{dz + (size_t)l * le, (const char*)saved_hT + (size_t)(l - 1) * le, g->dw[l], g->db[l]};
-        first.j[0] = W16Job{dz, saved_xT, g->dw[0], g->db[0]};
-        last.j[0] = W16Job{dout16, (const char*)saved_hT + (size_t)3 * le, g->dw[4], g->db[4]};
-        first.j[1] = first.j[2] = first.j[0]; last.j[1] = last.j[2] = last.j[0];
-        const W16Shape sh_mid{256, 256, 256, 256, 256}, sh_first{256, m.in_pad, 256, m.in_dim, m.in_dim}, sh_last{16, 256, m.out_dim, 256, 256};
+        for (int t = 0; t < n_terms; ++t) {
+            for (int l = 1; l <= 3; ++l) mid.j[(l - 1) * n_terms + t] = term(opnd(l), t, g->dw[l], g->db[l]);
+            first.j[t] = term(opnd(0), t, g->dw[0], g->db[0]);
+            last.j[t] = term(opnd(4), t, g->dw[4], g->db[4]);
+        }
+        const W16Shape sh_mid{256, 256, 256, 256, 256, NS * 256, NS * 256, split}, sh_first{256, m.in_pad, 256, m.in_dim, m.in_dim, NS * 256, NS * m.in_pad, split},
+            sh_last{16, 256, m.out_dim, 256, 256, NS * 16, NS * 256, split};
         if (f16) {
-            hipLaunchKernelGGL((gp_mlp16_bwd_weight_lds_kernel<_Float16, 4, 2, 4>), dim3(gx, 3), dim3(W16_THREADS), 0, s, mid, sh_mid, n_kb, kbs, absmax);
-            hipLaunchKernelGGL((gp_mlp16_bwd_weight_lds_kernel<_Float16, 2, 2, 2>), dim3(gx, 1), dim3(W16_THREADS), 0, s, first, sh_first, n_kb, kbs, absmax);
-            hipLaunchKernelGGL((gp_mlp16_bwd_weight_lds_kernel<_Float16, 1, 1, 8>), dim3(gx, 1), dim3(W16_THREADS), 0, s, last, sh_last, n_kb, kbs, absmax);
+            hipLaunchKernelGGL((gp_mlp16_bwd_weight_lds_kernel<_Float16, 4, 2, 4>), dim3(gx, 3 * n_terms), dim3(W16_THREADS), 0, s, mid, sh_mid, n_kb, kbs, absmax);
+            hipLaunchKernelGGL((gp_mlp16_bwd_weight_lds_kernel<_Float16, 2, 2, 2>), dim3(gx, n_terms), dim3(W16_THREADS), 0, s, first, sh_first, n_kb, kbs, absmax);
+            hipLaunchKernelGGL((gp_mlp16_bwd_weight_lds_kernel<_Float16, 1, 1, 8>), dim3(gx, n_terms), dim3(W16_THREADS), 0, s, last, sh_last, n_kb, kbs, absmax);
         } else {
             hipLaunchKernelGGL((gp_mlp16_bwd_weight_lds_kernel<__bf16, 4, 2, 4>), dim3(gx, 3), dim3(W16_THREADS), 0, s, mid, sh_mid, n_kb, kbs, absmax);
             hipLaunchKernelGGL((gp_mlp16_bwd_weight_lds_kernel<__bf16, 2, 2, 2>), dim3(gx, 1), dim3(W16_THREADS), 0, s, first, sh_first, n_kb, kbs, absmax);
@@ -896,14 +1148,13 @@ extern "C" int gp_mlp16_backward(const gp_mlp16_params* p /* w16 = TRANSPOSED co
         return 0;
     }
     for (int l = 0; l < 5; ++l) {
-        const void* dZl = l < 4 ? (const void*)(dz + (size_t)l * t16_elems(256, m.rows) * 2) : (const void*)dout16;
-        const int nf_z = l < 4 ? 256 : 16, nf_h = l == 0 ? m.in_pad : 256;
-        const int n_out = l < 4 ? 256 : m.out_dim;
-        const void* H = l == 0 ? saved_xT : (const void*)((const char*)saved_hT + (size_t)(l - 1) * t16_elems(256, m.rows) * 2);
-        const int n_in = l == 0 ? m.in_dim : 256;
-        const dim3 grid((unsigned)((n_in + 63) / 64) * (unsigned)((n_out + 63) / 64), nrb);
-        if (f16) hipLaunchKernelGGL(gp_mlp16_bwd_weight_f16_kernel, grid, dim3(M16_THREADS), 0, s, dZl, n_out, H, n_in, nf_z, nf_h, m.rows, rpb, g->dw[l], n_in, g->db[l], absmax);
-        else hipLaunchKernelGGL(gp_mlp16_bwd_weight_bf16_kernel, grid, dim3(M16_THREADS), 0, s, dZl, n_out, H, n_in, nf_z, nf_h, m.rows, rpb, g->dw[l], n_in, g->db[l], absmax);
+        const Opnd o = opnd(l);
+        const dim3 grid((unsigned)((o.n_in + 63) / 64) * (unsigned)((o.n_out + 63) / 64), nrb);
+        for (int t = 0; t < n_terms; ++t) {      // consecutive launches on one stream: the terms never add to dW concurrently
+            const W16Job jb = term(o, t, g->dw[l], g->db[l]);
+            if (f16) hipLaunchKernelGGL(gp_mlp16_bwd_weight_f16_kernel, grid, dim3(M16_THREADS), 0, s, jb.z, o.n_out, jb.h, o.n_in, NS * o.nf_z, NS * o.nf_h, m.rows, rpb, jb.dw, o.n_in, jb.db, absmax, jb.mul);
+            else hipLaunchKernelGGL(gp_mlp16_bwd_weight_bf16_kernel, grid, dim3(M16_THREADS), 0, s, jb.z, o.n_out, jb.h, o.n_in, NS * o.nf_z, NS * o.nf_h, m.rows, rpb, jb.dw, o.n_in, jb.db, absmax, jb.mul);
+        }
         GP_LAUNCH_CHECK();
     }
     return 0;

@@ -110,15 +110,30 @@ class FusedMlp(torch.autograd.Function):
         return (g_feat, g_xyz, None, None, None, *wb_grads)
 
 
+def _to16(w, tdt, split):
+    """16-bit copy of a weight matrix; split mode: [hi copy, lo' copy] with hi = fp16(w) (zero below the fp16 normal
+    range) and lo' = fp16((w - hi) * 2^11) (see GP_DTYPE_F16_SPLIT in include/gp_hip.h)."""
+    w = w.contiguous()
+    if not split:
+        return w.to(tdt)
+    c = w.clamp(-65504.0, 65504.0)
+    hi = torch.where(c.abs() < 6.103515625e-05, torch.zeros_like(c), c).to(torch.float16)
+    lo = ((c - hi.float()) * 2048.0).to(torch.float16)
+    return torch.stack([hi, lo]).contiguous()
+
+
 class FusedMlp16(torch.autograd.Function):
-    """FusedMlp with 16-bit operands on the matrix cores (fp16 or bf16, fp32 accumulate).  Opt-in."""
+    """FusedMlp with 16-bit operands on the matrix cores (fp16 or bf16, fp32 accumulate; "fp32s" = split fp16 pairs with
+    fp32-grade results).  Opt-in."""
 
     @staticmethod
     def forward(ctx, feature, xyz, t, xyz_freq, time_freq, precision, *wb):
         _need_cuda(feature, "FusedMlp16")
         dev = feature.device
-        tdt = {"fp16": torch.float16, "bf16": torch.bfloat16}[precision]
-        cdt = {"fp16": _lib.GP_DTYPE_F16, "bf16": _lib.GP_DTYPE_BF16}[precision]
+        tdt = {"fp16": torch.float16, "bf16": torch.bfloat16, "fp32s": torch.float16}[precision]
+        cdt = {"fp16": _lib.GP_DTYPE_F16, "bf16": _lib.GP_DTYPE_BF16, "fp32s": _lib.GP_DTYPE_F16_SPLIT}[precision]
+        split = precision == "fp32s"
+        ns = 2 if split else 1
         ws = [_c(w) for w in wb[0::2]]
         bs = [_c(b) for b in wb[1::2]]
         feature_c = _c(feature)
@@ -127,16 +142,16 @@ class FusedMlp16(torch.autograd.Function):
         rows, fd = feature_c.shape
         in_dim, out_dim = ws[0].shape[1], ws[4].shape[0]
         in_pad = (in_dim + 15) // 16 * 16
-        w0p = torch.zeros(256, in_pad, device=dev, dtype=tdt)
+        w0p = torch.zeros(256, in_pad, device=dev)
         w0p[:, :in_dim] = ws[0]
-        w4p = torch.zeros(32, 256, device=dev, dtype=tdt)
+        w4p = torch.zeros(32, 256, device=dev)
         w4p[:out_dim] = ws[4]
-        w16 = [w0p, ws[1].to(tdt), ws[2].to(tdt), ws[3].to(tdt), w4p]
+        w16 = [_to16(w, tdt, split) for w in (w0p, ws[1], ws[2], ws[3], w4p)]
         need_grad = any(x is not None and torch.is_tensor(x) and x.requires_grad for x in (feature, xyz) + tuple(wb))
         out = torch.empty(rows, out_dim, device=dev)
         rows64 = (rows + 63) // 64 * 64                     # blocked layout [row block of 16][feature][16], rows padded to 64
-        xT = torch.empty(in_pad * rows64, device=dev, dtype=tdt) if need_grad else None
-        hT = torch.empty(4 * 256 * rows64, device=dev, dtype=tdt) if need_grad else None
+        xT = torch.empty(ns * in_pad * rows64, device=dev, dtype=tdt) if need_grad else None
+        hT = torch.empty(ns * 4 * 256 * rows64, device=dev, dtype=tdt) if need_grad else None
         masks = torch.empty(4, rows, 8, device=dev, dtype=torch.int32) if need_grad else None
         params = _lib.Mlp16ParamsC(cdt, in_dim, 256, 4, out_dim)
         for l in range(5):
@@ -166,11 +181,12 @@ class FusedMlp16(torch.autograd.Function):
         rows, fd = feature_c.shape
         in_dim, out_dim = ws[0].shape[1], ws[4].shape[0]
         g = g_out.to(torch.float32).contiguous()
-        wt0 = torch.zeros(in_pad, 256, device=dev, dtype=tdt)
+        split = cdt == _lib.GP_DTYPE_F16_SPLIT
+        wt0 = torch.zeros(in_pad, 256, device=dev)
         wt0[:in_dim] = ws[0].t()
-        wt4 = torch.zeros(256, 16, device=dev, dtype=tdt)
+        wt4 = torch.zeros(256, 16, device=dev)
         wt4[:, :out_dim] = ws[4].t()
-        wt = [wt0, ws[1].t().contiguous().to(tdt), ws[2].t().contiguous().to(tdt), ws[3].t().contiguous().to(tdt), wt4]
+        wt = [_to16(w, tdt, split) for w in (wt0, ws[1].t(), ws[2].t(), ws[3].t(), wt4)]
         params = _lib.Mlp16ParamsC(cdt, in_dim, 256, 4, out_dim)
         grads = _lib.MlpGradsC()
         leaves = ctx.wb_leaves

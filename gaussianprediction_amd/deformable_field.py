@@ -18,8 +18,8 @@ class Deformable_Field(nn.Module):
         """`precision` (extension): "fp32" = exact-fp32 matrix cores (default, parity-grade); "fp16" / "bf16" =
         16-bit operands with fp32 accumulation, ~16x the MFMA rate (BASELINE config 5)."""
         super().__init__()
-        if precision not in ("fp32", "fp16", "bf16"):
-            raise ValueError("precision must be fp32, fp16 or bf16")
+        if precision not in ("fp32", "fp32s", "fp16", "bf16"):
+            raise ValueError("precision must be fp32, fp32s, fp16 or bf16")
         self.precision = precision
         if split_xyz or use_softmax:
             raise NotImplementedError("split_xyz / use_softmax are dead branches in the reference "

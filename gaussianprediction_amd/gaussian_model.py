@@ -219,11 +219,15 @@ class GaussianModel(TrainingMixin, nn.Module):
         if return_weights and iteration > self.second_stage_iter:
             weights = self.dense_weights()
         if a.step_opacity and iteration > a.step_opacity_iteration:
-            if a.opacity_type != "implicit":
-                raise NotImplementedError("opacity_type 'explicit' is not on any shipped script's path")
-            # second MLP pass over all N Gaussians with the per-Gaussian motion feature [REF :291-298]
-            delta2 = self.df_model.forward_fused(self.motion_feature, self._xyz, t_dev, xyz_freq, time_freq)
-            s, o = Activations.apply(self._scaling, self._opacity, delta2, 7, self.beta)
+            if a.opacity_type == "explicit":
+                # per-Gaussian birth time: sigmoid((t - opacity_thres) / beta) [REF :50, :294-295] (the reference also runs the MLP
+                # here and drops its output; nothing reads it, so it is not run)
+                gate = t_dev.reshape(1, 1) - self.opacity_thres
+                s, o = Activations.apply(self._scaling, self._opacity, gate, 0, self.beta)
+            else:
+                # second MLP pass over all N Gaussians with the per-Gaussian motion feature [REF :291-298]
+                delta2 = self.df_model.forward_fused(self.motion_feature, self._xyz, t_dev, xyz_freq, time_freq)
+                s, o = Activations.apply(self._scaling, self._opacity, delta2, 7, self.beta)
             self.lifecycle_opacity = o
             if weights:                              # the reference returns the PLAIN opacity beside the weights [REF :299-300]
                 return (xyz_t, q_t, s, self.get_opacity) + tuple(weights)

@@ -25,14 +25,19 @@ def _net(seed, d_in, d_out, device="cuda"):
     return net, sd
 
 
-def test_mlp_matches_reference_golden_vectors():
+@pytest.mark.parametrize("precision", ["fp32", "fp32s"])
+def test_mlp_matches_reference_golden_vectors(precision):
     g = np.load(os.path.join(G, "deformable_field.npz"))
     for tag in ("a", "b", "c"):
         d_in, d_out, M, seed = [int(v) for v in g[f"{tag}_meta"]]
         net, _ = _net(seed, d_in, d_out)
         x = torch.tensor(np.random.default_rng(seed + 100).uniform(-1, 1, size=(M, d_in)).astype(np.float32), device="cuda", requires_grad=True)
         gy = torch.tensor(np.random.default_rng(seed + 200).normal(size=(M, d_out)).astype(np.float32), device="cuda")
-        y = net(x)
+        if precision == "fp32s":      # the split-fp16 kernels on the plain-input form (no encoding): feature = x
+            from gaussianprediction_amd.deform_ops import FusedMlp16
+            y = FusedMlp16.apply(x, None, None, 0, 0, "fp32s", *net._wb())
+        else:
+            y = net(x)
         (y * gy).sum().backward()
         np.testing.assert_allclose(y.detach().cpu().numpy(), g[f"{tag}_y"], rtol=1e-4, atol=2e-6)
         np.testing.assert_allclose(x.grad.cpu().numpy(), g[f"{tag}_dx"], rtol=1e-3, atol=2e-6)
@@ -46,6 +51,18 @@ def test_mlp_matches_reference_golden_vectors():
 
 @pytest.mark.parametrize("rows,F,out_dim", [(1, 6, 7), (33, 8, 7), (250, 8, 7), (300, 10, 8), (5000, 6, 7), (20003, 8, 8), (40001, 6, 7)])   # last two: large-row weight-gradient kernel; two-tile fwd/bwd kernels (ragged)
 def test_fused_pe_mlp_forward_backward(rows, F, out_dim):
+    _check_mlp_against_f64(rows, F, out_dim, split=False)
+
+
+@pytest.mark.parametrize("rows,F,out_dim", [(1, 6, 7), (33, 8, 7), (300, 10, 8), (5000, 6, 7), (20003, 8, 8), (131072, 6, 7)])
+def test_split_fp16_mlp_meets_the_fp32_bars(rows, F, out_dim):
+    """precision="fp32s": every operand carried as an fp16 (hi, lo') pair, three 16-bit MFMA chains per product sum -- the SAME
+    bars as the exact-fp32 kernels above (|y - y64| < 2e-5, gradients rel-L2 < 1e-4), at every row count (small and LDS-staged
+    weight-gradient kernels)."""
+    _check_mlp_against_f64(rows, F, out_dim, split=True)
+
+
+def _check_mlp_against_f64(rows, F, out_dim, split):
     d_in = 32 + 60 + 2 * F
     net, sd = _net(40 + rows, d_in, out_dim)
     rng = np.random.default_rng(rows)
@@ -73,7 +90,11 @@ def test_fused_pe_mlp_forward_backward(rows, F, out_dim):
     (y64 * gy.double()).sum().backward()
     # HIP
     fd, xd = feat.cuda().requires_grad_(True), xyz.cuda().requires_grad_(True)
-    y = net.forward_fused(fd, xd, t.cuda(), 10, F)
+    if split:
+        from gaussianprediction_amd.deform_ops import FusedMlp16
+        y = FusedMlp16.apply(fd, xd, t.cuda(), 10, F, "fp32s", *net._wb())
+    else:
+        y = net.forward_fused(fd, xd, t.cuda(), 10, F)
     (y * gy.cuda()).sum().backward()
     assert np.abs(y.detach().cpu().numpy() - y64.detach().numpy()).max() < 2e-5
     assert rel_l2(fd.grad.cpu().numpy()[ok], f64.grad.numpy()[ok]) < 1e-4

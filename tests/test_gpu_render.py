@@ -139,3 +139,32 @@ def test_render_motion_and_python_fallback_flags():
         err = (a["render"] - b["render"]).abs()
         assert float(err.median()) < 1e-6 and float((err > 1e-4).float().mean()) < 1e-3
         assert (a["radii"] != b["radii"]).float().mean() < 1e-3
+
+
+def test_explicit_opacity_type_gates_by_birth_time():
+    """opacity_type="explicit": opacity = sigmoid(_opacity) * sigmoid((t - opacity_thres) / beta) with a learnt per-Gaussian threshold
+    [REF scene/gaussian_model.py:50, 294-295, 357-360]; forward and the gradient into opacity_thres against the float64 restatement."""
+    args = make_args(step_opacity=True, opacity_type="explicit")
+    pc, cam, P, sd, raw, raw_w, idx, args = build(N=1200, K=40, W=96, H=72, args=args)
+    thres = torch.randn(1200, 1, generator=torch.Generator().manual_seed(5)) * 0.3 + 0.2
+    with torch.no_grad():
+        pc.opacity_thres.copy_(thres.cuda())
+    t = torch.tensor([0.25], device="cuda")
+    xt, qt, s, o = pc(t, 50000)
+    assert pc.lifecycle_opacity is o
+    go = torch.randn(o.shape, generator=torch.Generator().manual_seed(6))
+    (o * go.cuda()).sum().backward()
+    P64 = {k: v.double() for k, v in P.items()}
+    P64["opacity_thres"] = thres.double().requires_grad_(True)
+    P64["opacity"] = P64["opacity"].requires_grad_(True)
+    sd64 = {k: v.double() for k, v in sd.items()}
+    _, _, _, oo = do.deform_forward(P64, sd64, torch.tensor(0.25, dtype=torch.float64), 50000, args, raw_w=raw_w.double(), knn_idx=idx)
+    (oo * go.double()).sum().backward()
+    assert float((o.detach().cpu().double() - oo.detach()).abs().max()) < 1e-6
+    from util import rel_l2
+    assert rel_l2(pc.opacity_thres.grad.cpu().numpy(), P64["opacity_thres"].grad.numpy()) < 1e-5
+    assert rel_l2(pc._opacity.grad.cpu().numpy(), P64["opacity"].grad.numpy()) < 1e-5
+    pipe = SimpleNamespace(convert_SHs_python=False, compute_cov3D_python=False, debug=False)
+    with torch.no_grad():
+        pkg = gpa.render(cam, pc, pipe, torch.zeros(3, device="cuda"), time=t, it=50000)
+    assert torch.isfinite(pkg["render"]).all() and float(pkg["render"].sum()) > 0
