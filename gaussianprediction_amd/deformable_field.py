@@ -15,8 +15,10 @@ from .deform_ops import FusedMlp, FusedMlp16
 
 class Deformable_Field(nn.Module):
     def __init__(self, input_dim, output_dim=10, d=8, w=256, use_softmax=False, split_xyz=False, precision="fp32"):
-        """`precision` (extension): "fp32" = exact-fp32 matrix cores (default, parity-grade); "fp16" / "bf16" =
-        16-bit operands with fp32 accumulation, ~16x the MFMA rate (BASELINE config 5)."""
+        """`precision` (extension): "fp32" = exact-fp32 matrix cores (default); "fp32s" = fp32 operands carried as fp16 (hi, lo')
+        pairs on the 16-bit matrix cores (22 significant bits, fp32 accumulation: meets the fp32 kernels' test bars at ~2x their speed;
+        |activations| < 65504); "fp16" / "bf16" = 16-bit operands with fp32 accumulation, ~16x the MFMA rate (BASELINE config 5).
+        The 16-bit kernels serve calls with more than 2048 rows; smaller ones always use the exact-fp32 small-row kernels."""
         super().__init__()
         if precision not in ("fp32", "fp32s", "fp16", "bf16"):
             raise ValueError("precision must be fp32, fp32s, fp16 or bf16")

@@ -61,7 +61,10 @@ class GaussianModel(TrainingMixin, nn.Module):
             self.opacity_thres = nn.Parameter((-2 * torch.ones_like(opacity)).requires_grad_(True))
         delta_dim = 8 if self.args.step_opacity else 7
         in_dim = self.time_input_dim + self.xyz_input_dim + self.motion_feature_dim
-        self.df_model = Deformable_Field(in_dim, d=self.d, w=self.w, output_dim=delta_dim, split_xyz=False).to(xyz.device)
+        # per-Gaussian passes (> 2048 rows) run the split-fp16 kernels by default: fp32-grade results (same test bars as the exact-fp32
+        # kernels, tests/test_gpu_deform.py) at twice their speed; args.mlp_precision = "fp32" selects the exact-fp32 matrix-core kernels
+        self.df_model = Deformable_Field(in_dim, d=self.d, w=self.w, output_dim=delta_dim, split_xyz=False,
+                                         precision=getattr(self.args, "mlp_precision", "fp32s")).to(xyz.device)
         if keypoints is not None:
             self.super_gaussians = nn.Parameter(keypoints.clone().requires_grad_(True))
             self.super_gaussians_feature = nn.Parameter(keypoint_features.clone().requires_grad_(True))
