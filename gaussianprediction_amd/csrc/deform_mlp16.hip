@@ -80,7 +80,8 @@ struct Mlp16Dev {
     long rows;
     int in_dim, in_pad, out_dim;       // in_pad = in_dim rounded up to 16
     int feature_dim, xyz_freq, time_freq;
-    const void* w[5];                  // 16-bit copies: [256][in_pad], 3 x [256][256], [32][256] (rows >= out_dim zero)
+    const void* w[5];                  // 16-bit copies of [256][in_pad], 3 x [256][256], [32][256] (rows >= out_dim zero), FRAGMENT-PACKED:
+                                       // element (f, k) of a [F][K] matrix at (((k / 16) * (F / 32) + f / 32) * 64 + ((k / 8) & 1) * 32 + f % 32) * 8 + k % 8
     const void* wlo[5];                // split mode: the lo' copies (same shapes), else null
     const float* b[5];                 // fp32 biases
     const float* feature;
@@ -288,10 +289,13 @@ __device__ __forceinline__ void gemm16(const T* cur, const T* __restrict__ W, in
                                        f32x16 (&acc)[RT][2]) {
     typedef typename Vec8<T>::type V8;
     const int half = lane >> 5, j = lane & 31;
-    const int f0 = (2 * wave) * 32 + j, f1 = f0 + 32;
-    const T* w0 = W + (size_t)f0 * ldk + 8 * half;
-    const T* w1 = W + (size_t)f1 * ldk + 8 * half;
-    const bool ok0 = f0 < n_feat, ok1 = f1 < n_feat;
+    // fragment-packed weights [k-step][feature tile of 32][lane][8]: a wave's load is 1 KB contiguous (row-major weights made
+    // every lane of a load touch its own cache line: the address unit, not the matrix pipe, set the pace)
+    const int n_tiles = (n_feat + 31) / 32;
+    const bool ok0 = 2 * wave < n_tiles, ok1 = 2 * wave + 1 < n_tiles;
+    const size_t kst = (size_t)n_tiles * 512;
+    const T* w0 = W + ((size_t)(2 * wave) * 64 + lane) * 8;
+    const T* w1 = w0 + 512;
     const int nks = K / 16;
     V8 zero;
 #pragma unroll
@@ -304,8 +308,8 @@ __device__ __forceinline__ void gemm16(const T* cur, const T* __restrict__ W, in
     V8 bn[G][2];
 #pragma unroll
     for (int u = 0; u < G; ++u) {
-        bn[u][0] = (ok0 && u < nks) ? *(const V8*)(w0 + u * 16) : zero;
-        bn[u][1] = (ok1 && u < nks) ? *(const V8*)(w1 + u * 16) : zero;
+        bn[u][0] = (ok0 && u < nks) ? *(const V8*)(w0 + u * kst) : zero;
+        bn[u][1] = (ok1 && u < nks) ? *(const V8*)(w1 + u * kst) : zero;
     }
     for (int ks = 0; ks < nks; ks += G) {
         V8 bc[G][2];
@@ -314,8 +318,8 @@ __device__ __forceinline__ void gemm16(const T* cur, const T* __restrict__ W, in
 #pragma unroll
         for (int u = 0; u < G; ++u) {   // prefetch the next group
             const int kn = ks + G + u;
-            bn[u][0] = (ok0 && kn < nks) ? *(const V8*)(w0 + kn * 16) : zero;
-            bn[u][1] = (ok1 && kn < nks) ? *(const V8*)(w1 + kn * 16) : zero;
+            bn[u][0] = (ok0 && kn < nks) ? *(const V8*)(w0 + kn * kst) : zero;
+            bn[u][1] = (ok1 && kn < nks) ? *(const V8*)(w1 + kn * kst) : zero;
         }
 #pragma unroll
         for (int u = 0; u < G; ++u) {
@@ -345,9 +349,10 @@ template <bool SWAPPED, int RT>
 __device__ __forceinline__ void gemm16s(const _Float16* cur, const _Float16* __restrict__ Wh, const _Float16* __restrict__ Wl, int ldk,
                                         int K, int n_feat, int wave, int lane, f32x16 (&am)[RT][2], f32x16 (&ax)[RT][2]) {
     const int half = lane >> 5, j = lane & 31;
-    const int f0 = (2 * wave) * 32 + j, f1 = f0 + 32;
-    const size_t o0 = (size_t)f0 * ldk + 8 * half, o1 = (size_t)f1 * ldk + 8 * half;
-    const bool ok0 = f0 < n_feat, ok1 = f1 < n_feat;
+    const int n_tiles = (n_feat + 31) / 32;                  // fragment-packed weights, see gemm16
+    const bool ok0 = 2 * wave < n_tiles, ok1 = 2 * wave + 1 < n_tiles;
+    const size_t kst = (size_t)n_tiles * 512;
+    const size_t o0 = ((size_t)(2 * wave) * 64 + lane) * 8, o1 = o0 + 512;
     const int nks = K / 16;
     h8 zero;
 #pragma unroll
@@ -364,10 +369,10 @@ __device__ __forceinline__ void gemm16s(const _Float16* cur, const _Float16* __r
 #pragma unroll
         for (int u = 0; u < 4; ++u) bc[u] = bn[u];
         const int kn = ks + 1;
-        bn[0] = (ok0 && kn < nks) ? *(const h8*)(Wh + o0 + kn * 16) : zero;
-        bn[1] = (ok1 && kn < nks) ? *(const h8*)(Wh + o1 + kn * 16) : zero;
-        bn[2] = (ok0 && kn < nks) ? *(const h8*)(Wl + o0 + kn * 16) : zero;
-        bn[3] = (ok1 && kn < nks) ? *(const h8*)(Wl + o1 + kn * 16) : zero;
+        bn[0] = (ok0 && kn < nks) ? *(const h8*)(Wh + o0 + kn * kst) : zero;
+        bn[1] = (ok1 && kn < nks) ? *(const h8*)(Wh + o1 + kn * kst) : zero;
+        bn[2] = (ok0 && kn < nks) ? *(const h8*)(Wl + o0 + kn * kst) : zero;
+        bn[3] = (ok1 && kn < nks) ? *(const h8*)(Wl + o1 + kn * kst) : zero;
         const int col = (ks * 16) ^ swz;
         h8 ah[RT], al[RT];
 #pragma unroll
@@ -503,14 +508,14 @@ __device__ __forceinline__ void mlp16_fwd_body(Mlp16Dev p, float* __restrict__ o
         for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) { acc[rt][r] = 0.f; if (SP) ax[rt][r] = 0.f; }
-        const T* w4 = (const T*)p.w[4] + (size_t)j * M16_W + 8 * half;
-        const T* w4l = SP ? (const T*)p.wlo[4] + (size_t)j * M16_W + 8 * half : nullptr;
+        const T* w4 = (const T*)p.w[4] + lane * 8;              // fragment-packed, one feature tile: [k-step][lane][8]
+        const T* w4l = SP ? (const T*)p.wlo[4] + lane * 8 : nullptr;
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int ks = 4 * wave + u;
-            const V8 b = *(const V8*)(w4 + ks * 16);
+            const V8 b = *(const V8*)(w4 + ks * 512);
             if constexpr (SP) {
-                const V8 bl = *(const V8*)(w4l + ks * 16);
+                const V8 bl = *(const V8*)(w4l + ks * 512);
 #pragma unroll
                 for (int rt = 0; rt < RT; ++rt) {
                     const V8 ah = *(const V8*)(cur + a16_idx<WS>(32 * rt + j, ks * 16 + 8 * half));
@@ -1018,7 +1023,8 @@ static int make16(const gp_mlp16_params* p, const gp_mlp_input* x, Mlp16Dev& m, 
     for (int l = 0; l < 5; ++l) {
         m.w[l] = p->w16[l]; m.b[l] = p->b[l];
         // split mode: each array is [hi copy][lo' copy]
-        const size_t elems = l == 0 ? (size_t)256 * m.in_pad : l < 4 ? (size_t)65536 : (transposed ? (size_t)256 * 16 : (size_t)32 * 256);
+        const size_t elems = l == 0 ? (transposed ? (size_t)((m.in_pad + 31) / 32 * 32) * 256 : (size_t)256 * m.in_pad)
+                                    : l < 4 ? (size_t)65536 : (transposed ? (size_t)256 * 16 : (size_t)32 * 256);
         m.wlo[l] = p->dtype == GP_DTYPE_F16_SPLIT ? (const void*)((const _Float16*)p->w16[l] + elems) : nullptr;
     }
     m.feature = x->feature; m.xyz = x->xyz; m.t = x->t;

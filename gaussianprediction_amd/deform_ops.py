@@ -113,13 +113,18 @@ class FusedMlp(torch.autograd.Function):
 def _to16(w, tdt, split):
     """16-bit copy of a weight matrix; split mode: [hi copy, lo' copy] with hi = fp16(w) (zero below the fp16 normal
     range) and lo' = fp16((w - hi) * 2^11) (see GP_DTYPE_F16_SPLIT in include/gp_hip.h)."""
+    def pack(m):            # [F, K] (F % 32 == 0, K % 16 == 0) -> fragment order [k-step][feature tile][half][j][8] (include/gp_hip.h)
+        F_, K_ = m.shape
+        return m.reshape(F_ // 32, 32, K_ // 16, 2, 8).permute(2, 0, 3, 1, 4).contiguous()
     w = w.contiguous()
+    if w.shape[0] % 32:
+        w = torch.cat([w, w.new_zeros(32 - w.shape[0] % 32, w.shape[1])])
     if not split:
-        return w.to(tdt)
+        return pack(w.to(tdt))
     c = w.clamp(-65504.0, 65504.0)
     hi = torch.where(c.abs() < 6.103515625e-05, torch.zeros_like(c), c).to(torch.float16)
     lo = ((c - hi.float()) * 2048.0).to(torch.float16)
-    return torch.stack([hi, lo]).contiguous()
+    return torch.stack([pack(hi), pack(lo)]).contiguous()
 
 
 class FusedMlp16(torch.autograd.Function):

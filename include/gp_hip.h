@@ -173,7 +173,9 @@ int gp_mlp_backward(const gp_mlp_params* p, const gp_mlp_input* x, const float* 
 /* ---- 16-bit-operand variant (fp16 or bf16 inputs, fp32 accumulate; BASELINE config 5).  Opt-in: results
  * differ from the fp32 path at the 1e-3 (fp16) / 1e-2 (bf16) relative level.  Weights are passed as 16-bit
  * copies prepared by the host (zero-padded): forward  w16[0]:[256,in_pad16] w16[1..3]:[256,256] w16[4]:[32,256];
- * backward takes the TRANSPOSED copies  w16[0]:[in_pad16,256] w16[1..3]:[256,256]^T w16[4]:[256,16].
+ * backward takes the TRANSPOSED copies  w16[0]:[in_pad32,256] w16[1..3]:[256,256]^T w16[4]:[256,16]
+ * (in_pad32 = in_dim rounded up to 32), each matrix [F][K] stored FRAGMENT-PACKED so that one wavefront load is 1 KB
+ * contiguous: element (f, k) at (((k / 16) * (F / 32) + f / 32) * 64 + ((k / 8) & 1) * 32 + f % 32) * 8 + k % 8.
  * GP_DTYPE_F16_SPLIT: fp32-grade results at the 16-bit matrix-core rate.  Every operand is carried as two fp16 numbers
  * (hi = fp16(x), zero below 2^-14; lo' = fp16((x - hi) * 2^11)) and a product sum as three MFMA chains
  * (hi.hi + 2^-11 (hi.lo' + lo'.hi), fp32 accumulate: ~22 significant bits per operand).  Each w16[l] then holds the hi
