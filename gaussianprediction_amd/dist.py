@@ -7,8 +7,19 @@ visibility filter follows from it [REF train.py:121-122].
 """
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.distributed as dist
+
+
+def active(group=None) -> bool:
+    """True when gradients / parameters have to be exchanged: a process group with more than one rank.
+    GP_DIST_FORCE_SINGLE=1 (test hook) also runs every collective on a ONE-rank group, so that the RCCL code path
+    (in-place reduce_scatter_tensor / all_gather_into_tensor, hooks, stream waits) is exercised on a single-GPU box."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size(group) > 1 or os.environ.get("GP_DIST_FORCE_SINGLE") == "1"
 
 
 class FlatGradBucket:
@@ -74,7 +85,7 @@ class FlatGradBucket:
                 p.grad = self.flat[off:off + p.numel()].view_as(p)
 
     def all_reduce_sum(self, group=None, async_op=False):
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        if active(group):
             return dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
         return None
 
@@ -112,7 +123,7 @@ class ShardedExchange:
 
     def __init__(self, bucket: FlatGradBucket, group=None):
         self.bucket, self.group = bucket, group
-        self.enabled = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+        self.enabled = active(group)
         self.world = dist.get_world_size(group) if self.enabled else 1
         self.rank = dist.get_rank(group) if self.enabled else 0
         assert bucket.shards == self.world, "bucket layout and process group disagree on the number of shards"
@@ -216,7 +227,7 @@ class OverlappedGradReducer:
     def __init__(self, bucket: FlatGradBucket, group=None, small_numel=1 << 20):
         self.bucket, self.group = bucket, group
         self.handles = []
-        self.enabled = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+        self.enabled = active(group)
         self.large = [p for p in bucket.params if p.numel() >= small_numel]
         self.small = [p for p in bucket.params if p.numel() < small_numel]
         self._fired = set()
@@ -280,20 +291,19 @@ class OverlappedGradReducer:
 def reduce_view_stats(radii: torch.Tensor, group=None):
     """radii = elementwise max over the views of the batch; visibility = radii > 0
     [REF train.py:121-122]."""
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    if active(group):
         dist.all_reduce(radii, op=dist.ReduceOp.MAX, group=group)
     return radii, radii > 0
 
 
 def init_from_env(backend: str | None = None):
     """torchrun-style init (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT)."""
-    import os
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if os.environ.get("GP_FORCE_LOCAL_RANK") is not None:     # test hook: several ranks on one GPU (gloo only)
         local = int(os.environ["GP_FORCE_LOCAL_RANK"])
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or os.environ.get("GP_DIST_FORCE_SINGLE") == "1") and not dist.is_initialized():
         if backend is None:
             backend = os.environ.get("GP_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")  # "nccl" IS RCCL on ROCm
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")

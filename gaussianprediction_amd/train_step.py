@@ -109,8 +109,9 @@ class TrainStep:
         # view-parallel: reduce-scatter -> sharded Adam -> all-gather by default (dist.ShardedExchange); sharded=False keeps
         # the all-reduce + replicated Adam of round 1
         import torch.distributed as tdist
+        from .dist import active as dist_active
         world = tdist.get_world_size(group) if (tdist.is_available() and tdist.is_initialized()) else 1
-        self.sharded = bool(fused and world > 1 and (sharded is None or sharded))
+        self.sharded = bool(fused and dist_active(group) and (sharded is None or sharded))
         shard = (tdist.get_rank(group), world) if self.sharded else None
         if pc.optimizer is None or getattr(pc, "_stage", None) != self._stage_of(iteration) or getattr(pc, "optimizer_shard", None) != shard:
             pc.optimizer_shard = shard

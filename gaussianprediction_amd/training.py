@@ -156,7 +156,7 @@ class TrainingMixin:
             p.requires_grad_(id(p) in optimized)   # changes no result
         params = [p for g in groups for p in g["params"]]
         shard = getattr(self, "optimizer_shard", None)       # (rank, world): set by a view-parallel harness (dist.ShardedExchange)
-        if shard is not None and shard[1] > 1:
+        if shard is not None:
             from .loss_ops import FusedAdam
             self.bucket = FlatGradBucket(params, shards=shard[1], flat_params=True)
             self.optimizer = FusedAdam(groups, self.bucket, eps=1e-15, shard=shard)

@@ -274,6 +274,40 @@ def test_two_rank_sharded_adam_equals_replicated_adam(tmp_path, step_opacity):
     assert sh[0]["bytes"] == 4 * sh[0]["n"]          # world 2: reduce-scatter + all-gather move half the flat buffer each, per rank
 
 
+def _rank_main_rccl_single(rank, world, port, out_dir, sharded):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", GP_DIST_FORCE_SINGLE="1")
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    pc, cams, gts, raw, rw, idx, args = build(n=3000, dev="cuda:0")
+    ts = TrainStep(pc, cams, gts, 50000, sharded=sharded)
+    assert ts.reducer.enabled and ts.reducer.nccl if sharded else ts.reducer.enabled
+    assert type(ts.reducer).__name__ == ("ShardedExchange" if sharded else "OverlappedGradReducer")
+    losses = [float(ts.step(step)[0]) for step in range(4)]
+    ts.sync_params()
+    torch.cuda.synchronize()
+    torch.save({"params": {n: p.detach().cpu() for n, p in pc.named_parameters()}, "losses": losses}, os.path.join(out_dir, f"single{int(sharded)}.pt"))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("sharded", [True, False])
+def test_rccl_code_path_on_a_one_rank_group(tmp_path, sharded):
+    """The RCCL branch of the exchange (in-place reduce_scatter_tensor / all_gather_into_tensor on views of the flat buffers, the
+    post-accumulate hooks, asynchronous handles awaited on the compute stream) run for real on a ONE-rank "nccl" group
+    (GP_DIST_FORCE_SINGLE): a SUM over one rank must reproduce the plain single-process steps.  This is what a one-GPU box can
+    check of the multi-GPU legs; the two-rank tests above use RCCL themselves as soon as two devices are visible."""
+    import torch.multiprocessing as mp
+    mp.spawn(_rank_main_rccl_single, args=(1, _free_port(), str(tmp_path), sharded), nprocs=1, join=True)
+    got = torch.load(os.path.join(tmp_path, f"single{int(sharded)}.pt"))
+    pc, cams, gts, raw, rw, idx, args = build(n=3000)
+    ts = TrainStep(pc, cams, gts, 50000)
+    losses = [float(ts.step(step)[0]) for step in range(4)]
+    assert all(abs(a - b) < 1e-4 * max(1.0, abs(b)) for a, b in zip(got["losses"], losses)), (got["losses"], losses)
+    for name, p in pc.named_parameters():
+        diff = (got["params"][name] - p.detach().cpu()).abs()
+        assert float((diff > 1e-6).float().mean()) < 2e-2 and float(diff.max()) < 0.05 * 4 + 1e-6, (name, float(diff.max()))
+
+
 def test_stage_transitions_and_teaching_path_inside_forward():
     """The reference switches stages INSIDE forward [REF scene/gaussian_model.py:246-250]: at second_stage_iter + 1 the keypoints are
     initialised by k-means and the stage-2 optimizer is built, at third_stage_iter + 1 the stage-3 one; with densify_from_teaching the
