@@ -49,7 +49,14 @@ class RasterSavedC(C.Structure):
 class RasterGradsC(C.Structure):
     _fields_ = [("dL_dmeans3D", C.c_void_p), ("dL_dmeans2D", C.c_void_p), ("dL_dshs", C.c_void_p),
                 ("dL_dshs_rest", C.c_void_p), ("dL_dcolors_precomp", C.c_void_p), ("dL_dopacities", C.c_void_p), ("dL_dscales", C.c_void_p),
-                ("dL_drotations", C.c_void_p), ("dL_dcov3D_precomp", C.c_void_p), ("accumulate_shs", C.c_int32)]
+                ("dL_drotations", C.c_void_p), ("dL_dcov3D_precomp", C.c_void_p), ("accumulate_shs", C.c_int32),
+                ("adam_shs", C.c_void_p)]
+
+
+class AdamFuseC(C.Structure):
+    _fields_ = [("exp_avg_dc", C.c_void_p), ("exp_avg_sq_dc", C.c_void_p), ("exp_avg_rest", C.c_void_p), ("exp_avg_sq_rest", C.c_void_p),
+                ("lr_dc", C.c_float), ("lr_rest", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
+                ("step", C.c_int64), ("skip_flag", C.c_void_p)]
 
 
 class MlpParamsC(C.Structure):

@@ -253,11 +253,7 @@ __global__ __launch_bounds__(256) void gp_adam_multi_kernel(AdamTable t, float b
     auto upd = [&](float4& pv, const float4& gv, float4& mv, float4& vv) {
         float* pp = (float*)&pv; const float* gg = (const float*)&gv; float* mm = (float*)&mv; float* vq = (float*)&vv;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            mm[u] = b1 * mm[u] + (1.f - b1) * gg[u];
-            vq[u] = b2 * vq[u] + (1.f - b2) * gg[u] * gg[u];
-            pp[u] -= step_size * (mm[u] / (sqrtf(vq[u]) / bc2_sqrt + eps));
-        }
+        for (int u = 0; u < 4; ++u) gp_adam_update(pp[u], gg[u], mm[u], vq[u], b1, b2, eps, step_size, bc2_sqrt);
     };
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
     size_t i = base + (size_t)threadIdx.x * 4;
@@ -285,10 +281,7 @@ __global__ __launch_bounds__(256) void gp_adam_multi_kernel(AdamTable t, float b
             if (zero_grad) *(float4*)(g + i) = zero4;
         } else {
             for (size_t j = i; j < n; ++j) {
-                const float gk = g[j];
-                const float mk = b1 * m[j] + (1.f - b1) * gk, vk = b2 * v[j] + (1.f - b2) * gk * gk;
-                p[j] -= step_size * (mk / (sqrtf(vk) / bc2_sqrt + eps));
-                m[j] = mk; v[j] = vk;
+                gp_adam_update(p[j], g[j], m[j], v[j], b1, b2, eps, step_size, bc2_sqrt);
                 if (zero_grad) g[j] = 0.f;
             }
         }

@@ -1436,6 +1436,35 @@ __global__ __launch_bounds__(64) void gp_composite_bwd_depth_kernel(CB_ARGS) {
     gp_composite_bwd_body<true, GP_BWD_ROWS, GP_BWD_COLS>(d, ranges, point_list, qmask, rec, pp, g_mean2D, g_conic, g_opacity, g_color, g_depth, order);
 }
 
+// Adam on the workgroup's span of SH-rest coefficients, gradients taken from LDS (instead of unstage_sh + a later pass of the
+// optimizer kernel over the same 180 B per Gaussian: the gradient is neither written nor read back, the coefficients are still in L2)
+template <int CNT>
+__device__ __forceinline__ void adam_unstage_sh(const float* s_sh, const AdamFuseDev& af, size_t off, int nblk, int tid) {
+    constexpr int STRIDE = CNT | 1;
+    const int total = nblk * CNT;
+    float* __restrict__ p = af.p_rest + off; float* __restrict__ m = af.m_rest + off; float* __restrict__ v = af.v_rest + off;
+    for (int e = tid * 4; e < total; e += 1024) {
+        float g[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int idx = e + u;
+            const int gi = idx / CNT, k = idx - gi * CNT;
+            g[u] = (idx < total) ? s_sh[gi * STRIDE + k] : 0.f;
+        }
+        if (e + 3 < total) {
+            float4 pv = *(const float4*)(p + e), mv = *(const float4*)(m + e), vv = *(const float4*)(v + e);
+            float* pp = (float*)&pv; float* mm = (float*)&mv; float* vq = (float*)&vv;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) gp_adam_update(pp[u], g[u], mm[u], vq[u], af.b1, af.b2, af.eps, af.step_rest, af.bc2_sqrt);
+            *(float4*)(p + e) = pv; *(float4*)(m + e) = mv; *(float4*)(v + e) = vv;
+        } else {
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (e + u < total) gp_adam_update(p[e + u], g[u], m[e + u], v[e + u], af.b1, af.b2, af.eps, af.step_rest, af.bc2_sqrt);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // preprocess backward (per Gaussian) -- mirrors gpo_preprocess_bwd of the oracle
 // ------------------------------------------------------------------------------------------------
@@ -1449,7 +1478,7 @@ __device__ __forceinline__ void preprocess_bwd_body(
     const float* __restrict__ g_depth, float* __restrict__ dL_dmeans3D, float* __restrict__ dL_dmeans2D,
     float* __restrict__ dL_dshs, float* __restrict__ dL_dshs_rest, float* __restrict__ dL_dcolors,
     float* __restrict__ dL_dopacities, float* __restrict__ dL_dscales, float* __restrict__ dL_drots,
-    float* __restrict__ dL_dcov3D, int accumulate_shs) {
+    float* __restrict__ dL_dcov3D, int accumulate_shs, AdamFuseDev af) {
     __shared__ float s_sh[SH_MODE == 0 ? 1 : 256 * 49];
     const int tid = threadIdx.x;
     const int base = blockIdx.x * 256;
@@ -1681,6 +1710,17 @@ __device__ __forceinline__ void preprocess_bwd_body(
         __syncthreads();
         if (SH_MODE == 1) {
             unstage_sh<48>(s_sh, dL_dshs + (size_t)base * 48, nblk, tid, accumulate_shs != 0);
+        } else if (af.on) {
+            // the optimizer step of the SH coefficients, here: no gradient leaves the kernel (skip: an invalid frame, nothing is touched)
+            if (!(af.skip && *af.skip != 0)) {
+                if (i < d.N) {
+#pragma unroll
+                    for (int k = 0; k < 3; ++k)
+                        gp_adam_update(af.p_dc[3 * (size_t)i + k], dsh_dc[k], af.m_dc[3 * (size_t)i + k], af.v_dc[3 * (size_t)i + k], af.b1, af.b2,
+                                       af.eps, af.step_dc, af.bc2_sqrt);
+                }
+                adam_unstage_sh<45>(s_sh, af, (size_t)base * 45, nblk, tid);
+            }
         } else {
             if (i < d.N) {
                 if (accumulate_shs) { dL_dshs[3 * (size_t)i] += dsh_dc[0]; dL_dshs[3 * (size_t)i + 1] += dsh_dc[1]; dL_dshs[3 * (size_t)i + 2] += dsh_dc[2]; }
@@ -1699,10 +1739,10 @@ __device__ __forceinline__ void preprocess_bwd_body(
     const float* __restrict__ g_color, const float* __restrict__ g_depth, float* __restrict__ dL_dmeans3D, \
     float* __restrict__ dL_dmeans2D, float* __restrict__ dL_dshs, float* __restrict__ dL_dshs_rest, \
     float* __restrict__ dL_dcolors, float* __restrict__ dL_dopacities, float* __restrict__ dL_dscales, \
-    float* __restrict__ dL_drots, float* __restrict__ dL_dcov3D, int accumulate_shs
+    float* __restrict__ dL_drots, float* __restrict__ dL_dcov3D, int accumulate_shs, AdamFuseDev af
 #define PB_PASS d, means3D, scales, rotations, shs, shs_rest, cov3D_precomp, view, proj, campos, radii, clamped, g_mean2D, \
     g_conic, g_opacity, g_color, g_depth, dL_dmeans3D, dL_dmeans2D, dL_dshs, dL_dshs_rest, dL_dcolors, dL_dopacities, \
-    dL_dscales, dL_drots, dL_dcov3D, accumulate_shs
+    dL_dscales, dL_drots, dL_dcov3D, accumulate_shs, af
 __global__ __launch_bounds__(256) void gp_preprocess_bwd_kernel(PB_ARGS) { preprocess_bwd_body<0>(PB_PASS); }
 __global__ __launch_bounds__(256) void gp_preprocess_bwd_sh16_kernel(PB_ARGS) { preprocess_bwd_body<1>(PB_PASS); }
 __global__ __launch_bounds__(256) void gp_preprocess_bwd_split_kernel(PB_ARGS) { preprocess_bwd_body<2>(PB_PASS); }

@@ -69,3 +69,23 @@ def unregister_callback(fn):
 def notify(param):
     for fn in list(_callbacks):
         fn(param)
+
+
+# ---- optimizer step fused into a producer kernel ---------------------------------------------------------------------------
+# A training harness that knows the next backward is the ONLY producer of some leaves' gradients (one view, one rank) can ask the
+# producer to apply the optimizer update itself: arm_fused_update(leaves, payload) before backward; the producer calls
+# take_fused_update(leaves) -- which disarms -- and, if it gets a payload, updates the parameters in place and writes no gradient.
+_fused = {}
+
+
+def arm_fused_update(leaves, payload):
+    _fused[tuple(id(t) for t in leaves)] = payload
+
+
+def take_fused_update(leaves):
+    return _fused.pop(tuple(id(t) for t in leaves), None)
+
+
+def disarm_fused_update(leaves):
+    """True if the update is still armed (no producer took it): the caller runs the ordinary optimizer step for these leaves."""
+    return _fused.pop(tuple(id(t) for t in leaves), None) is not None

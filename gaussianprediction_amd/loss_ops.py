@@ -132,6 +132,18 @@ class FusedAdam:
                     self.items.append((g, view, a, torch.zeros_like(view), torch.zeros_like(view)))
                     self.owner.append(p)
 
+    def fused_payload(self, p_dc, p_rest, skip_flag=None):
+        """What a producer kernel needs to apply THIS optimizer's next step to the SH pair itself (gp_adam_fuse; the caller then
+        runs step(exclude=(p_dc, p_rest))).  None when the pair is not (both) optimized here, sharded, or not in the [N,15,3] layout."""
+        if self.shard is not None or not self.bucket.flat.is_cuda:
+            return None
+        it = {id(p): (g, m, v) for g, p, _, m, v in self.items}
+        if id(p_dc) not in it or id(p_rest) not in it or p_rest.dim() != 3 or p_rest.shape[1] != 15:
+            return None
+        (g0, m0, v0), (g1, m1, v1) = it[id(p_dc)], it[id(p_rest)]
+        return dict(m_dc=m0, v_dc=v0, m_rest=m1, v_rest=v1, lr_dc=float(g0["lr"]), lr_rest=float(g1["lr"]), beta1=float(self.betas[0]),
+                    beta2=float(self.betas[1]), eps=float(self.eps), step=int(self.step_count + 1), skip_flag=skip_flag)
+
     def full_moments(self):
         """{id(param): (exp_avg, exp_avg_sq)} as whole tensors.  Sharded: a COLLECTIVE (every rank must call it)."""
         if self.shard is None:

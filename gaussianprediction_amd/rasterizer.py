@@ -161,7 +161,19 @@ class _RasterizeGaussians(torch.autograd.Function):
             use_sink = has_sh and m16 and sink_sh is not None and (not has_rest or sink_rest is not None) and \
                 sink_sh.shape == shs.shape and (not has_rest or sink_rest.shape == shs_r.shape)
             accumulate = 0
-            if use_sink:
+            # the harness may have asked for the optimizer step of the SH tensors inside this backward (grad_sink.arm_fused_update):
+            # only when the saved inputs ARE the parameters (no cast / copy in between) and the layout is the split one
+            fuse, fuse_c = None, None
+            if has_sh and has_rest and m16 and isinstance(leaf_sh, torch.Tensor) and isinstance(leaf_rest, torch.Tensor) \
+                    and shs.data_ptr() == leaf_sh.data_ptr() and shs_r.data_ptr() == leaf_rest.data_ptr():
+                fuse = grad_sink.take_fused_update((leaf_sh, leaf_rest))
+            if fuse is not None:
+                fuse_c = _lib.AdamFuseC(fuse["m_dc"].data_ptr(), fuse["v_dc"].data_ptr(), fuse["m_rest"].data_ptr(), fuse["v_rest"].data_ptr(),
+                                        fuse["lr_dc"], fuse["lr_rest"], fuse["beta1"], fuse["beta2"], fuse["eps"], fuse["step"],
+                                        fuse["skip_flag"].data_ptr() if fuse.get("skip_flag") is not None else None)
+                use_sink, g_sh, g_shr = False, None, None
+                fuse["taken"] = True
+            elif use_sink:
                 g_sh, g_shr = sink_sh, (sink_rest if has_rest else None)
                 # a sink the optimizer left un-zeroed (grad_sink.mark_stale) is overwritten; mixed states are normalised first
                 st_sh = grad_sink.take_stale(g_sh)
@@ -174,7 +186,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                     if st_r and has_rest:
                         g_shr.zero_()
                     accumulate = 1
-            else:
+            elif fuse is None:
                 for leaf in (leaf_sh, leaf_rest):   # autograd will ACCUMULATE into these: stale contents must not survive
                     if isinstance(leaf, torch.Tensor) and leaf.grad is not None and grad_sink.take_stale(leaf.grad):
                         leaf.grad.zero_()
@@ -186,7 +198,8 @@ class _RasterizeGaussians(torch.autograd.Function):
             g_rot = torch.empty(N, 4, device=device) if has_sr else None
             g_cov = torch.empty(N, 6, device=device) if has_cov else None
             grads = _lib.RasterGradsC(_lib.ptr(g_m3), _lib.ptr(g_m2), _lib.ptr(g_sh), _lib.ptr(g_shr), _lib.ptr(g_col), _lib.ptr(g_op),
-                                      _lib.ptr(g_scl), _lib.ptr(g_rot), _lib.ptr(g_cov), accumulate)
+                                      _lib.ptr(g_scl), _lib.ptr(g_rot), _lib.ptr(g_cov), accumulate,
+                                      C.cast(C.pointer(fuse_c), C.c_void_p) if fuse_c is not None else None)
             alloc = _lib.TorchAllocator(device)
             try:
                 rc = L.gp_raster_backward(C.byref(st), C.byref(inp), C.byref(out), C.byref(saved), _lib.ptr(gc), _lib.ptr(gd),

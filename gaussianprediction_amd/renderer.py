@@ -63,13 +63,17 @@ def _wait_params(pc):
 
 
 def _screenspace_points(pc):
-    # zero tensor whose .grad receives the 2D (screen-space) mean gradients [REF :27-31]
-    p = torch.zeros_like(pc.get_xyz, dtype=pc.get_xyz.dtype, requires_grad=True, device=pc.get_xyz.device) + 0
-    try:
-        p.retain_grad()
-    except Exception:
-        pass
-    return p
+    """Zero tensor whose .grad receives the 2D (screen-space) mean gradients [REF :27-31].  The reference builds
+    `zeros_like(xyz, requires_grad=True) + 0` and retain_grad()s it every frame: two [N,3] kernels, and autograd CLONES the
+    incoming gradient into a retained non-leaf's .grad (a third pass over [N,3]).  Here: a fresh LEAF over one cached block of
+    zeros (nothing ever writes its values; the rasterizer only routes a gradient through it) -- `.grad` is populated the same
+    way and takes the backward's tensor without a copy."""
+    xyz = pc.get_xyz
+    z = getattr(pc, "_screenspace_zeros", None)
+    if z is None or z.shape != xyz.shape or z.device != xyz.device or z.dtype != xyz.dtype:
+        z = torch.zeros_like(xyz, requires_grad=False).detach()
+        pc._screenspace_zeros = z
+    return z.detach().requires_grad_(True)
 
 
 def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=1.0, override_color=None, delta=None,

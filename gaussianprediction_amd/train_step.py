@@ -62,7 +62,7 @@ class TrainStep:
     SPEC_PAD = 4096
 
     def __init__(self, pc, cameras, gt_images, iteration, lambda_dssim=0.2, lrs=None, group=None, fused=True, speculative=False,
-                 overlap_sh_adam=False, batch=1, schedule=False, training_args=None, sharded=None):
+                 overlap_sh_adam=False, batch=1, schedule=False, training_args=None, sharded=None, fuse_sh_adam=True):
         self.pc, self.cameras, self.gt, self.iteration = pc, cameras, gt_images, iteration
         self.lambda_dssim = lambda_dssim
         self.group = group
@@ -87,6 +87,9 @@ class TrainStep:
         # the deformation forward of the next -- but those kernels share the HBM with it and queue behind its 2800
         # workgroups, which costs more than the overlap hides.  Single-process only.
         self.overlap_sh_adam = bool(overlap_sh_adam) and fused and dev.type == "cuda"
+        # single view, single rank: the rasterizer backward applies Adam to the SH coefficients itself (gp_adam_fuse): their gradient
+        # (192 of the 236 B per Gaussian) is never written or read back.  Bit-identical arithmetic to the optimizer kernel.
+        self.fuse_sh_adam = bool(fuse_sh_adam) and fused and dev.type == "cuda" and not self.overlap_sh_adam
         self._side = torch.cuda.Stream(device=dev) if self.overlap_sh_adam else None
         self._sh_early = False
         self._sink_cb = None
@@ -243,6 +246,12 @@ class TrainStep:
         self.reducer.set_late(list(self.bucket.params) if self.batch > 1 else ([pc._xyz] if lifecycle else []))
         if self.overlap_sh_adam and keep and not self.reducer.enabled:
             self._armed, self._keep, self._skip_flag = True, keep, skip_flag
+        sh_pair, fuse = (pc._features_dc, pc._features_rest), None
+        if self.fuse_sh_adam and keep and not self.reducer.enabled and not self.sharded:
+            from . import grad_sink
+            fuse = self.optimizer.fused_payload(sh_pair[0], sh_pair[1], skip_flag)
+            if fuse is not None:
+                grad_sink.arm_fused_update(sh_pair, fuse)
         world = torch.distributed.get_world_size(self.group) if self.reducer.enabled else 1
         losses, pkgs = [], []
         for b in range(self.batch):                  # [REF train.py:101-119]
@@ -252,7 +261,10 @@ class TrainStep:
             losses.append(self.loss_of(pkg["render"], self.gt[v % len(self.gt)]))
             pkgs.append(pkg)
         loss = losses[0] if self.batch == 1 else torch.stack(losses, dim=0).sum()
-        loss.backward()                              # hooks start the all-reduce of each large gradient as it completes
+        seed = getattr(self, "_seed_one", None)      # (autograd would fill a ones_like(loss) every step: one more launch)
+        if seed is None or seed.device != loss.device or seed.dtype != loss.dtype or seed.shape != loss.shape:
+            seed = self._seed_one = torch.ones_like(loss)
+        loss.backward(gradient=seed)                 # hooks start the all-reduce of each large gradient as it completes
         self._armed = False
         self.reducer.finish()                        # SUM over views == the reference's --batch semantics
         if skip_flag is not None and self.reducer.enabled:
@@ -269,7 +281,17 @@ class TrainStep:
             grads = [p["viewspace_points"].grad for p in pkgs if p["viewspace_points"].grad is not None]
             pkg = dict(pkg, radii=radii, visibility_filter=vis,
                        viewspace_point_tensor_grad=torch.stack(grads).sum(0) if grads else None)
-        if self.fused:
+        if fuse is not None:
+            from . import grad_sink
+            if grad_sink.disarm_fused_update(sh_pair):      # no producer took it (e.g. python SH conversion): ordinary step below
+                fuse = None
+            else:                                           # done inside the backward: the (unwritten) gradient buffers are stale
+                for p_ in sh_pair:
+                    if p_.grad is not None:
+                        grad_sink.mark_stale(p_.grad)
+        if self.fused and fuse is not None:
+            self.optimizer.step(zero_grad=True, keep_grad=keep, skip_flag=skip_flag, exclude=sh_pair)
+        elif self.fused:
             if self._sh_early:       # the SH tensors were updated on the side stream during the backward
                 self._sh_early = False
                 self.optimizer.step(zero_grad=True, keep_grad=keep, skip_flag=skip_flag,

@@ -93,6 +93,22 @@ typedef struct gp_raster_saved {
     int64_t num_rendered; /* R = sum of tiles touched (exact mode); the binning capacity in capacity mode */
 } gp_raster_saved;
 
+/* Optional: torch.optim.Adam's step of the SH coefficients applied INSIDE gp_raster_backward (extension; the reference runs
+ * optimizer.step() afterwards, train.py:196).  The preprocess backward holds a workgroup's SH gradients in LDS and the
+ * coefficients are still in L2: updating them there saves writing the gradient (192 B per Gaussian) and reading gradient +
+ * coefficients back in the optimizer kernel.  Same arithmetic as gp_adam_step_multi, bit for bit (one shared device function).
+ * in->shs / in->shs_rest are then UPDATED IN PLACE (they must be the parameters themselves), dL_dshs / dL_dshs_rest are not
+ * written and may be NULL.  skip_flag: optional device word, non-zero = leave parameters and moments untouched. */
+typedef struct gp_adam_fuse {
+    float* exp_avg_dc;       /* [N,1,3]  moments of shs */
+    float* exp_avg_sq_dc;
+    float* exp_avg_rest;     /* [N,15,3] moments of shs_rest */
+    float* exp_avg_sq_rest;
+    float lr_dc, lr_rest, beta1, beta2, eps;
+    int64_t step;            /* 1-based step number of this update */
+    const uint32_t* skip_flag;
+} gp_adam_fuse;
+
 typedef struct gp_raster_grads {
     float* dL_dmeans3D;        /* [N,3] */
     float* dL_dmeans2D;        /* [N,3] (x,y in NDC units, z = 0): the screenspace_points grad sink
@@ -106,6 +122,7 @@ typedef struct gp_raster_grads {
     float* dL_dcov3D_precomp;  /* [N,6] or NULL */
     int32_t accumulate_shs;    /* 1: dL_dshs / dL_dshs_rest are "+=" targets (the parameters' own .grad buffers:
                                   no temporary, no separate accumulate pass over 192 B/Gaussian); 0: "=" */
+    const gp_adam_fuse* adam_shs; /* NULL, or: apply the optimizer step of (shs, shs_rest) in this call (see gp_adam_fuse) */
 } gp_raster_grads;
 
 /* replaces _C.rasterize_gaussians (the forward of GaussianRasterizer). One host sync (reads R). */

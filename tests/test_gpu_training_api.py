@@ -308,6 +308,53 @@ def test_rccl_code_path_on_a_one_rank_group(tmp_path, sharded):
         assert float((diff > 1e-6).float().mean()) < 2e-2 and float(diff.max()) < 0.05 * 4 + 1e-6, (name, float(diff.max()))
 
 
+def test_sh_adam_fused_into_the_backward_equals_the_separate_step():
+    """One view, one rank: the rasterizer backward applies Adam to the SH coefficients itself (gp_adam_fuse; their gradient is never
+    written) and the optimizer launch covers the other tensors.  Parameters and moments must equal the separate-step run up to the
+    run-to-run noise of the backward's float atomics (the arithmetic is one shared device function)."""
+    from gaussianprediction_amd import grad_sink
+    runs = {}
+    for fuse in (True, False):
+        pc, cams, gts, raw, rw, idx, args = build(n=3000)
+        ts = TrainStep(pc, cams, gts, 50000, fuse_sh_adam=fuse)
+        seen = []
+        orig = ts.optimizer.step
+
+        def spy(*a, _orig=orig, _seen=seen, **k):
+            _seen.append(k.get("exclude"))
+            return _orig(*a, **k)
+        ts.optimizer.step = spy
+        d0 = pc._features_rest.detach().clone()
+        for step in range(3):
+            ts.step(step)
+        torch.cuda.synchronize()
+        assert all((e is not None) == fuse for e in seen) and len(seen) == 3
+        if fuse:
+            assert grad_sink.is_stale(pc._features_rest.grad) and grad_sink.is_stale(pc._features_dc.grad)
+        assert not torch.equal(pc._features_rest.detach(), d0)
+        mom = pc.adam_moments()
+        runs[fuse] = (pc, {n: p.detach().clone() for n, p in pc.named_parameters()},
+                      {n: tuple(t.clone() for t in mom[id(p)]) for n, p in pc.named_parameters() if id(p) in mom}, ts.optimizer.step_count)
+    (pa, A, MA, sa), (pb, B, MB, sb) = runs[True], runs[False]
+    assert sa == sb == 3
+    for name in ("_features_dc", "_features_rest", "_xyz", "_opacity"):
+        diff = (A[name] - B[name]).abs()
+        assert float((diff > 1e-6).float().mean()) < 2e-2, (name, float(diff.max()))
+        for k in range(2):
+            a, b = MA[name][k], MB[name][k]
+            assert float((a - b).norm() / b.norm().clamp_min(1e-30)) < 1e-3, (name, k)
+    # a later ordinary backward (no harness) must not accumulate into the stale buffers
+    pc = pa
+    pipe = SimpleNamespace(convert_SHs_python=False, compute_cov3D_python=False, debug=False)
+    pkg = gpa.render(cams[0], pc, pipe, torch.zeros(3, device="cuda"), time=torch.tensor([0.3], device="cuda"), it=50000)
+    pkg["render"].sum().backward()
+    g1 = pc._features_rest.grad.clone()
+    pc._features_rest.grad.zero_(); pc._features_dc.grad.zero_()
+    pkg = gpa.render(cams[0], pc, pipe, torch.zeros(3, device="cuda"), time=torch.tensor([0.3], device="cuda"), it=50000)
+    pkg["render"].sum().backward()
+    assert float((g1 - pc._features_rest.grad).norm() / pc._features_rest.grad.norm().clamp_min(1e-30)) < 1e-4
+
+
 def test_stage_transitions_and_teaching_path_inside_forward():
     """The reference switches stages INSIDE forward [REF scene/gaussian_model.py:246-250]: at second_stage_iter + 1 the keypoints are
     initialised by k-means and the stage-2 optimizer is built, at third_stage_iter + 1 the stage-3 one; with densify_from_teaching the
