@@ -689,6 +689,18 @@ __device__ __forceinline__ void softmax_n(const float* __restrict__ raw, int n, 
     for (int k = 0; k < n; ++k) w[k] *= inv;
 }
 
+// one Gaussian's 2*NN raw weights and NN neighbour ids with 16-byte loads (rows are 48 / 64 B: aligned whenever the tensors are)
+template <int NN>
+__device__ __forceinline__ void load_row_nn(const BlendDev& a, long i, float (&raw)[2 * NN], int (&kps)[NN]) {
+    const float4* r4 = (const float4*)(a.raw_w + i * 2 * NN);
+#pragma unroll
+    for (int u = 0; u < 2 * NN / 4; ++u) { const float4 t = r4[u]; raw[4 * u] = t.x; raw[4 * u + 1] = t.y; raw[4 * u + 2] = t.z; raw[4 * u + 3] = t.w; }
+    typedef long long ll2 __attribute__((ext_vector_type(2)));
+    const ll2* k2 = (const ll2*)(a.knn + i * NN);
+#pragma unroll
+    for (int u = 0; u < NN / 2; ++u) { const ll2 t = k2[u]; kps[2 * u] = (int)t.x; kps[2 * u + 1] = (int)t.y; }
+}
+
 // NN > 0: compile-time neighbour count (loops unroll, the nn gathers are issued together);
 // NN == 0: run-time a.nn (including the stage-1 case a.nn == 0)
 template <int NN>
@@ -700,11 +712,19 @@ __device__ __forceinline__ void blend_fwd_body(BlendDev a, float* __restrict__ x
     const int nn = NN > 0 ? NN : a.nn;
     if (nn > 0) {
         float wx[NN > 0 ? NN : GP_MAX_NN], wr[NN > 0 ? NN : GP_MAX_NN];
-        softmax_n(a.raw_w + i * 2 * nn, nn, wx);
-        softmax_n(a.raw_w + i * 2 * nn + nn, nn, wr);
+        int kpv[NN > 0 ? NN : 1];
+        if constexpr (NN > 0) {
+            float raw[2 * (NN > 0 ? NN : 1)];
+            load_row_nn<NN>(a, i, raw, kpv);
+            softmax_n(raw, NN, wx);
+            softmax_n(raw + NN, NN, wr);
+        } else {
+            softmax_n(a.raw_w + i * 2 * nn, nn, wx);
+            softmax_n(a.raw_w + i * 2 * nn + nn, nn, wr);
+        }
 #pragma unroll
         for (int k = 0; k < nn; ++k) {
-            const long kp = a.knn[i * nn + k];
+            const long kp = NN > 0 ? (long)kpv[NN > 0 ? k : 0] : a.knn[i * nn + k];
             const float* dl = a.delta + kp * od;
             dxyz[0] = fmaf(wx[k], dl[0], dxyz[0]);
             dxyz[1] = fmaf(wx[k], dl[1], dxyz[1]);
@@ -791,11 +811,18 @@ __device__ __forceinline__ void blend_bwd_body(BlendDev a, const float* __restri
             float wx[NN > 0 ? NN : GP_MAX_NN], wr[NN > 0 ? NN : GP_MAX_NN];
             float dq[4] = {0.f, 0.f, 0.f, 0.f};
             if (nn > 0) {
-                softmax_n(a.raw_w + i * 2 * nn, nn, wx);
-                softmax_n(a.raw_w + i * 2 * nn + nn, nn, wr);
+                if constexpr (NN > 0) {
+                    float raw[2 * (NN > 0 ? NN : 1)];
+                    load_row_nn<NN>(a, i, raw, kps);
+                    softmax_n(raw, NN, wx);
+                    softmax_n(raw + NN, NN, wr);
+                } else {
+                    softmax_n(a.raw_w + i * 2 * nn, nn, wx);
+                    softmax_n(a.raw_w + i * 2 * nn + nn, nn, wr);
+                }
 #pragma unroll
                 for (int k = 0; k < nn; ++k) {
-                    kps[k] = (int)a.knn[i * nn + k];
+                    if (NN == 0) kps[k] = (int)a.knn[i * nn + k];
                     const float* dl = s_delta + kps[k] * od;
                     float v[4] = {dl[3], dl[4], dl[5], dl[6]};
                     if (a.norm_rotation) { const float inv = 1.f / norm4(v); v[0] *= inv; v[1] *= inv; v[2] *= inv; v[3] *= inv; }
@@ -841,10 +868,20 @@ __device__ __forceinline__ void blend_bwd_body(BlendDev a, const float* __restri
                     s_w[tid * 2 * nn + nn + k] = wr[k];
                     rk[k] = atomicAdd(&s_cnt[kps[k]], 1);          // rank of this entry within its keypoint
                 }
+                if (g_raw_w) {        // (NULL: the weights are inputs without a gradient, 8 nn bytes per Gaussian not written)
+                    if constexpr (NN > 0) {
+                        float go[2 * (NN > 0 ? NN : 1)];
 #pragma unroll
-                for (int k = 0; k < nn; ++k) {
-                    g_raw_w[i * 2 * nn + k] = wx[k] * (gwx[k] - sx);
-                    g_raw_w[i * 2 * nn + nn + k] = wr[k] * (gwr[k] - sr);
+                        for (int k = 0; k < NN; ++k) { go[k] = wx[k] * (gwx[k] - sx); go[NN + k] = wr[k] * (gwr[k] - sr); }
+                        float4* o4 = (float4*)(g_raw_w + i * 2 * NN);
+#pragma unroll
+                        for (int u = 0; u < 2 * NN / 4; ++u) o4[u] = make_float4(go[4 * u], go[4 * u + 1], go[4 * u + 2], go[4 * u + 3]);
+                    } else {
+                        for (int k = 0; k < nn; ++k) {
+                            g_raw_w[i * 2 * nn + k] = wx[k] * (gwx[k] - sx);
+                            g_raw_w[i * 2 * nn + nn + k] = wr[k] * (gwr[k] - sr);
+                        }
+                    }
                 }
                 float* sg = s_g + tid * 8;
                 sg[0] = gx[0]; sg[1] = gx[1]; sg[2] = gx[2]; sg[3] = gdq[0]; sg[4] = gdq[1]; sg[5] = gdq[2]; sg[6] = gdq[3];
@@ -945,7 +982,10 @@ __global__ __launch_bounds__(256) void gp_blend_bwd_reduce_kernel(const float* _
     }
     s_r[wave][lane] = (v0 + v1) + (v2 + v3);
     __syncthreads();
-    if (wave == 0 && e < KA) g_delta[(size_t)(e / 7) * od + (e % 7)] = (s_r[0][lane] + s_r[1][lane]) + (s_r[2][lane] + s_r[3][lane]);
+    if (wave == 0 && e < KA) {
+        g_delta[(size_t)(e / 7) * od + (e % 7)] = (s_r[0][lane] + s_r[1][lane]) + (s_r[2][lane] + s_r[3][lane]);
+        if (e % 7 == 6) for (int c = 7; c < od; ++c) g_delta[(size_t)(e / 7) * od + c] = 0.f;   // (the whole row is written: no zero-fill by the caller)
+    }
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -149,7 +149,8 @@ extern "C" int gp_blend_forward(const gp_blend_args* a, float* xyz_t, float* q_t
     if (b.N == 0) return 0;
     if (!xyz_t || !q_t) GP_FAIL("null output");
     { GpProfScope _p("blend_fwd", (hipStream_t)stream_);
-        hipLaunchKernelGGL(b.nn == 6 ? gp_blend_fwd6_kernel : b.nn == 8 ? gp_blend_fwd8_kernel : gp_blend_fwd_kernel,
+        const bool al = (((uintptr_t)b.raw_w | (uintptr_t)b.knn) & 15) == 0;      // the fixed-nn kernels use 16-byte row loads
+        hipLaunchKernelGGL(b.nn == 6 && al ? gp_blend_fwd6_kernel : b.nn == 8 && al ? gp_blend_fwd8_kernel : gp_blend_fwd_kernel,
                        dim3(gp_blocks((size_t)b.N, 256)), dim3(256), 0, (hipStream_t)stream_, b, xyz_t, q_t);
     GP_LAUNCH_CHECK(); }
     return 0;
@@ -161,7 +162,7 @@ extern "C" int gp_blend_backward(const gp_blend_args* a, const float* dL_dxyz_t,
     BlendDev b;
     if (make_blend(a, b)) return 1;
     if (b.N == 0) return 0;
-    if (!dL_dxyz_t || !dL_dq_t || !dL_ddelta || !dL_dxyz || !dL_drot || (b.nn > 0 && !dL_draw_w)) GP_FAIL("null argument");
+    if (!dL_dxyz_t || !dL_dq_t || !dL_ddelta || !dL_dxyz || !dL_drot) GP_FAIL("null argument");     // dL_draw_w may be NULL
     unsigned blocks = gp_blocks((size_t)b.N, 256);
     if (b.nn > 0 && blocks > 512) blocks = 512;   // measured: 256-512 workgroups minimise partial-buffer traffic
     // acc[K*7] | delta[K*od] | cnt[K] | base[K+1] | g[256*8] | w[256*2*nn] | sorted u16 [256*nn]
@@ -175,7 +176,8 @@ extern "C" int gp_blend_backward(const gp_blend_args* a, const float* dL_dxyz_t,
         if (!partial) GP_FAIL("allocator returned NULL for TEMP");
     }
     { GpProfScope _p("blend_bwd", (hipStream_t)stream_);
-    hipLaunchKernelGGL(b.nn == 6 ? gp_blend_bwd6_kernel : b.nn == 8 ? gp_blend_bwd8_kernel : gp_blend_bwd_kernel,
+    const bool al = (((uintptr_t)b.raw_w | (uintptr_t)b.knn | (uintptr_t)dL_draw_w) & 15) == 0;
+    hipLaunchKernelGGL(b.nn == 6 && al ? gp_blend_bwd6_kernel : b.nn == 8 && al ? gp_blend_bwd8_kernel : gp_blend_bwd_kernel,
                        dim3(blocks), dim3(256), lds, (hipStream_t)stream_, b, dL_dxyz_t, dL_dq_t, dL_ddelta,
                        dL_draw_w, dL_dxyz, dL_drot, partial);
     GP_LAUNCH_CHECK();

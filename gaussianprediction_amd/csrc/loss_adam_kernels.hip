@@ -127,11 +127,17 @@ __global__ __launch_bounds__(256) void gp_l1_ssim_fwd_kernel(const float* __rest
 __global__ __launch_bounds__(256) void gp_l1_ssim_bwd_kernel(const float* __restrict__ img, const float* __restrict__ gt,
                                                             const float* __restrict__ dmap, int H, int W, Win11 win,
                                                             float lambda, const float* __restrict__ upstream,
-                                                            float* __restrict__ dimg) {
+                                                            float* __restrict__ dimg, const float* __restrict__ reg_x, long reg_n,
+                                                            float reg_scale_over_n, float* __restrict__ reg_g) {
     __shared__ float s_m[3][LE][LP];
     __shared__ float s_h[3][LE][LHP];
     const int tid = threadIdx.x;
     const int tx0 = blockIdx.x * LT, ty0 = blockIdx.y * LT, ch = blockIdx.z;
+    if (reg_g && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) {
+        // gradient of the regulariser scale * mean|x| riding along (a few thousand elements: not worth a launch of its own)
+        const float c = (upstream ? upstream[0] : 1.f) * reg_scale_over_n;
+        for (long i = tid; i < reg_n; i += 256) { const float v = reg_x[i]; reg_g[i] = v > 0.f ? c : (v < 0.f ? -c : 0.f); }
+    }
     const size_t HW = (size_t)H * W;
     for (int i = tid; i < LE * LE; i += 256) {
         const int y = i / LE, x = i - y * LE;
@@ -295,6 +301,21 @@ __global__ void gp_loss_finalize_kernel(const double* __restrict__ sums, double 
     loss[0] = (float)((1.0 - (double)lambda) * s0 / n + (double)lambda * (1.0 - s1 / n));
 }
 
+// the same + scale/n * sum|x| (one workgroup; fixed summation order)
+__global__ __launch_bounds__(256) void gp_loss_finalize_reg_kernel(const double* __restrict__ sums, double n, float lambda,
+                                                                  const float* __restrict__ x, long nx, float scale_over_n,
+                                                                  float* __restrict__ loss) {
+    __shared__ float s_red[4];
+    float acc = 0.f;
+    for (long i = threadIdx.x; i < nx; i += 256) acc += fabsf(x[i]);
+    const float tot = block_sum_256(acc, s_red);
+    if (threadIdx.x == 0) {
+        double s0 = 0.0, s1 = 0.0;
+        for (int k = 0; k < GP_LOSS_SUM_SLOTS; ++k) { s0 += sums[2 * k]; s1 += sums[2 * k + 1]; }
+        loss[0] = (float)((1.0 - (double)lambda) * s0 / n + (double)lambda * (1.0 - s1 / n)) + tot * scale_over_n;
+    }
+}
+
 // out[0] = base[0] + scale * mean|x|   [REF scene/gaussian_model.py:174-178: 1e-5 * mean(|motion feature|)]
 // (multi-block: out is initialised by block 0's thread 0 through the host-side memset + base add)
 __global__ __launch_bounds__(256) void gp_l1_mean_fwd_kernel(const float* __restrict__ x, long n, float scale_over_n,
@@ -355,7 +376,33 @@ extern "C" int gp_loss_l1_ssim_backward(const float* img, const float* gt, const
     if (channels != 3 || H <= 0 || W <= 0) GP_FAIL("expects a [3,H,W] image");
     GpProfScope _p("l1_ssim_bwd", s);
     hipLaunchKernelGGL(gp_l1_ssim_bwd_kernel, dim3((W + LT - 1) / LT, (H + LT - 1) / LT, 3), dim3(256), 0, s, img, gt, dmaps, H, W,
-                       make_window(), lambda_dssim, upstream, dimg);
+                       make_window(), lambda_dssim, upstream, dimg, (const float*)nullptr, 0L, 0.f, (float*)nullptr);
+    GP_LAUNCH_CHECK();
+    return 0;
+}
+
+// the two calls above with the regulariser  scale * mean|x|  [REF scene/gaussian_model.py:174-178] folded in (x small: the
+// keypoint features of stage 2/3) -- saves the regulariser's own forward and backward launches
+#define GP_LOSS_REG_MAX 65536
+extern "C" int gp_loss_l1_ssim_finalize_reg(const double* sums, int32_t channels, int32_t H, int32_t W, float lambda_dssim,
+                                            const float* x, int64_t n, float scale, float* loss, gp_stream_t stream_) {
+    if (!sums || !loss || !x) GP_FAIL("null argument");
+    if (n <= 0 || n > GP_LOSS_REG_MAX) GP_FAIL("regulariser input must have 1..%d elements (use gp_l1_mean_forward beyond)", GP_LOSS_REG_MAX);
+    hipLaunchKernelGGL(gp_loss_finalize_reg_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream_, sums, (double)channels * H * W, lambda_dssim,
+                       x, (long)n, scale / (float)n, loss);
+    GP_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int gp_loss_l1_ssim_backward_reg(const float* img, const float* gt, const float* dmaps, int32_t channels, int32_t H, int32_t W,
+                                            float lambda_dssim, const float* upstream, float* dimg, const float* x, int64_t n,
+                                            float scale, float* gx, gp_stream_t stream_) {
+    hipStream_t s = (hipStream_t)stream_;
+    if (!img || !gt || !dmaps || !dimg || !x || !gx) GP_FAIL("null argument");
+    if (channels != 3 || H <= 0 || W <= 0) GP_FAIL("expects a [3,H,W] image");
+    if (n <= 0 || n > GP_LOSS_REG_MAX) GP_FAIL("regulariser input must have 1..%d elements", GP_LOSS_REG_MAX);
+    GpProfScope _p("l1_ssim_bwd", s);
+    hipLaunchKernelGGL(gp_l1_ssim_bwd_kernel, dim3((W + LT - 1) / LT, (H + LT - 1) / LT, 3), dim3(256), 0, s, img, gt, dmaps, H, W,
+                       make_window(), lambda_dssim, upstream, dimg, x, (long)n, scale / (float)n, gx);
     GP_LAUNCH_CHECK();
     return 0;
 }

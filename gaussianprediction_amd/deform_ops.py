@@ -284,8 +284,8 @@ class KeypointBlend(torch.autograd.Function):
         args = _lib.BlendArgsC(N, K, nn_, delta_c.shape[1], norm_rotation, delta_c.data_ptr(),
                                raw_c.data_ptr() if nn_ else None, idx_c.data_ptr() if nn_ else None, xyz_c.data_ptr(),
                                rot_c.data_ptr())
-        g_delta = torch.zeros_like(delta_c)
-        g_raw = torch.empty_like(raw_c) if nn_ else None
+        g_delta = torch.empty_like(delta_c)          # every element is written (stage 1: per row; stage 2/3: by the reduction)
+        g_raw = torch.empty_like(raw_c) if (nn_ and ctx.needs_input_grad[1]) else None    # frozen weights: not computed
         # a leaf whose gradient buffer the optimizer left stale is OVERWRITTEN in place (no temporary + AccumulateGrad pass)
         sinks = [_overwrite_sink(t_) for t_ in ctx.leaves]
         g_xyz = sinks[0] if sinks[0] is not None else torch.empty(N, 3, device=dev)

@@ -14,8 +14,11 @@ from . import _lib
 
 
 class L1SSIMLoss(torch.autograd.Function):
+    """(1 - lambda) L1 + lambda (1 - SSIM) [+ reg_scale * mean|reg_x|: the motion-feature regulariser of
+    [REF scene/gaussian_model.py:174-178] folded into the same launches when reg_x is small (<= 65536 elements)]."""
+
     @staticmethod
-    def forward(ctx, image, gt, lambda_dssim):
+    def forward(ctx, image, gt, lambda_dssim, reg_x=None, reg_scale=0.0):
         if not image.is_cuda:
             raise RuntimeError("L1SSIMLoss: HIP kernels only (no CPU fallback)")
         dev = image.device
@@ -25,7 +28,7 @@ class L1SSIMLoss(torch.autograd.Function):
             raise RuntimeError("L1SSIMLoss expects two [3,H,W] images")
         _, H, W = img.shape
         sums = torch.empty(2 * _lib.GP_LOSS_SUM_SLOTS, dtype=torch.float64, device=dev)
-        need = image.requires_grad
+        need = image.requires_grad or (reg_x is not None and reg_x.requires_grad)
         dmaps = torch.empty(3, 3, H, W, device=dev) if need else None
         with _lib.on_device(dev):
             rc = _lib.lib().gp_loss_l1_ssim_forward(_lib.ptr(img), _lib.ptr(g), C.c_int32(3), C.c_int32(H), C.c_int32(W),
@@ -33,29 +36,44 @@ class L1SSIMLoss(torch.autograd.Function):
             _lib.check(rc, "gp_loss_l1_ssim_forward")
         lam = float(lambda_dssim)
         loss_t = torch.empty(1, dtype=torch.float32, device=dev)
+        xc = reg_x.detach().to(torch.float32).contiguous() if reg_x is not None else None
         with _lib.on_device(dev):
-            rc = _lib.lib().gp_loss_l1_ssim_finalize(_lib.ptr(sums), C.c_int32(3), C.c_int32(H), C.c_int32(W), C.c_float(lam),
-                                                     _lib.ptr(loss_t), _lib.stream_ptr(dev))
+            if xc is None:
+                rc = _lib.lib().gp_loss_l1_ssim_finalize(_lib.ptr(sums), C.c_int32(3), C.c_int32(H), C.c_int32(W), C.c_float(lam),
+                                                         _lib.ptr(loss_t), _lib.stream_ptr(dev))
+            else:
+                rc = _lib.lib().gp_loss_l1_ssim_finalize_reg(_lib.ptr(sums), C.c_int32(3), C.c_int32(H), C.c_int32(W), C.c_float(lam),
+                                                             _lib.ptr(xc), C.c_int64(xc.numel()), C.c_float(float(reg_scale)),
+                                                             _lib.ptr(loss_t), _lib.stream_ptr(dev))
             _lib.check(rc, "gp_loss_l1_ssim_finalize")
         loss = loss_t.reshape(())
         if need:
-            ctx.save_for_backward(img, g, dmaps)
-            ctx.lam = lam
+            ctx.save_for_backward(img, g, dmaps, xc if xc is not None else torch.empty(0, device=dev))
+            ctx.lam, ctx.reg = lam, (float(reg_scale), reg_x.shape) if xc is not None else None
         return loss
 
     @staticmethod
     def backward(ctx, grad_out):
-        img, g, dmaps = ctx.saved_tensors
+        img, g, dmaps, xc = ctx.saved_tensors
         dev = img.device
         _, H, W = img.shape
         up = grad_out.detach().to(torch.float32).reshape(1).contiguous()
         dimg = torch.empty_like(img)
+        gx = None
         with _lib.on_device(dev):
-            rc = _lib.lib().gp_loss_l1_ssim_backward(_lib.ptr(img), _lib.ptr(g), _lib.ptr(dmaps), C.c_int32(3), C.c_int32(H),
-                                                     C.c_int32(W), C.c_float(ctx.lam), _lib.ptr(up), _lib.ptr(dimg),
-                                                     _lib.stream_ptr(dev))
+            if ctx.reg is None:
+                rc = _lib.lib().gp_loss_l1_ssim_backward(_lib.ptr(img), _lib.ptr(g), _lib.ptr(dmaps), C.c_int32(3), C.c_int32(H),
+                                                         C.c_int32(W), C.c_float(ctx.lam), _lib.ptr(up), _lib.ptr(dimg),
+                                                         _lib.stream_ptr(dev))
+            else:
+                gx = torch.empty_like(xc)
+                rc = _lib.lib().gp_loss_l1_ssim_backward_reg(_lib.ptr(img), _lib.ptr(g), _lib.ptr(dmaps), C.c_int32(3), C.c_int32(H),
+                                                             C.c_int32(W), C.c_float(ctx.lam), _lib.ptr(up), _lib.ptr(dimg), _lib.ptr(xc),
+                                                             C.c_int64(xc.numel()), C.c_float(ctx.reg[0]), _lib.ptr(gx),
+                                                             _lib.stream_ptr(dev))
+                gx = gx.reshape(ctx.reg[1])
             _lib.check(rc, "gp_loss_l1_ssim_backward")
-        return dimg, None, None
+        return dimg, None, None, gx, None
 
 
 class _AddL1Mean(torch.autograd.Function):
@@ -91,8 +109,16 @@ def add_l1_mean(loss, x, scale):
     return _AddL1Mean.apply(loss, x, scale)
 
 
-def l1_ssim_loss(image, gt, lambda_dssim=0.2):
-    return L1SSIMLoss.apply(image, gt, lambda_dssim)
+GP_LOSS_REG_MAX = 65536
+
+
+def l1_ssim_loss(image, gt, lambda_dssim=0.2, reg_x=None, reg_scale=0.0):
+    """reg_x (optional): + reg_scale * mean|reg_x| -- in the same launches when it is small, through add_l1_mean otherwise."""
+    if reg_x is None:
+        return L1SSIMLoss.apply(image, gt, lambda_dssim)
+    if reg_x.numel() <= GP_LOSS_REG_MAX:
+        return L1SSIMLoss.apply(image, gt, lambda_dssim, reg_x, reg_scale)
+    return add_l1_mean(L1SSIMLoss.apply(image, gt, lambda_dssim), reg_x, reg_scale)
 
 
 class FusedAdam:

@@ -183,11 +183,10 @@ class TrainStep:
 
     def loss_of(self, image, gt):
         if self.fused:
-            loss = l1_ssim_loss(image, gt, self.lambda_dssim)
             if self.iteration >= self.pc.args.jointly_iteration:            # [REF scene/gaussian_model.py:174-178]
                 feat = self.pc.super_gaussians_feature if self.iteration > self.pc.second_stage_iter else self.pc.motion_feature
-                return add_l1_mean(loss, feat, 1.0e-5)
-            return loss
+                return l1_ssim_loss(image, gt, self.lambda_dssim, feat, 1.0e-5)
+            return l1_ssim_loss(image, gt, self.lambda_dssim)
         else:
             Ll1 = l1_loss(image, gt)
             loss = (1.0 - self.lambda_dssim) * Ll1 + self.lambda_dssim * (1.0 - ssim(image, gt, self.window))

@@ -237,9 +237,9 @@ typedef struct gp_blend_args {
 
 int gp_blend_forward(const gp_blend_args* a, float* xyz_t /*[N,3]*/, float* q_t /*[N,4]*/, gp_stream_t stream);
 
-/* grads (all "="): d delta, d raw_w, d xyz, d rot.  With nn>0 the keypoint gradient is reduced in two
- * deterministic stages (per-workgroup LDS partials, then a sum over workgroups); the caller zeroes
- * dL_ddelta beforehand (columns >= 7 are never written). */
+/* grads (all "="): d delta, d raw_w (may be NULL: weights without a gradient), d xyz, d rot.  With nn>0 the keypoint gradient
+ * is reduced in two deterministic stages (per-workgroup LDS partials, then a sum over workgroups); every element of
+ * dL_ddelta is written (columns >= 7 with zeros). */
 int gp_blend_backward(const gp_blend_args* a, const float* dL_dxyz_t, const float* dL_dq_t, float* dL_ddelta,
                       float* dL_draw_w, float* dL_dxyz, float* dL_drot, gp_alloc_fn alloc, void* alloc_ctx,
                       gp_stream_t stream);
@@ -271,6 +271,15 @@ int gp_loss_l1_ssim_finalize(const double* sums, int32_t channels, int32_t H, in
 /* dimg = upstream[0] * d loss / d img  (upstream: device scalar, NULL = 1). */
 int gp_loss_l1_ssim_backward(const float* img, const float* gt, const float* dmaps, int32_t channels, int32_t H, int32_t W,
                              float lambda_dssim, const float* upstream, float* dimg, gp_stream_t stream);
+
+/* finalize / backward with the regulariser  scale * mean(|x|)  folded in (n <= 65536: the keypoint features of stage 2/3;
+ * [REF scene/gaussian_model.py:174-178, train.py:108-109]):  loss[0] = the finalize value + scale * mean|x|;
+ * gx = upstream[0] * scale/n * sign(x) written by the backward launch. */
+int gp_loss_l1_ssim_finalize_reg(const double* sums, int32_t channels, int32_t H, int32_t W, float lambda_dssim, const float* x,
+                                 int64_t n, float scale, float* loss, gp_stream_t stream);
+int gp_loss_l1_ssim_backward_reg(const float* img, const float* gt, const float* dmaps, int32_t channels, int32_t H, int32_t W,
+                                 float lambda_dssim, const float* upstream, float* dimg, const float* x, int64_t n, float scale,
+                                 float* gx, gp_stream_t stream);
 
 /* out[0] = base[0] + scale * mean(|x|): the motion-feature regulariser added to the loss
  * [REF scene/gaussian_model.py:174-178, train.py:108-109]; g = upstream[0] * scale/n * sign(x). */
