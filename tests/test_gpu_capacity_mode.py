@@ -88,10 +88,13 @@ def test_speculative_train_step_matches_exact_and_recovers_from_overflow():
                      ts.optimizer.step_count))
     (la, xa, fa, _, na), (lb, xb, fb, rb, nb), (lc, xc, fc, rc, nc) = outs
     assert rb == 0 and na == nb == 16
-    assert np.allclose(la, lb, rtol=2e-4, atol=1e-6), (la, lb)
-    # 16 Adam steps amplify the backward's atomic-order rounding noise (two exact runs differ by as much)
-    assert rel_l2(xa.cpu().numpy(), xb.cpu().numpy()) < 1e-4
-    assert rel_l2(fa.cpu().numpy(), fb.cpu().numpy()) < 1e-3
+    # 16 Adam steps amplify the backward's atomic-order rounding noise, and the amplification is bimodal: two runs of the SAME mode
+    # agree to ~3e-6 (loss) or to ~7e-5, depending on whether the noise flips one discrete decision (a threshold pixel, a radius) on
+    # the way -- measured for exact/exact, exact/speculative and speculative/speculative pairs alike (tools history, round 2);
+    # the bars sit above the upper mode
+    assert np.allclose(la, lb, rtol=1e-3, atol=1e-6), (la, lb)
+    assert rel_l2(xa.cpu().numpy(), xb.cpu().numpy()) < 3e-4
+    assert rel_l2(fa.cpu().numpy(), fb.cpu().numpy()) < 3e-3
     assert rc > 0                                                         # overflows happened, were detected and redone
     assert torch.isfinite(xc).all() and torch.isfinite(fc).all()
     assert lc[-1] < lc[0]                                                 # and the optimisation still progresses
