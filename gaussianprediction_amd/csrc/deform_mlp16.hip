@@ -916,9 +916,11 @@ __device__ __forceinline__ void mlp16_bwd_weight_lds_body(W16Jobs jobs, W16Shape
     __shared__ T s_st[2][2][8][512];                           // [buffer][dZ | H][fragment of 32 features][16 rows x 32] = 32 KB
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, j = lane & 31;
     const int wo = wave / WI, wi = wave % WI;
-    const W16Job job = jobs.j[blockIdx.y];
+    // grid = (jobs, row slabs), jobs fastest: the workgroups that read the same slab (the three terms of a split-mode layer share
+    // dZ-hi and H-hi) are dispatched back to back, so the repeats are served by the Infinity Cache, not HBM
+    const W16Job job = jobs.j[blockIdx.x];
     const float inv_scale = (UsesScale<T>::v ? 1.f / grad_scale_from(absmax_bits) : 1.f) * job.mul;
-    const long kb0 = (long)blockIdx.x * kb_per_slab;
+    const long kb0 = (long)blockIdx.y * kb_per_slab;
     long kb1 = kb0 + kb_per_slab;
     if (kb1 > n_kb) kb1 = n_kb;
     const long nk = kb1 - kb0;
@@ -948,7 +950,7 @@ __device__ __forceinline__ void mlp16_bwd_weight_lds_body(W16Jobs jobs, W16Shape
     if (nk > 0) w16_group<T, V8, OT, IT, WI>(gq, acc, bsum, s_st, gz, gh, okz, okh, 0, nk, kstride_z, kstride_h, wave, lane, wo, wi, frag_off);
     for (long k0 = W16_DEPTH; k0 < nk; k0 += W16_DEPTH)
         w16_group<T, V8, OT, IT, WI>(gq, acc, bsum, s_st, gz, gh, okz, okh, k0, nk, kstride_z, kstride_h, wave, lane, wo, wi, frag_off);
-    const bool single = gridDim.x == 1 && !sh.shared;
+    const bool single = gridDim.y == 1 && !sh.shared;
 #pragma unroll
     for (int uo = 0; uo < OT; ++uo)
 #pragma unroll
@@ -1142,13 +1144,13 @@ extern "C" int gp_mlp16_backward(const gp_mlp16_params* p /* w16 = TRANSPOSED co
         const W16Shape sh_mid{256, 256, 256, 256, 256, NS * 256, NS * 256, split}, sh_first{256, m.in_pad, 256, m.in_dim, m.in_dim, NS * 256, NS * m.in_pad, split},
             sh_last{16, 256, m.out_dim, 256, 256, NS * 16, NS * 256, split};
         if (f16) {
-            hipLaunchKernelGGL((gp_mlp16_bwd_weight_lds_kernel<_Float16, 4, 2, 4>), dim3(gx, 3 * n_terms), dim3(W16_THREADS), 0, s, mid, sh_mid, n_kb, kbs, absmax);
-            hipLaunchKernelGGL((gp_mlp16_bwd_weight_lds_kernel<_Float16, 2, 2, 2>), dim3(gx, n_terms), dim3(W16_THREADS), 0, s, first, sh_first, n_kb, kbs, absmax);
-            hipLaunchKernelGGL((gp_mlp16_bwd_weight_lds_kernel<_Float16, 1, 1, 8>), dim3(gx, n_terms), dim3(W16_THREADS), 0, s, last, sh_last, n_kb, kbs, absmax);
+            hipLaunchKernelGGL((gp_mlp16_bwd_weight_lds_kernel<_Float16, 4, 2, 4>), dim3(3 * n_terms, gx), dim3(W16_THREADS), 0, s, mid, sh_mid, n_kb, kbs, absmax);
+            hipLaunchKernelGGL((gp_mlp16_bwd_weight_lds_kernel<_Float16, 2, 2, 2>), dim3(n_terms, gx), dim3(W16_THREADS), 0, s, first, sh_first, n_kb, kbs, absmax);
+            hipLaunchKernelGGL((gp_mlp16_bwd_weight_lds_kernel<_Float16, 1, 1, 8>), dim3(n_terms, gx), dim3(W16_THREADS), 0, s, last, sh_last, n_kb, kbs, absmax);
         } else {
-            hipLaunchKernelGGL((gp_mlp16_bwd_weight_lds_kernel<__bf16, 4, 2, 4>), dim3(gx, 3), dim3(W16_THREADS), 0, s, mid, sh_mid, n_kb, kbs, absmax);
-            hipLaunchKernelGGL((gp_mlp16_bwd_weight_lds_kernel<__bf16, 2, 2, 2>), dim3(gx, 1), dim3(W16_THREADS), 0, s, first, sh_first, n_kb, kbs, absmax);
-            hipLaunchKernelGGL((gp_mlp16_bwd_weight_lds_kernel<__bf16, 1, 1, 8>), dim3(gx, 1), dim3(W16_THREADS), 0, s, last, sh_last, n_kb, kbs, absmax);
+            hipLaunchKernelGGL((gp_mlp16_bwd_weight_lds_kernel<__bf16, 4, 2, 4>), dim3(3, gx), dim3(W16_THREADS), 0, s, mid, sh_mid, n_kb, kbs, absmax);
+            hipLaunchKernelGGL((gp_mlp16_bwd_weight_lds_kernel<__bf16, 2, 2, 2>), dim3(1, gx), dim3(W16_THREADS), 0, s, first, sh_first, n_kb, kbs, absmax);
+            hipLaunchKernelGGL((gp_mlp16_bwd_weight_lds_kernel<__bf16, 1, 1, 8>), dim3(1, gx), dim3(W16_THREADS), 0, s, last, sh_last, n_kb, kbs, absmax);
         }
         GP_LAUNCH_CHECK();
         return 0;
