@@ -263,7 +263,13 @@ class TrainStep:
         seed = getattr(self, "_seed_one", None)      # (autograd would fill a ones_like(loss) every step: one more launch)
         if seed is None or seed.device != loss.device or seed.dtype != loss.dtype or seed.shape != loss.shape:
             seed = self._seed_one = torch.ones_like(loss)
-        loss.backward(gradient=seed)                 # hooks start the all-reduce of each large gradient as it completes
+        try:
+            loss.backward(gradient=seed)             # hooks start the all-reduce of each large gradient as it completes
+        except BaseException:
+            if fuse is not None:                     # an armed update must not outlive the backward it was meant for
+                from . import grad_sink
+                grad_sink.disarm_fused_update(sh_pair)
+            raise
         self._armed = False
         self.reducer.finish()                        # SUM over views == the reference's --batch semantics
         if skip_flag is not None and self.reducer.enabled:
