@@ -253,20 +253,20 @@ class TrainStep:
                 grad_sink.arm_fused_update(sh_pair, fuse)
         world = torch.distributed.get_world_size(self.group) if self.reducer.enabled else 1
         losses, pkgs = [], []
-        for b in range(self.batch):                  # [REF train.py:101-119]
-            v = view_index * self.batch + b
-            cam = self.cameras[v % len(self.cameras)]
-            pkg = render(cam, pc, self.pipe, self.bg, time=self.times[v % len(self.cameras)], it=self.iteration, binning=binning)
-            losses.append(self.loss_of(pkg["render"], self.gt[v % len(self.gt)]))
-            pkgs.append(pkg)
-        loss = losses[0] if self.batch == 1 else torch.stack(losses, dim=0).sum()
-        seed = getattr(self, "_seed_one", None)      # (autograd would fill a ones_like(loss) every step: one more launch)
-        if seed is None or seed.device != loss.device or seed.dtype != loss.dtype or seed.shape != loss.shape:
-            seed = self._seed_one = torch.ones_like(loss)
         try:
+            for b in range(self.batch):              # [REF train.py:101-119]
+                v = view_index * self.batch + b
+                cam = self.cameras[v % len(self.cameras)]
+                pkg = render(cam, pc, self.pipe, self.bg, time=self.times[v % len(self.cameras)], it=self.iteration, binning=binning)
+                losses.append(self.loss_of(pkg["render"], self.gt[v % len(self.gt)]))
+                pkgs.append(pkg)
+            loss = losses[0] if self.batch == 1 else torch.stack(losses, dim=0).sum()
+            seed = getattr(self, "_seed_one", None)  # (autograd would fill a ones_like(loss) every step: one more launch)
+            if seed is None or seed.device != loss.device or seed.dtype != loss.dtype or seed.shape != loss.shape:
+                seed = self._seed_one = torch.ones_like(loss)
             loss.backward(gradient=seed)             # hooks start the all-reduce of each large gradient as it completes
         except BaseException:
-            if fuse is not None:                     # an armed update must not outlive the backward it was meant for
+            if fuse is not None:                     # an armed update must not outlive the step it was meant for
                 from . import grad_sink
                 grad_sink.disarm_fused_update(sh_pair)
             raise
