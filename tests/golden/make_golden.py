@@ -158,6 +158,32 @@ def main():
     loss.backward()
     np.savez_compressed(os.path.join(OUT, "loss.npz"), img=img.detach().numpy(), gt=gt.numpy(), l1=l1.item(),
                         ssim=ss.item(), loss=loss.item(), dimg=img.grad.numpy())
+    # ---- optimisation defaults + learning-rate schedules (arguments/__init__.py:72-99, utils/general_utils.py:29-62, the five
+    #      schedules of scene/gaussian_model.py training_setup) ------------------------------------------------------------
+    import argparse
+    ar = load_by_path("ref_arguments", "arguments/__init__.py")
+    op = ar.OptimizationParams(argparse.ArgumentParser())
+    defaults = {k: float(v) for k, v in vars(op).items() if isinstance(v, (int, float)) and not isinstance(v, bool)}
+    steps = np.array([0, 1, 10, 100, 500, 1000, 5000, 15000, 29999, 30000, 30001, 45000, 60000, 100000], dtype=np.int64)
+    sched = {}
+    for name, kw in dict(
+            xyz=dict(lr_init=op.position_lr_init * 5.0, lr_final=op.position_lr_final * 5.0, lr_delay_mult=op.position_lr_delay_mult,
+                     max_steps=op.position_lr_max_steps),
+            mlp=dict(lr_init=op.mlp_lr, lr_final=op.position_lr_final, lr_delay_mult=op.position_lr_delay_mult,
+                     max_steps=op.position_lr_max_steps),
+            hash=dict(lr_init=op.hash_lr, lr_final=op.hash_lr_final, lr_delay_steps=op.position_lr_max_steps,
+                      lr_delay_mult=op.position_lr_delay_mult, max_steps=op.position_lr_max_steps),
+            mfeature=dict(lr_init=op.mfeature_lr, lr_final=op.mfeature_lr_final, lr_delay_mult=op.position_lr_delay_mult,
+                          max_steps=op.position_lr_max_steps),
+            plain=dict(lr_init=1e-2, lr_final=1e-4, max_steps=2000), off=dict(lr_init=0.0, lr_final=0.0)).items():
+        f = ns["get_expon_lr_func"](**kw)
+        sched[name] = np.array([f(int(t)) for t in steps], dtype=np.float64)
+        sched[name + "_kw"] = np.array([kw.get("lr_init"), kw.get("lr_final"), kw.get("lr_delay_steps", 0), kw.get("lr_delay_mult", 1.0),
+                                        kw.get("max_steps", 1000000)], dtype=np.float64)
+    xs = np.array([1e-4, 0.01, 0.1, 0.5, 0.9, 0.999], dtype=np.float32)
+    np.savez_compressed(os.path.join(OUT, "training.npz"), steps=steps, default_names=np.array(sorted(defaults)),
+                        default_values=np.array([defaults[k] for k in sorted(defaults)]), inv_sig_x=xs,
+                        inv_sig_y=ns["inverse_sigmoid"](torch.tensor(xs)).numpy(), **sched)
     print("golden fixtures written to", OUT)
     for f in sorted(os.listdir(OUT)):
         if f.endswith(".npz"):
