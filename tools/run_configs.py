@@ -22,7 +22,7 @@ CONFIGS = {
 }
 
 
-def run(name, steps=15, warmup=5, precision="fp32"):
+def run(name, steps=15, warmup=5, precision="fp32s"):
     cfg = dict(CONFIGS[name])
     mode = cfg.pop("mode")
     args = SimpleNamespace(**cfg)
@@ -85,7 +85,7 @@ def run(name, steps=15, warmup=5, precision="fp32"):
 
 
 if __name__ == "__main__":
-    prec = os.environ.get("GP_MLP_PRECISION", "fp32")
+    prec = os.environ.get("GP_MLP_PRECISION", "fp32s")      # the model's default for passes over more than 2048 rows
     for n in (sys.argv[1:] or list(CONFIGS)):
         run(n, precision=prec)
         torch.cuda.empty_cache()
