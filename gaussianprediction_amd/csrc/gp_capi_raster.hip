@@ -227,6 +227,23 @@ extern "C" int gp_raster_backward(const gp_raster_settings* st, const gp_raster_
     if (in->shs ? (!g->dL_dshs && !g->adam_shs) : !g->dL_dcolors_precomp) GP_FAIL("missing colour gradient output");
     if (in->cov3D_precomp ? !g->dL_dcov3D_precomp : (!g->dL_dscales || !g->dL_drotations)) GP_FAIL("missing covariance gradient output");
     if (!saved->geom || !saved->image) GP_FAIL("saved state missing");
+    AdamFuseDev af;
+    memset(&af, 0, sizeof(af));
+    if (g->adam_shs) {      // the optimizer step of (shs, shs_rest) inside this kernel: validated before anything is written
+        const gp_adam_fuse* a = g->adam_shs;
+        if (!(in->shs && in->shs_rest) || d.M != 16) GP_FAIL("adam_shs needs the split SH layout (shs [N,1,3] + shs_rest [N,15,3])");
+        if (!a->exp_avg_dc || !a->exp_avg_sq_dc || !a->exp_avg_rest || !a->exp_avg_sq_rest) GP_FAIL("adam_shs: null moment pointer");
+        if ((((uintptr_t)in->shs_rest | (uintptr_t)a->exp_avg_rest | (uintptr_t)a->exp_avg_sq_rest) & 15) != 0)
+            GP_FAIL("adam_shs: shs_rest and its moments must be 16-byte aligned");
+        if (a->step < 1) GP_FAIL("adam_shs: bad step");
+        const float bc1 = 1.f - powf(a->beta1, (float)a->step);      // as gp_adam_step_multi
+        af.p_dc = (float*)in->shs; af.m_dc = a->exp_avg_dc; af.v_dc = a->exp_avg_sq_dc;
+        af.p_rest = (float*)in->shs_rest; af.m_rest = a->exp_avg_rest; af.v_rest = a->exp_avg_sq_rest;
+        af.step_dc = a->lr_dc / bc1; af.step_rest = a->lr_rest / bc1;
+        af.b1 = a->beta1; af.b2 = a->beta2; af.eps = a->eps;
+        af.bc2_sqrt = sqrtf(1.f - powf(a->beta2, (float)a->step));
+        af.skip = a->skip_flag; af.on = 1;
+    }
     GeomLayout gl(saved->geom, N);
     ImageLayout il(saved->image, T, P);
     const uint32_t R = (uint32_t)saved->num_rendered;
@@ -264,23 +281,6 @@ extern "C" int gp_raster_backward(const gp_raster_settings* st, const gp_raster_
         GpProfScope _p("preprocess_bwd", s);
         const bool al16 = (((uintptr_t)in->shs | (uintptr_t)in->shs_rest | (uintptr_t)g->dL_dshs | (uintptr_t)g->dL_dshs_rest) & 15) == 0;
         auto kern = gp_preprocess_bwd_kernel;
-        AdamFuseDev af;
-        memset(&af, 0, sizeof(af));
-        if (g->adam_shs) {      // the optimizer step of (shs, shs_rest) inside this kernel: validated before anything is written
-            const gp_adam_fuse* a = g->adam_shs;
-            if (!(in->shs && in->shs_rest) || d.M != 16) GP_FAIL("adam_shs needs the split SH layout (shs [N,1,3] + shs_rest [N,15,3])");
-            if (!a->exp_avg_dc || !a->exp_avg_sq_dc || !a->exp_avg_rest || !a->exp_avg_sq_rest) GP_FAIL("adam_shs: null moment pointer");
-            if ((((uintptr_t)in->shs_rest | (uintptr_t)a->exp_avg_rest | (uintptr_t)a->exp_avg_sq_rest) & 15) != 0)
-                GP_FAIL("adam_shs: shs_rest and its moments must be 16-byte aligned");
-            if (a->step < 1) GP_FAIL("adam_shs: bad step");
-            const float bc1 = 1.f - powf(a->beta1, (float)a->step);      // as gp_adam_step_multi
-            af.p_dc = (float*)in->shs; af.m_dc = a->exp_avg_dc; af.v_dc = a->exp_avg_sq_dc;
-            af.p_rest = (float*)in->shs_rest; af.m_rest = a->exp_avg_rest; af.v_rest = a->exp_avg_sq_rest;
-            af.step_dc = a->lr_dc / bc1; af.step_rest = a->lr_rest / bc1;
-            af.b1 = a->beta1; af.b2 = a->beta2; af.eps = a->eps;
-            af.bc2_sqrt = sqrtf(1.f - powf(a->beta2, (float)a->step));
-            af.skip = a->skip_flag; af.on = 1;
-        }
         if (in->shs && in->shs_rest) {
             if (!al16 || (!g->dL_dshs_rest && !af.on)) GP_FAIL("split SH mode needs 16-byte aligned tensors and dL_dshs_rest");
             kern = gp_preprocess_bwd_split_kernel;
