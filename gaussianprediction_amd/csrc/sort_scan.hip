@@ -82,12 +82,16 @@ int gp_scan_exclusive_u32(uint32_t* data, size_t n, uint32_t* tmp, size_t tmp_el
 // radix sort, 8-bit digits, 256 threads x 16 items per block
 // ------------------------------------------------------------------------------------------------
 #define RS_BLOCK 256
-// keys per workgroup = ITEMS * 256.  16 items amortise the per-block prologue on large inputs; small inputs (the depth
-// sort of ~1M Gaussians) use 4 so that the grid still covers every CU several times.
+// keys per workgroup = ITEMS * 256.  16 items amortise the per-block prologue on large inputs (the R tile-splat instances); the
+// depth sort of ~1M Gaussians is fastest at 8 (measured at N = 1M: 4 items 0.094 ms, 8 items 0.088 ms, 16 items 0.104 ms -- 245
+// workgroups no longer cover the 256 CUs; the tile sort of R = 4.1M pairs: 16 items 0.1015 ms, 8 items 0.098 ms); small inputs use 4
+// so that the grid still spans the chip.
 #define RS_ITEMS_LARGE 16
+#define RS_ITEMS_MID 8
 #define RS_ITEMS_SMALL 4
-#define RS_SMALL_N (2u << 20)
-static inline int rs_items_for(size_t n) { return n <= RS_SMALL_N ? RS_ITEMS_SMALL : RS_ITEMS_LARGE; }
+#define RS_SMALL_N (256u << 10)
+#define RS_MID_N (8u << 20)
+static inline int rs_items_for(size_t n) { return n <= RS_SMALL_N ? RS_ITEMS_SMALL : (n <= RS_MID_N ? RS_ITEMS_MID : RS_ITEMS_LARGE); }
 
 size_t gp_sort_hist_elems(size_t n) {
     const size_t tile = (size_t)rs_items_for(n) * RS_BLOCK;
@@ -269,6 +273,9 @@ int gp_radix_sort_pairs(GpSortBufs& b, size_t n, int nbits, hipStream_t s, bool 
         if (items == RS_ITEMS_SMALL)
             hipLaunchKernelGGL((gp_radix_hist_kernel<RS_ITEMS_SMALL>), dim3(nblocks), dim3(RS_BLOCK), 0, s, b.k[cur], n, shift, mask,
                                b.hist, nblocks);
+        else if (items == RS_ITEMS_MID)
+            hipLaunchKernelGGL((gp_radix_hist_kernel<RS_ITEMS_MID>), dim3(nblocks), dim3(RS_BLOCK), 0, s, b.k[cur], n, shift, mask,
+                               b.hist, nblocks);
         else
             hipLaunchKernelGGL((gp_radix_hist_kernel<RS_ITEMS_LARGE>), dim3(nblocks), dim3(RS_BLOCK), 0, s, b.k[cur], n, shift, mask,
                                b.hist, nblocks);
@@ -277,6 +284,9 @@ int gp_radix_sort_pairs(GpSortBufs& b, size_t n, int nbits, hipStream_t s, bool 
         hipLaunchKernelGGL(gp_radix_rowscan_kernel, dim3(256), dim3(256), 0, s, b.hist, nblocks, b.scan_tmp);
         if (items == RS_ITEMS_SMALL)
             hipLaunchKernelGGL((gp_radix_scatter_kernel<RS_ITEMS_SMALL>), dim3(nblocks), dim3(RS_BLOCK), 0, s, b.k[cur], vin,
+                               b.k[cur ^ 1], b.v[cur ^ 1], b.hist, b.scan_tmp, n, shift, mask, nblocks);
+        else if (items == RS_ITEMS_MID)
+            hipLaunchKernelGGL((gp_radix_scatter_kernel<RS_ITEMS_MID>), dim3(nblocks), dim3(RS_BLOCK), 0, s, b.k[cur], vin,
                                b.k[cur ^ 1], b.v[cur ^ 1], b.hist, b.scan_tmp, n, shift, mask, nblocks);
         else
             hipLaunchKernelGGL((gp_radix_scatter_kernel<RS_ITEMS_LARGE>), dim3(nblocks), dim3(RS_BLOCK), 0, s, b.k[cur], vin,
