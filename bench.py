@@ -146,11 +146,29 @@ def main():
     from gaussianprediction_amd import _lib
     from gaussianprediction_amd.dist import init_from_env
     from gaussianprediction_amd.train_step import TrainStep
-    rank, local, world = init_from_env()
-    assert world == args.gpus or world == 1, f"WORLD_SIZE={world} but --gpus {args.gpus}"
-    assert torch.cuda.is_available(), "bench.py needs a HIP device (no CPU fallback)"
-    device = torch.device("cuda", local)
-    torch.cuda.set_device(device)
+    # RCCL prints a version banner on stdout when a communicator is created; stdout carries exactly ONE line here (the JSON
+    # result), so file descriptor 1 points at stderr while the process group and its first communicator come up
+    sys.stdout.flush()
+    _fd1 = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        rank, local, world = init_from_env()
+        assert world == args.gpus or world == 1, f"WORLD_SIZE={world} but --gpus {args.gpus}"
+        assert torch.cuda.is_available(), "bench.py needs a HIP device (no CPU fallback)"
+        device = torch.device("cuda", local)
+        torch.cuda.set_device(device)
+        if dist.is_available() and dist.is_initialized():
+            dist.barrier()                          # (creates the communicator now)
+            torch.cuda.synchronize()
+    finally:
+        sys.stdout.flush()
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)          # the banner sits in the C library's stdio buffer: push it out while fd 1 is stderr
+        except Exception:
+            pass
+        os.dup2(_fd1, 1)
+        os.close(_fd1)
     pc, cams, gts, margs = build_workload(args, device)
     # learning rates of the reference at iteration 50000 (position lr has decayed to position_lr_final,
     # [REF arguments/__init__.py:75-76, scene/gaussian_model.py:474-491])
