@@ -29,7 +29,9 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
-HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s achievable
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s achievable (float4 copy: the guide and
+                               # this package's own microbenchmark agree, profiles/r03_copy_peak_sweep.jsonl)
+SHADER_CLOCK_GHZ = 2.4         # MI355X_MICROARCH.md; 256 CUs x 4 SIMDs, one wave64 VALU instruction per 4 cycles per SIMD
 
 
 def build_workload(args, device):
@@ -298,6 +300,16 @@ def main():
                     if tj.get("kernel_source_sha16") == kernel_source_stamp():
                         roof["traffic"] = tj.get("hbm_bytes_per_launch")
                         roof["traffic_source"] = tj.get("source")
+                        vj = tj.get("valu")
+                        if vj:
+                            # the kernel is declared "hbm"-bound by the contract's formula, but what it waits for is the vector
+                            # ALU: the instruction floor (every SIMD issuing one wave64 VALU instruction per 4 cycles) and how busy
+                            # the VALUs were, from the SQ counters of the same kernel source
+                            cycles = avg_ms * 1e-3 * SHADER_CLOCK_GHZ * 1e9
+                            roof["valu_floor_ms"] = round(4.0 * vj["SQ_INSTS_VALU"] / 1024.0 / (SHADER_CLOCK_GHZ * 1e9) * 1e3, 4)
+                            roof["valu_busy"] = round(min(1.0, 4.0 * vj["SQ_ACTIVE_INST_VALU"] / (1024.0 * cycles)), 3)
+                            roof["valu_insts_per_launch"] = int(vj["SQ_INSTS_VALU"])
+                            roof["valu_source"] = vj.get("source")
                     else:
                         roof["traffic_source"] = "profiles/composite_fwd_traffic.json describes another kernel source: not quoted"
                 except Exception:
@@ -305,12 +317,30 @@ def main():
         # the other HBM-bound kernels of the step against the same roofline (algorithmic bytes: SURVEY.md 8d / DESIGN.md 4;
         # durations from the untimed per-kernel pass), reported beside the contract's `roofline` object
         others = {}
-        n_par = int(ts.bucket.flat.numel())
-        alg = {"composite_bwd": 44 * R + 8 * T + 24 * P + 40 * n_vis, "preprocess_fwd": 312 * args.gaussians, "adam": 28 * n_par}
+        N = args.gaussians
+        # Adam: 28 B per parameter the launch ACTUALLY updates (p, g, m, v read; p, m, v written).  In single-view single-rank
+        # steps the two SH tensors (48 of the 59 floats per Gaussian) are updated inside the rasterizer backward instead
+        # (gp_adam_fuse) and their bytes belong to preprocess_bwd's line.
+        sh_fused = bool(getattr(ts, "fuse_sh_adam", False) and world == 1 and ts.batch == 1)
+        sh_ids = {id(pc._features_dc), id(pc._features_rest)}
+        n_adam = sum(int(p.numel()) for p in ts.bucket.params if not (sh_fused and id(p) in sh_ids))
+        n_sh = sum(int(p.numel()) for p in ts.bucket.params if id(p) in sh_ids)
+        # preprocess backward per Gaussian: reads means 12 + scales 12 + rotations 16 + SH 192 + radii 4 + clamp flags 1 + the
+        # 40 useful bytes of its accumulator line; writes d(means3D 12, means2D 12, opacity 4, scales 12, rotations 16) and
+        # dSH 192 -- or, with the SH Adam inside, no dSH but m, v read and p, m, v written for the 48 SH floats (5 x 192)
+        pb_plain = (277 + 56 + 192) * N
+        pb_fused = (277 + 56) * N + 20 * n_sh
+        alg = {"composite_bwd": 44 * R + 8 * T + 24 * P + 40 * n_vis, "preprocess_fwd": 312 * N, "adam": 28 * n_adam,
+               "preprocess_bwd": pb_fused if sh_fused else pb_plain}
         for k, nbytes in alg.items():
             if k in kern and kern[k]["ms_per_step"] > 0:
                 gbs = nbytes / (kern[k]["ms_per_step"] * 1e-3) / 1e9
                 others[k] = {"algorithmic_bytes": nbytes, "achieved": round(gbs, 1), "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4)}
+        if "adam" in others:
+            others["adam"]["parameters_updated"] = n_adam
+        if "preprocess_bwd" in others:
+            others["preprocess_bwd"]["includes_fused_sh_adam"] = sh_fused
+            others["preprocess_bwd"]["algorithmic_bytes_without_the_sh_adam"] = pb_plain
         result = {
             "metric": f"rendered views/s ({'eval render' if args.render_only else 'full train step'}) "
                       f"@{args.gaussians / 1e6:g}M Gaussians {args.width}x{args.height}",

@@ -93,6 +93,43 @@ __global__ __launch_bounds__(MB_THREADS) void gp_mb_copy_kernel(mb_f4* __restric
     for (; i < n16; i += stride) __builtin_nontemporal_store(__builtin_nontemporal_load(&src[i]), &dst[i]);
 }
 
+// Variants of the copy (gp_debug_option(2, v); tools/copy_peak_sweep.py): which access shape reaches the part's copy peak is
+// measured, not assumed (profiles/r03_copy_peak_sweep.jsonl, 1 / 4 GiB buffers): the plain float4 copy with ONE vector per
+// thread and a one-shot grid reaches 6.29 / 6.31 TB/s (the guide's figure); every persistent grid-stride form stays at
+// 4.5 - 5.8 TB/s (round 2's default, non-temporal grid-stride: 4.9).  Default (v = 0) is therefore the one-shot copy;
+// 1: temporal loads and stores, grid-stride; 2: the one-shot copy; 3: each workgroup owns one CONTIGUOUS chunk; 4: non-temporal
+// loads + temporal stores, grid-stride; 5: round 2's kernel (non-temporal both ways, grid-stride).
+template <int VARIANT>
+__global__ __launch_bounds__(MB_THREADS) void gp_mb_copy_var_kernel(mb_f4* __restrict__ dst, const mb_f4* __restrict__ src, size_t n16) {
+    if constexpr (VARIANT == 2) {
+        const size_t i = (size_t)blockIdx.x * MB_THREADS + threadIdx.x;
+        if (i < n16) dst[i] = src[i];
+    } else if constexpr (VARIANT == 3) {
+        const size_t per = (n16 + gridDim.x - 1) / gridDim.x;
+        const size_t lo = (size_t)blockIdx.x * per, hi = lo + per < n16 ? lo + per : n16;
+        size_t i = lo + threadIdx.x;
+        for (; i + (MB_UNROLL - 1) * MB_THREADS < hi; i += MB_UNROLL * MB_THREADS) {
+            mb_f4 v[MB_UNROLL];
+#pragma unroll
+            for (int u = 0; u < MB_UNROLL; ++u) v[u] = __builtin_nontemporal_load(&src[i + u * MB_THREADS]);
+#pragma unroll
+            for (int u = 0; u < MB_UNROLL; ++u) __builtin_nontemporal_store(v[u], &dst[i + u * MB_THREADS]);
+        }
+        for (; i < hi; i += MB_THREADS) __builtin_nontemporal_store(__builtin_nontemporal_load(&src[i]), &dst[i]);
+    } else {
+        const size_t stride = (size_t)gridDim.x * MB_THREADS;
+        size_t i = (size_t)blockIdx.x * MB_THREADS + threadIdx.x;
+        for (; i + (MB_UNROLL - 1) * stride < n16; i += MB_UNROLL * stride) {
+            mb_f4 v[MB_UNROLL];
+#pragma unroll
+            for (int u = 0; u < MB_UNROLL; ++u) v[u] = VARIANT == 1 ? src[i + u * stride] : __builtin_nontemporal_load(&src[i + u * stride]);
+#pragma unroll
+            for (int u = 0; u < MB_UNROLL; ++u) dst[i + u * stride] = v[u];
+        }
+        for (; i < n16; i += stride) dst[i] = src[i];
+    }
+}
+
 __global__ __launch_bounds__(MB_THREADS) void gp_mb_read_kernel(const mb_f4* __restrict__ src, size_t n16, float* __restrict__ sink) {
     const size_t stride = (size_t)gridDim.x * MB_THREADS;
     size_t i = (size_t)blockIdx.x * MB_THREADS + threadIdx.x;
@@ -158,7 +195,14 @@ extern "C" int gp_microbench_copy(void* dst, const void* src, size_t bytes, void
     hipStream_t s = (hipStream_t)stream;
     {
         GpProfScope _p("mb_copy", s, 1);
-        hipLaunchKernelGGL(gp_mb_copy_kernel, dim3(mb_grid()), dim3(MB_THREADS), 0, s, (mb_f4*)dst, (const mb_f4*)src, bytes / 16);
+        const int var = gp_debug_get(2) & 7, gmul = gp_debug_get(2) >> 3;      // (bits 3..: grid = CUs x 8 x 2^gmul)
+        const unsigned grid = (unsigned)mb_grid() << gmul;
+        const size_t n16 = bytes / 16;
+        if (var == 5) hipLaunchKernelGGL(gp_mb_copy_kernel, dim3(grid), dim3(MB_THREADS), 0, s, (mb_f4*)dst, (const mb_f4*)src, n16);
+        else if (var == 1) hipLaunchKernelGGL(gp_mb_copy_var_kernel<1>, dim3(grid), dim3(MB_THREADS), 0, s, (mb_f4*)dst, (const mb_f4*)src, n16);
+        else if (var == 3) hipLaunchKernelGGL(gp_mb_copy_var_kernel<3>, dim3(grid), dim3(MB_THREADS), 0, s, (mb_f4*)dst, (const mb_f4*)src, n16);
+        else if (var == 4) hipLaunchKernelGGL(gp_mb_copy_var_kernel<4>, dim3(grid), dim3(MB_THREADS), 0, s, (mb_f4*)dst, (const mb_f4*)src, n16);
+        else hipLaunchKernelGGL(gp_mb_copy_var_kernel<2>, dim3((unsigned)((n16 + MB_THREADS - 1) / MB_THREADS)), dim3(MB_THREADS), 0, s, (mb_f4*)dst, (const mb_f4*)src, n16);
     }
     GP_LAUNCH_CHECK();
     return 0;

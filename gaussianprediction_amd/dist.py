@@ -34,6 +34,7 @@ class FlatGradBucket:
     def __init__(self, params, shards=1, flat_params=False, small_numel=1 << 20):
         params = [p for p in params if p.requires_grad]
         self.shards = int(shards)
+        self.small_numel = int(small_numel)
         if self.shards > 1:                         # large tensors first (in order), then the small ones: two kinds of region
             params = [p for p in params if p.numel() >= small_numel] + [p for p in params if p.numel() < small_numel]
         self.params = params
@@ -134,17 +135,26 @@ class ShardedExchange:
         self.bytes_sent_per_step = 0
         if self.enabled:
             from . import grad_sink
-            self.large = [bucket.params[r[2][0]] for r in bucket.regions if len(r[2]) == 1 and bucket.params[r[2][0]].numel() >= (1 << 20)]
+            self.large = [bucket.params[r[2][0]] for r in bucket.regions if len(r[2]) == 1 and bucket.params[r[2][0]].numel() >= bucket.small_numel]
             hooks = {id(p): self._make_hook(p) for p in self.large}
-            for p in self.large:
-                p.register_post_accumulate_grad_hook(hooks[id(p)])
+            self._hook_handles = [p.register_post_accumulate_grad_hook(hooks[id(p)]) for p in self.large]
             self._sink_cb = grad_sink.register_callback(lambda p: hooks[id(p)](p) if id(p) in hooks else None)
 
     def close(self):
+        """Detach from the parameters and the gradient-sink registry and drain what is in flight (call before the bucket is
+        rebuilt: a late all-gather would otherwise still be writing the old parameter buffer, and a hook left on a Parameter
+        that survives the rebuild would fire a stray reduce-scatter on the old bucket every step)."""
         if self._sink_cb is not None:
             from . import grad_sink
             grad_sink.unregister_callback(self._sink_cb)
             self._sink_cb = None
+        for h in getattr(self, "_hook_handles", ()):
+            h.remove()
+        self._hook_handles = []
+        for h in self.handles:
+            h.wait()
+        self.handles.clear()
+        self.wait_params()
         self.enabled = False
 
     def set_late(self, params):
@@ -160,7 +170,7 @@ class ShardedExchange:
 
     def _make_hook(self, p):
         def hook(param):
-            if id(p) in self._fired or id(p) in self._late:
+            if not self.enabled or id(p) in self._fired or id(p) in self._late:
                 return
             self._fired.add(id(p))
             self.handles.append(self._reduce_scatter(self.bucket.region_of(p)))
@@ -236,18 +246,23 @@ class OverlappedGradReducer:
         if self.enabled:
             from . import grad_sink
             hooks = {id(p): self._make_hook(p) for p in self.large}
-            for p in self.large:
-                p.register_post_accumulate_grad_hook(hooks[id(p)])
+            self._hook_handles = [p.register_post_accumulate_grad_hook(hooks[id(p)]) for p in self.large]
             # leaves whose gradient is written directly by a kernel (grad_sink) never run AccumulateGrad:
             # they announce completion through the sink registry instead
             self._sink_cb = grad_sink.register_callback(lambda p: hooks[id(p)](p) if id(p) in hooks else None)
 
     def close(self):
-        """Detach from the gradient-sink registry (call before the bucket is rebuilt)."""
+        """Detach from the parameters and the gradient-sink registry (call before the bucket is rebuilt)."""
         if getattr(self, "_sink_cb", None) is not None:
             from . import grad_sink
             grad_sink.unregister_callback(self._sink_cb)
             self._sink_cb = None
+        for h in getattr(self, "_hook_handles", ()):
+            h.remove()
+        self._hook_handles = []
+        for h in self.handles:
+            h.wait()
+        self.handles.clear()
         self.enabled = False
 
     def set_late(self, params):
@@ -258,7 +273,7 @@ class OverlappedGradReducer:
 
     def _make_hook(self, p):
         def hook(param):
-            if id(p) in self._fired or id(p) in self._late:
+            if not self.enabled or id(p) in self._fired or id(p) in self._late:
                 return
             self._fired.add(id(p))
             self.handles.append(dist.all_reduce(self.bucket.segment(p), op=dist.ReduceOp.SUM, group=self.group, async_op=True))

@@ -33,9 +33,8 @@ def ply_attributes(n_dc=3, n_rest=45, n_scale=3, n_rot=4):
 def save_ply(model, path):
     """Write `model`'s Gaussians exactly as the reference's save_ply does."""
     os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
-    ev = getattr(model, "_param_ready_event", None)
-    if ev is not None:
-        ev.synchronize()            # a training harness may still be updating parameters on a second stream
+    if hasattr(model, "_sync_side_stream"):
+        model._sync_side_stream()   # a training harness may still be updating / gathering parameters (second stream, all-gather)
     xyz = model._xyz.detach().cpu().numpy()
     normals = np.zeros_like(xyz)
     f_dc = model._features_dc.detach().transpose(1, 2).flatten(start_dim=1).contiguous().cpu().numpy()
@@ -115,9 +114,8 @@ def load_ply(path, sh_degree=3, device="cpu"):
 def save_checkpoint(model, optimizer_state, iteration, path):
     """[REF train.py:199-201]"""
     os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
-    ev = getattr(model, "_param_ready_event", None)
-    if ev is not None:
-        ev.synchronize()
+    if hasattr(model, "_sync_side_stream"):
+        model._sync_side_stream()
     torch.save((model.state_dict(), optimizer_state, iteration), path)
 
 

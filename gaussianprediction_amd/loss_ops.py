@@ -130,6 +130,8 @@ class FusedAdam:
     every tensor with that slice, so a slice of the small-tensor region that spans several tensors still gets each one's own
     learning rate."""
 
+    host_step = None      # test seam: see step()
+
     def __init__(self, param_groups, bucket, betas=(0.9, 0.999), eps=1e-15, shard=None):
         self.param_groups = param_groups
         self.bucket = bucket
@@ -185,6 +187,13 @@ class FusedAdam:
         return {id(p): (full[0][off:off + p.numel()].view_as(p).clone(), full[1][off:off + p.numel()].view_as(p).clone())
                 for p, off in zip(self.bucket.params, self.bucket.offsets)}
 
+    def zero_moments(self, p):
+        """Zero the Adam moments of parameter `p` in place -- on every rank its own slice when sharded; no collective
+        [REF scene/gaussian_model.py:547-559 replace_tensor_to_optimizer]."""
+        for (_, _, _, m, v), owner in zip(self.items, self.owner):
+            if owner is p:
+                m.zero_(); v.zero_()
+
     def load_full_moments(self, p, m_full, v_full):
         """Install whole-tensor moments for parameter `p` (each rank keeps its own slice when sharded)."""
         off = next(o for q, o in zip(self.bucket.params, self.bucket.offsets) if q is p)
@@ -195,19 +204,6 @@ class FusedAdam:
                 else:
                     m.copy_(m_full.reshape(-1)[a - off:a - off + view.numel()].to(m.device, m.dtype))
                     v.copy_(v_full.reshape(-1)[a - off:a - off + view.numel()].to(v.device, v.dtype))
-
-    @torch.no_grad()
-    def _step_host(self, step_no, zero_grad, keep_ids):
-        b1, b2 = self.betas
-        bc1, bc2 = 1 - b1 ** step_no, 1 - b2 ** step_no
-        for (g, p, off, m, v), owner in zip(self.items, self.owner):
-            grad = self.bucket.flat[off:off + p.numel()].view_as(p)
-            m.mul_(b1).add_(grad, alpha=1 - b1)
-            v.mul_(b2).addcmul_(grad, grad, value=1 - b2)
-            denom = (v.sqrt() / (bc2 ** 0.5)).add_(self.eps)
-            p.addcdiv_(m, denom, value=-float(g["lr"]) / bc1)
-        if zero_grad:
-            self.bucket.flat.zero_()
 
     # ---- the torch.optim.Adam surface train.py and the checkpoint format use ---------------------------------------
     @property
@@ -268,8 +264,12 @@ class FusedAdam:
                     raise ValueError(f"group {g.get('name')}: moment shape {tuple(st['exp_avg'].shape)} vs parameter {tuple(p.shape)}")
                 self.load_full_moments(p, st["exp_avg"], st["exp_avg_sq"])
                 steps.append(int(float(st["step"])))
-        # one step counter for all tensors: every optimizer of the reference is created whole by a *_setup call, so its
-        # per-parameter steps are equal (densify / prune keep the stored state, step included)
+        # ONE step counter for all tensors -- a known deviation from torch.optim.Adam, which counts per parameter.  In the
+        # reference the counts can differ by a few: densify / prune / reset_opacity run BEFORE optimizer.step() of the same
+        # iteration [REF train.py:164-197] and replace the per-Gaussian Parameters, whose .grad is then None, so Adam skips
+        # them on that iteration and their `step` lags the MLP's by one per event.  Here the harness steps first and
+        # performs the surgery afterwards, every tensor is updated on every iteration, and a loaded checkpoint resumes at
+        # the LARGEST stored step (bias corrections differ from the reference's by < 1e-3 relative after a few hundred steps).
         self.step_count = max(steps) if steps else 0
 
     def step(self, zero_grad=True, keep_grad=(), skip_flag=None, only=None, exclude=None, stream=None, advance=True):
@@ -284,9 +284,11 @@ class FusedAdam:
             self.step_count = step_no
         n = len(self.items)
         if not self.bucket.flat.is_cuda:
-            # CPU tensors: the -m "not gpu" tests of the host logic (sharding, checkpoint layout) -- torch.optim.Adam's update
-            # rule in torch ops.  HIP tensors never come here: below is the only implementation the render path has.
-            return self._step_host(step_no, zero_grad, {id(p) for p in keep_grad})
+            # No CPU implementation ships.  The -m "not gpu" tests of the host logic around this class (sharding, checkpoint
+            # layout, optimizer-state surgery) install their own checker here (tests/host_checkers.py).
+            if FusedAdam.host_step is None:
+                raise RuntimeError("FusedAdam.step: HIP kernels only (no CPU fallback)")
+            return FusedAdam.host_step(self, step_no, zero_grad, {id(p) for p in keep_grad})
         if not hasattr(self, "_tab"):
             P = (C.c_void_p * n)(*[p.data_ptr() for _, p, _, _, _ in self.items])
             G = (C.c_void_p * n)(*[self.bucket.flat.data_ptr() + 4 * off for _, _, off, _, _ in self.items])

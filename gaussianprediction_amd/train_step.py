@@ -2,8 +2,8 @@
 path for one iteration [REF train.py:101-133, 196-197]:
     render -> 0.8*L1 + 0.2*(1-SSIM_11x11) + 1e-5*mean|motion feature| -> backward -> Adam(eps=1e-15).
 Render, deformation, loss (fused L1+SSIM) and optimizer (fused Adam + gradient zeroing) all run on
-this package's HIP kernels; `fused=False` switches loss and optimizer to the plain-torch restatement of
-the reference (used by the tests as the checker).
+this package's HIP kernels; there is no other implementation in the package (the tests build their own
+plain-torch restatement of the step as the checker, tests/host_checkers.py).
 """
 from __future__ import annotations
 
@@ -11,38 +11,12 @@ import os
 from types import SimpleNamespace
 
 import torch
-import torch.nn.functional as F
 
 from .dist import OverlappedGradReducer, ShardedExchange
 from . import grad_sink
-from .loss_ops import add_l1_mean, l1_ssim_loss
+from .loss_ops import l1_ssim_loss
 from .renderer import render
 from .training import default_training_args
-
-
-def _gauss_window(channels, device, size=11, sigma=1.5):
-    import math
-    g = torch.tensor([math.exp(-(x - size // 2) ** 2 / float(2 * sigma ** 2)) for x in range(size)], device=device)
-    g = (g / g.sum()).unsqueeze(1)
-    return (g @ g.t()).unsqueeze(0).unsqueeze(0).expand(channels, 1, size, size).contiguous()
-
-
-def l1_loss(a, b):                       # [REF utils/loss_utils.py:54-55]
-    return torch.abs(a - b).mean()
-
-
-def ssim(img1, img2, window):            # [REF utils/loss_utils.py:70-100]
-    C = img1.shape[-3]
-    i1, i2 = img1.unsqueeze(0), img2.unsqueeze(0)
-    pad = window.shape[-1] // 2
-    mu1 = F.conv2d(i1, window, padding=pad, groups=C)
-    mu2 = F.conv2d(i2, window, padding=pad, groups=C)
-    mu1_sq, mu2_sq, mu12 = mu1 * mu1, mu2 * mu2, mu1 * mu2
-    s1 = F.conv2d(i1 * i1, window, padding=pad, groups=C) - mu1_sq
-    s2 = F.conv2d(i2 * i2, window, padding=pad, groups=C) - mu2_sq
-    s12 = F.conv2d(i1 * i2, window, padding=pad, groups=C) - mu12
-    C1, C2 = 0.01 ** 2, 0.03 ** 2
-    return (((2 * mu12 + C1) * (2 * s12 + C2)) / ((mu1_sq + mu2_sq + C1) * (s1 + s2 + C2))).mean()
 
 
 class TrainStep:
@@ -61,16 +35,15 @@ class TrainStep:
     SPEC_MARGIN = 1.1
     SPEC_PAD = 4096
 
-    def __init__(self, pc, cameras, gt_images, iteration, lambda_dssim=0.2, lrs=None, group=None, fused=True, speculative=False,
+    def __init__(self, pc, cameras, gt_images, iteration, lambda_dssim=0.2, lrs=None, group=None, speculative=False,
                  overlap_sh_adam=False, batch=1, schedule=False, training_args=None, sharded=None, fuse_sh_adam=True):
         self.pc, self.cameras, self.gt, self.iteration = pc, cameras, gt_images, iteration
         self.lambda_dssim = lambda_dssim
         self.group = group
-        self.fused = fused
         self.batch = int(batch)
         self.schedule = bool(schedule)      # True: update_learning_rate(iteration) every step, as train.py:79 does
         dev = pc.get_xyz.device
-        self.speculative = bool(speculative) and fused and dev.type == "cuda"
+        self.speculative = bool(speculative) and dev.type == "cuda"
         if self.speculative:
             K = self.SPEC_SLOTS
             self._status = torch.zeros(K, 2, dtype=torch.int32, device=dev)
@@ -86,16 +59,15 @@ class TrainStep:
         # read again before the next rasterizer forward, so the update can overlap the deformation backward of this step and
         # the deformation forward of the next -- but those kernels share the HBM with it and queue behind its 2800
         # workgroups, which costs more than the overlap hides.  Single-process only.
-        self.overlap_sh_adam = bool(overlap_sh_adam) and fused and dev.type == "cuda"
+        self.overlap_sh_adam = bool(overlap_sh_adam) and dev.type == "cuda"
         # single view, single rank: the rasterizer backward applies Adam to the SH coefficients itself (gp_adam_fuse): their gradient
         # (192 of the 236 B per Gaussian) is never written or read back.  Bit-identical arithmetic to the optimizer kernel.
-        self.fuse_sh_adam = bool(fuse_sh_adam) and fused and dev.type == "cuda" and not self.overlap_sh_adam
+        self.fuse_sh_adam = bool(fuse_sh_adam) and dev.type == "cuda" and not self.overlap_sh_adam
         self._side = torch.cuda.Stream(device=dev) if self.overlap_sh_adam else None
         self._sh_early = False
         self._sink_cb = None
         self.bg = torch.zeros(3, device=dev)          # black background [REF train.py:59]
         self.pipe = SimpleNamespace(convert_SHs_python=False, compute_cov3D_python=False, debug=False)
-        self.window = _gauss_window(3, dev)
         # camera times live on the device: a per-step H2D copy from pageable memory would be a host sync
         self.times = [torch.from_numpy(c.time).to(torch.float32).to(dev) for c in cameras]
         # learning rates: the reference's defaults [REF arguments/__init__.py:74-90], overridable per group through `lrs`
@@ -108,13 +80,12 @@ class TrainStep:
                 over["feature_lr"] = 20.0 * lrs["f_rest"]
             training_args = default_training_args(**over)
         self.training_args = training_args
-        pc.use_fused_adam = bool(fused)
         # view-parallel: reduce-scatter -> sharded Adam -> all-gather by default (dist.ShardedExchange); sharded=False keeps
         # the all-reduce + replicated Adam of round 1
         import torch.distributed as tdist
         from .dist import active as dist_active
         world = tdist.get_world_size(group) if (tdist.is_available() and tdist.is_initialized()) else 1
-        self.sharded = bool(fused and dist_active(group) and (sharded is None or sharded))
+        self.sharded = bool(dist_active(group) and (sharded is None or sharded))
         shard = (tdist.get_rank(group), world) if self.sharded else None
         if pc.optimizer is None or getattr(pc, "_stage", None) != self._stage_of(iteration) or getattr(pc, "optimizer_shard", None) != shard:
             pc.optimizer_shard = shard
@@ -182,15 +153,10 @@ class TrainStep:
         self._sh_early = True
 
     def loss_of(self, image, gt):
-        if self.fused:
-            if self.iteration >= self.pc.args.jointly_iteration:            # [REF scene/gaussian_model.py:174-178]
-                feat = self.pc.super_gaussians_feature if self.iteration > self.pc.second_stage_iter else self.pc.motion_feature
-                return l1_ssim_loss(image, gt, self.lambda_dssim, feat, 1.0e-5)
-            return l1_ssim_loss(image, gt, self.lambda_dssim)
-        else:
-            Ll1 = l1_loss(image, gt)
-            loss = (1.0 - self.lambda_dssim) * Ll1 + self.lambda_dssim * (1.0 - ssim(image, gt, self.window))
-        return loss + self.pc.get_loss(self.iteration)
+        if self.iteration >= self.pc.args.jointly_iteration:            # [REF scene/gaussian_model.py:174-178]
+            feat = self.pc.super_gaussians_feature if self.iteration > self.pc.second_stage_iter else self.pc.motion_feature
+            return l1_ssim_loss(image, gt, self.lambda_dssim, feat, 1.0e-5)
+        return l1_ssim_loss(image, gt, self.lambda_dssim)
 
     def step(self, view_index: int):
         if not self.speculative:
@@ -203,8 +169,7 @@ class TrainStep:
             self._r_max = max(self._r_max, r)
             if overflow and self._slot_spec[slot]:   # its Adam update was skipped on the device: repeat the frame, exactly
                 self.redone += 1
-                if self.fused:
-                    self.optimizer.step_count -= 1
+                self.optimizer.step_count -= 1
                 self._events[slot] = None
                 self._run_slot(slot, self._slot_view[slot], exact=True)
                 self._n_steps += 1
@@ -234,7 +199,7 @@ class TrainStep:
         a = pc.args
         lifecycle = bool(a.step_opacity and self.iteration > a.step_opacity_iteration)
         keep = ()
-        if self.fused and self.batch == 1 and not self.pipe.convert_SHs_python and self.iteration > pc.third_stage_iter:
+        if self.batch == 1 and not self.pipe.convert_SHs_python and self.iteration > pc.third_stage_iter:
             # the per-Gaussian gradients each have exactly one producer kernel that writes the whole tensor (SH: rasterizer
             # backward; xyz / rotation: blend backward; scaling / opacity: activation backward): their zeroing pass is
             # skipped and the next backward overwrites instead of accumulating.  With the lifecycle opacity the second MLP
@@ -294,18 +259,13 @@ class TrainStep:
                 for p_ in sh_pair:
                     if p_.grad is not None:
                         grad_sink.mark_stale(p_.grad)
-        if self.fused and fuse is not None:
+        if fuse is not None:
             self.optimizer.step(zero_grad=True, keep_grad=keep, skip_flag=skip_flag, exclude=sh_pair)
-        elif self.fused:
-            if self._sh_early:       # the SH tensors were updated on the side stream during the backward
-                self._sh_early = False
-                self.optimizer.step(zero_grad=True, keep_grad=keep, skip_flag=skip_flag,
-                                    exclude=(pc._features_dc, pc._features_rest))
-            else:
-                self.optimizer.step(zero_grad=True, keep_grad=keep, skip_flag=skip_flag)
+        elif self._sh_early:         # the SH tensors were updated on the side stream during the backward
+            self._sh_early = False
+            self.optimizer.step(zero_grad=True, keep_grad=keep, skip_flag=skip_flag, exclude=(pc._features_dc, pc._features_rest))
         else:
-            self.optimizer.step()
-            self.bucket.zero()
+            self.optimizer.step(zero_grad=True, keep_grad=keep, skip_flag=skip_flag)
         if self.sharded:
             self.reducer.gather_params()             # asynchronous; awaited by the next step / render
         return loss.detach(), pkg

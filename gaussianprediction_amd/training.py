@@ -18,7 +18,8 @@ of the per-Gaussian row count rebuilds bucket + optimizer together: moments of s
 rows start at zero (`torch.zeros_like(extension_tensor)` in the reference), step count and learning rates are preserved.
 This is bookkeeping that runs every few hundred iterations: torch tensor ops (plumbing), except furthest-point sampling,
 which is a kernel (gp_furthest_point_sampling; the reference's is pointops' CUDA kernel, utils/fps.py:71-88).
-On CPU tensors (the -m "not gpu" tests of this logic) the optimizer is the plain `torch.optim.Adam` of the reference.
+Nothing here has a CPU implementation of a kernel: the -m "not gpu" tests of this bookkeeping run it on CPU tensors and install
+their own checkers for the two kernels it reaches (the Adam step, furthest-point sampling; tests/host_checkers.py).
 """
 from __future__ import annotations
 
@@ -75,8 +76,8 @@ def build_rotation(r):
 
 def furthest_point_sampling(xyz: torch.Tensor, m: int) -> torch.Tensor:
     """Indices (int64, [m]) of an iterative furthest-point sample of `xyz` [n,3] that starts at point 0 -- the contract of
-    pointops' `furthestsampling` for one batch [REF utils/fps.py:71-88].  HIP kernel on the GPU; torch loop on CPU tensors
-    (test infrastructure for the host logic only)."""
+    pointops' `furthestsampling` for one batch [REF utils/fps.py:71-88].  HIP kernel only; `host_fps` is the seam through
+    which the CPU tests of the keypoint-growth bookkeeping supply their own restatement (tests/host_checkers.py)."""
     n = xyz.shape[0]
     m = int(min(m, n))
     if m <= 0:
@@ -89,13 +90,12 @@ def furthest_point_sampling(xyz: torch.Tensor, m: int) -> torch.Tensor:
             _lib.check(_lib.lib().gp_furthest_point_sampling(C.c_int64(n), _lib.ptr(x), C.c_int64(m), _lib.ptr(idx), _lib.ptr(tmp),
                                                              _lib.stream_ptr(x.device)), "gp_furthest_point_sampling")
         return idx.to(torch.int64)
-    idx = torch.zeros(m, dtype=torch.int64)
-    dist = torch.full((n,), 1e10)
-    for j in range(1, m):
-        d = ((x - x[idx[j - 1]]) ** 2).sum(-1)
-        dist = torch.minimum(dist, d)
-        idx[j] = int(torch.argmax(dist))          # first maximum
-    return idx
+    if host_fps is None:
+        raise RuntimeError("furthest_point_sampling: HIP kernel only (no CPU fallback)")
+    return host_fps(x, m)
+
+
+host_fps = None
 
 
 def nearest_index(query: torch.Tensor, base: torch.Tensor, chunk: int = 256) -> torch.Tensor:
@@ -156,17 +156,13 @@ class TrainingMixin:
             p.requires_grad_(id(p) in optimized)   # changes no result
         params = [p for g in groups for p in g["params"]]
         shard = getattr(self, "optimizer_shard", None)       # (rank, world): set by a view-parallel harness (dist.ShardedExchange)
+        from .loss_ops import FusedAdam                      # Adam(lr=0.0, eps=1e-15) [REF :472] as one multi-tensor launch
         if shard is not None:
-            from .loss_ops import FusedAdam
             self.bucket = FlatGradBucket(params, shards=shard[1], flat_params=True)
             self.optimizer = FusedAdam(groups, self.bucket, eps=1e-15, shard=shard)
-        elif params[0].is_cuda and getattr(self, "use_fused_adam", True):
-            from .loss_ops import FusedAdam
-            self.bucket = FlatGradBucket(params)
-            self.optimizer = FusedAdam(groups, self.bucket, eps=1e-15)
         else:
             self.bucket = FlatGradBucket(params)
-            self.optimizer = torch.optim.Adam(groups, lr=0.0, eps=1e-15)     # [REF :472]
+            self.optimizer = FusedAdam(groups, self.bucket, eps=1e-15)
         self.optimizer_epoch += 1
 
     def _gaussian_groups(self):
@@ -300,15 +296,13 @@ class TrainingMixin:
         if self.active_sh_degree < self.max_sh_degree:
             self.active_sh_degree += 1
 
-    # ---- Adam-moment access (fused or torch) ---------------------------------------------------------------------
+    # ---- Adam-moment access --------------------------------------------------------------------------------------
     def adam_moments(self):
         """{id(param): (exp_avg, exp_avg_sq)} of the current optimizer."""
         opt = self.optimizer
         if opt is None:
             return {}
-        if hasattr(opt, "items"):
-            return opt.full_moments()            # (sharded: a collective -- every rank performs the same surgery)
-        return {id(p): (st["exp_avg"], st["exp_avg_sq"]) for p, st in opt.state.items() if "exp_avg" in st}
+        return opt.full_moments()                # (sharded: a collective -- every rank performs the same surgery)
 
     def _rebuild_optimizer(self, carried):
         """New bucket + optimizer over the model's CURRENT Parameters.  `carried` maps id(new per-Gaussian Parameter) to its
@@ -317,31 +311,19 @@ class TrainingMixin:
         if old is None:
             return
         old_mom = self.adam_moments()
-        fused = hasattr(old, "items")
         lrs = {g["name"]: g["lr"] for g in old.param_groups}
-        old_step = old.step_count if fused else None
-        old_state = None if fused else {id(p): st for p, st in old.state.items()}
+        old_step = old.step_count
         from . import grad_sink
         grad_sink.forget_all()
         self._install_optimizer(self._stage_groups(self._stage))
         for g in self.optimizer.param_groups:
             if g["name"] in lrs:
                 g["lr"] = lrs[g["name"]]
-        if fused:
-            self.optimizer.step_count = old_step
-            for p in self.bucket.params:
-                src = carried.get(id(p)) or old_mom.get(id(p))
-                if src is not None and src[0].shape == p.shape:
-                    self.optimizer.load_full_moments(p, src[0], src[1])
-        else:
-            some = next((st for st in old_state.values() if "step" in st), None)
-            for g in self.optimizer.param_groups:
-                for p in g["params"]:
-                    src = carried.get(id(p))
-                    if src is not None and some is not None:     # the reference keeps the stored state (and its step) [REF :595-598]
-                        self.optimizer.state[p] = {"step": some["step"].clone(), "exp_avg": src[0].clone(), "exp_avg_sq": src[1].clone()}
-                    elif id(p) in old_state:
-                        self.optimizer.state[p] = old_state[id(p)]
+        self.optimizer.step_count = old_step     # the reference keeps the stored state (and its step) [REF :595-598]
+        for p in self.bucket.params:
+            src = carried.get(id(p)) or old_mom.get(id(p))
+            if src is not None and src[0].shape == p.shape:
+                self.optimizer.load_full_moments(p, src[0], src[1])
 
     def _resize_per_gaussian(self, new_tensors, keep, n_new):
         """Install new per-Gaussian tensors (name -> tensor).  `keep` = bool mask over the OLD rows that survive, in order;
@@ -364,9 +346,16 @@ class TrainingMixin:
         self._rebuild_optimizer({id(fresh[name]): mv for name, mv in carried.items() if name in fresh})
 
     def _sync_side_stream(self):
-        ev = getattr(self, "_param_ready_event", None)      # a harness may be updating parameters on a second stream
+        """Before anything outside forward() / render() reads or rewrites parameters: a harness may still be updating them on
+        a second stream (`_param_ready_event`) or gathering other ranks' slices into them (`_param_ready_wait`, the
+        asynchronous all-gather of dist.ShardedExchange) -- surgery on stale rows, or an in-place reset that a late
+        all-gather overwrites, would otherwise depend on every driver remembering TrainStep.sync_params()."""
+        ev = getattr(self, "_param_ready_event", None)
         if ev is not None:
             torch.cuda.current_stream().wait_event(ev)
+        wait = getattr(self, "_param_ready_wait", None)
+        if wait is not None:
+            wait()
 
     # ---- densification statistics ----------------------------------------------------------------------------------
     def add_densification_stats(self, viewspace_point_tensor, update_filter):
@@ -465,9 +454,8 @@ class TrainingMixin:
         new = torch.log(new / (1 - new))
         with torch.no_grad():
             self._opacity.copy_(new)
-        mv = self.adam_moments().get(id(self._opacity))
-        if mv is not None:
-            mv[0].zero_(); mv[1].zero_()
+        if self.optimizer is not None:           # in place, on every rank its own slice (no collective, no temporaries)
+            self.optimizer.zero_moments(self._opacity)
 
     # ---- keypoint growth -----------------------------------------------------------------------------------------------
     def new_kpts_init(self):                      # [REF :170-172]
@@ -498,6 +486,7 @@ class TrainingMixin:
 
     def densification_motion_postfix(self, new_xyz, new_motion_feature):
         """Append keypoints (zero Adam moments) and reset every statistic [REF :612-630]."""
+        self._sync_side_stream()
         mom = self.adam_moments()
         old_kp, old_kf = self.super_gaussians, self.super_gaussians_feature
         carried = {}

@@ -4,8 +4,9 @@
   `weights_model(self.get_xyz.detach())` [REF :257]  ->  `WeightsModel`
 * `get_nearest_mask` = `frnn.frnn_grid_points(...)` [REF scene/gaussian_model.py:110-125]  ->  `knn_keypoints`
 
-The hash-grid encoding (forward + backward) and the kNN are HIP kernels (csrc/weights_kernels.hip); the 64-wide,
-bias-free MLP behind the encoding is three plain GEMMs and runs on the library (rocBLAS through torch.matmul).
+Hash-grid encoding + the 64-wide bias-free MLP behind it are ONE fused HIP kernel each way (gp_weights_forward / _backward,
+csrc/weights_kernels.hip: encode per level, MLP on v_mfma_f32_32x32x2_f32); the kNN is a HIP kernel too.  The stand-alone
+encoding kernels (gp_hashgrid_forward / _backward, `_HashGridEncode`) stay exported for callers that want the features only.
 tinycudann / frnn are absent from the reference tree: parity unpinned (oracle/weights_oracle.py states the algorithm).
 """
 from __future__ import annotations
@@ -151,7 +152,6 @@ class WeightsModel(nn.Module):
         grid = (torch.rand(entries * 4, generator=gen) * 2 - 1) * 1e-4     # tcnn's grid initialisation range
         self.params = nn.Parameter(torch.cat([mlp, grid]).to(device))
         self._perm, self._perm_age = None, 0
-        self.fused = True
         self.perm_refresh = 200          # frames between refreshes of the spatial order (Gaussians move slowly)
 
     def spatial_order(self, xyz):
@@ -162,19 +162,9 @@ class WeightsModel(nn.Module):
 
     def forward(self, xyz):
         perm = self.spatial_order(xyz) if xyz.shape[0] > 4096 else None
-        if self.cfg.n_levels == 16 and self.fused:
-            return _WeightsModelFused.apply(xyz, self.params, self.cfg, self.n_output_dims, perm)
-        return self.forward_unfused(xyz, perm)
-
-    def forward_unfused(self, xyz, perm=None):
-        """Encoding kernel + three library GEMMs (any n_levels; also the cross-check of the fused path)."""
-        p = self.params
-        w1, w2, w3 = p[0:4096].view(64, 64), p[4096:8192].view(64, 64), p[8192:MLP_FLOATS].view(16, 64)
-        table = p[MLP_FLOATS:].view(-1, 4)
-        feat = _HashGridEncode.apply(xyz, table, self.cfg, perm)
-        h = torch.relu(feat @ w1.t())
-        h = torch.relu(h @ w2.t())
-        return (h @ w3.t())[:, :self.n_output_dims]
+        if self.cfg.n_levels != 16:
+            raise RuntimeError("WeightsModel: the fused kernel is built for n_levels == 16 (the reference's configuration)")
+        return _WeightsModelFused.apply(xyz, self.params, self.cfg, self.n_output_dims, perm)
 
 
 def knn_keypoints(xyz, kp_xyz, nearest_num, feat=None, kp_feat=None, feature_amplify=5.0, knn_type="hybird",

@@ -359,7 +359,8 @@ int gp_profile_collect(gp_profile_entry* out, int max_entries, int* n_out);
 /* Peak microbenchmarks (the measured stream-copy and MFMA peaks are reported beside the vendor
  * numbers).  Each call enqueues ONE kernel on `stream`, bracketed (profile level >= 1) under the names "mb_copy",
  * "mb_read", "mb_mfma_f32|f16|bf16"; the caller divides bytes / flop by the collected time.
- *   copy: dst[0..bytes) = src[0..bytes), 16-byte vectors, non-temporal; moves 2*bytes over HBM.
+ *   copy: dst[0..bytes) = src[0..bytes), one 16-byte vector per thread, one-shot grid (the shape that reaches the part's copy
+ *         peak: profiles/r03_copy_peak_sweep.jsonl; bytes <= 64 GiB); moves 2*bytes over HBM.
  *   read: reads src[0..bytes) and discards it (sink is never written for a zero-filled source).
  *   mfma: 4 independent accumulator chains of `iters` 32x32 MFMAs per wave, 4 waves x 8 workgroups per CU; dtype
  *         0 = f32 (32x32x2), 1 = f16, 2 = bf16 (32x32x16); *flop_out = total floating-point operations enqueued. */
@@ -376,7 +377,8 @@ int gp_microbench_valu(int kind, int iters, float* sink, double* instr_out, gp_s
 int gp_microbench_gather(const void* src, int rec_bytes, int stride_bytes, const uint32_t* idx, size_t n_idx, float* sink,
                          gp_stream_t stream);
 /* Diagnostics: select a kernel variant for A/B profiling (key 0: composite forward, key 1: composite backward; value 0 =
- * the shipped default).  Never needed by a caller of the render path. */
+ * the shipped default; key 2: access shape of gp_microbench_copy, tools/copy_peak_sweep.py).  Never needed by a caller of the
+ * render path. */
 int gp_debug_option(int key, int value);
 
 const char* gp_last_error(void);

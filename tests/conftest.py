@@ -11,6 +11,8 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    import host_checkers
+    host_checkers.install()      # CPU tensors reach the tests' own Adam / FPS restatements; HIP tensors never do
 
 
 def pytest_collection_modifyitems(config, items):

@@ -54,7 +54,7 @@ def test_groups_and_restore_from_a_reference_layout_tuple(stage, iteration):
     sd["param_groups"][0]["lr"] = 1.25e-5                     # restore must take the saved learning rates
     dst = _model()
     dst.load_state_dict(src.state_dict(), strict=False)
-    dst.restore(sd, default_training_args(), iteration)       # CPU: the optimizer IS torch.optim.Adam
+    dst.restore(sd, default_training_args(), iteration)       # (FusedAdam: torch.optim.Adam's layout, both ways)
     assert [g["name"] for g in dst.optimizer.param_groups] == STAGE_GROUPS[stage]
     assert dst.optimizer.param_groups[0]["lr"] == 1.25e-5
     for (ga, gb) in zip(ref_opt.param_groups, dst.optimizer.param_groups):

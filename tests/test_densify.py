@@ -1,6 +1,7 @@
 """Densify / prune / opacity reset / keypoint growth with optimizer-state surgery
-[REF scene/gaussian_model.py:526-754, train.py:164-192].  CPU: the optimizer is the reference's plain
-torch.optim.Adam; the same code drives the fused Adam on the GPU (tests/test_gpu_densify.py)."""
+[REF scene/gaussian_model.py:526-754, train.py:164-192].  CPU tensors: the bookkeeping
+under test (bucket + FusedAdam rebuilds, moment carrying) is the product's; the Adam update and furthest-point sampling it
+reaches are the tests' restatements (tests/host_checkers.py, installed by conftest).  GPU: tests/test_gpu_densify.py."""
 from types import SimpleNamespace
 
 import numpy as np
@@ -9,7 +10,8 @@ import torch
 import gaussianprediction_amd as gpa
 from gaussianprediction_amd import densify as dn
 from gaussianprediction_amd.scene_synth import SceneSpec, make_gaussians
-from gaussianprediction_amd.training import default_training_args, furthest_point_sampling, get_expon_lr_func
+from gaussianprediction_amd.training import default_training_args, get_expon_lr_func
+from host_checkers import fps_host
 
 
 def _margs(**kw):
@@ -37,10 +39,11 @@ def _setup(n=40, keypoints=0, **kw):
 
 def _fake_adam_state(pc, step=17):
     """Give every optimized parameter a recognisable Adam state (as after `step` optimizer steps)."""
+    pc.optimizer.step_count = step
     for k, g in enumerate(pc.optimizer.param_groups):
         for p in g["params"]:
             m = torch.arange(p.numel(), dtype=torch.float32).reshape(p.shape) + 1000 * k
-            pc.optimizer.state[p] = {"step": torch.tensor(float(step)), "exp_avg": m.clone(), "exp_avg_sq": 2 * m}
+            pc.optimizer.load_full_moments(p, m.clone(), 2 * m)
 
 
 def test_densify_then_prune_as_the_reference_sequences_them():
@@ -140,7 +143,7 @@ def test_keypoint_growth_by_down_sampling():
     assert torch.equal(pc.super_gaussians.detach()[:8], old_kp)
     # the new keypoints are a furthest-point sample of the hot Gaussians, starting at the first one [REF utils/fps.py:71-88]
     hot = pc._xyz.detach()[:300]
-    idx = furthest_point_sampling(hot, 3)
+    idx = fps_host(hot, 3)
     assert int(idx[0]) == 0 and torch.equal(pc.super_gaussians.detach()[8:], hot[idx])
     d1 = ((hot - hot[0]) ** 2).sum(-1)
     assert int(idx[1]) == int(d1.argmax())

@@ -78,7 +78,8 @@ def test_forward_return_weights_is_the_reference_dense_form():
 def test_furthest_point_sampling_kernel_matches_the_host_restatement():
     g = torch.Generator().manual_seed(4)
     x = torch.randn(5000, 3, generator=g)
-    ref = furthest_point_sampling(x, 64)            # CPU tensors: the torch restatement
+    from host_checkers import fps_host
+    ref = fps_host(x, 64)                           # the tests' torch restatement
     out = furthest_point_sampling(x.cuda(), 64)
     assert out.dtype == torch.int64 and torch.equal(out.cpu(), ref)
     assert int(out[0]) == 0 and len(set(out.tolist())) == 64

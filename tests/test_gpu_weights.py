@@ -9,6 +9,7 @@ pytestmark = pytest.mark.gpu
 import gaussianprediction_amd as gpa  # noqa: E402
 from gaussianprediction_amd.weights_ops import WeightsModel, knn_keypoints  # noqa: E402
 from oracle import weights_oracle as wo  # noqa: E402
+from host_checkers import weights_model_unfused  # noqa: E402
 
 
 def _small_model(n_out=12, log2_T=12, levels=16):
@@ -79,9 +80,8 @@ def test_fused_matches_unfused_with_spatial_order():
         m.params[wo_mlp():] = torch.tensor(rng.normal(size=m.params.numel() - wo_mlp()).astype(np.float32)).cuda()
     res = []
     for fused in (True, False):
-        m.fused = fused
         m.params.grad = None
-        o = m(xyz)
+        o = m(xyz) if fused else weights_model_unfused(m, xyz, m.spatial_order(xyz))
         (o * gy).sum().backward()
         res.append((o.detach().cpu().numpy(), m.params.grad.cpu().numpy()))
     assert np.abs(res[0][0] - res[1][0]).max() < 2e-4 * max(1.0, np.abs(res[1][0]).max())
@@ -92,12 +92,11 @@ def test_fused_matches_unfused_with_spatial_order():
 @pytest.mark.parametrize("fused", [True, False])
 def test_hashgrid_backward_matches_autograd(fused):
     m = _small_model(log2_T=9)
-    m.fused = fused
     meta = wo.grid_meta(16, 4, 9, 16)
     rng = np.random.default_rng(5)
     xyz = torch.tensor(rng.uniform(-1.2, 1.2, size=(300, 3)).astype(np.float32))
     gy = torch.tensor(rng.normal(size=(300, 12)).astype(np.float32))
-    out = m(xyz.cuda())
+    out = m(xyz.cuda()) if fused else weights_model_unfused(m, xyz.cuda())
     (out * gy.cuda()).sum().backward()
     p64 = m.params.detach().cpu().double().requires_grad_(True)
     ref = wo.weights_model(xyz.double(), p64, meta, 12)
