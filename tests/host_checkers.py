@@ -85,3 +85,86 @@ class TorchTrainStep:
         self.opt.step()
         self.pc.bucket.zero()
         return loss.detach(), pkg
+
+
+def psnr(img, gt):
+    """[REF utils/image_utils.py:18-20] on a [3,H,W] pair: per-channel 20 log10(1 / sqrt(mse)), averaged as train.py:267 does."""
+    mse = ((img - gt) ** 2).reshape(img.shape[0], -1).mean(1)
+    return float((20.0 * torch.log10(1.0 / torch.sqrt(mse))).mean())
+
+
+class DenseRefTrainer:
+    """The reference's training iteration [REF train.py:101-133, 196-197] with NOTHING of this package in it: torch restatement
+    of GaussianModel.forward (oracle/deform_oracle.py, pinned by the reference's golden vectors) -> tests/dense_ref.py (every pixel
+    looks at every Gaussian, plain argsort, float64) -> torch L1 + SSIM + regulariser -> torch.autograd -> torch.optim.Adam(eps=1e-15)
+    over the reference's parameter groups.  The independent end of the convergence comparison."""
+
+    STAGE_GROUPS = {1: ("xyz", "f_dc", "f_rest", "opacity", "scaling", "rotation", "df_mlp", "motion_feature"),
+                    3: ("xyz", "f_dc", "f_rest", "opacity", "scaling", "rotation", "s_xyz", "s_motion_feature", "df_mlp")}
+    KEYS = {"xyz": "xyz", "f_dc": "features_dc", "f_rest": "features_rest", "opacity": "opacity", "scaling": "scaling", "rotation": "rotation",
+            "motion_feature": "motion_feature", "s_xyz": "super_gaussians", "s_motion_feature": "super_gaussians_feature"}
+
+    def __init__(self, P, sd, args, cameras, gts, raw_w, knn_idx, sh_degree=3, lambda_dssim=0.2):
+        import math
+        self.P = {k: v.detach().double().clone().requires_grad_(True) for k, v in P.items()}
+        self.sd = {k: v.detach().double().clone().requires_grad_(True) for k, v in sd.items()}
+        self.args, self.cams, self.lam, self.sh_degree = args, cameras, lambda_dssim, sh_degree
+        self.gts = [g.detach().double().cpu() for g in gts]
+        self.raw_w, self.knn_idx = raw_w.detach().double().cpu(), knn_idx.detach().cpu()
+        self.views = [dict(V=c.world_view_transform.detach().cpu().double(), Pm=c.full_proj_transform.detach().cpu().double(),
+                           campos=c.camera_center.detach().cpu().double(), tfx=math.tan(c.FoVx * 0.5), tfy=math.tan(c.FoVy * 0.5),
+                           H=int(c.image_height), W=int(c.image_width), t=torch.tensor(c.time, dtype=torch.float64).reshape(1))
+                      for c in cameras]
+        self.opt, self.iteration = None, None
+
+    def set_stage(self, iteration, lrs):
+        """New optimizer, as the reference's training*_setup calls create one [REF scene/gaussian_model.py:394-472]; lrs by group name."""
+        stage = 1 if iteration <= self.args.second_stage_iteration else 3
+        groups = []
+        for name in self.STAGE_GROUPS[stage]:
+            params = list(self.sd.values()) if name == "df_mlp" else [self.P[self.KEYS[name]]]
+            groups.append({"params": params, "lr": float(lrs[name]), "name": name})
+        self.opt = torch.optim.Adam(groups, lr=0.0, eps=1e-15)
+        self.iteration = iteration
+
+    def render(self, v, iteration=None):
+        from dense_ref import dense_render
+        it = self.iteration if iteration is None else iteration
+        c = self.views[v]
+        P = self.P
+        xyz, q, s, o = do.deform_forward(P, self.sd, c["t"], it, self.args, raw_w=self.raw_w, knn_idx=self.knn_idx)
+        shs = torch.cat([P["features_dc"], P["features_rest"]], dim=1)
+        img, _, _, _ = dense_render(xyz, torch.zeros(xyz.shape[0], 3, dtype=torch.float64), shs, None, o, s, q, None, c["V"], c["Pm"],
+                                    c["campos"], torch.zeros(3, dtype=torch.float64), c["H"], c["W"], c["tfx"], c["tfy"], self.sh_degree)
+        return img
+
+    def step(self, v):
+        img = self.render(v)
+        feat = self.P["super_gaussians_feature"] if self.iteration > self.args.second_stage_iteration else self.P["motion_feature"]
+        loss = torch_l1_ssim(img, self.gts[v], self.lam)
+        if self.iteration >= self.args.jointly_iteration:                 # [REF scene/gaussian_model.py:174-178]
+            loss = loss + 1.0e-5 * feat.abs().mean()
+        self.opt.zero_grad(set_to_none=True)
+        loss.backward()
+        self.opt.step()
+        self.last_image = img.detach()
+        return float(loss.detach())
+
+    def named_parameters(self):
+        """(name of the matching GaussianModel attribute / df_model key, tensor) of everything the current optimizer updates."""
+        attr = {"xyz": "_xyz", "features_dc": "_features_dc", "features_rest": "_features_rest", "opacity": "_opacity", "scaling": "_scaling",
+                "rotation": "_rotation", "motion_feature": "motion_feature", "super_gaussians": "super_gaussians",
+                "super_gaussians_feature": "super_gaussians_feature"}
+        out = []
+        for g in self.opt.param_groups:
+            if g["name"] == "df_mlp":
+                out += [("df_model." + k, self.sd[k]) for k in self.sd]
+            else:
+                out.append((attr[self.KEYS[g["name"]]], self.P[self.KEYS[g["name"]]]))
+        return out
+
+    def adam_state(self, p):
+        st = self.opt.state.get(p, {})
+        if "exp_avg" not in st:
+            return torch.zeros_like(p), torch.zeros_like(p), 0
+        return st["exp_avg"], st["exp_avg_sq"], int(float(st["step"]))

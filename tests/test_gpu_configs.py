@@ -78,6 +78,17 @@ def test_c3_full_size_rasterizer_parity_forward_and_backward():
     s64 = o64.forward_with_binning_of(s, st, a["means3D"], a["opacities"], shs=a["shs"], scales=a["scales"], rotations=a["rotations"])
     d64 = np.abs(s64["out_color"] - s["out_color"]).max(axis=0)                   # float32 vs float64 image, same order:
     assert float(np.median(d64)) < 2e-6 and float((d64[clean] > 1e-4).mean()) < 1e-3   # 1/255 decisions flip on a few pixels
+    # PSNR stand-in for north_star's "within 0.05 dB" (no dataset, no reference rasterizer: SURVEY 8d "otherwise report PSNR of GPU
+    # render vs oracle render"): (1) PSNR of the HIP image against the float64 oracle's image of the same Gaussians; (2) both
+    # images scored against one pseudo ground truth (the float64 image + 0.05 noise, ~26 dB): the score the evaluation would print
+    # [REF utils/image_utils.py:18-20, train.py:267] moves by less than 1e-3 dB
+    from host_checkers import psnr
+    himg = torch.tensor(h["color"].cpu().numpy().astype(np.float64))
+    oimg = torch.tensor(s64["out_color"])
+    gt = (oimg + 0.05 * torch.tensor(rng.normal(size=oimg.shape))).clamp(0, 1)
+    p_direct, p_hip, p_orc = psnr(himg, oimg), psnr(himg, gt), psnr(oimg, gt)
+    print(f"[c3 full size] PSNR(HIP, f64 oracle) = {p_direct:.1f} dB; against a common target: HIP {p_hip:.5f} dB, f64 oracle {p_orc:.5f} dB")
+    assert p_direct > 80.0 and abs(p_hip - p_orc) < 1e-3
     g64 = o64.backward(s64, wimg.astype(np.float64))
     L = {k: v.clone().requires_grad_(True) for k, v in dev.items()}
     m2 = torch.zeros(N, 3, device="cuda", requires_grad=True)
@@ -95,6 +106,59 @@ def test_c3_full_size_rasterizer_parity_forward_and_backward():
     for k in hip:
         assert e32[k] < 1e-4, f"{k}: rel L2 vs the float32 oracle {e32[k]:.3e}"
         assert e64[k] < 1.5 * floor[k] + 2e-5, f"{k}: {e64[k]:.3e} from the float64 shadow, the float32 oracle {floor[k]:.3e}"
+
+
+def test_large_R_binning_and_composite_parity():
+    """SURVEY 7 hard part "stable sort at R ~ 1e7 - 1e8": the c3 scene with 2.4 x larger splats -> R = 12.1 M tile-splat
+    instances (R / N = 12): the tile sort runs its > 8 M-key configuration (16 keys per thread, csrc/sort_scan.hip), tile lists
+    reach 4 000 entries.  Exact mode and capacity mode against the float32 oracle: every discrete result bit-exact, RGB <= 1e-4
+    on the unambiguous pixels; gradients vs the float32 oracle's backward <= 1e-4 (as at c3)."""
+    N, W, H = 1_000_000, 1352, 1014
+    raw = make_gaussians(SceneSpec(n_gaussians=N, extent=(1.5, 1.5, 0.5), scale_lo=0.007, scale_hi=0.03))
+    sc = dict(means3D=raw["xyz"], opacities=torch.sigmoid(raw["opacity"]), shs=torch.cat([raw["features_dc"], raw["features_rest"]], 1),
+              scales=torch.exp(raw["scaling"]), rotations=torch.nn.functional.normalize(raw["rotation"]))
+    a = {k: v.numpy().astype(np.float64) for k, v in sc.items()}
+    cam = orbit_cameras(8, 4.0, 2 * math.atan(1 / 1.8), W, H, arc_deg=40.0, elevation_deg=5.0)[3]
+    st = _settings_of(cam, bg=(0.1, 0.2, 0.3))
+    o32 = RasterOracle("f32", threads=THREADS)
+    s = o32.forward(st, a["means3D"], a["opacities"], shs=a["shs"], scales=a["scales"], rotations=a["rotations"])
+    assert s["R"] >= 12_000_000 and s["R"] > (8 << 20)              # the sort's large-input configuration
+    dev = {k: v.cuda() for k, v in sc.items()}
+    rs = torch_settings(st)
+    h = raster_forward_debug(rs, dev["means3D"], dev["opacities"], shs=dev["shs"], scales=dev["scales"], rotations=dev["rotations"])
+    np.testing.assert_array_equal(h["radii"].cpu().numpy(), s["radii"])
+    assert h["R"] == s["R"]
+    np.testing.assert_array_equal(h["ranges"].cpu().numpy(), s["ranges"])
+    np.testing.assert_array_equal(h["point_list"].cpu().numpy().astype(np.uint32), s["point_list"][:s["R"]])
+    clean = s["ambiguous"] == 0
+    assert clean.mean() > 0.99
+    err = np.abs(h["color"].cpu().numpy().astype(np.float64) - s["out_color"])
+    assert err[:, clean].max() <= 1e-4, f"RGB Linf {err[:, clean].max():.3e}"
+    assert (h["tidx"].cpu().numpy()[clean] == s["out_tidx"][clean]).all()
+    assert (h["n_contrib"].cpu().numpy() == s["n_contrib"])[clean].all()
+    # capacity mode (no host read of R; sentinel-padded sort over the capacity): bit-identical image and lists
+    status = torch.zeros(2, dtype=torch.int32, device="cuda")
+    rs_cap = rs._replace(binning_capacity=int(1.05 * s["R"]), binning_status=status)
+    hc = raster_forward_debug(rs_cap, dev["means3D"], dev["opacities"], shs=dev["shs"], scales=dev["scales"], rotations=dev["rotations"])
+    assert status.tolist() == [s["R"], 0]
+    assert torch.equal(hc["color"], h["color"]) and torch.equal(hc["tidx"], h["tidx"]) and torch.equal(hc["ranges"], h["ranges"])
+    assert torch.equal(hc["point_list"][:s["R"]], h["point_list"][:s["R"]])
+    print(f"[large R] R={s['R']} (R/N = {s['R'] / N:.1f}) longest tile list {int((s['ranges'][:, 1] - s['ranges'][:, 0]).max())} "
+          f"ambiguous={1 - clean.mean():.4%} RGB Linf(clean)={err[:, clean].max():.2e}")
+    # gradients against the float32 oracle's backward (different formulation, double accumulators)
+    wimg = np.random.default_rng(3).normal(size=(3, H, W)).astype(np.float32)
+    g32 = o32.backward(s, wimg.astype(np.float64))
+    L = {k: v.clone().requires_grad_(True) for k, v in dev.items()}
+    m2 = torch.zeros(N, 3, device="cuda", requires_grad=True)
+    img, radii, depth, tidx = gpa.GaussianRasterizer(raster_settings=rs)(
+        means3D=L["means3D"], means2D=m2, opacities=L["opacities"], shs=L["shs"], scales=L["scales"], rotations=L["rotations"])
+    (img * torch.tensor(wimg, device="cuda")).sum().backward()
+    hip = {k: L[k].grad.cpu().numpy() for k in ("means3D", "shs", "opacities", "scales", "rotations")}
+    hip["means2D"] = m2.grad[:, :2].cpu().numpy()
+    e32 = {k: rel_l2(hip[k], g32[k]) for k in hip}
+    print("[large R] gradient rel-L2  HIP vs f32 oracle:", {k: f"{v:.1e}" for k, v in e32.items()})
+    for k in hip:
+        assert e32[k] < 1e-4, f"{k}: rel L2 vs the float32 oracle {e32[k]:.3e}"
 
 
 def _c2_build(N=200_000, W=800, H=800, it=20000):
@@ -129,17 +193,24 @@ def test_c2_stage1_forward_and_backward_vs_composed_oracle():
     n64 = lambda t: t.detach().float().numpy().astype(np.float64)         # noqa: E731
     with torch.no_grad():
         xyz, q, s, o = do.deform_forward(P, sd, torch.tensor(0.6), it, args)
-    ref = RasterOracle("f32", threads=THREADS).forward(st, n64(xyz), n64(o), shs=n64(shs), scales=n64(s), rotations=n64(q))
+        xh, qh, sh_, oh = pc(time, it)            # the very values render() fed the rasterizer (the kernels are deterministic)
+    # (A) deformation: HIP (split-fp16 MFMA MLP at fp32 accuracy) vs the torch restatement
+    for got, want, tol in ((xh, xyz, 2e-5), (qh, q, 2e-5), (sh_, s, 1e-6), (oh, o, 5e-6)):
+        d = float((got.cpu() - want).abs().max())
+        assert d <= tol * max(1.0, float(want.abs().max())), f"deformation output off by {d:.2e}"
+    # (B) rasterizer on exactly those values: bit-exact discrete results, every unambiguous pixel within 1e-4
+    o32 = RasterOracle("f32", threads=THREADS)
+    ref = o32.forward(st, n64(xh.cpu()), n64(oh.cpu()), shs=n64(shs), scales=n64(sh_.cpu()), rotations=n64(qh.cpu()))
     img = pkg["render"].detach().cpu().numpy()
     err = np.abs(img - ref["out_color"]).max(axis=0)
     clean = ref["ambiguous"] == 0
-    # the two deformation paths differ in the last float32 bits, so a few threshold pixels may flip: bound them, check the rest
-    frac_bad = float((err[clean] > 1e-4).mean())
-    assert frac_bad < 2e-3, f"{frac_bad:.4%} pixels above 1e-4 (max {err[clean].max():.2e})"
-    assert float(np.median(err)) < 1e-5
+    assert clean.mean() > 0.99 and err[clean].max() <= 1e-4, f"RGB Linf {err[clean].max():.2e} on the unambiguous pixels"
+    np.testing.assert_array_equal(pkg["radii"].cpu().numpy(), ref["radii"])
     vis = pkg["visibility_filter"].cpu().numpy()
-    assert (vis != (ref["radii"] > 0)).mean() < 1e-3 and vis.sum() > 100_000
-    # ---- backward
+    assert (vis == (ref["radii"] > 0)).all() and vis.sum() > 100_000
+    # ---- backward: the whole chain in float64 (torch autograd through the deformation oracle, the C oracle's backward for the
+    # rasterizer).  The float64 rasterizer ADOPTS the float32 forward's visibility and per-tile order (forward_with_binning_of):
+    # what is compared is the calculus on one and the same set of (pixel, splat) pairs, not two different images
     G = torch.randn(3, cam.image_height, cam.image_width, generator=torch.Generator().manual_seed(5))
     (pkg["render"] * G.cuda()).sum().backward()
     P64 = {k: v.double().requires_grad_(True) for k, v in P.items()}
@@ -148,23 +219,41 @@ def test_c2_stage1_forward_and_backward_vs_composed_oracle():
     xo, qo, so, oo = do.deform_forward(P64, sd64, torch.tensor(0.6, dtype=torch.float64), it, args)
     orc = RasterOracle("f64", threads=THREADS)
     d64 = lambda t: t.detach().numpy()                                     # noqa: E731
-    s64 = orc.forward(st, d64(xo), d64(oo), shs=d64(shs64), scales=d64(so), rotations=d64(qo))
+    s64 = orc.forward_with_binning_of(ref, st, d64(xo), d64(oo), shs=d64(shs64), scales=d64(so), rotations=d64(qo))
     g = orc.backward(s64, G.double().numpy())
-    torch.autograd.backward([xo, qo, so, oo], [torch.tensor(g["means3D"]), torch.tensor(g["rotations"]), torch.tensor(g["scales"]),
-                                               torch.tensor(g["opacities"]).reshape(oo.shape)])
-    errs = {"xyz": rel_l2(pc._xyz.grad.cpu().numpy(), P64["xyz"].grad.numpy()),
-            "rotation": rel_l2(pc._rotation.grad.cpu().numpy(), P64["rotation"].grad.numpy()),
-            "scaling": rel_l2(pc._scaling.grad.cpu().numpy(), P64["scaling"].grad.numpy()),
-            "opacity": rel_l2(pc._opacity.grad.cpu().numpy(), P64["opacity"].grad.numpy()),
-            "motion_feature": rel_l2(pc.motion_feature.grad.cpu().numpy(), P64["motion_feature"].grad.numpy()),
-            "features_dc": rel_l2(pc._features_dc.grad.cpu().numpy(), g["shs"][:, :1]),
-            "features_rest": rel_l2(pc._features_rest.grad.cpu().numpy(), g["shs"][:, 1:])}
-    for k, p in pc.df_model.named_parameters():
-        errs["mlp." + k] = rel_l2(p.grad.cpu().numpy(), sd64[k].grad.numpy())
-    print("[c2] gradient rel-L2 vs composed f64 oracle:", {k: f"{v:.1e}" for k, v in errs.items()})
-    for k, e in errs.items():
-        # the f64 chain renders from f64 deformation outputs, the HIP path from f32 ones: a handful of threshold decisions differ
-        assert e < (2e-3 if k.startswith("mlp.") or k in ("motion_feature",) else 5e-4), f"{k}: rel L2 {e:.3e}"
+    g32 = o32.backward(ref, G.double().numpy())         # the float32 oracle's backward: same precision class as the kernels
+
+    def chain(gr):
+        """Rasterizer gradients `gr` pushed through the float64 deformation: {parameter: gradient}."""
+        for t in list(P64.values()) + list(sd64.values()):
+            t.grad = None
+        torch.autograd.backward([xo, qo, so, oo], [torch.tensor(gr["means3D"]), torch.tensor(gr["rotations"]), torch.tensor(gr["scales"]),
+                                                   torch.tensor(gr["opacities"]).reshape(oo.shape)], retain_graph=True)
+        out = {"xyz": P64["xyz"].grad, "rotation": P64["rotation"].grad, "scaling": P64["scaling"].grad, "opacity": P64["opacity"].grad,
+               "motion_feature": P64["motion_feature"].grad}
+        out = {k: v.numpy().copy() for k, v in out.items()}
+        out["features_dc"], out["features_rest"] = gr["shs"][:, :1], gr["shs"][:, 1:]
+        for k in sd64:
+            out["mlp." + k] = sd64[k].grad.numpy().copy()
+        return out
+
+    c64, c32 = chain(g), chain(g32)
+    hip = {"xyz": pc._xyz.grad, "rotation": pc._rotation.grad, "scaling": pc._scaling.grad, "opacity": pc._opacity.grad,
+           "motion_feature": pc.motion_feature.grad, "features_dc": pc._features_dc.grad, "features_rest": pc._features_rest.grad}
+    hip.update({"mlp." + k: p.grad for k, p in pc.df_model.named_parameters()})
+    hip = {k: v.cpu().numpy() for k, v in hip.items()}
+    e32 = {k: rel_l2(hip[k], c32[k]) for k in hip}
+    e64 = {k: rel_l2(hip[k], c64[k]) for k in hip}
+    floor = {k: rel_l2(c32[k], c64[k]) for k in hip}
+    print("[c2] gradient rel-L2, HIP vs (f32 raster oracle -> f64 deformation):", {k: f"{v:.1e}" for k, v in e32.items()})
+    print("[c2] gradient rel-L2, HIP vs the all-f64 chain:", {k: f"{v:.1e}" for k, v in e64.items()}, " f32 raster oracle vs all-f64:",
+          {k: f"{v:.1e}" for k, v in floor.items()})
+    # two bars, as at c3: (1) against the float32 rasterizer oracle (different formulation, double accumulators) + float64 deformation:
+    # SURVEY 8d's 1e-4; (2) no farther from the all-float64 chain than that float32 restatement is (at 800 x 800 float32 pixel
+    # coordinates alone put ~3e-4 between ANY float32 rasterizer backward and float64)
+    for k in hip:
+        assert e32[k] < 1e-4, f"{k}: rel L2 {e32[k]:.3e} vs the float32 rasterizer oracle chain"
+        assert e64[k] < 1.5 * floor[k] + 2e-5, f"{k}: {e64[k]:.3e} from the all-float64 chain, the float32 oracle chain {floor[k]:.3e}"
 
 
 def _c5_build(N, K=512, nn=8, W=800, H=800):

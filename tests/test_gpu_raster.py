@@ -52,6 +52,17 @@ def test_forward_parity(case):
     assert derr[clean].max() <= 1e-4 * max(1.0, s["out_depth"].max())
     tid_ok = (s["ambiguous"] == 0)
     assert (h["tidx"].cpu().numpy()[tid_ok] == s["out_tidx"][tid_ok]).all()
+    if case == "config1_like":
+        # configs[0] (10 k Gaussians, 400 x 400, forward only): PSNR of the HIP image against the FLOAT64 oracle's, and both scored
+        # against one noisy target -- the stand-in for north_star's 0.05 dB clause (tests/test_gpu_convergence.py has the training half)
+        from host_checkers import psnr
+        a = scene_f32_numpy(scene)
+        s64 = RasterOracle("f64").forward(st, a["means3D"], a["opacities"], shs=a["shs"], scales=a["scales"], rotations=a["rotations"])
+        himg, oimg = torch.tensor(h["color"].cpu().numpy().astype(np.float64)), torch.tensor(s64["out_color"])
+        gt = (oimg + 0.05 * torch.tensor(np.random.default_rng(0).normal(size=oimg.shape))).clamp(0, 1)
+        p_direct, p_hip, p_orc = psnr(himg, oimg), psnr(himg, gt), psnr(oimg, gt)
+        print(f"[c1] PSNR(HIP, f64 oracle) = {p_direct:.1f} dB; against a common target: HIP {p_hip:.5f} dB, f64 oracle {p_orc:.5f} dB")
+        assert p_direct > 80.0 and abs(p_hip - p_orc) < 1e-3
     assert (s["radii"] > 0).sum() > 10
 
 

@@ -68,18 +68,29 @@ def test_render_matches_composed_oracle(name, it, kw):
                         campos=cam.camera_center.cpu().numpy().astype(np.float64))
     shs = torch.cat([raw["features_dc"], raw["features_rest"]], 1)
     n64 = lambda t: t.detach().float().numpy().astype(np.float64)
-    ref = RasterOracle("f32").forward(st, n64(xyz), n64(o), shs=n64(shs), scales=n64(s), rotations=n64(q))
+    # The chain is checked link by link, each at its own bar, instead of end to end at a loosened one:
+    # (A) the deformation: HIP kernels vs the torch restatement, float32 both, a few ulp apart
+    with torch.no_grad():
+        xh, qh, sh_, oh = pc(time, it)            # the very values render() fed the rasterizer (the kernels are deterministic)
+    for got, want, tol in ((xh, xyz, 5e-6), (qh, q, 5e-6), (sh_, s, 1e-6), (oh, o, 5e-6)):
+        d = float((got.cpu() - want).abs().max())
+        assert d <= tol * max(1.0, float(want.abs().max())), f"{name}: deformation output off by {d:.2e}"
+    # (B) the rasterizer on EXACTLY those values: discrete results bit-exact, every unambiguous pixel within 1e-4 (no allowance)
+    ref = RasterOracle("f32").forward(st, n64(xh.cpu()), n64(oh.cpu()), shs=n64(shs), scales=n64(sh_.cpu()), rotations=n64(qh.cpu()))
     img = pkg["render"].cpu().numpy()
-    # the deformation feeds the rasterizer float32 values that differ in the last bits between the two
-    # paths, so discrete decisions may flip on a few threshold pixels: bound their number, check the rest
     err = np.abs(img - ref["out_color"]).max(axis=0)
     clean = ref["ambiguous"] == 0
-    frac_bad = float((err[clean] > 1e-4).mean())
-    assert frac_bad < 2e-3, f"{name}: {frac_bad:.4%} pixels above 1e-4 (max {err[clean].max():.2e})"
-    assert float(np.median(err)) < 1e-5
+    assert clean.mean() > 0.99
+    assert err[clean].max() <= 1e-4, f"{name}: RGB Linf {err[clean].max():.2e} on the unambiguous pixels"
+    np.testing.assert_array_equal(pkg["radii"].cpu().numpy(), ref["radii"])
     vis_h = pkg["visibility_filter"].cpu().numpy()
-    assert (vis_h != (ref["radii"] > 0)).mean() < 1e-3
-    assert vis_h.sum() > 100
+    assert (vis_h == (ref["radii"] > 0)).all() and vis_h.sum() > 100
+    assert (pkg["tidx"].cpu().numpy()[clean] == ref["out_tidx"][clean]).all()
+    # (C) end to end (oracle deformation -> oracle rasterizer) the last-bit differences of (A) may flip threshold decisions on a few
+    # pixels: reported, and bounded loosely -- (A) and (B) are the parity statement
+    ref2 = RasterOracle("f32").forward(st, n64(xyz), n64(o), shs=n64(shs), scales=n64(s), rotations=n64(q))
+    err2 = np.abs(img - ref2["out_color"]).max(axis=0)
+    assert float(np.median(err2)) < 1e-5 and float((err2[ref2["ambiguous"] == 0] > 1e-4).mean()) < 2e-3
 
 
 def test_render_backward_populates_all_grads_and_matches_oracle():

@@ -397,3 +397,12 @@ def test_stage_transitions_and_teaching_path_inside_forward():
     with torch.no_grad():
         pc(t, 40001)                                     # -> training3stage_setup
     assert pc.third_stage and [g["name"] for g in pc.optimizer.param_groups][:6] == ["xyz", "f_dc", "f_rest", "opacity", "scaling", "rotation"]
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_adam_kernel_equals_torch_adam_on_the_summed_loss(tmp_path, world):
+    """tests/test_dist_gloo.py's sharded-optimizer check (reduce-scatter -> Adam on this rank's 1/world of every region -> all-gather
+    == torch.optim.Adam on the SUM of the ranks' losses, parameters and gathered moments) with the buckets on the GPU: the slices
+    are updated by gp_adam_step_multi, not by the CPU tests' restatement.  All ranks share the one device; collectives run on gloo."""
+    from test_dist_gloo import check_sharded_against_torch_adam
+    check_sharded_against_torch_adam(tmp_path, world, device="cuda:0")
