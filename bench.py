@@ -141,6 +141,8 @@ def main():
                     help="size the binning buffers by reading R back every step (one host sync per step) instead of the "
                          "capacity mode with the high-water-mark protocol of TrainStep(speculative=True)")
     ap.add_argument("--render-only", action="store_true", help="time eval-style forward renders instead of train steps")
+    ap.add_argument("--no-chain-sh", action="store_true",
+                    help="N > 1, sharded exchange: keep the SH regions' Adam + all-gather on the compute stream (A/B of TrainStep._chain_sh)")
     ap.add_argument("--replicated-adam", action="store_true",
                     help="N > 1: all-reduce + replicated Adam (round 1) instead of reduce-scatter -> sharded Adam -> all-gather")
     args = ap.parse_args()
@@ -175,7 +177,7 @@ def main():
     # learning rates of the reference at iteration 50000 (position lr has decayed to position_lr_final,
     # [REF arguments/__init__.py:75-76, scene/gaussian_model.py:474-491])
     ts = TrainStep(pc, cams, gts, args.iteration, lrs=dict(xyz=1.6e-6 * 5.0), speculative=not args.exact_binning,
-                   sharded=False if args.replicated_adam else None)
+                   sharded=False if args.replicated_adam else None, chain_sh=not args.no_chain_sh)
 
     def one_step(i):
         view = i * world + rank            # rank r renders view world*i + r
@@ -321,7 +323,7 @@ def main():
         # Adam: 28 B per parameter the launch ACTUALLY updates (p, g, m, v read; p, m, v written).  In single-view single-rank
         # steps the two SH tensors (48 of the 59 floats per Gaussian) are updated inside the rasterizer backward instead
         # (gp_adam_fuse) and their bytes belong to preprocess_bwd's line.
-        sh_fused = bool(getattr(ts, "fuse_sh_adam", False) and world == 1 and ts.batch == 1)
+        sh_fused = bool(getattr(ts, "fuse_sh_adam", False) and not ts.reducer.enabled and ts.batch == 1)
         sh_ids = {id(pc._features_dc), id(pc._features_rest)}
         n_adam = sum(int(p.numel()) for p in ts.bucket.params if not (sh_fused and id(p) in sh_ids))
         n_sh = sum(int(p.numel()) for p in ts.bucket.params if id(p) in sh_ids)
@@ -334,7 +336,10 @@ def main():
                "preprocess_bwd": pb_fused if sh_fused else pb_plain}
         for k, nbytes in alg.items():
             if k in kern and kern[k]["ms_per_step"] > 0:
-                gbs = nbytes / (kern[k]["ms_per_step"] * 1e-3) / 1e9
+                ms_k = kern[k]["ms_per_step"]
+                if k == "preprocess_fwd" and "sh_color" in kern:       # (view-parallel: SH -> RGB runs as a kernel of its own)
+                    ms_k += kern["sh_color"]["ms_per_step"]
+                gbs = nbytes / (ms_k * 1e-3) / 1e9
                 others[k] = {"algorithmic_bytes": nbytes, "achieved": round(gbs, 1), "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4)}
         if "adam" in others:
             others["adam"]["parameters_updated"] = n_adam
@@ -354,9 +359,12 @@ def main():
                        "nearest_num": args.nearest_num, "time_freq": args.time_freq, "iteration": args.iteration,
                        "tiles": T, "pixels": P, "R": R, "R_before_timed_region": R0, "R_per_gaussian": round(R / max(args.gaussians, 1), 3),
                        "visible": n_vis, "parallelism": f"view-parallel x{world}",
-                       "gradient_exchange": None if world == 1 else (
+                       "gradient_exchange": None if not ts.reducer.enabled else (
                            "all-reduce(SUM) of the flat gradient bucket + replicated Adam" if not ts.sharded else
-                           "reduce-scatter(SUM) per region -> Adam on 1/N of every region -> asynchronous all-gather of the parameters"),
+                           "reduce-scatter(SUM) per region -> Adam on 1/N of every region -> asynchronous all-gather of the parameters"
+                           + ("; SH regions: Adam + all-gather on a side stream from the moment their reduce-scatter lands, awaited by the "
+                              "next forward in front of its SH->RGB kernel only" if getattr(ts, "chain_sh", False) else "")
+                           + (" [ONE-rank group, GP_DIST_FORCE_SINGLE: the code path, not a scaling number]" if world == 1 else "")),
                        "xgmi_bytes_sent_per_rank_per_step": None if world == 1 else (
                            getattr(ts.reducer, "bytes_sent_per_step", None) or int(2 * 4 * ts.bucket.flat.numel() * (world - 1) / world)),
                        "binning": "exact (R read back every step)" if args.exact_binning else

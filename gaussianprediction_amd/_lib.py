@@ -27,7 +27,7 @@ class RasterSettingsC(C.Structure):
                 ("tanfovy", C.c_float), ("scale_modifier", C.c_float), ("sh_degree", C.c_int32),
                 ("sh_coeffs", C.c_int32), ("prefiltered", C.c_int32), ("debug", C.c_int32),
                 ("bg", C.c_void_p), ("viewmatrix", C.c_void_p), ("projmatrix", C.c_void_p), ("campos", C.c_void_p),
-                ("binning_capacity", C.c_int64), ("binning_status", C.c_void_p)]
+                ("binning_capacity", C.c_int64), ("binning_status", C.c_void_p), ("sh_ready_event", C.c_void_p)]
 
 
 class RasterInputsC(C.Structure):

@@ -44,6 +44,7 @@ static int make_dims(const gp_raster_settings* st, const gp_raster_inputs* in, R
     d.fx = (float)d.W / (2.f * st->tanfovx);
     d.fy = (float)d.H / (2.f * st->tanfovy);
     d.scale_mod = st->scale_modifier;
+    d.late_color = (st->sh_ready_event && in->shs) ? 1 : 0;
     return 0;
 }
 
@@ -206,6 +207,18 @@ extern "C" int gp_raster_forward(const gp_raster_settings* st, const gp_raster_i
     saved->num_rendered = (int64_t)R;
     hipLaunchKernelGGL(gp_tile_order_kernel, dim3(1), dim3(1024), 0, s, il.ranges, (const int32_t*)nullptr, (int)T, il.order);
     GP_LAUNCH_CHECK();
+    if (d.late_color && N > 0) {    // the SH coefficients may still be in flight (parameter all-gather): wait here, not at the top
+        GP_HIP_CHECK(hipStreamWaitEvent(s, (hipEvent_t)st->sh_ready_event, 0));
+        GpProfScope _p("sh_color", s);
+        const bool al16 = (((uintptr_t)in->shs | (uintptr_t)in->shs_rest) & 15) == 0;
+        auto kern = gp_sh_color_kernel;
+        if (in->shs_rest) kern = gp_sh_color_split_kernel;                 // (alignment was checked for the preprocess launch)
+        else if (d.M == 16 && al16) kern = gp_sh_color_sh16_kernel;
+        GeomLayout glc(saved->geom, N);
+        hipLaunchKernelGGL(kern, dim3(gp_blocks(N, 256)), dim3(256), 0, s, d, in->means3D, in->shs, in->shs_rest, st->campos,
+                           (const int32_t*)out->radii, glc.rec, glc.clamped);
+        GP_LAUNCH_CHECK();
+    }
     { GpProfScope _p("composite_fwd", s, 1);
         hipLaunchKernelGGL(gp_debug_get(0) == 1 ? gp_composite_fwd_kernel : (gp_debug_get(0) == 2 ? gp_composite_fwd_sbc_kernel : gp_composite_fwd_sb_kernel), dim3((unsigned)T), dim3(256), 0, s, d, il.ranges, point_list, gl.rec, st->bg,
                        out->color, out->depth, out->tidx, il.final_T, il.n_contrib, il.order, il.tile_work,

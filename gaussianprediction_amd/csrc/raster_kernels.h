@@ -16,6 +16,7 @@ struct RasterDims {
     int N, M, D;       // gaussians, sh coeffs per channel, active sh degree
     int W, H, gx, gy;  // image and tile grid
     float tanfovx, tanfovy, fx, fy, scale_mod;
+    int late_color;    // 1: the preprocess kernel leaves the colour to gp_sh_color_*_kernel (gp_raster_settings.sh_ready_event)
 };
 
 __global__ __launch_bounds__(256) void gp_preprocess_fwd_kernel(RasterDims d, const float* __restrict__ means3D, const float* __restrict__ scales,      const float* __restrict__ rotations, const float* __restrict__ opacities, const float* __restrict__ shs,      const float* __restrict__ shs_rest, const float* __restrict__ colors_precomp, const float* __restrict__ cov3D_precomp,      const float* __restrict__ view, const float* __restrict__ proj, const float* __restrict__ campos,      int32_t* __restrict__ radii, float4* __restrict__ rec, uint32_t* __restrict__ depth_key,      uint2* __restrict__ tiles_touched, uint8_t* __restrict__ clamped);
@@ -23,6 +24,12 @@ __global__ __launch_bounds__(256) void gp_preprocess_fwd_kernel(RasterDims d, co
 __global__ __launch_bounds__(256) void gp_preprocess_fwd_sh16_kernel(RasterDims d, const float* __restrict__ means3D, const float* __restrict__ scales,      const float* __restrict__ rotations, const float* __restrict__ opacities, const float* __restrict__ shs,      const float* __restrict__ shs_rest, const float* __restrict__ colors_precomp, const float* __restrict__ cov3D_precomp,      const float* __restrict__ view, const float* __restrict__ proj, const float* __restrict__ campos,      int32_t* __restrict__ radii, float4* __restrict__ rec, uint32_t* __restrict__ depth_key,      uint2* __restrict__ tiles_touched, uint8_t* __restrict__ clamped);
 
 __global__ __launch_bounds__(256) void gp_preprocess_fwd_split_kernel(RasterDims d, const float* __restrict__ means3D, const float* __restrict__ scales,      const float* __restrict__ rotations, const float* __restrict__ opacities, const float* __restrict__ shs,      const float* __restrict__ shs_rest, const float* __restrict__ colors_precomp, const float* __restrict__ cov3D_precomp,      const float* __restrict__ view, const float* __restrict__ proj, const float* __restrict__ campos,      int32_t* __restrict__ radii, float4* __restrict__ rec, uint32_t* __restrict__ depth_key,      uint2* __restrict__ tiles_touched, uint8_t* __restrict__ clamped);
+
+#define GP_SC_ARGS RasterDims d, const float* __restrict__ means3D, const float* __restrict__ shs, const float* __restrict__ shs_rest, \
+    const float* __restrict__ campos, const int32_t* __restrict__ radii, float4* __restrict__ rec, uint8_t* __restrict__ clamped
+__global__ __launch_bounds__(256) void gp_sh_color_kernel(GP_SC_ARGS);
+__global__ __launch_bounds__(256) void gp_sh_color_sh16_kernel(GP_SC_ARGS);
+__global__ __launch_bounds__(256) void gp_sh_color_split_kernel(GP_SC_ARGS);
 
 __global__ __launch_bounds__(256) void gp_mark_visible_kernel(int n, const float* __restrict__ means3D,
                                                              const float* __restrict__ view, uint8_t* __restrict__ present);

@@ -211,6 +211,47 @@ __device__ __forceinline__ void unstage_sh(const float* s_sh, float* __restrict_
     }
 }
 
+// view-dependent colour of Gaussian i from its SH coefficients [REF gaussian_renderer/__init__.py:86-91, utils/sh_utils.py:57-112]:
+// clamp_min(eval_sh(...) + 0.5, 0); returns the per-channel clamp flags.  One statement of the arithmetic, used by the fused
+// preprocess kernel and by the late colour kernel below (bit-identical results).
+template <int SH_MODE>
+__device__ __forceinline__ uint8_t sh_color(const RasterDims& d, int i, int tid, float px, float py, float pz,
+                                            const float* __restrict__ campos, const float* __restrict__ shs, const float* s_sh,
+                                            float* col) {
+    const float dx = px - campos[0], dy = py - campos[1], dz = pz - campos[2];
+    const float len = sqrtf(fmaf(dx, dx, fmaf(dy, dy, dz * dz)));
+    const float inv = 1.f / len;
+    float raw[3];
+    if (SH_MODE == 0) {
+        sh_to_rgb(d.D, shs + (size_t)i * d.M * 3, dx * inv, dy * inv, dz * inv, raw);
+    } else {
+        float shl[48];
+        if (SH_MODE == 1) {
+            if (d.D > 0) {
+#pragma unroll
+                for (int k = 0; k < 48; ++k) shl[k] = s_sh[tid * 49 + k];
+            } else {
+                shl[0] = shs[(size_t)i * 48]; shl[1] = shs[(size_t)i * 48 + 1]; shl[2] = shs[(size_t)i * 48 + 2];
+            }
+        } else {
+            shl[0] = shs[3 * (size_t)i]; shl[1] = shs[3 * (size_t)i + 1]; shl[2] = shs[3 * (size_t)i + 2];
+            if (d.D > 0) {
+#pragma unroll
+                for (int k = 0; k < 45; ++k) shl[3 + k] = s_sh[tid * 45 + k];
+            }
+        }
+        sh_to_rgb(d.D, shl, dx * inv, dy * inv, dz * inv, raw);
+    }
+    uint8_t cl = 0;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float v = raw[k] + 0.5f;
+        if (v < 0.f) cl |= (uint8_t)(1u << k);
+        col[k] = fmaxf(v, 0.f);
+    }
+    return cl;
+}
+
 template <int SH_MODE>
 __device__ __forceinline__ void preprocess_fwd_body(RasterDims d, const float* __restrict__ means3D,
                                                     const float* __restrict__ scales, const float* __restrict__ rotations,
@@ -226,7 +267,7 @@ __device__ __forceinline__ void preprocess_fwd_body(RasterDims d, const float* _
     const int base = blockIdx.x * 256;
     const int i = base + tid;
     const int nblk = min(256, d.N - base);
-    const bool use_sh = !colors_precomp;
+    const bool use_sh = !colors_precomp && !d.late_color;
     if (SH_MODE == 1 && use_sh && d.D > 0) stage_sh<48>(s_sh, shs + (size_t)base * 48, nblk, tid);
     if (SH_MODE == 2 && use_sh && d.D > 0) stage_sh<45>(s_sh, shs_rest + (size_t)base * 45, nblk, tid);
     if (SH_MODE != 0) __syncthreads();
@@ -264,41 +305,12 @@ __device__ __forceinline__ void preprocess_fwd_body(RasterDims d, const float* _
     int minx, miny, maxx, maxy;
     tile_rect(pix, piy, rad_f, d.gx, d.gy, minx, miny, maxx, maxy);
     if ((maxx - minx) * (maxy - miny) == 0) return;
-    float col[3];
+    float col[3] = {0.f, 0.f, 0.f};
     uint8_t cl = 0;
     if (colors_precomp) {
         col[0] = colors_precomp[3 * i]; col[1] = colors_precomp[3 * i + 1]; col[2] = colors_precomp[3 * i + 2];
-    } else {
-        const float dx = px - campos[0], dy = py - campos[1], dz = pz - campos[2];
-        const float len = sqrtf(fmaf(dx, dx, fmaf(dy, dy, dz * dz)));
-        const float inv = 1.f / len;
-        float raw[3];
-        if (SH_MODE == 0) {
-            sh_to_rgb(d.D, shs + (size_t)i * d.M * 3, dx * inv, dy * inv, dz * inv, raw);
-        } else {
-            float shl[48];
-            if (SH_MODE == 1) {
-                if (d.D > 0) {
-#pragma unroll
-                    for (int k = 0; k < 48; ++k) shl[k] = s_sh[tid * 49 + k];
-                } else {
-                    shl[0] = shs[(size_t)i * 48]; shl[1] = shs[(size_t)i * 48 + 1]; shl[2] = shs[(size_t)i * 48 + 2];
-                }
-            } else {
-                shl[0] = shs[3 * (size_t)i]; shl[1] = shs[3 * (size_t)i + 1]; shl[2] = shs[3 * (size_t)i + 2];
-                if (d.D > 0) {
-#pragma unroll
-                    for (int k = 0; k < 45; ++k) shl[3 + k] = s_sh[tid * 45 + k];
-                }
-            }
-            sh_to_rgb(d.D, shl, dx * inv, dy * inv, dz * inv, raw);
-        }
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            const float v = raw[k] + 0.5f;
-            if (v < 0.f) cl |= (uint8_t)(1u << k);
-            col[k] = fmaxf(v, 0.f);
-        }
+    } else if (!d.late_color) {
+        cl = sh_color<SH_MODE>(d, i, tid, px, py, pz, campos, shs, s_sh, col);
     }
     radii[i] = f2i_sat(rad_f);
     clamped[i] = cl;
@@ -321,6 +333,34 @@ __device__ __forceinline__ void preprocess_fwd_body(RasterDims d, const float* _
 __global__ __launch_bounds__(256) void gp_preprocess_fwd_kernel(PF_ARGS) { preprocess_fwd_body<0>(PF_PASS); }
 __global__ __launch_bounds__(256) void gp_preprocess_fwd_sh16_kernel(PF_ARGS) { preprocess_fwd_body<1>(PF_PASS); }
 __global__ __launch_bounds__(256) void gp_preprocess_fwd_split_kernel(PF_ARGS) { preprocess_fwd_body<2>(PF_PASS); }
+
+// SH -> RGB as a kernel of its own (gp_raster_settings.sh_ready_event): the view-parallel harness updates and all-gathers the
+// SH coefficients (3/4 of all parameter bytes) asynchronously; projection, both sorts and the binning do not read them, so
+// the forward waits for them only here, right in front of the composite -- ~0.3 ms of cover for the exchange.  Same arithmetic
+// as the fused kernel (sh_color), visible Gaussians only; writes the colour third of the 48-byte record and the clamp flags.
+template <int SH_MODE>
+__device__ __forceinline__ void sh_color_body(RasterDims d, const float* __restrict__ means3D, const float* __restrict__ shs,
+                                              const float* __restrict__ shs_rest, const float* __restrict__ campos,
+                                              const int32_t* __restrict__ radii, float4* __restrict__ rec, uint8_t* __restrict__ clamped) {
+    __shared__ float s_sh[SH_MODE == 0 ? 1 : 256 * 49];
+    const int tid = threadIdx.x;
+    const int base = blockIdx.x * 256;
+    const int i = base + tid;
+    const int nblk = min(256, d.N - base);
+    if (SH_MODE == 1 && d.D > 0) stage_sh<48>(s_sh, shs + (size_t)base * 48, nblk, tid);
+    if (SH_MODE == 2 && d.D > 0) stage_sh<45>(s_sh, shs_rest + (size_t)base * 45, nblk, tid);
+    if (SH_MODE != 0) __syncthreads();
+    if (i >= d.N || radii[i] <= 0) return;
+    float col[3];
+    const uint8_t cl = sh_color<SH_MODE>(d, i, tid, means3D[3 * i], means3D[3 * i + 1], means3D[3 * i + 2], campos, shs, s_sh, col);
+    clamped[i] = cl;
+    rec[3 * (size_t)i + 2] = make_float4(col[0], col[1], col[2], 0.f);
+}
+#define SC_ARGS RasterDims d, const float* __restrict__ means3D, const float* __restrict__ shs, const float* __restrict__ shs_rest, \
+    const float* __restrict__ campos, const int32_t* __restrict__ radii, float4* __restrict__ rec, uint8_t* __restrict__ clamped
+__global__ __launch_bounds__(256) void gp_sh_color_kernel(SC_ARGS) { sh_color_body<0>(d, means3D, shs, shs_rest, campos, radii, rec, clamped); }
+__global__ __launch_bounds__(256) void gp_sh_color_sh16_kernel(SC_ARGS) { sh_color_body<1>(d, means3D, shs, shs_rest, campos, radii, rec, clamped); }
+__global__ __launch_bounds__(256) void gp_sh_color_split_kernel(SC_ARGS) { sh_color_body<2>(d, means3D, shs, shs_rest, campos, radii, rec, clamped); }
 
 __global__ __launch_bounds__(256) void gp_mark_visible_kernel(int n, const float* __restrict__ means3D,
                                                              const float* __restrict__ view, uint8_t* __restrict__ present) {

@@ -35,13 +35,14 @@ class FlatGradBucket:
         params = [p for p in params if p.requires_grad]
         self.shards = int(shards)
         self.small_numel = int(small_numel)
-        if self.shards > 1:                         # large tensors first (in order), then the small ones: two kinds of region
+        regioned = self.shards > 1 or flat_params   # (a one-rank group under GP_DIST_FORCE_SINGLE keeps the sharded layout)
+        if regioned:                                # large tensors first (in order), then the small ones: two kinds of region
             params = [p for p in params if p.numel() >= small_numel] + [p for p in params if p.numel() < small_numel]
         self.params = params
         self.offsets, self.regions = [], []         # regions: (start, end, [param indices])
         unit = 64 * self.shards
         n = 0
-        if self.shards > 1:
+        if regioned:
             tail = []
             for k, p in enumerate(params):
                 if p.numel() >= small_numel:
@@ -130,9 +131,16 @@ class ShardedExchange:
         assert bucket.shards == self.world, "bucket layout and process group disagree on the number of shards"
         self.nccl = self.enabled and dist.get_backend(group) == "nccl"
         self.handles, self._fired, self._late = [], set(), set()
-        self._gather = []                       # (param ids of the region, handle)
+        self._gather = []                       # (param ids of the region, handle, late)
         self._sink_cb = None
         self.bytes_sent_per_step = 0
+        # `chain(region, handle) -> bool`: set by the harness.  Called from the gradient hook right after a large region's
+        # reduce-scatter has been issued; returning True takes the handle over (the harness runs that region's Adam and
+        # all-gather on `side`, off the compute stream: train_step.TrainStep._chain_sh) and finish() / gather_params() skip it.
+        self.chain = None
+        self._chained = set()                   # region starts taken over this step
+        self.side = torch.cuda.Stream(device=bucket.flat.device) if (self.enabled and bucket.flat.is_cuda) else None
+        self._late_event = None
         if self.enabled:
             from . import grad_sink
             self.large = [bucket.params[r[2][0]] for r in bucket.regions if len(r[2]) == 1 and bucket.params[r[2][0]].numel() >= bucket.small_numel]
@@ -155,6 +163,9 @@ class ShardedExchange:
             h.wait()
         self.handles.clear()
         self.wait_params()
+        if self.side is not None:
+            torch.cuda.current_stream(self.bucket.flat.device).wait_stream(self.side)
+        self.chain = None
         self.enabled = False
 
     def set_late(self, params):
@@ -173,7 +184,12 @@ class ShardedExchange:
             if not self.enabled or id(p) in self._fired or id(p) in self._late:
                 return
             self._fired.add(id(p))
-            self.handles.append(self._reduce_scatter(self.bucket.region_of(p)))
+            region = self.bucket.region_of(p)
+            h = self._reduce_scatter(region)
+            if self.chain is not None and self.chain(region, h):
+                self._chained.add(region[0])
+            else:
+                self.handles.append(h)
         return hook
 
     def finish(self):
@@ -193,32 +209,64 @@ class ShardedExchange:
         n = self.bucket.flat.numel()
         self.bytes_sent_per_step = 2 * 4 * n * (self.world - 1) // self.world     # reduce-scatter + all-gather, per rank
 
+    def gather_region(self, region, late=False):
+        """Start the all-gather of ONE region's updated parameter slices, ordered behind the work already on the CURRENT stream
+        (a collective waits for the stream it is issued under).  `late`: render() does not wait for it on the compute stream but
+        hands the rasterizer an event instead (late_event)."""
+        pf = self.bucket.pflat
+        start, end, idx = region
+        lo, hi = self.bucket.shard_slice(region, self.rank)
+        if self.nccl:
+            h = dist.all_gather_into_tensor(pf[start:end], pf[lo:hi], group=self.group, async_op=True)
+        else:
+            n = (end - start) // self.world
+            outs = [pf[start + k * n:start + (k + 1) * n] for k in range(self.world)]
+            h = dist.all_gather(outs, pf[lo:hi].clone(), group=self.group, async_op=True)
+        self._gather.append(({id(self.bucket.params[k]) for k in idx}, h, bool(late)))
+
     def gather_params(self):
-        """Start the all-gather of the updated parameter slices (after the optimizer step), small / geometry regions first."""
+        """Start the all-gather of the updated parameter slices (after the optimizer step), small / geometry regions first;
+        regions the harness chained this step (their gather is already under way) are skipped."""
         if not self.enabled:
             return
-        pf = self.bucket.pflat
         order = sorted(self.bucket.regions, key=lambda r: r[1] - r[0])          # smallest first: the SH regions come last
         for region in order:
-            start, end, idx = region
-            lo, hi = self.bucket.shard_slice(region, self.rank)
-            if self.nccl:
-                h = dist.all_gather_into_tensor(pf[start:end], pf[lo:hi], group=self.group, async_op=True)
-            else:
-                n = (end - start) // self.world
-                outs = [pf[start + k * n:start + (k + 1) * n] for k in range(self.world)]
-                h = dist.all_gather(outs, pf[lo:hi].clone(), group=self.group, async_op=True)
-            self._gather.append(({id(self.bucket.params[k]) for k in idx}, h))
+            if region[0] not in self._chained:
+                self.gather_region(region)
+        self._chained.clear()
 
     def wait_params(self, only=None, exclude=None):
         """Make the current stream wait for the gathered parameters (`only` / `exclude`: sets of id(param))."""
         rest = []
-        for ids, h in self._gather:
+        for ids, h, late in self._gather:
             if (only is not None and not (ids & only)) or (exclude is not None and ids <= exclude):
-                rest.append((ids, h))
+                rest.append((ids, h, late))
             else:
                 h.wait()
         self._gather = rest
+
+    def late_event(self):
+        """For render(): wait -- on the current stream -- for every outstanding gather EXCEPT the late ones (the SH coefficients),
+        and return a torch.cuda.Event that fires when those have landed (None if there are none): the rasterizer forward waits
+        for it in front of its SH -> RGB kernel only (gp_raster_settings.sh_ready_event)."""
+        late = [g for g in self._gather if g[2]]
+        for g in self._gather:
+            if not g[2]:
+                g[1].wait()
+        self._gather = []
+        if not late:
+            return None
+        if self.side is None:                   # (CPU tensors: nothing to overlap with)
+            for g in late:
+                g[1].wait()
+            return None
+        with torch.cuda.stream(self.side):
+            for g in late:
+                g[1].wait()                     # blocks the SIDE stream until the gather is complete
+            ev = torch.cuda.Event()
+            ev.record(self.side)
+        self._late_event = ev
+        return ev
 
 
 class OverlappedGradReducer:

@@ -330,12 +330,17 @@ class FusedAdam:
                 if (mask >> k) & 1:
                     grad_sink.mark_stale(p.grad)
         if self.shard is not None and zero_grad:
-            # the launch zeroed this rank's slices only; the slices the other ranks own hold this rank's partial sums still
-            kept = set()
+            # the launch zeroed this rank's slices only; the slices the other ranks own hold this rank's partial sums still.
+            # Only regions this launch covered (`only` / `exclude`), on the stream of the launch.
+            act_ids = {id(p) for k, p in enumerate(self.owner) if active is None or active[k]}
             for region in self.bucket.regions:
                 ps = [self.bucket.params[i] for i in region[2]]
+                if not any(id(p) in act_ids for p in ps):
+                    continue
                 if all(id(p) in keep_ids for p in ps):
-                    kept.add(region[0])          # every tensor of the region is overwritten by its producer next step
-            for start, end, _ in self.bucket.regions:
-                if start not in kept:
-                    self.bucket.flat[start:end].zero_()
+                    continue                     # every tensor of the region is overwritten by its producer next step
+                if stream is not None:
+                    with torch.cuda.stream(stream):
+                        self.bucket.flat[region[0]:region[1]].zero_()
+                else:
+                    self.bucket.flat[region[0]:region[1]].zero_()

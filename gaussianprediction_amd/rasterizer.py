@@ -41,6 +41,10 @@ class GaussianRasterizationSettings(NamedTuple):
     # host sync per forward to read R).  capacity > 0 with a 2-word int32 device tensor = no host sync; status = {R, overflow}
     binning_capacity: int = 0
     binning_status: Optional[torch.Tensor] = None
+    # extension (gp_raster_settings.sh_ready_event): a torch.cuda.Event after which the SH tensors are valid (the asynchronous
+    # all-gather of the updated coefficients in view-parallel training).  The forward then reads them in a separate SH -> RGB
+    # kernel right before the composite and waits for the event only there.  None = they are ready now.
+    sh_ready_event: Optional[object] = None
 
 
 def _f32c(t: Optional[torch.Tensor], device) -> Optional[torch.Tensor]:
@@ -68,6 +72,10 @@ def _settings_c(rs: GaussianRasterizationSettings, device, sh_coeffs: int):
         keep.append(status)
     elif getattr(rs, "binning_capacity", 0):
         raise RuntimeError("binning_capacity needs binning_status")
+    ev = getattr(rs, "sh_ready_event", None)
+    if ev is not None:
+        st.sh_ready_event = int(ev.cuda_event)          # (hipEvent_t; an event that was never recorded counts as complete)
+        keep.append(ev)
     return st, keep
 
 

@@ -33,10 +33,11 @@ def _sh_to_rgb_python(deg, feats, dirs):
     return torch.clamp_min(res + 0.5, 0.0)
 
 
-def _settings(viewpoint_camera, pc, bg_color, scaling_modifier, binning=None):
+def _settings(viewpoint_camera, pc, bg_color, scaling_modifier, binning=None, sh_ready_event=None):
     return GaussianRasterizationSettings(
         binning_capacity=int(binning[0]) if binning else 0,
         binning_status=binning[1] if binning else None,
+        sh_ready_event=sh_ready_event,
         image_height=int(viewpoint_camera.image_height),
         image_width=int(viewpoint_camera.image_width),
         tanfovx=math.tan(viewpoint_camera.FoVx * 0.5),
@@ -82,7 +83,6 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=
     `binning` (extension, not in the reference signature): (capacity, status) of the rasterizer's capacity mode -- see
     GaussianRasterizationSettings.binning_capacity."""
     screenspace_points = _screenspace_points(pc)
-    rasterizer = GaussianRasterizer(raster_settings=_settings(viewpoint_camera, pc, bg_color, scaling_modifier, binning))
     cov3D_precomp = None
     if time is None:
         means3D = pc.get_xyz + delta if delta is not None else pc.get_xyz
@@ -94,7 +94,16 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=
     else:
         means3D, rotations, scales, opacity = pc(time, it)
     shs, shs_rest, colors_precomp = None, None, None
-    _wait_params(pc)         # (after the deformation was enqueued: it does not read the tensors a harness updates late)
+    # (after the deformation was enqueued: it does not read the tensors a harness updates late.)  The SH coefficients are read by
+    # the rasterizer alone, and only in front of its composite: a view-parallel harness hands over an EVENT for their all-gather
+    # (`_param_late_event`) instead of making this stream wait for it here -- when the two SH parameters go to the kernels as they are.
+    split_sh = (override_color is None and not getattr(pipe, "convert_SHs_python", False) and hasattr(pc, "_features_dc")
+                and hasattr(pc, "_features_rest") and pc._features_rest.shape[1] == 15)
+    late = getattr(pc, "_param_late_event", None) if split_sh else None
+    sh_ready = late() if late is not None else None
+    if late is None:
+        _wait_params(pc)
+    rasterizer = GaussianRasterizer(raster_settings=_settings(viewpoint_camera, pc, bg_color, scaling_modifier, binning, sh_ready))
     if override_color is None:
         if getattr(pipe, "convert_SHs_python", False):
             base = means3D.detach() if time is not None else pc.get_xyz + (delta if delta is not None else 0)

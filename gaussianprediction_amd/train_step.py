@@ -36,10 +36,11 @@ class TrainStep:
     SPEC_PAD = 4096
 
     def __init__(self, pc, cameras, gt_images, iteration, lambda_dssim=0.2, lrs=None, group=None, speculative=False,
-                 overlap_sh_adam=False, batch=1, schedule=False, training_args=None, sharded=None, fuse_sh_adam=True):
+                 overlap_sh_adam=False, batch=1, schedule=False, training_args=None, sharded=None, fuse_sh_adam=True, chain_sh=True):
         self.pc, self.cameras, self.gt, self.iteration = pc, cameras, gt_images, iteration
         self.lambda_dssim = lambda_dssim
         self.group = group
+        self.chain_sh = bool(chain_sh)      # sharded exchange: SH regions' Adam + all-gather on a side stream (_chain_sh)
         self.batch = int(batch)
         self.schedule = bool(schedule)      # True: update_learning_rate(iteration) every step, as train.py:79 does
         dev = pc.get_xyz.device
@@ -114,9 +115,13 @@ class TrainStep:
             self.reducer = ShardedExchange(self.pc.bucket, self.group)
             sh = {id(self.pc._features_dc), id(self.pc._features_rest)}
             self._early_params = {id(p) for p in self.pc.bucket.params} - sh
-            self.pc._param_ready_wait = self.reducer.wait_params          # render(): right before the rasterizer call
+            self.pc._param_ready_wait = self.reducer.wait_params          # surgery / checkpoints / plain renders: wait for everything
+            self.pc._param_late_event = self.reducer.late_event           # render(): an event for the SH gather instead of a wait
+            self.reducer.chain = self._chain_sh
+            self._chain_on, self._flag_handle = False, None
         else:
             self.reducer = OverlappedGradReducer(self.pc.bucket, self.group)
+            self.pc._param_late_event = None
         if getattr(self, "overlap_sh_adam", False) and self._sink_cb is None:
             self._armed = False
             self._ev_bwd, self._ev_sh = torch.cuda.Event(), torch.cuda.Event()
@@ -137,6 +142,29 @@ class TrainStep:
         parameters, their gradients or their Adam moments)."""
         if self._side is not None:
             torch.cuda.current_stream().wait_stream(self._side)
+
+    def _chain_sh(self, region, h_rs):
+        """ShardedExchange.chain: an SH region's reduce-scatter has just been issued (from the gradient hook, inside
+        loss.backward(), the moment the rasterizer backward finished writing that gradient).  Its remaining life runs on the
+        exchange's side stream, off the compute stream: wait for the reduced slice -> Adam on this rank's 1/world of the region ->
+        all-gather of the updated slices, all under the blend / MLP backward, the main Adam launch and the next step's
+        deformation, projection and sorts; the next rasterizer forward waits for the gather only in front of its SH -> RGB kernel
+        (late_event -> gp_raster_settings.sh_ready_event).  Returns False (the ordinary path) unless this is a single-producer
+        step on device tensors."""
+        if not self._chain_on or self.reducer.side is None:
+            return False
+        params = [self.bucket.params[k] for k in region[2]]
+        if not all(p is self.pc._features_dc or p is self.pc._features_rest for p in params):
+            return False
+        side = self.reducer.side
+        with torch.cuda.stream(side):
+            h_rs.wait()                                   # the SIDE stream waits for the reduced slice
+            if self._flag_handle is not None:
+                self._flag_handle.wait()                  # (capacity mode: the overflow flag, MAX over the ranks)
+            self.optimizer.step(zero_grad=True, keep_grad=self._keep, skip_flag=self._skip_flag, only=params, stream=side, advance=False)
+            self.reducer.gather_region(region, late=True)
+        self._chained_params.extend(params)
+        return True
 
     def _on_sink(self, p):
         """grad_sink callback (runs on the autograd thread, inside loss.backward()): the rasterizer backward has written the
@@ -205,9 +233,16 @@ class TrainStep:
             # skipped and the next backward overwrites instead of accumulating.  With the lifecycle opacity the second MLP
             # pass is a second producer of the xyz gradient, so xyz keeps the zero-and-accumulate protocol.
             keep = (pc._features_dc, pc._features_rest, pc._rotation, pc._scaling, pc._opacity) + (() if lifecycle else (pc._xyz,))
-        # a gradient that has more than one producer in this backward is final only when autograd says so: such leaves are
-        # reduced after backward (finish()), never from a kernel's completion notice
-        self.reducer.set_late(list(self.bucket.params) if self.batch > 1 else ([pc._xyz] if lifecycle else []))
+        # A gradient may leave for its exchange from a kernel's completion notice only if that kernel is its ONLY producer in this
+        # backward: the per-Gaussian tensors of a single-view step (SH: rasterizer backward; rotation / xyz: blend backward;
+        # scaling / opacity: activation backward; the stage-1 motion feature: MLP backward).  Everything else -- several views
+        # per step; under the lifecycle opacity `_xyz`, the motion feature AND the MLP weights, which the second MLP pass also
+        # differentiates; keypoints -- is exchanged after backward (finish()).  (Found by the two-rank test once it gave every
+        # tensor a region of its own: the MLP weights left after the first of their two producers.)
+        single = [] if self.batch > 1 else [pc._features_dc, pc._features_rest, pc._rotation, pc._scaling, pc._opacity] + \
+            ([] if lifecycle else [pc._xyz, pc.motion_feature])
+        sid = {id(p_) for p_ in single}
+        self.reducer.set_late([p_ for p_ in self.bucket.params if id(p_) not in sid])
         if self.overlap_sh_adam and keep and not self.reducer.enabled:
             self._armed, self._keep, self._skip_flag = True, keep, skip_flag
         sh_pair, fuse = (pc._features_dc, pc._features_rest), None
@@ -217,6 +252,10 @@ class TrainStep:
             if fuse is not None:
                 grad_sink.arm_fused_update(sh_pair, fuse)
         world = torch.distributed.get_world_size(self.group) if self.reducer.enabled else 1
+        if self.sharded:
+            # SH regions may leave the compute stream right after their reduce-scatter (_chain_sh): single-producer steps only
+            self._chain_on = bool(keep) and self.reducer.enabled and getattr(self, "chain_sh", True)
+            self._keep, self._skip_flag, self._chained_params, self._flag_handle = keep, skip_flag, [], None
         losses, pkgs = [], []
         try:
             for b in range(self.batch):              # [REF train.py:101-119]
@@ -225,6 +264,10 @@ class TrainStep:
                 pkg = render(cam, pc, self.pipe, self.bg, time=self.times[v % len(self.cameras)], it=self.iteration, binning=binning)
                 losses.append(self.loss_of(pkg["render"], self.gt[v % len(self.gt)]))
                 pkgs.append(pkg)
+            if skip_flag is not None and self.reducer.enabled:
+                # one rank's overflow invalidates the summed gradient: every rank must skip (and later repeat) this step.  The
+                # flag is final once the forward is enqueued, so its MAX over the ranks is started here, ahead of the backward
+                self._flag_handle = torch.distributed.all_reduce(skip_flag, op=torch.distributed.ReduceOp.MAX, group=self.group, async_op=True)
             loss = losses[0] if self.batch == 1 else torch.stack(losses, dim=0).sum()
             seed = getattr(self, "_seed_one", None)  # (autograd would fill a ones_like(loss) every step: one more launch)
             if seed is None or seed.device != loss.device or seed.dtype != loss.dtype or seed.shape != loss.shape:
@@ -237,8 +280,9 @@ class TrainStep:
             raise
         self._armed = False
         self.reducer.finish()                        # SUM over views == the reference's --batch semantics
-        if skip_flag is not None and self.reducer.enabled:
-            # one rank's overflow invalidates the summed gradient: every rank must skip (and later repeat) this step
+        if getattr(self, "_flag_handle", None) is not None:
+            self._flag_handle.wait()
+        elif skip_flag is not None and self.reducer.enabled:
             torch.distributed.all_reduce(skip_flag, op=torch.distributed.ReduceOp.MAX, group=self.group)
         pkg = pkgs[-1]
         if self.batch > 1 or world > 1:
@@ -259,7 +303,10 @@ class TrainStep:
                 for p_ in sh_pair:
                     if p_.grad is not None:
                         grad_sink.mark_stale(p_.grad)
-        if fuse is not None:
+        chained = getattr(self, "_chained_params", None) if self.sharded else None
+        if chained:                  # their Adam slice and all-gather are already running on the exchange's side stream
+            self.optimizer.step(zero_grad=True, keep_grad=keep, skip_flag=skip_flag, exclude=tuple(chained))
+        elif fuse is not None:
             self.optimizer.step(zero_grad=True, keep_grad=keep, skip_flag=skip_flag, exclude=sh_pair)
         elif self._sh_early:         # the SH tensors were updated on the side stream during the backward
             self._sh_early = False

@@ -158,7 +158,8 @@ class TrainingMixin:
         shard = getattr(self, "optimizer_shard", None)       # (rank, world): set by a view-parallel harness (dist.ShardedExchange)
         from .loss_ops import FusedAdam                      # Adam(lr=0.0, eps=1e-15) [REF :472] as one multi-tensor launch
         if shard is not None:
-            self.bucket = FlatGradBucket(params, shards=shard[1], flat_params=True)
+            # (bucket_small_numel: tensors below it share one region / one collective; tests lower it to reach the per-tensor paths)
+            self.bucket = FlatGradBucket(params, shards=shard[1], flat_params=True, small_numel=getattr(self, "bucket_small_numel", 1 << 20))
             self.optimizer = FusedAdam(groups, self.bucket, eps=1e-15, shard=shard)
         else:
             self.bucket = FlatGradBucket(params)

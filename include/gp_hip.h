@@ -62,6 +62,12 @@ typedef struct gp_raster_settings {
      * caller must discard the frame (gp_adam_step_multi takes the same word as its skip flag) and retry with more room. */
     int64_t binning_capacity;
     uint32_t* binning_status;
+    /* Optional hipEvent_t.  NULL: `shs` / `shs_rest` are read by the first kernel of the call (fused projection + SH -> RGB).
+     * Non-NULL: another stream may still be WRITING the SH tensors when gp_raster_forward is called (the asynchronous all-gather
+     * of the updated coefficients in view-parallel training -- 3/4 of all parameter bytes); projection, both sorts and the
+     * binning do not read them, so the call makes `stream` wait for this event only in front of a separate SH -> RGB kernel
+     * placed right before the composite.  Identical results (one shared device function). */
+    void* sh_ready_event;
 } gp_raster_settings;
 
 /* inputs of GaussianRasterizer.forward [REF gaussian_renderer/__init__.py:98-106] */

@@ -248,3 +248,40 @@ def test_full_size_backward_is_linear_in_the_upstream_gradient():
         err = float((r12[k] - lin).norm() / lin.norm().clamp_min(1e-30))
         assert err < 2e-4, (k, err)
         assert torch.isfinite(r12[k]).all()
+
+
+@pytest.mark.parametrize("layout", ["one_tensor_16", "dc_plus_rest", "generic_9_coeffs"])
+def test_late_sh_colour_kernel_is_bit_identical(layout):
+    """gp_raster_settings.sh_ready_event: projection / sorts / binning first, the SH coefficients read by a separate SH -> RGB
+    kernel behind an event wait (view-parallel training: their all-gather may still be in flight).  Same image, same saved state,
+    same gradients, bit for bit (forward) / to the atomics' noise (backward), in all three SH layouts."""
+    scene, st, cam = small_scene(n=3000, W=128, H=96, seed=12, scale_lo=0.02, scale_hi=0.15)
+    st = f32_settings(st)
+    dev = scene_to_device(scene)
+    rs = torch_settings(st)
+    shs = dev["shs"].contiguous()
+    if layout == "generic_9_coeffs":
+        shs, rs = shs[:, :9].contiguous(), rs._replace(sh_degree=2)
+    kw = dict(shs=shs[:, :1].contiguous(), shs_rest=shs[:, 1:].contiguous()) if layout == "dc_plus_rest" else dict(shs=shs)
+    side = torch.cuda.Stream()
+    outs = []
+    for late in (False, True):
+        ev = None
+        if late:
+            ev = torch.cuda.Event()
+            with torch.cuda.stream(side):
+                torch.cuda._sleep(20_000_000)        # the event fires ~10 ms after the forward was enqueued
+                ev.record(side)
+        L = {k: v.clone().requires_grad_(True) for k, v in kw.items()}
+        G = {k: dev[k].clone().requires_grad_(True) for k in ("means3D", "opacities", "scales", "rotations")}
+        m2 = torch.zeros(3000, 3, device="cuda", requires_grad=True)
+        r = gpa.GaussianRasterizer(raster_settings=rs._replace(sh_ready_event=ev))
+        img, radii, depth, tidx = r(means3D=G["means3D"], means2D=m2, opacities=G["opacities"], scales=G["scales"], rotations=G["rotations"], **L)
+        (img * torch.linspace(-1, 1, img.numel(), device="cuda").reshape(img.shape)).sum().backward()
+        torch.cuda.synchronize()
+        outs.append((img.detach(), radii, depth.detach(), tidx, [L[k].grad for k in sorted(L)] + [G[k].grad for k in sorted(G)]))
+    a, b = outs
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2]) and torch.equal(a[3], b[3])
+    assert float(a[0].abs().sum()) > 0
+    for ga, gb in zip(a[4], b[4]):
+        assert rel_l2(ga.cpu().numpy(), gb.cpu().numpy()) < 1e-5

@@ -238,10 +238,17 @@ def _rank_main_params(rank, world, port, out_dir, backend, sharded, step_opacity
     else:
         dist.init_process_group("gloo", rank=rank, world_size=world)
     pc, cams, gts, raw, rw, idx, args = build(n=3000, dev=f"cuda:{dev}", step_opacity=step_opacity)
-    ts = TrainStep(pc, cams, gts, 50000, sharded=sharded)
+    pc.bucket_small_numel = 8000          # (3000 Gaussians: the per-Gaussian tensors get regions of their own, as at 1 M)
+    ts = TrainStep(pc, cams, gts, 50000, sharded=sharded, chain_sh=os.environ.get("GP_TEST_NO_CHAIN") != "1")
     assert ts.sharded == sharded and type(ts.reducer).__name__ == ("ShardedExchange" if sharded else "OverlappedGradReducer")
+    chained = []
+    if sharded and ts.chain_sh:
+        orig_chain = ts.reducer.chain
+        ts.reducer.chain = lambda region, h: (lambda ok: (chained.append(region[0]) if ok else None, ok)[1])(orig_chain(region, h))
     for step in range(3):
         ts.step(step * world + rank)
+    if sharded and ts.chain_sh:          # the SH regions' Adam + all-gather ran on the exchange's side stream (TrainStep._chain_sh)
+        assert len(chained) == 6 and len(set(chained)) == 2 and len(ts._chained_params) == 2, chained
     ts.sync_params()
     sd = pc.optimizer.state_dict()                       # (sharded: a collective)
     torch.save({"params": {n: p.detach().cpu() for n, p in pc.named_parameters()}, "state": {k: {kk: vv.cpu() for kk, vv in v.items()} for k, v in sd["state"].items()},
@@ -281,10 +288,19 @@ def _rank_main_rccl_single(rank, world, port, out_dir, sharded):
     torch.cuda.set_device(0)
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     pc, cams, gts, raw, rw, idx, args = build(n=3000, dev="cuda:0")
+    pc.bucket_small_numel = 8000          # (3000 Gaussians: the per-Gaussian tensors get regions of their own, as at 1 M)
     ts = TrainStep(pc, cams, gts, 50000, sharded=sharded)
     assert ts.reducer.enabled and ts.reducer.nccl if sharded else ts.reducer.enabled
     assert type(ts.reducer).__name__ == ("ShardedExchange" if sharded else "OverlappedGradReducer")
+    chained, events = [], []
+    if sharded:      # the SH regions leave the compute stream after their reduce-scatter (Adam + all-gather on the side stream) ...
+        orig_chain, orig_late = ts.reducer.chain, pc._param_late_event
+        ts.reducer.chain = lambda region, h: (lambda ok: (chained.append(region[0]) if ok else None, ok)[1])(orig_chain(region, h))
+        pc._param_late_event = lambda: (lambda ev: (events.append(ev), ev)[1])(orig_late())
     losses = [float(ts.step(step)[0]) for step in range(4)]
+    if sharded:      # ... every step, both SH tensors; and from the second step on render() hands the rasterizer an event for them
+        assert len(chained) == 8 and len(set(chained)) == 2, chained
+        assert events[0] is None and all(e is not None for e in events[1:]), events
     ts.sync_params()
     torch.cuda.synchronize()
     torch.save({"params": {n: p.detach().cpu() for n, p in pc.named_parameters()}, "losses": losses}, os.path.join(out_dir, f"single{int(sharded)}.pt"))
