@@ -77,14 +77,50 @@ class GaussianModel(TrainingMixin, nn.Module):
     def set_keypoint_weights(self, raw_weights, knn_idx):
         self.raw_weights, self.knn_idx = raw_weights, knn_idx
 
+    @staticmethod
+    def _state_key(*tensors):
+        """Identity + version of every tensor a cached result depends on (optimizer kernels bump the versions of what they write)."""
+        return tuple((id(t), t._version, t.data_ptr(), tuple(t.shape)) for t in tensors)
+
     @torch.no_grad()
     def get_nearest_mask(self, keepshape=False):     # [REF scene/gaussian_model.py:110-125]
+        """The reference searches the neighbours on every forward; their inputs do not depend on the frame time, so the result
+        is kept until one of them changes (every training step -- but not between the frames of an evaluation, nor between the
+        views of a `--batch`).  Same kernel, same result."""
         a = self.args
-        nearest = knn_keypoints(self._xyz, self.super_gaussians, a.nearest_num, self.motion_feature,
-                                self.super_gaussians_feature, getattr(a, "feature_amplify", 5.0),
-                                getattr(a, "knn_type", "hybird"))
+        key = self._state_key(self._xyz, self.motion_feature, self.super_gaussians, self.super_gaussians_feature)
+        c = getattr(self, "_knn_cache", None)
+        if c is None or c[0] != key:
+            nearest = knn_keypoints(self._xyz, self.super_gaussians, a.nearest_num, self.motion_feature,
+                                    self.super_gaussians_feature, getattr(a, "feature_amplify", 5.0),
+                                    getattr(a, "knn_type", "hybird"))
+            c = self._knn_cache = (key, nearest)
+        nearest = c[1]
         self.nearest_mask = nearest if keepshape else nearest.view([-1])
         return self.nearest_mask
+
+    def _keypoint_raw_weights(self):
+        """`weights_model(self.get_xyz.detach())` [REF scene/gaussian_model.py:257], evaluated once per parameter state: positions
+        and the model's parameters do not depend on the frame time.  Without autograd (evaluation) the result is kept until
+        a version changes.  With autograd it can only be shared inside ONE backward's graph: a harness that sums several views
+        into one backward opens such a scope (`keypoint_weights_scope`; the weights model then runs once, and once backward
+        with the summed upstream gradient, instead of once per view)."""
+        wm = self.weights_model
+        key = self._state_key(self._xyz, wm.params)
+        grad = torch.is_grad_enabled() and wm.params.requires_grad
+        c = getattr(self, "_rw_cache", None)
+        scope = getattr(self, "_rw_scope", None)
+        if c is not None and c[0] == key and c[1] == (scope if grad else None) and (not grad or scope is not None):
+            return c[2]
+        out = wm(self.get_xyz.detach())
+        self._rw_cache = (key, scope if grad else None, out) if (not grad or scope is not None) else None
+        return out
+
+    def keypoint_weights_scope(self, token):
+        """Open (token not None) / close (None) the scope inside which autograd-tracked keypoint weights may be shared."""
+        self._rw_scope = token
+        if token is None and getattr(self, "_rw_cache", None) is not None and self._rw_cache[1] is not None:
+            self._rw_cache = None
 
     # ---- accessors [REF scene/gaussian_model.py:138-172] -----------------------------------------
     @property
@@ -205,7 +241,7 @@ class GaussianModel(TrainingMixin, nn.Module):
                 if getattr(self, "weights_model", None) is None:
                     raise RuntimeError("stage 2/3 needs set_keypoint_weights(raw_weights, knn_idx) or a weights_model "
                                        "(create_from_tensors(..., with_weights_model=True))")
-                raw_weights = self.weights_model(self.get_xyz.detach())          # [REF :257]
+                raw_weights = self._keypoint_raw_weights()                       # [REF :257]
                 knn_idx = self.get_nearest_mask(keepshape=True)                  # [REF :260]
             delta = self.df_model.forward_fused(self.super_gaussians_feature, kp, t_dev, xyz_freq, time_freq)
             self._last_delta = delta.detach()

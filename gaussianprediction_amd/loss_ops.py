@@ -324,6 +324,13 @@ class FusedAdam:
                                                C.c_int64(step_no), C.c_int32(1 if zero_grad else 0), C.c_uint32(mask),
                                                _lib.ptr(skip_flag), sp)
             _lib.check(rc, "gp_adam_step_multi")
+        # the kernel wrote the parameters through raw pointers: bump their version counters, so that whatever caches on
+        # `_version` (GaussianModel's keypoint-weights cache) or saved them for a backward sees the change
+        bump = getattr(torch.autograd.graph, "increment_version", None)
+        if bump is not None:
+            for k, p in enumerate(self.owner):
+                if active is None or active[k]:
+                    bump(p)
         if mask:
             from . import grad_sink
             for k, p in enumerate(self.owner):

@@ -47,6 +47,9 @@ class GaussianRasterizationSettings(NamedTuple):
     sh_ready_event: Optional[object] = None
 
 
+_bump_version = getattr(torch.autograd.graph, "increment_version", lambda t: None)
+
+
 def _f32c(t: Optional[torch.Tensor], device) -> Optional[torch.Tensor]:
     if t is None or t.numel() == 0 and t.dim() <= 1:
         return None
@@ -217,6 +220,9 @@ class _RasterizeGaussians(torch.autograd.Function):
                 _lib.check(rc, "gp_raster_backward")
             finally:
                 alloc.release()
+        if fuse is not None:         # the kernel rewrote the two parameters through raw pointers: keep their version counters honest
+            _bump_version(leaf_sh)
+            _bump_version(leaf_rest)
         if use_sink:
             grad_sink.notify(leaf_sh)
             if has_rest:

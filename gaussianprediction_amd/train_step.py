@@ -257,6 +257,9 @@ class TrainStep:
             self._chain_on = bool(keep) and self.reducer.enabled and getattr(self, "chain_sh", True)
             self._keep, self._skip_flag, self._chained_params, self._flag_handle = keep, skip_flag, [], None
         losses, pkgs = [], []
+        if self.batch > 1 and hasattr(pc, "keypoint_weights_scope"):
+            self._scope_no = getattr(self, "_scope_no", 0) + 1
+            pc.keypoint_weights_scope(self._scope_no)        # the views of this step share one evaluation of the weights model
         try:
             for b in range(self.batch):              # [REF train.py:101-119]
                 v = view_index * self.batch + b
@@ -278,6 +281,9 @@ class TrainStep:
                 from . import grad_sink
                 grad_sink.disarm_fused_update(sh_pair)
             raise
+        finally:
+            if self.batch > 1 and hasattr(pc, "keypoint_weights_scope"):
+                pc.keypoint_weights_scope(None)
         self._armed = False
         self.reducer.finish()                        # SUM over views == the reference's --batch semantics
         if getattr(self, "_flag_handle", None) is not None:

@@ -422,3 +422,57 @@ def test_sharded_adam_kernel_equals_torch_adam_on_the_summed_loss(tmp_path, worl
     are updated by gp_adam_step_multi, not by the CPU tests' restatement.  All ranks share the one device; collectives run on gloo."""
     from test_dist_gloo import check_sharded_against_torch_adam
     check_sharded_against_torch_adam(tmp_path, world, device="cuda:0")
+
+
+def test_keypoint_weights_and_knn_are_evaluated_once_per_parameter_state():
+    """The reference evaluates the hash-grid weights model and the kNN on every forward [REF scene/gaussian_model.py:257-260];
+    neither depends on the frame time.  Evaluation frames and the views of one `--batch` step share one evaluation; anything
+    that changes an input (an optimizer step: the kernels bump the tensors' version counters) invalidates it.  Results are the
+    uncached ones, bit for bit."""
+    from gaussianprediction_amd import weights_ops
+    from gaussianprediction_amd.weights_ops import WeightsModel
+    pc, cams, gts, raw, rw, idx, args = build(n=3000, knn_type="hybird", feature_amplify=5.0)
+    pc.weights_model = WeightsModel(2 * args.nearest_num, log2_hashmap_size=12, device="cuda")
+    pc.set_keypoint_weights(None, None)
+    calls = {"knn": 0, "wm": 0}
+    import gaussianprediction_amd.gaussian_model as gm
+    orig_knn, orig_fwd = gm.knn_keypoints, WeightsModel.forward
+    gm.knn_keypoints = lambda *a, **k: (calls.__setitem__("knn", calls["knn"] + 1), orig_knn(*a, **k))[1]
+    WeightsModel.forward = lambda self, x: (calls.__setitem__("wm", calls["wm"] + 1), orig_fwd(self, x))[1]
+    try:
+        pipe = SimpleNamespace(convert_SHs_python=False, compute_cov3D_python=False, debug=False)
+        bg = torch.zeros(3, device="cuda")
+        with torch.no_grad():
+            imgs = [render(cams[k % 4], pc, pipe, bg, time=torch.tensor([0.1 * k], device="cuda"), it=50000)["render"].clone() for k in range(5)]
+        assert calls == {"knn": 1, "wm": 1}, calls                       # five frames, one evaluation
+        pc._knn_cache = pc._rw_cache = None
+        with torch.no_grad():
+            again = render(cams[3], pc, pipe, bg, time=torch.tensor([0.3], device="cuda"), it=50000)["render"]
+        assert torch.equal(again, imgs[3]) and calls == {"knn": 2, "wm": 2}
+        # training, one view per step: every step changes the inputs -> one evaluation per step (and the autograd graph is never shared)
+        ts = TrainStep(pc, cams, gts, 50000)
+        v0 = pc._xyz._version
+        for s in range(3):
+            ts.step(s)
+        # (the first step still sees the state of the last evaluation frame: its neighbour search is served from the cache, the
+        # weights model -- now under autograd -- is not)
+        assert pc._xyz._version > v0 and calls == {"knn": 4, "wm": 5}, calls
+        # --batch 2: both views of a step share the evaluation; the gradient of the weights model is the sum over the views
+        ts2 = TrainStep(pc, cams, gts, 50000, batch=2)
+        for g_ in pc.optimizer.param_groups:
+            g_["lr"] = 0.0                              # (the step must leave the parameters where the per-view check below finds them)
+        got = {}
+        orig_step = ts2.optimizer.step
+        ts2.optimizer.step = lambda *a, **k: (got.__setitem__("g", pc.weights_model.params.grad.clone()), orig_step(*a, **k))[1]
+        ts2.step(0)
+        assert calls == {"knn": 5, "wm": 6}, calls
+        gsum = torch.zeros_like(got["g"])
+        for v in (0, 1):
+            pc.weights_model.params.grad.zero_()
+            pkg = render(cams[v], pc, pipe, bg, time=ts2.times[v], it=50000)
+            ts2.loss_of(pkg["render"], gts[v]).backward()
+            gsum += pc.weights_model.params.grad
+        rel = float((got["g"] - gsum).norm() / gsum.norm())
+        assert rel < 1e-4, rel
+    finally:
+        gm.knn_keypoints, WeightsModel.forward = orig_knn, orig_fwd
