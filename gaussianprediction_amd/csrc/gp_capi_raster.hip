@@ -67,9 +67,11 @@ struct ImageLayout {
     int32_t* tile_work;    // per tile: largest list position consumed by the forward (backward work estimate)
     uint32_t* order;       // heavy-first launch order of the forward
     size_t bytes;
+    uint32_t* total;       // R, written by the scan of the per-Gaussian tile counts (zeroed with `ranges`: it sits behind them)
     ImageLayout(void* base, size_t T, size_t P) {
         GpCarver c(base);
-        ranges = c.take<int2>(T);
+        ranges = c.take<int2>(T + 1);
+        total = (uint32_t*)(ranges + T);
         final_T = c.take<float>(P);
         n_contrib = c.take<int32_t>(P);
         tile_work = c.take<int32_t>(T);
@@ -99,14 +101,14 @@ extern "C" int gp_raster_forward(const gp_raster_settings* st, const gp_raster_i
     saved->image = img; saved->image_bytes = il.bytes;
     saved->binning = nullptr; saved->binning_bytes = 0; saved->num_rendered = 0;
 
-    GP_HIP_CHECK(hipMemsetAsync(il.ranges, 0, T * sizeof(int2), s));
+    GP_HIP_CHECK(hipMemsetAsync(il.ranges, 0, (T + 1) * sizeof(int2), s));      // (tile ranges + the instance counter behind them)
     uint32_t R = 0;
     uint32_t* point_list = nullptr;
     if (N > 0) {
         // ---- per-Gaussian temporaries -----------------------------------------------------------
         GpCarver tc0(nullptr);
         const size_t hist_elems = gp_sort_hist_elems(N);
-        const size_t scan_elems = gp_scan_tmp_elems(256 * ((N + 4095) / 4096) > N + 1 ? 256 * ((N + 4095) / 4096) : N + 1);
+        const size_t scan_elems = gp_scan_tmp_elems(256 * ((N + 4095) / 4096) > N + 1 ? 256 * ((N + 4095) / 4096) : N + 1) + (N + GP_SCAN_TILE - 1) / GP_SCAN_TILE + 64;
         auto carve_tmp = [&](GpCarver& c, uint32_t*& k0, uint32_t*& k1, uint32_t*& v0, uint32_t*& v1, uint2*& tiles,
                              uint2*& rects, uint32_t*& tt, uint32_t*& hist, uint32_t*& scan_tmp) {
             k0 = c.take<uint32_t>(N); k1 = c.take<uint32_t>(N); v0 = c.take<uint32_t>(N); v1 = c.take<uint32_t>(N);
@@ -140,23 +142,25 @@ extern "C" int gp_raster_forward(const gp_raster_settings* st, const gp_raster_i
         sb.k[0] = k0; sb.k[1] = k1; sb.v[0] = v0; sb.v[1] = v1; sb.hist = hist; sb.scan_tmp = scan_tmp; sb.scan_tmp_elems = scan_elems;
         int r1;
         // (values = 0 .. N-1, generated by the first pass)
-        { GpProfScope _p("depth_sort", s); r1 = gp_radix_sort_pairs(sb, N, 32, s, true); }
+        // the last pass also carries every Gaussian's tile rectangle + tile count into depth order (was a launch of its own)
+        const GpSortEpilogue ep = {tiles, rects, tt};
+        { GpProfScope _p("depth_sort", s); r1 = gp_radix_sort_pairs(sb, N, 32, s, true, &ep); }
         if (r1 < 0) return 1;
         const uint32_t* sorted_ids = sb.v[r1];
-        hipLaunchKernelGGL(gp_gather_tiles_kernel, dim3(gp_blocks(N + 1, 256)), dim3(256), 0, s, sorted_ids, tiles, tt, rects, d.N);
-        GP_LAUNCH_CHECK();
-        if (gp_scan_exclusive_u32(tt, N + 1, scan_tmp, scan_elems, s)) return 1;
+        // tile counts -> instance offsets: scanned inside blocks here, finished by the duplicate kernel (one launch, not three)
+        uint32_t* block_sums = scan_tmp;
+        if (gp_scan_blocks_u32(tt, N, block_sums, il.total, s)) return 1;
         const bool capacity_mode = st->binning_capacity > 0;
         if (capacity_mode) {    // no host synchronisation: everything below is sized by the caller's capacity
             if (!st->binning_status) GP_FAIL("binning_capacity needs binning_status (device, 2 words)");
             if (st->binning_capacity > 0x7FFFFF00ll) GP_FAIL("binning_capacity too large");
             R = (uint32_t)st->binning_capacity;          // (the status word and the sentinel keys are written by the duplicate launch)
         } else {
-            GP_HIP_CHECK(hipMemcpyAsync(&R, tt + N, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+            GP_HIP_CHECK(hipMemcpyAsync(&R, il.total, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
             GP_HIP_CHECK(hipStreamSynchronize(s));
             if (R > 0x7FFFFF00u) GP_FAIL("too many tile-splat instances (%u)", R);
             if (st->binning_status) {   // exact mode reports R too (a caller sizing its capacity reads it from here)
-                hipLaunchKernelGGL(gp_binning_status_kernel, dim3(1), dim3(1), 0, s, tt + N, 0xFFFFFFFFu, st->binning_status);
+                hipLaunchKernelGGL(gp_binning_status_kernel, dim3(1), dim3(1), 0, s, il.total, 0xFFFFFFFFu, st->binning_status);
                 GP_LAUNCH_CHECK();
             }
         }
@@ -191,7 +195,7 @@ extern "C" int gp_raster_forward(const gp_raster_settings* st, const gp_raster_i
             { GpProfScope _p("duplicate", s);
             const unsigned ndup = gp_blocks(N, 256);
             hipLaunchKernelGGL(gp_duplicate_kernel, dim3(ndup + (capacity_mode ? gp_blocks(R, 4096) : 0u)), dim3(256), 0, s, d, sorted_ids, tt,
-                               rects, tb.k[0], tb.v[0], R, st->binning_status, ndup);
+                               (const uint32_t*)block_sums, (const uint32_t*)il.total, rects, tb.k[0], tb.v[0], R, st->binning_status, ndup);
             GP_LAUNCH_CHECK(); }
             int r2;
             { GpProfScope _p("tile_sort", s); r2 = gp_radix_sort_pairs(tb, R, tbits, s); }
@@ -264,11 +268,9 @@ extern "C" int gp_raster_backward(const gp_raster_settings* st, const gp_raster_
     if (R > 0 && !point_list) GP_FAIL("saved binning state missing");
 
     const size_t acc_floats = (size_t)GP_ACC_STRIDE * N;
-    const size_t pp_bytes = T * GP_BWD_PARTS * GP_BWD_PAIRS * 64;   // (tile, part) x pixel pairs x 64 B
-    float* acc = (float*)alloc(alloc_ctx, GP_BUF_TEMP, gp_align_up(acc_floats * 4, 256) + gp_align_up(T * 4, 256) + pp_bytes);
+    float* acc = (float*)alloc(alloc_ctx, GP_BUF_TEMP, gp_align_up(acc_floats * 4, 256) + gp_align_up(T * 4, 256));
     if (!acc) GP_FAIL("allocator returned NULL for TEMP");
     uint32_t* order_bwd = (uint32_t*)((char*)acc + gp_align_up(acc_floats * 4, 256));
-    GpPixPair* pp = (GpPixPair*)((char*)order_bwd + gp_align_up(T * 4, 256));
     GP_HIP_CHECK(hipMemsetAsync(acc, 0, acc_floats * 4, s));
     float* g_mean2D = acc;   // AoS, stride GP_ACC_STRIDE
     float* g_conic = acc + 2;
@@ -278,16 +280,11 @@ extern "C" int gp_raster_backward(const gp_raster_settings* st, const gp_raster_
     if (R > 0) {
         hipLaunchKernelGGL(gp_tile_order_kernel, dim3(1), dim3(1024), 0, s, il.ranges, il.tile_work, (int)T, order_bwd);
         GP_LAUNCH_CHECK();
-        {
-            GpProfScope _p("bwd_pixprep", s);
-            hipLaunchKernelGGL(gp_bwd_pixprep_kernel, dim3(gp_blocks(T * GP_BWD_PARTS * GP_BWD_PAIRS, 256)), dim3(256), 0, s, d, st->bg,
-                               fwd->color, fwd->depth, il.final_T, il.n_contrib, dL_dcolor, dL_ddepth, pp);
-            GP_LAUNCH_CHECK();
-        }
         GpProfScope _p("composite_bwd", s);
         hipLaunchKernelGGL(dL_ddepth ? gp_composite_bwd_depth_kernel : gp_composite_bwd_kernel, dim3((unsigned)T * GP_BWD_PARTS),
                            dim3(64), 0, s, d, il.ranges, point_list, (const uint8_t*)point_list + gp_align_up((size_t)R * 4, 256), gl.rec,
-                           (const GpPixPair*)pp, g_mean2D, g_conic, g_opacity, g_color, g_depth, order_bwd);
+                           st->bg, (const float*)fwd->color, (const float*)fwd->depth, (const float*)il.final_T,
+                           (const int32_t*)il.n_contrib, dL_dcolor, dL_ddepth, g_mean2D, g_conic, g_opacity, g_color, g_depth, order_bwd);
         GP_LAUNCH_CHECK();
     }
     {

@@ -294,11 +294,30 @@ __global__ __launch_bounds__(256) void gp_adam_multi_kernel(AdamTable t, float b
     }
 }
 
-// loss = (1-lam) * sums[0]/n + lam * (1 - sums[1]/n)   (one thread; keeps the scalar on the device)
-__global__ void gp_loss_finalize_kernel(const double* __restrict__ sums, double n, float lambda, float* __restrict__ loss) {
-    double s0 = 0.0, s1 = 0.0;
-    for (int k = 0; k < GP_LOSS_SUM_SLOTS; ++k) { s0 += sums[2 * k]; s1 += sums[2 * k + 1]; }   // fixed order
-    loss[0] = (float)((1.0 - (double)lambda) * s0 / n + (double)lambda * (1.0 - s1 / n));
+// The slot totals in a fixed order (the result does not depend on which workgroup added to which slot first): thread k loads
+// slot k, xor-butterfly inside the wave, the four wave sums through LDS.  (Round 2 let ONE thread walk the 256 slots: 512
+// dependent double loads, 19 us for a scalar.)
+static_assert(GP_LOSS_SUM_SLOTS == 256, "one slot per thread");
+__device__ __forceinline__ void loss_slot_totals(const double* __restrict__ sums, double* s_red /*[8]*/, double& s0, double& s1) {
+    const int tid = threadIdx.x;
+    double a = sums[2 * tid], b = sums[2 * tid + 1];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        a += __shfl_xor(a, d);
+        b += __shfl_xor(b, d);
+    }
+    if ((tid & 63) == 0) { s_red[2 * (tid >> 6)] = a; s_red[2 * (tid >> 6) + 1] = b; }
+    __syncthreads();
+    s0 = (s_red[0] + s_red[2]) + (s_red[4] + s_red[6]);
+    s1 = (s_red[1] + s_red[3]) + (s_red[5] + s_red[7]);
+}
+
+// loss = (1-lam) * sums[0]/n + lam * (1 - sums[1]/n)   (keeps the scalar on the device)
+__global__ __launch_bounds__(256) void gp_loss_finalize_kernel(const double* __restrict__ sums, double n, float lambda, float* __restrict__ loss) {
+    __shared__ double s_tot[8];
+    double s0, s1;
+    loss_slot_totals(sums, s_tot, s0, s1);
+    if (threadIdx.x == 0) loss[0] = (float)((1.0 - (double)lambda) * s0 / n + (double)lambda * (1.0 - s1 / n));
 }
 
 // the same + scale/n * sum|x| (one workgroup; fixed summation order)
@@ -306,14 +325,23 @@ __global__ __launch_bounds__(256) void gp_loss_finalize_reg_kernel(const double*
                                                                   const float* __restrict__ x, long nx, float scale_over_n,
                                                                   float* __restrict__ loss) {
     __shared__ float s_red[4];
+    __shared__ double s_tot[8];
     float acc = 0.f;
-    for (long i = threadIdx.x; i < nx; i += 256) acc += fabsf(x[i]);
-    const float tot = block_sum_256(acc, s_red);
-    if (threadIdx.x == 0) {
-        double s0 = 0.0, s1 = 0.0;
-        for (int k = 0; k < GP_LOSS_SUM_SLOTS; ++k) { s0 += sums[2 * k]; s1 += sums[2 * k + 1]; }
-        loss[0] = (float)((1.0 - (double)lambda) * s0 / n + (double)lambda * (1.0 - s1 / n)) + tot * scale_over_n;
+    if ((nx & 3) == 0 && (((uintptr_t)x) & 15) == 0) {          // 16-byte loads, four independent per thread in flight
+        const float4* x4 = (const float4*)x;
+        const long n4 = nx >> 2;
+        for (long i = threadIdx.x; i < n4; i += 256) {
+            const float4 v = x4[i];
+            acc += (fabsf(v.x) + fabsf(v.y)) + (fabsf(v.z) + fabsf(v.w));
+        }
+    } else {
+        for (long i = threadIdx.x; i < nx; i += 256) acc += fabsf(x[i]);
     }
+    const float tot = block_sum_256(acc, s_red);
+    double s0, s1;
+    loss_slot_totals(sums, s_tot, s0, s1);
+    if (threadIdx.x == 0)
+        loss[0] = (float)((1.0 - (double)lambda) * s0 / n + (double)lambda * (1.0 - s1 / n)) + tot * scale_over_n;
 }
 
 // out[0] = base[0] + scale * mean|x|   [REF scene/gaussian_model.py:174-178: 1e-5 * mean(|motion feature|)]
@@ -364,7 +392,7 @@ extern "C" int gp_loss_l1_ssim_forward(const float* img, const float* gt, int32_
 extern "C" int gp_loss_l1_ssim_finalize(const double* sums, int32_t channels, int32_t H, int32_t W, float lambda_dssim, float* loss,
                                         gp_stream_t stream_) {
     if (!sums || !loss) GP_FAIL("null argument");
-    hipLaunchKernelGGL(gp_loss_finalize_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream_, sums, (double)channels * H * W, lambda_dssim, loss);
+    hipLaunchKernelGGL(gp_loss_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream_, sums, (double)channels * H * W, lambda_dssim, loss);
     GP_LAUNCH_CHECK();
     return 0;
 }

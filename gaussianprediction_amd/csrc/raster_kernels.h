@@ -35,12 +35,9 @@ __global__ __launch_bounds__(256) void gp_mark_visible_kernel(int n, const float
                                                              const float* __restrict__ view, uint8_t* __restrict__ present);
 
 
-__global__ __launch_bounds__(256) void gp_gather_tiles_kernel(const uint32_t* __restrict__ sorted_ids,
-                                                             const uint2* __restrict__ tiles_touched,
-                                                             uint32_t* __restrict__ out, uint2* __restrict__ rect_sorted, int n);
-
 __global__ __launch_bounds__(256) void gp_duplicate_kernel(RasterDims d, const uint32_t* __restrict__ sorted_ids,
                                                           const uint32_t* __restrict__ offsets,
+                                                          const uint32_t* __restrict__ block_sums, const uint32_t* __restrict__ total,
                                                           const uint2* __restrict__ rect_sorted,
                                                           uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, uint32_t capacity,
                                                           uint32_t* __restrict__ status, uint32_t n_dup_blocks);
@@ -88,14 +85,10 @@ __global__ __launch_bounds__(256) void gp_composite_fwd_sbc_kernel(RasterDims d,
                                                                   float* __restrict__ final_T,
                                                                   int32_t* __restrict__ n_contrib, const uint32_t* __restrict__ order, int32_t* __restrict__ tile_work, uint8_t* __restrict__ qmask);
 
-struct GpPixPair;
-__global__ __launch_bounds__(256) void gp_bwd_pixprep_kernel(RasterDims d, const float* __restrict__ bg, const float* __restrict__ out_color,
-                                                             const float* __restrict__ out_depth, const float* __restrict__ final_T,
-                                                             const int32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpix,
-                                                             const float* __restrict__ dL_dpixdepth, GpPixPair* __restrict__ pp);
-__global__ __launch_bounds__(64) void gp_composite_bwd_kernel(RasterDims d, const int2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
-    const uint8_t* __restrict__ qmask, const float4* __restrict__ rec, const GpPixPair* __restrict__ pp, float* __restrict__ g_mean2D, float* __restrict__ g_conic,
-    float* __restrict__ g_opacity, float* __restrict__ g_color, float* __restrict__ g_depth, const uint32_t* __restrict__ order);
-__global__ __launch_bounds__(64) void gp_composite_bwd_depth_kernel(RasterDims d, const int2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
-    const uint8_t* __restrict__ qmask, const float4* __restrict__ rec, const GpPixPair* __restrict__ pp, float* __restrict__ g_mean2D, float* __restrict__ g_conic,
-    float* __restrict__ g_opacity, float* __restrict__ g_color, float* __restrict__ g_depth, const uint32_t* __restrict__ order);
+#define GP_CB_ARGS RasterDims d, const int2* __restrict__ ranges, const uint32_t* __restrict__ point_list, \
+    const uint8_t* __restrict__ qmask, const float4* __restrict__ rec, const float* __restrict__ bg, const float* __restrict__ out_color, \
+    const float* __restrict__ out_depth, const float* __restrict__ final_T, const int32_t* __restrict__ n_contrib, \
+    const float* __restrict__ dL_dpix, const float* __restrict__ dL_dpixdepth, float* __restrict__ g_mean2D, float* __restrict__ g_conic, \
+    float* __restrict__ g_opacity, float* __restrict__ g_color, float* __restrict__ g_depth, const uint32_t* __restrict__ order
+__global__ __launch_bounds__(64) void gp_composite_bwd_kernel(GP_CB_ARGS);
+__global__ __launch_bounds__(64) void gp_composite_bwd_depth_kernel(GP_CB_ARGS);

@@ -373,34 +373,28 @@ __global__ __launch_bounds__(256) void gp_mark_visible_kernel(int n, const float
 // ------------------------------------------------------------------------------------------------
 // binning helpers
 // ------------------------------------------------------------------------------------------------
-// tiles touched and tile rectangles, in depth order (counts: n+1 entries, last = 0 so the exclusive scan yields the total)
-__global__ __launch_bounds__(256) void gp_gather_tiles_kernel(const uint32_t* __restrict__ sorted_ids,
-                                                             const uint2* __restrict__ tiles_touched,
-                                                             uint32_t* __restrict__ out, uint2* __restrict__ rect_sorted, int n) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < n) {
-        const uint2 r = tiles_touched[sorted_ids[i]];
-        rect_sorted[i] = r;
-        out[i] = (r.y & 0xFFFFu) * (r.y >> 16);
-    } else if (i == n) out[i] = 0;
-}
-// Expand every visible Gaussian into its (tile key, id) instances at offsets[i] .. (exclusive prefix sum over the depth order).
+// Expand every visible Gaussian into its (tile key, id) instances at offset[i] .. (exclusive prefix sum of the tile counts over
+// the depth order).  The prefix arrives in two pieces -- `offsets` scanned inside blocks of GP_SCAN_TILE entries and the blocks'
+// totals (gp_scan_blocks_u32) -- and every workgroup adds up the totals in front of its block itself (a few hundred values, one
+// reduction): one scan launch instead of three.  `total[0]` = R.
 // Wave-cooperative: the 64 Gaussians of a wave own one CONTIGUOUS run of instances, so the wave walks that run 64 entries
 // at a time -- each lane finds its entry's owner by a binary search over the wave's relative offsets (LDS) -- and every
-// store is one coalesced 256-byte line; the tile rectangles arrive in depth order from gp_gather_tiles_kernel, so nothing is
-// gathered here.  (One thread per Gaussian re-deriving its rectangle from `rec[id]` and looping over its own tiles: three
+// store is one coalesced 256-byte line; the tile rectangles arrive in depth order from the depth sort's last pass
+// (GpSortEpilogue), so nothing is gathered here.  (One thread per Gaussian re-deriving its rectangle from `rec[id]` and looping over its own tiles: three
 // random gathers per Gaussian, 64-way scattered stores, and one large footprint serialising its whole wave.)
 __global__ __launch_bounds__(256) void gp_duplicate_kernel(RasterDims d, const uint32_t* __restrict__ sorted_ids,
                                                           const uint32_t* __restrict__ offsets,
+                                                          const uint32_t* __restrict__ block_sums, const uint32_t* __restrict__ total_R,
                                                           const uint2* __restrict__ rect_sorted,
                                                           uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, uint32_t capacity,
                                                           uint32_t* __restrict__ status, uint32_t n_dup_blocks) {
     __shared__ int4 s_own[4][64];        // (relative offset, first tile x, first tile y, tiles per row)
     __shared__ uint32_t s_id[4][64];
+    __shared__ uint32_t s_part[4];
     if (blockIdx.x >= n_dup_blocks) {
         // capacity mode, the blocks behind the expansion: status = {R, R > capacity} and sentinel keys behind the R real
         // instances (their values are never read: no tile range covers them) -- two tiny kernels folded into this launch
-        const uint32_t R = offsets[d.N];
+        const uint32_t R = total_R[0];
         if (blockIdx.x == n_dup_blocks && threadIdx.x == 0) { status[0] = R; status[1] = R > capacity ? 1u : 0u; }
         const uint32_t b0 = (blockIdx.x - n_dup_blocks) * 4096u;
         for (uint32_t i = b0 + threadIdx.x; i < b0 + 4096u && i < capacity; i += 256u)
@@ -408,6 +402,17 @@ __global__ __launch_bounds__(256) void gp_duplicate_kernel(RasterDims d, const u
         return;
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t before = 0;                                     // instances of the scan blocks in front of this workgroup's
+    {
+        const int nsb = (blockIdx.x * 256) / GP_SCAN_TILE;   // (256 consecutive Gaussians never straddle a scan block)
+        uint32_t acc = 0;
+        for (int b = threadIdx.x; b < nsb; b += 256) acc += block_sums[b];
+#pragma unroll
+        for (int dd = 32; dd >= 1; dd >>= 1) acc += __shfl_xor(acc, dd);
+        if (lane == 0) s_part[wave] = acc;
+        __syncthreads();
+        before = s_part[0] + s_part[1] + s_part[2] + s_part[3];
+    }
     const int i0 = blockIdx.x * 256 + wave * 64;             // uniform per wave
     if (i0 >= d.N) return;
     const int i = i0 + lane;
@@ -421,7 +426,7 @@ __global__ __launch_bounds__(256) void gp_duplicate_kernel(RasterDims d, const u
         cnt = w * (int)(r.y >> 16);
         if (w < 1) w = 1;
     }
-    const uint32_t base = offsets[i0];
+    const uint32_t base = before + offsets[i0];
     int incl = cnt;                                          // inclusive scan of the counts over the wave
 #pragma unroll
     for (int dlt = 1; dlt < 64; dlt <<= 1) {
@@ -1069,31 +1074,17 @@ __device__ __forceinline__ void dpp_scan2_mul(float& a, float& b) {
 
 
 
-// Per-pixel-pair constants, prepared once per backward by gp_bwd_pixprep_kernel (coalesced, ~0.03 ms) so that the
-// composite waves start with one 64-byte load per lane instead of 14 strided ones:
-// per (tile, quadrant) GP_BWD_PAIRS pairs x 16 dwords
-//   [0..3] dLr0 dLr1 dLg0 dLg1  [4..7] dLb0 dLb1 tb0 tb1  [8,9] nc0 nc1  [10,11] rem0 rem1  [12,13] dLd0 dLd1
+// Per-pixel-pair constants of the backward: per (tile, quadrant) GP_BWD_PAIRS pairs x 4 float4
+//   o[0] dLr0 dLr1 dLg0 dLg1   o[1] dLb0 dLb1 tb0 tb1   o[2] nc0 nc1 rem0 rem1   o[3] dLd0 dLd1 - -
 // (tb = T_final * bg . dL_dpix, nc = n_contrib, rem = initial remaining suffix)
-struct GpPixPair { float v[16]; };
-
-template <int ROWS, int COLS>
-__device__ __forceinline__ void gp_bwd_pixprep_body(RasterDims d, const float* __restrict__ bg, const float* __restrict__ out_color,
-                                                    const float* __restrict__ out_depth, const float* __restrict__ final_T,
-                                                    const int32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpix,
-                                                    const float* __restrict__ dL_dpixdepth, GpPixPair* __restrict__ pp) {
-    const int parts_x = GP_TILE / COLS, parts = (GP_TILE / ROWS) * parts_x;
-    const int PAIRS = ROWS * COLS / 2;
-    const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
-    const size_t total = (size_t)d.gx * d.gy * parts * PAIRS;
-    if (gid >= total) return;
-    const int pr = (int)(gid % PAIRS);
-    const int tp = (int)(gid / PAIRS);
-    const int tile = tp / parts, part = tp % parts;
-    const int tx = tile % d.gx, ty = tile / d.gx;
+// The per-pixel-pair constants of the backward, from the forward's outputs and the incoming gradient: o[0..3] as listed above.
+// Round 2 computed them in a launch of their own (gp_bwd_pixprep_kernel: 88 MB of traffic + a launch, 0.032 ms at c3); every
+// pair is consumed by exactly one wave of the composite backward, whose prologue now computes its 32 pairs itself.
+__device__ __forceinline__ void gp_pixpair(const RasterDims& d, int px0, int py, float bg0, float bg1, float bg2,
+                                           const float* __restrict__ out_color, const float* __restrict__ out_depth,
+                                           const float* __restrict__ final_T, const int32_t* __restrict__ n_contrib,
+                                           const float* __restrict__ dL_dpix, const float* __restrict__ dL_dpixdepth, float4* o) {
     const size_t HW = (size_t)d.H * d.W;
-    const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
-    const int px0 = tx * GP_TILE + (part % parts_x) * COLS + 2 * (pr % (COLS / 2));
-    const int py = ty * GP_TILE + (part / parts_x) * ROWS + pr / (COLS / 2);
     float dl[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
     float tb[2] = {0.f, 0.f}, rem[2] = {0.f, 0.f};
     int nc[2] = {0, 0};
@@ -1110,23 +1101,20 @@ __device__ __forceinline__ void gp_bwd_pixprep_body(RasterDims d, const float* _
             nc[u] = n_contrib[pix];
         }
     }
-    float4* o = (float4*)&pp[gid];
     o[0] = make_float4(dl[0][0], dl[1][0], dl[0][1], dl[1][1]);
     o[1] = make_float4(dl[0][2], dl[1][2], tb[0], tb[1]);
     o[2] = make_float4(__int_as_float(nc[0]), __int_as_float(nc[1]), rem[0], rem[1]);
     o[3] = make_float4(dl[0][3], dl[1][3], 0.f, 0.f);
 }
-__global__ __launch_bounds__(256) void gp_bwd_pixprep_kernel(RasterDims d, const float* __restrict__ bg, const float* __restrict__ out_color,
-                                                             const float* __restrict__ out_depth, const float* __restrict__ final_T,
-                                                             const int32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpix,
-                                                             const float* __restrict__ dL_dpixdepth, GpPixPair* __restrict__ pp) {
-    gp_bwd_pixprep_body<GP_BWD_ROWS, GP_BWD_COLS>(d, bg, out_color, out_depth, final_T, n_contrib, dL_dpix, dL_dpixdepth, pp);
-}
 
 template <bool HAS_DEPTH, int ROWS, int COLS>
 __device__ __forceinline__ void gp_composite_bwd_body(RasterDims d, const int2* __restrict__ ranges,
                                                        const uint32_t* __restrict__ point_list, const uint8_t* __restrict__ qmask,
-                                                       const float4* __restrict__ rec, const GpPixPair* __restrict__ pp, float* __restrict__ g_mean2D,
+                                                       const float4* __restrict__ rec, const float* __restrict__ bg,
+                                                       const float* __restrict__ out_color, const float* __restrict__ out_depth,
+                                                       const float* __restrict__ final_T, const int32_t* __restrict__ n_contrib,
+                                                       const float* __restrict__ dL_dpix, const float* __restrict__ dL_dpixdepth,
+                                                       float* __restrict__ g_mean2D,
                                                        float* __restrict__ g_conic, float* __restrict__ g_opacity,
                                                        float* __restrict__ g_color, float* __restrict__ g_depth,
                                                        const uint32_t* __restrict__ order) {
@@ -1142,12 +1130,13 @@ __device__ __forceinline__ void gp_composite_bwd_body(RasterDims d, const int2* 
     const int tx = tile % d.gx, ty = tile / d.gx;
     const int lane = threadIdx.x;
     const int2 range = ranges[tile];
-    const GpPixPair* __restrict__ mypp = pp + ((size_t)tile * parts + part) * PAIRS;   // uniform base
     int max_nc;
     {
         max_nc = 0;
         if (lane < PAIRS) {
-            const float4* me = (const float4*)&mypp[lane];
+            float4 me[4];
+            gp_pixpair(d, tx * GP_TILE + (part % parts_x) * COLS + 2 * (lane % (COLS / 2)), ty * GP_TILE + (part / parts_x) * ROWS + lane / (COLS / 2),
+                       bg[0], bg[1], bg[2], out_color, out_depth, final_T, n_contrib, dL_dpix, HAS_DEPTH ? dL_dpixdepth : nullptr, me);
             const float4 t0 = me[0], t1 = me[1], t = me[2];
             s_pp[lane][1] = t0; s_pp[lane][2] = t1;
             s_pp[lane][0] = make_float4(t.x, t.y, 0.f, 0.f);
@@ -1466,14 +1455,16 @@ __device__ __forceinline__ void gp_composite_bwd_body(RasterDims d, const int2* 
     }
 }
 #define CB_ARGS RasterDims d, const int2* __restrict__ ranges, const uint32_t* __restrict__ point_list, \
-    const uint8_t* __restrict__ qmask, const float4* __restrict__ rec, const GpPixPair* __restrict__ pp, float* __restrict__ g_mean2D, \
+    const uint8_t* __restrict__ qmask, const float4* __restrict__ rec, const float* __restrict__ bg, const float* __restrict__ out_color, \
+    const float* __restrict__ out_depth, const float* __restrict__ final_T, const int32_t* __restrict__ n_contrib, \
+    const float* __restrict__ dL_dpix, const float* __restrict__ dL_dpixdepth, float* __restrict__ g_mean2D, \
     float* __restrict__ g_conic, float* __restrict__ g_opacity, float* __restrict__ g_color, float* __restrict__ g_depth, \
     const uint32_t* __restrict__ order
 __global__ __launch_bounds__(64) void gp_composite_bwd_kernel(CB_ARGS) {
-    gp_composite_bwd_body<false, GP_BWD_ROWS, GP_BWD_COLS>(d, ranges, point_list, qmask, rec, pp, g_mean2D, g_conic, g_opacity, g_color, g_depth, order);
+    gp_composite_bwd_body<false, GP_BWD_ROWS, GP_BWD_COLS>(d, ranges, point_list, qmask, rec, bg, out_color, out_depth, final_T, n_contrib, dL_dpix, dL_dpixdepth, g_mean2D, g_conic, g_opacity, g_color, g_depth, order);
 }
 __global__ __launch_bounds__(64) void gp_composite_bwd_depth_kernel(CB_ARGS) {
-    gp_composite_bwd_body<true, GP_BWD_ROWS, GP_BWD_COLS>(d, ranges, point_list, qmask, rec, pp, g_mean2D, g_conic, g_opacity, g_color, g_depth, order);
+    gp_composite_bwd_body<true, GP_BWD_ROWS, GP_BWD_COLS>(d, ranges, point_list, qmask, rec, bg, out_color, out_depth, final_T, n_contrib, dL_dpix, dL_dpixdepth, g_mean2D, g_conic, g_opacity, g_color, g_depth, order);
 }
 
 // Adam on the workgroup's span of SH-rest coefficients, gradients taken from LDS (instead of unstage_sh + a later pass of the

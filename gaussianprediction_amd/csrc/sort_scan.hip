@@ -14,9 +14,10 @@
 #define SCAN_ITEMS 8
 #define SCAN_BLOCK 256
 #define SCAN_TILE (SCAN_ITEMS * SCAN_BLOCK)
+static_assert(SCAN_TILE == GP_SCAN_TILE, "gp_duplicate_kernel finishes the scan of blocks of GP_SCAN_TILE elements");
 
 __global__ __launch_bounds__(SCAN_BLOCK) void gp_scan_block_kernel(uint32_t* __restrict__ data, size_t n,
-                                                                  uint32_t* __restrict__ block_sums) {
+                                                                  uint32_t* __restrict__ block_sums, uint32_t* __restrict__ total) {
     __shared__ uint32_t s_wave[SCAN_BLOCK / GP_WAVE];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const size_t base = (size_t)blockIdx.x * SCAN_TILE + (size_t)tid * SCAN_ITEMS;
@@ -43,7 +44,21 @@ __global__ __launch_bounds__(SCAN_BLOCK) void gp_scan_block_kernel(uint32_t* __r
         if (base + i < n) data[base + i] = run;
         run += v[i];
     }
-    if (tid == SCAN_BLOCK - 1) block_sums[blockIdx.x] = wave_off + x;
+    if (tid == SCAN_BLOCK - 1) {
+        block_sums[blockIdx.x] = wave_off + x;
+        if (total) atomicAdd(total, wave_off + x);      // (integer: the sum does not depend on the order)
+    }
+}
+
+// One-launch form for consumers that can finish the scan themselves (gp_duplicate_kernel): block-local exclusive scan in place,
+// block_sums[b] = the block's total, *total += all of it (the caller zeroes it).  The consumer adds the sum of the block sums
+// in front of its block -- a few hundred values it reduces in one step -- instead of two more launches doing that for it.
+int gp_scan_blocks_u32(uint32_t* data, size_t n, uint32_t* block_sums, uint32_t* total, hipStream_t s) {
+    if (n == 0) return 0;
+    const size_t nb = (n + SCAN_TILE - 1) / SCAN_TILE;
+    hipLaunchKernelGGL(gp_scan_block_kernel, dim3((unsigned)nb), dim3(SCAN_BLOCK), 0, s, data, n, block_sums, total);
+    GP_LAUNCH_CHECK();
+    return 0;
 }
 
 __global__ __launch_bounds__(256) void gp_scan_add_kernel(uint32_t* __restrict__ data, size_t n,
@@ -67,7 +82,7 @@ int gp_scan_exclusive_u32(uint32_t* data, size_t n, uint32_t* tmp, size_t tmp_el
     if (n == 0) return 0;
     size_t nb = (n + SCAN_TILE - 1) / SCAN_TILE;
     if (tmp_elems < gp_align_up(nb, 64)) GP_FAIL("scan: temp storage too small");
-    hipLaunchKernelGGL(gp_scan_block_kernel, dim3((unsigned)nb), dim3(SCAN_BLOCK), 0, s, data, n, tmp);
+    hipLaunchKernelGGL(gp_scan_block_kernel, dim3((unsigned)nb), dim3(SCAN_BLOCK), 0, s, data, n, tmp, (uint32_t*)nullptr);
     GP_LAUNCH_CHECK();
     if (nb > 1) {
         size_t used = gp_align_up(nb, 64);
@@ -159,7 +174,7 @@ __global__ __launch_bounds__(RS_BLOCK) void gp_radix_scatter_kernel(const uint32
                                                                     uint32_t* __restrict__ vals_out,
                                                                     const uint32_t* __restrict__ hist_scanned,
                                                                     const uint32_t* __restrict__ totals, size_t n,
-                                                                    int shift, uint32_t mask, uint32_t nblocks) {
+                                                                    int shift, uint32_t mask, uint32_t nblocks, GpSortEpilogue ep) {
     constexpr int RS_TILE = RS_ITEMS * RS_BLOCK;
     __shared__ uint32_t s_cnt[RS_BLOCK / GP_WAVE][256];
     __shared__ uint32_t s_dbase[256], s_dw[4];
@@ -253,14 +268,20 @@ __global__ __launch_bounds__(RS_BLOCK) void gp_radix_scatter_kernel(const uint32
     for (uint32_t p = tid; p < bn; p += RS_BLOCK) {
         const uint32_t kk = s_k[p];
         const uint32_t pos = p + s_dbase[(kk >> shift) & mask];
+        const uint32_t vv = s_v[p];
         keys_out[pos] = kk;
-        vals_out[pos] = s_v[p];
+        vals_out[pos] = vv;
+        if (ep.by_value) {      // last pass of the depth sort: the per-Gaussian tile rectangle follows its id into sorted order
+            const uint2 r = ep.by_value[vv];
+            ep.sorted_out[pos] = r;
+            ep.count_out[pos] = (r.y & 0xFFFFu) * (r.y >> 16);
+        }
     }
 }
 
 // the histogram kernel above partitions by block only (order inside a block is irrelevant for
 // counts), the scatter kernel uses the same block partition [b*4096, (b+1)*4096).
-int gp_radix_sort_pairs(GpSortBufs& b, size_t n, int nbits, hipStream_t s, bool iota_vals) {
+int gp_radix_sort_pairs(GpSortBufs& b, size_t n, int nbits, hipStream_t s, bool iota_vals, const GpSortEpilogue* epilogue) {
     if (n == 0 || nbits <= 0) return 0;
     const int items = rs_items_for(n);
     const size_t tile = (size_t)items * RS_BLOCK;
@@ -270,6 +291,8 @@ int gp_radix_sort_pairs(GpSortBufs& b, size_t n, int nbits, hipStream_t s, bool 
         const int bits = (nbits - shift) < 8 ? (nbits - shift) : 8;
         const uint32_t mask = (1u << bits) - 1u;
         const uint32_t* vin = (shift == 0 && iota_vals) ? nullptr : b.v[cur];
+        GpSortEpilogue ep = {nullptr, nullptr, nullptr};
+        if (epilogue && shift + 8 >= nbits) ep = *epilogue;      // (last pass)
         if (items == RS_ITEMS_SMALL)
             hipLaunchKernelGGL((gp_radix_hist_kernel<RS_ITEMS_SMALL>), dim3(nblocks), dim3(RS_BLOCK), 0, s, b.k[cur], n, shift, mask,
                                b.hist, nblocks);
@@ -284,13 +307,13 @@ int gp_radix_sort_pairs(GpSortBufs& b, size_t n, int nbits, hipStream_t s, bool 
         hipLaunchKernelGGL(gp_radix_rowscan_kernel, dim3(256), dim3(256), 0, s, b.hist, nblocks, b.scan_tmp);
         if (items == RS_ITEMS_SMALL)
             hipLaunchKernelGGL((gp_radix_scatter_kernel<RS_ITEMS_SMALL>), dim3(nblocks), dim3(RS_BLOCK), 0, s, b.k[cur], vin,
-                               b.k[cur ^ 1], b.v[cur ^ 1], b.hist, b.scan_tmp, n, shift, mask, nblocks);
+                               b.k[cur ^ 1], b.v[cur ^ 1], b.hist, b.scan_tmp, n, shift, mask, nblocks, ep);
         else if (items == RS_ITEMS_MID)
             hipLaunchKernelGGL((gp_radix_scatter_kernel<RS_ITEMS_MID>), dim3(nblocks), dim3(RS_BLOCK), 0, s, b.k[cur], vin,
-                               b.k[cur ^ 1], b.v[cur ^ 1], b.hist, b.scan_tmp, n, shift, mask, nblocks);
+                               b.k[cur ^ 1], b.v[cur ^ 1], b.hist, b.scan_tmp, n, shift, mask, nblocks, ep);
         else
             hipLaunchKernelGGL((gp_radix_scatter_kernel<RS_ITEMS_LARGE>), dim3(nblocks), dim3(RS_BLOCK), 0, s, b.k[cur], vin,
-                               b.k[cur ^ 1], b.v[cur ^ 1], b.hist, b.scan_tmp, n, shift, mask, nblocks);
+                               b.k[cur ^ 1], b.v[cur ^ 1], b.hist, b.scan_tmp, n, shift, mask, nblocks, ep);
         if (hipGetLastError() != hipSuccess) { snprintf(gp_err_buf, sizeof(gp_err_buf), "radix scatter launch failed"); return -1; }
         cur ^= 1;
     }
