@@ -278,6 +278,49 @@ extern "C" int gp_knn_keypoints(int64_t n, const float* xyz, const float* feat, 
 }
 
 // ------------------------------------------------------------------------------------------------
+// Mean squared distance of every point to its three nearest OTHER points -- simple_knn's distCUDA2, which sizes the initial
+// Gaussians in create_from_pcd [REF scene/gaussian_model.py:340-341].  simple_knn is an un-vendored CUDA dependency of the
+// reference (published algorithm: exact 3-NN over Morton-ordered boxes, self excluded BY INDEX -- a coincident point counts
+// with distance 0 -- result (d0 + d1 + d2) / 3 of the SQUARED distances): parity unpinned, oracle/weights_oracle.py states it.
+// Initialisation-time, run once: exact brute force, every workgroup streams all points through LDS in tiles of 256 (the
+// inner product form is NOT used: (x - y)^2 summed per axis keeps coincident points at exactly 0).  1e5 points: ~3 ms.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gp_knn3_mean_dist2_kernel(long n, const float* __restrict__ xyz, float* __restrict__ out) {
+    __shared__ float4 s_p[256];
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    float qx = 0.f, qy = 0.f, qz = 0.f;
+    if (i < n) { qx = xyz[3 * i]; qy = xyz[3 * i + 1]; qz = xyz[3 * i + 2]; }
+    float b0 = 3.402823466e38f, b1 = b0, b2 = b0;          // ascending; FLT_MAX where fewer than three other points exist
+    for (long t0 = 0; t0 < n; t0 += 256) {
+        const long j = t0 + threadIdx.x;
+        __syncthreads();
+        s_p[threadIdx.x] = j < n ? make_float4(xyz[3 * j], xyz[3 * j + 1], xyz[3 * j + 2], 0.f) : make_float4(0.f, 0.f, 0.f, 0.f);
+        __syncthreads();
+        const int cnt = (int)((n - t0) < 256 ? (n - t0) : 256);
+        for (int k = 0; k < cnt; ++k) {
+            const float4 p = s_p[k];                       // (broadcast read)
+            const float dx = p.x - qx, dy = p.y - qy, dz = p.z - qz;
+            float d = fmaf(dx, dx, fmaf(dy, dy, dz * dz));
+            if (t0 + k == i) d = 3.402823466e38f;           // self, by index
+            if (d < b2) {
+                if (d < b1) { b2 = b1; if (d < b0) { b1 = b0; b0 = d; } else b1 = d; }
+                else b2 = d;
+            }
+        }
+    }
+    if (i < n) out[i] = (b0 + b1 + b2) / 3.f;
+}
+
+extern "C" int gp_knn3_mean_dist2(int64_t n, const float* xyz, float* out, gp_stream_t stream_) {
+    if (n < 0) GP_FAIL("negative size");
+    if (n == 0) return 0;
+    if (!xyz || !out) GP_FAIL("null argument");
+    hipLaunchKernelGGL(gp_knn3_mean_dist2_kernel, dim3(gp_blocks((size_t)n, 256)), dim3(256), 0, (hipStream_t)stream_, (long)n, xyz, out);
+    GP_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
 // Fused weights model: hash-grid encoding + the 64-wide bias-free MLP (64 -> 64 -> 64 -> 16, ReLU) on the exact-fp32
 // matrix cores, persistent workgroups.  A workgroup walks blocks of 64 points (in `perm` order); per block the
 // activations live transposed in LDS, T[f][p] at f*64 + (p & 32) + ((p & 31) ^ (f & 31)) -- conflict-free both for the

@@ -19,7 +19,7 @@ from torch import nn
 from .deform_ops import Activations, KeypointBlend
 from .deformable_field import Deformable_Field
 from .training import TrainingMixin
-from .weights_ops import WeightsModel, knn_keypoints
+from .weights_ops import WeightsModel, dist_cuda2, knn_keypoints
 
 
 class GaussianModel(TrainingMixin, nn.Module):
@@ -37,6 +37,8 @@ class GaussianModel(TrainingMixin, nn.Module):
         self.xyz_input_dim = None
         self.knn_idx = None
         self.raw_weights = None
+        self.N_pcd_init = None                     # [REF scene/gaussian_model.py:70-71]: set by train.py / eval.py before create_from_pcd
+        self.final_kpts_num = None                 #   to size a model that a checkpoint is then loaded into
         self.lifecycle_opacity = None
         self._last_delta = None
         self._last_blend = None
@@ -46,7 +48,37 @@ class GaussianModel(TrainingMixin, nn.Module):
         self.time_input_dim = time_input_dim
         self.xyz_input_dim = xyz_input_dim
 
-    # ---- construction from raw tensors (stand-in for create_from_pcd, REF :327-392) ---------------
+    def create_from_pcd(self, pcd, spatial_lr_scale: float, device="cuda"):
+        """[REF scene/gaussian_model.py:327-392]: Gaussians from a point cloud (`pcd.points` [N,3], `pcd.colors` [N,3] in 0..1):
+        positions = the points, DC colour = RGB2SH(colour), isotropic scale = sqrt of the mean squared distance to the three
+        nearest points (`distCUDA2`), identity rotation, opacity 0.1, motion features 1e-3 U(-1,1), keypoints all ones
+        (`final_kpts_num` or `max_points` of them: placeholders until set_superKeypoints / a checkpoint), the hash-grid weights
+        model.  `N_pcd_init` (set by train.py / eval.py when a checkpoint will be loaded) replaces the cloud by that many
+        copies of its first point, exactly as the reference does."""
+        import numpy as np
+        self.spatial_lr_scale = spatial_lr_scale
+        pts = torch.tensor(np.asarray(pcd.points)).float().to(device)
+        col = (torch.tensor(np.asarray(pcd.colors)).float().to(device) - 0.5) / 0.28209479177387814     # RGB2SH [REF utils/sh_utils.py:114-115]
+        if self.N_pcd_init is not None:
+            pts, col = pts[0:1].repeat(self.N_pcd_init, 1), col[0:1].repeat(self.N_pcd_init, 1)
+        self.N_pcd_init = n = pts.shape[0]
+        features = torch.zeros((n, 3, (self.max_sh_degree + 1) ** 2), device=device)
+        features[:, :3, 0] = col
+        dist2 = torch.clamp_min(dist_cuda2(pts), 0.0000001)
+        scales = torch.log(torch.sqrt(dist2))[..., None].repeat(1, 3)
+        rots = torch.zeros((n, 4), device=device)
+        rots[:, 0] = 1
+        opac = torch.full((n, 1), 0.1, device=device)
+        opac = torch.log(opac / (1 - opac))                                   # inverse_sigmoid [REF utils/general_utils.py:18-19]
+        motion = 1e-3 * (2 * torch.rand((n, self.motion_feature_dim), device=device) - 1)
+        K = self.final_kpts_num if self.final_kpts_num is not None else self.args.max_points
+        self.create_from_tensors(pts, features[:, :, 0:1].transpose(1, 2).contiguous(), features[:, :, 1:].transpose(1, 2).contiguous(),
+                                 scales, rots, opac, motion, torch.ones(K, 3, device=device),
+                                 torch.ones(K, self.motion_feature_dim, device=device), with_weights_model=True)
+        self.active_sh_degree = 0                                             # (oneupSHdegree raises it, train.py:81-83)
+        return self
+
+    # ---- construction from raw tensors ---------------------------------------------------------
     def create_from_tensors(self, xyz, features_dc, features_rest, scaling, rotation, opacity, motion_feature,
                             keypoints=None, keypoint_features=None, with_weights_model=False):
         self._xyz = nn.Parameter(xyz.clone().requires_grad_(True))

@@ -187,3 +187,15 @@ def knn_keypoints(xyz, kp_xyz, nearest_num, feat=None, kp_feat=None, feature_amp
                                          C.c_int32(nearest_num), _lib.ptr(idx), _lib.ptr(d2), _lib.stream_ptr(x.device))
         _lib.check(rc, "gp_knn_keypoints")
     return (idx, d2) if return_dist else idx
+
+
+def dist_cuda2(points):
+    """Mean squared distance of every point to its three nearest other points: `simple_knn._C.distCUDA2`
+    [REF scene/gaussian_model.py:23, 340] (un-vendored CUDA dependency; HIP kernel gp_knn3_mean_dist2, exact brute force)."""
+    _need_cuda(points, "distCUDA2")
+    x = points.detach().to(torch.float32).contiguous()
+    out = torch.empty(x.shape[0], device=x.device)
+    with _lib.on_device(x.device):
+        _lib.check(_lib.lib().gp_knn3_mean_dist2(C.c_int64(x.shape[0]), _lib.ptr(x), _lib.ptr(out), _lib.stream_ptr(x.device)),
+                   "gp_knn3_mean_dist2")
+    return out

@@ -344,6 +344,11 @@ int gp_weights_backward(const gp_hashgrid_config* cfg, int64_t n, const float* x
 int gp_knn_keypoints(int64_t n, const float* xyz, const float* feat, int32_t feat_dim, float amplify, int64_t K,
                      const float* kp_xyz, const float* kp_feat, int32_t nn, int64_t* idx_out, float* d2_out, gp_stream_t stream);
 
+/* out[n] = mean of the squared distances from point i to its three nearest OTHER points (self excluded by index): replaces
+ * simple_knn's distCUDA2, which sizes the initial Gaussians [REF scene/gaussian_model.py:340-341 create_from_pcd].  Exact brute
+ * force, initialisation-time.  Fewer than three other points: the missing ones count as FLT_MAX (as the published kernel). */
+int gp_knn3_mean_dist2(int64_t n, const float* xyz /*[n,3]*/, float* out /*[n]*/, gp_stream_t stream);
+
 /* Furthest-point sampling of xyz[n,3], starting at point 0: idx_out[m] (int32); idx_out[j] is the point farthest from
  * {idx_out[0..j)} (first maximum on ties).  tmp_dist: n floats of scratch.  Replaces pointops' furthestsampling_cuda for one
  * batch [REF utils/fps.py:71-88, scene/gaussian_model.py:196-212 get_new_kpts]. */

@@ -104,3 +104,19 @@ def knn(points: np.ndarray, keypoints: np.ndarray, k: int):
         d2 = d2 + diff * diff
     idx = np.argsort(d2, axis=1, kind="stable")[:, :k]
     return idx.astype(np.int64), np.take_along_axis(d2, idx, axis=1)
+
+
+def knn3_mean_dist2(points):
+    """simple_knn's distCUDA2 [REF scene/gaussian_model.py:340]: mean of the squared distances to the three nearest OTHER points
+    (self excluded by index).  parity unpinned (simple_knn is absent): the published kernel's result, restated with a k-d tree."""
+    import numpy as np
+    from scipy.spatial import cKDTree
+    p = np.asarray(points, np.float64)
+    d, idx = cKDTree(p).query(p, k=min(4, len(p)))
+    out = np.empty(len(p))
+    for i in range(len(p)):                  # drop ONE occurrence of the point's own index (coincident points stay)
+        row = [dd for dd, j in zip(np.atleast_1d(d[i]), np.atleast_1d(idx[i])) if j != i]
+        if len(row) == len(np.atleast_1d(d[i])):
+            row = row[:-1] if len(row) > 3 else row
+        out[i] = np.sum(np.square(row[:3])) / 3.0 if len(row) >= 3 else np.inf
+    return out

@@ -476,3 +476,48 @@ def test_keypoint_weights_and_knn_are_evaluated_once_per_parameter_state():
         assert rel < 1e-4, rel
     finally:
         gm.knn_keypoints, WeightsModel.forward = orig_knn, orig_fwd
+
+
+def test_create_from_pcd_and_the_checkpoint_sizing_path():
+    """[REF scene/gaussian_model.py:327-392; train.py:50-57, eval.py:238-245]: Gaussians from a point cloud (distCUDA2 -> initial
+    scale), and the way the reference sizes a model before `load_state_dict`: N_pcd_init copies of the first point,
+    final_kpts_num keypoints."""
+    from types import SimpleNamespace as NS
+    from gaussianprediction_amd.weights_ops import dist_cuda2
+    from oracle import weights_oracle as wo
+    rng = np.random.default_rng(4)
+    pts = rng.uniform(-1.3, 1.3, size=(5000, 3)).astype(np.float32)
+    pts[100] = pts[7]                                       # a coincident pair: distance exactly 0, counted (self is excluded by index)
+    d2 = dist_cuda2(torch.tensor(pts).cuda()).cpu().numpy()
+    want = wo.knn3_mean_dist2(pts.astype(np.float64))
+    assert np.allclose(d2, want, rtol=2e-5, atol=1e-9) and d2[7] < want.mean()
+    for n in (1, 3, 4, 257):                               # fewer than three other points -> FLT_MAX terms, as the published kernel
+        got = dist_cuda2(torch.tensor(pts[:n]).cuda()).cpu().numpy()
+        assert got.shape == (n,) and (np.isfinite(got).all() and got.max() < 1e30) == (n >= 4)
+    args = margs(max_points=48)
+    pc = gpa.GaussianModel(3, args)
+    pc.set_inputDim(12, 60)
+    cols = rng.uniform(0, 1, size=(5000, 3)).astype(np.float32)
+    pc.create_from_pcd(NS(points=pts, colors=cols, normals=np.zeros_like(pts)), spatial_lr_scale=2.5)
+    assert pc.N_pcd_init == 5000 and pc.spatial_lr_scale == 2.5 and pc.active_sh_degree == 0
+    assert pc._xyz.shape == (5000, 3) and pc._features_dc.shape == (5000, 1, 3) and pc._features_rest.shape == (5000, 15, 3)
+    assert torch.allclose(pc._features_dc[:, 0].cpu(), (torch.tensor(cols) - 0.5) / 0.28209479177387814, atol=1e-6)
+    assert float(pc._features_rest.abs().max()) == 0.0
+    assert np.allclose(pc._scaling.detach().cpu().numpy(), np.log(np.sqrt(np.maximum(want, 1e-7)))[:, None].repeat(3, 1), atol=2e-5)
+    assert torch.equal(pc._rotation.detach().cpu(), torch.tensor([1.0, 0, 0, 0]).repeat(5000, 1))
+    assert torch.allclose(torch.sigmoid(pc._opacity.detach()), torch.full((5000, 1), 0.1, device="cuda"), atol=1e-6)
+    assert pc.super_gaussians.shape == (48, 3) and float(pc.motion_feature.abs().max()) <= 1e-3 and pc.weights_model is not None
+    # render + one training step straight from the point cloud (stage 0/1: static warm-up then the MLP)
+    cams = orbit_cameras(2, 4.0, 0.69, 96, 80, device="cuda")
+    pipe = SimpleNamespace(convert_SHs_python=False, compute_cov3D_python=False, debug=False)
+    img = render(cams[0], pc, pipe, torch.zeros(3, device="cuda"), time=torch.tensor([0.2], device="cuda"), it=100)["render"]
+    assert torch.isfinite(img).all() and float(img.sum()) > 0
+    # the reference's checkpoint path: size an empty model, then load the trained state
+    sd = pc.state_dict()
+    pc2 = gpa.GaussianModel(3, args)
+    pc2.set_inputDim(12, 60)
+    pc2.N_pcd_init, pc2.final_kpts_num = 5000, 48
+    pc2.create_from_pcd(NS(points=pts[:10], colors=cols[:10], normals=None), spatial_lr_scale=2.5)
+    assert pc2._xyz.shape == (5000, 3) and torch.equal(pc2._xyz[0], pc2._xyz[4999])          # N_pcd_init copies of the first point
+    missing, unexpected = pc2.load_state_dict(sd, strict=False)
+    assert not unexpected and torch.equal(pc2._xyz.detach(), pc._xyz.detach()) and torch.equal(pc2.weights_model.params.detach(), pc.weights_model.params.detach())
