@@ -281,7 +281,7 @@ extern "C" int gp_raster_backward(const gp_raster_settings* st, const gp_raster_
         hipLaunchKernelGGL(gp_tile_order_kernel, dim3(1), dim3(1024), 0, s, il.ranges, il.tile_work, (int)T, order_bwd);
         GP_LAUNCH_CHECK();
         GpProfScope _p("composite_bwd", s);
-        hipLaunchKernelGGL(dL_ddepth ? gp_composite_bwd_depth_kernel : gp_composite_bwd_kernel, dim3((unsigned)T * GP_BWD_PARTS),
+        hipLaunchKernelGGL(dL_ddepth ? gp_composite_bwd_depth_kernel : gp_composite_bwd_kernel, dim3((unsigned)((T + 7) / 8 * 8) * GP_BWD_PARTS),
                            dim3(64), 0, s, d, il.ranges, point_list, (const uint8_t*)point_list + gp_align_up((size_t)R * 4, 256), gl.rec,
                            st->bg, (const float*)fwd->color, (const float*)fwd->depth, (const float*)il.final_T,
                            (const int32_t*)il.n_contrib, dL_dcolor, dL_ddepth, g_mean2D, g_conic, g_opacity, g_color, g_depth, order_bwd);
