@@ -31,34 +31,47 @@ class FlatGradBucket:
     the small tensors together (MLP weights, keypoints: one collective instead of twenty).  `flat_params` additionally moves
     the parameters' storage into a second buffer of the same layout (p.data becomes a view), the all-gather operand."""
 
-    def __init__(self, params, shards=1, flat_params=False, small_numel=1 << 20):
+    def __init__(self, params, shards=1, flat_params=False, small_numel=1 << 20, groups=None):
+        """`groups` (sharded layout only): lists of parameters that share ONE region each, in the given order -- one reduce-scatter
+        and one all-gather per group instead of one per tensor (xGMI collectives have a fixed cost of tens of microseconds:
+        fewer, larger ones).  Tensors in no group: a region of their own when large, the common tail region when small."""
         params = [p for p in params if p.requires_grad]
         self.shards = int(shards)
         self.small_numel = int(small_numel)
         regioned = self.shards > 1 or flat_params   # (a one-rank group under GP_DIST_FORCE_SINGLE keeps the sharded layout)
-        if regioned:                                # large tensors first (in order), then the small ones: two kinds of region
-            params = [p for p in params if p.numel() >= small_numel] + [p for p in params if p.numel() < small_numel]
+        plan = []                                   # regioned: [[params of region 0], ...], the tail region last
+        if regioned:
+            known = {id(p) for p in params}
+            grouped = set()
+            for g in (groups or []):
+                members = [p for p in g if id(p) in known and id(p) not in grouped]
+                if members and sum(p.numel() for p in members) >= small_numel:
+                    plan.append(members)
+                    grouped.update(id(p) for p in members)
+            rest = [p for p in params if id(p) not in grouped]
+            plan += [[p] for p in rest if p.numel() >= small_numel]
+            tail = [p for p in rest if p.numel() < small_numel]
+            if tail:
+                plan.append(tail)
+            params = [p for region in plan for p in region]
+        self.tail_start = None                      # start of the region of small tensors (exchanged after backward, never early)
         self.params = params
         self.offsets, self.regions = [], []         # regions: (start, end, [param indices])
         unit = 64 * self.shards
         n = 0
         if regioned:
-            tail = []
-            for k, p in enumerate(params):
-                if p.numel() >= small_numel:
+            k = 0
+            for members in plan:
+                start, idx = n, []
+                for p in members:                   # 64-element (256 B) aligned segments inside the region
                     self.offsets.append(n)
-                    end = n + (p.numel() + unit - 1) // unit * unit
-                    self.regions.append((n, end, [k]))
-                    n = end
-                else:
-                    tail.append(k)
-            if tail:
-                start = n
-                for k in tail:                      # 64-element (256 B) aligned segments inside the tail region
-                    self.offsets.append(n)
-                    n += (params[k].numel() + 63) // 64 * 64
+                    idx.append(k)
+                    k += 1
+                    n += (p.numel() + 63) // 64 * 64
                 end = start + (n - start + unit - 1) // unit * unit
-                self.regions.append((start, end, tail))
+                self.regions.append((start, end, idx))
+                if tail and members is plan[-1]:
+                    self.tail_start = start
                 n = end
         else:
             for p in params:                        # 64-element (256 B) aligned segments
@@ -141,9 +154,11 @@ class ShardedExchange:
         self._chained = set()                   # region starts taken over this step
         self.side = torch.cuda.Stream(device=bucket.flat.device) if (self.enabled and bucket.flat.is_cuda) else None
         self._late_event = None
+        self._issued = set()                    # region starts whose reduce-scatter the hooks have issued this step
         if self.enabled:
             from . import grad_sink
-            self.large = [bucket.params[r[2][0]] for r in bucket.regions if len(r[2]) == 1 and bucket.params[r[2][0]].numel() >= bucket.small_numel]
+            # every region but the tail of small tensors may leave early: when ALL of its tensors' gradients are final
+            self.large = [bucket.params[k] for r in bucket.regions if r[0] != bucket.tail_start for k in r[2]]
             hooks = {id(p): self._make_hook(p) for p in self.large}
             self._hook_handles = [p.register_post_accumulate_grad_hook(hooks[id(p)]) for p in self.large]
             self._sink_cb = grad_sink.register_callback(lambda p: hooks[id(p)](p) if id(p) in hooks else None)
@@ -180,11 +195,16 @@ class ShardedExchange:
         return dist.all_reduce(seg, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     def _make_hook(self, p):
+        region = self.bucket.region_of(p)
+        members = [id(self.bucket.params[k]) for k in region[2]]
+
         def hook(param):
             if not self.enabled or id(p) in self._fired or id(p) in self._late:
                 return
             self._fired.add(id(p))
-            region = self.bucket.region_of(p)
+            if any(m in self._late for m in members) or not all(m in self._fired for m in members):
+                return                              # the region leaves with its last tensor -- or, with a late member, in finish()
+            self._issued.add(region[0])
             h = self._reduce_scatter(region)
             if self.chain is not None and self.chain(region, h):
                 self._chained.add(region[0])
@@ -198,14 +218,13 @@ class ShardedExchange:
         if not self.enabled:
             return
         for region in self.bucket.regions:
-            ids = [id(self.bucket.params[k]) for k in region[2]]
-            if len(ids) == 1 and ids[0] in self._fired:
-                continue
-            self.handles.append(self._reduce_scatter(region))
+            if region[0] not in self._issued:
+                self.handles.append(self._reduce_scatter(region))
         for h in self.handles:
             h.wait()
         self.handles.clear()
         self._fired.clear()
+        self._issued.clear()
         n = self.bucket.flat.numel()
         self.bytes_sent_per_step = 2 * 4 * n * (self.world - 1) // self.world     # reduce-scatter + all-gather, per rank
 

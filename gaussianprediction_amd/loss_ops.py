@@ -331,15 +331,21 @@ class FusedAdam:
             for k, p in enumerate(self.owner):
                 if active is None or active[k]:
                     bump(p)
-        if mask:
+        # which PARAMETERS this launch covered -- not only those this rank holds a slice of: under the sharded layout a tensor can
+        # lie entirely inside another rank's slice of its region (regions shared by several tensors), and its gradient buffer
+        # here still has to be marked stale / zeroed like everyone else's
+        inc = {id(p) for p in only} if only is not None else None
+        exc = {id(p) for p in exclude} if exclude is not None else set()
+        covered = [p for p in self.bucket.params if (inc is None or id(p) in inc) and id(p) not in exc]
+        if zero_grad and keep_ids:
             from . import grad_sink
-            for k, p in enumerate(self.owner):
-                if (mask >> k) & 1:
+            for p in covered:
+                if id(p) in keep_ids and p.grad is not None:
                     grad_sink.mark_stale(p.grad)
         if self.shard is not None and zero_grad:
             # the launch zeroed this rank's slices only; the slices the other ranks own hold this rank's partial sums still.
             # Only regions this launch covered (`only` / `exclude`), on the stream of the launch.
-            act_ids = {id(p) for k, p in enumerate(self.owner) if active is None or active[k]}
+            act_ids = {id(p) for p in covered}
             for region in self.bucket.regions:
                 ps = [self.bucket.params[i] for i in region[2]]
                 if not any(id(p) in act_ids for p in ps):

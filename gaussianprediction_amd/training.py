@@ -158,8 +158,14 @@ class TrainingMixin:
         shard = getattr(self, "optimizer_shard", None)       # (rank, world): set by a view-parallel harness (dist.ShardedExchange)
         from .loss_ops import FusedAdam                      # Adam(lr=0.0, eps=1e-15) [REF :472] as one multi-tensor launch
         if shard is not None:
-            # (bucket_small_numel: tensors below it share one region / one collective; tests lower it to reach the per-tensor paths)
-            self.bucket = FlatGradBucket(params, shards=shard[1], flat_params=True, small_numel=getattr(self, "bucket_small_numel", 1 << 20))
+            # (bucket_small_numel: tensors below it share one region / one collective; tests lower it to reach the per-region paths.)
+            # Two regions for the per-Gaussian tensors -- the SH coefficients, which the rasterizer backward finishes first, and
+            # the geometry (xyz, scaling, rotation, opacity), final after the blend / activation backward -- and the tail of small
+            # tensors: three reduce-scatters + three all-gathers per step instead of one pair per tensor.
+            by_attr = lambda *names: [getattr(self, a) for a in names if isinstance(getattr(self, a, None), nn.Parameter)]   # noqa: E731
+            self.bucket = FlatGradBucket(params, shards=shard[1], flat_params=True, small_numel=getattr(self, "bucket_small_numel", 1 << 20),
+                                         groups=[by_attr("_features_dc", "_features_rest"),
+                                                 by_attr("_xyz", "_scaling", "_rotation", "_opacity", "opacity_thres")])
             self.optimizer = FusedAdam(groups, self.bucket, eps=1e-15, shard=shard)
         else:
             self.bucket = FlatGradBucket(params)

@@ -109,7 +109,7 @@ def _named_groups(params):
             {"params": [params[2], params[3]], "lr": 2e-2, "name": "df_mlp"}]
 
 
-def _worker_sharded(rank, world, port, out_dir, device="cpu"):
+def _worker_sharded(rank, world, port, out_dir, device="cpu", grouped=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -122,8 +122,10 @@ def _worker_sharded(rank, world, port, out_dir, device="cpu"):
         params = [torch.nn.Parameter(p.detach().to(device)) for p in params]      # device tensors, FusedAdam -> gp_adam_step_multi
     groups = _named_groups(params)
     # small_numel = 200: the two larger tensors get a region of their own, the two small ones (different learning rates) share the tail
-    bucket = FlatGradBucket([p for g in groups for p in g["params"]], shards=world, flat_params=True, small_numel=200)
+    bucket = FlatGradBucket([p for g in groups for p in g["params"]], shards=world, flat_params=True, small_numel=200,
+                            groups=[[params[0], params[1]]] if grouped else None)      # grouped: xyz + f_rest share one region
     assert all((e - s) % (64 * world) == 0 for s, e, _ in bucket.regions) and len(bucket.regions) == 3
+    assert [len(r[2]) for r in bucket.regions] == ([2, 1, 1] if grouped else [1, 1, 2])
     opt = FusedAdam(groups, bucket, eps=1e-15, shard=(rank, world))
     ex = ShardedExchange(bucket)
     for step in range(3):
@@ -140,8 +142,8 @@ def _worker_sharded(rank, world, port, out_dir, device="cpu"):
     dist.destroy_process_group()
 
 
-def check_sharded_against_torch_adam(tmp_path, world, device="cpu"):
-    mp.spawn(_worker_sharded, args=(world, _free_port(), str(tmp_path), device), nprocs=world, join=True)
+def check_sharded_against_torch_adam(tmp_path, world, device="cpu", grouped=False):
+    mp.spawn(_worker_sharded, args=(world, _free_port(), str(tmp_path), device, grouped), nprocs=world, join=True)
     outs = [torch.load(os.path.join(tmp_path, f"sh{r}.pt"), weights_only=False) for r in range(world)]
     # single-process reference: torch.optim.Adam on the SUM of the ranks' losses [REF train.py:113-119, scene/gaussian_model.py:472]
     params = _params()
@@ -168,9 +170,9 @@ def check_sharded_against_torch_adam(tmp_path, world, device="cpu"):
     assert outs[0]["bytes"] == 2 * 4 * outs[0]["n"] * (world - 1) // world
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_sharded_adam_equals_replicated_adam(tmp_path, world):
-    check_sharded_against_torch_adam(tmp_path, world)
+@pytest.mark.parametrize("world,grouped", [(2, False), (3, False), (2, True), (3, True)])
+def test_sharded_adam_equals_replicated_adam(tmp_path, world, grouped):
+    check_sharded_against_torch_adam(tmp_path, world, grouped=grouped)
 
 
 # ---- optimizer-state surgery under the sharded optimizer ------------------------------------------------------------------

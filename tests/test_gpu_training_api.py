@@ -248,7 +248,7 @@ def _rank_main_params(rank, world, port, out_dir, backend, sharded, step_opacity
     for step in range(3):
         ts.step(step * world + rank)
     if sharded and ts.chain_sh:          # the SH regions' Adam + all-gather ran on the exchange's side stream (TrainStep._chain_sh)
-        assert len(chained) == 6 and len(set(chained)) == 2 and len(ts._chained_params) == 2, chained
+        assert len(chained) == 3 and len(set(chained)) == 1 and len(ts._chained_params) == 2, chained     # (one region: dc + rest)
     ts.sync_params()
     sd = pc.optimizer.state_dict()                       # (sharded: a collective)
     torch.save({"params": {n: p.detach().cpu() for n, p in pc.named_parameters()}, "state": {k: {kk: vv.cpu() for kk, vv in v.items()} for k, v in sd["state"].items()},
@@ -298,8 +298,8 @@ def _rank_main_rccl_single(rank, world, port, out_dir, sharded):
         ts.reducer.chain = lambda region, h: (lambda ok: (chained.append(region[0]) if ok else None, ok)[1])(orig_chain(region, h))
         pc._param_late_event = lambda: (lambda ev: (events.append(ev), ev)[1])(orig_late())
     losses = [float(ts.step(step)[0]) for step in range(4)]
-    if sharded:      # ... every step, both SH tensors; and from the second step on render() hands the rasterizer an event for them
-        assert len(chained) == 8 and len(set(chained)) == 2, chained
+    if sharded:      # ... every step; and from the second step on render() hands the rasterizer an event for them
+        assert len(chained) == 4 and len(set(chained)) == 1, chained            # (one region holds both SH tensors)
         assert events[0] is None and all(e is not None for e in events[1:]), events
     ts.sync_params()
     torch.cuda.synchronize()
