@@ -141,14 +141,20 @@ __device__ __forceinline__ void tiles_mfma_256(const float* __restrict__ W, int 
     const int i = lane & 15, kg = lane >> 4;
     const int r0 = 16 * t0 + i, r1 = r0 + 16;
     const bool ok0 = r0 < out_rows, ok1 = r1 < out_rows;
-    const float4* w0 = (const float4*)(W + (size_t)r0 * SW) + kg;
-    const float4* w1 = (const float4*)(W + (size_t)r1 * SW) + kg;
+    // Rows beyond out_rows are CLAMPED to a valid row instead of selected to zero after the load (their products land in
+    // accumulator rows nobody stores): a select on every loaded register made the compiler wait for ALL 32 loads
+    // (s_waitcnt vmcnt(0)) before the first MFMA -- 1.7 us of L2 streaming per layer in front of 3.4 us of matrix work that
+    // could have started after the first return.  With plain loads the waits are counted (vmcnt(30), (28), ...).
+    const float4* w0 = (const float4*)(W + (size_t)(ok0 ? r0 : 0) * SW) + kg;
+    const float4* w1 = (const float4*)(W + (size_t)(ok1 ? r1 : 0) * SW) + kg;
     float4 a0[16], a1[16];
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
-        a0[q] = ok0 ? w0[4 * q] : make_float4(0.f, 0.f, 0.f, 0.f);
-        a1[q] = ok1 ? w1[4 * q] : make_float4(0.f, 0.f, 0.f, 0.f);
+        a0[q] = w0[4 * q];
+        a1[q] = w1[4 * q];
     }
+    __builtin_amdgcn_sched_barrier(0);      // the 32 loads stay one burst in front of the MFMAs (the scheduler would otherwise
+                                            // trickle them in three at a time to save registers, exposing every L2 latency)
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
         const float* b = cur + (16 * q + kg) * SR + i;
@@ -168,15 +174,17 @@ __device__ __forceinline__ void tiles_mfma_T_256(const float* __restrict__ W, in
     const int i = lane & 15, kg = lane >> 4;
     const int r0 = 16 * t0 + i, r1 = r0 + 16;
     const bool ok0 = r0 < out_rows, ok1 = r1 < out_rows;
+    const int c0 = ok0 ? r0 : 0, c1 = ok1 ? r1 : 0;        // (clamped, not selected: see tiles_mfma_256)
     float a0[64], a1[64];
 #pragma unroll
     for (int q = 0; q < 16; ++q)
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int k = 16 * q + 4 * kg + u;
-            a0[4 * q + u] = ok0 ? W[(size_t)k * ldw + r0] : 0.f;
-            a1[4 * q + u] = ok1 ? W[(size_t)k * ldw + r1] : 0.f;
+            a0[4 * q + u] = W[(size_t)k * ldw + c0];
+            a1[4 * q + u] = W[(size_t)k * ldw + c1];
         }
+    __builtin_amdgcn_sched_barrier(0);      // (as in tiles_mfma_256)
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
         const float* b = cur + (16 * q + kg) * SR + i;
