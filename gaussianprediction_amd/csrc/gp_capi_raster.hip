@@ -70,7 +70,7 @@ struct ImageLayout {
     uint32_t* total;       // R, written by the scan of the per-Gaussian tile counts (zeroed with `ranges`: it sits behind them)
     ImageLayout(void* base, size_t T, size_t P) {
         GpCarver c(base);
-        ranges = c.take<int2>(T + 1);
+        ranges = c.take<int2>(T + GP_TOTAL_SLOTS / 2);
         total = (uint32_t*)(ranges + T);
         final_T = c.take<float>(P);
         n_contrib = c.take<int32_t>(P);
@@ -101,7 +101,7 @@ extern "C" int gp_raster_forward(const gp_raster_settings* st, const gp_raster_i
     saved->image = img; saved->image_bytes = il.bytes;
     saved->binning = nullptr; saved->binning_bytes = 0; saved->num_rendered = 0;
 
-    GP_HIP_CHECK(hipMemsetAsync(il.ranges, 0, (T + 1) * sizeof(int2), s));      // (tile ranges + the instance counter behind them)
+    GP_HIP_CHECK(hipMemsetAsync(il.ranges, 0, (T + GP_TOTAL_SLOTS / 2) * sizeof(int2), s));      // (tile ranges + the instance counter's slots behind them)
     uint32_t R = 0;
     uint32_t* point_list = nullptr;
     if (N > 0) {
@@ -156,8 +156,13 @@ extern "C" int gp_raster_forward(const gp_raster_settings* st, const gp_raster_i
             if (st->binning_capacity > 0x7FFFFF00ll) GP_FAIL("binning_capacity too large");
             R = (uint32_t)st->binning_capacity;          // (the status word and the sentinel keys are written by the duplicate launch)
         } else {
-            GP_HIP_CHECK(hipMemcpyAsync(&R, il.total, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+            uint32_t slots[GP_TOTAL_SLOTS];
+            GP_HIP_CHECK(hipMemcpyAsync(slots, il.total, sizeof(slots), hipMemcpyDeviceToHost, s));
             GP_HIP_CHECK(hipStreamSynchronize(s));
+            uint64_t Rsum = 0;
+            for (int k = 0; k < GP_TOTAL_SLOTS; ++k) Rsum += slots[k];
+            if (Rsum > 0x7FFFFF00ull) GP_FAIL("too many tile-splat instances (%llu)", (unsigned long long)Rsum);
+            R = (uint32_t)Rsum;
             if (R > 0x7FFFFF00u) GP_FAIL("too many tile-splat instances (%u)", R);
             if (st->binning_status) {   // exact mode reports R too (a caller sizing its capacity reads it from here)
                 hipLaunchKernelGGL(gp_binning_status_kernel, dim3(1), dim3(1), 0, s, il.total, 0xFFFFFFFFu, st->binning_status);

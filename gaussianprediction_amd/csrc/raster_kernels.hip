@@ -394,7 +394,7 @@ __global__ __launch_bounds__(256) void gp_duplicate_kernel(RasterDims d, const u
     if (blockIdx.x >= n_dup_blocks) {
         // capacity mode, the blocks behind the expansion: status = {R, R > capacity} and sentinel keys behind the R real
         // instances (their values are never read: no tile range covers them) -- two tiny kernels folded into this launch
-        const uint32_t R = total_R[0];
+        const uint32_t R = gp_total_of(total_R);
         if (blockIdx.x == n_dup_blocks && threadIdx.x == 0) { status[0] = R; status[1] = R > capacity ? 1u : 0u; }
         const uint32_t b0 = (blockIdx.x - n_dup_blocks) * 4096u;
         for (uint32_t i = b0 + threadIdx.x; i < b0 + 4096u && i < capacity; i += 256u)
@@ -466,7 +466,7 @@ __global__ __launch_bounds__(256) void gp_tile_ranges_kernel(const uint32_t* __r
 }
 // exact mode with a status word requested: status = {R, 0}  (capacity mode writes it from the duplicate launch)
 __global__ void gp_binning_status_kernel(const uint32_t* __restrict__ total, uint32_t capacity, uint32_t* __restrict__ status) {
-    const uint32_t R = total[0];
+    const uint32_t R = gp_total_of(total);
     status[0] = R;
     status[1] = R > capacity ? 1u : 0u;
 }

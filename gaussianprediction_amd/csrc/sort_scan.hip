@@ -46,12 +46,12 @@ __global__ __launch_bounds__(SCAN_BLOCK) void gp_scan_block_kernel(uint32_t* __r
     }
     if (tid == SCAN_BLOCK - 1) {
         block_sums[blockIdx.x] = wave_off + x;
-        if (total) atomicAdd(total, wave_off + x);      // (integer: the sum does not depend on the order)
+        if (total) atomicAdd(total + (blockIdx.x % GP_TOTAL_SLOTS), wave_off + x);      // (integer: the sum does not depend on the order)
     }
 }
 
 // One-launch form for consumers that can finish the scan themselves (gp_duplicate_kernel): block-local exclusive scan in place,
-// block_sums[b] = the block's total, *total += all of it (the caller zeroes it).  The consumer adds the sum of the block sums
+// block_sums[b] = the block's total, total[0 .. GP_TOTAL_SLOTS) += all of it, spread over the slots (the caller zeroes them).  The consumer adds the sum of the block sums
 // in front of its block -- a few hundred values it reduces in one step -- instead of two more launches doing that for it.
 int gp_scan_blocks_u32(uint32_t* data, size_t n, uint32_t* block_sums, uint32_t* total, hipStream_t s) {
     if (n == 0) return 0;

@@ -309,7 +309,7 @@ def raster_forward_debug(raster_settings, means3D, opacities, shs=None, colors_p
         rec = geom[:48 * N].view(torch.float32).view(N, 12).clone() if (geom is not None and N > 0) else None
         img = alloc.first(_lib.GP_BUF_IMAGE)
         al = lambda v: (v + 255) // 256 * 256                     # ImageLayout of gp_capi_raster.hip: 256-byte aligned arrays
-        nc_off = al(al(8 * (T + 1)) + 4 * H * W)               # ranges[T] + the instance counter, final_T[P], n_contrib[P]
+        nc_off = al(al(8 * (T + 8)) + 4 * H * W)               # ranges[T] + the instance counter's 16 slots, final_T[P], n_contrib[P]
         n_contrib = img[nc_off:nc_off + 4 * H * W].view(torch.int32).view(H, W).clone() if img is not None else None
         alloc.release()
     return dict(color=color, radii=radii, depth=depth, tidx=tidx, R=R, point_list=point_list[:R], ranges=ranges, rec=rec,

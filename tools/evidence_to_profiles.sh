@@ -19,4 +19,19 @@ open(f"profiles/{tag}_kernel_stats.txt", "w").write("\n".join(out) + "\n")
 PY
 { echo "# rocprofv3 --pmc <8 SQ counters> (two passes) -- python tools/composite_lab.py --fwd 1,0 --reps 3   (per-dispatch means; SQ_ACTIVE_INST_* and SQ_WAVE_CYCLES count quad-cycles; VALU busy = 4 * SQ_ACTIVE_INST_VALU / (1024 SIMDs * kernel cycles at 2.4 GHz))";
   python tools/pmc_table.py "$IN/pmc_sq*/*counter_collection.csv" gp_composite; } > "profiles/${TAG}_pmc_sq.txt"
+python - "$TAG" <<'PY'
+# the VALU figures bench.py prints beside the HBM fraction: SQ counters of the shipped composite forward, same kernel source
+import json, re, sys
+tag = sys.argv[1]
+txt = open(f"profiles/{tag}_pmc_sq.txt").read()
+blk = txt[txt.index("== gp_composite_fwd_sb_kernel"):]
+nxt = blk.find("\n== ", 3)
+blk = blk if nxt < 0 else blk[:nxt]
+val = lambda name: float(re.search(name + r"\s+mean\s+([0-9.]+)", blk).group(1))
+j = json.load(open("profiles/composite_fwd_traffic.json"))
+j["valu"] = {"SQ_INSTS_VALU": val("SQ_INSTS_VALU"), "SQ_ACTIVE_INST_VALU": val("SQ_ACTIVE_INST_VALU"), "SQ_BUSY_CYCLES": val("SQ_BUSY_CYCLES"),
+             "source": f"profiles/{tag}_pmc_sq.txt (rocprofv3 --pmc SQ counters over tools/composite_lab.py; same kernel source)",
+             "note": "SQ_ACTIVE_INST_VALU counts quad-cycles: VALU-busy = 4 x SQ_ACTIVE_INST_VALU / (1024 SIMDs x kernel cycles); floor = 4 cycles per wave64 VALU instruction x SQ_INSTS_VALU / 1024 SIMDs at the shader clock"}
+json.dump(j, open("profiles/composite_fwd_traffic.json", "w"), indent=1)
+PY
 ls -la profiles | grep "$TAG"
