@@ -860,7 +860,7 @@ struct W16Job { const void* z; const void* h; float* dw; float* db; float mul; }
 struct W16Jobs { W16Job j[9]; };
 // nf_* = features a job reads, ks_* = features per row block of the tensor (= nf, or 2 nf in split mode with pre-offset
 // pointers); shared = several jobs of one launch add into the same dw
-struct W16Shape { int nf_z, nf_h, n_out, n_in, lddw, ks_z, ks_h, shared; };
+struct W16Shape { int nf_z, nf_h, n_out, n_in, lddw, ks_z, ks_h, shared, xcd_terms, n_jobs, n_slabs; };
 #define W16_THREADS 512
 #define W16_DEPTH 4
 #define W16_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
@@ -916,11 +916,24 @@ __device__ __forceinline__ void mlp16_bwd_weight_lds_body(W16Jobs jobs, W16Shape
     __shared__ T s_st[2][2][8][512];                           // [buffer][dZ | H][fragment of 32 features][16 rows x 32] = 32 KB
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, j = lane & 31;
     const int wo = wave / WI, wi = wave % WI;
-    // grid = (jobs, row slabs), jobs fastest: the workgroups that read the same slab (the three terms of a split-mode layer share
-    // dZ-hi and H-hi) are dispatched back to back, so the repeats are served by the Infinity Cache, not HBM
-    const W16Job job = jobs.j[blockIdx.x];
+    // grid = (jobs, row slabs), jobs fastest: the workgroups that read the same slab are dispatched back to back.
+    // Split mode (xcd_terms = 3): the three terms of a layer read dZ-hi and H-hi twice each.  Workgroups go round-robin over
+    // the 8 XCDs (linear id & 7), each with its own L2, so "back to back" put the three terms on three L2s and every repeat
+    // went out to the fabric.  1-D grid instead: id -> (xcd, q); the terms of unit u = 8 (q / 3) + xcd are q % 3 -- one XCD,
+    // consecutive dispatch slots -- and units enumerate (slab, layer) with the layers of a slab adjacent.
+    int job_idx = blockIdx.x;
+    long slab = blockIdx.y;
+    if (sh.xcd_terms > 0) {
+        const long id = blockIdx.x, q = id >> 3;
+        const int nlay = sh.n_jobs / sh.xcd_terms;
+        const long u = (q / sh.xcd_terms) * 8 + (id & 7);
+        slab = u / nlay;
+        if (slab >= sh.n_slabs) return;
+        job_idx = (int)(u % nlay) * sh.xcd_terms + (int)(q % sh.xcd_terms);
+    }
+    const W16Job job = jobs.j[job_idx];
     const float inv_scale = (UsesScale<T>::v ? 1.f / grad_scale_from(absmax_bits) : 1.f) * job.mul;
-    const long kb0 = (long)blockIdx.y * kb_per_slab;
+    const long kb0 = slab * kb_per_slab;
     long kb1 = kb0 + kb_per_slab;
     if (kb1 > n_kb) kb1 = n_kb;
     const long nk = kb1 - kb0;
@@ -950,7 +963,7 @@ __device__ __forceinline__ void mlp16_bwd_weight_lds_body(W16Jobs jobs, W16Shape
     if (nk > 0) w16_group<T, V8, OT, IT, WI>(gq, acc, bsum, s_st, gz, gh, okz, okh, 0, nk, kstride_z, kstride_h, wave, lane, wo, wi, frag_off);
     for (long k0 = W16_DEPTH; k0 < nk; k0 += W16_DEPTH)
         w16_group<T, V8, OT, IT, WI>(gq, acc, bsum, s_st, gz, gh, okz, okh, k0, nk, kstride_z, kstride_h, wave, lane, wo, wi, frag_off);
-    const bool single = gridDim.y == 1 && !sh.shared;
+    const bool single = gridDim.y == 1 && !sh.shared && sh.xcd_terms == 0;
 #pragma unroll
     for (int uo = 0; uo < OT; ++uo)
 #pragma unroll
@@ -1141,12 +1154,16 @@ extern "C" int gp_mlp16_backward(const gp_mlp16_params* p /* w16 = TRANSPOSED co
             first.j[t] = term(opnd(0), t, g->dw[0], g->db[0]);
             last.j[t] = term(opnd(4), t, g->dw[4], g->db[4]);
         }
-        const W16Shape sh_mid{256, 256, 256, 256, 256, NS * 256, NS * 256, split}, sh_first{256, m.in_pad, 256, m.in_dim, m.in_dim, NS * 256, NS * m.in_pad, split},
-            sh_last{16, 256, m.out_dim, 256, 256, NS * 16, NS * 256, split};
+        const int xt = (split && gp_debug_get(3) == 0) ? n_terms : 0;      // (gp_debug_option(3, 1): the round-2 2-D grid, for A/B)
+        const W16Shape sh_mid{256, 256, 256, 256, 256, NS * 256, NS * 256, split, xt, 3 * n_terms, (int)gx},
+            sh_first{256, m.in_pad, 256, m.in_dim, m.in_dim, NS * 256, NS * m.in_pad, split, xt, n_terms, (int)gx},
+            sh_last{16, 256, m.out_dim, 256, 256, NS * 16, NS * 256, split, xt, n_terms, (int)gx};
+        // 1-D grids of the XCD-aware form: units = layers x slabs, rounded up to 8, x terms
+        auto grid_of = [&](int nlay) { return xt ? dim3((unsigned)(((size_t)nlay * gx + 7) / 8 * 8 * n_terms)) : dim3(nlay * n_terms, gx); };
         if (f16) {
-            hipLaunchKernelGGL((gp_mlp16_bwd_weight_lds_kernel<_Float16, 4, 2, 4>), dim3(3 * n_terms, gx), dim3(W16_THREADS), 0, s, mid, sh_mid, n_kb, kbs, absmax);
-            hipLaunchKernelGGL((gp_mlp16_bwd_weight_lds_kernel<_Float16, 2, 2, 2>), dim3(n_terms, gx), dim3(W16_THREADS), 0, s, first, sh_first, n_kb, kbs, absmax);
-            hipLaunchKernelGGL((gp_mlp16_bwd_weight_lds_kernel<_Float16, 1, 1, 8>), dim3(n_terms, gx), dim3(W16_THREADS), 0, s, last, sh_last, n_kb, kbs, absmax);
+            hipLaunchKernelGGL((gp_mlp16_bwd_weight_lds_kernel<_Float16, 4, 2, 4>), grid_of(3), dim3(W16_THREADS), 0, s, mid, sh_mid, n_kb, kbs, absmax);
+            hipLaunchKernelGGL((gp_mlp16_bwd_weight_lds_kernel<_Float16, 2, 2, 2>), grid_of(1), dim3(W16_THREADS), 0, s, first, sh_first, n_kb, kbs, absmax);
+            hipLaunchKernelGGL((gp_mlp16_bwd_weight_lds_kernel<_Float16, 1, 1, 8>), grid_of(1), dim3(W16_THREADS), 0, s, last, sh_last, n_kb, kbs, absmax);
         } else {
             hipLaunchKernelGGL((gp_mlp16_bwd_weight_lds_kernel<__bf16, 4, 2, 4>), dim3(3, gx), dim3(W16_THREADS), 0, s, mid, sh_mid, n_kb, kbs, absmax);
             hipLaunchKernelGGL((gp_mlp16_bwd_weight_lds_kernel<__bf16, 2, 2, 2>), dim3(1, gx), dim3(W16_THREADS), 0, s, first, sh_first, n_kb, kbs, absmax);

@@ -86,6 +86,8 @@ def run(name, steps=15, warmup=5, precision="fp32s"):
 
 if __name__ == "__main__":
     prec = os.environ.get("GP_MLP_PRECISION", "fp32s")      # the model's default for passes over more than 2048 rows
+    if os.environ.get("GP_W16_2D"):                         # A/B: the split-mode weight gradient's round-2 grid (jobs x slabs)
+        _lib.check(_lib.lib().gp_debug_option(3, 1), "gp_debug_option")
     for n in (sys.argv[1:] or list(CONFIGS)):
         run(n, precision=prec)
         torch.cuda.empty_cache()
