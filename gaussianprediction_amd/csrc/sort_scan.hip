@@ -9,7 +9,7 @@
 #include "gp_common.h"
 
 // ------------------------------------------------------------------------------------------------
-// exclusive scan (u32), in place
+// exclusive scan (u32) inside blocks of 2048, in place (the consumer finishes it: gp_scan_blocks_u32)
 // ------------------------------------------------------------------------------------------------
 #define SCAN_ITEMS 8
 #define SCAN_BLOCK 256
@@ -61,12 +61,6 @@ int gp_scan_blocks_u32(uint32_t* data, size_t n, uint32_t* block_sums, uint32_t*
     return 0;
 }
 
-__global__ __launch_bounds__(256) void gp_scan_add_kernel(uint32_t* __restrict__ data, size_t n,
-                                                         const uint32_t* __restrict__ block_offs) {
-    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < n) data[i] += block_offs[i / SCAN_TILE];
-}
-
 size_t gp_scan_tmp_elems(size_t n) {
     size_t total = 256 + 64;   // the radix sort keeps its 256 digit totals here
     while (n > 1) {
@@ -76,21 +70,6 @@ size_t gp_scan_tmp_elems(size_t n) {
         n = nb;
     }
     return total;
-}
-
-int gp_scan_exclusive_u32(uint32_t* data, size_t n, uint32_t* tmp, size_t tmp_elems, hipStream_t s) {
-    if (n == 0) return 0;
-    size_t nb = (n + SCAN_TILE - 1) / SCAN_TILE;
-    if (tmp_elems < gp_align_up(nb, 64)) GP_FAIL("scan: temp storage too small");
-    hipLaunchKernelGGL(gp_scan_block_kernel, dim3((unsigned)nb), dim3(SCAN_BLOCK), 0, s, data, n, tmp, (uint32_t*)nullptr);
-    GP_LAUNCH_CHECK();
-    if (nb > 1) {
-        size_t used = gp_align_up(nb, 64);
-        if (gp_scan_exclusive_u32(tmp, nb, tmp + used, tmp_elems - used, s)) return 1;
-        hipLaunchKernelGGL(gp_scan_add_kernel, dim3(gp_blocks(n, 256)), dim3(256), 0, s, data, n, tmp);
-        GP_LAUNCH_CHECK();
-    }
-    return 0;
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -521,3 +521,48 @@ def test_create_from_pcd_and_the_checkpoint_sizing_path():
     assert pc2._xyz.shape == (5000, 3) and torch.equal(pc2._xyz[0], pc2._xyz[4999])          # N_pcd_init copies of the first point
     missing, unexpected = pc2.load_state_dict(sd, strict=False)
     assert not unexpected and torch.equal(pc2._xyz.detach(), pc._xyz.detach()) and torch.equal(pc2.weights_model.params.detach(), pc.weights_model.params.detach())
+
+
+def _rank_main_spec(rank, world, port, out_dir, mode):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    pc, cams, gts, raw, rw, idx, args = build(n=3000, dev="cuda:0")
+    pc.bucket_small_numel = 8000
+    ts = TrainStep(pc, cams, gts, 50000, speculative=mode != "exact")
+    if mode == "overflowing" and rank == 1:
+        ts.SPEC_MARGIN, ts.SPEC_PAD = 0.5, 0          # only rank 1's frames overflow: rank 0 must skip and redo them too
+    if mode == "overflowing":
+        flags = []
+        orig = ts._step
+        ts._step = lambda v, b, sf: (lambda out: (flags.append(None if sf is None else int(sf.item())), out)[1])(orig(v, b, sf))
+    losses = [float(ts.step(i * world + rank)[0]) for i in range(14)]
+    ts.sync_params()
+    torch.cuda.synchronize()
+    torch.save({"losses": losses, "xyz": pc._xyz.detach().cpu(), "dc": pc._features_dc.detach().cpu(), "redone": getattr(ts, "redone", 0),
+                "steps": ts.optimizer.step_count, "flags": flags if mode == "overflowing" else None}, os.path.join(out_dir, f"sp_{mode}_{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_capacity_mode_overflow_is_agreed_on_by_all_ranks(tmp_path):
+    """Capacity mode (no host read of R) under the sharded exchange: the overflow word is all-reduced (MAX) right after the forward,
+    ahead of the backward, and both Adam launches of the step -- the SH region's on the side stream, the rest on the compute stream --
+    take it as their skip flag.  One rank overflowing must make EVERY rank skip that step and repeat it; replicas stay replicas."""
+    import torch.multiprocessing as mp
+    res = {}
+    for mode in ("exact", "speculative", "overflowing"):
+        mp.spawn(_rank_main_spec, args=(2, _free_port(), str(tmp_path), mode), nprocs=2, join=True)
+        res[mode] = [torch.load(os.path.join(tmp_path, f"sp_{mode}_{r}.pt")) for r in range(2)]
+    for mode, (a, b) in res.items():
+        assert torch.equal(a["xyz"], b["xyz"]) and torch.equal(a["dc"], b["dc"]), mode      # every rank holds the same parameters
+        assert a["steps"] == b["steps"]
+    ex, sp, ov = res["exact"][0], res["speculative"][0], res["overflowing"][0]
+    assert sp["redone"] == 0 and ex["steps"] == sp["steps"] == 14
+    assert np.allclose(ex["losses"], sp["losses"], rtol=2e-3, atol=1e-6)
+    assert float((ex["xyz"] - sp["xyz"]).norm() / ex["xyz"].norm()) < 3e-4
+    # rank 1 overflowed; rank 0 never did on its own, yet saw the flag (MAX over the ranks), skipped and redid the same steps
+    assert res["overflowing"][1]["redone"] > 0 and res["overflowing"][0]["redone"] == res["overflowing"][1]["redone"]
+    assert any(f == 1 for f in res["overflowing"][0]["flags"] if f is not None)
+    assert ov["steps"] == 14 and torch.isfinite(ov["xyz"]).all() and ov["losses"][-1] < ov["losses"][0]
