@@ -168,7 +168,23 @@ template <int CNT>
 __device__ __forceinline__ void stage_sh(float* s_sh, const float* __restrict__ src, int nblk, int tid) {
     constexpr int STRIDE = CNT | 1;
     const int total = nblk * CNT;
-    for (int e = tid * 4; e < total; e += 1024) {
+    int e = tid * 4;
+    for (; e + 3 * 1024 + 3 < total; e += 4 * 1024) {      // four 16-byte loads in flight per thread (see adam_unstage_sh)
+        float4 f[4];
+#pragma unroll
+        for (int w = 0; w < 4; ++w) f[w] = *(const float4*)(src + e + w * 1024);
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const float* fv = (const float*)&f[w];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int idx = e + w * 1024 + u;
+                const int g = idx / CNT, k = idx - g * CNT;
+                s_sh[g * STRIDE + k] = fv[u];
+            }
+        }
+    }
+    for (; e < total; e += 1024) {
         float v[4];
         if (e + 3 < total) {
             const float4 f = *(const float4*)(src + e);
