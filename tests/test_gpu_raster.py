@@ -74,8 +74,9 @@ def test_forward_lower_sh_degrees(sh_degree):
     assert err[:, clean].max() <= 1e-4
 
 
-def _grads_case(case, sh_degree=3, use_colors=False, use_cov=False, with_depth=True):
+def _grads_case(case, sh_degree=3, use_colors=False, use_cov=False, with_depth=True, scale_modifier=1.0):
     scene, st, cam = small_scene(sh_degree=sh_degree, **CASES[case])
+    st.scale_modifier = scale_modifier
     st = f32_settings(st)
     a = scene_f32_numpy(scene)
     N = a["means3D"].shape[0]
@@ -128,6 +129,29 @@ def test_backward_parity(case):
     e = rel_l2(L["means2D"].grad[:, :2].cpu().numpy(), g["means2D"])
     assert e < tol, f"means2D: rel L2 {e:.3e}"
     assert float(L["means2D"].grad[:, 2].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("mod", [0.6, 1.7])
+def test_scaling_modifier_forward_and_backward(mod):
+    """`scaling_modifier` of render() [REF gaussian_renderer/__init__.py:18,44]: scales every Gaussian before the covariance is
+    built; the scale gradient carries the factor."""
+    scene, st, cam = small_scene(**CASES["dense_big_splats"])
+    st.scale_modifier = mod
+    st = f32_settings(st)
+    a = scene_f32_numpy(scene)
+    s = RasterOracle("f32").forward(st, a["means3D"], a["opacities"], shs=a["shs"], scales=a["scales"], rotations=a["rotations"])
+    h = hip_forward_debug(st, scene_to_device(scene))
+    np.testing.assert_array_equal(h["radii"].cpu().numpy(), s["radii"])
+    np.testing.assert_array_equal(h["point_list"].cpu().numpy().astype(np.uint32), s["point_list"][:s["R"]])
+    clean = s["ambiguous"] == 0
+    assert np.abs(h["color"].cpu().numpy().astype(np.float64) - s["out_color"])[:, clean].max() <= 1e-4
+    s1 = RasterOracle("f32").forward(f32_settings(small_scene(**CASES["dense_big_splats"])[1]), a["means3D"], a["opacities"], shs=a["shs"],
+                                     scales=a["scales"], rotations=a["rotations"])
+    assert s["R"] != s1["R"]                                  # (the modifier really changed the footprints)
+    g, L = _grads_case("dense_big_splats", scale_modifier=mod)
+    for k in ("means3D", "shs", "opacities", "scales", "rotations"):
+        e = rel_l2(L[k].grad.cpu().numpy(), g[k])
+        assert e < 1e-4, f"{k}: rel L2 {e:.3e}"
 
 
 def test_backward_precomputed_color_and_cov():
