@@ -877,33 +877,43 @@ __device__ __forceinline__ V8 w16_keep(V8 v, bool ok) {
 // k + W16_DEPTH (the tail re-loads its own step: every k-step issues exactly two loads, in a fixed order, so the
 // compiler's vmcnt before an LDS write leaves the 2 (W16_DEPTH - 1) younger loads in flight), barrier, MFMA from LDS.
 template <typename T, typename V8, int OT, int IT, int WI>
-__device__ __forceinline__ void w16_group(V8 (&gq)[W16_DEPTH][2], f32x16 (&acc)[OT][IT], float (&bsum)[OT], T (*s_st)[2][8][512],
+__device__ __forceinline__ void w16_group(V8 (&gq)[W16_DEPTH][2], f32x16 (&acc)[OT][IT], float (&bsum)[OT], T (*s_st)[2][2][8][512],
                                           const T* gz, const T* gh, bool okz, bool okh, long k0, long nk, size_t kstride_z,
                                           size_t kstride_h, int wave, int lane, int wo, int wi, int frag_off) {
+    // TWO k-steps (32 rows) per barrier.  With 128 accumulator registers per wave one workgroup fills a CU, so nothing overlaps
+    // the chain  LDS write -> barrier -> LDS read -> MFMA  of a step; at one k-step per barrier that chain (~1 us) times the 256
+    // steps of a slab WAS the kernel's time (2.1 ms at 1 M rows for 8.5 GB of unique operands and 0.6 ms of matrix work).
+    static_assert(W16_DEPTH % 4 == 0, "pairs of k-steps, two stage buffers");
 #pragma unroll
-    for (int d = 0; d < W16_DEPTH; ++d) {
-        const long k = k0 + d;
-        const int buf = d & 1;                              // = k & 1 (W16_DEPTH is even)
-        *(V8*)&s_st[buf][0][wave][lane * 8] = w16_keep(gq[d][0], okz);
-        *(V8*)&s_st[buf][1][wave][lane * 8] = w16_keep(gq[d][1], okh);
-        const long kn = k + W16_DEPTH < nk ? k + W16_DEPTH : k;
-        gq[d][0] = *(const V8*)(gz + kn * kstride_z);
-        gq[d][1] = *(const V8*)(gh + kn * kstride_h);
-        W16_LDS_BARRIER();          // one barrier per k-step: a buffer is rewritten two steps later, behind the next barrier
-        V8 a[OT], b[IT];
+    for (int d = 0; d < W16_DEPTH; d += 2) {
+        const int buf = (d >> 1) & 1;
 #pragma unroll
-        for (int u = 0; u < OT; ++u) a[u] = *(const V8*)&s_st[buf][0][wo * OT + u][frag_off];
+        for (int kk = 0; kk < 2; ++kk) {
+            const long k = k0 + d + kk;
+            *(V8*)&s_st[buf][kk][0][wave][lane * 8] = w16_keep(gq[d + kk][0], okz);
+            *(V8*)&s_st[buf][kk][1][wave][lane * 8] = w16_keep(gq[d + kk][1], okh);
+            const long kn = k + W16_DEPTH < nk ? k + W16_DEPTH : k;
+            gq[d + kk][0] = *(const V8*)(gz + kn * kstride_z);
+            gq[d + kk][1] = *(const V8*)(gh + kn * kstride_h);
+        }
+        W16_LDS_BARRIER();          // one barrier per PAIR of k-steps: a buffer is rewritten two pairs later, behind the next barrier
 #pragma unroll
-        for (int u = 0; u < IT; ++u) b[u] = *(const V8*)&s_st[buf][1][wi * IT + u][frag_off];
+        for (int kk = 0; kk < 2; ++kk) {
+            V8 a[OT], b[IT];
 #pragma unroll
-        for (int uo = 0; uo < OT; ++uo)
+            for (int u = 0; u < OT; ++u) a[u] = *(const V8*)&s_st[buf][kk][0][wo * OT + u][frag_off];
 #pragma unroll
-            for (int ui = 0; ui < IT; ++ui) acc[uo][ui] = mfma16(a[uo], b[ui], acc[uo][ui]);
-        if (wi == 0) {
+            for (int u = 0; u < IT; ++u) b[u] = *(const V8*)&s_st[buf][kk][1][wi * IT + u][frag_off];
 #pragma unroll
-            for (int u = 0; u < OT; ++u)
+            for (int uo = 0; uo < OT; ++uo)
 #pragma unroll
-                for (int e = 0; e < 8; ++e) bsum[u] += (float)a[u][e];
+                for (int ui = 0; ui < IT; ++ui) acc[uo][ui] = mfma16(a[uo], b[ui], acc[uo][ui]);
+            if (wi == 0) {
+#pragma unroll
+                for (int u = 0; u < OT; ++u)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) bsum[u] += (float)a[u][e];
+            }
         }
     }
 }
@@ -913,7 +923,7 @@ __device__ __forceinline__ void mlp16_bwd_weight_lds_body(W16Jobs jobs, W16Shape
                                                           const uint32_t* __restrict__ absmax_bits) {
     typedef typename Vec8<T>::type V8;
     static_assert((8 / WI) * OT <= 8 && WI * IT <= 8, "eight fragment slots per operand");
-    __shared__ T s_st[2][2][8][512];                           // [buffer][dZ | H][fragment of 32 features][16 rows x 32] = 32 KB
+    __shared__ T s_st[2][2][2][8][512];                        // [buffer][k-step of the pair][dZ | H][fragment of 32 features][16 rows x 32] = 64 KB
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, j = lane & 31;
     const int wo = wave / WI, wi = wave % WI;
     // grid = (jobs, row slabs), jobs fastest: the workgroups that read the same slab are dispatched back to back.
