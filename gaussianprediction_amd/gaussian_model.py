@@ -72,10 +72,11 @@ class GaussianModel(TrainingMixin, nn.Module):
         opac = torch.log(opac / (1 - opac))                                   # inverse_sigmoid [REF utils/general_utils.py:18-19]
         motion = 1e-3 * (2 * torch.rand((n, self.motion_feature_dim), device=device) - 1)
         K = self.final_kpts_num if self.final_kpts_num is not None else self.args.max_points
+        degree = self.active_sh_degree            # untouched by the reference's create_from_pcd: 0 from __init__ when training
         self.create_from_tensors(pts, features[:, :, 0:1].transpose(1, 2).contiguous(), features[:, :, 1:].transpose(1, 2).contiguous(),
                                  scales, rots, opac, motion, torch.ones(K, 3, device=device),
                                  torch.ones(K, self.motion_feature_dim, device=device), with_weights_model=True)
-        self.active_sh_degree = 0                                             # (oneupSHdegree raises it, train.py:81-83)
+        self.active_sh_degree = degree            # (oneupSHdegree raises it, train.py:81-83; eval.py:241 / train.py:52 set the maximum beforehand)
         return self
 
     # ---- construction from raw tensors ---------------------------------------------------------
