@@ -50,9 +50,10 @@ def _scene():
     return SimpleNamespace(points=pts, colors=cols, normals=np.zeros_like(pts)), cams
 
 
-def _train(gaussians, cams, opt, args, pipe, background, first_iter, last_iter, rnd, log):
-    """train.py:76-201, batch = 1."""
+def _train(gaussians, cams, opt, args, pipe, background, first_iter, last_iter, rnd, log, batch=1):
+    """train.py:76-201 (with --batch > 1 the optimizer steps every `batch` iterations on the sum of their losses)."""
     viewpoint_stack = None
+    batch_loss, batch_viewspace_point_tensor, batch_radii, batch_visibility_filter = [], [], [], []
     for iteration in range(first_iter, last_iter + 1):
         gaussians.update_learning_rate(iteration)
         if iteration % 20 == 0:                                   # (every 1000 in the reference)
@@ -73,8 +74,23 @@ def _train(gaussians, cams, opt, args, pipe, background, first_iter, last_iter, 
         Ll1 = do.l1_loss(image, gt_image)
         loss = (1.0 - opt.lambda_dssim) * Ll1 + opt.lambda_dssim * (1.0 - do.ssim(image, gt_image))
         loss += gaussians.get_loss(iteration)
-        loss_ = torch.stack([loss], dim=0).sum()
-        loss_.backward()
+        batch_loss += [loss]
+        batch_radii += [radii.unsqueeze(0)]
+        batch_visibility_filter += [visibility_filter.unsqueeze(0)]
+        batch_viewspace_point_tensor += [viewspace_point_tensor]
+        if len(batch_loss) == batch:
+            loss_ = torch.stack(batch_loss, dim=0).sum()
+            loss_.backward()
+            radii = torch.cat(batch_radii, 0).max(dim=0).values
+            visibility_filter = torch.cat(batch_visibility_filter).any(dim=0)
+            viewspace_point_tensor_grad = torch.zeros_like(viewspace_point_tensor)
+            for idx in range(0, len(batch_viewspace_point_tensor)):
+                viewspace_point_tensor_grad = viewspace_point_tensor_grad + batch_viewspace_point_tensor[idx].grad
+            assert torch.isfinite(viewspace_point_tensor_grad).all()
+            batch_loss.clear(), batch_radii.clear(), batch_visibility_filter.clear(), batch_viewspace_point_tensor.clear()
+        else:
+            log["loss"].append(loss.item()), log["n"].append(gaussians.get_xyz.shape[0]), log["k"].append(gaussians.super_gaussians.shape[0])
+            continue
         with torch.no_grad():
             log["loss"].append(loss.item())
             log["n"].append(gaussians.get_xyz.shape[0])
@@ -106,7 +122,8 @@ def _train(gaussians, cams, opt, args, pipe, background, first_iter, last_iter, 
     return iteration
 
 
-def test_the_reference_training_loop_runs_unchanged(tmp_path):
+@pytest.mark.parametrize("batch", [1, 2])
+def test_the_reference_training_loop_runs_unchanged(tmp_path, batch):
     torch.manual_seed(0)
     args, opt = _args(), _opt()
     pcd, cams = _scene()
@@ -118,13 +135,15 @@ def test_the_reference_training_loop_runs_unchanged(tmp_path):
     gaussians.training_setup(opt)
     log = dict(loss=[], n=[], k=[])
     rnd = Random(0)
-    _train(gaussians, cams, opt, args, pipe, background, 1, 75, rnd, log)
+    last = 75 + (batch - 1)
+    _train(gaussians, cams, opt, args, pipe, background, 1, last, rnd, log, batch)
     L = np.array(log["loss"])
     assert np.isfinite(L).all()
     # it trains in every stage: stage 1 up to the opacity reset at 30 (which blacks the image out: the loss jumps), the recovery
     # after it, and stage 3 once the weights model drives the motion (stage 2, 41..60, only moves the keypoints)
-    assert L[25:30].mean() < L[0:5].mean() - 0.01 and L[30] > L[29] + 0.1 and L[36:40].mean() < L[30:34].mean() - 0.02
-    assert L[70:75].mean() < L[41:46].mean() - 0.04
+    if batch == 1:
+        assert L[25:30].mean() < L[0:5].mean() - 0.01 and L[30] > L[29] + 0.1 and L[36:40].mean() < L[30:34].mean() - 0.02
+    assert L[70:75].mean() < L[41:46].mean() - 0.04 / batch
     assert gaussians.active_sh_degree == 3
     assert log["n"][0] == 1500 and log["n"][-1] > 1500                                             # densify / prune changed the cloud
     assert gaussians.second_stage and gaussians.third_stage
@@ -132,8 +151,8 @@ def test_the_reference_training_loop_runs_unchanged(tmp_path):
     assert [g["name"] for g in gaussians.optimizer.param_groups][:3] == ["xyz", "f_dc", "f_rest"]   # stage-3 groups
     assert any(g["name"] == "weight_mlp" for g in gaussians.optimizer.param_groups)
     # ---- checkpoint tuple [REF train.py:199-201] and the restart path [REF train.py:48-57]
-    path = os.path.join(tmp_path, "chkpnt75.pth")
-    torch.save((gaussians.state_dict(), gaussians.optimizer.state_dict(), 75), path)
+    path = os.path.join(tmp_path, "chkpnt.pth")
+    torch.save((gaussians.state_dict(), gaussians.optimizer.state_dict(), last), path)
     (model_params, opt_dict, first_iter) = torch.load(path, weights_only=False)
     g2 = GaussianModel(3, args)
     g2.set_inputDim(12, 60)
@@ -150,11 +169,11 @@ def test_the_reference_training_loop_runs_unchanged(tmp_path):
     assert g2.optimizer.state_dict()["state"].keys() == opt_dict["state"].keys()
     time_ = torch.from_numpy(cams[2].time).float().cuda()
     with torch.no_grad():
-        a = render(cams[2], gaussians, pipe, background, time=time_, it=76)["render"]
-        b = render(cams[2], g2, pipe, background, time=time_, it=76)["render"]
+        a = render(cams[2], gaussians, pipe, background, time=time_, it=last + 1)["render"]
+        b = render(cams[2], g2, pipe, background, time=time_, it=last + 1)["render"]
     assert torch.equal(a, b)                                       # the restored model renders the same image, bit for bit
     log2 = dict(loss=[], n=[], k=[])
-    _train(g2, cams, opt, args, pipe, background, first_iter + 1, 90, Random(1), log2)
+    _train(g2, cams, opt, args, pipe, background, first_iter + 1, 90, Random(1), log2, batch)
     assert np.isfinite(log2["loss"]).all() and np.mean(log2["loss"][-5:]) < L[70:75].mean() + 0.02
     # ---- eval.py:226-247: restore WITHOUT training_setup, then the render loop and render_motion [REF eval.py:126,153,205-224]
     with torch.no_grad():
@@ -172,4 +191,4 @@ def test_the_reference_training_loop_runs_unchanged(tmp_path):
         xyz_t, r_t, s_t, o_t, wx, wr = g3(time_, first_iter, return_weights=True)
         pkg2 = render_motion(cams[-1], g3, pipe, background, xyz_t=xyz_t, r_t=r_t, opacity=o_t)
         assert torch.allclose(pkg2["render"], pkg["render"], atol=1e-6) and set(pkg2) == {"render", "viewspace_points", "visibility_filter", "radii"}
-        assert torch.equal(render(cams[2], g3, pipe, background, time=torch.from_numpy(cams[2].time).float().cuda(), it=76)["render"], a)
+        assert torch.equal(render(cams[2], g3, pipe, background, time=torch.from_numpy(cams[2].time).float().cuda(), it=last + 1)["render"], a)
