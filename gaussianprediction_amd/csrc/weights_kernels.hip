@@ -186,71 +186,113 @@ typedef float kv2f __attribute__((ext_vector_type(2)));
 // NN is a template parameter: a run-time `best_d[nn - 1]` would put the candidate list in scratch memory.
 // Two keypoints (j, j+1) are evaluated per step with packed fp32 math; each one's squared differences are still
 // summed in dimension order, so the distances are bit-identical to the sequential form.
+//
+// `order` (optional permutation of the points, e.g. along a Morton curve) only changes which points share a wavefront.  A
+// partial sum of squared differences is a lower bound of the full one (fp32 addition of non-negative terms never decreases),
+// so a keypoint whose partial sum already reaches every lane's current NN-th best cannot enter any list: the wavefront drops it
+// after 3 (and again after 19) of the 35 dimensions.  With spatially coherent wavefronts ~4 of 5 keypoints go that way;
+// distances that are completed are summed exactly as before, so the result does not depend on `order`.
 template <int D, int NN>
 __global__ __launch_bounds__(256) void gp_knn_kernel(long n, const float* __restrict__ xyz, const float* __restrict__ feat,
                                                     float amplify, int K, const float* __restrict__ kp_xyz,
-                                                    const float* __restrict__ kp_feat, int64_t* __restrict__ idx_out,
-                                                    float* __restrict__ d2_out) {
+                                                    const float* __restrict__ kp_feat, const int32_t* __restrict__ order,
+                                                    int64_t* __restrict__ idx_out, float* __restrict__ d2_out) {
     __shared__ float s_kp[D][KNN_TILE];
     const int tid = threadIdx.x;
-    const long i = (long)blockIdx.x * 256 + tid;
-    const bool live = i < n;
-    float x[D];
+    const long nchunks = (n + 255) / 256;
+    // K <= KNN_TILE (the reference's keypoint counts): the keypoints are staged ONCE and the workgroup walks over chunks of 256
+    // points; more keypoints: one chunk per workgroup, tiles restaged (the launch sizes the grid accordingly)
+    for (long chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+        const long slot = chunk * 256 + tid;
+        const bool live = slot < n;
+        const long i = order ? (long)order[live ? slot : n - 1] : (live ? slot : n - 1);   // clamped: the loads below are unconditional
+        float x[D];
 #pragma unroll
-    for (int d = 0; d < 3; ++d) x[d] = live ? xyz[3 * i + d] : 0.f;
+        for (int d = 0; d < 3; ++d) x[d] = xyz[3 * i + d];
+        if (D > 3) {                                                                   // rows of 32 floats, 16-byte aligned (checked at launch)
+            const float4* row = (const float4*)(feat + (size_t)i * (D - 3));
 #pragma unroll
-    for (int d = 3; d < D; ++d) x[d] = live ? amplify * feat[(size_t)i * (D - 3) + (d - 3)] : 0.f;
-    float best_d[NN];
-    int best_i[NN];
+            for (int q = 0; q < (D - 3) / 4; ++q) {
+                const float4 v = row[q];
+                x[3 + 4 * q + 0] = amplify * v.x; x[3 + 4 * q + 1] = amplify * v.y; x[3 + 4 * q + 2] = amplify * v.z; x[3 + 4 * q + 3] = amplify * v.w;
+            }
+        }
+        float best_d[NN];
+        int best_i[NN];
 #pragma unroll
-    for (int k = 0; k < NN; ++k) { best_d[k] = 3.4e38f; best_i[k] = -1; }
-    auto offer = [&](float cd, int ci) {
-        if (cd < best_d[NN - 1] || best_i[NN - 1] < 0) {
-            // insert, keeping ascending order; equal distances keep the earlier (lower) index first
+        for (int k = 0; k < NN; ++k) { best_d[k] = 3.4e38f; best_i[k] = -1; }
+        auto offer = [&](float cd, int ci) {
+            if (cd < best_d[NN - 1] || best_i[NN - 1] < 0) {
+                // insert, keeping ascending order; equal distances keep the earlier (lower) index first.  Once the new entry is
+                // placed everything behind it moves down one place (also entries that TIE with the one being carried)
+                bool take = false;
+#pragma unroll
+                for (int k = 0; k < NN; ++k) {
+                    take = take || best_i[k] < 0 || cd < best_d[k];
+                    const float td = best_d[k];
+                    const int ti = best_i[k];
+                    if (take) { best_d[k] = cd; best_i[k] = ci; cd = td; ci = ti; }
+                }
+            }
+        };
+        for (int k0 = 0; k0 < K; k0 += KNN_TILE) {
+            const int kt = min(KNN_TILE, K - k0);
+            if (K > KNN_TILE || chunk == (long)blockIdx.x) {                            // uniform
+                __syncthreads();
+                for (int e = tid; e < KNN_TILE * 4; e += 256) {                         // positions (+ one padding lane of the /4 split)
+                    const int j = e >> 2, d = e & 3;
+                    if (d < 3) s_kp[d][j] = j < kt ? kp_xyz[3 * (size_t)(k0 + j) + d] : 3.0e18f;   // padding keypoints: never among the nearest
+                }
+                if (D > 3) {
+                    for (int e = tid; e < KNN_TILE * (D - 3); e += 256) {               // coalesced feature rows
+                        const int j = e / (D - 3), d = e - j * (D - 3);
+                        s_kp[3 + d][j] = j < kt ? amplify * kp_feat[(size_t)(k0 + j) * (D - 3) + d] : 3.0e18f;
+                    }
+                }
+                __syncthreads();
+            }
+            for (int j = 0; j < kt; j += 2) {
+                kv2f d2 = {0.f, 0.f};
+                constexpr int CUT0 = D > 3 ? 3 : D, CUT1 = D > 19 ? 19 : D;
+#pragma unroll
+                for (int d = 0; d < CUT0; ++d) {
+                    const kv2f kp2 = *(const kv2f*)&s_kp[d][j];
+                    const kv2f df = (kv2f){x[d], x[d]} - kp2;
+                    d2 = d2 + df * df;
+                }
+                if (D > CUT0 && !__any(best_i[NN - 1] < 0 || d2.x < best_d[NN - 1] || d2.y < best_d[NN - 1])) continue;
+#pragma unroll
+                for (int d = CUT0; d < CUT1; ++d) {
+                    const kv2f kp2 = *(const kv2f*)&s_kp[d][j];
+                    const kv2f df = (kv2f){x[d], x[d]} - kp2;
+                    d2 = d2 + df * df;
+                }
+                if (D > CUT1 && !__any(best_i[NN - 1] < 0 || d2.x < best_d[NN - 1] || d2.y < best_d[NN - 1])) continue;
+#pragma unroll
+                for (int d = CUT1; d < D; ++d) {
+                    const kv2f kp2 = *(const kv2f*)&s_kp[d][j];
+                    const kv2f df = (kv2f){x[d], x[d]} - kp2;
+                    d2 = d2 + df * df;
+                }
+                offer(d2.x, k0 + j);
+                if (j + 1 < kt) offer(d2.y, k0 + j + 1);
+            }
+        }
+        if (live) {
 #pragma unroll
             for (int k = 0; k < NN; ++k) {
-                const bool take = best_i[k] < 0 || cd < best_d[k];
-                const float td = best_d[k];
-                const int ti = best_i[k];
-                if (take) { best_d[k] = cd; best_i[k] = ci; cd = td; ci = ti; }
+                idx_out[i * NN + k] = best_i[k];
+                if (d2_out) d2_out[i * NN + k] = best_d[k];
             }
         }
-    };
-    for (int k0 = 0; k0 < K; k0 += KNN_TILE) {
-        const int kt = min(KNN_TILE, K - k0);
-        __syncthreads();
-        for (int e = tid; e < KNN_TILE * D; e += 256) {
-            const int j = e / D, d = e - j * D;
-            float v = 3.0e18f;                                   // padding keypoints: never among the nearest
-            if (j < kt) v = d < 3 ? kp_xyz[3 * (size_t)(k0 + j) + d] : amplify * kp_feat[(size_t)(k0 + j) * (D - 3) + (d - 3)];
-            s_kp[d][j] = v;
-        }
-        __syncthreads();
-        for (int j = 0; j < kt; j += 2) {
-            kv2f d2 = {0.f, 0.f};
-#pragma unroll
-            for (int d = 0; d < D; ++d) {
-                const kv2f kp2 = *(const kv2f*)&s_kp[d][j];
-                const kv2f df = (kv2f){x[d], x[d]} - kp2;
-                d2 = d2 + df * df;
-            }
-            offer(d2.x, k0 + j);
-            if (j + 1 < kt) offer(d2.y, k0 + j + 1);
-        }
-    }
-    if (!live) return;
-#pragma unroll
-    for (int k = 0; k < NN; ++k) {
-        idx_out[i * NN + k] = best_i[k];
-        if (d2_out) d2_out[i * NN + k] = best_d[k];
     }
 }
 
 template <int D>
 static void launch_knn(int nn, dim3 grid, hipStream_t s, long n, const float* xyz, const float* feat, float amplify, int K,
-                       const float* kp_xyz, const float* kp_feat, int64_t* idx_out, float* d2_out) {
+                       const float* kp_xyz, const float* kp_feat, const int32_t* order, int64_t* idx_out, float* d2_out) {
 #define KNN_CASE(NNV) case NNV: hipLaunchKernelGGL((gp_knn_kernel<D, NNV>), grid, dim3(256), 0, s, n, xyz, feat, amplify, K, kp_xyz, \
-                                                   kp_feat, idx_out, d2_out); break;
+                                                   kp_feat, order, idx_out, d2_out); break;
     switch (nn) {
         KNN_CASE(1) KNN_CASE(2) KNN_CASE(3) KNN_CASE(4) KNN_CASE(5) KNN_CASE(6) KNN_CASE(7) KNN_CASE(8)
         KNN_CASE(9) KNN_CASE(10) KNN_CASE(11) KNN_CASE(12) KNN_CASE(13) KNN_CASE(14) KNN_CASE(15) KNN_CASE(16)
@@ -259,8 +301,8 @@ static void launch_knn(int nn, dim3 grid, hipStream_t s, long n, const float* xy
 }
 
 extern "C" int gp_knn_keypoints(int64_t n, const float* xyz, const float* feat, int32_t feat_dim, float amplify, int64_t K,
-                                const float* kp_xyz, const float* kp_feat, int32_t nn, int64_t* idx_out, float* d2_out,
-                                gp_stream_t stream_) {
+                                const float* kp_xyz, const float* kp_feat, int32_t nn, const int32_t* order, int64_t* idx_out,
+                                float* d2_out, gp_stream_t stream_) {
     if (n < 0 || K < 0) GP_FAIL("negative size");
     if (n == 0) return 0;
     if (nn < 1 || nn > KNN_MAX_NN) GP_FAIL("knn: nearest_num %d unsupported (1..%d)", nn, KNN_MAX_NN);
@@ -270,9 +312,12 @@ extern "C" int gp_knn_keypoints(int64_t n, const float* xyz, const float* feat, 
     if (feat_dim && (!feat || !kp_feat)) GP_FAIL("knn: null feature pointers");
     hipStream_t s = (hipStream_t)stream_;
     GpProfScope _p("knn", s);
-    const dim3 grid(gp_blocks((size_t)n, 256));
-    if (feat_dim == 0) launch_knn<3>(nn, grid, s, (long)n, xyz, feat, amplify, (int)K, kp_xyz, kp_feat, idx_out, d2_out);
-    else launch_knn<35>(nn, grid, s, (long)n, xyz, feat, amplify, (int)K, kp_xyz, kp_feat, idx_out, d2_out);
+    if (feat_dim && (((uintptr_t)feat & 15) != 0)) GP_FAIL("knn: feat must be 16-byte aligned");
+    const unsigned nchunks = gp_blocks((size_t)n, 256);
+    const unsigned resident = 256u * (feat_dim ? 4u : 8u);                             // workgroups the chip holds (registers / LDS of the two forms)
+    const dim3 grid(K <= KNN_TILE && nchunks > resident ? resident : nchunks);
+    if (feat_dim == 0) launch_knn<3>(nn, grid, s, (long)n, xyz, feat, amplify, (int)K, kp_xyz, kp_feat, order, idx_out, d2_out);
+    else launch_knn<35>(nn, grid, s, (long)n, xyz, feat, amplify, (int)K, kp_xyz, kp_feat, order, idx_out, d2_out);
     GP_LAUNCH_CHECK();
     return 0;
 }

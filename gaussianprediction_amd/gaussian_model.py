@@ -124,9 +124,11 @@ class GaussianModel(TrainingMixin, nn.Module):
         key = self._state_key(self._xyz, self.motion_feature, self.super_gaussians, self.super_gaussians_feature)
         c = getattr(self, "_knn_cache", None)
         if c is None or c[0] != key:
+            wm = getattr(self, "weights_model", None)          # the spatial order its encode already keeps (a performance hint only)
+            order = wm.spatial_order(self._xyz.detach(), age=False) if wm is not None and self._xyz.shape[0] > 4096 else None
             nearest = knn_keypoints(self._xyz, self.super_gaussians, a.nearest_num, self.motion_feature,
                                     self.super_gaussians_feature, getattr(a, "feature_amplify", 5.0),
-                                    getattr(a, "knn_type", "hybird"))
+                                    getattr(a, "knn_type", "hybird"), order=order)
             c = self._knn_cache = (key, nearest)
         nearest = c[1]
         self.nearest_mask = nearest if keepshape else nearest.view([-1])

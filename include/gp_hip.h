@@ -340,9 +340,12 @@ int gp_weights_backward(const gp_hashgrid_config* cfg, int64_t n, const float* x
                         void* alloc_ctx, gp_stream_t stream);
 /* idx_out[n, nn] (int64, ascending squared distance; ties to the lower index) = the nn nearest of the K keypoints, in 3-D
  * (feat_dim = 0: knn_type "3D") or in [xyz | amplify * feature] (feat_dim = 32: "hybird")
- * [REF scene/gaussian_model.py:110-125, frnn.frnn_grid_points].  d2_out (optional) receives the squared distances. */
+ * [REF scene/gaussian_model.py:110-125, frnn.frnn_grid_points].  d2_out (optional) receives the squared distances.
+ * order (optional, int32[n]: a permutation of the points, e.g. along a Morton curve) only decides which points share a
+ * wavefront -- spatially coherent wavefronts drop most keypoints after 3 of the 35 dimensions; the result does not depend on it. */
 int gp_knn_keypoints(int64_t n, const float* xyz, const float* feat, int32_t feat_dim, float amplify, int64_t K,
-                     const float* kp_xyz, const float* kp_feat, int32_t nn, int64_t* idx_out, float* d2_out, gp_stream_t stream);
+                     const float* kp_xyz, const float* kp_feat, int32_t nn, const int32_t* order, int64_t* idx_out, float* d2_out,
+                     gp_stream_t stream);
 
 /* out[n] = mean of the squared distances from point i to its three nearest OTHER points (self excluded by index): replaces
  * simple_knn's distCUDA2, which sizes the initial Gaussians [REF scene/gaussian_model.py:340-341 create_from_pcd].  Exact brute

@@ -126,6 +126,31 @@ def test_knn_matches_oracle(knn_type, K, nn):
     assert np.array_equal(d2.cpu().numpy(), rd)
 
 
+@pytest.mark.parametrize("feat_scale", [1e-3, 1e-1, 1.0])
+def test_knn_visiting_order_does_not_change_the_result(feat_scale):
+    """`order` regroups the points into spatially coherent wavefronts so that a wavefront can drop a keypoint after a prefix of
+    the dimensions; indices AND distances stay those of the plain kernel (and of the oracle) whatever the order is."""
+    from gaussianprediction_amd.weights_ops import morton_order
+    rng = np.random.default_rng(7)
+    N, K, nn = 40000, 250, 6
+    xyz = torch.tensor(rng.uniform(-1.3, 1.3, size=(N, 3)).astype(np.float32)).cuda()
+    feat = torch.tensor((feat_scale * rng.uniform(-1, 1, size=(N, 32))).astype(np.float32)).cuda()
+    kp = xyz[torch.tensor(rng.choice(N, K, replace=False)).cuda()].clone()
+    kp[:10] = kp[10:20]                                     # coincident keypoints: ties go to the lower index
+    kpf = feat[:K].clone()
+    kpf[:10] = kpf[10:20]
+    base_i, base_d = knn_keypoints(xyz, kp, nn, feat, kpf, 5.0, "hybird", return_dist=True)
+    for order in (morton_order(xyz), torch.randperm(N, generator=torch.Generator().manual_seed(1)).to(torch.int32).cuda()):
+        i2, d2 = knn_keypoints(xyz, kp, nn, feat, kpf, 5.0, "hybird", return_dist=True, order=order)
+        assert torch.equal(i2, base_i) and torch.equal(d2, base_d)
+    sub = slice(0, 2000)
+    ri, rd = wo.knn(np.concatenate([xyz.cpu().numpy(), np.float32(5.0) * feat.cpu().numpy()], 1)[sub],
+                    np.concatenate([kp.cpu().numpy(), np.float32(5.0) * kpf.cpu().numpy()], 1), nn)
+    assert np.array_equal(base_i[sub].cpu().numpy(), ri) and np.array_equal(base_d[sub].cpu().numpy(), rd)
+    with pytest.raises(RuntimeError):
+        knn_keypoints(xyz, kp, nn, feat, kpf, 5.0, "hybird", order=torch.arange(N, device="cuda"))    # int64: refused
+
+
 def test_model_forward_computes_its_own_weights():
     """Stage-3 forward without set_keypoint_weights: weights model + kNN per frame, as the reference [REF :257-262]."""
     from types import SimpleNamespace

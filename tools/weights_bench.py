@@ -32,6 +32,11 @@ def fwdbwd():
 print(f"weights model forward          {timeit(fwd):8.3f} ms")
 print(f"weights model forward+backward {timeit(fwdbwd):8.3f} ms")
 print(f"kNN hybird (35-D)              {timeit(lambda: knn_keypoints(xyz, kp, nn, feat, kpf, 5.0, 'hybird')):8.3f} ms")
+from gaussianprediction_amd.weights_ops import morton_order
+order = morton_order(xyz)
+print(f"kNN hybird, Morton order       {timeit(lambda: knn_keypoints(xyz, kp, nn, feat, kpf, 5.0, 'hybird', order=order)):8.3f} ms")
+print(f"kNN 3D, Morton order           {timeit(lambda: knn_keypoints(xyz, kp, nn, None, None, 5.0, '3D', order=order)):8.3f} ms")
+print(f"morton_order (torch ops)       {timeit(lambda: morton_order(xyz)):8.3f} ms")
 print(f"kNN 3D                         {timeit(lambda: knn_keypoints(xyz, kp, nn, None, None, 5.0, '3D')):8.3f} ms")
 _lib.profile_enable(2); _lib.profile_collect()
 for _ in range(5): fwdbwd()
