@@ -443,7 +443,7 @@ __device__ __forceinline__ void wm_load_cols(float (&a)[32], const float* __rest
     for (int s = 0; s < 32; ++s) a[s] = (2 * s + half) < k_valid ? W[(2 * s + half) * 64 + 32 * ti + i] : 0.f;
 }
 
-__global__ __launch_bounds__(WM_THREADS) void gp_wm_fwd_kernel(HashGridDev g, long n, const float* __restrict__ xyz,
+__global__ __launch_bounds__(WM_THREADS, 2) void gp_wm_fwd_kernel(HashGridDev g, long n, const float* __restrict__ xyz,
                                                               const int32_t* __restrict__ perm, const float* __restrict__ params,
                                                               int n_out, float* __restrict__ out, float* __restrict__ saved_feat) {
     __shared__ float sA[64 * 64], sB[64 * 64];
@@ -493,9 +493,59 @@ __global__ __launch_bounds__(WM_THREADS) void gp_wm_fwd_kernel(HashGridDev g, lo
     }
 }
 
+// ---- backward: row-strip tiling on v_mfma_f32_16x16x4_f32 -------------------------------------------------------
+// Wave w of a workgroup owns the 16 feature rows 16 w .. 16 w + 15 of every 64-row product and all 64 points of the block (four
+// 16-point column tiles = four independent accumulator chains).  A strip of a 64 x 64 matrix is 16 registers (a[s] =
+// A[16 w + i][s + 16 kg], lane = (i, kg)), so the four weight operands of the backward (W1, W2, W1^T, W2^T) cost 64 registers
+// instead of the 128 the 32 x 32 tiling needs, the kernel fits 256 registers and TWO workgroups share a CU: one's
+// matrix-core phases cover the other's LDS epilogues, barriers and staging (matrix pipe 29 % busy before, one wave per SIMD).
+// K index of MFMA step s in lane group kg: s + 16 kg.  LDS tiles are T[f][p] with a row pitch of 65 words: every operand read
+// is conflict-free (rows s / s + 16 land 16 banks apart, a column of 16 rows walks 16 banks) and -- unlike an XOR swizzle -- an
+// address is lane base + compile-time offset, so the reads are immediates off ONE register per access pattern (with XOR the
+// compiler hoists some 150 loop-invariant addresses out of the block loop and spills).
+typedef float wf32x4 __attribute__((ext_vector_type(4)));
+#define WM4_PITCH 65
+__device__ __forceinline__ int wm4_ti(int f, int p) { return f * WM4_PITCH + p; }
+
+// acc[c][r] = sum_k A[16 w + 4 kg + r][k] T[k][16 c + n]   (a[s] = A-strip operand, K = 64)
+__device__ __forceinline__ void wm4_layer(wf32x4 (&acc)[4], const float (&a)[16], const float* T, int lane) {
+    const int n = lane & 15, kg = lane >> 4;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc[c] = (wf32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+        const int k = s + 16 * kg;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], T[wm4_ti(k, 16 * c + n)], acc[c], 0, 0, 0);
+    }
+}
+// g[t][r] += sum over the block's 64 points of TA[ra + 4 kg + r][p] * TB[16 t + n][p]
+__device__ __forceinline__ void wm4_outer(wf32x4 (&g)[4], const float* TA, int ra, const float* TB, int lane) {
+    const int n = lane & 15, kg = lane >> 4;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+        const int p = s + 16 * kg;
+        const float a = TA[wm4_ti(ra + n, p)];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) g[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, TB[wm4_ti(16 * t + n, p)], g[t], 0, 0, 0);
+    }
+}
+// write a strip's product back: T[16 w + 4 kg + r][16 c + n] = f(acc[c][r])
+template <class F>
+__device__ __forceinline__ void wm4_store(float* T, const wf32x4 (&acc)[4], int w, int lane, F f) {
+    const int n = lane & 15, kg = lane >> 4;
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int idx = wm4_ti(16 * w + 4 * kg + r, 16 * c + n);
+            T[idx] = f(acc[c][r], idx);
+        }
+}
+
 // One block's inputs of the backward kernel into registers: 64 points x 64 saved features (float4 per thread x 4) and
 // the upstream gradient rows (gathered through the Morton permutation), issued a whole block ahead of their use.
-__device__ __forceinline__ void wm_bwd_fetch(float4 (&px)[4], float (&pd)[8], long b, long nblocks, long n, const int32_t* __restrict__ perm,
+__device__ __forceinline__ void wm_bwd_fetch(float4 (&px)[4], float (&pd)[4], long b, long nblocks, long n, const int32_t* __restrict__ perm,
                                              int n_out, const float* __restrict__ saved_feat, const float* __restrict__ dL_dout, int tid) {
     if (b >= nblocks) return;
     const long slot0 = b * 64;
@@ -505,40 +555,41 @@ __device__ __forceinline__ void wm_bwd_fetch(float4 (&px)[4], float (&pd)[8], lo
         px[u] = slot0 + p < n ? *(const float4*)(saved_feat + (slot0 + p) * 64 + f) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-        const int e = tid + WM_THREADS * u, p = e >> 5, f = e & 31;
+    for (int u = 0; u < 4; ++u) {
+        const int e = tid + WM_THREADS * u, p = e >> 4, f = e & 15;
         float v = 0.f;
         if (f < n_out && slot0 + p < n) v = dL_dout[(perm ? (long)perm[slot0 + p] : slot0 + p) * n_out + f];
         pd[u] = v;
     }
 }
 
-__global__ __launch_bounds__(WM_THREADS) void gp_wm_bwd_kernel(long n, const int32_t* __restrict__ perm,
-                                                              const float* __restrict__ params, int n_out,
-                                                              const float* __restrict__ saved_feat, const float* __restrict__ dL_dout,
-                                                              float* __restrict__ dparams, float* __restrict__ dfeat) {
-    __shared__ float sA[64 * 64], sB[64 * 64], sC[64 * 64], sD[32 * 64];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, half = lane >> 5;
-    const int ti = wave & 1, tj = wave >> 1;
+__global__ __launch_bounds__(WM_THREADS, 2) void gp_wm_bwd_kernel(long n, const int32_t* __restrict__ perm,
+                                                                 const float* __restrict__ params, int n_out,
+                                                                 const float* __restrict__ saved_feat, const float* __restrict__ dL_dout,
+                                                                 float* __restrict__ dparams, float* __restrict__ dfeat) {
+    __shared__ float sA[64 * WM4_PITCH], sB[64 * WM4_PITCH], sC[64 * WM4_PITCH], sD[16 * WM4_PITCH];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, i = lane & 15, kg = lane >> 4;
     const float* W1 = params;
     const float* W2 = params + 4096;
     const float* W3 = params + 8192;
-    float w1[32], w2[32], w1t[32], w2t[32], w3t[8];
-    wm_load_rows(w1, W1, ti, 64, lane);
-    wm_load_rows(w2, W2, ti, 64, lane);
-    wm_load_cols(w1t, W1, ti, 64, lane);
-    wm_load_cols(w2t, W2, ti, 64, lane);
-    {
-        const int i = lane & 31;
+    float w1[16], w2[16], w1t[16], w2t[16], w3t[4];
 #pragma unroll
-        for (int s = 0; s < 8; ++s) w3t[s] = W3[(2 * s + half) * 64 + 32 * ti + i];   // W3^T, k = 2 s + half < 16
+    for (int s = 0; s < 16; ++s) {
+        const int k = s + 16 * kg, row = 16 * w + i;
+        w1[s] = W1[row * 64 + k];
+        w2[s] = W2[row * 64 + k];
+        w1t[s] = W1[k * 64 + row];                                    // (W1^T)[row][k]
+        w2t[s] = W2[k * 64 + row];
     }
-    wf32x16 g1, g2, g3;   // dW1 / dW2 tile (ti = output rows, tj = input columns), dW3 tile (rows 0..31, columns 32 tj ..) on ti == 0
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { g1[r] = 0.f; g2[r] = 0.f; g3[r] = 0.f; }
+    for (int s = 0; s < 4; ++s) w3t[s] = W3[(s + 4 * kg) * 64 + 16 * w + i];   // (W3^T)[row][k], k = s + 4 kg < 16
+    wf32x4 g1[4], g2[4], g3;   // rows 16 w.. of dW1 / dW2 (all 64 columns); columns 16 w.. of dW3 (its 16 rows)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { g1[t] = (wf32x4){0.f, 0.f, 0.f, 0.f}; g2[t] = g1[t]; }
+    g3 = (wf32x4){0.f, 0.f, 0.f, 0.f};
     const long nblocks = (n + 63) / 64;
     float4 px[4];
-    float pd[8];
+    float pd[4];
     wm_bwd_fetch(px, pd, blockIdx.x, nblocks, n, perm, n_out, saved_feat, dL_dout, tid);
     for (long b = blockIdx.x; b < nblocks; b += gridDim.x) {
         const long slot0 = b * 64;
@@ -546,64 +597,66 @@ __global__ __launch_bounds__(WM_THREADS) void gp_wm_bwd_kernel(long n, const int
 #pragma unroll
         for (int u = 0; u < 4; ++u) {                                // X^T (prefetched one block ahead)
             const int e4 = tid + WM_THREADS * u, p = e4 >> 4, f = 4 * (e4 & 15);
-            sA[wm_ti(f + 0, p)] = px[u].x; sA[wm_ti(f + 1, p)] = px[u].y; sA[wm_ti(f + 2, p)] = px[u].z; sA[wm_ti(f + 3, p)] = px[u].w;
+            sA[wm4_ti(f + 0, p)] = px[u].x; sA[wm4_ti(f + 1, p)] = px[u].y; sA[wm4_ti(f + 2, p)] = px[u].z; sA[wm4_ti(f + 3, p)] = px[u].w;
         }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {                                // dZ3^T, rows >= n_out zero
+        for (int u = 0; u < 4; ++u) {                                // dZ3^T (16 rows, those >= n_out zero)
             const int e = tid + WM_THREADS * u;
-            sD[wm_ti(e & 31, e >> 5)] = pd[u];
+            sD[wm4_ti(e & 15, e >> 4)] = pd[u];
         }
-        wm_bwd_fetch(px, pd, b + gridDim.x, nblocks, n, perm, n_out, saved_feat, dL_dout, tid);   // in flight during this block's 7 GEMM phases
+        wm_bwd_fetch(px, pd, b + gridDim.x, nblocks, n, perm, n_out, saved_feat, dL_dout, tid);   // in flight during this block's GEMM phases
         __syncthreads();
-        wf32x16 acc = wm_layer(w1, sA, tj, lane);                    // H1^T -> sB
-#pragma unroll
-        for (int r = 0; r < 16; ++r) sB[wm_ti(32 * ti + wm_row(r, half), 32 * tj + j)] = fmaxf(acc[r], 0.f);
+        wf32x4 acc[4];
+        wm4_layer(acc, w1, sA, lane);                                // H1^T -> sB
+        wm4_store(sB, acc, w, lane, [](float v, int) { return fmaxf(v, 0.f); });
         __syncthreads();
-        acc = wm_layer(w2, sB, tj, lane);                            // H2^T -> sC
-#pragma unroll
-        for (int r = 0; r < 16; ++r) sC[wm_ti(32 * ti + wm_row(r, half), 32 * tj + j)] = fmaxf(acc[r], 0.f);
+        wm4_layer(acc, w2, sB, lane);                                // H2^T -> sC
+        wm4_store(sC, acc, w, lane, [](float v, int) { return fmaxf(v, 0.f); });
         __syncthreads();
-        if (ti == 0) wm_outer(g3, sD, 0, sC, tj, lane);              // dW3[o][i] += dZ3^T[o][p] H2^T[i][p]
-        {   // dH2^T = W3^T dZ3^T (K = 16), masked by H2 > 0, in place over sC
+        {   // dW3[o][16 w + n] += dZ3^T[o][p] H2^T[16 w + n][p]      (one 16 x 16 tile per wave)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-#pragma unroll
-            for (int s = 0; s < 8; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w3t[s], sD[wm_ti(2 * s + half, 32 * tj + j)], acc, 0, 0, 0);
-            __syncthreads();                                         // dW3 products have read sC
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int idx = wm_ti(32 * ti + wm_row(r, half), 32 * tj + j);
-                sC[idx] = sC[idx] > 0.f ? acc[r] : 0.f;
+            for (int s = 0; s < 16; ++s) {
+                const int p = s + 16 * kg;
+                g3 = __builtin_amdgcn_mfma_f32_16x16x4f32(sD[wm4_ti(i, p)], sC[wm4_ti(16 * w + i, p)], g3, 0, 0, 0);
             }
         }
-        __syncthreads();
-        wm_outer(g2, sC, ti, sB, tj, lane);                          // dW2[o][i] += dZ2^T[o][p] H1^T[i][p]
-        acc = wm_layer(w2t, sC, tj, lane);                           // dH1^T = W2^T dZ2^T
-        __syncthreads();
+        {   // dH2^T = W3^T dZ3^T (K = 16), masked by H2 > 0, in place over sC
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int idx = wm_ti(32 * ti + wm_row(r, half), 32 * tj + j);
-            sB[idx] = sB[idx] > 0.f ? acc[r] : 0.f;                  // dZ1^T in place over H1^T
+            for (int c = 0; c < 4; ++c) acc[c] = (wf32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(w3t[s], sD[wm4_ti(s + 4 * kg, 16 * c + i)], acc[c], 0, 0, 0);
+            __syncthreads();                                         // every wave's dW3 products have read sC
+            wm4_store(sC, acc, w, lane, [&](float v, int idx) { return sC[idx] > 0.f ? v : 0.f; });
         }
         __syncthreads();
-        wm_outer(g1, sB, ti, sA, tj, lane);                          // dW1[o][i] += dZ1^T[o][p] X^T[i][p]
-        acc = wm_layer(w1t, sB, tj, lane);                           // dX^T = W1^T dZ1^T -> sC
-#pragma unroll
-        for (int r = 0; r < 16; ++r) sC[wm_ti(32 * ti + wm_row(r, half), 32 * tj + j)] = acc[r];
+        wm4_outer(g2, sC, 16 * w, sB, lane);                         // dW2[o][i] += dZ2^T[o][p] H1^T[i][p]
+        wm4_layer(acc, w2t, sC, lane);                               // dH1^T = W2^T dZ2^T
+        __syncthreads();                                             // every wave's dW2 products have read sB
+        wm4_store(sB, acc, w, lane, [&](float v, int idx) { return sB[idx] > 0.f ? v : 0.f; });   // dZ1^T in place over H1^T
+        __syncthreads();
+        wm4_outer(g1, sB, 16 * w, sA, lane);                         // dW1[o][i] += dZ1^T[o][p] X^T[i][p]
+        wm4_layer(acc, w1t, sB, lane);                               // dX^T = W1^T dZ1^T -> sC (dZ2 is dead: all waves passed the barrier above)
+        wm4_store(sC, acc, w, lane, [](float v, int) { return v; });
         __syncthreads();
         for (int e = tid; e < 64 * 64; e += WM_THREADS) {            // slot-major rows for the table-gradient kernel
             const int p = e >> 6, f = e & 63;
-            if (slot0 + p < n) dfeat[(slot0 + p) * 64 + f] = sC[wm_ti(f, p)];
+            if (slot0 + p < n) dfeat[(slot0 + p) * 64 + f] = sC[wm4_ti(f, p)];
         }
     }
-    // flush the weight gradients: for a fixed register the 32 lanes of a half write 128 contiguous bytes
+    // flush the weight gradients: for a fixed register the 16 lanes of a group write 64 contiguous bytes
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int row = 32 * ti + wm_row(r, half);
-        atomicAdd(&dparams[row * 64 + 32 * tj + j], g1[r]);
-        atomicAdd(&dparams[4096 + row * 64 + 32 * tj + j], g2[r]);
-        if (ti == 0 && wm_row(r, half) < 16) atomicAdd(&dparams[8192 + wm_row(r, half) * 64 + 32 * tj + j], g3[r]);
-    }
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = 16 * w + 4 * kg + r;
+            atomicAdd(&dparams[row * 64 + 16 * t + i], g1[t][r]);
+            atomicAdd(&dparams[4096 + row * 64 + 16 * t + i], g2[t][r]);
+        }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) atomicAdd(&dparams[8192 + (4 * kg + r) * 64 + 16 * w + i], g3[r]);
 }
 
 // table gradient from slot-major feature gradients (the fused backward's output).
@@ -701,7 +754,8 @@ extern "C" int gp_weights_forward(const gp_hashgrid_config* cfg, int64_t n, cons
     hipStream_t s = (hipStream_t)stream_;
     GpProfScope _p("weights_fwd", s);
     const unsigned nb = (unsigned)((n + 63) / 64);
-    hipLaunchKernelGGL(gp_wm_fwd_kernel, dim3(nb < 1024u ? nb : 1024u), dim3(WM_THREADS), 0, s, g, (long)n, xyz, perm, params, n_out, out,
+    const unsigned cap = gp_debug_get(4) > 0 ? (unsigned)gp_debug_get(4) : 512u;   // two resident workgroups per CU (254 registers), persistent
+    hipLaunchKernelGGL(gp_wm_fwd_kernel, dim3(nb < cap ? nb : cap), dim3(WM_THREADS), 0, s, g, (long)n, xyz, perm, params, n_out, out,
                        saved_feat);
     GP_LAUNCH_CHECK();
     return 0;
