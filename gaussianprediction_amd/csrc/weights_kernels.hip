@@ -367,39 +367,27 @@ extern "C" int gp_knn3_mean_dist2(int64_t n, const float* xyz, float* out, gp_st
 
 // ------------------------------------------------------------------------------------------------
 // Fused weights model: hash-grid encoding + the 64-wide bias-free MLP (64 -> 64 -> 64 -> 16, ReLU) on the exact-fp32
-// matrix cores, persistent workgroups.  A workgroup walks blocks of 64 points (in `perm` order); per block the
-// activations live transposed in LDS, T[f][p] at f*64 + (p & 32) + ((p & 31) ^ (f & 31)) -- conflict-free both for the
-// layer products (lanes = points) and for the weight-gradient products (lanes = features).  The weight matrices stay in
-// registers as MFMA A operands for the whole kernel.
+// matrix cores (v_mfma_f32_16x16x4_f32), persistent workgroups.  A workgroup walks blocks of 64 points (in `perm` order); per
+// block the activations live transposed in LDS, T[f][p] with a row pitch of 65 words.
 //   forward : out[i][0..n_out) and (training) the encoded features, saved slot-major ([slot][64], slot = position in perm)
 //   backward: recomputes the two hidden layers from the saved features, back-propagates, accumulates the three weight
-//             gradients in MFMA accumulators across all of the workgroup's blocks (flushed once, as full cache lines)
-//             and writes dL/d(features) slot-major for the table-gradient kernel.
+//             gradients in MFMA accumulators across all of the workgroup's blocks (flushed once) and writes dL/d(features)
+//             slot-major for the table-gradient kernel.
+// Row-strip tiling: wave w of a workgroup owns the 16 feature rows 16 w .. 16 w + 15 of every 64-row product and all 64 points of
+// the block (four 16-point column tiles = four independent accumulator chains).  A strip of a 64 x 64 matrix is 16 registers
+// (a[s] = A[16 w + i][s + 16 kg], lane = (i, kg)), so the four weight operands of the backward (W1, W2, W1^T, W2^T) cost 64
+// registers instead of the 128 a 32 x 32 tiling needs; the kernels fit 256 registers and TWO workgroups share a CU: one's
+// matrix-core phases cover the other's gathers, LDS epilogues and barriers (32 x 32 tiles, one wave per SIMD: backward 1.23 ms
+// with the matrix pipe 29 % busy, forward 1.16 ms; now 0.58 / 0.90 ms at 1 M points).
+// K index of MFMA step s in lane group kg: s + 16 kg.  With the pitch of 65 every operand read is conflict-free (rows s / s + 16
+// land 16 banks apart, a column of 16 rows walks 16 banks) and -- unlike an XOR swizzle -- an address is lane base + compile-time
+// offset, so the reads are immediates off ONE register per access pattern (with XOR the compiler hoists some 150 loop-invariant
+// addresses out of the block loop and spills).
 // ------------------------------------------------------------------------------------------------
-typedef float wf32x16 __attribute__((ext_vector_type(16)));
 #define WM_THREADS 256
-__device__ __forceinline__ int wm_ti(int f, int p) { return f * 64 + (p & 32) + ((p & 31) ^ (f & 31)); }
-__device__ __forceinline__ int wm_row(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
-
-// acc[32 x 32] += A[32 x 64] . T[64 x 32 points of tile tj], A rows in registers (a[s] = A[i][2 s + half])
-__device__ __forceinline__ wf32x16 wm_layer(const float (&a)[32], const float* T, int tj, int lane) {
-    const int j = lane & 31, half = lane >> 5;
-    wf32x16 acc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-#pragma unroll
-    for (int s = 0; s < 32; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], T[wm_ti(2 * s + half, 32 * tj + j)], acc, 0, 0, 0);
-    return acc;
-}
-// acc[32 features ta x 32 features tb] += sum over the block's 64 points of  TA[32 ta + i][p] * TB[32 tb + j][p]
-__device__ __forceinline__ void wm_outer(wf32x16& acc, const float* TA, int ta, const float* TB, int tb, int lane) {
-    const int j = lane & 31, half = lane >> 5;
-#pragma unroll 8
-    for (int s = 0; s < 32; ++s) {
-        const int p = 2 * s + half;
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(TA[wm_ti(32 * ta + j, p)], TB[wm_ti(32 * tb + j, p)], acc, 0, 0, 0);
-    }
-}
+typedef float wf32x4 __attribute__((ext_vector_type(4)));
+#define WM4_PITCH 65
+__device__ __forceinline__ int wm4_ti(int f, int p) { return f * WM4_PITCH + p; }
 
 __device__ __forceinline__ void wm_encode_block(const HashGridDev& g, long n, long slot0, const float* __restrict__ xyz,
                                                 const int32_t* __restrict__ perm, const float4* __restrict__ table, float* T,
@@ -425,87 +413,9 @@ __device__ __forceinline__ void wm_encode_block(const HashGridDev& g, long n, lo
                 acc.x = acc.x + cw * v.x; acc.y = acc.y + cw * v.y; acc.z = acc.z + cw * v.z; acc.w = acc.w + cw * v.w;
             }
         }
-        T[wm_ti(4 * l + 0, p)] = acc.x; T[wm_ti(4 * l + 1, p)] = acc.y; T[wm_ti(4 * l + 2, p)] = acc.z; T[wm_ti(4 * l + 3, p)] = acc.w;
+        T[wm4_ti(4 * l + 0, p)] = acc.x; T[wm4_ti(4 * l + 1, p)] = acc.y; T[wm4_ti(4 * l + 2, p)] = acc.z; T[wm4_ti(4 * l + 3, p)] = acc.w;
     }
 }
-
-// A operand rows of W (row-major [rows, 64]): a[s] = W[32 ti + i][2 s + half]   (rows >= valid_rows read as 0)
-__device__ __forceinline__ void wm_load_rows(float (&a)[32], const float* __restrict__ W, int ti, int valid_rows, int lane) {
-    const int i = lane & 31, half = lane >> 5;
-    const int row = 32 * ti + i;
-#pragma unroll
-    for (int s = 0; s < 32; ++s) a[s] = row < valid_rows ? W[row * 64 + 2 * s + half] : 0.f;
-}
-// A operand rows of W^T: a[s] = W[2 s + half][32 ti + i]   (W is [k_valid, 64]; rows >= k_valid read as 0)
-__device__ __forceinline__ void wm_load_cols(float (&a)[32], const float* __restrict__ W, int ti, int k_valid, int lane) {
-    const int i = lane & 31, half = lane >> 5;
-#pragma unroll
-    for (int s = 0; s < 32; ++s) a[s] = (2 * s + half) < k_valid ? W[(2 * s + half) * 64 + 32 * ti + i] : 0.f;
-}
-
-__global__ __launch_bounds__(WM_THREADS, 2) void gp_wm_fwd_kernel(HashGridDev g, long n, const float* __restrict__ xyz,
-                                                              const int32_t* __restrict__ perm, const float* __restrict__ params,
-                                                              int n_out, float* __restrict__ out, float* __restrict__ saved_feat) {
-    __shared__ float sA[64 * 64], sB[64 * 64];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, half = lane >> 5;
-    const int ti = wave & 1, tj = wave >> 1;
-    const float* W1 = params;
-    const float* W2 = params + 4096;
-    const float* W3 = params + 8192;
-    const float4* table = (const float4*)(params + 9216);
-    float w1[32], w2[32], w3[32];
-    wm_load_rows(w1, W1, ti, 64, lane);
-    wm_load_rows(w2, W2, ti, 64, lane);
-    wm_load_rows(w3, W3, 0, 16, lane);
-    const long nblocks = (n + 63) / 64;
-    for (long b = blockIdx.x; b < nblocks; b += gridDim.x) {
-        const long slot0 = b * 64;
-        __syncthreads();
-        wm_encode_block(g, n, slot0, xyz, perm, table, sA, tid);
-        __syncthreads();
-        if (saved_feat) {   // slot-major rows of 64 floats
-            for (int e = tid; e < 64 * 64; e += WM_THREADS) {
-                const int p = e >> 6, f = e & 63;
-                if (slot0 + p < n) saved_feat[(slot0 + p) * 64 + f] = sA[wm_ti(f, p)];
-            }
-        }
-        wf32x16 acc = wm_layer(w1, sA, tj, lane);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) sB[wm_ti(32 * ti + wm_row(r, half), 32 * tj + j)] = fmaxf(acc[r], 0.f);
-        __syncthreads();
-        acc = wm_layer(w2, sB, tj, lane);
-        __syncthreads();                        // everyone is done reading sA (features) before it is overwritten
-#pragma unroll
-        for (int r = 0; r < 16; ++r) sA[wm_ti(32 * ti + wm_row(r, half), 32 * tj + j)] = fmaxf(acc[r], 0.f);
-        __syncthreads();
-        if (ti == 0) {                          // output layer: rows 0..15 of a 32-row tile, one tile per point half
-            acc = wm_layer(w3, sA, tj, lane);
-            const long slot = slot0 + 32 * tj + j;
-            if (slot < n) {
-                const long i = perm ? (long)perm[slot] : slot;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int f = wm_row(r, half);
-                    if (f < n_out) out[i * n_out + f] = acc[r];
-                }
-            }
-        }
-    }
-}
-
-// ---- backward: row-strip tiling on v_mfma_f32_16x16x4_f32 -------------------------------------------------------
-// Wave w of a workgroup owns the 16 feature rows 16 w .. 16 w + 15 of every 64-row product and all 64 points of the block (four
-// 16-point column tiles = four independent accumulator chains).  A strip of a 64 x 64 matrix is 16 registers (a[s] =
-// A[16 w + i][s + 16 kg], lane = (i, kg)), so the four weight operands of the backward (W1, W2, W1^T, W2^T) cost 64 registers
-// instead of the 128 the 32 x 32 tiling needs, the kernel fits 256 registers and TWO workgroups share a CU: one's
-// matrix-core phases cover the other's LDS epilogues, barriers and staging (matrix pipe 29 % busy before, one wave per SIMD).
-// K index of MFMA step s in lane group kg: s + 16 kg.  LDS tiles are T[f][p] with a row pitch of 65 words: every operand read
-// is conflict-free (rows s / s + 16 land 16 banks apart, a column of 16 rows walks 16 banks) and -- unlike an XOR swizzle -- an
-// address is lane base + compile-time offset, so the reads are immediates off ONE register per access pattern (with XOR the
-// compiler hoists some 150 loop-invariant addresses out of the block loop and spills).
-typedef float wf32x4 __attribute__((ext_vector_type(4)));
-#define WM4_PITCH 65
-__device__ __forceinline__ int wm4_ti(int f, int p) { return f * WM4_PITCH + p; }
 
 // acc[c][r] = sum_k A[16 w + 4 kg + r][k] T[k][16 c + n]   (a[s] = A-strip operand, K = 64)
 __device__ __forceinline__ void wm4_layer(wf32x4 (&acc)[4], const float (&a)[16], const float* T, int lane) {
@@ -541,6 +451,58 @@ __device__ __forceinline__ void wm4_store(float* T, const wf32x4 (&acc)[4], int 
             const int idx = wm4_ti(16 * w + 4 * kg + r, 16 * c + n);
             T[idx] = f(acc[c][r], idx);
         }
+}
+
+__global__ __launch_bounds__(WM_THREADS, 2) void gp_wm_fwd_kernel(HashGridDev g, long n, const float* __restrict__ xyz,
+                                                                 const int32_t* __restrict__ perm, const float* __restrict__ params,
+                                                                 int n_out, float* __restrict__ out, float* __restrict__ saved_feat) {
+    __shared__ float sA[64 * WM4_PITCH], sB[64 * WM4_PITCH];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, i = lane & 15, kg = lane >> 4;
+    const float* W1 = params;
+    const float* W2 = params + 4096;
+    const float* W3 = params + 8192;
+    const float4* table = (const float4*)(params + 9216);
+    float w1[16], w2[16], w3[16];
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+        const int k = s + 16 * kg;
+        w1[s] = W1[(16 * w + i) * 64 + k];
+        w2[s] = W2[(16 * w + i) * 64 + k];
+        w3[s] = W3[i * 64 + k];                                       // the output layer's 16 (padded) rows, the same strip in every wave
+    }
+    const long nblocks = (n + 63) / 64;
+    for (long b = blockIdx.x; b < nblocks; b += gridDim.x) {
+        const long slot0 = b * 64;
+        __syncthreads();
+        wm_encode_block(g, n, slot0, xyz, perm, table, sA, tid);
+        __syncthreads();
+        if (saved_feat) {   // slot-major rows of 64 floats
+            for (int e = tid; e < 64 * 64; e += WM_THREADS) {
+                const int p = e >> 6, f = e & 63;
+                if (slot0 + p < n) saved_feat[(slot0 + p) * 64 + f] = sA[wm4_ti(f, p)];
+            }
+        }
+        wf32x4 acc[4];
+        wm4_layer(acc, w1, sA, lane);
+        wm4_store(sB, acc, w, lane, [](float v, int) { return fmaxf(v, 0.f); });
+        __syncthreads();
+        wm4_layer(acc, w2, sB, lane);
+        __syncthreads();                        // everyone is done reading sA (features) before it is overwritten
+        wm4_store(sA, acc, w, lane, [](float v, int) { return fmaxf(v, 0.f); });
+        __syncthreads();
+        {                                       // output layer: 16 rows x the wave's 16 points (column tile w)
+            wf32x4 o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < 16; ++s) o = __builtin_amdgcn_mfma_f32_16x16x4f32(w3[s], sA[wm4_ti(s + 16 * kg, 16 * w + i)], o, 0, 0, 0);
+            const long slot = slot0 + 16 * w + i;
+            if (slot < n) {
+                const long pt = perm ? (long)perm[slot] : slot;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (4 * kg + r < n_out) out[pt * n_out + 4 * kg + r] = o[r];
+            }
+        }
+    }
 }
 
 // One block's inputs of the backward kernel into registers: 64 points x 64 saved features (float4 per thread x 4) and
