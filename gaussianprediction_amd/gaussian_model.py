@@ -116,23 +116,49 @@ class GaussianModel(TrainingMixin, nn.Module):
         return tuple((id(t), t._version, t.data_ptr(), tuple(t.shape)) for t in tensors)
 
     @torch.no_grad()
-    def get_nearest_mask(self, keepshape=False):     # [REF scene/gaussian_model.py:110-125]
+    def get_nearest_mask(self, keepshape=False, defer=False):     # [REF scene/gaussian_model.py:110-125]
         """The reference searches the neighbours on every forward; their inputs do not depend on the frame time, so the result
         is kept until one of them changes (every training step -- but not between the frames of an evaluation, nor between the
-        views of a `--batch`).  Same kernel, same result."""
+        views of a `--batch`).  Same kernel, same result.
+        `defer=True` (forward's own call): a large search is enqueued on a side stream so that it runs beside the weights model's
+        encode (the search is vector-ALU work, the encode waits on random table lines); `_knn_join()` orders the calling stream
+        behind it before the indices are consumed."""
         a = self.args
         key = self._state_key(self._xyz, self.motion_feature, self.super_gaussians, self.super_gaussians_feature)
         c = getattr(self, "_knn_cache", None)
         if c is None or c[0] != key:
+            self._knn_join()
             wm = getattr(self, "weights_model", None)          # the spatial order its encode already keeps (a performance hint only)
-            order = wm.spatial_order(self._xyz.detach(), age=False) if wm is not None and self._xyz.shape[0] > 4096 else None
-            nearest = knn_keypoints(self._xyz, self.super_gaussians, a.nearest_num, self.motion_feature,
-                                    self.super_gaussians_feature, getattr(a, "feature_amplify", 5.0),
-                                    getattr(a, "knn_type", "hybird"), order=order)
+            n = self._xyz.shape[0]
+            order = wm.spatial_order(self._xyz.detach(), age=False) if wm is not None and n > 4096 else None
+            run = lambda: knn_keypoints(self._xyz, self.super_gaussians, a.nearest_num, self.motion_feature,
+                                        self.super_gaussians_feature, getattr(a, "feature_amplify", 5.0),
+                                        getattr(a, "knn_type", "hybird"), order=order)
+            if defer and self._xyz.is_cuda and n >= (1 << 17):
+                dev = self._xyz.device
+                side = getattr(self, "_knn_stream", None)
+                if side is None or side.device != dev:
+                    side = self._knn_stream = torch.cuda.Stream(device=dev)
+                cur = torch.cuda.current_stream(dev)
+                side.wait_stream(cur)
+                with torch.cuda.stream(side):
+                    nearest = run()
+                nearest.record_stream(cur)
+                self._knn_pending = side
+            else:
+                nearest = run()
             c = self._knn_cache = (key, nearest)
+        if not defer:
+            self._knn_join()
         nearest = c[1]
         self.nearest_mask = nearest if keepshape else nearest.view([-1])
         return self.nearest_mask
+
+    def _knn_join(self):
+        side = getattr(self, "_knn_pending", None)
+        if side is not None:
+            torch.cuda.current_stream(side.device).wait_stream(side)
+            self._knn_pending = None
 
     def _keypoint_raw_weights(self):
         """`weights_model(self.get_xyz.detach())` [REF scene/gaussian_model.py:257], evaluated once per parameter state: positions
@@ -276,8 +302,9 @@ class GaussianModel(TrainingMixin, nn.Module):
                 if getattr(self, "weights_model", None) is None:
                     raise RuntimeError("stage 2/3 needs set_keypoint_weights(raw_weights, knn_idx) or a weights_model "
                                        "(create_from_tensors(..., with_weights_model=True))")
+                knn_idx = self.get_nearest_mask(keepshape=True, defer=True)      # [REF :260] (enqueued first: runs beside the encode)
                 raw_weights = self._keypoint_raw_weights()                       # [REF :257]
-                knn_idx = self.get_nearest_mask(keepshape=True)                  # [REF :260]
+                self._knn_join()
             delta = self.df_model.forward_fused(self.super_gaussians_feature, kp, t_dev, xyz_freq, time_freq)
             self._last_delta = delta.detach()
             self._last_blend = (raw_weights.detach(), knn_idx, self.super_gaussians.shape[0])
