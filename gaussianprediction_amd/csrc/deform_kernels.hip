@@ -772,6 +772,8 @@ __device__ __forceinline__ void normalize_bwd(const float* v, const float* g, fl
 // per (workgroup, keypoint) after the sum.  Workgroup partials go to `partial`; gp_blend_bwd_reduce_kernel adds them.
 //
 // dynamic LDS: acc[K*7] | delta[K*od] | cnt[K] | base[K+1] | g[256*8] | w[256*2*nn] | sorted u16 [256*nn]
+#define BB_LONG 12          // a keypoint's list beyond this length is summed by a wave (mean length = nn)
+#define BB_LONG_CAP 320     // >= 256 * GP_MAX_NN / (BB_LONG + 1) lists can be that long
 template <int NN>
 __device__ __forceinline__ void blend_bwd_body(BlendDev a, const float* __restrict__ g_xyz_t,
                                                const float* __restrict__ g_q_t, float* __restrict__ g_delta,
@@ -790,6 +792,7 @@ __device__ __forceinline__ void blend_bwd_body(BlendDev a, const float* __restri
     float* s_w = s_g + 256 * 8;                         // [2*nn][256] chunk; [256][8] / [256][12] put 64 lanes on 4 / 8 banks (measured: 71 % of the LDS cycles were conflicts)
     unsigned short* s_sorted = (unsigned short*)(s_w + 256 * 2 * nn);   // [256*nn]
     __shared__ int s_wsum[4];
+    __shared__ int s_nlong, s_long[BB_LONG_CAP];
     if (nn > 0) {
         for (int e = tid; e < K * 7; e += 256) s_acc[e] = 0.f;
         for (int e = tid; e < K * od; e += 256) s_delta[e] = a.delta[e];
@@ -800,6 +803,7 @@ __device__ __forceinline__ void blend_bwd_body(BlendDev a, const float* __restri
         const bool live = i < a.N;
         if (nn > 0) {
             for (int e = tid; e < K; e += 256) s_cnt[e] = 0;
+            if (tid == 0) s_nlong = 0;
             __syncthreads();
         }
         int kps[NN > 0 ? NN : GP_MAX_NN], rk[NN > 0 ? NN : GP_MAX_NN];
@@ -923,6 +927,7 @@ __device__ __forceinline__ void blend_bwd_body(BlendDev a, const float* __restri
             for (int kp = tid; kp < K; kp += 256) {
                 float sacc[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
                 const int pe = s_base[kp + 1];
+                if (pe - s_base[kp] > BB_LONG) { s_long[atomicAdd(&s_nlong, 1)] = kp; continue; }   // summed by a whole wave below
                 for (int pp = s_base[kp]; pp < pe; pp += 2) {          // two entries per round: their gathers overlap (summed in list order)
                     const int e0 = s_sorted[pp], e1 = pp + 1 < pe ? s_sorted[pp + 1] : -1;
                     const int t0 = e0 & 255, k0 = e0 >> 8, t1 = e1 & 255, k1 = (e1 >> 8) & 15;
@@ -945,6 +950,32 @@ __device__ __forceinline__ void blend_bwd_body(BlendDev a, const float* __restri
                 for (int cc = 0; cc < 7; ++cc) acc[cc] += sacc[cc];
             }
             __syncthreads();
+            // Long lists (spatially coherent storage order -- a densified or sorted cloud -- puts most of a chunk's 256 x nn entries
+            // on a dozen keypoints: their owner threads would walk hundreds of entries while the rest of the workgroup idles;
+            // the bench scene stored along a Morton curve: 0.09 -> 0.21 ms).  A wave strides over such a list and reduces.
+            const int nlong = s_nlong;
+            for (int q = tid >> 6; q < nlong; q += 4) {
+                const int kp = s_long[q], pe = s_base[kp + 1];
+                float sacc[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                for (int pp = s_base[kp] + (tid & 63); pp < pe; pp += 64) {
+                    const int e = s_sorted[pp], t = e & 255, k = e >> 8;
+                    const float wxk = s_w[k * 256 + t], wrk = s_w[(nn + k) * 256 + t];
+                    sacc[0] = fmaf(wxk, s_g[0 * 256 + t], sacc[0]); sacc[1] = fmaf(wxk, s_g[1 * 256 + t], sacc[1]);
+                    sacc[2] = fmaf(wxk, s_g[2 * 256 + t], sacc[2]); sacc[3] = fmaf(wrk, s_g[3 * 256 + t], sacc[3]);
+                    sacc[4] = fmaf(wrk, s_g[4 * 256 + t], sacc[4]); sacc[5] = fmaf(wrk, s_g[5 * 256 + t], sacc[5]);
+                    sacc[6] = fmaf(wrk, s_g[6 * 256 + t], sacc[6]);
+                }
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+                    for (int cc = 0; cc < 7; ++cc) sacc[cc] += __shfl_xor(sacc[cc], off);
+                if ((tid & 63) == 0) {
+                    float* acc = s_acc + kp * 7;
+#pragma unroll
+                    for (int cc = 0; cc < 7; ++cc) acc[cc] += sacc[cc];
+                }
+            }
+            if (nlong > 0) __syncthreads();                  // (uniform) the next chunk re-uses s_sorted / s_w / s_g
         }
     }
     if (nn > 0) {
