@@ -55,7 +55,7 @@ __global__ __launch_bounds__(256) void gp_blend_bwd8_kernel(BlendDev a, const fl
                                                            const float* __restrict__ g_q_t, float* __restrict__ g_delta,
                                                            float* __restrict__ g_raw_w, float* __restrict__ g_xyz,
                                                            float* __restrict__ g_rot, float* __restrict__ partial);
-__global__ __launch_bounds__(256) void gp_blend_bwd_reduce_kernel(const float* __restrict__ partial, int nblocks, int KA,
+__global__ __launch_bounds__(1024) void gp_blend_bwd_reduce_kernel(const float* __restrict__ partial, int nblocks, int KA,
                                                                   int od, float* __restrict__ g_delta);
 __global__ __launch_bounds__(256) void gp_act_fwd_kernel(long n, const float* __restrict__ scaling_raw,
                                                          const float* __restrict__ opacity_raw,

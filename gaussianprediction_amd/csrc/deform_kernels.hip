@@ -1004,25 +1004,28 @@ __global__ __launch_bounds__(256) void gp_blend_bwd6_kernel(BB_ARGS) { blend_bwd
 __global__ __launch_bounds__(256) void gp_blend_bwd8_kernel(BB_ARGS) { blend_bwd_body<8>(a, g_xyz_t, g_q_t, g_delta, g_raw_w, g_xyz, g_rot, partial); }
 
 // stage 2: g_delta[k, c] = sum over workgroups (deterministic, no atomics).  64 elements per workgroup, the
-// workgroup's 4 waves split the partials and meet in LDS.
-__global__ __launch_bounds__(256) void gp_blend_bwd_reduce_kernel(const float* __restrict__ partial, int nblocks, int KA,
-                                                                 int od, float* __restrict__ g_delta) {
-    __shared__ float s_r[4][64];
+// workgroup's 16 waves split the partials (four independent sums each) and meet in LDS.
+__global__ __launch_bounds__(1024) void gp_blend_bwd_reduce_kernel(const float* __restrict__ partial, int nblocks, int KA,
+                                                                  int od, float* __restrict__ g_delta) {
+    __shared__ float s_r[16][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int e = blockIdx.x * 64 + lane;
     float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
     if (e < KA) {
         int b = wave;
-        for (; b + 12 < nblocks; b += 16) {
-            v0 += partial[(size_t)b * KA + e]; v1 += partial[(size_t)(b + 4) * KA + e];
-            v2 += partial[(size_t)(b + 8) * KA + e]; v3 += partial[(size_t)(b + 12) * KA + e];
+        for (; b + 48 < nblocks; b += 64) {
+            v0 += partial[(size_t)b * KA + e]; v1 += partial[(size_t)(b + 16) * KA + e];
+            v2 += partial[(size_t)(b + 32) * KA + e]; v3 += partial[(size_t)(b + 48) * KA + e];
         }
-        for (; b < nblocks; b += 4) v0 += partial[(size_t)b * KA + e];
+        for (; b < nblocks; b += 16) v0 += partial[(size_t)b * KA + e];
     }
     s_r[wave][lane] = (v0 + v1) + (v2 + v3);
     __syncthreads();
     if (wave == 0 && e < KA) {
-        g_delta[(size_t)(e / 7) * od + (e % 7)] = (s_r[0][lane] + s_r[1][lane]) + (s_r[2][lane] + s_r[3][lane]);
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) t += s_r[w][lane];
+        g_delta[(size_t)(e / 7) * od + (e % 7)] = t;
         if (e % 7 == 6) for (int c = 7; c < od; ++c) g_delta[(size_t)(e / 7) * od + c] = 0.f;   // (the whole row is written: no zero-fill by the caller)
     }
 }

@@ -182,7 +182,7 @@ extern "C" int gp_blend_backward(const gp_blend_args* a, const float* dL_dxyz_t,
                        dL_draw_w, dL_dxyz, dL_drot, partial);
     GP_LAUNCH_CHECK();
     if (b.nn > 0) {
-        hipLaunchKernelGGL(gp_blend_bwd_reduce_kernel, dim3(gp_blocks((size_t)KA, 64)), dim3(256), 0, (hipStream_t)stream_, partial,
+        hipLaunchKernelGGL(gp_blend_bwd_reduce_kernel, dim3(gp_blocks((size_t)KA, 64)), dim3(1024), 0, (hipStream_t)stream_, partial,
                            (int)blocks, KA, b.out_dim, dL_ddelta);
         GP_LAUNCH_CHECK();
     } }
