@@ -14,7 +14,9 @@ import torch  # noqa: F401  (must be imported first: libgp_hip.so binds to the H
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libgp_hip.so")
 
-GP_LOSS_SUM_SLOTS = 256   # include/gp_hip.h
+def GP_LOSS_SUM_SLOTS(H, W):   # include/gp_hip.h
+    return 3 * ((W + 31) // 32) * ((H + 31) // 32)
+
 GP_BUF_GEOM, GP_BUF_BINNING, GP_BUF_IMAGE, GP_BUF_TEMP = 0, 1, 2, 3
 
 ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_int, C.c_size_t)
@@ -37,7 +39,7 @@ class RasterInputsC(C.Structure):
 
 
 class RasterOutputsC(C.Structure):
-    _fields_ = [("color", C.c_void_p), ("radii", C.c_void_p), ("depth", C.c_void_p), ("tidx", C.c_void_p)]
+    _fields_ = [("color", C.c_void_p), ("radii", C.c_void_p), ("depth", C.c_void_p), ("tidx", C.c_void_p), ("visible", C.c_void_p)]
 
 
 class RasterSavedC(C.Structure):

@@ -45,6 +45,7 @@ static int make_dims(const gp_raster_settings* st, const gp_raster_inputs* in, R
     d.fy = (float)d.H / (2.f * st->tanfovy);
     d.scale_mod = st->scale_modifier;
     d.late_color = (st->sh_ready_event && in->shs) ? 1 : 0;
+    d.visible = nullptr; d.zero_words = nullptr; d.n_zero = 0;
     return 0;
 }
 
@@ -101,7 +102,13 @@ extern "C" int gp_raster_forward(const gp_raster_settings* st, const gp_raster_i
     saved->image = img; saved->image_bytes = il.bytes;
     saved->binning = nullptr; saved->binning_bytes = 0; saved->num_rendered = 0;
 
-    GP_HIP_CHECK(hipMemsetAsync(il.ranges, 0, (T + GP_TOTAL_SLOTS / 2) * sizeof(int2), s));      // (tile ranges + the instance counter's slots behind them)
+    {   // tile ranges + the instance counter's slots behind them start from zero: by the preprocess launch when it has enough
+        // threads, else by a memset of its own
+        const size_t words = (T + GP_TOTAL_SLOTS / 2) * 2;
+        if ((size_t)N >= words) { d.zero_words = (uint32_t*)il.ranges; d.n_zero = (int)words; }
+        else GP_HIP_CHECK(hipMemsetAsync(il.ranges, 0, words * sizeof(uint32_t), s));
+    }
+    d.visible = out->visible;
     uint32_t R = 0;
     uint32_t* point_list = nullptr;
     if (N > 0) {

@@ -116,10 +116,10 @@ __global__ __launch_bounds__(256) void gp_l1_ssim_fwd_kernel(const float* __rest
     const float l1_tot = block_sum_256(l1, s_red);
     __syncthreads();
     const float ss_tot = block_sum_256(ss, s_red);
-    if (tid == 0) {
-        const unsigned slot = (blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) % GP_LOSS_SUM_SLOTS;
-        atomicAdd(&sums[2 * slot], (double)l1_tot);
-        atomicAdd(&sums[2 * slot + 1], (double)ss_tot);
+    if (tid == 0) {      // one slot per workgroup, plain stores: nothing to zero beforehand, and the finalize sums in a fixed order
+        const unsigned slot = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+        sums[2 * slot] = (double)l1_tot;
+        sums[2 * slot + 1] = (double)ss_tot;
     }
 }
 
@@ -294,13 +294,12 @@ __global__ __launch_bounds__(256) void gp_adam_multi_kernel(AdamTable t, float b
     }
 }
 
-// The slot totals in a fixed order (the result does not depend on which workgroup added to which slot first): thread k loads
-// slot k, xor-butterfly inside the wave, the four wave sums through LDS.  (Round 2 let ONE thread walk the 256 slots: 512
-// dependent double loads, 19 us for a scalar.)
-static_assert(GP_LOSS_SUM_SLOTS == 256, "one slot per thread");
-__device__ __forceinline__ void loss_slot_totals(const double* __restrict__ sums, double* s_red /*[8]*/, double& s0, double& s1) {
+// The slot totals in a fixed order: thread k walks slots k, k + 256, ..., xor-butterfly inside the wave, the four wave sums
+// through LDS.  (Round 2 let ONE thread walk the slots: 512 dependent double loads, 19 us for a scalar.)
+__device__ __forceinline__ void loss_slot_totals(const double* __restrict__ sums, int nslots, double* s_red /*[8]*/, double& s0, double& s1) {
     const int tid = threadIdx.x;
-    double a = sums[2 * tid], b = sums[2 * tid + 1];
+    double a = 0.0, b = 0.0;
+    for (int k = tid; k < nslots; k += 256) { a += sums[2 * k]; b += sums[2 * k + 1]; }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) {
         a += __shfl_xor(a, d);
@@ -313,15 +312,15 @@ __device__ __forceinline__ void loss_slot_totals(const double* __restrict__ sums
 }
 
 // loss = (1-lam) * sums[0]/n + lam * (1 - sums[1]/n)   (keeps the scalar on the device)
-__global__ __launch_bounds__(256) void gp_loss_finalize_kernel(const double* __restrict__ sums, double n, float lambda, float* __restrict__ loss) {
+__global__ __launch_bounds__(256) void gp_loss_finalize_kernel(const double* __restrict__ sums, int nslots, double n, float lambda, float* __restrict__ loss) {
     __shared__ double s_tot[8];
     double s0, s1;
-    loss_slot_totals(sums, s_tot, s0, s1);
+    loss_slot_totals(sums, nslots, s_tot, s0, s1);
     if (threadIdx.x == 0) loss[0] = (float)((1.0 - (double)lambda) * s0 / n + (double)lambda * (1.0 - s1 / n));
 }
 
 // the same + scale/n * sum|x| (one workgroup; fixed summation order)
-__global__ __launch_bounds__(256) void gp_loss_finalize_reg_kernel(const double* __restrict__ sums, double n, float lambda,
+__global__ __launch_bounds__(256) void gp_loss_finalize_reg_kernel(const double* __restrict__ sums, int nslots, double n, float lambda,
                                                                   const float* __restrict__ x, long nx, float scale_over_n,
                                                                   float* __restrict__ loss) {
     __shared__ float s_red[4];
@@ -339,7 +338,7 @@ __global__ __launch_bounds__(256) void gp_loss_finalize_reg_kernel(const double*
     }
     const float tot = block_sum_256(acc, s_red);
     double s0, s1;
-    loss_slot_totals(sums, s_tot, s0, s1);
+    loss_slot_totals(sums, nslots, s_tot, s0, s1);
     if (threadIdx.x == 0)
         loss[0] = (float)((1.0 - (double)lambda) * s0 / n + (double)lambda * (1.0 - s1 / n)) + tot * scale_over_n;
 }
@@ -381,7 +380,6 @@ extern "C" int gp_loss_l1_ssim_forward(const float* img, const float* gt, int32_
     hipStream_t s = (hipStream_t)stream_;
     if (!img || !gt || !sums) GP_FAIL("null argument");
     if (channels != 3 || H <= 0 || W <= 0) GP_FAIL("expects a [3,H,W] image (got C=%d H=%d W=%d)", channels, H, W);
-    GP_HIP_CHECK(hipMemsetAsync(sums, 0, 2 * GP_LOSS_SUM_SLOTS * sizeof(double), s));
     GpProfScope _p("l1_ssim_fwd", s);
     hipLaunchKernelGGL(gp_l1_ssim_fwd_kernel, dim3((W + LT - 1) / LT, (H + LT - 1) / LT, 3), dim3(256), 0, s, img, gt, H, W,
                        make_window(), sums, dmaps);
@@ -392,7 +390,7 @@ extern "C" int gp_loss_l1_ssim_forward(const float* img, const float* gt, int32_
 extern "C" int gp_loss_l1_ssim_finalize(const double* sums, int32_t channels, int32_t H, int32_t W, float lambda_dssim, float* loss,
                                         gp_stream_t stream_) {
     if (!sums || !loss) GP_FAIL("null argument");
-    hipLaunchKernelGGL(gp_loss_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream_, sums, (double)channels * H * W, lambda_dssim, loss);
+    hipLaunchKernelGGL(gp_loss_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream_, sums, (int)GP_LOSS_SUM_SLOTS(H, W), (double)channels * H * W, lambda_dssim, loss);
     GP_LAUNCH_CHECK();
     return 0;
 }
@@ -416,7 +414,7 @@ extern "C" int gp_loss_l1_ssim_finalize_reg(const double* sums, int32_t channels
                                             const float* x, int64_t n, float scale, float* loss, gp_stream_t stream_) {
     if (!sums || !loss || !x) GP_FAIL("null argument");
     if (n <= 0 || n > GP_LOSS_REG_MAX) GP_FAIL("regulariser input must have 1..%d elements (use gp_l1_mean_forward beyond)", GP_LOSS_REG_MAX);
-    hipLaunchKernelGGL(gp_loss_finalize_reg_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream_, sums, (double)channels * H * W, lambda_dssim,
+    hipLaunchKernelGGL(gp_loss_finalize_reg_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream_, sums, (int)GP_LOSS_SUM_SLOTS(H, W), (double)channels * H * W, lambda_dssim,
                        x, (long)n, scale / (float)n, loss);
     GP_LAUNCH_CHECK();
     return 0;

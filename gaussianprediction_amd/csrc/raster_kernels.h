@@ -17,6 +17,10 @@ struct RasterDims {
     int W, H, gx, gy;  // image and tile grid
     float tanfovx, tanfovy, fx, fy, scale_mod;
     int late_color;    // 1: the preprocess kernel leaves the colour to gp_sh_color_*_kernel (gp_raster_settings.sh_ready_event)
+    // riding on the preprocess launch instead of launches of their own (each ~4 us on the step's critical path):
+    uint8_t* visible;      // optional [N]: radii > 0 (the renderer's visibility_filter)
+    uint32_t* zero_words;  // optional: n_zero words the binning stage expects zeroed (tile ranges + instance-counter slots)
+    int n_zero;
 };
 
 __global__ __launch_bounds__(256) void gp_preprocess_fwd_kernel(RasterDims d, const float* __restrict__ means3D, const float* __restrict__ scales,      const float* __restrict__ rotations, const float* __restrict__ opacities, const float* __restrict__ shs,      const float* __restrict__ shs_rest, const float* __restrict__ colors_precomp, const float* __restrict__ cov3D_precomp,      const float* __restrict__ view, const float* __restrict__ proj, const float* __restrict__ campos,      int32_t* __restrict__ radii, float4* __restrict__ rec, uint32_t* __restrict__ depth_key,      uint2* __restrict__ tiles_touched, uint8_t* __restrict__ clamped);

@@ -288,7 +288,9 @@ __device__ __forceinline__ void preprocess_fwd_body(RasterDims d, const float* _
     if (SH_MODE == 2 && use_sh && d.D > 0) stage_sh<45>(s_sh, shs_rest + (size_t)base * 45, nblk, tid);
     if (SH_MODE != 0) __syncthreads();
     if (i >= d.N) return;
+    if (i < d.n_zero) d.zero_words[i] = 0u;              // (only handed over when N >= n_zero)
     radii[i] = 0;
+    if (d.visible) d.visible[i] = 0;
     tiles_touched[i] = make_uint2(0u, 0u);
     depth_key[i] = 0xFFFFFFFFu;
     clamped[i] = 0;
@@ -328,7 +330,9 @@ __device__ __forceinline__ void preprocess_fwd_body(RasterDims d, const float* _
     } else if (!d.late_color) {
         cl = sh_color<SH_MODE>(d, i, tid, px, py, pz, campos, shs, s_sh, col);
     }
-    radii[i] = f2i_sat(rad_f);
+    const int rad_i = f2i_sat(rad_f);
+    radii[i] = rad_i;
+    if (d.visible) d.visible[i] = rad_i > 0;
     clamped[i] = cl;
     depth_key[i] = __float_as_uint(pv.z);
     // tile rectangle (first tile | extent, 16 bits each): the binning stage expands it without touching `rec` again

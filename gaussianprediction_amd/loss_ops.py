@@ -27,7 +27,7 @@ class L1SSIMLoss(torch.autograd.Function):
         if img.dim() != 3 or img.shape[0] != 3 or g.shape != img.shape:
             raise RuntimeError("L1SSIMLoss expects two [3,H,W] images")
         _, H, W = img.shape
-        sums = torch.empty(2 * _lib.GP_LOSS_SUM_SLOTS, dtype=torch.float64, device=dev)
+        sums = torch.empty(2 * _lib.GP_LOSS_SUM_SLOTS(H, W), dtype=torch.float64, device=dev)
         need = image.requires_grad or (reg_x is not None and reg_x.requires_grad)
         dmaps = torch.empty(3, 3, H, W, device=dev) if need else None
         with _lib.on_device(dev):

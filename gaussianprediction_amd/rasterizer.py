@@ -45,6 +45,9 @@ class GaussianRasterizationSettings(NamedTuple):
     # all-gather of the updated coefficients in view-parallel training).  The forward then reads them in a separate SH -> RGB
     # kernel right before the composite and waits for the event only there.  None = they are ready now.
     sh_ready_event: Optional[object] = None
+    # extension (gp_raster_outputs.visible): a contiguous uint8 [N] tensor on the render device that the projection kernel fills with
+    # radii > 0 -- render()'s visibility_filter without a compare launch per frame.  None = not wanted.
+    visible_out: Optional[torch.Tensor] = None
 
 
 _bump_version = getattr(torch.autograd.graph, "increment_version", lambda t: None)
@@ -114,7 +117,10 @@ class _RasterizeGaussians(torch.autograd.Function):
             radii = torch.empty(N, device=device, dtype=torch.int32)
             depth = torch.empty(1, H, W, device=device, dtype=torch.float32)
             tidx = torch.empty(H, W, device=device, dtype=torch.int32)
-            out = _lib.RasterOutputsC(_lib.ptr(color), _lib.ptr(radii), _lib.ptr(depth), _lib.ptr(tidx))
+            vis = getattr(rs, "visible_out", None)
+            if vis is not None and (vis.device != device or vis.dtype != torch.uint8 or vis.numel() != N or not vis.is_contiguous()):
+                raise RuntimeError("visible_out: contiguous uint8 tensor of N elements on the render device expected")
+            out = _lib.RasterOutputsC(_lib.ptr(color), _lib.ptr(radii), _lib.ptr(depth), _lib.ptr(tidx), _lib.ptr(vis))
             saved = _lib.RasterSavedC()
             alloc = _lib.TorchAllocator(device)
             try:

@@ -33,8 +33,9 @@ def _sh_to_rgb_python(deg, feats, dirs):
     return torch.clamp_min(res + 0.5, 0.0)
 
 
-def _settings(viewpoint_camera, pc, bg_color, scaling_modifier, binning=None, sh_ready_event=None):
+def _settings(viewpoint_camera, pc, bg_color, scaling_modifier, binning=None, sh_ready_event=None, visible_out=None):
     return GaussianRasterizationSettings(
+        visible_out=visible_out,
         binning_capacity=int(binning[0]) if binning else 0,
         binning_status=binning[1] if binning else None,
         sh_ready_event=sh_ready_event,
@@ -103,7 +104,8 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=
     sh_ready = late() if late is not None else None
     if late is None:
         _wait_params(pc)
-    rasterizer = GaussianRasterizer(raster_settings=_settings(viewpoint_camera, pc, bg_color, scaling_modifier, binning, sh_ready))
+    vis = torch.empty(means3D.shape[0], dtype=torch.uint8, device=means3D.device)     # filled by the projection kernel (radii > 0)
+    rasterizer = GaussianRasterizer(raster_settings=_settings(viewpoint_camera, pc, bg_color, scaling_modifier, binning, sh_ready, vis))
     if override_color is None:
         if getattr(pipe, "convert_SHs_python", False):
             base = means3D.detach() if time is not None else pc.get_xyz + (delta if delta is not None else 0)
@@ -118,7 +120,7 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=
     rendered_image, radii, depth, tidx = rasterizer(means3D=means3D, means2D=screenspace_points, shs=shs,
                                                     colors_precomp=colors_precomp, opacities=opacity, scales=scales,
                                                     rotations=rotations, cov3D_precomp=cov3D_precomp, shs_rest=shs_rest)
-    return {"render": rendered_image, "viewspace_points": screenspace_points, "visibility_filter": radii > 0,
+    return {"render": rendered_image, "viewspace_points": screenspace_points, "visibility_filter": vis.view(torch.bool),
             "radii": radii, "depth": depth, "tidx": tidx}
 
 

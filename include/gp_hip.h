@@ -89,6 +89,8 @@ typedef struct gp_raster_outputs {
     int32_t* radii; /* [N] */
     float* depth;   /* [1,H,W]  sum_i z_i alpha_i T_i */
     int32_t* tidx;  /* [H,W]    id of the Gaussian with the largest blend weight, -1 if none */
+    uint8_t* visible; /* optional [N]: radii > 0, what render() returns as visibility_filter [REF gaussian_renderer/__init__.py:113]
+                       * (written by the projection kernel: saves the caller a compare launch per frame); NULL = not wanted */
 } gp_raster_outputs;
 
 /* opaque state saved between forward and backward */
@@ -263,12 +265,12 @@ int gp_activations_backward(int64_t n, const float* scaling_raw, const float* op
 /* ---- loss + optimizer (the steps right after the render in every training iteration) ---------- */
 
 /* sum |img - gt| and the sum of the SSIM map (11x11 Gaussian window, sigma 1.5, zero padding) over a [3,H,W]
- * image pair [REF utils/loss_utils.py:54-100].  `sums` has 2 * GP_LOSS_SUM_SLOTS doubles: workgroups add into
- * slot (id % GP_LOSS_SUM_SLOTS) -- (sums[2s], sums[2s+1]) -- because thousands of atomics on ONE address serialise
- * in L2; the totals are the sums over the slots.  gp_loss_l1_ssim_finalize forms
+ * image pair [REF utils/loss_utils.py:54-100].  `sums` has 2 * GP_LOSS_SUM_SLOTS(H, W) doubles, one (sum |a-b|, sum ssim) pair
+ * per workgroup (a 32 x 32 tile of one channel), written with plain stores: it need not be initialised, and the totals the
+ * finalize calls form are summed in a fixed order (bit-reproducible).  gp_loss_l1_ssim_finalize forms
  * (1-l) * S0/n + l * (1 - S1/n) [REF train.py:108].  dmaps (optional, [3,3,H,W]) receives the SSIM
  * partial-derivative maps the backward needs. */
-#define GP_LOSS_SUM_SLOTS 256
+#define GP_LOSS_SUM_SLOTS(H, W) (3 * (((W) + 31) / 32) * (((H) + 31) / 32))
 int gp_loss_l1_ssim_forward(const float* img, const float* gt, int32_t channels, int32_t H, int32_t W, double* sums,
                             float* dmaps, gp_stream_t stream);
 /* loss[0] = (1-l) * S0/n + l * (1 - S1/n), n = channels*H*W, S = slot totals: keeps the scalar on the device. */

@@ -309,3 +309,24 @@ def test_late_sh_colour_kernel_is_bit_identical(layout):
     assert float(a[0].abs().sum()) > 0
     for ga, gb in zip(a[4], b[4]):
         assert rel_l2(ga.cpu().numpy(), gb.cpu().numpy()) < 1e-5
+
+
+@pytest.mark.parametrize("n,W,H", [(3000, 128, 96), (40, 400, 304)])
+def test_visible_out_and_folded_zeroing(n, W, H):
+    """gp_raster_outputs.visible = radii > 0 from the projection kernel, and the binning state (tile ranges + instance-counter
+    slots) zeroed by that same launch when it has enough threads (n >= 2 (T + 8): first case) or by a memset (second case: 475
+    tiles, 40 Gaussians) -- same image either way, twice in a row on recycled buffers."""
+    scene, st, cam = small_scene(n=n, W=W, H=H, seed=5, scale_lo=0.02, scale_hi=0.2)
+    st = f32_settings(st)
+    dev = scene_to_device(scene)
+    rs = torch_settings(st)
+    kw = dict(means3D=dev["means3D"], means2D=torch.zeros(n, 3, device="cuda"), opacities=dev["opacities"], shs=dev["shs"],
+              scales=dev["scales"], rotations=dev["rotations"])
+    ref = gpa.GaussianRasterizer(raster_settings=rs)(**kw)
+    for _ in range(2):
+        vis = torch.full((n,), 7, dtype=torch.uint8, device="cuda")
+        out = gpa.GaussianRasterizer(raster_settings=rs._replace(visible_out=vis))(**kw)
+        assert all(torch.equal(a, b) for a, b in zip(out, ref))
+        assert torch.equal(vis.view(torch.bool), out[1] > 0) and int(vis.max()) <= 1 and bool(vis.any())
+    with pytest.raises(RuntimeError):
+        gpa.GaussianRasterizer(raster_settings=rs._replace(visible_out=torch.zeros(n + 1, dtype=torch.uint8, device="cuda")))(**kw)
