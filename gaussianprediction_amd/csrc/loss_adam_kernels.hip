@@ -40,12 +40,26 @@ __global__ __launch_bounds__(256) void gp_l1_ssim_fwd_kernel(const float* __rest
     const size_t HW = (size_t)H * W;
     const float* a_img = img + ch * HW;
     const float* b_img = gt + ch * HW;
-    for (int i = tid; i < LE * LE; i += 256) {
-        const int y = i / LE, x = i - y * LE;
-        const int gy = ty0 - LH + y, gx = tx0 - LH + x;
-        const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
-        s_a[y][x] = in ? a_img[(size_t)gy * W + gx] : 0.f;
-        s_b[y][x] = in ? b_img[(size_t)gy * W + gx] : 0.f;
+    {   // halo staging: ALL of a thread's loads issued before the first LDS store (clamped addresses, selected afterwards).  As a
+        // rolled loop with conditional loads this was load -> wait -> store, 14 dependent round trips to memory per workgroup:
+        // the kernel's whole duration (0.067 ms; the filter arithmetic is 0.02 ms)
+        constexpr int NST = (LE * LE + 255) / 256;
+        float va[NST], vb[NST];
+#pragma unroll
+        for (int u = 0; u < NST; ++u) {
+            const int i = tid + 256 * u, y = i / LE, x = i - y * LE;
+            const int gy = ty0 - LH + y, gx = tx0 - LH + x;
+            const bool in = i < LE * LE && gy >= 0 && gy < H && gx >= 0 && gx < W;
+            const size_t o = in ? (size_t)gy * W + gx : 0;
+            va[u] = a_img[o]; vb[u] = b_img[o];
+        }
+#pragma unroll
+        for (int u = 0; u < NST; ++u) {
+            const int i = tid + 256 * u, y = i / LE, x = i - y * LE;
+            const int gy = ty0 - LH + y, gx = tx0 - LH + x;
+            const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
+            if (i < LE * LE) { s_a[y][x] = in ? va[u] : 0.f; s_b[y][x] = in ? vb[u] : 0.f; }
+        }
     }
     __syncthreads();
     // horizontal pass: a thread owns 8 consecutive outputs of one staged row -- 18 + 18 LDS reads feed 8 x 5 outputs
@@ -139,14 +153,35 @@ __global__ __launch_bounds__(256) void gp_l1_ssim_bwd_kernel(const float* __rest
         for (long i = tid; i < reg_n; i += 256) { const float v = reg_x[i]; reg_g[i] = v > 0.f ? c : (v < 0.f ? -c : 0.f); }
     }
     const size_t HW = (size_t)H * W;
-    for (int i = tid; i < LE * LE; i += 256) {
-        const int y = i / LE, x = i - y * LE;
-        const int gy = ty0 - LH + y, gx = tx0 - LH + x;
-        const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
-        const size_t o = ch * HW + (size_t)(in ? gy : 0) * W + (in ? gx : 0);
-        s_m[0][y][x] = in ? dmap[o] : 0.f;
-        s_m[1][y][x] = in ? dmap[3 * HW + o] : 0.f;
-        s_m[2][y][x] = in ? dmap[6 * HW + o] : 0.f;
+    // the output pixels' own (img, gt) values: fetched up front (clamped addresses), consumed after the two filter passes --
+    // as conditional loads inside the output loop they were four more dependent round trips per workgroup
+    float pa[4], pb[4];
+    {
+        const int x = tid & 31, y0 = (tid >> 5) * 4, gx = min(tx0 + x, W - 1);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const size_t oo = ch * HW + (size_t)min(ty0 + y0 + e, H - 1) * W + gx;
+            pa[e] = img[oo]; pb[e] = gt[oo];
+        }
+    }
+    {   // halo staging with every load in flight before the first LDS store (see the forward kernel)
+        constexpr int NST = (LE * LE + 255) / 256;
+        float v0[NST], v1[NST], v2[NST];
+#pragma unroll
+        for (int u = 0; u < NST; ++u) {
+            const int i = tid + 256 * u, y = i / LE, x = i - y * LE;
+            const int gy = ty0 - LH + y, gx = tx0 - LH + x;
+            const bool in = i < LE * LE && gy >= 0 && gy < H && gx >= 0 && gx < W;
+            const size_t o = ch * HW + (in ? (size_t)gy * W + gx : 0);
+            v0[u] = dmap[o]; v1[u] = dmap[3 * HW + o]; v2[u] = dmap[6 * HW + o];
+        }
+#pragma unroll
+        for (int u = 0; u < NST; ++u) {
+            const int i = tid + 256 * u, y = i / LE, x = i - y * LE;
+            const int gy = ty0 - LH + y, gx = tx0 - LH + x;
+            const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
+            if (i < LE * LE) { s_m[0][y][x] = in ? v0[u] : 0.f; s_m[1][y][x] = in ? v1[u] : 0.f; s_m[2][y][x] = in ? v2[u] : 0.f; }
+        }
     }
     __syncthreads();
     if (tid < LE * 4) {   // horizontal pass, 8 outputs per thread (see the forward kernel)
@@ -190,7 +225,7 @@ __global__ __launch_bounds__(256) void gp_l1_ssim_bwd_kernel(const float* __rest
             const int gy = ty0 + y0 + e;
             if (gy >= H || gx >= W) continue;
             const size_t oo = ch * HW + (size_t)gy * W + gx;
-            const float a = img[oo], b = gt[oo];
+            const float a = pa[e], b = pb[e];
             const float d = a - b;
             const float sgn = (d > 0.f) ? 1.f : ((d < 0.f) ? -1.f : 0.f);
             dimg[oo] = g * inv_n * ((1.f - lambda) * sgn - lambda * (o[0][e] + 2.f * a * o[1][e] + b * o[2][e]));
