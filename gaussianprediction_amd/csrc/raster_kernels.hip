@@ -1501,7 +1501,33 @@ __device__ __forceinline__ void adam_unstage_sh(const float* s_sh, const AdamFus
     constexpr int STRIDE = CNT | 1;
     const int total = nblk * CNT;
     float* __restrict__ p = af.p_rest + off; float* __restrict__ m = af.m_rest + off; float* __restrict__ v = af.v_rest + off;
-    for (int e = tid * 4; e < total; e += 1024) {
+    // The stream that bounds the kernel (28 B per coefficient, 1.35 GB per launch at 1 M Gaussians).  One 1024-float chunk per
+    // iteration put three 16-byte loads in flight per thread, twelve waves per CU: ~36 KB per CU, i.e. latency x bandwidth for
+    // ~5 TB/s and no more.  AU chunks per iteration: 3 AU loads in flight before the first update.
+    constexpr int AU = 3;
+    int e = tid * 4;
+    for (; e + (AU - 1) * 1024 + 3 < total; e += AU * 1024) {
+        float4 pv[AU], mv[AU], vv[AU];
+#pragma unroll
+        for (int c = 0; c < AU; ++c) {
+            pv[c] = *(const float4*)(p + e + 1024 * c); mv[c] = *(const float4*)(m + e + 1024 * c); vv[c] = *(const float4*)(v + e + 1024 * c);
+        }
+#pragma unroll
+        for (int c = 0; c < AU; ++c) {
+            float* pp = (float*)&pv[c]; float* mm = (float*)&mv[c]; float* vq = (float*)&vv[c];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int idx = e + 1024 * c + u;
+                const int gi = idx / CNT, k = idx - gi * CNT;
+                gp_adam_update(pp[u], s_sh[gi * STRIDE + k], mm[u], vq[u], af.b1, af.b2, af.eps, af.step_rest, af.bc2_sqrt);
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < AU; ++c) {
+            *(float4*)(p + e + 1024 * c) = pv[c]; *(float4*)(m + e + 1024 * c) = mv[c]; *(float4*)(v + e + 1024 * c) = vv[c];
+        }
+    }
+    for (; e < total; e += 1024) {
         float g[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -1555,45 +1581,50 @@ __device__ __forceinline__ void preprocess_bwd_body(
         }
         __syncthreads();
     }
-    auto zero_row = [&]() {
-        if (SH_MODE != 0 && use_sh) {
+    // Everything the thread reads from global memory, issued TOGETHER up front (clamped index, unconditional): as loads placed
+    // where the values are used -- behind the visibility branch, inside the covariance / colour / rotation sections -- they were
+    // some ten dependent round trips to memory per wave.  The five accumulator pointers are offsets into ONE 64-byte line per
+    // Gaussian (gp_capi_raster.hip: mean2D 0..1 | conic 2..4 | opacity 5 | colour 6..8 | depth 9): three 16-byte loads.
+    const int ii = i < d.N ? i : d.N - 1;
+    const int rad_i = radii[ii];
+    const float4* accl = (const float4*)(g_mean2D + GP_ACC_STRIDE * (size_t)ii);
+    const float4 A0 = accl[0], A1 = accl[1], A2 = accl[2];
+    const float px = means3D[3 * ii], py = means3D[3 * ii + 1], pz = means3D[3 * ii + 2];
+    float sc3[3] = {0.f, 0.f, 0.f}, q4[4] = {0.f, 0.f, 0.f, 0.f};
+    if (!cov3D_precomp) {
 #pragma unroll
-            for (int k = 0; k < (SH_MODE == 1 ? 48 : 45); ++k) s_sh[tid * SROW + k] = 0.f;
-        }
-    };
+        for (int k = 0; k < 3; ++k) sc3[k] = scales[3 * ii + k];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) q4[k] = rotations[4 * ii + k];
+    }
+    const uint8_t cl = dL_dcolors ? (uint8_t)0 : clamped[ii];
+    const float acc_mean2D[2] = {A0.x, A0.y}, acc_conic[3] = {A0.z, A0.w, A1.x}, acc_opacity = A1.y,
+                acc_color[3] = {A1.z, A1.w, A2.x}, acc_depth = A2.y;
     do {
     if (i >= d.N) break;
-    const bool vis = radii[i] > 0;
-    dL_dmeans2D[3 * i] = vis ? g_mean2D[GP_ACC_STRIDE * (size_t)i] : 0.f;
-    dL_dmeans2D[3 * i + 1] = vis ? g_mean2D[GP_ACC_STRIDE * (size_t)i + 1] : 0.f;
+    const bool vis = rad_i > 0;
+    dL_dmeans2D[3 * i] = vis ? acc_mean2D[0] : 0.f;
+    dL_dmeans2D[3 * i + 1] = vis ? acc_mean2D[1] : 0.f;
     dL_dmeans2D[3 * i + 2] = 0.f;
-    dL_dopacities[i] = vis ? g_opacity[GP_ACC_STRIDE * (size_t)i] : 0.f;
-    if (!vis) {
-#pragma unroll
-        for (int k = 0; k < 3; ++k) dL_dmeans3D[3 * i + k] = 0.f;
-        if (dL_dscales) { dL_dscales[3 * i] = dL_dscales[3 * i + 1] = dL_dscales[3 * i + 2] = 0.f; }
-        if (dL_drots) { dL_drots[4 * i] = dL_drots[4 * i + 1] = dL_drots[4 * i + 2] = dL_drots[4 * i + 3] = 0.f; }
-        if (dL_dcov3D) for (int k = 0; k < 6; ++k) dL_dcov3D[6 * i + k] = 0.f;
-        if (dL_dcolors) { dL_dcolors[3 * i] = dL_dcolors[3 * i + 1] = dL_dcolors[3 * i + 2] = 0.f; }
-        if (SH_MODE == 0 && dL_dshs) for (int k = 0; k < d.M * 3; ++k) dL_dshs[(size_t)i * d.M * 3 + k] = 0.f;
-        zero_row();
-        break;
-    }
-    const float px = means3D[3 * i], py = means3D[3 * i + 1], pz = means3D[3 * i + 2];
+    dL_dopacities[i] = vis ? acc_opacity : 0.f;
+    // A culled Gaussian (radii = 0: 0.4 % of the bench scene) runs the same arithmetic on whatever its position gives -- its
+    // accumulator line is zero, so every colour / SH term is an exact zero -- and `vis` SELECTS zeros where a division by a
+    // non-positive depth could have produced NaN.  (As an early-out branch it let the compiler sink the loads of scales, rotations
+    // and the clamp flags behind it: a second and third dependent round trip for every wave.)
     const float3 pv = xform4x3(view, px, py, pz);
     float c6[6];
     if (cov3D_precomp) {
 #pragma unroll
         for (int k = 0; k < 6; ++k) c6[k] = cov3D_precomp[6 * i + k];
     } else {
-        compute_cov3D(scales + 3 * i, d.scale_mod, rotations + 4 * i, c6);
+        compute_cov3D(sc3, d.scale_mod, q4, c6);
     }
     float abc[3];
     ProjCtx cx;
     compute_cov2D(pv, d.fx, d.fy, d.tanfovx, d.tanfovy, c6, view, abc, &cx);
     const float a = abc[0] + 0.3f, b = abc[1], c = abc[2] + 0.3f;
     const float det = a * c - b * b;
-    const float gA = g_conic[GP_ACC_STRIDE * (size_t)i], gB = g_conic[GP_ACC_STRIDE * (size_t)i + 1], gC = g_conic[GP_ACC_STRIDE * (size_t)i + 2];
+    const float gA = acc_conic[0], gB = acc_conic[1], gC = acc_conic[2];
     float gm0 = 0.f, gm1 = 0.f, gm2 = 0.f;
     float g6[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     const float W0[3] = {view[0], view[4], view[8]};
@@ -1635,26 +1666,25 @@ __device__ __forceinline__ void preprocess_bwd_body(
         gm2 += W0[2] * dtx + W1[2] * dty + W2[2] * dtz;
     }
     {   // depth
-        const float gd = g_depth[GP_ACC_STRIDE * (size_t)i];
+        const float gd = acc_depth;
         gm0 += view[2] * gd; gm1 += view[6] * gd; gm2 += view[10] * gd;
     }
     {   // mean2D (NDC) -> mean3D
         const float4 ph = xform4x4(proj, px, py, pz);
         const float mw = 1.f / (ph.w + 0.0000001f);
         const float mul1 = ph.x * mw * mw, mul2 = ph.y * mw * mw;
-        const float g2x = g_mean2D[GP_ACC_STRIDE * (size_t)i], g2y = g_mean2D[GP_ACC_STRIDE * (size_t)i + 1];
+        const float g2x = acc_mean2D[0], g2y = acc_mean2D[1];
         gm0 += (proj[0] * mw - proj[3] * mul1) * g2x + (proj[1] * mw - proj[3] * mul2) * g2y;
         gm1 += (proj[4] * mw - proj[7] * mul1) * g2x + (proj[5] * mw - proj[7] * mul2) * g2y;
         gm2 += (proj[8] * mw - proj[11] * mul1) * g2x + (proj[9] * mw - proj[11] * mul2) * g2y;
     }
     if (dL_dcolors) {
-        dL_dcolors[3 * i] = g_color[GP_ACC_STRIDE * (size_t)i]; dL_dcolors[3 * i + 1] = g_color[GP_ACC_STRIDE * (size_t)i + 1]; dL_dcolors[3 * i + 2] = g_color[GP_ACC_STRIDE * (size_t)i + 2];
+        dL_dcolors[3 * i] = acc_color[0]; dL_dcolors[3 * i + 1] = acc_color[1]; dL_dcolors[3 * i + 2] = acc_color[2];
     } else {
         const float ddx0 = px - campos[0], ddy0 = py - campos[1], ddz0 = pz - campos[2];
         const float len = sqrtf(fmaf(ddx0, ddx0, fmaf(ddy0, ddy0, ddz0 * ddz0)));
         const float inv = 1.f / len;
         const float x = ddx0 * inv, y = ddy0 * inv, z = ddz0 * inv;
-        const uint8_t cl = clamped[i];
         float ddir0 = 0.f, ddir1 = 0.f, ddir2 = 0.f;
         const int D = d.D;
         const int used = (D + 1) * (D + 1);
@@ -1663,7 +1693,7 @@ __device__ __forceinline__ void preprocess_bwd_body(
         float* row = s_sh + tid * SROW - SOFF;                  // SH_MODE 1/2: row[3 k + ch], k >= SOFF / 3
 #pragma unroll
         for (int ch = 0; ch < 3; ++ch) {
-            const float g = ((cl >> ch) & 1) ? 0.f : g_color[GP_ACC_STRIDE * (size_t)i + ch];
+            const float g = ((cl >> ch) & 1) ? 0.f : acc_color[ch];
             // this channel's coefficients first (their slots are about to be overwritten by the gradients)
             float sh[16];
 #pragma unroll
@@ -1716,12 +1746,12 @@ __device__ __forceinline__ void preprocess_bwd_body(
             }
             if (SH_MODE == 0) {
 #pragma unroll
-                for (int k = 0; k < 16; ++k) if (k < d.M) dsh_g[3 * k + ch] = dsh[k];
+                for (int k = 0; k < 16; ++k) if (k < d.M) dsh_g[3 * k + ch] = vis ? dsh[k] : 0.f;
                 for (int k = 16; k < d.M; ++k) dsh_g[3 * k + ch] = 0.f;
             } else {
-                if (SH_MODE == 2) dsh_dc[ch] = dsh[0]; else row[ch] = dsh[0];
+                if (SH_MODE == 2) dsh_dc[ch] = vis ? dsh[0] : 0.f; else row[ch] = vis ? dsh[0] : 0.f;
 #pragma unroll
-                for (int k = 1; k < 16; ++k) row[3 * k + ch] = dsh[k];
+                for (int k = 1; k < 16; ++k) row[3 * k + ch] = vis ? dsh[k] : 0.f;
             }
         }
         const float dot = x * ddir0 + y * ddir1 + z * ddir2;
@@ -1729,16 +1759,16 @@ __device__ __forceinline__ void preprocess_bwd_body(
         gm1 += (ddir1 - y * dot) * inv;
         gm2 += (ddir2 - z * dot) * inv;
     }
-    dL_dmeans3D[3 * i] = gm0; dL_dmeans3D[3 * i + 1] = gm1; dL_dmeans3D[3 * i + 2] = gm2;
+    dL_dmeans3D[3 * i] = vis ? gm0 : 0.f; dL_dmeans3D[3 * i + 1] = vis ? gm1 : 0.f; dL_dmeans3D[3 * i + 2] = vis ? gm2 : 0.f;
     if (cov3D_precomp) {
 #pragma unroll
-        for (int k = 0; k < 6; ++k) dL_dcov3D[6 * i + k] = g6[k];
+        for (int k = 0; k < 6; ++k) dL_dcov3D[6 * i + k] = vis ? g6[k] : 0.f;
     } else {
         const float Gs[9] = {g6[0], 0.5f * g6[1], 0.5f * g6[2], 0.5f * g6[1], g6[3], 0.5f * g6[4], 0.5f * g6[2], 0.5f * g6[4], g6[5]};
-        const float* q = rotations + 4 * i;
+        const float* q = q4;
         float Rm[9];
         quat_to_R(q[0], q[1], q[2], q[3], Rm);
-        const float s[3] = {d.scale_mod * scales[3 * i], d.scale_mod * scales[3 * i + 1], d.scale_mod * scales[3 * i + 2]};
+        const float s[3] = {d.scale_mod * sc3[0], d.scale_mod * sc3[1], d.scale_mod * sc3[2]};
         float L[9], dLm[9], dR[9];
 #pragma unroll
         for (int r = 0; r < 3; ++r)
@@ -1754,13 +1784,13 @@ __device__ __forceinline__ void preprocess_bwd_body(
             float acc = 0.f;
 #pragma unroll
             for (int r = 0; r < 3; ++r) { acc += dLm[3 * r + k] * Rm[3 * r + k]; dR[3 * r + k] = dLm[3 * r + k] * s[k]; }
-            dL_dscales[3 * i + k] = acc * d.scale_mod;
+            dL_dscales[3 * i + k] = vis ? acc * d.scale_mod : 0.f;
         }
         const float r = q[0], x = q[1], y = q[2], z = q[3];
-        dL_drots[4 * i + 0] = 2.f * (-z * dR[1] + y * dR[2] + z * dR[3] - x * dR[5] - y * dR[6] + x * dR[7]);
-        dL_drots[4 * i + 1] = 2.f * (y * dR[1] + z * dR[2] + y * dR[3] - 2.f * x * dR[4] - r * dR[5] + z * dR[6] + r * dR[7] - 2.f * x * dR[8]);
-        dL_drots[4 * i + 2] = 2.f * (-2.f * y * dR[0] + x * dR[1] + r * dR[2] + x * dR[3] + z * dR[5] - r * dR[6] + z * dR[7] - 2.f * y * dR[8]);
-        dL_drots[4 * i + 3] = 2.f * (-2.f * z * dR[0] - r * dR[1] + x * dR[2] + r * dR[3] - 2.f * z * dR[4] + y * dR[5] + x * dR[6] + y * dR[7]);
+        dL_drots[4 * i + 0] = vis ? 2.f * (-z * dR[1] + y * dR[2] + z * dR[3] - x * dR[5] - y * dR[6] + x * dR[7]) : 0.f;
+        dL_drots[4 * i + 1] = vis ? 2.f * (y * dR[1] + z * dR[2] + y * dR[3] - 2.f * x * dR[4] - r * dR[5] + z * dR[6] + r * dR[7] - 2.f * x * dR[8]) : 0.f;
+        dL_drots[4 * i + 2] = vis ? 2.f * (-2.f * y * dR[0] + x * dR[1] + r * dR[2] + x * dR[3] + z * dR[5] - r * dR[6] + z * dR[7] - 2.f * y * dR[8]) : 0.f;
+        dL_drots[4 * i + 3] = vis ? 2.f * (-2.f * z * dR[0] - r * dR[1] + x * dR[2] + r * dR[3] - 2.f * z * dR[4] + y * dR[5] + x * dR[6] + y * dR[7]) : 0.f;
     }
     } while (0);
     if (SH_MODE != 0 && use_sh) {
@@ -1771,11 +1801,14 @@ __device__ __forceinline__ void preprocess_bwd_body(
         } else if (af.on) {
             // the optimizer step of the SH coefficients, here: no gradient leaves the kernel (skip: an invalid frame, nothing is touched)
             if (!(af.skip && *af.skip != 0)) {
-                if (i < d.N) {
+                if (i < d.N) {      // (all nine values first: through the references the three updates were nine dependent round trips)
+                    float pp[3], mm[3], vq[3];
 #pragma unroll
-                    for (int k = 0; k < 3; ++k)
-                        gp_adam_update(af.p_dc[3 * (size_t)i + k], dsh_dc[k], af.m_dc[3 * (size_t)i + k], af.v_dc[3 * (size_t)i + k], af.b1, af.b2,
-                                       af.eps, af.step_dc, af.bc2_sqrt);
+                    for (int k = 0; k < 3; ++k) { pp[k] = af.p_dc[3 * (size_t)i + k]; mm[k] = af.m_dc[3 * (size_t)i + k]; vq[k] = af.v_dc[3 * (size_t)i + k]; }
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) gp_adam_update(pp[k], dsh_dc[k], mm[k], vq[k], af.b1, af.b2, af.eps, af.step_dc, af.bc2_sqrt);
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) { af.p_dc[3 * (size_t)i + k] = pp[k]; af.m_dc[3 * (size_t)i + k] = mm[k]; af.v_dc[3 * (size_t)i + k] = vq[k]; }
                 }
                 adam_unstage_sh<45>(s_sh, af, (size_t)base * 45, nblk, tid);
             }

@@ -103,11 +103,15 @@ __global__ __launch_bounds__(RS_BLOCK) void gp_radix_hist_kernel(const uint32_t*
     s_hist[tid] = 0;
     __syncthreads();
     const size_t base = (size_t)blockIdx.x * RS_TILE;
+    uint32_t k[RS_ITEMS];
 #pragma unroll
-    for (int it = 0; it < RS_ITEMS; ++it) {
-        size_t idx = base + (size_t)it * RS_BLOCK + tid;
-        if (idx < n) atomicAdd(&s_hist[(keys[idx] >> shift) & mask], 1u);
+    for (int it = 0; it < RS_ITEMS; ++it) {        // every load in flight before the first use (as `if (idx < n) atomicAdd(.. keys[idx] ..)`
+        const size_t idx = base + (size_t)it * RS_BLOCK + tid;                     // each load was waited for on its own)
+        k[it] = keys[idx < n ? idx : n - 1];
     }
+#pragma unroll
+    for (int it = 0; it < RS_ITEMS; ++it)
+        if (base + (size_t)it * RS_BLOCK + tid < n) atomicAdd(&s_hist[(k[it] >> shift) & mask], 1u);
     __syncthreads();
     hist[(size_t)tid * nblocks + blockIdx.x] = s_hist[tid];
 }
