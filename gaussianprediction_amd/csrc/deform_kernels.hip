@@ -710,6 +710,8 @@ __device__ __forceinline__ void blend_fwd_body(BlendDev a, float* __restrict__ x
     float dxyz[3] = {0.f, 0.f, 0.f}, dq[4] = {0.f, 0.f, 0.f, 0.f};
     const int od = a.out_dim;
     const int nn = NN > 0 ? NN : a.nn;
+    const float x0[3] = {a.xyz[3 * i], a.xyz[3 * i + 1], a.xyz[3 * i + 2]};          // (issued with the row loads, used at the end)
+    const float r[4] = {a.rot[4 * i], a.rot[4 * i + 1], a.rot[4 * i + 2], a.rot[4 * i + 3]};
     if (nn > 0) {
         float wx[NN > 0 ? NN : GP_MAX_NN], wr[NN > 0 ? NN : GP_MAX_NN];
         int kpv[NN > 0 ? NN : 1];
@@ -722,17 +724,38 @@ __device__ __forceinline__ void blend_fwd_body(BlendDev a, float* __restrict__ x
             softmax_n(a.raw_w + i * 2 * nn, nn, wx);
             softmax_n(a.raw_w + i * 2 * nn + nn, nn, wr);
         }
+        if constexpr (NN > 0) {
+            // the NN keypoint rows gathered first, all in flight (inside the blend loop every gather was waited for on its own:
+            // NN dependent trips to L2 per wave), then the blend in the same order
+            float dlr[NN > 0 ? NN : 1][7];
 #pragma unroll
-        for (int k = 0; k < nn; ++k) {
-            const long kp = NN > 0 ? (long)kpv[NN > 0 ? k : 0] : a.knn[i * nn + k];
-            const float* dl = a.delta + kp * od;
-            dxyz[0] = fmaf(wx[k], dl[0], dxyz[0]);
-            dxyz[1] = fmaf(wx[k], dl[1], dxyz[1]);
-            dxyz[2] = fmaf(wx[k], dl[2], dxyz[2]);
-            float v[4] = {dl[3], dl[4], dl[5], dl[6]};
-            if (a.norm_rotation) { const float inv = 1.f / norm4(v); v[0] *= inv; v[1] *= inv; v[2] *= inv; v[3] *= inv; }
-            dq[0] = fmaf(wr[k], v[0], dq[0]); dq[1] = fmaf(wr[k], v[1], dq[1]);
-            dq[2] = fmaf(wr[k], v[2], dq[2]); dq[3] = fmaf(wr[k], v[3], dq[3]);
+            for (int k = 0; k < NN; ++k) {
+                const float* dl = a.delta + (long)kpv[k] * od;
+#pragma unroll
+                for (int c = 0; c < 7; ++c) dlr[k][c] = dl[c];
+            }
+#pragma unroll
+            for (int k = 0; k < NN; ++k) {
+                dxyz[0] = fmaf(wx[k], dlr[k][0], dxyz[0]);
+                dxyz[1] = fmaf(wx[k], dlr[k][1], dxyz[1]);
+                dxyz[2] = fmaf(wx[k], dlr[k][2], dxyz[2]);
+                float v[4] = {dlr[k][3], dlr[k][4], dlr[k][5], dlr[k][6]};
+                if (a.norm_rotation) { const float inv = 1.f / norm4(v); v[0] *= inv; v[1] *= inv; v[2] *= inv; v[3] *= inv; }
+                dq[0] = fmaf(wr[k], v[0], dq[0]); dq[1] = fmaf(wr[k], v[1], dq[1]);
+                dq[2] = fmaf(wr[k], v[2], dq[2]); dq[3] = fmaf(wr[k], v[3], dq[3]);
+            }
+        } else {
+            for (int k = 0; k < nn; ++k) {
+                const long kp = a.knn[i * nn + k];
+                const float* dl = a.delta + kp * od;
+                dxyz[0] = fmaf(wx[k], dl[0], dxyz[0]);
+                dxyz[1] = fmaf(wx[k], dl[1], dxyz[1]);
+                dxyz[2] = fmaf(wx[k], dl[2], dxyz[2]);
+                float v[4] = {dl[3], dl[4], dl[5], dl[6]};
+                if (a.norm_rotation) { const float inv = 1.f / norm4(v); v[0] *= inv; v[1] *= inv; v[2] *= inv; v[3] *= inv; }
+                dq[0] = fmaf(wr[k], v[0], dq[0]); dq[1] = fmaf(wr[k], v[1], dq[1]);
+                dq[2] = fmaf(wr[k], v[2], dq[2]); dq[3] = fmaf(wr[k], v[3], dq[3]);
+            }
         }
     } else {
         const float* dl = a.delta + i * od;
@@ -740,12 +763,11 @@ __device__ __forceinline__ void blend_fwd_body(BlendDev a, float* __restrict__ x
         dq[0] = dl[3]; dq[1] = dl[4]; dq[2] = dl[5]; dq[3] = dl[6];
         if (a.norm_rotation) { const float inv = 1.f / norm4(dq); dq[0] *= inv; dq[1] *= inv; dq[2] *= inv; dq[3] *= inv; }
     }
-    xyz_t[3 * i] = a.xyz[3 * i] + dxyz[0];
-    xyz_t[3 * i + 1] = a.xyz[3 * i + 1] + dxyz[1];
-    xyz_t[3 * i + 2] = a.xyz[3 * i + 2] + dxyz[2];
+    xyz_t[3 * i] = x0[0] + dxyz[0];
+    xyz_t[3 * i + 1] = x0[1] + dxyz[1];
+    xyz_t[3 * i + 2] = x0[2] + dxyz[2];
     const float invq = 1.f / norm4(dq);
     const float q[4] = {dq[0] * invq, dq[1] * invq, dq[2] * invq, dq[3] * invq};
-    const float r[4] = {a.rot[4 * i], a.rot[4 * i + 1], a.rot[4 * i + 2], a.rot[4 * i + 3]};
     float pq[4];
     quat_mul(q, r, pq);
     const float invp = 1.f / norm4(pq);
@@ -810,7 +832,9 @@ __device__ __forceinline__ void blend_bwd_body(BlendDev a, const float* __restri
         if (live) {
             const float gx[3] = {g_xyz_t[3 * i], g_xyz_t[3 * i + 1], g_xyz_t[3 * i + 2]};
             const float gq[4] = {g_q_t[4 * i], g_q_t[4 * i + 1], g_q_t[4 * i + 2], g_q_t[4 * i + 3]};
-            g_xyz[3 * i] = gx[0]; g_xyz[3 * i + 1] = gx[1]; g_xyz[3 * i + 2] = gx[2];
+            const float r[4] = {a.rot[4 * i], a.rot[4 * i + 1], a.rot[4 * i + 2], a.rot[4 * i + 3]};
+            // (every global load of the chunk is issued before the first global store: a store through g_xyz may alias the
+            // rows read through `a` as far as the compiler knows, and used to split the loads into two dependent round trips)
             // recompute forward
             float wx[NN > 0 ? NN : GP_MAX_NN], wr[NN > 0 ? NN : GP_MAX_NN];
             float dq[4] = {0.f, 0.f, 0.f, 0.f};
@@ -840,7 +864,7 @@ __device__ __forceinline__ void blend_bwd_body(BlendDev a, const float* __restri
             }
             const float invq = 1.f / norm4(dq);
             const float q[4] = {dq[0] * invq, dq[1] * invq, dq[2] * invq, dq[3] * invq};
-            const float r[4] = {a.rot[4 * i], a.rot[4 * i + 1], a.rot[4 * i + 2], a.rot[4 * i + 3]};
+            g_xyz[3 * i] = gx[0]; g_xyz[3 * i + 1] = gx[1]; g_xyz[3 * i + 2] = gx[2];
             float pq[4];
             quat_mul(q, r, pq);
             float gp[4];

@@ -288,13 +288,24 @@ __device__ __forceinline__ void preprocess_fwd_body(RasterDims d, const float* _
     if (SH_MODE == 2 && use_sh && d.D > 0) stage_sh<45>(s_sh, shs_rest + (size_t)base * 45, nblk, tid);
     if (SH_MODE != 0) __syncthreads();
     if (i >= d.N) return;
+    // the thread's own inputs, issued together and pinned in front of the culling branches (placed where they are used, the
+    // compiler sinks them behind each early return: position -> wait -> rotation, scale -> wait -> opacity -> wait)
+    const float px = means3D[3 * i], py = means3D[3 * i + 1], pz = means3D[3 * i + 2];
+    float sc3[3] = {0.f, 0.f, 0.f}, q4[4] = {0.f, 0.f, 0.f, 0.f};
+    if (!cov3D_precomp) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) sc3[k] = scales[3 * i + k];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) q4[k] = rotations[4 * i + k];
+    }
+    const float opac = opacities[i];
+    asm volatile("" ::"v"(px), "v"(py), "v"(pz), "v"(sc3[0]), "v"(sc3[1]), "v"(sc3[2]), "v"(q4[0]), "v"(q4[1]), "v"(q4[2]), "v"(q4[3]), "v"(opac));
     if (i < d.n_zero) d.zero_words[i] = 0u;              // (only handed over when N >= n_zero)
     radii[i] = 0;
     if (d.visible) d.visible[i] = 0;
     tiles_touched[i] = make_uint2(0u, 0u);
     depth_key[i] = 0xFFFFFFFFu;
     clamped[i] = 0;
-    const float px = means3D[3 * i], py = means3D[3 * i + 1], pz = means3D[3 * i + 2];
     const float3 pv = xform4x3(view, px, py, pz);
     if (!(pv.z > 0.2f)) return;
     const float4 ph = xform4x4(proj, px, py, pz);
@@ -305,7 +316,7 @@ __device__ __forceinline__ void preprocess_fwd_body(RasterDims d, const float* _
 #pragma unroll
         for (int k = 0; k < 6; ++k) c6[k] = cov3D_precomp[6 * i + k];
     } else {
-        compute_cov3D(scales + 3 * i, d.scale_mod, rotations + 4 * i, c6);
+        compute_cov3D(sc3, d.scale_mod, q4, c6);
     }
     float abc[3];
     compute_cov2D(pv, d.fx, d.fy, d.tanfovx, d.tanfovy, c6, view, abc, nullptr);
@@ -338,7 +349,7 @@ __device__ __forceinline__ void preprocess_fwd_body(RasterDims d, const float* _
     // tile rectangle (first tile | extent, 16 bits each): the binning stage expands it without touching `rec` again
     tiles_touched[i] = make_uint2((uint32_t)minx | ((uint32_t)miny << 16), (uint32_t)(maxx - minx) | ((uint32_t)(maxy - miny) << 16));
     rec[3 * (size_t)i + 0] = make_float4(pix, piy, -0.5f * conx, -cony);
-    rec[3 * (size_t)i + 1] = make_float4(-0.5f * conz, opacities[i], pv.z, __int_as_float(i));
+    rec[3 * (size_t)i + 1] = make_float4(-0.5f * conz, opac, pv.z, __int_as_float(i));
     rec[3 * (size_t)i + 2] = make_float4(col[0], col[1], col[2], 0.f);
 }
 
