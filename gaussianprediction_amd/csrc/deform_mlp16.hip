@@ -610,17 +610,29 @@ __device__ __forceinline__ void mlp16_bwd_data_body(Mlp16Dev p, const uint32_t* 
             for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) { acc[rt][nt][r] = 0.f; if (SP) ax[rt][nt][r] = 0.f; }
+        // the ReLU sign words of this layer's epilogue, requested BEFORE the product (loaded where they are used, each of the
+        // RT x 2 words was a dependent round trip to memory behind the matrix work: 16 per 64-row block and backward)
+        const uint32_t* mk = masks + (size_t)(l - 1) * p.rows * 8;
+        constexpr bool PRE = RT == 2;          // (the 128-row variants have no registers to spare: they load in the epilogue)
+        uint32_t mreg[RT][2];
+        if (PRE) {
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+                const long grow = row0 + rt * 32 + j;
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) mreg[rt][nt] = mk[(grow < p.rows ? grow : p.rows - 1) * 8 + (2 * wave + nt)];
+            }
+        }
         if constexpr (SP) gemm16s<true, RT>(cur, (const _Float16*)p.w[l], (const _Float16*)p.wlo[l], K, K, M16_W, wave, lane, acc, ax);
         else gemm16<T, true, RT>(cur, (const T*)p.w[l], K, K, M16_W, wave, lane, acc);
         if (INPLACE) __syncthreads();
-        const uint32_t* mk = masks + (size_t)(l - 1) * p.rows * 8;
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
             const int row = rt * 32 + j;
             const long grow = row0 + row;
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) {
-                const uint32_t m = grow < p.rows ? mk[grow * 8 + (2 * wave + nt)] : 0u;
+                const uint32_t m = grow < p.rows ? (PRE ? mreg[rt][nt] : mk[grow * 8 + (2 * wave + nt)]) : 0u;
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const int f0 = (2 * wave + nt) * 32 + 8 * g + 4 * half;
@@ -1013,8 +1025,12 @@ __global__ __launch_bounds__(256) void gp_mlp16_pack_dout_kernel(const float* __
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= ((rows + 63) & ~63L)) return;                      // the padding rows (to 64) are written as zeros
     const float scale = UsesScale<T>::v ? grad_scale_from(absmax_bits) : 1.f;
+    float v[16];
+    const long ii = i < rows ? i : rows - 1;                    // (the row's values first, all in flight: clamped addresses)
 #pragma unroll
-    for (int f = 0; f < 16; ++f) dst[t16_idx(f, i, 16)] = (T)((f < out_dim && i < rows) ? dL_dout[i * out_dim + f] * scale : 0.f);
+    for (int f = 0; f < 16; ++f) v[f] = dL_dout[ii * out_dim + (f < out_dim ? f : out_dim - 1)];
+#pragma unroll
+    for (int f = 0; f < 16; ++f) dst[t16_idx(f, i, 16)] = (T)((f < out_dim && i < rows) ? v[f] * scale : 0.f);
 }
 
 // split mode: [16 hi | 16 lo'] "features"
@@ -1023,9 +1039,13 @@ __global__ __launch_bounds__(256) void gp_mlp16_pack_dout_split_kernel(const flo
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= ((rows + 63) & ~63L)) return;
     const float scale = grad_scale_from(absmax_bits);
+    float v[16];
+    const long ii = i < rows ? i : rows - 1;
+#pragma unroll
+    for (int f = 0; f < 16; ++f) v[f] = dL_dout[ii * out_dim + (f < out_dim ? f : out_dim - 1)];
 #pragma unroll
     for (int f = 0; f < 16; ++f)
-        split1((f < out_dim && i < rows) ? dL_dout[i * out_dim + f] * scale : 0.f, dst[t16_idx(f, i, 32)], dst[t16_idx(16 + f, i, 32)]);
+        split1((f < out_dim && i < rows) ? v[f] * scale : 0.f, dst[t16_idx(f, i, 32)], dst[t16_idx(16 + f, i, 32)]);
 }
 
 // ------------------------------------------------------------------------------------------------
