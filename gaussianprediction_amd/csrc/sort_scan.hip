@@ -168,12 +168,22 @@ __global__ __launch_bounds__(RS_BLOCK) void gp_radix_scatter_kernel(const uint32
     __syncthreads();
     const size_t base = (size_t)blockIdx.x * RS_TILE + (size_t)wave * (GP_WAVE * RS_ITEMS);
     uint32_t k[RS_ITEMS], v[RS_ITEMS], r[RS_ITEMS];
+    // every global load of the block up front (clamped addresses): inside the ranking loop each pair was waited for before its
+    // eight ballots -- RS_ITEMS dependent round trips per block, plus one each for the two scan inputs below
+#pragma unroll
+    for (int it = 0; it < RS_ITEMS; ++it) {
+        const size_t idx = base + (size_t)it * GP_WAVE + lane;
+        const size_t ic = idx < n ? idx : n - 1;
+        k[it] = keys_in[ic];
+        v[it] = vals_in ? vals_in[ic] : (uint32_t)idx;                       // vals_in == NULL: the values are the indices (first pass)
+    }
+    const uint32_t tv_pre = totals[tid];
+    const uint32_t hs_pre = hist_scanned[(size_t)tid * nblocks + blockIdx.x];
 #pragma unroll
     for (int it = 0; it < RS_ITEMS; ++it) {
         const size_t idx = base + (size_t)it * GP_WAVE + lane;
         const bool valid = idx < n;
-        k[it] = valid ? keys_in[idx] : 0xFFFFFFFFu;
-        v[it] = valid ? (vals_in ? vals_in[idx] : (uint32_t)idx) : 0u;      // vals_in == NULL: the values are the indices (first pass)
+        if (!valid) { k[it] = 0xFFFFFFFFu; v[it] = 0u; }
         const uint32_t digit = (k[it] >> shift) & mask;
         // peers = lanes of this wave (valid only) holding the same digit
         unsigned long long peers = __ballot(valid);
@@ -196,7 +206,7 @@ __global__ __launch_bounds__(RS_BLOCK) void gp_radix_scatter_kernel(const uint32
     }
     __syncthreads();
     {   // global base of digit `tid` = exclusive scan of the 256 row totals
-        const uint32_t tv = totals[tid];
+        const uint32_t tv = tv_pre;
         uint32_t x = tv;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
@@ -230,7 +240,7 @@ __global__ __launch_bounds__(RS_BLOCK) void gp_radix_scatter_kernel(const uint32
 #pragma unroll
         for (int w = 0; w < RS_BLOCK / GP_WAVE; ++w) { s_cnt[w][tid] = run; run += c[w]; }
         // element at block-local sorted position p with this digit goes to global  p + s_dbase[digit]
-        s_dbase[tid] = s_dbase[tid] + hist_scanned[(size_t)tid * nblocks + blockIdx.x] - lbase;
+        s_dbase[tid] = s_dbase[tid] + hs_pre - lbase;
     }
     __syncthreads();
     // stage the block's pairs in sorted order in LDS, then write them out: consecutive threads -> consecutive addresses
@@ -248,16 +258,32 @@ __global__ __launch_bounds__(RS_BLOCK) void gp_radix_scatter_kernel(const uint32
     __syncthreads();
     const size_t bbase = (size_t)blockIdx.x * RS_TILE;
     const uint32_t bn = (uint32_t)(n - bbase < RS_TILE ? n - bbase : RS_TILE);
-    for (uint32_t p = tid; p < bn; p += RS_BLOCK) {
-        const uint32_t kk = s_k[p];
-        const uint32_t pos = p + s_dbase[(kk >> shift) & mask];
-        const uint32_t vv = s_v[p];
-        keys_out[pos] = kk;
-        vals_out[pos] = vv;
-        if (ep.by_value) {      // last pass of the depth sort: the per-Gaussian tile rectangle follows its id into sorted order
-            const uint2 r = ep.by_value[vv];
-            ep.sorted_out[pos] = r;
-            ep.count_out[pos] = (r.y & 0xFFFFu) * (r.y >> 16);
+    if (!ep.by_value) {
+        for (uint32_t p = tid; p < bn; p += RS_BLOCK) {
+            const uint32_t kk = s_k[p];
+            const uint32_t pos = p + s_dbase[(kk >> shift) & mask];
+            keys_out[pos] = kk;
+            vals_out[pos] = s_v[p];
+        }
+    } else {                    // last pass of the depth sort: the per-Gaussian tile rectangle follows its id into sorted order
+        uint32_t pos[RS_ITEMS], vv[RS_ITEMS];
+        uint2 rr[RS_ITEMS];
+#pragma unroll
+        for (int it = 0; it < RS_ITEMS; ++it) {                 // (the gathers of all of a thread's elements in flight together)
+            const uint32_t p = tid + it * RS_BLOCK;
+            const bool ok = p < bn;
+            const uint32_t kk = ok ? s_k[p] : 0u;
+            vv[it] = ok ? s_v[p] : 0u;
+            pos[it] = p + s_dbase[(kk >> shift) & mask];
+            if (ok) { keys_out[pos[it]] = kk; vals_out[pos[it]] = vv[it]; }
+            rr[it] = ep.by_value[vv[it]];
+        }
+#pragma unroll
+        for (int it = 0; it < RS_ITEMS; ++it) {
+            if (tid + it * RS_BLOCK < bn) {
+                ep.sorted_out[pos[it]] = rr[it];
+                ep.count_out[pos[it]] = (rr[it].y & 0xFFFFu) * (rr[it].y >> 16);
+            }
         }
     }
 }
