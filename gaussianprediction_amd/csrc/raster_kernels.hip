@@ -284,22 +284,24 @@ __device__ __forceinline__ void preprocess_fwd_body(RasterDims d, const float* _
     const int i = base + tid;
     const int nblk = min(256, d.N - base);
     const bool use_sh = !colors_precomp && !d.late_color;
-    if (SH_MODE == 1 && use_sh && d.D > 0) stage_sh<48>(s_sh, shs + (size_t)base * 48, nblk, tid);
-    if (SH_MODE == 2 && use_sh && d.D > 0) stage_sh<45>(s_sh, shs_rest + (size_t)base * 45, nblk, tid);
-    if (SH_MODE != 0) __syncthreads();
-    if (i >= d.N) return;
-    // the thread's own inputs, issued together and pinned in front of the culling branches (placed where they are used, the
-    // compiler sinks them behind each early return: position -> wait -> rotation, scale -> wait -> opacity -> wait)
-    const float px = means3D[3 * i], py = means3D[3 * i + 1], pz = means3D[3 * i + 2];
+    // the thread's own inputs, issued together IN FRONT of the SH staging (they ride on its first round trip) and pinned behind
+    // it, before the culling branches (placed where they are used, the compiler sinks them behind each early return: position ->
+    // wait -> rotation, scale -> wait -> opacity -> wait)
+    const int ii = i < d.N ? i : d.N - 1;
+    const float px = means3D[3 * ii], py = means3D[3 * ii + 1], pz = means3D[3 * ii + 2];
     float sc3[3] = {0.f, 0.f, 0.f}, q4[4] = {0.f, 0.f, 0.f, 0.f};
     if (!cov3D_precomp) {
 #pragma unroll
-        for (int k = 0; k < 3; ++k) sc3[k] = scales[3 * i + k];
+        for (int k = 0; k < 3; ++k) sc3[k] = scales[3 * ii + k];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) q4[k] = rotations[4 * i + k];
+        for (int k = 0; k < 4; ++k) q4[k] = rotations[4 * ii + k];
     }
-    const float opac = opacities[i];
+    const float opac = opacities[ii];
+    if (SH_MODE == 1 && use_sh && d.D > 0) stage_sh<48>(s_sh, shs + (size_t)base * 48, nblk, tid);
+    if (SH_MODE == 2 && use_sh && d.D > 0) stage_sh<45>(s_sh, shs_rest + (size_t)base * 45, nblk, tid);
+    if (SH_MODE != 0) __syncthreads();
     asm volatile("" ::"v"(px), "v"(py), "v"(pz), "v"(sc3[0]), "v"(sc3[1]), "v"(sc3[2]), "v"(q4[0]), "v"(q4[1]), "v"(q4[2]), "v"(q4[3]), "v"(opac));
+    if (i >= d.N) return;
     if (i < d.n_zero) d.zero_words[i] = 0u;              // (only handed over when N >= n_zero)
     radii[i] = 0;
     if (d.visible) d.visible[i] = 0;
@@ -1585,14 +1587,7 @@ __device__ __forceinline__ void preprocess_bwd_body(
     constexpr int SROW = SH_MODE == 1 ? 49 : 45;        // LDS row stride (odd: conflict-free)
     constexpr int SOFF = SH_MODE == 1 ? 0 : 3;          // first coefficient float held in the row
     float dsh_dc[3] = {0.f, 0.f, 0.f};                  // SH_MODE 2: gradient of the dc coefficient (separate tensor)
-    if (SH_MODE != 0) {
-        if (use_sh && d.D > 0) {
-            if (SH_MODE == 1) stage_sh<48>(s_sh, shs + (size_t)base * 48, nblk, tid);
-            if (SH_MODE == 2) stage_sh<45>(s_sh, shs_rest + (size_t)base * 45, nblk, tid);
-        }
-        __syncthreads();
-    }
-    // Everything the thread reads from global memory, issued TOGETHER up front (clamped index, unconditional): as loads placed
+    // Everything the thread reads from global memory, issued TOGETHER up front, in front of the SH staging (they ride on its first round trip) (clamped index, unconditional): as loads placed
     // where the values are used -- behind the visibility branch, inside the covariance / colour / rotation sections -- they were
     // some ten dependent round trips to memory per wave.  The five accumulator pointers are offsets into ONE 64-byte line per
     // Gaussian (gp_capi_raster.hip: mean2D 0..1 | conic 2..4 | opacity 5 | colour 6..8 | depth 9): three 16-byte loads.
@@ -1611,6 +1606,13 @@ __device__ __forceinline__ void preprocess_bwd_body(
     const uint8_t cl = dL_dcolors ? (uint8_t)0 : clamped[ii];
     const float acc_mean2D[2] = {A0.x, A0.y}, acc_conic[3] = {A0.z, A0.w, A1.x}, acc_opacity = A1.y,
                 acc_color[3] = {A1.z, A1.w, A2.x}, acc_depth = A2.y;
+    if (SH_MODE != 0) {
+        if (use_sh && d.D > 0) {
+            if (SH_MODE == 1) stage_sh<48>(s_sh, shs + (size_t)base * 48, nblk, tid);
+            if (SH_MODE == 2) stage_sh<45>(s_sh, shs_rest + (size_t)base * 45, nblk, tid);
+        }
+        __syncthreads();
+    }
     do {
     if (i >= d.N) break;
     const bool vis = rad_i > 0;
