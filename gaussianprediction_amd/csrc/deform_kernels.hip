@@ -1065,11 +1065,14 @@ __global__ __launch_bounds__(256) void gp_act_fwd_kernel(long n, const float* __
                                                         float* __restrict__ scale, float* __restrict__ opacity) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    scale[3 * i] = expf(scaling_raw[3 * i]);
-    scale[3 * i + 1] = expf(scaling_raw[3 * i + 1]);
-    scale[3 * i + 2] = expf(scaling_raw[3 * i + 2]);
-    float o = sigmoidf(opacity_raw[i]);
-    if (delta_o) o *= 1.f / (1.f + expf(-delta_o[i * stride] / beta));  // sharp_sigmoid [REF gaussian_model.py:51]
+    const float s0 = scaling_raw[3 * i], s1 = scaling_raw[3 * i + 1], s2 = scaling_raw[3 * i + 2];   // (all loads first)
+    const float op_raw = opacity_raw[i];
+    const float dlt = delta_o ? delta_o[i * stride] : 0.f;
+    scale[3 * i] = expf(s0);
+    scale[3 * i + 1] = expf(s1);
+    scale[3 * i + 2] = expf(s2);
+    float o = sigmoidf(op_raw);
+    if (delta_o) o *= 1.f / (1.f + expf(-dlt / beta));  // sharp_sigmoid [REF gaussian_model.py:51]
     opacity[i] = o;
 }
 __global__ __launch_bounds__(256) void gp_act_bwd_kernel(long n, const float* __restrict__ scaling_raw,
@@ -1080,15 +1083,22 @@ __global__ __launch_bounds__(256) void gp_act_bwd_kernel(long n, const float* __
                                                         float* __restrict__ g_delta_o) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    if (g_scaling_raw) {
-        g_scaling_raw[3 * i] = g_scale ? g_scale[3 * i] * expf(scaling_raw[3 * i]) : 0.f;
-        g_scaling_raw[3 * i + 1] = g_scale ? g_scale[3 * i + 1] * expf(scaling_raw[3 * i + 1]) : 0.f;
-        g_scaling_raw[3 * i + 2] = g_scale ? g_scale[3 * i + 2] * expf(scaling_raw[3 * i + 2]) : 0.f;
+    // every load first (interleaved with the stores they were three dependent round trips: load -> store -> load ...)
+    float gs[3] = {0.f, 0.f, 0.f}, sr[3] = {0.f, 0.f, 0.f};
+    if (g_scaling_raw && g_scale) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { gs[k] = g_scale[3 * i + k]; sr[k] = scaling_raw[3 * i + k]; }
     }
-    const float so = sigmoidf(opacity_raw[i]);
+    const float op_raw = opacity_raw[i];
     const float go = g_opacity ? g_opacity[i] : 0.f;
+    const float dlt = delta_o ? delta_o[i * stride] : 0.f;
+    if (g_scaling_raw) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) g_scaling_raw[3 * i + k] = g_scale ? gs[k] * expf(sr[k]) : 0.f;
+    }
+    const float so = sigmoidf(op_raw);
     float life = 1.f;
-    if (delta_o) life = 1.f / (1.f + expf(-delta_o[i * stride] / beta));
+    if (delta_o) life = 1.f / (1.f + expf(-dlt / beta));
     if (g_opacity_raw) g_opacity_raw[i] = go * life * so * (1.f - so);
     if (delta_o && g_delta_o) g_delta_o[i * stride] = go * so * life * (1.f - life) / beta;
 }
