@@ -127,9 +127,30 @@ __global__ __launch_bounds__(256) void gp_radix_rowscan_kernel(uint32_t* __restr
     uint32_t* row = hist + (size_t)blockIdx.x * nblocks;
     if (tid == 0) s_carry = 0;
     __syncthreads();
-    for (uint32_t b0 = 0; b0 < nblocks; b0 += 256) {
+    // up to RSC chunks of 256 counters are fetched up front (one round trip instead of one per chunk: the tile sort's rows are
+    // 2 016 counters long, eight dependent loads before); longer rows fall through to the chunk-at-a-time loop
+    constexpr int RSC = 16;
+    uint32_t pre[RSC];
+    const bool batched = nblocks <= 256u * RSC;
+    if (batched) {
+#pragma unroll
+        for (int c = 0; c < RSC; ++c) {
+            const uint32_t b = 256u * c + tid;
+            pre[c] = (256u * c < nblocks) ? row[b < nblocks ? b : nblocks - 1] : 0u;
+        }
+    }
+    int c = 0;
+    for (uint32_t b0 = 0; b0 < nblocks; b0 += 256, ++c) {
         const uint32_t b = b0 + tid;
-        const uint32_t v = b < nblocks ? row[b] : 0u;
+        uint32_t v;
+        if (batched) {
+            v = 0u;
+#pragma unroll
+            for (int k = 0; k < RSC; ++k) v = (k == c) ? pre[k] : v;       // (register select: no dynamic indexing)
+            v = b < nblocks ? v : 0u;
+        } else {
+            v = b < nblocks ? row[b] : 0u;
+        }
         uint32_t x = v;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
