@@ -317,12 +317,15 @@ int gp_radix_sort_pairs(GpSortBufs& b, size_t n, int nbits, hipStream_t s, bool 
     const size_t tile = (size_t)items * RS_BLOCK;
     const uint32_t nblocks = (uint32_t)((n + tile - 1) / tile);
     int cur = 0;
-    for (int shift = 0; shift < nbits; shift += 8) {
-        const int bits = (nbits - shift) < 8 ? (nbits - shift) : 8;
+    // the passes share the key bits evenly (13-bit tile ids: 7 + 6 rather than 8 + 5 -- the first pass's scatter then writes runs of
+    // 16 keys = 64 bytes per digit and block instead of 8; 32-bit depth keys: 8 + 8 + 8 + 8 as before)
+    const int npass = (nbits + 7) / 8, per = (nbits + npass - 1) / npass;
+    for (int shift = 0; shift < nbits; shift += per) {
+        const int bits = (nbits - shift) < per ? (nbits - shift) : per;
         const uint32_t mask = (1u << bits) - 1u;
         const uint32_t* vin = (shift == 0 && iota_vals) ? nullptr : b.v[cur];
         GpSortEpilogue ep = {nullptr, nullptr, nullptr};
-        if (epilogue && shift + 8 >= nbits) ep = *epilogue;      // (last pass)
+        if (epilogue && shift + per >= nbits) ep = *epilogue;      // (last pass)
         if (items == RS_ITEMS_SMALL)
             hipLaunchKernelGGL((gp_radix_hist_kernel<RS_ITEMS_SMALL>), dim3(nblocks), dim3(RS_BLOCK), 0, s, b.k[cur], n, shift, mask,
                                b.hist, nblocks);
