@@ -793,7 +793,7 @@ __device__ __forceinline__ void normalize_bwd(const float* v, const float* g, fl
 // The normalisation Jacobian of a keypoint's quaternion is linear in the incoming gradient, so it is applied once
 // per (workgroup, keypoint) after the sum.  Workgroup partials go to `partial`; gp_blend_bwd_reduce_kernel adds them.
 //
-// dynamic LDS: acc[K*7] | delta[K*od] | cnt[K] | base[K+1] | g[256*8] | w[256*2*nn] | sorted u16 [256*nn]
+// dynamic LDS: acc[K*7] | delta[K*od] | cnt[K] | base[K+1] | g[7*256] | inv[K] | w[256*2*nn] | sorted u16 [256*nn]
 #define BB_LONG 12          // a keypoint's list beyond this length is summed by a wave (mean length = nn)
 #define BB_LONG_CAP 320     // >= 256 * GP_MAX_NN / (BB_LONG + 1) lists can be that long
 template <int NN>
@@ -810,14 +810,28 @@ __device__ __forceinline__ void blend_bwd_body(BlendDev a, const float* __restri
     float* s_delta = s_acc + (nn > 0 ? K * 7 : 0);      // [K*od]
     int* s_cnt = (int*)(s_delta + (nn > 0 ? K * od : 0));   // [K]
     int* s_base = s_cnt + (nn > 0 ? K : 0);             // [K+1]
-    float* s_g = (float*)(s_base + (nn > 0 ? K + 1 : 0));   // [8][256]   component-major: a keypoint's owner gathers RANDOM Gaussians of the
-    float* s_w = s_g + 256 * 8;                         // [2*nn][256] chunk; [256][8] / [256][12] put 64 lanes on 4 / 8 banks (measured: 71 % of the LDS cycles were conflicts)
+    float* s_g = (float*)(s_base + (nn > 0 ? K + 1 : 0));   // [7][256]   component-major: a keypoint's owner gathers RANDOM Gaussians of the
+    float* s_inv = s_g + 256 * 7;                       // [K] 1 / |keypoint quaternion| (norm_rotation)
+    float* s_w = s_inv + (nn > 0 ? K : 0);              // [2*nn][256] chunk; [256][8] / [256][12] put 64 lanes on 4 / 8 banks (measured: 71 % of the LDS cycles were conflicts)
     unsigned short* s_sorted = (unsigned short*)(s_w + 256 * 2 * nn);   // [256*nn]
     __shared__ int s_wsum[4];
     __shared__ int s_nlong, s_long[BB_LONG_CAP];
     if (nn > 0) {
         for (int e = tid; e < K * 7; e += 256) s_acc[e] = 0.f;
         for (int e = tid; e < K * od; e += 256) s_delta[e] = a.delta[e];
+        if (a.norm_rotation) {
+            // the keypoints' quaternions are normalised ONCE per workgroup, in place (y = v / |v|, 1 / |v| beside it): per (Gaussian,
+            // neighbour) that was a square root and a division, twice -- a third of the per-Gaussian arithmetic.  Same expression
+            // per keypoint as before, so the values are the same.
+            __syncthreads();
+            for (int kp = tid; kp < K; kp += 256) {
+                float* dl = s_delta + kp * od;
+                const float v[4] = {dl[3], dl[4], dl[5], dl[6]};
+                const float inv = 1.f / norm4(v);
+                s_inv[kp] = inv;
+                dl[3] = v[0] * inv; dl[4] = v[1] * inv; dl[5] = v[2] * inv; dl[6] = v[3] * inv;
+            }
+        }
     }
     const long chunks = (a.N + 255) / 256;
     for (long c = blockIdx.x; c < chunks; c += gridDim.x) {
@@ -852,8 +866,7 @@ __device__ __forceinline__ void blend_bwd_body(BlendDev a, const float* __restri
                 for (int k = 0; k < nn; ++k) {
                     if (NN == 0) kps[k] = (int)a.knn[i * nn + k];
                     const float* dl = s_delta + kps[k] * od;
-                    float v[4] = {dl[3], dl[4], dl[5], dl[6]};
-                    if (a.norm_rotation) { const float inv = 1.f / norm4(v); v[0] *= inv; v[1] *= inv; v[2] *= inv; v[3] *= inv; }
+                    const float v[4] = {dl[3], dl[4], dl[5], dl[6]};          // (normalised in LDS when norm_rotation)
                     dq[0] = fmaf(wr[k], v[0], dq[0]); dq[1] = fmaf(wr[k], v[1], dq[1]);
                     dq[2] = fmaf(wr[k], v[2], dq[2]); dq[3] = fmaf(wr[k], v[3], dq[3]);
                 }
@@ -887,8 +900,7 @@ __device__ __forceinline__ void blend_bwd_body(BlendDev a, const float* __restri
                 for (int k = 0; k < nn; ++k) {
                     const float* dl = s_delta + kps[k] * od;
                     gwx[k] = dl[0] * gx[0] + dl[1] * gx[1] + dl[2] * gx[2];
-                    float vn[4] = {dl[3], dl[4], dl[5], dl[6]};
-                    if (a.norm_rotation) { const float inv = 1.f / norm4(vn); vn[0] *= inv; vn[1] *= inv; vn[2] *= inv; vn[3] *= inv; }
+                    const float vn[4] = {dl[3], dl[4], dl[5], dl[6]};
                     gwr[k] = vn[0] * gdq[0] + vn[1] * gdq[1] + vn[2] * gdq[2] + vn[3] * gdq[3];
                     sx += wx[k] * gwx[k];
                     sr += wr[k] * gwr[k];
@@ -1007,13 +1019,13 @@ __device__ __forceinline__ void blend_bwd_body(BlendDev a, const float* __restri
         const int KA = K * 7;
         for (int kp = tid; kp < K; kp += 256) {
             float* acc = s_acc + kp * 7;
-            if (a.norm_rotation) {
-                const float* dl = s_delta + kp * od;
-                const float v[4] = {dl[3], dl[4], dl[5], dl[6]};
+            if (a.norm_rotation) {      // normalize_bwd with y and 1 / |v| as stored at the top
+                const float* y = s_delta + kp * od + 3;
+                const float inv = s_inv[kp];
                 const float cq[4] = {acc[3], acc[4], acc[5], acc[6]};
-                float gv[4];
-                normalize_bwd(v, cq, gv);
-                acc[3] = gv[0]; acc[4] = gv[1]; acc[5] = gv[2]; acc[6] = gv[3];
+                const float dot = y[0] * cq[0] + y[1] * cq[1] + y[2] * cq[2] + y[3] * cq[3];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) acc[3 + k] = (cq[k] - y[k] * dot) * inv;
             }
         }
         __syncthreads();

@@ -165,8 +165,8 @@ extern "C" int gp_blend_backward(const gp_blend_args* a, const float* dL_dxyz_t,
     if (!dL_dxyz_t || !dL_dq_t || !dL_ddelta || !dL_dxyz || !dL_drot) GP_FAIL("null argument");     // dL_draw_w may be NULL
     unsigned blocks = gp_blocks((size_t)b.N, 256);
     if (b.nn > 0 && blocks > 1024) blocks = 1024;   // persistent: four workgroups per CU (LDS), their partials are summed by the reduce kernel
-    // acc[K*7] | delta[K*od] | cnt[K] | base[K+1] | g[256*8] | w[256*2*nn] | sorted u16 [256*nn]
-    const size_t lds = b.nn > 0 ? ((size_t)b.K * (7 + b.out_dim + 2) + 1 + 256 * 8 + 256 * 2 * (size_t)b.nn) * 4 + 256 * (size_t)b.nn * 2 + 16 : 256 * 8 * 4;
+    // acc[K*7] | delta[K*od] | cnt[K] | base[K+1] | g[7*256] | inv[K] | w[256*2*nn] | sorted u16 [256*nn]
+    const size_t lds = b.nn > 0 ? ((size_t)b.K * (7 + b.out_dim + 3) + 1 + 256 * 7 + 256 * 2 * (size_t)b.nn) * 4 + 256 * (size_t)b.nn * 2 + 16 : 256 * 8 * 4;
     if (lds > 64 * 1024) GP_FAIL("keypoint blend backward: K = %ld, nn = %d needs %zu B of LDS (> 64 KiB)", (long)b.K, b.nn, lds);
     float* partial = nullptr;
     const int KA = (int)b.K * 7;
