@@ -1204,15 +1204,21 @@ __device__ __forceinline__ void gp_composite_bwd_body(RasterDims d, const int2* 
     int qn = 0, src = 0;
     auto refill = [&]() {   // candidates src + 64 e + lane, e = 0..3: coalesced byte / dword loads
         bool r[4];
-        uint32_t ids[4];
+        uint32_t ids[4], qm[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int k = src + 64 * e + lane;
-            r[e] = false; ids[e] = 0u;
-            if (k < count) {
-                r[e] = (qmask[range.x + k] >> part) & 1u;
-                ids[e] = point_list[range.x + k];
-            }
+            const int kk = range.x + (k < count ? k : count - 1);       // clamped (count > 0 here)
+            qm[e] = qmask[kk];
+            ids[e] = point_list[kk];
+        }
+        // pinned: the eight loads leave together and are waited for once (as conditional loads each (mask, id) pair was waited for
+        // before the next was issued: four dependent trips to L2 per refill)
+        asm volatile("" ::"v"(qm[0]), "v"(qm[1]), "v"(qm[2]), "v"(qm[3]), "v"(ids[0]), "v"(ids[1]), "v"(ids[2]), "v"(ids[3]));
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int k = src + 64 * e + lane;
+            r[e] = k < count && ((qm[e] >> part) & 1u);
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
