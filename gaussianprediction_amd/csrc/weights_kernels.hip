@@ -396,24 +396,48 @@ __device__ __forceinline__ void wm_encode_block(const HashGridDev& g, long n, lo
     const long slot = slot0 + p;
     const bool live = slot < n;
     const long i = live ? (perm ? (long)perm[slot] : slot) : 0;
-    for (int l = tid >> 6; l < HG_MAX_LEVELS; l += 4) {
-        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (live && l < g.L) {
-            float w[3];
+    const float x3[3] = {xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]};
+    // a wave encodes levels w, w + 4, w + 8, w + 12: TWO levels' sixteen corner fetches are in flight at a time (one level at a
+    // time, each level's eight gathers were waited for before the next level's addresses were even computed)
+#pragma unroll
+    for (int lp = 0; lp < 2; ++lp) {
+        float4 v[2][8];
+        float w[2][3];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int l = (tid >> 6) + 8 * lp + 4 * h;
             uint32_t c[3];
-            hg_cell(g, l, xyz, i, w, c);
+            const float s = g.scale[l];
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {                       // (hg_cell on the registers)
+                const float pp = fmaf(s, x3[d], 0.5f);
+                const float f = floorf(pp);
+                w[h][d] = pp - f;
+                c[d] = (uint32_t)(int)f;
+            }
             const float4* tl = table + g.off[l];
 #pragma unroll
             for (int corner = 0; corner < 8; ++corner) {
                 const int bx = corner & 1, by = (corner >> 1) & 1, bz = corner >> 2;
-                float cw = (bx ? w[0] : 1.f - w[0]);
-                cw = cw * (by ? w[1] : 1.f - w[1]);
-                cw = cw * (bz ? w[2] : 1.f - w[2]);
-                const float4 v = tl[hg_index(g, l, c[0] + bx, c[1] + by, c[2] + bz)];
-                acc.x = acc.x + cw * v.x; acc.y = acc.y + cw * v.y; acc.z = acc.z + cw * v.z; acc.w = acc.w + cw * v.w;
+                v[h][corner] = tl[hg_index(g, l, c[0] + bx, c[1] + by, c[2] + bz)];
             }
         }
-        T[wm4_ti(4 * l + 0, p)] = acc.x; T[wm4_ti(4 * l + 1, p)] = acc.y; T[wm4_ti(4 * l + 2, p)] = acc.z; T[wm4_ti(4 * l + 3, p)] = acc.w;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int l = (tid >> 6) + 8 * lp + 4 * h;
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int corner = 0; corner < 8; ++corner) {
+                const int bx = corner & 1, by = (corner >> 1) & 1, bz = corner >> 2;
+                float cw = (bx ? w[h][0] : 1.f - w[h][0]);
+                cw = cw * (by ? w[h][1] : 1.f - w[h][1]);
+                cw = cw * (bz ? w[h][2] : 1.f - w[h][2]);
+                const float4 q = v[h][corner];
+                acc.x = acc.x + cw * q.x; acc.y = acc.y + cw * q.y; acc.z = acc.z + cw * q.z; acc.w = acc.w + cw * q.w;
+            }
+            if (!(live && l < g.L)) acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            T[wm4_ti(4 * l + 0, p)] = acc.x; T[wm4_ti(4 * l + 1, p)] = acc.y; T[wm4_ti(4 * l + 2, p)] = acc.z; T[wm4_ti(4 * l + 3, p)] = acc.w;
+        }
     }
 }
 
