@@ -205,7 +205,8 @@ __global__ __launch_bounds__(256) void gp_knn_kernel(long n, const float* __rest
     for (long chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
         const long slot = chunk * 256 + tid;
         const bool live = slot < n;
-        const long i = order ? (long)order[live ? slot : n - 1] : (live ? slot : n - 1);   // clamped: the loads below are unconditional
+        long i = order ? (long)order[live ? slot : n - 1] : (live ? slot : n - 1);         // clamped: the loads below are unconditional
+        if ((unsigned long)i >= (unsigned long)n) i = n - 1;                              // (a malformed `order` must not read out of bounds)
         float x[D];
 #pragma unroll
         for (int d = 0; d < 3; ++d) x[d] = xyz[3 * i + d];
