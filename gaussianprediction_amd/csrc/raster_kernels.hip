@@ -492,10 +492,10 @@ __global__ __launch_bounds__(256) void gp_tile_ranges_kernel(const uint32_t* __r
                                                             int2* __restrict__ ranges) {
     const uint32_t k = blockIdx.x * 256 + threadIdx.x;
     if (k >= R) return;
-    const uint32_t t = keys[k];
+    const uint32_t t = keys[k], tp = keys[k > 0 ? k - 1 : 0], tn = keys[k + 1 < R ? k + 1 : R - 1];   // (three loads, one round trip)
     if (t >= n_tiles) return;                            // sentinel padding of the capacity mode (sorted behind every tile)
-    if (k == 0 || keys[k - 1] != t) ranges[t].x = (int)k;
-    if (k == R - 1 || keys[k + 1] != t) ranges[t].y = (int)(k + 1);
+    if (k == 0 || tp != t) ranges[t].x = (int)k;
+    if (k == R - 1 || tn != t) ranges[t].y = (int)(k + 1);
 }
 // exact mode with a status word requested: status = {R, 0}  (capacity mode writes it from the duplicate launch)
 __global__ void gp_binning_status_kernel(const uint32_t* __restrict__ total, uint32_t capacity, uint32_t* __restrict__ status) {
