@@ -393,7 +393,8 @@ int gp_microbench_valu(int kind, int iters, float* sink, double* instr_out, gp_s
 int gp_microbench_gather(const void* src, int rec_bytes, int stride_bytes, const uint32_t* idx, size_t n_idx, float* sink,
                          gp_stream_t stream);
 /* Diagnostics: select a kernel variant for A/B profiling (key 0: composite forward, key 1: composite backward; value 0 =
- * the shipped default; key 2: access shape of gp_microbench_copy, tools/copy_peak_sweep.py).  Never needed by a caller of the
+ * the shipped default; key 2: access shape of gp_microbench_copy, tools/copy_peak_sweep.py; key 3: 1 = round 2's 2-D grid of the
+ * split-mode weight-gradient kernel; key 4: workgroup cap of the fused weights-model forward).  Never needed by a caller of the
  * render path. */
 int gp_debug_option(int key, int value);
 
