@@ -8,13 +8,15 @@ neighbour search's row loads this way: step 1.45 -> 1.33 ms.
 import os, re, subprocess, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "gaussianprediction_amd", "csrc")
-files = sys.argv[1:] or [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(".hip") and not f.startswith("gp_capi")]
-hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-for f in files:
+
+
+def audit(path, hipcc=None):
+    """{kernel symbol: (global loads, full waits, full waits right behind a load)} of one .hip file compiled for gfx950."""
+    hipcc = hipcc or os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     with tempfile.TemporaryDirectory() as td:
         out = os.path.join(td, "k.s")
         subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-munsafe-fp-atomics", "-I", os.path.join(ROOT, "include"),
-                        "-I", CSRC, "-S", "--cuda-device-only", "-o", out, f], check=True, stderr=subprocess.DEVNULL)
+                        "-I", CSRC, "-S", "--cuda-device-only", "-o", out, path], check=True, stderr=subprocess.DEVNULL)
         name, stats, last = None, {}, -100
         for i, l in enumerate(open(out)):
             m = re.match(r"^(_Z\w+):", l)
@@ -32,6 +34,12 @@ for f in files:
                 stats[name][2] += i - last <= 6
             if "s_endpgm" in l:
                 name = None
-        for k, (nl, nw, ns) in stats.items():
+    return {k: tuple(v) for k, v in stats.items()}
+
+
+if __name__ == "__main__":
+    files = sys.argv[1:] or [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(".hip") and not f.startswith("gp_capi")]
+    for f in files:
+        for k, (nl, nw, ns) in audit(f).items():
             if nl and ns >= 3:
                 print(f"{os.path.basename(f):24s} {k[:64]:64s} loads {nl:4d}  full waits {nw:3d}  right behind a load {ns:3d}")
