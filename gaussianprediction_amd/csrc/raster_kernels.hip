@@ -1546,24 +1546,41 @@ __device__ __forceinline__ void adam_unstage_sh(const float* s_sh, const AdamFus
             *(float4*)(p + e + 1024 * c) = pv[c]; *(float4*)(m + e + 1024 * c) = mv[c]; *(float4*)(v + e + 1024 * c) = vv[c];
         }
     }
-    for (; e < total; e += 1024) {
-        float g[4];
+    {   // the rest -- at most AU - 1 whole chunks and one ragged 16 bytes -- fetched together as well (one chunk per iteration,
+        // these were two more dependent round trips per thread: as many as the whole unrolled part above)
+        float4 pv[AU - 1], mv[AU - 1], vv[AU - 1];
+        bool ok[AU - 1];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int idx = e + u;
-            const int gi = idx / CNT, k = idx - gi * CNT;
-            g[u] = (idx < total) ? s_sh[gi * STRIDE + k] : 0.f;
+        for (int c = 0; c < AU - 1; ++c) {
+            const int ec = e + 1024 * c;
+            ok[c] = ec + 3 < total;
+            const int el = ok[c] ? ec : 0;
+            pv[c] = *(const float4*)(p + el); mv[c] = *(const float4*)(m + el); vv[c] = *(const float4*)(v + el);
         }
-        if (e + 3 < total) {
-            float4 pv = *(const float4*)(p + e), mv = *(const float4*)(m + e), vv = *(const float4*)(v + e);
-            float* pp = (float*)&pv; float* mm = (float*)&mv; float* vq = (float*)&vv;
 #pragma unroll
-            for (int u = 0; u < 4; ++u) gp_adam_update(pp[u], g[u], mm[u], vq[u], af.b1, af.b2, af.eps, af.step_rest, af.bc2_sqrt);
-            *(float4*)(p + e) = pv; *(float4*)(m + e) = mv; *(float4*)(v + e) = vv;
-        } else {
+        for (int c = 0; c < AU - 1; ++c) {
+            if (!ok[c]) continue;
+            float* pp = (float*)&pv[c]; float* mm = (float*)&mv[c]; float* vq = (float*)&vv[c];
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
-                if (e + u < total) gp_adam_update(p[e + u], g[u], m[e + u], v[e + u], af.b1, af.b2, af.eps, af.step_rest, af.bc2_sqrt);
+            for (int u = 0; u < 4; ++u) {
+                const int idx = e + 1024 * c + u;
+                const int gi = idx / CNT, k = idx - gi * CNT;
+                gp_adam_update(pp[u], s_sh[gi * STRIDE + k], mm[u], vq[u], af.b1, af.b2, af.eps, af.step_rest, af.bc2_sqrt);
+            }
+            *(float4*)(p + e + 1024 * c) = pv[c]; *(float4*)(m + e + 1024 * c) = mv[c]; *(float4*)(v + e + 1024 * c) = vv[c];
+        }
+#pragma unroll
+        for (int c = 0; c < AU - 1; ++c) {              // a ragged last vector (partial workgroups only)
+            const int ec = e + 1024 * c;
+            if (!ok[c] && ec < total) {
+                for (int u = 0; u < 4; ++u) {
+                    const int idx = ec + u;
+                    if (idx < total) {
+                        const int gi = idx / CNT, k = idx - gi * CNT;
+                        gp_adam_update(p[idx], s_sh[gi * STRIDE + k], m[idx], v[idx], af.b1, af.b2, af.eps, af.step_rest, af.bc2_sqrt);
+                    }
+                }
+            }
         }
     }
 }
