@@ -794,7 +794,7 @@ __device__ __forceinline__ void normalize_bwd(const float* v, const float* g, fl
 // per (workgroup, keypoint) after the sum.  Workgroup partials go to `partial`; gp_blend_bwd_reduce_kernel adds them.
 //
 // dynamic LDS: acc[K*7] | delta[K*od] | cnt[K] | base[K+1] | g[7*256] | inv[K] | w[256*2*nn] | sorted u16 [256*nn]
-#define BB_LONG 12          // a keypoint's list beyond this length is summed by a wave (mean length = nn)
+#define BB_LONG 20          // a keypoint's list beyond this length is summed by a wave (mean length = nn)
 #define BB_LONG_CAP 320     // >= 256 * GP_MAX_NN / (BB_LONG + 1) lists can be that long
 template <int NN>
 __device__ __forceinline__ void blend_bwd_body(BlendDev a, const float* __restrict__ g_xyz_t,
