@@ -13,6 +13,12 @@ N>1: one process per GPU, view-parallel, RCCL all-reduce(SUM) of the flat gradie
 scaling: one view per GPU per step).  value = views/s of full train steps over the whole job.
 
 Contract: python bench.py --gpus N --steps K --warmup W  ->  ONE JSON line on rank 0.
+
+Launch forms.  Under a launcher (`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`: WORLD_SIZE is set)
+this process is one of the N ranks.  As plain `python bench.py --gpus N` with N > 1 (WORLD_SIZE unset) it STARTS the N ranks
+itself -- it re-executes under `torch.distributed.run` on 127.0.0.1 with a free port and relays rank 0's line -- and it fails
+loudly when the box shows fewer than N devices: a request for N GPUs never degrades to fewer ranks.  `--dry-launch` runs the
+same launch with gloo and no device work (the launcher's CPU test).
 """
 import argparse
 import json
@@ -110,6 +116,75 @@ def cpu_baseline(args, pc, cams, seconds_budget=30.0):
                       + f"; host has {cores} hardware threads; deformation/loss/Adam not included"}
 
 
+import contextlib
+
+
+@contextlib.contextmanager
+def stdout_to_stderr():
+    """Communicator start-up prints banners on the C library's stdout (RCCL's version line, gloo's "[Gloo] Rank ..."); stdout
+    carries exactly ONE line here (the JSON result), so file descriptor 1 points at stderr while a process group comes up."""
+    sys.stdout.flush()
+    fd1 = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        yield
+    finally:
+        sys.stdout.flush()
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)          # the banner sits in the C library's stdio buffer: push it out while fd 1 is stderr
+        except Exception:
+            pass
+        os.dup2(fd1, 1)
+        os.close(fd1)
+
+
+def self_launch(args, argv):
+    """`python bench.py --gpus N` (N > 1) without a launcher: start N ranks of this script under torch.distributed.run on this
+    node (one process per GPU, rendezvous on 127.0.0.1 at a free port) and exit with its return code.  Never fewer ranks than
+    asked for."""
+    import socket
+    import subprocess
+    if not args.dry_launch:
+        have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if have < args.gpus:
+            sys.stderr.write(f"bench.py: --gpus {args.gpus} but this box shows {have} HIP device(s); refusing to run fewer ranks\n")
+            sys.exit(2)
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ, GP_BENCH_SELF_LAUNCHED="1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # (dmabuf IPC: RCCL across processes needs it on this driver)
+    env.setdefault("OMP_NUM_THREADS", "8")
+    sys.stderr.write("[bench] self-launch: " + " ".join(cmd) + "\n")
+    sys.exit(subprocess.call(cmd, env=env))
+
+
+def dry_launch(args):
+    """The launch path without device work: the ranks rendezvous over gloo, prove they see each other with one all-reduce, and
+    rank 0 prints the one line (tests/test_bench_launch.py)."""
+    os.environ["GP_DIST_BACKEND"] = "gloo"
+    from gaussianprediction_amd.dist import init_from_env
+    with stdout_to_stderr():
+        rank, local, world = init_from_env("gloo")
+        if world != args.gpus:
+            raise SystemExit(f"bench.py: WORLD_SIZE={world} but --gpus {args.gpus}")
+        seen = torch.tensor([float(rank + 1)])
+        if world > 1:
+            dist.all_reduce(seen)
+            dist.barrier()
+    if rank == 0:
+        print(json.dumps({"metric": "dry launch (no device work)", "value": None, "n_gpus": world, "dry_launch": True,
+                          "config": {"ranks_seen_by_rccl": dist.get_world_size() if dist.is_initialized() else 1,
+                                     "backend": "gloo", "rank_id_sum": float(seen.item()),
+                                     "self_launched": os.environ.get("GP_BENCH_SELF_LAUNCHED") == "1"}}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def _sha16(path):
     import hashlib
     return hashlib.sha256(open(path, "rb").read()).hexdigest()[:16]
@@ -145,34 +220,29 @@ def main():
                     help="N > 1, sharded exchange: keep the SH regions' Adam + all-gather on the compute stream (A/B of TrainStep._chain_sh)")
     ap.add_argument("--replicated-adam", action="store_true",
                     help="N > 1: all-reduce + replicated Adam (round 1) instead of reduce-scatter -> sharded Adam -> all-gather")
+    ap.add_argument("--dry-launch", action="store_true",
+                    help="launch path only: N ranks rendezvous over gloo, one all-reduce, one JSON line, no device work")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args, sys.argv[1:])             # does not return
+    if args.dry_launch:
+        return dry_launch(args)
 
     from gaussianprediction_amd import _lib
     from gaussianprediction_amd.dist import init_from_env
     from gaussianprediction_amd.train_step import TrainStep
-    # RCCL prints a version banner on stdout when a communicator is created; stdout carries exactly ONE line here (the JSON
-    # result), so file descriptor 1 points at stderr while the process group and its first communicator come up
-    sys.stdout.flush()
-    _fd1 = os.dup(1)
-    os.dup2(2, 1)
-    try:
+    with stdout_to_stderr():
         rank, local, world = init_from_env()
-        assert world == args.gpus or world == 1, f"WORLD_SIZE={world} but --gpus {args.gpus}"
+        if world != args.gpus:                      # (a launcher that started another number of ranks than --gpus names)
+            raise SystemExit(f"bench.py: WORLD_SIZE={world} but --gpus {args.gpus}")
         assert torch.cuda.is_available(), "bench.py needs a HIP device (no CPU fallback)"
         device = torch.device("cuda", local)
         torch.cuda.set_device(device)
         if dist.is_available() and dist.is_initialized():
             dist.barrier()                          # (creates the communicator now)
             torch.cuda.synchronize()
-    finally:
-        sys.stdout.flush()
-        try:
-            import ctypes
-            ctypes.CDLL(None).fflush(None)          # the banner sits in the C library's stdio buffer: push it out while fd 1 is stderr
-        except Exception:
-            pass
-        os.dup2(_fd1, 1)
-        os.close(_fd1)
     pc, cams, gts, margs = build_workload(args, device)
     # learning rates of the reference at iteration 50000 (position lr has decayed to position_lr_final,
     # [REF arguments/__init__.py:75-76, scene/gaussian_model.py:474-491])
@@ -359,6 +429,8 @@ def main():
                        "nearest_num": args.nearest_num, "time_freq": args.time_freq, "iteration": args.iteration,
                        "tiles": T, "pixels": P, "R": R, "R_before_timed_region": R0, "R_per_gaussian": round(R / max(args.gaussians, 1), 3),
                        "visible": n_vis, "parallelism": f"view-parallel x{world}",
+                       "ranks_seen_by_rccl": dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1,
+                       "self_launched": os.environ.get("GP_BENCH_SELF_LAUNCHED") == "1",
                        "gradient_exchange": None if not ts.reducer.enabled else (
                            "all-reduce(SUM) of the flat gradient bucket + replicated Adam" if not ts.sharded else
                            "reduce-scatter(SUM) per region -> Adam on 1/N of every region -> asynchronous all-gather of the parameters"
