@@ -204,6 +204,24 @@ class GaussianModel(TrainingMixin, nn.Module):
     def get_rotation(self):
         return torch.nn.functional.normalize(self._rotation)
 
+    rotation_activation = staticmethod(torch.nn.functional.normalize)      # [REF scene/gaussian_model.py:49]
+
+    def get_rotation_(self, delta):
+        """normalize(delta (x) _rotation), Hamilton product in (w, x, y, z) with the RAW stored rotation
+        [REF scene/gaussian_model.py:314-315; eval.py:141 calls it on blended keypoint rotations].  Runs the per-Gaussian form
+        of the blend kernel (gp_blend_forward, nn = 0), the same arithmetic as forward()'s composition."""
+        n = self._rotation.shape[0]
+        d = torch.zeros(n, 7, dtype=torch.float32, device=self._rotation.device)
+        d[:, 3:7] = delta
+        return KeypointBlend.apply(d, None, None, self._xyz.detach(), self._rotation, False)[1]
+
+    @property
+    def all_xyz_motion(self):
+        """Per-Gaussian displacement of the LAST forward, xyz_t - xyz.  [REF eval.py:60] reads this attribute in
+        project_trajectory; no code in the reference assigns it, so the definition is this package's."""
+        last = getattr(self, "_last_xyz_t", None)
+        return None if last is None else last - self._xyz.detach()
+
     def get_covariance(self, scaling_modifier=1):
         """Packed world-space covariance [N,6] (xx,xy,xz,yy,yz,zz) = (R S)(R S)^T, with the *raw*
         `_rotation` normalised inside, as the reference's python fallback does
@@ -267,6 +285,19 @@ class GaussianModel(TrainingMixin, nn.Module):
         self.add_desification_stats_motion(delta_xyz - teach[:, 0:3])
 
     # ---- the hot path [REF scene/gaussian_model.py:231-304] ---------------------------------------
+    def stage_transitions(self, iteration):
+        """The stage hooks the reference runs inside forward [REF scene/gaussian_model.py:246-250]: at second_stage_iter + 1 the
+        keypoints are initialised (k-means of the motion features) and the stage-2 optimizer is installed, at third_stage_iter + 1
+        the stage-3 optimizer.  They need a training set-up; a harness may call this ahead of the forward (TrainStep does, so
+        that the optimizer / gradient bucket it works with is the one the step's backward fills)."""
+        if self.training_args is None:
+            return
+        if iteration == self.third_stage_iter + 1 and not self.third_stage:
+            self.training3stage_setup()
+        if iteration == self.second_stage_iter + 1 and not self.second_stage:
+            self.set_superKeypoints()
+            self.training2stage_setup()
+
     def forward(self, t, iteration, return_weights=False):
         if torch.is_tensor(iteration):
             iteration = iteration.item()
@@ -276,13 +307,7 @@ class GaussianModel(TrainingMixin, nn.Module):
             s, o = Activations.apply(self._scaling, self._opacity, None, 0, 1.0)
             return self._xyz, self.get_rotation, s, o
         t_dev = t.to(self._xyz.device, torch.float32).reshape(-1)[:1]
-        # stage transitions happen inside forward in the reference [REF :246-250]; they need a training set-up
-        if self.training_args is not None:
-            if iteration == self.third_stage_iter + 1 and not self.third_stage:
-                self.training3stage_setup()
-            if iteration == self.second_stage_iter + 1 and not self.second_stage:
-                self.set_superKeypoints()
-                self.training2stage_setup()
+        self.stage_transitions(iteration)
         self._last_blend = None
         if iteration <= self.second_stage_iter:      # stage 1: MLP over all N Gaussians, xyz detached
             noise = getattr(a, "xyz_noise_iteration", 0)
@@ -316,6 +341,7 @@ class GaussianModel(TrainingMixin, nn.Module):
                     if iteration % a.adaptive_interval == 0:
                         self.get_new_kpts(self.xyz_motion_accum_max.squeeze(-1) >= a.teaching_threshold)
         self.lifecycle_opacity = None
+        self._last_xyz_t = xyz_t.detach()
         weights = ()
         if return_weights and iteration > self.second_stage_iter:
             weights = self.dense_weights()

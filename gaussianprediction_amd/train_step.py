@@ -52,6 +52,7 @@ class TrainStep:
             self._events = [None] * K
             self._slot_view = [None] * K            # view rendered by the step that last used the slot
             self._slot_spec = [False] * K           # ... and whether it ran in capacity mode
+            self._slot_toff = [None] * K            # ... and its time offset (a repeated frame is repeated with it)
             self._r_max, self._n_steps, self.redone = 0, 0, 0
             if os.environ.get("GP_SPEC_MARGIN"):     # test hook: a margin < 1 forces overflows (and the redo protocol)
                 self.SPEC_MARGIN, self.SPEC_PAD = float(os.environ["GP_SPEC_MARGIN"]), 0
@@ -186,7 +187,10 @@ class TrainStep:
             return l1_ssim_loss(image, gt, self.lambda_dssim, feat, 1.0e-5)
         return l1_ssim_loss(image, gt, self.lambda_dssim)
 
-    def step(self, view_index: int):
+    def step(self, view_index: int, time_offset=None):
+        """`time_offset`: a [1] device tensor added to every rendered view's time (the decaying time noise of the training
+        loop [REF train.py:92-99]); None = the cameras' own times."""
+        self._time_offset = time_offset
         if not self.speculative:
             return self._step(view_index, None, None)
         K = self.SPEC_SLOTS
@@ -199,9 +203,10 @@ class TrainStep:
                 self.redone += 1
                 self.optimizer.step_count -= 1
                 self._events[slot] = None
+                self._time_offset = self._slot_toff[slot]
                 self._run_slot(slot, self._slot_view[slot], exact=True)
                 self._n_steps += 1
-                return self.step(view_index)
+                return self.step(view_index, time_offset)
         exact = self._n_steps < len(self.cameras) + K or self._r_max == 0   # until every view's R has been read back
         out = self._run_slot(slot, view_index, exact)
         self._n_steps += 1
@@ -215,10 +220,13 @@ class TrainStep:
         ev = self._events[slot] or torch.cuda.Event()
         ev.record()
         self._events[slot], self._slot_view[slot], self._slot_spec[slot] = ev, view_index, not exact
+        self._slot_toff[slot] = self._time_offset
         return out
 
     def _step(self, view_index: int, binning, skip_flag):
         pc = self.pc
+        if self.iteration >= pc.args.jointly_iteration:
+            pc.stage_transitions(self.iteration)     # (the hooks forward would run: the optimizer must be this step's from the start)
         self._attach()                               # (densify / prune / stage changes rebuild bucket + optimizer)
         if self.sharded:                             # parameters the deformation reads: their all-gather must have landed
             self.reducer.wait_params(only=self._early_params)
@@ -264,7 +272,10 @@ class TrainStep:
             for b in range(self.batch):              # [REF train.py:101-119]
                 v = view_index * self.batch + b
                 cam = self.cameras[v % len(self.cameras)]
-                pkg = render(cam, pc, self.pipe, self.bg, time=self.times[v % len(self.cameras)], it=self.iteration, binning=binning)
+                t_view = self.times[v % len(self.cameras)]
+                if getattr(self, "_time_offset", None) is not None:
+                    t_view = t_view + self._time_offset
+                pkg = render(cam, pc, self.pipe, self.bg, time=t_view, it=self.iteration, binning=binning)
                 losses.append(self.loss_of(pkg["render"], self.gt[v % len(self.gt)]))
                 pkgs.append(pkg)
             if skip_flag is not None and self.reducer.enabled:

@@ -204,3 +204,22 @@ def test_fused_mlp16_close_to_fp32(precision, tol_y, tol_g, rows, F, out_dim):
     assert rel_l2(xd.grad.cpu().numpy(), x64.grad.numpy()) < tol_g
     for k, p in net.named_parameters():
         assert rel_l2(p.grad.cpu().numpy(), sd64[k].grad.numpy()) < tol_g, k
+
+
+def test_get_rotation_matches_reference_quat_mul_golden():
+    """GaussianModel.get_rotation_(delta) = normalize(delta (x) _rotation) [REF scene/gaussian_model.py:314-315; eval.py:141]
+    against the reference-generated quaternion products (tests/golden/quat_mul.npz)."""
+    g = np.load(os.path.join(G, "quat_mul.npz"))
+    q1, q2 = torch.tensor(g["q1"]).float().cuda(), torch.tensor(g["q2"]).float().cuda()
+    args = SimpleNamespace(beta=0.1, d=4, w=256, feature_dim=32, jointly_iteration=1000, second_stage_iteration=30000,
+                           third_stage_iteration=40000, nearest_num=6, norm_rotation=True, step_opacity=False, step_opacity_iteration=5000,
+                           opacity_type="implicit", xyz_noise_iteration=0)
+    pc = gpa.GaussianModel(3, args)
+    pc.set_inputDim(12, 60)
+    n = q2.shape[0]
+    z = lambda *s: torch.zeros(*s, device="cuda")
+    pc.create_from_tensors(z(n, 3), z(n, 1, 3), z(n, 15, 3), z(n, 3), q2, z(n, 1), z(n, 32))
+    out = pc.get_rotation_(pc.rotation_activation(q1))
+    # the product is bilinear: normalize(normalize(q1) (x) q2) == normalize(q1 (x) q2), the golden product
+    want = torch.nn.functional.normalize(torch.tensor(g["q1q2"]).double())
+    assert float((out.double().cpu() - want).abs().max()) < 1e-6

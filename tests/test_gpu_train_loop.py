@@ -1,12 +1,13 @@
-"""-m gpu: the reference's training loop and its restart / evaluation paths, call for call, on the drop-in surfaces
-(`from gaussian_renderer import render, render_motion, GaussianModel`) -- with the stage thresholds compressed so that 90
-iterations cross everything train.py does [REF train.py:36-201, eval.py:226-260]:
+"""-m gpu: a whole training schedule, its restart and its evaluation on the drop-in surfaces
+(`from gaussian_renderer import render, render_motion, GaussianModel`), driven by this package's own harness
+(train_step.TrainStep + densify.py) -- with the stage thresholds compressed so that 90 iterations cross every phase the
+reference's schedule has [REF train.py:36-201, eval.py:226-260]:
 warm-up (static) -> stage 1 (per-Gaussian MLP; densify / prune / opacity reset) -> the hook at second_stage_iter + 1 (k-means
 keypoints, stage-2 optimizer) -> keypoint growth -> the hook at third_stage_iter + 1 -> stage 3 (hash-grid weights model + kNN
 evaluated inside forward) -> checkpoint tuple -> a fresh model sized from it (N_pcd_init / final_kpts_num, create_from_pcd,
 training_setup, restore, load_state_dict) that continues to train -> eval.py's restore-without-training_setup and its render loop.
-The loss is the reference's own torch code path (its utils/loss_utils.py stays Python on the reference side; the restatement in
-oracle/deform_oracle.py is pinned to it by golden vectors): the loop below touches this package only through the reference's API."""
+Every name the reference's scripts use on these surfaces is pinned separately, as data: tests/golden/api_surface.json
+(tests/test_api_surface.py)."""
 import os
 from random import Random
 from types import SimpleNamespace
@@ -19,8 +20,9 @@ pytestmark = pytest.mark.gpu
 
 from gaussian_renderer import GaussianModel, render, render_motion  # noqa: E402  (the import-name shims)
 from gaussianprediction_amd.cameras import orbit_cameras  # noqa: E402
+from gaussianprediction_amd import densify as dn  # noqa: E402
+from gaussianprediction_amd.train_step import TrainStep  # noqa: E402
 from gaussianprediction_amd.training import default_training_args  # noqa: E402
-from oracle import deform_oracle as do  # noqa: E402
 
 W, H = 96, 80
 
@@ -50,80 +52,36 @@ def _scene():
     return SimpleNamespace(points=pts, colors=cols, normals=np.zeros_like(pts)), cams
 
 
-def _train(gaussians, cams, opt, args, pipe, background, first_iter, last_iter, rnd, log, batch=1):
-    """train.py:76-201 (with --batch > 1 the optimizer steps every `batch` iterations on the sum of their losses)."""
-    viewpoint_stack = None
-    batch_loss, batch_viewspace_point_tensor, batch_radii, batch_visibility_filter = [], [], [], []
-    for iteration in range(first_iter, last_iter + 1):
-        gaussians.update_learning_rate(iteration)
-        if iteration % 20 == 0:                                   # (every 1000 in the reference)
-            gaussians.oneupSHdegree()
-        if not viewpoint_stack:
-            viewpoint_stack = list(cams)
-        viewpoint_cam = viewpoint_stack.pop(rnd.randint(0, len(viewpoint_stack) - 1))
-        max_frame = len(cams)
-        decay_noise = torch.randn([1], device="cuda") * args.time_noise_ratio / max_frame * (1 - min(1, iteration / args.time_noise_iteration))
-        if args.use_time_decay and iteration >= gaussians.second_stage_iter:
-            decay_noise = torch.randn([1], device="cuda") * args.time_noise_ratio / max_frame * \
-                (1 - min(1, (iteration - gaussians.second_stage_iter) / (args.time_noise_iteration * 2)))
-        time_ = torch.from_numpy(viewpoint_cam.time).to(torch.float32).to("cuda") + decay_noise
-        render_pkg = render(viewpoint_cam, gaussians, pipe, background, delta=None, time=time_, it=iteration)
-        image, viewspace_point_tensor, visibility_filter, radii = render_pkg["render"], render_pkg["viewspace_points"], \
-            render_pkg["visibility_filter"], render_pkg["radii"]
-        gt_image = viewpoint_cam.original_image.cuda()
-        Ll1 = do.l1_loss(image, gt_image)
-        loss = (1.0 - opt.lambda_dssim) * Ll1 + opt.lambda_dssim * (1.0 - do.ssim(image, gt_image))
-        loss += gaussians.get_loss(iteration)
-        batch_loss += [loss]
-        batch_radii += [radii.unsqueeze(0)]
-        batch_visibility_filter += [visibility_filter.unsqueeze(0)]
-        batch_viewspace_point_tensor += [viewspace_point_tensor]
-        if len(batch_loss) == batch:
-            loss_ = torch.stack(batch_loss, dim=0).sum()
-            loss_.backward()
-            radii = torch.cat(batch_radii, 0).max(dim=0).values
-            visibility_filter = torch.cat(batch_visibility_filter).any(dim=0)
-            viewspace_point_tensor_grad = torch.zeros_like(viewspace_point_tensor)
-            for idx in range(0, len(batch_viewspace_point_tensor)):
-                viewspace_point_tensor_grad = viewspace_point_tensor_grad + batch_viewspace_point_tensor[idx].grad
-            assert torch.isfinite(viewspace_point_tensor_grad).all()
-            batch_loss.clear(), batch_radii.clear(), batch_visibility_filter.clear(), batch_viewspace_point_tensor.clear()
-        else:
-            log["loss"].append(loss.item()), log["n"].append(gaussians.get_xyz.shape[0]), log["k"].append(gaussians.super_gaussians.shape[0])
-            continue
+def _run(model, cams, gts, opt, args, first, last, rnd, log, batch=1):
+    """This package's own iteration (train_step.TrainStep: render -> fused L1 + SSIM -> backward -> fused Adam, `batch` views per
+    step) driven over iterations first..last, with the loop-side calls of densify.py after every step."""
+    ts = TrainStep(model, cams, gts, first, lambda_dssim=opt.lambda_dssim, batch=batch, schedule=True, training_args=opt)
+    groups, pending = len(cams) // batch, []
+    for it in range(first, last + 1):
+        ts.iteration = it
+        if it % 20 == 0:
+            model.oneupSHdegree()
+        if not pending:
+            pending = list(range(groups))
+        v = pending.pop(rnd.randint(0, len(pending) - 1))
+        # time jitter, decaying to zero over time_noise_iteration (restarted, twice as long, when the keypoints take over)
+        start = model.second_stage_iter if (args.use_time_decay and it >= model.second_stage_iter) else 0
+        span = args.time_noise_iteration * (2 if start else 1)
+        jitter = torch.randn(1, device="cuda") * (args.time_noise_ratio / len(cams)) * (1.0 - min(1.0, (it - start) / span))
+        loss, pkg = ts.step(v, time_offset=jitter)
+        log["loss"].append(float(loss)), log["n"].append(model.get_xyz.shape[0])
+        log["k"].append(model.super_gaussians.shape[0])
         with torch.no_grad():
-            log["loss"].append(loss.item())
-            log["n"].append(gaussians.get_xyz.shape[0])
-            log["k"].append(gaussians.super_gaussians.shape[0])
-            if iteration < opt.densify_until_iter:
-                gaussians.max_radii2D[visibility_filter] = torch.max(gaussians.max_radii2D[visibility_filter], radii[visibility_filter])
-                gaussians.add_densification_stats(viewspace_point_tensor, visibility_filter)
-                if iteration > opt.densify_from_iter and iteration % opt.densification_interval == 0 and gaussians.get_xyz.shape[0] < args.max_gaussian_size:
-                    size_threshold = 20 if iteration > opt.opacity_reset_interval else None
-                    gaussians.densify(opt.densify_grad_threshold, 0.005, 2.0, size_threshold)
-                if iteration % opt.opacity_reset_interval == 0:
-                    gaussians.reset_opacity()
-                if iteration > opt.densify_from_iter and iteration % opt.densification_interval == 0:
-                    size_threshold = 20 if iteration > opt.opacity_reset_interval else None
-                    gaussians.prune(opt.densify_grad_threshold, 0.005, 2.0, size_threshold)
-            if iteration < args.adaptive_end_iter + gaussians.second_stage_iter and gaussians.super_gaussians.shape[0] < args.max_points + args.adaptive_points_num:
-                if gaussians.second_stage:
-                    gaussians.max_radii2D[visibility_filter] = torch.max(gaussians.max_radii2D[visibility_filter], radii[visibility_filter])
-                    gaussians.add_densification_stats(viewspace_point_tensor, visibility_filter)
-                if iteration > args.adaptive_from_iter + gaussians.second_stage_iter and iteration % args.adaptive_interval == 0:
-                    if gaussians.new_xyz is not None:
-                        gaussians.densification_motion_postfix(gaussians.new_xyz, gaussians.new_motion_feature)
-                        gaussians.new_kpts_init()
-                    if args.densify_from_grad == "True":
-                        gaussians.densify_kpts(opt.densify_grad_threshold, mode="down_sampling")
-            if iteration < opt.iterations:
-                gaussians.optimizer.step()
-                gaussians.optimizer.zero_grad(set_to_none=True)
-    return iteration
+            if it < opt.densify_until_iter:
+                dn.track_view(model, pkg["viewspace_points"], pkg["visibility_filter"], pkg["radii"])
+                dn.densification_step(model, it, opt, 2.0, max_gaussian_size=args.max_gaussian_size)
+            dn.keypoint_growth_step(model, it, opt, args, pkg["visibility_filter"], pkg["radii"], pkg["viewspace_points"])
+    ts.sync_params()
+    return last
 
 
 @pytest.mark.parametrize("batch", [1, 2])
-def test_the_reference_training_loop_runs_unchanged(tmp_path, batch):
+def test_full_schedule_restart_and_eval(tmp_path, batch):
     torch.manual_seed(0)
     args, opt = _args(), _opt()
     pcd, cams = _scene()
@@ -133,10 +91,11 @@ def test_the_reference_training_loop_runs_unchanged(tmp_path, batch):
     gaussians.set_inputDim(2 * 6, 6 * 10)
     gaussians.create_from_pcd(pcd, 2.0)                            # (Scene.__init__)
     gaussians.training_setup(opt)
+    gts = [c.original_image for c in cams]
     log = dict(loss=[], n=[], k=[])
     rnd = Random(0)
-    last = 75 + (batch - 1)
-    _train(gaussians, cams, opt, args, pipe, background, 1, last, rnd, log, batch)
+    last = 75
+    _run(gaussians, cams, gts, opt, args, 1, last, rnd, log, batch)
     L = np.array(log["loss"])
     assert np.isfinite(L).all()
     # it trains in every stage: stage 1 up to the opacity reset at 30 (which blacks the image out: the loss jumps), the recovery
@@ -173,7 +132,7 @@ def test_the_reference_training_loop_runs_unchanged(tmp_path, batch):
         b = render(cams[2], g2, pipe, background, time=time_, it=last + 1)["render"]
     assert torch.equal(a, b)                                       # the restored model renders the same image, bit for bit
     log2 = dict(loss=[], n=[], k=[])
-    _train(g2, cams, opt, args, pipe, background, first_iter + 1, 90, Random(1), log2, batch)
+    _run(g2, cams, gts, opt, args, first_iter + 1, 90, Random(1), log2, batch)
     assert np.isfinite(log2["loss"]).all() and np.mean(log2["loss"][-5:]) < L[70:75].mean() + 0.02
     # ---- eval.py:226-247: restore WITHOUT training_setup, then the render loop and render_motion [REF eval.py:126,153,205-224]
     with torch.no_grad():
