@@ -103,8 +103,9 @@ EXPORTS = [
     "gp_weights_forward", "gp_weights_backward", "gp_l1_mean_forward", "gp_l1_mean_backward", "gp_loss_l1_ssim_finalize_reg", "gp_loss_l1_ssim_backward_reg", "gp_furthest_point_sampling", "gp_knn3_mean_dist2",
     "gp_microbench_copy", "gp_microbench_read", "gp_microbench_mfma", "gp_microbench_valu", "gp_microbench_gather",
     "gp_debug_option",
-    "gp_last_error", "gp_version",
+    "gp_last_error", "gp_version", "gp_abi_version",
 ]
+GP_ABI_VERSION = 3         # include/gp_hip.h: the struct layouts / signatures / buffer-size macros this binding was written against
 
 _lib = None
 _lock = threading.Lock()
@@ -137,6 +138,9 @@ def lib() -> C.CDLL:
             if name not in ("gp_last_error", "gp_version"):
                 getattr(l, name).restype = C.c_int
         l.gp_hashgrid_table_entries.restype = C.c_int64
+        if int(l.gp_abi_version()) != GP_ABI_VERSION:
+            raise GpHipError(f"{LIB_PATH} implements ABI {int(l.gp_abi_version())}, this binding is written against ABI "
+                             f"{GP_ABI_VERSION} (include/gp_hip.h): rebuild the library (__graft_entry__.build(force=True))")
         _lib = l
         return _lib
 

@@ -8,7 +8,8 @@
 thread_local char gp_err_buf[512] = "";
 
 extern "C" const char* gp_last_error(void) { return gp_err_buf; }
-extern "C" const char* gp_version(void) { return "gaussianprediction_amd 0.1 (gfx950)"; }
+extern "C" const char* gp_version(void) { return "gaussianprediction_amd 0.4 (gfx950)"; }
+extern "C" int gp_abi_version(void) { return GP_ABI_VERSION; }
 
 static int tile_bits_for(int T) {
     int b = 1;

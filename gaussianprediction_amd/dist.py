@@ -153,7 +153,7 @@ class ShardedExchange:
         self.chain = None
         self._chained = set()                   # region starts taken over this step
         self.side = torch.cuda.Stream(device=bucket.flat.device) if (self.enabled and bucket.flat.is_cuda) else None
-        self._late_event = None
+        self._late_event, self._late_ids = None, set()
         self._issued = set()                    # region starts whose reduce-scatter the hooks have issued this step
         if self.enabled:
             from . import grad_sink
@@ -263,6 +263,13 @@ class ShardedExchange:
             else:
                 h.wait()
         self._gather = rest
+        # late gathers handed to a rasterizer call as an event (late_event) are awaited on the SIDE stream only; if that call
+        # never consumed the event (no Gaussians, an exception before the kernel) nothing else orders the compute stream behind
+        # them -- so any wait that covers their tensors (checkpoint, save_ply, surgery: only=None) also waits for the event
+        ev = self._late_event
+        if ev is not None and (only is None or (self._late_ids & only)) and not (exclude is not None and self._late_ids <= exclude):
+            torch.cuda.current_stream(self.bucket.flat.device).wait_event(ev)
+            self._late_event = None
 
     def late_event(self):
         """For render(): wait -- on the current stream -- for every outstanding gather EXCEPT the late ones (the SH coefficients),
@@ -284,7 +291,7 @@ class ShardedExchange:
                 g[1].wait()                     # blocks the SIDE stream until the gather is complete
             ev = torch.cuda.Event()
             ev.record(self.side)
-        self._late_event = ev
+        self._late_event, self._late_ids = ev, set().union(*[g[0] for g in late])
         return ev
 
 

@@ -272,23 +272,8 @@ class FusedAdam:
         # the LARGEST stored step (bias corrections differ from the reference's by < 1e-3 relative after a few hundred steps).
         self.step_count = max(steps) if steps else 0
 
-    def step(self, zero_grad=True, keep_grad=(), skip_flag=None, only=None, exclude=None, stream=None, advance=True):
-        """One launch for all parameter tensors (gp_adam_step_multi).  Parameters listed in `keep_grad` are not
-        zeroed: their gradient buffers are marked stale (grad_sink.mark_stale) and the next backward overwrites them.
-        `skip_flag`: optional int32 device word; non-zero = leave parameters and moments untouched (invalid frame).
-        `only` / `exclude`: restrict the launch to a subset of the parameter tensors; `stream`: a torch.cuda.Stream other
-        than the current one; `advance=False` uses step number step_count + 1 without committing it (the first of two
-        partial launches of one optimisation step)."""
-        step_no = self.step_count + 1
-        if advance:
-            self.step_count = step_no
-        n = len(self.items)
-        if not self.bucket.flat.is_cuda:
-            # No CPU implementation ships.  The -m "not gpu" tests of the host logic around this class (sharding, checkpoint
-            # layout, optimizer-state surgery) install their own checker here (tests/host_checkers.py).
-            if FusedAdam.host_step is None:
-                raise RuntimeError("FusedAdam.step: HIP kernels only (no CPU fallback)")
-            return FusedAdam.host_step(self, step_no, zero_grad, {id(p) for p in keep_grad})
+    def _launch(self, n, step_no, zero_grad, keep_ids, skip_flag, only, exclude, stream):
+        """gp_adam_step_multi over the launch table (this rank's slices), restricted by `only` / `exclude`."""
         if not hasattr(self, "_tab"):
             P = (C.c_void_p * n)(*[p.data_ptr() for _, p, _, _, _ in self.items])
             G = (C.c_void_p * n)(*[self.bucket.flat.data_ptr() + 4 * off for _, _, off, _, _ in self.items])
@@ -310,7 +295,6 @@ class FusedAdam:
                 self._num_subsets[key] = sub
             NUM, active = sub
         LR = (C.c_float * n)(*[float(g["lr"]) for g, _, _, _, _ in self.items])
-        keep_ids = {id(p) for p in keep_grad}
         mask = 0
         if zero_grad:
             for k, p in enumerate(self.owner):
@@ -324,19 +308,45 @@ class FusedAdam:
                                                C.c_int64(step_no), C.c_int32(1 if zero_grad else 0), C.c_uint32(mask),
                                                _lib.ptr(skip_flag), sp)
             _lib.check(rc, "gp_adam_step_multi")
-        # the kernel wrote the parameters through raw pointers: bump their version counters, so that whatever caches on
-        # `_version` (GaussianModel's keypoint-weights cache) or saved them for a backward sees the change
-        bump = getattr(torch.autograd.graph, "increment_version", None)
-        if bump is not None:
-            for k, p in enumerate(self.owner):
-                if active is None or active[k]:
-                    bump(p)
+
+    def step(self, zero_grad=True, keep_grad=(), skip_flag=None, only=None, exclude=None, stream=None, advance=True):
+        """One launch for all parameter tensors (gp_adam_step_multi).  Parameters listed in `keep_grad` are not
+        zeroed: their gradient buffers are marked stale (grad_sink.mark_stale) and the next backward overwrites them.
+        `skip_flag`: optional int32 device word; non-zero = leave parameters and moments untouched (invalid frame).
+        `only` / `exclude`: restrict the launch to a subset of the parameter tensors; `stream`: a torch.cuda.Stream other
+        than the current one; `advance=False` uses step number step_count + 1 without committing it (the first of two
+        partial launches of one optimisation step)."""
+        step_no = self.step_count + 1
+        if advance:
+            self.step_count = step_no
+        n = len(self.items)
+        keep_ids = {id(p) for p in keep_grad}
+        if not self.bucket.flat.is_cuda:
+            # No CPU implementation ships.  The -m "not gpu" tests of the host logic around this class (sharding, checkpoint
+            # layout, optimizer-state surgery) install their own checker here (tests/host_checkers.py); the bookkeeping below
+            # (version counters, stale marks, zeroing of foreign slices) is the product's either way.
+            if FusedAdam.host_step is None:
+                raise RuntimeError("FusedAdam.step: HIP kernels only (no CPU fallback)")
+            FusedAdam.host_step(self, step_no, zero_grad, keep_ids)
+        else:
+            self._launch(n, step_no, zero_grad, keep_ids, skip_flag, only, exclude, stream)
         # which PARAMETERS this launch covered -- not only those this rank holds a slice of: under the sharded layout a tensor can
         # lie entirely inside another rank's slice of its region (regions shared by several tensors), and its gradient buffer
         # here still has to be marked stale / zeroed like everyone else's
         inc = {id(p) for p in only} if only is not None else None
         exc = {id(p) for p in exclude} if exclude is not None else set()
         covered = [p for p in self.bucket.params if (inc is None or id(p) in inc) and id(p) not in exc]
+        # The parameters were written through raw pointers (or, on ranks that own no slice of a tensor, will be by the all-gather
+        # into the flat parameter buffer, which does not touch p._version either: p.data is a view with a counter of its own).
+        # Whatever caches on `_version` (GaussianModel's neighbour-search and keypoint-weights caches) or saved a parameter for a
+        # backward must see the change ON EVERY RANK, so every covered parameter is bumped, not only this rank's slices --
+        # otherwise ranks without a slice of _xyz / the keypoints keep blending with stale neighbour indices (rank-divergent
+        # forwards, no error).
+        bump = getattr(torch.autograd.graph, "increment_version", None)
+        if bump is None:
+            raise RuntimeError("torch.autograd.graph.increment_version is missing: cached keypoint weights could not be invalidated")
+        for p in covered:
+            bump(p)
         if zero_grad and keep_ids:
             from . import grad_sink
             for p in covered:

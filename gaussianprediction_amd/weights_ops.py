@@ -134,6 +134,10 @@ class WeightsModel(nn.Module):
         super().__init__()
         if n_output_dims > 16:
             raise RuntimeError("WeightsModel: n_output_dims must be <= 16")
+        if n_levels != 16 or n_features_per_level != 4:
+            # the reference's only configuration [REF scene/gaussian_model.py:370-392]; the fused encode + MLP kernel is built for it
+            raise RuntimeError("WeightsModel: built for n_levels == 16, n_features_per_level == 4 (the reference's hash-grid "
+                               "configuration); other grids are not implemented")
         if per_level_scale is None:
             per_level_scale = math.exp(math.log(2048 / base_resolution) / (n_levels - 1))   # [REF :372]
         self.n_output_dims = n_output_dims
@@ -162,8 +166,6 @@ class WeightsModel(nn.Module):
 
     def forward(self, xyz):
         perm = self.spatial_order(xyz) if xyz.shape[0] > 4096 else None
-        if self.cfg.n_levels != 16:
-            raise RuntimeError("WeightsModel: the fused kernel is built for n_levels == 16 (the reference's configuration)")
         return _WeightsModelFused.apply(xyz, self.params, self.cfg, self.n_output_dims, perm)
 
 

@@ -401,6 +401,13 @@ int gp_debug_option(int key, int value);
 const char* gp_last_error(void);
 const char* gp_version(void);
 
+/* ABI number of this header.  It changes whenever a struct gains / loses a field, an entry point's signature changes or a
+ * buffer-size macro (GP_LOSS_SUM_SLOTS) changes; a binding built against another number must refuse to run (the Python loader
+ * does: gaussianprediction_amd/_lib.py).  History: 1 = rounds 1-2; 2 = round 3 (gp_raster_settings.sh_ready_event / visible,
+ * gp_knn_keypoints' `order`, GP_LOSS_SUM_SLOTS per image size); 3 = round 4 (gp_abi_version itself, packed neighbour indices). */
+#define GP_ABI_VERSION 3
+int gp_abi_version(void);
+
 #ifdef __cplusplus
 }
 #endif

@@ -131,7 +131,10 @@ def _worker_sharded(rank, world, port, out_dir, device="cpu", grouped=False):
     for step in range(3):
         _view_loss([p.cpu() for p in params] if device != "cpu" else params, rank + 10 * step).backward()   # rank r renders view r
         ex.finish()
+        before = [p._version for p in params]
         opt.step()
+        # caches keyed on `_version` must be invalidated on EVERY rank, also for tensors this rank holds no slice of
+        assert all(p._version > b for p, b in zip(params, before)), (rank, [p._version - b for p, b in zip(params, before)])
         ex.gather_params()
         ex.wait_params()
     sd = opt.state_dict()                                         # collective: whole-tensor moments in torch's layout

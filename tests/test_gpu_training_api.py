@@ -282,6 +282,52 @@ def test_two_rank_sharded_adam_equals_replicated_adam(tmp_path, step_opacity):
     assert sh[0]["bytes"] == 4 * sh[0]["n"]          # world 2: reduce-scatter + all-gather move half the flat buffer each, per rank
 
 
+def _rank_main_knn(rank, world, port, out_dir, backend):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch.distributed as dist
+    dev = rank if backend == "nccl" else 0
+    torch.cuda.set_device(dev)
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    from gaussianprediction_amd import gaussian_model as gm
+    from gaussianprediction_amd.weights_ops import WeightsModel
+    pc, cams, gts, raw, rw, idx, args = build(n=3000, dev=f"cuda:{dev}", knn_type="hybird", feature_amplify=5.0)
+    pc.weights_model = WeightsModel(2 * args.nearest_num, device=f"cuda:{dev}")
+    pc.set_keypoint_weights(None, None)            # stage 3 as the reference runs it: weights model + neighbour search inside forward
+    pc.bucket_small_numel = 8000                   # grouped regions: with two ranks one of them owns no slice of _xyz / the keypoints
+    calls, orig = [], gm.knn_keypoints
+    gm.knn_keypoints = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+    ts = TrainStep(pc, cams, gts, 50000, sharded=True)
+    owned = {id(p) for p in pc.optimizer.owner}
+    for step in range(3):
+        ts.step(step * world + rank)
+    ts.sync_params()
+    with torch.no_grad():
+        pc(torch.tensor([0.3], device=f"cuda:{dev}"), 50000)          # one more forward on the final parameters
+    torch.cuda.synchronize()
+    torch.save({"calls": len(calls), "knn": pc._knn_cache[1].cpu(), "xyz": pc._xyz.detach().cpu(),
+                "owns_xyz": id(pc._xyz) in owned, "owns_kp": id(pc.super_gaussians) in owned}, os.path.join(out_dir, f"knn_{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharded_step_recomputes_the_neighbour_search_on_every_rank(tmp_path):
+    """The neighbour-search cache is keyed on parameter versions; under the sharded optimizer a rank that holds no slice of
+    `_xyz` / the keypoints receives their new values through the all-gather only.  Every rank must still see the change: one
+    search per step on each rank, and identical indices at the end (round-3 advisor finding: ranks without a slice kept stale
+    indices)."""
+    import torch.multiprocessing as mp
+    backend = "nccl" if torch.cuda.device_count() >= 2 else "gloo"
+    mp.spawn(_rank_main_knn, args=(2, _free_port(), str(tmp_path), backend), nprocs=2, join=True)
+    r = [torch.load(os.path.join(tmp_path, f"knn_{k}.pt")) for k in range(2)]
+    assert not (r[0]["owns_xyz"] and r[1]["owns_xyz"]) or not (r[0]["owns_kp"] and r[1]["owns_kp"])   # (the hazardous layout is the one tested)
+    for k in range(2):
+        assert r[k]["calls"] == 4, (k, r[k]["calls"])       # 3 training steps + the final forward: the parameters changed each time
+    assert torch.equal(r[0]["xyz"], r[1]["xyz"]) and torch.equal(r[0]["knn"], r[1]["knn"])
+
+
 def _rank_main_rccl_single(rank, world, port, out_dir, sharded):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", GP_DIST_FORCE_SINGLE="1")
     import torch.distributed as dist
