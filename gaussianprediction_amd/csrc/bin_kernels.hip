@@ -1,0 +1,429 @@
+// bin_kernels.hip -- tile binning BY COUNTING: the per-tile splat lists, in depth order, without a sort over the R instances.
+//
+// The public algorithm duplicates every Gaussian into one (tile, depth) key per touched tile and radix-sorts the R keys; rounds
+// 1-3 of this library sorted the Gaussians by depth first (N keys) and then stable-sorted the R (tile, id) pairs by tile id in two
+// radix passes -- 9 launches and ~200 MB of key/value traffic at configs[2].  But "stable sort by tile id of a sequence that is
+// already in depth order" is a COUNTING sort whose histogram has one bin per tile, and on CDNA4 a workgroup's LDS (160 KB) holds
+// that whole histogram (T = 5 440 tiles at 1352 x 1014: 22 KB):
+//
+//   A  gp_bin_count_kernel     block b owns the b-th chunk of the depth-ordered Gaussians: counts its instances per tile in LDS,
+//                              writes the row hist[b][0..T) (and adds its instance count into the R slots)
+//   B  gp_bin_scan_kernel      per tile: exclusive prefix of the counts over the blocks (in place) + the tile's total
+//   C  gp_bin_scatter_kernel   every block: tile_start = exclusive scan of the totals (block 0 also writes `ranges` and the status
+//                              word), then walks its chunk again and stores every instance's Gaussian id at
+//                              tile_start[tile] + (instances of that tile in earlier blocks / waves / steps / lanes)
+//
+// Order inside a tile = block order, then wave order (wave w owns the w-th quarter of the chunk), then the 64-instance steps of the
+// wave, then lane order, with the ranks of equal tiles inside a step from wave64 match-any ballots: exactly the depth order, so the
+// result is bit-identical to the stable sort it replaces (tests/test_gpu_raster.py compares the whole point_list with the
+// oracle's).  No key array exists any more: instances are never materialised, only their final slots are written.
+// Traffic: 2 x 12 B per Gaussian + 4 B per instance + 3 x 4 B x T x NB of histogram (11 MB at NB = 489) instead of 48 B per instance.
+#include "gp_common.h"
+#include "raster_kernels.h"
+#include <stdlib.h>
+
+#define BIN_THREADS 256
+#define BIN_WAVES (BIN_THREADS / GP_WAVE)
+#define BIN_SEGS 16                // gp_bin_scan_kernel: 16 waves, each sums a 16th of the blocks
+#define BIN_SEG_MAX 32             // ... with up to 32 counters per thread in registers (NB <= 512)
+
+// inclusive wave64 scans on the DPP network (row_shr 1 / 2 / 4 / 8 inside the rows of 16 lanes, row_bcast 15 / 31 across them): no
+// LDS round trips -- __shfl_up is a ds_bpermute, six DEPENDENT trips per scan, and these kernels run at one to three waves per
+// SIMD, where nothing hides them
+#define BIN_DPP(x, ctrl, rmask) __builtin_amdgcn_update_dpp(0, (x), (ctrl), (rmask), 0xf, false)
+__device__ __forceinline__ int bin_scan_add(int x) {
+    x += BIN_DPP(x, 0x111, 0xf); x += BIN_DPP(x, 0x112, 0xf); x += BIN_DPP(x, 0x114, 0xf); x += BIN_DPP(x, 0x118, 0xf);
+    x += BIN_DPP(x, 0x142, 0xa); x += BIN_DPP(x, 0x143, 0xc);
+    return x;
+}
+__device__ __forceinline__ int bin_scan_max(int x) {          // (values >= 0)
+    x = max(x, BIN_DPP(x, 0x111, 0xf)); x = max(x, BIN_DPP(x, 0x112, 0xf)); x = max(x, BIN_DPP(x, 0x114, 0xf)); x = max(x, BIN_DPP(x, 0x118, 0xf));
+    x = max(x, BIN_DPP(x, 0x142, 0xa)); x = max(x, BIN_DPP(x, 0x143, 0xc));
+    return x;
+}
+
+// Instances of the 64 Gaussians of a wave, 128 at a time.  Lane g holds Gaussian g's run (cnt = w * h tiles of the rectangle at
+// (minx, miny), row-major); the runs are laid end to end (exclusive scan of cnt) and an iteration covers instances [b, b + 128) as
+// two steps of 64.  Which Gaussian owns instance j: every run that begins inside the iteration -- or reaches into it from before --
+// marks its first slot in LDS, and an inclusive max-scan over the lanes spreads the marks (a binary search over the run starts, as
+// gp_duplicate_kernel does it, is six dependent LDS trips; here there are two per iteration, and the two steps' chains overlap).
+// The owner's rectangle comes back from the per-wave table s_own with one 16-byte read.
+// f(valid, tile, id) is called once per step by all lanes, steps in order.  BinWave: this wave's LDS scratch (marks zero on entry
+// and on exit).
+struct BinWave {
+    int4 own[64];            // (run start, first tile x, first tile y, tiles per row)
+    uint32_t id[64];
+    int mark[128];
+};
+template <bool WITH_ID, class F>
+__device__ __forceinline__ void bin_walk(int lane, BinWave& sw, int cnt, int minx, int miny, int w, uint32_t id, int gx, F&& f) {
+    const int incl = bin_scan_add(cnt);
+    const int total = __builtin_amdgcn_readlane(incl, 63);
+    const int start = incl - cnt;
+    sw.own[lane] = make_int4(start, minx, miny, w);
+    if (WITH_ID) sw.id[lane] = id;
+    for (int b = 0; b < total; b += 128) {
+        const bool mine = cnt > 0 && start < b + 128 && start + cnt > b;
+        const int mpos = start > b ? start - b : 0;
+        if (mine) sw.mark[mpos] = lane + 1;
+        __builtin_amdgcn_wave_barrier();
+        int m0 = sw.mark[lane], m1 = sw.mark[64 + lane];
+        __builtin_amdgcn_wave_barrier();
+        if (mine) sw.mark[mpos] = 0;
+        m0 = bin_scan_max(m0);                       // (slot 0 of an iteration is always marked: m0 >= 1 in every lane)
+        m1 = max(bin_scan_max(m1), __builtin_amdgcn_readlane(m0, 63));
+        const int4 o0 = sw.own[m0 - 1], o1 = sw.own[m1 - 1];
+        uint32_t id0 = 0, id1 = 0;
+        if (WITH_ID) { id0 = sw.id[m0 - 1]; id1 = sw.id[m1 - 1]; }
+        {
+            const int j = b + lane, k = j - o0.x;
+            int yy = (int)((float)k * __builtin_amdgcn_rcpf((float)o0.w));       // k / w: the reciprocal estimate, corrected to the exact quotient
+            if (yy * o0.w > k) --yy;
+            else if ((yy + 1) * o0.w <= k) ++yy;
+            f(j < total, (uint32_t)((o0.z + yy) * gx + o0.y + (k - yy * o0.w)), id0);
+        }
+        if (b + 64 < total) {
+            const int j = b + 64 + lane, k = j - o1.x;
+            int yy = (int)((float)k * __builtin_amdgcn_rcpf((float)o1.w));
+            if (yy * o1.w > k) --yy;
+            else if ((yy + 1) * o1.w <= k) ++yy;
+            f(j < total, (uint32_t)((o1.z + yy) * gx + o1.y + (k - yy * o1.w)), id1);
+        }
+    }
+    __builtin_amdgcn_wave_barrier();                 // (the table is rewritten by the next chunk)
+}
+
+__device__ __forceinline__ void bin_unpack(const uint2 r, bool ok, int& cnt, int& minx, int& miny, int& w) {
+    minx = (int)(r.x & 0xFFFFu); miny = (int)(r.x >> 16);
+    w = (int)(r.y & 0xFFFFu);
+    cnt = ok ? w * (int)(r.y >> 16) : 0;
+    if (w < 1) w = 1;
+}
+
+// A wave keeps ALL of its Gaussians in registers, CH chunks of 64 (loaded once, up front, in one burst): on this part stores and
+// loads share one in-order counter (vmcnt), so a load waited for behind the scatter's stores waits for the stores' acknowledgements
+// too -- per chunk, with two waves per SIMD to cover it (measured: 57 of the scatter's 82 us).  The chunk loop stays rolled; the
+// chunk's registers are picked by a compare-select chain over the (uniform) chunk index.
+template <int CH>
+__device__ __forceinline__ uint32_t bin_pick(const uint32_t (&a)[CH], int c) {
+    uint32_t r = a[0];
+    c = __builtin_amdgcn_readfirstlane(c);       // (the chunk index is uniform: the select masks live in scalar registers)
+#pragma unroll
+    for (int k = 1; k < CH; ++k) {      // (the empty asm keeps the chain a chain: without it the compiler turns it back into an
+        r = (c == k) ? a[k] : r;        // indexed load from a scratch copy of the array -- global memory)
+        asm volatile("" : "+v"(r));
+    }
+    return r;
+}
+
+// A.  grid = NB blocks of G depth-ordered Gaussians; dynamic LDS: T counters.  Counting is order-free, so the block is 16 waves
+// (each walks a 16th of the chunk: the walk is a chain of LDS round trips, and only more waves hide them).
+#define BINA_THREADS 1024
+#define BINA_WAVES (BINA_THREADS / GP_WAVE)
+template <int CH>
+__global__ __launch_bounds__(BINA_THREADS) void gp_bin_count_kernel(int N, int gx, int T, const uint2* __restrict__ rect_sorted,
+                                                                   uint32_t* __restrict__ hist, uint32_t* __restrict__ total_slots) {
+    extern __shared__ uint32_t s_dyn[];
+    __shared__ BinWave s_w[BINA_WAVES];
+    __shared__ uint32_t s_part[BINA_WAVES];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int G = CH * 64 * BINA_WAVES;
+    const int i_begin = blockIdx.x * G + wave * (CH * 64);
+    uint32_t rx[CH], ry[CH];
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+        const int i = i_begin + c * 64 + lane;
+        const uint2 r = rect_sorted[i < N ? i : N - 1];
+        rx[c] = r.x; ry[c] = i < N ? r.y : 0u;                                // (tiles per row | rows: 0 rows = no instances)
+    }
+    for (int t = tid; t < T; t += BINA_THREADS) s_dyn[t] = 0u;
+    s_w[wave].mark[lane] = 0; s_w[wave].mark[64 + lane] = 0;
+    __syncthreads();
+    uint32_t mine_total = 0;
+#pragma unroll 1
+    for (int c = 0; c < CH; ++c) {
+        if (i_begin + c * 64 >= N) break;
+        int cnt, minx, miny, w;
+        bin_unpack(make_uint2(bin_pick<CH>(rx, c), bin_pick<CH>(ry, c)), true, cnt, minx, miny, w);
+        mine_total += (uint32_t)cnt;
+        bin_walk<false>(lane, s_w[wave], cnt, minx, miny, w, 0u, gx, [&](bool valid, uint32_t tile, uint32_t) {
+            if (valid) atomicAdd(&s_dyn[tile], 1u);                           // (integer LDS atomic, no return: order-free)
+        });
+    }
+#pragma unroll
+    for (int dd = 32; dd >= 1; dd >>= 1) mine_total += __shfl_xor(mine_total, dd);
+    if (lane == 0) s_part[wave] = mine_total;
+    __syncthreads();
+    uint32_t* row = hist + (size_t)blockIdx.x * T;
+    for (int t = tid; t < T; t += BINA_THREADS) row[t] = s_dyn[t];
+    if (tid == 0) {
+        uint32_t tot = 0;
+        for (int w2 = 0; w2 < BINA_WAVES; ++w2) tot += s_part[w2];
+        if (tot) atomicAdd(total_slots + (blockIdx.x % GP_TOTAL_SLOTS), tot);
+    }
+}
+
+// B.  grid = ceil(T / 64) workgroups of 16 waves: lane = tile (64 consecutive tiles: every load is one 256-byte line), wave =
+// segment of the blocks.  hist[b][t] <- sum over b' < b of hist[b'][t];  totals[t] = the column sum.
+__global__ __launch_bounds__(64 * BIN_SEGS) void gp_bin_scan_kernel(uint32_t* __restrict__ hist, int NB, int T, uint32_t* __restrict__ totals) {
+    __shared__ uint32_t s_tot[BIN_SEGS][64];
+    const int lane = threadIdx.x & 63, seg = threadIdx.x >> 6;
+    const int t = blockIdx.x * 64 + lane;
+    const bool live = t < T;
+    const int per = (NB + BIN_SEGS - 1) / BIN_SEGS;
+    const int b0 = seg * per;
+    int b1 = b0 + per;
+    if (b1 > NB) b1 = NB;
+    uint32_t sum = 0;
+    if (per <= BIN_SEG_MAX) {
+        uint32_t v[BIN_SEG_MAX];
+#pragma unroll
+        for (int k = 0; k < BIN_SEG_MAX; ++k) v[k] = (live && b0 + k < b1) ? hist[(size_t)(b0 + k) * T + t] : 0u;
+#pragma unroll
+        for (int k = 0; k < BIN_SEG_MAX; ++k) sum += v[k];
+        s_tot[seg][lane] = sum;
+        __syncthreads();
+        uint32_t run = 0, tot = 0;
+#pragma unroll
+        for (int s2 = 0; s2 < BIN_SEGS; ++s2) { const uint32_t x = s_tot[s2][lane]; run += s2 < seg ? x : 0u; tot += x; }
+#pragma unroll
+        for (int k = 0; k < BIN_SEG_MAX; ++k) {
+            if (live && b0 + k < b1) hist[(size_t)(b0 + k) * T + t] = run;
+            run += v[k];
+        }
+        if (seg == 0 && live) totals[t] = tot;
+    } else {                                   // more than 512 blocks: two passes over the column (the second one hits L2)
+        for (int b = b0; b < b1; ++b) sum += live ? hist[(size_t)b * T + t] : 0u;
+        s_tot[seg][lane] = sum;
+        __syncthreads();
+        uint32_t run = 0, tot = 0;
+        for (int s2 = 0; s2 < BIN_SEGS; ++s2) { const uint32_t x = s_tot[s2][lane]; run += s2 < seg ? x : 0u; tot += x; }
+        for (int b = b0; b < b1 && live; ++b) {
+            const uint32_t x = hist[(size_t)b * T + t];
+            hist[(size_t)b * T + t] = run;
+            run += x;
+        }
+        if (seg == 0 && live) totals[t] = tot;
+    }
+}
+
+// C.  grid = NB (the blocks of A).  dynamic LDS: s_base[T] u32 | s_cnt[BIN_WAVES][ceil(T / 2)] (two u16 counters per word: a wave's
+// quarter of a chunk holds at most G / 4 < 65 536 Gaussians, and a Gaussian puts at most one instance into a tile).
+template <int CH>
+__global__ __launch_bounds__(BIN_THREADS) void gp_bin_scatter_kernel(int N, int gx, int T,
+                                                                     const uint32_t* __restrict__ sorted_ids,
+                                                                     const uint2* __restrict__ rect_sorted,
+                                                                     const uint32_t* __restrict__ hist_scanned,
+                                                                     const uint32_t* __restrict__ totals,
+                                                                     uint32_t* __restrict__ point_list, uint32_t capacity,
+                                                                     int2* __restrict__ ranges, uint32_t* __restrict__ status, int ablate) {
+    extern __shared__ uint32_t s_dyn[];
+    __shared__ BinWave s_w[BIN_WAVES];
+    __shared__ uint32_t s_wsum[BIN_WAVES];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int G = CH * 64 * BIN_WAVES;
+    const int i_begin = blockIdx.x * G + wave * (CH * 64);
+    uint32_t rx[CH], ry[CH], rid[CH];           // this wave's Gaussians: tile rectangle and id, the only global loads of the walks
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+        const int i = i_begin + c * 64 + lane;
+        const uint2 r = rect_sorted[i < N ? i : N - 1];
+        rx[c] = r.x; ry[c] = i < N ? r.y : 0u;
+        rid[c] = sorted_ids[i < N ? i : N - 1];
+    }
+    const int words = (T + 1) / 2;
+    uint32_t* s_base = s_dyn;
+    uint32_t* s_cnt = s_dyn + T;
+    // ---- tile_start = exclusive scan of the T totals (every block for itself: T <= 8192 values out of L2, ~2 us in parallel with
+    // the 500 other blocks, instead of one more launch)
+    // (every global load of the prologue leaves up front -- the T totals and this block's row of scanned counts, up to 2 x 32 per
+    // thread: as two loops of load -> LDS store they were 2 x 22 dependent round trips to L2, 60 of the kernel's 86 us)
+    constexpr int PRE = GP_BIN_MAX_TILES / BIN_THREADS;
+    uint32_t tv[PRE], rv[PRE];
+    {
+        const uint32_t* row = hist_scanned + (size_t)blockIdx.x * T;
+#pragma unroll
+        for (int k = 0; k < PRE; ++k) {
+            const int t = tid + k * BIN_THREADS;
+            tv[k] = (k * BIN_THREADS < T) ? totals[t < T ? t : T - 1] : 0u;
+            rv[k] = (k * BIN_THREADS < T) ? row[t < T ? t : T - 1] : 0u;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < PRE; ++k) {
+        const int t = tid + k * BIN_THREADS;
+        if (t < T) s_base[t] = tv[k];
+    }
+    for (int i = tid; i < BIN_WAVES * words; i += BIN_THREADS) s_cnt[i] = 0u;
+    s_w[wave].mark[lane] = 0; s_w[wave].mark[64 + lane] = 0;
+    __syncthreads();
+    {
+        const int PT = (T + BIN_THREADS - 1) / BIN_THREADS;
+        const int t0 = tid * PT;
+        int t1 = t0 + PT;
+        if (t1 > T) t1 = T;
+        uint32_t loc = 0;
+        for (int t = t0; t < t1; ++t) loc += s_base[t];
+        uint32_t x = (uint32_t)bin_scan_add((int)loc);
+        if (lane == 63) s_wsum[wave] = x;
+        __syncthreads();
+        uint32_t run = x - loc;
+        for (int w2 = 0; w2 < wave; ++w2) run += s_wsum[w2];
+        for (int t = t0; t < t1; ++t) {
+            const uint32_t c = s_base[t];
+            s_base[t] = run;
+            run += c;
+        }
+        if (blockIdx.x == 0 && tid == BIN_THREADS - 1 && status) {      // (the last thread's running sum is the grand total R)
+            status[0] = run;
+            status[1] = run > capacity ? 1u : 0u;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < PRE; ++k) {
+        const int t = tid + k * BIN_THREADS;
+        if (t < T) {
+            const uint32_t st = s_base[t];
+            if (blockIdx.x == 0) {              // per-tile [start, end) -- cut at the capacity (capacity mode, overflow: flagged above)
+                const uint32_t c = tv[k];
+                const uint32_t lo = st < capacity ? st : capacity, hi = st + c < capacity ? st + c : capacity;
+                ranges[t] = c ? make_int2((int)lo, (int)hi) : make_int2(0, 0);
+            }
+            s_base[t] = st + rv[k];
+        }
+    }
+    // ---- pass 1: this wave's instances per tile
+    uint32_t* my_cnt = s_cnt + wave * words;
+    if (!(ablate & 1)) {
+#pragma unroll 1
+        for (int c = 0; c < CH; ++c) {
+            if (i_begin + c * 64 >= N) break;
+            int cnt, minx, miny, w;
+            bin_unpack(make_uint2(bin_pick<CH>(rx, c), bin_pick<CH>(ry, c)), true, cnt, minx, miny, w);
+            bin_walk<false>(lane, s_w[wave], cnt, minx, miny, w, 0u, gx, [&](bool valid, uint32_t tile, uint32_t) {
+                if (valid) atomicAdd(&my_cnt[tile >> 1], 1u << (16u * (tile & 1u)));
+            });
+        }
+    }
+    __syncthreads();
+    // ---- exclusive prefix over the waves, both halves of a word at once (sums stay below 65 536)
+    for (int i = tid; i < words; i += BIN_THREADS) {
+        uint32_t run = 0;
+#pragma unroll
+        for (int w2 = 0; w2 < BIN_WAVES; ++w2) {
+            const uint32_t c = s_cnt[w2 * words + i];
+            s_cnt[w2 * words + i] = run;
+            run += c;
+        }
+    }
+    __syncthreads();
+    // ---- pass 2: the same walk, now placing every instance
+    if (!(ablate & 2)) {
+#pragma unroll 1
+        for (int c = 0; c < CH; ++c) {
+            if (i_begin + c * 64 >= N) break;
+            int cnt, minx, miny, w;
+            bin_unpack(make_uint2(bin_pick<CH>(rx, c), bin_pick<CH>(ry, c)), true, cnt, minx, miny, w);
+            const uint32_t id = bin_pick<CH>(rid, c);
+            bin_walk<true>(lane, s_w[wave], cnt, minx, miny, w, id, gx, [&](bool valid, uint32_t tile, uint32_t oid) {
+                // Rank among the step's lanes that hit the same tile.  Equal tiles inside one step are the exception (the 64
+                // instances belong to ~16 Gaussians scattered over the screen), so the step asks the counters instead of matching
+                // all lanes against all lanes: read the (wave, tile) count, add one per lane (an atomic that returns nothing), read
+                // it again -- three LDS operations issued back to back, executed in program order, ONE round trip.  A count that
+                // went up by exactly one had a single hit: its lane's slot is the count before.  Lanes whose count went up by more
+                // (0.7 tiles per step at configs[2], in 28 % of the steps) are matched against each other bit by bit (lower lane =
+                // earlier instance = in front).  [A `while (tiles left)` loop over those tiles with readlane + ballot measured 3x the
+                // cost of this fixed 13-ballot block.]
+                const uint32_t sh = 16u * (tile & 1u);
+                const uint32_t tsafe = valid ? tile : 0u;
+                const uint32_t a_cnt = (uint32_t)(uintptr_t)&my_cnt[tsafe >> 1], a_base = (uint32_t)(uintptr_t)&s_base[tsafe];
+                const uint32_t inc = valid ? (1u << sh) : 0u;
+                uint32_t w0, w1, tbase;
+                // (spelled out: a volatile C++ access to LDS becomes a flat load with its own vmcnt wait)
+                asm volatile("ds_read_b32 %0, %3\n\t"
+                             "ds_add_u32 %3, %4\n\t"
+                             "ds_read_b32 %1, %3\n\t"
+                             "ds_read_b32 %2, %5\n\t"
+                             "s_waitcnt lgkmcnt(0)"
+                             : "=&v"(w0), "=&v"(w1), "=&v"(tbase) : "v"(a_cnt), "v"(inc), "v"(a_base) : "memory");
+                const uint32_t c0 = (w0 >> sh) & 0xFFFFu, hits = ((w1 >> sh) & 0xFFFFu) - c0;
+                uint32_t rank = 0;
+                const bool isdup = valid && hits > 1u;
+                const unsigned long long dup = __ballot(isdup);
+                if (dup) {            // (28 % of the steps at configs[2]) match the duplicated lanes against each other, bit by bit
+                    unsigned long long peers = dup;
+#pragma unroll
+                    for (int b = 0; b < 13; ++b) {               // (T <= GP_BIN_MAX_TILES = 2^13)
+                        const bool bit = (tile >> b) & 1u;
+                        const unsigned long long mm = __ballot(bit);
+                        peers &= bit ? mm : ~mm;
+                    }
+                    if (isdup) rank = gp_mbcnt(peers);
+                }
+                if (valid) {
+                    const uint32_t pos = tbase + c0 + rank;
+                    if (pos < capacity && !(ablate & 4)) point_list[pos] = oid;      // (capacity-mode overflow: the lists are cut at the capacity)
+                }
+            });
+        }
+    }
+}
+
+// ---- host side ---------------------------------------------------------------------------------------------------------------------
+// Gaussians per block G = 2048, 4096 or 8192 (8 / 16 / 32 register-resident chunks per wave of the scatter kernel), at most 512
+// blocks: up to 4.2 M Gaussians; beyond that -- or beyond GP_BIN_MAX_TILES tiles -- the caller falls back to duplicate + radix sort.
+// (gp_debug_option(5, 1) forces that path: the A/B switch of tools/ and of the parity tests)
+bool gp_bin_supported(size_t N, size_t T) { return N > 0 && N <= 512u * 8192u && T >= 1 && T <= GP_BIN_MAX_TILES && gp_debug_get(5) == 0; }
+
+GpBinPlan gp_bin_plan(size_t N, size_t T) {
+    GpBinPlan p;
+    size_t G = 2048;
+    while ((N + G - 1) / G > 512 && G < 8192) G *= 2;
+    p.G = (int)G;
+    p.NB = (int)((N + G - 1) / G);
+    p.hist_elems = (size_t)p.NB * T + T + 64;             // rows + totals
+    return p;
+}
+
+int gp_bin_count(const GpBinPlan& p, size_t N, int gx, size_t T, const uint2* rect_sorted, uint32_t* hist, uint32_t* total_slots, hipStream_t s) {
+    const dim3 grid((unsigned)p.NB), block(BINA_THREADS);
+    const size_t lds = T * sizeof(uint32_t);
+    if (p.G == 2048) hipLaunchKernelGGL(gp_bin_count_kernel<2>, grid, block, lds, s, (int)N, gx, (int)T, rect_sorted, hist, total_slots);
+    else if (p.G == 4096) hipLaunchKernelGGL(gp_bin_count_kernel<4>, grid, block, lds, s, (int)N, gx, (int)T, rect_sorted, hist, total_slots);
+    else if (p.G == 8192) hipLaunchKernelGGL(gp_bin_count_kernel<8>, grid, block, lds, s, (int)N, gx, (int)T, rect_sorted, hist, total_slots);
+    else GP_FAIL("bin: unsupported block size %d", p.G);
+    GP_LAUNCH_CHECK();
+    return 0;
+}
+
+template <int CH>
+static int bin_scatter_launch(const GpBinPlan& p, size_t N, int gx, size_t T, const uint32_t* sorted_ids, const uint2* rect_sorted, const uint32_t* hist,
+                              const uint32_t* totals, uint32_t* point_list, uint32_t capacity, int2* ranges, uint32_t* status, size_t lds, hipStream_t s) {
+    static thread_local size_t lds_set = 0;
+    if (lds > 48 * 1024 && lds > lds_set) {
+        GP_HIP_CHECK(hipFuncSetAttribute((const void*)gp_bin_scatter_kernel<CH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        lds_set = lds;
+    }
+    hipLaunchKernelGGL(gp_bin_scatter_kernel<CH>, dim3((unsigned)p.NB), dim3(BIN_THREADS), lds, s, (int)N, gx, (int)T, sorted_ids, rect_sorted, hist,
+                       totals, point_list, capacity, ranges, status, gp_debug_get(6));
+    GP_LAUNCH_CHECK();
+    return 0;
+}
+
+int gp_bin_scatter(const GpBinPlan& p, size_t N, int gx, size_t T, const uint32_t* sorted_ids, const uint2* rect_sorted, uint32_t* hist,
+                   uint32_t* point_list, uint32_t capacity, int2* ranges, uint32_t* status, hipStream_t s) {
+    uint32_t* totals = hist + (size_t)p.NB * T;
+    {
+        GpProfScope _p("bin_scan", s);
+        hipLaunchKernelGGL(gp_bin_scan_kernel, dim3((unsigned)((T + 63) / 64)), dim3(64 * BIN_SEGS), 0, s, hist, p.NB, (int)T, totals);
+        GP_LAUNCH_CHECK();
+    }
+    const size_t lds = (T + BIN_WAVES * ((T + 1) / 2)) * sizeof(uint32_t);
+    if (gp_debug_get(6)) GP_HIP_CHECK(hipMemsetAsync(point_list, 0, (size_t)capacity * 4, s));   // (ablation runs leave slots unwritten: id 0 is a valid one)
+    GpProfScope _p("bin_scatter", s);
+    if (p.G == 2048) return bin_scatter_launch<8>(p, N, gx, T, sorted_ids, rect_sorted, hist, totals, point_list, capacity, ranges, status, lds, s);
+    if (p.G == 4096) return bin_scatter_launch<16>(p, N, gx, T, sorted_ids, rect_sorted, hist, totals, point_list, capacity, ranges, status, lds, s);
+    if (p.G == 8192) return bin_scatter_launch<32>(p, N, gx, T, sorted_ids, rect_sorted, hist, totals, point_list, capacity, ranges, status, lds, s);
+    GP_FAIL("bin: unsupported block size %d", p.G);
+}

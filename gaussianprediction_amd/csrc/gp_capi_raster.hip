@@ -117,19 +117,24 @@ extern "C" int gp_raster_forward(const gp_raster_settings* st, const gp_raster_i
         GpCarver tc0(nullptr);
         const size_t hist_elems = gp_sort_hist_elems(N);
         const size_t scan_elems = gp_scan_tmp_elems(256 * ((N + 4095) / 4096) > N + 1 ? 256 * ((N + 4095) / 4096) : N + 1) + (N + GP_SCAN_TILE - 1) / GP_SCAN_TILE + 64;
+        // binning by counting (bin_kernels.hip) whenever the per-tile histogram fits a workgroup's LDS; else duplicate + radix sort
+        const bool counting = gp_bin_supported(N, T);
+        GpBinPlan bp = {0, 0, 0};
+        if (counting) bp = gp_bin_plan(N, T);
         auto carve_tmp = [&](GpCarver& c, uint32_t*& k0, uint32_t*& k1, uint32_t*& v0, uint32_t*& v1, uint2*& tiles,
-                             uint2*& rects, uint32_t*& tt, uint32_t*& hist, uint32_t*& scan_tmp) {
+                             uint2*& rects, uint32_t*& tt, uint32_t*& hist, uint32_t*& scan_tmp, uint32_t*& binhist) {
             k0 = c.take<uint32_t>(N); k1 = c.take<uint32_t>(N); v0 = c.take<uint32_t>(N); v1 = c.take<uint32_t>(N);
             tiles = c.take<uint2>(N); rects = c.take<uint2>(N); tt = c.take<uint32_t>(N + 1);
             hist = c.take<uint32_t>(hist_elems); scan_tmp = c.take<uint32_t>(scan_elems);
+            binhist = c.take<uint32_t>(bp.hist_elems);
         };
-        uint32_t *k0, *k1, *v0, *v1, *tt, *hist, *scan_tmp;
+        uint32_t *k0, *k1, *v0, *v1, *tt, *hist, *scan_tmp, *binhist;
         uint2 *tiles, *rects;      // per-Gaussian tile rectangle by id, and the same in depth order
-        carve_tmp(tc0, k0, k1, v0, v1, tiles, rects, tt, hist, scan_tmp);
+        carve_tmp(tc0, k0, k1, v0, v1, tiles, rects, tt, hist, scan_tmp, binhist);
         void* tmp = alloc(alloc_ctx, GP_BUF_TEMP, tc0.bytes());
         if (!tmp) GP_FAIL("allocator returned NULL for TEMP (%zu B)", tc0.bytes());
         GpCarver tc(tmp);
-        carve_tmp(tc, k0, k1, v0, v1, tiles, rects, tt, hist, scan_tmp);
+        carve_tmp(tc, k0, k1, v0, v1, tiles, rects, tt, hist, scan_tmp, binhist);
 
         {
             GpProfScope _p("preprocess_fwd", s);
@@ -157,7 +162,10 @@ extern "C" int gp_raster_forward(const gp_raster_settings* st, const gp_raster_i
         const uint32_t* sorted_ids = sb.v[r1];
         // tile counts -> instance offsets: scanned inside blocks here, finished by the duplicate kernel (one launch, not three)
         uint32_t* block_sums = scan_tmp;
-        if (gp_scan_blocks_u32(tt, N, block_sums, il.total, s)) return 1;
+        if (counting) {         // per-(block, tile) instance counts; the blocks' totals go into the R slots
+            GpProfScope _p("bin_count", s);
+            if (gp_bin_count(bp, N, d.gx, T, rects, binhist, il.total, s)) return 1;
+        } else if (gp_scan_blocks_u32(tt, N, block_sums, il.total, s)) return 1;
         const bool capacity_mode = st->binning_capacity > 0;
         if (capacity_mode) {    // no host synchronisation: everything below is sized by the caller's capacity
             if (!st->binning_status) GP_FAIL("binning_capacity needs binning_status (device, 2 words)");
@@ -172,13 +180,20 @@ extern "C" int gp_raster_forward(const gp_raster_settings* st, const gp_raster_i
             if (Rsum > 0x7FFFFF00ull) GP_FAIL("too many tile-splat instances (%llu)", (unsigned long long)Rsum);
             R = (uint32_t)Rsum;
             if (R > 0x7FFFFF00u) GP_FAIL("too many tile-splat instances (%u)", R);
-            if (st->binning_status) {   // exact mode reports R too (a caller sizing its capacity reads it from here)
+            if (st->binning_status && (!counting || R == 0)) {   // exact mode reports R too (a caller sizing its capacity reads it from here; the counting path's scatter writes it)
                 hipLaunchKernelGGL(gp_binning_status_kernel, dim3(1), dim3(1), 0, s, il.total, 0xFFFFFFFFu, st->binning_status);
                 GP_LAUNCH_CHECK();
             }
         }
 
-        if (R > 0) {
+        if (R > 0 && counting) {
+            const size_t bin_bytes = gp_align_up((size_t)R * 4, 256) + gp_align_up((size_t)R + 4, 256);
+            void* bin = alloc(alloc_ctx, GP_BUF_BINNING, bin_bytes);
+            if (!bin) GP_FAIL("allocator returned NULL for BINNING");
+            point_list = (uint32_t*)bin;
+            saved->binning = bin; saved->binning_bytes = bin_bytes;
+            if (gp_bin_scatter(bp, N, d.gx, T, sorted_ids, rects, binhist, point_list, R, il.ranges, st->binning_status, s)) return 1;
+        } else if (R > 0) {
             // capacity mode pads the keys with 0xFFFFFFFF: its low `tbits` bits must sort behind every real tile id
             const int tbits = tile_bits_for((int)T + (capacity_mode ? 1 : 0));
             const int passes = (tbits + 7) / 8;
@@ -237,7 +252,7 @@ extern "C" int gp_raster_forward(const gp_raster_settings* st, const gp_raster_i
         GP_LAUNCH_CHECK();
     }
     { GpProfScope _p("composite_fwd", s, 1);
-        hipLaunchKernelGGL(gp_debug_get(0) == 1 ? gp_composite_fwd_kernel : (gp_debug_get(0) == 2 ? gp_composite_fwd_sbc_kernel : gp_composite_fwd_sb_kernel), dim3((unsigned)T), dim3(256), 0, s, d, il.ranges, point_list, gl.rec, st->bg,
+        hipLaunchKernelGGL((gp_debug_get(0) == 2 ? gp_composite_fwd_sbc_kernel : gp_composite_fwd_sb_kernel), dim3((unsigned)T), dim3(256), 0, s, d, il.ranges, point_list, gl.rec, st->bg,
                        out->color, out->depth, out->tidx, il.final_T, il.n_contrib, il.order, il.tile_work,
                        point_list ? (uint8_t*)point_list + gp_align_up((size_t)R * 4, 256) : (uint8_t*)nullptr);
     GP_LAUNCH_CHECK(); }

@@ -51,15 +51,7 @@ __global__ __launch_bounds__(256) void gp_tile_ranges_kernel(const uint32_t* __r
 __global__ void gp_binning_status_kernel(const uint32_t* __restrict__ total, uint32_t capacity, uint32_t* __restrict__ status);
 
 __global__ __launch_bounds__(1024) void gp_tile_order_kernel(const int2* __restrict__ ranges, const int32_t* __restrict__ work_hint, int T, uint32_t* __restrict__ order);
-__global__ __launch_bounds__(256) void gp_composite_fwd_kernel(RasterDims d, const int2* __restrict__ ranges,
-                                                                      const uint32_t* __restrict__ point_list,
-                                                                      const float4* __restrict__ rec,
-                                                                      const float* __restrict__ bg,
-                                                                      float* __restrict__ out_color,
-                                                                      float* __restrict__ out_depth,
-                                                                      int32_t* __restrict__ out_tidx,
-                                                                      float* __restrict__ final_T,
-                                                                      int32_t* __restrict__ n_contrib, const uint32_t* __restrict__ order, int32_t* __restrict__ tile_work, uint8_t* __restrict__ qmask);
+
 
 
 __global__ __launch_bounds__(256) void gp_preprocess_bwd_kernel(RasterDims d, const float* __restrict__ means3D, const float* __restrict__ scales,      const float* __restrict__ rotations, const float* __restrict__ shs, const float* __restrict__ shs_rest,      const float* __restrict__ cov3D_precomp, const float* __restrict__ view, const float* __restrict__ proj,      const float* __restrict__ campos, const int32_t* __restrict__ radii, const uint8_t* __restrict__ clamped,      const float* __restrict__ g_mean2D, const float* __restrict__ g_conic, const float* __restrict__ g_opacity,      const float* __restrict__ g_color, const float* __restrict__ g_depth, float* __restrict__ dL_dmeans3D,      float* __restrict__ dL_dmeans2D, float* __restrict__ dL_dshs, float* __restrict__ dL_dshs_rest,      float* __restrict__ dL_dcolors, float* __restrict__ dL_dopacities, float* __restrict__ dL_dscales,      float* __restrict__ dL_drots, float* __restrict__ dL_dcov3D, int accumulate_shs, AdamFuseDev af);

@@ -15,6 +15,7 @@
 #include "raster_kernels.h"
 
 // SH constants [REF utils/sh_utils.py:26-44]
+#define GP_LOG2E 1.4426950408889634f      // 0x3fb8aa3b
 __device__ static const float SH_C0 = 0.28209479177387814f;
 __device__ static const float SH_C1 = 0.4886025119029199f;
 __device__ static const float SH_C2[5] = {1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f,
@@ -350,9 +351,12 @@ __device__ __forceinline__ void preprocess_fwd_body(RasterDims d, const float* _
     depth_key[i] = __float_as_uint(pv.z);
     // tile rectangle (first tile | extent, 16 bits each): the binning stage expands it without touching `rec` again
     tiles_touched[i] = make_uint2((uint32_t)minx | ((uint32_t)miny << 16), (uint32_t)(maxx - minx) | ((uint32_t)(maxy - miny) << 16));
-    rec[3 * (size_t)i + 0] = make_float4(pix, piy, -0.5f * conx, -cony);
-    rec[3 * (size_t)i + 1] = make_float4(-0.5f * conz, opac, pv.z, __int_as_float(i));
-    rec[3 * (size_t)i + 2] = make_float4(col[0], col[1], col[2], 0.f);
+    // The composite evaluates alpha = min(0.99, opacity exp(power)) as exp2(power' + log2 opacity) with power' = log2(e) power:
+    // the record carries the quadratic form pre-scaled by log2(e) and log2(opacity) beside the opacity itself (GP_LOG2E; the
+    // oracle restates the same products), which takes two multiplies out of every (pixel, splat) evaluation of both passes.
+    rec[3 * (size_t)i + 0] = make_float4(pix, piy, (-0.5f * conx) * GP_LOG2E, (-cony) * GP_LOG2E);
+    rec[3 * (size_t)i + 1] = make_float4((-0.5f * conz) * GP_LOG2E, log2f(opac), pv.z, __int_as_float(i));
+    rec[3 * (size_t)i + 2] = make_float4(col[0], col[1], col[2], opac);
 }
 
 #define PF_ARGS RasterDims d, const float* __restrict__ means3D, const float* __restrict__ scales, \
@@ -387,7 +391,8 @@ __device__ __forceinline__ void sh_color_body(RasterDims d, const float* __restr
     float col[3];
     const uint8_t cl = sh_color<SH_MODE>(d, i, tid, means3D[3 * i], means3D[3 * i + 1], means3D[3 * i + 2], campos, shs, s_sh, col);
     clamped[i] = cl;
-    rec[3 * (size_t)i + 2] = make_float4(col[0], col[1], col[2], 0.f);
+    float* c3 = (float*)(rec + 3 * (size_t)i + 2);       // (the fourth word is the opacity, written by the projection kernel)
+    c3[0] = col[0]; c3[1] = col[1]; c3[2] = col[2];
 }
 #define SC_ARGS RasterDims d, const float* __restrict__ means3D, const float* __restrict__ shs, const float* __restrict__ shs_rest, \
     const float* __restrict__ campos, const int32_t* __restrict__ radii, float4* __restrict__ rec, uint8_t* __restrict__ clamped
@@ -534,203 +539,16 @@ __global__ __launch_bounds__(1024) void gp_tile_order_kernel(const int2* __restr
     for (int t = tid; t < T; t += 1024) order[atomicAdd(&s_base[bucket_of(t)], 1u)] = (uint32_t)t;
 }
 
-// Can the splat reach alpha >= 1/255 anywhere on the pixel-centre rectangle [X0,X1] x [Y0,Y1]?
-// alpha >= 1/255  <=>  q(d) := cx dx^2 + 2 cy dx dy + cz dy^2 <= 2 ln(255 o) =: two_tau  (d = pixel - centre).
-// First the bounding box of that ellipse, then the exact minimum of the convex q over the rectangle (it lies on
-// an edge when the centre is outside).  Conservative: slack on two_tau and on the box, so a culled splat has
-// no contributing pixel in the rectangle.
-struct GpFootprint {
-    float mx, my, cx, cy, cz, two_tau, ex, ey, rx, ry;
-    int state;   // 0: never contributes, 1: degenerate conic (do not cull), 2: regular
-    __device__ __forceinline__ GpFootprint(const float4 q0, const float4 q1) {
-        mx = q0.x; my = q0.y;
-        cx = -2.f * q0.z; cy = -q0.w; cz = -2.f * q1.x;
-        const float detc = cx * cz - cy * cy;
-        const float tau = __logf(255.f * q1.y);
-        two_tau = 2.f * tau * 1.004f;
-        state = !(tau > 0.f) ? 0 : (!(detc > 0.f) ? 1 : 2);
-        const float e2 = two_tau / detc;
-        ex = sqrtf(e2 * cz) + 0.01f; ey = sqrtf(e2 * cx) + 0.01f;
-        ry = -cy / cz; rx = -cy / cx;                      // argmin of q along a vertical / horizontal line
-    }
-    __device__ __forceinline__ bool hits(float X0, float X1, float Y0, float Y1) const {
-        if (state < 2) return state == 1;
-        const float dx0 = X0 - mx, dx1 = X1 - mx, dy0 = Y0 - my, dy1 = Y1 - my;
-        if (!(dx0 <= ex && dx1 >= -ex && dy0 <= ey && dy1 >= -ey)) return false;
-        if (dx0 <= 0.f && dx1 >= 0.f && dy0 <= 0.f && dy1 >= 0.f) return true;   // centre inside
-        float qmin;
-        {
-            const float dy = fminf(fmaxf(ry * dx0, dy0), dy1);
-            qmin = cx * dx0 * dx0 + (2.f * cy * dx0 + cz * dy) * dy;
-        }
-        {
-            const float dy = fminf(fmaxf(ry * dx1, dy0), dy1);
-            qmin = fminf(qmin, cx * dx1 * dx1 + (2.f * cy * dx1 + cz * dy) * dy);
-        }
-        {
-            const float dx = fminf(fmaxf(rx * dy0, dx0), dx1);
-            qmin = fminf(qmin, cz * dy0 * dy0 + (2.f * cy * dy0 + cx * dx) * dx);
-        }
-        {
-            const float dx = fminf(fmaxf(rx * dy1, dx0), dx1);
-            qmin = fminf(qmin, cz * dy1 * dy1 + (2.f * cy * dy1 + cx * dx) * dx);
-        }
-        return qmin <= two_tau + 0.02f;
-    }
-};
-__device__ __forceinline__ bool gp_splat_hits_rect(const float4 q0, const float4 q1, float X0, float X1, float Y0, float Y1) {
-    return GpFootprint(q0, q1).hits(X0, X1, Y0, Y1);
-}
-
-// ------------------------------------------------------------------------------------------------
-// composite forward.  One 256-thread workgroup (4 waves) per 16x16 tile; wave w owns the 8x8 quadrant
-// (w & 1, w >> 1), one pixel per lane.  Splat records (48 B) are gathered once per tile into LDS in batches
-// of 256; each staging lane also decides -- exactly, ellipse against rectangle -- which of the four quadrants
-// its splat's alpha >= 1/255 footprint can touch.  The ballots of those decisions let each consumer wave walk
-// only the splats that matter to it, and the 4-bit masks are saved per tile-splat instance (qmask) so that
-// the backward never repeats the test or fetches records it does not need.
-// ------------------------------------------------------------------------------------------------
 #define CF_THREADS 256
 typedef float v2f __attribute__((ext_vector_type(2)));
 
-struct PixAcc {
-    float T, C0, C1, C2, Dp, best;
-    int best_id, last;
-    bool done;
-};
-
-__device__ __forceinline__ void blend_px(PixAcc& p, float pxf, float pyf, const float4& q0, const float4& q1,
-                                         const float4& q2, int contributor) {
-    const float dx = q0.x - pxf, dy = q0.y - pyf;
-    const float power = fmaf(dx, fmaf(q0.z, dx, q0.w * dy), (q1.x * dy) * dy);
-    if (p.done || power > 0.f) return;
-    const float alpha = fminf(0.99f, q1.y * gp_exp(power));
-    if (alpha < 1.f / 255.f) return;
-    const float test_T = p.T * (1.f - alpha);
-    if (test_T < 0.0001f) { p.done = true; return; }
-    const float w = alpha * p.T;
-    p.C0 = fmaf(q2.x, w, p.C0);
-    p.C1 = fmaf(q2.y, w, p.C1);
-    p.C2 = fmaf(q2.z, w, p.C2);
-    p.Dp = fmaf(q1.z, w, p.Dp);
-    if (w > p.best) { p.best = w; p.best_id = __float_as_int(q1.w); }
-    p.T = test_T;
-    p.last = contributor;
-}
-
-__global__ __launch_bounds__(CF_THREADS) void gp_composite_fwd_kernel(RasterDims d, const int2* __restrict__ ranges,
-                                                                      const uint32_t* __restrict__ point_list,
-                                                                      const float4* __restrict__ rec,
-                                                                      const float* __restrict__ bg,
-                                                                      float* __restrict__ out_color,
-                                                                      float* __restrict__ out_depth,
-                                                                      int32_t* __restrict__ out_tidx,
-                                                                      float* __restrict__ final_T,
-                                                                      int32_t* __restrict__ n_contrib,
-                                                                      const uint32_t* __restrict__ order,
-                                                                      int32_t* __restrict__ tile_work,
-                                                                      uint8_t* __restrict__ qmask) {
-    __shared__ float4 s_q0[CF_THREADS], s_q1[CF_THREADS], s_q2[CF_THREADS];
-    __shared__ unsigned long long s_mask[4][4];   // [quadrant][staging wave]
-    __shared__ __attribute__((aligned(4))) unsigned char s_list[4][CF_THREADS];   // per quadrant: batch slots in order
-    __shared__ int s_done[4];
-    __shared__ int s_last[4];
-    const int tile = order ? (int)order[blockIdx.x] : (int)blockIdx.x;
-    const int tx = tile % d.gx, ty = tile / d.gx;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int px = tx * GP_TILE + (wave & 1) * 8 + (lane & 7);
-    const int py = ty * GP_TILE + (wave >> 1) * 8 + (lane >> 3);
-    const float pxf = (float)px, pyf = (float)py;
-    const int2 range = ranges[tile];
-    PixAcc a;
-    a.T = 1.f;
-    a.C0 = a.C1 = a.C2 = a.Dp = a.best = 0.f;
-    a.best_id = -1;
-    a.last = 0;
-    const bool inside = px < d.W && py < d.H;
-    a.done = !inside;
-    bool wave_done = false;
-    if (tid < 4) s_done[tid] = 0;
-    // quadrant pixel-centre rectangles for culling
-    const float X0 = (float)(tx * GP_TILE), Y0 = (float)(ty * GP_TILE);
-
-    for (int base = range.x; base < range.y; base += CF_THREADS) {
-        __syncthreads();
-        if (s_done[0] && s_done[1] && s_done[2] && s_done[3]) break;
-        const int k = base + tid;
-        unsigned rel = 0;
-        if (k < range.y) {
-            const uint32_t id = point_list[k];
-            const float4 q0 = rec[3 * (size_t)id], q1 = rec[3 * (size_t)id + 1], q2 = rec[3 * (size_t)id + 2];
-            s_q0[tid] = q0; s_q1[tid] = q1; s_q2[tid] = q2;
-            const GpFootprint f(q0, q1);
-            rel = (f.hits(X0, X0 + 7.f, Y0, Y0 + 7.f) ? 1u : 0u) | (f.hits(X0 + 8.f, X0 + 15.f, Y0, Y0 + 7.f) ? 2u : 0u) |
-                  (f.hits(X0, X0 + 7.f, Y0 + 8.f, Y0 + 15.f) ? 4u : 0u) | (f.hits(X0 + 8.f, X0 + 15.f, Y0 + 8.f, Y0 + 15.f) ? 8u : 0u);
-            qmask[k] = (uint8_t)rel;
-        }
-        const unsigned long long m0 = __ballot(rel & 1u), m1 = __ballot(rel & 2u), m2 = __ballot(rel & 4u), m3 = __ballot(rel & 8u);
-        if (lane == 0) { s_mask[0][wave] = m0; s_mask[1][wave] = m1; s_mask[2][wave] = m2; s_mask[3][wave] = m3; }
-        __syncthreads();
-        // compact the batch into one slot list per quadrant (depth order kept: staging waves in order, lanes in order).
-        // A consumer then runs a plain counted loop over bytes instead of peeling bits off 64-bit masks with the scalar
-        // unit -- that walk cost as much as the blending itself.
-        {
-            const unsigned long long own[4] = {m0, m1, m2, m3};
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                int off = 0;
-                for (int w = 0; w < wave; ++w) off += __popcll(s_mask[q][w]);
-                if ((rel >> q) & 1u) s_list[q][off + (int)gp_mbcnt(own[q])] = (unsigned char)tid;
-            }
-        }
-        __syncthreads();
-        if (!wave_done) {
-            const int cnt = __builtin_amdgcn_readfirstlane(__popcll(s_mask[wave][0]) + __popcll(s_mask[wave][1]) +
-                                                           __popcll(s_mask[wave][2]) + __popcll(s_mask[wave][3]));
-            const unsigned char* lst = s_list[wave];
-#pragma unroll 1
-            for (int i = 0; i < cnt && !wave_done; i += 4) {
-                const uint32_t four = *(const uint32_t*)(lst + i);       // four slots per LDS read
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    if (i + u < cnt) {
-                        const int slot = (int)((four >> (8 * u)) & 255u);
-                        const float4 q0 = s_q0[slot], q1 = s_q1[slot], q2 = s_q2[slot];
-                        blend_px(a, pxf, pyf, q0, q1, q2, base - range.x + slot + 1);
-                        if (__all(a.done)) { wave_done = true; break; }
-                    }
-                }
-            }
-            if (wave_done && lane == 0) s_done[wave] = 1;
-        }
-    }
-    const size_t HW = (size_t)d.H * d.W;
-    if (inside) {
-        const size_t pix = (size_t)py * d.W + px;
-        out_color[pix] = fmaf(a.T, bg[0], a.C0);
-        out_color[HW + pix] = fmaf(a.T, bg[1], a.C1);
-        out_color[2 * HW + pix] = fmaf(a.T, bg[2], a.C2);
-        out_depth[pix] = a.Dp;
-        out_tidx[pix] = a.best_id;
-        final_T[pix] = a.T;
-        n_contrib[pix] = a.last;
-    }
-    if (tile_work) {   // largest list position any pixel of the tile consumed: the backward's work estimate
-        int mx = inside ? a.last : 0;
-#pragma unroll
-        for (int dd = 32; dd >= 1; dd >>= 1) mx = max(mx, __shfl_xor(mx, dd));
-        if (lane == 0) s_last[wave] = mx;
-        __syncthreads();
-        if (tid == 0) tile_work[tile] = max(max(s_last[0], s_last[1]), max(s_last[2], s_last[3]));
-    }
-}
-
-
 // ------------------------------------------------------------------------------------------------
-// composite forward, sub-block lists (the shipped kernel; gp_composite_fwd_kernel above is kept as the A/B baseline
-// behind gp_debug_option(0, 1)).
+// composite forward, sub-block lists.  One 256-thread workgroup (4 waves) per 16x16 tile; splat records (48 B) are gathered
+// once per tile into LDS in batches of 256.  (Round 1's kernel -- wave = 8x8 quadrant, one list per quadrant -- was kept as an
+// A/B baseline through round 3 and is gone: round 4 changed the alpha expression, see the record format in
+// preprocess_fwd_body.)
 //
-// Measured on MI355X the quadrant kernel above is bound by the vector ALU (41 issue slots per wave-visit x 4 cycles
+// Measured on MI355X that quadrant kernel was bound by the vector ALU (41 issue slots per wave-visit x 4 cycles
 // x 3.2 M wave-visits = its whole 0.22 ms), with only one lane in three contributing: a splat that touches an 8x8
 // quadrant reaches alpha >= 1/255 on a third of its pixels.  This kernel culls at 4x4 granularity instead:
 //   * a tile is 4 x 4 sub-blocks (SB) of 4 x 4 pixels; wave w still owns quadrant w, but its four 16-lane groups are
@@ -742,20 +560,24 @@ __global__ __launch_bounds__(CF_THREADS) void gp_composite_fwd_kernel(RasterDims
 //     four rectangle tests it replaces;
 //   * 'done' and 'list exhausted' are ONE per-lane limit (i < lim), so a visit carries one compare for both.
 // Wave-steps per tile drop from 4 x 146 to 4 x 96 (lock-step over four lists costs 14 % against ideal 4x4 culling) and
-// a visit from 41 to 29 VALU slots.  The arithmetic per (pixel, splat) is unchanged, expression for expression, so the
-// outputs are bit-identical to the quadrant kernel's.
+// a visit from 41 to 29 VALU slots (round 2), 24 with the exponent folded into the record (round 4):
+//     e = dx (A' dx + B' dy) + ((C' dy) dy + lop),   A' B' C' = log2(e) x the quadratic form, lop = log2(opacity)
+//     skip if e > lop (i.e. power > 0);  alpha = min(0.99, exp2(e));  skip if alpha < 1/255;  stop if T (1 - alpha) < 1e-4
+// -- the published algorithm's min(0.99, opacity exp(power)) with the two multiplies moved into the per-Gaussian record.
 // ------------------------------------------------------------------------------------------------
-#define CF2_REC 48            // bytes per staged record: (x, y, A, B) (C, opacity, r, g) (b, depth, -, -)
+#define CF2_REC 48            // bytes per staged record: (x, y, A', B') (C', log2 opacity, r, g) (b, depth, -, -)
 __device__ __forceinline__ uint32_t gp_sb_mask(const float4 q0, const float4 q1, float X0, float Y0) {
-    // hardware rcp / sqrt / log (about 1 ulp) instead of the correctly rounded sequences (10 - 15 instructions each): the test
-    // carries 0.4 % + 0.02 of slack on q and 0.01 px on the spans, orders of magnitude above their error
+    // alpha >= 1/255  <=>  q'(d) := cx dx^2 + 2 cy dx dy + cz dy^2 <= 2 (lop + log2 255) =: 2 tau, everything in the record's
+    // log2 units (cx = -2 A' ..., the geometry is homogeneous in the scale).
+    // hardware rcp / sqrt (about 1 ulp) instead of the correctly rounded sequences (10 - 15 instructions each): the test
+    // carries 0.4 % + 0.03 of slack on q' and 0.01 px on the spans, orders of magnitude above their error
     const float mx = q0.x - X0, my = q0.y - Y0;                  // centre in tile-local pixel coordinates
     const float cx = -2.f * q0.z, cy = -q0.w, cz = -2.f * q1.x;
     const float det = cx * cz - cy * cy;
-    const float tau = __logf(255.f * q1.y);
+    const float tau = q1.y + 7.994353436858858f;                 // log2(255 opacity)
     if (!(tau > 0.f)) return 0u;                                 // opacity < 1/255: alpha never reaches the threshold
     if (!(det > 0.f && cx > 0.f && cz > 0.f)) return 0xFFFFu;    // degenerate conic: do not cull
-    const float tt = 2.f * tau * 1.004f + 0.02f;                 // q <= tt, with slack for the rounding of power / exp / log
+    const float tt = 2.f * tau * 1.004f + 0.03f;                 // q' <= tt, with slack for the rounding of the exponent / exp2
     const float ex = __builtin_amdgcn_sqrtf(tt * cz * __builtin_amdgcn_rcpf(det));   // half extent in x; rightmost point at dy = -(cy / cz) ex
     if (!(ex <= 1e8f)) return 0xFFFFu;
     const float inv_cx = __builtin_amdgcn_rcpf(cx), rxy = -cy * inv_cx;              // centre line of the row spans: c(dy) = rxy dy
@@ -891,14 +713,12 @@ __device__ __forceinline__ void gp_composite_fwd_sb_body(RasterDims d, const int
     "v_mul_f32 v50, " B_ ", v49\n\t"                                                                                \
     "v_fmac_f32 v50, " A_ ", v48\n\t"                                                                               \
     "v_mul_f32 v51, " C_ ", v49\n\t"                                                                                \
-    "v_mul_f32 v51, v51, v49\n\t"                                                                                   \
+    "v_fma_f32 v51, v51, v49, " OP "\n\t"            /* (C' dy) dy + lop */                                          \
     "v_fmac_f32 v51, v48, v50\n\t"                                                                                  \
-    "v_cmp_nlt_f32 vcc, 0, v51\n\t"                                                                                 \
+    "v_cmp_ngt_f32 vcc, v51, " OP "\n\t"             /* not (e > lop)  <=>  not (power > 0) */                       \
     "s_and_b64 exec, exec, vcc\n\t"                                                                                 \
-    "v_mul_f32 v51, 0x3fb8aa3b, v51\n\t"                                                                            \
     "v_exp_f32 v51, v51\n\t"                                                                                        \
     "s_nop 0\n\t"                                                                                                   \
-    "v_mul_f32 v51, " OP ", v51\n\t"                                                                                \
     "v_min_f32 v51, 0x3f7d70a4, v51\n\t"                                                                            \
     "v_cmp_ngt_f32 vcc, 0x3b808081, v51\n\t"                                                                        \
     "s_and_b64 exec, exec, vcc\n\t"                                                                                 \
@@ -977,9 +797,9 @@ __device__ __forceinline__ void gp_composite_fwd_sb_body(RasterDims d, const int
                         const float4 q1 = *(const float4*)(s_rec + off + 16);
                         const float2 q2 = *(const float2*)(s_rec + off + 32);
                         const float dx = q0.x - pxf, dy = q0.y - pyf;
-                        const float power = fmaf(dx, fmaf(q0.z, dx, q0.w * dy), (q1.x * dy) * dy);
-                        if (!(power > 0.f)) {
-                            const float alpha = fminf(0.99f, q1.y * gp_exp(power));
+                        const float e = fmaf(dx, fmaf(q0.z, dx, q0.w * dy), fmaf(q1.x * dy, dy, q1.y));     // q1.y = log2(opacity)
+                        if (!(e > q1.y)) {
+                            const float alpha = fminf(0.99f, __builtin_amdgcn_exp2f(e));
                             if (!(alpha < 1.f / 255.f)) {
                                 const float test_T = T * (1.f - alpha);
                                 if (test_T < 0.0001f) {
@@ -1191,7 +1011,6 @@ __device__ __forceinline__ void gp_composite_bwd_body(RasterDims d, const int2* 
     const float halfW = 0.5f * (float)d.W, halfH = 0.5f * (float)d.H;
     const int count = min(range.y - range.x, max_nc);
     const float px_base = (float)(tx * GP_TILE + (part % parts_x) * COLS), py_base = (float)(ty * GP_TILE + (part / parts_x) * ROWS);
-    const float LOG2E = 1.4426950408889634f;
     // ---- compaction.  The forward saved, per tile-splat instance, which quadrants its footprint touches
     // (qmask): a refill reads 256 mask bytes + ids with two coalesced loads, keeps the instances of THIS part
     // (stable, so depth order is kept) and appends (list position, id) to a queue.  Records are gathered only
@@ -1263,10 +1082,15 @@ __device__ __forceinline__ void gp_composite_bwd_body(RasterDims d, const int2* 
             }
         }
         // alpha is recomputed with the FORWARD's expression tree, bit for bit (dx = x - px, dy = y - py from the same operands, the same
-        // fma nesting, exp2(power * log2e)): the backward's discrete decisions (power > 0, alpha < 1/255) are then the forward's own
+        // fma nesting, exp2 of the same exponent): the backward's discrete decisions (e > lop, alpha < 1/255) are then the forward's own.
+        // The record holds A' B' C' = log2(e) x the quadratic form and lop = log2(opacity) (preprocess_fwd_body); E := exp2(e) =
+        // opacity G is the unclamped alpha, so  h = dL/dG G = E dL/dalpha  needs no opacity factor and  dL/dopacity = sum(E dL/dalpha) /
+        // opacity  is divided once per (batch, splat) at the flush.
         const float As = q0.z, Bs = q0.w, Cs = q1.x;
-        const float op = have ? q1.y : 0.f, zdep = q1.z;
-        const float cxx = -2.f * q0.z, cxy = -q0.w, cyy = -2.f * q1.x;
+        const float lop = have ? q1.y : -INFINITY, zdep = q1.z;         // (an idle lane: exponent -inf, E = 0)
+        const float opac = q2.w;
+        const float LN2 = 0.6931471805599453f;                         // conic = ln 2 x the record's primed form
+        const float cxx = -2.f * LN2 * q0.z, cxy = -LN2 * q0.w, cyy = -2.f * LN2 * q1.x;
         const v2f cr = {q2.x, q2.x}, cg = {q2.y, q2.y}, cb = {q2.z, q2.z};
         // h := dL/dG * G per (splat, pixel).  The geometric gradients are moments of h:
         //   S_x = sum h dx, S_y = sum h dy, S_xx = sum h dx^2, S_xy = sum h dx dy, S_yy = sum h dy^2
@@ -1282,13 +1106,13 @@ __device__ __forceinline__ void gp_composite_bwd_body(RasterDims d, const int2* 
 #pragma unroll 1
         for (int row = 0; row < ROWS; ++row) {
             const float dy = q0.y - (py_base + (float)row);
-            const float tB = Bs * dy, uC = (Cs * dy) * dy;
+            const float tB = Bs * dy, uC = fmaf(Cs * dy, dy, lop);
             v2f r_h = {0.f, 0.f}, r_hx = {0.f, 0.f};
             if (!HAS_DEPTH) {
                 // The four pixel-pair steps of a row, hand-scheduled (the compiler's version of the step below carries ~95 issue
                 // slots: phi copies at the merge points, address moves, duplicated selects; this one 80).  Temporaries v64..v97 are
                 // fixed registers (clobbered); exec is restored before leaving.  Same arithmetic as the C++ step (HAS_DEPTH path).
-                const v2f As2 = {As, As}, tB2 = {tB, tB}, uC2 = {uC, uC}, op2 = {op, op}, l2e = {LOG2E, LOG2E};
+                const v2f As2 = {As, As}, tB2 = {tB, tB}, uC2 = {uC, uC};
                 const v2f dx0 = dxs[0], dx1 = dxs[1], dx2 = dxs[2], dx3 = dxs[3];
                 const uint32_t vpp = (uint32_t)(uintptr_t)&s_pp[row * (COLS / 2)][0];
                 unsigned long long sv, c0, c1, t0;
@@ -1324,32 +1148,24 @@ __device__ __forceinline__ void gp_composite_bwd_body(RasterDims d, const int2* 
     "v_max_i32 v80, v64, v65\n\t"                                                                                    \
     "v_cmp_lt_i32 vcc, %[b0], v80\n\t"                                                                               \
     "s_cbranch_vccz 9" #CP "f\n\t"                                                                                   \
-    "v_pk_mul_f32 v[80:81], v[78:79], %[l2e]\n\t"     /* gp_exp(power) = exp2(power * log2e), as the forward */     \
-    "s_nop 0\n\t"                                                                                                   \
-    "v_min_f32 v80, 0, v80\n\t"                                                                                      \
-    "v_min_f32 v81, 0, v81\n\t"                                                                                      \
-    "v_exp_f32 v80, v80\n\t"                                                                                         \
-    "v_exp_f32 v81, v81\n\t"                                                                                         \
+    "v_exp_f32 v80, v78\n\t"                         /* E = exp2(e): the unclamped alpha (opacity x G) */           \
+    "v_exp_f32 v81, v79\n\t"                                                                                         \
     "v_cmp_lt_i32 %[c0], %[pos], v64\n\t"                                                                            \
     "v_cmp_lt_i32 %[c1], %[pos], v65\n\t"                                                                            \
-    "v_cmp_nlt_f32 %[t0], 0, v78\n\t"                                                                                \
+    "v_cmp_ngt_f32 %[t0], v78, %[lop]\n\t"           /* not (e > lop)  <=>  not (power > 0), as the forward */      \
     "s_and_b64 %[c0], %[c0], %[t0]\n\t"                                                                              \
-    "v_cmp_nlt_f32 %[t0], 0, v79\n\t"                                                                                \
+    "v_cmp_ngt_f32 %[t0], v79, %[lop]\n\t"                                                                           \
     "s_and_b64 %[c1], %[c1], %[t0]\n\t"                                                                              \
-    "v_pk_mul_f32 v[82:83], %[op2], v[80:81] op_sel_hi:[0,1]\n\t"                                                     \
-    "s_nop 0\n\t"                                                                                                   \
-    "v_min_f32 v82, 0x3f7d70a4, v82\n\t"                                                                             \
-    "v_min_f32 v83, 0x3f7d70a4, v83\n\t"                                                                             \
-    "v_cmp_ngt_f32 vcc, 0x3b808081, v82\n\t"         /* (a literal needs the VOPC encoding: destination vcc) */      \
+    "v_cmp_ngt_f32 vcc, 0x3b808081, v80\n\t"         /* alpha < 1/255 <=> E < 1/255 (a literal needs VOPC: vcc) */   \
     "s_and_b64 %[c0], %[c0], vcc\n\t"                                                                                \
-    "v_cmp_ngt_f32 vcc, 0x3b808081, v83\n\t"                                                                         \
+    "v_cmp_ngt_f32 vcc, 0x3b808081, v81\n\t"                                                                         \
     "s_and_b64 %[c1], %[c1], vcc\n\t"                                                                              \
     "s_or_b64 %[t0], %[c0], %[c1]\n\t"                                                                               \
     "s_cbranch_scc0 9" #CP "f\n\t"                                                                                   \
-    "v_cndmask_b32 v80, 0, v80, %[c0]\n\t"                                                                           \
+    "v_cndmask_b32 v80, 0, v80, %[c0]\n\t"           /* a lane that does not contribute takes part with E = alpha = 0 */ \
     "v_cndmask_b32 v81, 0, v81, %[c1]\n\t"                                                                           \
-    "v_cndmask_b32 v82, 0, v82, %[c0]\n\t"                                                                           \
-    "v_cndmask_b32 v83, 0, v83, %[c1]\n\t"                                                                           \
+    "v_min_f32 v82, 0x3f7d70a4, v80\n\t"                                                                             \
+    "v_min_f32 v83, 0x3f7d70a4, v81\n\t"                                                                             \
     "v_max3_f32 %[any], %[any], v82, v83\n\t"                                                                        \
     "v_pk_add_f32 v[84:85], v[82:83], 1.0 op_sel_hi:[1,0] neg_lo:[1,0] neg_hi:[1,0]\n\t"                              \
     "s_waitcnt lgkmcnt(0)\n\t"                                                                                       \
@@ -1379,9 +1195,7 @@ __device__ __forceinline__ void gp_composite_bwd_body(RasterDims d, const int2* 
     "v_pk_fma_f32 %[a_b], v[94:95], v[70:71], %[a_b]\n\t"                                                            \
     "v_pk_mul_f32 v[96:97], v[80:81], v[96:97]\n\t"                                                                  \
     "s_nop 0\n\t"                                                                                                   \
-    "v_pk_add_f32 %[a_op], %[a_op], v[96:97]\n\t"                                                                    \
-    "v_pk_mul_f32 v[96:97], %[op2], v[96:97] op_sel_hi:[0,1]\n\t"                                                     \
-    "s_nop 0\n\t"                                                                                                   \
+    "v_pk_add_f32 %[a_op], %[a_op], v[96:97]\n\t"      /* sum E dL/dalpha = opacity dL/dopacity = sum h */           \
     "v_pk_add_f32 %[r_h], %[r_h], v[96:97]\n\t"                                                                      \
     "v_pk_mul_f32 v[96:97], v[96:97], " DX "\n\t"                                                                    \
     "s_nop 0\n\t"                                                                                                   \
@@ -1396,8 +1210,8 @@ __device__ __forceinline__ void gp_composite_bwd_body(RasterDims d, const int2* 
                     CB_STEP(3, 192, 208, 224, 240, "%[dx3]")
                     : [a_op] "+v"(a_op), [a_r] "+v"(a_r), [a_g] "+v"(a_g), [a_b] "+v"(a_b), [s_xx] "+v"(s_xx), [r_h] "+v"(r_h), [r_hx] "+v"(r_hx),
                       [any] "+v"(any_m), [sv] "=&s"(sv), [c0] "=&s"(c0), [c1] "=&s"(c1), [t0] "=&s"(t0)
-                    : [As2] "v"(As2), [tB2] "v"(tB2), [uC2] "v"(uC2), [op2] "v"(op2), [cr] "v"(cr), [cg] "v"(cg), [cb] "v"(cb), [dx0] "v"(dx0),
-                      [dx1] "v"(dx1), [dx2] "v"(dx2), [dx3] "v"(dx3), [pos] "v"(pos), [vpp] "v"(vpp), [l2e] "v"(l2e), [b0] "s"(b0)
+                    : [As2] "v"(As2), [tB2] "v"(tB2), [uC2] "v"(uC2), [lop] "v"(lop), [cr] "v"(cr), [cg] "v"(cg), [cb] "v"(cb), [dx0] "v"(dx0),
+                      [dx1] "v"(dx1), [dx2] "v"(dx2), [dx3] "v"(dx3), [pos] "v"(pos), [vpp] "v"(vpp), [b0] "s"(b0)
                     : "vcc", "scc", "memory", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77",
                       "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94",
                       "v95", "v96", "v97");
@@ -1415,17 +1229,16 @@ __device__ __forceinline__ void gp_composite_bwd_body(RasterDims d, const int2* 
                 if (HAS_DEPTH) v3 = s_dd[pr];
                 const v2f dx = dxs[cp];
                 const v2f pw = {fmaf(dx.x, fmaf(As, dx.x, tB), uC), fmaf(dx.y, fmaf(As, dx.y, tB), uC)};
-                const v2f G = {__builtin_amdgcn_exp2f(fminf(pw.x * LOG2E, 0.f)), __builtin_amdgcn_exp2f(fminf(pw.y * LOG2E, 0.f))};
-                const v2f alpha = {fminf(0.99f, op * G.x), fminf(0.99f, op * G.y)};
+                const v2f E = {__builtin_amdgcn_exp2f(pw.x), __builtin_amdgcn_exp2f(pw.y)};          // pw = the exponent e (uC carries lop)
                 const int ncx = nc.x, ncy = nc.y;
                 if (max(ncx, ncy) > b0) {   // uniform: otherwise both pixels finished before this batch
-                    const bool c0 = (pos < ncx) && !(pw.x > 0.f) && !(alpha.x < 1.f / 255.f);
-                    const bool c1 = (pos < ncy) && !(pw.y > 0.f) && !(alpha.y < 1.f / 255.f);
+                    const bool c0 = (pos < ncx) && !(pw.x > lop) && !(E.x < 1.f / 255.f);
+                    const bool c1 = (pos < ncy) && !(pw.y > lop) && !(E.y < 1.f / 255.f);
                     if (__builtin_amdgcn_ballot_w64(c0 || c1) != 0ull) {   // otherwise nobody in the wave touches either pixel
                         // a lane that does not contribute to a pixel takes part with G = 0 (alpha = 0, factor 1 in the product scan,
                         // 0 in the sum scan, zero gradient): one select per pixel instead of mask multiplications
-                        const v2f Gm = {c0 ? G.x : 0.f, c1 ? G.y : 0.f};
-                        const v2f am = {c0 ? alpha.x : 0.f, c1 ? alpha.y : 0.f};
+                        const v2f Em = {c0 ? E.x : 0.f, c1 ? E.y : 0.f};
+                        const v2f am = {fminf(0.99f, Em.x), fminf(0.99f, Em.y)};
                         any_m = fmaxf(any_m, fmaxf(am.x, am.y));
                         const v2f om = 1.f - am;
                         v2f cdot = cb * (v2f){v1.x, v1.y};
@@ -1451,9 +1264,8 @@ __device__ __forceinline__ void gp_composite_bwd_body(RasterDims d, const int2* 
                         a_g = fma2(w, (v2f){v0.z, v0.w}, a_g);
                         a_b = fma2(w, (v2f){v1.x, v1.y}, a_b);
                         if (HAS_DEPTH) a_d = fma2(w, dLd, a_d);
-                        const v2f gda = Gm * dL_dalpha;
-                        a_op += gda;
-                        const v2f h = op * gda;
+                        const v2f h = Em * dL_dalpha;
+                        a_op += h;
                         const v2f hx = h * dx;
                         r_h += h;
                         r_hx += hx;
@@ -1482,7 +1294,7 @@ __device__ __forceinline__ void gp_composite_bwd_body(RasterDims d, const int2* 
             const float S_xx = s_xx.x + s_xx.y;
             const float g_mx = -(cxx * S_x + cxy * S_y), g_my = -(cyy * S_y + cxy * S_x);
             ((float4*)fl)[lane] = make_float4(g_mx * halfW, g_my * halfH, -0.5f * S_xx, -S_xy);
-            ((float4*)fm)[lane] = make_float4(-0.5f * S_yy, a_op.x + a_op.y, a_r.x + a_r.y, a_g.x + a_g.y);
+            ((float4*)fm)[lane] = make_float4(-0.5f * S_yy, mine ? (a_op.x + a_op.y) / opac : 0.f, a_r.x + a_r.y, a_g.x + a_g.y);
             ((float4*)fh)[lane] = make_float4(a_b.x + a_b.y, HAS_DEPTH ? a_d.x + a_d.y : 0.f, 0.f, 0.f);
             s_flid[lane] = mine ? id : 0xffffffffu;
             __builtin_amdgcn_wave_barrier();

@@ -24,7 +24,8 @@
  *     - SH -> RGB (+0.5, clamp >= 0):                     utils/sh_utils.py:57-112,
  *                                                        gaussian_renderer/__init__.py:86-91
  *   Declared (not derivable from the reference) semantics: near plane 0.2, 16x16 tiles, 3-sigma
- *   radius, +0.3 px^2 low-pass, alpha = min(0.99, o*G), skip alpha < 1/255, stop when T < 1e-4,
+ *   radius, +0.3 px^2 low-pass, alpha = min(0.99, o*G) (evaluated as exp2 of one folded exponent, see
+ *   gauss_exponent), skip alpha < 1/255, stop when T < 1e-4,
  *   depth image = sum_i z_i alpha_i T_i, tidx = index of the Gaussian with the largest blending
  *   weight alpha_i T_i at that pixel (first wins on ties), -1 if none.
  *
@@ -42,6 +43,8 @@ typedef double real;
 #define FMA(a, b, c) fma((a), (b), (c))
 #define SQRT(x) sqrt(x)
 #define EXPR(x) exp(x)
+#define EXP2R(x) exp2(x)
+#define LOG2R(x) log2(x)
 #define CEILR(x) ceil(x)
 #define FMINR(a, b) fmin((a), (b))
 #define FMAXR(a, b) fmax((a), (b))
@@ -51,6 +54,8 @@ typedef float real;
 #define FMA(a, b, c) fmaf((a), (b), (c))
 #define SQRT(x) sqrtf(x)
 #define EXPR(x) expf(x)
+#define EXP2R(x) exp2f(x)
+#define LOG2R(x) log2f(x)
 #define CEILR(x) ceilf(x)
 #define FMINR(a, b) fminf((a), (b))
 #define FMAXR(a, b) fmaxf((a), (b))
@@ -352,11 +357,18 @@ long gpo_bin(int N, int W, int H, const uint32_t* tiles_touched, const int32_t* 
 /* ------------------------------------------------------------------------------------------- */
 /* 3. composite forward (per tile, per pixel, front to back)                                   */
 /* ------------------------------------------------------------------------------------------- */
-/* canonical quadratic form: power = dx*(A*dx + B*dy) + (C*dy)*dy, A=-0.5*conic.x, B=-conic.y,
- * C=-0.5*conic.z  (== -0.5*(cx dx^2 + cz dy^2) - cy dx dy) */
-static inline real gauss_power(real conx, real cony, real conz, real dx, real dy) {
-    real A = R(-0.5) * conx, B = -cony, C = R(-0.5) * conz;
-    return FMA(dx, FMA(A, dx, B * dy), (C * dy) * dy);
+/* The composite's alpha = min(0.99, opacity * exp(power)), power = -0.5 (cx dx^2 + cz dy^2) - cy dx dy, in the form the HIP
+ * kernels evaluate it since round 4 (csrc/raster_kernels.hip, preprocess_fwd_body / CF2_VISIT): the quadratic form is
+ * pre-scaled by log2(e), the opacity enters as its base-2 logarithm, and alpha = min(0.99, exp2(e)) with
+ *     e = dx (A' dx + B' dy) + ((C' dy) dy + lop),  A' = (-0.5 cx) log2e, B' = (-cy) log2e, C' = (-0.5 cz) log2e, lop = log2(opacity)
+ * "power > 0" (never true for a positive-definite conic except by rounding) is the test e > lop.  Same expression tree,
+ * operand for operand, in float32; exp2 / log2 are the only operations whose last bits differ (libm vs v_exp_f32 / ocml). */
+#define GP_LOG2E R(1.4426950408889634)
+static inline real gauss_exponent(const real* co /* conic x, y, z, opacity */, real dx, real dy, real* lop_out) {
+    real A = (R(-0.5) * co[0]) * GP_LOG2E, B = (-co[1]) * GP_LOG2E, C = (R(-0.5) * co[2]) * GP_LOG2E;
+    real lop = LOG2R(co[3]);
+    *lop_out = lop;
+    return FMA(dx, FMA(A, dx, B * dy), FMA(C * dy, dy, lop));
 }
 
 int gpo_composite_fwd(int W, int H, const int32_t* ranges, const uint32_t* point_list, const real* xy,
@@ -380,10 +392,10 @@ int gpo_composite_fwd(int W, int H, const int32_t* ranges, const uint32_t* point
                     uint32_t id = point_list[k];
                     real dx = xy[2 * id] - pxf, dy = xy[2 * id + 1] - pyf;
                     const real* co = conic_opacity + 4 * id;
-                    real power = gauss_power(co[0], co[1], co[2], dx, dy);
-                    if (FABSR(power) < R(1e-6)) amb |= 1;
-                    if (power > R(0)) continue;
-                    real alpha = FMINR(R(0.99), co[3] * EXPR(power));
+                    real lop, e = gauss_exponent(co, dx, dy, &lop);
+                    if (FABSR(e - lop) < R(2e-6)) amb |= 1;
+                    if (e > lop) continue;
+                    real alpha = FMINR(R(0.99), EXP2R(e));
                     if (FABSR(alpha * R(255) - R(1)) < R(2e-5)) amb |= 1;
                     if (alpha < R(1) / R(255)) continue;
                     real test_T = T * (R(1) - alpha);
@@ -452,10 +464,11 @@ int gpo_composite_bwd(int W, int H, int N, const int32_t* ranges, const uint32_t
                     uint32_t id = point_list[k];
                     real dx = xy[2 * id] - pxf, dy = xy[2 * id + 1] - pyf;
                     const real* co = conic_opacity + 4 * id;
-                    real power = gauss_power(co[0], co[1], co[2], dx, dy);
-                    if (power > R(0)) continue;
-                    real G = EXPR(power);
-                    real alpha = FMINR(R(0.99), co[3] * G);
+                    real lop, e = gauss_exponent(co, dx, dy, &lop);
+                    if (e > lop) continue;
+                    real E = EXP2R(e);                          /* = opacity * G, the unclamped alpha */
+                    real G = E / co[3];
+                    real alpha = FMINR(R(0.99), E);
                     if (alpha < R(1) / R(255)) continue;
                     T = T / (R(1) - alpha);
                     real w = alpha * T;

@@ -330,3 +330,23 @@ def test_visible_out_and_folded_zeroing(n, W, H):
         assert torch.equal(vis.view(torch.bool), out[1] > 0) and int(vis.max()) <= 1 and bool(vis.any())
     with pytest.raises(RuntimeError):
         gpa.GaussianRasterizer(raster_settings=rs._replace(visible_out=torch.zeros(n + 1, dtype=torch.uint8, device="cuda")))(**kw)
+
+
+@pytest.mark.parametrize("case", list(CASES))
+def test_counting_binning_equals_the_radix_sort_path(case):
+    """The per-tile lists built by counting (csrc/bin_kernels.hip: LDS histogram of all tiles, no instance keys) are the lists the
+    duplicate + stable radix sort path produces, entry for entry -- and both are the oracle's (test_forward_parity)."""
+    from gaussianprediction_amd import _lib
+    scene, st, cam = small_scene(sh_degree=3, **CASES[case])
+    st = f32_settings(st)
+    dev = scene_to_device(scene)
+    L = _lib.lib()
+    try:
+        _lib.check(L.gp_debug_option(5, 1), "opt")
+        ref = hip_forward_debug(st, dev)
+    finally:
+        _lib.check(L.gp_debug_option(5, 0), "opt")
+    got = hip_forward_debug(st, dev)
+    assert got["R"] == ref["R"] and got["R"] > 0
+    assert torch.equal(got["ranges"], ref["ranges"]) and torch.equal(got["point_list"], ref["point_list"])
+    assert torch.equal(got["color"], ref["color"]) and torch.equal(got["n_contrib"], ref["n_contrib"])

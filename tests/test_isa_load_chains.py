@@ -20,6 +20,7 @@ pytestmark = pytest.mark.skipif(shutil.which(HIPCC) is None and not os.path.exis
     ("deform_kernels.hip", ["gp_blend_fwd6_kernel", "gp_blend_bwd6_kernel", "gp_act_fwd_kernel", "gp_act_bwd_kernel"]),
     ("weights_kernels.hip", ["gp_knn_kernelILi35ELi6E"]),
     ("raster_kernels.hip", ["gp_tile_ranges_kernel", "gp_preprocess_fwd_split_kernel"]),
+    ("bin_kernels.hip", ["gp_bin_count_kernelILi2E", "gp_bin_scan_kernel", "gp_bin_scatter_kernelILi8E"]),
 ])
 def test_hot_kernels_keep_their_loads_batched(src, kernels):
     from isa_load_audit import CSRC, audit

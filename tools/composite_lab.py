@@ -41,7 +41,7 @@ def ubench(dev):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--fwd", default="1,0")
+    ap.add_argument("--fwd", default="2,0")      # 2 = compiler-scheduled visit loop (the readable reference), 0 = shipped
     ap.add_argument("--bwd", default="0")
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--ubench", action="store_true")
