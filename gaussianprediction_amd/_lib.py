@@ -86,7 +86,7 @@ class MlpInputC(C.Structure):
 class BlendArgsC(C.Structure):
     _fields_ = [("num_gaussians", C.c_int64), ("num_keypoints", C.c_int64), ("nearest_num", C.c_int32),
                 ("out_dim", C.c_int32), ("norm_rotation", C.c_int32), ("delta", C.c_void_p), ("raw_w", C.c_void_p),
-                ("knn_idx", C.c_void_p), ("xyz", C.c_void_p), ("rot", C.c_void_p)]
+                ("knn_idx", C.c_void_p), ("xyz", C.c_void_p), ("rot", C.c_void_p), ("knn_idx16", C.c_void_p)]
 
 
 class ProfileEntryC(C.Structure):

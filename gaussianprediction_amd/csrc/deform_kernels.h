@@ -29,6 +29,7 @@ struct BlendDev {
     const int64_t* knn;
     const float* xyz;
     const float* rot;
+    const uint16_t* knn16;      // the neighbour indices as 16-bit words, or NULL
 };
 
 __global__ __launch_bounds__(512) void gp_mlp_fwd_kernel(MlpDev p, float* __restrict__ out, float* __restrict__ saved_x,

@@ -695,6 +695,12 @@ __device__ __forceinline__ void load_row_nn(const BlendDev& a, long i, float (&r
     const float4* r4 = (const float4*)(a.raw_w + i * 2 * NN);
 #pragma unroll
     for (int u = 0; u < 2 * NN / 4; ++u) { const float4 t = r4[u]; raw[4 * u] = t.x; raw[4 * u + 1] = t.y; raw[4 * u + 2] = t.z; raw[4 * u + 3] = t.w; }
+    if (a.knn16) {            // packed copy: NN / 2 dwords per row instead of NN quadwords (36 of ~170 B per Gaussian at nn = 6)
+        const uint32_t* k1 = (const uint32_t*)(a.knn16 + i * NN);
+#pragma unroll
+        for (int u = 0; u < NN / 2; ++u) { const uint32_t t = k1[u]; kps[2 * u] = (int)(t & 0xFFFFu); kps[2 * u + 1] = (int)(t >> 16); }
+        return;
+    }
     typedef long long ll2 __attribute__((ext_vector_type(2)));
     const ll2* k2 = (const ll2*)(a.knn + i * NN);
 #pragma unroll
@@ -746,7 +752,7 @@ __device__ __forceinline__ void blend_fwd_body(BlendDev a, float* __restrict__ x
             }
         } else {
             for (int k = 0; k < nn; ++k) {
-                const long kp = a.knn[i * nn + k];
+                const long kp = a.knn16 ? (long)a.knn16[i * nn + k] : a.knn[i * nn + k];
                 const float* dl = a.delta + kp * od;
                 dxyz[0] = fmaf(wx[k], dl[0], dxyz[0]);
                 dxyz[1] = fmaf(wx[k], dl[1], dxyz[1]);
@@ -864,7 +870,7 @@ __device__ __forceinline__ void blend_bwd_body(BlendDev a, const float* __restri
                 }
 #pragma unroll
                 for (int k = 0; k < nn; ++k) {
-                    if (NN == 0) kps[k] = (int)a.knn[i * nn + k];
+                    if (NN == 0) kps[k] = a.knn16 ? (int)a.knn16[i * nn + k] : (int)a.knn[i * nn + k];
                     const float* dl = s_delta + kps[k] * od;
                     const float v[4] = {dl[3], dl[4], dl[5], dl[6]};          // (normalised in LDS when norm_rotation)
                     dq[0] = fmaf(wr[k], v[0], dq[0]); dq[1] = fmaf(wr[k], v[1], dq[1]);

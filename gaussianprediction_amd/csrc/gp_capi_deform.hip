@@ -138,8 +138,9 @@ static int make_blend(const gp_blend_args* a, BlendDev& b) {
     if (a->nearest_num > 0 && (a->num_keypoints <= 0 || !a->raw_w || !a->knn_idx)) GP_FAIL("stage-2 blend needs keypoints, raw_w and knn_idx");
     if (a->nearest_num > 0 && a->num_keypoints * 7 * sizeof(float) > 60000) GP_FAIL("too many keypoints (%ld) for the LDS accumulator", (long)a->num_keypoints);
     if (a->num_gaussians > 0 && (!a->delta || !a->xyz || !a->rot)) GP_FAIL("null blend input");
+    if (a->knn_idx16 && (a->num_keypoints > 65535 || ((uintptr_t)a->knn_idx16 & 3) != 0)) GP_FAIL("knn_idx16 needs K < 65536 and 4-byte alignment");
     b.N = a->num_gaussians; b.K = a->num_keypoints; b.nn = a->nearest_num; b.out_dim = a->out_dim;
-    b.norm_rotation = a->norm_rotation; b.delta = a->delta; b.raw_w = a->raw_w; b.knn = a->knn_idx; b.xyz = a->xyz; b.rot = a->rot;
+    b.norm_rotation = a->norm_rotation; b.delta = a->delta; b.raw_w = a->raw_w; b.knn = a->knn_idx; b.xyz = a->xyz; b.rot = a->rot; b.knn16 = a->knn_idx16;
     return 0;
 }
 

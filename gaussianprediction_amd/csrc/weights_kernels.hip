@@ -196,7 +196,8 @@ template <int D, int NN>
 __global__ __launch_bounds__(256) void gp_knn_kernel(long n, const float* __restrict__ xyz, const float* __restrict__ feat,
                                                     float amplify, int K, const float* __restrict__ kp_xyz,
                                                     const float* __restrict__ kp_feat, const int32_t* __restrict__ order,
-                                                    int64_t* __restrict__ idx_out, float* __restrict__ d2_out) {
+                                                    int64_t* __restrict__ idx_out, float* __restrict__ d2_out,
+                                                    uint16_t* __restrict__ idx16_out) {
     __shared__ float s_kp[D][KNN_TILE];
     const int tid = threadIdx.x;
     const long nchunks = (n + 255) / 256;
@@ -284,6 +285,7 @@ __global__ __launch_bounds__(256) void gp_knn_kernel(long n, const float* __rest
             for (int k = 0; k < NN; ++k) {
                 idx_out[i * NN + k] = best_i[k];
                 if (d2_out) d2_out[i * NN + k] = best_d[k];
+                if (idx16_out) idx16_out[i * NN + k] = (uint16_t)best_i[k];       // (the blend kernels' packed copy: K < 65536)
             }
         }
     }
@@ -291,9 +293,10 @@ __global__ __launch_bounds__(256) void gp_knn_kernel(long n, const float* __rest
 
 template <int D>
 static void launch_knn(int nn, dim3 grid, hipStream_t s, long n, const float* xyz, const float* feat, float amplify, int K,
-                       const float* kp_xyz, const float* kp_feat, const int32_t* order, int64_t* idx_out, float* d2_out) {
+                       const float* kp_xyz, const float* kp_feat, const int32_t* order, int64_t* idx_out, float* d2_out,
+                       uint16_t* idx16_out) {
 #define KNN_CASE(NNV) case NNV: hipLaunchKernelGGL((gp_knn_kernel<D, NNV>), grid, dim3(256), 0, s, n, xyz, feat, amplify, K, kp_xyz, \
-                                                   kp_feat, order, idx_out, d2_out); break;
+                                                   kp_feat, order, idx_out, d2_out, idx16_out); break;
     switch (nn) {
         KNN_CASE(1) KNN_CASE(2) KNN_CASE(3) KNN_CASE(4) KNN_CASE(5) KNN_CASE(6) KNN_CASE(7) KNN_CASE(8)
         KNN_CASE(9) KNN_CASE(10) KNN_CASE(11) KNN_CASE(12) KNN_CASE(13) KNN_CASE(14) KNN_CASE(15) KNN_CASE(16)
@@ -303,12 +306,13 @@ static void launch_knn(int nn, dim3 grid, hipStream_t s, long n, const float* xy
 
 extern "C" int gp_knn_keypoints(int64_t n, const float* xyz, const float* feat, int32_t feat_dim, float amplify, int64_t K,
                                 const float* kp_xyz, const float* kp_feat, int32_t nn, const int32_t* order, int64_t* idx_out,
-                                float* d2_out, gp_stream_t stream_) {
+                                float* d2_out, uint16_t* idx16_out, gp_stream_t stream_) {
     if (n < 0 || K < 0) GP_FAIL("negative size");
     if (n == 0) return 0;
     if (nn < 1 || nn > KNN_MAX_NN) GP_FAIL("knn: nearest_num %d unsupported (1..%d)", nn, KNN_MAX_NN);
     if (K < nn) GP_FAIL("knn: fewer keypoints (%ld) than nearest_num (%d)", (long)K, nn);
     if (!xyz || !kp_xyz || !idx_out) GP_FAIL("null argument");
+    if (idx16_out && K > 65535) GP_FAIL("knn: idx16_out needs fewer than 65536 keypoints");
     if (feat_dim != 0 && feat_dim != 32) GP_FAIL("knn: feature_dim must be 0 (knn_type 3D) or 32 (knn_type hybird), got %d", feat_dim);
     if (feat_dim && (!feat || !kp_feat)) GP_FAIL("knn: null feature pointers");
     hipStream_t s = (hipStream_t)stream_;
@@ -317,8 +321,8 @@ extern "C" int gp_knn_keypoints(int64_t n, const float* xyz, const float* feat, 
     const unsigned nchunks = gp_blocks((size_t)n, 256);
     const unsigned resident = 256u * (feat_dim ? 4u : 8u);                             // workgroups the chip holds (registers / LDS of the two forms)
     const dim3 grid(K <= KNN_TILE && nchunks > resident ? resident : nchunks);
-    if (feat_dim == 0) launch_knn<3>(nn, grid, s, (long)n, xyz, feat, amplify, (int)K, kp_xyz, kp_feat, order, idx_out, d2_out);
-    else launch_knn<35>(nn, grid, s, (long)n, xyz, feat, amplify, (int)K, kp_xyz, kp_feat, order, idx_out, d2_out);
+    if (feat_dim == 0) launch_knn<3>(nn, grid, s, (long)n, xyz, feat, amplify, (int)K, kp_xyz, kp_feat, order, idx_out, d2_out, idx16_out);
+    else launch_knn<35>(nn, grid, s, (long)n, xyz, feat, amplify, (int)K, kp_xyz, kp_feat, order, idx_out, d2_out, idx16_out);
     GP_LAUNCH_CHECK();
     return 0;
 }

@@ -240,6 +240,24 @@ def _overwrite_sink(leaf):
     return None
 
 
+def packed_idx16(knn_idx, K):
+    """The neighbour indices as 16-bit words (gp_blend_args.knn_idx16): the reference's tensor is int64, 8 bytes per neighbour for
+    values below K <= 512 -- 48 of the ~170 bytes per Gaussian each blend kernel moves.  Made once per index tensor state (the
+    neighbour-search kernel emits it itself, weights_ops.knn_keypoints) and kept on the tensor."""
+    if K > 65535 or knn_idx is None:
+        return None
+    key = (knn_idx._version, knn_idx.data_ptr(), tuple(knn_idx.shape))
+    c = getattr(knn_idx, "_gp_idx16", None)
+    if c is not None and c[0] == key:
+        return c[1]
+    t16 = knn_idx.detach().to(torch.int32).to(torch.int16).contiguous()      # (K < 65536: the low 16 bits are the index)
+    try:
+        knn_idx._gp_idx16 = (key, t16)
+    except Exception:
+        pass
+    return t16
+
+
 class KeypointBlend(torch.autograd.Function):
     """(xyz_t, q_t) from per-keypoint (nn>0) or per-Gaussian (raw_w is None) deltas."""
 
@@ -258,9 +276,11 @@ class KeypointBlend(torch.autograd.Function):
                 raise RuntimeError("raw_w must be [N, 2*nearest_num]")
         else:
             raw_c, idx_c, nn_, K = None, None, 0, 0
+        idx16 = packed_idx16(knn_idx, K) if raw_w is not None else None
         args = _lib.BlendArgsC(N, K, nn_, delta_c.shape[1], int(bool(norm_rotation)), delta_c.data_ptr(),
                                raw_c.data_ptr() if raw_c is not None else None,
-                               idx_c.data_ptr() if idx_c is not None else None, xyz_c.data_ptr(), rot_c.data_ptr())
+                               idx_c.data_ptr() if idx_c is not None else None, xyz_c.data_ptr(), rot_c.data_ptr(),
+                               idx16.data_ptr() if idx16 is not None else None)
         xyz_t = torch.empty(N, 3, device=dev)
         q_t = torch.empty(N, 4, device=dev)
         with _lib.on_device(dev):
@@ -270,6 +290,7 @@ class KeypointBlend(torch.autograd.Function):
         ctx.save_for_backward(delta_c, raw_c if raw_c is not None else e,
                               idx_c if idx_c is not None else torch.empty(0, dtype=torch.int64, device=dev), xyz_c, rot_c)
         ctx.meta = (nn_, K, int(bool(norm_rotation)))
+        ctx.idx16 = idx16
         ctx.leaves = (xyz, rot)
         return xyz_t, q_t
 
@@ -283,7 +304,7 @@ class KeypointBlend(torch.autograd.Function):
         gq = g_q_t.to(torch.float32).contiguous() if g_q_t is not None else torch.zeros(N, 4, device=dev)
         args = _lib.BlendArgsC(N, K, nn_, delta_c.shape[1], norm_rotation, delta_c.data_ptr(),
                                raw_c.data_ptr() if nn_ else None, idx_c.data_ptr() if nn_ else None, xyz_c.data_ptr(),
-                               rot_c.data_ptr())
+                               rot_c.data_ptr(), ctx.idx16.data_ptr() if (nn_ and ctx.idx16 is not None) else None)
         g_delta = torch.empty_like(delta_c)          # every element is written (stage 1: per row; stage 2/3: by the reduction)
         g_raw = torch.empty_like(raw_c) if (nn_ and ctx.needs_input_grad[1]) else None    # frozen weights: not computed
         # a leaf whose gradient buffer the optimizer left stale is OVERWRITTEN in place (no temporary + AccumulateGrad pass)

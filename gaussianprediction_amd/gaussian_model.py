@@ -144,6 +144,8 @@ class GaussianModel(TrainingMixin, nn.Module):
                 with torch.cuda.stream(side):
                     nearest = run()
                 nearest.record_stream(cur)
+                if getattr(nearest, "_gp_idx16", None) is not None:       # (the packed copy the search kernel wrote beside it)
+                    nearest._gp_idx16[1].record_stream(cur)
                 self._knn_pending = side
             else:
                 nearest = run()

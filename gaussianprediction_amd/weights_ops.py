@@ -183,14 +183,18 @@ def knn_keypoints(xyz, kp_xyz, nearest_num, feat=None, kp_feat=None, feature_amp
     kf = kp_feat.detach().to(torch.float32).contiguous() if hybrid else None
     n, K = x.shape[0], k.shape[0]
     idx = torch.empty(n, nearest_num, dtype=torch.int64, device=x.device)
+    idx16 = torch.empty(n, nearest_num, dtype=torch.int16, device=x.device) if K < 65536 else None   # the blend kernels' packed copy
     d2 = torch.empty(n, nearest_num, device=x.device) if return_dist else None
     if order is not None and (order.dtype != torch.int32 or order.shape[0] != n or not order.is_contiguous() or order.device != x.device):
         raise RuntimeError("knn: order must be a contiguous int32 permutation of the points, on their device")
     with _lib.on_device(x.device):
         rc = _lib.lib().gp_knn_keypoints(C.c_int64(n), _lib.ptr(x), _lib.ptr(f), C.c_int32(f.shape[1] if hybrid else 0),
                                          C.c_float(feature_amplify), C.c_int64(K), _lib.ptr(k), _lib.ptr(kf),
-                                         C.c_int32(nearest_num), _lib.ptr(order), _lib.ptr(idx), _lib.ptr(d2), _lib.stream_ptr(x.device))
+                                         C.c_int32(nearest_num), _lib.ptr(order), _lib.ptr(idx), _lib.ptr(d2), _lib.ptr(idx16),
+                                         _lib.stream_ptr(x.device))
         _lib.check(rc, "gp_knn_keypoints")
+    if idx16 is not None:
+        idx._gp_idx16 = ((idx._version, idx.data_ptr(), tuple(idx.shape)), idx16)      # (deform_ops.packed_idx16 finds it here)
     return (idx, d2) if return_dist else idx
 
 

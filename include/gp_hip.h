@@ -241,6 +241,9 @@ typedef struct gp_blend_args {
     const int64_t* knn_idx;  /* [N, nn] or NULL */
     const float* xyz;        /* [N,3] */
     const float* rot;        /* [N,4] raw (un-normalised) _rotation */
+    const uint16_t* knn_idx16; /* optional: the same indices as 16-bit words (K < 65536; 4-byte aligned).  The reference's
+                                * tensor is int64 [REF scene/gaussian_model.py:110-125]: 8 B per neighbour for values below 512;
+                                * with this copy the kernels read 2 (gp_knn_keypoints can emit it; NULL = read knn_idx) */
 } gp_blend_args;
 
 int gp_blend_forward(const gp_blend_args* a, float* xyz_t /*[N,3]*/, float* q_t /*[N,4]*/, gp_stream_t stream);
@@ -342,12 +345,13 @@ int gp_weights_backward(const gp_hashgrid_config* cfg, int64_t n, const float* x
                         void* alloc_ctx, gp_stream_t stream);
 /* idx_out[n, nn] (int64, ascending squared distance; ties to the lower index) = the nn nearest of the K keypoints, in 3-D
  * (feat_dim = 0: knn_type "3D") or in [xyz | amplify * feature] (feat_dim = 32: "hybird")
- * [REF scene/gaussian_model.py:110-125, frnn.frnn_grid_points].  d2_out (optional) receives the squared distances.
+ * [REF scene/gaussian_model.py:110-125, frnn.frnn_grid_points].  d2_out (optional) receives the squared distances, idx16_out
+ * (optional, K < 65536) the indices again as 16-bit words (gp_blend_args.knn_idx16).
  * order (optional, int32[n]: a permutation of the points, e.g. along a Morton curve) only decides which points share a
  * wavefront -- spatially coherent wavefronts drop most keypoints after 3 of the 35 dimensions; the result does not depend on it. */
 int gp_knn_keypoints(int64_t n, const float* xyz, const float* feat, int32_t feat_dim, float amplify, int64_t K,
                      const float* kp_xyz, const float* kp_feat, int32_t nn, const int32_t* order, int64_t* idx_out, float* d2_out,
-                     gp_stream_t stream);
+                     uint16_t* idx16_out, gp_stream_t stream);
 
 /* out[n] = mean of the squared distances from point i to its three nearest OTHER points (self excluded by index): replaces
  * simple_knn's distCUDA2, which sizes the initial Gaussians [REF scene/gaussian_model.py:340-341 create_from_pcd].  Exact brute
