@@ -77,15 +77,38 @@ def build_workload(args, device):
     return pc, cams, gts, margs
 
 
-def cpu_baseline(args, pc, cams, seconds_budget=30.0):
-    """The oracle (a CPU port of the same path) timed on this box's host cores, on a bounded sample: ONE view, rasterizer
-    forward + backward (C oracle, OpenMP) fed by the deformed Gaussians, at 16 threads, at every core, and -- budget
-    permitting -- at one thread; the BEST of them is the baseline (its OpenMP loops stop scaling long before 256 threads)."""
+def cpu_baseline(args, pc, cams, gts, margs, seconds_budget=30.0):
+    """The oracle (a CPU port of the same path) timed on this box's host cores, on a bounded sample: ONE view of the same step,
+    leg by leg -- deformation forward + backward (oracle/deform_oracle.py, the reference's dense scatter + matmul form, torch on
+    CPU), rasterizer forward + backward (C oracle, OpenMP: at 16 threads, at every core and -- budget permitting -- at one; the
+    best of them counts, its loops stop scaling long before 256 threads), L1 + SSIM forward + backward (torch on CPU) and one Adam
+    step over all parameters (torch.optim.Adam on CPU copies).  value = 1 / the sum of the legs."""
+    from oracle import deform_oracle as do
     from oracle.oracle import RasterOracle, RasterSettings
     cam = cams[0]
+    legs = {}
+    dev = pc.get_xyz.device
+    t_cpu = torch.from_numpy(cam.time).float()
+    # ---- deformation, stage 3 [REF scene/gaussian_model.py:231-304]
+    try:
+        P = {"xyz": pc._xyz, "rotation": pc._rotation, "scaling": pc._scaling, "opacity": pc._opacity, "motion_feature": pc.motion_feature,
+             "super_gaussians": pc.super_gaussians, "super_gaussians_feature": pc.super_gaussians_feature}
+        P = {k: v.detach().float().cpu().requires_grad_(True) for k, v in P.items()}
+        sd = {k: v.detach().float().cpu().requires_grad_(True) for k, v in pc.df_model.state_dict().items()}
+        oa = SimpleNamespace(**vars(margs))
+        oa.xyz_freq, oa.time_freq = 10, args.time_freq
+        rw, idx = pc.raw_weights.detach().float().cpu(), pc.knn_idx.detach().cpu()
+        t0 = time.perf_counter()
+        x_, q_, s_, o_ = do.deform_forward(P, sd, t_cpu, args.iteration, oa, rw, idx)
+        (x_.sum() + q_.sum() + s_.sum() + o_.sum()).backward()
+        legs["deform_fwd_bwd"] = time.perf_counter() - t0
+        del x_, q_, s_, o_
+    except Exception as e:
+        legs["deform_fwd_bwd"] = None
+        legs["deform_error"] = str(e)[:200]
+    # ---- rasterizer
     with torch.no_grad():
-        t = torch.from_numpy(cam.time).float().to(pc.get_xyz.device)
-        xyz, q, s, o = pc(t, args.iteration)
+        xyz, q, s, o = pc(t_cpu.to(dev), args.iteration)
         shs = pc.get_features
     n64 = lambda x: x.detach().float().cpu().numpy().astype(np.float64)
     st = RasterSettings(image_height=cam.image_height, image_width=cam.image_width, tanfovx=math.tan(cam.FoVx * 0.5),
@@ -94,7 +117,7 @@ def cpu_baseline(args, pc, cams, seconds_budget=30.0):
                         campos=n64(cam.camera_center))
     cores = os.cpu_count() or 1
     A = dict(means3D=n64(xyz), opacities=n64(o), shs=n64(shs), scales=n64(s), rotations=n64(q))
-    g = None
+    g, image = None, None
     timings, spent = {}, 0.0
     for threads in sorted({min(16, cores), cores}) + [1]:
         if threads in timings:
@@ -106,14 +129,33 @@ def cpu_baseline(args, pc, cams, seconds_budget=30.0):
         sres = orc.forward(st, A["means3D"], A["opacities"], shs=A["shs"], scales=A["scales"], rotations=A["rotations"])
         if g is None:
             g = np.random.default_rng(0).normal(size=sres["out_color"].shape)
+            image = torch.tensor(np.asarray(sres["out_color"], dtype=np.float32))
         orc.backward(sres, g)
         timings[threads] = time.perf_counter() - t0
         spent += timings[threads]
     best = min(timings, key=timings.get)
-    return {"value": 1.0 / timings[best], "unit": "views/s", "cores": best, "kind": "port",
-            "sample": "1 view: C oracle raster forward+backward (OpenMP), same scene/camera; seconds by thread count: "
+    legs["raster_fwd_bwd"] = timings[best]
+    # ---- loss [REF train.py:105-108, utils/loss_utils.py]
+    img = image.clone().requires_grad_(True)
+    gt = gts[0].detach().float().cpu()
+    t0 = time.perf_counter()
+    loss = 0.8 * do.l1_loss(img, gt) + 0.2 * (1.0 - do.ssim(img, gt))
+    loss.backward()
+    legs["l1_ssim_fwd_bwd"] = time.perf_counter() - t0
+    # ---- Adam over every parameter [REF train.py:196-197]
+    cp = [torch.nn.Parameter(p.detach().float().cpu().clone()) for p in pc.bucket.params]
+    for p_ in cp:
+        p_.grad = torch.full_like(p_, 1e-3)
+    opt = torch.optim.Adam(cp, lr=1e-4, eps=1e-15)
+    t0 = time.perf_counter()
+    opt.step()
+    legs["adam_step"] = time.perf_counter() - t0
+    total = sum(v for k, v in legs.items() if isinstance(v, float))
+    return {"value": 1.0 / total, "unit": "views/s", "cores": best, "kind": "port", "legs_s": {k: (round(v, 3) if isinstance(v, float) else v) for k, v in legs.items()},
+            "sample": "1 view of the same train step, leg by leg (legs_s): deformation fwd+bwd (torch CPU, the reference's dense form), "
+                      "raster fwd+bwd (C oracle, OpenMP; seconds by thread count: "
                       + ", ".join(f"{k}: {v:.2f}" for k, v in sorted(timings.items()))
-                      + f"; host has {cores} hardware threads; deformation/loss/Adam not included"}
+                      + f"; `cores` = the best), L1+SSIM fwd+bwd and one Adam step (torch CPU, its own thread pool); host has {cores} hardware threads"}
 
 
 import contextlib
@@ -220,6 +262,9 @@ def main():
                     help="N > 1, sharded exchange: keep the SH regions' Adam + all-gather on the compute stream (A/B of TrainStep._chain_sh)")
     ap.add_argument("--replicated-adam", action="store_true",
                     help="N > 1: all-reduce + replicated Adam (round 1) instead of reduce-scatter -> sharded Adam -> all-gather")
+    ap.add_argument("--time-waits", action="store_true",
+                    help="N > 1, sharded exchange: bracket every wait of the compute stream for a collective with events and report "
+                         "config.exposed_wait_ms_per_step (adds a few stream bubbles: an A/B aid, not the headline run)")
     ap.add_argument("--dry-launch", action="store_true",
                     help="launch path only: N ranks rendezvous over gloo, one all-reduce, one JSON line, no device work")
     args = ap.parse_args()
@@ -284,6 +329,9 @@ def main():
     # bracket costs ~10 us of stream bubble, so the full per-kernel table is taken in a separate pass
     _lib.profile_enable(1)
     _lib.profile_collect()
+    if args.time_waits and getattr(ts.reducer, "exposed_wait_ms", None):
+        ts.reducer.time_waits = True
+        ts.reducer.exposed_wait_ms(1)                  # (drop what the warm-up recorded)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     pkg = None
@@ -295,6 +343,9 @@ def main():
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    waits = ts.reducer.exposed_wait_ms(args.steps) if (args.time_waits and getattr(ts.reducer, "exposed_wait_ms", None)) else None
+    if waits is not None:
+        ts.reducer.time_waits = False
     prof = _lib.profile_collect()
     _lib.profile_enable(0)
     # eval-style forward renders (the "rendered views/s" half of the metric, [REF eval.py:208-224]); separate
@@ -366,6 +417,30 @@ def main():
             # source (it is stamped with the source's hash); otherwise null -- a stale constant is not a measurement
             tf = os.path.join(ROOT, "profiles", "composite_fwd_traffic.json")
             roof["traffic_source"] = None
+            roof["traffic_measured_in_this_run"] = False          # (`traffic` is a stored PMC result of the same kernel source)
+            try:
+                # contributing (pixel, splat) pairs, counted by the kernel's counting variant on one untimed render of the last view,
+                # and the instruction floor they imply: every contributing pair costs at least the straight-line visit of the
+                # kernel (21 vector-ALU instructions per 64 pairs), on 1024 SIMDs issuing one wave64 instruction per 4 cycles
+                import ctypes as C
+                L = _lib.lib()
+                _lib.check(L.gp_debug_option(0, 3), "opt")
+                cnt = (C.c_uint64 * 4)()
+                _lib.check(L.gp_debug_counters(cnt), "counters")          # (clears what earlier renders left)
+                with torch.no_grad():
+                    raster_forward_debug(_settings(cam, pc, ts.bg, 1.0), xyz, o, shs=pc.get_features, scales=s, rotations=q)
+                _lib.check(L.gp_debug_counters(cnt), "counters")
+                _lib.check(L.gp_debug_option(0, 0), "opt")
+                MIN_VALU = 21
+                roof["contributing_pairs"], roof["evaluated_pairs"] = int(cnt[0]), int(cnt[1])
+                roof["min_valu_per_pair"] = MIN_VALU
+                roof["valu_lower_bound_ms"] = round(int(cnt[0]) * MIN_VALU / 64.0 * 4.0 / 1024.0 / (SHADER_CLOCK_GHZ * 1e9) * 1e3, 4)
+            except Exception as e:
+                roof["contributing_pairs"] = f"failed: {e}"
+                try:
+                    _lib.check(_lib.lib().gp_debug_option(0, 0), "opt")
+                except Exception:
+                    pass
             if os.path.exists(tf):
                 try:
                     tj = json.load(open(tf))
@@ -439,6 +514,7 @@ def main():
                            + (" [ONE-rank group, GP_DIST_FORCE_SINGLE: the code path, not a scaling number]" if world == 1 else "")),
                        "xgmi_bytes_sent_per_rank_per_step": None if world == 1 else (
                            getattr(ts.reducer, "bytes_sent_per_step", None) or int(2 * 4 * ts.bucket.flat.numel() * (world - 1) / world)),
+                       "exposed_wait_ms_per_step": waits,          # (--time-waits: compute-stream time inside waits for collectives, rank 0)
                        "binning": "exact (R read back every step)" if args.exact_binning else
                                   f"capacity mode in warm-up and timed steps (no host sync; {preroll} exact-mode set-up steps before the "
                                   f"warm-up; {getattr(ts, 'redone', 0)} frames repeated after overflow)",
@@ -462,7 +538,7 @@ def main():
                 roof["peak_measured"] = f"failed: {e}"
         if not args.no_cpu_baseline and world == 1:
             try:
-                result["cpu_baseline"] = cpu_baseline(args, pc, cams)
+                result["cpu_baseline"] = cpu_baseline(args, pc, cams, gts, margs)
             except Exception as e:  # the baseline must never kill the bench line
                 result["cpu_baseline"] = {"value": None, "unit": "views/s", "cores": os.cpu_count(), "kind": "port",
                                           "sample": f"failed: {e}"}

@@ -252,7 +252,7 @@ extern "C" int gp_raster_forward(const gp_raster_settings* st, const gp_raster_i
         GP_LAUNCH_CHECK();
     }
     { GpProfScope _p("composite_fwd", s, 1);
-        hipLaunchKernelGGL((gp_debug_get(0) == 2 ? gp_composite_fwd_sbc_kernel : gp_composite_fwd_sb_kernel), dim3((unsigned)T), dim3(256), 0, s, d, il.ranges, point_list, gl.rec, st->bg,
+        hipLaunchKernelGGL((gp_debug_get(0) == 3 ? gp_composite_fwd_count_kernel : gp_debug_get(0) == 2 ? gp_composite_fwd_sbc_kernel : gp_composite_fwd_sb_kernel), dim3((unsigned)T), dim3(256), 0, s, d, il.ranges, point_list, gl.rec, st->bg,
                        out->color, out->depth, out->tidx, il.final_T, il.n_contrib, il.order, il.tile_work,
                        point_list ? (uint8_t*)point_list + gp_align_up((size_t)R * 4, 256) : (uint8_t*)nullptr);
     GP_LAUNCH_CHECK(); }
@@ -334,6 +334,14 @@ extern "C" int gp_raster_backward(const gp_raster_settings* st, const gp_raster_
                            g->dL_drotations, g->dL_dcov3D_precomp, (kern != gp_preprocess_bwd_kernel) ? g->accumulate_shs : 0, af);
         GP_LAUNCH_CHECK();
     }
+    return 0;
+}
+
+extern "C" int gp_debug_counters(uint64_t* out4) {
+    if (!out4) GP_FAIL("null argument");
+    unsigned long long v[4];
+    if (gp_pair_counters_read(v)) GP_FAIL("gp_debug_counters: device read failed");
+    for (int k = 0; k < 4; ++k) out4[k] = v[k];
     return 0;
 }
 

@@ -71,6 +71,17 @@ __global__ __launch_bounds__(256) void gp_composite_fwd_sb_kernel(RasterDims d, 
                                                                   float* __restrict__ final_T,
                                                                   int32_t* __restrict__ n_contrib, const uint32_t* __restrict__ order, int32_t* __restrict__ tile_work, uint8_t* __restrict__ qmask);
 
+int gp_pair_counters_read(unsigned long long* out4);
+__global__ __launch_bounds__(256) void gp_composite_fwd_count_kernel(RasterDims d, const int2* __restrict__ ranges,
+                                                                  const uint32_t* __restrict__ point_list,
+                                                                  const float4* __restrict__ rec,
+                                                                  const float* __restrict__ bg,
+                                                                  float* __restrict__ out_color,
+                                                                  float* __restrict__ out_depth,
+                                                                  int32_t* __restrict__ out_tidx,
+                                                                  float* __restrict__ final_T,
+                                                                  int32_t* __restrict__ n_contrib, const uint32_t* __restrict__ order, int32_t* __restrict__ tile_work, uint8_t* __restrict__ qmask);
+
 __global__ __launch_bounds__(256) void gp_composite_fwd_sbc_kernel(RasterDims d, const int2* __restrict__ ranges,
                                                                   const uint32_t* __restrict__ point_list,
                                                                   const float4* __restrict__ rec,

@@ -602,7 +602,12 @@ __device__ __forceinline__ uint32_t gp_sb_mask(const float4 q0, const float4 q1,
     return mask;
 }
 
+// (MODE 2) pair counters of the composite forward: [0] (pixel, splat) pairs that CONTRIBUTE (alpha >= 1/255, pixel not saturated),
+// [1] pairs the sub-block lists make the kernel evaluate.  Read and cleared by gp_debug_counters(); bench.py's roofline.contributing_pairs.
+__device__ unsigned long long g_pair_counters[4];
+
 template <int MODE>   // 0: compiler-scheduled visit loop (the readable statement of the algorithm)  1: hand-scheduled (shipped)
+                      // 2: as 0, and counts evaluated / contributing pairs into g_pair_counters (diagnostics)
 __device__ __forceinline__ void gp_composite_fwd_sb_body(RasterDims d, const int2* __restrict__ ranges,
                                                                          const uint32_t* __restrict__ point_list,
                                                                          const float4* __restrict__ rec,
@@ -646,6 +651,7 @@ __device__ __forceinline__ void gp_composite_fwd_sb_body(RasterDims d, const int
     const float X0 = (float)(tx * GP_TILE), Y0 = (float)(ty * GP_TILE);
     const unsigned short* lst = s_list[mysb];
     v2f C01 = {0.f, 0.f}, C2D = {0.f, 0.f};              // (C0, C1), (C2, depth): the packed accumulators of the asm path
+    unsigned n_eval = 0, n_contr = 0;                    // (MODE 2 only)
 
     for (int base = range.x; base < range.y; base += CF_THREADS) {
         __syncthreads();
@@ -792,6 +798,7 @@ __device__ __forceinline__ void gp_composite_fwd_sb_body(RasterDims d, const int
                     const bool act = i < lim;
                     if (!__any(act)) break;
                     if (act) {
+                        if (MODE == 2) ++n_eval;
                         const int off = (int)lst[i];
                         const float4 q0 = *(const float4*)(s_rec + off);
                         const float4 q1 = *(const float4*)(s_rec + off + 16);
@@ -814,6 +821,7 @@ __device__ __forceinline__ void gp_composite_fwd_sb_body(RasterDims d, const int
                                     if (w > best) { best = w; best_pos = posv; }
                                     T = test_T;
                                     last = posv;
+                                    if (MODE == 2) ++n_contr;
                                 }
                             }
                         }
@@ -822,6 +830,11 @@ __device__ __forceinline__ void gp_composite_fwd_sb_body(RasterDims d, const int
             }
             if (!__any(lim >= 0) && lane == 0) s_done[wave] = 1;
         }
+    }
+    if (MODE == 2) {
+#pragma unroll
+        for (int dd = 32; dd >= 1; dd >>= 1) { n_eval += __shfl_xor(n_eval, dd); n_contr += __shfl_xor(n_contr, dd); }
+        if (lane == 0) { atomicAdd(&g_pair_counters[0], (unsigned long long)n_contr); atomicAdd(&g_pair_counters[1], (unsigned long long)n_eval); }
     }
     const float C0 = C01.x, C1 = C01.y, C2 = C2D.x, Dp = C2D.y;
     const size_t HW = (size_t)d.H * d.W;
@@ -854,6 +867,15 @@ __global__ __launch_bounds__(CF_THREADS) void gp_composite_fwd_sb_kernel(CF2_ARG
 }
 __global__ __launch_bounds__(CF_THREADS) void gp_composite_fwd_sbc_kernel(CF2_ARGS) {   // compiler-scheduled inner loop (A/B reference)
     gp_composite_fwd_sb_body<0>(d, ranges, point_list, rec, bg, out_color, out_depth, out_tidx, final_T, n_contrib, order, tile_work, qmask);
+}
+__global__ __launch_bounds__(CF_THREADS) void gp_composite_fwd_count_kernel(CF2_ARGS) {   // ... + pair counters (gp_debug_option(0, 3))
+    gp_composite_fwd_sb_body<2>(d, ranges, point_list, rec, bg, out_color, out_depth, out_tidx, final_T, n_contrib, order, tile_work, qmask);
+}
+int gp_pair_counters_read(unsigned long long* out4) {
+    if (hipDeviceSynchronize() != hipSuccess) return 1;
+    if (hipMemcpyFromSymbol(out4, HIP_SYMBOL(g_pair_counters), 4 * sizeof(unsigned long long)) != hipSuccess) return 1;
+    unsigned long long z[4] = {0, 0, 0, 0};
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_pair_counters), z, sizeof(z)) == hipSuccess ? 0 : 1;
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -154,6 +154,10 @@ class ShardedExchange:
         self._chained = set()                   # region starts taken over this step
         self.side = torch.cuda.Stream(device=bucket.flat.device) if (self.enabled and bucket.flat.is_cuda) else None
         self._late_event, self._late_ids = None, set()
+        # optional: how long the COMPUTE stream sits in each kind of wait (a pair of events around the wait: with nothing else queued
+        # on the stream between them, their distance is the exposed part of the collective).  bench.py --time-waits.
+        self.time_waits = False
+        self._wait_events = []                  # (kind, before, after)
         self._issued = set()                    # region starts whose reduce-scatter the hooks have issued this step
         if self.enabled:
             from . import grad_sink
@@ -162,6 +166,33 @@ class ShardedExchange:
             hooks = {id(p): self._make_hook(p) for p in self.large}
             self._hook_handles = [p.register_post_accumulate_grad_hook(hooks[id(p)]) for p in self.large]
             self._sink_cb = grad_sink.register_callback(lambda p: hooks[id(p)](p) if id(p) in hooks else None)
+
+    def _timed_wait(self, kind, handles):
+        """h.wait() for every handle (the current stream waits for the collective), bracketed by events when time_waits is on."""
+        handles = [h for h in handles if h is not None]
+        if not handles:
+            return
+        if self.time_waits and self.bucket.flat.is_cuda:
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for h in handles:
+                h.wait()
+            b.record()
+            self._wait_events.append((kind, a, b))
+        else:
+            for h in handles:
+                h.wait()
+
+    def exposed_wait_ms(self, steps):
+        """{kind: ms per step the compute stream spent waiting} over the waits recorded since the last call (synchronises)."""
+        if not self._wait_events:
+            return {}
+        torch.cuda.synchronize(self.bucket.flat.device)
+        out = {}
+        for kind, a, b in self._wait_events:
+            out[kind] = out.get(kind, 0.0) + a.elapsed_time(b)
+        self._wait_events = []
+        return {k: round(v / max(steps, 1), 4) for k, v in out.items()}
 
     def close(self):
         """Detach from the parameters and the gradient-sink registry and drain what is in flight (call before the bucket is
@@ -220,8 +251,7 @@ class ShardedExchange:
         for region in self.bucket.regions:
             if region[0] not in self._issued:
                 self.handles.append(self._reduce_scatter(region))
-        for h in self.handles:
-            h.wait()
+        self._timed_wait("reduce_scatter", self.handles)
         self.handles.clear()
         self._fired.clear()
         self._issued.clear()
@@ -256,12 +286,13 @@ class ShardedExchange:
 
     def wait_params(self, only=None, exclude=None):
         """Make the current stream wait for the gathered parameters (`only` / `exclude`: sets of id(param))."""
-        rest = []
+        rest, now = [], []
         for ids, h, late in self._gather:
             if (only is not None and not (ids & only)) or (exclude is not None and ids <= exclude):
                 rest.append((ids, h, late))
             else:
-                h.wait()
+                now.append(h)
+        self._timed_wait("all_gather", now)
         self._gather = rest
         # late gathers handed to a rasterizer call as an event (late_event) are awaited on the SIDE stream only; if that call
         # never consumed the event (no Gaussians, an exception before the kernel) nothing else orders the compute stream behind
@@ -276,9 +307,7 @@ class ShardedExchange:
         and return a torch.cuda.Event that fires when those have landed (None if there are none): the rasterizer forward waits
         for it in front of its SH -> RGB kernel only (gp_raster_settings.sh_ready_event)."""
         late = [g for g in self._gather if g[2]]
-        for g in self._gather:
-            if not g[2]:
-                g[1].wait()
+        self._timed_wait("all_gather", [g[1] for g in self._gather if not g[2]])
         self._gather = []
         if not late:
             return None

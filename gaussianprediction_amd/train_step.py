@@ -298,7 +298,10 @@ class TrainStep:
         self._armed = False
         self.reducer.finish()                        # SUM over views == the reference's --batch semantics
         if getattr(self, "_flag_handle", None) is not None:
-            self._flag_handle.wait()
+            if self.sharded:
+                self.reducer._timed_wait("overflow_flag", [self._flag_handle])
+            else:
+                self._flag_handle.wait()
         elif skip_flag is not None and self.reducer.enabled:
             torch.distributed.all_reduce(skip_flag, op=torch.distributed.ReduceOp.MAX, group=self.group)
         pkg = pkgs[-1]

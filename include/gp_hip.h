@@ -402,6 +402,10 @@ int gp_microbench_gather(const void* src, int rec_bytes, int stride_bytes, const
  * key 5: 1 = tile binning by duplicate + radix sort instead of by counting, csrc/bin_kernels.hip).  Never needed by a caller of the
  * render path. */
 int gp_debug_option(int key, int value);
+/* Diagnostics: with gp_debug_option(0, 3) the composite forward counts, over all launches since the last call, out4[0] = the
+ * (pixel, splat) pairs that contribute (alpha >= 1/255, pixel not yet saturated) and out4[1] = the pairs its sub-block lists make
+ * it evaluate; this call synchronises the device, returns and clears them (bench.py: roofline.contributing_pairs). */
+int gp_debug_counters(uint64_t* out4);
 
 const char* gp_last_error(void);
 const char* gp_version(void);
