@@ -15,8 +15,8 @@ for c in FETCH_SIZE WRITE_SIZE; do
   timeout 300 rocprofv3 --pmc $c -d "$OUT/pmc_cal_$c" -o c --output-format csv -- python tools/pmc_calibrate.py > "$OUT/pmc_cal_$c.log" 2>&1
 done
 timeout 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAVES \
-  -d "$OUT/pmc_sq1" -o sq1 --output-format csv -- python tools/composite_lab.py --fwd 1,0 --reps 3 > "$OUT/pmc_sq1.log" 2>&1
+  -d "$OUT/pmc_sq1" -o sq1 --output-format csv -- python tools/composite_lab.py --fwd 2,0 --reps 3 > "$OUT/pmc_sq1.log" 2>&1
 timeout 300 rocprofv3 --pmc SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_WAIT_ANY SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_ANY SQ_INSTS_SMEM SQ_LDS_IDX_ACTIVE \
-  -d "$OUT/pmc_sq2" -o sq2 --output-format csv -- python tools/composite_lab.py --fwd 1,0 --reps 3 > "$OUT/pmc_sq2.log" 2>&1
+  -d "$OUT/pmc_sq2" -o sq2 --output-format csv -- python tools/composite_lab.py --fwd 2,0 --reps 3 > "$OUT/pmc_sq2.log" 2>&1
 ls "$OUT"
 tail -c 600 "$OUT/bench.json"

@@ -17,7 +17,7 @@ for r in rows[:48]:
                f"{float(r['MinNs'])/1e3:9.2f} {float(r['MaxNs'])/1e3:9.2f} {float(r['Percentage']):6.2f}")
 open(f"profiles/{tag}_kernel_stats.txt", "w").write("\n".join(out) + "\n")
 PY
-{ echo "# rocprofv3 --pmc <8 SQ counters> (two passes) -- python tools/composite_lab.py --fwd 1,0 --reps 3   (per-dispatch means; SQ_ACTIVE_INST_* and SQ_WAVE_CYCLES count quad-cycles; VALU busy = 4 * SQ_ACTIVE_INST_VALU / (1024 SIMDs * kernel cycles at 2.4 GHz))";
+{ echo "# rocprofv3 --pmc <8 SQ counters> (two passes) -- python tools/composite_lab.py --fwd 2,0 --reps 3   (per-dispatch means; SQ_ACTIVE_INST_* and SQ_WAVE_CYCLES count quad-cycles; VALU busy = 4 * SQ_ACTIVE_INST_VALU / (1024 SIMDs * kernel cycles at 2.4 GHz))";
   python tools/pmc_table.py "$IN/pmc_sq*/*counter_collection.csv" gp_composite; } > "profiles/${TAG}_pmc_sq.txt"
 python - "$TAG" <<'PY'
 # the VALU figures bench.py prints beside the HBM fraction: SQ counters of the shipped composite forward, same kernel source
