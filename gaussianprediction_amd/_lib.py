@@ -63,7 +63,7 @@ class AdamFuseC(C.Structure):
 
 class MlpParamsC(C.Structure):
     _fields_ = [("in_dim", C.c_int32), ("width", C.c_int32), ("depth", C.c_int32), ("out_dim", C.c_int32),
-                ("w", C.c_void_p * 5), ("b", C.c_void_p * 5)]
+                ("w", C.c_void_p * 5), ("b", C.c_void_p * 5), ("packed", C.c_void_p)]
 
 
 class Mlp16ParamsC(C.Structure):
@@ -95,7 +95,7 @@ class ProfileEntryC(C.Structure):
 
 EXPORTS = [
     "gp_raster_forward", "gp_raster_backward", "gp_raster_mark_visible", "gp_raster_debug_binning",
-    "gp_mlp_forward", "gp_mlp_backward", "gp_mlp16_forward", "gp_mlp16_backward", "gp_blend_forward", "gp_blend_backward",
+    "gp_mlp_forward", "gp_mlp_backward", "gp_mlp_pack", "gp_mlp_packed_floats", "gp_mlp16_forward", "gp_mlp16_backward", "gp_blend_forward", "gp_blend_backward",
     "gp_activations_forward", "gp_activations_backward", "gp_profile_enable", "gp_profile_collect",
     "gp_loss_l1_ssim_forward", "gp_loss_l1_ssim_finalize", "gp_loss_l1_ssim_backward", "gp_adam_step",
     "gp_adam_step_multi",
@@ -138,6 +138,7 @@ def lib() -> C.CDLL:
             if name not in ("gp_last_error", "gp_version"):
                 getattr(l, name).restype = C.c_int
         l.gp_hashgrid_table_entries.restype = C.c_int64
+        l.gp_mlp_packed_floats.restype = C.c_int64
         if int(l.gp_abi_version()) != GP_ABI_VERSION:
             raise GpHipError(f"{LIB_PATH} implements ABI {int(l.gp_abi_version())}, this binding is written against ABI "
                              f"{GP_ABI_VERSION} (include/gp_hip.h): rebuild the library (__graft_entry__.build(force=True))")

@@ -11,7 +11,32 @@ struct MlpDev {
     const float* feature;
     const float* xyz;
     const float* t;
+    const float* pk;        // fragment-ordered copy of w[0..3] for the small-row kernels (gp_mlp_pack), or NULL
 };
+
+// Layout of the fragment-ordered weight copy (float4 units).  A wave's operand load of the 16-row kernels is
+// (16 features) x (4 lane groups x one float4 of k): from the row-major matrices that is 16 separate 64-byte pieces per
+// instruction, and the rate at which ONE CU takes those in bounds a 250-row pass (deform_mlp_small.hip).  Here the float4 of
+// (tile t, k-step q, lane) sits at ((t * nq + q) * 64 + lane): one contiguous kilobyte per instruction.
+//   forward  layer l:  F_l[t][q][lane] = W_l[16 t + (lane & 15)][16 q + 4 (lane >> 4) + 0..3]            (out^T = W . cur^T)
+//   backward layer l:  B_l[t][q][lane] = W_l[16 q + 4 (lane >> 4) + 0..3][16 t + (lane & 15)]            (out^T = W^T . cur^T)
+struct MlpPackLayout {
+    int q0;                 // k-steps of layer 0's forward: ceil(in_dim / 16)
+    int tb0;                // tiles of layer 0's backward: 2 ceil(in_dim / 32)
+    long off_f[4], off_b[4], total;      // float4 offsets
+};
+static inline __host__ __device__ MlpPackLayout mlp_pack_layout(int in_dim) {
+    MlpPackLayout L;
+    L.q0 = (in_dim + 15) / 16;
+    L.tb0 = 2 * ((in_dim + 31) / 32);
+    long o = 0;
+    L.off_f[0] = o; o += 16L * L.q0 * 64;
+    for (int l = 1; l < 4; ++l) { L.off_f[l] = o; o += 16L * 16 * 64; }
+    L.off_b[0] = o; o += (long)L.tb0 * 16 * 64;
+    for (int l = 1; l < 4; ++l) { L.off_b[l] = o; o += 16L * 16 * 64; }
+    L.total = o;
+    return L;
+}
 
 struct MlpWeightJobs {
     const float* dZ[5];
@@ -32,6 +57,7 @@ struct BlendDev {
     const uint16_t* knn16;      // the neighbour indices as 16-bit words, or NULL
 };
 
+__global__ __launch_bounds__(256) void gp_mlp_pack_kernel(MlpDev p, float4* __restrict__ out);
 __global__ __launch_bounds__(512) void gp_mlp_fwd_kernel(MlpDev p, float* __restrict__ out, float* __restrict__ saved_x,
                                                          float* __restrict__ saved_h);
 __global__ __launch_bounds__(512) void gp_mlp_bwd_data_kernel(MlpDev p, const float* __restrict__ saved_h,

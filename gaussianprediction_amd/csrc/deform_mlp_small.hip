@@ -217,6 +217,103 @@ __device__ __forceinline__ void tiles_mfma_T_256(const float* __restrict__ W, in
     }
 }
 
+// ---- fragment-ordered weights (MlpPackLayout, deform_kernels.h): every operand load of a wave is one contiguous kilobyte ----------
+// generic k range (layer 0's forward: nq = ceil(in_dim / 16) k-steps, zero-padded in the copy)
+__device__ __forceinline__ void tiles_mfma_pk(const float4* __restrict__ P, int nq, int t0, const float* cur, int lane,
+                                              f32x4& acc0, f32x4& acc1) {
+    const int i = lane & 15, kg = lane >> 4;
+    const float4* w0 = P + (size_t)t0 * nq * 64 + lane;
+    const float4* w1 = w0 + (size_t)nq * 64;
+    for (int q0 = 0; q0 < nq; q0 += 2) {
+        float4 a0[2], a1[2];
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            const int q = q0 + g < nq ? q0 + g : nq - 1;          // (clamped: a repeated step is not used)
+            a0[g] = w0[64 * q]; a1[g] = w1[64 * q];
+        }
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            if (q0 + g < nq) {
+                const float* b = cur + (16 * (q0 + g) + kg) * SR + i;
+                const float b0 = b[0], b1 = b[4 * SR], b2 = b[8 * SR], b3 = b[12 * SR];
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[g].x, b0, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[g].x, b0, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[g].y, b1, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[g].y, b1, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[g].z, b2, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[g].z, b2, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[g].w, b3, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[g].w, b3, acc1, 0, 0, 0);
+            }
+        }
+    }
+}
+// K = 256 (16 k-steps), forward AND backward: the two copies differ in what they hold, not in how they are read -- the backward's
+// four scalar loads per k-step (W[k][r]: four rows) are one float4 of the B copy.  Same two-groups-ahead prefetch as tiles_mfma_256.
+__device__ __forceinline__ void tiles_mfma_256_pk(const float4* __restrict__ P, int t0, const float* cur, int lane,
+                                                  f32x4& acc0, f32x4& acc1) {
+    const int i = lane & 15, kg = lane >> 4;
+    const float4* w0 = P + (size_t)t0 * 16 * 64 + lane;
+    const float4* w1 = w0 + 16 * 64;
+    float4 a0[16], a1[16];
+    auto fetch = [&](int g) {
+#pragma unroll
+        for (int q = 4 * g; q < 4 * g + 4; ++q) { a0[q] = w0[64 * q]; a1[q] = w1[64 * q]; }
+    };
+    fetch(0);
+    fetch(1);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        if (g + 2 < 4) fetch(g + 2);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 4 * g; q < 4 * g + 4; ++q) {
+            const float* b = cur + (16 * q + kg) * SR + i;
+            const float b0 = b[0], b1 = b[4 * SR], b2 = b[8 * SR], b3 = b[12 * SR];
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[q].x, b0, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[q].x, b0, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[q].y, b1, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[q].y, b1, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[q].z, b2, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[q].z, b2, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[q].w, b3, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[q].w, b3, acc1, 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// one thread per float4 of the copy (0.9 MB: a few microseconds, once per weight state)
+__global__ __launch_bounds__(256) void gp_mlp_pack_kernel(MlpDev p, float4* __restrict__ out) {
+    const MlpPackLayout L = mlp_pack_layout(p.in_dim);
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= L.total) return;
+    int l = 0;
+    bool bwd = false;
+    long base = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (e >= L.off_f[k]) { l = k; bwd = false; base = L.off_f[k]; }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (e >= L.off_b[k]) { l = k; bwd = true; base = L.off_b[k]; }
+    }
+    const int ldw = l == 0 ? p.in_dim : SW;                    // W_l is [256, ldw]
+    const float* W = p.w[l];
+    const long r = e - base;
+    const int nq = (!bwd && l == 0) ? L.q0 : 16;
+    const int lane = (int)(r & 63), q = (int)((r >> 6) % nq), t = (int)((r >> 6) / nq);
+    const int i = lane & 15, k0 = 16 * q + 4 * (lane >> 4);
+    float v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        if (!bwd) { const int row = 16 * t + i, col = k0 + u; v[u] = col < ldw ? W[(size_t)row * ldw + col] : 0.f; }
+        else { const int row = k0 + u, col = 16 * t + i; v[u] = col < ldw ? W[(size_t)row * ldw + col] : 0.f; }
+    }
+    out[e] = make_float4(v[0], v[1], v[2], v[3]);
+}
+
 __global__ __launch_bounds__(ST) void gp_mlp_fwd_small_kernel(MlpDev p, float* __restrict__ out, float* __restrict__ saved_x,
                                                               float* __restrict__ saved_h) {
     __shared__ float smem[2][SW * SR];
@@ -237,7 +334,12 @@ __global__ __launch_bounds__(ST) void gp_mlp_fwd_small_kernel(MlpDev p, float* _
             acc0[r] = p.b[l][32 * wave + 4 * kg + r];
             acc1[r] = p.b[l][32 * wave + 16 + 4 * kg + r];
         }
-        if (l == 0) tiles_mfma(p.w[l], ldw, kv, K16, SW, 2 * wave, cur, lane, acc0, acc1);
+        if (p.pk) {
+            const MlpPackLayout L = mlp_pack_layout(p.in_dim);
+            const float4* P = (const float4*)p.pk + L.off_f[l];
+            if (l == 0) tiles_mfma_pk(P, L.q0, 2 * wave, cur, lane, acc0, acc1);
+            else tiles_mfma_256_pk(P, 2 * wave, cur, lane, acc0, acc1);
+        } else if (l == 0) tiles_mfma(p.w[l], ldw, kv, K16, SW, 2 * wave, cur, lane, acc0, acc1);
         else tiles_mfma_256(p.w[l], SW, 2 * wave, cur, lane, acc0, acc1);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -288,6 +390,7 @@ __global__ __launch_bounds__(ST) void gp_mlp_bwd_data_small_kernel(MlpDev p, con
         const int K16 = l == 4 ? 16 : SW, kv = l == 4 ? p.out_dim : SW;
         f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
         if (l == 4) tiles_mfma_T(p.w[l], SW, kv, K16, SW, 2 * wave, cur, lane, acc0, acc1);
+        else if (p.pk) tiles_mfma_256_pk((const float4*)p.pk + mlp_pack_layout(p.in_dim).off_b[l], 2 * wave, cur, lane, acc0, acc1);
         else tiles_mfma_T_256(p.w[l], SW, SW, 2 * wave, cur, lane, acc0, acc1);
         const float* h = saved_h + (size_t)(l - 1) * p.rows * SW;
         const long row = row0 + n;
@@ -306,7 +409,8 @@ __global__ __launch_bounds__(ST) void gp_mlp_bwd_data_small_kernel(MlpDev p, con
     if (dfeature || dxyz) {
         if (32 * wave < p.in_dim) {
             f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
-            tiles_mfma_T_256(p.w[0], p.in_dim, p.in_dim, 2 * wave, cur, lane, acc0, acc1);
+            if (p.pk) tiles_mfma_256_pk((const float4*)p.pk + mlp_pack_layout(p.in_dim).off_b[0], 2 * wave, cur, lane, acc0, acc1);
+            else tiles_mfma_T_256(p.w[0], p.in_dim, p.in_dim, 2 * wave, cur, lane, acc0, acc1);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 nxt[sidx(32 * wave + 4 * kg + r, n)] = acc0[r];

@@ -20,6 +20,29 @@ static int make_mlp(const gp_mlp_params* p, const gp_mlp_input* x, MlpDev& m) {
     m.feature_dim = x->feature_dim; m.xyz_freq = x->xyz_freq; m.time_freq = x->time_freq;
     for (int l = 0; l < 5; ++l) { m.w[l] = p->w[l]; m.b[l] = p->b[l]; }
     m.feature = x->feature; m.xyz = x->xyz; m.t = x->t;
+    m.pk = p->packed;
+    if (m.pk && ((uintptr_t)m.pk & 15) != 0) GP_FAIL("gp_mlp_params.packed must be 16-byte aligned");
+    return 0;
+}
+
+extern "C" int64_t gp_mlp_packed_floats(int32_t in_dim) {
+    if (in_dim <= 0 || in_dim > 256) return -1;
+    return 4 * (int64_t)mlp_pack_layout(in_dim).total;
+}
+
+extern "C" int gp_mlp_pack(const gp_mlp_params* p, float* packed, gp_stream_t stream_) {
+    if (!p || !packed) GP_FAIL("null argument");
+    if (p->width != 256 || p->depth != 4) GP_FAIL("Deformable_Field: only d=4, w=256 is implemented");
+    if (p->in_dim <= 0 || p->in_dim % 4 || p->in_dim > 256) GP_FAIL("in_dim %d must be a multiple of 4 and <= 256", p->in_dim);
+    if (((uintptr_t)packed & 15) != 0) GP_FAIL("packed must be 16-byte aligned");
+    MlpDev m;
+    memset(&m, 0, sizeof(m));
+    m.in_dim = p->in_dim;
+    for (int l = 0; l < 4; ++l) { if (!p->w[l]) GP_FAIL("null weight pointer (layer %d)", l); m.w[l] = p->w[l]; }
+    const long total = mlp_pack_layout(p->in_dim).total;
+    GpProfScope _p("mlp_pack", (hipStream_t)stream_);
+    hipLaunchKernelGGL(gp_mlp_pack_kernel, dim3(gp_blocks((size_t)total, 256)), dim3(256), 0, (hipStream_t)stream_, m, (float4*)packed);
+    GP_LAUNCH_CHECK();
     return 0;
 }
 

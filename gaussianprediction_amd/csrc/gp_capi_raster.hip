@@ -306,6 +306,8 @@ extern "C" int gp_raster_backward(const gp_raster_settings* st, const gp_raster_
     float* g_color = acc + 6;
     float* g_depth = acc + 9;
     if (R > 0) {
+        static thread_local int ablate_set = 0;
+        if (gp_debug_get(1) != ablate_set) { ablate_set = gp_debug_get(1); if (gp_bwd_set_ablate(ablate_set)) GP_FAIL("bwd ablate flag"); }
         hipLaunchKernelGGL(gp_tile_order_kernel, dim3(1), dim3(1024), 0, s, il.ranges, il.tile_work, (int)T, order_bwd);
         GP_LAUNCH_CHECK();
         GpProfScope _p("composite_bwd", s);

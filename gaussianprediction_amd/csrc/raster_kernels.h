@@ -72,6 +72,7 @@ __global__ __launch_bounds__(256) void gp_composite_fwd_sb_kernel(RasterDims d, 
                                                                   int32_t* __restrict__ n_contrib, const uint32_t* __restrict__ order, int32_t* __restrict__ tile_work, uint8_t* __restrict__ qmask);
 
 int gp_pair_counters_read(unsigned long long* out4);
+int gp_bwd_set_ablate(int v);
 __global__ __launch_bounds__(256) void gp_composite_fwd_count_kernel(RasterDims d, const int2* __restrict__ ranges,
                                                                   const uint32_t* __restrict__ point_list,
                                                                   const float4* __restrict__ rec,

@@ -1035,6 +1035,11 @@ __device__ __forceinline__ void gp_pixpair(const RasterDims& d, int px0, int py,
     o[3] = make_float4(dl[0][3], dl[1][3], 0.f, 0.f);
 }
 
+// (diagnostics, gp_debug_option(1, bits): 1 = the flush computes but does not issue its atomics, 2 = no pixel walk: what the
+// accumulator traffic and the arithmetic each cost, tools/probe/bwd_ablate.sh)
+__device__ int g_bwd_ablate;
+int gp_bwd_set_ablate(int v) { return hipMemcpyToSymbol(HIP_SYMBOL(g_bwd_ablate), &v, sizeof(int)) == hipSuccess ? 0 : 1; }
+
 template <bool HAS_DEPTH, int ROWS, int COLS>
 __device__ __forceinline__ void gp_composite_bwd_body(RasterDims d, const int2* __restrict__ ranges,
                                                        const uint32_t* __restrict__ point_list, const uint8_t* __restrict__ qmask,
@@ -1084,6 +1089,7 @@ __device__ __forceinline__ void gp_composite_bwd_body(RasterDims d, const int2* 
     for (int dd = 32; dd >= 1; dd >>= 1) max_nc = max(max_nc, __shfl_xor(max_nc, dd));
     __builtin_amdgcn_wave_barrier();
     const float halfW = 0.5f * (float)d.W, halfH = 0.5f * (float)d.H;
+    const int ablate = g_bwd_ablate;
     const int count = min(range.y - range.x, max_nc);
     const float px_base = (float)(tx * GP_TILE + (part % parts_x) * COLS), py_base = (float)(ty * GP_TILE + (part / parts_x) * ROWS);
     // ---- compaction.  The forward saved, per tile-splat instance, which quadrants its footprint touches
@@ -1179,7 +1185,7 @@ __device__ __forceinline__ void gp_composite_bwd_body(RasterDims d, const int2* 
 #pragma unroll
         for (int cp = 0; cp < COLS / 2; ++cp) dxs[cp] = (v2f){q0.x - (px_base + (float)(2 * cp)), q0.x - (px_base + (float)(2 * cp + 1))};
 #pragma unroll 1
-        for (int row = 0; row < ROWS; ++row) {
+        for (int row = 0; row < ((ablate & 2) ? 0 : ROWS); ++row) {
             const float dy = q0.y - (py_base + (float)row);
             const float tB = Bs * dy, uC = fmaf(Cs * dy, dy, lop);
             v2f r_h = {0.f, 0.f}, r_hx = {0.f, 0.f};
@@ -1380,7 +1386,7 @@ __device__ __forceinline__ void gp_composite_bwd_body(RasterDims d, const int2* 
                 for (int r = 0; r < 16; ++r) {
                     const int sp = r * 4 + sub;
                     const uint32_t gid = s_flid[sp];
-                    if (gid != 0xffffffffu) atomicAdd(&g_mean2D[GP_ACC_STRIDE * (size_t)gid + comp], src_c[sp * 4 + (comp & 3)]);
+                    if (gid != 0xffffffffu && !(ablate & 1)) atomicAdd(&g_mean2D[GP_ACC_STRIDE * (size_t)gid + comp], src_c[sp * 4 + (comp & 3)]);
                 }
             }
         }

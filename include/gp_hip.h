@@ -163,7 +163,16 @@ typedef struct gp_mlp_params {
     int32_t out_dim;    /* 7 or 8 */
     const float* w[5];  /* w[0]:[width,in_dim]  w[1..3]:[width,width]  w[4]:[out_dim,width] */
     const float* b[5];
+    const float* packed; /* optional (NULL = read w[] as they are): gp_mlp_pack's fragment-ordered copy of w[0..3]; used by the
+                          * passes over <= 2048 rows (stage 2/3: the rows are the keypoints), which are bound by the rate at which a
+                          * single CU takes the weights in.  Must describe the CURRENT values of w[0..3]. */
 } gp_mlp_params;
+
+/* fragment-ordered copy of w[0..3] (both the forward's and the backward's operand order; gp_mlp_packed_floats(in_dim) floats,
+ * 16-byte aligned): one contiguous kilobyte per wavefront operand load instead of sixteen 64-byte pieces.  Repack whenever the
+ * weights change (the Python host keys it on the parameters' version counters). */
+int64_t gp_mlp_packed_floats(int32_t in_dim);
+int gp_mlp_pack(const gp_mlp_params* p, float* packed, gp_stream_t stream);
 
 typedef struct gp_mlp_grads {
     float* dw[5]; /* accumulated INTO (+=), caller zeroes */

@@ -223,3 +223,40 @@ def test_get_rotation_matches_reference_quat_mul_golden():
     # the product is bilinear: normalize(normalize(q1) (x) q2) == normalize(q1 (x) q2), the golden product
     want = torch.nn.functional.normalize(torch.tensor(g["q1q2"]).double())
     assert float((out.double().cpu() - want).abs().max()) < 1e-6
+
+
+def test_small_row_mlp_with_fragment_ordered_weights_is_bit_identical():
+    """gp_mlp_pack's fragment-ordered weight copy (used by passes without autograd) changes where the operands are read from, not
+    the arithmetic: same result, bit for bit, forward and backward, and it follows the weights when they change."""
+    from gaussianprediction_amd import deform_ops
+    net, _ = _net(3, 108, 7)
+    feat = (torch.rand(250, 32, device="cuda") - 0.5)
+    xyz = torch.rand(250, 3, device="cuda") * 2 - 1
+    t = torch.tensor([0.37], device="cuda")
+    f1 = feat.clone().requires_grad_(True)
+    y_plain = net.forward_fused(f1, xyz, t, 10, 8)                   # autograd on: w[] read directly
+    with torch.no_grad():
+        y_packed = net.forward_fused(feat, xyz, t, 10, 8)            # no autograd: packed copy
+    assert torch.equal(y_plain.detach(), y_packed)
+    with torch.no_grad():
+        net.mlp[2].weight.mul_(1.5)                                  # (in-place: the version counter moves -> repack)
+        y2 = net.forward_fused(feat, xyz, t, 10, 8)
+    y2_plain = net.forward_fused(f1, xyz, t, 10, 8)
+    assert torch.equal(y2, y2_plain.detach()) and not torch.equal(y2, y_packed)
+    # backward through the packed copy (forced): same gradients as through w[]
+    gy = torch.randn_like(y2_plain)
+    y2_plain.backward(gy)
+    g_ref = [p.grad.clone() for p in net.parameters()] + [f1.grad.clone()]
+    for p in net.parameters():
+        p.grad = None
+    f2 = feat.clone().requires_grad_(True)
+    orig = deform_ops.packed_weights
+    try:
+        deform_ops.FORCE_PACKED = True
+        y3 = net.forward_fused(f2, xyz, t, 10, 8)
+        y3.backward(gy)
+    finally:
+        deform_ops.FORCE_PACKED = False
+    assert torch.equal(y3.detach(), y2)
+    for a, b in zip([p.grad for p in net.parameters()] + [f2.grad], g_ref):
+        assert torch.equal(a, b)
