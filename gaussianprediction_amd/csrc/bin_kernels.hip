@@ -121,20 +121,22 @@ __device__ __forceinline__ uint32_t bin_pick(const uint32_t (&a)[CH], int c) {
 #define BINA_THREADS 1024
 #define BINA_WAVES (BINA_THREADS / GP_WAVE)
 template <int CH>
-__global__ __launch_bounds__(BINA_THREADS) void gp_bin_count_kernel(int N, int gx, int T, const uint2* __restrict__ rect_sorted,
+__global__ __launch_bounds__(BINA_THREADS) void gp_bin_count_kernel(int N, int gx, int T, int G, const uint2* __restrict__ rect_sorted,
                                                                    uint32_t* __restrict__ hist, uint32_t* __restrict__ total_slots) {
     extern __shared__ uint32_t s_dyn[];
     __shared__ BinWave s_w[BINA_WAVES];
     __shared__ uint32_t s_part[BINA_WAVES];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    constexpr int G = CH * 64 * BINA_WAVES;
-    const int i_begin = blockIdx.x * G + wave * (CH * 64);
+    const int per_wave = G / BINA_WAVES;                        // 16 .. 64 CH Gaussians (small clouds use small blocks)
+    const int i_begin = blockIdx.x * G + wave * per_wave;
+    int i_end = i_begin + per_wave;
+    if (i_end > N) i_end = N;
     uint32_t rx[CH], ry[CH];
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
         const int i = i_begin + c * 64 + lane;
         const uint2 r = rect_sorted[i < N ? i : N - 1];
-        rx[c] = r.x; ry[c] = i < N ? r.y : 0u;                                // (tiles per row | rows: 0 rows = no instances)
+        rx[c] = r.x; ry[c] = i < i_end ? r.y : 0u;                            // (tiles per row | rows: 0 rows = no instances)
     }
     for (int t = tid; t < T; t += BINA_THREADS) s_dyn[t] = 0u;
     s_w[wave].mark[lane] = 0; s_w[wave].mark[64 + lane] = 0;
@@ -142,7 +144,7 @@ __global__ __launch_bounds__(BINA_THREADS) void gp_bin_count_kernel(int N, int g
     uint32_t mine_total = 0;
 #pragma unroll 1
     for (int c = 0; c < CH; ++c) {
-        if (i_begin + c * 64 >= N) break;
+        if (i_begin + c * 64 >= i_end) break;
         int cnt, minx, miny, w;
         bin_unpack(make_uint2(bin_pick<CH>(rx, c), bin_pick<CH>(ry, c)), true, cnt, minx, miny, w);
         mine_total += (uint32_t)cnt;
@@ -371,15 +373,15 @@ __global__ __launch_bounds__(BIN_THREADS) void gp_bin_scatter_kernel(int N, int 
 }
 
 // ---- host side ---------------------------------------------------------------------------------------------------------------------
-// Gaussians per block G = 2048, 4096 or 8192 (8 / 16 / 32 register-resident chunks per wave of the scatter kernel), at most 512
+// Gaussians per block G = 256 ... 8192 (1 ... 32 register-resident chunks of 64 per wave of the scatter kernel), at most 512
 // blocks: up to 4.2 M Gaussians; beyond that -- or beyond GP_BIN_MAX_TILES tiles -- the caller falls back to duplicate + radix sort.
 // (gp_debug_option(5, 1) forces that path: the A/B switch of tools/ and of the parity tests)
 bool gp_bin_supported(size_t N, size_t T) { return N > 0 && N <= 512u * 8192u && T >= 1 && T <= GP_BIN_MAX_TILES && gp_debug_get(5) == 0; }
 
 GpBinPlan gp_bin_plan(size_t N, size_t T) {
     GpBinPlan p;
-    size_t G = 2048;
-    while ((N + G - 1) / G > 512 && G < 8192) G *= 2;
+    size_t G = 256;                                       // small clouds: small blocks, so that the grid still spans the chip
+    while ((N + G - 1) / G > 512 && G < 8192) G *= 2;     // (10 k Gaussians in blocks of 2048 were FIVE workgroups: 96 us)
     p.G = (int)G;
     p.NB = (int)((N + G - 1) / G);
     p.hist_elems = (size_t)p.NB * T + T + 64;             // rows + totals
@@ -389,9 +391,10 @@ GpBinPlan gp_bin_plan(size_t N, size_t T) {
 int gp_bin_count(const GpBinPlan& p, size_t N, int gx, size_t T, const uint2* rect_sorted, uint32_t* hist, uint32_t* total_slots, hipStream_t s) {
     const dim3 grid((unsigned)p.NB), block(BINA_THREADS);
     const size_t lds = T * sizeof(uint32_t);
-    if (p.G == 2048) hipLaunchKernelGGL(gp_bin_count_kernel<2>, grid, block, lds, s, (int)N, gx, (int)T, rect_sorted, hist, total_slots);
-    else if (p.G == 4096) hipLaunchKernelGGL(gp_bin_count_kernel<4>, grid, block, lds, s, (int)N, gx, (int)T, rect_sorted, hist, total_slots);
-    else if (p.G == 8192) hipLaunchKernelGGL(gp_bin_count_kernel<8>, grid, block, lds, s, (int)N, gx, (int)T, rect_sorted, hist, total_slots);
+    if (p.G <= 1024) hipLaunchKernelGGL(gp_bin_count_kernel<1>, grid, block, lds, s, (int)N, gx, (int)T, p.G, rect_sorted, hist, total_slots);
+    else if (p.G == 2048) hipLaunchKernelGGL(gp_bin_count_kernel<2>, grid, block, lds, s, (int)N, gx, (int)T, p.G, rect_sorted, hist, total_slots);
+    else if (p.G == 4096) hipLaunchKernelGGL(gp_bin_count_kernel<4>, grid, block, lds, s, (int)N, gx, (int)T, p.G, rect_sorted, hist, total_slots);
+    else if (p.G == 8192) hipLaunchKernelGGL(gp_bin_count_kernel<8>, grid, block, lds, s, (int)N, gx, (int)T, p.G, rect_sorted, hist, total_slots);
     else GP_FAIL("bin: unsupported block size %d", p.G);
     GP_LAUNCH_CHECK();
     return 0;
@@ -422,6 +425,9 @@ int gp_bin_scatter(const GpBinPlan& p, size_t N, int gx, size_t T, const uint32_
     const size_t lds = (T + BIN_WAVES * ((T + 1) / 2)) * sizeof(uint32_t);
     if (gp_debug_get(6)) GP_HIP_CHECK(hipMemsetAsync(point_list, 0, (size_t)capacity * 4, s));   // (ablation runs leave slots unwritten: id 0 is a valid one)
     GpProfScope _p("bin_scatter", s);
+    if (p.G == 256) return bin_scatter_launch<1>(p, N, gx, T, sorted_ids, rect_sorted, hist, totals, point_list, capacity, ranges, status, lds, s);
+    if (p.G == 512) return bin_scatter_launch<2>(p, N, gx, T, sorted_ids, rect_sorted, hist, totals, point_list, capacity, ranges, status, lds, s);
+    if (p.G == 1024) return bin_scatter_launch<4>(p, N, gx, T, sorted_ids, rect_sorted, hist, totals, point_list, capacity, ranges, status, lds, s);
     if (p.G == 2048) return bin_scatter_launch<8>(p, N, gx, T, sorted_ids, rect_sorted, hist, totals, point_list, capacity, ranges, status, lds, s);
     if (p.G == 4096) return bin_scatter_launch<16>(p, N, gx, T, sorted_ids, rect_sorted, hist, totals, point_list, capacity, ranges, status, lds, s);
     if (p.G == 8192) return bin_scatter_launch<32>(p, N, gx, T, sorted_ids, rect_sorted, hist, totals, point_list, capacity, ranges, status, lds, s);
