@@ -433,3 +433,190 @@ int gp_bin_scatter(const GpBinPlan& p, size_t N, int gx, size_t T, const uint32_
     if (p.G == 8192) return bin_scatter_launch<32>(p, N, gx, T, sorted_ids, rect_sorted, hist, totals, point_list, capacity, ranges, status, lds, s);
     GP_FAIL("bin: unsupported block size %d", p.G);
 }
+
+// =====================================================================================================================================
+// Depth sort of the N Gaussians with the same three-kernel counting pass, 11 bits at a time.
+//
+// Rounds 1-3 sorted the 32-bit depth keys in four 8-bit LSD passes of three launches each (block histograms, one row scan per
+// digit, scatter): twelve launches of 5 - 13 us for a million keys, every one at its launch / latency floor.  With 2048-bin
+// histograms in LDS (8 KB) the key has three digits (11 + 11 + 10 bits), and a pass is the binning stage's own shape:
+//   count    block b (KPB = 2048 ... 8192 keys) counts its keys per digit in LDS and writes the row hist[b][0..2048)
+//   scan     gp_bin_scan_kernel, as for the tiles: per digit the exclusive prefix over the blocks + the digit totals
+//   scatter  digit_start = exclusive scan of the totals (every block for itself), per-(wave, digit) 16-bit counters for the order
+//            across the block's four waves, ranks inside a 64-key step from the counters (read, add, read) and masked match-any
+// Stable for the same reason the binning is: blocks, waves, steps and lanes are walked in input order.  The last pass carries every
+// Gaussian's tile rectangle into depth order (GpSortEpilogue), as the radix sort's last pass did.
+// =====================================================================================================================================
+#define DS_BITS 11
+#define DS_BINS (1 << DS_BITS)
+#define DS_THREADS 256
+#define DS_WAVES (DS_THREADS / GP_WAVE)
+
+template <int IT>      // keys per thread; a block owns IT * 256 consecutive keys
+__global__ __launch_bounds__(DS_THREADS) void gp_dsort_count_kernel(const uint32_t* __restrict__ keys, int n, int shift, uint32_t mask,
+                                                                    uint32_t* __restrict__ hist) {
+    __shared__ uint32_t s_hist[DS_BINS];
+    const int tid = threadIdx.x;
+    const int base = blockIdx.x * (IT * DS_THREADS);
+    uint32_t k[IT];
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+        const int idx = base + it * DS_THREADS + tid;
+        k[it] = keys[idx < n ? idx : n - 1];
+    }
+    for (int d = tid; d < DS_BINS; d += DS_THREADS) s_hist[d] = 0u;
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < IT; ++it)
+        if (base + it * DS_THREADS + tid < n) atomicAdd(&s_hist[(k[it] >> shift) & mask], 1u);
+    __syncthreads();
+    uint32_t* row = hist + (size_t)blockIdx.x * DS_BINS;
+    for (int d = tid; d < DS_BINS; d += DS_THREADS) row[d] = s_hist[d];
+}
+
+template <int IT>
+__global__ __launch_bounds__(DS_THREADS) void gp_dsort_scatter_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
+                                                                      uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
+                                                                      const uint32_t* __restrict__ hist_scanned,
+                                                                      const uint32_t* __restrict__ totals, int n, int shift, uint32_t mask,
+                                                                      int nbits, GpSortEpilogue ep) {
+    __shared__ uint32_t s_base[DS_BINS];
+    __shared__ uint32_t s_cnt[DS_WAVES][DS_BINS / 2];          // two 16-bit counters per word (a wave holds IT * 64 <= 2048 keys)
+    __shared__ uint32_t s_wsum[DS_WAVES];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int PER_WAVE = IT * 64;
+    const int wbase = blockIdx.x * (IT * DS_THREADS) + wave * PER_WAVE;       // wave w owns keys [w * PER_WAVE, (w + 1) * PER_WAVE)
+    uint32_t k[IT], v[IT];
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+        const int idx = wbase + it * 64 + lane;
+        const int ic = idx < n ? idx : n - 1;
+        k[it] = keys_in[ic];
+        v[it] = vals_in ? vals_in[ic] : (uint32_t)idx;         // vals_in == NULL: the values are the indices (first pass)
+    }
+    constexpr int PB = DS_BINS / DS_THREADS;                  // 8 digits per thread
+    uint32_t tv[PB], rv[PB];
+    {
+        const uint32_t* row = hist_scanned + (size_t)blockIdx.x * DS_BINS;
+#pragma unroll
+        for (int j = 0; j < PB; ++j) { tv[j] = totals[tid * PB + j]; rv[j] = row[tid * PB + j]; }
+    }
+    for (int i = tid; i < DS_WAVES * (DS_BINS / 2); i += DS_THREADS) (&s_cnt[0][0])[i] = 0u;
+    // digit_start = exclusive scan of the totals: thread t owns digits [8 t, 8 t + 8)
+    {
+        uint32_t loc = 0;
+#pragma unroll
+        for (int j = 0; j < PB; ++j) loc += tv[j];
+        const uint32_t x = (uint32_t)bin_scan_add((int)loc);
+        if (lane == 63) s_wsum[wave] = x;
+        __syncthreads();
+        uint32_t run = x - loc;
+        for (int w2 = 0; w2 < wave; ++w2) run += s_wsum[w2];
+#pragma unroll
+        for (int j = 0; j < PB; ++j) { s_base[tid * PB + j] = run + rv[j]; run += tv[j]; }
+    }
+    __syncthreads();
+    uint32_t* my_cnt = s_cnt[wave];
+    // pass 1: this wave's keys per digit
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+        const uint32_t d = (k[it] >> shift) & mask;
+        if (wbase + it * 64 + lane < n) atomicAdd(&my_cnt[d >> 1], 1u << (16u * (d & 1u)));
+    }
+    __syncthreads();
+    for (int i = tid; i < DS_BINS / 2; i += DS_THREADS) {      // exclusive prefix over the waves, both halves of a word at once
+        uint32_t run = 0;
+#pragma unroll
+        for (int w2 = 0; w2 < DS_WAVES; ++w2) { const uint32_t c = s_cnt[w2][i]; s_cnt[w2][i] = run; run += c; }
+    }
+    __syncthreads();
+    // pass 2: place.  Rank inside a step: the digit's counter before / after one add per lane, then the lanes that share a digit
+    // (most steps have some: 64 keys into 2048 bins, and the top digit takes a handful of values) are matched bit by bit.
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+        const bool valid = wbase + it * 64 + lane < n;
+        const uint32_t d = (k[it] >> shift) & mask;
+        const uint32_t sh = 16u * (d & 1u);
+        const uint32_t a_cnt = (uint32_t)(uintptr_t)&my_cnt[d >> 1], a_base = (uint32_t)(uintptr_t)&s_base[d];
+        const uint32_t inc = valid ? (1u << sh) : 0u;
+        uint32_t w0, w1, dbase;
+        asm volatile("ds_read_b32 %0, %3\n\t"
+                     "ds_add_u32 %3, %4\n\t"
+                     "ds_read_b32 %1, %3\n\t"
+                     "ds_read_b32 %2, %5\n\t"
+                     "s_waitcnt lgkmcnt(0)"
+                     : "=&v"(w0), "=&v"(w1), "=&v"(dbase) : "v"(a_cnt), "v"(inc), "v"(a_base) : "memory");
+        const uint32_t c0 = (w0 >> sh) & 0xFFFFu, hits = ((w1 >> sh) & 0xFFFFu) - c0;
+        uint32_t rank = 0;
+        const bool isdup = valid && hits > 1u;
+        const unsigned long long dup = __ballot(isdup);
+        if (dup) {
+            unsigned long long peers = dup;
+            for (int b = 0; b < nbits; ++b) {
+                const bool bit = (d >> b) & 1u;
+                const unsigned long long mm = __ballot(bit);
+                peers &= bit ? mm : ~mm;
+            }
+            if (isdup) rank = gp_mbcnt(peers);
+        }
+        if (valid) {
+            const uint32_t pos = dbase + c0 + rank;
+            keys_out[pos] = k[it];
+            vals_out[pos] = v[it];
+            if (ep.by_value) {          // last pass: the Gaussian's tile rectangle (and tile count) follows its id into depth order
+                const uint2 rr = ep.by_value[v[it]];
+                ep.sorted_out[pos] = rr;
+                ep.count_out[pos] = (rr.y & 0xFFFFu) * (rr.y >> 16);
+            }
+        }
+    }
+}
+
+// MEASURED SLOWER than the four 8-bit radix passes at configs[2] and therefore OFF by default (gp_debug_option(8, 2) selects it; the
+// parity tests run both): 3 x (count 5.8 + scan 5.6 + scatter 25.4 us) = 0.113 ms against 4 x (5.8 + 5.0 + 12.6) = 0.089 ms
+// (profiles/r04_depth_sort_ab.txt).  Nine launches instead of twelve do not pay for a scatter that is twice as long: with 2048 bins
+// and 2048 keys per block every key is its own digit run (no coalescing to stage for), and the kernel is one latency chain -- key
+// loads, a 2048-entry prefix, eight counter round trips per wave -- at two workgroups per CU.
+bool gp_dsort_supported(size_t n) { return n > 0 && n <= 512u * 8192u && gp_debug_get(8) == 2; }
+size_t gp_dsort_hist_elems(size_t n) {
+    size_t kpb = 2048;
+    while ((n + kpb - 1) / kpb > 512 && kpb < 8192) kpb *= 2;
+    return ((n + kpb - 1) / kpb) * DS_BINS + DS_BINS + 64;
+}
+
+template <int IT>
+static int dsort_pass(const uint32_t* kin, const uint32_t* vin, uint32_t* kout, uint32_t* vout, uint32_t* hist, int n, int nb, int shift, int bits,
+                      const GpSortEpilogue& ep, hipStream_t s) {
+    const uint32_t mask = (1u << bits) - 1u;
+    uint32_t* totals = hist + (size_t)nb * DS_BINS;
+    hipLaunchKernelGGL(gp_dsort_count_kernel<IT>, dim3((unsigned)nb), dim3(DS_THREADS), 0, s, kin, n, shift, mask, hist);
+    GP_LAUNCH_CHECK();
+    hipLaunchKernelGGL(gp_bin_scan_kernel, dim3(DS_BINS / 64), dim3(64 * BIN_SEGS), 0, s, hist, nb, DS_BINS, totals);
+    GP_LAUNCH_CHECK();
+    hipLaunchKernelGGL(gp_dsort_scatter_kernel<IT>, dim3((unsigned)nb), dim3(DS_THREADS), 0, s, kin, vin, kout, vout, (const uint32_t*)hist,
+                       (const uint32_t*)totals, n, shift, mask, bits, ep);
+    GP_LAUNCH_CHECK();
+    return 0;
+}
+
+// keys in b.k[0] (values = indices); returns the index of the buffer pair holding the result (1: three passes), or -1
+int gp_depth_sort3(GpSortBufs& b, size_t n, uint32_t* hist, hipStream_t s, const GpSortEpilogue* epilogue) {
+    if (n == 0) return 0;
+    size_t kpb = 2048;
+    while ((n + kpb - 1) / kpb > 512 && kpb < 8192) kpb *= 2;
+    const int nb = (int)((n + kpb - 1) / kpb);
+    const int shifts[3] = {0, 11, 22}, bits[3] = {11, 11, 10};
+    int cur = 0;
+    for (int p = 0; p < 3; ++p) {
+        GpSortEpilogue ep = {nullptr, nullptr, nullptr};
+        if (epilogue && p == 2) ep = *epilogue;
+        const uint32_t* vin = p == 0 ? nullptr : b.v[cur];
+        int rc;
+        if (kpb == 2048) rc = dsort_pass<8>(b.k[cur], vin, b.k[cur ^ 1], b.v[cur ^ 1], hist, (int)n, nb, shifts[p], bits[p], ep, s);
+        else if (kpb == 4096) rc = dsort_pass<16>(b.k[cur], vin, b.k[cur ^ 1], b.v[cur ^ 1], hist, (int)n, nb, shifts[p], bits[p], ep, s);
+        else rc = dsort_pass<32>(b.k[cur], vin, b.k[cur ^ 1], b.v[cur ^ 1], hist, (int)n, nb, shifts[p], bits[p], ep, s);
+        if (rc) return -1;
+        cur ^= 1;
+    }
+    return cur;
+}

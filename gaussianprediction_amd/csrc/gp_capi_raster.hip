@@ -121,20 +121,22 @@ extern "C" int gp_raster_forward(const gp_raster_settings* st, const gp_raster_i
         const bool counting = gp_bin_supported(N, T);
         GpBinPlan bp = {0, 0, 0};
         if (counting) bp = gp_bin_plan(N, T);
+        const bool dsort3 = gp_dsort_supported(N);          // depth sort in three 11-bit counting passes (else four 8-bit radix passes)
         auto carve_tmp = [&](GpCarver& c, uint32_t*& k0, uint32_t*& k1, uint32_t*& v0, uint32_t*& v1, uint2*& tiles,
-                             uint2*& rects, uint32_t*& tt, uint32_t*& hist, uint32_t*& scan_tmp, uint32_t*& binhist) {
+                             uint2*& rects, uint32_t*& tt, uint32_t*& hist, uint32_t*& scan_tmp, uint32_t*& binhist, uint32_t*& dshist) {
             k0 = c.take<uint32_t>(N); k1 = c.take<uint32_t>(N); v0 = c.take<uint32_t>(N); v1 = c.take<uint32_t>(N);
             tiles = c.take<uint2>(N); rects = c.take<uint2>(N); tt = c.take<uint32_t>(N + 1);
             hist = c.take<uint32_t>(hist_elems); scan_tmp = c.take<uint32_t>(scan_elems);
             binhist = c.take<uint32_t>(bp.hist_elems);
+            dshist = c.take<uint32_t>(dsort3 ? gp_dsort_hist_elems(N) : 0);
         };
-        uint32_t *k0, *k1, *v0, *v1, *tt, *hist, *scan_tmp, *binhist;
+        uint32_t *k0, *k1, *v0, *v1, *tt, *hist, *scan_tmp, *binhist, *dshist;
         uint2 *tiles, *rects;      // per-Gaussian tile rectangle by id, and the same in depth order
-        carve_tmp(tc0, k0, k1, v0, v1, tiles, rects, tt, hist, scan_tmp, binhist);
+        carve_tmp(tc0, k0, k1, v0, v1, tiles, rects, tt, hist, scan_tmp, binhist, dshist);
         void* tmp = alloc(alloc_ctx, GP_BUF_TEMP, tc0.bytes());
         if (!tmp) GP_FAIL("allocator returned NULL for TEMP (%zu B)", tc0.bytes());
         GpCarver tc(tmp);
-        carve_tmp(tc, k0, k1, v0, v1, tiles, rects, tt, hist, scan_tmp, binhist);
+        carve_tmp(tc, k0, k1, v0, v1, tiles, rects, tt, hist, scan_tmp, binhist, dshist);
 
         {
             GpProfScope _p("preprocess_fwd", s);
@@ -157,7 +159,7 @@ extern "C" int gp_raster_forward(const gp_raster_settings* st, const gp_raster_i
         // (values = 0 .. N-1, generated by the first pass)
         // the last pass also carries every Gaussian's tile rectangle + tile count into depth order (was a launch of its own)
         const GpSortEpilogue ep = {tiles, rects, tt};
-        { GpProfScope _p("depth_sort", s); r1 = gp_radix_sort_pairs(sb, N, 32, s, true, &ep); }
+        { GpProfScope _p("depth_sort", s); r1 = dsort3 ? gp_depth_sort3(sb, N, dshist, s, &ep) : gp_radix_sort_pairs(sb, N, 32, s, true, &ep); }
         if (r1 < 0) return 1;
         const uint32_t* sorted_ids = sb.v[r1];
         // tile counts -> instance offsets: scanned inside blocks here, finished by the duplicate kernel (one launch, not three)
