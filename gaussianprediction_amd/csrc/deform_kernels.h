@@ -70,6 +70,8 @@ __global__ __launch_bounds__(512) void gp_mlp_bwd_weight_kernel(const float* __r
 __global__ __launch_bounds__(256) void gp_blend_fwd_kernel(BlendDev a, float* __restrict__ xyz_t, float* __restrict__ q_t);
 __global__ __launch_bounds__(256) void gp_blend_fwd6_kernel(BlendDev a, float* __restrict__ xyz_t, float* __restrict__ q_t);
 __global__ __launch_bounds__(256) void gp_blend_fwd8_kernel(BlendDev a, float* __restrict__ xyz_t, float* __restrict__ q_t);
+__global__ __launch_bounds__(256) void gp_blend_fwd6_i16_kernel(BlendDev a, float* __restrict__ xyz_t, float* __restrict__ q_t);
+__global__ __launch_bounds__(256) void gp_blend_fwd8_i16_kernel(BlendDev a, float* __restrict__ xyz_t, float* __restrict__ q_t);
 __global__ __launch_bounds__(256) void gp_blend_bwd_kernel(BlendDev a, const float* __restrict__ g_xyz_t,
                                                            const float* __restrict__ g_q_t, float* __restrict__ g_delta,
                                                            float* __restrict__ g_raw_w, float* __restrict__ g_xyz,
@@ -79,6 +81,14 @@ __global__ __launch_bounds__(256) void gp_blend_bwd6_kernel(BlendDev a, const fl
                                                            float* __restrict__ g_raw_w, float* __restrict__ g_xyz,
                                                            float* __restrict__ g_rot, float* __restrict__ partial);
 __global__ __launch_bounds__(256) void gp_blend_bwd8_kernel(BlendDev a, const float* __restrict__ g_xyz_t,
+                                                           const float* __restrict__ g_q_t, float* __restrict__ g_delta,
+                                                           float* __restrict__ g_raw_w, float* __restrict__ g_xyz,
+                                                           float* __restrict__ g_rot, float* __restrict__ partial);
+__global__ __launch_bounds__(256) void gp_blend_bwd6_i16_kernel(BlendDev a, const float* __restrict__ g_xyz_t,
+                                                           const float* __restrict__ g_q_t, float* __restrict__ g_delta,
+                                                           float* __restrict__ g_raw_w, float* __restrict__ g_xyz,
+                                                           float* __restrict__ g_rot, float* __restrict__ partial);
+__global__ __launch_bounds__(256) void gp_blend_bwd8_i16_kernel(BlendDev a, const float* __restrict__ g_xyz_t,
                                                            const float* __restrict__ g_q_t, float* __restrict__ g_delta,
                                                            float* __restrict__ g_raw_w, float* __restrict__ g_xyz,
                                                            float* __restrict__ g_rot, float* __restrict__ partial);

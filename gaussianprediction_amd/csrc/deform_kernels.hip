@@ -690,26 +690,26 @@ __device__ __forceinline__ void softmax_n(const float* __restrict__ raw, int n, 
 }
 
 // one Gaussian's 2*NN raw weights and NN neighbour ids with 16-byte loads (rows are 48 / 64 B: aligned whenever the tensors are)
-template <int NN>
+template <int NN, bool I16>
 __device__ __forceinline__ void load_row_nn(const BlendDev& a, long i, float (&raw)[2 * NN], int (&kps)[NN]) {
     const float4* r4 = (const float4*)(a.raw_w + i * 2 * NN);
 #pragma unroll
     for (int u = 0; u < 2 * NN / 4; ++u) { const float4 t = r4[u]; raw[4 * u] = t.x; raw[4 * u + 1] = t.y; raw[4 * u + 2] = t.z; raw[4 * u + 3] = t.w; }
-    if (a.knn16) {            // packed copy: NN / 2 dwords per row instead of NN quadwords (36 of ~170 B per Gaussian at nn = 6)
-        const uint32_t* k1 = (const uint32_t*)(a.knn16 + i * NN);
-#pragma unroll
+    if (I16) {                // packed copy: NN / 2 dwords per row instead of NN quadwords (36 of ~170 B per Gaussian at nn = 6).  A
+        const uint32_t* k1 = (const uint32_t*)(a.knn16 + i * NN);      // kernel VARIANT, not a branch: behind `if (a.knn16)` the row's
+#pragma unroll                                                          // loads were waited for one group at a time
         for (int u = 0; u < NN / 2; ++u) { const uint32_t t = k1[u]; kps[2 * u] = (int)(t & 0xFFFFu); kps[2 * u + 1] = (int)(t >> 16); }
-        return;
-    }
-    typedef long long ll2 __attribute__((ext_vector_type(2)));
-    const ll2* k2 = (const ll2*)(a.knn + i * NN);
+    } else {
+        typedef long long ll2 __attribute__((ext_vector_type(2)));
+        const ll2* k2 = (const ll2*)(a.knn + i * NN);
 #pragma unroll
-    for (int u = 0; u < NN / 2; ++u) { const ll2 t = k2[u]; kps[2 * u] = (int)t.x; kps[2 * u + 1] = (int)t.y; }
+        for (int u = 0; u < NN / 2; ++u) { const ll2 t = k2[u]; kps[2 * u] = (int)t.x; kps[2 * u + 1] = (int)t.y; }
+    }
 }
 
 // NN > 0: compile-time neighbour count (loops unroll, the nn gathers are issued together);
 // NN == 0: run-time a.nn (including the stage-1 case a.nn == 0)
-template <int NN>
+template <int NN, bool I16 = false>
 __device__ __forceinline__ void blend_fwd_body(BlendDev a, float* __restrict__ xyz_t, float* __restrict__ q_t) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= a.N) return;
@@ -723,7 +723,7 @@ __device__ __forceinline__ void blend_fwd_body(BlendDev a, float* __restrict__ x
         int kpv[NN > 0 ? NN : 1];
         if constexpr (NN > 0) {
             float raw[2 * (NN > 0 ? NN : 1)];
-            load_row_nn<NN>(a, i, raw, kpv);
+            load_row_nn<NN, I16>(a, i, raw, kpv);
             softmax_n(raw, NN, wx);
             softmax_n(raw + NN, NN, wr);
         } else {
@@ -782,6 +782,8 @@ __device__ __forceinline__ void blend_fwd_body(BlendDev a, float* __restrict__ x
 __global__ __launch_bounds__(256) void gp_blend_fwd_kernel(BlendDev a, float* __restrict__ xyz_t, float* __restrict__ q_t) { blend_fwd_body<0>(a, xyz_t, q_t); }
 __global__ __launch_bounds__(256) void gp_blend_fwd6_kernel(BlendDev a, float* __restrict__ xyz_t, float* __restrict__ q_t) { blend_fwd_body<6>(a, xyz_t, q_t); }
 __global__ __launch_bounds__(256) void gp_blend_fwd8_kernel(BlendDev a, float* __restrict__ xyz_t, float* __restrict__ q_t) { blend_fwd_body<8>(a, xyz_t, q_t); }
+__global__ __launch_bounds__(256) void gp_blend_fwd6_i16_kernel(BlendDev a, float* __restrict__ xyz_t, float* __restrict__ q_t) { blend_fwd_body<6, true>(a, xyz_t, q_t); }
+__global__ __launch_bounds__(256) void gp_blend_fwd8_i16_kernel(BlendDev a, float* __restrict__ xyz_t, float* __restrict__ q_t) { blend_fwd_body<8, true>(a, xyz_t, q_t); }
 
 // gradient through y = v / max(|v|, eps):  dv = (g - y (y.g)) / |v|
 __device__ __forceinline__ void normalize_bwd(const float* v, const float* g, float* dv) {
@@ -802,7 +804,7 @@ __device__ __forceinline__ void normalize_bwd(const float* v, const float* g, fl
 // dynamic LDS: acc[K*7] | delta[K*od] | cnt[K] | base[K+1] | g[7*256] | inv[K] | w[256*2*nn] | sorted u16 [256*nn]
 #define BB_LONG 20          // a keypoint's list beyond this length is summed by a wave (mean length = nn)
 #define BB_LONG_CAP 320     // >= 256 * GP_MAX_NN / (BB_LONG + 1) lists can be that long
-template <int NN>
+template <int NN, bool I16 = false>
 __device__ __forceinline__ void blend_bwd_body(BlendDev a, const float* __restrict__ g_xyz_t,
                                                const float* __restrict__ g_q_t, float* __restrict__ g_delta,
                                                float* __restrict__ g_raw_w, float* __restrict__ g_xyz,
@@ -861,7 +863,7 @@ __device__ __forceinline__ void blend_bwd_body(BlendDev a, const float* __restri
             if (nn > 0) {
                 if constexpr (NN > 0) {
                     float raw[2 * (NN > 0 ? NN : 1)];
-                    load_row_nn<NN>(a, i, raw, kps);
+                    load_row_nn<NN, I16>(a, i, raw, kps);
                     softmax_n(raw, NN, wx);
                     softmax_n(raw + NN, NN, wr);
                 } else {
@@ -1044,6 +1046,8 @@ __device__ __forceinline__ void blend_bwd_body(BlendDev a, const float* __restri
 __global__ __launch_bounds__(256) void gp_blend_bwd_kernel(BB_ARGS) { blend_bwd_body<0>(a, g_xyz_t, g_q_t, g_delta, g_raw_w, g_xyz, g_rot, partial); }
 __global__ __launch_bounds__(256) void gp_blend_bwd6_kernel(BB_ARGS) { blend_bwd_body<6>(a, g_xyz_t, g_q_t, g_delta, g_raw_w, g_xyz, g_rot, partial); }
 __global__ __launch_bounds__(256) void gp_blend_bwd8_kernel(BB_ARGS) { blend_bwd_body<8>(a, g_xyz_t, g_q_t, g_delta, g_raw_w, g_xyz, g_rot, partial); }
+__global__ __launch_bounds__(256) void gp_blend_bwd6_i16_kernel(BB_ARGS) { blend_bwd_body<6, true>(a, g_xyz_t, g_q_t, g_delta, g_raw_w, g_xyz, g_rot, partial); }
+__global__ __launch_bounds__(256) void gp_blend_bwd8_i16_kernel(BB_ARGS) { blend_bwd_body<8, true>(a, g_xyz_t, g_q_t, g_delta, g_raw_w, g_xyz, g_rot, partial); }
 
 // stage 2: g_delta[k, c] = sum over workgroups (deterministic, no atomics).  64 elements per workgroup, the
 // workgroup's 16 waves split the partials (four independent sums each) and meet in LDS.

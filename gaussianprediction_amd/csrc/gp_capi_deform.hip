@@ -174,7 +174,9 @@ extern "C" int gp_blend_forward(const gp_blend_args* a, float* xyz_t, float* q_t
     if (!xyz_t || !q_t) GP_FAIL("null output");
     { GpProfScope _p("blend_fwd", (hipStream_t)stream_);
         const bool al = (((uintptr_t)b.raw_w | (uintptr_t)b.knn) & 15) == 0;      // the fixed-nn kernels use 16-byte row loads
-        hipLaunchKernelGGL(b.nn == 6 && al ? gp_blend_fwd6_kernel : b.nn == 8 && al ? gp_blend_fwd8_kernel : gp_blend_fwd_kernel,
+        const bool i16 = b.knn16 != nullptr;
+        hipLaunchKernelGGL(b.nn == 6 && al ? (i16 ? gp_blend_fwd6_i16_kernel : gp_blend_fwd6_kernel)
+                           : b.nn == 8 && al ? (i16 ? gp_blend_fwd8_i16_kernel : gp_blend_fwd8_kernel) : gp_blend_fwd_kernel,
                        dim3(gp_blocks((size_t)b.N, 256)), dim3(256), 0, (hipStream_t)stream_, b, xyz_t, q_t);
     GP_LAUNCH_CHECK(); }
     return 0;
@@ -201,7 +203,9 @@ extern "C" int gp_blend_backward(const gp_blend_args* a, const float* dL_dxyz_t,
     }
     { GpProfScope _p("blend_bwd", (hipStream_t)stream_);
     const bool al = (((uintptr_t)b.raw_w | (uintptr_t)b.knn | (uintptr_t)dL_draw_w) & 15) == 0;
-    hipLaunchKernelGGL(b.nn == 6 && al ? gp_blend_bwd6_kernel : b.nn == 8 && al ? gp_blend_bwd8_kernel : gp_blend_bwd_kernel,
+    const bool i16 = b.knn16 != nullptr;
+    hipLaunchKernelGGL(b.nn == 6 && al ? (i16 ? gp_blend_bwd6_i16_kernel : gp_blend_bwd6_kernel)
+                       : b.nn == 8 && al ? (i16 ? gp_blend_bwd8_i16_kernel : gp_blend_bwd8_kernel) : gp_blend_bwd_kernel,
                        dim3(blocks), dim3(256), lds, (hipStream_t)stream_, b, dL_dxyz_t, dL_dq_t, dL_ddelta,
                        dL_draw_w, dL_dxyz, dL_drot, partial);
     GP_LAUNCH_CHECK();
