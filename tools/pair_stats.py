@@ -29,7 +29,9 @@ with torch.no_grad():
         if b <= a: continue
         ids = pl[a:b]
         r = rec[ids]                                      # [L,12]
-        x, y, A, B, Cc, op = r[:, 0], r[:, 1], r[:, 2], r[:, 3], r[:, 4], r[:, 5]
+        # record (round 4): (x, y, A', B') (C', log2 opacity, depth, id) (r, g, b, opacity); A' B' C' = log2(e) x the quadratic form
+        LN2 = 0.6931471805599453
+        x, y, A, B, Cc, op = r[:, 0], r[:, 1], r[:, 2] * LN2, r[:, 3] * LN2, r[:, 4] * LN2, r[:, 11]
         tx, ty = tl % gx, tl // gx
         px = (torch.arange(16, device=dev) + 16 * tx).float()
         py = (torch.arange(16, device=dev) + 16 * ty).float()
@@ -65,9 +67,11 @@ with torch.no_grad():
         tot["row2"] += blocks(2, 16)[0]
         tot["q8x2"] += blocks(2, 8)[0]
         tot["q4x4"] += blocks(4, 4)[0]
+        tot["q8x4"] = tot.get("q8x4", 0) + blocks(8, 4)[0]          # 8 rows x 4 columns (two pixels per lane, vertically)
+        tot["q4x8"] = tot.get("q4x8", 0) + blocks(4, 8)[0]
         tot["exact"] += int(hit.sum())
         tot["lens"] += L
     print("sampled tiles:", len(tiles), "mean list length", tot["lens"] / len(tiles))
-    for k in ("tile", "bbhalf", "half", "bbquad", "quad", "row2", "q8x2", "bb4x4", "q4x4", "exact"):
+    for k in ("tile", "bbhalf", "half", "bbquad", "quad", "row2", "q8x2", "q8x4", "q4x8", "bb4x4", "q4x4", "exact"):
         print(f"{k:6s} pairs/tile {tot[k] / len(tiles):10.0f}   x exact {tot[k] / max(tot['exact'], 1):6.2f}")
     print("half-tile visits/tile", tot["halfvis"] / len(tiles), " quadrant visits/tile", tot["quadvis"] / len(tiles))
