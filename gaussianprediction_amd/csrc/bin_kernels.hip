@@ -6,11 +6,13 @@
 // already in depth order" is a COUNTING sort whose histogram has one bin per tile, and on CDNA4 a workgroup's LDS (160 KB) holds
 // that whole histogram (T = 5 440 tiles at 1352 x 1014: 22 KB):
 //
-//   A  gp_bin_count_kernel     block b owns the b-th chunk of the depth-ordered Gaussians: counts its instances per tile in LDS,
-//                              writes the row hist[b][0..T) (and adds its instance count into the R slots)
+//   A  gp_bin_count_kernel     block b owns the b-th chunk of the depth-ordered Gaussians: counts its instances per tile in LDS --
+//                              per QUARTER of the chunk, in packed 16-bit counters -- and writes the row hist[b][0..T), the four
+//                              quarter rows for kernel C (and adds its instance count into the R slots)
 //   B  gp_bin_scan_kernel      per tile: exclusive prefix of the counts over the blocks (in place) + the tile's total
 //   C  gp_bin_scatter_kernel   every block: tile_start = exclusive scan of the totals (block 0 also writes `ranges` and the status
-//                              word), then walks its chunk again and stores every instance's Gaussian id at
+//                              word), the quarter rows prefixed over its four waves (wave w owns quarter w), then walks its chunk
+//                              and stores every instance's Gaussian id at
 //                              tile_start[tile] + (instances of that tile in earlier blocks / waves / steps / lanes)
 //
 // Order inside a tile = block order, then wave order (wave w owns the w-th quarter of the chunk), then the 64-instance steps of the
@@ -75,20 +77,19 @@ __device__ __forceinline__ void bin_walk(int lane, BinWave& sw, int cnt, int min
         const int4 o0 = sw.own[m0 - 1], o1 = sw.own[m1 - 1];
         uint32_t id0 = 0, id1 = 0;
         if (WITH_ID) { id0 = sw.id[m0 - 1]; id1 = sw.id[m1 - 1]; }
-        {
-            const int j = b + lane, k = j - o0.x;
-            int yy = (int)((float)k * __builtin_amdgcn_rcpf((float)o0.w));       // k / w: the reciprocal estimate, corrected to the exact quotient
-            if (yy * o0.w > k) --yy;
-            else if ((yy + 1) * o0.w <= k) ++yy;
-            f(j < total, (uint32_t)((o0.z + yy) * gx + o0.y + (k - yy * o0.w)), id0);
-        }
-        if (b + 64 < total) {
-            const int j = b + 64 + lane, k = j - o1.x;
-            int yy = (int)((float)k * __builtin_amdgcn_rcpf((float)o1.w));
-            if (yy * o1.w > k) --yy;
-            else if ((yy + 1) * o1.w <= k) ++yy;
-            f(j < total, (uint32_t)((o1.z + yy) * gx + o1.y + (k - yy * o1.w)), id1);
-        }
+        const int j0 = b + lane, k0 = j0 - o0.x;
+        int yy0 = (int)((float)k0 * __builtin_amdgcn_rcpf((float)o0.w));       // k / w: the reciprocal estimate, corrected to the exact quotient
+        if (yy0 * o0.w > k0) --yy0;
+        else if ((yy0 + 1) * o0.w <= k0) ++yy0;
+        const uint32_t t0 = (uint32_t)((o0.z + yy0) * gx + o0.y + (k0 - yy0 * o0.w));
+        const bool second = b + 64 < total;
+        const int j1 = b + 64 + lane, k1 = j1 - o1.x;
+        int yy1 = (int)((float)k1 * __builtin_amdgcn_rcpf((float)o1.w));
+        if (yy1 * o1.w > k1) --yy1;
+        else if ((yy1 + 1) * o1.w <= k1) ++yy1;
+        const uint32_t t1 = (uint32_t)((o1.z + yy1) * gx + o1.y + (k1 - yy1 * o1.w));
+        f(j0 < total, t0, id0);
+        if (second) f(j1 < total, t1, id1);          // (issuing both steps' counter operations as ONE LDS round trip was measured: no gain)
     }
     __builtin_amdgcn_wave_barrier();                 // (the table is rewritten by the next chunk)
 }
@@ -122,11 +123,13 @@ __device__ __forceinline__ uint32_t bin_pick(const uint32_t (&a)[CH], int c) {
 #define BINA_WAVES (BINA_THREADS / GP_WAVE)
 template <int CH>
 __global__ __launch_bounds__(BINA_THREADS) void gp_bin_count_kernel(int N, int gx, int T, int G, const uint2* __restrict__ rect_sorted,
-                                                                   uint32_t* __restrict__ hist, uint32_t* __restrict__ total_slots) {
-    extern __shared__ uint32_t s_dyn[];
+                                                                   uint32_t* __restrict__ hist, uint32_t* __restrict__ wave_cnt,
+                                                                   uint32_t* __restrict__ total_slots) {
+    extern __shared__ uint32_t s_dyn[];                         // [BIN_WAVES][ceil(T / 2)]: two 16-bit counters per word
     __shared__ BinWave s_w[BINA_WAVES];
     __shared__ uint32_t s_part[BINA_WAVES];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int words = (T + 1) / 2;
     const int per_wave = G / BINA_WAVES;                        // 16 .. 64 CH Gaussians (small clouds use small blocks)
     const int i_begin = blockIdx.x * G + wave * per_wave;
     int i_end = i_begin + per_wave;
@@ -138,9 +141,12 @@ __global__ __launch_bounds__(BINA_THREADS) void gp_bin_count_kernel(int N, int g
         const uint2 r = rect_sorted[i < N ? i : N - 1];
         rx[c] = r.x; ry[c] = i < i_end ? r.y : 0u;                            // (tiles per row | rows: 0 rows = no instances)
     }
-    for (int t = tid; t < T; t += BINA_THREADS) s_dyn[t] = 0u;
+    for (int e = tid; e < BIN_WAVES * words; e += BINA_THREADS) s_dyn[e] = 0u;
     s_w[wave].mark[lane] = 0; s_w[wave].mark[64 + lane] = 0;
     __syncthreads();
+    // The scatter kernel's wave q owns the q-th quarter of the chunk = this kernel's waves 4 q .. 4 q + 3: they count into its
+    // counters, and the scatter kernel loads them instead of walking the chunk a second time (its counting pass was 13 us).
+    uint32_t* q_cnt = s_dyn + (wave / (BINA_WAVES / BIN_WAVES)) * words;
     uint32_t mine_total = 0;
 #pragma unroll 1
     for (int c = 0; c < CH; ++c) {
@@ -149,15 +155,23 @@ __global__ __launch_bounds__(BINA_THREADS) void gp_bin_count_kernel(int N, int g
         bin_unpack(make_uint2(bin_pick<CH>(rx, c), bin_pick<CH>(ry, c)), true, cnt, minx, miny, w);
         mine_total += (uint32_t)cnt;
         bin_walk<false>(lane, s_w[wave], cnt, minx, miny, w, 0u, gx, [&](bool valid, uint32_t tile, uint32_t) {
-            if (valid) atomicAdd(&s_dyn[tile], 1u);                           // (integer LDS atomic, no return: order-free)
+            if (valid) atomicAdd(&q_cnt[tile >> 1], 1u << (16u * (tile & 1u)));      // (integer LDS atomic, no return: order-free)
         });
     }
 #pragma unroll
     for (int dd = 32; dd >= 1; dd >>= 1) mine_total += __shfl_xor(mine_total, dd);
     if (lane == 0) s_part[wave] = mine_total;
     __syncthreads();
+    uint32_t* wrow = wave_cnt + (size_t)blockIdx.x * BIN_WAVES * words;
+    for (int e = tid; e < BIN_WAVES * words; e += BINA_THREADS) wrow[e] = s_dyn[e];
     uint32_t* row = hist + (size_t)blockIdx.x * T;
-    for (int t = tid; t < T; t += BINA_THREADS) row[t] = s_dyn[t];
+    for (int i = tid; i < words; i += BINA_THREADS) {             // the block's row: the four waves' counts added up, unpacked
+        uint32_t sum = 0;
+#pragma unroll
+        for (int q = 0; q < BIN_WAVES; ++q) sum += s_dyn[q * words + i];      // (both halves at once: sums stay below 65 536)
+        row[2 * i] = sum & 0xFFFFu;
+        if (2 * i + 1 < T) row[2 * i + 1] = sum >> 16;
+    }
     if (tid == 0) {
         uint32_t tot = 0;
         for (int w2 = 0; w2 < BINA_WAVES; ++w2) tot += s_part[w2];
@@ -217,6 +231,7 @@ __global__ __launch_bounds__(BIN_THREADS) void gp_bin_scatter_kernel(int N, int 
                                                                      const uint2* __restrict__ rect_sorted,
                                                                      const uint32_t* __restrict__ hist_scanned,
                                                                      const uint32_t* __restrict__ totals,
+                                                                     const uint32_t* __restrict__ wave_cnt,
                                                                      uint32_t* __restrict__ point_list, uint32_t capacity,
                                                                      int2* __restrict__ ranges, uint32_t* __restrict__ status, int ablate) {
     extern __shared__ uint32_t s_dyn[];
@@ -256,7 +271,17 @@ __global__ __launch_bounds__(BIN_THREADS) void gp_bin_scatter_kernel(int N, int 
         const int t = tid + k * BIN_THREADS;
         if (t < T) s_base[t] = tv[k];
     }
-    for (int i = tid; i < BIN_WAVES * words; i += BIN_THREADS) s_cnt[i] = 0u;
+    {   // the per-(wave, tile) counts of this chunk, counted by gp_bin_count_kernel (coalesced copy)
+        const uint32_t* wrow = wave_cnt + (size_t)blockIdx.x * BIN_WAVES * words;
+        const int nw = BIN_WAVES * words;
+        for (int i0 = 0; i0 < nw; i0 += 16 * BIN_THREADS) {            // 16 loads in flight per thread, then 16 LDS stores
+            uint32_t v[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) { const int i = i0 + k * BIN_THREADS + tid; v[k] = wrow[i < nw ? i : nw - 1]; }
+#pragma unroll
+            for (int k = 0; k < 16; ++k) { const int i = i0 + k * BIN_THREADS + tid; if (i < nw) s_cnt[i] = (ablate & 1) ? 0u : v[k]; }
+        }
+    }
     s_w[wave].mark[lane] = 0; s_w[wave].mark[64 + lane] = 0;
     __syncthreads();
     {
@@ -295,19 +320,7 @@ __global__ __launch_bounds__(BIN_THREADS) void gp_bin_scatter_kernel(int N, int 
             s_base[t] = st + rv[k];
         }
     }
-    // ---- pass 1: this wave's instances per tile
     uint32_t* my_cnt = s_cnt + wave * words;
-    if (!(ablate & 1)) {
-#pragma unroll 1
-        for (int c = 0; c < CH; ++c) {
-            if (i_begin + c * 64 >= N) break;
-            int cnt, minx, miny, w;
-            bin_unpack(make_uint2(bin_pick<CH>(rx, c), bin_pick<CH>(ry, c)), true, cnt, minx, miny, w);
-            bin_walk<false>(lane, s_w[wave], cnt, minx, miny, w, 0u, gx, [&](bool valid, uint32_t tile, uint32_t) {
-                if (valid) atomicAdd(&my_cnt[tile >> 1], 1u << (16u * (tile & 1u)));
-            });
-        }
-    }
     __syncthreads();
     // ---- exclusive prefix over the waves, both halves of a word at once (sums stay below 65 536)
     for (int i = tid; i < words; i += BIN_THREADS) {
@@ -384,17 +397,30 @@ GpBinPlan gp_bin_plan(size_t N, size_t T) {
     while ((N + G - 1) / G > 512 && G < 8192) G *= 2;     // (10 k Gaussians in blocks of 2048 were FIVE workgroups: 96 us)
     p.G = (int)G;
     p.NB = (int)((N + G - 1) / G);
-    p.hist_elems = (size_t)p.NB * T + T + 64;             // rows + totals
+    p.hist_elems = (size_t)p.NB * T + T + 64 + (size_t)p.NB * BIN_WAVES * ((T + 1) / 2);      // rows + totals + per-wave packed counts
     return p;
 }
 
+static inline uint32_t* bin_wave_cnt(const GpBinPlan& p, size_t T, uint32_t* hist) { return hist + (size_t)p.NB * T + T + 64; }
+
 int gp_bin_count(const GpBinPlan& p, size_t N, int gx, size_t T, const uint2* rect_sorted, uint32_t* hist, uint32_t* total_slots, hipStream_t s) {
     const dim3 grid((unsigned)p.NB), block(BINA_THREADS);
-    const size_t lds = T * sizeof(uint32_t);
-    if (p.G <= 1024) hipLaunchKernelGGL(gp_bin_count_kernel<1>, grid, block, lds, s, (int)N, gx, (int)T, p.G, rect_sorted, hist, total_slots);
-    else if (p.G == 2048) hipLaunchKernelGGL(gp_bin_count_kernel<2>, grid, block, lds, s, (int)N, gx, (int)T, p.G, rect_sorted, hist, total_slots);
-    else if (p.G == 4096) hipLaunchKernelGGL(gp_bin_count_kernel<4>, grid, block, lds, s, (int)N, gx, (int)T, p.G, rect_sorted, hist, total_slots);
-    else if (p.G == 8192) hipLaunchKernelGGL(gp_bin_count_kernel<8>, grid, block, lds, s, (int)N, gx, (int)T, p.G, rect_sorted, hist, total_slots);
+    const size_t lds = (size_t)BIN_WAVES * ((T + 1) / 2) * sizeof(uint32_t);
+    uint32_t* wave_cnt = bin_wave_cnt(p, T, hist);
+    if (lds > 48 * 1024) {
+        static thread_local size_t lds_set[4] = {0, 0, 0, 0};
+        const int v = p.G <= 1024 ? 0 : p.G == 2048 ? 1 : p.G == 4096 ? 2 : 3;
+        if (lds > lds_set[v]) {
+            const void* f = v == 0 ? (const void*)gp_bin_count_kernel<1> : v == 1 ? (const void*)gp_bin_count_kernel<2> : v == 2 ? (const void*)gp_bin_count_kernel<4>
+                                                                                                                                   : (const void*)gp_bin_count_kernel<8>;
+            GP_HIP_CHECK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            lds_set[v] = lds;
+        }
+    }
+    if (p.G <= 1024) hipLaunchKernelGGL(gp_bin_count_kernel<1>, grid, block, lds, s, (int)N, gx, (int)T, p.G, rect_sorted, hist, wave_cnt, total_slots);
+    else if (p.G == 2048) hipLaunchKernelGGL(gp_bin_count_kernel<2>, grid, block, lds, s, (int)N, gx, (int)T, p.G, rect_sorted, hist, wave_cnt, total_slots);
+    else if (p.G == 4096) hipLaunchKernelGGL(gp_bin_count_kernel<4>, grid, block, lds, s, (int)N, gx, (int)T, p.G, rect_sorted, hist, wave_cnt, total_slots);
+    else if (p.G == 8192) hipLaunchKernelGGL(gp_bin_count_kernel<8>, grid, block, lds, s, (int)N, gx, (int)T, p.G, rect_sorted, hist, wave_cnt, total_slots);
     else GP_FAIL("bin: unsupported block size %d", p.G);
     GP_LAUNCH_CHECK();
     return 0;
@@ -402,14 +428,14 @@ int gp_bin_count(const GpBinPlan& p, size_t N, int gx, size_t T, const uint2* re
 
 template <int CH>
 static int bin_scatter_launch(const GpBinPlan& p, size_t N, int gx, size_t T, const uint32_t* sorted_ids, const uint2* rect_sorted, const uint32_t* hist,
-                              const uint32_t* totals, uint32_t* point_list, uint32_t capacity, int2* ranges, uint32_t* status, size_t lds, hipStream_t s) {
+                              const uint32_t* totals, const uint32_t* wave_cnt, uint32_t* point_list, uint32_t capacity, int2* ranges, uint32_t* status, size_t lds, hipStream_t s) {
     static thread_local size_t lds_set = 0;
     if (lds > 48 * 1024 && lds > lds_set) {
         GP_HIP_CHECK(hipFuncSetAttribute((const void*)gp_bin_scatter_kernel<CH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         lds_set = lds;
     }
     hipLaunchKernelGGL(gp_bin_scatter_kernel<CH>, dim3((unsigned)p.NB), dim3(BIN_THREADS), lds, s, (int)N, gx, (int)T, sorted_ids, rect_sorted, hist,
-                       totals, point_list, capacity, ranges, status, gp_debug_get(6));
+                       totals, wave_cnt, point_list, capacity, ranges, status, gp_debug_get(6));
     GP_LAUNCH_CHECK();
     return 0;
 }
@@ -425,12 +451,12 @@ int gp_bin_scatter(const GpBinPlan& p, size_t N, int gx, size_t T, const uint32_
     const size_t lds = (T + BIN_WAVES * ((T + 1) / 2)) * sizeof(uint32_t);
     if (gp_debug_get(6)) GP_HIP_CHECK(hipMemsetAsync(point_list, 0, (size_t)capacity * 4, s));   // (ablation runs leave slots unwritten: id 0 is a valid one)
     GpProfScope _p("bin_scatter", s);
-    if (p.G == 256) return bin_scatter_launch<1>(p, N, gx, T, sorted_ids, rect_sorted, hist, totals, point_list, capacity, ranges, status, lds, s);
-    if (p.G == 512) return bin_scatter_launch<2>(p, N, gx, T, sorted_ids, rect_sorted, hist, totals, point_list, capacity, ranges, status, lds, s);
-    if (p.G == 1024) return bin_scatter_launch<4>(p, N, gx, T, sorted_ids, rect_sorted, hist, totals, point_list, capacity, ranges, status, lds, s);
-    if (p.G == 2048) return bin_scatter_launch<8>(p, N, gx, T, sorted_ids, rect_sorted, hist, totals, point_list, capacity, ranges, status, lds, s);
-    if (p.G == 4096) return bin_scatter_launch<16>(p, N, gx, T, sorted_ids, rect_sorted, hist, totals, point_list, capacity, ranges, status, lds, s);
-    if (p.G == 8192) return bin_scatter_launch<32>(p, N, gx, T, sorted_ids, rect_sorted, hist, totals, point_list, capacity, ranges, status, lds, s);
+    if (p.G == 256) return bin_scatter_launch<1>(p, N, gx, T, sorted_ids, rect_sorted, hist, totals, bin_wave_cnt(p, T, hist), point_list, capacity, ranges, status, lds, s);
+    if (p.G == 512) return bin_scatter_launch<2>(p, N, gx, T, sorted_ids, rect_sorted, hist, totals, bin_wave_cnt(p, T, hist), point_list, capacity, ranges, status, lds, s);
+    if (p.G == 1024) return bin_scatter_launch<4>(p, N, gx, T, sorted_ids, rect_sorted, hist, totals, bin_wave_cnt(p, T, hist), point_list, capacity, ranges, status, lds, s);
+    if (p.G == 2048) return bin_scatter_launch<8>(p, N, gx, T, sorted_ids, rect_sorted, hist, totals, bin_wave_cnt(p, T, hist), point_list, capacity, ranges, status, lds, s);
+    if (p.G == 4096) return bin_scatter_launch<16>(p, N, gx, T, sorted_ids, rect_sorted, hist, totals, bin_wave_cnt(p, T, hist), point_list, capacity, ranges, status, lds, s);
+    if (p.G == 8192) return bin_scatter_launch<32>(p, N, gx, T, sorted_ids, rect_sorted, hist, totals, bin_wave_cnt(p, T, hist), point_list, capacity, ranges, status, lds, s);
     GP_FAIL("bin: unsupported block size %d", p.G);
 }
 
