@@ -375,3 +375,26 @@ def test_depth_sort_is_stable_on_equal_depths():
     a = {k: v.detach().cpu().numpy().astype(np.float64) for k, v in dev.items()}
     o = RasterOracle("f32").forward(st, a["means3D"], a["opacities"], shs=a["shs"], scales=a["scales"], rotations=a["rotations"])
     np.testing.assert_array_equal(got["point_list"].cpu().numpy().astype(np.uint32), o["point_list"][:o["R"]])
+
+
+@pytest.mark.parametrize("W,H,expect_counting", [(2000, 1000, True), (2100, 1050, False)])
+def test_binning_paths_at_the_tile_count_limit(W, H, expect_counting):
+    """7 875 tiles (the counting path with its largest LDS footprint: 64 KB in the count kernel, 96 KB in the scatter kernel, both
+    beyond the default 64 KB of dynamic LDS) and 8 712 tiles (beyond GP_BIN_MAX_TILES: duplicate + radix sort takes over): either way
+    the lists equal the forced radix path's, entry for entry."""
+    from gaussianprediction_amd import _lib
+    scene, st, cam = small_scene(n=5000, W=W, H=H, seed=31, scale_lo=0.01, scale_hi=0.2)
+    st = f32_settings(st)
+    dev = scene_to_device(scene)
+    T = ((W + 15) // 16) * ((H + 15) // 16)
+    assert (T <= 8192) == expect_counting
+    L = _lib.lib()
+    try:
+        _lib.check(L.gp_debug_option(5, 1), "opt")
+        ref = hip_forward_debug(st, dev)
+    finally:
+        _lib.check(L.gp_debug_option(5, 0), "opt")
+    got = hip_forward_debug(st, dev)
+    assert got["R"] == ref["R"] and got["R"] > 10000
+    assert torch.equal(got["ranges"], ref["ranges"]) and torch.equal(got["point_list"], ref["point_list"])
+    assert torch.equal(got["color"], ref["color"])
