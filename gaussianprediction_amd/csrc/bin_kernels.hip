@@ -233,11 +233,42 @@ __global__ __launch_bounds__(BIN_THREADS) void gp_bin_scatter_kernel(int N, int 
                                                                      const uint32_t* __restrict__ totals,
                                                                      const uint32_t* __restrict__ wave_cnt,
                                                                      uint32_t* __restrict__ point_list, uint32_t capacity,
-                                                                     int2* __restrict__ ranges, uint32_t* __restrict__ status, int ablate) {
+                                                                     int2* __restrict__ ranges, uint32_t* __restrict__ status, int ablate,
+                                                                     uint32_t* __restrict__ order, int n_chunks) {
     extern __shared__ uint32_t s_dyn[];
     __shared__ BinWave s_w[BIN_WAVES];
     __shared__ uint32_t s_wsum[BIN_WAVES];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if ((int)blockIdx.x == n_chunks) {
+        // One workgroup more than there are chunks: the composite forward's heavy-first launch order (gp_tile_order_kernel's job:
+        // a counting sort of the tiles by a logarithm of their list length = the tile totals this kernel reads anyway), computed
+        // BESIDE the scatter instead of in a 9 us launch of its own behind it.
+        uint32_t* s_cntb = s_dyn;                    // [128] bucket counts, [128] bases, then one bucket byte per tile
+        uint32_t* s_baseb = s_dyn + 128;
+        uint8_t* s_bk = reinterpret_cast<uint8_t*>(s_dyn + 256);
+        if (tid < 128) s_cntb[tid] = 0u;
+        __syncthreads();
+        for (int t0 = 0; t0 < T; t0 += 16 * BIN_THREADS) {
+            uint32_t c[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) { const int t = t0 + k * BIN_THREADS + tid; c[k] = totals[t < T ? t : T - 1]; }
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const int t = t0 + k * BIN_THREADS + tid;
+                if (t < T) { const int b = gp_tile_bucket((int)c[k]); s_bk[t] = (uint8_t)b; atomicAdd(&s_cntb[b], 1u); }
+            }
+        }
+        __syncthreads();
+        if (tid < 128) {
+            uint32_t run = 0;
+#pragma unroll 16
+            for (int b = 0; b < 128; ++b) { const uint32_t x = s_cntb[b]; run += b < tid ? x : 0u; }
+            s_baseb[tid] = run;
+        }
+        __syncthreads();
+        for (int t = tid; t < T; t += BIN_THREADS) order[atomicAdd(&s_baseb[s_bk[t]], 1u)] = (uint32_t)t;
+        return;
+    }
     constexpr int G = CH * 64 * BIN_WAVES;
     const int i_begin = blockIdx.x * G + wave * (CH * 64);
     uint32_t rx[CH], ry[CH], rid[CH];           // this wave's Gaussians: tile rectangle and id, the only global loads of the walks
@@ -428,35 +459,37 @@ int gp_bin_count(const GpBinPlan& p, size_t N, int gx, size_t T, const uint2* re
 
 template <int CH>
 static int bin_scatter_launch(const GpBinPlan& p, size_t N, int gx, size_t T, const uint32_t* sorted_ids, const uint2* rect_sorted, const uint32_t* hist,
-                              const uint32_t* totals, const uint32_t* wave_cnt, uint32_t* point_list, uint32_t capacity, int2* ranges, uint32_t* status, size_t lds, hipStream_t s) {
+                              const uint32_t* totals, const uint32_t* wave_cnt, uint32_t* point_list, uint32_t capacity, int2* ranges, uint32_t* status, size_t lds,
+                              uint32_t* order, hipStream_t s) {
     static thread_local size_t lds_set = 0;
     if (lds > 48 * 1024 && lds > lds_set) {
         GP_HIP_CHECK(hipFuncSetAttribute((const void*)gp_bin_scatter_kernel<CH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         lds_set = lds;
     }
-    hipLaunchKernelGGL(gp_bin_scatter_kernel<CH>, dim3((unsigned)p.NB), dim3(BIN_THREADS), lds, s, (int)N, gx, (int)T, sorted_ids, rect_sorted, hist,
-                       totals, wave_cnt, point_list, capacity, ranges, status, gp_debug_get(6));
+    hipLaunchKernelGGL(gp_bin_scatter_kernel<CH>, dim3((unsigned)p.NB + (order ? 1u : 0u)), dim3(BIN_THREADS), lds, s, (int)N, gx, (int)T, sorted_ids,
+                       rect_sorted, hist, totals, wave_cnt, point_list, capacity, ranges, status, gp_debug_get(6), order, p.NB);
     GP_LAUNCH_CHECK();
     return 0;
 }
 
 int gp_bin_scatter(const GpBinPlan& p, size_t N, int gx, size_t T, const uint32_t* sorted_ids, const uint2* rect_sorted, uint32_t* hist,
-                   uint32_t* point_list, uint32_t capacity, int2* ranges, uint32_t* status, hipStream_t s) {
+                   uint32_t* point_list, uint32_t capacity, int2* ranges, uint32_t* status, uint32_t* order, hipStream_t s) {
     uint32_t* totals = hist + (size_t)p.NB * T;
     {
         GpProfScope _p("bin_scan", s);
         hipLaunchKernelGGL(gp_bin_scan_kernel, dim3((unsigned)((T + 63) / 64)), dim3(64 * BIN_SEGS), 0, s, hist, p.NB, (int)T, totals);
         GP_LAUNCH_CHECK();
     }
-    const size_t lds = (T + BIN_WAVES * ((T + 1) / 2)) * sizeof(uint32_t);
+    size_t lds = (T + BIN_WAVES * ((T + 1) / 2)) * sizeof(uint32_t);
+    if (order && lds < 1024 + T + 4) lds = 1024 + T + 4;        // (the tile-order workgroup's two 128-entry tables and a byte per tile)
     if (gp_debug_get(6)) GP_HIP_CHECK(hipMemsetAsync(point_list, 0, (size_t)capacity * 4, s));   // (ablation runs leave slots unwritten: id 0 is a valid one)
     GpProfScope _p("bin_scatter", s);
-    if (p.G == 256) return bin_scatter_launch<1>(p, N, gx, T, sorted_ids, rect_sorted, hist, totals, bin_wave_cnt(p, T, hist), point_list, capacity, ranges, status, lds, s);
-    if (p.G == 512) return bin_scatter_launch<2>(p, N, gx, T, sorted_ids, rect_sorted, hist, totals, bin_wave_cnt(p, T, hist), point_list, capacity, ranges, status, lds, s);
-    if (p.G == 1024) return bin_scatter_launch<4>(p, N, gx, T, sorted_ids, rect_sorted, hist, totals, bin_wave_cnt(p, T, hist), point_list, capacity, ranges, status, lds, s);
-    if (p.G == 2048) return bin_scatter_launch<8>(p, N, gx, T, sorted_ids, rect_sorted, hist, totals, bin_wave_cnt(p, T, hist), point_list, capacity, ranges, status, lds, s);
-    if (p.G == 4096) return bin_scatter_launch<16>(p, N, gx, T, sorted_ids, rect_sorted, hist, totals, bin_wave_cnt(p, T, hist), point_list, capacity, ranges, status, lds, s);
-    if (p.G == 8192) return bin_scatter_launch<32>(p, N, gx, T, sorted_ids, rect_sorted, hist, totals, bin_wave_cnt(p, T, hist), point_list, capacity, ranges, status, lds, s);
+    if (p.G == 256) return bin_scatter_launch<1>(p, N, gx, T, sorted_ids, rect_sorted, hist, totals, bin_wave_cnt(p, T, hist), point_list, capacity, ranges, status, lds, order, s);
+    if (p.G == 512) return bin_scatter_launch<2>(p, N, gx, T, sorted_ids, rect_sorted, hist, totals, bin_wave_cnt(p, T, hist), point_list, capacity, ranges, status, lds, order, s);
+    if (p.G == 1024) return bin_scatter_launch<4>(p, N, gx, T, sorted_ids, rect_sorted, hist, totals, bin_wave_cnt(p, T, hist), point_list, capacity, ranges, status, lds, order, s);
+    if (p.G == 2048) return bin_scatter_launch<8>(p, N, gx, T, sorted_ids, rect_sorted, hist, totals, bin_wave_cnt(p, T, hist), point_list, capacity, ranges, status, lds, order, s);
+    if (p.G == 4096) return bin_scatter_launch<16>(p, N, gx, T, sorted_ids, rect_sorted, hist, totals, bin_wave_cnt(p, T, hist), point_list, capacity, ranges, status, lds, order, s);
+    if (p.G == 8192) return bin_scatter_launch<32>(p, N, gx, T, sorted_ids, rect_sorted, hist, totals, bin_wave_cnt(p, T, hist), point_list, capacity, ranges, status, lds, order, s);
     GP_FAIL("bin: unsupported block size %d", p.G);
 }
 

@@ -112,6 +112,7 @@ extern "C" int gp_raster_forward(const gp_raster_settings* st, const gp_raster_i
     d.visible = out->visible;
     uint32_t R = 0;
     uint32_t* point_list = nullptr;
+    bool order_done = false;            // (the counting path's scatter launch also writes the forward's tile order)
     if (N > 0) {
         // ---- per-Gaussian temporaries -----------------------------------------------------------
         GpCarver tc0(nullptr);
@@ -194,7 +195,8 @@ extern "C" int gp_raster_forward(const gp_raster_settings* st, const gp_raster_i
             if (!bin) GP_FAIL("allocator returned NULL for BINNING");
             point_list = (uint32_t*)bin;
             saved->binning = bin; saved->binning_bytes = bin_bytes;
-            if (gp_bin_scatter(bp, N, d.gx, T, sorted_ids, rects, binhist, point_list, R, il.ranges, st->binning_status, s)) return 1;
+            if (gp_bin_scatter(bp, N, d.gx, T, sorted_ids, rects, binhist, point_list, R, il.ranges, st->binning_status, il.order, s)) return 1;
+            order_done = true;
         } else if (R > 0) {
             // capacity mode pads the keys with 0xFFFFFFFF: its low `tbits` bits must sort behind every real tile id
             const int tbits = tile_bits_for((int)T + (capacity_mode ? 1 : 0));
@@ -239,8 +241,10 @@ extern "C" int gp_raster_forward(const gp_raster_settings* st, const gp_raster_i
     if (N == 0 && st->binning_status)      // nothing to bin: {R, overflow} = {0, 0} (a stale overflow word would make Adam skip the step)
         GP_HIP_CHECK(hipMemsetAsync(st->binning_status, 0, 2 * sizeof(uint32_t), s));
     saved->num_rendered = (int64_t)R;
-    hipLaunchKernelGGL(gp_tile_order_kernel, dim3(1), dim3(1024), 0, s, il.ranges, (const int32_t*)nullptr, (int)T, il.order);
-    GP_LAUNCH_CHECK();
+    if (!order_done) {
+        hipLaunchKernelGGL(gp_tile_order_kernel, dim3(1), dim3(1024), 0, s, il.ranges, (const int32_t*)nullptr, (int)T, il.order);
+        GP_LAUNCH_CHECK();
+    }
     if (d.late_color && N > 0) {    // the SH coefficients may still be in flight (parameter all-gather): wait here, not at the top
         GP_HIP_CHECK(hipStreamWaitEvent(s, (hipEvent_t)st->sh_ready_event, 0));
         GpProfScope _p("sh_color", s);
@@ -301,7 +305,13 @@ extern "C" int gp_raster_backward(const gp_raster_settings* st, const gp_raster_
     float* acc = (float*)alloc(alloc_ctx, GP_BUF_TEMP, gp_align_up(acc_floats * 4, 256) + gp_align_up(T * 4, 256));
     if (!acc) GP_FAIL("allocator returned NULL for TEMP");
     uint32_t* order_bwd = (uint32_t*)((char*)acc + gp_align_up(acc_floats * 4, 256));
-    GP_HIP_CHECK(hipMemsetAsync(acc, 0, acc_floats * 4, s));
+    if (R > 0) {        // (tile order for the composite backward + the accumulators' fill, one launch)
+        const unsigned zb = (unsigned)std::min<size_t>(2048, std::max<size_t>(1, (acc_floats / 4 + 1023) / 1024));
+        hipLaunchKernelGGL(gp_bwd_prologue_kernel, dim3(1 + zb), dim3(1024), 0, s, il.ranges, il.tile_work, (int)T, order_bwd, acc, acc_floats);
+        GP_LAUNCH_CHECK();
+    } else {
+        GP_HIP_CHECK(hipMemsetAsync(acc, 0, acc_floats * 4, s));
+    }
     float* g_mean2D = acc;   // AoS, stride GP_ACC_STRIDE
     float* g_conic = acc + 2;
     float* g_opacity = acc + 5;
@@ -310,8 +320,6 @@ extern "C" int gp_raster_backward(const gp_raster_settings* st, const gp_raster_
     if (R > 0) {
         static thread_local int ablate_set = 0;
         if (gp_debug_get(1) != ablate_set) { ablate_set = gp_debug_get(1); if (gp_bwd_set_ablate(ablate_set)) GP_FAIL("bwd ablate flag"); }
-        hipLaunchKernelGGL(gp_tile_order_kernel, dim3(1), dim3(1024), 0, s, il.ranges, il.tile_work, (int)T, order_bwd);
-        GP_LAUNCH_CHECK();
         GpProfScope _p("composite_bwd", s);
         hipLaunchKernelGGL(dL_ddepth ? gp_composite_bwd_depth_kernel : gp_composite_bwd_kernel, dim3((unsigned)((T + 7) / 8 * 8) * GP_BWD_PARTS),
                            dim3(64), 0, s, d, il.ranges, point_list, (const uint8_t*)point_list + gp_align_up((size_t)R * 4, 256), gl.rec,

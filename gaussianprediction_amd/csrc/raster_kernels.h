@@ -51,6 +51,8 @@ __global__ __launch_bounds__(256) void gp_tile_ranges_kernel(const uint32_t* __r
 __global__ void gp_binning_status_kernel(const uint32_t* __restrict__ total, uint32_t capacity, uint32_t* __restrict__ status);
 
 __global__ __launch_bounds__(1024) void gp_tile_order_kernel(const int2* __restrict__ ranges, const int32_t* __restrict__ work_hint, int T, uint32_t* __restrict__ order);
+__global__ __launch_bounds__(1024) void gp_bwd_prologue_kernel(const int2* __restrict__ ranges, const int32_t* __restrict__ work_hint, int T,
+                                                               uint32_t* __restrict__ order, float* __restrict__ acc, size_t acc_floats);
 
 
 
@@ -71,6 +73,14 @@ __global__ __launch_bounds__(256) void gp_composite_fwd_sb_kernel(RasterDims d, 
                                                                   float* __restrict__ final_T,
                                                                   int32_t* __restrict__ n_contrib, const uint32_t* __restrict__ order, int32_t* __restrict__ tile_work, uint8_t* __restrict__ qmask);
 
+// heavy-first launch order: bucket of a tile by a 2-mantissa-bit logarithm of its work (0 = heaviest ... 127 = no work)
+__device__ __forceinline__ int gp_tile_bucket(int w) {
+    if (w <= 0) return 127;
+    const int lg = 31 - __clz(w);
+    const int sub = lg >= 2 ? ((w >> (lg - 2)) & 3) : 0;
+    const int v = lg * 4 + sub;
+    return 126 - (v < 126 ? v : 126);
+}
 int gp_pair_counters_read(unsigned long long* out4);
 int gp_bwd_set_ablate(int v);
 __global__ __launch_bounds__(256) void gp_composite_fwd_count_kernel(RasterDims d, const int2* __restrict__ ranges,
