@@ -600,9 +600,9 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 //     four rectangle tests it replaces;
 //   * 'done' and 'list exhausted' are ONE per-lane limit (i < lim), so a visit carries one compare for both.
 // Wave-steps per tile drop from 4 x 146 to 4 x 96 (lock-step over four lists costs 14 % against ideal 4x4 culling) and
-// a visit from 41 to 29 VALU slots (round 2), 24 with the exponent folded into the record (round 4):
+// a visit from 41 to 29 VALU slots (round 2), 19 - 20 with the exponent folded into the record (round 4):
 //     e = dx (A' dx + B' dy) + ((C' dy) dy + lop),   A' B' C' = log2(e) x the quadratic form, lop = log2(opacity)
-//     skip if e > lop (i.e. power > 0);  alpha = min(0.99, exp2(e));  skip if alpha < 1/255;  stop if T (1 - alpha) < 1e-4
+//     skip if e > lop (i.e. power > 0);  alpha = min(0.99, exp2(e));  skip if alpha < 1/255;  w = alpha T;  stop if T - w < 1e-4
 // -- the published algorithm's min(0.99, opacity exp(power)) with the two multiplies moved into the per-Gaussian record.
 // ------------------------------------------------------------------------------------------------
 #define CF2_REC 48            // bytes per staged record: (x, y, A', B') (C', log2 opacity, r, g) (b, depth, -, -)
@@ -741,19 +741,23 @@ __device__ __forceinline__ void gp_composite_fwd_sb_body(RasterDims d, const int
             const int sbase = (base - range.x) * CF2_REC;
             if (MODE == 1) {
                 // Four visits per block, hand-scheduled: the compiler's version of this loop carries 37 VALU slots per visit
-                // (flag bytes, moves, duplicated compares); this one carries 29.  Temporaries and the two record buffers are
-                // fixed registers v24 .. v53 (clobbered); LDS returns in order, so `s_waitcnt lgkmcnt(3)` = "the older record
-                // buffer is complete" while the younger one is still in flight.  exec is restored before leaving.
+                // (flag bytes, moves, duplicated compares); this one carries 20 (19 on the fast path).  Temporaries and the two
+                // record buffers are fixed registers v24 .. v53 (clobbered); LDS returns in order, so `s_waitcnt lgkmcnt(3)` =
+                // "the older record buffer is complete" while the younger one is still in flight.  exec is restored before leaving.
+                // FAST blocks (all four visits lie inside every group's list: i0 + 3 < the shortest of the wave's four lists) run
+                // under the mask of the pixels still alive, kept in an SGPR pair and shrunk when a pixel saturates, instead of
+                // comparing the list position with `lim` in front of every visit.
                 uint32_t lp = (uint32_t)(uintptr_t)lst;
-#pragma unroll 1
-                for (int i0 = 0; i0 < nmax; i0 += 4, lp += 8) {
-                    unsigned long long sv, am, sd;
-                    int sk;
-#define CF2_VISIT(K, X, Y, A_, B_, C_, OP, RG, BD, OFF)                                                             \
+                const int nmin = min(min(__builtin_amdgcn_readlane(tot, 0), __builtin_amdgcn_readlane(tot, 16)),
+                                     min(__builtin_amdgcn_readlane(tot, 32), __builtin_amdgcn_readlane(tot, 48)));
+                unsigned long long alive = __builtin_amdgcn_ballot_w64(lim >= 0);
+#define CF2_HEAD_SLOW(K)                                                                                            \
     "s_add_i32 %[sk], %[i0], " #K "\n\t"                                                                            \
     "v_cmp_lt_i32 vcc, %[sk], %[lim]\n\t"                                                                           \
     "s_and_b64 exec, %[sv], vcc\n\t"                                                                                \
-    "s_cbranch_execz 1" #K "f\n\t"                                                                                  \
+    "s_cbranch_execz 1" #K "f\n\t"
+#define CF2_VISIT(K, HEAD, TERM, RESTORE, X, Y, A_, B_, C_, OP, RG, BD, OFF)                                        \
+    HEAD                                                                                                            \
     "v_sub_f32 v48, " X ", %[pxf]\n\t"                                                                              \
     "v_sub_f32 v49, " Y ", %[pyf]\n\t"                                                                              \
     "v_mul_f32 v50, " B_ ", v49\n\t"                                                                                \
@@ -769,16 +773,16 @@ __device__ __forceinline__ void gp_composite_fwd_sb_body(RasterDims d, const int
     "v_cmp_ngt_f32 vcc, 0x3b808081, v51\n\t"                                                                        \
     "s_and_b64 exec, exec, vcc\n\t"                                                                                 \
     "s_cbranch_execz 1" #K "f\n\t"                                                                                  \
-    "v_sub_f32 v50, 1.0, v51\n\t"                                                                                   \
-    "v_mul_f32 v50, %[T], v50\n\t"                                                                                  \
+    "v_mul_f32 v52, v51, %[T]\n\t"                  /* w = alpha T */                                               \
+    "v_sub_f32 v50, %[T], v52\n\t"                  /* T - w: the transmittance behind this splat */                \
     "v_cmp_ngt_f32 vcc, 0x38d1b717, v50\n\t"                                                                        \
     "s_andn2_b64 %[sd], exec, vcc\n\t"              /* lanes whose transmittance would drop below 1e-4: finished */ \
     "s_cbranch_scc0 2" #K "f\n\t"                                                                                   \
     "s_mov_b64 exec, %[sd]\n\t"                                                                                     \
     "v_mov_b32 %[lim], -1\n\t"                                                                                      \
+    TERM                                                                                                            \
     "2" #K ":\n\t"                                                                                                  \
     "s_mov_b64 exec, vcc\n\t"                       /* (v_cmp leaves vcc a subset of the lanes it ran on) */        \
-    "v_mul_f32 v52, v51, %[T]\n\t"                                                                                  \
     "v_add_u32 %[last], %[sbase], " OFF "\n\t"                                                                      \
     "v_cmp_gt_f32 vcc, v52, %[best]\n\t"                                                                            \
     "v_pk_fma_f32 %[C01], " RG ", v[52:53], %[C01] op_sel_hi:[1,0,1]\n\t"                                           \
@@ -788,50 +792,80 @@ __device__ __forceinline__ void gp_composite_fwd_sb_body(RasterDims d, const int
     "v_cndmask_b32 %[best], %[best], v52, vcc\n\t"                                                                  \
     "v_cndmask_b32 %[bpos], %[bpos], %[last], vcc\n\t"                                                              \
     "1" #K ":\n\t"                                                                                                  \
-    "s_mov_b64 exec, %[sv]\n\t"
-#define CF2_VISIT_A(K, OFF) CF2_VISIT(K, "v24", "v25", "v26", "v27", "v28", "v29", "v[30:31]", "v[32:33]", OFF)
-#define CF2_VISIT_B(K, OFF) CF2_VISIT(K, "v34", "v35", "v36", "v37", "v38", "v39", "v[40:41]", "v[42:43]", OFF)
-                    asm volatile(
-                        "s_mov_b64 %[sv], exec\n\t"
-                        "ds_read_u16 v44, %[lp]\n\t"
-                        "ds_read_u16 v45, %[lp] offset:2\n\t"
-                        "ds_read_u16 v46, %[lp] offset:4\n\t"
-                        "ds_read_u16 v47, %[lp] offset:6\n\t"
-                        "s_waitcnt lgkmcnt(2)\n\t"
-                        "ds_read_b128 v[24:27], v44\n\t"
-                        "ds_read_b128 v[28:31], v44 offset:16\n\t"
-                        "ds_read_b64 v[32:33], v44 offset:32\n\t"
-                        "ds_read_b128 v[34:37], v45\n\t"
-                        "ds_read_b128 v[38:41], v45 offset:16\n\t"
-                        "ds_read_b64 v[42:43], v45 offset:32\n\t"
-                        "s_waitcnt lgkmcnt(3)\n\t"
-                        CF2_VISIT_A(0, "v44")
-                        "ds_read_b128 v[24:27], v46\n\t"
-                        "ds_read_b128 v[28:31], v46 offset:16\n\t"
-                        "ds_read_b64 v[32:33], v46 offset:32\n\t"
-                        "s_waitcnt lgkmcnt(3)\n\t"
-                        CF2_VISIT_B(1, "v45")
-                        "ds_read_b128 v[34:37], v47\n\t"
-                        "ds_read_b128 v[38:41], v47 offset:16\n\t"
-                        "ds_read_b64 v[42:43], v47 offset:32\n\t"
-                        "s_waitcnt lgkmcnt(3)\n\t"
-                        CF2_VISIT_A(2, "v46")
-                        "s_waitcnt lgkmcnt(0)\n\t"
-                        CF2_VISIT_B(3, "v47")
-                        "s_add_i32 %[sk], %[i0], 4\n\t"
-                        "v_cmp_lt_i32 vcc, %[sk], %[lim]\n\t"
-                        "s_mov_b64 %[am], vcc\n\t"
+    "s_mov_b64 exec, " RESTORE "\n\t"
+#define CF2_BLOCK(ENTER, VA, VB)                                                                                    \
+                        "s_mov_b64 %[sv], exec\n\t"                                                                 \
+                        ENTER                                                                                       \
+                        "ds_read_u16 v44, %[lp]\n\t"                                                                \
+                        "ds_read_u16 v45, %[lp] offset:2\n\t"                                                       \
+                        "ds_read_u16 v46, %[lp] offset:4\n\t"                                                       \
+                        "ds_read_u16 v47, %[lp] offset:6\n\t"                                                       \
+                        "s_waitcnt lgkmcnt(2)\n\t"                                                                  \
+                        "ds_read_b128 v[24:27], v44\n\t"                                                            \
+                        "ds_read_b128 v[28:31], v44 offset:16\n\t"                                                  \
+                        "ds_read_b64 v[32:33], v44 offset:32\n\t"                                                   \
+                        "ds_read_b128 v[34:37], v45\n\t"                                                            \
+                        "ds_read_b128 v[38:41], v45 offset:16\n\t"                                                  \
+                        "ds_read_b64 v[42:43], v45 offset:32\n\t"                                                   \
+                        "s_waitcnt lgkmcnt(3)\n\t"                                                                  \
+                        VA(0, "v44")                                                                                \
+                        "ds_read_b128 v[24:27], v46\n\t"                                                            \
+                        "ds_read_b128 v[28:31], v46 offset:16\n\t"                                                  \
+                        "ds_read_b64 v[32:33], v46 offset:32\n\t"                                                   \
+                        "s_waitcnt lgkmcnt(3)\n\t"                                                                  \
+                        VB(1, "v45")                                                                                \
+                        "ds_read_b128 v[34:37], v47\n\t"                                                            \
+                        "ds_read_b128 v[38:41], v47 offset:16\n\t"                                                  \
+                        "ds_read_b64 v[42:43], v47 offset:32\n\t"                                                   \
+                        "s_waitcnt lgkmcnt(3)\n\t"                                                                  \
+                        VA(2, "v46")                                                                                \
+                        "s_waitcnt lgkmcnt(0)\n\t"                                                                  \
+                        VB(3, "v47")                                                                                \
+                        "s_add_i32 %[sk], %[i0], 4\n\t"                                                             \
+                        "v_cmp_lt_i32 vcc, %[sk], %[lim]\n\t"                                                       \
+                        "s_mov_b64 %[am], vcc\n\t"                                                                  \
+                        "s_mov_b64 exec, %[sv]\n\t"
+#define CF2_SLOW_A(K, OFF) CF2_VISIT(K, CF2_HEAD_SLOW(K), "", "%[sv]", "v24", "v25", "v26", "v27", "v28", "v29", "v[30:31]", "v[32:33]", OFF)
+#define CF2_SLOW_B(K, OFF) CF2_VISIT(K, CF2_HEAD_SLOW(K), "", "%[sv]", "v34", "v35", "v36", "v37", "v38", "v39", "v[40:41]", "v[42:43]", OFF)
+#define CF2_FAST_TERM "s_andn2_b64 %[al], %[al], %[sd]\n\t"
+#define CF2_FAST_A(K, OFF) CF2_VISIT(K, "", CF2_FAST_TERM, "%[al]", "v24", "v25", "v26", "v27", "v28", "v29", "v[30:31]", "v[32:33]", OFF)
+#define CF2_FAST_B(K, OFF) CF2_VISIT(K, "", CF2_FAST_TERM, "%[al]", "v34", "v35", "v36", "v37", "v38", "v39", "v[40:41]", "v[42:43]", OFF)
+#define CF2_CLOBBERS "vcc", "scc", "memory", "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35",      \
+                          "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", \
+                          "v52", "v53"
+                const int nmin_s = __builtin_amdgcn_readfirstlane(nmin), nmax_s = __builtin_amdgcn_readfirstlane(nmax);
+                const int sbase_s = __builtin_amdgcn_readfirstlane(sbase);
+                int i0 = 0;                          // (kept in an SGPR by the statement below, which also advances it and lp)
+#pragma unroll 1
+                for (;;) {
+                    unsigned long long sv, am, sd;
+                    int sk;
+                    asm volatile(       // (one statement for both block forms: as two, the compiler shuffled 14 registers between them per block)
+                        "s_add_i32 %[sk], %[i0], 3\n\t"
+                        "s_cmp_lt_i32 %[sk], %[nmin]\n\t"
+                        "s_cbranch_scc0 90f\n\t"
+                        CF2_BLOCK("s_mov_b64 exec, %[al]\n\t", CF2_FAST_A, CF2_FAST_B)
+                        "s_branch 91f\n\t"
+                        "90:\n\t"
+                        CF2_BLOCK("", CF2_SLOW_A, CF2_SLOW_B)
+                        "91:\n\t"
+                        "s_add_i32 %[i0], %[i0], 4\n\t"
+                        "v_add_u32 %[lp], 8, %[lp]\n\t"
                         : [T] "+v"(T), [C01] "+v"(C01), [C2D] "+v"(C2D), [best] "+v"(best), [bpos] "+v"(best_pos), [last] "+v"(last),
-                          [lim] "+v"(lim), [sv] "=&s"(sv), [am] "=&s"(am), [sk] "=&s"(sk), [sd] "=&s"(sd)
-                        : [pxf] "v"(pxf), [pyf] "v"(pyf), [lp] "v"(lp), [i0] "s"(__builtin_amdgcn_readfirstlane(i0)), [sbase] "s"(__builtin_amdgcn_readfirstlane(sbase))
-                        : "vcc", "scc", "memory", "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35",
-                          "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51",
-                          "v52", "v53");
-#undef CF2_VISIT_A
-#undef CF2_VISIT_B
-#undef CF2_VISIT
-                    if (am == 0ull) break;
+                          [lim] "+v"(lim), [lp] "+v"(lp), [i0] "+s"(i0), [al] "+s"(alive), [sv] "=&s"(sv), [am] "=&s"(am), [sk] "=&s"(sk), [sd] "=&s"(sd)
+                        : [pxf] "v"(pxf), [pyf] "v"(pyf), [sbase] "s"(sbase_s), [nmin] "s"(nmin_s)
+                        : CF2_CLOBBERS);
+                    if (am == 0ull || i0 >= nmax_s) break;
                 }
+#undef CF2_HEAD_SLOW
+#undef CF2_VISIT
+#undef CF2_BLOCK
+#undef CF2_SLOW_A
+#undef CF2_SLOW_B
+#undef CF2_FAST_TERM
+#undef CF2_FAST_A
+#undef CF2_FAST_B
+#undef CF2_CLOBBERS
             } else {
 #pragma unroll 1
                 for (int i = 0; i < nmax; ++i) {
@@ -848,11 +882,11 @@ __device__ __forceinline__ void gp_composite_fwd_sb_body(RasterDims d, const int
                         if (!(e > q1.y)) {
                             const float alpha = fminf(0.99f, __builtin_amdgcn_exp2f(e));
                             if (!(alpha < 1.f / 255.f)) {
-                                const float test_T = T * (1.f - alpha);
+                                const float w = alpha * T;
+                                const float test_T = T - w;          // (the published T (1 - alpha), one operation shorter)
                                 if (test_T < 0.0001f) {
                                     lim = -1;
                                 } else {
-                                    const float w = alpha * T;
                                     const int posv = off + sbase;
                                     C01.x = fmaf(q1.z, w, C01.x);
                                     C01.y = fmaf(q1.w, w, C01.y);

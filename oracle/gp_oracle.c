@@ -398,10 +398,10 @@ int gpo_composite_fwd(int W, int H, const int32_t* ranges, const uint32_t* point
                     real alpha = FMINR(R(0.99), EXP2R(e));
                     if (FABSR(alpha * R(255) - R(1)) < R(2e-5)) amb |= 1;
                     if (alpha < R(1) / R(255)) continue;
-                    real test_T = T * (R(1) - alpha);
+                    real w = alpha * T;
+                    real test_T = T - w;                       /* the published T * (1 - alpha), written as the kernel computes it */
                     if (FABSR(test_T * R(1e4) - R(1)) < R(1e-4)) amb |= 1;
                     if (test_T < R(0.0001)) break;
-                    real w = alpha * T;
                     C0 = FMA(rgb[3 * id], w, C0);
                     C1 = FMA(rgb[3 * id + 1], w, C1);
                     C2 = FMA(rgb[3 * id + 2], w, C2);
