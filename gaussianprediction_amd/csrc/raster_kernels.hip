@@ -663,13 +663,13 @@ __device__ __forceinline__ void gp_composite_fwd_sb_body(RasterDims d, const int
     __shared__ __attribute__((aligned(16))) unsigned char s_rec[CF_THREADS * CF2_REC];
     __shared__ unsigned short s_list[16][CF_THREADS];    // per SB: byte offsets of the batch's records that touch it, in depth order
     __shared__ int s_cnt[4][16];                         // [staging wave][SB]
-    __shared__ int s_off[4][16];                         // exclusive prefix over the staging waves
     __shared__ int s_tot[16];
     __shared__ int s_done[4];
     __shared__ int s_last[4];
     const int tile = order ? (int)order[blockIdx.x] : (int)blockIdx.x;
     const int tx = tile % d.gx, ty = tile / d.gx;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wave_s = __builtin_amdgcn_readfirstlane(wave);
     // wave = quadrant, 16-lane group = 4x4 sub-block of the quadrant
     const int grp = lane >> 4;
     const int sbx = 2 * (wave & 1) + (grp & 1), sby = 2 * (wave >> 1) + (grp >> 1);
@@ -693,13 +693,16 @@ __device__ __forceinline__ void gp_composite_fwd_sb_body(RasterDims d, const int
     v2f C01 = {0.f, 0.f}, C2D = {0.f, 0.f};              // (C0, C1), (C2, depth): the packed accumulators of the asm path
     unsigned n_eval = 0, n_contr = 0;                    // (MODE 2 only)
 
+    // the batch's Gaussian ids are fetched one batch ahead (in flight during the previous batch's visits): a batch then waits for ONE
+    // trip to memory (the record gather), not two dependent ones
+    uint32_t id_next = range.x + tid < range.y ? point_list[range.x + tid] : 0u;
     for (int base = range.x; base < range.y; base += CF_THREADS) {
         __syncthreads();
         if (s_done[0] && s_done[1] && s_done[2] && s_done[3]) break;
         const int k = base + tid;
         uint32_t rel = 0u;
+        const uint32_t id = id_next;
         if (k < range.y) {
-            const uint32_t id = point_list[k];
             const float4 q0 = rec[3 * (size_t)id], q1 = rec[3 * (size_t)id + 1], q2 = rec[3 * (size_t)id + 2];
             float4* dst = (float4*)(s_rec + tid * CF2_REC);
             dst[0] = q0;
@@ -721,18 +724,40 @@ __device__ __forceinline__ void gp_composite_fwd_sb_body(RasterDims d, const int
         }
         if (lane < 16) s_cnt[wave][lane] = mycnt;
         __syncthreads();
-        if (lane < 16) {
-            int off = 0;
-            for (int w = 0; w < wave; ++w) off += s_cnt[w][lane];
-            s_off[wave][lane] = off;
-            if (wave == 3) s_tot[lane] = off + mycnt;
+        int offv = 0;                                    // lanes 0 .. 15: exclusive prefix of SB `lane` over the staging waves
+        if (lane < 16) {                                 // (three loads in flight, selected by the wave-uniform wave number)
+            const int c0 = s_cnt[0][lane], c1 = s_cnt[1][lane], c2 = s_cnt[2][lane];
+            offv = (wave_s > 0 ? c0 : 0) + (wave_s > 1 ? c1 : 0) + (wave_s > 2 ? c2 : 0);
+            if (wave_s == 3) s_tot[lane] = offv + mycnt;
         }
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int sb = 0; sb < 16; ++sb) {
-            if ((rel >> sb) & 1u) s_list[sb][s_off[wave][sb] + (int)gp_mbcnt(bal[sb])] = (unsigned short)(tid * CF2_REC);
+        {   // list entries.  The lanes that write SB sb's list ARE its ballot (exec <- bal[sb]); the slot is the wave's base for the
+            // SB (a readlane of the prefix above: no LDS round trip per SB) + the lane's rank in the ballot.  4 VALU per SB.
+            const uint32_t val = (uint32_t)(tid * CF2_REC);
+            uint32_t t;
+            unsigned long long sv;
+#define CF2_PUT(SB)                                                                                         \
+    "s_mov_b32 exec_lo, %[l" #SB "]\n\t"                                                                    \
+    "s_mov_b32 exec_hi, %[h" #SB "]\n\t"                                                                    \
+    "v_mbcnt_lo_u32_b32 %[t], %[l" #SB "], 0\n\t"                                                           \
+    "v_mbcnt_hi_u32_b32 %[t], %[h" #SB "], %[t]\n\t"                                                        \
+    "v_lshl_add_u32 %[t], %[t], 1, %[b" #SB "]\n\t"                                                         \
+    "ds_write_b16 %[t], %[val]\n\t"
+#define CF2_ADDR(SB) ((uint32_t)(uintptr_t)&s_list[SB][0] + 2u * (uint32_t)__builtin_amdgcn_readlane(offv, SB))
+#define CF2_PUT4(A, B, C_, D)                                                                                               \
+    asm volatile("s_mov_b64 %[sv], exec\n\t" CF2_PUT(A) CF2_PUT(B) CF2_PUT(C_) CF2_PUT(D) "s_mov_b64 exec, %[sv]\n\t"      \
+                 : [t] "=&v"(t), [sv] "=&s"(sv)                                                                             \
+                 : [val] "v"(val), [l##A] "s"((uint32_t)bal[A]), [h##A] "s"((uint32_t)(bal[A] >> 32)), [b##A] "s"(CF2_ADDR(A)), \
+                   [l##B] "s"((uint32_t)bal[B]), [h##B] "s"((uint32_t)(bal[B] >> 32)), [b##B] "s"(CF2_ADDR(B)),               \
+                   [l##C_] "s"((uint32_t)bal[C_]), [h##C_] "s"((uint32_t)(bal[C_] >> 32)), [b##C_] "s"(CF2_ADDR(C_)),          \
+                   [l##D] "s"((uint32_t)bal[D]), [h##D] "s"((uint32_t)(bal[D] >> 32)), [b##D] "s"(CF2_ADDR(D))                \
+                 : "memory");
+            CF2_PUT4(0, 1, 2, 3) CF2_PUT4(4, 5, 6, 7) CF2_PUT4(8, 9, 10, 11) CF2_PUT4(12, 13, 14, 15)
+#undef CF2_PUT4
+#undef CF2_ADDR
+#undef CF2_PUT
         }
         __syncthreads();
+        if (k + CF_THREADS < range.y) id_next = point_list[k + CF_THREADS];     // (issued behind the last barrier of the batch: nothing waits for it before the visits are done)
         if (__any(lim >= 0)) {
             const int tot = s_tot[mysb];
             lim = lim < 0 ? -1 : tot;
