@@ -620,24 +620,30 @@ __device__ __forceinline__ uint32_t gp_sb_mask(const float4 q0, const float4 q1,
     const float tt = 2.f * tau * 1.004f + 0.03f;                 // q' <= tt, with slack for the rounding of the exponent / exp2
     const float ex = __builtin_amdgcn_sqrtf(tt * cz * __builtin_amdgcn_rcpf(det));   // half extent in x; rightmost point at dy = -(cy / cz) ex
     if (!(ex <= 1e8f)) return 0xFFFFu;
-    const float inv_cx = __builtin_amdgcn_rcpf(cx), rxy = -cy * inv_cx;              // centre line of the row spans: c(dy) = rxy dy
+    // everything below in SB columns (quarter pixels): column k covers pixel centres 4k .. 4k + 3
+    const float inv_cx = 0.25f * __builtin_amdgcn_rcpf(cx), rxy = -cy * inv_cx;      // centre line of the row spans: c(dy) = rxy dy
     const float dyr = -(cy * __builtin_amdgcn_rcpf(cz)) * ex;
     const float ctt = cx * tt;
+    const float mxr = fmaf(mx + 0.01f, 0.25f, 1.f);              // (+ 1: floor(x) + 1 = one past the last column)
+    const float mxl = (mx - 3.01f) * 0.25f;                      // (xl - 3) / 4
+    const float ndet = -det;
     uint32_t mask = 0u;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
         const float d0 = (float)(4 * s) - my, d1 = d0 + 3.f;
         const float dr = __builtin_amdgcn_fmed3f(dyr, d0, d1), dl = __builtin_amdgcn_fmed3f(-dyr, d0, d1);
-        const float Dr = fmaf(-det * dr, dr, ctt), Dl = fmaf(-det * dl, dl, ctt);
-        // (either discriminant < 0: the strip misses the ellipse's y range)
-        const float xr = fmaf(__builtin_amdgcn_sqrtf(fmaxf(Dr, 0.f)), inv_cx, fmaf(rxy, dr, mx + 0.01f));
-        const float xl = fmaf(-__builtin_amdgcn_sqrtf(fmaxf(Dl, 0.f)), inv_cx, fmaf(rxy, dl, mx - 0.01f));
-        // column k covers pixel centres 4k .. 4k + 3
-        const float khf = floorf(fminf(xr, 15.5f) * 0.25f);                       // floor(xr / 4) <= 3
-        const float klf = ceilf(__builtin_amdgcn_fmed3f(xl - 3.f, 0.f, 16.f) * 0.25f);   // ceil((xl - 3) / 4) in 0 .. 4
-        const bool hit = fminf(Dr, Dl) >= 0.f && xr >= 0.f && klf <= khf;         // (hit => 0 <= k_lo <= k_hi <= 3)
-        const uint32_t bits = (2u << ((int)khf & 3)) - (1u << ((int)klf & 7));    // bits k_lo .. k_hi
-        if (hit) mask |= bits << (4 * s);
+        const float Dr = fmaf(ndet * dr, dr, ctt), Dl = fmaf(ndet * dl, dl, ctt);
+        // A strip that misses the ellipse's y range has Dr < 0: its square root is a NaN, which travels through floor and the
+        // subtraction into the width and is turned into ZERO by the clamp (v_med3_f32 with a NaN operand returns the smallest of
+        // the other two): no compare, no select.  (Dl < 0 with Dr >= 0 -- rounding at the very edge of the y range -- clamps to
+        // column 0: a superset.)
+        const float kh1 = floorf(fmaf(__builtin_amdgcn_sqrtf(Dr), inv_cx, fmaf(rxy, dr, mxr)));        // last column + 1 (unclamped)
+        const float klf = ceilf(fmaf(-__builtin_amdgcn_sqrtf(Dl), inv_cx, fmaf(rxy, dl, mxl)));        // first column (unclamped)
+        const float kl = __builtin_amdgcn_fmed3f(klf, 0.f, 4.f);
+        const float w = __builtin_amdgcn_fmed3f(kh1 - kl, 0.f, 4.f);                                   // columns kl .. kl + w - 1
+        uint32_t bits;
+        asm("v_bfm_b32 %0, %1, %2" : "=v"(bits) : "v"((uint32_t)w), "v"((uint32_t)kl));               // ((1 << w) - 1) << kl
+        mask |= (bits & 0xFu) << (4 * s);
     }
     return mask;
 }
