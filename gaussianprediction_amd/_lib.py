@@ -98,14 +98,14 @@ EXPORTS = [
     "gp_mlp_forward", "gp_mlp_backward", "gp_mlp_pack", "gp_mlp_packed_floats", "gp_mlp16_forward", "gp_mlp16_backward", "gp_blend_forward", "gp_blend_backward",
     "gp_activations_forward", "gp_activations_backward", "gp_profile_enable", "gp_profile_collect",
     "gp_loss_l1_ssim_forward", "gp_loss_l1_ssim_finalize", "gp_loss_l1_ssim_backward", "gp_adam_step",
-    "gp_adam_step_multi",
+    "gp_adam_step_multi", "gp_adam_step_multi_steps",
     "gp_hashgrid_table_entries", "gp_hashgrid_forward", "gp_hashgrid_backward", "gp_knn_keypoints",
     "gp_weights_forward", "gp_weights_backward", "gp_l1_mean_forward", "gp_l1_mean_backward", "gp_loss_l1_ssim_finalize_reg", "gp_loss_l1_ssim_backward_reg", "gp_furthest_point_sampling", "gp_knn3_mean_dist2",
     "gp_microbench_copy", "gp_microbench_read", "gp_microbench_mfma", "gp_microbench_valu", "gp_microbench_gather",
     "gp_debug_option", "gp_debug_counters",
     "gp_last_error", "gp_version", "gp_abi_version",
 ]
-GP_ABI_VERSION = 3         # include/gp_hip.h: the struct layouts / signatures / buffer-size macros this binding was written against
+GP_ABI_VERSION = 4         # include/gp_hip.h: the struct layouts / signatures / buffer-size macros this binding was written against
 
 _lib = None
 _lock = threading.Lock()

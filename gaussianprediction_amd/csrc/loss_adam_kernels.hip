@@ -274,13 +274,14 @@ struct AdamTable {
     float* m[ADAM_MAX_TENSORS];
     float* v[ADAM_MAX_TENSORS];
     unsigned long long n[ADAM_MAX_TENSORS];
-    float lr[ADAM_MAX_TENSORS];
+    float step_size[ADAM_MAX_TENSORS];           // lr / (1 - beta1^t) with the TENSOR's step count t
+    float bc2_sqrt[ADAM_MAX_TENSORS];            // sqrt(1 - beta2^t)
     unsigned keep_grad_mask;                     // bit k: leave tensor k's gradient as it is
     unsigned chunk_begin[ADAM_MAX_TENSORS + 1];   // prefix of chunk counts
     int count;
 };
-__global__ __launch_bounds__(256) void gp_adam_multi_kernel(AdamTable t, float b1, float b2, float eps, float bc1, float bc2_sqrt,
-                                                           int zero_grad, const uint32_t* __restrict__ skip_flag) {
+__global__ __launch_bounds__(256) void gp_adam_multi_kernel(AdamTable t, float b1, float b2, float eps, int zero_grad,
+                                                           const uint32_t* __restrict__ skip_flag) {
     const bool skip = skip_flag && *skip_flag != 0;      // the frame that produced these gradients was invalid: no update
     const unsigned chunk = blockIdx.x;
     int k = 0;
@@ -288,7 +289,7 @@ __global__ __launch_bounds__(256) void gp_adam_multi_kernel(AdamTable t, float b
     const size_t base = (size_t)(chunk - t.chunk_begin[k]) * ADAM_CHUNK;
     const size_t n = t.n[k];
     float* __restrict__ p = t.p[k]; float* __restrict__ g = t.g[k]; float* __restrict__ m = t.m[k]; float* __restrict__ v = t.v[k];
-    const float step_size = t.lr[k] / bc1;
+    const float step_size = t.step_size[k], bc2_sqrt = t.bc2_sqrt[k];
     if ((t.keep_grad_mask >> k) & 1u) zero_grad = 0;
     const size_t end = base + ADAM_CHUNK < n ? base + ADAM_CHUNK : n;
     auto upd = [&](float4& pv, const float4& gv, float4& mv, float4& vv) {
@@ -484,38 +485,53 @@ extern "C" int gp_adam_step(float* param, float* grad, float* exp_avg, float* ex
     return 0;
 }
 
-extern "C" int gp_adam_step_multi(int32_t count, float* const* params, float* const* grads, float* const* exp_avgs,
-                                  float* const* exp_avg_sqs, const int64_t* numels, const float* lrs, float beta1, float beta2,
-                                  float eps, int64_t step, int32_t zero_grad, uint32_t keep_grad_mask, const uint32_t* skip_flag,
-                                  gp_stream_t stream_) {
+// torch.optim.Adam counts steps PER PARAMETER: a tensor whose .grad is None when step() runs is skipped and its count stays behind
+// (in the reference: the per-Gaussian tensors on every densify / prune iteration, train.py:164-197).  `steps` = the 1-based count of
+// each tensor's update; the bias corrections are formed per tensor on the host.
+extern "C" int gp_adam_step_multi_steps(int32_t count, float* const* params, float* const* grads, float* const* exp_avgs,
+                                        float* const* exp_avg_sqs, const int64_t* numels, const float* lrs, const int64_t* steps,
+                                        float beta1, float beta2, float eps, int32_t zero_grad, uint32_t keep_grad_mask,
+                                        const uint32_t* skip_flag, gp_stream_t stream_) {
     hipStream_t s = (hipStream_t)stream_;
     if (count < 0 || count > ADAM_MAX_TENSORS) GP_FAIL("adam: at most %d tensors per call (got %d)", ADAM_MAX_TENSORS, count);
-    if (step < 1) GP_FAIL("bad step");
     if (count == 0) return 0;
-    if (!params || !grads || !exp_avgs || !exp_avg_sqs || !numels || !lrs) GP_FAIL("null argument");
+    if (!params || !grads || !exp_avgs || !exp_avg_sqs || !numels || !lrs || !steps) GP_FAIL("null argument");
     AdamTable t;
     t.count = 0;
     t.keep_grad_mask = 0;
     unsigned chunks = 0;
     for (int k = 0; k < count; ++k) {
         if (numels[k] <= 0) continue;
+        if (steps[k] < 1) GP_FAIL("adam: bad step %lld (tensor %d)", (long long)steps[k], k);
         if ((((uintptr_t)params[k] | (uintptr_t)grads[k] | (uintptr_t)exp_avgs[k] | (uintptr_t)exp_avg_sqs[k]) & 15) != 0)
             GP_FAIL("adam: pointers must be 16-byte aligned (tensor %d)", k);
         const int j = t.count++;
         if ((keep_grad_mask >> k) & 1u) t.keep_grad_mask |= 1u << j;
         t.p[j] = params[k]; t.g[j] = grads[k]; t.m[j] = exp_avgs[k]; t.v[j] = exp_avg_sqs[k];
-        t.n[j] = (unsigned long long)numels[k]; t.lr[j] = lrs[k];
+        t.n[j] = (unsigned long long)numels[k];
+        t.step_size[j] = lrs[k] / (1.f - powf(beta1, (float)steps[k]));
+        t.bc2_sqrt[j] = sqrtf(1.f - powf(beta2, (float)steps[k]));
         t.chunk_begin[j] = chunks;
         chunks += (unsigned)((numels[k] + ADAM_CHUNK - 1) / ADAM_CHUNK);
     }
     t.chunk_begin[t.count] = chunks;
     if (chunks == 0) return 0;
-    const float bc1 = 1.f - powf(beta1, (float)step);
-    const float bc2_sqrt = sqrtf(1.f - powf(beta2, (float)step));
     GpProfScope _p("adam", s);
-    hipLaunchKernelGGL(gp_adam_multi_kernel, dim3(chunks), dim3(256), 0, s, t, beta1, beta2, eps, bc1, bc2_sqrt, zero_grad, skip_flag);
+    hipLaunchKernelGGL(gp_adam_multi_kernel, dim3(chunks), dim3(256), 0, s, t, beta1, beta2, eps, zero_grad, skip_flag);
     GP_LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" int gp_adam_step_multi(int32_t count, float* const* params, float* const* grads, float* const* exp_avgs,
+                                  float* const* exp_avg_sqs, const int64_t* numels, const float* lrs, float beta1, float beta2,
+                                  float eps, int64_t step, int32_t zero_grad, uint32_t keep_grad_mask, const uint32_t* skip_flag,
+                                  gp_stream_t stream_) {
+    if (count < 0 || count > ADAM_MAX_TENSORS) GP_FAIL("adam: at most %d tensors per call (got %d)", ADAM_MAX_TENSORS, count);
+    if (step < 1) GP_FAIL("bad step");
+    int64_t steps[ADAM_MAX_TENSORS];
+    for (int k = 0; k < count; ++k) steps[k] = step;
+    return gp_adam_step_multi_steps(count, params, grads, exp_avgs, exp_avg_sqs, numels, lrs, steps, beta1, beta2, eps, zero_grad,
+                                    keep_grad_mask, skip_flag, stream_);
 }
 
 extern "C" int gp_l1_mean_forward(const float* x, int64_t n, float scale, const float* base, float* out, gp_stream_t stream_) {

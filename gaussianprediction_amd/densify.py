@@ -20,6 +20,26 @@ def track_view(model, viewspace_point_tensor, visibility_filter, radii):
     model.add_densification_stats(viewspace_point_tensor, visibility_filter)
 
 
+def held_groups(model, iteration, opt, white_background=False):
+    """Names of the optimizer groups whose Adam update the REFERENCE skips on this iteration: its loop runs densify / prune /
+    reset_opacity between backward and optimizer.step() [REF train.py:164-197]; they replace the per-Gaussian Parameters (prune
+    always does, whatever its mask [REF scene/gaussian_model.py:547-585]; reset_opacity the opacity tensor [REF :526-545]), the new
+    tensors' .grad is None and torch.optim.Adam passes over them: no update from this iteration's gradient, step count one behind.
+    This package's harness updates first and operates afterwards, so it asks for the same outcome up front:
+        ts.step(view, hold=densify.held_groups(model, it, opt))
+    Not predicted (it depends on this iteration's gradients): the keypoint tensors on an iteration whose keypoint growth actually
+    adds keypoints [REF train.py:179-192]."""
+    if not iteration < opt.densify_until_iter:
+        return ()
+    names = set()
+    if iteration > opt.densify_from_iter and iteration % opt.densification_interval == 0:
+        names.update(model._per_gaussian().keys())
+    if iteration % opt.opacity_reset_interval == 0 or (white_background and iteration == opt.densify_from_iter):
+        names.add("opacity")
+    have = {g["name"] for g in model.optimizer.param_groups} if model.optimizer is not None else set()
+    return tuple(sorted(names & have))
+
+
 def densification_step(model, iteration, opt, scene_extent, max_gaussian_size=200_000, white_background=False, generator=None):
     """[REF train.py:169-177]: returns (n_cloned, n_split_sources, n_pruned), None where the call was not due."""
     n_clone = n_src = n_pruned = None

@@ -137,6 +137,11 @@ class FusedAdam:
         self.bucket = bucket
         self.betas, self.eps = betas, eps
         self.step_count = 0
+        # torch.optim.Adam counts steps per parameter; here: one counter + how far each GROUP is behind it (name -> skipped steps).
+        # A group falls behind when a step holds it back (step(hold=...): the reference's densify / prune / reset_opacity replace the
+        # per-Gaussian tensors BEFORE optimizer.step() of the same iteration, their .grad is None and Adam skips them
+        # [REF train.py:164-197]) or when a loaded state dict says so.  Bias corrections use step_count - lag per tensor.
+        self.lag = {}
         self.shard = shard
         off_of = {id(p): off for p, off in zip(bucket.params, bucket.offsets)}
         self.items = []        # (group, tensor the launch updates, its offset in the flat buffers, exp_avg, exp_avg_sq)
@@ -169,8 +174,17 @@ class FusedAdam:
         if id(p_dc) not in it or id(p_rest) not in it or p_rest.dim() != 3 or p_rest.shape[1] != 15:
             return None
         (g0, m0, v0), (g1, m1, v1) = it[id(p_dc)], it[id(p_rest)]
+        if self.lag_of(g0) != self.lag_of(g1):      # (one step number per fused launch)
+            return None
         return dict(m_dc=m0, v_dc=v0, m_rest=m1, v_rest=v1, lr_dc=float(g0["lr"]), lr_rest=float(g1["lr"]), beta1=float(self.betas[0]),
-                    beta2=float(self.betas[1]), eps=float(self.eps), step=int(self.step_count + 1), skip_flag=skip_flag)
+                    beta2=float(self.betas[1]), eps=float(self.eps), step=int(self.step_count + 1 - self.lag_of(g0)), skip_flag=skip_flag)
+
+    def lag_of(self, group):
+        return int(self.lag.get(group.get("name"), 0))
+
+    def item_steps(self, step_no):
+        """The step number of every launch-table entry for the optimisation step `step_no` (its group's own count)."""
+        return [step_no - self.lag_of(g) for g, _, _, _, _ in self.items]
 
     def full_moments(self):
         """{id(param): (exp_avg, exp_avg_sq)} as whole tensors.  Sharded: a COLLECTIVE (every rank must call it)."""
@@ -212,7 +226,8 @@ class FusedAdam:
         if self.step_count == 0:
             return {}
         mom = self.full_moments()
-        return {p: {"step": torch.tensor(float(self.step_count)), "exp_avg": mom[id(p)][0], "exp_avg_sq": mom[id(p)][1]}
+        step_of = {id(p): self.step_count - self.lag_of(g) for g in self.param_groups for p in g["params"]}
+        return {p: {"step": torch.tensor(float(step_of.get(id(p), self.step_count))), "exp_avg": mom[id(p)][0], "exp_avg_sq": mom[id(p)][1]}
                 for p in self.bucket.params if id(p) in mom}
 
     def zero_grad(self, set_to_none=True):
@@ -237,7 +252,7 @@ class FusedAdam:
             for p in g["params"]:
                 if self.step_count > 0 and id(p) in mom:
                     m, v = mom[id(p)]
-                    state[k] = {"step": torch.tensor(float(self.step_count)), "exp_avg": m.detach().clone(),
+                    state[k] = {"step": torch.tensor(float(self.step_count - self.lag_of(g))), "exp_avg": m.detach().clone(),
                                 "exp_avg_sq": v.detach().clone()}
                 k += 1
             groups.append(entry)
@@ -249,7 +264,7 @@ class FusedAdam:
         if len(groups) != len(self.param_groups):
             raise ValueError(f"loaded state dict has {len(groups)} parameter groups, the optimizer has {len(self.param_groups)}")
         known = {id(p) for p in self.bucket.params}
-        steps = []
+        steps = {}                                   # group name -> smallest stored step of its tensors
         for g, saved in zip(self.param_groups, groups):
             if len(saved["params"]) != len(g["params"]):
                 raise ValueError(f"group {g.get('name')}: {len(saved['params'])} parameters saved, {len(g['params'])} expected")
@@ -263,14 +278,13 @@ class FusedAdam:
                 if tuple(st["exp_avg"].shape) != tuple(p.shape):
                     raise ValueError(f"group {g.get('name')}: moment shape {tuple(st['exp_avg'].shape)} vs parameter {tuple(p.shape)}")
                 self.load_full_moments(p, st["exp_avg"], st["exp_avg_sq"])
-                steps.append(int(float(st["step"])))
-        # ONE step counter for all tensors -- a known deviation from torch.optim.Adam, which counts per parameter.  In the
-        # reference the counts can differ by a few: densify / prune / reset_opacity run BEFORE optimizer.step() of the same
-        # iteration [REF train.py:164-197] and replace the per-Gaussian Parameters, whose .grad is then None, so Adam skips
-        # them on that iteration and their `step` lags the MLP's by one per event.  Here the harness steps first and
-        # performs the surgery afterwards, every tensor is updated on every iteration, and a loaded checkpoint resumes at
-        # the LARGEST stored step (bias corrections differ from the reference's by < 1e-3 relative after a few hundred steps).
-        self.step_count = max(steps) if steps else 0
+                steps[g.get("name")] = min(steps.get(g.get("name"), 1 << 62), int(float(st["step"])))
+        # torch.optim.Adam counts per parameter, and in the reference the counts differ: densify / prune / reset_opacity run BEFORE
+        # optimizer.step() of the same iteration [REF train.py:164-197] and replace the per-Gaussian Parameters, whose .grad is then
+        # None, so Adam skips them on that iteration and their `step` falls behind the MLP's by one per event.  The stored counts
+        # are kept as they are: step_count = the largest, every group's distance to it in `lag` (bias corrections per tensor).
+        self.step_count = max(steps.values()) if steps else 0
+        self.lag = {name: self.step_count - st for name, st in steps.items() if st != self.step_count}
 
     def _launch(self, n, step_no, zero_grad, keep_ids, skip_flag, only, exclude, stream):
         """gp_adam_step_multi over the launch table (this rank's slices), restricted by `only` / `exclude`."""
@@ -295,6 +309,7 @@ class FusedAdam:
                 self._num_subsets[key] = sub
             NUM, active = sub
         LR = (C.c_float * n)(*[float(g["lr"]) for g, _, _, _, _ in self.items])
+        STEPS = (C.c_int64 * n)(*[max(1, st) for st in self.item_steps(step_no)])
         mask = 0
         if zero_grad:
             for k, p in enumerate(self.owner):
@@ -304,21 +319,29 @@ class FusedAdam:
         dev = self.bucket.flat.device
         sp = _lib.stream_ptr(dev) if stream is None else C.c_void_p(stream.cuda_stream)
         with _lib.on_device(dev):
-            rc = _lib.lib().gp_adam_step_multi(C.c_int32(n), P, G, M, V, NUM, LR, C.c_float(b1), C.c_float(b2), C.c_float(self.eps),
-                                               C.c_int64(step_no), C.c_int32(1 if zero_grad else 0), C.c_uint32(mask),
-                                               _lib.ptr(skip_flag), sp)
-            _lib.check(rc, "gp_adam_step_multi")
+            rc = _lib.lib().gp_adam_step_multi_steps(C.c_int32(n), P, G, M, V, NUM, LR, STEPS, C.c_float(b1), C.c_float(b2),
+                                                     C.c_float(self.eps), C.c_int32(1 if zero_grad else 0), C.c_uint32(mask),
+                                                     _lib.ptr(skip_flag), sp)
+            _lib.check(rc, "gp_adam_step_multi_steps")
 
-    def step(self, zero_grad=True, keep_grad=(), skip_flag=None, only=None, exclude=None, stream=None, advance=True):
-        """One launch for all parameter tensors (gp_adam_step_multi).  Parameters listed in `keep_grad` are not
+    def step(self, zero_grad=True, keep_grad=(), skip_flag=None, only=None, exclude=None, stream=None, advance=True, hold=()):
+        """One launch for all parameter tensors (gp_adam_step_multi_steps).  Parameters listed in `keep_grad` are not
         zeroed: their gradient buffers are marked stale (grad_sink.mark_stale) and the next backward overwrites them.
         `skip_flag`: optional int32 device word; non-zero = leave parameters and moments untouched (invalid frame).
         `only` / `exclude`: restrict the launch to a subset of the parameter tensors; `stream`: a torch.cuda.Stream other
         than the current one; `advance=False` uses step number step_count + 1 without committing it (the first of two
-        partial launches of one optimisation step)."""
+        partial launches of one optimisation step).
+        `hold`: group names that SKIP this optimisation step as torch.optim.Adam skips a parameter whose .grad is None: no update,
+        moments untouched, the group's own step count does not advance (`lag`), its gradient is discarded."""
         step_no = self.step_count + 1
+        held = [g for g in self.param_groups if g.get("name") in set(hold)]
         if advance:
             self.step_count = step_no
+            for g in held:
+                self.lag[g["name"]] = self.lag_of(g) + 1
+        held_params = [p for g in held for p in g["params"] if p.requires_grad]
+        if held_params:
+            exclude = tuple(exclude or ()) + tuple(held_params)
         n = len(self.items)
         keep_ids = {id(p) for p in keep_grad}
         if not self.bucket.flat.is_cuda:
@@ -327,7 +350,10 @@ class FusedAdam:
             # (version counters, stale marks, zeroing of foreign slices) is the product's either way.
             if FusedAdam.host_step is None:
                 raise RuntimeError("FusedAdam.step: HIP kernels only (no CPU fallback)")
-            FusedAdam.host_step(self, step_no, zero_grad, keep_ids)
+            inc_h = {id(p) for p in only} if only is not None else None
+            exc_h = {id(p) for p in exclude} if exclude is not None else set()
+            FusedAdam.host_step(self, step_no, zero_grad, keep_ids,
+                                [(inc_h is None or id(p) in inc_h) and id(p) not in exc_h for p in self.owner])
         else:
             self._launch(n, step_no, zero_grad, keep_ids, skip_flag, only, exclude, stream)
         # which PARAMETERS this launch covered -- not only those this rank holds a slice of: under the sharded layout a tensor can
@@ -347,6 +373,10 @@ class FusedAdam:
             raise RuntimeError("torch.autograd.graph.increment_version is missing: cached keypoint weights could not be invalidated")
         for p in covered:
             bump(p)
+        if zero_grad:
+            off_of = {id(q): o for q, o in zip(self.bucket.params, self.bucket.offsets)}
+            for p in held_params:                # a held group's gradient is dropped, as the replaced tensor's is in the reference
+                self.bucket.flat[off_of[id(p)]:off_of[id(p)] + p.numel()].zero_()
         if zero_grad and keep_ids:
             from . import grad_sink
             for p in covered:

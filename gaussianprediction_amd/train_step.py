@@ -53,6 +53,7 @@ class TrainStep:
             self._slot_view = [None] * K            # view rendered by the step that last used the slot
             self._slot_spec = [False] * K           # ... and whether it ran in capacity mode
             self._slot_toff = [None] * K            # ... and its time offset (a repeated frame is repeated with it)
+            self._slot_hold = [()] * K              # ... and the optimizer groups it held back
             self._r_max, self._n_steps, self.redone = 0, 0, 0
             if os.environ.get("GP_SPEC_MARGIN"):     # test hook: a margin < 1 forces overflows (and the redo protocol)
                 self.SPEC_MARGIN, self.SPEC_PAD = float(os.environ["GP_SPEC_MARGIN"]), 0
@@ -187,10 +188,13 @@ class TrainStep:
             return l1_ssim_loss(image, gt, self.lambda_dssim, feat, 1.0e-5)
         return l1_ssim_loss(image, gt, self.lambda_dssim)
 
-    def step(self, view_index: int, time_offset=None):
+    def step(self, view_index: int, time_offset=None, hold=()):
         """`time_offset`: a [1] device tensor added to every rendered view's time (the decaying time noise of the training
-        loop [REF train.py:92-99]); None = the cameras' own times."""
+        loop [REF train.py:92-99]); None = the cameras' own times.
+        `hold`: optimizer group names that skip this step's Adam update (densify.held_groups: the tensors the reference's loop
+        replaces before its optimizer.step() on this iteration) -- FusedAdam.step(hold=...)."""
         self._time_offset = time_offset
+        self._hold = tuple(hold)
         if not self.speculative:
             return self._step(view_index, None, None)
         K = self.SPEC_SLOTS
@@ -202,11 +206,13 @@ class TrainStep:
             if overflow and self._slot_spec[slot]:   # its Adam update was skipped on the device: repeat the frame, exactly
                 self.redone += 1
                 self.optimizer.step_count -= 1
+                for name in self._slot_hold[slot]:   # (the repeated step holds the same groups again)
+                    self.optimizer.lag[name] -= 1
                 self._events[slot] = None
-                self._time_offset = self._slot_toff[slot]
+                self._time_offset, self._hold = self._slot_toff[slot], self._slot_hold[slot]
                 self._run_slot(slot, self._slot_view[slot], exact=True)
                 self._n_steps += 1
-                return self.step(view_index, time_offset)
+                return self.step(view_index, time_offset, hold)
         exact = self._n_steps < len(self.cameras) + K or self._r_max == 0   # until every view's R has been read back
         out = self._run_slot(slot, view_index, exact)
         self._n_steps += 1
@@ -221,6 +227,7 @@ class TrainStep:
         ev.record()
         self._events[slot], self._slot_view[slot], self._slot_spec[slot] = ev, view_index, not exact
         self._slot_toff[slot] = self._time_offset
+        self._slot_hold[slot] = tuple(getattr(self, "_hold", ()))
         return out
 
     def _step(self, view_index: int, binning, skip_flag):
@@ -251,10 +258,12 @@ class TrainStep:
             ([] if lifecycle else [pc._xyz, pc.motion_feature])
         sid = {id(p_) for p_ in single}
         self.reducer.set_late([p_ for p_ in self.bucket.params if id(p_) not in sid])
-        if self.overlap_sh_adam and keep and not self.reducer.enabled:
+        hold = tuple(getattr(self, "_hold", ()))     # groups that skip this step's update: every early / fused / chained form of the
+        plain = bool(hold)                           # SH update is off, one ordinary optimizer launch runs at the end
+        if self.overlap_sh_adam and keep and not self.reducer.enabled and not plain:
             self._armed, self._keep, self._skip_flag = True, keep, skip_flag
         sh_pair, fuse = (pc._features_dc, pc._features_rest), None
-        if self.fuse_sh_adam and keep and not self.reducer.enabled and not self.sharded:
+        if self.fuse_sh_adam and keep and not self.reducer.enabled and not self.sharded and not plain:
             from . import grad_sink
             fuse = self.optimizer.fused_payload(sh_pair[0], sh_pair[1], skip_flag)
             if fuse is not None:
@@ -262,7 +271,7 @@ class TrainStep:
         world = torch.distributed.get_world_size(self.group) if self.reducer.enabled else 1
         if self.sharded:
             # SH regions may leave the compute stream right after their reduce-scatter (_chain_sh): single-producer steps only
-            self._chain_on = bool(keep) and self.reducer.enabled and getattr(self, "chain_sh", True)
+            self._chain_on = bool(keep) and self.reducer.enabled and getattr(self, "chain_sh", True) and not plain
             self._keep, self._skip_flag, self._chained_params, self._flag_handle = keep, skip_flag, [], None
         losses, pkgs = [], []
         if self.batch > 1 and hasattr(pc, "keypoint_weights_scope"):
@@ -332,7 +341,7 @@ class TrainStep:
             self._sh_early = False
             self.optimizer.step(zero_grad=True, keep_grad=keep, skip_flag=skip_flag, exclude=(pc._features_dc, pc._features_rest))
         else:
-            self.optimizer.step(zero_grad=True, keep_grad=keep, skip_flag=skip_flag)
+            self.optimizer.step(zero_grad=True, keep_grad=keep, skip_flag=skip_flag, hold=hold)
         if self.sharded:
             self.reducer.gather_params()             # asynchronous; awaited by the next step / render
         return loss.detach(), pkg

@@ -327,6 +327,7 @@ class TrainingMixin:
             if g["name"] in lrs:
                 g["lr"] = lrs[g["name"]]
         self.optimizer.step_count = old_step     # the reference keeps the stored state (and its step) [REF :595-598]
+        self.optimizer.lag = dict(old.lag)       # ... per group: the steps it skipped
         for p in self.bucket.params:
             src = carried.get(id(p)) or old_mom.get(id(p))
             if src is not None and src[0].shape == p.shape:

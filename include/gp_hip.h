@@ -320,6 +320,14 @@ int gp_adam_step_multi(int32_t count, float* const* params, float* const* grads,
                        float* const* exp_avg_sqs, const int64_t* numels, const float* lrs, float beta1, float beta2, float eps,
                        int64_t step, int32_t zero_grad, uint32_t keep_grad_mask, const uint32_t* skip_flag, gp_stream_t stream);
 
+/* the same with a step count PER TENSOR (host array, 1-based), as torch.optim.Adam keeps it: a parameter whose .grad is None when
+ * step() runs is skipped and its count stays behind -- in the reference the per-Gaussian tensors on every densify / prune
+ * iteration, which replace them before optimizer.step() [REF train.py:164-197, scene/gaussian_model.py:547-599]. */
+int gp_adam_step_multi_steps(int32_t count, float* const* params, float* const* grads, float* const* exp_avgs,
+                             float* const* exp_avg_sqs, const int64_t* numels, const float* lrs, const int64_t* steps, float beta1,
+                             float beta2, float eps, int32_t zero_grad, uint32_t keep_grad_mask, const uint32_t* skip_flag,
+                             gp_stream_t stream);
+
 /* ---- keypoint weights (parity unpinned: tinycudann / frnn are absent from the reference tree) --- */
 
 /* the Grid/Hash encoding of weights_model = tcnn.NetworkWithInputEncoding(...) [REF scene/gaussian_model.py:370-392] */
@@ -424,7 +432,7 @@ const char* gp_version(void);
  * buffer-size macro (GP_LOSS_SUM_SLOTS) changes; a binding built against another number must refuse to run (the Python loader
  * does: gaussianprediction_amd/_lib.py).  History: 1 = rounds 1-2; 2 = round 3 (gp_raster_settings.sh_ready_event / visible,
  * gp_knn_keypoints' `order`, GP_LOSS_SUM_SLOTS per image size); 3 = round 4 (gp_abi_version itself, packed neighbour indices). */
-#define GP_ABI_VERSION 3
+#define GP_ABI_VERSION 4
 int gp_abi_version(void);
 
 #ifdef __cplusplus

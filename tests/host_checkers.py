@@ -8,12 +8,14 @@ from oracle import deform_oracle as do
 
 
 @torch.no_grad()
-def adam_host_step(opt, step_no, zero_grad, keep_ids):
-    """torch.optim.Adam's update rule (amsgrad off, no weight decay) over a FusedAdam's launch table
-    [REF scene/gaussian_model.py:472, train.py:196-197]."""
+def adam_host_step(opt, step_no, zero_grad, keep_ids, active=None):
+    """torch.optim.Adam's update rule (amsgrad off, no weight decay) over a FusedAdam's launch table, every tensor with its own
+    step count [REF scene/gaussian_model.py:472, train.py:196-197]; `active`: which entries take part (None = all)."""
     b1, b2 = opt.betas
-    bc1, bc2 = 1 - b1 ** step_no, 1 - b2 ** step_no
-    for (g, p, off, m, v) in opt.items:
+    for k, ((g, p, off, m, v), st) in enumerate(zip(opt.items, opt.item_steps(step_no))):
+        if active is not None and not active[k]:
+            continue
+        bc1, bc2 = 1 - b1 ** st, 1 - b2 ** st
         grad = opt.bucket.flat[off:off + p.numel()].view_as(p)
         m.mul_(b1).add_(grad, alpha=1 - b1)
         v.mul_(b2).addcmul_(grad, grad, value=1 - b2)

@@ -68,7 +68,8 @@ def _run(model, cams, gts, opt, args, first, last, rnd, log, batch=1):
         start = model.second_stage_iter if (args.use_time_decay and it >= model.second_stage_iter) else 0
         span = args.time_noise_iteration * (2 if start else 1)
         jitter = torch.randn(1, device="cuda") * (args.time_noise_ratio / len(cams)) * (1.0 - min(1.0, (it - start) / span))
-        loss, pkg = ts.step(v, time_offset=jitter)
+        # (the groups whose update the reference's loop skips on this iteration: it densifies / prunes before optimizer.step())
+        loss, pkg = ts.step(v, time_offset=jitter, hold=dn.held_groups(model, it, opt) if it < opt.densify_until_iter else ())
         log["loss"].append(float(loss)), log["n"].append(model.get_xyz.shape[0])
         log["k"].append(model.super_gaussians.shape[0])
         with torch.no_grad():
