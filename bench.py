@@ -421,7 +421,8 @@ def main():
             try:
                 # contributing (pixel, splat) pairs, counted by the kernel's counting variant on one untimed render of the last view,
                 # and the instruction floor they imply: every contributing pair costs at least the straight-line visit of the
-                # kernel (21 vector-ALU instructions per 64 pairs), on 1024 SIMDs issuing one wave64 instruction per 4 cycles
+                # kernel (19 vector-ALU instructions per 64 pairs: the visit of a fast block, raster_kernels.hip CF2_VISIT), on 1024 SIMDs issuing
+                # one wave64 instruction per 4 cycles
                 import ctypes as C
                 L = _lib.lib()
                 _lib.check(L.gp_debug_option(0, 3), "opt")
@@ -431,7 +432,7 @@ def main():
                     raster_forward_debug(_settings(cam, pc, ts.bg, 1.0), xyz, o, shs=pc.get_features, scales=s, rotations=q)
                 _lib.check(L.gp_debug_counters(cnt), "counters")
                 _lib.check(L.gp_debug_option(0, 0), "opt")
-                MIN_VALU = 21
+                MIN_VALU = 19
                 roof["contributing_pairs"], roof["evaluated_pairs"] = int(cnt[0]), int(cnt[1])
                 roof["min_valu_per_pair"] = MIN_VALU
                 roof["valu_lower_bound_ms"] = round(int(cnt[0]) * MIN_VALU / 64.0 * 4.0 / 1024.0 / (SHADER_CLOCK_GHZ * 1e9) * 1e3, 4)
