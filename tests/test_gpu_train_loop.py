@@ -69,7 +69,7 @@ def _run(model, cams, gts, opt, args, first, last, rnd, log, batch=1):
         span = args.time_noise_iteration * (2 if start else 1)
         jitter = torch.randn(1, device="cuda") * (args.time_noise_ratio / len(cams)) * (1.0 - min(1.0, (it - start) / span))
         # (the groups whose update the reference's loop skips on this iteration: it densifies / prunes before optimizer.step())
-        loss, pkg = ts.step(v, time_offset=jitter, hold=dn.held_groups(model, it, opt) if it < opt.densify_until_iter else ())
+        loss, pkg = ts.step(v, time_offset=jitter, hold=dn.held_groups(model, it, opt))
         log["loss"].append(float(loss)), log["n"].append(model.get_xyz.shape[0])
         log["k"].append(model.super_gaussians.shape[0])
         with torch.no_grad():
