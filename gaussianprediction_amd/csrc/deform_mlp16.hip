@@ -215,19 +215,74 @@ __device__ __forceinline__ void build_input16s(_Float16* buf, const Mlp16Dev& p,
     const int fd = p.feature_dim, xf = p.xyz_freq, tf = p.time_freq;
     const float tv = tf > 0 ? p.t[0] : 0.f;
     auto put = [&](int jj, int f, float v) { split1(v, buf[a16_idx<SP_W>(jj, f)], buf[a16_idx<SP_W>(jj, 256 + f)]); };
-    for (int e = tid; e < fd * ROWS; e += M16_THREADS) {
-        const int jj = e / fd, f = e - jj * fd;
-        const long row = row0 + jj;
-        put(jj, f, row < p.rows ? p.feature[row * fd + f] : 0.f);
-    }
-    for (int e = tid; e < 3 * xf * ROWS; e += M16_THREADS) {
-        const int jj = e % ROWS, cf = e / ROWS;
-        const int c = cf / xf, fr = cf - c * xf;
-        const long row = row0 + jj;
-        float sv = 0.f, cv = 0.f;
-        if (row < p.rows) sincosf(p.xyz[row * 3 + c] * (float)(1u << fr), &sv, &cv);
-        put(jj, fd + 2 * cf, sv);
-        put(jj, fd + 2 * cf + 1, cv);
+    constexpr int FU = ROWS * 64 / 4 / M16_THREADS;         // float4 feature loads per thread at feature_dim = 64 (4 for 64 rows)
+    if ((fd & 3) == 0 && fd <= 64 && ((uintptr_t)p.feature & 15) == 0) {
+        // EVERY global load of the tile is issued before the first LDS store: as `for (e = tid; ...) put(.., p.feature[..])` and
+        // `sincosf(p.xyz[..] ..)` loops the tile cost 8 + 8 dependent trips to memory per workgroup (a rolled loop with a conditional
+        // load waits for each one) -- a quarter of a 64-row workgroup's lifetime at two workgroups per CU.  Same values, same
+        // expressions per element.
+        const int q = fd >> 2, nq = ROWS * q;
+        float4 fv[FU];
+#pragma unroll
+        for (int u = 0; u < FU; ++u) {
+            const int e = tid + M16_THREADS * u;
+            const int jj = e < nq ? e / q : 0, f4 = e < nq ? e - jj * q : 0;
+            const long row = row0 + jj;
+            const bool ok = e < nq && row < p.rows;
+            fv[u] = *(const float4*)(p.feature + (ok ? row * fd + 4 * f4 : 0));
+            if (!ok) fv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        static_assert(3 * ROWS <= 2 * M16_THREADS, "two coordinates per thread at most");
+        float xv[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int e = tid + M16_THREADS * u;
+            const long row = row0 + e / 3;
+            const bool ok = e < 3 * ROWS && row < p.rows;
+            xv[u] = p.xyz[ok ? row * 3 + e % 3 : 0];
+            if (!ok) xv[u] = 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < FU; ++u) {
+            const int e = tid + M16_THREADS * u;
+            if (e < nq) {
+                const int jj = e / q, f4 = e - jj * q;
+                const float v[4] = {fv[u].x, fv[u].y, fv[u].z, fv[u].w};
+                h4 hi, lo;
+                split4(v, hi, lo);
+                *(h4*)&buf[a16_idx<SP_W>(jj, 4 * f4)] = hi;
+                *(h4*)&buf[a16_idx<SP_W>(jj, 256 + 4 * f4)] = lo;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int e = tid + M16_THREADS * u;
+            if (e < 3 * ROWS) {
+                const int jj = e / 3, c = e - 3 * jj;
+                const bool ok = row0 + jj < p.rows;
+                for (int fr = 0; fr < xf; ++fr) {
+                    float sv = 0.f, cv = 0.f;
+                    if (ok) sincosf(xv[u] * (float)(1u << fr), &sv, &cv);
+                    put(jj, fd + 2 * (c * xf + fr), sv);
+                    put(jj, fd + 2 * (c * xf + fr) + 1, cv);
+                }
+            }
+        }
+    } else {
+        for (int e = tid; e < fd * ROWS; e += M16_THREADS) {
+            const int jj = e / fd, f = e - jj * fd;
+            const long row = row0 + jj;
+            put(jj, f, row < p.rows ? p.feature[row * fd + f] : 0.f);
+        }
+        for (int e = tid; e < 3 * xf * ROWS; e += M16_THREADS) {
+            const int jj = e % ROWS, cf = e / ROWS;
+            const int c = cf / xf, fr = cf - c * xf;
+            const long row = row0 + jj;
+            float sv = 0.f, cv = 0.f;
+            if (row < p.rows) sincosf(p.xyz[row * 3 + c] * (float)(1u << fr), &sv, &cv);
+            put(jj, fd + 2 * cf, sv);
+            put(jj, fd + 2 * cf + 1, cv);
+        }
     }
     for (int e = tid; e < tf * ROWS; e += M16_THREADS) {
         const int jj = e % ROWS, fr = e / ROWS;
@@ -591,12 +646,24 @@ __device__ __forceinline__ void mlp16_bwd_data_body(Mlp16Dev p, const uint32_t* 
     const float S = UsesScale<T>::v ? grad_scale_from(absmax_bits) : 1.f;
     T* cur = smem[0];
     T* nxt = smem[INPLACE ? 0 : 1];
-    for (int e = tid; e < 16 * ROWS; e += M16_THREADS) {
-        const int r = e / 16, f = e % 16;
-        const long row = row0 + r;
-        const float v = (f < p.out_dim && row < p.rows) ? dL_dout[row * p.out_dim + f] * S : 0.f;
-        if constexpr (SP) split1(v, cur[a16_idx<WS>(r, f)], cur[a16_idx<WS>(r, 256 + f)]);
-        else cur[a16_idx(r, f)] = (T)v;
+    {   // (all loads of the upstream gradient before the first LDS store: as a rolled loop they were dependent trips to memory)
+        constexpr int DU = 16 * ROWS / M16_THREADS;
+        float dv[DU];
+#pragma unroll
+        for (int u = 0; u < DU; ++u) {
+            const int e = tid + M16_THREADS * u, r = e / 16, f = e % 16;
+            const long row = row0 + r;
+            const bool ok = f < p.out_dim && row < p.rows;
+            dv[u] = dL_dout[ok ? row * p.out_dim + f : 0];
+            if (!ok) dv[u] = 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < DU; ++u) {
+            const int e = tid + M16_THREADS * u, r = e / 16, f = e % 16;
+            const float v = dv[u] * S;
+            if constexpr (SP) split1(v, cur[a16_idx<WS>(r, f)], cur[a16_idx<WS>(r, 256 + f)]);
+            else cur[a16_idx(r, f)] = (T)v;
+        }
     }
     __syncthreads();
     typedef typename Vec4<T>::type V4;
