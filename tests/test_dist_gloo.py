@@ -178,6 +178,66 @@ def test_sharded_adam_equals_replicated_adam(tmp_path, world, grouped):
     check_sharded_against_torch_adam(tmp_path, world, grouped=grouped)
 
 
+def _worker_sharded_hold(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from gaussianprediction_amd.dist import ShardedExchange
+    from gaussianprediction_amd.loss_ops import FusedAdam
+    import host_checkers
+    host_checkers.install()
+    params = _params()
+    groups = _named_groups(params)
+    bucket = FlatGradBucket([p for g in groups for p in g["params"]], shards=world, flat_params=True, small_numel=200)
+    opt = FusedAdam(groups, bucket, eps=1e-15, shard=(rank, world))
+    ex = ShardedExchange(bucket)
+    for step, held in enumerate(HOLD_SCHEDULE):
+        _view_loss(params, rank + 10 * step).backward()
+        ex.finish()
+        before = [p.detach().clone() for p in params]
+        opt.step(hold=held)
+        ex.gather_params()
+        ex.wait_params()
+        if "xyz" in held:
+            assert torch.equal(before[0], params[0].detach())     # held: untouched on every rank, whoever owns its slices
+        assert float(bucket.flat.abs().max()) == 0.0              # own slices, foreign slices and the held tensor's gradient: all dropped
+    sd = opt.state_dict()
+    torch.save({"params": [p.detach().clone() for p in params], "sd": sd, "lag": dict(opt.lag)}, os.path.join(out_dir, f"hold{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+HOLD_SCHEDULE = [(), ("xyz", "f_rest"), (), ("xyz",)]
+
+
+def test_sharded_adam_holds_groups_back_like_grad_none(tmp_path):
+    """FusedAdam.step(hold=...) under the sharded optimizer (every rank owns 1/world of every region): the held groups skip the step
+    on all ranks and fall behind in their step count, as a parameter with .grad None does in torch.optim.Adam -- the reference's
+    per-Gaussian tensors on a densify / prune iteration [REF train.py:164-197]."""
+    world = 2
+    mp.spawn(_worker_sharded_hold, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    outs = [torch.load(os.path.join(tmp_path, f"hold{r}.pt"), weights_only=False) for r in range(world)]
+    params = _params()
+    groups = _named_groups(params)
+    ref = torch.optim.Adam(groups, lr=0.0, eps=1e-15)
+    for step, held in enumerate(HOLD_SCHEDULE):
+        ref.zero_grad()
+        torch.stack([_view_loss(params, r + 10 * step) for r in range(world)]).sum().backward()
+        for g in groups:
+            if g["name"] in held:
+                for p_ in g["params"]:
+                    p_.grad = None
+        ref.step()
+    for r in range(world):
+        assert outs[r]["lag"] == {"xyz": 2, "f_rest": 1}
+        for a, b in zip(outs[r]["params"], params):
+            torch.testing.assert_close(a, b.detach(), rtol=2e-5, atol=2e-6)
+    want, got = ref.state_dict(), outs[0]["sd"]
+    assert {k: float(v["step"]) for k, v in got["state"].items()} == {k: float(v["step"]) for k, v in want["state"].items()}
+    for k in want["state"]:
+        torch.testing.assert_close(got["state"][k]["exp_avg"], want["state"][k]["exp_avg"], rtol=2e-5, atol=1e-7)
+
+
 # ---- optimizer-state surgery under the sharded optimizer ------------------------------------------------------------------
 def _worker_reset_opacity(rank, world, port, out_dir):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
