@@ -76,6 +76,11 @@ template <int WS = M16_W>
 __device__ __forceinline__ int a16_idx(int row, int f) { return row * WS + (f ^ ((row & 15) << 3)); }
 __device__ __forceinline__ int cd_row16(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
 
+// Ablation bits of the forward body (gp_debug_option(9, bits); tools/probe/mlp16_ablate.sh): 1 no saved-tensor stores, 2 no ReLU-mask
+// stores, 4 no matrix products, 8 no input staging (zeros), 16 no epilogue.  Timing only: the results are garbage.
+__device__ int g_m16_ablate;
+static int m16_set_ablate(int v) { return hipMemcpyToSymbol(HIP_SYMBOL(g_m16_ablate), &v, sizeof(int)) == hipSuccess ? 0 : 1; }
+
 struct Mlp16Dev {
     long rows;
     int in_dim, in_pad, out_dim;       // in_pad = in_dim rounded up to 16
@@ -483,7 +488,9 @@ __device__ __forceinline__ void mlp16_fwd_body(Mlp16Dev p, float* __restrict__ o
     const long rows_pad = (p.rows + 63) & ~63L;                 // the saved tensors are allocated (and zero-padded) to 64 rows
     T* cur = smem[0];
     T* nxt = smem[INPLACE ? 0 : 1];
-    if constexpr (SP) build_input16s<ROWS>(cur, p, row0, tid);
+    const int ablate = g_m16_ablate;
+    if (ablate & 8) { for (int e = tid; e < ROWS * WS; e += M16_THREADS) cur[e] = (T)0.f; }
+    else if constexpr (SP) build_input16s<ROWS>(cur, p, row0, tid);
     else build_input16<T, ROWS>(cur, p, row0, tid);
     __syncthreads();
     auto store_T = [&](const T* buf, T* dst, int nf) {      // this workgroup's block: NS x nf x ROWS contiguous elements
@@ -491,6 +498,8 @@ __device__ __forceinline__ void mlp16_fwd_body(Mlp16Dev p, float* __restrict__ o
         store_tile_T<T, ROWS, WS>(buf, blk, nf, NS * nf, row0, p.rows, rows_pad, wave, lane);
         if constexpr (SP) store_tile_T<T, ROWS, WS>(buf + 256, blk + (size_t)nf * T16_BLK, nf, NS * nf, row0, p.rows, rows_pad, wave, lane);
     };
+    if (ablate & 1) { saved_xT = nullptr; saved_hT = nullptr; }
+    if (ablate & 2) masks = nullptr;
     if (saved_xT) store_T(cur, saved_xT, p.in_pad);
     typedef typename Vec4<T>::type V4;
     for (int l = 0; l < 4; ++l) {
@@ -514,11 +523,12 @@ __device__ __forceinline__ void mlp16_fwd_body(Mlp16Dev p, float* __restrict__ o
                 for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) ax[rt][nt][r] = 0.f;
-            gemm16s<true, RT>(cur, (const _Float16*)p.w[l], (const _Float16*)p.wlo[l], K, K, M16_W, wave, lane, acc, ax);
+            if (!(ablate & 4)) gemm16s<true, RT>(cur, (const _Float16*)p.w[l], (const _Float16*)p.wlo[l], K, K, M16_W, wave, lane, acc, ax);
         } else {
-            gemm16<T, true, RT>(cur, (const T*)p.w[l], K, K, M16_W, wave, lane, acc);
+            if (!(ablate & 4)) gemm16<T, true, RT>(cur, (const T*)p.w[l], K, K, M16_W, wave, lane, acc);
         }
         if (INPLACE) __syncthreads();       // every wave has read the layer's input before anyone overwrites it
+        if (!(ablate & 16))
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
             const int row = rt * 32 + j;
@@ -1150,6 +1160,10 @@ extern "C" int gp_mlp16_forward(const gp_mlp16_params* p, const gp_mlp_input* x,
     if (m.rows == 0) return 0;
     if (!out) GP_FAIL("null output");
     hipStream_t s = (hipStream_t)stream_;
+    {
+        static thread_local int ablate_set = 0;
+        if (gp_debug_get(9) != ablate_set) { ablate_set = gp_debug_get(9); if (m16_set_ablate(ablate_set)) GP_FAIL("mlp16 ablate flag"); }
+    }
     GpProfScope _p("mlp16_fwd", s);
     if (p->dtype == GP_DTYPE_F16_SPLIT) {
         hipLaunchKernelGGL(gp_mlp16_fwd_split_kernel, dim3(gp_blocks((size_t)m.rows, M16_ROWS)), dim3(M16_THREADS), 0, s, m, out, saved_xT, saved_hT, masks);

@@ -417,7 +417,8 @@ int gp_microbench_gather(const void* src, int rec_bytes, int stride_bytes, const
  * the shipped default; key 2: access shape of gp_microbench_copy, tools/copy_peak_sweep.py; key 3: 1 = round 2's 2-D grid of the
  * split-mode weight-gradient kernel; key 4: workgroup cap of the fused weights-model forward;
  * key 5: 1 = tile binning by duplicate + radix sort instead of by counting, csrc/bin_kernels.hip; key 6: ablation bits of the
- * binning scatter kernel; key 8: 2 = depth sort in three 11-bit counting passes instead of four 8-bit radix passes -- measured slower, kept for the A/B).  Never needed by a caller of the
+ * binning scatter kernel; key 8: 2 = depth sort in three 11-bit counting passes instead of four 8-bit radix passes -- measured slower, kept for the A/B;
+ * key 9: ablation bits of the 16-bit MLP forward, tools/probe/mlp16_ablate.py).  Never needed by a caller of the
  * render path. */
 int gp_debug_option(int key, int value);
 /* Diagnostics: with gp_debug_option(0, 3) the composite forward counts, over all launches since the last call, out4[0] = the
