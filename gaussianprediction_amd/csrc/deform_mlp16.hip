@@ -128,28 +128,52 @@ __device__ __forceinline__ void build_input16(T* buf, const Mlp16Dev& p, long ro
     typedef typename Vec2<T>::type V2;
     const int fd = p.feature_dim, xf = p.xyz_freq, tf = p.time_freq;
     const float tv = tf > 0 ? p.t[0] : 0.f;
-    if ((fd & 3) == 0 && ((uintptr_t)p.feature & 15) == 0) {
-        const int q = fd >> 2;
-        for (int jj = tid >> 3; jj < ROWS; jj += M16_THREADS / 8) {
+    if ((fd & 3) == 0 && fd <= 64 && ((uintptr_t)p.feature & 15) == 0) {
+        // every global load of the tile before the first LDS store (as rolled loops: ROWS / 32 + 2 dependent trips to memory per workgroup)
+        const int q = fd >> 2, nq = ROWS * q;
+        constexpr int FU = ROWS * 64 / 4 / M16_THREADS, XU = (3 * ROWS + M16_THREADS - 1) / M16_THREADS;
+        float4 fv[FU];
+        float xv[XU];
+#pragma unroll
+        for (int u = 0; u < FU; ++u) {
+            const int e = tid + M16_THREADS * u;
+            const int jj = e < nq ? e / q : 0, f4 = e < nq ? e - jj * q : 0;
             const long row = row0 + jj;
-            for (int f4 = tid & 7; f4 < q; f4 += 8) {
-                const float4 v = row < p.rows ? *(const float4*)(p.feature + row * fd + 4 * f4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const bool ok = e < nq && row < p.rows;
+            fv[u] = *(const float4*)(p.feature + (ok ? row * fd + 4 * f4 : 0));
+            if (!ok) fv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < XU; ++u) {
+            const int e = tid + M16_THREADS * u;
+            const long row = row0 + e / 3;
+            const bool ok = e < 3 * ROWS && row < p.rows;
+            xv[u] = p.xyz[ok ? row * 3 + e % 3 : 0];
+            if (!ok) xv[u] = 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < FU; ++u) {
+            const int e = tid + M16_THREADS * u;
+            if (e < nq) {
+                const int jj = e / q, f4 = e - jj * q;
                 V4 pk;
-                pk[0] = (T)v.x; pk[1] = (T)v.y; pk[2] = (T)v.z; pk[3] = (T)v.w;
+                pk[0] = (T)fv[u].x; pk[1] = (T)fv[u].y; pk[2] = (T)fv[u].z; pk[3] = (T)fv[u].w;
                 *(V4*)&buf[a16_idx(jj, 4 * f4)] = pk;
             }
         }
-        for (int e = tid; e < 3 * ROWS; e += M16_THREADS) {
-            const int jj = e / 3, c = e - 3 * jj;
-            const long row = row0 + jj;
-            const bool ok = row < p.rows;
-            const float x = ok ? p.xyz[row * 3 + c] : 0.f;
-            for (int fr = 0; fr < xf; ++fr) {
-                float sv, cv;
-                fast_sincos(x * (float)(1u << fr), &sv, &cv);
-                V2 pk;
-                pk[0] = (T)(ok ? sv : 0.f); pk[1] = (T)(ok ? cv : 0.f);
-                *(V2*)&buf[a16_idx(jj, fd + 2 * (c * xf + fr))] = pk;
+#pragma unroll
+        for (int u = 0; u < XU; ++u) {
+            const int e = tid + M16_THREADS * u;
+            if (e < 3 * ROWS) {
+                const int jj = e / 3, c = e - 3 * jj;
+                const bool ok = row0 + jj < p.rows;
+                for (int fr = 0; fr < xf; ++fr) {
+                    float sv, cv;
+                    fast_sincos(xv[u] * (float)(1u << fr), &sv, &cv);
+                    V2 pk;
+                    pk[0] = (T)(ok ? sv : 0.f); pk[1] = (T)(ok ? cv : 0.f);
+                    *(V2*)&buf[a16_idx(jj, fd + 2 * (c * xf + fr))] = pk;
+                }
             }
         }
         for (int e = tid; e < tf * ROWS; e += M16_THREADS) {
