@@ -309,7 +309,7 @@ class FusedAdam:
                 self._num_subsets[key] = sub
             NUM, active = sub
         LR = (C.c_float * n)(*[float(g["lr"]) for g, _, _, _, _ in self.items])
-        STEPS = (C.c_int64 * n)(*[max(1, st) for st in self.item_steps(step_no)])
+        STEPS = (C.c_int64 * n)(*[max(1, st) for st in self.item_steps(step_no)]) if self.lag else None   # (no group behind: one count)
         mask = 0
         if zero_grad:
             for k, p in enumerate(self.owner):
@@ -319,10 +319,15 @@ class FusedAdam:
         dev = self.bucket.flat.device
         sp = _lib.stream_ptr(dev) if stream is None else C.c_void_p(stream.cuda_stream)
         with _lib.on_device(dev):
-            rc = _lib.lib().gp_adam_step_multi_steps(C.c_int32(n), P, G, M, V, NUM, LR, STEPS, C.c_float(b1), C.c_float(b2),
-                                                     C.c_float(self.eps), C.c_int32(1 if zero_grad else 0), C.c_uint32(mask),
-                                                     _lib.ptr(skip_flag), sp)
-            _lib.check(rc, "gp_adam_step_multi_steps")
+            if STEPS is None:
+                rc = _lib.lib().gp_adam_step_multi(C.c_int32(n), P, G, M, V, NUM, LR, C.c_float(b1), C.c_float(b2), C.c_float(self.eps),
+                                                   C.c_int64(step_no), C.c_int32(1 if zero_grad else 0), C.c_uint32(mask),
+                                                   _lib.ptr(skip_flag), sp)
+            else:
+                rc = _lib.lib().gp_adam_step_multi_steps(C.c_int32(n), P, G, M, V, NUM, LR, STEPS, C.c_float(b1), C.c_float(b2),
+                                                         C.c_float(self.eps), C.c_int32(1 if zero_grad else 0), C.c_uint32(mask),
+                                                         _lib.ptr(skip_flag), sp)
+            _lib.check(rc, "gp_adam_step_multi")
 
     def step(self, zero_grad=True, keep_grad=(), skip_flag=None, only=None, exclude=None, stream=None, advance=True, hold=()):
         """One launch for all parameter tensors (gp_adam_step_multi_steps).  Parameters listed in `keep_grad` are not
@@ -334,14 +339,18 @@ class FusedAdam:
         `hold`: group names that SKIP this optimisation step as torch.optim.Adam skips a parameter whose .grad is None: no update,
         moments untouched, the group's own step count does not advance (`lag`), its gradient is discarded."""
         step_no = self.step_count + 1
-        held = [g for g in self.param_groups if g.get("name") in set(hold)]
+        held_params = ()
         if advance:
             self.step_count = step_no
-            for g in held:
-                self.lag[g["name"]] = self.lag_of(g) + 1
-        held_params = [p for g in held for p in g["params"] if p.requires_grad]
-        if held_params:
-            exclude = tuple(exclude or ()) + tuple(held_params)
+        if hold:
+            names = set(hold)
+            held = [g for g in self.param_groups if g.get("name") in names]
+            if advance:
+                for g in held:
+                    self.lag[g["name"]] = self.lag_of(g) + 1
+            held_params = [p for g in held for p in g["params"] if p.requires_grad]
+            if held_params:
+                exclude = tuple(exclude or ()) + tuple(held_params)
         n = len(self.items)
         keep_ids = {id(p) for p in keep_grad}
         if not self.bucket.flat.is_cuda:
@@ -373,7 +382,7 @@ class FusedAdam:
             raise RuntimeError("torch.autograd.graph.increment_version is missing: cached keypoint weights could not be invalidated")
         for p in covered:
             bump(p)
-        if zero_grad:
+        if zero_grad and held_params:
             off_of = {id(q): o for q, o in zip(self.bucket.params, self.bucket.offsets)}
             for p in held_params:                # a held group's gradient is dropped, as the replaced tensor's is in the reference
                 self.bucket.flat[off_of[id(p)]:off_of[id(p)] + p.numel()].zero_()
