@@ -54,6 +54,15 @@ def packed_weights(wb, ws):
     return pk
 
 
+def _input_sink(leaf, shape):
+    """The .grad buffer of `leaf` if a kernel may WRITE this backward's gradient into it: an eligible leaf whose buffer is marked
+    fresh (zeros, unwritten since the optimizer's zeroing pass: grad_sink.mark_fresh; the mark is consumed), else None."""
+    g = grad_sink.sink_of(leaf)
+    if g is None or tuple(g.shape) != tuple(shape) or not grad_sink.take_fresh(g):
+        return None
+    return g
+
+
 class FusedMlp(torch.autograd.Function):
     """out = Deformable_Field(cat[feature, PE(xyz, xyz_freq), PE(t, time_freq)])  (d=4, w=256)."""
 
@@ -93,6 +102,7 @@ class FusedMlp(torch.autograd.Function):
             ctx.meta = (int(xyz_freq), int(time_freq), xyz_c is not None, t_c is not None)
             ctx.needs = (feature.requires_grad, xyz is not None and xyz.requires_grad)
             ctx.wb_leaves = tuple(wb)
+            ctx.in_leaves = (feature, xyz)      # (their .grad may take the input gradients directly: _input_sink)
             ctx.pk = pk              # (the weights do not change between a forward and its backward)
         return out
 
@@ -126,8 +136,15 @@ class FusedMlp(torch.autograd.Function):
         inp = _lib.MlpInputC(rows, fd, xyz_freq, time_freq, feature_c.data_ptr(), xyz_c.data_ptr() if has_xyz else None,
                              t_c.data_ptr() if has_t else None)
         need_f, need_x = ctx.needs
-        g_feat = torch.empty(rows, fd, device=dev) if need_f else None
-        g_xyz = torch.empty(rows, 3, device=dev) if (need_x and has_xyz and xyz_freq > 0) else None
+        # The input gradients are WRITTEN (not accumulated) by the kernels.  Where the input is a leaf whose .grad buffer is marked
+        # fresh (zeros since the optimizer's pass, nobody has written: TrainStep asks FusedAdam to mark the keypoint tensors), the
+        # kernel writes straight into it and autograd gets None: no temporary, no AccumulateGrad add launch (three 4 us kernels per
+        # step on K x 32 / K x 3 tensors, round 4).  A later contribution to the same leaf finds no mark and is accumulated by autograd.
+        f_leaf, x_leaf = getattr(ctx, "in_leaves", (None, None))
+        f_sink = _input_sink(f_leaf, (rows, fd)) if need_f else None
+        x_sink = _input_sink(x_leaf, (rows, 3)) if (need_x and has_xyz and xyz_freq > 0) else None
+        g_feat = f_sink if f_sink is not None else (torch.empty(rows, fd, device=dev) if need_f else None)
+        g_xyz = x_sink if x_sink is not None else (torch.empty(rows, 3, device=dev) if (need_x and has_xyz and xyz_freq > 0) else None)
         alloc = _lib.TorchAllocator(dev)
         with _lib.on_device(dev):
             rc = _lib.lib().gp_mlp_backward(C.byref(params), C.byref(inp), _lib.ptr(acts), _lib.ptr(g), C.byref(grads),
@@ -144,6 +161,12 @@ class FusedMlp(torch.autograd.Function):
         if use_sink:
             for t in leaves:
                 grad_sink.notify(t)
+        if f_sink is not None:
+            grad_sink.notify(f_leaf)
+            g_feat = None
+        if x_sink is not None:
+            grad_sink.notify(x_leaf)
+            g_xyz = None
         return (g_feat, g_xyz, None, None, None, *wb_grads)
 
 

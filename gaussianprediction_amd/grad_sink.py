@@ -48,8 +48,34 @@ def take_stale(g):
 
 
 def forget_all():
-    """Drop every stale mark (the gradient buffers were re-allocated)."""
+    """Drop every mark (the gradient buffers were re-allocated)."""
     _stale.clear()
+    _fresh.clear()
+
+
+# Gradient buffers known to hold ZEROS that nobody has written since (the optimizer marks them right after its zeroing pass):
+# the first producer may WRITE its gradient into such a buffer instead of handing autograd a temporary to be added -- writing
+# over zeros is accumulating.  The mark is consumed by the first taker; every later contribution of the same backward (or of
+# another view of the same step) goes through autograd's accumulate as usual, so the protocol holds for any number of producers.
+_fresh = set()
+
+
+def mark_fresh(g):
+    _fresh.add(g.data_ptr())
+
+
+def unmark_fresh(g):
+    if g is not None:
+        _fresh.discard(g.data_ptr())
+
+
+def take_fresh(g):
+    """True (and forget it) if `g` is all zeros and unwritten since: the caller may overwrite it with a first contribution."""
+    k = g.data_ptr()
+    if k in _fresh:
+        _fresh.discard(k)
+        return True
+    return False
 
 
 def is_stale(g):

@@ -50,6 +50,7 @@ class L1SSIMLoss(torch.autograd.Function):
         if need:
             ctx.save_for_backward(img, g, dmaps, xc if xc is not None else torch.empty(0, device=dev))
             ctx.lam, ctx.reg = lam, (float(reg_scale), reg_x.shape) if xc is not None else None
+            ctx.reg_leaf = reg_x
         return loss
 
     @staticmethod
@@ -66,12 +67,19 @@ class L1SSIMLoss(torch.autograd.Function):
                                                          C.c_int32(W), C.c_float(ctx.lam), _lib.ptr(up), _lib.ptr(dimg),
                                                          _lib.stream_ptr(dev))
             else:
-                gx = torch.empty_like(xc)
+                # (a leaf whose .grad buffer is marked fresh takes the regulariser's gradient directly: deform_ops._input_sink)
+                from .deform_ops import _input_sink
+                sink = _input_sink(getattr(ctx, "reg_leaf", None), ctx.reg[1]) if xc.is_contiguous() else None
+                gx = sink if sink is not None else torch.empty_like(xc)
                 rc = _lib.lib().gp_loss_l1_ssim_backward_reg(_lib.ptr(img), _lib.ptr(g), _lib.ptr(dmaps), C.c_int32(3), C.c_int32(H),
                                                              C.c_int32(W), C.c_float(ctx.lam), _lib.ptr(up), _lib.ptr(dimg), _lib.ptr(xc),
                                                              C.c_int64(xc.numel()), C.c_float(ctx.reg[0]), _lib.ptr(gx),
                                                              _lib.stream_ptr(dev))
                 gx = gx.reshape(ctx.reg[1])
+                if sink is not None:
+                    from . import grad_sink
+                    grad_sink.notify(ctx.reg_leaf)
+                    gx = None
             _lib.check(rc, "gp_loss_l1_ssim_backward")
         return dimg, None, None, gx, None
 
@@ -329,7 +337,7 @@ class FusedAdam:
                                                          _lib.ptr(skip_flag), sp)
             _lib.check(rc, "gp_adam_step_multi")
 
-    def step(self, zero_grad=True, keep_grad=(), skip_flag=None, only=None, exclude=None, stream=None, advance=True, hold=()):
+    def step(self, zero_grad=True, keep_grad=(), skip_flag=None, only=None, exclude=None, stream=None, advance=True, hold=(), fresh_grad=()):
         """One launch for all parameter tensors (gp_adam_step_multi_steps).  Parameters listed in `keep_grad` are not
         zeroed: their gradient buffers are marked stale (grad_sink.mark_stale) and the next backward overwrites them.
         `skip_flag`: optional int32 device word; non-zero = leave parameters and moments untouched (invalid frame).
@@ -337,7 +345,9 @@ class FusedAdam:
         than the current one; `advance=False` uses step number step_count + 1 without committing it (the first of two
         partial launches of one optimisation step).
         `hold`: group names that SKIP this optimisation step as torch.optim.Adam skips a parameter whose .grad is None: no update,
-        moments untouched, the group's own step count does not advance (`lag`), its gradient is discarded."""
+        moments untouched, the group's own step count does not advance (`lag`), its gradient is discarded.
+        `fresh_grad`: parameters whose gradient buffer -- zeroed by this very call -- is marked fresh (grad_sink.mark_fresh): the
+        first producer of the next backward may write into it instead of going through autograd's accumulate."""
         step_no = self.step_count + 1
         held_params = ()
         if advance:
@@ -391,6 +401,16 @@ class FusedAdam:
             for p in covered:
                 if id(p) in keep_ids and p.grad is not None:
                     grad_sink.mark_stale(p.grad)
+        if zero_grad and fresh_grad:
+            from . import grad_sink
+            cov = {id(p) for p in covered} | {id(p) for p in held_params}          # (zeroed by the launch, or explicitly above)
+            hooked = self.__dict__.setdefault("_fresh_hooked", set())
+            for p in fresh_grad:
+                if id(p) in cov and id(p) not in keep_ids and p.grad is not None:
+                    if id(p) not in hooked:      # a contribution that arrives through autograd instead ends the buffer's freshness
+                        p.register_post_accumulate_grad_hook(lambda q: grad_sink.unmark_fresh(q.grad))
+                        hooked.add(id(p))
+                    grad_sink.mark_fresh(p.grad)
         if self.shard is not None and zero_grad:
             # the launch zeroed this rank's slices only; the slices the other ranks own hold this rank's partial sums still.
             # Only regions this launch covered (`only` / `exclude`), on the stream of the launch.

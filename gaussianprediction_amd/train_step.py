@@ -248,6 +248,7 @@ class TrainStep:
             # skipped and the next backward overwrites instead of accumulating.  With the lifecycle opacity the second MLP
             # pass is a second producer of the xyz gradient, so xyz keeps the zero-and-accumulate protocol.
             keep = (pc._features_dc, pc._features_rest, pc._rotation, pc._scaling, pc._opacity) + (() if lifecycle else (pc._xyz,))
+
         # A gradient may leave for its exchange from a kernel's completion notice only if that kernel is its ONLY producer in this
         # backward: the per-Gaussian tensors of a single-view step (SH: rasterizer backward; rotation / xyz: blend backward;
         # scaling / opacity: activation backward; the stage-1 motion feature: MLP backward).  Everything else -- several views
@@ -332,16 +333,19 @@ class TrainStep:
                 for p_ in sh_pair:
                     if p_.grad is not None:
                         grad_sink.mark_stale(p_.grad)
+        # the small leaf inputs of the keypoint MLP / the regulariser: their zeroed gradient buffers are marked fresh, so that the first
+        # producer of the next backward writes into them (deform_ops._input_sink) instead of launching an accumulate per tensor
+        fresh = (pc.super_gaussians, pc.super_gaussians_feature) if self.iteration > pc.second_stage_iter else ()
         chained = getattr(self, "_chained_params", None) if self.sharded else None
         if chained:                  # their Adam slice and all-gather are already running on the exchange's side stream
-            self.optimizer.step(zero_grad=True, keep_grad=keep, skip_flag=skip_flag, exclude=tuple(chained))
+            self.optimizer.step(zero_grad=True, keep_grad=keep, skip_flag=skip_flag, exclude=tuple(chained), fresh_grad=fresh)
         elif fuse is not None:
-            self.optimizer.step(zero_grad=True, keep_grad=keep, skip_flag=skip_flag, exclude=sh_pair)
+            self.optimizer.step(zero_grad=True, keep_grad=keep, skip_flag=skip_flag, exclude=sh_pair, fresh_grad=fresh)
         elif self._sh_early:         # the SH tensors were updated on the side stream during the backward
             self._sh_early = False
-            self.optimizer.step(zero_grad=True, keep_grad=keep, skip_flag=skip_flag, exclude=(pc._features_dc, pc._features_rest))
+            self.optimizer.step(zero_grad=True, keep_grad=keep, skip_flag=skip_flag, exclude=(pc._features_dc, pc._features_rest), fresh_grad=fresh)
         else:
-            self.optimizer.step(zero_grad=True, keep_grad=keep, skip_flag=skip_flag, hold=hold)
+            self.optimizer.step(zero_grad=True, keep_grad=keep, skip_flag=skip_flag, hold=hold, fresh_grad=fresh)
         if self.sharded:
             self.reducer.gather_params()             # asynchronous; awaited by the next step / render
         return loss.detach(), pkg
