@@ -277,7 +277,7 @@ int gp_activations_backward(int64_t n, const float* scaling_raw, const float* op
 /* ---- loss + optimizer (the steps right after the render in every training iteration) ---------- */
 
 /* sum |img - gt| and the sum of the SSIM map (11x11 Gaussian window, sigma 1.5, zero padding) over a [3,H,W]
- * image pair [REF utils/loss_utils.py:54-100].  `sums` has 2 * GP_LOSS_SUM_SLOTS(H, W) doubles, one (sum |a-b|, sum ssim) pair
+ * image pair [REF utils/loss_utils.py:54-100].  `sums` (16-byte aligned) has 2 * GP_LOSS_SUM_SLOTS(H, W) doubles, one (sum |a-b|, sum ssim) pair
  * per workgroup (a 32 x 32 tile of one channel), written with plain stores: it need not be initialised, and the totals the
  * finalize calls form are summed in a fixed order (bit-reproducible).  gp_loss_l1_ssim_finalize forms
  * (1-l) * S0/n + l * (1 - S1/n) [REF train.py:108].  dmaps (optional, [3,3,H,W]) receives the SSIM

@@ -15,7 +15,8 @@ pytestmark = pytest.mark.skipif(shutil.which(HIPCC) is None and not os.path.exis
 
 
 @pytest.mark.parametrize("src,kernels", [
-    ("loss_adam_kernels.hip", ["gp_l1_ssim_fwd_kernel", "gp_l1_ssim_bwd_kernel"]),
+    ("loss_adam_kernels.hip", ["gp_l1_ssim_fwd_kernel", "gp_l1_ssim_bwd_kernel", "gp_loss_finalize_reg_kernel", "gp_loss_finalize_kernel"]),
+    ("deform_mlp16.hip", ["gp_mlp16_bwd_data_split_kernel"]),
     ("sort_scan.hip", ["gp_radix_hist_kernelILi8E", "gp_radix_scatter_kernelILi8E", "gp_radix_hist_kernelILi16E"]),
     ("deform_kernels.hip", ["gp_blend_fwd6_kernel", "gp_blend_bwd6_kernel", "gp_blend_fwd6_i16_kernel", "gp_blend_bwd6_i16_kernel", "gp_act_fwd_kernel", "gp_act_bwd_kernel"]),
     ("weights_kernels.hip", ["gp_knn_kernelILi35ELi6E"]),
