@@ -323,17 +323,21 @@ __global__ __launch_bounds__(ST) void gp_mlp_fwd_small_kernel(MlpDev p, float* _
     float* cur = smem[0];
     float* nxt = smem[1];
     const int k16 = (p.in_dim + 15) & ~15;
+    // this lane's biases of all four hidden layers, requested with the input tile's loads (fetched at the top of each layer they were
+    // a trip to L2 in front of every layer's product: the accumulators start from them)
+    float4 bia[4][2];
+#pragma unroll
+    for (int l = 0; l < 4; ++l) {
+        bia[l][0] = *(const float4*)(p.b[l] + 32 * wave + 4 * kg);
+        bia[l][1] = *(const float4*)(p.b[l] + 32 * wave + 16 + 4 * kg);
+    }
     build_input_s(cur, p, row0, tid, k16);
     __syncthreads();
     if (saved_x) store_rows_s(cur, saved_x, p.in_pad, p.in_dim, p.in_pad, row0, p.rows, tid);
+#pragma unroll
     for (int l = 0; l < 4; ++l) {
         const int kv = l == 0 ? p.in_dim : SW, K16 = l == 0 ? k16 : SW, ldw = l == 0 ? p.in_dim : SW;
-        f32x4 acc0, acc1;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            acc0[r] = p.b[l][32 * wave + 4 * kg + r];
-            acc1[r] = p.b[l][32 * wave + 16 + 4 * kg + r];
-        }
+        f32x4 acc0 = {bia[l][0].x, bia[l][0].y, bia[l][0].z, bia[l][0].w}, acc1 = {bia[l][1].x, bia[l][1].y, bia[l][1].z, bia[l][1].w};
         if (p.pk) {
             const MlpPackLayout L = mlp_pack_layout(p.in_dim);
             const float4* P = (const float4*)p.pk + L.off_f[l];
@@ -389,17 +393,24 @@ __global__ __launch_bounds__(ST) void gp_mlp_bwd_data_small_kernel(MlpDev p, con
         // dH_l^T = W_l^T dZ_{l+1}^T ; W_l = p.w[l] is [Kout, 256]
         const int K16 = l == 4 ? 16 : SW, kv = l == 4 ? p.out_dim : SW;
         f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+        // the saved activations that gate this layer's gradient (ReLU) are requested BEFORE the product (clamped row, selected
+        // afterwards): loaded where they are used they were a dependent trip to memory behind every layer's matrix work
+        const float* h = saved_h + (size_t)(l - 1) * p.rows * SW;
+        const long row = row0 + n, rowc = row < p.rows ? row : p.rows - 1;
+        float hv0[4], hv1[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            hv0[r] = h[rowc * SW + 32 * wave + 4 * kg + r];
+            hv1[r] = h[rowc * SW + 32 * wave + 16 + 4 * kg + r];
+        }
         if (l == 4) tiles_mfma_T(p.w[l], SW, kv, K16, SW, 2 * wave, cur, lane, acc0, acc1);
         else if (p.pk) tiles_mfma_256_pk((const float4*)p.pk + mlp_pack_layout(p.in_dim).off_b[l], 2 * wave, cur, lane, acc0, acc1);
         else tiles_mfma_T_256(p.w[l], SW, SW, 2 * wave, cur, lane, acc0, acc1);
-        const float* h = saved_h + (size_t)(l - 1) * p.rows * SW;
-        const long row = row0 + n;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int f0 = 32 * wave + 4 * kg + r, f1 = f0 + 16;
-            const float h0 = row < p.rows ? h[row * SW + f0] : 0.f, h1 = row < p.rows ? h[row * SW + f1] : 0.f;
-            nxt[sidx(f0, n)] = h0 > 0.f ? acc0[r] : 0.f;
-            nxt[sidx(f1, n)] = h1 > 0.f ? acc1[r] : 0.f;
+            nxt[sidx(f0, n)] = (row < p.rows && hv0[r] > 0.f) ? acc0[r] : 0.f;
+            nxt[sidx(f1, n)] = (row < p.rows && hv1[r] > 0.f) ? acc1[r] : 0.f;
         }
         __syncthreads();
         store_rows_s(nxt, dz + (size_t)(l - 1) * p.rows * SW, SW, SW, SW, row0, p.rows, tid);
