@@ -952,8 +952,7 @@ __device__ __forceinline__ void blend_bwd_body(BlendDev a, const float* __restri
                 int loc = 0;
                 for (int e = 0; e < per; ++e) if (b0 + e < K) loc += s_cnt[b0 + e];
                 int inc = loc;
-#pragma unroll
-                for (int dd = 1; dd < 64; dd <<= 1) { const int t = __shfl_up(inc, dd); if ((tid & 63) >= dd) inc += t; }
+                inc = gp_wave_scan_add(inc);
                 if ((tid & 63) == 63) s_wsum[tid >> 6] = inc;
                 __syncthreads();
                 int woff = 0;
@@ -1059,6 +1058,13 @@ __global__ __launch_bounds__(1024) void gp_blend_bwd_reduce_kernel(const float* 
     float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
     if (e < KA) {
         int b = wave;
+        for (; b + 240 < nblocks; b += 256) {         // sixteen partials per trip to memory, added in the order of the loop below
+            float t[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) t[u] = partial[(size_t)(b + 16 * u) * KA + e];
+#pragma unroll
+            for (int u = 0; u < 16; u += 4) { v0 += t[u]; v1 += t[u + 1]; v2 += t[u + 2]; v3 += t[u + 3]; }
+        }
         for (; b + 48 < nblocks; b += 64) {
             v0 += partial[(size_t)b * KA + e]; v1 += partial[(size_t)(b + 16) * KA + e];
             v2 += partial[(size_t)(b + 32) * KA + e]; v3 += partial[(size_t)(b + 48) * KA + e];

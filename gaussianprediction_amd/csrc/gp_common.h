@@ -70,6 +70,16 @@ struct GpProfScope {
 
 int gp_debug_get(int key);
 
+// Inclusive wave-wide prefix sum on the DPP network (row_shr 1/2/4/8 inside each row of 16 lanes, then row_bcast 15 / 31 across the
+// rows): six VALU instructions.  `__shfl_up` is a ds_bpermute -- a scan built from it is six DEPENDENT LDS round trips.
+__device__ __forceinline__ int gp_wave_scan_add(int x) {
+#define GP_DPP_(v, ctrl, rmask) __builtin_amdgcn_update_dpp(0, (v), (ctrl), (rmask), 0xf, false)
+    x += GP_DPP_(x, 0x111, 0xf); x += GP_DPP_(x, 0x112, 0xf); x += GP_DPP_(x, 0x114, 0xf); x += GP_DPP_(x, 0x118, 0xf);
+    x += GP_DPP_(x, 0x142, 0xa); x += GP_DPP_(x, 0x143, 0xc);
+#undef GP_DPP_
+    return x;
+}
+
 // torch.optim.Adam's update of one element (eps added after the bias-corrected sqrt) -- the ONE statement of the arithmetic,
 // shared by gp_adam_multi_kernel and the update fused into the rasterizer backward, so the two are bit-identical.
 __device__ __forceinline__ void gp_adam_update(float& p, float g, float& m, float& v, float b1, float b2, float eps, float step_size,

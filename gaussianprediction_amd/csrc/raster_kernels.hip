@@ -465,12 +465,7 @@ __global__ __launch_bounds__(256) void gp_duplicate_kernel(RasterDims d, const u
         if (w < 1) w = 1;
     }
     const uint32_t base = before + offsets[i0];
-    int incl = cnt;                                          // inclusive scan of the counts over the wave
-#pragma unroll
-    for (int dlt = 1; dlt < 64; dlt <<= 1) {
-        const int t = __shfl_up(incl, dlt);
-        if (lane >= dlt) incl += t;
-    }
+    const int incl = gp_wave_scan_add(cnt);                  // inclusive scan of the counts over the wave
     const int total = __shfl(incl, 63);
     s_own[wave][lane] = make_int4(incl - cnt, minx, miny, w);
     s_id[wave][lane] = id;

@@ -29,11 +29,7 @@ __global__ __launch_bounds__(SCAN_BLOCK) void gp_scan_block_kernel(uint32_t* __r
         tsum += v[i];
     }
     uint32_t x = tsum;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        uint32_t t = __shfl_up(x, d);
-        if (lane >= d) x += t;
-    }
+        x = (uint32_t)gp_wave_scan_add((int)x);
     if (lane == 63) s_wave[wave] = x;
     __syncthreads();
     uint32_t wave_off = 0;
@@ -152,11 +148,7 @@ __global__ __launch_bounds__(256) void gp_radix_rowscan_kernel(uint32_t* __restr
             v = b < nblocks ? row[b] : 0u;
         }
         uint32_t x = v;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t t = __shfl_up(x, d);
-            if (lane >= d) x += t;
-        }
+        x = (uint32_t)gp_wave_scan_add((int)x);
         if (lane == 63) s_wave[wave] = x;
         __syncthreads();
         uint32_t off = s_carry;
@@ -229,11 +221,7 @@ __global__ __launch_bounds__(RS_BLOCK) void gp_radix_scatter_kernel(const uint32
     {   // global base of digit `tid` = exclusive scan of the 256 row totals
         const uint32_t tv = tv_pre;
         uint32_t x = tv;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t t = __shfl_up(x, d);
-            if (lane >= d) x += t;
-        }
+        x = (uint32_t)gp_wave_scan_add((int)x);
         if (lane == 63) s_dw[wave] = x;
         __syncthreads();
         uint32_t off = 0;
@@ -246,11 +234,7 @@ __global__ __launch_bounds__(RS_BLOCK) void gp_radix_scatter_kernel(const uint32
         for (int w = 0; w < RS_BLOCK / GP_WAVE; ++w) { c[w] = s_cnt[w][tid]; bc += c[w]; }
         // block-local exclusive scan of the 256 digit counts
         uint32_t x = bc;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t t = __shfl_up(x, d);
-            if (lane >= d) x += t;
-        }
+        x = (uint32_t)gp_wave_scan_add((int)x);
         __syncthreads();                 // s_dw is reused
         if (lane == 63) s_dw[wave] = x;
         __syncthreads();
