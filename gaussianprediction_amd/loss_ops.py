@@ -404,12 +404,12 @@ class FusedAdam:
         if zero_grad and fresh_grad:
             from . import grad_sink
             cov = {id(p) for p in covered} | {id(p) for p in held_params}          # (zeroed by the launch, or explicitly above)
-            hooked = self.__dict__.setdefault("_fresh_hooked", set())
             for p in fresh_grad:
                 if id(p) in cov and id(p) not in keep_ids and p.grad is not None:
-                    if id(p) not in hooked:      # a contribution that arrives through autograd instead ends the buffer's freshness
+                    if not getattr(p, "_gp_fresh_hook", False):      # (once per Parameter, whatever optimizer objects come and go)
+                        # a contribution that arrives through autograd instead ends the buffer's freshness
                         p.register_post_accumulate_grad_hook(lambda q: grad_sink.unmark_fresh(q.grad))
-                        hooked.add(id(p))
+                        p._gp_fresh_hook = True
                     grad_sink.mark_fresh(p.grad)
         if self.shard is not None and zero_grad:
             # the launch zeroed this rank's slices only; the slices the other ranks own hold this rank's partial sums still.

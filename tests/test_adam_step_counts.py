@@ -99,3 +99,30 @@ def test_held_groups_follow_the_reference_loops_conditions():
     model.optimizer.param_groups = [{"name": "s_xyz"}, {"name": "df_mlp"}]                                   # stage 2: nothing to hold
     assert densify.held_groups(model, 600, SimpleNamespace(densify_until_iter=15000, densify_from_iter=500, densification_interval=100,
                                                            opacity_reset_interval=3000)) == ()
+
+
+def test_fresh_gradient_buffers_take_exactly_one_direct_write():
+    """FusedAdam.step(fresh_grad=...) marks a just-zeroed .grad buffer fresh; the FIRST producer of the next backward may write into it
+    (deform_ops._input_sink) and every later contribution goes through autograd's accumulate -- which also ends the freshness."""
+    from gaussianprediction_amd import grad_sink
+    from gaussianprediction_amd.deform_ops import _input_sink
+    ref, fused, bucket = _pair(seed=8)
+    xyz, opa = fused.param_groups[0]["params"][0], fused.param_groups[1]["params"][0]
+    for p_ in (xyz, opa):
+        p_.grad.copy_(torch.ones_like(p_))
+    fused.step(zero_grad=True, fresh_grad=(xyz, opa))
+    assert float(bucket.flat.abs().max()) == 0.0 and getattr(xyz, "_gp_fresh_hook", False)
+    # a producer takes the buffer once, the second asker is sent through autograd
+    buf = _input_sink(xyz, tuple(xyz.shape))
+    assert buf is not None and buf.data_ptr() == xyz.grad.data_ptr()
+    assert _input_sink(xyz, tuple(xyz.shape)) is None
+    # a shape that is not the leaf's, or a non-leaf, never gets one (and does not consume the mark)
+    assert _input_sink(opa, (3, 3)) is None and _input_sink(opa * 2.0, tuple(opa.shape)) is None
+    # a contribution through autograd ends the freshness of a buffer nobody took
+    (opa * 3.0).sum().backward()
+    assert float(opa.grad.min()) == 3.0 and _input_sink(opa, tuple(opa.shape)) is None
+    # the next optimizer step marks again (same hook, registered once)
+    fused.step(zero_grad=True, fresh_grad=(xyz, opa))
+    assert _input_sink(opa, tuple(opa.shape)) is not None
+    grad_sink.forget_all()
+    assert _input_sink(xyz, tuple(xyz.shape)) is None
