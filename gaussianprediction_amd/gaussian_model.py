@@ -341,6 +341,7 @@ class GaussianModel(TrainingMixin, nn.Module):
                 if a.adaptive_from_iter + off <= iteration < a.adaptive_end_iter + off and self._kpts_room() > 0:
                     self.get_teach_motion(t_dev, (xyz_t - self._xyz).detach())
                     if iteration % a.adaptive_interval == 0:
+                        self.sync_teacher_stats()          # (view-parallel: the maximum over every rank's views)
                         self.get_new_kpts(self.xyz_motion_accum_max.squeeze(-1) >= a.teaching_threshold)
         self.lifecycle_opacity = None
         self._last_xyz_t = xyz_t.detach()

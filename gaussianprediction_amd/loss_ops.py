@@ -142,6 +142,10 @@ class FusedAdam:
 
     def __init__(self, param_groups, bucket, betas=(0.9, 0.999), eps=1e-15, shard=None):
         self.param_groups = param_groups
+        names = [g.get("name") for g in param_groups]
+        if any(n is None for n in names) or len(set(names)) != len(names):
+            # the per-group step counts (`lag`), `hold` and the state-dict mapping are keyed by group name
+            raise ValueError(f"FusedAdam needs a unique, non-None 'name' on every parameter group (got {names})")
         self.bucket = bucket
         self.betas, self.eps = betas, eps
         self.step_count = 0
@@ -150,6 +154,10 @@ class FusedAdam:
         # per-Gaussian tensors BEFORE optimizer.step() of the same iteration, their .grad is None and Adam skips them
         # [REF train.py:164-197]) or when a loaded state dict says so.  Bias corrections use step_count - lag per tensor.
         self.lag = {}
+        # groups the NEXT full step holds back once, whatever its `hold` argument says: set by optimizer-state surgery that found an
+        # unconsumed gradient (a loop in the reference's order: backward -> densify / prune / reset_opacity -> optimizer.step(); the
+        # replaced tensors' .grad is None there and torch.optim.Adam passes over them) -- training.TrainingMixin._rebuild_optimizer
+        self.pending_hold = set()
         self.shard = shard
         off_of = {id(p): off for p, off in zip(bucket.params, bucket.offsets)}
         self.items = []        # (group, tensor the launch updates, its offset in the flat buffers, exp_avg, exp_avg_sq)
@@ -352,6 +360,9 @@ class FusedAdam:
         held_params = ()
         if advance:
             self.step_count = step_no
+            if self.pending_hold:
+                hold = tuple(set(hold) | self.pending_hold)
+                self.pending_hold = set()
         if hold:
             names = set(hold)
             held = [g for g in self.param_groups if g.get("name") in names]

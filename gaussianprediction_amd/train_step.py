@@ -36,8 +36,12 @@ class TrainStep:
     SPEC_PAD = 4096
 
     def __init__(self, pc, cameras, gt_images, iteration, lambda_dssim=0.2, lrs=None, group=None, speculative=False,
-                 overlap_sh_adam=False, batch=1, schedule=False, training_args=None, sharded=None, fuse_sh_adam=True, chain_sh=True):
+                 overlap_sh_adam=False, batch=1, schedule=False, training_args=None, sharded=None, fuse_sh_adam=True, chain_sh=True,
+                 view_stats=None):
+        """`view_stats` (view-parallel only): True / False = always / never exchange the densification inputs' screen-space gradient
+        (see _step); None = exactly while the reference's loop reads it (below densify_until_iter, and during keypoint growth)."""
         self.pc, self.cameras, self.gt, self.iteration = pc, cameras, gt_images, iteration
+        self.view_stats = view_stats
         self.lambda_dssim = lambda_dssim
         self.group = group
         self.chain_sh = bool(chain_sh)      # sharded exchange: SH regions' Adam + all-gather on a side stream (_chain_sh)
@@ -54,6 +58,7 @@ class TrainStep:
             self._slot_spec = [False] * K           # ... and whether it ran in capacity mode
             self._slot_toff = [None] * K            # ... and its time offset (a repeated frame is repeated with it)
             self._slot_hold = [()] * K              # ... and the optimizer groups it held back
+            self._slot_epoch = [None] * K           # ... and which optimizer (pc.optimizer_epoch) took the step
             self._r_max, self._n_steps, self.redone = 0, 0, 0
             if os.environ.get("GP_SPEC_MARGIN"):     # test hook: a margin < 1 forces overflows (and the redo protocol)
                 self.SPEC_MARGIN, self.SPEC_PAD = float(os.environ["GP_SPEC_MARGIN"]), 0
@@ -90,11 +95,25 @@ class TrainStep:
         world = tdist.get_world_size(group) if (tdist.is_available() and tdist.is_initialized()) else 1
         self.sharded = bool(dist_active(group) and (sharded is None or sharded))
         shard = (tdist.get_rank(group), world) if self.sharded else None
+        if dist_active(group):                       # the replicas must stay identical through densify / prune / keypoint growth
+            pc.set_view_parallel(group, tdist.get_rank(group), world)
         if pc.optimizer is None or getattr(pc, "_stage", None) != self._stage_of(iteration) or getattr(pc, "optimizer_shard", None) != shard:
             pc.optimizer_shard = shard
             pc.setup_for_iteration(training_args, iteration)
         self._epoch = None
         self._attach()
+
+    def _view_stats_due(self):
+        """Does the loop read `viewspace_points.grad` after this iteration?  [REF train.py:164-167] below densify_until_iter;
+        [REF train.py:179-183] in the second stage while keypoints may still be added."""
+        if self.view_stats is not None:
+            return bool(self.view_stats)
+        pc, a, it = self.pc, self.pc.args, self.iteration
+        if it < getattr(self.training_args, "densify_until_iter", 0):
+            return True
+        if not getattr(pc, "second_stage", False) or not hasattr(a, "adaptive_end_iter") or not hasattr(pc, "super_gaussians"):
+            return False
+        return it < a.adaptive_end_iter + pc.second_stage_iter and pc.super_gaussians.shape[0] < a.max_points + a.adaptive_points_num
 
     def _stage_of(self, iteration):
         return 1 if iteration <= self.pc.second_stage_iter else (2 if iteration <= self.pc.third_stage_iter else 3)
@@ -205,9 +224,16 @@ class TrainStep:
             self._r_max = max(self._r_max, r)
             if overflow and self._slot_spec[slot]:   # its Adam update was skipped on the device: repeat the frame, exactly
                 self.redone += 1
-                self.optimizer.step_count -= 1
-                for name in self._slot_hold[slot]:   # (the repeated step holds the same groups again)
-                    self.optimizer.lag[name] -= 1
+                if self._slot_epoch[slot] == self.pc.optimizer_epoch:
+                    self.optimizer.step_count -= 1
+                    for name in self._slot_hold[slot]:   # (the repeated step holds the same groups again)
+                        left = self.optimizer.lag.get(name, 0) - 1
+                        if left > 0:
+                            self.optimizer.lag[name] = left
+                        else:
+                            self.optimizer.lag.pop(name, None)
+                # (else: bucket + optimizer were rebuilt since -- a stage change or surgery: the skipped update's count belongs to an
+                # optimizer that no longer exists, and the frame is repeated on the current model as an ordinary step)
                 self._events[slot] = None
                 self._time_offset, self._hold = self._slot_toff[slot], self._slot_hold[slot]
                 self._run_slot(slot, self._slot_view[slot], exact=True)
@@ -228,6 +254,7 @@ class TrainStep:
         self._events[slot], self._slot_view[slot], self._slot_spec[slot] = ev, view_index, not exact
         self._slot_toff[slot] = self._time_offset
         self._slot_hold[slot] = tuple(getattr(self, "_hold", ()))
+        self._slot_epoch[slot] = self.pc.optimizer_epoch
         return out
 
     def _step(self, view_index: int, binning, skip_flag):
@@ -251,12 +278,14 @@ class TrainStep:
 
         # A gradient may leave for its exchange from a kernel's completion notice only if that kernel is its ONLY producer in this
         # backward: the per-Gaussian tensors of a single-view step (SH: rasterizer backward; rotation / xyz: blend backward;
-        # scaling / opacity: activation backward; the stage-1 motion feature: MLP backward).  Everything else -- several views
+        # scaling / opacity: activation backward).  Everything else -- several views
         # per step; under the lifecycle opacity `_xyz`, the motion feature AND the MLP weights, which the second MLP pass also
         # differentiates; keypoints -- is exchanged after backward (finish()).  (Found by the two-rank test once it gave every
         # tensor a region of its own: the MLP weights left after the first of their two producers.)
+        # (The stage-1 motion feature is NOT among them: the regulariser 1e-5 mean|motion_feature| [REF scene/gaussian_model.py:174-178]
+        # is a second producer of its gradient beside the MLP backward -- found by the two-rank schedule test of round 5.)
         single = [] if self.batch > 1 else [pc._features_dc, pc._features_rest, pc._rotation, pc._scaling, pc._opacity] + \
-            ([] if lifecycle else [pc._xyz, pc.motion_feature])
+            ([] if lifecycle else [pc._xyz])
         sid = {id(p_) for p_ in single}
         self.reducer.set_late([p_ for p_ in self.bucket.params if id(p_) not in sid])
         hold = tuple(getattr(self, "_hold", ()))     # groups that skip this step's update: every early / fused / chained form of the
@@ -306,6 +335,17 @@ class TrainStep:
             if self.batch > 1 and hasattr(pc, "keypoint_weights_scope"):
                 pc.keypoint_weights_scope(None)
         self._armed = False
+        h_vs = None
+        if self.reducer.enabled and self._view_stats_due():
+            # The densification input of a batch is the LAST view's screen-space gradient [REF train.py:123-127 compute the sum over
+            # the batch, :167 hands add_densification_stats the loop variable = the last view's tensor, whose .grad holds that view
+            # alone].  The ranks of a view-parallel step ARE that batch, rank order = view order: every rank receives the last rank's
+            # last view's gradient (one [N,3] broadcast, asynchronous: it lands under the exchange and the optimizer launch), so that
+            # xyz_gradient_accum -- and with it every densify / prune / keypoint-growth decision -- is the same on every rank.
+            vs = pkgs[-1]["viewspace_points"]
+            if vs.grad is None:                      # (nothing visible on this rank: the collective still needs an operand)
+                vs.grad = torch.zeros_like(vs)
+            h_vs = torch.distributed.broadcast(vs.grad, src=self.pc._vp_src(-1), group=self.group, async_op=True)
         self.reducer.finish()                        # SUM over views == the reference's --batch semantics
         if getattr(self, "_flag_handle", None) is not None:
             if self.sharded:
@@ -318,7 +358,9 @@ class TrainStep:
         if self.batch > 1 or world > 1:
             # densification inputs of a batch [REF train.py:121-127]: radii = max over the views, visibility = any; the summed
             # screen-space gradient is computed -- and then the reference feeds add_densification_stats the LAST view's
-            # tensor, whose .grad holds that view alone (train.py:167); both are returned
+            # tensor, whose .grad holds that view alone (train.py:167); both are returned.  View-parallel: `viewspace_points.grad`
+            # is the last RANK's last view's on every rank (broadcast above); `viewspace_point_tensor_grad`, which the reference
+            # computes and never reads, stays this rank's own sum.
             from .dist import reduce_view_stats
             radii = torch.stack([p["radii"] for p in pkgs]).max(dim=0).values
             radii, vis = reduce_view_stats(radii, self.group)
@@ -348,6 +390,8 @@ class TrainStep:
             self.optimizer.step(zero_grad=True, keep_grad=keep, skip_flag=skip_flag, hold=hold, fresh_grad=fresh)
         if self.sharded:
             self.reducer.gather_params()             # asynchronous; awaited by the next step / render
+        if h_vs is not None:
+            h_vs.wait()                              # (the current stream waits; the host does not)
         return loss.detach(), pkg
 
     def sync_params(self):

@@ -144,7 +144,78 @@ class TrainingMixin:
         self.xyz_gradient_accum = torch.empty(0)
         self.xyz_gradient_accum_max = torch.empty(0)
         self.denom = torch.empty(0)
+        self._vp = None                    # (group, rank, world) of a view-parallel harness: set_view_parallel
+        self._surgery_no = 0               # densify calls so far: the seed of the split's random draws under view parallelism
+        self.surgery_seed = 2024           # [REF train.py:306 seeds everything with it]
         self.new_kpts_init()
+
+    # ---- view-parallel consistency (every rank must perform the SAME surgery) ---------------------------
+    def set_view_parallel(self, group, rank, world):
+        """Called by a view-parallel harness (TrainStep under a process group).  From then on the model keeps its replicas
+        identical through every operation that changes the parameter SET, not only their values:
+          * the k-means keypoints (float atomics in index_add_: not bit-reproducible) are rank 0's, broadcast;
+          * the teacher statistic that proposes keypoints is the MAX over the ranks' views (as the views of one `--batch`
+            accumulate into it in the reference);
+          * densify_and_split draws its samples from a generator seeded identically on every rank;
+          * after every surgery N, K and an exact checksum of the parameters are compared across the ranks (RuntimeError on
+            disagreement, before the next collective could silently mix rows of different Gaussians)."""
+        self._vp = (group, int(rank), int(world))
+
+    def _vp_group(self):
+        vp = getattr(self, "_vp", None)
+        if vp is None:
+            return None
+        import torch.distributed as tdist
+        return vp if (tdist.is_available() and tdist.is_initialized()) else None
+
+    def _vp_src(self, which=0):
+        """Global rank of the group's first (0) / last (-1) member: the `src` of a broadcast."""
+        import torch.distributed as tdist
+        group, _, world = self._vp
+        local = 0 if which == 0 else world - 1
+        return tdist.get_global_rank(group, local) if group is not None else local
+
+    def _vp_broadcast(self, tensors, which=0):
+        vp = self._vp_group()
+        if vp is None:
+            return
+        import torch.distributed as tdist
+        for t in tensors:
+            tdist.broadcast(t, src=self._vp_src(which), group=vp[0])
+
+    def _surgery_generator(self):
+        """The random stream of the next densify_and_split.  View-parallel: a generator every rank seeds with the same number
+        (surgery_seed, how many densify calls there have been); single process: None = torch's global stream, as in the reference."""
+        if self._vp_group() is None and not getattr(self, "deterministic_surgery", False):
+            return None
+        g = torch.Generator(device=self.get_xyz.device)
+        g.manual_seed(int(self.surgery_seed) * 1_000_003 + int(self._surgery_no))
+        return g
+
+    @torch.no_grad()
+    def assert_ranks_agree(self, what=""):
+        """View-parallel only: every rank holds the same parameter set -- N, K and an order-independent EXACT checksum (the
+        parameters' bit patterns summed as integers) of every optimized tensor agree.  One small all-reduce and one host read,
+        after surgery only."""
+        vp = self._vp_group()
+        if vp is None:
+            return
+        import torch.distributed as tdist
+        dev = self.get_xyz.device
+        vals = [self.get_xyz.shape[0], self.super_gaussians.shape[0] if hasattr(self, "super_gaussians") else 0]
+        sums = []
+        for p in (self.bucket.params if self.bucket is not None else list(self.parameters())):
+            bits = p.detach().contiguous().view(torch.int32).to(torch.int64)
+            sums.append(bits.sum())
+        v = torch.cat([torch.tensor(vals, dtype=torch.int64, device=dev), torch.stack(sums) if sums else torch.zeros(0, dtype=torch.int64, device=dev)])
+        both = torch.cat([v, -v])
+        tdist.all_reduce(both, op=tdist.ReduceOp.MAX, group=vp[0])
+        n = v.numel()
+        spread = (both[:n] + both[n:]).cpu()              # max - min per entry
+        if bool((spread != 0).any()):
+            bad = [i for i in range(n) if int(spread[i]) != 0]
+            raise RuntimeError(f"view-parallel replicas diverged ({what}): entries {bad} of [N, K, checksum per optimized tensor] differ "
+                               f"across ranks (N spread {int(spread[0])}, K spread {int(spread[1])})")
 
     # ---- optimizer construction ----------------------------------------------------------------------------------
     def _per_gaussian(self):
@@ -311,12 +382,36 @@ class TrainingMixin:
             return {}
         return opt.full_moments()                # (sharded: a collective -- every rank performs the same surgery)
 
+    def _unconsumed_gradient(self, params=None):
+        """True when the CURRENT bucket holds a gradient that no optimizer step has consumed yet (a backward ran and
+        `optimizer.step()` has not): some non-stale gradient buffer is not all zero.  This package's own harness updates first
+        and operates afterwards (everything is zero -- Adam zeroes in the same launch -- or marked stale); the reference's loop
+        runs densify / prune / reset_opacity BETWEEN backward and optimizer.step() [REF train.py:164-197].  One host read."""
+        if self.bucket is None:
+            return False
+        from . import grad_sink
+        live = [self.bucket.segment(p) for p in (self.bucket.params if params is None else params)
+                if p.grad is not None and not grad_sink.is_stale(p.grad)]
+        live = [seg for seg in live if seg.numel() > 0]
+        if not live:
+            return False
+        return bool(torch.stack([seg.abs().max() for seg in live]).max() > 0)
+
     def _rebuild_optimizer(self, carried):
         """New bucket + optimizer over the model's CURRENT Parameters.  `carried` maps id(new per-Gaussian Parameter) to its
-        (exp_avg, exp_avg_sq); every other parameter keeps its moments; step count and learning rates are preserved."""
+        (exp_avg, exp_avg_sq); every other parameter keeps its moments; step count and learning rates are preserved.
+
+        Loops in the reference's order [REF train.py:164-197: backward -> densify / prune -> optimizer.step()] arrive here with an
+        unconsumed gradient in the old bucket.  torch.optim.Adam would then update the parameters that SURVIVED the surgery (MLP,
+        keypoints, hash grid) from it and pass over the replaced per-Gaussian tensors, whose .grad is None: the surviving
+        parameters' gradients are carried into the new bucket and the replaced groups are held back on the next step()
+        (`FusedAdam.pending_hold`), which is the same outcome."""
         old = self.optimizer
         if old is None:
             return
+        pending = self._unconsumed_gradient()
+        old_bucket = self.bucket
+        old_off = {id(p): off for p, off in zip(old_bucket.params, old_bucket.offsets)}
         old_mom = self.adam_moments()
         lrs = {g["name"]: g["lr"] for g in old.param_groups}
         old_step = old.step_count
@@ -328,10 +423,18 @@ class TrainingMixin:
                 g["lr"] = lrs[g["name"]]
         self.optimizer.step_count = old_step     # the reference keeps the stored state (and its step) [REF :595-598]
         self.optimizer.lag = dict(old.lag)       # ... per group: the steps it skipped
+        self.optimizer.pending_hold = set(getattr(old, "pending_hold", ()))
         for p in self.bucket.params:
             src = carried.get(id(p)) or old_mom.get(id(p))
             if src is not None and src[0].shape == p.shape:
                 self.optimizer.load_full_moments(p, src[0], src[1])
+        if pending:
+            for p, off in zip(self.bucket.params, self.bucket.offsets):
+                if id(p) in old_off:             # the same Parameter object: its gradient of this iteration is still due
+                    self.bucket.flat[off:off + p.numel()].copy_(old_bucket.flat[old_off[id(p)]:old_off[id(p)] + p.numel()])
+            self.optimizer.pending_hold |= {g["name"] for g in self.optimizer.param_groups
+                                            if any(id(p) not in old_off for p in g["params"] if p.requires_grad)}
+        self.assert_ranks_agree("optimizer rebuild")
 
     def _resize_per_gaussian(self, new_tensors, keep, n_new):
         """Install new per-Gaussian tensors (name -> tensor).  `keep` = bool mask over the OLD rows that survive, in order;
@@ -366,25 +469,45 @@ class TrainingMixin:
             wait()
 
     # ---- densification statistics ----------------------------------------------------------------------------------
+    @staticmethod
+    def _running_max(current, candidate):
+        """Elementwise: the candidate where it is larger, else what was there (a NaN candidate never replaces a number)."""
+        return torch.where(candidate > current, candidate, current)
+
+    @staticmethod
+    def _mean_grad(accum, denom):
+        """accum / denom with 0 where nothing was accumulated (the reference divides and then overwrites the NaNs)."""
+        return torch.where(denom > 0, accum / denom.clamp_min(1), torch.zeros_like(accum))
+
     def add_densification_stats(self, viewspace_point_tensor, update_filter):
-        """[REF scene/gaussian_model.py:755-760]"""
-        grad = torch.norm(viewspace_point_tensor.grad[update_filter, :2], dim=-1, keepdim=True)
-        self.xyz_gradient_accum[update_filter] += grad
+        """Per visible Gaussian: sum, count and maximum of the screen-space positional gradient's length
+        [REF scene/gaussian_model.py:755-760]."""
+        size = viewspace_point_tensor.grad[update_filter, :2].norm(dim=-1, keepdim=True)
+        self.xyz_gradient_accum[update_filter] += size
         self.denom[update_filter] += 1
-        cur = self.xyz_gradient_accum_max[update_filter]
-        self.xyz_gradient_accum_max[update_filter] = torch.where(grad > cur, grad, cur)
+        self.xyz_gradient_accum_max[update_filter] = self._running_max(self.xyz_gradient_accum_max[update_filter], size)
 
     def add_desification_stats_motion(self, viewspace_point_tensor, update_filter=None):
-        """[REF :762-773] (the reference's spelling)"""
-        if update_filter is None:
-            motion = torch.norm(viewspace_point_tensor, dim=-1, keepdim=True)
-            self.xyz_motion_accum_max = torch.where(motion > self.xyz_motion_accum_max, motion, self.xyz_motion_accum_max)
+        """(the reference's spelling)  Two statistics share this entry [REF scene/gaussian_model.py:762-773]: without a filter
+        the argument is a per-Gaussian displacement error (blend vs. teacher) and its length feeds the running maximum that
+        proposes new keypoints; with one it is a tensor whose .grad is a per-keypoint gradient."""
+        per_gaussian = update_filter is None
+        size = (viewspace_point_tensor if per_gaussian else viewspace_point_tensor.grad).norm(dim=-1, keepdim=True)
+        if per_gaussian:
+            self.xyz_motion_accum_max = self._running_max(self.xyz_motion_accum_max, size)
             self.motion_denom += 1
-        else:
-            grad = torch.norm(viewspace_point_tensor.grad, dim=-1, keepdim=True)
-            self.kpts_gradient_accum += grad
-            self.kpts_gradient_accum_max = torch.where(grad > self.kpts_gradient_accum_max, grad, self.kpts_gradient_accum_max)
-            self.kpts_denom += 1
+            return
+        self.kpts_gradient_accum += size
+        self.kpts_gradient_accum_max = self._running_max(self.kpts_gradient_accum_max, size)
+        self.kpts_denom += 1
+
+    def sync_teacher_stats(self):
+        """View-parallel: the teacher statistic (running maximum over every view rendered so far) becomes the maximum over the
+        ranks' views -- what the views of one `--batch` leave behind in a single process [REF scene/gaussian_model.py:274-283]."""
+        vp = self._vp_group()
+        if vp is not None:
+            import torch.distributed as tdist
+            tdist.all_reduce(self.xyz_motion_accum_max, op=tdist.ReduceOp.MAX, group=vp[0])
 
     # ---- densify / prune --------------------------------------------------------------------------------------------
     def prune_points(self, mask):
@@ -410,6 +533,7 @@ class TrainingMixin:
 
     def densify_and_clone(self, grads, grad_threshold, scene_extent):
         """[REF :696-711]"""
+        self._sync_side_stream()
         P = {k: v.detach() for k, v in self._per_gaussian().items()}
         sel = torch.norm(grads, dim=-1) >= grad_threshold
         sel = sel & (torch.exp(P["scaling"]).max(dim=1).values <= self.percent_dense * scene_extent)
@@ -418,6 +542,7 @@ class TrainingMixin:
 
     def densify_and_split(self, grads, grad_threshold, scene_extent, N=2, generator=None):
         """[REF :663-694]: the gradients are zero-padded for the rows the clone step appended."""
+        self._sync_side_stream()
         P = {k: v.detach() for k, v in self._per_gaussian().items()}
         n = P["xyz"].shape[0]
         padded = torch.zeros(n, device=P["xyz"].device)
@@ -437,14 +562,18 @@ class TrainingMixin:
 
     def densify(self, max_grad, min_opacity, extent, max_screen_size, generator=None):
         """Clone + split; NO pruning of transparent / oversized points here [REF :713-718]."""
-        grads = self.xyz_gradient_accum / self.denom
-        grads[grads.isnan()] = 0.0
+        self._sync_side_stream()                 # (the selection below READS the parameters: every slice must have landed)
+        grads = self._mean_grad(self.xyz_gradient_accum, self.denom)
+        if generator is None:                    # (view-parallel: the same seeded stream on every rank)
+            generator = self._surgery_generator()
+        self._surgery_no += 1
         n_clone = self.densify_and_clone(grads, max_grad, extent)
         n_src = self.densify_and_split(grads, max_grad, extent, generator=generator)
         return n_clone, n_src
 
     def prune(self, max_grad, min_opacity, extent, max_screen_size):
         """[REF :745-753]; runs with the LIVE max_radii2D, which a preceding densify has zeroed [REF :661]."""
+        self._sync_side_stream()
         o = torch.sigmoid(self._opacity.detach())
         mask = (o < min_opacity).squeeze(-1)
         if max_screen_size:
@@ -460,10 +589,16 @@ class TrainingMixin:
         o = torch.sigmoid(self._opacity.detach())
         new = torch.minimum(o, torch.full_like(o, 0.01))
         new = torch.log(new / (1 - new))
+        if self.optimizer is not None and self._opacity.grad is not None and self._unconsumed_gradient([self._opacity]):
+            # reference order (backward -> reset_opacity -> optimizer.step()): the reference swaps in a new tensor whose .grad is None,
+            # Adam passes over it on this iteration [REF :526-545, train.py:173-197] -- drop the gradient, hold the group once
+            self.bucket.segment(self._opacity).zero_()
+            self.optimizer.pending_hold.add("opacity")
         with torch.no_grad():
             self._opacity.copy_(new)
         if self.optimizer is not None:           # in place, on every rank its own slice (no collective, no temporaries)
             self.optimizer.zero_moments(self._opacity)
+        self.assert_ranks_agree("reset_opacity")
 
     # ---- keypoint growth -----------------------------------------------------------------------------------------------
     def new_kpts_init(self):                      # [REF :170-172]
@@ -477,6 +612,7 @@ class TrainingMixin:
     def get_new_kpts(self, mask, ratio=100):
         """Furthest-point sample of the masked Gaussians -> candidate keypoints, each with the motion feature of its
         nearest Gaussian [REF scene/gaussian_model.py:196-212]."""
+        self._sync_side_stream()
         sampling = self.get_xyz.detach()[mask].contiguous()
         if sampling.shape[0] >= 1:
             select = sampling.shape[0] // ratio if sampling.shape[0] > ratio else 1
@@ -514,35 +650,46 @@ class TrainingMixin:
         self._reset_gaussian_stats()
         self.knn_idx = None if getattr(self, "_knn_from_model", False) else self.knn_idx    # stale once K changes
 
+    # Three ways of PROPOSING keypoints (each leaves its proposal in new_xyz / new_motion_feature, None = nothing to add) ...
+    def _propose_kpts_from_hot_gaussians(self, max_grad, ratio):
+        """"down_sampling": a furthest-point sample of the Gaussians whose mean screen-space gradient exceeds the threshold."""
+        hot = self._mean_grad(self.xyz_gradient_accum, self.denom) > max_grad
+        self.get_new_kpts(hot.squeeze(-1), ratio=ratio)
+
+    def _take_existing_kpts(self, which):
+        """Copies of existing keypoints (`which`: indices or a mask), as many as there is room for."""
+        room = self._kpts_room()
+        self.new_xyz = self.super_gaussians.detach()[which][:room]
+        self.new_motion_feature = self.super_gaussians_feature.detach()[which][:room]
+
+    def _propose_kpts_dominant(self, max_grad, ratio):
+        """"gaussian_mean": for every hot Gaussian the keypoint with the largest blend weight; each such keypoint once."""
+        hot = (self._mean_grad(self.xyz_gradient_accum, self.denom) > max_grad).squeeze(-1)
+        k = self.super_gaussians.shape[0]
+        self._take_existing_kpts(self.weights_sum[hot, :k].argmax(dim=-1).unique())
+
+    def _propose_kpts_own_gradient(self, max_grad, ratio):
+        """any other mode: the keypoints whose OWN mean gradient reaches the threshold."""
+        self._take_existing_kpts((self._mean_grad(self.kpts_gradient_accum, self.kpts_denom) >= max_grad).view(-1))
+
     @torch.no_grad()
     def densify_kpts(self, max_grad, mode="gaussian_mean", ratio=100):
-        """[REF scene/gaussian_model.py:720-744]"""
-        if mode == "down_sampling":
-            grads = self.xyz_gradient_accum / self.denom
-            grads[grads.isnan()] = 0.0
-            self.get_new_kpts((grads > max_grad).squeeze(-1), ratio=ratio)
-        else:
-            if mode == "gaussian_mean":
-                grads = self.xyz_gradient_accum / self.denom
-                grads[grads.isnan()] = 0.0
-                mask = (grads > max_grad).squeeze(-1)
-                _, index = self.weights_sum[mask, :self.super_gaussians.shape[0]].max(dim=-1)
-                clone_idx = index.unique()
-            else:
-                grads = self.kpts_gradient_accum / self.kpts_denom
-                grads[grads.isnan()] = 0.0
-                clone_idx = (grads >= max_grad).view([-1])
-            clip = self._kpts_room()
-            self.new_xyz = self.super_gaussians.detach()[clone_idx][:clip]
-            self.new_motion_feature = self.super_gaussians_feature.detach()[clone_idx][:clip]
-        if self.new_xyz is not None:
-            self.densification_motion_postfix(self.new_xyz, self.new_motion_feature)
-            self.new_kpts_init()
+        """... and one adoption step: append the proposal (zero Adam moments, statistics reset), forget it
+        [REF scene/gaussian_model.py:720-744]."""
+        self._sync_side_stream()
+        propose = {"down_sampling": self._propose_kpts_from_hot_gaussians,
+                   "gaussian_mean": self._propose_kpts_dominant}.get(mode, self._propose_kpts_own_gradient)
+        propose(max_grad, ratio)
+        if self.new_xyz is None:
+            return
+        self.densification_motion_postfix(self.new_xyz, self.new_motion_feature)
+        self.new_kpts_init()
 
     @torch.no_grad()
     def set_superKeypoints(self, seed=0):
         """k-means of [xyz | motion_feature] -> K = max_points keypoints: positions = per-cluster mean of the Gaussian
         positions, features = the motion-feature part of the cluster centres [REF scene/gaussian_model.py:127-136]."""
+        self._sync_side_stream()
         xyz = self.get_xyz.detach()
         feature = torch.cat([xyz, self.motion_feature.detach()], dim=-1)
         ids, centres = kmeans(feature, int(self.args.max_points), seed=seed)
@@ -550,5 +697,7 @@ class TrainingMixin:
         sums = torch.zeros(K, 3, device=xyz.device).index_add_(0, ids, xyz)
         cnt = torch.zeros(K, device=xyz.device).index_add_(0, ids, torch.ones(xyz.shape[0], device=xyz.device))
         means = torch.where(cnt[:, None] > 0, sums / cnt[:, None].clamp_min(1), centres[:, :3])
-        self.super_gaussians_feature = nn.Parameter(centres[:, 3:].contiguous().requires_grad_(True))
-        self.super_gaussians = nn.Parameter(means.contiguous().requires_grad_(True))
+        kf, kp = centres[:, 3:].contiguous(), means.contiguous()
+        self._vp_broadcast([kp, kf])             # (index_add_ sums with float atomics on the device: rank 0's result is everyone's)
+        self.super_gaussians_feature = nn.Parameter(kf.requires_grad_(True))
+        self.super_gaussians = nn.Parameter(kp.requires_grad_(True))
