@@ -126,3 +126,82 @@ def test_fresh_gradient_buffers_take_exactly_one_direct_write():
     assert _input_sink(opa, tuple(opa.shape)) is not None
     grad_sink.forget_all()
     assert _input_sink(xyz, tuple(xyz.shape)) is None
+
+
+# ---- a loop in the REFERENCE's order: backward -> densify / reset_opacity / prune -> optimizer.step() [REF train.py:164-197] -------
+def test_reference_order_loop_updates_the_survivors_and_passes_over_the_replaced_tensors():
+    """The advisor's round-4 finding.  In the reference's order the surgery runs on a model whose gradient of this iteration has
+    not been consumed yet.  torch.optim.Adam then (a) updates every parameter that SURVIVES as an object -- the MLP, the keypoints --
+    from that gradient and (b) passes over the replaced per-Gaussian tensors (.grad None), whose step count falls one behind.
+    Rebuilding bucket + optimizer must not throw (a) away, and must not turn (b) into an update with a zero gradient (moments
+    decaying, parameters coasting on momentum)."""
+    from test_densify import _fake_adam_state, _setup
+    pc = _setup(n=40)
+    _fake_adam_state(pc, step=17)
+    mlp = list(pc.df_model.parameters())
+    # the twin: torch.optim.Adam over clones of the MLP, same state
+    twin_p = [torch.nn.Parameter(p.detach().clone()) for p in mlp]
+    twin = torch.optim.Adam([{"params": twin_p, "lr": 0.0, "name": "df_mlp"}], lr=0.0, eps=1e-15)
+    mom = pc.adam_moments()
+    for q, p in zip(twin_p, mlp):
+        twin.state[q] = {"step": torch.tensor(17.0), "exp_avg": mom[id(p)][0].clone(), "exp_avg_sq": mom[id(p)][1].clone()}
+    lr_mlp = next(g["lr"] for g in pc.optimizer.param_groups if g["name"] == "df_mlp")
+    twin.param_groups[0]["lr"] = lr_mlp
+    g = torch.Generator().manual_seed(0)
+    for p in pc.bucket.params:                             # "loss.backward()": every optimized tensor has a gradient
+        p.grad.copy_(torch.randn(p.shape, generator=g) * 1e-2)
+    for q, p in zip(twin_p, mlp):
+        q.grad = p.grad.detach().clone()
+    # ---- the reference's calls between backward and step
+    n = pc._xyz.shape[0]
+    pc.denom += 1
+    pc.xyz_gradient_accum[[1, 4, 7]] = 1.0
+    with torch.no_grad():
+        pc._scaling[[1, 4]] = float(torch.log(torch.tensor(0.2)))
+        pc._scaling[7] = float(torch.log(torch.tensor(0.01)))
+        pc._opacity[[1, 4, 7]] = 2.0
+    pc.densify(0.0002, 0.005, 5.0, None, generator=torch.Generator().manual_seed(1))
+    pc.reset_opacity()
+    pc.prune(0.0002, 0.005, 5.0, None)
+    per_g = set(pc._per_gaussian().keys())
+    assert pc.optimizer.pending_hold == per_g & {gr["name"] for gr in pc.optimizer.param_groups}
+    before = {k: v.detach().clone() for k, v in pc._per_gaussian().items()}
+    mom_before = {k: tuple(t.clone() for t in pc.adam_moments()[id(v)]) for k, v in pc._per_gaussian().items()}
+    pc.optimizer.step()                                    # train.py:196
+    pc.optimizer.zero_grad(set_to_none=True)               # train.py:197
+    twin.step()
+    # (a) the MLP took this iteration's gradient, exactly as torch.optim.Adam does
+    for q, p in zip(twin_p, mlp):
+        torch.testing.assert_close(p.detach(), q.detach(), rtol=2e-6, atol=1e-8)      # (one ulp of the parameter)
+    assert float(pc.optimizer.state[mlp[0]]["step"]) == 18.0
+    # (b) the replaced tensors: values and moments untouched, count one behind, nothing pending any more
+    for k, v in pc._per_gaussian().items():
+        assert torch.equal(v.detach(), before[k]), k
+        m, s = pc.adam_moments()[id(v)]
+        assert torch.equal(m, mom_before[k][0]) and torch.equal(s, mom_before[k][1]), k
+        assert float(pc.optimizer.state[v]["step"]) == 17.0, k
+    assert pc.optimizer.pending_hold == set() and float(pc.bucket.flat.abs().max()) == 0.0
+    assert pc.optimizer.lag == {k: 1 for k in per_g if k in {gr["name"] for gr in pc.optimizer.param_groups}}
+    # the next iteration is an ordinary one: everybody steps, the per-Gaussian groups with THEIR count (18, the MLP 19)
+    for p in pc.bucket.params:
+        p.grad.copy_(torch.randn(p.shape, generator=g) * 1e-2)
+    pc.optimizer.step()
+    assert float(pc.optimizer.state[pc._xyz]["step"]) == 18.0 and float(pc.optimizer.state[mlp[0]]["step"]) == 19.0
+    assert not torch.equal(pc._xyz.detach(), before["xyz"])
+
+
+def test_this_packages_own_order_holds_nothing_back():
+    """update first, operate afterwards (TrainStep + densify.py): no unconsumed gradient at surgery time -> nothing pending."""
+    from test_densify import _fake_adam_state, _setup
+    pc = _setup(n=40)
+    _fake_adam_state(pc, step=3)
+    g = torch.Generator().manual_seed(0)
+    for p in pc.bucket.params:
+        p.grad.copy_(torch.randn(p.shape, generator=g) * 1e-2)
+    pc.optimizer.step()                                    # consumes and zeroes
+    pc.denom += 1
+    pc.xyz_gradient_accum[:5] = 1.0
+    pc.densify(0.0002, 0.005, 5.0, None, generator=torch.Generator().manual_seed(1))
+    pc.reset_opacity()
+    pc.prune(0.0002, 0.005, 5.0, None)
+    assert pc.optimizer.pending_hold == set() and pc.optimizer.lag == {}
