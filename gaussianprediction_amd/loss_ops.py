@@ -142,10 +142,13 @@ class FusedAdam:
 
     def __init__(self, param_groups, bucket, betas=(0.9, 0.999), eps=1e-15, shard=None):
         self.param_groups = param_groups
-        names = [g.get("name") for g in param_groups]
-        if any(n is None for n in names) or len(set(names)) != len(names):
-            # the per-group step counts (`lag`), `hold` and the state-dict mapping are keyed by group name
-            raise ValueError(f"FusedAdam needs a unique, non-None 'name' on every parameter group (got {names})")
+        # the per-group step counts (`lag`), `hold` and `pending_hold` are keyed by group name: unnamed groups get one, duplicates are refused
+        for k, g in enumerate(param_groups):
+            if g.get("name") is None:
+                g["name"] = f"group{k}"
+        names = [g["name"] for g in param_groups]
+        if len(set(names)) != len(names):
+            raise ValueError(f"FusedAdam needs a unique 'name' on every parameter group (got {names})")
         self.bucket = bucket
         self.betas, self.eps = betas, eps
         self.step_count = 0

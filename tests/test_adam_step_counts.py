@@ -205,3 +205,13 @@ def test_this_packages_own_order_holds_nothing_back():
     pc.reset_opacity()
     pc.prune(0.0002, 0.005, 5.0, None)
     assert pc.optimizer.pending_hold == set() and pc.optimizer.lag == {}
+
+
+def test_group_names_are_unique_keys():
+    """`lag` / `hold` are keyed by group name (the advisor's round-4 note): unnamed groups are given one, duplicates are refused."""
+    p = [torch.nn.Parameter(torch.zeros(3)), torch.nn.Parameter(torch.zeros(4))]
+    groups = [{"params": [p[0]], "lr": 0.1}, {"params": [p[1]], "lr": 0.2}]
+    opt = FusedAdam(groups, FlatGradBucket(p))
+    assert [g["name"] for g in opt.param_groups] == ["group0", "group1"]
+    with pytest.raises(ValueError):
+        FusedAdam([{"params": [p[0]], "lr": 0.1, "name": "a"}, {"params": [p[1]], "lr": 0.2, "name": "a"}], FlatGradBucket(p))

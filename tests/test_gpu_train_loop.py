@@ -185,6 +185,18 @@ def _run_pairs(model, cams, gts, opt, args, last, world, rank, batch, log, shard
     ts.sync_params()
 
 
+def _opt_fast():
+    """Densification every 6 iterations from 6 on (three doublings fit under the cap of 7000 before iteration 38), reset at 30."""
+    return default_training_args(iterations=90, densify_from_iter=5, densification_interval=6, opacity_reset_interval=30,
+                                 densify_until_iter=38, densify_grad_threshold=1e-6, position_lr_max_steps=90)
+
+
+def _args_fast():
+    a = _args()
+    a.max_gaussian_size = 7000
+    return a
+
+
 def _new_log():
     return dict(loss=[], n=[], k=[], densify=0, prune=0, reset=0, grown=0)
 
@@ -206,7 +218,7 @@ def _rank_schedule(rank, world, port, out_dir, sharded, last):
     import torch.distributed as dist
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    args, opt = _args(), _opt()
+    args, opt = _args_fast(), _opt_fast()
     g, cams, gts = _fresh_model(args, opt)
     log = _new_log()
     _run_pairs(g, cams, gts, opt, args, last, world, rank, 1, log, sharded=sharded)
@@ -228,11 +240,11 @@ def test_two_rank_schedule_stays_rank_identical_through_surgery(tmp_path, sharde
     import socket
     import torch.multiprocessing as mp
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    last = 58
+    last = 51
     mp.spawn(_rank_schedule, args=(2, port, str(tmp_path), sharded, last), nprocs=2, join=True)
     r = [torch.load(os.path.join(tmp_path, f"sch{k}.pt"), weights_only=False) for k in range(2)]
     L = r[0]["log"]
-    assert L["densify"] >= 2 and L["prune"] >= 3 and L["reset"] >= 1 and L["grown"] >= 1, {k: L[k] for k in ("densify", "prune", "reset", "grown")}
+    assert L["densify"] >= 3 and L["prune"] >= 3 and L["reset"] >= 1 and L["grown"] >= 1, {k: L[k] for k in ("densify", "prune", "reset", "grown")}
     assert max(L["n"]) > 1500 and L["k"][-1] > 24
     assert L["n"] == r[1]["log"]["n"] and L["k"] == r[1]["log"]["k"] and r[0]["lag"] == r[1]["lag"]
     for k in r[0]["params"]:
@@ -245,7 +257,7 @@ def test_two_rank_schedule_stays_rank_identical_through_surgery(tmp_path, sharde
     # ---- the single-process --batch 2 run over the same pairs.  The kernels accumulate with atomics and Adam(eps = 1e-15) amplifies
     # the last bits, so the two trajectories are compared as two runs of ONE implementation are: the same events,
     # N within 2 % and K within 2 after every iteration, the per-step losses (sum of the two ranks' = the batch loss) within 2 %.
-    args, opt = _args(), _opt()
+    args, opt = _args_fast(), _opt_fast()
     g, cams, gts = _fresh_model(args, opt)
     one = _new_log()
     _run_pairs(g, cams, gts, opt, args, last, 1, 0, 2, one)
@@ -290,10 +302,10 @@ def test_reference_order_loop_equals_the_harness_order():
     torch.optim.Adam does with .grad None.  Checked against this package's own order (TrainStep: update with the replaced groups
     held, then operate), which is the same computation: same N after every iteration, same step counts, parameters within the
     noise of two runs."""
-    args, opt = _args(), _opt()
+    args, opt = _args_fast(), _opt_fast()
     pipe = SimpleNamespace(convert_SHs_python=False, compute_cov3D_python=False, debug=False)
     bg = torch.zeros(3, device="cuda")
-    last = 34                                           # stage 1: densify at 20 and 30, the opacity reset at 30
+    last = 34                                           # stage 1: densify at 6, 12, 18 (then the cap), prune every 6, the opacity reset at 30
     out = []
     for order in ("reference", "harness"):
         g, cams, gts = _fresh_model(args, opt)
@@ -322,7 +334,12 @@ def test_reference_order_loop_equals_the_harness_order():
     assert np.abs(np.array(ref["n"]) - np.array(har["n"])).max() <= 0.01 * max(ref["n"]), (ref["n"], har["n"])
     assert ref["lag"] == har["lag"] and ref["lag"].get("xyz", 0) >= 2 and ref["steps"] == har["steps"]
     assert np.abs(np.array(ref["loss"]) - np.array(har["loss"])).max() < 0.02
-    if ref["n"] == har["n"]:                            # (same rows: compare element for element, in units of a learning-rate step)
+    if ref["n"] == har["n"]:
+        # Same rows: compare element for element, in units of a learning-rate step.  Two runs of ONE implementation differ like this too
+        # (atomics in the backward; Adam with eps = 1e-15 turns the last bit of a near-zero gradient into up to 2 lr per step): the typical
+        # element agrees to a few percent of one step, 99 % of them to 2 steps, none by more than every step going the other way.
         for k, a in ref["params"].items():
-            lr, d = ref["lr"][k], (a - har["params"][k]).abs()
-            assert float(d.median()) <= 0.05 * lr + 1e-7 and float(d.max()) <= 4 * lr + 1e-5, (k, float(d.median()), float(d.max()), lr)
+            lr, d = ref["lr"][k], (a - har["params"][k]).abs().flatten().float()
+            q99 = float(torch.quantile(d[:1_000_000], 0.99)) if d.numel() > 1 else float(d.max())
+            assert float(d.median()) <= 0.05 * lr + 1e-7 and q99 <= 2 * lr + 1e-6 and float(d.max()) <= 2 * last * lr + 1e-5, \
+                (k, float(d.median()), q99, float(d.max()), lr)
