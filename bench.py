@@ -232,6 +232,55 @@ def _sha16(path):
     return hashlib.sha256(open(path, "rb").read()).hexdigest()[:16]
 
 
+def dense_variant(args, device, steps=20):
+    """The same scene with 1.5 x larger splats (scale 0.0045 .. 0.018: R / N at the UPPER end of SURVEY.md 8d's 4 .. 9 range, where
+    the bytes per (pixel, splat) pair fall and the composite's HBM fraction with them): set-up + warm-up as the headline, `steps`
+    timed steps, then the per-kernel pass.  Untimed as far as the headline is concerned (it runs after it)."""
+    from gaussianprediction_amd import _lib
+    from gaussianprediction_amd.rasterizer import raster_forward_debug
+    from gaussianprediction_amd.renderer import _settings
+    from gaussianprediction_amd.train_step import TrainStep
+    a2 = argparse.Namespace(**vars(args))
+    a2.scale_lo, a2.scale_hi = 1.5 * args.scale_lo, 1.5 * args.scale_hi
+    pc, cams, gts, _ = build_workload(a2, device)
+    ts = TrainStep(pc, cams, gts, a2.iteration, lrs=dict(xyz=1.6e-6 * 5.0), speculative=not args.exact_binning)
+    pre = len(cams) + TrainStep.SPEC_SLOTS + 1 + 5
+    for i in range(pre):
+        ts.step(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        ts.step(pre + i)
+    torch.cuda.synchronize()
+    ms = 1000.0 * (time.perf_counter() - t0) / steps
+    _lib.profile_enable(2)
+    _lib.profile_collect()
+    for i in range(5):
+        ts.step(pre + steps + i)
+    torch.cuda.synchronize()
+    prof = _lib.profile_collect()
+    _lib.profile_enable(0)
+    with torch.no_grad():
+        cam = cams[(pre + steps + 4) % len(cams)]
+        xyz, q, s, o = pc(torch.from_numpy(cam.time).float().to(device), a2.iteration)
+        dbg = raster_forward_debug(_settings(cam, pc, ts.bg, 1.0), xyz, o, shs=pc.get_features, scales=s, rotations=q)
+    R, n_vis = int(dbg["R"]), int((dbg["radii"] > 0).sum())
+    W, H = args.width, args.height
+    T, P = ((W + 15) // 16) * ((H + 15) // 16), W * H
+    k = {name: prof[name][1] / 5 for name in ("composite_fwd", "composite_bwd") if name in prof}
+    out = {"scale_lo": a2.scale_lo, "scale_hi": a2.scale_hi, "R": R, "R_per_gaussian": round(R / max(args.gaussians, 1), 3), "visible": n_vis,
+           "steps": steps, "ms_per_step": round(ms, 3), "frames_repeated_after_overflow": getattr(ts, "redone", 0)}
+    if "composite_fwd" in k:
+        out["composite_fwd_ms"] = round(k["composite_fwd"], 4)
+        out["composite_fwd_frac"] = round((44 * R + 8 * T + 28 * P) / (k["composite_fwd"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+    if "composite_bwd" in k:
+        out["composite_bwd_ms"] = round(k["composite_bwd"], 4)
+        out["composite_bwd_frac"] = round((44 * R + 8 * T + 24 * P + 40 * n_vis) / (k["composite_bwd"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+    del ts, pc
+    torch.cuda.empty_cache()
+    return out
+
+
 def kernel_source_stamp():
     """Identifies the composite kernels' source: a traffic figure from a PMC run is only quoted for the kernel it measured."""
     return _sha16(os.path.join(ROOT, "gaussianprediction_amd", "csrc", "raster_kernels.hip"))
@@ -252,6 +301,7 @@ def main():
     ap.add_argument("--scale_lo", type=float, default=0.003)
     ap.add_argument("--scale_hi", type=float, default=0.012)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-dense-variant", action="store_true", help="skip the 20 extra steps of the scene with 1.5 x larger splats (dense_variant)")
     ap.add_argument("--no-weights-model-step", action="store_true", help="skip the secondary measurement of the step that also "
                     "runs the per-frame hash-grid weights model + kNN")
     ap.add_argument("--exact-binning", action="store_true",
@@ -447,6 +497,9 @@ def main():
                     tj = json.load(open(tf))
                     if tj.get("kernel_source_sha16") == kernel_source_stamp():
                         roof["traffic"] = tj.get("hbm_bytes_per_launch")
+                        # (the same counters read as if every request were a 128-byte one: what the traffic could be at most if the
+                        # gather calibration of the PMC file's header did not hold)
+                        roof["traffic_upper_bound"] = tj.get("hbm_bytes_per_launch_upper_bound")
                         roof["traffic_source"] = tj.get("source")
                         vj = tj.get("valu")
                         if vj:
@@ -455,6 +508,7 @@ def main():
                             # the VALUs were, from the SQ counters of the same kernel source
                             cycles = avg_ms * 1e-3 * SHADER_CLOCK_GHZ * 1e9
                             roof["valu_floor_ms"] = round(4.0 * vj["SQ_INSTS_VALU"] / 1024.0 / (SHADER_CLOCK_GHZ * 1e9) * 1e3, 4)
+                            roof["valu_issue_frac"] = round(roof["valu_floor_ms"] / avg_ms, 4)     # the roof the kernel actually runs under
                             roof["valu_busy"] = round(min(1.0, 4.0 * vj["SQ_ACTIVE_INST_VALU"] / (1024.0 * cycles)), 3)
                             roof["valu_insts_per_launch"] = int(vj["SQ_INSTS_VALU"])
                             roof["valu_source"] = vj.get("source")
@@ -543,6 +597,11 @@ def main():
             except Exception as e:  # the baseline must never kill the bench line
                 result["cpu_baseline"] = {"value": None, "unit": "views/s", "cores": os.cpu_count(), "kind": "port",
                                           "sample": f"failed: {e}"}
+        if world == 1 and not args.render_only and not args.no_dense_variant:
+            try:
+                result["dense_variant"] = dense_variant(args, device)
+            except Exception as e:
+                result["dense_variant"] = f"failed: {e}"
         if world == 1 and not args.render_only and not args.no_weights_model_step:
             # the step the REFERENCE runs in stage 3 also evaluates the hash-grid weights model and the kNN every frame (and
             # optimizes the former) [REF scene/gaussian_model.py:257-260,402]; north_star takes their outputs as inputs, so the

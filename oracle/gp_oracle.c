@@ -426,6 +426,64 @@ int gpo_composite_fwd(int W, int H, const int32_t* ranges, const uint32_t* point
     return 0;
 }
 
+/* 3b. The same loop in the PUBLISHED form -- power = -0.5 (cx dx^2 + cz dy^2) - cy dx dy, skip power > 0,
+ *     alpha = min(0.99, opacity * exp(power)), skip alpha < 1/255, test_T = T * (1 - alpha), stop below 1e-4 -- with none of the
+ *     kernels' algebra (no log2 folding, no T - alpha T).  It exists to keep gauss_exponent() honest: the folded expression was
+ *     adopted so that the float32 oracle and the kernels make bit-identical discrete decisions, which makes the oracle follow
+ *     the kernels' algebra; this entry point is the independent statement the folded one is compared with at full size
+ *     (tests/test_oracle_published_form.py): same n_contrib and tidx on every pixel outside the ambiguity bands, same image.
+ *     `ambiguous` uses the same relative bands around the same three thresholds (+ the tidx tie). */
+int gpo_composite_fwd_published(int W, int H, const int32_t* ranges, const uint32_t* point_list, const real* xy,
+                                const real* rgb, const real* depths, const real* conic_opacity, const real* bg,
+                                real* out_color /*3,H,W*/, int32_t* out_tidx /*H,W*/, real* final_T /*H,W*/,
+                                int32_t* n_contrib /*H,W*/, uint8_t* ambiguous /*H,W or NULL*/, double band_scale) {
+    /* band_scale widens the ambiguity bands: 1 when both sides compute in one precision; the float64 run that is compared with a
+     * float32 one uses 20 (a pixel coordinate near 1000 carries 6e-5 px of float32 rounding, i.e. ~1e-4 relative on alpha) */
+    const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
+    const real bs = (real)band_scale;
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int tile = 0; tile < gx * gy; ++tile) {
+        int tx0 = (tile % gx) * TILE, ty0 = (tile / gx) * TILE;
+        int lo = ranges[2 * tile], hi = ranges[2 * tile + 1];
+        for (int py = ty0; py < ty0 + TILE && py < H; ++py)
+            for (int px = tx0; px < tx0 + TILE && px < W; ++px) {
+                real T = R(1), C[3] = {0, 0, 0}, best = 0, second = 0;
+                int32_t best_id = -1;
+                int contributor = 0, last = 0;
+                uint8_t amb = 0;
+                for (int k = lo; k < hi; ++k) {
+                    ++contributor;
+                    uint32_t id = point_list[k];
+                    real dx = xy[2 * id] - (real)px, dy = xy[2 * id + 1] - (real)py;
+                    const real* co = conic_opacity + 4 * id;
+                    real power = R(-0.5) * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
+                    if (FABSR(power) < R(1.4e-6) * bs) amb |= 1;
+                    if (power > R(0)) continue;
+                    real alpha = FMINR(R(0.99), co[3] * EXPR(power));
+                    if (FABSR(alpha * R(255) - R(1)) < R(2e-5) * bs) amb |= 1;
+                    if (alpha < R(1) / R(255)) continue;
+                    real test_T = T * (R(1) - alpha);
+                    if (FABSR(test_T * R(1e4) - R(1)) < R(1e-4) * bs) amb |= 1;
+                    if (test_T < R(0.0001)) break;
+                    real w = alpha * T;
+                    for (int c = 0; c < 3; ++c) C[c] += rgb[3 * id + c] * w;
+                    if (w > best) { second = best; best = w; best_id = (int32_t)id; }
+                    else if (w > second) second = w;
+                    T = test_T;
+                    last = contributor;
+                }
+                if (best > 0 && second > best * (R(1) - R(1e-4) * bs)) amb |= 2;
+                size_t pix = (size_t)py * W + px;
+                for (int c = 0; c < 3; ++c) out_color[c * (size_t)H * W + pix] = C[c] + T * bg[c];
+                out_tidx[pix] = best_id;
+                final_T[pix] = T;
+                n_contrib[pix] = last;
+                if (ambiguous) ambiguous[pix] = amb;
+            }
+    }
+    return 0;
+}
+
 /* ------------------------------------------------------------------------------------------- */
 /* 4. composite backward (per pixel, BACK to front replay, upstream-style recursion)            */
 /*    outputs (double accumulators, deterministic order inside a tile, atomics across tiles):   */

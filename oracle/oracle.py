@@ -129,6 +129,21 @@ class RasterOracle:
         assert rc == 0
         return s
 
+    def composite_published(self, s, band_scale=1.0):
+        """The composite of state `s` (preprocess + bin done) in the PUBLISHED form of the algorithm -- opacity * exp(power),
+        T * (1 - alpha); none of the kernels' folded algebra (gp_oracle.c section 3b).  -> dict(out_color, out_tidx, final_T,
+        n_contrib, ambiguous); `s` is left untouched.  `band_scale` widens the ambiguity bands (a float64 run compared with a float32 one)."""
+        st = s["st"]
+        W, H, dt = st.image_width, st.image_height, self.dt
+        o = dict(out_color=np.zeros((3, H, W), dt), out_tidx=np.zeros((H, W), np.int32), final_T=np.zeros((H, W), dt),
+                 n_contrib=np.zeros((H, W), np.int32), ambiguous=np.zeros((H, W), np.uint8))
+        rc = self.lib.gpo_composite_fwd_published(
+            C.c_int(W), C.c_int(H), _ptr(s["ranges"]), _ptr(s["point_list"]), _ptr(s["xy"]), _ptr(s["rgb"]), _ptr(s["depths"]),
+            _ptr(s["conic_opacity"]), _ptr(s["bg"]), _ptr(o["out_color"]), _ptr(o["out_tidx"]), _ptr(o["final_T"]),
+            _ptr(o["n_contrib"]), _ptr(o["ambiguous"]), C.c_double(band_scale))
+        assert rc == 0
+        return o
+
     def forward(self, st: RasterSettings, means3D, opacities, shs=None, colors_precomp=None, scales=None,
                 rotations=None, cov3D_precomp=None):
         """-> state dict with out_color[3,H,W], radii[N], out_depth[H,W], out_tidx[H,W] (+ saved state)."""
