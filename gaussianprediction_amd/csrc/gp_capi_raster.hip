@@ -190,7 +190,7 @@ extern "C" int gp_raster_forward(const gp_raster_settings* st, const gp_raster_i
         }
 
         if (R > 0 && counting) {
-            const size_t bin_bytes = gp_align_up((size_t)R * 4, 256) + gp_align_up((size_t)R + 4, 256);
+            const size_t bin_bytes = gp_align_up((size_t)R * 4, 256) + gp_align_up(2 * (size_t)R + 8, 256);
             void* bin = alloc(alloc_ctx, GP_BUF_BINNING, bin_bytes);
             if (!bin) GP_FAIL("allocator returned NULL for BINNING");
             point_list = (uint32_t*)bin;
@@ -202,8 +202,8 @@ extern "C" int gp_raster_forward(const gp_raster_settings* st, const gp_raster_i
             const int tbits = tile_bits_for((int)T + (capacity_mode ? 1 : 0));
             const int passes = (tbits + 7) / 8;
             const int res = passes & 1;  // buffer pair holding the sorted result
-            // BINNING = point_list[R] (u32) followed by qmask[R] (u8: which 8x8 quadrants of its tile an instance can touch)
-            const size_t bin_bytes = gp_align_up((size_t)R * 4, 256) + gp_align_up((size_t)R + 4, 256);
+            // BINNING = point_list[R] (u32) followed by smask[R] (u16: which 4x4 sub-blocks of its tile an instance can touch)
+            const size_t bin_bytes = gp_align_up((size_t)R * 4, 256) + gp_align_up(2 * (size_t)R + 8, 256);
             void* bin = alloc(alloc_ctx, GP_BUF_BINNING, bin_bytes);
             if (!bin) GP_FAIL("allocator returned NULL for BINNING");
             point_list = (uint32_t*)bin;
@@ -260,7 +260,7 @@ extern "C" int gp_raster_forward(const gp_raster_settings* st, const gp_raster_i
     { GpProfScope _p("composite_fwd", s, 1);
         hipLaunchKernelGGL((gp_debug_get(0) == 3 ? gp_composite_fwd_count_kernel : gp_debug_get(0) == 2 ? gp_composite_fwd_sbc_kernel : gp_composite_fwd_sb_kernel), dim3((unsigned)T), dim3(256), 0, s, d, il.ranges, point_list, gl.rec, st->bg,
                        out->color, out->depth, out->tidx, il.final_T, il.n_contrib, il.order, il.tile_work,
-                       point_list ? (uint8_t*)point_list + gp_align_up((size_t)R * 4, 256) : (uint8_t*)nullptr);
+                       point_list ? (uint16_t*)((uint8_t*)point_list + gp_align_up((size_t)R * 4, 256)) : (uint16_t*)nullptr);
     GP_LAUNCH_CHECK(); }
     return 0;
 }
@@ -321,8 +321,15 @@ extern "C" int gp_raster_backward(const gp_raster_settings* st, const gp_raster_
         static thread_local int ablate_set = 0;
         if (gp_debug_get(1) != ablate_set) { ablate_set = gp_debug_get(1); if (gp_bwd_set_ablate(ablate_set)) GP_FAIL("bwd ablate flag"); }
         GpProfScope _p("composite_bwd", s);
-        hipLaunchKernelGGL(dL_ddepth ? gp_composite_bwd_depth_kernel : gp_composite_bwd_kernel, dim3((unsigned)((T + 7) / 8 * 8) * GP_BWD_PARTS),
-                           dim3(64), 0, s, d, il.ranges, point_list, (const uint8_t*)point_list + gp_align_up((size_t)R * 4, 256), gl.rec,
+        // gp_debug_option(7, v): 0 = the quadrant kernel (shipped); 3 = the sub-block kernel of round 5 (4x4 culling: 1.5 evaluated pairs
+        // per contributing one instead of 3.0, and slower -- raster_kernels.hip), 2 = its counting variant
+        // (g_pair_counters[2], [3]).  The sub-block kernel packs four bits above the Gaussian id: N < GP_BWD_SB_MAX_N.
+        const int variant = gp_debug_get(7);
+        auto kern = dL_ddepth ? gp_composite_bwd_depth_kernel : gp_composite_bwd_kernel;
+        if (variant == 3 && N < (size_t)GP_BWD_SB_MAX_N) kern = dL_ddepth ? gp_composite_bwd_sb_depth_kernel : gp_composite_bwd_sb_kernel;
+        else if (variant == 2 && !dL_ddepth && N < (size_t)GP_BWD_SB_MAX_N) kern = gp_composite_bwd_sb_count_kernel;
+        hipLaunchKernelGGL(kern, dim3((unsigned)((T + 7) / 8 * 8) * GP_BWD_PARTS),
+                           dim3(64), 0, s, d, il.ranges, point_list, (const uint16_t*)((const uint8_t*)point_list + gp_align_up((size_t)R * 4, 256)), gl.rec,
                            st->bg, (const float*)fwd->color, (const float*)fwd->depth, (const float*)il.final_T,
                            (const int32_t*)il.n_contrib, dL_dcolor, dL_ddepth, g_mean2D, g_conic, g_opacity, g_color, g_depth, order_bwd);
         GP_LAUNCH_CHECK();

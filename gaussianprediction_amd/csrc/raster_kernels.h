@@ -71,7 +71,7 @@ __global__ __launch_bounds__(256) void gp_composite_fwd_sb_kernel(RasterDims d, 
                                                                   float* __restrict__ out_depth,
                                                                   int32_t* __restrict__ out_tidx,
                                                                   float* __restrict__ final_T,
-                                                                  int32_t* __restrict__ n_contrib, const uint32_t* __restrict__ order, int32_t* __restrict__ tile_work, uint8_t* __restrict__ qmask);
+                                                                  int32_t* __restrict__ n_contrib, const uint32_t* __restrict__ order, int32_t* __restrict__ tile_work, uint16_t* __restrict__ smask);
 
 // heavy-first launch order: bucket of a tile by a 2-mantissa-bit logarithm of its work (0 = heaviest ... 127 = no work)
 __device__ __forceinline__ int gp_tile_bucket(int w) {
@@ -91,7 +91,7 @@ __global__ __launch_bounds__(256) void gp_composite_fwd_count_kernel(RasterDims 
                                                                   float* __restrict__ out_depth,
                                                                   int32_t* __restrict__ out_tidx,
                                                                   float* __restrict__ final_T,
-                                                                  int32_t* __restrict__ n_contrib, const uint32_t* __restrict__ order, int32_t* __restrict__ tile_work, uint8_t* __restrict__ qmask);
+                                                                  int32_t* __restrict__ n_contrib, const uint32_t* __restrict__ order, int32_t* __restrict__ tile_work, uint16_t* __restrict__ smask);
 
 __global__ __launch_bounds__(256) void gp_composite_fwd_sbc_kernel(RasterDims d, const int2* __restrict__ ranges,
                                                                   const uint32_t* __restrict__ point_list,
@@ -101,12 +101,17 @@ __global__ __launch_bounds__(256) void gp_composite_fwd_sbc_kernel(RasterDims d,
                                                                   float* __restrict__ out_depth,
                                                                   int32_t* __restrict__ out_tidx,
                                                                   float* __restrict__ final_T,
-                                                                  int32_t* __restrict__ n_contrib, const uint32_t* __restrict__ order, int32_t* __restrict__ tile_work, uint8_t* __restrict__ qmask);
+                                                                  int32_t* __restrict__ n_contrib, const uint32_t* __restrict__ order, int32_t* __restrict__ tile_work, uint16_t* __restrict__ smask);
 
 #define GP_CB_ARGS RasterDims d, const int2* __restrict__ ranges, const uint32_t* __restrict__ point_list, \
-    const uint8_t* __restrict__ qmask, const float4* __restrict__ rec, const float* __restrict__ bg, const float* __restrict__ out_color, \
+    const uint16_t* __restrict__ smask, const float4* __restrict__ rec, const float* __restrict__ bg, const float* __restrict__ out_color, \
     const float* __restrict__ out_depth, const float* __restrict__ final_T, const int32_t* __restrict__ n_contrib, \
     const float* __restrict__ dL_dpix, const float* __restrict__ dL_dpixdepth, float* __restrict__ g_mean2D, float* __restrict__ g_conic, \
     float* __restrict__ g_opacity, float* __restrict__ g_color, float* __restrict__ g_depth, const uint32_t* __restrict__ order
 __global__ __launch_bounds__(64) void gp_composite_bwd_kernel(GP_CB_ARGS);
 __global__ __launch_bounds__(64) void gp_composite_bwd_depth_kernel(GP_CB_ARGS);
+// round 5: 16-lane groups walk the quadrant's four 4x4 sub-blocks (an A/B variant, gp_debug_option(7, 3): measured slower than the two above)
+__global__ __launch_bounds__(64) void gp_composite_bwd_sb_kernel(GP_CB_ARGS);
+__global__ __launch_bounds__(64) void gp_composite_bwd_sb_depth_kernel(GP_CB_ARGS);
+__global__ __launch_bounds__(64) void gp_composite_bwd_sb_count_kernel(GP_CB_ARGS);
+#define GP_BWD_SB_MAX_N (1 << 28)      // the sub-block kernel packs its 4 sub-block bits above the Gaussian id

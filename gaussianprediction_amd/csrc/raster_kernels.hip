@@ -660,7 +660,7 @@ __device__ __forceinline__ void gp_composite_fwd_sb_body(RasterDims d, const int
                                                                          int32_t* __restrict__ n_contrib,
                                                                          const uint32_t* __restrict__ order,
                                                                          int32_t* __restrict__ tile_work,
-                                                                         uint8_t* __restrict__ qmask) {
+                                                                         uint16_t* __restrict__ smask) {
     __shared__ __attribute__((aligned(16))) unsigned char s_rec[CF_THREADS * CF2_REC];
     __shared__ unsigned short s_list[16][CF_THREADS];    // per SB: byte offsets of the batch's records that touch it, in depth order
     __shared__ int s_cnt[4][16];                         // [staging wave][SB]
@@ -710,7 +710,7 @@ __device__ __forceinline__ void gp_composite_fwd_sb_body(RasterDims d, const int
             dst[1] = make_float4(q1.x, q1.y, q2.x, q2.y);
             *(float2*)(dst + 2) = make_float2(q2.z, q1.z);
             rel = gp_sb_mask(q0, q1, X0, Y0);
-            qmask[k] = (uint8_t)(((rel & 0x0033u) ? 1u : 0u) | ((rel & 0x00CCu) ? 2u : 0u) | ((rel & 0x3300u) ? 4u : 0u) | ((rel & 0xCC00u) ? 8u : 0u));
+            smask[k] = (uint16_t)rel;           // saved for the backward: which 4x4 sub-blocks of its tile the instance can touch
         }
         unsigned long long bal[16];
         int mycnt = 0;
@@ -961,15 +961,15 @@ __device__ __forceinline__ void gp_composite_fwd_sb_body(RasterDims d, const int
 #define CF2_ARGS RasterDims d, const int2* __restrict__ ranges, const uint32_t* __restrict__ point_list, const float4* __restrict__ rec, \
     const float* __restrict__ bg, float* __restrict__ out_color, float* __restrict__ out_depth, int32_t* __restrict__ out_tidx, \
     float* __restrict__ final_T, int32_t* __restrict__ n_contrib, const uint32_t* __restrict__ order, int32_t* __restrict__ tile_work, \
-    uint8_t* __restrict__ qmask
+    uint16_t* __restrict__ smask
 __global__ __launch_bounds__(CF_THREADS) void gp_composite_fwd_sb_kernel(CF2_ARGS) {
-    gp_composite_fwd_sb_body<1>(d, ranges, point_list, rec, bg, out_color, out_depth, out_tidx, final_T, n_contrib, order, tile_work, qmask);
+    gp_composite_fwd_sb_body<1>(d, ranges, point_list, rec, bg, out_color, out_depth, out_tidx, final_T, n_contrib, order, tile_work, smask);
 }
 __global__ __launch_bounds__(CF_THREADS) void gp_composite_fwd_sbc_kernel(CF2_ARGS) {   // compiler-scheduled inner loop (A/B reference)
-    gp_composite_fwd_sb_body<0>(d, ranges, point_list, rec, bg, out_color, out_depth, out_tidx, final_T, n_contrib, order, tile_work, qmask);
+    gp_composite_fwd_sb_body<0>(d, ranges, point_list, rec, bg, out_color, out_depth, out_tidx, final_T, n_contrib, order, tile_work, smask);
 }
 __global__ __launch_bounds__(CF_THREADS) void gp_composite_fwd_count_kernel(CF2_ARGS) {   // ... + pair counters (gp_debug_option(0, 3))
-    gp_composite_fwd_sb_body<2>(d, ranges, point_list, rec, bg, out_color, out_depth, out_tidx, final_T, n_contrib, order, tile_work, qmask);
+    gp_composite_fwd_sb_body<2>(d, ranges, point_list, rec, bg, out_color, out_depth, out_tidx, final_T, n_contrib, order, tile_work, smask);
 }
 int gp_pair_counters_read(unsigned long long* out4) {
     if (hipDeviceSynchronize() != hipSuccess) return 1;
@@ -1089,7 +1089,7 @@ int gp_bwd_set_ablate(int v) { return hipMemcpyToSymbol(HIP_SYMBOL(g_bwd_ablate)
 
 template <bool HAS_DEPTH, int ROWS, int COLS>
 __device__ __forceinline__ void gp_composite_bwd_body(RasterDims d, const int2* __restrict__ ranges,
-                                                       const uint32_t* __restrict__ point_list, const uint8_t* __restrict__ qmask,
+                                                       const uint32_t* __restrict__ point_list, const uint16_t* __restrict__ smask,
                                                        const float4* __restrict__ rec, const float* __restrict__ bg,
                                                        const float* __restrict__ out_color, const float* __restrict__ out_depth,
                                                        const float* __restrict__ final_T, const int32_t* __restrict__ n_contrib,
@@ -1143,7 +1143,8 @@ __device__ __forceinline__ void gp_composite_bwd_body(RasterDims d, const int2* 
     // (qmask): a refill reads 256 mask bytes + ids with two coalesced loads, keeps the instances of THIS part
     // (stable, so depth order is kept) and appends (list position, id) to a queue.  Records are gathered only
     // for queued instances, one batch ahead of the pixel walk.
-    static_assert(ROWS == 8 && COLS == 8, "qmask bits are 8x8 quadrants");
+    static_assert(ROWS == 8 && COLS == 8, "parts are the 8x8 quadrants: four sub-block bits of the saved 16-bit mask each");
+    const uint32_t quad_bits = 0x33u << (8 * (part >> 1) + 2 * (part & 1));
     constexpr int QCAP = 448;
     __shared__ int2 s_q[QCAP];            // (list position, gaussian id)
     __shared__ float4 s_fl[3][64];        // flush staging
@@ -1156,7 +1157,7 @@ __device__ __forceinline__ void gp_composite_bwd_body(RasterDims d, const int2* 
         for (int e = 0; e < 4; ++e) {
             const int k = src + 64 * e + lane;
             const int kk = range.x + (k < count ? k : count - 1);       // clamped (count > 0 here)
-            qm[e] = qmask[kk];
+            qm[e] = smask[kk];
             ids[e] = point_list[kk];
         }
         // pinned: the eight loads leave together and are waited for once (as conditional loads each (mask, id) pair was waited for
@@ -1165,7 +1166,7 @@ __device__ __forceinline__ void gp_composite_bwd_body(RasterDims d, const int2* 
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int k = src + 64 * e + lane;
-            r[e] = k < count && ((qm[e] >> part) & 1u);
+            r[e] = k < count && (qm[e] & quad_bits) != 0u;
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -1441,16 +1442,342 @@ __device__ __forceinline__ void gp_composite_bwd_body(RasterDims d, const int2* 
     }
 }
 #define CB_ARGS RasterDims d, const int2* __restrict__ ranges, const uint32_t* __restrict__ point_list, \
-    const uint8_t* __restrict__ qmask, const float4* __restrict__ rec, const float* __restrict__ bg, const float* __restrict__ out_color, \
+    const uint16_t* __restrict__ smask, const float4* __restrict__ rec, const float* __restrict__ bg, const float* __restrict__ out_color, \
     const float* __restrict__ out_depth, const float* __restrict__ final_T, const int32_t* __restrict__ n_contrib, \
     const float* __restrict__ dL_dpix, const float* __restrict__ dL_dpixdepth, float* __restrict__ g_mean2D, \
     float* __restrict__ g_conic, float* __restrict__ g_opacity, float* __restrict__ g_color, float* __restrict__ g_depth, \
     const uint32_t* __restrict__ order
 __global__ __launch_bounds__(64) void gp_composite_bwd_kernel(CB_ARGS) {
-    gp_composite_bwd_body<false, GP_BWD_ROWS, GP_BWD_COLS>(d, ranges, point_list, qmask, rec, bg, out_color, out_depth, final_T, n_contrib, dL_dpix, dL_dpixdepth, g_mean2D, g_conic, g_opacity, g_color, g_depth, order);
+    gp_composite_bwd_body<false, GP_BWD_ROWS, GP_BWD_COLS>(d, ranges, point_list, smask, rec, bg, out_color, out_depth, final_T, n_contrib, dL_dpix, dL_dpixdepth, g_mean2D, g_conic, g_opacity, g_color, g_depth, order);
 }
 __global__ __launch_bounds__(64) void gp_composite_bwd_depth_kernel(CB_ARGS) {
-    gp_composite_bwd_body<true, GP_BWD_ROWS, GP_BWD_COLS>(d, ranges, point_list, qmask, rec, bg, out_color, out_depth, final_T, n_contrib, dL_dpix, dL_dpixdepth, g_mean2D, g_conic, g_opacity, g_color, g_depth, order);
+    gp_composite_bwd_body<true, GP_BWD_ROWS, GP_BWD_COLS>(d, ranges, point_list, smask, rec, bg, out_color, out_depth, final_T, n_contrib, dL_dpix, dL_dpixdepth, g_mean2D, g_conic, g_opacity, g_color, g_depth, order);
+}
+
+// ------------------------------------------------------------------------------------------------
+// composite backward, SUB-BLOCK groups (round 5).  AN EXPERIMENT, NOT SHIPPED: gp_debug_option(7, 3) selects it, the quadrant kernel
+// above stays the default.  Same wave geometry -- one wave per (tile, 8x8 quadrant), the same queue of the quadrant's instances, the
+// same per-pixel state in LDS -- but the walk is culled at 4x4:
+//
+//   the forward saves the 16-bit sub-block mask of every instance (which 4x4 blocks of its tile its alpha >= 1/255 footprint can
+//   reach; the quadrant kernel keeps an instance if it reaches any of the quadrant's four blocks, and then walks ALL 64 pixels with it:
+//   3.0 evaluated (pixel, splat) pairs per contributing one at configs[2], because an instance that reaches a quadrant reaches on
+//   average two of its four blocks).  Here a batch of 64 queued instances is split into FOUR lists, one per sub-block, and the wave's
+//   four DPP rows (16 lanes each) walk one sub-block each: row r takes the next 16 entries of list r into its lanes and steps through
+//   the 8 pixel pairs of ITS 4x4 block, with the scans running inside the row (row_shr 1 / 2 / 4 / 8: four DPP stages instead of
+//   six).  A batch costs max_r ceil(n_r / 16) rounds of 8 steps instead of 32 steps.  Records are staged once per batch in LDS (the
+//   lanes of a round pick theirs by list entry).  The queue entry carries the instance's four sub-block bits above the Gaussian id
+//   (N < 2^28: GP_BWD_SB_MAX_N, checked by the host).
+//
+// What it measured (configs[2], profiles/r05_bwd_subblock_ab.txt; gradients equal to the quadrant kernel's to 7e-7 rel-L2):
+//   * evaluated / contributing pairs 3.0 -> 1.51 (counting variant, g_pair_counters[2], [3]): the culling works;
+//   * vector instructions 122.6 M -> 107.2 M only: the lists are SHORT (a quadrant's batch of 64 gives ~33 entries per sub-block =
+//     3 rounds of 16 where 2.05 would do, and the wave runs the longest of its four lists): 24 steps per batch instead of 32, plus
+//     the per-round staging;
+//   * the sums of a (splat, sub-block) have to meet the splat's other sub-blocks' before they leave, or leave on their own:
+//       - gathered in LDS with ds_add_f32: an LDS float atomic costs ~190 cycles per wave instruction here -- 1 700 LDS cycles per
+//         round against 2 400 of arithmetic: 0.48 ms;
+//       - flushed per round (the form below): 3 x the global atomic instructions of the quadrant kernel, and the texture-address
+//         path retires roughly ONE atomic lane per cycle and CU -- 2.4 M wave-atomics = 0.25 ms of that unit: 0.40 ms with them,
+//         0.219 ms with the atomics ablated (quadrant kernel: 0.243 / 0.231).
+//   With a non-atomic four-phase read-modify-write in LDS and a hand-scheduled step the estimate is ~0.21 ms against 0.243: not
+//   enough for a second hand-written walk in the tree.  Kept selectable so the numbers above can be reproduced.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void dpp_rowscan2_add(float& a, float& b) {
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %1, %1, %1 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 0\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %1, %1, %1 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 0\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %1, %1, %1 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 0\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %1, %1, %1 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1"
+        : "+v"(a), "+v"(b));
+}
+__device__ __forceinline__ void dpp_rowscan2_mul(float& a, float& b) {
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_mul_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+        "v_mul_f32_dpp %1, %1, %1 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 0\n\t"
+        "v_mul_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+        "v_mul_f32_dpp %1, %1, %1 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 0\n\t"
+        "v_mul_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+        "v_mul_f32_dpp %1, %1, %1 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 0\n\t"
+        "v_mul_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_mul_f32_dpp %1, %1, %1 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1"
+        : "+v"(a), "+v"(b));
+}
+
+// (MODE 1 of the kernel below) pairs the backward evaluates / that contribute, as the forward's counters: g_pair_counters[2], [3]
+template <bool HAS_DEPTH, int MODE>     // MODE 0: shipped  1: + pair counters (diagnostics)
+__device__ __forceinline__ void gp_composite_bwd_sb_body(RasterDims d, const int2* __restrict__ ranges,
+                                                          const uint32_t* __restrict__ point_list, const uint16_t* __restrict__ smask,
+                                                          const float4* __restrict__ rec, const float* __restrict__ bg,
+                                                          const float* __restrict__ out_color, const float* __restrict__ out_depth,
+                                                          const float* __restrict__ final_T, const int32_t* __restrict__ n_contrib,
+                                                          const float* __restrict__ dL_dpix, const float* __restrict__ dL_dpixdepth,
+                                                          float* __restrict__ g_mean2D, const uint32_t* __restrict__ order) {
+    constexpr int PAIRS = 32;                            // pair index = sub-block (0..3) * 8 + pixel row (0..3) * 2 + column pair (0..1)
+    constexpr int QCAP = 192;                            // (<= 63 queued + one refill of 128 candidates)
+    // per pixel pair, 64 B, as the quadrant kernel: [0] n_contrib0 n_contrib1 - -  [1] dLr0 dLr1 dLg0 dLg1  [2] dLb0 dLb1 tb0 tb1
+    //                                               [3] Tin0 Tin1 rem0 rem1 (carried from round to round)
+    // The four rows read FOUR different pairs in one instruction: a row's eight pairs are 33 float4 apart (528 B), which puts the rows'
+    // 16-byte reads on four different bank groups (at 512 B -- the natural stride -- every read was a 4-way bank conflict: the first
+    // version of this kernel spent 2.3 x the quadrant kernel's time waiting for LDS).
+    constexpr int RS = 33;                               // float4 per row of pairs
+    __shared__ float4 s_ppf[4 * RS];
+    __shared__ float2 s_dd[HAS_DEPTH ? 4 * 9 : 1];       // (row stride 9 float2 = 72 B)
+#define SPP(pr, j) s_ppf[((pr) >> 3) * RS + ((pr) & 7) * 4 + (j)]
+#define SDD(pr) s_dd[((pr) >> 3) * 9 + ((pr) & 7)]
+    __shared__ int2 s_q[QCAP];                           // queue of the quadrant's instances: (list position, id | sub-block bits << 28)
+    __shared__ float4 s_rec[64][3];                      // the batch's records: (x y A' B') (C' lop r g) (b depth pos -)
+    __shared__ unsigned char s_rl[4][64];                // per sub-block: the batch lanes whose instance reaches it, in depth order
+    __shared__ uint32_t s_gid[64];                       // the batch's Gaussian ids
+    __shared__ float s_fl[10][64];                       // flush staging (per ROUND: a first version gathered a splat's sums from its
+    __shared__ uint32_t s_flid[64];                      // up to four rounds in LDS with ds_add_f32 -- ~190 cycles per wave instruction,
+                                                         // 1 700 LDS cycles per round against 2 400 of arithmetic: the kernel ran at 0.48 ms)
+    const int xcd = blockIdx.x & 7, jw = blockIdx.x >> 3;
+    const int slot_t = (jw >> 2) * 8 + xcd;
+    const int part = jw & 3;
+    if (slot_t >= d.gx * d.gy) return;
+    const int tile = __builtin_amdgcn_readfirstlane(order ? (int)order[slot_t] : slot_t);
+    const int tx = tile % d.gx, ty = tile / d.gx;
+    const int lane = threadIdx.x;
+    const int row = lane >> 4, li = lane & 15;
+    const int2 range = ranges[tile];
+    const int qx = tx * GP_TILE + (part & 1) * 8, qy = ty * GP_TILE + (part >> 1) * 8;
+    int max_nc = 0;
+    if (lane < PAIRS) {
+        const int r = lane >> 3, y = (lane >> 1) & 3, cp = lane & 1;
+        float4 me[4];
+        gp_pixpair(d, qx + (r & 1) * 4 + 2 * cp, qy + (r >> 1) * 4 + y, bg[0], bg[1], bg[2], out_color, out_depth, final_T, n_contrib, dL_dpix,
+                   HAS_DEPTH ? dL_dpixdepth : nullptr, me);
+        const float4 t0 = me[0], t1 = me[1], t = me[2];
+        SPP(lane, 1) = t0; SPP(lane, 2) = t1;
+        SPP(lane, 0) = make_float4(t.x, t.y, 0.f, 0.f);
+        if (HAS_DEPTH) { const float4 t3 = me[3]; SDD(lane) = make_float2(t3.x, t3.y); }
+        SPP(lane, 3) = make_float4(1.f, 1.f, t.z, t.w);
+        max_nc = max(__float_as_int(t.x), __float_as_int(t.y));
+    }
+#pragma unroll
+    for (int dd = 32; dd >= 1; dd >>= 1) max_nc = max(max_nc, __shfl_xor(max_nc, dd));
+    __builtin_amdgcn_wave_barrier();
+    const float halfW = 0.5f * (float)d.W, halfH = 0.5f * (float)d.H;
+    const int ablate = g_bwd_ablate;
+    const int count = min(range.y - range.x, max_nc);
+    const int shift = 8 * (part >> 1) + 2 * (part & 1);          // bit of the quadrant's first sub-block in the 16-bit mask
+    const float pxs = (float)(qx + (row & 1) * 4), pys = (float)(qy + (row >> 1) * 4);   // this ROW's sub-block origin
+    int qn = 0, src = 0;
+    auto refill = [&]() {   // candidates src + 64 e + lane, e = 0, 1: coalesced loads of the masks and ids
+        bool r[2];
+        uint32_t ids[2], qm[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int k = src + 64 * e + lane;
+            const int kk = range.x + (k < count ? k : count - 1);
+            qm[e] = smask[kk];
+            ids[e] = point_list[kk];
+        }
+        asm volatile("" ::"v"(qm[0]), "v"(qm[1]), "v"(ids[0]), "v"(ids[1]));
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int k = src + 64 * e + lane;
+            const uint32_t t = qm[e] >> shift;                   // bits 0, 1: upper two sub-blocks; bits 4, 5: lower two
+            qm[e] = (t & 3u) | ((t >> 2) & 12u);
+            r[e] = k < count && qm[e] != 0u;
+        }
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const unsigned long long bal = __ballot(r[e]);
+            if (r[e]) s_q[qn + (int)gp_mbcnt(bal)] = make_int2(src + 64 * e + lane, (int)(ids[e] | (qm[e] << 28)));
+            qn += (int)__popcll(bal);
+        }
+        src += 128;
+    };
+    while (qn < 64 && src < count) refill();
+    __builtin_amdgcn_wave_barrier();
+    float4 n0 = make_float4(0.f, 0.f, 0.f, 0.f), n1 = n0, n2 = n0;
+    int2 ne = make_int2(0x7fffffff, 0);
+    if (lane < qn) {
+        ne = s_q[lane];
+        const size_t gid = (size_t)((uint32_t)ne.y & 0x0FFFFFFFu);
+        n0 = rec[3 * gid]; n1 = rec[3 * gid + 1]; n2 = rec[3 * gid + 2];
+    }
+    auto fma2 = [](v2f a, v2f b, v2f c) { return (v2f){fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y)}; };
+    unsigned n_eval = 0, n_contr = 0;
+    while (qn > 0) {
+        const int nb = min(64, qn);
+        const bool have = lane < nb;
+        const uint32_t idm = (uint32_t)ne.y;
+        const uint32_t id = idm & 0x0FFFFFFFu;
+        const uint32_t m4 = have ? idm >> 28 : 0u;
+        const float4 q0 = n0, q1 = n1, q2 = n2;
+        // ---- stage the batch: records, zeroed accumulators, the four sub-block lists
+        s_rec[lane][0] = q0;
+        s_rec[lane][1] = make_float4(q1.x, q1.y, q2.x, q2.y);
+        s_rec[lane][2] = make_float4(q2.z, q1.z, __int_as_float(have ? ne.x : 0x7fffffff), q2.w);
+        s_gid[lane] = id;
+        int nr0, nr1, nr2, nr3;
+        {
+            const unsigned long long b0 = __ballot((m4 & 1u) != 0u), b1 = __ballot((m4 & 2u) != 0u), b2 = __ballot((m4 & 4u) != 0u),
+                                     b3 = __ballot((m4 & 8u) != 0u);
+            if (m4 & 1u) s_rl[0][gp_mbcnt(b0)] = (unsigned char)lane;
+            if (m4 & 2u) s_rl[1][gp_mbcnt(b1)] = (unsigned char)lane;
+            if (m4 & 4u) s_rl[2][gp_mbcnt(b2)] = (unsigned char)lane;
+            if (m4 & 8u) s_rl[3][gp_mbcnt(b3)] = (unsigned char)lane;
+            nr0 = (int)__popcll(b0); nr1 = (int)__popcll(b1); nr2 = (int)__popcll(b2); nr3 = (int)__popcll(b3);
+        }
+        {   // pop the batch, top the queue up, start fetching the next batch's records
+            int2 mv[2];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) mv[e] = (64 + e * 64 + lane < qn) ? s_q[64 + e * 64 + lane] : make_int2(0, 0);
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int e = 0; e < 2; ++e) if (64 + e * 64 + lane < qn) s_q[e * 64 + lane] = mv[e];
+            qn -= nb;
+            __builtin_amdgcn_wave_barrier();
+            while (qn < 64 && src < count) refill();
+            __builtin_amdgcn_wave_barrier();
+            n0 = make_float4(0.f, 0.f, 0.f, 0.f); n1 = n0; n2 = n0;
+            ne = make_int2(0x7fffffff, 0);
+            if (lane < qn) {
+                ne = s_q[lane];
+                const size_t gid = (size_t)((uint32_t)ne.y & 0x0FFFFFFFu);
+                n0 = rec[3 * gid]; n1 = rec[3 * gid + 1]; n2 = rec[3 * gid + 2];
+            }
+        }
+        const int n_mine = row == 0 ? nr0 : (row == 1 ? nr1 : (row == 2 ? nr2 : nr3));
+        const int rounds = (ablate & 2) ? 0 : (max(max(nr0, nr1), max(nr2, nr3)) + 15) >> 4;
+#pragma unroll 1
+        for (int k = 0; k < rounds; ++k) {
+            const int sl = 16 * k + li;
+            const bool act = sl < n_mine;
+            const int idx = act ? (int)s_rl[row][sl] : 0;
+            const float4 r0 = s_rec[idx][0], r1 = s_rec[idx][1], r2 = s_rec[idx][2];
+            // alpha is recomputed with the FORWARD's expression tree, bit for bit (see the quadrant kernel above)
+            const float As = r0.z, Bs = r0.w, Cs = r1.x;
+            const float lop = act ? r1.y : -INFINITY, zdep = r2.y;
+            const int pos = act ? __float_as_int(r2.z) : 0x7fffffff;
+            const v2f cr = {r1.z, r1.z}, cg = {r1.w, r1.w}, cb = {r2.x, r2.x};
+            v2f a_op = {0.f, 0.f}, a_r = {0.f, 0.f}, a_g = {0.f, 0.f}, a_b = {0.f, 0.f}, a_d = {0.f, 0.f}, s_xx = {0.f, 0.f};
+            float S_x = 0.f, S_y = 0.f, S_xy = 0.f, S_yy = 0.f, any_m = 0.f;
+            const v2f dxs[2] = {(v2f){r0.x - pxs, r0.x - (pxs + 1.f)}, (v2f){r0.x - (pxs + 2.f), r0.x - (pxs + 3.f)}};
+#pragma unroll
+            for (int y = 0; y < 4; ++y) {
+                const float dy = r0.y - (pys + (float)y);
+                const float tB = Bs * dy, uC = fmaf(Cs * dy, dy, lop);
+                v2f r_h = {0.f, 0.f}, r_hx = {0.f, 0.f};
+#pragma unroll
+                for (int cp = 0; cp < 2; ++cp) {
+                    const int pr = row * 8 + y * 2 + cp;
+                    const float4 ncf = SPP(pr, 0);
+                    const int ncx = __float_as_int(ncf.x), ncy = __float_as_int(ncf.y);
+                    const float4 v0 = SPP(pr, 1), v1 = SPP(pr, 2), cy = SPP(pr, 3);
+                    float2 v3 = make_float2(0.f, 0.f);
+                    if (HAS_DEPTH) v3 = SDD(pr);
+                    const v2f dx = dxs[cp];
+                    const v2f pw = {fmaf(dx.x, fmaf(As, dx.x, tB), uC), fmaf(dx.y, fmaf(As, dx.y, tB), uC)};
+                    const v2f E = {__builtin_amdgcn_exp2f(pw.x), __builtin_amdgcn_exp2f(pw.y)};
+                    if (MODE == 1 && act) n_eval += (pos < ncx) + (pos < ncy);
+                    const bool c0 = (pos < ncx) && !(pw.x > lop) && !(E.x < 1.f / 255.f);
+                    const bool c1 = (pos < ncy) && !(pw.y > lop) && !(E.y < 1.f / 255.f);
+                    if (__builtin_amdgcn_ballot_w64(c0 || c1) != 0ull) {      // otherwise no row has anything to do at its pixel pair
+                        if (MODE == 1) n_contr += (unsigned)c0 + (unsigned)c1;
+                        const v2f Em = {c0 ? E.x : 0.f, c1 ? E.y : 0.f};
+                        const v2f am = {fminf(0.99f, Em.x), fminf(0.99f, Em.y)};
+                        any_m = fmaxf(any_m, fmaxf(am.x, am.y));
+                        const v2f om = 1.f - am;
+                        v2f cdot = cb * (v2f){v1.x, v1.y};
+                        cdot = fma2(cg, (v2f){v0.z, v0.w}, cdot);
+                        cdot = fma2(cr, (v2f){v0.x, v0.y}, cdot);
+                        v2f dLd = {0.f, 0.f};
+                        if (HAS_DEPTH) { dLd.x = v3.x; dLd.y = v3.y; cdot = fma2((v2f){zdep, zdep}, dLd, cdot); }
+                        const v2f rom = {__builtin_amdgcn_rcpf(om.x), __builtin_amdgcn_rcpf(om.y)};
+                        float il0 = om.x, il1 = om.y;
+                        dpp_rowscan2_mul(il0, il1);                             // product over the ROW's splats up to and including this one
+                        const v2f Tnext = (v2f){cy.x, cy.y} * (v2f){il0, il1};
+                        const v2f Tj = Tnext * rom;
+                        const v2f w = am * Tj;
+                        const v2f sv = w * cdot;
+                        float is0 = sv.x, is1 = sv.y;
+                        dpp_rowscan2_add(is0, is1);
+                        const v2f rem = {cy.z, cy.w};
+                        const v2f tbv = {v1.z, v1.w};
+                        const v2f suffix = rem - (v2f){is0, is1};
+                        const v2f dL_dalpha = fma2(Tj, cdot, -((suffix + tbv) * rom));
+                        a_r = fma2(w, (v2f){v0.x, v0.y}, a_r);
+                        a_g = fma2(w, (v2f){v0.z, v0.w}, a_g);
+                        a_b = fma2(w, (v2f){v1.x, v1.y}, a_b);
+                        if (HAS_DEPTH) a_d = fma2(w, dLd, a_d);
+                        const v2f h = Em * dL_dalpha;
+                        a_op += h;
+                        const v2f hx = h * dx;
+                        r_h += h;
+                        r_hx += hx;
+                        s_xx = fma2(hx, dx, s_xx);
+                        if (li == 15) SPP(pr, 3) = make_float4(Tnext.x, Tnext.y, cy.z - is0, cy.w - is1);     // the row's carry
+                    }
+                }
+                const float rh = r_h.x + r_h.y, rhx = r_hx.x + r_hx.y;
+                S_x += rhx;
+                S_y = fmaf(dy, rh, S_y);
+                S_xy = fmaf(dy, rhx, S_xy);
+                S_yy = fmaf(dy * dy, rh, S_yy);
+            }
+            // ---- flush of the round: 16 consecutive lanes add to the 16 consecutive floats of ONE Gaussian's accumulator line (as the
+            // quadrant kernel; a splat that reaches several sub-blocks is flushed once per sub-block)
+            {
+                const bool mine = act && any_m > 0.f;
+                const float LN2 = 0.6931471805599453f;
+                const float cxx = -2.f * LN2 * As, cxy = -LN2 * Bs, cyy = -2.f * LN2 * Cs;
+                const float S_xx = s_xx.x + s_xx.y;
+                s_fl[0][lane] = -(cxx * S_x + cxy * S_y) * halfW; s_fl[1][lane] = -(cyy * S_y + cxy * S_x) * halfH;
+                s_fl[2][lane] = -0.5f * S_xx; s_fl[3][lane] = -S_xy; s_fl[4][lane] = -0.5f * S_yy;
+                s_fl[5][lane] = mine ? (a_op.x + a_op.y) / r2.w : 0.f;
+                s_fl[6][lane] = a_r.x + a_r.y; s_fl[7][lane] = a_g.x + a_g.y; s_fl[8][lane] = a_b.x + a_b.y;
+                if (HAS_DEPTH) s_fl[9][lane] = a_d.x + a_d.y;
+                s_flid[lane] = mine ? s_gid[idx] : 0xffffffffu;
+                __builtin_amdgcn_wave_barrier();
+                const int comp = lane & 15, sub = lane >> 4;
+                if (comp < (HAS_DEPTH ? 10 : 9)) {
+                    const float* src_c = &s_fl[comp][0];
+#pragma unroll 4
+                    for (int r = 0; r < 16; ++r) {
+                        const int sp = r * 4 + sub;
+                        const uint32_t gid = s_flid[sp];
+                        if (gid != 0xffffffffu && !(ablate & 1)) atomicAdd(&g_mean2D[GP_ACC_STRIDE * (size_t)gid + comp], src_c[sp]);
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+    }
+    if (MODE == 1) {
+#pragma unroll
+        for (int dd = 32; dd >= 1; dd >>= 1) { n_eval += __shfl_xor(n_eval, dd); n_contr += __shfl_xor(n_contr, dd); }
+        if (lane == 0) { atomicAdd(&g_pair_counters[2], (unsigned long long)n_contr); atomicAdd(&g_pair_counters[3], (unsigned long long)n_eval); }
+    }
+#undef SPP
+#undef SDD
+}
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void gp_composite_bwd_sb_kernel(CB_ARGS) {
+    gp_composite_bwd_sb_body<false, 0>(d, ranges, point_list, smask, rec, bg, out_color, out_depth, final_T, n_contrib, dL_dpix, dL_dpixdepth, g_mean2D, order);
+}
+__global__ __launch_bounds__(64) void gp_composite_bwd_sb_depth_kernel(CB_ARGS) {
+    gp_composite_bwd_sb_body<true, 0>(d, ranges, point_list, smask, rec, bg, out_color, out_depth, final_T, n_contrib, dL_dpix, dL_dpixdepth, g_mean2D, order);
+}
+__global__ __launch_bounds__(64) void gp_composite_bwd_sb_count_kernel(CB_ARGS) {     // + pair counters (gp_debug_option(7, 2))
+    gp_composite_bwd_sb_body<false, 1>(d, ranges, point_list, smask, rec, bg, out_color, out_depth, final_T, n_contrib, dL_dpix, dL_dpixdepth, g_mean2D, order);
 }
 
 // Adam on the workgroup's span of SH-rest coefficients, gradients taken from LDS (instead of unstage_sh + a later pass of the

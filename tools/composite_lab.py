@@ -2,7 +2,9 @@
 """A/B laboratory for the composite kernels on the bench workload (configs[2]): selects kernel variants through
 gp_debug_option, checks every variant's outputs against the baseline variant bit for bit, and times them with the
 library's hipEvent brackets.  Also prints the instruction-rate microbenchmarks (gp_microbench_valu).
-    python tools/composite_lab.py [--fwd 1,0] [--bwd 0] [--reps 20] [--ubench]"""
+    python tools/composite_lab.py [--fwd 1,0] [--bwd 0] [--bwdk 1,0,2] [--reps 20] [--ubench]
+--bwdk: the composite backward's kernel (gp_debug_option(7, v)): 0 = quadrant kernel (shipped), 3 = sub-block kernel (round 5 experiment),
+2 = the sub-block kernel's counting variant (prints evaluated / contributing pairs)."""
 import argparse, ctypes as C, json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from types import SimpleNamespace
@@ -43,6 +45,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--fwd", default="2,0")      # 2 = compiler-scheduled visit loop (the readable reference), 0 = shipped
     ap.add_argument("--bwd", default="0")
+    ap.add_argument("--bwdk", default="0")
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--ubench", action="store_true")
     ap.add_argument("--gaussians", type=int, default=1_000_000)
@@ -64,14 +67,16 @@ def main():
     rs = _settings(cam, pc, torch.zeros(3, device=dev), 1.0)
     base = None
     fwd_variants = [int(v) for v in a.fwd.split(",")]
-    bwd_variants = [int(v) for v in a.bwd.split(",")]
+    bwd_variants = [(int(v), int(kk)) for kk in a.bwdk.split(",") for v in a.bwd.split(",")]
     gw = torch.randn(3, 1014, 1352, device=dev)
     for fv in fwd_variants:
-        for bv in bwd_variants:
-            _lib.check(L.gp_debug_option(0, fv), "opt"); _lib.check(L.gp_debug_option(1, bv), "opt")
+        for bv, bk in bwd_variants:
+            _lib.check(L.gp_debug_option(0, fv), "opt"); _lib.check(L.gp_debug_option(1, bv), "opt"); _lib.check(L.gp_debug_option(7, bk), "opt")
+            cnt = (C.c_uint64 * 4)()
+            _lib.check(L.gp_debug_counters(cnt), "counters")
             with torch.no_grad():
                 dbg = raster_forward_debug(rs, xyz, o, shs=shs, scales=s, rotations=q)
-            key = f"fwd{fv}_bwd{bv}"
+            key = f"fwd{fv}_bwd{bv}_k{bk}"
             r = {"R": dbg["R"]}
             leaves = [x.detach().clone().requires_grad_(True) for x in (xyz, o, shs, s, q)]
             m2 = torch.zeros(xyz.shape[0], 3, device=dev, requires_grad=True)
@@ -80,6 +85,10 @@ def main():
             (img * gw).sum().backward()
             torch.cuda.synchronize()
             grads = [l.grad.clone() for l in leaves] + [m2.grad.clone()]
+            if bk == 2:
+                _lib.check(L.gp_debug_counters(cnt), "counters")
+                r["bwd_contributing_pairs"], r["bwd_evaluated_pairs"] = int(cnt[2]), int(cnt[3])
+                r["bwd_evaluated_per_contributing"] = round(int(cnt[3]) / max(int(cnt[2]), 1), 3)
             cur = dict(color=dbg["color"], depth=dbg["depth"], tidx=dbg["tidx"], n_contrib=dbg["n_contrib"], grads=grads)
             if base is None:
                 base = cur
@@ -101,7 +110,7 @@ def main():
             r["ms"] = {k: round(v[1] / v[0], 4) for k, v in prof.items() if k in ("composite_fwd", "composite_bwd", "bwd_pixprep", "tile_sort", "duplicate", "preprocess_fwd", "preprocess_bwd")}
             res[key] = r
             print(key, json.dumps(r), flush=True)
-    _lib.check(L.gp_debug_option(0, 0), "opt"); _lib.check(L.gp_debug_option(1, 0), "opt")
+    _lib.check(L.gp_debug_option(0, 0), "opt"); _lib.check(L.gp_debug_option(1, 0), "opt"); _lib.check(L.gp_debug_option(7, 0), "opt")
 
 
 if __name__ == "__main__":
