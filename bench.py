@@ -307,6 +307,9 @@ def main():
     ap.add_argument("--exact-binning", action="store_true",
                     help="size the binning buffers by reading R back every step (one host sync per step) instead of the "
                          "capacity mode with the high-water-mark protocol of TrainStep(speculative=True)")
+    ap.add_argument("--no-fused", action="store_true",
+                    help="take every step through the autograd graph (render -> loss -> backward -> FusedAdam.step) instead of the one-call "
+                         "fused step (gp_train_step_run): the A/B of TrainStep(fused=...)")
     ap.add_argument("--render-only", action="store_true", help="time eval-style forward renders instead of train steps")
     ap.add_argument("--no-chain-sh", action="store_true",
                     help="N > 1, sharded exchange: keep the SH regions' Adam + all-gather on the compute stream (A/B of TrainStep._chain_sh)")
@@ -342,7 +345,7 @@ def main():
     # learning rates of the reference at iteration 50000 (position lr has decayed to position_lr_final,
     # [REF arguments/__init__.py:75-76, scene/gaussian_model.py:474-491])
     ts = TrainStep(pc, cams, gts, args.iteration, lrs=dict(xyz=1.6e-6 * 5.0), speculative=not args.exact_binning,
-                   sharded=False if args.replicated_adam else None, chain_sh=not args.no_chain_sh)
+                   sharded=False if args.replicated_adam else None, chain_sh=not args.no_chain_sh, fused=not args.no_fused)
 
     def one_step(i):
         view = i * world + rank            # rank r renders view world*i + r
@@ -570,6 +573,8 @@ def main():
                        "xgmi_bytes_sent_per_rank_per_step": None if world == 1 else (
                            getattr(ts.reducer, "bytes_sent_per_step", None) or int(2 * 4 * ts.bucket.flat.numel() * (world - 1) / world)),
                        "exposed_wait_ms_per_step": waits,          # (--time-waits: compute-stream time inside waits for collectives, rank 0)
+                       "step_driver": (f"one library call per step (gp_train_step_run): {getattr(ts, 'fused_steps', 0)} of the steps since the set-up"
+                                       if getattr(ts, "fused_steps", 0) else "autograd graph (render -> loss -> backward -> FusedAdam.step)"),
                        "binning": "exact (R read back every step)" if args.exact_binning else
                                   f"capacity mode in warm-up and timed steps (no host sync; {preroll} exact-mode set-up steps before the "
                                   f"warm-up; {getattr(ts, 'redone', 0)} frames repeated after overflow)",

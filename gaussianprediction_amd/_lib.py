@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(_PKG, "libgp_hip.so")
 def GP_LOSS_SUM_SLOTS(H, W):   # include/gp_hip.h
     return 3 * ((W + 31) // 32) * ((H + 31) // 32)
 
-GP_BUF_GEOM, GP_BUF_BINNING, GP_BUF_IMAGE, GP_BUF_TEMP = 0, 1, 2, 3
+GP_BUF_GEOM, GP_BUF_BINNING, GP_BUF_IMAGE, GP_BUF_TEMP, GP_BUF_TEMP_DONE = 0, 1, 2, 3, 4
 
 ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_int, C.c_size_t)
 
@@ -89,6 +89,42 @@ class BlendArgsC(C.Structure):
                 ("knn_idx", C.c_void_p), ("xyz", C.c_void_p), ("rot", C.c_void_p), ("knn_idx16", C.c_void_p)]
 
 
+class StepPlanC(C.Structure):
+    """gp_step_plan (include/gp_hip.h)."""
+    _fields_ = [("num_gaussians", C.c_int64), ("num_keypoints", C.c_int64), ("nearest_num", C.c_int32), ("norm_rotation", C.c_int32),
+                ("sh_degree", C.c_int32), ("image_height", C.c_int32), ("image_width", C.c_int32), ("lambda_dssim", C.c_float),
+                ("reg_scale", C.c_float),
+                ("xyz", C.c_void_p), ("scaling", C.c_void_p), ("rotation", C.c_void_p), ("opacity", C.c_void_p),
+                ("features_dc", C.c_void_p), ("features_rest", C.c_void_p), ("keypoints", C.c_void_p), ("keypoint_features", C.c_void_p),
+                ("mlp", MlpParamsC), ("feature_dim", C.c_int32), ("xyz_freq", C.c_int32), ("time_freq", C.c_int32), ("reserved0", C.c_int32),
+                ("raw_w", C.c_void_p), ("knn_idx", C.c_void_p), ("knn_idx16", C.c_void_p),
+                ("g_xyz", C.c_void_p), ("g_scaling", C.c_void_p), ("g_rotation", C.c_void_p), ("g_opacity", C.c_void_p),
+                ("g_features_dc", C.c_void_p), ("g_features_rest", C.c_void_p), ("g_keypoints", C.c_void_p), ("g_keypoint_features", C.c_void_p),
+                ("g_mlp", MlpGradsC),
+                ("delta", C.c_void_p), ("acts", C.c_void_p), ("xyz_t", C.c_void_p), ("q_t", C.c_void_p), ("scale", C.c_void_p),
+                ("opacity_t", C.c_void_p), ("out", RasterOutputsC), ("loss_sums", C.c_void_p), ("dmaps", C.c_void_p), ("loss", C.c_void_p),
+                ("dL_dimage", C.c_void_p), ("g_xyz_t", C.c_void_p), ("g_q_t", C.c_void_p), ("g_scale", C.c_void_p), ("g_opacity_t", C.c_void_p),
+                ("g_means2D", C.c_void_p), ("g_delta", C.c_void_p), ("g_feature_tmp", C.c_void_p)]
+
+
+class StepViewC(C.Structure):
+    """gp_step_view."""
+    _fields_ = [("tanfovx", C.c_float), ("tanfovy", C.c_float), ("bg", C.c_void_p), ("viewmatrix", C.c_void_p), ("projmatrix", C.c_void_p),
+                ("campos", C.c_void_p), ("gt_image", C.c_void_p), ("time", C.c_void_p)]
+
+
+STEP_HOOK_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_int32)
+
+
+class StepUpdateC(C.Structure):
+    """gp_step_update."""
+    _fields_ = [("binning_capacity", C.c_int64), ("binning_status", C.c_void_p), ("sh_ready_event", C.c_void_p), ("adam_shs", C.c_void_p),
+                ("adam_count", C.c_int32), ("adam_params", C.c_void_p), ("adam_grads", C.c_void_p), ("adam_exp_avgs", C.c_void_p),
+                ("adam_exp_avg_sqs", C.c_void_p), ("adam_numels", C.c_void_p), ("adam_lrs", C.c_void_p), ("adam_steps", C.c_void_p),
+                ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float), ("step", C.c_int64), ("keep_grad_mask", C.c_uint32),
+                ("skip_flag", C.c_void_p), ("hook", STEP_HOOK_FN), ("hook_ctx", C.c_void_p)]
+
+
 class ProfileEntryC(C.Structure):
     _fields_ = [("name", C.c_char * 48), ("launches", C.c_int32), ("total_ms", C.c_float)]
 
@@ -102,10 +138,10 @@ EXPORTS = [
     "gp_hashgrid_table_entries", "gp_hashgrid_forward", "gp_hashgrid_backward", "gp_knn_keypoints",
     "gp_weights_forward", "gp_weights_backward", "gp_l1_mean_forward", "gp_l1_mean_backward", "gp_loss_l1_ssim_finalize_reg", "gp_loss_l1_ssim_backward_reg", "gp_furthest_point_sampling", "gp_knn3_mean_dist2",
     "gp_microbench_copy", "gp_microbench_read", "gp_microbench_mfma", "gp_microbench_valu", "gp_microbench_gather",
-    "gp_debug_option", "gp_debug_counters",
+    "gp_debug_option", "gp_debug_counters", "gp_train_step_run",
     "gp_last_error", "gp_version", "gp_abi_version",
 ]
-GP_ABI_VERSION = 4         # include/gp_hip.h: the struct layouts / signatures / buffer-size macros this binding was written against
+GP_ABI_VERSION = 5         # include/gp_hip.h: the struct layouts / signatures / buffer-size macros this binding was written against
 
 _lib = None
 _lock = threading.Lock()
@@ -215,6 +251,9 @@ class TorchAllocator:
 
     def _alloc(self, _ctx, which, nbytes):
         try:
+            if which == GP_BUF_TEMP_DONE:     # (gp_train_step_run, between its sub-calls: the TEMP slots start over, as they do for
+                self._temp_slot = 0           # the separate entry points, each of which gets an allocator of its own)
+                return 0
             nbytes = max(int(nbytes), 1)
             if which == GP_BUF_TEMP and self.device.type == "cuda":
                 key = (self.device.index, self._stream, self._temp_slot)

@@ -1,0 +1,108 @@
+// gp_train_step.hip -- gp_train_step_run (include/gp_hip.h): one training iteration of the hot path enqueued by one call.
+// It CALLS the library's own entry points in the order the autograd graph of gaussianprediction_amd/train_step.py runs them:
+// nothing is re-implemented here, so the fused step and the drop-in surfaces cannot drift apart.
+// [REF train.py:101-133, 196-197; scene/gaussian_model.py:251-273]
+#include "gp_common.h"
+
+// dst[i] += src[i]: the keypoint features take a gradient from the regulariser AND from the MLP's input (both "=" producers)
+__global__ __launch_bounds__(256) void gp_step_accumulate_kernel(float* __restrict__ dst, const float* __restrict__ src, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) dst[i] += src[i];
+}
+
+extern "C" int gp_train_step_run(const gp_step_plan* p, const gp_step_view* v, const gp_step_update* u, gp_alloc_fn alloc,
+                                 void* alloc_ctx, gp_stream_t stream) {
+    if (!p || !v || !u || !alloc) GP_FAIL("gp_train_step_run: null argument");
+    const int64_t N = p->num_gaussians, K = p->num_keypoints;
+    if (N <= 0 || K <= 0 || p->nearest_num <= 0) GP_FAIL("gp_train_step_run: needs Gaussians, keypoints and neighbours (the stage-3 form)");
+    if (u->binning_capacity <= 0 || !u->binning_status) GP_FAIL("gp_train_step_run: capacity mode only (binning_capacity > 0 with a status word)");
+    if (!p->xyz || !p->scaling || !p->rotation || !p->opacity || !p->features_dc || !p->features_rest || !p->keypoints ||
+        !p->keypoint_features || !p->raw_w || !p->knn_idx)
+        GP_FAIL("gp_train_step_run: null parameter pointer");
+    if (!p->g_xyz || !p->g_scaling || !p->g_rotation || !p->g_opacity || !p->g_keypoints || !p->g_keypoint_features)
+        GP_FAIL("gp_train_step_run: null gradient pointer");
+    if (!u->adam_shs && (!p->g_features_dc || !p->g_features_rest)) GP_FAIL("gp_train_step_run: SH gradient buffers or adam_shs needed");
+    if (!p->delta || !p->acts || !p->xyz_t || !p->q_t || !p->scale || !p->opacity_t || !p->loss_sums || !p->dmaps || !p->loss ||
+        !p->dL_dimage || !p->g_xyz_t || !p->g_q_t || !p->g_scale || !p->g_opacity_t || !p->g_means2D || !p->g_delta || !p->g_feature_tmp)
+        GP_FAIL("gp_train_step_run: null intermediate buffer");
+    if (!v->bg || !v->viewmatrix || !v->projmatrix || !v->campos || !v->gt_image || !v->time) GP_FAIL("gp_train_step_run: null view pointer");
+    const int H = p->image_height, W = p->image_width, od = p->mlp.out_dim;
+    const bool reg = p->reg_scale != 0.f;
+    const int64_t nfeat = K * (int64_t)p->feature_dim;
+    if (reg && nfeat > 65536) GP_FAIL("gp_train_step_run: the folded regulariser takes at most 65536 feature elements");
+
+    // ---- GaussianModel.forward, stage 3 [REF scene/gaussian_model.py:251-273, 285-286]
+    gp_mlp_input mi;
+    mi.rows = K; mi.feature_dim = p->feature_dim; mi.xyz_freq = p->xyz_freq; mi.time_freq = p->time_freq;
+    mi.feature = p->keypoint_features; mi.xyz = p->keypoints; mi.t = v->time;
+    if (gp_mlp_forward(&p->mlp, &mi, p->delta, p->acts, stream)) return 1;
+    gp_blend_args ba;
+    ba.num_gaussians = N; ba.num_keypoints = K; ba.nearest_num = p->nearest_num; ba.out_dim = od; ba.norm_rotation = p->norm_rotation;
+    ba.delta = p->delta; ba.raw_w = p->raw_w; ba.knn_idx = p->knn_idx; ba.xyz = p->xyz; ba.rot = p->rotation; ba.knn_idx16 = p->knn_idx16;
+    if (gp_blend_forward(&ba, p->xyz_t, p->q_t, stream)) return 1;
+    if (gp_activations_forward(N, p->scaling, p->opacity, nullptr, 0, 1.f, p->scale, p->opacity_t, stream)) return 1;
+
+    // ---- GaussianRasterizer [REF gaussian_renderer/__init__.py:37-52, 98-106]
+    gp_raster_settings st;
+    memset(&st, 0, sizeof(st));
+    st.image_height = H; st.image_width = W; st.tanfovx = v->tanfovx; st.tanfovy = v->tanfovy; st.scale_modifier = 1.f;
+    st.sh_degree = p->sh_degree; st.sh_coeffs = 16;
+    st.bg = v->bg; st.viewmatrix = v->viewmatrix; st.projmatrix = v->projmatrix; st.campos = v->campos;
+    st.binning_capacity = u->binning_capacity; st.binning_status = u->binning_status; st.sh_ready_event = u->sh_ready_event;
+    gp_raster_inputs in;
+    memset(&in, 0, sizeof(in));
+    in.num_gaussians = N; in.means3D = p->xyz_t; in.shs = p->features_dc; in.shs_rest = p->features_rest; in.opacities = p->opacity_t;
+    in.scales = p->scale; in.rotations = p->q_t;
+    gp_raster_outputs out = p->out;
+    gp_raster_saved saved;
+    memset(&saved, 0, sizeof(saved));
+    if (gp_raster_forward(&st, &in, &out, &saved, alloc, alloc_ctx, stream)) return 1;
+    alloc(alloc_ctx, GP_BUF_TEMP_DONE, 0);
+
+    // ---- loss [REF train.py:105-109, utils/loss_utils.py:54-100] and its image gradient
+    if (gp_loss_l1_ssim_forward(out.color, v->gt_image, 3, H, W, p->loss_sums, p->dmaps, stream)) return 1;
+    if (reg) {
+        if (gp_loss_l1_ssim_finalize_reg(p->loss_sums, 3, H, W, p->lambda_dssim, p->keypoint_features, nfeat, p->reg_scale, p->loss, stream)) return 1;
+        if (gp_loss_l1_ssim_backward_reg(out.color, v->gt_image, p->dmaps, 3, H, W, p->lambda_dssim, nullptr, p->dL_dimage,
+                                         p->keypoint_features, nfeat, p->reg_scale, p->g_keypoint_features, stream)) return 1;
+    } else {
+        if (gp_loss_l1_ssim_finalize(p->loss_sums, 3, H, W, p->lambda_dssim, p->loss, stream)) return 1;
+        if (gp_loss_l1_ssim_backward(out.color, v->gt_image, p->dmaps, 3, H, W, p->lambda_dssim, nullptr, p->dL_dimage, stream)) return 1;
+    }
+
+    // ---- backward, in the order autograd runs it
+    gp_raster_grads g;
+    memset(&g, 0, sizeof(g));
+    g.dL_dmeans3D = p->g_xyz_t; g.dL_dmeans2D = p->g_means2D; g.dL_dshs = p->g_features_dc; g.dL_dshs_rest = p->g_features_rest;
+    g.dL_dopacities = p->g_opacity_t; g.dL_dscales = p->g_scale; g.dL_drotations = p->g_q_t; g.accumulate_shs = 0; g.adam_shs = u->adam_shs;
+    if (gp_raster_backward(&st, &in, &out, &saved, p->dL_dimage, nullptr, &g, alloc, alloc_ctx, stream)) return 1;
+    alloc(alloc_ctx, GP_BUF_TEMP_DONE, 0);
+    if (u->hook) u->hook(u->hook_ctx, GP_STEP_AFTER_RASTER_BACKWARD);
+    if (gp_activations_backward(N, p->scaling, p->opacity, nullptr, 0, 1.f, p->g_scale, p->g_opacity_t, p->g_scaling, p->g_opacity, nullptr, stream))
+        return 1;
+    if (gp_blend_backward(&ba, p->g_xyz_t, p->g_q_t, p->g_delta, nullptr, p->g_xyz, p->g_rotation, alloc, alloc_ctx, stream)) return 1;
+    alloc(alloc_ctx, GP_BUF_TEMP_DONE, 0);
+    gp_mlp_grads mg = p->g_mlp;
+    if (gp_mlp_backward(&p->mlp, &mi, p->acts, p->g_delta, &mg, reg ? p->g_feature_tmp : p->g_keypoint_features, p->g_keypoints, alloc,
+                        alloc_ctx, stream))
+        return 1;
+    if (reg) {
+        hipLaunchKernelGGL(gp_step_accumulate_kernel, dim3(gp_blocks((size_t)nfeat, 256)), dim3(256), 0, (hipStream_t)stream,
+                           p->g_keypoint_features, (const float*)p->g_feature_tmp, nfeat);
+        GP_LAUNCH_CHECK();
+    }
+    if (u->hook) u->hook(u->hook_ctx, GP_STEP_AFTER_BACKWARD);
+
+    // ---- optimizer [REF train.py:196-197, scene/gaussian_model.py:472]
+    if (u->adam_count > 0) {
+        if (u->adam_steps) {
+            if (gp_adam_step_multi_steps(u->adam_count, u->adam_params, u->adam_grads, u->adam_exp_avgs, u->adam_exp_avg_sqs, u->adam_numels,
+                                         u->adam_lrs, u->adam_steps, u->beta1, u->beta2, u->eps, 1, u->keep_grad_mask, u->skip_flag, stream))
+                return 1;
+        } else if (gp_adam_step_multi(u->adam_count, u->adam_params, u->adam_grads, u->adam_exp_avgs, u->adam_exp_avg_sqs, u->adam_numels,
+                                      u->adam_lrs, u->beta1, u->beta2, u->eps, u->step, 1, u->keep_grad_mask, u->skip_flag, stream)) {
+            return 1;
+        }
+    }
+    return 0;
+}

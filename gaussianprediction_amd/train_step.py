@@ -37,11 +37,17 @@ class TrainStep:
 
     def __init__(self, pc, cameras, gt_images, iteration, lambda_dssim=0.2, lrs=None, group=None, speculative=False,
                  overlap_sh_adam=False, batch=1, schedule=False, training_args=None, sharded=None, fuse_sh_adam=True, chain_sh=True,
-                 view_stats=None):
-        """`view_stats` (view-parallel only): True / False = always / never exchange the densification inputs' screen-space gradient
+                 view_stats=None, fused=True):
+        """`fused`: take plain stage-3 steps through ONE call of the library (fused_step.FusedStage3 / gp_train_step_run) instead of
+        the autograd graph -- same kernels, same results, a fraction of the host work; steps of any other shape use the graph.
+        Buffers of the returned dict (`render`, `radii`, ...) are then the plan's own and are overwritten by the next step.
+        `view_stats` (view-parallel only): True / False = always / never exchange the densification inputs' screen-space gradient
         (see _step); None = exactly while the reference's loop reads it (below densify_until_iter, and during keypoint growth)."""
         self.pc, self.cameras, self.gt, self.iteration = pc, cameras, gt_images, iteration
         self.view_stats = view_stats
+        self.fused = bool(fused)
+        self._fused_plan = None
+        self.fused_steps = 0
         self.lambda_dssim = lambda_dssim
         self.group = group
         self.chain_sh = bool(chain_sh)      # sharded exchange: SH regions' Adam + all-gather on a side stream (_chain_sh)
@@ -268,6 +274,21 @@ class TrainStep:
             pc.update_learning_rate(self.iteration)  # [REF train.py:79]
         a = pc.args
         lifecycle = bool(a.step_opacity and self.iteration > a.step_opacity_iteration)
+        if self.fused and self.batch == 1:
+            from .fused_step import FusedStage3
+            if FusedStage3.eligible(self, binning, getattr(self, "_hold", ())):
+                plan = self._fused_plan
+                if plan is None or plan.stale():
+                    plan = self._fused_plan = FusedStage3(self)
+                v = view_index % len(self.cameras)
+                t_view = None
+                if getattr(self, "_time_offset", None) is not None:
+                    t_view = self.times[v] + self._time_offset
+                # per-Gaussian "=" gradients: their producers overwrite them, the optimizer launch need not zero them (and the graph path
+                # finds them marked stale, as after its own steps); the small tensors are zeroed as the graph path leaves them
+                keep_f = (pc._features_dc, pc._features_rest, pc._rotation, pc._scaling, pc._opacity, pc._xyz)
+                self.fused_steps += 1
+                return plan.run(v, t_view, binning[0], binning[1], skip_flag, keep_f)
         keep = ()
         if self.batch == 1 and not self.pipe.convert_SHs_python and self.iteration > pc.third_stage_iter:
             # the per-Gaussian gradients each have exactly one producer kernel that writes the whole tensor (SH: rasterizer

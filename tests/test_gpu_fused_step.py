@@ -1,0 +1,100 @@
+"""-m gpu: the stage-3 train step through ONE call of the library (gp_train_step_run; fused_step.FusedStage3) against the same step
+through the autograd graph (render() -> L1SSIMLoss -> backward -> FusedAdam.step).  The C entry calls the library's own entry points
+in the order the graph runs them, so everything must agree up to the summation order of the backward's atomics: gradients (read
+off the first Adam moment at zero learning rate), losses, and parameters after real updates.  [REF train.py:101-133, 196-197]"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from gaussianprediction_amd.train_step import TrainStep  # noqa: E402
+from test_gpu_training_api import build  # noqa: E402
+
+ZERO = dict(xyz=0.0, f_dc=0.0, opacity=0.0, scaling=0.0, rotation=0.0, kpts=0.0, mlp=0.0)
+
+
+def _run(fused, lrs, steps, time_offset=False, n=6000):
+    pc, cams, gts, raw, rw, idx, args = build(n=n)
+    ts = TrainStep(pc, cams, gts, 50000, lrs=lrs, speculative=True, fused=fused)
+    pre = len(cams) + TrainStep.SPEC_SLOTS                     # exact-mode set-up steps (graph path in both runs)
+    losses = []
+    for i in range(pre + steps):
+        off = torch.full((1,), 0.01 * (i % 3), device="cuda") if time_offset else None
+        loss, pkg = ts.step(i, time_offset=off)
+        losses.append(loss)
+    torch.cuda.synchronize()
+    sd = pc.optimizer.state_dict()
+    names = [n_ for n_, p in pc.named_parameters() if p.requires_grad]
+    return dict(ts=ts, pc=pc, loss=[float(x) for x in losses], pkg={k: v.clone() if torch.is_tensor(v) else v for k, v in pkg.items()},
+                vs_grad=pkg["viewspace_points"].grad.clone(), params={n_: p.detach().clone() for n_, p in pc.named_parameters()},
+                state=sd["state"], names=names, steps=pre + steps, redone=ts.redone)
+
+
+def test_fused_step_equals_the_graph_step_gradients():
+    """Zero learning rates: the parameters stand still, every step sees the same model, and the Adam moments after k steps are a
+    fixed function of the k gradients -- so equal moments = equal gradients, for every optimized tensor, MLP weights included."""
+    a = _run(True, ZERO, 6)
+    b = _run(False, ZERO, 6)
+    assert a["ts"].fused_steps == 6 and b["ts"].fused_steps == 0 and a["redone"] == b["redone"] == 0
+    assert np.allclose(a["loss"], b["loss"], rtol=2e-6, atol=1e-7), (a["loss"], b["loss"])
+    for k in a["params"]:
+        assert torch.equal(a["params"][k], b["params"][k]), k           # lr = 0: nothing moved in either
+    assert a["state"].keys() == b["state"].keys()
+    for k in a["state"]:
+        for kk in ("exp_avg", "exp_avg_sq"):
+            x, y = a["state"][k][kk], b["state"][k][kk]
+            e = float((x - y).norm() / y.norm().clamp_min(1e-30))
+            assert e < 2e-5, (k, kk, e)
+        assert float(a["state"][k]["step"]) == float(b["state"][k]["step"])
+    # the result dict has render()'s shape and contents
+    for k in ("render", "radii", "visibility_filter", "depth", "tidx"):
+        x, y = a["pkg"][k], b["pkg"][k]
+        assert x.shape == y.shape and x.dtype == y.dtype, k
+        assert torch.equal(x, y) if x.dtype != torch.float32 else torch.allclose(x, y, atol=1e-6), k
+    e = float((a["vs_grad"] - b["vs_grad"]).norm() / b["vs_grad"].norm())
+    assert e < 2e-5, e
+
+
+def test_fused_step_trains_like_the_graph_step():
+    """The reference's learning rates: after 10 updates the two paths' parameters differ by what two runs of ONE path differ by
+    (atomics in the backward + Adam's eps = 1e-15): the typical element a few percent of one learning-rate step."""
+    a = _run(True, None, 10, time_offset=True)
+    b = _run(False, None, 10, time_offset=True)
+    assert a["ts"].fused_steps == 10
+    assert np.abs(np.array(a["loss"]) - np.array(b["loss"])).max() < 2e-4
+    lr = {}
+    for g in b["pc"].optimizer.param_groups:
+        for p in g["params"]:
+            lr[id(p)] = max(float(g["lr"]), 1e-7)
+    for (k, x), (_, p) in zip(a["params"].items(), b["pc"].named_parameters()):
+        if id(p) not in lr:
+            continue
+        d = (x - b["params"][k]).abs().flatten()
+        assert float(d.median()) <= 0.05 * lr[id(p)] + 1e-8 and float(d.max()) <= 2 * 10 * lr[id(p)] + 1e-6, (k, float(d.median()), float(d.max()), lr[id(p)])
+    assert not torch.equal(a["params"]["_xyz"], build(n=6000)[0]._xyz.detach())        # (it did move)
+
+
+def test_fused_step_falls_back_when_the_step_has_another_shape():
+    """Held groups, several views per step, exact-mode binning: the graph path, silently, with the same results as ever -- and back
+    to the fused path afterwards, with the gradient buffers in the state it expects."""
+    pc, cams, gts, raw, rw, idx, args = build(n=3000)
+    ts = TrainStep(pc, cams, gts, 50000, speculative=True, fused=True)
+    pre = len(cams) + TrainStep.SPEC_SLOTS
+    for i in range(pre):
+        ts.step(i)
+    assert ts.fused_steps == 0
+    ts.step(pre)
+    assert ts.fused_steps == 1
+    ts.step(pre + 1, hold=("xyz",))                       # a held group: graph path
+    assert ts.fused_steps == 1 and pc.optimizer.lag == {"xyz": 1}
+    loss, pkg = ts.step(pre + 2)                          # lagging step counts: still fused (per-tensor steps)
+    assert ts.fused_steps == 2 and bool(torch.isfinite(loss))
+    sd = pc.optimizer.state_dict()
+    steps = {g["name"]: float(sd["state"][g["params"][0]]["step"]) for g in sd["param_groups"]}
+    assert steps["xyz"] == steps["f_dc"] - 1
+    pc.set_keypoint_weights(rw.clone(), idx)              # new weights tensor: the plan is rebuilt, not reused with a dead pointer
+    ts.step(pre + 3)
+    assert ts.fused_steps == 3
+    torch.cuda.synchronize()
+    assert all(bool(torch.isfinite(p).all()) for p in pc.parameters())

@@ -118,7 +118,8 @@ def test_capacity_mode_settings_are_validated_on_the_host():
 _STRUCTS = {"gp_raster_settings": "RasterSettingsC", "gp_raster_inputs": "RasterInputsC", "gp_raster_outputs": "RasterOutputsC",
             "gp_raster_saved": "RasterSavedC", "gp_raster_grads": "RasterGradsC", "gp_adam_fuse": "AdamFuseC",
             "gp_mlp_params": "MlpParamsC", "gp_mlp16_params": "Mlp16ParamsC", "gp_mlp_grads": "MlpGradsC",
-            "gp_mlp_input": "MlpInputC", "gp_blend_args": "BlendArgsC", "gp_profile_entry": "ProfileEntryC"}
+            "gp_mlp_input": "MlpInputC", "gp_blend_args": "BlendArgsC", "gp_profile_entry": "ProfileEntryC",
+            "gp_step_plan": "StepPlanC", "gp_step_view": "StepViewC", "gp_step_update": "StepUpdateC"}
 
 
 def _header_layout(tmp_path):

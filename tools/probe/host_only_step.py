@@ -8,10 +8,11 @@ from gaussianprediction_amd.train_step import TrainStep
 dev = torch.device("cuda", 0)
 args = SimpleNamespace(gaussians=2000, width=160, height=128, keypoints=250, nearest_num=6, time_freq=8, iteration=50000, scale_lo=0.01, scale_hi=0.03)
 pc, cams, gts, margs = bench.build_workload(args, dev)
-for spec in (True, False):
-    ts = TrainStep(pc, cams, gts, 50000, lrs=dict(xyz=8e-6), speculative=spec)
+for spec, fused in ((True, True), (True, False), (False, False)):
+    ts = TrainStep(pc, cams, gts, 50000, lrs=dict(xyz=8e-6), speculative=spec, fused=fused)
     for i in range(50): ts.step(i)
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for i in range(500): ts.step(i)
     torch.cuda.synchronize()
-    print("speculative" if spec else "exact (one host sync per step)", round(1e3 * (time.perf_counter() - t0) / 500, 4), "ms per step on a 2 000-Gaussian scene", flush=True)
+    name = ("capacity mode, ONE library call per step (gp_train_step_run)" if fused else "capacity mode, autograd graph") if spec else "exact (one host sync per step), autograd graph"
+    print(name, round(1e3 * (time.perf_counter() - t0) / 500, 4), "ms per step on a 2 000-Gaussian scene;", ts.fused_steps, "fused steps", flush=True)
