@@ -335,11 +335,12 @@ def test_reference_order_loop_equals_the_harness_order():
     assert ref["lag"] == har["lag"] and ref["lag"].get("xyz", 0) >= 2 and ref["steps"] == har["steps"]
     assert np.abs(np.array(ref["loss"]) - np.array(har["loss"])).max() < 0.02
     if ref["n"] == har["n"]:
-        # Same rows: compare element for element, in units of a learning-rate step.  Two runs of ONE implementation differ like this too
-        # (atomics in the backward; Adam with eps = 1e-15 turns the last bit of a near-zero gradient into up to 2 lr per step): the typical
-        # element agrees to a few percent of one step, 99 % of them to 2 steps, none by more than every step going the other way.
+        # Same rows: compare element for element, in units of a learning-rate step.  The bars come from a calibration, not from a guess
+        # (tools/probe/order_noise.py, profiles/r05_order_noise.txt): two runs of the SAME order end 0.01 - 0.23 lr apart in the median
+        # (the MLP weights and the motion feature most: small gradients, Adam's eps = 1e-15), 0.02 - 1.8 lr at the 99th percentile,
+        # 0.1 - 23 lr at the maximum -- and the two orders end exactly that far from each other (0.0001 - 0.22 / 0.01 - 1.7 / 0.1 - 9).
         for k, a in ref["params"].items():
             lr, d = ref["lr"][k], (a - har["params"][k]).abs().flatten().float()
             q99 = float(torch.quantile(d[:1_000_000], 0.99)) if d.numel() > 1 else float(d.max())
-            assert float(d.median()) <= 0.05 * lr + 1e-7 and q99 <= 2 * lr + 1e-6 and float(d.max()) <= 2 * last * lr + 1e-5, \
+            assert float(d.median()) <= 0.5 * lr + 1e-7 and q99 <= 4 * lr + 1e-6 and float(d.max()) <= 2 * last * lr + 1e-5, \
                 (k, float(d.median()), q99, float(d.max()), lr)
