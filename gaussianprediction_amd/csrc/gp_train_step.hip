@@ -58,6 +58,7 @@ extern "C" int gp_train_step_run(const gp_step_plan* p, const gp_step_view* v, c
     memset(&saved, 0, sizeof(saved));
     if (gp_raster_forward(&st, &in, &out, &saved, alloc, alloc_ctx, stream)) return 1;
     alloc(alloc_ctx, GP_BUF_TEMP_DONE, 0);
+    if (u->hook) u->hook(u->hook_ctx, GP_STEP_AFTER_FORWARD);
 
     // ---- loss [REF train.py:105-109, utils/loss_utils.py:54-100] and its image gradient
     if (gp_loss_l1_ssim_forward(out.color, v->gt_image, 3, H, W, p->loss_sums, p->dmaps, stream)) return 1;

@@ -113,6 +113,8 @@ class FusedStage3:
         # the optimizer's launch table, SH pair excluded when its update rides in the rasterizer backward
         self.upd = _lib.StepUpdateC()
         self._adam_key = None
+        self._hook_cb = _lib.STEP_HOOK_FN(self._on_point)      # (kept alive with the plan)
+        self._hook_error = None
 
     # ---- eligibility ------------------------------------------------------------------------------------------------------------
     @staticmethod
@@ -120,8 +122,10 @@ class FusedStage3:
         pc, a = ts.pc, ts.pc.args
         if not getattr(ts, "fused", True) or binning is None or not binning[0] or hold or ts.batch != 1:
             return False
-        if pc.get_xyz.device.type != "cuda" or ts.iteration <= pc.third_stage_iter or ts.reducer.enabled or ts.overlap_sh_adam:
+        if pc.get_xyz.device.type != "cuda" or ts.iteration <= pc.third_stage_iter or ts.overlap_sh_adam:
             return False
+        if ts.reducer.enabled and not (ts.sharded and hasattr(ts.reducer, "gather_params")):
+            return False                     # (view-parallel: the sharded exchange only; all-reduce + replicated Adam stays on the graph path)
         if pc.raw_weights is None or pc.knn_idx is None or getattr(pc, "weights_model", None) is not None and pc.raw_weights is None:
             return False
         if a.step_opacity and ts.iteration > a.step_opacity_iteration:
@@ -138,7 +142,7 @@ class FusedStage3:
         if ts.iteration < pc.args.jointly_iteration:
             return False
         opt = pc.optimizer
-        if opt is None or opt.shard is not None or opt.pending_hold:
+        if opt is None or opt.pending_hold or (opt.shard is not None) != bool(ts.reducer.enabled):
             return False
         need = [pc._xyz, pc._scaling, pc._rotation, pc._opacity, pc._features_dc, pc._features_rest, pc.super_gaussians,
                 pc.super_gaussians_feature] + list(pc.df_model.parameters())
@@ -159,7 +163,9 @@ class FusedStage3:
 
     # ---- one step -----------------------------------------------------------------------------------------------------------------
     def _adam_tables(self, opt, fuse_sh):
-        """The launch table of FusedAdam as the C entry takes it; rebuilt only when the set of tensors changes."""
+        """The launch table of FusedAdam as the C entry takes it (sharded: this rank's slices); rebuilt only when the set of tensors
+        changes.  `fuse_sh`: the SH pair is updated elsewhere (inside the rasterizer backward, or -- view-parallel -- on the exchange's
+        side stream: TrainStep._chain_sh)."""
         pc = self.pc
         skip = {id(pc._features_dc), id(pc._features_rest)} if fuse_sh else set()
         key = (id(opt), bool(fuse_sh), len(opt.items))
@@ -180,21 +186,71 @@ class FusedStage3:
             self._adam_key = key
         return self._tab
 
+    # ---- view-parallel: the exchange is issued from the host BETWEEN the library's enqueues (gp_step_update.hook) ----------------
+    def _on_point(self, _ctx, point):
+        """GP_STEP_AFTER_FORWARD: the overflow word is final -> its MAX over the ranks.  GP_STEP_AFTER_RASTER_BACKWARD: the SH
+        gradients (3/4 of the bytes) and the screen-space gradient are final -> their reduce-scatter (chained to its Adam slice and
+        all-gather on the side stream), the densification input's broadcast.  GP_STEP_AFTER_BACKWARD: everything else, then the
+        compute stream waits for the reduced slices in front of the optimizer launch.  Never raises across the C boundary."""
+        try:
+            ts, ex = self.ts, self.ts.reducer
+            import torch.distributed as dist
+            if point == 2:
+                if self._skip_flag is not None:
+                    ts._flag_handle = dist.all_reduce(self._skip_flag, op=dist.ReduceOp.MAX, group=ts.group, async_op=True)
+            elif point == 0:
+                if self._stats_due:
+                    self._h_vs = dist.broadcast(self.viewspace.grad, src=self.pc._vp_src(-1), group=ts.group, async_op=True)
+                for region in self._sh_regions:
+                    h = ex._reduce_scatter(region)
+                    if ex.chain is not None and ex.chain(region, h):
+                        ex._chained.add(region[0])
+                    else:
+                        ex.handles.append(h)
+            elif point == 1:
+                sh = {r[0] for r in self._sh_regions}
+                for region in ex.bucket.regions:
+                    if region[0] not in sh:
+                        ex.handles.append(ex._reduce_scatter(region))
+                ex._timed_wait("reduce_scatter", ex.handles)
+                ex.handles.clear()
+                if ts._flag_handle is not None:
+                    ex._timed_wait("overflow_flag", [ts._flag_handle])
+                n = ex.bucket.flat.numel()
+                ex.bytes_sent_per_step = 2 * 4 * n * (ex.world - 1) // ex.world
+        except BaseException as e:       # noqa: BLE001  (re-raised by run() once the library call has returned)
+            self._hook_error = self._hook_error or e
+
     def run(self, view, time_tensor, capacity, status, skip_flag, keep):
         """Enqueue the whole step for camera `view`; returns (loss [] tensor, result dict shaped like render()'s)."""
         ts, pc, opt = self.ts, self.pc, self.pc.optimizer
         sh_pair = (pc._features_dc, pc._features_rest)
-        fuse = opt.fused_payload(sh_pair[0], sh_pair[1], skip_flag) if ts.fuse_sh_adam else None
-        fuse_c = None
-        if fuse is not None:
-            fuse_c = _lib.AdamFuseC(fuse["m_dc"].data_ptr(), fuse["v_dc"].data_ptr(), fuse["m_rest"].data_ptr(), fuse["v_rest"].data_ptr(),
-                                    fuse["lr_dc"], fuse["lr_rest"], fuse["beta1"], fuse["beta2"], fuse["eps"], fuse["step"],
-                                    skip_flag.data_ptr() if skip_flag is not None else None)
-        tab = self._adam_tables(opt, fuse is not None)
+        ex = ts.reducer if ts.reducer.enabled else None
+        u = self.upd
+        fuse, fuse_c, chained = None, None, False
+        if ex is None:
+            fuse = opt.fused_payload(sh_pair[0], sh_pair[1], skip_flag) if ts.fuse_sh_adam else None
+            if fuse is not None:
+                fuse_c = _lib.AdamFuseC(fuse["m_dc"].data_ptr(), fuse["v_dc"].data_ptr(), fuse["m_rest"].data_ptr(), fuse["v_rest"].data_ptr(),
+                                        fuse["lr_dc"], fuse["lr_rest"], fuse["beta1"], fuse["beta2"], fuse["eps"], fuse["step"],
+                                        skip_flag.data_ptr() if skip_flag is not None else None)
+            u.hook, u.sh_ready_event = _lib.STEP_HOOK_FN(), None
+        else:
+            # what TrainStep._step sets up for its gradient hooks, here for the three hook points of the library call
+            sh_ids = {id(sh_pair[0]), id(sh_pair[1])}
+            self._sh_regions = [r for r in ex.bucket.regions if r[0] != ex.bucket.tail_start and all(id(ex.bucket.params[k]) in sh_ids for k in r[2])]
+            chained = bool(self._sh_regions) and bool(getattr(ts, "chain_sh", True)) and ex.side is not None
+            ts._chain_on, ts._keep, ts._skip_flag, ts._chained_params, ts._flag_handle = chained, keep, skip_flag, [], None
+            self._skip_flag, self._h_vs, self._stats_due, self._hook_error = skip_flag, None, ts._view_stats_due(), None
+            late = getattr(pc, "_param_late_event", None)
+            ev = late() if late is not None else None            # (waits for the early gathers; an event for the SH coefficients')
+            u.sh_ready_event = int(ev.cuda_event) if ev is not None else None
+            self._keep_ev = ev
+            u.hook = self._hook_cb
+        tab = self._adam_tables(opt, fuse is not None or chained)
         step_no = opt.step_count + 1
         for k, (g, _, _, _, _) in enumerate(opt.items):
             tab["LR"][k] = float(g["lr"])
-        u = self.upd
         if opt.lag:
             for k, st in enumerate(opt.item_steps(step_no)):
                 tab["STEPS"][k] = max(1, st)
@@ -207,7 +263,6 @@ class FusedStage3:
             if id(own) in keep_ids and tab["NUM"][k] != 0:
                 mask |= 1 << k
         u.binning_capacity, u.binning_status = int(capacity), status.data_ptr()
-        u.sh_ready_event = None
         u.adam_shs = C.cast(C.pointer(fuse_c), C.c_void_p) if fuse_c is not None else None
         u.beta1, u.beta2, u.eps, u.step, u.keep_grad_mask = float(opt.betas[0]), float(opt.betas[1]), float(opt.eps), int(step_no), mask
         u.skip_flag = skip_flag.data_ptr() if skip_flag is not None else None
@@ -221,20 +276,31 @@ class FusedStage3:
         with _lib.on_device(self.dev):
             try:
                 rc = _lib.lib().gp_train_step_run(C.byref(P), C.byref(v), C.byref(u), alloc.cb, None, _lib.stream_ptr(self.dev))
+                if self._hook_error is not None:
+                    err, self._hook_error = self._hook_error, None
+                    raise err
                 if alloc.error is not None:
                     raise alloc.error
                 _lib.check(rc, "gp_train_step_run")
             finally:
                 alloc.release()
-        # ---- the bookkeeping FusedAdam.step does around its launch
-        opt.step_count = step_no
-        bump = torch.autograd.graph.increment_version
-        for p in opt.bucket.params:
-            bump(p)
-        for p in opt.bucket.params:                  # buffers the launch did not zero hold this step's values: their next producer overwrites
-            if (id(p) in keep_ids or (fuse is not None and (p is sh_pair[0] or p is sh_pair[1]))) and p.grad is not None:
-                grad_sink.mark_stale(p.grad)
+        # ---- what FusedAdam.step does around its launch
+        excluded = sh_pair if fuse is not None else (tuple(ts._chained_params) if chained else None)
+        opt.external_step(keep_grad=keep, exclude=excluded)
+        if fuse is not None:                         # updated inside the rasterizer backward; their (unwritten) gradient buffers are stale
+            bump = torch.autograd.graph.increment_version
+            for p in sh_pair:
+                bump(p)
+                if p.grad is not None:
+                    grad_sink.mark_stale(p.grad)
         b = self.buf
-        pkg = {"render": b["color"], "viewspace_points": self.viewspace, "visibility_filter": b["visible"].view(torch.bool), "radii": b["radii"],
+        radii, vis = b["radii"], b["visible"].view(torch.bool)
+        if ex is not None:
+            ex.gather_params()                       # asynchronous; awaited by the next step / render
+            from .dist import reduce_view_stats      # radii = max over the ranks' views, visibility = any [REF train.py:121-122]
+            radii, vis = reduce_view_stats(radii, ts.group)
+            if self._h_vs is not None:
+                self._h_vs.wait()
+        pkg = {"render": b["color"], "viewspace_points": self.viewspace, "visibility_filter": vis, "radii": radii,
                "depth": b["depth"], "tidx": b["tidx"]}
         return b["loss"].reshape(()).clone(), pkg

@@ -389,6 +389,16 @@ class FusedAdam:
                                 [(inc_h is None or id(p) in inc_h) and id(p) not in exc_h for p in self.owner])
         else:
             self._launch(n, step_no, zero_grad, keep_ids, skip_flag, only, exclude, stream)
+        self._after_launch(only, exclude, zero_grad, keep_ids, held_params, fresh_grad, stream)
+
+    def external_step(self, keep_grad=(), exclude=None):
+        """The bookkeeping of step() for a launch somebody else enqueued with THIS optimizer's tables (gp_train_step_run: the optimizer
+        launch is the last thing the fused train step enqueues): the step count, the parameters' version counters, the stale marks,
+        and -- sharded -- the zeroing of the slices the other ranks own."""
+        self.step_count += 1
+        self._after_launch(None, exclude, True, {id(p) for p in keep_grad}, (), (), None)
+
+    def _after_launch(self, only, exclude, zero_grad, keep_ids, held_params, fresh_grad, stream):
         # which PARAMETERS this launch covered -- not only those this rank holds a slice of: under the sharded layout a tensor can
         # lie entirely inside another rank's slice of its region (regions shared by several tensors), and its gradient buffer
         # here still has to be marked stale / zeroed like everyone else's

@@ -392,7 +392,8 @@ typedef struct gp_step_view {   /* the camera of this step [REF gaussian_rendere
 
 typedef void (*gp_step_hook_fn)(void* ctx, int32_t point);
 enum { GP_STEP_AFTER_RASTER_BACKWARD = 0,   /* the SH gradients (and g_means2D) are final: a view-parallel caller starts their exchange */
-       GP_STEP_AFTER_BACKWARD = 1 };        /* every gradient is final (called in front of the optimizer launch, if there is one) */
+       GP_STEP_AFTER_BACKWARD = 1,          /* every gradient is final (called in front of the optimizer launch, if there is one) */
+       GP_STEP_AFTER_FORWARD = 2 };         /* the rasterizer forward is enqueued: binning_status is final once the stream gets there */
 
 typedef struct gp_step_update {
     int64_t binning_capacity;    /* > 0: capacity mode (required: the call never synchronises) */

@@ -98,3 +98,57 @@ def test_fused_step_falls_back_when_the_step_has_another_shape():
     assert ts.fused_steps == 3
     torch.cuda.synchronize()
     assert all(bool(torch.isfinite(p).all()) for p in pc.parameters())
+
+
+# ---- view-parallel: the same call with the exchange issued at its hook points ---------------------------------------------------
+def _rank_fused(rank, world, port, out_dir, fused, steps):
+    import os
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    pc, cams, gts, raw, rw, idx, args = build(n=5000)
+    pc.bucket_small_numel = 12000            # the SH pair and the geometry get regions of their own, as at 1 M Gaussians
+    ts = TrainStep(pc, cams, gts, 50000, speculative=True, fused=fused)
+    assert ts.sharded and type(ts.reducer).__name__ == "ShardedExchange"
+    pre = len(cams) + TrainStep.SPEC_SLOTS
+    losses = []
+    for i in range(pre + steps):
+        loss, pkg = ts.step(i * world + rank)
+        losses.append(float(loss))
+    ts.sync_params()
+    torch.cuda.synchronize()
+    sd = pc.optimizer.state_dict()
+    torch.save({"params": {n: p.detach().cpu() for n, p in pc.named_parameters()}, "loss": losses, "fused_steps": ts.fused_steps,
+                "state": {k: {kk: vv.cpu() for kk, vv in v.items()} for k, v in sd["state"].items()},
+                "radii": pkg["radii"].cpu(), "vis": pkg["visibility_filter"].cpu()}, os.path.join(out_dir, f"f{int(fused)}_{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_fused_step_equals_the_two_rank_graph_step(tmp_path):
+    """Two ranks (one GPU, gloo), sharded exchange: reduce-scatter per region at the library call's hook points -> Adam on this rank's
+    slices inside the call -> asynchronous all-gather; the SH region chained to the side stream.  Rank-identical parameters, and the
+    trajectory of the graph path."""
+    import os
+    import socket
+    import torch.multiprocessing as mp
+    steps = 6
+    for fused in (True, False):
+        s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+        mp.spawn(_rank_fused, args=(2, port, str(tmp_path), fused, steps), nprocs=2, join=True)
+    r = {(f, k): torch.load(os.path.join(tmp_path, f"f{f}_{k}.pt"), weights_only=False) for f in (0, 1) for k in (0, 1)}
+    assert r[(1, 0)]["fused_steps"] == steps and r[(1, 1)]["fused_steps"] == steps and r[(0, 0)]["fused_steps"] == 0
+    for f in (0, 1):
+        for k in r[(f, 0)]["params"]:
+            assert torch.equal(r[(f, 0)]["params"][k], r[(f, 1)]["params"][k]), (f, k)        # both ranks hold the same model
+        assert torch.equal(r[(f, 0)]["radii"], r[(f, 1)]["radii"]) and torch.equal(r[(f, 0)]["vis"], r[(f, 1)]["vis"])
+    a, b = r[(1, 0)], r[(0, 0)]
+    assert np.abs(np.array(a["loss"]) - np.array(b["loss"])).max() < 2e-4
+    assert {k: float(v["step"]) for k, v in a["state"].items()} == {k: float(v["step"]) for k, v in b["state"].items()}
+    for k in a["state"]:
+        x, y = a["state"][k]["exp_avg"], b["state"][k]["exp_avg"]
+        assert float((x - y).norm() / y.norm().clamp_min(1e-30)) < 2e-2, k            # (six real updates apart: not bit-equal, the same walk)
+    for k, x in a["params"].items():
+        d = (x - b["params"][k]).abs()
+        assert float(d.median()) <= 2e-6 and float(d.max()) <= 0.05, (k, float(d.median()), float(d.max()))

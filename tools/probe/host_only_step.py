@@ -6,6 +6,9 @@ from types import SimpleNamespace
 import torch, bench
 from gaussianprediction_amd.train_step import TrainStep
 dev = torch.device("cuda", 0)
+if os.environ.get("GP_DIST_FORCE_SINGLE") == "1":      # the view-parallel exchange on a one-rank RCCL group: its HOST cost
+    from gaussianprediction_amd.dist import init_from_env
+    init_from_env()
 args = SimpleNamespace(gaussians=2000, width=160, height=128, keypoints=250, nearest_num=6, time_freq=8, iteration=50000, scale_lo=0.01, scale_hi=0.03)
 pc, cams, gts, margs = bench.build_workload(args, dev)
 for spec, fused in ((True, True), (True, False), (False, False)):
