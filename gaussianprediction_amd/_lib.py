@@ -68,7 +68,7 @@ class MlpParamsC(C.Structure):
 
 class Mlp16ParamsC(C.Structure):
     _fields_ = [("dtype", C.c_int32), ("in_dim", C.c_int32), ("width", C.c_int32), ("depth", C.c_int32), ("out_dim", C.c_int32),
-                ("w16", C.c_void_p * 5), ("b", C.c_void_p * 5)]
+                ("w16", C.c_void_p * 5), ("b", C.c_void_p * 5), ("range_flag", C.c_void_p)]
 
 
 GP_DTYPE_F16, GP_DTYPE_BF16, GP_DTYPE_F16_SPLIT = 1, 2, 3

@@ -92,6 +92,7 @@ struct Mlp16Dev {
     const float* feature;
     const float* xyz;
     const float* t;
+    uint32_t* range_flag;              // split forward: OR-ed with 1 when a hidden activation reached 2^15 (gp_mlp16_params.range_flag)
 };
 
 // hardware sin/cos (v_sin_f32 / v_cos_f32 take revolutions and reduce the range themselves, |x| < 256 rev):
@@ -526,6 +527,7 @@ __device__ __forceinline__ void mlp16_fwd_body(Mlp16Dev p, float* __restrict__ o
     if (ablate & 2) masks = nullptr;
     if (saved_xT) store_T(cur, saved_xT, p.in_pad);
     typedef typename Vec4<T>::type V4;
+    float amax = 0.f;                   // split mode: the largest hidden activation this lane carried into (hi, lo') form
     for (int l = 0; l < 4; ++l) {
         const int K = l == 0 ? p.in_pad : M16_W;
         f32x16 acc[RT][2];
@@ -574,6 +576,7 @@ __device__ __forceinline__ void mlp16_fwd_body(Mlp16Dev p, float* __restrict__ o
                     if constexpr (SP) {
                         h4 hi, lo;
                         split4(v, hi, lo);
+                        amax = fmaxf(fmaxf(amax, fmaxf(v[0], v[1])), fmaxf(v[2], v[3]));       // (post-ReLU: non-negative; two v_max3)
                         *(h4*)&nxt[a16_idx<WS>(row, f0)] = hi;
                         *(h4*)&nxt[a16_idx<WS>(row, 256 + f0)] = lo;
                     } else {
@@ -589,6 +592,12 @@ __device__ __forceinline__ void mlp16_fwd_body(Mlp16Dev p, float* __restrict__ o
         __syncthreads();
         if (saved_hT) store_T(nxt, saved_hT + (size_t)l * t16_elems(NS * M16_W, p.rows), M16_W);
         T* t = cur; cur = nxt; nxt = t;
+    }
+    if constexpr (SP) {
+        // The range guard of "fp32s" (round-4 verdict): hi = fp16(x) saturates at 65504 -- silently.  An activation at or above 2^15
+        // (a factor 2 of headroom) raises the caller's flag; the host then re-runs the pass on the exact-fp32 kernels or, checking
+        // lazily, switches to them from the next pass on (deform_ops / deformable_field.py).  NaN compares false: not flagged here.
+        if (p.range_flag && amax >= 32768.f) atomicOr(p.range_flag, 1u);
     }
     {   // output layer: W4 padded to [32][256]; the 4 waves split K, reduce through LDS (fp32)
         f32x16 acc[RT];
@@ -1174,6 +1183,7 @@ static int make16(const gp_mlp16_params* p, const gp_mlp_input* x, Mlp16Dev& m, 
         m.wlo[l] = p->dtype == GP_DTYPE_F16_SPLIT ? (const void*)((const _Float16*)p->w16[l] + elems) : nullptr;
     }
     m.feature = x->feature; m.xyz = x->xyz; m.t = x->t;
+    m.range_flag = p->range_flag;
     return 0;
 }
 

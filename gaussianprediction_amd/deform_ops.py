@@ -192,7 +192,9 @@ class FusedMlp16(torch.autograd.Function):
     fp32-grade results).  Opt-in."""
 
     @staticmethod
-    def forward(ctx, feature, xyz, t, xyz_freq, time_freq, precision, *wb):
+    def forward(ctx, feature, xyz, t, xyz_freq, time_freq, precision, range_flag, *wb):
+        """`range_flag`: None, or an int32 [1] device tensor the split-mode ("fp32s") kernel ORs 1 into when a hidden activation
+        reached 2^15 (gp_mlp16_params.range_flag; Deformable_Field's range guard)."""
         _need_cuda(feature, "FusedMlp16")
         dev = feature.device
         tdt = {"fp16": torch.float16, "bf16": torch.bfloat16, "fp32s": torch.float16}[precision]
@@ -222,6 +224,8 @@ class FusedMlp16(torch.autograd.Function):
         for l in range(5):
             params.w16[l] = w16[l].data_ptr()
             params.b[l] = bs[l].data_ptr()
+        if split and range_flag is not None:
+            params.range_flag = range_flag.data_ptr()
         inp = _lib.MlpInputC(rows, fd, int(xyz_freq), int(time_freq), feature_c.data_ptr(),
                              xyz_c.data_ptr() if xyz_c is not None else None, t_c.data_ptr() if t_c is not None else None)
         with _lib.on_device(dev):
@@ -288,7 +292,7 @@ class FusedMlp16(torch.autograd.Function):
         if use_sink:
             for t_ in leaves:
                 grad_sink.notify(t_)
-        return (g_feat, g_xyz, None, None, None, None, *wb_grads)
+        return (g_feat, g_xyz, None, None, None, None, None, *wb_grads)
 
 
 def _overwrite_sink(leaf):

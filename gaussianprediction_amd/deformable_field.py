@@ -14,15 +14,25 @@ from .deform_ops import FusedMlp, FusedMlp16
 
 
 class Deformable_Field(nn.Module):
-    def __init__(self, input_dim, output_dim=10, d=8, w=256, use_softmax=False, split_xyz=False, precision="fp32"):
+    def __init__(self, input_dim, output_dim=10, d=8, w=256, use_softmax=False, split_xyz=False, precision="fp32", range_guard="lazy"):
         """`precision` (extension): "fp32" = exact-fp32 matrix cores (default); "fp32s" = fp32 operands carried as fp16 (hi, lo')
         pairs on the 16-bit matrix cores (22 significant bits, fp32 accumulation: meets the fp32 kernels' test bars at ~2x their speed;
         |activations| < 65504); "fp16" / "bf16" = 16-bit operands with fp32 accumulation, ~16x the MFMA rate (BASELINE config 5).
-        The 16-bit kernels serve calls with more than 2048 rows; smaller ones always use the exact-fp32 small-row kernels."""
+        The 16-bit kernels serve calls with more than 2048 rows; smaller ones always use the exact-fp32 small-row kernels.
+        `range_guard` ("fp32s" only): the (hi, lo') form saturates at the fp16 range, silently; the split kernel therefore raises a
+        device flag when a hidden activation reaches 2^15.  "sync": the flag is read after every pass (one host synchronisation)
+        and a flagged pass is REPEATED on the exact-fp32 kernels; "lazy" (default): the flag travels to the host asynchronously and
+        is looked at when the next pass starts -- a flagged model switches to the exact-fp32 kernels from then on, with a warning
+        (the flagged pass itself ran saturated: finite, and wrong where an activation exceeded 65504); "off": no flag."""
         super().__init__()
         if precision not in ("fp32", "fp32s", "fp16", "bf16"):
             raise ValueError("precision must be fp32, fp32s, fp16 or bf16")
         self.precision = precision
+        if range_guard not in ("lazy", "sync", "off"):
+            raise ValueError("range_guard must be lazy, sync or off")
+        self.range_guard = range_guard
+        self.range_tripped = False            # an activation left the split form's range: the exact-fp32 kernels from now on
+        self._flag = self._flag_host = self._flag_event = None
         if split_xyz or use_softmax:
             raise NotImplementedError("split_xyz / use_softmax are dead branches in the reference "
                                       "(scene/gaussian_model.py:79) and are not implemented")
@@ -55,6 +65,37 @@ class Deformable_Field(nn.Module):
         [M,256] activations never touch HBM in inference."""
         # 16-bit operands pay off for the per-Gaussian passes (10^5..10^6 rows).  A few hundred rows (the keypoints of
         # stage 2/3) are a latency problem, for which the 16-row fp32 kernels are both faster and exact.
-        if self.precision != "fp32" and feature.shape[0] > 2048:
-            return FusedMlp16.apply(feature, xyz, t, xyz_freq, time_freq, self.precision, *self._wb())
+        if self.precision != "fp32" and feature.shape[0] > 2048 and not self.range_tripped:
+            guard = self.range_guard if self.precision == "fp32s" else "off"
+            flag = self._range_flag(feature.device) if guard != "off" else None
+            if flag is not None and self.range_tripped:                       # (the lazy check just tripped)
+                return FusedMlp.apply(feature, xyz, t, xyz_freq, time_freq, *self._wb())
+            out = FusedMlp16.apply(feature, xyz, t, xyz_freq, time_freq, self.precision, flag, *self._wb())
+            if guard == "sync":
+                if int(flag.item()) != 0:                                     # this pass saturated: repeat it exactly
+                    self._trip("this pass was repeated on the exact-fp32 kernels")
+                    return FusedMlp.apply(feature, xyz, t, xyz_freq, time_freq, *self._wb())
+            elif guard == "lazy":
+                self._flag_host.copy_(flag, non_blocking=True)
+                self._flag_event = torch.cuda.Event()
+                self._flag_event.record()
+            return out
         return FusedMlp.apply(feature, xyz, t, xyz_freq, time_freq, *self._wb())
+
+    def _trip(self, what):
+        import warnings
+        self.range_tripped = True
+        warnings.warn("Deformable_Field(precision='fp32s'): a hidden activation reached 2^15 (the split-fp16 form saturates at 65504); "
+                      + what + "; every later pass uses them too", RuntimeWarning, stacklevel=3)
+
+    def _range_flag(self, device):
+        """The device word of the range guard (created on first use); in lazy mode first looks at what the PREVIOUS pass left."""
+        if self._flag is None or self._flag.device != device:
+            self._flag = torch.zeros(1, dtype=torch.int32, device=device)
+            self._flag_host = torch.zeros(1, dtype=torch.int32).pin_memory()
+            self._flag_event = None
+        if self.range_guard == "lazy" and self._flag_event is not None and self._flag_event.query():
+            self._flag_event = None
+            if int(self._flag_host[0]) != 0:
+                self._trip("the pass that raised the flag ran saturated; from this pass on the exact-fp32 kernels run")
+        return self._flag

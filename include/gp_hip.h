@@ -225,6 +225,8 @@ typedef struct gp_mlp16_params {
     int32_t in_dim, width, depth, out_dim;
     const void* w16[5];
     const float* b[5];
+    uint32_t* range_flag;   /* optional device word (GP_DTYPE_F16_SPLIT forward): OR-ed with 1 when a hidden activation reached 2^15 --
+                             * half the fp16 range the (hi, lo') form saturates at; the caller then repeats the pass with gp_mlp_forward */
 } gp_mlp16_params;
 /* saved (training, all optional together), 16-bit, BLOCKED by 16 rows, rows zero-padded to a multiple of 64:
  * xT [ceil(rows/64)*4][in_pad16][16] and hT [4][ceil(rows/64)*4][256][16]

@@ -35,7 +35,7 @@ def test_mlp_matches_reference_golden_vectors(precision):
         gy = torch.tensor(np.random.default_rng(seed + 200).normal(size=(M, d_out)).astype(np.float32), device="cuda")
         if precision == "fp32s":      # the split-fp16 kernels on the plain-input form (no encoding): feature = x
             from gaussianprediction_amd.deform_ops import FusedMlp16
-            y = FusedMlp16.apply(x, None, None, 0, 0, "fp32s", *net._wb())
+            y = FusedMlp16.apply(x, None, None, 0, 0, "fp32s", None, *net._wb())
         else:
             y = net(x)
         (y * gy).sum().backward()
@@ -92,7 +92,7 @@ def _check_mlp_against_f64(rows, F, out_dim, split):
     fd, xd = feat.cuda().requires_grad_(True), xyz.cuda().requires_grad_(True)
     if split:
         from gaussianprediction_amd.deform_ops import FusedMlp16
-        y = FusedMlp16.apply(fd, xd, t.cuda(), 10, F, "fp32s", *net._wb())
+        y = FusedMlp16.apply(fd, xd, t.cuda(), 10, F, "fp32s", None, *net._wb())
     else:
         y = net.forward_fused(fd, xd, t.cuda(), 10, F)
     (y * gy.cuda()).sum().backward()
@@ -194,7 +194,7 @@ def test_fused_mlp16_close_to_fp32(precision, tol_y, tol_g, rows, F, out_dim):
     (y64 * gy.double()).sum().backward()
     fd, xd = feat.cuda().requires_grad_(True), xyz.cuda().requires_grad_(True)
     from gaussianprediction_amd.deform_ops import FusedMlp16
-    y = FusedMlp16.apply(fd, xd, t.cuda(), 10, F, precision, *net._wb())      # the 16-bit kernels at every row count
+    y = FusedMlp16.apply(fd, xd, t.cuda(), 10, F, precision, None, *net._wb())      # the 16-bit kernels at every row count
     (y * gy.cuda()).sum().backward()
     scale = float(y64.detach().abs().max())
     assert np.abs(y.detach().cpu().numpy() - y64.detach().numpy()).max() < tol_y * max(scale, 1e-3)
@@ -260,3 +260,57 @@ def test_small_row_mlp_with_fragment_ordered_weights_is_bit_identical():
     assert torch.equal(y3.detach(), y2)
     for a, b in zip([p.grad for p in net.parameters()] + [f2.grad], g_ref):
         assert torch.equal(a, b)
+
+
+# ---- the range guard of precision="fp32s" (round-4 verdict: hi = fp16(x) saturates at 65504, silently) ----------------------------------
+def _scaled_net(scale, seed=3):
+    net, _ = _net(seed, 104, 7)
+    with torch.no_grad():
+        net.mlp[0].weight.mul_(scale)          # hidden activations of layer 0 grow by `scale`; the later layers carry them on
+        net.mlp[0].bias.mul_(scale)
+    return net
+
+
+@pytest.mark.parametrize("guard", ["sync", "lazy"])
+def test_fp32s_range_guard_detects_saturation_and_falls_back_to_the_exact_kernels(guard):
+    """Layer-0 weights scaled by 2^17: hidden activations beyond 65504.  `sync`: the flagged pass is repeated on the exact-fp32 kernels
+    (results = the fp32 path's); `lazy`: the flag is seen when the NEXT pass starts and the model stays on the exact kernels from
+    there; an unscaled model raises nothing and keeps the split kernels."""
+    import warnings
+    rows, F = 5000, 6
+    g = torch.Generator().manual_seed(0)
+    feat = (torch.rand(rows, 32, generator=g) * 2 - 1).cuda()
+    xyz = (torch.rand(rows, 3, generator=g) * 2 - 1).cuda()
+    t = torch.tensor([0.3]).cuda()
+    # (1) no overflow: nothing trips, the split kernels stay
+    net = _scaled_net(1.0)
+    net.precision, net.range_guard = "fp32s", guard
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        for _ in range(3):
+            y = net.forward_fused(feat, xyz, t, 10, F)
+            torch.cuda.synchronize()
+    assert not net.range_tripped and bool(torch.isfinite(y).all())
+    # (2) overflow
+    big = _scaled_net(2.0 ** 17)
+    ref = _scaled_net(2.0 ** 17)
+    ref.precision = "fp32"
+    y_ref = ref.forward_fused(feat, xyz, t, 10, F)
+    assert float(torch.relu(torch.nn.functional.linear(torch.cat([feat, do.positional_encoding(xyz.cpu(), 10).cuda(),
+                 do.positional_encoding(t.cpu(), F).cuda().expand(rows, -1)], 1), big.mlp[0].weight, big.mlp[0].bias)).max()) > 65504.0
+    big.precision, big.range_guard = "fp32s", guard
+    with pytest.warns(RuntimeWarning, match="2\\^15"):
+        y1 = big.forward_fused(feat, xyz, t, 10, F)
+        torch.cuda.synchronize()
+        if guard == "lazy":
+            assert not big.range_tripped and bool(torch.isfinite(y1).all())      # (saturated, finite: the flag is still in flight)
+            y1 = big.forward_fused(feat, xyz, t, 10, F)                          # the next pass sees it and runs exactly
+    assert big.range_tripped
+    torch.testing.assert_close(y1, y_ref, rtol=1e-5, atol=1e-5 * float(y_ref.abs().max()))
+    y2 = big.forward_fused(feat, xyz, t, 10, F)                                 # ... and so does every later one, with its backward
+    torch.testing.assert_close(y2, y_ref, rtol=1e-5, atol=1e-5 * float(y_ref.abs().max()))
+    # guard off: the pass runs saturated and nothing is said
+    off = _scaled_net(2.0 ** 17)
+    off.precision, off.range_guard = "fp32s", "off"
+    y3 = off.forward_fused(feat, xyz, t, 10, F)
+    assert not off.range_tripped and bool(torch.isfinite(y3).all()) and not torch.allclose(y3, y_ref, rtol=1e-3, atol=1e-3 * float(y_ref.abs().max()))
