@@ -22,8 +22,7 @@ extern "C" int gp_train_step_run(const gp_step_plan* p, const gp_step_view* v, c
     if (!p->g_xyz || !p->g_scaling || !p->g_rotation || !p->g_opacity || !p->g_keypoints || !p->g_keypoint_features)
         GP_FAIL("gp_train_step_run: null gradient pointer");
     if (!u->adam_shs && (!p->g_features_dc || !p->g_features_rest)) GP_FAIL("gp_train_step_run: SH gradient buffers or adam_shs needed");
-    if (!p->delta || !p->acts || !p->xyz_t || !p->q_t || !p->scale || !p->opacity_t || !p->loss_sums || !p->dmaps || !p->loss ||
-        !p->dL_dimage || !p->g_xyz_t || !p->g_q_t || !p->g_scale || !p->g_opacity_t || !p->g_means2D || !p->g_delta || !p->g_feature_tmp)
+    if (!p->delta || !p->acts || !p->xyz_t || !p->q_t || !p->scale || !p->opacity_t || !p->loss_sums || !p->loss || !p->g_xyz_t || !p->g_q_t || !p->g_scale || !p->g_opacity_t || !p->g_means2D || !p->g_delta || !p->g_feature_tmp)
         GP_FAIL("gp_train_step_run: null intermediate buffer");
     if (!v->bg || !v->viewmatrix || !v->projmatrix || !v->campos || !v->gt_image || !v->time) GP_FAIL("gp_train_step_run: null view pointer");
     const int H = p->image_height, W = p->image_width, od = p->mlp.out_dim;
@@ -60,23 +59,35 @@ extern "C" int gp_train_step_run(const gp_step_plan* p, const gp_step_view* v, c
     alloc(alloc_ctx, GP_BUF_TEMP_DONE, 0);
     if (u->hook) u->hook(u->hook_ctx, GP_STEP_AFTER_FORWARD);
 
-    // ---- loss [REF train.py:105-109, utils/loss_utils.py:54-100] and its image gradient
-    if (gp_loss_l1_ssim_forward(out.color, v->gt_image, 3, H, W, p->loss_sums, p->dmaps, stream)) return 1;
+    // ---- loss [REF train.py:105-109, utils/loss_utils.py:54-100] and its image gradient.  The SSIM derivative maps live from the
+    // loss forward to the loss backward only: with NULL in the plan they are a TEMP buffer -- the allocator hands out the memory the
+    // rasterizer forward's sort just used and the rasterizer backward's accumulators use next (TEMP_DONE below), so they add nothing
+    // to the step's working set (9 floats per pixel: 49 MB at 1352 x 1014).  The image gradient is read by the composite backward
+    // WHILE those accumulators are written: it stays a buffer of its own.
+    float* dmaps = p->dmaps;
+    float* dimg = p->dL_dimage;
+    if (!dimg) GP_FAIL("gp_train_step_run: null intermediate buffer");
+    if (!dmaps) {
+        dmaps = (float*)alloc(alloc_ctx, GP_BUF_TEMP, gp_align_up((size_t)9 * H * W * 4, 256));
+        if (!dmaps) GP_FAIL("gp_train_step_run: allocator returned NULL for the SSIM derivative maps");
+    }
+    if (gp_loss_l1_ssim_forward(out.color, v->gt_image, 3, H, W, p->loss_sums, dmaps, stream)) return 1;
     if (reg) {
         if (gp_loss_l1_ssim_finalize_reg(p->loss_sums, 3, H, W, p->lambda_dssim, p->keypoint_features, nfeat, p->reg_scale, p->loss, stream)) return 1;
-        if (gp_loss_l1_ssim_backward_reg(out.color, v->gt_image, p->dmaps, 3, H, W, p->lambda_dssim, nullptr, p->dL_dimage,
+        if (gp_loss_l1_ssim_backward_reg(out.color, v->gt_image, dmaps, 3, H, W, p->lambda_dssim, nullptr, dimg,
                                          p->keypoint_features, nfeat, p->reg_scale, p->g_keypoint_features, stream)) return 1;
     } else {
         if (gp_loss_l1_ssim_finalize(p->loss_sums, 3, H, W, p->lambda_dssim, p->loss, stream)) return 1;
-        if (gp_loss_l1_ssim_backward(out.color, v->gt_image, p->dmaps, 3, H, W, p->lambda_dssim, nullptr, p->dL_dimage, stream)) return 1;
+        if (gp_loss_l1_ssim_backward(out.color, v->gt_image, dmaps, 3, H, W, p->lambda_dssim, nullptr, dimg, stream)) return 1;
     }
 
+    if (!p->dmaps) alloc(alloc_ctx, GP_BUF_TEMP_DONE, 0);
     // ---- backward, in the order autograd runs it
     gp_raster_grads g;
     memset(&g, 0, sizeof(g));
     g.dL_dmeans3D = p->g_xyz_t; g.dL_dmeans2D = p->g_means2D; g.dL_dshs = p->g_features_dc; g.dL_dshs_rest = p->g_features_rest;
     g.dL_dopacities = p->g_opacity_t; g.dL_dscales = p->g_scale; g.dL_drotations = p->g_q_t; g.accumulate_shs = 0; g.adam_shs = u->adam_shs;
-    if (gp_raster_backward(&st, &in, &out, &saved, p->dL_dimage, nullptr, &g, alloc, alloc_ctx, stream)) return 1;
+    if (gp_raster_backward(&st, &in, &out, &saved, dimg, nullptr, &g, alloc, alloc_ctx, stream)) return 1;
     alloc(alloc_ctx, GP_BUF_TEMP_DONE, 0);
     if (u->hook) u->hook(u->hook_ctx, GP_STEP_AFTER_RASTER_BACKWARD);
     if (gp_activations_backward(N, p->scaling, p->opacity, nullptr, 0, 1.f, p->g_scale, p->g_opacity_t, p->g_scaling, p->g_opacity, nullptr, stream))

@@ -54,7 +54,7 @@ class FusedStage3:
             delta=e(K, out_dim), acts=e((K * in_pad + 63) // 64 * 64 + 4 * K * 256 + 4 * K * 8), xyz_t=e(N, 3), q_t=e(N, 4), scale=e(N, 3),
             opacity_t=e(N, 1), color=e(3, H, W), radii=e(N, dtype=torch.int32), depth=e(1, H, W),
             tidx=e(H, W, dtype=torch.int32), visible=e(N, dtype=torch.uint8),
-            loss_sums=e(2 * _lib.GP_LOSS_SUM_SLOTS(H, W), dtype=torch.float64), dmaps=e(3, 3, H, W), loss=e(1),
+            loss_sums=e(2 * _lib.GP_LOSS_SUM_SLOTS(H, W), dtype=torch.float64), loss=e(1),
             dL_dimage=e(3, H, W), g_xyz_t=e(N, 3), g_q_t=e(N, 4), g_scale=e(N, 3), g_opacity_t=e(N, 1), g_means2D=e(N, 3),
             g_delta=e(K, out_dim), g_feature_tmp=e(K, fd))
         offs, off = [], 0
@@ -89,7 +89,8 @@ class FusedStage3:
         P.feature_dim, P.xyz_freq, P.time_freq = fd, xyz_freq, time_freq
         P.raw_w, P.knn_idx = self.raw_w.data_ptr(), self.knn.data_ptr()
         P.knn_idx16 = self.idx16.data_ptr() if self.idx16 is not None else None
-        for k in ("delta", "acts", "xyz_t", "q_t", "scale", "opacity_t", "loss_sums", "dmaps", "loss", "dL_dimage", "g_xyz_t", "g_q_t",
+        P.dmaps = None      # (a TEMP buffer of the call: it shares memory with the sort's and the backward's scratch)
+        for k in ("delta", "acts", "xyz_t", "q_t", "scale", "opacity_t", "loss_sums", "loss", "dL_dimage", "g_xyz_t", "g_q_t",
                   "g_scale", "g_opacity_t", "g_means2D", "g_delta", "g_feature_tmp"):
             setattr(P, k, self.buf[k].data_ptr())
         P.out = _lib.RasterOutputsC(self.buf["color"].data_ptr(), self.buf["radii"].data_ptr(), self.buf["depth"].data_ptr(),

@@ -376,7 +376,7 @@ typedef struct gp_step_plan {
     float *xyz_t, *q_t, *scale, *opacity_t;               /* [N,3] [N,4] [N,3] [N,1] */
     gp_raster_outputs out;       /* color [3,H,W], radii [N], depth [1,H,W], tidx [H,W], visible [N] (optional) */
     double* loss_sums;           /* 2 * GP_LOSS_SUM_SLOTS(H, W) */
-    float* dmaps;                /* [3,3,H,W] */
+    float* dmaps;                /* [3,3,H,W], or NULL: taken from the allocator as a TEMP buffer (it is dead before the backward's own TEMP) */
     float* loss;                 /* [1] */
     float* dL_dimage;            /* [3,H,W] */
     float *g_xyz_t, *g_q_t, *g_scale, *g_opacity_t;       /* [N,3] [N,4] [N,3] [N,1] */
