@@ -7,7 +7,7 @@ set -u
 OUT=${1:-gpurun_out/evidence}
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-B="python bench.py --no-cpu-baseline --no-weights-model-step"
+B="python bench.py --no-cpu-baseline --no-weights-model-step --no-dense-variant"
 timeout 600 python bench.py --steps 200 --warmup 30 > "$OUT/bench.json" 2> "$OUT/bench.err"
 timeout 300 rocprofv3 --kernel-trace --stats -d "$OUT/stats" -o s --output-format csv -- $B --steps 20 --warmup 5 > "$OUT/bench_under_rocprof.json" 2> "$OUT/stats.log"
 for c in FETCH_SIZE WRITE_SIZE; do
