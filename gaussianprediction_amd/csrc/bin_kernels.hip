@@ -420,7 +420,30 @@ __global__ __launch_bounds__(BIN_THREADS) void gp_bin_scatter_kernel(int N, int 
 // Gaussians per block G = 256 ... 8192 (1 ... 32 register-resident chunks of 64 per wave of the scatter kernel), at most 512
 // blocks: up to 4.2 M Gaussians; beyond that -- or beyond GP_BIN_MAX_TILES tiles -- the caller falls back to duplicate + radix sort.
 // (gp_debug_option(5, 1) forces that path: the A/B switch of tools/ and of the parity tests)
-bool gp_bin_supported(size_t N, size_t T) { return N > 0 && N <= 512u * 8192u && T >= 1 && T <= GP_BIN_MAX_TILES && gp_debug_get(5) == 0; }
+// The two kernels need the whole per-tile histogram in ONE workgroup's LDS: dynamic (4 + 2 BIN_WAVES) T bytes for the scatter, 2 BIN_WAVES T for
+// the count, plus a few KB of static arrays (bounded below by 32 KB: the count kernel's per-wave records).  gfx950 offers 160 KB per
+// workgroup; the device's own figure is asked once (round-4 advisor: on a part with a smaller limit the launch would fail where the
+// duplicate + radix-sort path could have taken over).  The DPP row_bcast scans of these kernels (gp_wave_scan_add) are gfx9 / CDNA forms:
+// the library is built for gfx950 only (__graft_entry__.HIP_FLAGS), nothing else can load it.
+static size_t bin_lds_limit() {
+    static thread_local int cached_dev = -1;
+    static thread_local size_t cached = 0;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 64 * 1024;
+    if (dev != cached_dev) {
+        int v = 0;
+        cached = (hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) == hipSuccess && v > 0) ? (size_t)v : 64 * 1024;
+        cached_dev = dev;
+    }
+    return cached;
+}
+static size_t bin_lds_need(size_t T) {
+    const size_t packed = (size_t)BIN_WAVES * ((T + 1) / 2) * sizeof(uint32_t);
+    return 32 * 1024 + T * sizeof(uint32_t) + packed;      // (the larger of the two kernels + the static bound)
+}
+bool gp_bin_supported(size_t N, size_t T) {
+    return N > 0 && N <= 512u * 8192u && T >= 1 && T <= GP_BIN_MAX_TILES && gp_debug_get(5) == 0 && bin_lds_need(T) <= bin_lds_limit();
+}
 
 GpBinPlan gp_bin_plan(size_t N, size_t T) {
     GpBinPlan p;
