@@ -37,11 +37,10 @@ class FusedStage3:
         in_dim, out_dim = wb[0].shape[1], wb[8].shape[0]
         nn_ = pc.knn_idx.shape[1]
         f32 = dict(dtype=torch.float32, device=dev)
-        # The intermediates are carved out of ONE block at staggered offsets.  As separate torch.empty() tensors the per-Gaussian arrays
-        # ([N,3], [N,4], [N,1] floats: several MB each) all start on 2 MB boundaries, the projection kernels walk a dozen of them at
-        # the same relative offset, and those streams fall on the same HBM channels: preprocess fwd / bwd and the blend backward ran
-        # 4 - 7 % slower than in the graph path, whose per-step allocations land wherever the caching allocator has room.
-        sizes, self._stagger = [], int(__import__("os").environ.get("GP_FUSED_STAGGER", "4352"))
+        # The intermediates are carved out of ONE block (their addresses never change: the plan is filled once).  (An experiment on the
+        # way: the first version of the fused step ran its HBM-bound kernels 4 - 7 % slower than the graph path; staggering these
+        # buffers' start addresses against each other changed nothing -- the cause was the step's working set, see GP_BUF_TEMP_DONE.)
+        sizes = []
 
         def e(*shape, dtype=torch.float32):
             n = 1
@@ -59,7 +58,7 @@ class FusedStage3:
             g_delta=e(K, out_dim), g_feature_tmp=e(K, fd))
         offs, off = [], 0
         for k, (_, _, nbytes) in enumerate(sizes):
-            off = (off + 255) // 256 * 256 + (k % 13) * self._stagger
+            off = (off + 255) // 256 * 256
             offs.append(off)
             off += nbytes
         self._block = torch.empty(off + 256, dtype=torch.uint8, device=dev)
@@ -127,7 +126,7 @@ class FusedStage3:
             return False
         if ts.reducer.enabled and not (ts.sharded and hasattr(ts.reducer, "gather_params")):
             return False                     # (view-parallel: the sharded exchange only; all-reduce + replicated Adam stays on the graph path)
-        if pc.raw_weights is None or pc.knn_idx is None or getattr(pc, "weights_model", None) is not None and pc.raw_weights is None:
+        if pc.raw_weights is None or pc.knn_idx is None:      # (the per-frame weights model + kNN have autograd functions of their own)
             return False
         if a.step_opacity and ts.iteration > a.step_opacity_iteration:
             return False

@@ -348,3 +348,31 @@ def test_c4_single_gpu_form_lifecycle_opacity_batch_of_views():
     assert pkg["radii"].shape == (N,) and int(pkg["visibility_filter"].sum()) > N // 2
     assert torch.isfinite(pc._xyz).all() and not torch.equal(pc._xyz.detach(), x0)
     assert all(torch.isfinite(p).all() for p in pc.df_model.parameters())
+
+
+def test_c3_fused_step_equals_the_graph_step_at_full_size():
+    """configs[2] at FULL size (1 M Gaussians, 1352 x 1014, K = 250) -- the bench's own workload: three steps at zero learning rates
+    through gp_train_step_run and through the autograd graph leave the same Adam moments (= the same gradients, every tensor) and
+    the same losses; the step the bench times is the step the parity tests check."""
+    import bench
+    from gaussianprediction_amd.train_step import TrainStep
+    args = SimpleNamespace(gaussians=1_000_000, width=1352, height=1014, keypoints=250, nearest_num=6, time_freq=8, iteration=50000,
+                           scale_lo=0.003, scale_hi=0.012)
+    zero = dict(xyz=0.0, f_dc=0.0, opacity=0.0, scaling=0.0, rotation=0.0, kpts=0.0, mlp=0.0)
+    res = []
+    for fused in (True, False):
+        pc, cams, gts, margs = bench.build_workload(args, torch.device("cuda", 0))
+        ts = TrainStep(pc, cams, gts, 50000, lrs=zero, speculative=True, fused=fused)
+        pre = len(cams) + TrainStep.SPEC_SLOTS
+        losses = [float(ts.step(i)[0]) for i in range(pre + 3)]
+        torch.cuda.synchronize()
+        assert ts.fused_steps == (3 if fused else 0) and ts.redone == 0
+        sd = pc.optimizer.state_dict()
+        res.append(dict(loss=losses, state={k: v["exp_avg"].clone() for k, v in sd["state"].items()}, names=[g["name"] for g in sd["param_groups"]]))
+        del pc, ts
+        torch.cuda.empty_cache()
+    a, b = res
+    assert np.allclose(a["loss"], b["loss"], rtol=5e-6, atol=1e-7), (a["loss"], b["loss"])
+    for k in a["state"]:
+        e = float((a["state"][k] - b["state"][k]).norm() / b["state"][k].norm().clamp_min(1e-30))
+        assert e < 5e-5, (k, e)
