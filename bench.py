@@ -578,6 +578,9 @@ def main():
                        "binning": "exact (R read back every step)" if args.exact_binning else
                                   f"capacity mode in warm-up and timed steps (no host sync; {preroll} exact-mode set-up steps before the "
                                   f"warm-up; {getattr(ts, 'redone', 0)} frames repeated after overflow)",
+                       "depth_sort": "32-bit keys, four 8-bit passes" if not getattr(ts, "last_depth_key_promise", None) else
+                                     (f"{ts.last_depth_key_promise[0]}-bit keys above a promised base ({-(-ts.last_depth_key_promise[0] // 8)} passes; the "
+                                      "projection kernel checks the promise, a broken one repeats the frame like a binning overflow)"),
                        "keypoint_weights": "raw_weights / knn_idx are inputs of the step (BASELINE.json north_star); the reference "
                                            "recomputes them per frame (hash-grid weights model + kNN): see train_step_with_weights_model_ms"},
             "roofline": roof,

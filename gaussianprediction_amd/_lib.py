@@ -29,7 +29,8 @@ class RasterSettingsC(C.Structure):
                 ("tanfovy", C.c_float), ("scale_modifier", C.c_float), ("sh_degree", C.c_int32),
                 ("sh_coeffs", C.c_int32), ("prefiltered", C.c_int32), ("debug", C.c_int32),
                 ("bg", C.c_void_p), ("viewmatrix", C.c_void_p), ("projmatrix", C.c_void_p), ("campos", C.c_void_p),
-                ("binning_capacity", C.c_int64), ("binning_status", C.c_void_p), ("sh_ready_event", C.c_void_p)]
+                ("binning_capacity", C.c_int64), ("binning_status", C.c_void_p), ("sh_ready_event", C.c_void_p),
+                ("depth_key_bits", C.c_int32), ("depth_key_base", C.c_uint32), ("depth_key_range", C.c_void_p)]
 
 
 class RasterInputsC(C.Structure):
@@ -118,7 +119,8 @@ STEP_HOOK_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_int32)
 
 class StepUpdateC(C.Structure):
     """gp_step_update."""
-    _fields_ = [("binning_capacity", C.c_int64), ("binning_status", C.c_void_p), ("sh_ready_event", C.c_void_p), ("adam_shs", C.c_void_p),
+    _fields_ = [("binning_capacity", C.c_int64), ("binning_status", C.c_void_p), ("depth_key_bits", C.c_int32), ("depth_key_base", C.c_uint32),
+                ("sh_ready_event", C.c_void_p), ("adam_shs", C.c_void_p),
                 ("adam_count", C.c_int32), ("adam_params", C.c_void_p), ("adam_grads", C.c_void_p), ("adam_exp_avgs", C.c_void_p),
                 ("adam_exp_avg_sqs", C.c_void_p), ("adam_numels", C.c_void_p), ("adam_lrs", C.c_void_p), ("adam_steps", C.c_void_p),
                 ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float), ("step", C.c_int64), ("keep_grad_mask", C.c_uint32),

@@ -234,7 +234,7 @@ __global__ __launch_bounds__(BIN_THREADS) void gp_bin_scatter_kernel(int N, int 
                                                                      const uint32_t* __restrict__ wave_cnt,
                                                                      uint32_t* __restrict__ point_list, uint32_t capacity,
                                                                      int2* __restrict__ ranges, uint32_t* __restrict__ status, int ablate,
-                                                                     uint32_t* __restrict__ order, int n_chunks) {
+                                                                     uint32_t* __restrict__ order, int n_chunks, uint32_t key_tag) {
     extern __shared__ uint32_t s_dyn[];
     __shared__ BinWave s_w[BIN_WAVES];
     __shared__ uint32_t s_wsum[BIN_WAVES];
@@ -334,7 +334,7 @@ __global__ __launch_bounds__(BIN_THREADS) void gp_bin_scatter_kernel(int N, int 
         }
         if (blockIdx.x == 0 && tid == BIN_THREADS - 1 && status) {      // (the last thread's running sum is the grand total R)
             status[0] = run;
-            status[1] = run > capacity ? 1u : 0u;
+            status[1] = (run > capacity || (key_tag && status[2] == key_tag)) ? 1u : 0u;      // (key_tag: gp_raster_settings.depth_key_bits)
         }
     }
     __syncthreads();
@@ -483,20 +483,20 @@ int gp_bin_count(const GpBinPlan& p, size_t N, int gx, size_t T, const uint2* re
 template <int CH>
 static int bin_scatter_launch(const GpBinPlan& p, size_t N, int gx, size_t T, const uint32_t* sorted_ids, const uint2* rect_sorted, const uint32_t* hist,
                               const uint32_t* totals, const uint32_t* wave_cnt, uint32_t* point_list, uint32_t capacity, int2* ranges, uint32_t* status, size_t lds,
-                              uint32_t* order, hipStream_t s) {
+                              uint32_t* order, uint32_t key_tag, hipStream_t s) {
     static thread_local size_t lds_set = 0;
     if (lds > 48 * 1024 && lds > lds_set) {
         GP_HIP_CHECK(hipFuncSetAttribute((const void*)gp_bin_scatter_kernel<CH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         lds_set = lds;
     }
     hipLaunchKernelGGL(gp_bin_scatter_kernel<CH>, dim3((unsigned)p.NB + (order ? 1u : 0u)), dim3(BIN_THREADS), lds, s, (int)N, gx, (int)T, sorted_ids,
-                       rect_sorted, hist, totals, wave_cnt, point_list, capacity, ranges, status, gp_debug_get(6), order, p.NB);
+                       rect_sorted, hist, totals, wave_cnt, point_list, capacity, ranges, status, gp_debug_get(6), order, p.NB, key_tag);
     GP_LAUNCH_CHECK();
     return 0;
 }
 
 int gp_bin_scatter(const GpBinPlan& p, size_t N, int gx, size_t T, const uint32_t* sorted_ids, const uint2* rect_sorted, uint32_t* hist,
-                   uint32_t* point_list, uint32_t capacity, int2* ranges, uint32_t* status, uint32_t* order, hipStream_t s) {
+                   uint32_t* point_list, uint32_t capacity, int2* ranges, uint32_t* status, uint32_t* order, uint32_t key_tag, hipStream_t s) {
     uint32_t* totals = hist + (size_t)p.NB * T;
     {
         GpProfScope _p("bin_scan", s);
@@ -507,12 +507,12 @@ int gp_bin_scatter(const GpBinPlan& p, size_t N, int gx, size_t T, const uint32_
     if (order && lds < 1024 + T + 4) lds = 1024 + T + 4;        // (the tile-order workgroup's two 128-entry tables and a byte per tile)
     if (gp_debug_get(6)) GP_HIP_CHECK(hipMemsetAsync(point_list, 0, (size_t)capacity * 4, s));   // (ablation runs leave slots unwritten: id 0 is a valid one)
     GpProfScope _p("bin_scatter", s);
-    if (p.G == 256) return bin_scatter_launch<1>(p, N, gx, T, sorted_ids, rect_sorted, hist, totals, bin_wave_cnt(p, T, hist), point_list, capacity, ranges, status, lds, order, s);
-    if (p.G == 512) return bin_scatter_launch<2>(p, N, gx, T, sorted_ids, rect_sorted, hist, totals, bin_wave_cnt(p, T, hist), point_list, capacity, ranges, status, lds, order, s);
-    if (p.G == 1024) return bin_scatter_launch<4>(p, N, gx, T, sorted_ids, rect_sorted, hist, totals, bin_wave_cnt(p, T, hist), point_list, capacity, ranges, status, lds, order, s);
-    if (p.G == 2048) return bin_scatter_launch<8>(p, N, gx, T, sorted_ids, rect_sorted, hist, totals, bin_wave_cnt(p, T, hist), point_list, capacity, ranges, status, lds, order, s);
-    if (p.G == 4096) return bin_scatter_launch<16>(p, N, gx, T, sorted_ids, rect_sorted, hist, totals, bin_wave_cnt(p, T, hist), point_list, capacity, ranges, status, lds, order, s);
-    if (p.G == 8192) return bin_scatter_launch<32>(p, N, gx, T, sorted_ids, rect_sorted, hist, totals, bin_wave_cnt(p, T, hist), point_list, capacity, ranges, status, lds, order, s);
+    if (p.G == 256) return bin_scatter_launch<1>(p, N, gx, T, sorted_ids, rect_sorted, hist, totals, bin_wave_cnt(p, T, hist), point_list, capacity, ranges, status, lds, order, key_tag, s);
+    if (p.G == 512) return bin_scatter_launch<2>(p, N, gx, T, sorted_ids, rect_sorted, hist, totals, bin_wave_cnt(p, T, hist), point_list, capacity, ranges, status, lds, order, key_tag, s);
+    if (p.G == 1024) return bin_scatter_launch<4>(p, N, gx, T, sorted_ids, rect_sorted, hist, totals, bin_wave_cnt(p, T, hist), point_list, capacity, ranges, status, lds, order, key_tag, s);
+    if (p.G == 2048) return bin_scatter_launch<8>(p, N, gx, T, sorted_ids, rect_sorted, hist, totals, bin_wave_cnt(p, T, hist), point_list, capacity, ranges, status, lds, order, key_tag, s);
+    if (p.G == 4096) return bin_scatter_launch<16>(p, N, gx, T, sorted_ids, rect_sorted, hist, totals, bin_wave_cnt(p, T, hist), point_list, capacity, ranges, status, lds, order, key_tag, s);
+    if (p.G == 8192) return bin_scatter_launch<32>(p, N, gx, T, sorted_ids, rect_sorted, hist, totals, bin_wave_cnt(p, T, hist), point_list, capacity, ranges, status, lds, order, key_tag, s);
     GP_FAIL("bin: unsupported block size %d", p.G);
 }
 

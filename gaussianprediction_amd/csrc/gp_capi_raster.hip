@@ -4,8 +4,10 @@
 #include "gp_common.h"
 #include "raster_kernels.h"
 #include <stdlib.h>
+#include <atomic>
 
 thread_local char gp_err_buf[512] = "";
+static std::atomic<uint32_t> g_key_tag{0};       // numbers the forward calls that check a depth-key promise (never 0)
 
 extern "C" const char* gp_last_error(void) { return gp_err_buf; }
 extern "C" const char* gp_version(void) { return "gaussianprediction_amd 0.4 (gfx950)"; }
@@ -47,6 +49,17 @@ static int make_dims(const gp_raster_settings* st, const gp_raster_inputs* in, R
     d.scale_mod = st->scale_modifier;
     d.late_color = (st->sh_ready_event && in->shs) ? 1 : 0;
     d.visible = nullptr; d.zero_words = nullptr; d.n_zero = 0;
+    d.key_hi = 0u; d.key_base = 0u; d.key_culled = 0xFFFFFFFFu; d.key_flag = nullptr; d.key_tag = 0u;
+    if (st->depth_key_bits != 0 && st->depth_key_bits != 32) {
+        if (st->depth_key_bits < 8 || st->depth_key_bits > 31) GP_FAIL("depth_key_bits must be 0, 32 or 8 .. 31 (got %d)", st->depth_key_bits);
+        if (!st->binning_status) GP_FAIL("depth_key_bits needs binning_status (the word a broken promise raises)");
+        const uint32_t low = (1u << st->depth_key_bits) - 1u;
+        d.key_hi = ~low;
+        d.key_base = st->depth_key_base;
+        d.key_culled = low;                         // behind (or level with) every visible key of the promised range
+        d.key_flag = st->binning_status + 2;        // (the status block's scratch word: 3 words are required then)
+        do { d.key_tag = ++g_key_tag; } while (d.key_tag == 0u);
+    }
     return 0;
 }
 
@@ -160,7 +173,15 @@ extern "C" int gp_raster_forward(const gp_raster_settings* st, const gp_raster_i
         // (values = 0 .. N-1, generated by the first pass)
         // the last pass also carries every Gaussian's tile rectangle + tile count into depth order (was a launch of its own)
         const GpSortEpilogue ep = {tiles, rects, tt};
-        { GpProfScope _p("depth_sort", s); r1 = dsort3 ? gp_depth_sort3(sb, N, dshist, s, &ep) : gp_radix_sort_pairs(sb, N, 32, s, true, &ep); }
+        const int key_bits = d.key_hi ? st->depth_key_bits : 32;       // (a promised key range: fewer passes, same order)
+        if (st->depth_key_range) {      // {min, max} key of the visible Gaussians, for a caller that sizes depth_key_bits from it
+            GP_HIP_CHECK(hipMemsetAsync(st->depth_key_range, 0xFF, 4, s));
+            GP_HIP_CHECK(hipMemsetAsync(st->depth_key_range + 1, 0, 4, s));
+            hipLaunchKernelGGL(gp_key_range_kernel, dim3(gp_blocks(N, 1024)), dim3(256), 0, s, (const uint32_t*)k0, (const int32_t*)out->radii, (int)N,
+                               d.key_base, st->depth_key_range);
+            GP_LAUNCH_CHECK();
+        }
+        { GpProfScope _p("depth_sort", s); r1 = (dsort3 && key_bits == 32) ? gp_depth_sort3(sb, N, dshist, s, &ep) : gp_radix_sort_pairs(sb, N, key_bits, s, true, &ep); }
         if (r1 < 0) return 1;
         const uint32_t* sorted_ids = sb.v[r1];
         // tile counts -> instance offsets: scanned inside blocks here, finished by the duplicate kernel (one launch, not three)
@@ -184,7 +205,7 @@ extern "C" int gp_raster_forward(const gp_raster_settings* st, const gp_raster_i
             R = (uint32_t)Rsum;
             if (R > 0x7FFFFF00u) GP_FAIL("too many tile-splat instances (%u)", R);
             if (st->binning_status && (!counting || R == 0)) {   // exact mode reports R too (a caller sizing its capacity reads it from here; the counting path's scatter writes it)
-                hipLaunchKernelGGL(gp_binning_status_kernel, dim3(1), dim3(1), 0, s, il.total, 0xFFFFFFFFu, st->binning_status);
+                hipLaunchKernelGGL(gp_binning_status_kernel, dim3(1), dim3(1), 0, s, il.total, 0xFFFFFFFFu, st->binning_status, d.key_tag);
                 GP_LAUNCH_CHECK();
             }
         }
@@ -195,7 +216,7 @@ extern "C" int gp_raster_forward(const gp_raster_settings* st, const gp_raster_i
             if (!bin) GP_FAIL("allocator returned NULL for BINNING");
             point_list = (uint32_t*)bin;
             saved->binning = bin; saved->binning_bytes = bin_bytes;
-            if (gp_bin_scatter(bp, N, d.gx, T, sorted_ids, rects, binhist, point_list, R, il.ranges, st->binning_status, il.order, s)) return 1;
+            if (gp_bin_scatter(bp, N, d.gx, T, sorted_ids, rects, binhist, point_list, R, il.ranges, st->binning_status, il.order, d.key_tag, s)) return 1;
             order_done = true;
         } else if (R > 0) {
             // capacity mode pads the keys with 0xFFFFFFFF: its low `tbits` bits must sort behind every real tile id
@@ -227,7 +248,7 @@ extern "C" int gp_raster_forward(const gp_raster_settings* st, const gp_raster_i
             { GpProfScope _p("duplicate", s);
             const unsigned ndup = gp_blocks(N, 256);
             hipLaunchKernelGGL(gp_duplicate_kernel, dim3(ndup + (capacity_mode ? gp_blocks(R, 4096) : 0u)), dim3(256), 0, s, d, sorted_ids, tt,
-                               (const uint32_t*)block_sums, (const uint32_t*)il.total, rects, tb.k[0], tb.v[0], R, st->binning_status, ndup);
+                               (const uint32_t*)block_sums, (const uint32_t*)il.total, rects, tb.k[0], tb.v[0], R, st->binning_status, ndup, d.key_tag);
             GP_LAUNCH_CHECK(); }
             int r2;
             { GpProfScope _p("tile_sort", s); r2 = gp_radix_sort_pairs(tb, R, tbits, s); }

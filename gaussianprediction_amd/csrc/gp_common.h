@@ -136,7 +136,7 @@ bool gp_bin_supported(size_t N, size_t T);
 GpBinPlan gp_bin_plan(size_t N, size_t T);
 int gp_bin_count(const GpBinPlan& p, size_t N, int gx, size_t T, const uint2* rect_sorted, uint32_t* hist, uint32_t* total_slots, hipStream_t s);
 int gp_bin_scatter(const GpBinPlan& p, size_t N, int gx, size_t T, const uint32_t* sorted_ids, const uint2* rect_sorted, uint32_t* hist,
-                   uint32_t* point_list, uint32_t capacity, int2* ranges, uint32_t* status, uint32_t* order, hipStream_t s);
+                   uint32_t* point_list, uint32_t capacity, int2* ranges, uint32_t* status, uint32_t* order, uint32_t key_tag, hipStream_t s);
 // (`order`, optional: the composite forward's heavy-first tile order, computed by one extra workgroup of the scatter launch)
 #define GP_SCAN_TILE 2048      // elements per block of gp_scan_blocks_u32
 #define GP_TOTAL_SLOTS 16       // gp_scan_blocks_u32 spreads its grand total over this many words (block b adds into word b % 16:

@@ -48,6 +48,7 @@ extern "C" int gp_train_step_run(const gp_step_plan* p, const gp_step_view* v, c
     st.sh_degree = p->sh_degree; st.sh_coeffs = 16;
     st.bg = v->bg; st.viewmatrix = v->viewmatrix; st.projmatrix = v->projmatrix; st.campos = v->campos;
     st.binning_capacity = u->binning_capacity; st.binning_status = u->binning_status; st.sh_ready_event = u->sh_ready_event;
+    st.depth_key_bits = u->depth_key_bits; st.depth_key_base = u->depth_key_base;
     gp_raster_inputs in;
     memset(&in, 0, sizeof(in));
     in.num_gaussians = N; in.means3D = p->xyz_t; in.shs = p->features_dc; in.shs_rest = p->features_rest; in.opacities = p->opacity_t;

@@ -21,7 +21,13 @@ struct RasterDims {
     uint8_t* visible;      // optional [N]: radii > 0 (the renderer's visibility_filter)
     uint32_t* zero_words;  // optional: n_zero words the binning stage expects zeroed (tile ranges + instance-counter slots)
     int n_zero;
+    // depth-key speculation (gp_raster_settings.depth_key_bits): key_hi = the bits of (key - key_base) the caller promised to be zero (0 = no promise),
+    // key_culled = the key of a Gaussian without tiles (sorts behind every visible one), key_flag = the word raised on a broken promise
+    uint32_t key_hi, key_base, key_culled, key_tag;
+    uint32_t* key_flag;     // binning_status + 2: receives key_tag (this call's number) when a visible key breaks the promise
 };
+__global__ __launch_bounds__(256) void gp_key_range_kernel(const uint32_t* __restrict__ keys, const int32_t* __restrict__ radii, int n,
+                                                          uint32_t base, uint32_t* __restrict__ out2);
 
 __global__ __launch_bounds__(256) void gp_preprocess_fwd_kernel(RasterDims d, const float* __restrict__ means3D, const float* __restrict__ scales,      const float* __restrict__ rotations, const float* __restrict__ opacities, const float* __restrict__ shs,      const float* __restrict__ shs_rest, const float* __restrict__ colors_precomp, const float* __restrict__ cov3D_precomp,      const float* __restrict__ view, const float* __restrict__ proj, const float* __restrict__ campos,      int32_t* __restrict__ radii, float4* __restrict__ rec, uint32_t* __restrict__ depth_key,      uint2* __restrict__ tiles_touched, uint8_t* __restrict__ clamped);
 
@@ -44,11 +50,11 @@ __global__ __launch_bounds__(256) void gp_duplicate_kernel(RasterDims d, const u
                                                           const uint32_t* __restrict__ block_sums, const uint32_t* __restrict__ total,
                                                           const uint2* __restrict__ rect_sorted,
                                                           uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, uint32_t capacity,
-                                                          uint32_t* __restrict__ status, uint32_t n_dup_blocks);
+                                                          uint32_t* __restrict__ status, uint32_t n_dup_blocks, uint32_t key_tag);
 
 __global__ __launch_bounds__(256) void gp_tile_ranges_kernel(const uint32_t* __restrict__ keys, uint32_t R, uint32_t n_tiles,
                                                             int2* __restrict__ ranges);
-__global__ void gp_binning_status_kernel(const uint32_t* __restrict__ total, uint32_t capacity, uint32_t* __restrict__ status);
+__global__ void gp_binning_status_kernel(const uint32_t* __restrict__ total, uint32_t capacity, uint32_t* __restrict__ status, uint32_t key_tag);
 
 __global__ __launch_bounds__(1024) void gp_tile_order_kernel(const int2* __restrict__ ranges, const int32_t* __restrict__ work_hint, int T, uint32_t* __restrict__ order);
 __global__ __launch_bounds__(1024) void gp_bwd_prologue_kernel(const int2* __restrict__ ranges, const int32_t* __restrict__ work_hint, int T,

@@ -307,7 +307,7 @@ __device__ __forceinline__ void preprocess_fwd_body(RasterDims d, const float* _
     radii[i] = 0;
     if (d.visible) d.visible[i] = 0;
     tiles_touched[i] = make_uint2(0u, 0u);
-    depth_key[i] = 0xFFFFFFFFu;
+    depth_key[i] = d.key_culled;
     clamped[i] = 0;
     const float3 pv = xform4x3(view, px, py, pz);
     if (!(pv.z > 0.2f)) return;
@@ -348,7 +348,15 @@ __device__ __forceinline__ void preprocess_fwd_body(RasterDims d, const float* _
     radii[i] = rad_i;
     if (d.visible) d.visible[i] = rad_i > 0;
     clamped[i] = cl;
-    depth_key[i] = __float_as_uint(pv.z);
+    {
+        const uint32_t key = __float_as_uint(pv.z) - d.key_base;      // (key_base = 0 without a promise)
+        depth_key[i] = key;
+        // the caller's promise about the keys' range (gp_raster_settings.depth_key_bits), checked for every visible Gaussian:
+        // a plain store of THIS call's tag (every writer writes the same value) into the status block's scratch word; the kernel that
+        // writes {R, overflow} later in the call turns `scratch == tag` into the overflow flag -- no word has to be cleared between
+        // frames, a stale tag of an earlier call never matches
+        if (key & d.key_hi) *d.key_flag = d.key_tag;      // (key_hi = 0 without a promise; a key below the base wraps around)
+    }
     // tile rectangle (first tile | extent, 16 bits each): the binning stage expands it without touching `rec` again
     tiles_touched[i] = make_uint2((uint32_t)minx | ((uint32_t)miny << 16), (uint32_t)(maxx - minx) | ((uint32_t)(maxy - miny) << 16));
     // The composite evaluates alpha = min(0.99, opacity exp(power)) as exp2(power' + log2 opacity) with power' = log2(e) power:
@@ -400,6 +408,29 @@ __global__ __launch_bounds__(256) void gp_sh_color_kernel(SC_ARGS) { sh_color_bo
 __global__ __launch_bounds__(256) void gp_sh_color_sh16_kernel(SC_ARGS) { sh_color_body<1>(d, means3D, shs, shs_rest, campos, radii, rec, clamped); }
 __global__ __launch_bounds__(256) void gp_sh_color_split_kernel(SC_ARGS) { sh_color_body<2>(d, means3D, shs, shs_rest, campos, radii, rec, clamped); }
 
+// {min, max} of the visible Gaussians' depth keys (gp_raster_settings.depth_key_range; out2 = {0xFFFFFFFF, 0} on entry): one pair
+// of atomics per workgroup of 1024 keys -- a set-up-step kernel, not part of the timed path
+__global__ __launch_bounds__(256) void gp_key_range_kernel(const uint32_t* __restrict__ keys, const int32_t* __restrict__ radii, int n,
+                                                          uint32_t base, uint32_t* __restrict__ out2) {
+    __shared__ uint32_t s_mn[4], s_mx[4];
+    uint32_t mn = 0xFFFFFFFFu, mx = 0u;
+    const int first = blockIdx.x * 1024 + threadIdx.x;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int i = first + 256 * u;
+        if (i < n && radii[i] > 0) { const uint32_t k = keys[i] + base; mn = min(mn, k); mx = max(mx, k); }
+    }
+#pragma unroll
+    for (int dd = 32; dd >= 1; dd >>= 1) { mn = min(mn, (uint32_t)__shfl_xor((int)mn, dd)); mx = max(mx, (uint32_t)__shfl_xor((int)mx, dd)); }
+    if ((threadIdx.x & 63) == 0) { s_mn[threadIdx.x >> 6] = mn; s_mx[threadIdx.x >> 6] = mx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        mn = min(min(s_mn[0], s_mn[1]), min(s_mn[2], s_mn[3]));
+        mx = max(max(s_mx[0], s_mx[1]), max(s_mx[2], s_mx[3]));
+        if (mn <= mx) { atomicMin(out2, mn); atomicMax(out2 + 1, mx); }
+    }
+}
+
 __global__ __launch_bounds__(256) void gp_mark_visible_kernel(int n, const float* __restrict__ means3D,
                                                              const float* __restrict__ view, uint8_t* __restrict__ present) {
     const int i = blockIdx.x * 256 + threadIdx.x;
@@ -425,7 +456,7 @@ __global__ __launch_bounds__(256) void gp_duplicate_kernel(RasterDims d, const u
                                                           const uint32_t* __restrict__ block_sums, const uint32_t* __restrict__ total_R,
                                                           const uint2* __restrict__ rect_sorted,
                                                           uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, uint32_t capacity,
-                                                          uint32_t* __restrict__ status, uint32_t n_dup_blocks) {
+                                                          uint32_t* __restrict__ status, uint32_t n_dup_blocks, uint32_t key_tag) {
     __shared__ int4 s_own[4][64];        // (relative offset, first tile x, first tile y, tiles per row)
     __shared__ uint32_t s_id[4][64];
     __shared__ uint32_t s_part[4];
@@ -433,7 +464,7 @@ __global__ __launch_bounds__(256) void gp_duplicate_kernel(RasterDims d, const u
         // capacity mode, the blocks behind the expansion: status = {R, R > capacity} and sentinel keys behind the R real
         // instances (their values are never read: no tile range covers them) -- two tiny kernels folded into this launch
         const uint32_t R = gp_total_of(total_R);
-        if (blockIdx.x == n_dup_blocks && threadIdx.x == 0) { status[0] = R; status[1] = R > capacity ? 1u : 0u; }
+        if (blockIdx.x == n_dup_blocks && threadIdx.x == 0) { status[0] = R; status[1] = (R > capacity || (key_tag && status[2] == key_tag)) ? 1u : 0u; }
         const uint32_t b0 = (blockIdx.x - n_dup_blocks) * 4096u;
         for (uint32_t i = b0 + threadIdx.x; i < b0 + 4096u && i < capacity; i += 256u)
             if (i >= R) keys[i] = 0xFFFFFFFFu;
@@ -498,10 +529,10 @@ __global__ __launch_bounds__(256) void gp_tile_ranges_kernel(const uint32_t* __r
     if (k == R - 1 || tn != t) ranges[t].y = (int)(k + 1);
 }
 // exact mode with a status word requested: status = {R, 0}  (capacity mode writes it from the duplicate launch)
-__global__ void gp_binning_status_kernel(const uint32_t* __restrict__ total, uint32_t capacity, uint32_t* __restrict__ status) {
+__global__ void gp_binning_status_kernel(const uint32_t* __restrict__ total, uint32_t capacity, uint32_t* __restrict__ status, uint32_t key_tag) {
     const uint32_t R = gp_total_of(total);
     status[0] = R;
-    status[1] = R > capacity ? 1u : 0u;
+    status[1] = (R > capacity || (key_tag && status[2] == key_tag)) ? 1u : 0u;      // (key_tag: gp_raster_settings.depth_key_bits)
 }
 
 // Heavy-first launch order.  Per-tile work varies by >10x; the hardware dispatches workgroups in blockIdx order, so

@@ -221,8 +221,9 @@ class FusedStage3:
         except BaseException as e:       # noqa: BLE001  (re-raised by run() once the library call has returned)
             self._hook_error = self._hook_error or e
 
-    def run(self, view, time_tensor, capacity, status, skip_flag, keep):
-        """Enqueue the whole step for camera `view`; returns (loss [] tensor, result dict shaped like render()'s)."""
+    def run(self, view, time_tensor, capacity, status, skip_flag, keep, depth_key=None):
+        """Enqueue the whole step for camera `view`; returns (loss [] tensor, result dict shaped like render()'s).
+        `depth_key`: None or (bits, base), gp_raster_settings.depth_key_bits (status then has the library's scratch word)."""
         ts, pc, opt = self.ts, self.pc, self.pc.optimizer
         sh_pair = (pc._features_dc, pc._features_rest)
         ex = ts.reducer if ts.reducer.enabled else None
@@ -263,6 +264,7 @@ class FusedStage3:
             if id(own) in keep_ids and tab["NUM"][k] != 0:
                 mask |= 1 << k
         u.binning_capacity, u.binning_status = int(capacity), status.data_ptr()
+        u.depth_key_bits, u.depth_key_base = (int(depth_key[0]), int(depth_key[1]) & 0xFFFFFFFF) if depth_key else (0, 0)
         u.adam_shs = C.cast(C.pointer(fuse_c), C.c_void_p) if fuse_c is not None else None
         u.beta1, u.beta2, u.eps, u.step, u.keep_grad_mask = float(opt.betas[0]), float(opt.betas[1]), float(opt.eps), int(step_no), mask
         u.skip_flag = skip_flag.data_ptr() if skip_flag is not None else None

@@ -48,6 +48,13 @@ class GaussianRasterizationSettings(NamedTuple):
     # extension (gp_raster_outputs.visible): a contiguous uint8 [N] tensor on the render device that the projection kernel fills with
     # radii > 0 -- render()'s visibility_filter without a compare launch per frame.  None = not wanted.
     visible_out: Optional[torch.Tensor] = None
+    # extension (gp_raster_settings.depth_key_bits / depth_key_base / depth_key_range): the caller promises that the visible Gaussians'
+    # depth keys k (the bit patterns of their view-space depths) satisfy 0 <= k - depth_key_base < 2^depth_key_bits -- the depth sort
+    # then runs over that many bits only (24: three passes instead of four, same order); a broken promise raises binning_status[1]
+    # (status needs 3 words).  `depth_key_range`: int32 [2] device tensor that receives {min, max} visible key.
+    depth_key_bits: int = 0
+    depth_key_base: int = 0
+    depth_key_range: Optional[torch.Tensor] = None
 
 
 _bump_version = getattr(torch.autograd.graph, "increment_version", lambda t: None)
@@ -78,6 +85,17 @@ def _settings_c(rs: GaussianRasterizationSettings, device, sh_coeffs: int):
         keep.append(status)
     elif getattr(rs, "binning_capacity", 0):
         raise RuntimeError("binning_capacity needs binning_status")
+    kb = int(getattr(rs, "depth_key_bits", 0) or 0)
+    if kb not in (0, 32):
+        if status is None or status.numel() < 3:
+            raise RuntimeError("depth_key_bits needs a binning_status of >= 3 words")
+        st.depth_key_bits, st.depth_key_base = kb, int(getattr(rs, "depth_key_base", 0)) & 0xFFFFFFFF
+    kr = getattr(rs, "depth_key_range", None)
+    if kr is not None:
+        if kr.device != device or kr.dtype != torch.int32 or kr.numel() < 2 or not kr.is_contiguous():
+            raise RuntimeError("depth_key_range: contiguous int32 tensor of >= 2 elements on the render device expected")
+        st.depth_key_range = kr.data_ptr()
+        keep.append(kr)
     ev = getattr(rs, "sh_ready_event", None)
     if ev is not None:
         st.sh_ready_event = int(ev.cuda_event)          # (hipEvent_t; an event that was never recorded counts as complete)

@@ -38,6 +38,9 @@ def _settings(viewpoint_camera, pc, bg_color, scaling_modifier, binning=None, sh
         visible_out=visible_out,
         binning_capacity=int(binning[0]) if binning else 0,
         binning_status=binning[1] if binning else None,
+        depth_key_bits=int(binning[2][0]) if (binning and len(binning) > 2 and binning[2]) else 0,
+        depth_key_base=int(binning[2][1]) if (binning and len(binning) > 2 and binning[2]) else 0,
+        depth_key_range=binning[3] if (binning and len(binning) > 3) else None,
         sh_ready_event=sh_ready_event,
         image_height=int(viewpoint_camera.image_height),
         image_width=int(viewpoint_camera.image_width),
@@ -81,8 +84,8 @@ def _screenspace_points(pc):
 def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=1.0, override_color=None, delta=None,
            time=None, it=1, binning=None):
     """Render the scene.  Background tensor (bg_color) must be on the GPU.
-    `binning` (extension, not in the reference signature): (capacity, status) of the rasterizer's capacity mode -- see
-    GaussianRasterizationSettings.binning_capacity."""
+    `binning` (extension, not in the reference signature): (capacity, status[, (depth_key_bits, depth_key_base) | None[, depth_key_range]])
+    of the rasterizer's capacity mode / depth-key speculation -- see GaussianRasterizationSettings.binning_capacity, .depth_key_bits."""
     screenspace_points = _screenspace_points(pc)
     cov3D_precomp = None
     if time is None:

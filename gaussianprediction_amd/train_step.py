@@ -34,6 +34,14 @@ class TrainStep:
     SPEC_SLOTS = 4
     SPEC_MARGIN = 1.1
     SPEC_PAD = 4096
+    # The same protocol carries the DEPTH-KEY speculation (gp_raster_settings.depth_key_bits): the exact-mode steps also ask for the
+    # {min, max} depth key of their visible Gaussians (status words 4, 5); once every view has reported, the capacity-mode steps
+    # promise that the keys lie in a window of 2^KEY_BITS keys (two octaves: a factor of 4 in depth) centred on the range seen
+    # so far -- if that leaves at least KEY_MIN_MARGIN keys (1/32 octave: 2 % in depth) on either side; the depth sort then runs three
+    # passes instead of four.  A Gaussian outside the promised range raises the overflow word like a binning overflow: the frame is
+    # repeated in exact mode, which also refreshes the range.
+    KEY_BITS, KEY_MIN_MARGIN = 24, 1 << 18
+    STATUS_WORDS = 8                # {R, overflow, library scratch, -, key min, key max, -, -}
 
     def __init__(self, pc, cameras, gt_images, iteration, lambda_dssim=0.2, lrs=None, group=None, speculative=False,
                  overlap_sh_adam=False, batch=1, schedule=False, training_args=None, sharded=None, fuse_sh_adam=True, chain_sh=True,
@@ -57,8 +65,10 @@ class TrainStep:
         self.speculative = bool(speculative) and dev.type == "cuda"
         if self.speculative:
             K = self.SPEC_SLOTS
-            self._status = torch.zeros(K, 2, dtype=torch.int32, device=dev)
-            self._status_host = torch.zeros(K, 2, dtype=torch.int32).pin_memory()
+            self._status = torch.zeros(K, self.STATUS_WORDS, dtype=torch.int32, device=dev)
+            self._status_host = torch.zeros(K, self.STATUS_WORDS, dtype=torch.int32).pin_memory()
+            self._key_lo = self._key_hi = None      # smallest / largest visible depth key reported so far (over all views)
+            self.depth_key_speculation = os.environ.get("GP_DEPTH_KEY_SPEC", "1") != "0"
             self._events = [None] * K
             self._slot_view = [None] * K            # view rendered by the step that last used the slot
             self._slot_spec = [False] * K           # ... and whether it ran in capacity mode
@@ -66,6 +76,7 @@ class TrainStep:
             self._slot_hold = [()] * K              # ... and the optimizer groups it held back
             self._slot_epoch = [None] * K           # ... and which optimizer (pc.optimizer_epoch) took the step
             self._r_max, self._n_steps, self.redone = 0, 0, 0
+            self.last_depth_key_promise = None
             if os.environ.get("GP_SPEC_MARGIN"):     # test hook: a margin < 1 forces overflows (and the redo protocol)
                 self.SPEC_MARGIN, self.SPEC_PAD = float(os.environ["GP_SPEC_MARGIN"]), 0
         # Optional (off: measured 1.83 -> 1.90 ms on the bench): Adam for the SH coefficients (3/4 of all parameter bytes) on
@@ -228,6 +239,11 @@ class TrainStep:
             self._events[slot].synchronize()
             r, overflow = int(self._status_host[slot, 0]), int(self._status_host[slot, 1])
             self._r_max = max(self._r_max, r)
+            if not self._slot_spec[slot]:            # an exact-mode step: it also reported the visible Gaussians' depth-key range
+                lo, hi = int(self._status_host[slot, 4]) & 0xFFFFFFFF, int(self._status_host[slot, 5]) & 0xFFFFFFFF
+                if lo <= hi:
+                    self._key_lo = lo if self._key_lo is None else min(self._key_lo, lo)
+                    self._key_hi = hi if self._key_hi is None else max(self._key_hi, hi)
             if overflow and self._slot_spec[slot]:   # its Adam update was skipped on the device: repeat the frame, exactly
                 self.redone += 1
                 if self._slot_epoch[slot] == self.pc.optimizer_epoch:
@@ -250,10 +266,25 @@ class TrainStep:
         self._n_steps += 1
         return out
 
+    def _depth_key_promise(self):
+        """(bits, base) for gp_raster_settings.depth_key_bits / depth_key_base, or None.  The depth keys are the bit patterns of positive
+        floats (monotonic in the depth; an octave is 2^23 consecutive keys): the 2^24-key window is centred on the range seen so far,
+        so the room left over is the margin on both sides."""
+        if not getattr(self, "depth_key_speculation", False) or self._key_lo is None or self._key_hi < self._key_lo:
+            return None
+        bits = self.KEY_BITS
+        slack = (1 << bits) - 1 - (self._key_hi - self._key_lo)
+        if slack < 2 * self.KEY_MIN_MARGIN:
+            return None
+        return bits, max(1, self._key_lo - slack // 2)
+
     def _run_slot(self, slot, view_index, exact):
         status = self._status[slot]
         capacity = 0 if exact else (int(self._r_max * self.SPEC_MARGIN) + self.SPEC_PAD)
-        out = self._step(view_index, (capacity, status), None if exact else status[1:2])
+        # (capacity, {R, overflow, scratch}, the depth-key promise of a capacity-mode step, the key-range words of an exact one)
+        binning = (capacity, status[0:3], None if exact else self._depth_key_promise(), status[4:6] if exact else None)
+        self.last_depth_key_promise = binning[2]
+        out = self._step(view_index, binning, None if exact else status[1:2])
         self._status_host[slot].copy_(status, non_blocking=True)
         ev = self._events[slot] or torch.cuda.Event()
         ev.record()
@@ -288,7 +319,7 @@ class TrainStep:
                 # finds them marked stale, as after its own steps); the small tensors are zeroed as the graph path leaves them
                 keep_f = (pc._features_dc, pc._features_rest, pc._rotation, pc._scaling, pc._opacity, pc._xyz)
                 self.fused_steps += 1
-                return plan.run(v, t_view, binning[0], binning[1], skip_flag, keep_f)
+                return plan.run(v, t_view, binning[0], binning[1], skip_flag, keep_f, depth_key=binning[2] if len(binning) > 2 else None)
         keep = ()
         if self.batch == 1 and not self.pipe.convert_SHs_python and self.iteration > pc.third_stage_iter:
             # the per-Gaussian gradients each have exactly one producer kernel that writes the whole tensor (SH: rasterizer

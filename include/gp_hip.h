@@ -72,6 +72,20 @@ typedef struct gp_raster_settings {
      * binning do not read them, so the call makes `stream` wait for this event only in front of a separate SH -> RGB kernel
      * placed right before the composite.  Identical results (one shared device function). */
     void* sh_ready_event;
+    /* Depth-key speculation (round 5).  The depth sort orders the 32-bit patterns of the view-space depths (positive floats) in four
+     * 8-bit passes.  The visible Gaussians of a frame usually span less than a factor of four in depth, i.e. their keys (two octaves
+     * of floats = 2^24 consecutive patterns) fit 24 bits above the smallest one -- which the library cannot know without reading the
+     * keys back.  depth_key_bits = B (8 .. 31): the CALLER promises that every visible Gaussian's key k satisfies
+     * 0 <= k - depth_key_base < 2^B; the sort then orders k - depth_key_base on its low B bits (24 bits: three passes instead of four;
+     * the order of the visible Gaussians is the full sort's, bit for bit -- the subtraction is monotonic).  The projection kernel checks the
+     * promise for every visible Gaussian and raises binning_status[1] when it is broken: the frame is invalid exactly as after a binning
+     * overflow.  binning_status is required then and has THREE words: [2] is scratch of the library (it receives the number of the call
+     * whose promise broke; nothing needs clearing between frames).  0 (or 32) = sort all 32 bits.
+     * depth_key_range (optional, device, 2 words): receives {min, max} of the visible Gaussians' keys ({0xFFFFFFFF, 0} if none) --
+     * what a caller sizes B and the prefix from (TrainStep: during its exact-mode set-up steps, with a margin). */
+    int32_t depth_key_bits;
+    uint32_t depth_key_base;
+    uint32_t* depth_key_range;
 } gp_raster_settings;
 
 /* inputs of GaussianRasterizer.forward [REF gaussian_renderer/__init__.py:98-106] */
@@ -400,6 +414,8 @@ enum { GP_STEP_AFTER_RASTER_BACKWARD = 0,   /* the SH gradients (and g_means2D) 
 typedef struct gp_step_update {
     int64_t binning_capacity;    /* > 0: capacity mode (required: the call never synchronises) */
     uint32_t* binning_status;    /* device {R, overflow} */
+    int32_t depth_key_bits;      /* see gp_raster_settings */
+    uint32_t depth_key_base;
     void* sh_ready_event;        /* see gp_raster_settings */
     const gp_adam_fuse* adam_shs;/* NULL, or the SH pair's update inside the rasterizer backward */
     /* the optimizer launch behind the backward: gp_adam_step_multi (steps == NULL) / gp_adam_step_multi_steps; count 0 = none */

@@ -126,3 +126,82 @@ def test_side_stream_sh_adam_matches_the_single_stream_step():
     assert rel_l2(da.cpu().numpy(), db.cpu().numpy()) < 1e-3
     assert rel_l2(ra.cpu().numpy(), rb.cpu().numpy()) < 1e-3
     assert rel_l2(xa.cpu().numpy(), xb.cpu().numpy()) < 1e-4
+
+
+def _f2k(z):
+    import struct
+    return struct.unpack("<I", struct.pack("<f", z))[0]
+
+
+def test_depth_key_promise_is_exact_when_kept_and_flagged_when_broken():
+    """gp_raster_settings.depth_key_bits: a kept promise (24 bits above the smallest visible key) gives the exact mode's frame bit for
+    bit with three sort passes; a broken one -- a visible key below the base, or beyond base + 2^bits -- raises the overflow word."""
+    from test_gpu_render import build
+    pc, cam, *_ = build(N=3000, K=60, W=120, H=90)
+    status = torch.zeros(8, dtype=torch.int32, device="cuda")
+    a = _render(pc, cam, 50000, binning=(0, status[0:3], None, status[4:6]))
+    R, lo, hi = int(status[0]), int(status[4]) & 0xFFFFFFFF, int(status[5]) & 0xFFFFFFFF
+    assert R > 0 and int(status[1]) == 0 and lo < hi
+    # the reported range is the visible Gaussians' view-space depth range
+    with torch.no_grad():
+        xyz, *_ = pc(torch.tensor([0.3], device="cuda"), 50000)
+        z = (torch.cat([xyz, torch.ones_like(xyz[:, :1])], 1) @ cam.world_view_transform)[:, 2][a["visibility_filter"]]
+    assert abs(np.float32(z.min().item()) / np.array([lo], np.uint32).view(np.float32)[0] - 1) < 1e-5
+    assert abs(np.float32(z.max().item()) / np.array([hi], np.uint32).view(np.float32)[0] - 1) < 1e-5
+    assert hi - lo < (1 << 24) and hi - lo >= (1 << 16)
+    for bits, base, broken in ((24, lo, False), (24, hi - (1 << 24) + 1, False), (31, _f2k(0.2), False),
+                               (24, lo + 1, True), (16, lo, True), (8, hi - 255 + 1, True), (24, hi + 1, True)):
+        st = torch.full((3,), -1, dtype=torch.int32, device="cuda")
+        b = _render(pc, cam, 50000, binning=(R, st, (bits, base)))
+        assert int(st[0]) == R or broken
+        assert int(st[1]) == int(broken), (bits, base, st.tolist())
+        if not broken:
+            for k in ("render", "radii", "depth", "tidx"):
+                assert torch.equal(a[k], b[k]), (k, bits, base)
+    # the scratch word carries the NUMBER of the call whose promise broke: reusing the block for a kept promise is clean without clearing it
+    st = torch.zeros(3, dtype=torch.int32, device="cuda")
+    _render(pc, cam, 50000, binning=(R, st, (16, lo)))
+    assert int(st[1]) == 1
+    b = _render(pc, cam, 50000, binning=(R, st, (24, lo)))
+    assert st[:2].tolist() == [R, 0] and torch.equal(a["render"], b["render"])
+    c = _render(pc, cam, 50000, binning=(0, st, (24, lo)))               # exact binning under a promise
+    assert st[:2].tolist() == [R, 0] and torch.equal(a["render"], c["render"])
+    with pytest.raises(RuntimeError):
+        _render(pc, cam, 50000, binning=(R, st[:2], (24, lo)))           # no scratch word
+
+
+def test_train_step_speculates_on_the_depth_key_range():
+    """TrainStep sizes the promise from the ranges its exact-mode set-up steps report; a promise that breaks is redone in exact mode,
+    which widens the range."""
+    from test_gpu_render import build, make_args
+    from gaussianprediction_amd.cameras import orbit_cameras
+    from gaussianprediction_amd.train_step import TrainStep
+    res = []
+    for spec in (True, False):
+        pc, cam, *_ = build(N=2000, K=40, W=96, H=80, args=make_args())
+        cams = orbit_cameras(5, 4.0, 0.6911, 96, 80, device="cuda")[:3]
+        gts = [torch.rand(3, 80, 96, generator=torch.Generator().manual_seed(5 + i)).cuda() for i in range(3)]
+        ts = TrainStep(pc, cams, gts, 50000, speculative=True)
+        ts.depth_key_speculation = spec
+        losses = [float(ts.step(i)[0]) for i in range(14)]
+        torch.cuda.synchronize()
+        res.append((losses, ts.last_depth_key_promise, ts.redone, ts))
+    (la, pa, ra, ts), (lb, pb, rb, _) = res
+    lo, hi = (np.array([k], np.uint32).view(np.float32)[0] for k in (ts._key_lo, ts._key_hi))
+    assert pb is None and pa is not None and pa[0] == 24 and ra == 0 and rb == 0, (pa, pb, ra, rb, lo, hi)
+    assert pa[1] < ts._key_lo and ts._key_hi < pa[1] + (1 << 24)          # the window holds the range, with room on both sides
+    assert abs((ts._key_lo - pa[1]) - (pa[1] + (1 << 24) - 1 - ts._key_hi)) <= 1
+    assert np.allclose(la, lb, rtol=1e-3, atol=1e-6), (la, lb)
+    # break it: pretend only the nearest Gaussian was ever seen -- the window around it ends at twice its depth
+    assert hi > 2.2 * lo
+    ts._key_hi = ts._key_lo
+    n0 = ts.optimizer.step_count
+    for i in range(14, 14 + 3 * ts.SPEC_SLOTS):
+        ts.step(i)
+    torch.cuda.synchronize()
+    assert ts.redone > 0                                                  # detected, repeated in exact mode ...
+    assert ts._key_hi - ts._key_lo >= (1 << 16)                           # ... whose report widened the range again
+    assert ts.last_depth_key_promise is not None and ts.last_depth_key_promise[0] == 24
+    assert ts.optimizer.step_count > n0
+    for p in ts.pc.parameters():
+        assert torch.isfinite(p).all()
