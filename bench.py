@@ -232,6 +232,12 @@ def _sha16(path):
     return hashlib.sha256(open(path, "rb").read()).hexdigest()[:16]
 
 
+def _key_depth(key):
+    """view-space depth of a depth key (the key is the float's bit pattern)"""
+    import struct
+    return struct.unpack("<f", struct.pack("<I", int(key) & 0xFFFFFFFF))[0]
+
+
 def dense_variant(args, device, steps=20):
     """The same scene with 1.5 x larger splats (scale 0.0045 .. 0.018: R / N at the UPPER end of SURVEY.md 8d's 4 .. 9 range, where
     the bytes per (pixel, splat) pair fall and the composite's HBM fraction with them): set-up + warm-up as the headline, `steps`
@@ -580,7 +586,8 @@ def main():
                                   f"warm-up; {getattr(ts, 'redone', 0)} frames repeated after overflow)",
                        "depth_sort": "32-bit keys, four 8-bit passes" if not getattr(ts, "last_depth_key_promise", None) else
                                      (f"{ts.last_depth_key_promise[0]}-bit keys above a promised base ({-(-ts.last_depth_key_promise[0] // 8)} passes; the "
-                                      "projection kernel checks the promise, a broken one repeats the frame like a binning overflow)"),
+                                      "projection kernel checks the promise, a broken one repeats the frame like a binning overflow; visible depths "
+                                      f"seen in the set-up steps: {_key_depth(ts._key_lo):.3f} .. {_key_depth(ts._key_hi):.3f})"),
                        "keypoint_weights": "raw_weights / knn_idx are inputs of the step (BASELINE.json north_star); the reference "
                                            "recomputes them per frame (hash-grid weights model + kNN): see train_step_with_weights_model_ms"},
             "roofline": roof,
