@@ -1200,7 +1200,13 @@ extern "C" int gp_mlp16_forward(const gp_mlp16_params* p, const gp_mlp_input* x,
     }
     GpProfScope _p("mlp16_fwd", s);
     if (p->dtype == GP_DTYPE_F16_SPLIT) {
-        hipLaunchKernelGGL(gp_mlp16_fwd_split_kernel, dim3(gp_blocks((size_t)m.rows, M16_ROWS)), dim3(M16_THREADS), 0, s, m, out, saved_xT, saved_hT, masks);
+        size_t dyn = 0;
+        if (gp_debug_get(9) & 32) {       // (probe: 40 KB of unused dynamic LDS = ONE workgroup per CU instead of two)
+            static thread_local bool set = false;
+            if (!set) { GP_HIP_CHECK(hipFuncSetAttribute((const void*)gp_mlp16_fwd_split_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 40 * 1024)); set = true; }
+            dyn = 40 * 1024;
+        }
+        hipLaunchKernelGGL(gp_mlp16_fwd_split_kernel, dim3(gp_blocks((size_t)m.rows, M16_ROWS)), dim3(M16_THREADS), dyn, s, m, out, saved_xT, saved_hT, masks);
     } else if (m.rows >= GP_MLP16_BIG_ROWS) {        // 128 rows per workgroup
         const dim3 grid(gp_blocks((size_t)m.rows, 128));
         if (p->dtype == GP_DTYPE_F16) hipLaunchKernelGGL(gp_mlp16_fwd4_f16_kernel, grid, dim3(M16_THREADS), 0, s, m, out, saved_xT, saved_hT, masks);

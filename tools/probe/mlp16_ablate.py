@@ -16,7 +16,8 @@ xyz = (torch.rand(rows, 3, device="cuda") * 2.6 - 1.3).requires_grad_(True)
 t = torch.tensor([0.3], device="cuda")
 L = _lib.lib()
 for bits, what in [(0, "full (first: clocks still settling)"), (0, "full"), (1, "no saved-tensor stores"), (3, "no stores at all"), (8, "no input staging"), (4, "no matrix products"),
-                   (16, "no epilogue"), (4 + 16, "no products, no epilogue"), (1 + 2 + 4 + 8 + 16, "nothing but barriers and the output layer"), (0, "full")]:
+                   (16, "no epilogue"), (4 + 16, "no products, no epilogue"), (1 + 2 + 4 + 8 + 16, "nothing but barriers and the output layer"), (0, "full"),
+                   (32, "ONE workgroup per CU"), (32 + 3, "one workgroup per CU, no stores"), (32 + 3 + 8 + 16, "one workgroup per CU: products only"), (3 + 8 + 16, "products only")]:
     _lib.check(L.gp_debug_option(9, bits), "opt")
     for _ in range(4):
         net.forward_fused(feat, xyz, t, 10, F)
