@@ -316,6 +316,10 @@ def main():
     ap.add_argument("--no-fused", action="store_true",
                     help="take every step through the autograd graph (render -> loss -> backward -> FusedAdam.step) instead of the one-call "
                          "fused step (gp_train_step_run): the A/B of TrainStep(fused=...)")
+    ap.add_argument("--early-adam", action="store_true",
+                    help="fused step: the per-Gaussian tensors' Adam update on the library's second stream beside the keypoint MLP's backward "
+                         "instead of ONE optimizer launch behind the backward (gp_step_update.adam_early_mask; measured slower: "
+                         "profiles/r05_early_adam_ab.txt)")
     ap.add_argument("--render-only", action="store_true", help="time eval-style forward renders instead of train steps")
     ap.add_argument("--no-chain-sh", action="store_true",
                     help="N > 1, sharded exchange: keep the SH regions' Adam + all-gather on the compute stream (A/B of TrainStep._chain_sh)")
@@ -352,6 +356,7 @@ def main():
     # [REF arguments/__init__.py:75-76, scene/gaussian_model.py:474-491])
     ts = TrainStep(pc, cams, gts, args.iteration, lrs=dict(xyz=1.6e-6 * 5.0), speculative=not args.exact_binning,
                    sharded=False if args.replicated_adam else None, chain_sh=not args.no_chain_sh, fused=not args.no_fused)
+    ts.early_adam = bool(args.early_adam)
 
     def one_step(i):
         view = i * world + rank            # rank r renders view world*i + r
@@ -580,6 +585,8 @@ def main():
                            getattr(ts.reducer, "bytes_sent_per_step", None) or int(2 * 4 * ts.bucket.flat.numel() * (world - 1) / world)),
                        "exposed_wait_ms_per_step": waits,          # (--time-waits: compute-stream time inside waits for collectives, rank 0)
                        "step_driver": (f"one library call per step (gp_train_step_run): {getattr(ts, 'fused_steps', 0)} of the steps since the set-up"
+                                       + ("; the per-Gaussian tensors' Adam launch runs on a second stream beside the keypoint MLP's backward, so the "
+                                          "sum of kernels_ms may exceed ms_per_step" if (getattr(ts, "early_adam", False) and world == 1) else "")
                                        if getattr(ts, "fused_steps", 0) else "autograd graph (render -> loss -> backward -> FusedAdam.step)"),
                        "binning": "exact (R read back every step)" if args.exact_binning else
                                   f"capacity mode in warm-up and timed steps (no host sync; {preroll} exact-mode set-up steps before the "

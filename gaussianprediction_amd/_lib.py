@@ -121,7 +121,7 @@ class StepUpdateC(C.Structure):
     """gp_step_update."""
     _fields_ = [("binning_capacity", C.c_int64), ("binning_status", C.c_void_p), ("depth_key_bits", C.c_int32), ("depth_key_base", C.c_uint32),
                 ("sh_ready_event", C.c_void_p), ("adam_shs", C.c_void_p),
-                ("adam_count", C.c_int32), ("adam_params", C.c_void_p), ("adam_grads", C.c_void_p), ("adam_exp_avgs", C.c_void_p),
+                ("adam_count", C.c_int32), ("adam_early_mask", C.c_uint32), ("adam_params", C.c_void_p), ("adam_grads", C.c_void_p), ("adam_exp_avgs", C.c_void_p),
                 ("adam_exp_avg_sqs", C.c_void_p), ("adam_numels", C.c_void_p), ("adam_lrs", C.c_void_p), ("adam_steps", C.c_void_p),
                 ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float), ("step", C.c_int64), ("keep_grad_mask", C.c_uint32),
                 ("skip_flag", C.c_void_p), ("hook", STEP_HOOK_FN), ("hook_ctx", C.c_void_p)]

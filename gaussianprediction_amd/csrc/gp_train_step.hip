@@ -10,6 +10,43 @@ __global__ __launch_bounds__(256) void gp_step_accumulate_kernel(float* __restri
     if (i < n) dst[i] += src[i];
 }
 
+// The second stream of the early optimizer launch (gp_step_update.adam_early_mask): one per device, created on first use, never destroyed.
+struct StepSide { hipStream_t s; hipEvent_t fork, join; bool ok; };
+static StepSide* step_side() {
+    static StepSide side[32];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32) return nullptr;
+    StepSide& x = side[dev];
+    if (!x.ok) {
+        if (hipStreamCreateWithFlags(&x.s, hipStreamNonBlocking) != hipSuccess) return nullptr;
+        if (hipEventCreateWithFlags(&x.fork, hipEventDisableTiming) != hipSuccess) return nullptr;
+        if (hipEventCreateWithFlags(&x.join, hipEventDisableTiming) != hipSuccess) return nullptr;
+        x.ok = true;
+    }
+    return &x;
+}
+
+// gp_adam_step_multi[_steps] over the tensors of `u`'s tables selected by `sel`
+static int step_adam(const gp_step_update* u, uint32_t sel, gp_stream_t stream) {
+    float *P[32], *G[32], *M[32], *V[32];
+    int64_t NUM[32], ST[32];
+    float LR[32];
+    int n = 0;
+    uint32_t keep = 0;
+    for (int k = 0; k < u->adam_count && k < 32; ++k) {
+        if (!((sel >> k) & 1u)) continue;
+        P[n] = u->adam_params[k]; G[n] = u->adam_grads[k]; M[n] = u->adam_exp_avgs[k]; V[n] = u->adam_exp_avg_sqs[k];
+        NUM[n] = u->adam_numels[k]; LR[n] = u->adam_lrs[k];
+        if (u->adam_steps) ST[n] = u->adam_steps[k];
+        if ((u->keep_grad_mask >> k) & 1u) keep |= 1u << n;
+        ++n;
+    }
+    if (n == 0) return 0;
+    if (u->adam_steps)
+        return gp_adam_step_multi_steps(n, P, G, M, V, NUM, LR, ST, u->beta1, u->beta2, u->eps, 1, keep, u->skip_flag, stream);
+    return gp_adam_step_multi(n, P, G, M, V, NUM, LR, u->beta1, u->beta2, u->eps, u->step, 1, keep, u->skip_flag, stream);
+}
+
 extern "C" int gp_train_step_run(const gp_step_plan* p, const gp_step_view* v, const gp_step_update* u, gp_alloc_fn alloc,
                                  void* alloc_ctx, gp_stream_t stream) {
     if (!p || !v || !u || !alloc) GP_FAIL("gp_train_step_run: null argument");
@@ -95,6 +132,19 @@ extern "C" int gp_train_step_run(const gp_step_plan* p, const gp_step_view* v, c
         return 1;
     if (gp_blend_backward(&ba, p->g_xyz_t, p->g_q_t, p->g_delta, nullptr, p->g_xyz, p->g_rotation, alloc, alloc_ctx, stream)) return 1;
     alloc(alloc_ctx, GP_BUF_TEMP_DONE, 0);
+    // ---- optimizer, first part [REF train.py:196-197]: the per-Gaussian tensors' gradients are final here.  Their update (HBM-bound,
+    // every CU) runs on the second stream beside the keypoint MLP's backward (latency-bound, 16 CUs): neither touches the other's tensors.
+    if (u->adam_count > 32) GP_FAIL("gp_train_step_run: at most 32 optimizer tensors");
+    const uint32_t all = u->adam_count >= 32 ? 0xFFFFFFFFu : ((1u << u->adam_count) - 1u);
+    uint32_t early = (u->hook || u->adam_count <= 0) ? 0u : (u->adam_early_mask & all);
+    StepSide* side = early ? step_side() : nullptr;
+    if (early && !side) early = 0u;         // (no second stream: one launch behind the backward, as without the mask)
+    if (early) {
+        GP_HIP_CHECK(hipEventRecord(side->fork, (hipStream_t)stream));
+        GP_HIP_CHECK(hipStreamWaitEvent(side->s, side->fork, 0));
+        if (step_adam(u, early, (gp_stream_t)side->s)) return 1;
+        GP_HIP_CHECK(hipEventRecord(side->join, side->s));
+    }
     gp_mlp_grads mg = p->g_mlp;
     if (gp_mlp_backward(&p->mlp, &mi, p->acts, p->g_delta, &mg, reg ? p->g_feature_tmp : p->g_keypoint_features, p->g_keypoints, alloc,
                         alloc_ctx, stream))
@@ -108,14 +158,8 @@ extern "C" int gp_train_step_run(const gp_step_plan* p, const gp_step_view* v, c
 
     // ---- optimizer [REF train.py:196-197, scene/gaussian_model.py:472]
     if (u->adam_count > 0) {
-        if (u->adam_steps) {
-            if (gp_adam_step_multi_steps(u->adam_count, u->adam_params, u->adam_grads, u->adam_exp_avgs, u->adam_exp_avg_sqs, u->adam_numels,
-                                         u->adam_lrs, u->adam_steps, u->beta1, u->beta2, u->eps, 1, u->keep_grad_mask, u->skip_flag, stream))
-                return 1;
-        } else if (gp_adam_step_multi(u->adam_count, u->adam_params, u->adam_grads, u->adam_exp_avgs, u->adam_exp_avg_sqs, u->adam_numels,
-                                      u->adam_lrs, u->beta1, u->beta2, u->eps, u->step, 1, u->keep_grad_mask, u->skip_flag, stream)) {
-            return 1;
-        }
+        if (step_adam(u, all & ~early, stream)) return 1;
+        if (early) GP_HIP_CHECK(hipStreamWaitEvent((hipStream_t)stream, side->join, 0));     // the caller sees ONE stream
     }
     return 0;
 }

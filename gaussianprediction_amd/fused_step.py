@@ -263,6 +263,16 @@ class FusedStage3:
         for k, own in enumerate(opt.owner):
             if id(own) in keep_ids and tab["NUM"][k] != 0:
                 mask |= 1 << k
+        # the per-Gaussian tensors' gradients are final after the blend backward: their update runs beside the keypoint MLP's backward
+        # (gp_step_update.adam_early_mask; single-rank only -- a view-parallel step reduces the gradients first).  OFF by default: measured
+        # slower on the bench workload (profiles/r05_early_adam_ab.txt: the MLP backward slows down beside the HBM-bound Adam stream).
+        early = 0
+        if not ts.reducer.enabled and getattr(ts, "early_adam", False):
+            early_ids = {id(t) for t in (pc._xyz, pc._rotation, pc._scaling, pc._opacity, pc._features_dc, pc._features_rest)}
+            for k, own in enumerate(opt.owner):
+                if id(own) in early_ids and tab["NUM"][k] != 0:
+                    early |= 1 << k
+        u.adam_early_mask = early
         u.binning_capacity, u.binning_status = int(capacity), status.data_ptr()
         u.depth_key_bits, u.depth_key_base = (int(depth_key[0]), int(depth_key[1]) & 0xFFFFFFFF) if depth_key else (0, 0)
         u.adam_shs = C.cast(C.pointer(fuse_c), C.c_void_p) if fuse_c is not None else None

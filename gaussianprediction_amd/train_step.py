@@ -54,6 +54,7 @@ class TrainStep:
         self.pc, self.cameras, self.gt, self.iteration = pc, cameras, gt_images, iteration
         self.view_stats = view_stats
         self.fused = bool(fused)
+        self.early_adam = False                 # fused step: gp_step_update.adam_early_mask (measured slower, profiles/r05_early_adam_ab.txt)
         self._fused_plan = None
         self.fused_steps = 0
         self.lambda_dssim = lambda_dssim

@@ -420,6 +420,13 @@ typedef struct gp_step_update {
     const gp_adam_fuse* adam_shs;/* NULL, or the SH pair's update inside the rasterizer backward */
     /* the optimizer launch behind the backward: gp_adam_step_multi (steps == NULL) / gp_adam_step_multi_steps; count 0 = none */
     int32_t adam_count;
+    /* bit k: tensor k's gradient is FINAL once the blend backward has run (the per-Gaussian tensors: nothing behind that point writes
+     * them) -- those updates are launched there, on a second stream of the library's own, and run beside the keypoint MLP's backward
+     * (three small, latency-bound kernels that occupy 16 CUs); the other tensors follow the MLP backward as before and the call's
+     * stream waits for the second one before the call returns, so a caller sees one stream.  0 = one launch behind the backward
+     * (what TrainStep passes: on the bench workload the overlap measured SLOWER, profiles/r05_early_adam_ab.txt).
+     * Ignored (one launch) when `hook` is set: a view-parallel caller reduces the gradients at GP_STEP_AFTER_BACKWARD first. */
+    uint32_t adam_early_mask;
     float* const* adam_params; float* const* adam_grads; float* const* adam_exp_avgs; float* const* adam_exp_avg_sqs;
     const int64_t* adam_numels; const float* adam_lrs; const int64_t* adam_steps;
     float beta1, beta2, eps;

@@ -14,9 +14,10 @@ from test_gpu_training_api import build  # noqa: E402
 ZERO = dict(xyz=0.0, f_dc=0.0, opacity=0.0, scaling=0.0, rotation=0.0, kpts=0.0, mlp=0.0)
 
 
-def _run(fused, lrs, steps, time_offset=False, n=6000):
+def _run(fused, lrs, steps, time_offset=False, n=6000, early_adam=True):
     pc, cams, gts, raw, rw, idx, args = build(n=n)
     ts = TrainStep(pc, cams, gts, 50000, lrs=lrs, speculative=True, fused=fused)
+    ts.early_adam = early_adam
     pre = len(cams) + TrainStep.SPEC_SLOTS                     # exact-mode set-up steps (graph path in both runs)
     losses = []
     for i in range(pre + steps):
@@ -154,3 +155,32 @@ def test_two_rank_fused_step_equals_the_two_rank_graph_step(tmp_path):
     for k, x in a["params"].items():          # in units of the tensor's learning rate (run-to-run noise: profiles/r05_order_noise.txt)
         d, lr = (x - b["params"][k]).abs(), a["lr"][k]
         assert float(d.median()) <= 0.25 * lr + 1e-7 and float(d.max()) <= 2 * steps * lr + 1e-6, (k, float(d.median()), float(d.max()), lr)
+
+
+def test_early_optimizer_launch_on_the_second_stream_changes_nothing():
+    """gp_step_update.adam_early_mask: the per-Gaussian tensors' Adam update leaves on the library's second stream as soon as the blend
+    backward has run, beside the keypoint MLP's backward.  Same updates as the single launch behind the backward: parameters after
+    real steps agree as two runs of one path do, the step counts are equal, and the call returns with both streams joined (the
+    parameters read right after a step on the caller's stream are the updated ones)."""
+    a = _run(True, None, 8, early_adam=True)
+    b = _run(True, None, 8, early_adam=False)
+    assert a["ts"]._fused_plan.upd.adam_early_mask != 0 and b["ts"]._fused_plan.upd.adam_early_mask == 0
+    assert a["ts"].fused_steps == b["ts"].fused_steps == 8
+    assert np.abs(np.array(a["loss"]) - np.array(b["loss"])).max() < 2e-4
+    lr = {}
+    for g in b["pc"].optimizer.param_groups:
+        for p in g["params"]:
+            lr[id(p)] = max(float(g["lr"]), 1e-7)
+    for (k, x), (_, p) in zip(a["params"].items(), b["pc"].named_parameters()):
+        if id(p) in lr:
+            d = (x - b["params"][k]).abs().flatten()
+            assert float(d.median()) <= 0.25 * lr[id(p)] + 1e-8, (k, float(d.median()), lr[id(p)])
+    for k in a["state"]:
+        assert float(a["state"][k]["step"]) == float(b["state"][k]["step"])
+    # one more step, and the parameters read on the caller's stream WITHOUT a device synchronisation are the updated ones
+    ts, pc = a["ts"], a["pc"]
+    before = pc._xyz.detach().clone()
+    ts.step(a["steps"])
+    after = pc._xyz.detach().clone()          # (enqueued on the caller's stream behind the call)
+    torch.cuda.synchronize()
+    assert torch.equal(after, pc._xyz.detach()) and not torch.equal(before, after)
