@@ -439,3 +439,105 @@ class Activations(torch.autograd.Function):
             if sk is not None:
                 grad_sink.notify(t_)
         return (None if sinks[0] is not None else g_sraw), (None if sinks[1] is not None else g_oraw), g_delta, None, None
+
+
+class MlpInput(torch.autograd.Function):
+    """[feature | PE(xyz, xyz_freq) | PE(t, time_freq)] as a tensor (gp_mlp_input_forward): the input of the GENERIC Deformable_Field
+    path -- the fused kernels build it in LDS [REF scene/gaussian_model.py:180-189, scene/deformable_field.py:63-72]."""
+
+    @staticmethod
+    def forward(ctx, feature, xyz, t, xyz_freq, time_freq):
+        _need_cuda(feature, "MlpInput")
+        dev = feature.device
+        f_c = _c(feature)
+        x_c = _c(xyz) if xyz is not None and xyz_freq > 0 else None
+        t_c = _c(t).reshape(-1)[:1] if t is not None and time_freq > 0 else None
+        rows, fd = f_c.shape
+        xf, tf = (int(xyz_freq) if x_c is not None else 0), (int(time_freq) if t_c is not None else 0)
+        out = torch.empty(rows, fd + 6 * xf + 2 * tf, device=dev)
+        inp = _lib.MlpInputC(rows, fd, xf, tf, f_c.data_ptr(), x_c.data_ptr() if x_c is not None else None,
+                             t_c.data_ptr() if t_c is not None else None)
+        with _lib.on_device(dev):
+            _lib.check(_lib.lib().gp_mlp_input_forward(C.byref(inp), _lib.ptr(out), _lib.stream_ptr(dev)), "gp_mlp_input_forward")
+        ctx.save_for_backward(x_c if x_c is not None else torch.empty(0, device=dev))
+        ctx.meta = (rows, fd, xf, tf, feature.requires_grad, xyz is not None and torch.is_tensor(xyz) and xyz.requires_grad and xf > 0)
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        (x_c,) = ctx.saved_tensors
+        rows, fd, xf, tf, need_f, need_x = ctx.meta
+        dev = g_out.device
+        g = g_out.to(torch.float32).contiguous()
+        d_f = torch.empty(rows, fd, device=dev) if need_f else None
+        d_x = torch.empty(rows, 3, device=dev) if need_x else None
+        if need_f or need_x:
+            inp = _lib.MlpInputC(rows, fd, xf, tf, None, x_c.data_ptr() if xf > 0 else None, None)
+            with _lib.on_device(dev):
+                _lib.check(_lib.lib().gp_mlp_input_backward(C.byref(inp), _lib.ptr(g), _lib.ptr(d_f), _lib.ptr(d_x), _lib.stream_ptr(dev)),
+                           "gp_mlp_input_backward")
+        return d_f, d_x, None, None, None
+
+
+class GenericMlp(torch.autograd.Function):
+    """nn.Sequential(Linear, ReLU, ..., Linear[, Softmax(dim=-1)]) of ANY depth and width, layer by layer on the library's generic
+    dense-layer entries (gp_linear_forward / gp_linear_backward, exact fp32 on the matrix cores) -- Deformable_Field for the shapes the
+    fused kernels do not cover [REF scene/deformable_field.py:74-127].  `wb` = w0, b0, w1, b1, ..., w_out, b_out."""
+
+    @staticmethod
+    def forward(ctx, x, use_softmax, *wb):
+        _need_cuda(x, "GenericMlp")
+        dev = x.device
+        L = _lib.lib()
+        ws = [_c(w) for w in wb[0::2]]
+        bs = [_c(b) for b in wb[1::2]]
+        h = _c(x)
+        rows = h.shape[0]
+        acts = [h]
+        with _lib.on_device(dev):
+            st = _lib.stream_ptr(dev)
+            for l, (w, b) in enumerate(zip(ws, bs)):
+                if w.shape[1] != acts[-1].shape[1]:
+                    raise RuntimeError(f"GenericMlp: layer {l} takes {w.shape[1]} inputs, got {acts[-1].shape[1]}")
+                y = torch.empty(rows, w.shape[0], device=dev)
+                _lib.check(L.gp_linear_forward(_lib.ptr(acts[-1]), C.c_int64(rows), C.c_int32(w.shape[1]), _lib.ptr(w), _lib.ptr(b),
+                                               C.c_int32(w.shape[0]), C.c_int32(1 if l < len(ws) - 1 else 0), _lib.ptr(y), st), "gp_linear_forward")
+                acts.append(y)
+            out = acts[-1]
+            if use_softmax:
+                out = torch.empty_like(acts[-1])
+                _lib.check(L.gp_softmax_forward(_lib.ptr(acts[-1]), C.c_int64(rows), C.c_int32(out.shape[1]), _lib.ptr(out), st), "gp_softmax_forward")
+        need = x.requires_grad or any(t.requires_grad for t in wb)
+        if need:
+            ctx.save_for_backward(out if use_softmax else torch.empty(0, device=dev), *acts[:-1], *ws)
+            ctx.meta = (len(ws), bool(use_softmax), x.requires_grad)
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        n, use_softmax, need_x = ctx.meta
+        saved = ctx.saved_tensors
+        sm, acts, ws = saved[0], saved[1:1 + n], saved[1 + n:1 + 2 * n]
+        dev = g_out.device
+        L = _lib.lib()
+        rows = acts[0].shape[0]
+        g = g_out.to(torch.float32).contiguous()
+        grads = [None] * (2 * n)
+        with _lib.on_device(dev):
+            st = _lib.stream_ptr(dev)
+            if use_softmax:
+                g2 = torch.empty_like(g)
+                _lib.check(L.gp_softmax_backward(_lib.ptr(sm), _lib.ptr(g), C.c_int64(rows), C.c_int32(g.shape[1]), _lib.ptr(g2), st), "gp_softmax_backward")
+                g = g2
+            for l in range(n - 1, -1, -1):
+                w = ws[l]
+                relu = 1 if l < n - 1 else 0
+                # behind a ReLU the layer's own output masks dy: it is the next layer's saved input
+                y = acts[l + 1] if relu else None
+                dw, db = torch.zeros_like(w), torch.zeros(w.shape[0], device=dev)
+                dx = torch.empty(rows, w.shape[1], device=dev) if (l > 0 or need_x) else None
+                _lib.check(L.gp_linear_backward(_lib.ptr(acts[l]), _lib.ptr(y), _lib.ptr(g), C.c_int64(rows), C.c_int32(w.shape[1]), _lib.ptr(w),
+                                                C.c_int32(w.shape[0]), C.c_int32(relu), _lib.ptr(dx), _lib.ptr(dw), _lib.ptr(db), st), "gp_linear_backward")
+                grads[2 * l], grads[2 * l + 1] = dw, db
+                g = dx
+        return (g if need_x else None, None, *grads)

@@ -2,15 +2,17 @@
 [REF scene/deformable_field.py:74-127] (`mlp.{0,2,4,6}.{weight,bias}`, `feature_to_deformation.0.*`), so
 reference checkpoints (`gaussians.state_dict()`, [REF train.py:199-201]) load unchanged and
 `self.df_model.parameters()` feeds the same optimizer group "df_mlp" [REF scene/gaussian_model.py:406].
-The forward is the fused HIP kernel over those same Parameters (fp32 matrix cores); only the live
-configuration of the reference is implemented (d=4, w=256, split_xyz=False, use_softmax=False).
+The forward is the fused HIP kernel over those same Parameters (fp32 matrix cores) for the reference's operating point
+(d=4, w=256, split_xyz=False, use_softmax=False: options/gaussian_option.py:54-55, scene/gaussian_model.py:79).  Every other
+depth / width and the two dormant variants (use_softmax, split_xyz -- same ModuleDict names, so their state_dicts load too) run
+layer by layer on the library's generic dense-layer entries (deform_ops.GenericMlp: exact fp32, any sizes; csrc/deform_generic.hip).
 """
 from __future__ import annotations
 
 import torch
 from torch import nn
 
-from .deform_ops import FusedMlp, FusedMlp16
+from .deform_ops import FusedMlp, FusedMlp16, GenericMlp, MlpInput
 
 
 class Deformable_Field(nn.Module):
@@ -33,36 +35,57 @@ class Deformable_Field(nn.Module):
         self.range_guard = range_guard
         self.range_tripped = False            # an activation left the split form's range: the exact-fp32 kernels from now on
         self._flag = self._flag_host = self._flag_event = None
-        if split_xyz or use_softmax:
-            raise NotImplementedError("split_xyz / use_softmax are dead branches in the reference "
-                                      "(scene/gaussian_model.py:79) and are not implemented")
-        if d != 4 or w != 256:
-            raise NotImplementedError("the HIP kernel implements the reference's operating point d=4, w=256 "
-                                      "(options/gaussian_option.py:54-55)")
+        if d < 1 or w < 1:
+            raise ValueError("Deformable_Field needs d >= 1 hidden layers of width w >= 1")
         self.input_dim, self.output_dim, self.d, self.w = input_dim, output_dim, d, w
         self.use_softmax, self.split_xyz = use_softmax, split_xyz
-        layers = []
-        for i in range(d):
-            layers.append(nn.Linear(input_dim if i == 0 else w, w))
-            layers.append(nn.ReLU())
-        self.mlp = nn.Sequential(*layers)
-        self.feature_to_deformation = nn.Sequential(nn.Linear(w, output_dim))
+        # the fused kernels implement d = 4, w = 256 without the dormant variants; anything else takes the generic layers
+        self.generic = bool(split_xyz or use_softmax or d != 4 or w != 256)
 
-    def _wb(self):
+        def hidden():
+            layers = []
+            for i in range(d):
+                layers.append(nn.Linear(input_dim if i == 0 else w, w))
+                layers.append(nn.ReLU())
+            return nn.Sequential(*layers)
+        if split_xyz:                    # one network per output channel, each with ONE output [REF scene/deformable_field.py:84-99]
+            self.output_times, self.output_dim = output_dim, 1
+            self.mlp = nn.ModuleDict({f"mlp{k:d}": hidden() for k in range(self.output_times)})
+            self.feature_to_deformation = nn.ModuleDict({f"feature_to_deformation{k:d}": nn.Sequential(nn.Linear(w, 1))
+                                                         for k in range(self.output_times)})
+        else:
+            self.mlp = hidden()
+            self.feature_to_deformation = nn.Sequential(nn.Linear(w, output_dim))
+
+    def _chain(self, mlp, head):
         wb = []
         for i in range(self.d):
-            wb += [self.mlp[2 * i].weight, self.mlp[2 * i].bias]
-        wb += [self.feature_to_deformation[0].weight, self.feature_to_deformation[0].bias]
-        return wb
+            wb += [mlp[2 * i].weight, mlp[2 * i].bias]
+        return wb + [head[0].weight, head[0].bias]
+
+    def _generic(self, x):
+        """[REF scene/deformable_field.py:112-127]"""
+        if self.split_xyz:
+            outs = [GenericMlp.apply(x, self.use_softmax, *self._chain(self.mlp[f"mlp{k:d}"], self.feature_to_deformation[f"feature_to_deformation{k:d}"]))
+                    for k in range(self.output_times)]
+            return torch.cat(outs, dim=-1)
+        return GenericMlp.apply(x, self.use_softmax, *self._chain(self.mlp, self.feature_to_deformation))
+
+    def _wb(self):
+        return self._chain(self.mlp, self.feature_to_deformation)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         """x: [M, input_dim] already-concatenated input (the reference's call form)."""
+        if self.generic:
+            return self._generic(x)
         return FusedMlp.apply(x, None, None, 0, 0, *self._wb())
 
     def forward_fused(self, feature, xyz, t, xyz_freq, time_freq) -> torch.Tensor:
         """Fused form used by GaussianModel: builds [feature | PE(xyz) | PE(t)] inside the kernel
         (get_motion_delta, REF scene/gaussian_model.py:180-184) -- the [M, input_dim] input and the
         [M,256] activations never touch HBM in inference."""
+        if self.generic:
+            return self._generic(MlpInput.apply(feature, xyz, t, xyz_freq, time_freq))
         # 16-bit operands pay off for the per-Gaussian passes (10^5..10^6 rows).  A few hundred rows (the keypoints of
         # stage 2/3) are a latency problem, for which the 16-row fp32 kernels are both faster and exact.
         if self.precision != "fp32" and feature.shape[0] > 2048 and not self.range_tripped:

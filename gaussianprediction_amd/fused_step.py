@@ -124,6 +124,8 @@ class FusedStage3:
             return False
         if pc.get_xyz.device.type != "cuda" or ts.iteration <= pc.third_stage_iter or ts.overlap_sh_adam:
             return False
+        if getattr(pc.df_model, "generic", False):       # (--d / --w off the operating point: the layer-by-layer network is an autograd graph)
+            return False
         if ts.reducer.enabled and not (ts.sharded and hasattr(ts.reducer, "gather_params")):
             return False                     # (view-parallel: the sharded exchange only; all-reduce + replicated Adam stays on the graph path)
         if pc.raw_weights is None or pc.knn_idx is None:      # (the per-frame weights model + kNN have autograd functions of their own)

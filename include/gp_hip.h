@@ -222,6 +222,24 @@ int gp_mlp_backward(const gp_mlp_params* p, const gp_mlp_input* x, const float* 
                     gp_mlp_grads* g, float* dL_dfeature, float* dL_dxyz, gp_alloc_fn alloc, void* alloc_ctx,
                     gp_stream_t stream);
 
+/* ---- Deformable_Field for shapes other than d = 4, w = 256 [REF options/gaussian_option.py:54-55; scene/deformable_field.py:74-127:
+ * any depth / width, and the dormant use_softmax / split_xyz variants].  The network runs layer by layer: exact-fp32 matrix cores,
+ * any sizes >= 1, row-major tensors.  (round 5; the fused entries above stay the path of every shipped configuration) */
+/* row i of the network input: [ feature[i, :] | PE(xyz[i], xyz_freq) | PE(t, time_freq) ] -> out [rows, feature_dim + 6 xyz_freq + 2 time_freq] */
+int gp_mlp_input_forward(const gp_mlp_input* x, float* out, gp_stream_t stream);
+/* dL_dfeature [rows, feature_dim] (=, may be NULL), dL_dxyz [rows, 3] through the encoding (=, may be NULL) */
+int gp_mlp_input_backward(const gp_mlp_input* x, const float* dL_din, float* dL_dfeature, float* dL_dxyz, gp_stream_t stream);
+/* nn.Linear (+ nn.ReLU when relu != 0): y [rows, out_dim] = act(x [rows, in_dim] . w [out_dim, in_dim]^T + b [out_dim] (b may be NULL)) */
+int gp_linear_forward(const float* x, int64_t rows, int32_t in_dim, const float* w, const float* b, int32_t out_dim, int32_t relu,
+                      float* y, gp_stream_t stream);
+/* its backward.  y = the forward's output (read only behind a ReLU: dz = dy where y > 0).  dx (=, may be NULL), dw [out_dim, in_dim] and
+ * db [out_dim] (+=, atomics: the caller zeroes or accumulates; each may be NULL) */
+int gp_linear_backward(const float* x, const float* y, const float* dy, int64_t rows, int32_t in_dim, const float* w, int32_t out_dim,
+                       int32_t relu, float* dx, float* dw, float* db, gp_stream_t stream);
+/* nn.Softmax(dim=-1) over [rows, dim] and its backward (dx = y (dy - sum_j y_j dy_j)) */
+int gp_softmax_forward(const float* x, int64_t rows, int32_t dim, float* y, gp_stream_t stream);
+int gp_softmax_backward(const float* y, const float* dy, int64_t rows, int32_t dim, float* dx, gp_stream_t stream);
+
 /* ---- 16-bit-operand variant (fp16 or bf16 inputs, fp32 accumulate; BASELINE config 5).  Opt-in: results
  * differ from the fp32 path at the 1e-3 (fp16) / 1e-2 (bf16) relative level.  Weights are passed as 16-bit
  * copies prepared by the host (zero-padded): forward  w16[0]:[256,in_pad16] w16[1..3]:[256,256] w16[4]:[32,256];

@@ -34,7 +34,7 @@ def build(N=3000, K=60, W=120, H=90, args=None, seed=3):
     kpf = kpf * 50
     d_out = 8 if args.step_opacity else 7
     d_in = 32 + 6 * args.xyz_freq + 2 * args.time_freq
-    sd = mlp_state(77, d_in, d_out)
+    sd = mlp_state(77, d_in, d_out, d=args.d, w=args.w)
     pc = gpa.GaussianModel(3, args)
     pc.set_inputDim(2 * args.time_freq, 6 * args.xyz_freq)
     dev = "cuda"
