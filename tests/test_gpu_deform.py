@@ -222,7 +222,7 @@ def test_get_rotation_matches_reference_quat_mul_golden():
     out = pc.get_rotation_(pc.rotation_activation(q1))
     # the product is bilinear: normalize(normalize(q1) (x) q2) == normalize(q1 (x) q2), the golden product
     want = torch.nn.functional.normalize(torch.tensor(g["q1q2"]).double())
-    assert float((out.double().cpu() - want).abs().max()) < 1e-6
+    assert float((out.detach().double().cpu() - want).abs().max()) < 1e-6
 
 
 def test_small_row_mlp_with_fragment_ordered_weights_is_bit_identical():
