@@ -1292,7 +1292,10 @@ extern "C" int gp_mlp16_backward(const gp_mlp16_params* p /* w16 = TRANSPOSED co
     };
     if (m.rows >= 4096) {       // LDS-staged kernel: grid = (row slabs, jobs), three launches cover the five layers
         const long n_kb = (m.rows + 63) / 64 * (64 / T16_BLK);   // 16-row blocks incl. the zero padding to 64 rows
-        long nslab = n_kb / 64;                                  // 1024-row slabs (every slab ends in 64 k atomic adds) ...
+        // 4096-row slabs: every slab ends in 64 k atomic adds per (layer, term), and below that size they show (round 5, tools/probe/
+        // mlp16_wgrad_slabs.py at 200 k rows: 1024-row slabs 0.72 ms, 4096-row slabs 0.59; 1 M rows sat at the 256-slab cap = 4096 rows already)
+        const int slab_kb = gp_debug_get(10) > 0 ? gp_debug_get(10) : 256;    // (gp_debug_option(10, n): n 16-row blocks per slab)
+        long nslab = n_kb / slab_kb;
         const long few = n_kb / 16 < 32 ? n_kb / 16 : 32;        // ... but at least 32 slabs of >= 256 rows at small row counts
         if (nslab < few) nslab = few;
         if (nslab > 256) nslab = 256;
