@@ -320,6 +320,8 @@ def main():
                     help="fused step: the per-Gaussian tensors' Adam update on the library's second stream beside the keypoint MLP's backward "
                          "instead of ONE optimizer launch behind the backward (gp_step_update.adam_early_mask; measured slower: "
                          "profiles/r05_early_adam_ab.txt)")
+    ap.add_argument("--debug-option", action="append", default=[], metavar="KEY=VALUE",
+                    help="gp_debug_option(KEY, VALUE) before the run (the library's A/B knobs, e.g. 8=2: the three-pass 11-bit depth sort); repeatable")
     ap.add_argument("--render-only", action="store_true", help="time eval-style forward renders instead of train steps")
     ap.add_argument("--no-chain-sh", action="store_true",
                     help="N > 1, sharded exchange: keep the SH regions' Adam + all-gather on the compute stream (A/B of TrainStep._chain_sh)")
@@ -351,6 +353,9 @@ def main():
         if dist.is_available() and dist.is_initialized():
             dist.barrier()                          # (creates the communicator now)
             torch.cuda.synchronize()
+    for kv in args.debug_option:
+        k, v = kv.split("=")
+        _lib.check(_lib.lib().gp_debug_option(int(k), int(v)), "gp_debug_option")
     pc, cams, gts, margs = build_workload(args, device)
     # learning rates of the reference at iteration 50000 (position lr has decayed to position_lr_final,
     # [REF arguments/__init__.py:75-76, scene/gaussian_model.py:474-491])
