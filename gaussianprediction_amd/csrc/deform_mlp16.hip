@@ -492,6 +492,56 @@ __device__ __forceinline__ void gemm16s(const _Float16* cur, const _Float16* __r
     }
 }
 
+#include "deform_mlp16_kloop.inc"
+// The K = 256 split product of a 64-row workgroup as ONE hand-scheduled asm statement (tools/gen_mlp16_kloop.py; same
+// arithmetic and the same MFMA order per accumulator as gemm16s<true, 2>, so the results are bit-identical): weight fragments
+// three k-steps ahead, activation fragments one k-step ahead, counted waits.  CARRY: the statement also writes the tile it is
+// reading -- the saved tensor of the previous layer, `st` = this workgroup's [4 row blocks][512 features][16 rows] block -- one 1 KB
+// store per k-step (wave w owns row block w; k-step g = features 32 g .. 32 g + 31 of [hi | lo']), so that the stores leave the CU
+// at the rate of the product instead of as a 64 KB burst between two products.
+struct Kloop16sAddr {
+    uint32_t abase, voff, sbt, vost;
+};
+__device__ __forceinline__ Kloop16sAddr kloop16s_addr(const _Float16* cur, int wave, int lane) {
+    Kloop16sAddr a;
+    const int half = lane >> 5, j = lane & 31;
+    const uint32_t base = (uint32_t)(uintptr_t)cur;
+    a.abase = base + j * (SP_W * 2) + 2 * ((((j & 15) << 3)) ^ (8 * half));
+    a.voff = lane * 16;
+    // the carried store (one 16-row block x 32 features per k-step g, wave w = row block w): 16-lane group G covers features
+    // 32 g + 16 (G & 1) + 0..15 of rows 8 (G >> 1) + 0..7; as a SOURCE of the transpose read lane 4 jj + q of the group supplies the
+    // address of features 4 q .. 4 q + 3 of row jj (+ 4 in the second pass); k-step and pass enter as one XOR with 64 (g ^ pass)
+    // (+ 4096 for the pass), see tools/gen_mlp16_kloop.py
+    const int G = lane >> 4, fb = G & 1, h = G >> 1, jj = (lane >> 2) & 3, q = lane & 3;
+    a.sbt = base + (16 * wave + 8 * h + jj) * (SP_W * 2) + 2 * (((4 * q + 16 * fb) ^ (jj << 3)) + (h << 6));
+    a.vost = (16 * fb + (lane & 15)) * 32 + 16 * h;
+    return a;
+}
+template <typename P>
+__device__ __forceinline__ P* uniform_ptr(P* p) {       // a wave-uniform pointer, in scalar registers for sure (the "s" operands below)
+    const uint64_t v = (uint64_t)(uintptr_t)p;
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return (P*)(uintptr_t)(((uint64_t)hi << 32) | lo);
+}
+template <bool CARRY>
+__device__ __forceinline__ void kloop16s_asm(const Kloop16sAddr& a, const _Float16* wh, const _Float16* wl, _Float16* st,
+                                             f32x16 (&am)[2][2], f32x16 (&ax)[2][2]) {
+    wh = uniform_ptr(wh); wl = uniform_ptr(wl); st = uniform_ptr(st);
+    if constexpr (CARRY) {
+        asm volatile(M16S_KLOOP_CARRY_ASM
+                     : [am00] "+v"(am[0][0]), [am01] "+v"(am[0][1]), [am10] "+v"(am[1][0]), [am11] "+v"(am[1][1]),
+                       [ax00] "+v"(ax[0][0]), [ax01] "+v"(ax[0][1]), [ax10] "+v"(ax[1][0]), [ax11] "+v"(ax[1][1])
+                     : [abase] "v"(a.abase), [voff] "v"(a.voff), [swh] "s"(wh), [swl] "s"(wl), [sst] "s"(st), [sbt] "v"(a.sbt), [vost] "v"(a.vost)
+                     : "memory", M16S_KLOOP_CARRY_CLOBBERS);
+    } else {
+        asm volatile(M16S_KLOOP_PLAIN_ASM
+                     : [am00] "+v"(am[0][0]), [am01] "+v"(am[0][1]), [am10] "+v"(am[1][0]), [am11] "+v"(am[1][1]),
+                       [ax00] "+v"(ax[0][0]), [ax01] "+v"(ax[0][1]), [ax10] "+v"(ax[1][0]), [ax11] "+v"(ax[1][1])
+                     : [abase] "v"(a.abase), [voff] "v"(a.voff), [swh] "s"(wh), [swl] "s"(wl)
+                     : "memory", M16S_KLOOP_PLAIN_CLOBBERS);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------
@@ -518,18 +568,31 @@ __device__ __forceinline__ void mlp16_fwd_body(Mlp16Dev p, float* __restrict__ o
     else if constexpr (SP) build_input16s<ROWS>(cur, p, row0, tid);
     else build_input16<T, ROWS>(cur, p, row0, tid);
     __syncthreads();
-    auto store_T = [&](const T* buf, T* dst, int nf) {      // this workgroup's block: NS x nf x ROWS contiguous elements
+    auto store_T = [&](const T* buf, T* dst, int nf, int wave, int lane) {      // this workgroup's block: NS x nf x ROWS contiguous elements
         T* blk = dst + (size_t)blockIdx.x * NS * nf * ROWS;
         store_tile_T<T, ROWS, WS>(buf, blk, nf, NS * nf, row0, p.rows, rows_pad, wave, lane);
         if constexpr (SP) store_tile_T<T, ROWS, WS>(buf + 256, blk + (size_t)nf * T16_BLK, nf, NS * nf, row0, p.rows, rows_pad, wave, lane);
     };
     if (ablate & 1) { saved_xT = nullptr; saved_hT = nullptr; }
     if (ablate & 2) masks = nullptr;
-    if (saved_xT) store_T(cur, saved_xT, p.in_pad);
+    if (saved_xT) store_T(cur, saved_xT, p.in_pad, wave, lane);
     typedef typename Vec4<T>::type V4;
+    // split mode, 64-row workgroups: the K = 256 products run as hand-scheduled statements which also write the saved tensor of the
+    // layer they read (kloop16s_asm); the last, partial workgroup (zero padding rows) and the `ablate & 64` A/B keep the burst form
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    [[maybe_unused]] const bool carry = SP && RT == 2 && saved_hT && row0 + ROWS <= p.rows && !(ablate & 64);
+    [[maybe_unused]] auto hblk = [&](int i) { return (_Float16*)saved_hT + (size_t)i * t16_elems(NS * M16_W, p.rows) + (size_t)blockIdx.x * NS * M16_W * ROWS; };
     float amax = 0.f;                   // split mode: the largest hidden activation this lane carried into (hi, lo') form
+    const int lane_k = lane;
     for (int l = 0; l < 4; ++l) {
         const int K = l == 0 ? p.in_pad : M16_W;
+        // Everything derived from the lane number is recomputed per layer (the empty statement hides the value's origin): hoisted out
+        // of the layer loop, the epilogue's and the stores' per-lane addresses were ~70 registers live ACROSS the product, which has
+        // none to spare -- its statement owns 104 fixed registers beside the 128 accumulators
+        int lane = lane_k;
+        if constexpr (SP && RT == 2) asm volatile("" : "+v"(lane));
+        const int half = lane >> 5, j = lane & 31;
+        const int wave = wave_u;        // (uniform: whatever is derived from it lives in scalar registers)
         f32x16 acc[RT][2];
         f32x16 ax[SP ? RT : 1][2];
 #pragma unroll
@@ -549,7 +612,17 @@ __device__ __forceinline__ void mlp16_fwd_body(Mlp16Dev p, float* __restrict__ o
                 for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) ax[rt][nt][r] = 0.f;
-            if (!(ablate & 4)) gemm16s<true, RT>(cur, (const _Float16*)p.w[l], (const _Float16*)p.wlo[l], K, K, M16_W, wave, lane, acc, ax);
+            if (!(ablate & 4)) {
+                if constexpr (RT == 2) {
+                    if (l >= 1 && !(ablate & 64)) {     // the hand-scheduled product (K = 256), carrying the stores of H_{l-1}
+                        const Kloop16sAddr ka = kloop16s_addr((const _Float16*)cur, wave_u, lane);
+                        const _Float16* wh = (const _Float16*)p.w[l] + wave_u * 1024;
+                        const _Float16* wl = (const _Float16*)p.wlo[l] + wave_u * 1024;
+                        if (carry) kloop16s_asm<true>(ka, wh, wl, hblk(l - 1) + wave_u * (NS * M16_W * T16_BLK), acc, ax);
+                        else kloop16s_asm<false>(ka, wh, wl, nullptr, acc, ax);
+                    } else gemm16s<true, RT>(cur, (const _Float16*)p.w[l], (const _Float16*)p.wlo[l], K, K, M16_W, wave, lane, acc, ax);
+                } else gemm16s<true, RT>(cur, (const _Float16*)p.w[l], (const _Float16*)p.wlo[l], K, K, M16_W, wave, lane, acc, ax);
+            }
         } else {
             if (!(ablate & 4)) gemm16<T, true, RT>(cur, (const T*)p.w[l], K, K, M16_W, wave, lane, acc);
         }
@@ -590,7 +663,7 @@ __device__ __forceinline__ void mlp16_fwd_body(Mlp16Dev p, float* __restrict__ o
             }
         }
         __syncthreads();
-        if (saved_hT) store_T(nxt, saved_hT + (size_t)l * t16_elems(NS * M16_W, p.rows), M16_W);
+        if (saved_hT && !(carry && l < 3)) store_T(nxt, saved_hT + (size_t)l * t16_elems(NS * M16_W, p.rows), M16_W, wave, lane);
         T* t = cur; cur = nxt; nxt = t;
     }
     if constexpr (SP) {
