@@ -783,8 +783,20 @@ __device__ __forceinline__ void mlp16_bwd_data_body(Mlp16Dev p, const uint32_t* 
     }
     __syncthreads();
     typedef typename Vec4<T>::type V4;
+    // split mode, 64-row workgroups: the K = 256 products (l = 3, 2, 1) are the hand-scheduled statements of the forward
+    // (kloop16s_asm), each carrying the stores of the tensor it reads, dZ of layer index l; index 0 and the last, partial
+    // workgroup keep the burst form.  gp_debug_option(9, 64): the compiler's loops, for A/B.
+    const int ablate = g_m16_ablate;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    [[maybe_unused]] const bool carry = SP && RT == 2 && row0 + ROWS <= p.rows && !(ablate & 64);
+    [[maybe_unused]] auto zblk = [&](int i) { return (_Float16*)dzT + (size_t)i * t16_elems(NS * M16_W, p.rows) + (size_t)blockIdx.x * NS * M16_W * ROWS; };
+    const int lane_k = lane;
     for (int l = 4; l >= 1; --l) {
         const int K = l == 4 ? 16 : M16_W;
+        int lane = lane_k;                  // (per-lane addresses recomputed per layer: see the forward)
+        if constexpr (SP && RT == 2) asm volatile("" : "+v"(lane));
+        const int half = lane >> 5, j = lane & 31;
+        const int wave = wave_u;
         f32x16 acc[RT][2];
         f32x16 ax[SP ? RT : 1][2];
 #pragma unroll
@@ -806,8 +818,17 @@ __device__ __forceinline__ void mlp16_bwd_data_body(Mlp16Dev p, const uint32_t* 
                 for (int nt = 0; nt < 2; ++nt) mreg[rt][nt] = mk[(grow < p.rows ? grow : p.rows - 1) * 8 + (2 * wave + nt)];
             }
         }
-        if constexpr (SP) gemm16s<true, RT>(cur, (const _Float16*)p.w[l], (const _Float16*)p.wlo[l], K, K, M16_W, wave, lane, acc, ax);
-        else gemm16<T, true, RT>(cur, (const T*)p.w[l], K, K, M16_W, wave, lane, acc);
+        if constexpr (SP) {
+            if constexpr (RT == 2) {
+                if (l <= 3 && !(ablate & 64)) {
+                    const Kloop16sAddr ka = kloop16s_addr((const _Float16*)cur, wave_u, lane);
+                    const _Float16* wh = (const _Float16*)p.w[l] + wave_u * 1024;
+                    const _Float16* wl = (const _Float16*)p.wlo[l] + wave_u * 1024;
+                    if (carry) kloop16s_asm<true>(ka, wh, wl, zblk(l) + wave_u * (NS * M16_W * T16_BLK), acc, ax);
+                    else kloop16s_asm<false>(ka, wh, wl, nullptr, acc, ax);
+                } else gemm16s<true, RT>(cur, (const _Float16*)p.w[l], (const _Float16*)p.wlo[l], K, K, M16_W, wave, lane, acc, ax);
+            } else gemm16s<true, RT>(cur, (const _Float16*)p.w[l], (const _Float16*)p.wlo[l], K, K, M16_W, wave, lane, acc, ax);
+        } else gemm16<T, true, RT>(cur, (const T*)p.w[l], K, K, M16_W, wave, lane, acc);
         if (INPLACE) __syncthreads();
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
@@ -838,7 +859,7 @@ __device__ __forceinline__ void mlp16_bwd_data_body(Mlp16Dev p, const uint32_t* 
             }
         }
         __syncthreads();
-        {   // dZ_l^T -> global, blocked
+        if (!(carry && l > 1)) {   // dZ_l^T -> global, blocked (carried by the next product otherwise)
             T* blk = dzT + (size_t)(l - 1) * t16_elems(NS * M16_W, p.rows) + (size_t)blockIdx.x * NS * M16_W * ROWS;
             store_tile_T<T, ROWS, WS>(nxt, blk, M16_W, NS * M16_W, row0, p.rows, rows_pad, wave, lane);
             if constexpr (SP) store_tile_T<T, ROWS, WS>(nxt + 256, blk + (size_t)M16_W * T16_BLK, M16_W, NS * M16_W, row0, p.rows, rows_pad, wave, lane);

@@ -42,6 +42,25 @@ for n in (rows, 64 * 3 + 37, 4096 + 5):
     same = [bool(torch.equal(x.view(torch.int16) if x.dtype in (torch.float16, torch.bfloat16) else x, y.view(torch.int16) if y.dtype in (torch.float16, torch.bfloat16) else y)) for x, y in zip(a, b)]
     print(f"rows {n}: out / xT / hT / masks bit-identical between the two forms: {same}", flush=True)
 
+
+
+def grads(n, bits):
+    g = torch.Generator("cuda").manual_seed(5)
+    f = (torch.rand(n, 32, device="cuda", generator=g) - 0.5).requires_grad_(True)
+    x = (torch.rand(n, 3, device="cuda", generator=g) * 2.6 - 1.3).requires_grad_(True)
+    gy = torch.randn(n, 7, device="cuda", generator=g)
+    _lib.check(L.gp_debug_option(9, bits), "opt")
+    net.zero_grad(set_to_none=True)
+    net.forward_fused(f, x, torch.tensor([0.3], device="cuda"), 10, F).backward(gy)
+    torch.cuda.synchronize()
+    return [f.grad, x.grad] + [q.grad.clone() for q in net.parameters()]
+
+
+for n in (65536 + 77, 64 * 3 + 37 + 4096):
+    a, b = grads(n, 64), grads(n, 0)
+    print(f"rows {n}: backward: dfeature / dxyz bit-identical {torch.equal(a[0], b[0])} {torch.equal(a[1], b[1])};  weight-gradient rel. differences (atomic order only) "
+          + " ".join(f"{float((u - v).norm() / u.norm()):.1e}" for u, v in zip(a[2:], b[2:])), flush=True)
+
 feat = (torch.rand(rows, 32, device="cuda") - 0.5).requires_grad_(True)
 xyz = (torch.rand(rows, 3, device="cuda") * 2.6 - 1.3).requires_grad_(True)
 t = torch.tensor([0.3], device="cuda")
