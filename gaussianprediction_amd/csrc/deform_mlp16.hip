@@ -116,6 +116,19 @@ __device__ __forceinline__ b4 pack4(float a, float b, float c, float d, __bf16) 
     return (b4){lo[0], lo[1], hi[0], hi[1]};
 }
 
+// ReLU sign masks (forward -> data backward).  The two kernels give a lane the same values -- row = lane & 31 (+ 32 rt), half = lane >> 5,
+// 16 features per 32-feature tile: 8 g + 4 half + e -- so a lane keeps ITS 32 signs of a row (two tiles) in one private dword:
+// masks[layer][wave][row][half], bit 31 - (16 nt + 4 g + e) (the values are pushed in loop order, newest at bit 0).
+__device__ __forceinline__ size_t relu_mask_idx(int l, int wave, long row, int half, long rows) { return (((size_t)l * 4 + wave) * rows + row) * 2 + half; }
+__device__ __forceinline__ constexpr int relu_mask_pos(int nt, int g, int e) { return 31 - (16 * nt + 4 * g + e); }
+// max(z, 0) and its sign pushed into `m`: the INTEGER maximum maps every non-positive float (-0 included) to +0 exactly, after
+// which "v > 0" is "the bits are not zero" = the sign of (0 - bits): three instructions per value (v_max_i32, v_sub_u32, v_alignbit_b32)
+__device__ __forceinline__ float relu_push(float z, uint32_t& m) {
+    const int b = max(__float_as_int(z), 0);
+    m = __builtin_amdgcn_alignbit(m, 0u - (uint32_t)b, 31);
+    return __int_as_float(b);
+}
+
 template <typename T> struct Vec2;
 template <> struct Vec2<_Float16> { typedef _Float16 type __attribute__((ext_vector_type(2))); };
 template <> struct Vec2<__bf16> { typedef __bf16 type __attribute__((ext_vector_type(2))); };
@@ -493,12 +506,13 @@ __device__ __forceinline__ void gemm16s(const _Float16* cur, const _Float16* __r
 }
 
 #include "deform_mlp16_kloop.inc"
-// The K = 256 split product of a 64-row workgroup as ONE hand-scheduled asm statement (tools/gen_mlp16_kloop.py; same
-// arithmetic and the same MFMA order per accumulator as gemm16s<true, 2>, so the results are bit-identical): weight fragments
-// three k-steps ahead, activation fragments one k-step ahead, counted waits.  CARRY: the statement also writes the tile it is
-// reading -- the saved tensor of the previous layer, `st` = this workgroup's [4 row blocks][512 features][16 rows] block -- one 1 KB
-// store per k-step (wave w owns row block w; k-step g = features 32 g .. 32 g + 31 of [hi | lo']), so that the stores leave the CU
-// at the rate of the product instead of as a 64 KB burst between two products.
+// The split product of a 64-row workgroup as ONE hand-scheduled asm statement per layer (tools/gen_mlp16_kloop.py; same arithmetic and
+// the same MFMA order per accumulator as gemm16s<true, 2>: bit-identical results): weight fragments three k-steps ahead, activation
+// fragments one k-step ahead, counted waits, and -- in the training / backward forms -- the stores of the tile being read: the saved
+// tensor of the previous layer, `st` = this workgroup's [4 row blocks][512 features][16 rows] block, one 1 KB store per k-step (wave w
+// owns row block w; k-step g = features 32 g .. 32 g + 31 of [hi | lo']), so that the stores leave the CU at the rate of the product
+// instead of as a 64 KB burst between two products.  `sel` picks the statement's second path: the layer with its own depth
+// (forward: layer 0, K = 112; data backward: the output layer, K = 16), which carries nothing.
 struct Kloop16sAddr {
     uint32_t abase, voff, sbt, vost;
 };
@@ -523,155 +537,53 @@ __device__ __forceinline__ P* uniform_ptr(P* p) {       // a wave-uniform pointe
     const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
     return (P*)(uintptr_t)(((uint64_t)hi << 32) | lo);
 }
-template <bool CARRY>
-__device__ __forceinline__ void kloop16s_asm(const Kloop16sAddr& a, const _Float16* wh, const _Float16* wl, _Float16* st,
+#define M16S_ACC_OUT(am, ax)                                                                                                   \
+    [am10] "=&v"(am[1][0]), [am11] "=&v"(am[1][1]), [ax00] "=&v"(ax[0][0]), [ax01] "=&v"(ax[0][1]), [ax10] "=&v"(ax[1][0]),       \
+        [ax11] "=&v"(ax[1][1])
+// forward: am[0][*] hold the biases on entry (the statement never initialises an accumulator with moves), everything else is output only
+template <bool TRAIN>
+__device__ __forceinline__ void kloop16s_fwd(const Kloop16sAddr& a, const _Float16* wh, const _Float16* wl, _Float16* st, int first,
+                                             f32x16 (&am)[2][2], f32x16 (&ax)[2][2]) {
+    wh = uniform_ptr(wh); wl = uniform_ptr(wl);
+    first = __builtin_amdgcn_readfirstlane(first);
+    if constexpr (TRAIN) {
+        st = uniform_ptr(st);
+        asm volatile(M16S_FWD_TRAIN_ASM
+                     : [am00] "+v"(am[0][0]), [am01] "+v"(am[0][1]), M16S_ACC_OUT(am, ax)
+                     : [abase] "v"(a.abase), [voff] "v"(a.voff), [swh] "s"(wh), [swl] "s"(wl), [sel] "s"(first), [sst] "s"(st), [sbt] "v"(a.sbt),
+                       [vost] "v"(a.vost)
+                     : "memory", "scc", M16S_KLOOP_CLOBBERS);
+    } else {
+        asm volatile(M16S_FWD_INFER_ASM
+                     : [am00] "+v"(am[0][0]), [am01] "+v"(am[0][1]), M16S_ACC_OUT(am, ax)
+                     : [abase] "v"(a.abase), [voff] "v"(a.voff), [swh] "s"(wh), [swl] "s"(wl), [sel] "s"(first)
+                     : "memory", "scc", M16S_KLOOP_CLOBBERS);
+    }
+}
+// data backward: nothing is read on entry
+__device__ __forceinline__ void kloop16s_bwd(const Kloop16sAddr& a, const _Float16* wh, const _Float16* wl, _Float16* st, int last,
                                              f32x16 (&am)[2][2], f32x16 (&ax)[2][2]) {
     wh = uniform_ptr(wh); wl = uniform_ptr(wl); st = uniform_ptr(st);
-    if constexpr (CARRY) {
-        asm volatile(M16S_KLOOP_CARRY_ASM
-                     : [am00] "+v"(am[0][0]), [am01] "+v"(am[0][1]), [am10] "+v"(am[1][0]), [am11] "+v"(am[1][1]),
-                       [ax00] "+v"(ax[0][0]), [ax01] "+v"(ax[0][1]), [ax10] "+v"(ax[1][0]), [ax11] "+v"(ax[1][1])
-                     : [abase] "v"(a.abase), [voff] "v"(a.voff), [swh] "s"(wh), [swl] "s"(wl), [sst] "s"(st), [sbt] "v"(a.sbt), [vost] "v"(a.vost)
-                     : "memory", M16S_KLOOP_CARRY_CLOBBERS);
-    } else {
-        asm volatile(M16S_KLOOP_PLAIN_ASM
-                     : [am00] "+v"(am[0][0]), [am01] "+v"(am[0][1]), [am10] "+v"(am[1][0]), [am11] "+v"(am[1][1]),
-                       [ax00] "+v"(ax[0][0]), [ax01] "+v"(ax[0][1]), [ax10] "+v"(ax[1][0]), [ax11] "+v"(ax[1][1])
-                     : [abase] "v"(a.abase), [voff] "v"(a.voff), [swh] "s"(wh), [swl] "s"(wl)
-                     : "memory", M16S_KLOOP_PLAIN_CLOBBERS);
-    }
+    last = __builtin_amdgcn_readfirstlane(last);
+    asm volatile(M16S_BWD_DATA_ASM
+                 : [am00] "=&v"(am[0][0]), [am01] "=&v"(am[0][1]), M16S_ACC_OUT(am, ax)
+                 : [abase] "v"(a.abase), [voff] "v"(a.voff), [swh] "s"(wh), [swl] "s"(wl), [sel] "s"(last), [sst] "s"(st), [sbt] "v"(a.sbt),
+                   [vost] "v"(a.vost)
+                 : "memory", "scc", M16S_KLOOP_CLOBBERS);
 }
 
 // ------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------
-// RT = 32-row tiles per wave.  RT = 2: 64 rows per workgroup, double-buffered activations.  RT = 4 (large row counts): 128
-// rows per workgroup, so every weight fragment fetched from L2 feeds four MFMAs instead of two; the activations are
-// updated IN PLACE (one 64 KB tile, two workgroups per CU) behind one extra barrier per layer.
-template <typename T, int RT, bool SP = false>
-__device__ __forceinline__ void mlp16_fwd_body(Mlp16Dev p, float* __restrict__ out, T* __restrict__ saved_xT /*[in_pad][rows]*/,
-                                               T* __restrict__ saved_hT /*[4][256][rows]*/,
-                                               uint32_t* __restrict__ masks /*[4][rows][8]*/) {
+// The output layer of the forward: W4 padded to [32][256]; the 4 waves split K, reduce through LDS (fp32).  `cur` = the last hidden
+// activations (LDS), `nxt` = scratch for the reduction (the same tile when the activations are updated in place).
+template <typename T, int RT, bool SP>
+__device__ __forceinline__ void mlp16_output_layer(const Mlp16Dev& p, float* __restrict__ out, const T* cur, T* nxt, long row0, int tid) {
     constexpr int ROWS = 32 * RT;
     constexpr int WS = SP ? SP_W : M16_W;
-    constexpr int NS = SP ? 2 : 1;                              // saved "features" per real feature
     constexpr bool INPLACE = RT > 2 || SP;
-    __shared__ T smem[INPLACE ? 1 : 2][ROWS * WS];
     typedef typename Vec8<T>::type V8;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, j = lane & 31;
-    const long row0 = (long)blockIdx.x * ROWS;
-    const long rows_pad = (p.rows + 63) & ~63L;                 // the saved tensors are allocated (and zero-padded) to 64 rows
-    T* cur = smem[0];
-    T* nxt = smem[INPLACE ? 0 : 1];
-    const int ablate = g_m16_ablate;
-    if (ablate & 8) { for (int e = tid; e < ROWS * WS; e += M16_THREADS) cur[e] = (T)0.f; }
-    else if constexpr (SP) build_input16s<ROWS>(cur, p, row0, tid);
-    else build_input16<T, ROWS>(cur, p, row0, tid);
-    __syncthreads();
-    auto store_T = [&](const T* buf, T* dst, int nf, int wave, int lane) {      // this workgroup's block: NS x nf x ROWS contiguous elements
-        T* blk = dst + (size_t)blockIdx.x * NS * nf * ROWS;
-        store_tile_T<T, ROWS, WS>(buf, blk, nf, NS * nf, row0, p.rows, rows_pad, wave, lane);
-        if constexpr (SP) store_tile_T<T, ROWS, WS>(buf + 256, blk + (size_t)nf * T16_BLK, nf, NS * nf, row0, p.rows, rows_pad, wave, lane);
-    };
-    if (ablate & 1) { saved_xT = nullptr; saved_hT = nullptr; }
-    if (ablate & 2) masks = nullptr;
-    if (saved_xT) store_T(cur, saved_xT, p.in_pad, wave, lane);
-    typedef typename Vec4<T>::type V4;
-    // split mode, 64-row workgroups: the K = 256 products run as hand-scheduled statements which also write the saved tensor of the
-    // layer they read (kloop16s_asm); the last, partial workgroup (zero padding rows) and the `ablate & 64` A/B keep the burst form
-    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-    [[maybe_unused]] const bool carry = SP && RT == 2 && saved_hT && row0 + ROWS <= p.rows && !(ablate & 64);
-    [[maybe_unused]] auto hblk = [&](int i) { return (_Float16*)saved_hT + (size_t)i * t16_elems(NS * M16_W, p.rows) + (size_t)blockIdx.x * NS * M16_W * ROWS; };
-    float amax = 0.f;                   // split mode: the largest hidden activation this lane carried into (hi, lo') form
-    const int lane_k = lane;
-    for (int l = 0; l < 4; ++l) {
-        const int K = l == 0 ? p.in_pad : M16_W;
-        // Everything derived from the lane number is recomputed per layer (the empty statement hides the value's origin): hoisted out
-        // of the layer loop, the epilogue's and the stores' per-lane addresses were ~70 registers live ACROSS the product, which has
-        // none to spare -- its statement owns 104 fixed registers beside the 128 accumulators
-        int lane = lane_k;
-        if constexpr (SP && RT == 2) asm volatile("" : "+v"(lane));
-        const int half = lane >> 5, j = lane & 31;
-        const int wave = wave_u;        // (uniform: whatever is derived from it lives in scalar registers)
-        f32x16 acc[RT][2];
-        f32x16 ax[SP ? RT : 1][2];
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {   // this lane's features of tile nt: runs of four at (2 wave + nt) * 32 + 8 g + 4 half
-                const float4 bv = *(const float4*)(p.b[l] + (2 * wave + nt) * 32 + 8 * g + 4 * half);
-#pragma unroll
-                for (int rt = 0; rt < RT; ++rt) {
-                    acc[rt][nt][4 * g + 0] = bv.x; acc[rt][nt][4 * g + 1] = bv.y; acc[rt][nt][4 * g + 2] = bv.z; acc[rt][nt][4 * g + 3] = bv.w;
-                }
-            }
-        if constexpr (SP) {
-#pragma unroll
-            for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-                for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) ax[rt][nt][r] = 0.f;
-            if (!(ablate & 4)) {
-                if constexpr (RT == 2) {
-                    if (l >= 1 && !(ablate & 64)) {     // the hand-scheduled product (K = 256), carrying the stores of H_{l-1}
-                        const Kloop16sAddr ka = kloop16s_addr((const _Float16*)cur, wave_u, lane);
-                        const _Float16* wh = (const _Float16*)p.w[l] + wave_u * 1024;
-                        const _Float16* wl = (const _Float16*)p.wlo[l] + wave_u * 1024;
-                        if (carry) kloop16s_asm<true>(ka, wh, wl, hblk(l - 1) + wave_u * (NS * M16_W * T16_BLK), acc, ax);
-                        else kloop16s_asm<false>(ka, wh, wl, nullptr, acc, ax);
-                    } else gemm16s<true, RT>(cur, (const _Float16*)p.w[l], (const _Float16*)p.wlo[l], K, K, M16_W, wave, lane, acc, ax);
-                } else gemm16s<true, RT>(cur, (const _Float16*)p.w[l], (const _Float16*)p.wlo[l], K, K, M16_W, wave, lane, acc, ax);
-            }
-        } else {
-            if (!(ablate & 4)) gemm16<T, true, RT>(cur, (const T*)p.w[l], K, K, M16_W, wave, lane, acc);
-        }
-        if (INPLACE) __syncthreads();       // every wave has read the layer's input before anyone overwrites it
-        if (!(ablate & 16))
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt) {
-            const int row = rt * 32 + j;
-            const long grow = row0 + row;
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt) {
-                uint32_t mbits = 0;
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int f0 = (2 * wave + nt) * 32 + 8 * g + 4 * half;
-                    float v[4];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        float z = acc[rt][nt][4 * g + e];
-                        if constexpr (SP) z = fmaf(ax[rt][nt][4 * g + e], SP_LO_INV, z);
-                        v[e] = fmaxf(z, 0.f);
-                        mbits |= (v[e] > 0.f ? 1u : 0u) << (8 * g + 4 * half + e);
-                    }
-                    if constexpr (SP) {
-                        h4 hi, lo;
-                        split4(v, hi, lo);
-                        amax = fmaxf(fmaxf(amax, fmaxf(v[0], v[1])), fmaxf(v[2], v[3]));       // (post-ReLU: non-negative; two v_max3)
-                        *(h4*)&nxt[a16_idx<WS>(row, f0)] = hi;
-                        *(h4*)&nxt[a16_idx<WS>(row, 256 + f0)] = lo;
-                    } else {
-                        *(V4*)&nxt[a16_idx(row, f0)] = pack4(v[0], v[1], v[2], v[3], T());   // four consecutive features: one 8-byte store
-                    }
-                }
-                if (masks) {   // sign bits of this (row, 32-feature tile): the two halves hold complementary bits
-                    const uint32_t full = mbits | (uint32_t)__shfl_xor((int)mbits, 32);
-                    if (half == 0 && grow < p.rows) masks[((size_t)l * p.rows + grow) * 8 + (2 * wave + nt)] = full;
-                }
-            }
-        }
-        __syncthreads();
-        if (saved_hT && !(carry && l < 3)) store_T(nxt, saved_hT + (size_t)l * t16_elems(NS * M16_W, p.rows), M16_W, wave, lane);
-        T* t = cur; cur = nxt; nxt = t;
-    }
-    if constexpr (SP) {
-        // The range guard of "fp32s" (round-4 verdict): hi = fp16(x) saturates at 65504 -- silently.  An activation at or above 2^15
-        // (a factor 2 of headroom) raises the caller's flag; the host then re-runs the pass on the exact-fp32 kernels or, checking
-        // lazily, switches to them from the next pass on (deform_ops / deformable_field.py).  NaN compares false: not flagged here.
-        if (p.range_flag && amax >= 32768.f) atomicOr(p.range_flag, 1u);
-    }
+    const int lane = tid & 63, wave = tid >> 6, half = lane >> 5, j = lane & 31;
     {   // output layer: W4 padded to [32][256]; the 4 waves split K, reduce through LDS (fp32)
         f32x16 acc[RT];
         f32x16 ax[SP ? RT : 1];
@@ -725,6 +637,111 @@ __device__ __forceinline__ void mlp16_fwd_body(Mlp16Dev p, float* __restrict__ o
     }
 }
 
+// RT = 32-row tiles per wave.  RT = 2: 64 rows per workgroup, double-buffered activations.  RT = 4 (large row counts): 128
+// rows per workgroup, so every weight fragment fetched from L2 feeds four MFMAs instead of two; the activations are
+// updated IN PLACE (one 64 KB tile, two workgroups per CU) behind one extra barrier per layer.
+template <typename T, int RT, bool SP = false>
+__device__ __forceinline__ void mlp16_fwd_body(Mlp16Dev p, float* __restrict__ out, T* __restrict__ saved_xT /*[in_pad][rows]*/,
+                                               T* __restrict__ saved_hT /*[4][256][rows]*/,
+                                               uint32_t* __restrict__ masks /*[4][rows][8]*/) {
+    constexpr int ROWS = 32 * RT;
+    constexpr int WS = SP ? SP_W : M16_W;
+    constexpr int NS = SP ? 2 : 1;                              // saved "features" per real feature
+    constexpr bool INPLACE = RT > 2 || SP;
+    __shared__ T smem[INPLACE ? 1 : 2][ROWS * WS];
+    typedef typename Vec8<T>::type V8;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, j = lane & 31;
+    const long row0 = (long)blockIdx.x * ROWS;
+    const long rows_pad = (p.rows + 63) & ~63L;                 // the saved tensors are allocated (and zero-padded) to 64 rows
+    T* cur = smem[0];
+    T* nxt = smem[INPLACE ? 0 : 1];
+    const int ablate = g_m16_ablate;
+    if (ablate & 8) { for (int e = tid; e < ROWS * WS; e += M16_THREADS) cur[e] = (T)0.f; }
+    else if constexpr (SP) build_input16s<ROWS>(cur, p, row0, tid);
+    else build_input16<T, ROWS>(cur, p, row0, tid);
+    __syncthreads();
+    auto store_T = [&](const T* buf, T* dst, int nf, int wave, int lane) {      // this workgroup's block: NS x nf x ROWS contiguous elements
+        T* blk = dst + (size_t)blockIdx.x * NS * nf * ROWS;
+        store_tile_T<T, ROWS, WS>(buf, blk, nf, NS * nf, row0, p.rows, rows_pad, wave, lane);
+        if constexpr (SP) store_tile_T<T, ROWS, WS>(buf + 256, blk + (size_t)nf * T16_BLK, nf, NS * nf, row0, p.rows, rows_pad, wave, lane);
+    };
+    if (ablate & 1) { saved_xT = nullptr; saved_hT = nullptr; }
+    if (ablate & 2) masks = nullptr;
+    if (saved_xT) store_T(cur, saved_xT, p.in_pad, wave, lane);
+    typedef typename Vec4<T>::type V4;
+    float amax = 0.f;                   // split mode: the largest hidden activation this lane carried into (hi, lo') form
+    for (int l = 0; l < 4; ++l) {
+        const int K = l == 0 ? p.in_pad : M16_W;
+        f32x16 acc[RT][2];
+        f32x16 ax[SP ? RT : 1][2];
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {   // this lane's features of tile nt: runs of four at (2 wave + nt) * 32 + 8 g + 4 half
+                const float4 bv = *(const float4*)(p.b[l] + (2 * wave + nt) * 32 + 8 * g + 4 * half);
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) {
+                    acc[rt][nt][4 * g + 0] = bv.x; acc[rt][nt][4 * g + 1] = bv.y; acc[rt][nt][4 * g + 2] = bv.z; acc[rt][nt][4 * g + 3] = bv.w;
+                }
+            }
+        if constexpr (SP) {
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) ax[rt][nt][r] = 0.f;
+            if (!(ablate & 4)) gemm16s<true, RT>(cur, (const _Float16*)p.w[l], (const _Float16*)p.wlo[l], K, K, M16_W, wave, lane, acc, ax);
+        } else {
+            if (!(ablate & 4)) gemm16<T, true, RT>(cur, (const T*)p.w[l], K, K, M16_W, wave, lane, acc);
+        }
+        if (INPLACE) __syncthreads();       // every wave has read the layer's input before anyone overwrites it
+        if (!(ablate & 16))
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            const int row = rt * 32 + j;
+            const long grow = row0 + row;
+            uint32_t mbits = 0;                 // ReLU signs of this lane's 32 values of the row (relu_mask_pos)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int f0 = (2 * wave + nt) * 32 + 8 * g + 4 * half;
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float z = acc[rt][nt][4 * g + e];
+                        if constexpr (SP) z = fmaf(ax[rt][nt][4 * g + e], SP_LO_INV, z);
+                        v[e] = relu_push(z, mbits);
+                    }
+                    if constexpr (SP) {
+                        h4 hi, lo;
+                        split4(v, hi, lo);
+                        amax = fmaxf(fmaxf(amax, fmaxf(v[0], v[1])), fmaxf(v[2], v[3]));       // (post-ReLU: non-negative; two v_max3)
+                        *(h4*)&nxt[a16_idx<WS>(row, f0)] = hi;
+                        *(h4*)&nxt[a16_idx<WS>(row, 256 + f0)] = lo;
+                    } else {
+                        *(V4*)&nxt[a16_idx(row, f0)] = pack4(v[0], v[1], v[2], v[3], T());   // four consecutive features: one 8-byte store
+                    }
+                }
+            }
+            // one dword per lane and row: 32 lanes x 2 halves = 256 contiguous bytes per store (the [row][tile] words of rounds 1-5 --
+            // half the lanes storing 4 bytes at a 32-byte stride after a cross-half shuffle -- cost 8 % of the kernel)
+            if (masks && grow < p.rows) masks[relu_mask_idx(l, wave, grow, half, p.rows)] = mbits;
+        }
+        __syncthreads();
+        if (saved_hT) store_T(nxt, saved_hT + (size_t)l * t16_elems(NS * M16_W, p.rows), M16_W, wave, lane);
+        T* t = cur; cur = nxt; nxt = t;
+    }
+    if constexpr (SP) {
+        // The range guard of "fp32s" (round-4 verdict): hi = fp16(x) saturates at 65504 -- silently.  An activation at or above 2^15
+        // (a factor 2 of headroom) raises the caller's flag; the host then re-runs the pass on the exact-fp32 kernels or, checking
+        // lazily, switches to them from the next pass on (deform_ops / deformable_field.py).  NaN compares false: not flagged here.
+        if (p.range_flag && amax >= 32768.f) atomicOr(p.range_flag, 1u);
+    }
+    mlp16_output_layer<T, RT, SP>(p, out, cur, nxt, row0, tid);
+}
+
 __global__ __launch_bounds__(M16_THREADS) void gp_mlp16_fwd_f16_kernel(Mlp16Dev p, float* out, void* sx, void* sh, uint32_t* masks) {
     mlp16_fwd_body<_Float16, 2>(p, out, (_Float16*)sx, (_Float16*)sh, masks);
 }
@@ -742,130 +759,117 @@ __global__ __launch_bounds__(M16_THREADS, 2) void gp_mlp16_fwd4_bf16_kernel(Mlp1
 }
 
 // ------------------------------------------------------------------------------------------------
-// backward, data chain.  wt[l] = TRANSPOSED 16-bit weights: wt[4]: [256][16] (k >= out_dim zero),
-// wt[1..3]: [256][256] (= W_l^T), wt[0]: [in_pad][256] (= W_0^T, rows >= in_dim zero).
-// Writes dZ_l TRANSPOSED ([4][256][rows], scaled) for the weight-gradient GEMM.
+// Split mode, 64-row workgroups, input width 112 (the reference's 104 / 108 / 112 inputs): the forward on the hand-scheduled
+// products.  One statement per layer (kloop16s_fwd) inside one rolled layer loop; TRAIN: the statement of layer l >= 1 also writes
+// the saved tensor of layer l - 1 (the tile it reads), X and the last hidden layer leave as bursts (the latter has no product behind
+// it to ride on).  Same arithmetic in the same order as mlp16_fwd_body<_Float16, 2, true>: bit-identical results
+// (tools/probe/mlp16_kloop_ab.py, tests/test_gpu_deform.py).
 // ------------------------------------------------------------------------------------------------
-template <typename T, int RT, bool SP = false>
-__device__ __forceinline__ void mlp16_bwd_data_body(Mlp16Dev p, const uint32_t* __restrict__ masks,
-                                                    const float* __restrict__ dL_dout, T* __restrict__ dzT,
-                                                    float* __restrict__ dfeature, float* __restrict__ dxyz,
-                                                    const uint32_t* __restrict__ absmax_bits) {
-    constexpr int ROWS = 32 * RT;
-    constexpr int WS = SP ? SP_W : M16_W;
-    constexpr int NS = SP ? 2 : 1;
-    constexpr bool INPLACE = RT > 2 || SP;
-    __shared__ T smem[INPLACE ? 1 : 2][ROWS * WS];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, j = lane & 31;
+template <bool TRAIN>
+__device__ __forceinline__ void mlp16s_fwd_hand_body(Mlp16Dev p, float* __restrict__ out, _Float16* __restrict__ saved_xT,
+                                                     _Float16* __restrict__ saved_hT, uint32_t* __restrict__ masks) {
+    constexpr int ROWS = 64, WS = SP_W, NS = 2;
+    typedef _Float16 T;
+    __shared__ __attribute__((aligned(1024))) T smem[ROWS * WS];       // one tile, updated in place
+    const int tid = threadIdx.x, lane_k = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);          // (uniform: whatever is derived from it lives in scalar registers)
     const long row0 = (long)blockIdx.x * ROWS;
     const long rows_pad = (p.rows + 63) & ~63L;
-    const float S = UsesScale<T>::v ? grad_scale_from(absmax_bits) : 1.f;
-    T* cur = smem[0];
-    T* nxt = smem[INPLACE ? 0 : 1];
-    {   // (all loads of the upstream gradient before the first LDS store: as a rolled loop they were dependent trips to memory)
-        constexpr int DU = 16 * ROWS / M16_THREADS;
-        float dv[DU];
-#pragma unroll
-        for (int u = 0; u < DU; ++u) {
-            const int e = tid + M16_THREADS * u, r = e / 16, f = e % 16;
-            const long row = row0 + r;
-            const bool ok = f < p.out_dim && row < p.rows;
-            dv[u] = dL_dout[ok ? row * p.out_dim + f : 0];
-            if (!ok) dv[u] = 0.f;
-        }
-#pragma unroll
-        for (int u = 0; u < DU; ++u) {
-            const int e = tid + M16_THREADS * u, r = e / 16, f = e % 16;
-            const float v = dv[u] * S;
-            if constexpr (SP) split1(v, cur[a16_idx<WS>(r, f)], cur[a16_idx<WS>(r, 256 + f)]);
-            else cur[a16_idx(r, f)] = (T)v;
-        }
-    }
-    __syncthreads();
-    typedef typename Vec4<T>::type V4;
-    // split mode, 64-row workgroups: the K = 256 products (l = 3, 2, 1) are the hand-scheduled statements of the forward
-    // (kloop16s_asm), each carrying the stores of the tensor it reads, dZ of layer index l; index 0 and the last, partial
-    // workgroup keep the burst form.  gp_debug_option(9, 64): the compiler's loops, for A/B.
     const int ablate = g_m16_ablate;
-    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-    [[maybe_unused]] const bool carry = SP && RT == 2 && row0 + ROWS <= p.rows && !(ablate & 64);
-    [[maybe_unused]] auto zblk = [&](int i) { return (_Float16*)dzT + (size_t)i * t16_elems(NS * M16_W, p.rows) + (size_t)blockIdx.x * NS * M16_W * ROWS; };
-    const int lane_k = lane;
-    for (int l = 4; l >= 1; --l) {
-        const int K = l == 4 ? 16 : M16_W;
-        int lane = lane_k;                  // (per-lane addresses recomputed per layer: see the forward)
-        if constexpr (SP && RT == 2) asm volatile("" : "+v"(lane));
+    if (ablate & 8) { for (int e = tid; e < ROWS * WS; e += M16_THREADS) smem[e] = (T)0.f; }
+    else build_input16s<ROWS>(smem, p, row0, tid);
+    __syncthreads();
+    if (ablate & 2) masks = nullptr;
+    auto burst = [&](T* dst, int nf, int lane) {            // this workgroup's block of a saved tensor: NS x nf x ROWS contiguous elements
+        T* blk = dst + (size_t)blockIdx.x * NS * nf * ROWS;
+        store_tile_T<T, ROWS, WS>(smem, blk, nf, NS * nf, row0, p.rows, rows_pad, wave, lane);
+        store_tile_T<T, ROWS, WS>(smem + 256, blk + (size_t)nf * T16_BLK, nf, NS * nf, row0, p.rows, rows_pad, wave, lane);
+    };
+    if constexpr (TRAIN) burst(saved_xT, p.in_pad, lane_k);
+    const size_t layer_elems = t16_elems(NS * M16_W, p.rows);
+    const int bad_row = row0 + ROWS > p.rows ? (int)(p.rows - row0) : ROWS;        // the first row of the tile that does not exist
+    float amax = 0.f;                   // the largest hidden activation this lane carried into (hi, lo') form
+    for (int l = 0; l < 4; ++l) {
+        // Everything derived from the lane number is recomputed per layer (the empty statement hides the value's origin): hoisted out
+        // of the layer loop, the epilogue's per-lane addresses were ~70 registers live ACROSS the product, which has none to spare --
+        // its statement owns 104 fixed registers beside the 128 accumulators
+        int lane = lane_k;
+        asm volatile("" : "+v"(lane));
         const int half = lane >> 5, j = lane & 31;
-        const int wave = wave_u;
-        f32x16 acc[RT][2];
-        f32x16 ax[SP ? RT : 1][2];
+        f32x16 am[2][2], ax[2][2];
 #pragma unroll
-        for (int rt = 0; rt < RT; ++rt)
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {   // this lane's features of tile nt: runs of four at (2 wave + nt) * 32 + 8 g + 4 half
+                const float4 bv = *(const float4*)(p.b[l] + (2 * wave + nt) * 32 + 8 * g + 4 * half);
+                am[0][nt][4 * g + 0] = bv.x; am[0][nt][4 * g + 1] = bv.y; am[0][nt][4 * g + 2] = bv.z; am[0][nt][4 * g + 3] = bv.w;
+            }
+        if (!(ablate & 4)) {
+            const Kloop16sAddr ka = kloop16s_addr(smem, wave, lane);
+            _Float16* st = TRAIN ? saved_hT + (size_t)(l > 0 ? l - 1 : 0) * layer_elems + (size_t)blockIdx.x * NS * M16_W * ROWS + wave * (NS * M16_W * T16_BLK) : nullptr;
+            kloop16s_fwd<TRAIN>(ka, (const _Float16*)p.w[l] + wave * 1024, (const _Float16*)p.wlo[l] + wave * 1024, st, l == 0, am, ax);
+        } else {
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) { acc[rt][nt][r] = 0.f; if (SP) ax[rt][nt][r] = 0.f; }
-        // the ReLU sign words of this layer's epilogue, requested BEFORE the product (loaded where they are used, each of the
-        // RT x 2 words was a dependent round trip to memory behind the matrix work: 16 per 64-row block and backward)
-        const uint32_t* mk = masks + (size_t)(l - 1) * p.rows * 8;
-        constexpr bool PRE = RT == 2;          // (the 128-row variants have no registers to spare: they load in the epilogue)
-        uint32_t mreg[RT][2];
-        if (PRE) {
-#pragma unroll
-            for (int rt = 0; rt < RT; ++rt) {
-                const long grow = row0 + rt * 32 + j;
-#pragma unroll
-                for (int nt = 0; nt < 2; ++nt) mreg[rt][nt] = mk[(grow < p.rows ? grow : p.rows - 1) * 8 + (2 * wave + nt)];
-            }
+                for (int r = 0; r < 16; ++r) { am[1][nt][r] = am[0][nt][r]; ax[0][nt][r] = 0.f; ax[1][nt][r] = 0.f; }
         }
-        if constexpr (SP) {
-            if constexpr (RT == 2) {
-                if (l <= 3 && !(ablate & 64)) {
-                    const Kloop16sAddr ka = kloop16s_addr((const _Float16*)cur, wave_u, lane);
-                    const _Float16* wh = (const _Float16*)p.w[l] + wave_u * 1024;
-                    const _Float16* wl = (const _Float16*)p.wlo[l] + wave_u * 1024;
-                    if (carry) kloop16s_asm<true>(ka, wh, wl, zblk(l) + wave_u * (NS * M16_W * T16_BLK), acc, ax);
-                    else kloop16s_asm<false>(ka, wh, wl, nullptr, acc, ax);
-                } else gemm16s<true, RT>(cur, (const _Float16*)p.w[l], (const _Float16*)p.wlo[l], K, K, M16_W, wave, lane, acc, ax);
-            } else gemm16s<true, RT>(cur, (const _Float16*)p.w[l], (const _Float16*)p.wlo[l], K, K, M16_W, wave, lane, acc, ax);
-        } else gemm16<T, true, RT>(cur, (const T*)p.w[l], K, K, M16_W, wave, lane, acc);
-        if (INPLACE) __syncthreads();
+        __syncthreads();                    // every wave has read the layer's input before anyone overwrites it
+        if (!(ablate & 16))
 #pragma unroll
-        for (int rt = 0; rt < RT; ++rt) {
+        for (int rt = 0; rt < 2; ++rt) {
             const int row = rt * 32 + j;
             const long grow = row0 + row;
+            uint32_t mbits = 0;
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt) {
-                const uint32_t m = grow < p.rows ? (PRE ? mreg[rt][nt] : mk[grow * 8 + (2 * wave + nt)]) : 0u;
+            for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const int f0 = (2 * wave + nt) * 32 + 8 * g + 4 * half;
                     float v[4];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {   // sign-extended mask bit (v_bfe_i32) AND value bits: two instructions per value
-                        float z = acc[rt][nt][4 * g + e];
-                        if constexpr (SP) z = fmaf(ax[rt][nt][4 * g + e], SP_LO_INV, z);
-                        v[e] = __uint_as_float(__float_as_uint(z) & (uint32_t)__builtin_amdgcn_sbfe((int)m, 8 * g + 4 * half + e, 1));
-                    }
-                    if constexpr (SP) {
-                        h4 hi, lo;
-                        split4(v, hi, lo);
-                        *(h4*)&nxt[a16_idx<WS>(row, f0)] = hi;
-                        *(h4*)&nxt[a16_idx<WS>(row, 256 + f0)] = lo;
-                    } else {
-                        *(V4*)&nxt[a16_idx(row, f0)] = pack4(v[0], v[1], v[2], v[3], T());
-                    }
+                    for (int e = 0; e < 4; ++e) v[e] = relu_push(fmaf(ax[rt][nt][4 * g + e], SP_LO_INV, am[rt][nt][4 * g + e]), mbits);
+                    h4 hi, lo;
+                    split4(v, hi, lo);
+                    amax = fmaxf(fmaxf(amax, fmaxf(v[0], v[1])), fmaxf(v[2], v[3]));
+                    *(h4*)&smem[a16_idx<WS>(row, f0)] = hi;
+                    *(h4*)&smem[a16_idx<WS>(row, 256 + f0)] = lo;
                 }
-            }
+            if (masks && grow < p.rows) masks[relu_mask_idx(l, wave, grow, half, p.rows)] = mbits;
         }
         __syncthreads();
-        if (!(carry && l > 1)) {   // dZ_l^T -> global, blocked (carried by the next product otherwise)
-            T* blk = dzT + (size_t)(l - 1) * t16_elems(NS * M16_W, p.rows) + (size_t)blockIdx.x * NS * M16_W * ROWS;
-            store_tile_T<T, ROWS, WS>(nxt, blk, M16_W, NS * M16_W, row0, p.rows, rows_pad, wave, lane);
-            if constexpr (SP) store_tile_T<T, ROWS, WS>(nxt + 256, blk + (size_t)M16_W * T16_BLK, M16_W, NS * M16_W, row0, p.rows, rows_pad, wave, lane);
+        if constexpr (TRAIN) {
+            if (bad_row < ROWS) {           // last workgroup only: rows beyond the input are stored as zeros (the weight gradient sums over them)
+                typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+                for (int e = tid; e < (ROWS - bad_row) * (WS * 2 / 16); e += M16_THREADS) ((u4*)(smem + (size_t)bad_row * WS))[e] = u4{0u, 0u, 0u, 0u};
+                __syncthreads();
+            }
+            if (l == 3) burst(saved_hT + 3 * layer_elems, M16_W, lane);
         }
-        T* t = cur; cur = nxt; nxt = t;
     }
+    if (p.range_flag && amax >= 32768.f) atomicOr(p.range_flag, 1u);         // the range guard of "fp32s": see mlp16_fwd_body
+    mlp16_output_layer<T, 2, true>(p, out, smem, smem, row0, tid);
+}
+__global__ __launch_bounds__(M16_THREADS, 2) void gp_mlp16_fwd_split_train_kernel(Mlp16Dev p, float* out, void* sx, void* sh, uint32_t* masks) {
+    mlp16s_fwd_hand_body<true>(p, out, (_Float16*)sx, (_Float16*)sh, masks);
+}
+__global__ __launch_bounds__(M16_THREADS, 2) void gp_mlp16_fwd_split_infer_kernel(Mlp16Dev p, float* out, void* sx, void* sh, uint32_t* masks) {
+    mlp16s_fwd_hand_body<false>(p, out, nullptr, nullptr, nullptr);
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward, data chain.  wt[l] = TRANSPOSED 16-bit weights: wt[4]: [256][16] (k >= out_dim zero),
+// wt[1..3]: [256][256] (= W_l^T), wt[0]: [in_pad][256] (= W_0^T, rows >= in_dim zero).
+// Writes dZ_l TRANSPOSED ([4][256][rows], scaled) for the weight-gradient GEMM.
+// ------------------------------------------------------------------------------------------------
+// The tail of the data backward: dX[rows][in_pad] = dZ_1 . W_0 (feature tiles beyond in_pad are skipped; the result is kept in fp32 in
+// LDS), then d feature and d xyz (through the encoding's derivative).  `cur` = dZ_1 (LDS), `nxt` = scratch, S = the loss scale.
+template <typename T, int RT, bool SP>
+__device__ __forceinline__ void mlp16_input_grad(const Mlp16Dev& p, const T* cur, T* nxt, float* __restrict__ dfeature, float* __restrict__ dxyz,
+                                                 float S, long row0, int tid) {
+    constexpr int ROWS = 32 * RT;
+    constexpr bool INPLACE = RT > 2 || SP;
+    const int lane = tid & 63, wave = tid >> 6, half = lane >> 5, j = lane & 31;
     if (dfeature || dxyz) {
         // dX[64][in_pad] = dZ_1 . W_0 ; feature tiles beyond in_pad are skipped; result kept in fp32 in LDS
         f32x16 acc[RT][2];
@@ -924,6 +928,106 @@ __device__ __forceinline__ void mlp16_bwd_data_body(Mlp16Dev p, const uint32_t* 
         }
     }
 }
+
+template <typename T, int RT, bool SP = false>
+__device__ __forceinline__ void mlp16_bwd_data_body(Mlp16Dev p, const uint32_t* __restrict__ masks,
+                                                    const float* __restrict__ dL_dout, T* __restrict__ dzT,
+                                                    float* __restrict__ dfeature, float* __restrict__ dxyz,
+                                                    const uint32_t* __restrict__ absmax_bits) {
+    constexpr int ROWS = 32 * RT;
+    constexpr int WS = SP ? SP_W : M16_W;
+    constexpr int NS = SP ? 2 : 1;
+    constexpr bool INPLACE = RT > 2 || SP;
+    __shared__ T smem[INPLACE ? 1 : 2][ROWS * WS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, j = lane & 31;
+    const long row0 = (long)blockIdx.x * ROWS;
+    const long rows_pad = (p.rows + 63) & ~63L;
+    const float S = UsesScale<T>::v ? grad_scale_from(absmax_bits) : 1.f;
+    T* cur = smem[0];
+    T* nxt = smem[INPLACE ? 0 : 1];
+    {   // (all loads of the upstream gradient before the first LDS store: as a rolled loop they were dependent trips to memory)
+        constexpr int DU = 16 * ROWS / M16_THREADS;
+        float dv[DU];
+#pragma unroll
+        for (int u = 0; u < DU; ++u) {
+            const int e = tid + M16_THREADS * u, r = e / 16, f = e % 16;
+            const long row = row0 + r;
+            const bool ok = f < p.out_dim && row < p.rows;
+            dv[u] = dL_dout[ok ? row * p.out_dim + f : 0];
+            if (!ok) dv[u] = 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < DU; ++u) {
+            const int e = tid + M16_THREADS * u, r = e / 16, f = e % 16;
+            const float v = dv[u] * S;
+            if constexpr (SP) split1(v, cur[a16_idx<WS>(r, f)], cur[a16_idx<WS>(r, 256 + f)]);
+            else cur[a16_idx(r, f)] = (T)v;
+        }
+    }
+    __syncthreads();
+    typedef typename Vec4<T>::type V4;
+    for (int l = 4; l >= 1; --l) {
+        const int K = l == 4 ? 16 : M16_W;
+        f32x16 acc[RT][2];
+        f32x16 ax[SP ? RT : 1][2];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { acc[rt][nt][r] = 0.f; if (SP) ax[rt][nt][r] = 0.f; }
+        // the ReLU sign words of this layer's epilogue, requested BEFORE the product (loaded where they are used, each of the
+        // RT x 2 words was a dependent round trip to memory behind the matrix work: 16 per 64-row block and backward)
+        constexpr bool PRE = RT == 2;          // (the 128-row variants have no registers to spare: they load in the epilogue)
+        uint32_t mreg[RT];
+        if (PRE) {
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+                const long grow = row0 + rt * 32 + j;
+                mreg[rt] = masks[relu_mask_idx(l - 1, wave, grow < p.rows ? grow : p.rows - 1, half, p.rows)];
+            }
+        }
+        if constexpr (SP) gemm16s<true, RT>(cur, (const _Float16*)p.w[l], (const _Float16*)p.wlo[l], K, K, M16_W, wave, lane, acc, ax);
+        else gemm16<T, true, RT>(cur, (const T*)p.w[l], K, K, M16_W, wave, lane, acc);
+        if (INPLACE) __syncthreads();
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            const int row = rt * 32 + j;
+            const long grow = row0 + row;
+            const uint32_t m = grow < p.rows ? (PRE ? mreg[rt] : masks[relu_mask_idx(l - 1, wave, grow, half, p.rows)]) : 0u;
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int f0 = (2 * wave + nt) * 32 + 8 * g + 4 * half;
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {   // sign-extended mask bit (v_bfe_i32, constant position) AND value bits: two instructions per value
+                        float z = acc[rt][nt][4 * g + e];
+                        if constexpr (SP) z = fmaf(ax[rt][nt][4 * g + e], SP_LO_INV, z);
+                        v[e] = __uint_as_float(__float_as_uint(z) & (uint32_t)__builtin_amdgcn_sbfe((int)m, relu_mask_pos(nt, g, e), 1));
+                    }
+                    if constexpr (SP) {
+                        h4 hi, lo;
+                        split4(v, hi, lo);
+                        *(h4*)&nxt[a16_idx<WS>(row, f0)] = hi;
+                        *(h4*)&nxt[a16_idx<WS>(row, 256 + f0)] = lo;
+                    } else {
+                        *(V4*)&nxt[a16_idx(row, f0)] = pack4(v[0], v[1], v[2], v[3], T());
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        {   // dZ_l^T -> global, blocked
+            T* blk = dzT + (size_t)(l - 1) * t16_elems(NS * M16_W, p.rows) + (size_t)blockIdx.x * NS * M16_W * ROWS;
+            store_tile_T<T, ROWS, WS>(nxt, blk, M16_W, NS * M16_W, row0, p.rows, rows_pad, wave, lane);
+            if constexpr (SP) store_tile_T<T, ROWS, WS>(nxt + 256, blk + (size_t)M16_W * T16_BLK, M16_W, NS * M16_W, row0, p.rows, rows_pad, wave, lane);
+        }
+        T* t = cur; cur = nxt; nxt = t;
+    }
+    mlp16_input_grad<T, RT, SP>(p, cur, nxt, dfeature, dxyz, S, row0, tid);
+}
 __global__ __launch_bounds__(M16_THREADS) void gp_mlp16_bwd_data_f16_kernel(Mlp16Dev p, const uint32_t* masks, const float* dL_dout,
                                                                              void* dzT, float* dfeature, float* dxyz, const uint32_t* absmax_bits) {
     mlp16_bwd_data_body<_Float16, 2>(p, masks, dL_dout, (_Float16*)dzT, dfeature, dxyz, absmax_bits);
@@ -943,6 +1047,91 @@ __global__ __launch_bounds__(M16_THREADS, 2) void gp_mlp16_bwd_data4_f16_kernel(
 __global__ __launch_bounds__(M16_THREADS, 2) void gp_mlp16_bwd_data4_bf16_kernel(Mlp16Dev p, const uint32_t* masks, const float* dL_dout,
                                                                                   void* dzT, float* dfeature, float* dxyz, const uint32_t* absmax_bits) {
     mlp16_bwd_data_body<__bf16, 4>(p, masks, dL_dout, (__bf16*)dzT, dfeature, dxyz, absmax_bits);
+}
+
+// Split mode, 64-row workgroups: the data backward on the hand-scheduled products (kloop16s_bwd): the statement of layer l <= 3 also
+// writes dZ of layer index l (the tile it reads); index 0 leaves as a burst in front of the input-gradient product.  Rows beyond
+// the input carry zeros by construction (their upstream gradient and their ReLU words are zero).  Bit-identical to
+// mlp16_bwd_data_body<_Float16, 2, true>.
+__device__ __forceinline__ void mlp16s_bwd_data_hand_body(Mlp16Dev p, const uint32_t* __restrict__ masks, const float* __restrict__ dL_dout,
+                                                          _Float16* __restrict__ dzT, float* __restrict__ dfeature, float* __restrict__ dxyz,
+                                                          const uint32_t* __restrict__ absmax_bits) {
+    constexpr int ROWS = 64, WS = SP_W, NS = 2;
+    typedef _Float16 T;
+    __shared__ __attribute__((aligned(1024))) T smem[ROWS * WS];
+    const int tid = threadIdx.x, lane_k = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const long row0 = (long)blockIdx.x * ROWS;
+    const long rows_pad = (p.rows + 63) & ~63L;
+    const float S = grad_scale_from(absmax_bits);
+    {   // (all loads of the upstream gradient before the first LDS store)
+        constexpr int DU = 16 * ROWS / M16_THREADS;
+        float dv[DU];
+#pragma unroll
+        for (int u = 0; u < DU; ++u) {
+            const int e = tid + M16_THREADS * u, r = e / 16, f = e % 16;
+            const long row = row0 + r;
+            const bool ok = f < p.out_dim && row < p.rows;
+            dv[u] = dL_dout[ok ? row * p.out_dim + f : 0];
+            if (!ok) dv[u] = 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < DU; ++u) {
+            const int e = tid + M16_THREADS * u, r = e / 16, f = e % 16;
+            split1(dv[u] * S, smem[a16_idx<WS>(r, f)], smem[a16_idx<WS>(r, 256 + f)]);
+        }
+    }
+    __syncthreads();
+    const size_t layer_elems = t16_elems(NS * M16_W, p.rows);
+    for (int l = 4; l >= 1; --l) {
+        int lane = lane_k;                  // (per-lane addresses recomputed per layer: see the forward)
+        asm volatile("" : "+v"(lane));
+        const int half = lane >> 5, j = lane & 31;
+        uint32_t mreg[2];                   // the ReLU sign words of this layer's epilogue, requested BEFORE the product
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) {
+            const long grow = row0 + rt * 32 + j;
+            mreg[rt] = masks[relu_mask_idx(l - 1, wave, grow < p.rows ? grow : p.rows - 1, half, p.rows)];
+        }
+        f32x16 am[2][2], ax[2][2];
+        {
+            const Kloop16sAddr ka = kloop16s_addr(smem, wave, lane);
+            _Float16* st = dzT + (size_t)(l < 4 ? l : 0) * layer_elems + (size_t)blockIdx.x * NS * M16_W * ROWS + wave * (NS * M16_W * T16_BLK);
+            kloop16s_bwd(ka, (const _Float16*)p.w[l] + wave * 1024, (const _Float16*)p.wlo[l] + wave * 1024, st, l == 4, am, ax);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) {
+            const int row = rt * 32 + j;
+            const uint32_t m = row0 + row < p.rows ? mreg[rt] : 0u;
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int f0 = (2 * wave + nt) * 32 + 8 * g + 4 * half;
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        v[e] = __uint_as_float(__float_as_uint(fmaf(ax[rt][nt][4 * g + e], SP_LO_INV, am[rt][nt][4 * g + e])) &
+                                               (uint32_t)__builtin_amdgcn_sbfe((int)m, relu_mask_pos(nt, g, e), 1));
+                    h4 hi, lo;
+                    split4(v, hi, lo);
+                    *(h4*)&smem[a16_idx<WS>(row, f0)] = hi;
+                    *(h4*)&smem[a16_idx<WS>(row, 256 + f0)] = lo;
+                }
+        }
+        __syncthreads();
+        if (l == 1) {   // dZ of layer index 0 -> global, blocked
+            T* blk = dzT + (size_t)blockIdx.x * NS * M16_W * ROWS;
+            store_tile_T<T, ROWS, WS>(smem, blk, M16_W, NS * M16_W, row0, p.rows, rows_pad, wave, lane);
+            store_tile_T<T, ROWS, WS>(smem + 256, blk + (size_t)M16_W * T16_BLK, M16_W, NS * M16_W, row0, p.rows, rows_pad, wave, lane);
+        }
+    }
+    mlp16_input_grad<T, 2, true>(p, smem, smem, dfeature, dxyz, S, row0, tid);
+}
+__global__ __launch_bounds__(M16_THREADS, 2) void gp_mlp16_bwd_data_split_hand_kernel(Mlp16Dev p, const uint32_t* masks, const float* dL_dout,
+                                                                                       void* dzT, float* dfeature, float* dxyz, const uint32_t* absmax_bits) {
+    mlp16s_bwd_data_hand_body(p, masks, dL_dout, (_Float16*)dzT, dfeature, dxyz, absmax_bits);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1300,7 +1489,13 @@ extern "C" int gp_mlp16_forward(const gp_mlp16_params* p, const gp_mlp_input* x,
             if (!set) { GP_HIP_CHECK(hipFuncSetAttribute((const void*)gp_mlp16_fwd_split_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 40 * 1024)); set = true; }
             dyn = 40 * 1024;
         }
-        hipLaunchKernelGGL(gp_mlp16_fwd_split_kernel, dim3(gp_blocks((size_t)m.rows, M16_ROWS)), dim3(M16_THREADS), dyn, s, m, out, saved_xT, saved_hT, masks);
+        // the hand-scheduled kernels (gp_debug_option(9, 64): the compiler's loops, for A/B; other input widths than 112 keep them too)
+        const bool hand = m.in_pad == 112 && !(gp_debug_get(9) & (64 | 32));
+        const bool train = saved_xT && saved_hT && masks && !(gp_debug_get(9) & 1);
+        if (hand && train) hipLaunchKernelGGL(gp_mlp16_fwd_split_train_kernel, dim3(gp_blocks((size_t)m.rows, M16_ROWS)), dim3(M16_THREADS), 0, s, m, out, saved_xT, saved_hT, masks);
+        else if (hand && ((!saved_xT && !saved_hT && !masks) || (gp_debug_get(9) & 1)))
+            hipLaunchKernelGGL(gp_mlp16_fwd_split_infer_kernel, dim3(gp_blocks((size_t)m.rows, M16_ROWS)), dim3(M16_THREADS), 0, s, m, out, saved_xT, saved_hT, masks);
+        else hipLaunchKernelGGL(gp_mlp16_fwd_split_kernel, dim3(gp_blocks((size_t)m.rows, M16_ROWS)), dim3(M16_THREADS), dyn, s, m, out, saved_xT, saved_hT, masks);
     } else if (m.rows >= GP_MLP16_BIG_ROWS) {        // 128 rows per workgroup
         const dim3 grid(gp_blocks((size_t)m.rows, 128));
         if (p->dtype == GP_DTYPE_F16) hipLaunchKernelGGL(gp_mlp16_fwd4_f16_kernel, grid, dim3(M16_THREADS), 0, s, m, out, saved_xT, saved_hT, masks);
@@ -1342,7 +1537,8 @@ extern "C" int gp_mlp16_backward(const gp_mlp16_params* p /* w16 = TRANSPOSED co
         const bool big_rows = m.rows >= GP_MLP16_BIG_ROWS;
         const dim3 grid(gp_blocks((size_t)m.rows, big_rows ? 128 : M16_ROWS));
         if (split) {
-            hipLaunchKernelGGL(gp_mlp16_bwd_data_split_kernel, dim3(gp_blocks((size_t)m.rows, M16_ROWS)), dim3(M16_THREADS), 0, s, m, masks, dL_dout, (void*)dz, dL_dfeature, dL_dxyz, absmax);
+            if (gp_debug_get(9) & 64) hipLaunchKernelGGL(gp_mlp16_bwd_data_split_kernel, dim3(gp_blocks((size_t)m.rows, M16_ROWS)), dim3(M16_THREADS), 0, s, m, masks, dL_dout, (void*)dz, dL_dfeature, dL_dxyz, absmax);
+            else hipLaunchKernelGGL(gp_mlp16_bwd_data_split_hand_kernel, dim3(gp_blocks((size_t)m.rows, M16_ROWS)), dim3(M16_THREADS), 0, s, m, masks, dL_dout, (void*)dz, dL_dfeature, dL_dxyz, absmax);
             hipLaunchKernelGGL(gp_mlp16_pack_dout_split_kernel, dim3(gp_blocks((size_t)((m.rows + 63) & ~63L), 256)), dim3(256), 0, s, dL_dout, m.out_dim, m.rows, (_Float16*)dout16, absmax);
         } else if (f16) {
             hipLaunchKernelGGL(big_rows ? gp_mlp16_bwd_data4_f16_kernel : gp_mlp16_bwd_data_f16_kernel, grid, dim3(M16_THREADS), 0, s, m, masks, dL_dout, (void*)dz, dL_dfeature, dL_dxyz, absmax);

@@ -107,15 +107,11 @@ class Plan:
         return ", ".join(f'"v{i}"' for i in range(self.first, self.end))
 
 
-def gen_split(carry, depth=3, nks=16, first=None):
-    """Split-fp16 product of one K = 256 layer for a 64-row workgroup (RT = 2): see the module docstring.
-    Operands: am00 am01 am10 am11 ax00 ax01 ax10 ax11 (f32x16, "+v"), abase (LDS byte address of this lane's row, swizzle
-    folded in), voff (lane * 16), swh / swl (SGPR pairs: this wave's hi / lo' weight fragments), and with CARRY sbt (LDS byte
-    address this lane supplies to the transpose reads), vost (this lane's byte offset in a 1 KB chunk of the saved tensor) and sst
-    (SGPR pair: this wave's 16-row block of the saved tensor)."""
-    n_b, n_a = 4, 4
-    p = Plan(first if first is not None else 256 - (16 * (depth + 1) + 32 + 8), depth, n_b, n_a, carry)
-    e = Emitter()
+def gen_split_path(e, p, nks, carry, init, depth):
+    """One product (nks k-steps) of the split-fp16 form into the emitter `e`.  init = "bias": am00 / am01 hold the bias on entry
+    (every row tile starts from the same 32 features' biases: the first MFMA of am10 / am11 reads am00 / am01 as its addend BEFORE
+    these are overwritten, so no accumulator is ever initialised by VALU moves); init = "zero": nothing is read on entry.
+    The cross-term accumulators start from the inline constant 0."""
     KST = 8192                                        # bytes per k-step of the fragment-packed weights (8 feature tiles x 1 KB)
     A_OFF = [0, 512, 32768, 33280]                    # ah rt0, al' rt0, ah rt1, al' rt1
 
@@ -166,22 +162,29 @@ def gen_split(carry, depth=3, nks=16, first=None):
         e.ins(f"global_store_dwordx4 {off}, {vr(p.ST, 4)}, %[sst]")
         e.vm.issue(("S", g))
 
-    def mfma(acc, ks, bq, aq):
+    def mfma(acc, ks, bq, aq, src=None):
         e.need_vm(("B", ks))
         e.need_lgkm(("A", ks, aq))
-        e.ins(f"v_mfma_f32_32x32x16_f16 %[{acc}], {p.b(ks, bq)}, {p.a(ks, aq)}, %[{acc}]")
+        e.ins(f"v_mfma_f32_32x32x16_f16 %[{acc}], {p.b(ks, bq)}, {p.a(ks, aq)}, {src if src is not None else '%[' + acc + ']'}")
 
     # prologue: the first `depth` weight groups and the first activation group
     for ks in range(min(depth, nks)):
         load_b(ks)
     read_a(0, [0, 1, 2, 3])
     for ks in range(nks):
-        # (acc, weight fragment, activation fragment): hi x hi first, then the two cross terms
-        seq = [("am00", 0, 0), ("am01", 1, 0), ("am10", 0, 2), ("am11", 1, 2),
-               ("ax00", 2, 0), ("ax01", 3, 0), ("ax10", 2, 2), ("ax11", 3, 2),
-               ("ax00", 0, 1), ("ax01", 1, 1), ("ax10", 0, 3), ("ax11", 1, 3)]
-        for m, (acc, bq, aq) in enumerate(seq):
-            mfma(acc, ks, bq, aq)
+        # (acc, weight fragment, activation fragment, addend): hi x hi first, then the two cross terms
+        seq = [("am00", 0, 0, None), ("am01", 1, 0, None), ("am10", 0, 2, None), ("am11", 1, 2, None),
+               ("ax00", 2, 0, None), ("ax01", 3, 0, None), ("ax10", 2, 2, None), ("ax11", 3, 2, None),
+               ("ax00", 0, 1, None), ("ax01", 1, 1, None), ("ax10", 0, 3, None), ("ax11", 1, 3, None)]
+        if ks == 0:
+            z = "0"
+            if init == "bias":      # row tile 1 first: it reads the biases out of am00 / am01
+                seq[0:4] = [("am10", 0, 2, "%[am00]"), ("am11", 1, 2, "%[am01]"), ("am00", 0, 0, None), ("am01", 1, 0, None)]
+            else:
+                seq[0:4] = [(a, b, c, z) for a, b, c, _ in seq[0:4]]
+            seq[4:8] = [(a, b, c, z) for a, b, c, _ in seq[4:8]]
+        for m, (acc, bq, aq, src) in enumerate(seq):
+            mfma(acc, ks, bq, aq, src)
             # the slots behind the MFMAs (the matrix pipe is busy for 32 cycles per MFMA: anything here issues for free)
             if m == 0 and ks + depth < nks:
                 load_b(ks + depth)
@@ -193,6 +196,31 @@ def gen_split(carry, depth=3, nks=16, first=None):
                 read_a(ks + 1, [2, 3])
             if carry and m == 9:
                 store(ks)
+    assert not e.lgkm.q, e.lgkm.q
+    e.vm.q = []                 # (stores may still be in flight at the end of a path: nothing below depends on the count)
+
+
+def gen_split(paths, init, depth=3):
+    """One asm statement = the split-fp16 product of a 64-row workgroup (RT = 2) with one or two PATHS selected by the scalar operand
+    `sel` (0 = the first path): the K = 256 layers, and the layer with its own k-step count (forward: layer 0, K = in_pad; data
+    backward: the output layer, K = 16).  Both paths use the same operands and registers, so the layer loop around the statement is
+    one rolled loop with ONE statement in it -- with several statements (or the compiler's loop beside it) hipcc assigned the 128
+    accumulator registers differently per path and moved them between the paths (240 v_mov per layer).
+    paths = [(nks, carry), ...].  Operands: am00 am01 am10 am11 ax00 ax01 ax10 ax11 (f32x16), abase (LDS byte address of this lane's row,
+    swizzle folded in), voff (lane * 16), swh / swl (SGPR pairs: this wave's hi / lo' weight fragments), sel, and for a carrying path sbt
+    (LDS byte address this lane supplies to the transpose reads), vost (this lane's byte offset in a 1 KB chunk of the saved tensor) and
+    sst (SGPR pair: this wave's 16-row block of the saved tensor)."""
+    p = Plan(256 - (16 * (depth + 1) + 32 + 8), depth, 4, 4, any(c for _, c in paths))
+    e = Emitter()
+    if len(paths) > 1:
+        e.ins("s_cmp_eq_u32 %[sel], 0")
+        e.ins("s_cbranch_scc0 71f")
+    gen_split_path(e, p, paths[0][0], paths[0][1], init, depth)
+    if len(paths) > 1:
+        e.ins("s_branch 72f")
+        e.lines.append("71:")
+        gen_split_path(e, p, paths[1][0], paths[1][1], init, depth)
+        e.lines.append("72:")
     # the accumulators are read by VALU code right behind this statement: XDL write -> VALU read needs passes + 3 wait states
     e.ins("s_nop 15")
     return e.text(), p
@@ -206,10 +234,12 @@ HEADER = """// GENERATED by tools/gen_mlp16_kloop.py -- do not edit.  The hand-s
 
 def main():
     parts = [HEADER]
-    for name, carry in (("M16S_KLOOP_CARRY", True), ("M16S_KLOOP_PLAIN", False)):
-        text, p = gen_split(carry)
+    plan = None
+    for name, paths, init in (("M16S_FWD_TRAIN", [(16, True), (7, False)], "bias"), ("M16S_FWD_INFER", [(16, False), (7, False)], "bias"),
+                              ("M16S_BWD_DATA", [(16, True), (1, False)], "zero")):
+        text, plan = gen_split(paths, init)
         parts.append(f"#define {name}_ASM \\\n" + text.replace("\n", " \\\n").rstrip(" \\\n") + "\n")
-        parts.append(f"#define {name}_CLOBBERS {p.clobbers()}\n")
+    parts.append(f"#define M16S_KLOOP_CLOBBERS {plan.clobbers()}\n")
     with open(OUT, "w") as f:
         f.write("\n".join(parts))
     print("wrote", OUT)
