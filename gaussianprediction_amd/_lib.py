@@ -133,7 +133,7 @@ class ProfileEntryC(C.Structure):
 
 EXPORTS = [
     "gp_raster_forward", "gp_raster_backward", "gp_raster_mark_visible", "gp_raster_debug_binning",
-    "gp_mlp_forward", "gp_mlp_backward", "gp_mlp_pack", "gp_mlp_packed_floats", "gp_mlp16_forward", "gp_mlp16_backward", "gp_blend_forward", "gp_blend_backward",
+    "gp_mlp_forward", "gp_mlp_backward", "gp_mlp_pack", "gp_mlp_packed_floats", "gp_mlp16_forward", "gp_mlp16_backward", "gp_mlp16_pack", "gp_mlp16_packed_elems", "gp_blend_forward", "gp_blend_backward",
     "gp_activations_forward", "gp_activations_backward", "gp_profile_enable", "gp_profile_collect",
     "gp_loss_l1_ssim_forward", "gp_loss_l1_ssim_finalize", "gp_loss_l1_ssim_backward", "gp_adam_step",
     "gp_adam_step_multi", "gp_adam_step_multi_steps",
@@ -144,7 +144,7 @@ EXPORTS = [
     "gp_mlp_input_forward", "gp_mlp_input_backward", "gp_linear_forward", "gp_linear_backward", "gp_softmax_forward", "gp_softmax_backward",
     "gp_last_error", "gp_version", "gp_abi_version",
 ]
-GP_ABI_VERSION = 5         # include/gp_hip.h: the struct layouts / signatures / buffer-size macros this binding was written against
+GP_ABI_VERSION = 6         # include/gp_hip.h: the struct layouts / signatures / buffer-size macros this binding was written against
 
 _lib = None
 _lock = threading.Lock()
@@ -178,6 +178,7 @@ def lib() -> C.CDLL:
                 getattr(l, name).restype = C.c_int
         l.gp_hashgrid_table_entries.restype = C.c_int64
         l.gp_mlp_packed_floats.restype = C.c_int64
+        l.gp_mlp16_packed_elems.restype = C.c_int64
         if int(l.gp_abi_version()) != GP_ABI_VERSION:
             raise GpHipError(f"{LIB_PATH} implements ABI {int(l.gp_abi_version())}, this binding is written against ABI "
                              f"{GP_ABI_VERSION} (include/gp_hip.h): rebuild the library (__graft_entry__.build(force=True))")

@@ -1442,6 +1442,83 @@ __global__ __launch_bounds__(256) void gp_mlp16_pack_dout_split_kernel(const flo
 }
 
 // ------------------------------------------------------------------------------------------------
+// gp_mlp16_pack: the five weight matrices -> their zero-padded, fragment-packed 16-bit copies (forward or transposed operand order;
+// split mode: [hi copy][lo' copy]) in ONE launch.  The torch expression of the same (pad, clamp, compare, where, two casts, subtract,
+// scale, reshape / permute / contiguous, stack: ~14 launches per matrix, ten matrices per training step) was 0.4 ms of launch-bound
+// work per step beside kernels of 2 ms.
+// ------------------------------------------------------------------------------------------------
+struct Pack16Job {
+    const float* w;     // nn.Linear weight [n_out][n_in], row-major
+    void* out;
+    int F, K;           // packed matrix [F][K]
+    int n_out, n_in;
+};
+struct Pack16Jobs {
+    Pack16Job j[5];
+    long start[6];      // first packed position of every layer
+};
+__host__ __device__ __forceinline__ long mlp16_packed_elems(int l, int in_pad, bool transposed) {
+    return l == 0 ? (transposed ? (long)((in_pad + 31) / 32 * 32) * 256 : 256L * in_pad) : l < 4 ? 65536L : (transposed ? 256L * 16 : 32L * 256);
+}
+template <int MODE /* 0 fp16, 1 bf16, 2 split fp16 */>
+__global__ __launch_bounds__(256) void gp_mlp16_pack_kernel(Pack16Jobs jobs, int transposed) {
+    const long pos = (long)blockIdx.x * 256 + threadIdx.x;
+    if (pos >= jobs.start[5]) return;
+    int l = 0;
+#pragma unroll
+    for (int i = 1; i < 5; ++i) l += pos >= jobs.start[i];
+    const Pack16Job jb = jobs.j[l];
+    const long q = pos - jobs.start[l];
+    // position -> (f, k): (((k / 16) * (F / 32) + f / 32) * 64 + ((k / 8) & 1) * 32 + f % 32) * 8 + k % 8
+    const int e = (int)(q & 7), lane64 = (int)((q >> 3) & 63);
+    const long tile = q >> 9;
+    const int ft = (int)(tile % (jb.F / 32)), ks = (int)(tile / (jb.F / 32));
+    const int f = ft * 32 + (lane64 & 31), k = ks * 16 + (lane64 >> 5) * 8 + e;
+    float v = 0.f;
+    if (!transposed) { if (f < jb.n_out && k < jb.n_in) v = jb.w[(size_t)f * jb.n_in + k]; }
+    else { if (k < jb.n_out && f < jb.n_in) v = jb.w[(size_t)k * jb.n_in + f]; }
+    if constexpr (MODE == 0) ((_Float16*)jb.out)[q] = (_Float16)v;
+    else if constexpr (MODE == 1) ((__bf16*)jb.out)[q] = (__bf16)v;
+    else {
+        _Float16 hi, lo;
+        split1(v, hi, lo);
+        ((_Float16*)jb.out)[q] = hi;
+        ((_Float16*)jb.out)[(size_t)jb.F * jb.K + q] = lo;
+    }
+}
+extern "C" int64_t gp_mlp16_packed_elems(int32_t layer, int32_t in_dim, int32_t transposed) {
+    if (layer < 0 || layer > 4 || in_dim <= 0) return 0;
+    return mlp16_packed_elems(layer, (in_dim + 15) / 16 * 16, transposed != 0);
+}
+extern "C" int gp_mlp16_pack(const gp_mlp_params* p, int32_t dtype, int32_t transposed, void* const* out, gp_stream_t stream_) {
+    if (!p || !out) GP_FAIL("null mlp16 pack argument");
+    if (dtype != GP_DTYPE_F16 && dtype != GP_DTYPE_BF16 && dtype != GP_DTYPE_F16_SPLIT) GP_FAIL("mlp16 pack: dtype must be GP_DTYPE_F16, GP_DTYPE_BF16 or GP_DTYPE_F16_SPLIT");
+    if (p->width != 256 || p->depth != 4) GP_FAIL("Deformable_Field: only d=4, w=256 is implemented");
+    if (p->in_dim <= 0 || p->in_dim > 128 || p->out_dim < 1 || p->out_dim > 16) GP_FAIL("mlp16 pack: in_dim must be 1..128, out_dim 1..16");
+    const int in_pad = (p->in_dim + 15) / 16 * 16;
+    Pack16Jobs jobs;
+    long at = 0;
+    for (int l = 0; l < 5; ++l) {
+        if (!p->w[l] || !out[l]) GP_FAIL("null weight / output pointer (layer %d)", l);
+        Pack16Job& jb = jobs.j[l];
+        jb.w = p->w[l]; jb.out = out[l];
+        jb.n_out = l < 4 ? 256 : p->out_dim; jb.n_in = l == 0 ? p->in_dim : 256;
+        if (!transposed) { jb.F = l < 4 ? 256 : 32; jb.K = l == 0 ? in_pad : 256; }
+        else { jb.F = l == 0 ? (in_pad + 31) / 32 * 32 : 256; jb.K = l < 4 ? 256 : 16; }
+        jobs.start[l] = at;
+        at += (long)jb.F * jb.K;
+    }
+    jobs.start[5] = at;
+    hipStream_t s = (hipStream_t)stream_;
+    const dim3 grid(gp_blocks((size_t)at, 256));
+    if (dtype == GP_DTYPE_F16) hipLaunchKernelGGL(gp_mlp16_pack_kernel<0>, grid, dim3(256), 0, s, jobs, (int)(transposed != 0));
+    else if (dtype == GP_DTYPE_BF16) hipLaunchKernelGGL(gp_mlp16_pack_kernel<1>, grid, dim3(256), 0, s, jobs, (int)(transposed != 0));
+    else hipLaunchKernelGGL(gp_mlp16_pack_kernel<2>, grid, dim3(256), 0, s, jobs, (int)(transposed != 0));
+    GP_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
 // C ABI
 // ------------------------------------------------------------------------------------------------
 static int make16(const gp_mlp16_params* p, const gp_mlp_input* x, Mlp16Dev& m, bool transposed) {

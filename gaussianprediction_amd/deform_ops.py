@@ -172,7 +172,8 @@ class FusedMlp(torch.autograd.Function):
 
 def _to16(w, tdt, split):
     """16-bit copy of a weight matrix; split mode: [hi copy, lo' copy] with hi = fp16(w) (zero below the fp16 normal
-    range) and lo' = fp16((w - hi) * 2^11) (see GP_DTYPE_F16_SPLIT in include/gp_hip.h)."""
+    range) and lo' = fp16((w - hi) * 2^11) (see GP_DTYPE_F16_SPLIT in include/gp_hip.h).  The torch statement of what
+    gp_mlp16_pack does in one launch (kept as the checker of tests/test_gpu_deform.py::test_mlp16_pack_matches_the_torch_form)."""
     def pack(m):            # [F, K] (F % 32 == 0, K % 16 == 0) -> fragment order [k-step][feature tile][half][j][8] (include/gp_hip.h)
         F_, K_ = m.shape
         return m.reshape(F_ // 32, 32, K_ // 16, 2, 8).permute(2, 0, 3, 1, 4).contiguous()
@@ -185,6 +186,45 @@ def _to16(w, tdt, split):
     hi = torch.where(c.abs() < 6.103515625e-05, torch.zeros_like(c), c).to(torch.float16)
     lo = ((c - hi.float()) * 2048.0).to(torch.float16)
     return torch.stack([pack(hi), pack(lo)]).contiguous()
+
+
+def _torch_w16(ws, tdt, split, transposed):
+    """The five 16-bit weight copies built with torch ops (the form of rounds 1-5; the checker of gp_mlp16_pack)."""
+    dev = ws[0].device
+    in_dim, out_dim = ws[0].shape[1], ws[4].shape[0]
+    in_pad = (in_dim + 15) // 16 * 16
+    if not transposed:
+        w0p = torch.zeros(256, in_pad, device=dev)
+        w0p[:, :in_dim] = ws[0]
+        w4p = torch.zeros(32, 256, device=dev)
+        w4p[:out_dim] = ws[4]
+        return [_to16(w, tdt, split) for w in (w0p, ws[1], ws[2], ws[3], w4p)]
+    wt0 = torch.zeros(in_pad, 256, device=dev)
+    wt0[:in_dim] = ws[0].t()
+    wt4 = torch.zeros(256, 16, device=dev)
+    wt4[:, :out_dim] = ws[4].t()
+    return [_to16(w, tdt, split) for w in (wt0, ws[1].t(), ws[2].t(), ws[3].t(), wt4)]
+
+
+def packed_w16(ws, tdt, cdt, transposed):
+    """The five zero-padded, fragment-packed 16-bit weight copies of gp_mlp16_forward (transposed=False) / gp_mlp16_backward (True):
+    one buffer, one launch (gp_mlp16_pack).  Returns (buffer, [data pointers])."""
+    dev = ws[0].device
+    in_dim, out_dim = ws[0].shape[1], ws[4].shape[0]
+    ns = 2 if cdt == _lib.GP_DTYPE_F16_SPLIT else 1
+    L = _lib.lib()
+    sizes = [ns * int(L.gp_mlp16_packed_elems(C.c_int32(l), C.c_int32(in_dim), C.c_int32(1 if transposed else 0))) for l in range(5)]
+    offs = [0]
+    for n in sizes:
+        offs.append(offs[-1] + (n + 127) // 128 * 128)          # 256-byte aligned pieces
+    buf = torch.empty(offs[-1], device=dev, dtype=tdt)
+    params = _lib.MlpParamsC(in_dim, 256, 4, out_dim)
+    for l in range(5):
+        params.w[l] = ws[l].data_ptr()
+    ptrs = (C.c_void_p * 5)(*[buf.data_ptr() + 2 * offs[l] for l in range(5)])
+    with _lib.on_device(dev):
+        _lib.check(L.gp_mlp16_pack(C.byref(params), C.c_int32(cdt), C.c_int32(1 if transposed else 0), ptrs, _lib.stream_ptr(dev)), "gp_mlp16_pack")
+    return buf, [int(ptrs[l]) for l in range(5)]
 
 
 class FusedMlp16(torch.autograd.Function):
@@ -209,11 +249,7 @@ class FusedMlp16(torch.autograd.Function):
         rows, fd = feature_c.shape
         in_dim, out_dim = ws[0].shape[1], ws[4].shape[0]
         in_pad = (in_dim + 15) // 16 * 16
-        w0p = torch.zeros(256, in_pad, device=dev)
-        w0p[:, :in_dim] = ws[0]
-        w4p = torch.zeros(32, 256, device=dev)
-        w4p[:out_dim] = ws[4]
-        w16 = [_to16(w, tdt, split) for w in (w0p, ws[1], ws[2], ws[3], w4p)]
+        w16_buf, w16 = packed_w16(ws, tdt, cdt, False)
         need_grad = any(x is not None and torch.is_tensor(x) and x.requires_grad for x in (feature, xyz) + tuple(wb))
         out = torch.empty(rows, out_dim, device=dev)
         rows64 = (rows + 63) // 64 * 64                     # blocked layout [row block of 16][feature][16], rows padded to 64
@@ -222,7 +258,7 @@ class FusedMlp16(torch.autograd.Function):
         masks = torch.empty(4, rows, 8, device=dev, dtype=torch.int32) if need_grad else None
         params = _lib.Mlp16ParamsC(cdt, in_dim, 256, 4, out_dim)
         for l in range(5):
-            params.w16[l] = w16[l].data_ptr()
+            params.w16[l] = w16[l]
             params.b[l] = bs[l].data_ptr()
         if split and range_flag is not None:
             params.range_flag = range_flag.data_ptr()
@@ -251,11 +287,7 @@ class FusedMlp16(torch.autograd.Function):
         in_dim, out_dim = ws[0].shape[1], ws[4].shape[0]
         g = g_out.to(torch.float32).contiguous()
         split = cdt == _lib.GP_DTYPE_F16_SPLIT
-        wt0 = torch.zeros(in_pad, 256, device=dev)
-        wt0[:in_dim] = ws[0].t()
-        wt4 = torch.zeros(256, 16, device=dev)
-        wt4[:, :out_dim] = ws[4].t()
-        wt = [_to16(w, tdt, split) for w in (wt0, ws[1].t(), ws[2].t(), ws[3].t(), wt4)]
+        wt_buf, wt = packed_w16(ws, tdt, cdt, True)
         params = _lib.Mlp16ParamsC(cdt, in_dim, 256, 4, out_dim)
         grads = _lib.MlpGradsC()
         leaves = ctx.wb_leaves
@@ -267,7 +299,7 @@ class FusedMlp16(torch.autograd.Function):
             dws = [torch.zeros_like(w) for w in ws]
             dbs = [torch.zeros_like(b) for b in bs]
         for l in range(5):
-            params.w16[l] = wt[l].data_ptr()
+            params.w16[l] = wt[l]
             params.b[l] = bs[l].data_ptr()
             grads.dw[l] = dws[l].data_ptr()
             grads.db[l] = dbs[l].data_ptr()

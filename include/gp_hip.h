@@ -263,12 +263,19 @@ typedef struct gp_mlp16_params {
 /* saved (training, all optional together), 16-bit, BLOCKED by 16 rows, rows zero-padded to a multiple of 64:
  * xT [ceil(rows/64)*4][in_pad16][16] and hT [4][ceil(rows/64)*4][256][16]
  * (element (f, row) at ((row >> 4) * nf + f) * 16 + (row & 15));
- * masks [4, rows, 8] u32 = ReLU sign bits. */
+ * masks: 8 rows u32 per layer, an opaque hand-over from the forward to the backward (ReLU sign bits: [4][4 feature groups][rows][2],
+ * one word per lane of the kernels that write and read it; round 6). */
 int gp_mlp16_forward(const gp_mlp16_params* p, const gp_mlp_input* x, float* out, void* saved_xT, void* saved_hT,
                      uint32_t* masks, gp_stream_t stream);
 int gp_mlp16_backward(const gp_mlp16_params* p_transposed, const gp_mlp_input* x, const void* saved_xT, const void* saved_hT,
                       const uint32_t* masks, const float* dL_dout, gp_mlp_grads* g, float* dL_dfeature, float* dL_dxyz,
                       gp_alloc_fn alloc, void* alloc_ctx, gp_stream_t stream);
+/* The host's part of the above as one launch: the 16-bit copies w16[0..4] (zero-padded, fragment-packed; GP_DTYPE_F16_SPLIT: hi copy
+ * followed by lo' copy) of the nn.Linear weights p->w[0..4], in the forward's (transposed = 0) or the backward's (transposed != 0)
+ * operand order.  out[l] must hold gp_mlp16_packed_elems(l, in_dim, transposed) 16-bit elements (twice that in split mode).  (round 6:
+ * the torch expression of the same was ~140 launches per training step) */
+int64_t gp_mlp16_packed_elems(int32_t layer, int32_t in_dim, int32_t transposed);
+int gp_mlp16_pack(const gp_mlp_params* p, int32_t dtype, int32_t transposed, void* const* out, gp_stream_t stream);
 
 /* keypoint blend + pose composition  [REF scene/gaussian_model.py:214-229,266-273,285-286,314-315;
  * utils/camera_utils.py:158-170]:
@@ -563,8 +570,9 @@ const char* gp_version(void);
  * buffer-size macro (GP_LOSS_SUM_SLOTS) changes; a binding built against another number must refuse to run (the Python loader
  * does: gaussianprediction_amd/_lib.py).  History: 1 = rounds 1-2; 2 = round 3 (gp_raster_settings.sh_ready_event / visible,
  * gp_knn_keypoints' `order`, GP_LOSS_SUM_SLOTS per image size); 3 = round 4 (gp_abi_version itself); 4 = round 4 (gp_mlp_params.packed, gp_blend_args.knn_idx16, gp_knn_keypoints' signature,
- * gp_adam_step_multi_steps); 5 = round 5 (gp_train_step_run and its three structs). */
-#define GP_ABI_VERSION 5
+ * gp_adam_step_multi_steps); 5 = round 5 (gp_train_step_run and its three structs);
+ * 6 = round 6 (gp_mlp16_pack / gp_mlp16_packed_elems; the ReLU words gp_mlp16_forward hands to gp_mlp16_backward changed layout). */
+#define GP_ABI_VERSION 6
 int gp_abi_version(void);
 
 #ifdef __cplusplus

@@ -314,3 +314,28 @@ def test_fp32s_range_guard_detects_saturation_and_falls_back_to_the_exact_kernel
     off.precision, off.range_guard = "fp32s", "off"
     y3 = off.forward_fused(feat, xyz, t, 10, F)
     assert not off.range_tripped and bool(torch.isfinite(y3).all()) and not torch.allclose(y3, y_ref, rtol=1e-3, atol=1e-3 * float(y_ref.abs().max()))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision", ["fp16", "bf16", "fp32s"])
+def test_mlp16_pack_matches_the_torch_form(precision):
+    """gp_mlp16_pack (one launch: zero padding, fragment order, the (hi, lo') split, both operand orders) against the torch statement
+    of the same layout, bit for bit -- for the reference's input widths and an odd one."""
+    import torch
+    from gaussianprediction_amd import _lib
+    from gaussianprediction_amd.deform_ops import _torch_w16, packed_w16
+    tdt = {"fp16": torch.float16, "bf16": torch.bfloat16, "fp32s": torch.float16}[precision]
+    cdt = {"fp16": _lib.GP_DTYPE_F16, "bf16": _lib.GP_DTYPE_BF16, "fp32s": _lib.GP_DTYPE_F16_SPLIT}[precision]
+    g = torch.Generator("cuda").manual_seed(3)
+    for in_dim, out_dim in ((104, 7), (108, 7), (112, 8), (37, 7)):
+        ws = [torch.randn(256, in_dim, device="cuda", generator=g) * 0.1] + [torch.randn(256, 256, device="cuda", generator=g) * 0.06 for _ in range(3)] \
+            + [torch.randn(out_dim, 256, device="cuda", generator=g) * 0.06]
+        ws[1][0, :8] = torch.tensor([0.0, 1e-6, -3e-5, 7e4, -7e4, 6.1e-5, 1.0, -2.5], device="cuda")   # flush range, saturation
+        for transposed in (False, True):
+            buf, ptrs = packed_w16(ws, tdt, cdt, transposed)
+            ref = _torch_w16(ws, tdt, precision == "fp32s", transposed)
+            for l in range(5):
+                n = ref[l].numel()
+                off = (ptrs[l] - buf.data_ptr()) // 2
+                got = buf[off:off + n].view(torch.int16)
+                assert torch.equal(got, ref[l].reshape(-1).view(torch.int16)), (precision, in_dim, transposed, l)
