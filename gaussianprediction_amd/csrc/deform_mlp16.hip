@@ -28,6 +28,7 @@ typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef __bf16 b8 __attribute__((ext_vector_type(8)));
 
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) h4 lds_h4;      // (an LDS location addressed by its 32-bit byte address)
 typedef __bf16 b4 __attribute__((ext_vector_type(4)));
 template <typename T> struct Vec4;
 template <> struct Vec4<_Float16> { typedef h4 type; };
@@ -101,6 +102,24 @@ __device__ __forceinline__ void fast_sincos(float a, float* s, float* c) {
     const float rev = a * 0.15915494309189535f;
     *s = __builtin_amdgcn_sinf(rev);
     *c = __builtin_amdgcn_cosf(rev);
+}
+
+// sin and cos of a positional-encoding argument (|a| up to a few thousand: 2^9 times a coordinate) for the split-mode kernels: the
+// quadrant from rint(a 2/pi), a three-constant Cody-Waite reduction (pi/2 = C1 + C2 + C3 in fp32; the first step is exact for |a| < 2^13,
+// the fma keeps every product unrounded), Cephes' minimax polynomials on [-pi/4, pi/4].  |error| <= 9.2e-8 (1.5 ulp at 1; ocml's sincosf: 0.5
+// ulp) in ~25 instructions instead of ~110 with branches -- the encoding was a fifth of the forward's vector instructions.
+__device__ __forceinline__ void sincos_pe(float a, float* s, float* c) {
+    const float n = rintf(a * 0.6366197466850281f);
+    float r = fmaf(-n, 1.5707963705062866f, a);
+    r = fmaf(-n, -4.371138828673793e-08f, r);
+    r = fmaf(-n, -1.7151245100058819e-15f, r);
+    const float z = r * r;
+    const float sr = fmaf(r * z, fmaf(fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f), z, -1.6666654611e-1f), r);
+    const float cr = fmaf(z * z, fmaf(fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f), z, 4.166664568298827e-2f), fmaf(-0.5f, z, 1.f));
+    const int q = (int)n;
+    const float ss = (q & 1) ? cr : sr, cc = (q & 1) ? sr : cr;
+    *s = __uint_as_float(__float_as_uint(ss) ^ ((uint32_t)(q & 2) << 30));
+    *c = __uint_as_float(__float_as_uint(cc) ^ ((uint32_t)((q + 1) & 2) << 30));
 }
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -261,7 +280,7 @@ __device__ __forceinline__ void build_input16s(_Float16* buf, const Mlp16Dev& p,
     constexpr int FU = ROWS * 64 / 4 / M16_THREADS;         // float4 feature loads per thread at feature_dim = 64 (4 for 64 rows)
     if ((fd & 3) == 0 && fd <= 64 && ((uintptr_t)p.feature & 15) == 0) {
         // EVERY global load of the tile is issued before the first LDS store: as `for (e = tid; ...) put(.., p.feature[..])` and
-        // `sincosf(p.xyz[..] ..)` loops the tile cost 8 + 8 dependent trips to memory per workgroup (a rolled loop with a conditional
+        // `sincos_pe(p.xyz[..] ..)` loops the tile cost 8 + 8 dependent trips to memory per workgroup (a rolled loop with a conditional
         // load waits for each one) -- a quarter of a 64-row workgroup's lifetime at two workgroups per CU.  Same values, same
         // expressions per element.
         const int q = fd >> 2, nq = ROWS * q;
@@ -305,7 +324,7 @@ __device__ __forceinline__ void build_input16s(_Float16* buf, const Mlp16Dev& p,
                 const bool ok = row0 + jj < p.rows;
                 for (int fr = 0; fr < xf; ++fr) {
                     float sv = 0.f, cv = 0.f;
-                    if (ok) sincosf(xv[u] * (float)(1u << fr), &sv, &cv);
+                    if (ok) sincos_pe(xv[u] * (float)(1u << fr), &sv, &cv);
                     put(jj, fd + 2 * (c * xf + fr), sv);
                     put(jj, fd + 2 * (c * xf + fr) + 1, cv);
                 }
@@ -322,7 +341,7 @@ __device__ __forceinline__ void build_input16s(_Float16* buf, const Mlp16Dev& p,
             const int c = cf / xf, fr = cf - c * xf;
             const long row = row0 + jj;
             float sv = 0.f, cv = 0.f;
-            if (row < p.rows) sincosf(p.xyz[row * 3 + c] * (float)(1u << fr), &sv, &cv);
+            if (row < p.rows) sincos_pe(p.xyz[row * 3 + c] * (float)(1u << fr), &sv, &cv);
             put(jj, fd + 2 * cf, sv);
             put(jj, fd + 2 * cf + 1, cv);
         }
@@ -330,7 +349,7 @@ __device__ __forceinline__ void build_input16s(_Float16* buf, const Mlp16Dev& p,
     for (int e = tid; e < tf * ROWS; e += M16_THREADS) {
         const int jj = e % ROWS, fr = e / ROWS;
         float sv, cv;
-        sincosf(tv * (float)(1u << fr), &sv, &cv);
+        sincos_pe(tv * (float)(1u << fr), &sv, &cv);
         const bool ok = row0 + jj < p.rows;
         put(jj, fd + 6 * xf + 2 * fr, ok ? sv : 0.f);
         put(jj, fd + 6 * xf + 2 * fr + 1, ok ? cv : 0.f);
@@ -788,7 +807,7 @@ __device__ __forceinline__ void mlp16s_fwd_hand_body(Mlp16Dev p, float* __restri
     if constexpr (TRAIN) burst(saved_xT, p.in_pad, lane_k);
     const size_t layer_elems = t16_elems(NS * M16_W, p.rows);
     const int bad_row = row0 + ROWS > p.rows ? (int)(p.rows - row0) : ROWS;        // the first row of the tile that does not exist
-    float amax = 0.f;                   // the largest hidden activation this lane carried into (hi, lo') form
+    int amax_bits = 0;                  // the largest hidden activation this lane carried into (hi, lo') form (its bit pattern)
     for (int l = 0; l < 4; ++l) {
         // Everything derived from the lane number is recomputed per layer (the empty statement hides the value's origin): hoisted out
         // of the layer loop, the epilogue's per-lane addresses were ~70 registers live ACROSS the product, which has none to spare --
@@ -804,36 +823,35 @@ __device__ __forceinline__ void mlp16s_fwd_hand_body(Mlp16Dev p, float* __restri
                 const float4 bv = *(const float4*)(p.b[l] + (2 * wave + nt) * 32 + 8 * g + 4 * half);
                 am[0][nt][4 * g + 0] = bv.x; am[0][nt][4 * g + 1] = bv.y; am[0][nt][4 * g + 2] = bv.z; am[0][nt][4 * g + 3] = bv.w;
             }
-        if (!(ablate & 4)) {
+        {   // (no "products off" switch here: a second definition of the accumulators costs ~130 moves per layer in THIS path)
             const Kloop16sAddr ka = kloop16s_addr(smem, wave, lane);
             _Float16* st = TRAIN ? saved_hT + (size_t)(l > 0 ? l - 1 : 0) * layer_elems + (size_t)blockIdx.x * NS * M16_W * ROWS + wave * (NS * M16_W * T16_BLK) : nullptr;
             kloop16s_fwd<TRAIN>(ka, (const _Float16*)p.w[l] + wave * 1024, (const _Float16*)p.wlo[l] + wave * 1024, st, l == 0, am, ax);
-        } else {
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) { am[1][nt][r] = am[0][nt][r]; ax[0][nt][r] = 0.f; ax[1][nt][r] = 0.f; }
         }
         __syncthreads();                    // every wave has read the layer's input before anyone overwrites it
+        // this lane's element (row j, feature 64 wave + 4 half) of the tile, as an LDS byte address; the feature bits of (nt, g) enter by XOR
+        // (they lie inside the swizzled field), row tile and (hi | lo') half as instruction offsets: one v_xor per eight bytes stored
+        const uint32_t ebase = (uint32_t)(uintptr_t)smem + 2 * a16_idx<WS>(j, 64 * wave + 4 * half);
         if (!(ablate & 16))
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt) {
-            const int row = rt * 32 + j;
-            const long grow = row0 + row;
+            const long grow = row0 + rt * 32 + j;
             uint32_t mbits = 0;
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    const int f0 = (2 * wave + nt) * 32 + 8 * g + 4 * half;
                     float v[4];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = relu_push(fmaf(ax[rt][nt][4 * g + e], SP_LO_INV, am[rt][nt][4 * g + e]), mbits);
                     h4 hi, lo;
                     split4(v, hi, lo);
-                    amax = fmaxf(fmaxf(amax, fmaxf(v[0], v[1])), fmaxf(v[2], v[3]));
-                    *(h4*)&smem[a16_idx<WS>(row, f0)] = hi;
-                    *(h4*)&smem[a16_idx<WS>(row, 256 + f0)] = lo;
+                    // (non-negative floats order like their bit patterns: two v_max3_i32 per four values)
+                    amax_bits = max(max(amax_bits, __float_as_int(v[0])), __float_as_int(v[1]));
+                    amax_bits = max(max(amax_bits, __float_as_int(v[2])), __float_as_int(v[3]));
+                    const uint32_t a = (ebase ^ (uint32_t)(64 * nt + 16 * g)) + rt * (32 * WS * 2);
+                    *(lds_h4*)(uintptr_t)a = hi;
+                    *(lds_h4*)(uintptr_t)(a + 512) = lo;
                 }
             if (masks && grow < p.rows) masks[relu_mask_idx(l, wave, grow, half, p.rows)] = mbits;
         }
@@ -847,7 +865,7 @@ __device__ __forceinline__ void mlp16s_fwd_hand_body(Mlp16Dev p, float* __restri
             if (l == 3) burst(saved_hT + 3 * layer_elems, M16_W, lane);
         }
     }
-    if (p.range_flag && amax >= 32768.f) atomicOr(p.range_flag, 1u);         // the range guard of "fp32s": see mlp16_fwd_body
+    if (p.range_flag && __int_as_float(amax_bits) >= 32768.f) atomicOr(p.range_flag, 1u);         // the range guard of "fp32s": see mlp16_fwd_body
     mlp16_output_layer<T, 2, true>(p, out, smem, smem, row0, tid);
 }
 __global__ __launch_bounds__(M16_THREADS, 2) void gp_mlp16_fwd_split_train_kernel(Mlp16Dev p, float* out, void* sx, void* sh, uint32_t* masks) {
@@ -918,7 +936,7 @@ __device__ __forceinline__ void mlp16_input_grad(const Mlp16Dev& p, const T* cur
                 for (int fr = 0; fr < p.xyz_freq; ++fr) {
                     const float sc = (float)(1u << fr);
                     float sv, cv;
-                    if constexpr (SP) sincosf(x * sc, &sv, &cv);
+                    if constexpr (SP) sincos_pe(x * sc, &sv, &cv);
                     else fast_sincos(x * sc, &sv, &cv);      // the same hardware sin/cos the forward encoded with
                     const int f = p.feature_dim + 2 * (c * p.xyz_freq + fr);
                     g += sc * (cv * dX[r * 128 + f] - sv * dX[r * 128 + f + 1]);
@@ -1100,24 +1118,28 @@ __device__ __forceinline__ void mlp16s_bwd_data_hand_body(Mlp16Dev p, const uint
             kloop16s_bwd(ka, (const _Float16*)p.w[l] + wave * 1024, (const _Float16*)p.wlo[l] + wave * 1024, st, l == 4, am, ax);
         }
         __syncthreads();
+        const uint32_t ebase = (uint32_t)(uintptr_t)smem + 2 * a16_idx<WS>(j, 64 * wave + 4 * half);      // (see the forward's epilogue)
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt) {
-            const int row = rt * 32 + j;
-            const uint32_t m = row0 + row < p.rows ? mreg[rt] : 0u;
+            const uint32_t m = row0 + rt * 32 + j < p.rows ? mreg[rt] : 0u;
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    const int f0 = (2 * wave + nt) * 32 + 8 * g + 4 * half;
                     float v[4];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        v[e] = __uint_as_float(__float_as_uint(fmaf(ax[rt][nt][4 * g + e], SP_LO_INV, am[rt][nt][4 * g + e])) &
-                                               (uint32_t)__builtin_amdgcn_sbfe((int)m, relu_mask_pos(nt, g, e), 1));
+                    for (int e = 0; e < 4; ++e) {
+                        // the sign-extended mask bit AND the value: two instructions (written as the instruction: from `z & sbfe(m, pos, 1)`
+                        // hipcc makes v_and + v_cmp_ne + v_cndmask)
+                        uint32_t keep;
+                        asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(keep) : "v"(m), "n"(relu_mask_pos(nt, g, e)));
+                        v[e] = __uint_as_float(__float_as_uint(fmaf(ax[rt][nt][4 * g + e], SP_LO_INV, am[rt][nt][4 * g + e])) & keep);
+                    }
                     h4 hi, lo;
                     split4(v, hi, lo);
-                    *(h4*)&smem[a16_idx<WS>(row, f0)] = hi;
-                    *(h4*)&smem[a16_idx<WS>(row, 256 + f0)] = lo;
+                    const uint32_t a = (ebase ^ (uint32_t)(64 * nt + 16 * g)) + rt * (32 * WS * 2);
+                    *(lds_h4*)(uintptr_t)a = hi;
+                    *(lds_h4*)(uintptr_t)(a + 512) = lo;
                 }
         }
         __syncthreads();
@@ -1567,7 +1589,7 @@ extern "C" int gp_mlp16_forward(const gp_mlp16_params* p, const gp_mlp_input* x,
             dyn = 40 * 1024;
         }
         // the hand-scheduled kernels (gp_debug_option(9, 64): the compiler's loops, for A/B; other input widths than 112 keep them too)
-        const bool hand = m.in_pad == 112 && !(gp_debug_get(9) & (64 | 32));
+        const bool hand = m.in_pad == 112 && !(gp_debug_get(9) & (64 | 32 | 4));
         const bool train = saved_xT && saved_hT && masks && !(gp_debug_get(9) & 1);
         if (hand && train) hipLaunchKernelGGL(gp_mlp16_fwd_split_train_kernel, dim3(gp_blocks((size_t)m.rows, M16_ROWS)), dim3(M16_THREADS), 0, s, m, out, saved_xT, saved_hT, masks);
         else if (hand && ((!saved_xT && !saved_hT && !masks) || (gp_debug_get(9) & 1)))
