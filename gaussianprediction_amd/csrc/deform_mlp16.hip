@@ -668,7 +668,6 @@ __device__ __forceinline__ void mlp16_fwd_body(Mlp16Dev p, float* __restrict__ o
     constexpr int NS = SP ? 2 : 1;                              // saved "features" per real feature
     constexpr bool INPLACE = RT > 2 || SP;
     __shared__ T smem[INPLACE ? 1 : 2][ROWS * WS];
-    typedef typename Vec8<T>::type V8;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, j = lane & 31;
     const long row0 = (long)blockIdx.x * ROWS;
     const long rows_pad = (p.rows + 63) & ~63L;                 // the saved tensors are allocated (and zero-padded) to 64 rows

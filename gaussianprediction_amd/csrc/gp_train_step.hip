@@ -97,29 +97,36 @@ extern "C" int gp_train_step_run(const gp_step_plan* p, const gp_step_view* v, c
     alloc(alloc_ctx, GP_BUF_TEMP_DONE, 0);
     if (u->hook) u->hook(u->hook_ctx, GP_STEP_AFTER_FORWARD);
 
-    // ---- loss [REF train.py:105-109, utils/loss_utils.py:54-100] and its image gradient.  The SSIM derivative maps live from the
-    // loss forward to the loss backward only: with NULL in the plan they are a TEMP buffer -- the allocator hands out the memory the
-    // rasterizer forward's sort just used and the rasterizer backward's accumulators use next (TEMP_DONE below), so they add nothing
-    // to the step's working set (9 floats per pixel: 49 MB at 1352 x 1014).  The image gradient is read by the composite backward
-    // WHILE those accumulators are written: it stays a buffer of its own.
-    float* dmaps = p->dmaps;
+    // ---- loss [REF train.py:105-109, utils/loss_utils.py:54-100] and its image gradient: one kernel (gp_loss_l1_ssim_fused: the SSIM
+    // derivative maps stay in LDS).  The pair-of-kernels form keeps its plan field: there the maps live from the loss forward to the loss
+    // backward only -- with NULL in the plan they are a TEMP buffer the allocator carves out of memory the rasterizer's sort just used.
+    // The image gradient is read by the composite backward WHILE its accumulators are written: it stays a buffer of its own.
     float* dimg = p->dL_dimage;
     if (!dimg) GP_FAIL("gp_train_step_run: null intermediate buffer");
-    if (!dmaps) {
-        dmaps = (float*)alloc(alloc_ctx, GP_BUF_TEMP, gp_align_up((size_t)9 * H * W * 4, 256));
-        if (!dmaps) GP_FAIL("gp_train_step_run: allocator returned NULL for the SSIM derivative maps");
-    }
-    if (gp_loss_l1_ssim_forward(out.color, v->gt_image, 3, H, W, p->loss_sums, dmaps, stream)) return 1;
-    if (reg) {
-        if (gp_loss_l1_ssim_finalize_reg(p->loss_sums, 3, H, W, p->lambda_dssim, p->keypoint_features, nfeat, p->reg_scale, p->loss, stream)) return 1;
-        if (gp_loss_l1_ssim_backward_reg(out.color, v->gt_image, dmaps, 3, H, W, p->lambda_dssim, nullptr, dimg,
-                                         p->keypoint_features, nfeat, p->reg_scale, p->g_keypoint_features, stream)) return 1;
+    if (gp_debug_get(11) == 0) {
+        // one launch: the sums of the loss and its image gradient (round 6; gp_debug_option(11, 1): the pair of kernels, for A/B)
+        if (gp_loss_l1_ssim_fused(out.color, v->gt_image, 3, H, W, p->lambda_dssim, nullptr, p->loss_sums, dimg, reg ? p->keypoint_features : nullptr,
+                                  nfeat, p->reg_scale, reg ? p->g_keypoint_features : nullptr, stream)) return 1;
+        if (reg) { if (gp_loss_l1_ssim_finalize_reg(p->loss_sums, 3, H, W, p->lambda_dssim, p->keypoint_features, nfeat, p->reg_scale, p->loss, stream)) return 1; }
+        else if (gp_loss_l1_ssim_finalize(p->loss_sums, 3, H, W, p->lambda_dssim, p->loss, stream)) return 1;
     } else {
-        if (gp_loss_l1_ssim_finalize(p->loss_sums, 3, H, W, p->lambda_dssim, p->loss, stream)) return 1;
-        if (gp_loss_l1_ssim_backward(out.color, v->gt_image, dmaps, 3, H, W, p->lambda_dssim, nullptr, dimg, stream)) return 1;
+        float* dmaps = p->dmaps;
+        if (!dmaps) {
+            dmaps = (float*)alloc(alloc_ctx, GP_BUF_TEMP, gp_align_up((size_t)9 * H * W * 4, 256));
+            if (!dmaps) GP_FAIL("gp_train_step_run: allocator returned NULL for the SSIM derivative maps");
+        }
+        if (gp_loss_l1_ssim_forward(out.color, v->gt_image, 3, H, W, p->loss_sums, dmaps, stream)) return 1;
+        if (reg) {
+            if (gp_loss_l1_ssim_finalize_reg(p->loss_sums, 3, H, W, p->lambda_dssim, p->keypoint_features, nfeat, p->reg_scale, p->loss, stream)) return 1;
+            if (gp_loss_l1_ssim_backward_reg(out.color, v->gt_image, dmaps, 3, H, W, p->lambda_dssim, nullptr, dimg,
+                                             p->keypoint_features, nfeat, p->reg_scale, p->g_keypoint_features, stream)) return 1;
+        } else {
+            if (gp_loss_l1_ssim_finalize(p->loss_sums, 3, H, W, p->lambda_dssim, p->loss, stream)) return 1;
+            if (gp_loss_l1_ssim_backward(out.color, v->gt_image, dmaps, 3, H, W, p->lambda_dssim, nullptr, dimg, stream)) return 1;
+        }
+        if (!p->dmaps) alloc(alloc_ctx, GP_BUF_TEMP_DONE, 0);
     }
 
-    if (!p->dmaps) alloc(alloc_ctx, GP_BUF_TEMP_DONE, 0);
     // ---- backward, in the order autograd runs it
     gp_raster_grads g;
     memset(&g, 0, sizeof(g));

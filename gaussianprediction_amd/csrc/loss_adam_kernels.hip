@@ -234,6 +234,190 @@ __global__ __launch_bounds__(256) void gp_l1_ssim_bwd_kernel(const float* __rest
 }
 
 // ------------------------------------------------------------------------------------------------
+// Loss forward AND image gradient in one kernel (round 6; the fused train step's form -- the two kernels above stay the autograd
+// path's).  d loss / d img does not depend on the loss value, only on the SSIM derivative maps within 5 pixels of the output
+// pixel: a workgroup owning 32 x 32 outputs therefore needs the maps on 42 x 42, i.e. the statistics on 42 x 42, i.e. the two
+// images on 52 x 52 -- staged ONCE; the three derivative maps never leave the CU (the pair of kernels wrote 9 floats per pixel and
+// read them back with a halo: ~370 MB of traffic at 1352 x 1014 for 16 MB of images).  Same filter chains in the same order: the
+// gradient and the per-tile sums are bit-identical to gp_l1_ssim_fwd_kernel + gp_l1_ssim_bwd_kernel.
+// LDS: the image halos (22 KB; the derivative maps take their place once the last horizontal pass has read them) + two horizontally
+// filtered planes at a time (18 KB; later the backward's three) = 40 KB, three to four workgroups per CU.
+// ------------------------------------------------------------------------------------------------
+#define LF (LT + 4 * LH)    // staged image edge (52)
+#define LFP (LF + 1)
+__global__ __launch_bounds__(256) void gp_l1_ssim_fused_kernel(const float* __restrict__ img, const float* __restrict__ gt, int H, int W,
+                                                              Win11 win, float lambda, const float* __restrict__ upstream,
+                                                              double* __restrict__ sums, float* __restrict__ dimg,
+                                                              const float* __restrict__ reg_x, long reg_n, float reg_scale_over_n,
+                                                              float* __restrict__ reg_g) {
+    __shared__ float s_ab[2][LF][LFP];
+    __shared__ float s_h[2][LF][LP];
+    __shared__ float s_red[4];
+    float (*s_m)[LE][LP] = (float (*)[LE][LP]) & s_ab[0][0][0];          // [3][42][43] <= [2][52][53]
+    float (*s_h2)[LE][LHP] = (float (*)[LE][LHP]) & s_h[0][0][0];        // [3][42][33] <= [2][52][43]
+    static_assert(3 * LE * LP <= 2 * LF * LFP && 3 * LE * LHP <= 2 * LF * LP, "aliased planes must fit");
+    const int tid = threadIdx.x;
+    const int tx0 = blockIdx.x * LT, ty0 = blockIdx.y * LT, ch = blockIdx.z;
+    if (reg_g && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) {   // the regulariser's gradient rides along (see the backward kernel)
+        const float c = (upstream ? upstream[0] : 1.f) * reg_scale_over_n;
+        for (long i = tid; i < reg_n; i += 256) { const float v = reg_x[i]; reg_g[i] = v > 0.f ? c : (v < 0.f ? -c : 0.f); }
+    }
+    const size_t HW = (size_t)H * W;
+    const float* a_img = img + ch * HW;
+    const float* b_img = gt + ch * HW;
+    {   // halo staging, every load in flight before the first LDS store
+        constexpr int NST = (LF * LF + 255) / 256;
+        float va[NST], vb[NST];
+#pragma unroll
+        for (int u = 0; u < NST; ++u) {
+            const int i = tid + 256 * u, y = i / LF, x = i - y * LF;
+            const int gy = ty0 - 2 * LH + y, gx = tx0 - 2 * LH + x;
+            const bool in = i < LF * LF && gy >= 0 && gy < H && gx >= 0 && gx < W;
+            const size_t o = in ? (size_t)gy * W + gx : 0;
+            va[u] = a_img[o]; vb[u] = b_img[o];
+        }
+#pragma unroll
+        for (int u = 0; u < NST; ++u) {
+            const int i = tid + 256 * u, y = i / LF, x = i - y * LF;
+            const int gy = ty0 - 2 * LH + y, gx = tx0 - 2 * LH + x;
+            const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
+            if (i < LF * LF) { s_ab[0][y][x] = in ? va[u] : 0.f; s_ab[1][y][x] = in ? vb[u] : 0.f; }
+        }
+    }
+    __syncthreads();
+    // this thread's four output pixels (column ox, rows oy0 .. oy0 + 3): their own values, kept for the L1 term and the last step
+    const int ox = tid & 31, oy0 = (tid >> 5) * 4;
+    float pa[4], pb[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { pa[e] = s_ab[0][oy0 + e + 2 * LH][ox + 2 * LH]; pb[e] = s_ab[1][oy0 + e + 2 * LH][ox + 2 * LH]; }
+    // ---- statistics on 42 x 42: five maps, two horizontally filtered planes at a time, the two maps of a round as the halves of
+    // packed fp32 operations (v_pk_fma_f32: one instruction per tap and output for BOTH maps).  Horizontal: an item = 11 consecutive
+    // outputs of one staged row (52 rows x 4 groups = 208 items: one pass over the threads); vertical: a thread = 7 consecutive rows of
+    // one column (42 columns x 6 groups = 252 threads).
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    const int vx = tid % LE, vy0 = (tid / LE) * 7;
+    const bool vert = tid < LE * 6;
+    float st[5][7];
+#pragma unroll
+    for (int round = 0; round < 3; ++round) {
+        if (tid < LF * 4) {
+            const int y = tid >> 2, x0 = (tid & 3) * 11;
+            f2 v[21];           // (columns beyond the staged 52 feed outputs beyond 42 only: discarded)
+#pragma unroll
+            for (int j = 0; j < 21; ++j) {
+                const float a = s_ab[0][y][x0 + j], b = s_ab[1][y][x0 + j];
+                v[j] = round == 0 ? f2{a, b} : round == 1 ? f2{a * a, b * b} : f2{a * b, 0.f};
+            }
+#pragma unroll
+            for (int e = 0; e < 11; ++e) {
+                f2 m = {0.f, 0.f};
+#pragma unroll
+                for (int k = 0; k < 11; ++k) m = __builtin_elementwise_fma(f2{win.w[k], win.w[k]}, v[e + k], m);
+                if (x0 + e < LE) {
+                    s_h[0][y][x0 + e] = m[0];
+                    if (round < 2) s_h[1][y][x0 + e] = m[1];
+                }
+            }
+        }
+        __syncthreads();
+        if (vert) {
+            f2 v[17];
+#pragma unroll
+            for (int j = 0; j < 17; ++j) v[j] = f2{s_h[0][vy0 + j][vx], round < 2 ? s_h[1][vy0 + j][vx] : 0.f};
+#pragma unroll
+            for (int e = 0; e < 7; ++e) {
+                f2 acc = {0.f, 0.f};
+#pragma unroll
+                for (int k = 0; k < 11; ++k) acc = __builtin_elementwise_fma(f2{win.w[k], win.w[k]}, v[e + k], acc);
+                st[2 * round][e] = acc[0];
+                if (round < 2) st[2 * round + 1][e] = acc[1];
+            }
+        }
+        if (round < 2) __syncthreads();         // (after the last round nobody reads the image planes again: the maps may overwrite them)
+    }
+    // ---- SSIM and its three derivative maps on 42 x 42 (zero outside the image, as the backward's staging had them)
+    float l1 = 0.f, ss = 0.f;
+    const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
+    if (vert) {
+        const int gx = tx0 - LH + vx;
+#pragma unroll
+        for (int e = 0; e < 7; ++e) {
+            const int y = vy0 + e, gy = ty0 - LH + y;
+            float d0 = 0.f, d1 = 0.f, d2 = 0.f;
+            if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
+                const float mu1 = st[0][e], mu2 = st[1][e], aa = st[2][e], bb = st[3][e], ab = st[4][e];
+                const float mu1s = mu1 * mu1, mu2s = mu2 * mu2, mu12 = mu1 * mu2;
+                const float s11 = aa - mu1s, s22 = bb - mu2s, s12 = ab - mu12;
+                const float N1 = 2.f * mu12 + C1, N2 = 2.f * s12 + C2, D1 = mu1s + mu2s + C1, D2 = s11 + s22 + C2;
+                const float inv = 1.f / (D1 * D2);
+                const float ssim = N1 * N2 * inv;
+                if (vx >= LH && vx < LH + LT && y >= LH && y < LH + LT) ss += ssim;        // this workgroup's own 32 x 32
+                d0 = (2.f * mu2 * N2 - 2.f * mu2 * N1) * inv - ssim * (2.f * mu1 * D2 - 2.f * mu1 * D1) * inv;
+                d1 = -ssim / D2;
+                d2 = 2.f * N1 * inv;
+            }
+            s_m[0][y][vx] = d0; s_m[1][y][vx] = d1; s_m[2][y][vx] = d2;
+        }
+    }
+    __syncthreads();
+    // ---- the gradient's two filter passes (as gp_l1_ssim_bwd_kernel; maps 0 and 1 as a packed pair)
+    if (tid < LE * 4) {
+        const int y = tid >> 2, x0 = (tid & 3) * 8;
+        f2 v[18];
+        float v2[18];
+#pragma unroll
+        for (int j = 0; j < 18; ++j) { v[j] = f2{s_m[0][y][x0 + j], s_m[1][y][x0 + j]}; v2[j] = s_m[2][y][x0 + j]; }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            f2 acc = {0.f, 0.f};
+            float acc2 = 0.f;
+#pragma unroll
+            for (int k = 0; k < 11; ++k) { acc = __builtin_elementwise_fma(f2{win.w[k], win.w[k]}, v[e + k], acc); acc2 = fmaf(win.w[k], v2[e + k], acc2); }
+            s_h2[0][y][x0 + e] = acc[0]; s_h2[1][y][x0 + e] = acc[1]; s_h2[2][y][x0 + e] = acc2;
+        }
+    }
+    __syncthreads();
+    const float g = upstream ? upstream[0] : 1.f;
+    const float inv_n = 1.f / (3.f * (float)HW);
+    {
+        float o[3][4];
+        {
+            f2 v[14];
+            float v2[14];
+#pragma unroll
+            for (int j = 0; j < 14; ++j) { v[j] = f2{s_h2[0][oy0 + j][ox], s_h2[1][oy0 + j][ox]}; v2[j] = s_h2[2][oy0 + j][ox]; }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                f2 acc = {0.f, 0.f};
+                float acc2 = 0.f;
+#pragma unroll
+                for (int k = 0; k < 11; ++k) { acc = __builtin_elementwise_fma(f2{win.w[k], win.w[k]}, v[e + k], acc); acc2 = fmaf(win.w[k], v2[e + k], acc2); }
+                o[0][e] = acc[0]; o[1][e] = acc[1]; o[2][e] = acc2;
+            }
+        }
+        const int gx = tx0 + ox;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int gy = ty0 + oy0 + e;
+            if (gy >= H || gx >= W) continue;
+            const float a = pa[e], b = pb[e];
+            const float d = a - b;
+            l1 += fabsf(d);
+            const float sgn = (d > 0.f) ? 1.f : ((d < 0.f) ? -1.f : 0.f);
+            dimg[ch * HW + (size_t)gy * W + gx] = g * inv_n * ((1.f - lambda) * sgn - lambda * (o[0][e] + 2.f * a * o[1][e] + b * o[2][e]));
+        }
+    }
+    const float l1_tot = block_sum_256(l1, s_red);
+    __syncthreads();
+    const float ss_tot = block_sum_256(ss, s_red);
+    if (tid == 0) {
+        const unsigned slot = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+        sums[2 * slot] = (double)l1_tot;
+        sums[2 * slot + 1] = (double)ss_tot;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Adam (torch.optim.Adam semantics, amsgrad=False, weight_decay=0) + gradient zeroing
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void gp_adam_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
@@ -453,6 +637,22 @@ extern "C" int gp_loss_l1_ssim_backward(const float* img, const float* gt, const
     GpProfScope _p("l1_ssim_bwd", s);
     hipLaunchKernelGGL(gp_l1_ssim_bwd_kernel, dim3((W + LT - 1) / LT, (H + LT - 1) / LT, 3), dim3(256), 0, s, img, gt, dmaps, H, W,
                        make_window(), lambda_dssim, upstream, dimg, (const float*)nullptr, 0L, 0.f, (float*)nullptr);
+    GP_LAUNCH_CHECK();
+    return 0;
+}
+
+// forward sums + image gradient in one launch (gp_l1_ssim_fused_kernel); the loss value still comes from a finalize call on `sums`
+extern "C" int gp_loss_l1_ssim_fused(const float* img, const float* gt, int32_t channels, int32_t H, int32_t W, float lambda_dssim,
+                                     const float* upstream, double* sums, float* dimg, const float* x, int64_t n, float scale, float* gx,
+                                     gp_stream_t stream_) {
+    hipStream_t s = (hipStream_t)stream_;
+    if (!img || !gt || !sums || !dimg) GP_FAIL("null argument");
+    if (channels != 3 || H <= 0 || W <= 0) GP_FAIL("expects a [3,H,W] image (got C=%d H=%d W=%d)", channels, H, W);
+    if ((x != nullptr) != (gx != nullptr)) GP_FAIL("regulariser input and gradient must be given together");
+    if (x && (n <= 0 || n > 65536)) GP_FAIL("regulariser input must have 1..65536 elements");
+    GpProfScope _p("l1_ssim_fused", s);
+    hipLaunchKernelGGL(gp_l1_ssim_fused_kernel, dim3((W + LT - 1) / LT, (H + LT - 1) / LT, 3), dim3(256), 0, s, img, gt, H, W, make_window(),
+                       lambda_dssim, upstream, sums, dimg, x, x ? (long)n : 0L, x ? scale / (float)n : 0.f, gx);
     GP_LAUNCH_CHECK();
     return 0;
 }

@@ -337,6 +337,13 @@ int gp_loss_l1_ssim_finalize(const double* sums, int32_t channels, int32_t H, in
 int gp_loss_l1_ssim_backward(const float* img, const float* gt, const float* dmaps, int32_t channels, int32_t H, int32_t W,
                              float lambda_dssim, const float* upstream, float* dimg, gp_stream_t stream);
 
+/* gp_loss_l1_ssim_forward's sums AND gp_loss_l1_ssim_backward[_reg]'s gradient in ONE launch (round 6: the fused train step's form;
+ * the derivative maps never leave the CU).  Bit-identical sums and gradient.  x / gx: the regulariser's input and gradient as in
+ * gp_loss_l1_ssim_backward_reg (both NULL: none).  The loss value: a finalize call on `sums` as before. */
+int gp_loss_l1_ssim_fused(const float* img, const float* gt, int32_t channels, int32_t H, int32_t W, float lambda_dssim,
+                          const float* upstream, double* sums, float* dimg, const float* x, int64_t n, float scale, float* gx,
+                          gp_stream_t stream);
+
 /* finalize / backward with the regulariser  scale * mean(|x|)  folded in (n <= 65536: the keypoint features of stage 2/3;
  * [REF scene/gaussian_model.py:174-178, train.py:108-109]):  loss[0] = the finalize value + scale * mean|x|;
  * gx = upstream[0] * scale/n * sign(x) written by the backward launch. */
@@ -571,7 +578,7 @@ const char* gp_version(void);
  * does: gaussianprediction_amd/_lib.py).  History: 1 = rounds 1-2; 2 = round 3 (gp_raster_settings.sh_ready_event / visible,
  * gp_knn_keypoints' `order`, GP_LOSS_SUM_SLOTS per image size); 3 = round 4 (gp_abi_version itself); 4 = round 4 (gp_mlp_params.packed, gp_blend_args.knn_idx16, gp_knn_keypoints' signature,
  * gp_adam_step_multi_steps); 5 = round 5 (gp_train_step_run and its three structs);
- * 6 = round 6 (gp_mlp16_pack / gp_mlp16_packed_elems; the ReLU words gp_mlp16_forward hands to gp_mlp16_backward changed layout). */
+ * 6 = round 6 (gp_mlp16_pack / gp_mlp16_packed_elems, gp_loss_l1_ssim_fused; the ReLU words gp_mlp16_forward hands to gp_mlp16_backward changed layout). */
 #define GP_ABI_VERSION 6
 int gp_abi_version(void);
 
