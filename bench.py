@@ -271,14 +271,39 @@ def dense_variant(args, device, steps=20):
         xyz, q, s, o = pc(torch.from_numpy(cam.time).float().to(device), a2.iteration)
         dbg = raster_forward_debug(_settings(cam, pc, ts.bg, 1.0), xyz, o, shs=pc.get_features, scales=s, rotations=q)
     R, n_vis = int(dbg["R"]), int((dbg["radii"] > 0).sum())
+    pairs = None
+    try:        # (pixel, splat) pairs of the same view, as the headline's roofline object counts them: the fraction below is only readable beside them
+        import ctypes as C
+        L = _lib.lib()
+        _lib.check(L.gp_debug_option(0, 3), "opt")
+        cnt = (C.c_uint64 * 4)()
+        _lib.check(L.gp_debug_counters(cnt), "counters")
+        with torch.no_grad():
+            raster_forward_debug(_settings(cam, pc, ts.bg, 1.0), xyz, o, shs=pc.get_features, scales=s, rotations=q)
+        _lib.check(L.gp_debug_counters(cnt), "counters")
+        pairs = (int(cnt[0]), int(cnt[1]))
+    except Exception:
+        pairs = None
+    finally:
+        try:
+            _lib.check(_lib.lib().gp_debug_option(0, 0), "opt")
+        except Exception:
+            pass
     W, H = args.width, args.height
     T, P = ((W + 15) // 16) * ((H + 15) // 16), W * H
     k = {name: prof[name][1] / 5 for name in ("composite_fwd", "composite_bwd") if name in prof}
     out = {"scale_lo": a2.scale_lo, "scale_hi": a2.scale_hi, "R": R, "R_per_gaussian": round(R / max(args.gaussians, 1), 3), "visible": n_vis,
            "steps": steps, "ms_per_step": round(ms, 3), "frames_repeated_after_overflow": getattr(ts, "redone", 0)}
+    if pairs is not None:
+        # the denser scene's pixels saturate earlier: tiles stop reading their lists, so 44 R over-counts the bytes the kernel needs --
+        # contributing pairs per list entry say by how much (headline: see roofline.contributing_pairs / R)
+        out["contributing_pairs"], out["evaluated_pairs"] = pairs
+        out["contributing_pairs_per_list_entry"] = round(pairs[0] / max(R, 1), 2)
     if "composite_fwd" in k:
         out["composite_fwd_ms"] = round(k["composite_fwd"], 4)
         out["composite_fwd_frac"] = round((44 * R + 8 * T + 28 * P) / (k["composite_fwd"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+        if pairs is not None:
+            out["composite_fwd_ns_per_1e3_contributing_pairs"] = round(k["composite_fwd"] * 1e6 / max(pairs[0], 1) * 1e3, 3)
     if "composite_bwd" in k:
         out["composite_bwd_ms"] = round(k["composite_bwd"], 4)
         out["composite_bwd_frac"] = round((44 * R + 8 * T + 24 * P + 40 * n_vis) / (k["composite_bwd"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
@@ -417,6 +442,33 @@ def main():
         ts.reducer.time_waits = False
     prof = _lib.profile_collect()
     _lib.profile_enable(0)
+    # the headline's depth sort runs three passes under a promise about the key range, which holds for scenes whose visible depths span less
+    # than a factor of four (config.depth_sort): the same step WITHOUT the promise (four passes, what a deeper scene pays), 10 untimed-for-
+    # the-headline steps, so that the scene-dependent part of the number is visible in the record
+    no_promise_ms, four_pass_sort_ms = None, None
+    if world == 1 and not args.render_only and getattr(ts, "speculative", False) and getattr(ts, "last_depth_key_promise", None):
+        try:
+            ts.depth_key_speculation = False
+            for i in range(3):
+                one_step(preroll + args.warmup + args.steps + i)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for i in range(10):
+                one_step(preroll + args.warmup + args.steps + 3 + i)
+            torch.cuda.synchronize()
+            no_promise_ms = 1000.0 * (time.perf_counter() - t1) / 10
+            _lib.profile_enable(2); _lib.profile_collect()
+            for i in range(5):
+                one_step(preroll + args.warmup + args.steps + 13 + i)
+            torch.cuda.synchronize()
+            pp = _lib.profile_collect(); _lib.profile_enable(0)
+            if "depth_sort" in pp:
+                four_pass_sort_ms = pp["depth_sort"][1] / 5
+        finally:
+            ts.depth_key_speculation = True
+            for i in range(2):
+                one_step(preroll + args.warmup + args.steps + 18 + i)       # (the promise is back for whatever follows)
+            torch.cuda.synchronize()
     # eval-style forward renders (the "rendered views/s" half of the metric, [REF eval.py:208-224]); separate
     # timed loop, reported as an extra field
     eval_fps, eval_ms = None, None
@@ -481,7 +533,10 @@ def main():
             ach = bytes_alg / (avg_ms * 1e-3) / 1e9
             roof = {"kernel": "composite_fwd", "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
-                    "algorithmic_bytes": bytes_alg, "avg_ms": round(avg_ms, 4)}
+                    "algorithmic_bytes": bytes_alg, "avg_ms": round(avg_ms, 4),
+                    # `bound` is the contract's roofline (SURVEY 8d prices the kernel in bytes); what the kernel WAITS for is the vector ALU
+                    # (valu_issue_frac / valu_busy below): the fraction of the HBM roof is therefore capped by instructions, not by traffic
+                    "binding_resource": "valu"}
             # HBM bytes per launch from the PMC passes (tools/pmc_hbm.py): quoted only while the file describes THIS kernel
             # source (it is stamped with the source's hash); otherwise null -- a stale constant is not a measurement
             tf = os.path.join(ROOT, "profiles", "composite_fwd_traffic.json")
@@ -602,6 +657,8 @@ def main():
                                       f"seen in the set-up steps: {_key_depth(ts._key_lo):.3f} .. {_key_depth(ts._key_hi):.3f})"),
                        "keypoint_weights": "raw_weights / knn_idx are inputs of the step (BASELINE.json north_star); the reference "
                                            "recomputes them per frame (hash-grid weights model + kNN): see train_step_with_weights_model_ms"},
+            "ms_per_step_without_depth_promise": None if no_promise_ms is None else round(no_promise_ms, 4),
+            "depth_sort_four_pass_ms": None if four_pass_sort_ms is None else round(four_pass_sort_ms, 4),
             "roofline": roof,
             "roofline_other_kernels": others,
             "eval_render_ms_per_view_synced": None if eval_ms is None else round(eval_ms, 3),      # eval.py's own timing loop

@@ -3,6 +3,7 @@
 // nothing is re-implemented here, so the fused step and the drop-in surfaces cannot drift apart.
 // [REF train.py:101-133, 196-197; scene/gaussian_model.py:251-273]
 #include "gp_common.h"
+#include <mutex>
 
 // dst[i] += src[i]: the keypoint features take a gradient from the regulariser AND from the MLP's input (both "=" producers)
 __global__ __launch_bounds__(256) void gp_step_accumulate_kernel(float* __restrict__ dst, const float* __restrict__ src, int64_t n) {
@@ -14,14 +15,24 @@ __global__ __launch_bounds__(256) void gp_step_accumulate_kernel(float* __restri
 struct StepSide { hipStream_t s; hipEvent_t fork, join; bool ok; };
 static StepSide* step_side() {
     static StepSide side[32];
+    static std::mutex mu;                       // (two host threads driving one device: the table is filled once, under the lock)
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32) return nullptr;
+    std::lock_guard<std::mutex> lock(mu);
     StepSide& x = side[dev];
     if (!x.ok) {
-        if (hipStreamCreateWithFlags(&x.s, hipStreamNonBlocking) != hipSuccess) return nullptr;
-        if (hipEventCreateWithFlags(&x.fork, hipEventDisableTiming) != hipSuccess) return nullptr;
-        if (hipEventCreateWithFlags(&x.join, hipEventDisableTiming) != hipSuccess) return nullptr;
-        x.ok = true;
+        hipStream_t st = nullptr;
+        hipEvent_t f = nullptr, j = nullptr;
+        const bool good = hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess &&
+                          hipEventCreateWithFlags(&f, hipEventDisableTiming) == hipSuccess &&
+                          hipEventCreateWithFlags(&j, hipEventDisableTiming) == hipSuccess;
+        if (!good) {                            // nothing half-made is left behind
+            if (j) (void)hipEventDestroy(j);
+            if (f) (void)hipEventDestroy(f);
+            if (st) (void)hipStreamDestroy(st);
+            return nullptr;
+        }
+        x.s = st; x.fork = f; x.join = j; x.ok = true;
     }
     return &x;
 }
@@ -62,6 +73,11 @@ extern "C" int gp_train_step_run(const gp_step_plan* p, const gp_step_view* v, c
     if (!p->delta || !p->acts || !p->xyz_t || !p->q_t || !p->scale || !p->opacity_t || !p->loss_sums || !p->loss || !p->g_xyz_t || !p->g_q_t || !p->g_scale || !p->g_opacity_t || !p->g_means2D || !p->g_delta || !p->g_feature_tmp)
         GP_FAIL("gp_train_step_run: null intermediate buffer");
     if (!v->bg || !v->viewmatrix || !v->projmatrix || !v->campos || !v->gt_image || !v->time) GP_FAIL("gp_train_step_run: null view pointer");
+    // the optimizer's table is checked BEFORE anything is enqueued: a refusal behind the backward would leave the gradients written and the
+    // SH coefficients (updated inside the rasterizer backward) already stepped
+    if (u->adam_count < 0 || u->adam_count > 32) GP_FAIL("gp_train_step_run: 0..32 optimizer tensors (got %d)", u->adam_count);
+    if (u->adam_count > 0 && (!u->adam_params || !u->adam_grads || !u->adam_exp_avgs || !u->adam_exp_avg_sqs || !u->adam_numels || !u->adam_lrs))
+        GP_FAIL("gp_train_step_run: null optimizer table");
     const int H = p->image_height, W = p->image_width, od = p->mlp.out_dim;
     const bool reg = p->reg_scale != 0.f;
     const int64_t nfeat = K * (int64_t)p->feature_dim;
@@ -141,32 +157,36 @@ extern "C" int gp_train_step_run(const gp_step_plan* p, const gp_step_view* v, c
     alloc(alloc_ctx, GP_BUF_TEMP_DONE, 0);
     // ---- optimizer, first part [REF train.py:196-197]: the per-Gaussian tensors' gradients are final here.  Their update (HBM-bound,
     // every CU) runs on the second stream beside the keypoint MLP's backward (latency-bound, 16 CUs): neither touches the other's tensors.
-    if (u->adam_count > 32) GP_FAIL("gp_train_step_run: at most 32 optimizer tensors");
     const uint32_t all = u->adam_count >= 32 ? 0xFFFFFFFFu : ((1u << u->adam_count) - 1u);
     uint32_t early = (u->hook || u->adam_count <= 0) ? 0u : (u->adam_early_mask & all);
     StepSide* side = early ? step_side() : nullptr;
     if (early && !side) early = 0u;         // (no second stream: one launch behind the backward, as without the mask)
+    // (an error behind the fork still joins the side stream: the caller sees ONE stream, whatever the return code)
+    auto join_side = [&]() { if (early) { (void)hipEventRecord(side->join, side->s); (void)hipStreamWaitEvent((hipStream_t)stream, side->join, 0); } };
     if (early) {
         GP_HIP_CHECK(hipEventRecord(side->fork, (hipStream_t)stream));
         GP_HIP_CHECK(hipStreamWaitEvent(side->s, side->fork, 0));
-        if (step_adam(u, early, (gp_stream_t)side->s)) return 1;
+        if (step_adam(u, early, (gp_stream_t)side->s)) { join_side(); return 1; }
         GP_HIP_CHECK(hipEventRecord(side->join, side->s));
     }
     gp_mlp_grads mg = p->g_mlp;
     if (gp_mlp_backward(&p->mlp, &mi, p->acts, p->g_delta, &mg, reg ? p->g_feature_tmp : p->g_keypoint_features, p->g_keypoints, alloc,
-                        alloc_ctx, stream))
+                        alloc_ctx, stream)) {
+        join_side();
         return 1;
+    }
     if (reg) {
         hipLaunchKernelGGL(gp_step_accumulate_kernel, dim3(gp_blocks((size_t)nfeat, 256)), dim3(256), 0, (hipStream_t)stream,
                            p->g_keypoint_features, (const float*)p->g_feature_tmp, nfeat);
-        GP_LAUNCH_CHECK();
+        if (hipGetLastError() != hipSuccess) { join_side(); GP_FAIL("gp_train_step_run: launch failed"); }
     }
     if (u->hook) u->hook(u->hook_ctx, GP_STEP_AFTER_BACKWARD);
 
     // ---- optimizer [REF train.py:196-197, scene/gaussian_model.py:472]
     if (u->adam_count > 0) {
-        if (step_adam(u, all & ~early, stream)) return 1;
+        const int rc = step_adam(u, all & ~early, stream);
         if (early) GP_HIP_CHECK(hipStreamWaitEvent((hipStream_t)stream, side->join, 0));     // the caller sees ONE stream
+        if (rc) return 1;
     }
     return 0;
 }

@@ -786,38 +786,38 @@ extern "C" int gp_weights_backward(const gp_hashgrid_config* cfg, int64_t n, con
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void gp_fps_kernel(long n, const float* __restrict__ xyz, long m, int32_t* __restrict__ idx,
                                                        float* __restrict__ dist) {
-    __shared__ float s_best[16];
-    __shared__ int s_besti[16];
+    __shared__ float s_far_d2[16];
+    __shared__ int s_far_id[16];
     __shared__ int s_sel;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (long k = tid; k < n; k += 1024) dist[k] = 1e10f;
     if (tid == 0) { idx[0] = 0; s_sel = 0; }
     __syncthreads();
     for (long j = 1; j < m; ++j) {
-        const int old = s_sel;
-        const float x1 = xyz[3 * (size_t)old], y1 = xyz[3 * (size_t)old + 1], z1 = xyz[3 * (size_t)old + 2];
-        float best = -1.f;
-        int besti = 0x7fffffff;
+        const int cur = s_sel;
+        const float cx = xyz[3 * (size_t)cur], cy = xyz[3 * (size_t)cur + 1], cz = xyz[3 * (size_t)cur + 2];
+        float far_d2 = -1.f;
+        int far_id = 0x7fffffff;
         for (long k = tid; k < n; k += 1024) {
-            const float dx = xyz[3 * k] - x1, dy = xyz[3 * k + 1] - y1, dz = xyz[3 * k + 2] - z1;
+            const float dx = xyz[3 * k] - cx, dy = xyz[3 * k + 1] - cy, dz = xyz[3 * k + 2] - cz;
             const float d = fminf(dx * dx + dy * dy + dz * dz, dist[k]);
             dist[k] = d;
-            if (d > best) { best = d; besti = (int)k; }          // strictly greater: the first maximum of this thread's share
+            if (d > far_d2) { far_d2 = d; far_id = (int)k; }          // strictly greater: the first maximum of this thread's share
         }
 #pragma unroll
         for (int dd = 32; dd >= 1; dd >>= 1) {
-            const float ob = __shfl_xor(best, dd);
-            const int oi = __shfl_xor(besti, dd);
-            if (ob > best || (ob == best && oi < besti)) { best = ob; besti = oi; }
+            const float o_d2 = __shfl_xor(far_d2, dd);
+            const int o_id = __shfl_xor(far_id, dd);
+            if (o_d2 > far_d2 || (o_d2 == far_d2 && o_id < far_id)) { far_d2 = o_d2; far_id = o_id; }
         }
         __syncthreads();                                         // (s_sel was read by everyone)
-        if (lane == 0) { s_best[wave] = best; s_besti[wave] = besti; }
+        if (lane == 0) { s_far_d2[wave] = far_d2; s_far_id[wave] = far_id; }
         __syncthreads();
         if (tid == 0) {
-            float b = s_best[0];
-            int bi = s_besti[0];
+            float b = s_far_d2[0];
+            int bi = s_far_id[0];
             for (int w = 1; w < 16; ++w)
-                if (s_best[w] > b || (s_best[w] == b && s_besti[w] < bi)) { b = s_best[w]; bi = s_besti[w]; }
+                if (s_far_d2[w] > b || (s_far_d2[w] == b && s_far_id[w] < bi)) { b = s_far_d2[w]; bi = s_far_id[w]; }
             idx[j] = bi;
             s_sel = bi;
         }

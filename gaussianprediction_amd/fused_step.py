@@ -97,8 +97,7 @@ class FusedStage3:
         self.plan = P
         self.params = [pc._xyz, pc._scaling, pc._rotation, pc._opacity, pc._features_dc, pc._features_rest, pc.super_gaussians,
                        pc.super_gaussians_feature] + list(wb)
-        self._addr = [(p.data_ptr(), p.grad.data_ptr()) for p in self.params] + [(self.raw_w.data_ptr(), pc.raw_weights.data_ptr()),
-                                                                                   (self.knn.data_ptr(), pc.knn_idx.data_ptr())]
+        self._addr = [(p.data_ptr(), p.grad.data_ptr()) for p in self.params]          # (raw_w / knn: tracked by _kw_key below)
         self._kw_key = (id(pc.raw_weights), pc.raw_weights._version, id(pc.knn_idx), pc.knn_idx._version)
         # one view struct per camera (matrices, target, time all resident on the device)
         self.views, self._keep = [], []
@@ -133,8 +132,8 @@ class FusedStage3:
         if a.step_opacity and ts.iteration > a.step_opacity_iteration:
             return False
         noise = getattr(a, "xyz_noise_iteration", 0)
-        if noise and (ts.iteration - pc.second_stage_iter) < noise:
-            return False
+        if noise and ((ts.iteration - pc.second_stage_iter) < noise or getattr(pc, "reference_rng", False)):
+            return False                     # (the keypoint noise -- or, with reference_rng, its zero-scaled draw -- is a torch op of the graph path)
         if getattr(a, "densify_from_teaching", False) or ts.pipe.convert_SHs_python or ts.pipe.compute_cov3D_python:
             return False
         if pc._features_rest.dim() != 3 or pc._features_rest.shape[1] != 15 or pc.super_gaussians.shape[0] * pc.super_gaussians_feature.shape[1] > 65536:
@@ -145,6 +144,8 @@ class FusedStage3:
             return False
         opt = pc.optimizer
         if opt is None or opt.pending_hold or (opt.shard is not None) != bool(ts.reducer.enabled):
+            return False
+        if len(opt.items) > 32:              # (gp_step_update's launch table and its 32-bit masks)
             return False
         need = [pc._xyz, pc._scaling, pc._rotation, pc._opacity, pc._features_dc, pc._features_rest, pc.super_gaussians,
                 pc.super_gaussians_feature] + list(pc.df_model.parameters())
@@ -315,6 +316,13 @@ class FusedStage3:
             radii, vis = reduce_view_stats(radii, ts.group)
             if self._h_vs is not None:
                 self._h_vs.wait()
+        # the forward's side outputs GaussianModel.forward leaves behind (all_xyz_motion, kpts_*_motion, weights_sum, dense_weights():
+        # densify_kpts(mode="gaussian_mean") reads them): views of the plan's buffers, overwritten by the next step -- without this a
+        # fused step left the LAST GRAPH-PATH step's values there (round-5 advisor)
+        pc._last_delta, pc._last_xyz_t = b["delta"], b["xyz_t"]
+        pc._last_blend = (self.raw_w, self.knn, int(pc.super_gaussians.shape[0]))
         pkg = {"render": b["color"], "viewspace_points": self.viewspace, "visibility_filter": vis, "radii": radii,
                "depth": b["depth"], "tidx": b["tidx"]}
+        if ex is not None:
+            pkg["viewspace_point_tensor_grad"] = self.viewspace.grad        # (the graph path's multi-rank key)
         return b["loss"].reshape(()).clone(), pkg

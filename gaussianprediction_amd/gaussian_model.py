@@ -300,10 +300,17 @@ class GaussianModel(TrainingMixin, nn.Module):
             self.set_superKeypoints()
             self.training2stage_setup()
 
-    def forward(self, t, iteration, return_weights=False):
+    def forward(self, t, iteration, return_weights=False, reference_rng=None):
+        """`reference_rng` (default: the model's `reference_rng` attribute, False): draw `torch.randn_like` on EVERY stage-1 / stage-2/3
+        pass, also once the noise's scale has decayed to zero, as the reference does [REF scene/gaussian_model.py:241,254] -- a seeded
+        training run then consumes the random stream exactly like the reference's (matters for bit-reproducible training
+        comparisons, not for render parity).  Off: the draw is skipped once its factor is zero (one launch less per step); the fused
+        train step is not taken with it on."""
         if torch.is_tensor(iteration):
             iteration = iteration.item()
         a = self.args
+        if reference_rng is None:
+            reference_rng = bool(getattr(self, "reference_rng", False))
         xyz_freq, time_freq = int(self.xyz_input_dim / 6), self.time_input_dim // 2
         if iteration < a.jointly_iteration:          # warm-up: static Gaussians
             s, o = Activations.apply(self._scaling, self._opacity, None, 0, 1.0)
@@ -314,7 +321,7 @@ class GaussianModel(TrainingMixin, nn.Module):
         if iteration <= self.second_stage_iter:      # stage 1: MLP over all N Gaussians, xyz detached
             noise = getattr(a, "xyz_noise_iteration", 0)
             xyz_in = self._xyz.detach()
-            if noise and iteration < noise:
+            if noise and (iteration < noise or reference_rng):
                 xyz_in = xyz_in + torch.randn_like(xyz_in) * 0.1 * (1 - min(1, iteration / noise))
             delta = self.df_model.forward_fused(self.motion_feature, xyz_in, t_dev, xyz_freq, time_freq)
             self._last_delta = delta.detach()        # (side outputs only: holding the graph alive would pin its AccumulateGrad nodes)
@@ -322,7 +329,7 @@ class GaussianModel(TrainingMixin, nn.Module):
         else:                                        # stage 2/3: MLP over K keypoints + sparse blend
             noise = getattr(a, "xyz_noise_iteration", 0)
             kp = self.super_gaussians
-            if noise and (iteration - self.second_stage_iter) < noise:
+            if noise and ((iteration - self.second_stage_iter) < noise or reference_rng):
                 kp = kp + torch.randn_like(kp) * 0.1 * (1 - min(1, (iteration - self.second_stage_iter) / noise))
             raw_weights, knn_idx = self.raw_weights, self.knn_idx
             if raw_weights is None or knn_idx is None:

@@ -69,6 +69,7 @@ class TrainStep:
             self._status = torch.zeros(K, self.STATUS_WORDS, dtype=torch.int32, device=dev)
             self._status_host = torch.zeros(K, self.STATUS_WORDS, dtype=torch.int32).pin_memory()
             self._key_lo = self._key_hi = None      # smallest / largest visible depth key reported so far (over all views)
+            self._key_none = torch.tensor([-1, 0], dtype=self._status.dtype, device=self._status.device)    # {0xFFFFFFFF, 0}: nothing reported
             self.depth_key_speculation = os.environ.get("GP_DEPTH_KEY_SPEC", "1") != "0"
             self._events = [None] * K
             self._slot_view = [None] * K            # view rendered by the step that last used the slot
@@ -242,7 +243,7 @@ class TrainStep:
             self._r_max = max(self._r_max, r)
             if not self._slot_spec[slot]:            # an exact-mode step: it also reported the visible Gaussians' depth-key range
                 lo, hi = int(self._status_host[slot, 4]) & 0xFFFFFFFF, int(self._status_host[slot, 5]) & 0xFFFFFFFF
-                if lo <= hi:
+                if lo <= hi and hi != 0:            # ({0xFFFFFFFF, 0} = nothing reported: see _run_slot)
                     self._key_lo = lo if self._key_lo is None else min(self._key_lo, lo)
                     self._key_hi = hi if self._key_hi is None else max(self._key_hi, hi)
             if overflow and self._slot_spec[slot]:   # its Adam update was skipped on the device: repeat the frame, exactly
@@ -285,6 +286,11 @@ class TrainStep:
         # (capacity, {R, overflow, scratch}, the depth-key promise of a capacity-mode step, the key-range words of an exact one)
         binning = (capacity, status[0:3], None if exact else self._depth_key_promise(), status[4:6] if exact else None)
         self.last_depth_key_promise = binning[2]
+        if exact:
+            # "no report": the library fills the two range words only on the sorting path of a render that sorts something -- a step that
+            # returns early (no Gaussians, nothing visible) must not leave {0, 0}, which would read as a range and pin the window's base
+            # at 0 (round-5 advisor).  (min, max) start values: a batch's views then accumulate through the kernel's atomics.
+            status[4:6].copy_(self._key_none, non_blocking=True)
         out = self._step(view_index, binning, None if exact else status[1:2])
         self._status_host[slot].copy_(status, non_blocking=True)
         ev = self._events[slot] or torch.cuda.Event()
@@ -341,8 +347,11 @@ class TrainStep:
             ([] if lifecycle else [pc._xyz])
         sid = {id(p_) for p_ in single}
         self.reducer.set_late([p_ for p_ in self.bucket.params if id(p_) not in sid])
-        hold = tuple(getattr(self, "_hold", ()))     # groups that skip this step's update: every early / fused / chained form of the
-        plain = bool(hold)                           # SH update is off, one ordinary optimizer launch runs at the end
+        # groups that skip this step's update (the caller's, and the ones surgery left pending: FusedAdam.step merges `pending_hold` in,
+        # but the early / fused / chained forms of the SH update are decided HERE -- round-5 advisor): with any, all of those forms are
+        # off and one ordinary optimizer launch runs at the end
+        hold = tuple(dict.fromkeys(tuple(getattr(self, "_hold", ())) + tuple(getattr(self.optimizer, "pending_hold", ()) or ())))
+        plain = bool(hold)
         if self.overlap_sh_adam and keep and not self.reducer.enabled and not plain:
             self._armed, self._keep, self._skip_flag = True, keep, skip_flag
         sh_pair, fuse = (pc._features_dc, pc._features_rest), None

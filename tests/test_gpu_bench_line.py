@@ -40,7 +40,12 @@ def test_bench_prints_one_well_formed_line():
     c = d["cpu_baseline"]
     assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and isinstance(c["sample"], str) and c["unit"]
     ks = d["kernels_ms"]
-    for name in ("composite_fwd", "composite_bwd", "preprocess_fwd", "preprocess_bwd", "depth_sort", "adam", "l1_ssim_fwd", "l1_ssim_bwd"):
+    for name in ("composite_fwd", "composite_bwd", "preprocess_fwd", "preprocess_bwd", "depth_sort", "adam", "l1_ssim_fused"):
         assert ks[name]["ms_per_step"] > 0, name
     assert sum(v["ms_per_step"] for v in ks.values()) <= 1.15 * d["ms_per_step"]                           # one stream: the kernels fit in the step
     assert d["dense_variant"]["R_per_gaussian"] > d["config"]["R_per_gaussian"]
+    assert d["dense_variant"]["contributing_pairs"] > 0 and d["dense_variant"]["evaluated_pairs"] >= d["dense_variant"]["contributing_pairs"]
+    assert r["binding_resource"] == "valu"
+    # the headline's depth sort runs under a key-range promise that depends on the scene: the same step without it is in the record
+    if "promised base" in d["config"]["depth_sort"]:
+        assert d["ms_per_step_without_depth_promise"] > 0 and d["depth_sort_four_pass_ms"] > 0

@@ -179,3 +179,25 @@ def test_explicit_opacity_type_gates_by_birth_time():
     with torch.no_grad():
         pkg = gpa.render(cam, pc, pipe, torch.zeros(3, device="cuda"), time=t, it=50000)
     assert torch.isfinite(pkg["render"]).all() and float(pkg["render"].sum()) > 0
+
+
+@pytest.mark.parametrize("it", [20000, 50000])
+def test_reference_rng_draws_the_decayed_noise_like_the_reference(it):
+    """[REF scene/gaussian_model.py:241,254] draws torch.randn_like on every forward, also when its factor has decayed to zero: with
+    reference_rng the model consumes the generator's stream the same way (same outputs: the draw is multiplied by 0); without it the
+    draw is skipped and the stream does not move."""
+    pc, cam, *_ = build(N=1500, K=40, args=make_args(xyz_noise_iteration=10000))
+    t = torch.tensor([0.4])
+    with torch.no_grad():
+        torch.manual_seed(11)
+        s0 = torch.cuda.get_rng_state()
+        plain = pc(t, it)
+        assert torch.equal(torch.cuda.get_rng_state(), s0)                   # past the noise schedule: nothing drawn
+        ref = pc(t, it, reference_rng=True)
+        assert not torch.equal(torch.cuda.get_rng_state(), s0)               # one randn_like drawn
+        for a, b in zip(plain, ref):
+            assert torch.equal(a, b)
+        pc.reference_rng = True                                              # (the attribute form: what a training loop sets once)
+        s1 = torch.cuda.get_rng_state()
+        pc(t, it)
+        assert not torch.equal(torch.cuda.get_rng_state(), s1)
