@@ -591,6 +591,47 @@ __device__ __forceinline__ void kloop16s_bwd(const Kloop16sAddr& a, const _Float
                  : "memory", "scc", M16S_KLOOP_CLOBBERS);
 }
 
+// The plain 16-bit statements (fp16 / bf16 operands, 128-row workgroups: 4 row tiles x 2 feature tiles per wave; tools/gen_mlp16_kloop.py
+// gen_plain): same structure -- two paths, counted waits, weight fragments five k-steps ahead, the carried store (wave w owns row blocks
+// 2 w and 2 w + 1 of the tile, k-step g = features 32 (g & 7) .. + 31 of block 2 w + (g >> 3)).
+__device__ __forceinline__ Kloop16sAddr kloop16p_addr(const void* cur, int wave, int lane) {
+    Kloop16sAddr a;
+    const int half = lane >> 5, j = lane & 31;
+    const uint32_t base = (uint32_t)(uintptr_t)cur;
+    a.abase = base + j * (M16_W * 2) + 2 * ((((j & 15) << 3)) ^ (8 * half));
+    a.voff = lane * 16;
+    const int G = lane >> 4, fb = G & 1, h = G >> 1, jj = (lane >> 2) & 3, q = lane & 3;
+    a.sbt = base + (32 * wave + 8 * h + jj) * (M16_W * 2) + 2 * (((4 * q + 16 * fb) ^ (jj << 3)) + (h << 6));
+    a.vost = (16 * fb + (lane & 15)) * 32 + 16 * h;
+    return a;
+}
+#define M16P_ACC_OUT(c)                                                                                                              \
+    [c10] "=&v"(c[1][0]), [c11] "=&v"(c[1][1]), [c20] "=&v"(c[2][0]), [c21] "=&v"(c[2][1]), [c30] "=&v"(c[3][0]), [c31] "=&v"(c[3][1])
+#define M16P_IN(a) [abase] "v"(a.abase), [voff] "v"(a.voff), [swh] "s"(w), [sel] "s"(sel)
+#define M16P_IN_CARRY(a) M16P_IN(a), [sst] "s"(st), [sbt] "v"(a.sbt), [vost] "v"(a.vost)
+template <typename T, bool TRAIN>
+__device__ __forceinline__ void kloop16p_fwd(const Kloop16sAddr& a, const T* w, T* st, int sel, f32x16 (&c)[4][2]) {
+    w = uniform_ptr(w);
+    sel = __builtin_amdgcn_readfirstlane(sel);
+    constexpr bool F16 = sizeof(T) == 2 && UsesScale<T>::v;
+    if constexpr (TRAIN) {
+        st = uniform_ptr(st);
+        if constexpr (F16) asm volatile(M16P_F16_FWD_TRAIN_ASM : [c00] "+v"(c[0][0]), [c01] "+v"(c[0][1]), M16P_ACC_OUT(c) : M16P_IN_CARRY(a) : "memory", "scc", M16P_KLOOP_CLOBBERS);
+        else asm volatile(M16P_BF16_FWD_TRAIN_ASM : [c00] "+v"(c[0][0]), [c01] "+v"(c[0][1]), M16P_ACC_OUT(c) : M16P_IN_CARRY(a) : "memory", "scc", M16P_KLOOP_CLOBBERS);
+    } else {
+        if constexpr (F16) asm volatile(M16P_F16_FWD_INFER_ASM : [c00] "+v"(c[0][0]), [c01] "+v"(c[0][1]), M16P_ACC_OUT(c) : M16P_IN(a) : "memory", "scc", M16P_KLOOP_CLOBBERS);
+        else asm volatile(M16P_BF16_FWD_INFER_ASM : [c00] "+v"(c[0][0]), [c01] "+v"(c[0][1]), M16P_ACC_OUT(c) : M16P_IN(a) : "memory", "scc", M16P_KLOOP_CLOBBERS);
+    }
+}
+template <typename T>
+__device__ __forceinline__ void kloop16p_bwd(const Kloop16sAddr& a, const T* w, T* st, int sel, f32x16 (&c)[4][2]) {
+    w = uniform_ptr(w); st = uniform_ptr(st);
+    sel = __builtin_amdgcn_readfirstlane(sel);
+    constexpr bool F16 = sizeof(T) == 2 && UsesScale<T>::v;
+    if constexpr (F16) asm volatile(M16P_F16_BWD_DATA_ASM : [c00] "=&v"(c[0][0]), [c01] "=&v"(c[0][1]), M16P_ACC_OUT(c) : M16P_IN_CARRY(a) : "memory", "scc", M16P_KLOOP_CLOBBERS);
+    else asm volatile(M16P_BF16_BWD_DATA_ASM : [c00] "=&v"(c[0][0]), [c01] "=&v"(c[0][1]), M16P_ACC_OUT(c) : M16P_IN_CARRY(a) : "memory", "scc", M16P_KLOOP_CLOBBERS);
+}
+
 // ------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------
@@ -874,6 +915,84 @@ __global__ __launch_bounds__(M16_THREADS, 2) void gp_mlp16_fwd_split_infer_kerne
     mlp16s_fwd_hand_body<false>(p, out, nullptr, nullptr, nullptr);
 }
 
+// The same for the plain 16-bit kernels (fp16 / bf16 operands, 128-row workgroups, >= 65536 rows, input width 112): bit-identical
+// to mlp16_fwd_body<T, 4>.
+template <typename T, bool TRAIN>
+__device__ __forceinline__ void mlp16p_fwd_hand_body(Mlp16Dev p, float* __restrict__ out, T* __restrict__ saved_xT, T* __restrict__ saved_hT,
+                                                     uint32_t* __restrict__ masks) {
+    constexpr int ROWS = 128, WS = M16_W;
+    typedef typename Vec4<T>::type V4;
+    typedef __attribute__((address_space(3))) V4 lds_v4;
+    __shared__ __attribute__((aligned(1024))) T smem[ROWS * WS];       // one tile, updated in place
+    const int tid = threadIdx.x, lane_k = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const long row0 = (long)blockIdx.x * ROWS;
+    const long rows_pad = (p.rows + 63) & ~63L;
+    build_input16<T, ROWS>(smem, p, row0, tid);
+    __syncthreads();
+    if constexpr (TRAIN)
+        store_tile_T<T, ROWS, WS>(smem, saved_xT + (size_t)blockIdx.x * p.in_pad * ROWS, p.in_pad, p.in_pad, row0, p.rows, rows_pad, wave, lane_k);
+    const size_t layer_elems = t16_elems(M16_W, p.rows);
+    const int bad_row = row0 + ROWS > p.rows ? (int)(p.rows - row0) : ROWS;
+    for (int l = 0; l < 4; ++l) {
+        int lane = lane_k;                  // (per-lane addresses recomputed per layer: see mlp16s_fwd_hand_body)
+        asm volatile("" : "+v"(lane));
+        const int half = lane >> 5, j = lane & 31;
+        f32x16 c[4][2];
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 bv = *(const float4*)(p.b[l] + (2 * wave + nt) * 32 + 8 * g + 4 * half);
+                c[0][nt][4 * g + 0] = bv.x; c[0][nt][4 * g + 1] = bv.y; c[0][nt][4 * g + 2] = bv.z; c[0][nt][4 * g + 3] = bv.w;
+            }
+        {
+            const Kloop16sAddr ka = kloop16p_addr(smem, wave, lane);
+            T* st = TRAIN ? saved_hT + (size_t)(l > 0 ? l - 1 : 0) * layer_elems + (size_t)blockIdx.x * M16_W * ROWS + wave * (2 * M16_W * T16_BLK) : nullptr;
+            kloop16p_fwd<T, TRAIN>(ka, (const T*)p.w[l] + wave * 1024, st, l == 0, c);
+        }
+        __syncthreads();
+        const uint32_t ebase = (uint32_t)(uintptr_t)smem + 2 * a16_idx<WS>(j, 64 * wave + 4 * half);
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) {
+            const long grow = row0 + rt * 32 + j;
+            uint32_t mbits = 0;
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = relu_push(c[rt][nt][4 * g + e], mbits);
+                    *(lds_v4*)(uintptr_t)((ebase ^ (uint32_t)(64 * nt + 16 * g)) + rt * (32 * WS * 2)) = pack4(v[0], v[1], v[2], v[3], T());
+                }
+            if (masks && grow < p.rows) masks[relu_mask_idx(l, wave, grow, half, p.rows)] = mbits;
+        }
+        __syncthreads();
+        if constexpr (TRAIN) {
+            if (bad_row < ROWS) {           // last workgroup only: rows beyond the input are stored as zeros
+                typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+                for (int e = tid; e < (ROWS - bad_row) * (WS * 2 / 16); e += M16_THREADS) ((u4*)(smem + (size_t)bad_row * WS))[e] = u4{0u, 0u, 0u, 0u};
+                __syncthreads();
+            }
+            if (l == 3) store_tile_T<T, ROWS, WS>(smem, saved_hT + 3 * layer_elems + (size_t)blockIdx.x * M16_W * ROWS, M16_W, M16_W, row0, p.rows, rows_pad, wave, lane);
+        }
+    }
+    mlp16_output_layer<T, 4, false>(p, out, smem, smem, row0, tid);
+}
+__global__ __launch_bounds__(M16_THREADS, 2) void gp_mlp16_fwd4_f16_train_kernel(Mlp16Dev p, float* out, void* sx, void* sh, uint32_t* masks) {
+    mlp16p_fwd_hand_body<_Float16, true>(p, out, (_Float16*)sx, (_Float16*)sh, masks);
+}
+__global__ __launch_bounds__(M16_THREADS, 2) void gp_mlp16_fwd4_f16_infer_kernel(Mlp16Dev p, float* out, void* sx, void* sh, uint32_t* masks) {
+    mlp16p_fwd_hand_body<_Float16, false>(p, out, nullptr, nullptr, nullptr);
+}
+__global__ __launch_bounds__(M16_THREADS, 2) void gp_mlp16_fwd4_bf16_train_kernel(Mlp16Dev p, float* out, void* sx, void* sh, uint32_t* masks) {
+    mlp16p_fwd_hand_body<__bf16, true>(p, out, (__bf16*)sx, (__bf16*)sh, masks);
+}
+__global__ __launch_bounds__(M16_THREADS, 2) void gp_mlp16_fwd4_bf16_infer_kernel(Mlp16Dev p, float* out, void* sx, void* sh, uint32_t* masks) {
+    mlp16p_fwd_hand_body<__bf16, false>(p, out, nullptr, nullptr, nullptr);
+}
+
 // ------------------------------------------------------------------------------------------------
 // backward, data chain.  wt[l] = TRANSPOSED 16-bit weights: wt[4]: [256][16] (k >= out_dim zero),
 // wt[1..3]: [256][256] (= W_l^T), wt[0]: [in_pad][256] (= W_0^T, rows >= in_dim zero).
@@ -1153,6 +1272,88 @@ __device__ __forceinline__ void mlp16s_bwd_data_hand_body(Mlp16Dev p, const uint
 __global__ __launch_bounds__(M16_THREADS, 2) void gp_mlp16_bwd_data_split_hand_kernel(Mlp16Dev p, const uint32_t* masks, const float* dL_dout,
                                                                                        void* dzT, float* dfeature, float* dxyz, const uint32_t* absmax_bits) {
     mlp16s_bwd_data_hand_body(p, masks, dL_dout, (_Float16*)dzT, dfeature, dxyz, absmax_bits);
+}
+
+// ... and the plain 16-bit data backward (128-row workgroups): bit-identical to mlp16_bwd_data_body<T, 4>.
+template <typename T>
+__device__ __forceinline__ void mlp16p_bwd_data_hand_body(Mlp16Dev p, const uint32_t* __restrict__ masks, const float* __restrict__ dL_dout,
+                                                          T* __restrict__ dzT, float* __restrict__ dfeature, float* __restrict__ dxyz,
+                                                          const uint32_t* __restrict__ absmax_bits) {
+    constexpr int ROWS = 128, WS = M16_W;
+    typedef typename Vec4<T>::type V4;
+    typedef __attribute__((address_space(3))) V4 lds_v4;
+    __shared__ __attribute__((aligned(1024))) T smem[ROWS * WS];
+    const int tid = threadIdx.x, lane_k = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const long row0 = (long)blockIdx.x * ROWS;
+    const long rows_pad = (p.rows + 63) & ~63L;
+    const float S = UsesScale<T>::v ? grad_scale_from(absmax_bits) : 1.f;
+    {
+        constexpr int DU = 16 * ROWS / M16_THREADS;
+        float dv[DU];
+#pragma unroll
+        for (int u = 0; u < DU; ++u) {
+            const int e = tid + M16_THREADS * u, r = e / 16, f = e % 16;
+            const long row = row0 + r;
+            const bool ok = f < p.out_dim && row < p.rows;
+            dv[u] = dL_dout[ok ? row * p.out_dim + f : 0];
+            if (!ok) dv[u] = 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < DU; ++u) {
+            const int e = tid + M16_THREADS * u, r = e / 16, f = e % 16;
+            smem[a16_idx(r, f)] = (T)(dv[u] * S);
+        }
+    }
+    __syncthreads();
+    const size_t layer_elems = t16_elems(M16_W, p.rows);
+    for (int l = 4; l >= 1; --l) {
+        int lane = lane_k;
+        asm volatile("" : "+v"(lane));
+        const int half = lane >> 5, j = lane & 31;
+        uint32_t mreg[4];
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) {
+            const long grow = row0 + rt * 32 + j;
+            mreg[rt] = masks[relu_mask_idx(l - 1, wave, grow < p.rows ? grow : p.rows - 1, half, p.rows)];
+        }
+        f32x16 c[4][2];
+        {
+            const Kloop16sAddr ka = kloop16p_addr(smem, wave, lane);
+            T* st = dzT + (size_t)(l < 4 ? l : 0) * layer_elems + (size_t)blockIdx.x * M16_W * ROWS + wave * (2 * M16_W * T16_BLK);
+            kloop16p_bwd<T>(ka, (const T*)p.w[l] + wave * 1024, st, l == 4, c);
+        }
+        __syncthreads();
+        const uint32_t ebase = (uint32_t)(uintptr_t)smem + 2 * a16_idx<WS>(j, 64 * wave + 4 * half);
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) {
+            const uint32_t m = row0 + rt * 32 + j < p.rows ? mreg[rt] : 0u;
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        uint32_t keep;
+                        asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(keep) : "v"(m), "n"(relu_mask_pos(nt, g, e)));
+                        v[e] = __uint_as_float(__float_as_uint(c[rt][nt][4 * g + e]) & keep);
+                    }
+                    *(lds_v4*)(uintptr_t)((ebase ^ (uint32_t)(64 * nt + 16 * g)) + rt * (32 * WS * 2)) = pack4(v[0], v[1], v[2], v[3], T());
+                }
+        }
+        __syncthreads();
+        if (l == 1) store_tile_T<T, ROWS, WS>(smem, dzT + (size_t)blockIdx.x * M16_W * ROWS, M16_W, M16_W, row0, p.rows, rows_pad, wave, lane);
+    }
+    mlp16_input_grad<T, 4, false>(p, smem, smem, dfeature, dxyz, S, row0, tid);
+}
+__global__ __launch_bounds__(M16_THREADS, 2) void gp_mlp16_bwd_data4_f16_hand_kernel(Mlp16Dev p, const uint32_t* masks, const float* dL_dout,
+                                                                                      void* dzT, float* dfeature, float* dxyz, const uint32_t* absmax_bits) {
+    mlp16p_bwd_data_hand_body<_Float16>(p, masks, dL_dout, (_Float16*)dzT, dfeature, dxyz, absmax_bits);
+}
+__global__ __launch_bounds__(M16_THREADS, 2) void gp_mlp16_bwd_data4_bf16_hand_kernel(Mlp16Dev p, const uint32_t* masks, const float* dL_dout,
+                                                                                       void* dzT, float* dfeature, float* dxyz, const uint32_t* absmax_bits) {
+    mlp16p_bwd_data_hand_body<__bf16>(p, masks, dL_dout, (__bf16*)dzT, dfeature, dxyz, absmax_bits);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1596,7 +1797,12 @@ extern "C" int gp_mlp16_forward(const gp_mlp16_params* p, const gp_mlp_input* x,
         else hipLaunchKernelGGL(gp_mlp16_fwd_split_kernel, dim3(gp_blocks((size_t)m.rows, M16_ROWS)), dim3(M16_THREADS), dyn, s, m, out, saved_xT, saved_hT, masks);
     } else if (m.rows >= GP_MLP16_BIG_ROWS) {        // 128 rows per workgroup
         const dim3 grid(gp_blocks((size_t)m.rows, 128));
-        if (p->dtype == GP_DTYPE_F16) hipLaunchKernelGGL(gp_mlp16_fwd4_f16_kernel, grid, dim3(M16_THREADS), 0, s, m, out, saved_xT, saved_hT, masks);
+        const bool f16 = p->dtype == GP_DTYPE_F16;
+        const bool hand = m.in_pad == 112 && gp_debug_get(9) == 0;        // (any gp_debug_option(9, bits): the compiler's loops, for A/B and ablation)
+        const bool train = saved_xT && saved_hT && masks;
+        if (hand && train) hipLaunchKernelGGL(f16 ? gp_mlp16_fwd4_f16_train_kernel : gp_mlp16_fwd4_bf16_train_kernel, grid, dim3(M16_THREADS), 0, s, m, out, saved_xT, saved_hT, masks);
+        else if (hand && !saved_xT && !saved_hT && !masks) hipLaunchKernelGGL(f16 ? gp_mlp16_fwd4_f16_infer_kernel : gp_mlp16_fwd4_bf16_infer_kernel, grid, dim3(M16_THREADS), 0, s, m, out, saved_xT, saved_hT, masks);
+        else if (f16) hipLaunchKernelGGL(gp_mlp16_fwd4_f16_kernel, grid, dim3(M16_THREADS), 0, s, m, out, saved_xT, saved_hT, masks);
         else hipLaunchKernelGGL(gp_mlp16_fwd4_bf16_kernel, grid, dim3(M16_THREADS), 0, s, m, out, saved_xT, saved_hT, masks);
     } else {
         const dim3 grid(gp_blocks((size_t)m.rows, M16_ROWS));
@@ -1639,10 +1845,12 @@ extern "C" int gp_mlp16_backward(const gp_mlp16_params* p /* w16 = TRANSPOSED co
             else hipLaunchKernelGGL(gp_mlp16_bwd_data_split_hand_kernel, dim3(gp_blocks((size_t)m.rows, M16_ROWS)), dim3(M16_THREADS), 0, s, m, masks, dL_dout, (void*)dz, dL_dfeature, dL_dxyz, absmax);
             hipLaunchKernelGGL(gp_mlp16_pack_dout_split_kernel, dim3(gp_blocks((size_t)((m.rows + 63) & ~63L), 256)), dim3(256), 0, s, dL_dout, m.out_dim, m.rows, (_Float16*)dout16, absmax);
         } else if (f16) {
-            hipLaunchKernelGGL(big_rows ? gp_mlp16_bwd_data4_f16_kernel : gp_mlp16_bwd_data_f16_kernel, grid, dim3(M16_THREADS), 0, s, m, masks, dL_dout, (void*)dz, dL_dfeature, dL_dxyz, absmax);
+            const bool hand = big_rows && gp_debug_get(9) == 0;
+            hipLaunchKernelGGL(hand ? gp_mlp16_bwd_data4_f16_hand_kernel : big_rows ? gp_mlp16_bwd_data4_f16_kernel : gp_mlp16_bwd_data_f16_kernel, grid, dim3(M16_THREADS), 0, s, m, masks, dL_dout, (void*)dz, dL_dfeature, dL_dxyz, absmax);
             hipLaunchKernelGGL((gp_mlp16_pack_dout_kernel<_Float16>), dim3(gp_blocks((size_t)((m.rows + 63) & ~63L), 256)), dim3(256), 0, s, dL_dout, m.out_dim, m.rows, (_Float16*)dout16, absmax);
         } else {
-            hipLaunchKernelGGL(big_rows ? gp_mlp16_bwd_data4_bf16_kernel : gp_mlp16_bwd_data_bf16_kernel, grid, dim3(M16_THREADS), 0, s, m, masks, dL_dout, (void*)dz, dL_dfeature, dL_dxyz, absmax);
+            const bool hand = big_rows && gp_debug_get(9) == 0;
+            hipLaunchKernelGGL(hand ? gp_mlp16_bwd_data4_bf16_hand_kernel : big_rows ? gp_mlp16_bwd_data4_bf16_kernel : gp_mlp16_bwd_data_bf16_kernel, grid, dim3(M16_THREADS), 0, s, m, masks, dL_dout, (void*)dz, dL_dfeature, dL_dxyz, absmax);
             hipLaunchKernelGGL((gp_mlp16_pack_dout_kernel<__bf16>), dim3(gp_blocks((size_t)((m.rows + 63) & ~63L), 256)), dim3(256), 0, s, dL_dout, m.out_dim, m.rows, (__bf16*)dout16, absmax);
         }
         GP_LAUNCH_CHECK();

@@ -226,6 +226,110 @@ def gen_split(paths, init, depth=3):
     return e.text(), p
 
 
+def gen_plain_path(e, p, nks, carry, init, depth, mn):
+    """One product (nks k-steps) of the plain 16-bit form (fp16 / bf16 operands, `mn` = the MFMA mnemonic) of a 128-row workgroup: RT = 4
+    row tiles x 2 feature tiles per wave = 8 accumulators c<rt><nt>, 8 MFMAs per k-step from TWO weight fragments (1 KB each) and FOUR
+    activation fragments.  Carried store: wave w owns row blocks 2 w and 2 w + 1; k-step g writes features 32 (g & 7) .. + 31 of row
+    block 2 w + (g >> 3) -- the byte offset in the wave's part of the saved tensor is again g KB.
+    init = "bias": c00 / c01 hold the biases on entry and row tiles 1 .. 3 take them as the addend of their first MFMA."""
+    KST = 8192
+    A_OFF = [0, 16384, 32768, 49152]
+
+    def load_b(ks):
+        if ks == 0:
+            off = "%[voff]"
+        else:
+            e.ins(f"v_add_u32 {vr(p.vw)}, {ks * KST}, %[voff]")
+            off = vr(p.vw)
+        for q in range(2):
+            e.ins(f"global_load_dwordx4 {p.b(ks, q)}, {off}, %[swh]" + (" offset:1024" if q else ""))
+            e.vm.issue(("B", ks))
+
+    def read_a(ks, qs):
+        if qs[0] == 0:
+            if ks == 0:
+                e.ins(f"v_mov_b32 {vr(p.va)}, %[abase]")
+            else:
+                e.ins(f"v_xor_b32 {vr(p.va)}, {ks * 32}, %[abase]")
+        for q in qs:
+            e.ins(f"ds_read_b128 {p.a(ks, q)}, {vr(p.va)}" + (f" offset:{A_OFF[q]}" if A_OFF[q] else ""))
+            e.lgkm.issue(("A", ks, q))
+
+    def gather(g, ps):                      # (see gen_split_path: the LDS transpose read; rows are 512 bytes here)
+        t = vr(p.t0 if ps == 0 else p.t1)
+        lit = 64 * ((g & 7) ^ ps)
+        if lit:
+            e.ins(f"v_xor_b32 {t}, {lit}, %[sbt]")
+            src = t
+        else:
+            src = "%[sbt]"
+        off = 2048 * ps + 8192 * (g >> 3)
+        e.ins(f"ds_read_b64_tr_b16 {vr(p.ST + 2 * ps, 2)}, {src}" + (f" offset:{off}" if off else ""))
+        e.lgkm.issue(("G", g))
+
+    def store(g):
+        e.need_lgkm(("G", g))
+        if g == 0:
+            off = "%[vost]"
+        else:
+            e.ins(f"v_add_u32 {vr(p.vw)}, {g * 1024}, %[vost]")
+            off = vr(p.vw)
+        e.ins(f"global_store_dwordx4 {off}, {vr(p.ST, 4)}, %[sst]")
+        e.vm.issue(("S", g))
+
+    def mfma(acc, ks, bq, aq, src=None):
+        e.need_vm(("B", ks))
+        e.need_lgkm(("A", ks, aq))
+        e.ins(f"{mn} %[{acc}], {p.b(ks, bq)}, {p.a(ks, aq)}, {src if src is not None else '%[' + acc + ']'}")
+
+    for ks in range(min(depth, nks)):
+        load_b(ks)
+    read_a(0, [0, 1, 2, 3])
+    for ks in range(nks):
+        order = [0, 1, 2, 3]
+        if ks == 0 and init == "bias":
+            order = [1, 2, 3, 0]            # row tile 0 last: the others read the biases out of its accumulators
+        seq = []
+        for rt in order:
+            for nt in range(2):
+                src = None
+                if ks == 0:
+                    src = "0" if init == "zero" else (f"%[c0{nt}]" if rt else None)
+                seq.append((f"c{rt}{nt}", nt, rt, src))
+        for m, (acc, bq, aq, src) in enumerate(seq):
+            mfma(acc, ks, bq, aq, src)
+            if m == 0 and ks + depth < nks:
+                load_b(ks + depth)
+            if carry and m in (1, 2):
+                gather(ks, m - 1)
+            if m == 3 and ks + 1 < nks:
+                read_a(ks + 1, [0, 1])
+            if m == 4 and ks + 1 < nks:
+                read_a(ks + 1, [2, 3])
+            if carry and m == 6:
+                store(ks)
+    assert not e.lgkm.q, e.lgkm.q
+    e.vm.q = []
+
+
+def gen_plain(paths, init, mn, depth=5):
+    """The plain 16-bit statement (see gen_split for the two-path form).  Operands: c00 .. c31 (f32x16), abase, voff, swh, sel, and for a
+    carrying path sbt, vost, sst."""
+    p = Plan(256 - (8 * (depth + 1) + 32 + 8), depth, 2, 4, any(c for _, c in paths))
+    e = Emitter()
+    if len(paths) > 1:
+        e.ins("s_cmp_eq_u32 %[sel], 0")
+        e.ins("s_cbranch_scc0 71f")
+    gen_plain_path(e, p, paths[0][0], paths[0][1], init, depth, mn)
+    if len(paths) > 1:
+        e.ins("s_branch 72f")
+        e.lines.append("71:")
+        gen_plain_path(e, p, paths[1][0], paths[1][1], init, depth, mn)
+        e.lines.append("72:")
+    e.ins("s_nop 15")
+    return e.text(), p
+
+
 HEADER = """// GENERATED by tools/gen_mlp16_kloop.py -- do not edit.  The hand-scheduled k-loops of the large-row 16-bit MLP kernels:
 // one inline-asm statement per (layer product, variant); register plan, counted waits and the carried saved-tensor stores are
 // described in the generator.
@@ -240,6 +344,12 @@ def main():
         text, plan = gen_split(paths, init)
         parts.append(f"#define {name}_ASM \\\n" + text.replace("\n", " \\\n").rstrip(" \\\n") + "\n")
     parts.append(f"#define M16S_KLOOP_CLOBBERS {plan.clobbers()}\n")
+    for tag, mn in (("F16", "v_mfma_f32_32x32x16_f16"), ("BF16", "v_mfma_f32_32x32x16_bf16")):
+        for name, paths, init in ((f"M16P_{tag}_FWD_TRAIN", [(16, True), (7, False)], "bias"), (f"M16P_{tag}_FWD_INFER", [(16, False), (7, False)], "bias"),
+                                  (f"M16P_{tag}_BWD_DATA", [(16, True), (1, False)], "zero")):
+            text, plan = gen_plain(paths, init, mn)
+            parts.append(f"#define {name}_ASM \\\n" + text.replace("\n", " \\\n").rstrip(" \\\n") + "\n")
+    parts.append(f"#define M16P_KLOOP_CLOBBERS {plan.clobbers()}\n")
     with open(OUT, "w") as f:
         f.write("\n".join(parts))
     print("wrote", OUT)
