@@ -1489,7 +1489,9 @@ struct W16Jobs { W16Job j[9]; };
 // pointers); shared = several jobs of one launch add into the same dw
 struct W16Shape { int nf_z, nf_h, n_out, n_in, lddw, ks_z, ks_h, shared, xcd_terms, n_jobs, n_slabs; };
 #define W16_THREADS 512
+#ifndef W16_DEPTH
 #define W16_DEPTH 4
+#endif
 #define W16_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
 template <typename V8>
