@@ -352,6 +352,9 @@ def main():
                     help="N > 1, sharded exchange: keep the SH regions' Adam + all-gather on the compute stream (A/B of TrainStep._chain_sh)")
     ap.add_argument("--replicated-adam", action="store_true",
                     help="N > 1: all-reduce + replicated Adam (round 1) instead of reduce-scatter -> sharded Adam -> all-gather")
+    ap.add_argument("--factorised-sh", action="store_true",
+                    help="N > 1: replicated Adam with the SH gradients exchanged as (dL/dRGB, view direction) factors -- one all-gather of 24 B per "
+                         "Gaussian and rank instead of the 192-B gradient's all-reduce (implies --replicated-adam; DESIGN.md section 6)")
     ap.add_argument("--time-waits", action="store_true",
                     help="N > 1, sharded exchange: bracket every wait of the compute stream for a collective with events and report "
                          "config.exposed_wait_ms_per_step (adds a few stream bubbles: an A/B aid, not the headline run)")
@@ -385,7 +388,8 @@ def main():
     # learning rates of the reference at iteration 50000 (position lr has decayed to position_lr_final,
     # [REF arguments/__init__.py:75-76, scene/gaussian_model.py:474-491])
     ts = TrainStep(pc, cams, gts, args.iteration, lrs=dict(xyz=1.6e-6 * 5.0), speculative=not args.exact_binning,
-                   sharded=False if args.replicated_adam else None, chain_sh=not args.no_chain_sh, fused=not args.no_fused)
+                   sharded=False if (args.replicated_adam or args.factorised_sh) else None, chain_sh=not args.no_chain_sh, fused=not args.no_fused,
+                   factorised_sh=args.factorised_sh)
     ts.early_adam = bool(args.early_adam)
 
     def one_step(i):
@@ -636,13 +640,19 @@ def main():
                        "ranks_seen_by_rccl": dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1,
                        "self_launched": os.environ.get("GP_BENCH_SELF_LAUNCHED") == "1",
                        "gradient_exchange": None if not ts.reducer.enabled else (
-                           "all-reduce(SUM) of the flat gradient bucket + replicated Adam" if not ts.sharded else
+                           ("all-reduce(SUM) of the flat gradient bucket + replicated Adam" if not getattr(ts, "factorised_sh", False) else
+                            "replicated Adam; SH gradients as (dL/dRGB, view direction) factors: one all-gather of 24 B per Gaussian and rank, summed "
+                            "over the views in rank order on every rank (gp_sh_factor_gradient); all-reduce(SUM) of everything else") if not ts.sharded else
                            "reduce-scatter(SUM) per region -> Adam on 1/N of every region -> asynchronous all-gather of the parameters"
                            + ("; SH regions: Adam + all-gather on a side stream from the moment their reduce-scatter lands, awaited by the "
                               "next forward in front of its SH->RGB kernel only" if getattr(ts, "chain_sh", False) else "")
                            + (" [ONE-rank group, GP_DIST_FORCE_SINGLE: the code path, not a scaling number]" if world == 1 else "")),
                        "xgmi_bytes_sent_per_rank_per_step": None if world == 1 else (
-                           getattr(ts.reducer, "bytes_sent_per_step", None) or int(2 * 4 * ts.bucket.flat.numel() * (world - 1) / world)),
+                           getattr(ts.reducer, "bytes_sent_per_step", None) or
+                           (int(2 * 4 * ts.bucket.flat.numel() * (world - 1) / world) if not getattr(ts, "factorised_sh", False) else
+                            # the all-reduce of everything but the SH tensors + the factor all-gather (every rank sends its 24 B per Gaussian to world - 1 peers)
+                            int(2 * 4 * (ts.bucket.flat.numel() - pc._features_dc.numel() - pc._features_rest.numel()) * (world - 1) / world)
+                            + 24 * int(pc._features_dc.shape[0]) * (world - 1))),
                        "exposed_wait_ms_per_step": waits,          # (--time-waits: compute-stream time inside waits for collectives, rank 0)
                        "step_driver": (f"one library call per step (gp_train_step_run): {getattr(ts, 'fused_steps', 0)} of the steps since the set-up"
                                        + ("; the per-Gaussian tensors' Adam launch runs on a second stream beside the keypoint MLP's backward, so the "

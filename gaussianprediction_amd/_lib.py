@@ -140,7 +140,7 @@ EXPORTS = [
     "gp_hashgrid_table_entries", "gp_hashgrid_forward", "gp_hashgrid_backward", "gp_knn_keypoints",
     "gp_weights_forward", "gp_weights_backward", "gp_l1_mean_forward", "gp_l1_mean_backward", "gp_loss_l1_ssim_finalize_reg", "gp_loss_l1_ssim_backward_reg", "gp_furthest_point_sampling", "gp_knn3_mean_dist2",
     "gp_microbench_copy", "gp_microbench_read", "gp_microbench_mfma", "gp_microbench_valu", "gp_microbench_gather",
-    "gp_debug_option", "gp_debug_counters", "gp_train_step_run",
+    "gp_debug_option", "gp_debug_counters", "gp_train_step_run", "gp_sh_factor_gradient",
     "gp_mlp_input_forward", "gp_mlp_input_backward", "gp_linear_forward", "gp_linear_backward", "gp_softmax_forward", "gp_softmax_backward",
     "gp_last_error", "gp_version", "gp_abi_version",
 ]

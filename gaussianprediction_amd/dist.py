@@ -324,6 +324,45 @@ class ShardedExchange:
         return ev
 
 
+SH_C0 = 0.28209479177387814
+
+
+def sh_basis(dirs: torch.Tensor, degree: int) -> torch.Tensor:
+    """Y_k(dir), k < (degree + 1)^2, as [n, (degree + 1)^2]: the real SH basis of [REF utils/sh_utils.py:57-112] (the statement of what
+    gp_sh_factor_gradient evaluates; used by the tests and by the CPU seam of the factorised exchange)."""
+    x, y, z = dirs[:, 0], dirs[:, 1], dirs[:, 2]
+    xx, yy, zz = x * x, y * y, z * z
+    c1, c2, c3 = 0.4886025119029199, (1.0925484305920792, -1.0925484305920792, 0.31539156525252005, -1.0925484305920792, 0.5462742152960396), \
+        (-0.5900435899266435, 2.890611442640554, -0.4570457994644658, 0.3731763325901154, -0.4570457994644658, 1.445305721320277, -0.5900435899266435)
+    Y = [torch.full_like(x, SH_C0), -c1 * y, c1 * z, -c1 * x,
+         c2[0] * (x * y), c2[1] * (y * z), c2[2] * (2 * zz - xx - yy), c2[3] * (x * z), c2[4] * (xx - yy),
+         c3[0] * y * (3 * xx - yy), c3[1] * (x * y) * z, c3[2] * y * (4 * zz - xx - yy), c3[3] * z * (2 * zz - 3 * xx - 3 * yy),
+         c3[4] * x * (4 * zz - xx - yy), c3[5] * z * (xx - yy), c3[6] * x * (xx - 3 * yy)]
+    return torch.stack(Y[:(degree + 1) ** 2], dim=1)
+
+
+# CPU tensors (the gloo tests) have no kernel: the tests install a torch restatement here (tests/host_checkers.py); the product itself
+# never falls back -- without the seam a CPU call raises
+host_sh_factor_gradient = None
+
+
+def sh_factor_gradient(factors: torch.Tensor, degree: int, g_dc: torch.Tensor, g_rest: torch.Tensor):
+    """g_dc [n,1,3] / g_rest [n,15,3] <- the sum over the views (dim 0 of `factors` [world, n, 6] = (dL/dRGB | unit view direction), in
+    order) of the rank-one SH gradients (gp_sh_factor_gradient)."""
+    world, n, _ = factors.shape
+    if factors.is_cuda:
+        import ctypes as C
+        from . import _lib
+        assert factors.is_contiguous() and g_dc.is_contiguous() and g_rest.is_contiguous() and factors.dtype == torch.float32
+        with _lib.on_device(factors.device):
+            _lib.check(_lib.lib().gp_sh_factor_gradient(C.c_int64(n), C.c_int32(world), _lib.ptr(factors), C.c_int32(int(degree)), _lib.ptr(g_dc),
+                                                        _lib.ptr(g_rest), _lib.stream_ptr(factors.device)), "gp_sh_factor_gradient")
+        return
+    if host_sh_factor_gradient is None:
+        raise RuntimeError("sh_factor_gradient: CPU tensors have no implementation (the HIP library is the only one)")
+    host_sh_factor_gradient(factors, degree, g_dc, g_rest)
+
+
 class OverlappedGradReducer:
     """SUM-all-reduce of the gradient bucket, overlapped with the rest of backward.
 
@@ -341,14 +380,21 @@ class OverlappedGradReducer:
         self.bucket, self.group = bucket, group
         self.handles = []
         self.enabled = active(group)
+        # FACTORISED SH exchange (set_factorised): the two SH tensors' gradients are not all-reduced; the ranks all-gather
+        # (dL/dRGB, view direction) per Gaussian instead and every rank forms the sum over the views itself
+        self._factor = None                     # (features_dc, features_rest, dirs_fn, degree_fn)
+        self._factor_pending = None             # (handle, gathered factors) of this step
+        self.factor_bytes_received_per_step = 0
         self.large = [p for p in bucket.params if p.numel() >= small_numel]
         self.small = [p for p in bucket.params if p.numel() < small_numel]
         self._fired = set()
         self._late = set()
         self._sink_cb = None
+        self._hooks = {}
         if self.enabled:
             from . import grad_sink
-            hooks = {id(p): self._make_hook(p) for p in self.large}
+            hooks = self._hooks
+            hooks.update({id(p): self._make_hook(p) for p in self.large})
             self._hook_handles = [p.register_post_accumulate_grad_hook(hooks[id(p)]) for p in self.large]
             # leaves whose gradient is written directly by a kernel (grad_sink) never run AccumulateGrad:
             # they announce completion through the sink registry instead
@@ -374,11 +420,47 @@ class OverlappedGradReducer:
         finish(), which runs after backward."""
         self._late = {id(p) for p in params}
 
+    def set_factorised(self, features_dc, features_rest, dirs_fn, degree_fn):
+        """Exchange the SH gradients in factorised form from now on (single-view steps only: a rank's gradient must be ONE view's).
+        `dirs_fn()` -> [n, 3] unit view directions of this rank's view (the ones the rasterizer evaluated the SH basis at),
+        `degree_fn()` -> the active SH degree.  Per Gaussian and step a rank receives 24 (world - 1) bytes instead of sending and
+        receiving 2 x 192 (world - 1) / world: 168 against 336 B at world 8 -- the price is that every rank keeps (as in this
+        replicated-optimizer path anyway) the full SH moments and streams them every step."""
+        self._factor = (features_dc, features_rest, dirs_fn, degree_fn)
+        for p in (features_dc, features_rest):          # (small test scenes: the two tensors must be hooked leaves, not part of the tail)
+            if any(q is p for q in self.small):
+                self.small = [q for q in self.small if q is not p]
+                self.large.append(p)
+                if self.enabled:
+                    self._hooks[id(p)] = self._make_hook(p)
+                    self._hook_handles.append(p.register_post_accumulate_grad_hook(self._hooks[id(p)]))
+
+    def _factor_ids(self):
+        return () if self._factor is None else (id(self._factor[0]), id(self._factor[1]))
+
+    def _start_factor_gather(self):
+        dc, rest, dirs_fn, _ = self._factor
+        world = dist.get_world_size(self.group)
+        n = dc.shape[0]
+        mine = torch.cat([dc.grad.reshape(n, 3) * (1.0 / SH_C0), dirs_fn().reshape(n, 3).to(dc.grad.dtype)], dim=1).contiguous()
+        out = torch.empty(world, n, 6, dtype=mine.dtype, device=mine.device)
+        if dist.get_backend(self.group) == "nccl":
+            h = dist.all_gather_into_tensor(out.view(-1), mine.view(-1), group=self.group, async_op=True)
+        else:
+            h = dist.all_gather([out[k] for k in range(world)], mine, group=self.group, async_op=True)
+        self._factor_pending = (h, out)
+        self.factor_bytes_received_per_step = 24 * n * (world - 1)
+
     def _make_hook(self, p):
         def hook(param):
             if not self.enabled or id(p) in self._fired or id(p) in self._late:
                 return
             self._fired.add(id(p))
+            fid = self._factor_ids()
+            if id(p) in fid:
+                if all(i in self._fired for i in fid) and self._factor_pending is None:
+                    self._start_factor_gather()          # both SH tensors' gradients are final (one kernel writes them)
+                return
             self.handles.append(dist.all_reduce(self.bucket.segment(p), op=dist.ReduceOp.SUM, group=self.group, async_op=True))
         return hook
 
@@ -386,6 +468,13 @@ class OverlappedGradReducer:
         """Call after loss.backward(): reduces what the hooks did not cover, waits for everything."""
         if not self.enabled:
             return
+        fid = self._factor_ids()
+        if fid and self._factor_pending is None:
+            if any(i in self._late for i in fid):
+                raise RuntimeError("factorised SH exchange: the SH gradients of this step have several producers (more than one view per step?)")
+            for i in fid:
+                self._fired.add(i)
+            self._start_factor_gather()            # (the hooks did not fire: e.g. nothing visible -- the collective still needs every rank)
         for p in self.large:                       # leaves that received no gradient this step (still zero)
             if id(p) not in self._fired:
                 self.handles.append(dist.all_reduce(self.bucket.segment(p), op=dist.ReduceOp.SUM, group=self.group, async_op=True))
@@ -403,6 +492,12 @@ class OverlappedGradReducer:
         for h in self.handles:
             h.wait()
         self.handles.clear()
+        if self._factor_pending is not None:       # the sum over the views, in rank order: identical on every rank
+            h, factors = self._factor_pending
+            h.wait()
+            dc, rest, _, degree_fn = self._factor
+            sh_factor_gradient(factors, int(degree_fn()), dc.grad, rest.grad)
+            self._factor_pending = None
         self._fired.clear()
 
 

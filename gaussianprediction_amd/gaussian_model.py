@@ -314,6 +314,7 @@ class GaussianModel(TrainingMixin, nn.Module):
         xyz_freq, time_freq = int(self.xyz_input_dim / 6), self.time_input_dim // 2
         if iteration < a.jointly_iteration:          # warm-up: static Gaussians
             s, o = Activations.apply(self._scaling, self._opacity, None, 0, 1.0)
+            self._last_xyz_t = self._xyz.detach()       # (what the view was rendered at: the factorised SH exchange's view directions)
             return self._xyz, self.get_rotation, s, o
         t_dev = t.to(self._xyz.device, torch.float32).reshape(-1)[:1]
         self.stage_transitions(iteration)

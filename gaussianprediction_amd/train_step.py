@@ -45,7 +45,7 @@ class TrainStep:
 
     def __init__(self, pc, cameras, gt_images, iteration, lambda_dssim=0.2, lrs=None, group=None, speculative=False,
                  overlap_sh_adam=False, batch=1, schedule=False, training_args=None, sharded=None, fuse_sh_adam=True, chain_sh=True,
-                 view_stats=None, fused=True):
+                 view_stats=None, fused=True, factorised_sh=False):
         """`fused`: take plain stage-3 steps through ONE call of the library (fused_step.FusedStage3 / gp_train_step_run) instead of
         the autograd graph -- same kernels, same results, a fraction of the host work; steps of any other shape use the graph.
         Buffers of the returned dict (`render`, `radii`, ...) are then the plan's own and are overwritten by the next step.
@@ -53,6 +53,10 @@ class TrainStep:
         (see _step); None = exactly while the reference's loop reads it (below densify_until_iter, and during keypoint growth)."""
         self.pc, self.cameras, self.gt, self.iteration = pc, cameras, gt_images, iteration
         self.view_stats = view_stats
+        # view-parallel, replicated optimizer only (sharded=False), one view per step: the SH gradients travel as (dL/dRGB, view direction)
+        # factors -- one all-gather of 24 B per Gaussian and rank -- instead of an all-reduce of 192 B (dist.OverlappedGradReducer.set_factorised)
+        self.factorised_sh = bool(factorised_sh)
+        self._view_center = None
         self.fused = bool(fused)
         self.early_adam = False                 # fused step: gp_step_update.adam_early_mask (measured slower, profiles/r05_early_adam_ab.txt)
         self._fused_plan = None
@@ -162,6 +166,10 @@ class TrainStep:
         else:
             self.reducer = OverlappedGradReducer(self.pc.bucket, self.group)
             self.pc._param_late_event = None
+            if self.factorised_sh and self.reducer.enabled:
+                if self.batch != 1:
+                    raise RuntimeError("factorised_sh needs one view per step and rank (batch=1): a rank's SH gradient must be ONE view's")
+                self.reducer.set_factorised(self.pc._features_dc, self.pc._features_rest, self._view_dirs, lambda: int(self.pc.active_sh_degree))
         if getattr(self, "overlap_sh_adam", False) and self._sink_cb is None:
             self._armed = False
             self._ev_bwd, self._ev_sh = torch.cuda.Event(), torch.cuda.Event()
@@ -376,6 +384,7 @@ class TrainStep:
                 t_view = self.times[v % len(self.cameras)]
                 if getattr(self, "_time_offset", None) is not None:
                     t_view = t_view + self._time_offset
+                self._view_center = cam.camera_center
                 pkg = render(cam, pc, self.pipe, self.bg, time=t_view, it=self.iteration, binning=binning)
                 losses.append(self.loss_of(pkg["render"], self.gt[v % len(self.gt)]))
                 pkgs.append(pkg)
@@ -455,6 +464,12 @@ class TrainStep:
         if h_vs is not None:
             h_vs.wait()                              # (the current stream waits; the host does not)
         return loss.detach(), pkg
+
+    def _view_dirs(self):
+        """Unit directions camera -> deformed Gaussian of the view this rank has just rendered: where the rasterizer evaluated the SH basis
+        (raster_kernels.hip sh_color: (p - campos) / |p - campos|)."""
+        d = self.pc._last_xyz_t - self._view_center.to(self.pc._last_xyz_t.dtype).reshape(1, 3)
+        return d / d.norm(dim=1, keepdim=True)
 
     def sync_params(self):
         """Wait for every outstanding parameter exchange (before anything outside step() / render() reads the parameters)."""

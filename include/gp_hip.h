@@ -573,12 +573,18 @@ int gp_debug_counters(uint64_t* out4);
 const char* gp_last_error(void);
 const char* gp_version(void);
 
+/* View-parallel training, factorised SH exchange (round 6; gaussianprediction_amd/dist.py): per view the SH gradient is
+ * rank one, dL/dSH[k][ch] = Y_k(dir) dL/dRGB[ch] [REF utils/sh_utils.py:57-112], so the ranks all-gather factors [world][n][6] =
+ * (dL/dRGB[3] | unit view direction[3]) -- 24 B per Gaussian and view instead of 192 B of gradient -- and this call forms the SUM over the
+ * views in rank order (identical on every rank): g_dc [n,3] and g_rest [n,15,3] are WRITTEN (coefficients beyond sh_degree: zero). */
+int gp_sh_factor_gradient(int64_t n, int32_t world, const float* factors, int32_t sh_degree, float* g_dc, float* g_rest, gp_stream_t stream);
+
 /* ABI number of this header.  It changes whenever a struct gains / loses a field, an entry point's signature changes or a
  * buffer-size macro (GP_LOSS_SUM_SLOTS) changes; a binding built against another number must refuse to run (the Python loader
  * does: gaussianprediction_amd/_lib.py).  History: 1 = rounds 1-2; 2 = round 3 (gp_raster_settings.sh_ready_event / visible,
  * gp_knn_keypoints' `order`, GP_LOSS_SUM_SLOTS per image size); 3 = round 4 (gp_abi_version itself); 4 = round 4 (gp_mlp_params.packed, gp_blend_args.knn_idx16, gp_knn_keypoints' signature,
  * gp_adam_step_multi_steps); 5 = round 5 (gp_train_step_run and its three structs);
- * 6 = round 6 (gp_mlp16_pack / gp_mlp16_packed_elems, gp_loss_l1_ssim_fused; the ReLU words gp_mlp16_forward hands to gp_mlp16_backward changed layout). */
+ * 6 = round 6 (gp_mlp16_pack / gp_mlp16_packed_elems, gp_loss_l1_ssim_fused, gp_sh_factor_gradient; the ReLU words gp_mlp16_forward hands to gp_mlp16_backward changed layout). */
 #define GP_ABI_VERSION 6
 int gp_abi_version(void);
 

@@ -44,6 +44,8 @@ def install():
     from gaussianprediction_amd.loss_ops import FusedAdam
     FusedAdam.host_step = staticmethod(adam_host_step)
     training.host_fps = fps_host
+    from gaussianprediction_amd import dist as gdist
+    gdist.host_sh_factor_gradient = sh_factor_gradient_host
 
 
 def torch_l1_ssim(image, gt, lambda_dssim=0.2):
@@ -170,3 +172,15 @@ class DenseRefTrainer:
         if "exp_avg" not in st:
             return torch.zeros_like(p), torch.zeros_like(p), 0
         return st["exp_avg"], st["exp_avg_sq"], int(float(st["step"]))
+
+
+def sh_factor_gradient_host(factors, degree, g_dc, g_rest):
+    """gp_sh_factor_gradient in torch ops (CPU tensors of the gloo tests): the sum over the views, in order, of Y_k(dir) x dL/dRGB."""
+    from gaussianprediction_amd.dist import sh_basis
+    world, n, _ = factors.shape
+    nc = (degree + 1) ** 2
+    acc = torch.zeros(n, 16, 3, dtype=factors.dtype)
+    for v in range(world):
+        acc[:, :nc] += sh_basis(factors[v, :, 3:6], degree).unsqueeze(2) * factors[v, :, 0:3].unsqueeze(1)
+    g_dc.copy_(acc[:, 0:1].reshape(g_dc.shape))
+    g_rest.copy_(acc[:, 1:].reshape(g_rest.shape))

@@ -617,3 +617,85 @@ def test_two_rank_capacity_mode_overflow_is_agreed_on_by_all_ranks(tmp_path):
     assert res["overflowing"][1]["redone"] > 0 and res["overflowing"][0]["redone"] == res["overflowing"][1]["redone"]
     assert any(f == 1 for f in res["overflowing"][0]["flags"] if f is not None)
     assert ov["steps"] == 14 and torch.isfinite(ov["xyz"]).all() and ov["losses"][-1] < ov["losses"][0]
+
+
+# ---- factorised SH exchange --------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("degree", [0, 1, 2, 3])
+def test_sh_factor_gradient_kernel_matches_the_torch_statement(degree):
+    """gp_sh_factor_gradient (sum over the views, in order, of Y_k(dir) x dL/dRGB) against the torch statement of the SH basis."""
+    import host_checkers
+    from gaussianprediction_amd.dist import sh_factor_gradient
+    g = torch.Generator().manual_seed(degree)
+    n, world = 1003, 3
+    f = torch.randn(world, n, 6, generator=g)
+    f[:, :, 3:6] /= f[:, :, 3:6].norm(dim=2, keepdim=True)
+    f[1, ::7, 0:3] = 0.0
+    want_dc, want_rest = torch.empty(n, 1, 3), torch.empty(n, 15, 3)
+    host_checkers.sh_factor_gradient_host(f, degree, want_dc, want_rest)
+    got_dc, got_rest = torch.full((n, 1, 3), float("nan"), device="cuda"), torch.full((n, 15, 3), float("nan"), device="cuda")
+    sh_factor_gradient(f.cuda(), degree, got_dc, got_rest)
+    torch.testing.assert_close(got_dc.cpu(), want_dc, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(got_rest.cpu(), want_rest, rtol=1e-5, atol=1e-6)
+    if degree < 3:
+        assert float(got_rest[:, (degree + 1) ** 2 - 1:].abs().max()) == 0.0          # coefficients beyond the degree: written as zeros
+
+
+def test_sh_factors_reproduce_the_rasterizer_backwards_sh_gradient():
+    """The factors a rank sends -- dL/dRGB = (features_dc gradient) / C0 and the unit direction camera -> deformed Gaussian -- rebuild
+    through gp_sh_factor_gradient the SH gradient the rasterizer backward itself wrote for that view (the basis, its signs and the
+    direction convention are the kernels' own [REF utils/sh_utils.py:57-112, gaussian_renderer/__init__.py:86-91])."""
+    from gaussianprediction_amd.dist import SH_C0, sh_factor_gradient
+    pc, cams, gts, *_ = build(n=3000)
+    pipe = SimpleNamespace(convert_SHs_python=False, compute_cov3D_python=False, debug=False)
+    pc.active_sh_degree = 3
+    pkg = render(cams[1], pc, pipe, torch.zeros(3, device="cuda"), time=torch.tensor([0.3], device="cuda"), it=50000)
+    (pkg["render"] * torch.randn_like(pkg["render"])).sum().backward()
+    g_dc, g_rest = pc._features_dc.grad.clone(), pc._features_rest.grad.clone()
+    assert float(g_rest.abs().max()) > 0
+    d = pc._last_xyz_t - cams[1].camera_center.reshape(1, 3)
+    f = torch.cat([g_dc.reshape(-1, 3) / SH_C0, d / d.norm(dim=1, keepdim=True)], dim=1).reshape(1, -1, 6).contiguous()
+    r_dc, r_rest = torch.empty_like(g_dc), torch.empty_like(g_rest)
+    sh_factor_gradient(f, 3, r_dc, r_rest)
+    torch.testing.assert_close(r_dc, g_dc, rtol=1e-5, atol=1e-7 * float(g_dc.abs().max()) + 1e-12)
+    assert float((r_rest - g_rest).norm() / g_rest.norm()) < 1e-5
+    assert float((r_rest - g_rest).abs().max()) < 1e-4 * float(g_rest.abs().max())
+
+
+def _rank_main_factor(rank, world, port, out_dir, backend, factorised):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch.distributed as dist
+    dev = rank if backend == "nccl" else 0
+    torch.cuda.set_device(dev)
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    pc, cams, gts, raw, rw, idx, args = build(n=3000, dev=f"cuda:{dev}")
+    ts = TrainStep(pc, cams, gts, 50000, sharded=False, factorised_sh=factorised)
+    assert type(ts.reducer).__name__ == "OverlappedGradReducer" and (ts.reducer._factor is not None) == factorised
+    for step in range(3):
+        ts.step(step * world + rank)
+    torch.cuda.synchronize()
+    torch.save({"params": {n: p.detach().cpu() for n, p in pc.named_parameters()},
+                "recv": getattr(ts.reducer, "factor_bytes_received_per_step", 0)}, os.path.join(out_dir, f"fx{int(factorised)}_{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_factorised_sh_exchange_equals_the_all_reduce(tmp_path):
+    """Three view-parallel steps with the SH gradients exchanged as factors (one all-gather of 24 B per Gaussian) leave both ranks with
+    bit-identical parameters, equal to the all-reduce path's (Adam with eps = 1e-15 moves an element whose gradient is rounding noise
+    by a full lr: the same allowance as the sharded-vs-replicated test)."""
+    import torch.multiprocessing as mp
+    backend = "nccl" if torch.cuda.device_count() >= 2 else "gloo"
+    for factorised in (False, True):
+        mp.spawn(_rank_main_factor, args=(2, _free_port(), str(tmp_path), backend, factorised), nprocs=2, join=True)
+    rep = [torch.load(os.path.join(tmp_path, f"fx0_{r}.pt")) for r in range(2)]
+    fac = [torch.load(os.path.join(tmp_path, f"fx1_{r}.pt")) for r in range(2)]
+    assert fac[0]["recv"] == 24 * 3000
+    for name in rep[0]["params"]:
+        assert torch.equal(fac[0]["params"][name], fac[1]["params"][name]), name          # replicas stay replicas
+        diff = (rep[0]["params"][name] - fac[0]["params"][name]).abs()
+        frac = float((diff > 1e-6).float().mean())
+        print(f"[factorised] {name}: fraction moved apart {frac:.4f}, max {float(diff.max()):.3e}")
+        assert frac < 5e-2 and float(diff.max()) < 0.05 * 3 + 1e-6, (name, frac, float(diff.max()))
