@@ -1276,26 +1276,39 @@ __device__ __forceinline__ void gp_composite_bwd_body(RasterDims d, const int2* 
                 const v2f dx0 = dxs[0], dx1 = dxs[1], dx2 = dxs[2], dx3 = dxs[3];
                 const uint32_t vpp = (uint32_t)(uintptr_t)&s_pp[row * (COLS / 2)][0];
                 unsigned long long sv, c0, c1, t0;
+// (-DGP_CB_LADDER_NOPS=0: the two scans WITHOUT their wait states -- wrong sums, timing only: the most that any re-pairing of the ladders
+// (two pixel pairs through one ladder, so that independent DPP operations take the place of the nops) could ever gain;
+// tools/probe/bwd_ladder_nops.sh, profiles/r06_bwd_ladder_nops.txt)
+#ifndef GP_CB_LADDER_NOPS
+#define GP_CB_LADDER_NOPS 1
+#endif
+#if GP_CB_LADDER_NOPS
+#define CB_NOP0 "s_nop 0\n\t"
+#define CB_NOP1 "s_nop 1\n\t"
+#else
+#define CB_NOP0 ""
+#define CB_NOP1 ""
+#endif
 #define CB_SCAN2(OPC, R0, R1)                                                                   \
-    "s_nop 1\n\t"                                                                               \
+    CB_NOP1                                                                                     \
     OPC " " R0 ", " R0 ", " R0 " row_shr:1 row_mask:0xf bank_mask:0xf\n\t"                       \
     OPC " " R1 ", " R1 ", " R1 " row_shr:1 row_mask:0xf bank_mask:0xf\n\t"                       \
-    "s_nop 0\n\t"                                                                               \
+    CB_NOP0                                                                                     \
     OPC " " R0 ", " R0 ", " R0 " row_shr:2 row_mask:0xf bank_mask:0xf\n\t"                       \
     OPC " " R1 ", " R1 ", " R1 " row_shr:2 row_mask:0xf bank_mask:0xf\n\t"                       \
-    "s_nop 0\n\t"                                                                               \
+    CB_NOP0                                                                                     \
     OPC " " R0 ", " R0 ", " R0 " row_shr:4 row_mask:0xf bank_mask:0xf\n\t"                       \
     OPC " " R1 ", " R1 ", " R1 " row_shr:4 row_mask:0xf bank_mask:0xf\n\t"                       \
-    "s_nop 0\n\t"                                                                               \
+    CB_NOP0                                                                                     \
     OPC " " R0 ", " R0 ", " R0 " row_shr:8 row_mask:0xf bank_mask:0xf\n\t"                       \
     OPC " " R1 ", " R1 ", " R1 " row_shr:8 row_mask:0xf bank_mask:0xf\n\t"                       \
-    "s_nop 0\n\t"                                                                               \
+    CB_NOP0                                                                                     \
     OPC " " R0 ", " R0 ", " R0 " row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"                    \
     OPC " " R1 ", " R1 ", " R1 " row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"                    \
-    "s_nop 0\n\t"                                                                               \
+    CB_NOP0                                                                                     \
     OPC " " R0 ", " R0 ", " R0 " row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"                    \
     OPC " " R1 ", " R1 ", " R1 " row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"                    \
-    "s_nop 1\n\t"
+    CB_NOP1
 #define CB_STEP(CP, O0, O1, O2, O3, DX)                                                                               \
     "ds_read_b64 v[64:65], %[vpp] offset:" #O0 "\n\t"                                                                \
     "ds_read_b128 v[66:69], %[vpp] offset:" #O1 "\n\t"                                                               \
