@@ -250,11 +250,16 @@ __global__ __launch_bounds__(256) void gp_l1_ssim_fused_kernel(const float* __re
                                                               double* __restrict__ sums, float* __restrict__ dimg,
                                                               const float* __restrict__ reg_x, long reg_n, float reg_scale_over_n,
                                                               float* __restrict__ reg_g) {
-    __shared__ float s_ab[2][LF][LFP];
-    __shared__ float s_h[2][LF][LP];
+    // The two maps of a filter round live INTERLEAVED in LDS (one 8-byte read = the operand pair of a packed operation; as two planes
+    // every pair cost two reads and two register moves: a quarter of the kernel's instructions).
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    __shared__ f2 s_ab[LF][LFP];                 // (img, gt) halos, 22 KB; later the derivative maps: pairs [42][43] + single [42][43]
+    __shared__ f2 s_h[LF][LP];                   // the horizontally filtered pair, 18 KB; later the backward's pair [42][33] + single [42][33]
     __shared__ float s_red[4];
-    float (*s_m)[LE][LP] = (float (*)[LE][LP]) & s_ab[0][0][0];          // [3][42][43] <= [2][52][53]
-    float (*s_h2)[LE][LHP] = (float (*)[LE][LHP]) & s_h[0][0][0];        // [3][42][33] <= [2][52][43]
+    f2 (*s_m01)[LP] = (f2 (*)[LP]) & s_ab[0][0];
+    float (*s_m2)[LP] = (float (*)[LP])((float*)&s_ab[0][0] + 2 * LE * LP);
+    f2 (*s_g01)[LHP] = (f2 (*)[LHP]) & s_h[0][0];
+    float (*s_g2)[LHP] = (float (*)[LHP])((float*)&s_h[0][0] + 2 * LE * LHP);
     static_assert(3 * LE * LP <= 2 * LF * LFP && 3 * LE * LHP <= 2 * LF * LP, "aliased planes must fit");
     const int tid = threadIdx.x;
     const int tx0 = blockIdx.x * LT, ty0 = blockIdx.y * LT, ch = blockIdx.z;
@@ -281,20 +286,19 @@ __global__ __launch_bounds__(256) void gp_l1_ssim_fused_kernel(const float* __re
             const int i = tid + 256 * u, y = i / LF, x = i - y * LF;
             const int gy = ty0 - 2 * LH + y, gx = tx0 - 2 * LH + x;
             const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
-            if (i < LF * LF) { s_ab[0][y][x] = in ? va[u] : 0.f; s_ab[1][y][x] = in ? vb[u] : 0.f; }
+            if (i < LF * LF) s_ab[y][x] = in ? f2{va[u], vb[u]} : f2{0.f, 0.f};
         }
     }
     __syncthreads();
     // this thread's four output pixels (column ox, rows oy0 .. oy0 + 3): their own values, kept for the L1 term and the last step
     const int ox = tid & 31, oy0 = (tid >> 5) * 4;
-    float pa[4], pb[4];
+    f2 pab[4];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) { pa[e] = s_ab[0][oy0 + e + 2 * LH][ox + 2 * LH]; pb[e] = s_ab[1][oy0 + e + 2 * LH][ox + 2 * LH]; }
-    // ---- statistics on 42 x 42: five maps, two horizontally filtered planes at a time, the two maps of a round as the halves of
-    // packed fp32 operations (v_pk_fma_f32: one instruction per tap and output for BOTH maps).  Horizontal: an item = 11 consecutive
-    // outputs of one staged row (52 rows x 4 groups = 208 items: one pass over the threads); vertical: a thread = 7 consecutive rows of
-    // one column (42 columns x 6 groups = 252 threads).
-    typedef float f2 __attribute__((ext_vector_type(2)));
+    for (int e = 0; e < 4; ++e) pab[e] = s_ab[oy0 + e + 2 * LH][ox + 2 * LH];
+    // ---- statistics on 42 x 42: five maps in three rounds -- (a, b), (a^2, b^2) as the halves of packed fp32 operations (v_pk_fma_f32:
+    // one instruction per tap and output for BOTH maps), then a b alone.  Horizontal: an item = 11 consecutive outputs of one staged row
+    // (52 rows x 4 groups = 208 items: one pass over the threads); vertical: a thread = 7 consecutive rows of one column (42 columns x 6
+    // groups = 252 threads).
     const int vx = tid % LE, vy0 = (tid / LE) * 7;
     const bool vert = tid < LE * 6;
     float st[5][7];
@@ -304,33 +308,57 @@ __global__ __launch_bounds__(256) void gp_l1_ssim_fused_kernel(const float* __re
             const int y = tid >> 2, x0 = (tid & 3) * 11;
             f2 v[21];           // (columns beyond the staged 52 feed outputs beyond 42 only: discarded)
 #pragma unroll
-            for (int j = 0; j < 21; ++j) {
-                const float a = s_ab[0][y][x0 + j], b = s_ab[1][y][x0 + j];
-                v[j] = round == 0 ? f2{a, b} : round == 1 ? f2{a * a, b * b} : f2{a * b, 0.f};
-            }
+            for (int j = 0; j < 21; ++j) v[j] = s_ab[y][x0 + j];
+            if (round < 2) {
+                if (round == 1) {
 #pragma unroll
-            for (int e = 0; e < 11; ++e) {
-                f2 m = {0.f, 0.f};
+                    for (int j = 0; j < 21; ++j) v[j] = v[j] * v[j];
+                }
 #pragma unroll
-                for (int k = 0; k < 11; ++k) m = __builtin_elementwise_fma(f2{win.w[k], win.w[k]}, v[e + k], m);
-                if (x0 + e < LE) {
-                    s_h[0][y][x0 + e] = m[0];
-                    if (round < 2) s_h[1][y][x0 + e] = m[1];
+                for (int e = 0; e < 11; ++e) {
+                    f2 m = {0.f, 0.f};
+#pragma unroll
+                    for (int k = 0; k < 11; ++k) m = __builtin_elementwise_fma(f2{win.w[k], win.w[k]}, v[e + k], m);
+                    if (x0 + e < LE) s_h[y][x0 + e] = m;
+                }
+            } else {
+                float p[21];
+#pragma unroll
+                for (int j = 0; j < 21; ++j) p[j] = v[j][0] * v[j][1];
+#pragma unroll
+                for (int e = 0; e < 11; ++e) {
+                    float m = 0.f;
+#pragma unroll
+                    for (int k = 0; k < 11; ++k) m = fmaf(win.w[k], p[e + k], m);
+                    if (x0 + e < LE) s_h[y][x0 + e][0] = m;
                 }
             }
         }
         __syncthreads();
         if (vert) {
-            f2 v[17];
+            if (round < 2) {
+                f2 v[17];
 #pragma unroll
-            for (int j = 0; j < 17; ++j) v[j] = f2{s_h[0][vy0 + j][vx], round < 2 ? s_h[1][vy0 + j][vx] : 0.f};
+                for (int j = 0; j < 17; ++j) v[j] = s_h[vy0 + j][vx];
 #pragma unroll
-            for (int e = 0; e < 7; ++e) {
-                f2 acc = {0.f, 0.f};
+                for (int e = 0; e < 7; ++e) {
+                    f2 acc = {0.f, 0.f};
 #pragma unroll
-                for (int k = 0; k < 11; ++k) acc = __builtin_elementwise_fma(f2{win.w[k], win.w[k]}, v[e + k], acc);
-                st[2 * round][e] = acc[0];
-                if (round < 2) st[2 * round + 1][e] = acc[1];
+                    for (int k = 0; k < 11; ++k) acc = __builtin_elementwise_fma(f2{win.w[k], win.w[k]}, v[e + k], acc);
+                    st[2 * round][e] = acc[0];
+                    st[2 * round + 1][e] = acc[1];
+                }
+            } else {
+                float v[17];
+#pragma unroll
+                for (int j = 0; j < 17; ++j) v[j] = s_h[vy0 + j][vx][0];
+#pragma unroll
+                for (int e = 0; e < 7; ++e) {
+                    float acc = 0.f;
+#pragma unroll
+                    for (int k = 0; k < 11; ++k) acc = fmaf(win.w[k], v[e + k], acc);
+                    st[4][e] = acc;
+                }
             }
         }
         if (round < 2) __syncthreads();         // (after the last round nobody reads the image planes again: the maps may overwrite them)
@@ -356,7 +384,8 @@ __global__ __launch_bounds__(256) void gp_l1_ssim_fused_kernel(const float* __re
                 d1 = -ssim / D2;
                 d2 = 2.f * N1 * inv;
             }
-            s_m[0][y][vx] = d0; s_m[1][y][vx] = d1; s_m[2][y][vx] = d2;
+            s_m01[y][vx] = f2{d0, d1};
+            s_m2[y][vx] = d2;
         }
     }
     __syncthreads();
@@ -366,14 +395,15 @@ __global__ __launch_bounds__(256) void gp_l1_ssim_fused_kernel(const float* __re
         f2 v[18];
         float v2[18];
 #pragma unroll
-        for (int j = 0; j < 18; ++j) { v[j] = f2{s_m[0][y][x0 + j], s_m[1][y][x0 + j]}; v2[j] = s_m[2][y][x0 + j]; }
+        for (int j = 0; j < 18; ++j) { v[j] = s_m01[y][x0 + j]; v2[j] = s_m2[y][x0 + j]; }
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             f2 acc = {0.f, 0.f};
             float acc2 = 0.f;
 #pragma unroll
             for (int k = 0; k < 11; ++k) { acc = __builtin_elementwise_fma(f2{win.w[k], win.w[k]}, v[e + k], acc); acc2 = fmaf(win.w[k], v2[e + k], acc2); }
-            s_h2[0][y][x0 + e] = acc[0]; s_h2[1][y][x0 + e] = acc[1]; s_h2[2][y][x0 + e] = acc2;
+            s_g01[y][x0 + e] = acc;
+            s_g2[y][x0 + e] = acc2;
         }
     }
     __syncthreads();
@@ -385,7 +415,7 @@ __global__ __launch_bounds__(256) void gp_l1_ssim_fused_kernel(const float* __re
             f2 v[14];
             float v2[14];
 #pragma unroll
-            for (int j = 0; j < 14; ++j) { v[j] = f2{s_h2[0][oy0 + j][ox], s_h2[1][oy0 + j][ox]}; v2[j] = s_h2[2][oy0 + j][ox]; }
+            for (int j = 0; j < 14; ++j) { v[j] = s_g01[oy0 + j][ox]; v2[j] = s_g2[oy0 + j][ox]; }
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 f2 acc = {0.f, 0.f};
@@ -400,7 +430,7 @@ __global__ __launch_bounds__(256) void gp_l1_ssim_fused_kernel(const float* __re
         for (int e = 0; e < 4; ++e) {
             const int gy = ty0 + oy0 + e;
             if (gy >= H || gx >= W) continue;
-            const float a = pa[e], b = pb[e];
+            const float a = pab[e][0], b = pab[e][1];
             const float d = a - b;
             l1 += fabsf(d);
             const float sgn = (d > 0.f) ? 1.f : ((d < 0.f) ? -1.f : 0.f);
