@@ -50,6 +50,7 @@ static int make_dims(const gp_raster_settings* st, const gp_raster_inputs* in, R
     d.late_color = (st->sh_ready_event && in->shs) ? 1 : 0;
     d.visible = nullptr; d.zero_words = nullptr; d.n_zero = 0;
     d.key_hi = 0u; d.key_base = 0u; d.key_culled = 0xFFFFFFFFu; d.key_flag = nullptr; d.key_tag = 0u;
+    d.sb_side = nullptr;
     if (st->depth_key_bits != 0 && st->depth_key_bits != 32) {
         if (st->depth_key_bits < 8 || st->depth_key_bits > 31) GP_FAIL("depth_key_bits must be 0, 32 or 8 .. 31 (got %d)", st->depth_key_bits);
         if (!st->binning_status) GP_FAIL("depth_key_bits needs binning_status (the word a broken promise raises)");
@@ -67,11 +68,13 @@ static int make_dims(const gp_raster_settings* st, const gp_raster_inputs* in, R
 struct GeomLayout {
     float4* rec;
     uint8_t* clamped;
+    float2* sb_side;        // (RasterDims.sb_side)
     size_t bytes;
     GeomLayout(void* base, size_t N) {
         GpCarver c(base);
         rec = c.take<float4>(3 * N + 1);
         clamped = c.take<uint8_t>(N + 1);
+        sb_side = c.take<float2>(GP_SB_HOIST == 1 ? N + 1 : 0);
         bytes = c.bytes();
     }
 };
@@ -112,6 +115,7 @@ extern "C" int gp_raster_forward(const gp_raster_settings* st, const gp_raster_i
     void* geom = alloc(alloc_ctx, GP_BUF_GEOM, gl0.bytes);
     if (!geom) GP_FAIL("allocator returned NULL for GEOM (%zu B)", gl0.bytes);
     GeomLayout gl(geom, N);
+    d.sb_side = gl.sb_side;
     saved->geom = geom; saved->geom_bytes = gl.bytes;
     saved->image = img; saved->image_bytes = il.bytes;
     saved->binning = nullptr; saved->binning_bytes = 0; saved->num_rendered = 0;

@@ -12,6 +12,11 @@
 #define GP_BWD_PARTS ((16 / GP_BWD_ROWS) * (16 / GP_BWD_COLS))
 #define GP_BWD_PAIRS (GP_BWD_ROWS * GP_BWD_COLS / 2)
 
+// 0 (shipped): the composite forward's staging lanes compute the whole sub-block test per instance; 1: its per-Gaussian half comes from a side
+// array the projection kernel writes; 2: from the record's spare word (raster_kernels.hip gp_sb_side; tools/probe/sb_hoist_ab.sh)
+#ifndef GP_SB_HOIST
+#define GP_SB_HOIST 0
+#endif
 struct RasterDims {
     int N, M, D;       // gaussians, sh coeffs per channel, active sh degree
     int W, H, gx, gy;  // image and tile grid
@@ -25,6 +30,9 @@ struct RasterDims {
     // key_culled = the key of a Gaussian without tiles (sorts behind every visible one), key_flag = the word raised on a broken promise
     uint32_t key_hi, key_base, key_culled, key_tag;
     uint32_t* key_flag;     // binning_status + 2: receives key_tag (this call's number) when a visible key breaks the promise
+    // per-Gaussian half of the composite forward's sub-block test (gp_sb_mask), written by the projection kernel: (dyr, inv_cx), inv_cx = NaN
+    // for "do not cull" (degenerate conic).  The staging lanes computed these -- three rcp and a sqrt -- per tile-splat INSTANCE (R = 4 N)
+    float2* sb_side;
 };
 __global__ __launch_bounds__(256) void gp_key_range_kernel(const uint32_t* __restrict__ keys, const int32_t* __restrict__ radii, int n,
                                                           uint32_t base, uint32_t* __restrict__ out2);

@@ -269,6 +269,24 @@ __device__ __forceinline__ uint8_t sh_color(const RasterDims& d, int i, int tid,
     return cl;
 }
 
+// The per-Gaussian half of the composite forward's sub-block test (gp_sb_mask below, which states the geometry): (dyr, inv_cx) from the
+// record's own floats with the hardware rcp / sqrt -- once per Gaussian here instead of once per tile-splat instance in the staging lanes
+// (R / N = 4 instances per Gaussian; three rcp and one sqrt each).  BUILT AND MEASURED, SHIPS OFF (GP_SB_HOIST = 0, raster_kernels.h):
+// profiles/r06_sb_hoist_ab.txt -- through the record's spare word the composite forward does not move (0.1148 against 0.1150 ms), through
+// a side array (a fourth gathered line per instance) it is 10 % slower: the staging phase waits for its gathers, not for its arithmetic.  inv_cx = NaN: do not cull (degenerate conic, or an extent beyond 1e8;
+// an opacity below 1/255 gives NaN as well and is caught in front by the mask's own test of tau).
+__device__ __forceinline__ float2 gp_sb_side(const float4 q0, const float4 q1) {
+    const float cx = -2.f * q0.z, cy = -q0.w, cz = -2.f * q1.x;
+    const float det = cx * cz - cy * cy;
+    const float tau = q1.y + 7.994353436858858f;
+    const float tt = 2.f * tau * 1.004f + 0.03f;
+    const float ex = __builtin_amdgcn_sqrtf(tt * cz * __builtin_amdgcn_rcpf(det));
+    const float inv_cx = 0.25f * __builtin_amdgcn_rcpf(cx);
+    const float dyr = -(cy * __builtin_amdgcn_rcpf(cz)) * ex;
+    const bool cull = det > 0.f && cx > 0.f && cz > 0.f && ex <= 1e8f;
+    return make_float2(dyr, cull ? inv_cx : __uint_as_float(0x7fc00000u));
+}
+
 template <int SH_MODE>
 __device__ __forceinline__ void preprocess_fwd_body(RasterDims d, const float* __restrict__ means3D,
                                                     const float* __restrict__ scales, const float* __restrict__ rotations,
@@ -363,7 +381,19 @@ __device__ __forceinline__ void preprocess_fwd_body(RasterDims d, const float* _
     // the record carries the quadratic form pre-scaled by log2(e) and log2(opacity) beside the opacity itself (GP_LOG2E; the
     // oracle restates the same products), which takes two multiplies out of every (pixel, splat) evaluation of both passes.
     rec[3 * (size_t)i + 0] = make_float4(pix, piy, (-0.5f * conx) * GP_LOG2E, (-cony) * GP_LOG2E);
-    rec[3 * (size_t)i + 1] = make_float4((-0.5f * conz) * GP_LOG2E, log2f(opac), pv.z, __int_as_float(i));
+    {
+        const float4 r0 = make_float4(pix, piy, (-0.5f * conx) * GP_LOG2E, (-cony) * GP_LOG2E);
+        float4 r1 = make_float4((-0.5f * conz) * GP_LOG2E, log2f(opac), pv.z, __int_as_float(i));
+#if GP_SB_HOIST
+        const float2 side = gp_sb_side(r0, r1);
+#endif
+#if GP_SB_HOIST == 2
+        r1.w = side.y != side.y ? side.y : side.x;      // the word that held the Gaussian's id (read by nobody): dyr, or NaN for "do not cull"
+#elif GP_SB_HOIST == 1
+        if (d.sb_side) d.sb_side[i] = side;
+#endif
+        rec[3 * (size_t)i + 1] = r1;
+    }
     rec[3 * (size_t)i + 2] = make_float4(col[0], col[1], col[2], opac);
 }
 
@@ -632,7 +662,7 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 // -- the published algorithm's min(0.99, opacity exp(power)) with the two multiplies moved into the per-Gaussian record.
 // ------------------------------------------------------------------------------------------------
 #define CF2_REC 48            // bytes per staged record: (x, y, A', B') (C', log2 opacity, r, g) (b, depth, -, -)
-__device__ __forceinline__ uint32_t gp_sb_mask(const float4 q0, const float4 q1, float X0, float Y0) {
+__device__ __forceinline__ uint32_t gp_sb_mask(const float4 q0, const float4 q1, const float2 side, float X0, float Y0) {
     // alpha >= 1/255  <=>  q'(d) := cx dx^2 + 2 cy dx dy + cz dy^2 <= 2 (lop + log2 255) =: 2 tau, everything in the record's
     // log2 units (cx = -2 A' ..., the geometry is homogeneous in the scale).
     // hardware rcp / sqrt (about 1 ulp) instead of the correctly rounded sequences (10 - 15 instructions each): the test
@@ -642,13 +672,27 @@ __device__ __forceinline__ uint32_t gp_sb_mask(const float4 q0, const float4 q1,
     const float det = cx * cz - cy * cy;
     const float tau = q1.y + 7.994353436858858f;                 // log2(255 opacity)
     if (!(tau > 0.f)) return 0u;                                 // opacity < 1/255: alpha never reaches the threshold
-    if (!(det > 0.f && cx > 0.f && cz > 0.f)) return 0xFFFFu;    // degenerate conic: do not cull
+    // per Gaussian, from the projection kernel (gp_sb_side): ex = sqrt(tt cz / det) = half extent in x, the rightmost point at
+    // dy = dyr = -(cy / cz) ex, inv_cx = 1 / (4 cx); NaN = degenerate conic (det, cx or cz not positive) or ex > 1e8: do not cull
+#if GP_SB_HOIST == 1
+    const float dyr = side.x, inv_cx = side.y;
+    if (inv_cx != inv_cx) return 0xFFFFu;
     const float tt = 2.f * tau * 1.004f + 0.03f;                 // q' <= tt, with slack for the rounding of the exponent / exp2
-    const float ex = __builtin_amdgcn_sqrtf(tt * cz * __builtin_amdgcn_rcpf(det));   // half extent in x; rightmost point at dy = -(cy / cz) ex
+#elif GP_SB_HOIST == 2   // dyr alone, in the record's spare word (q1.w): no second gather; NaN = do not cull
+    const float dyr = q1.w;
+    if (dyr != dyr) return 0xFFFFu;
+    const float tt = 2.f * tau * 1.004f + 0.03f;
+    const float inv_cx = 0.25f * __builtin_amdgcn_rcpf(cx);
+#else       // (-DGP_SB_HOIST=0: the same values computed per instance, as through round 5 -- the A/B of profiles/r06_sb_hoist_ab.txt)
+    if (!(det > 0.f && cx > 0.f && cz > 0.f)) return 0xFFFFu;
+    const float tt = 2.f * tau * 1.004f + 0.03f;
+    const float ex = __builtin_amdgcn_sqrtf(tt * cz * __builtin_amdgcn_rcpf(det));
     if (!(ex <= 1e8f)) return 0xFFFFu;
-    // everything below in SB columns (quarter pixels): column k covers pixel centres 4k .. 4k + 3
-    const float inv_cx = 0.25f * __builtin_amdgcn_rcpf(cx), rxy = -cy * inv_cx;      // centre line of the row spans: c(dy) = rxy dy
+    const float inv_cx = 0.25f * __builtin_amdgcn_rcpf(cx);
     const float dyr = -(cy * __builtin_amdgcn_rcpf(cz)) * ex;
+#endif
+    // everything below in SB columns (quarter pixels): column k covers pixel centres 4k .. 4k + 3
+    const float rxy = -cy * inv_cx;                              // centre line of the row spans: c(dy) = rxy dy
     const float ctt = cx * tt;
     const float mxr = fmaf(mx + 0.01f, 0.25f, 1.f);              // (+ 1: floor(x) + 1 = one past the last column)
     const float mxl = (mx - 3.01f) * 0.25f;                      // (xl - 3) / 4
@@ -736,11 +780,16 @@ __device__ __forceinline__ void gp_composite_fwd_sb_body(RasterDims d, const int
         const uint32_t id = id_next;
         if (k < range.y) {
             const float4 q0 = rec[3 * (size_t)id], q1 = rec[3 * (size_t)id + 1], q2 = rec[3 * (size_t)id + 2];
+#if GP_SB_HOIST == 1
+            const float2 side = d.sb_side[id];
+#else
+            const float2 side = make_float2(0.f, 0.f);
+#endif
             float4* dst = (float4*)(s_rec + tid * CF2_REC);
             dst[0] = q0;
             dst[1] = make_float4(q1.x, q1.y, q2.x, q2.y);
             *(float2*)(dst + 2) = make_float2(q2.z, q1.z);
-            rel = gp_sb_mask(q0, q1, X0, Y0);
+            rel = gp_sb_mask(q0, q1, side, X0, Y0);
             smask[k] = (uint16_t)rel;           // saved for the backward: which 4x4 sub-blocks of its tile the instance can touch
         }
         unsigned long long bal[16];
