@@ -382,7 +382,7 @@ __device__ __forceinline__ void preprocess_fwd_body(RasterDims d, const float* _
     // oracle restates the same products), which takes two multiplies out of every (pixel, splat) evaluation of both passes.
     rec[3 * (size_t)i + 0] = make_float4(pix, piy, (-0.5f * conx) * GP_LOG2E, (-cony) * GP_LOG2E);
     {
-        const float4 r0 = make_float4(pix, piy, (-0.5f * conx) * GP_LOG2E, (-cony) * GP_LOG2E);
+        [[maybe_unused]] const float4 r0 = make_float4(pix, piy, (-0.5f * conx) * GP_LOG2E, (-cony) * GP_LOG2E);
         float4 r1 = make_float4((-0.5f * conz) * GP_LOG2E, log2f(opac), pv.z, __int_as_float(i));
 #if GP_SB_HOIST
         const float2 side = gp_sb_side(r0, r1);
