@@ -67,7 +67,10 @@ __device__ __forceinline__ f32x16 mfma16(b8 a, b8 b, f32x16 c) { return __builti
 // different page (2 MB stride at 1M rows: TLB-bound); 64-row blocks made each load touch 64 separate cache lines.
 #define T16_BLK 16
 __device__ __host__ __forceinline__ size_t t16_idx(int f, long row, int nf) { return ((size_t)(row >> 4) * nf + f) * T16_BLK + (row & 15); }
-__device__ __host__ __forceinline__ size_t t16_elems(int nf, long rows) { return (size_t)((rows + 63) / 64) * nf * 64; }
+// (a tensor's extent is padded to 128 rows, the tile of the 128-row workgroups: their carried stores -- one 1 KB store per k-step inside
+// the product's asm statement -- are unguarded, so the last workgroup's rows beyond the 64-row padding need a place inside the same tensor;
+// readers never look past the zero padding to 64 rows)
+__device__ __host__ __forceinline__ size_t t16_elems(int nf, long rows) { return (size_t)((rows + 127) / 128) * nf * 128; }
 #define M16_THREADS 256
 #define GP_MLP16_BIG_ROWS 65536   // from here on forward / data-backward use 128-row workgroups
 #define M16_W 256

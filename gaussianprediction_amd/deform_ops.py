@@ -252,9 +252,10 @@ class FusedMlp16(torch.autograd.Function):
         w16_buf, w16 = packed_w16(ws, tdt, cdt, False)
         need_grad = any(x is not None and torch.is_tensor(x) and x.requires_grad for x in (feature, xyz) + tuple(wb))
         out = torch.empty(rows, out_dim, device=dev)
-        rows64 = (rows + 63) // 64 * 64                     # blocked layout [row block of 16][feature][16], rows padded to 64
-        xT = torch.empty(ns * in_pad * rows64, device=dev, dtype=tdt) if need_grad else None
-        hT = torch.empty(ns * 4 * 256 * rows64, device=dev, dtype=tdt) if need_grad else None
+        # blocked layout [row block of 16][feature][16]: rows zero-padded to 64, every tensor's extent padded to 128 rows (include/gp_hip.h)
+        rows128 = (rows + 127) // 128 * 128
+        xT = torch.empty(ns * in_pad * rows128, device=dev, dtype=tdt) if need_grad else None
+        hT = torch.empty(ns * 4 * 256 * rows128, device=dev, dtype=tdt) if need_grad else None
         masks = torch.empty(4, rows, 8, device=dev, dtype=torch.int32) if need_grad else None
         params = _lib.Mlp16ParamsC(cdt, in_dim, 256, 4, out_dim)
         for l in range(5):

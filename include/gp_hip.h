@@ -260,9 +260,10 @@ typedef struct gp_mlp16_params {
     uint32_t* range_flag;   /* optional device word (GP_DTYPE_F16_SPLIT forward): OR-ed with 1 when a hidden activation reached 2^15 --
                              * half the fp16 range the (hi, lo') form saturates at; the caller then repeats the pass with gp_mlp_forward */
 } gp_mlp16_params;
-/* saved (training, all optional together), 16-bit, BLOCKED by 16 rows, rows zero-padded to a multiple of 64:
- * xT [ceil(rows/64)*4][in_pad16][16] and hT [4][ceil(rows/64)*4][256][16]
- * (element (f, row) at ((row >> 4) * nf + f) * 16 + (row & 15));
+/* saved (training, all optional together), 16-bit, BLOCKED by 16 rows, rows zero-padded to a multiple of 64, every tensor's EXTENT
+ * padded to a multiple of 128 rows (the 128-row workgroups store whole tiles; what lies beyond the 64-row padding is never read):
+ * xT [ceil(rows/128)*8][in_pad16][16] and hT [4][ceil(rows/128)*8][256][16]
+ * (element (f, row) at ((row >> 4) * nf + f) * 16 + (row & 15)); GP_DTYPE_F16_SPLIT: twice the features ([hi | lo'] per row block);
  * masks: 8 rows u32 per layer, an opaque hand-over from the forward to the backward (ReLU sign bits: [4][4 feature groups][rows][2],
  * one word per lane of the kernels that write and read it; round 6). */
 int gp_mlp16_forward(const gp_mlp16_params* p, const gp_mlp_input* x, float* out, void* saved_xT, void* saved_hT,
