@@ -341,10 +341,9 @@ def main():
     ap.add_argument("--no-fused", action="store_true",
                     help="take every step through the autograd graph (render -> loss -> backward -> FusedAdam.step) instead of the one-call "
                          "fused step (gp_train_step_run): the A/B of TrainStep(fused=...)")
-    ap.add_argument("--early-adam", action="store_true",
-                    help="fused step: the per-Gaussian tensors' Adam update on the library's second stream beside the keypoint MLP's backward "
-                         "instead of ONE optimizer launch behind the backward (gp_step_update.adam_early_mask; measured slower: "
-                         "profiles/r05_early_adam_ab.txt)")
+    ap.add_argument("--no-early-adam", action="store_true",
+                    help="fused step: ONE optimizer launch behind the backward instead of the per-Gaussian tensors' Adam update riding in the "
+                         "launch of the keypoint MLP's data backward (gp_step_update.adam_early_mask; A/B: profiles/r06_adam_rider_ab.txt)")
     ap.add_argument("--debug-option", action="append", default=[], metavar="KEY=VALUE",
                     help="gp_debug_option(KEY, VALUE) before the run (the library's A/B knobs, e.g. 8=2: the three-pass 11-bit depth sort); repeatable")
     ap.add_argument("--render-only", action="store_true", help="time eval-style forward renders instead of train steps")
@@ -390,7 +389,7 @@ def main():
     ts = TrainStep(pc, cams, gts, args.iteration, lrs=dict(xyz=1.6e-6 * 5.0), speculative=not args.exact_binning,
                    sharded=False if (args.replicated_adam or args.factorised_sh) else None, chain_sh=not args.no_chain_sh, fused=not args.no_fused,
                    factorised_sh=args.factorised_sh)
-    ts.early_adam = bool(args.early_adam)
+    ts.early_adam = not args.no_early_adam
 
     def one_step(i):
         view = i * world + rank            # rank r renders view world*i + r
@@ -655,8 +654,9 @@ def main():
                             + 24 * int(pc._features_dc.shape[0]) * (world - 1))),
                        "exposed_wait_ms_per_step": waits,          # (--time-waits: compute-stream time inside waits for collectives, rank 0)
                        "step_driver": (f"one library call per step (gp_train_step_run): {getattr(ts, 'fused_steps', 0)} of the steps since the set-up"
-                                       + ("; the per-Gaussian tensors' Adam launch runs on a second stream beside the keypoint MLP's backward, so the "
-                                          "sum of kernels_ms may exceed ms_per_step" if (getattr(ts, "early_adam", False) and world == 1) else "")
+                                       + ("; the per-Gaussian tensors' Adam update rides in the launch of the keypoint MLP's data backward "
+                                          "(kernels_ms.adam = that launch + the MLP tensors' update; no mlp_bwd_data entry)"
+                                          if (getattr(ts, "early_adam", False) and world == 1) else "")
                                        if getattr(ts, "fused_steps", 0) else "autograd graph (render -> loss -> backward -> FusedAdam.step)"),
                        "binning": "exact (R read back every step)" if args.exact_binning else
                                   f"capacity mode in warm-up and timed steps (no host sync; {preroll} exact-mode set-up steps before the "

@@ -113,6 +113,13 @@ __global__ __launch_bounds__(512) void gp_mlp_bwd_data_small_kernel(MlpDev p, co
                                                                     const float* __restrict__ dL_dout, float* __restrict__ dz,
                                                                     float* __restrict__ dfeature, float* __restrict__ dxyz);
 
+struct AdamTable;      // loss_adam_kernels.h
+__global__ __launch_bounds__(512) void gp_mlp_bwd_data_small_adam_kernel(MlpDev p, const float* __restrict__ saved_h,
+                                                                         const float* __restrict__ dL_dout, float* __restrict__ dz,
+                                                                         float* __restrict__ dfeature, float* __restrict__ dxyz,
+                                                                         unsigned n_mlp, AdamTable t, float b1, float b2, float eps,
+                                                                         int zero_grad, const uint32_t* __restrict__ skip_flag);
+
 __global__ __launch_bounds__(256) void gp_mlp_bwd_weight64_kernel(const float* __restrict__ dZ, int n_out, const float* __restrict__ H,
                                                                  int ldh, int n_in, long rows, long rows_per_block,
                                                                  unsigned n_row_blocks, float* __restrict__ dW, int lddw,

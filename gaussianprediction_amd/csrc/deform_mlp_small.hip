@@ -12,6 +12,7 @@
 // layout (lane group kg' holds features 4 kg' + r) writes back as 64 consecutive floats per register r as well.
 #include "gp_common.h"
 #include "deform_kernels.h"
+#include "loss_adam_kernels.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -374,12 +375,12 @@ __global__ __launch_bounds__(ST) void gp_mlp_fwd_small_kernel(MlpDev p, float* _
     }
 }
 
-__global__ __launch_bounds__(ST) void gp_mlp_bwd_data_small_kernel(MlpDev p, const float* __restrict__ saved_h,
-                                                                   const float* __restrict__ dL_dout, float* __restrict__ dz,
-                                                                   float* __restrict__ dfeature, float* __restrict__ dxyz) {
+__device__ __forceinline__ void mlp_bwd_data_small_body(const MlpDev& p, const float* __restrict__ saved_h,
+                                                        const float* __restrict__ dL_dout, float* __restrict__ dz,
+                                                        float* __restrict__ dfeature, float* __restrict__ dxyz, unsigned block) {
     __shared__ float smem[2][SW * SR];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, kg = lane >> 4, n = lane & 15;
-    const long row0 = (long)blockIdx.x * SR;
+    const long row0 = (long)block * SR;
     float* cur = smem[0];
     float* nxt = smem[1];
     // dZ5^T [16][16] (zero-padded beyond out_dim)
@@ -450,4 +451,30 @@ __global__ __launch_bounds__(ST) void gp_mlp_bwd_data_small_kernel(MlpDev p, con
             }
         }
     }
+}
+
+__global__ __launch_bounds__(ST) void gp_mlp_bwd_data_small_kernel(MlpDev p, const float* __restrict__ saved_h,
+                                                                   const float* __restrict__ dL_dout, float* __restrict__ dz,
+                                                                   float* __restrict__ dfeature, float* __restrict__ dxyz) {
+    mlp_bwd_data_small_body(p, saved_h, dL_dout, dz, dfeature, dxyz, blockIdx.x);
+}
+
+// The same launch with a RIDER (loss_adam_kernels.h): workgroups [0, n_mlp) are the data backward above -- a handful of workgroups, each
+// bound for tens of microseconds by the rate at which ONE CU takes the layer weights in -- and workgroups [n_mlp, ...) are the chunks of an
+// optimizer launch that needs nothing this backward produces (the per-Gaussian tensors' Adam: HBM-bound, every CU).  The low block ids
+// are dispatched first, so the long-running MLP workgroups start at once and the stream of Adam chunks fills the rest of the part around
+// them.  (Round 5 ran the two as separate launches on two streams: the fork / join events cost more than the overlap brought,
+// profiles/r05_early_adam_ab.txt.)  The chunk body is element-wise: the update is bit-identical to gp_adam_multi_kernel's.
+// Measured (profiles/r06_adam_rider_ab.txt): 0.039 + 0.058 ms as two launches, 0.080 ms as one -- not the 0.058 of the longer half:
+// the MLP body's 196 registers leave ONE 512-thread workgroup per CU, and at that occupancy the update alone takes 0.078 ms whatever
+// its shape (one chunk per workgroup in two trips of 8 loads per lane: 0.078; the whole chunk in one trip of 32 loads: 0.086; half a chunk
+// per workgroup: 0.080; eight chunks per workgroup, plain or software-pipelined: 0.13 - 0.14 -- on this part a wave's loads queue behind
+// its own earlier STORES, one counter in order, so every further trip of a workgroup waits for the write acknowledgements of the trip before).
+__global__ __launch_bounds__(ST) void gp_mlp_bwd_data_small_adam_kernel(MlpDev p, const float* __restrict__ saved_h,
+                                                                        const float* __restrict__ dL_dout, float* __restrict__ dz,
+                                                                        float* __restrict__ dfeature, float* __restrict__ dxyz,
+                                                                        unsigned n_mlp, AdamTable t, float b1, float b2, float eps,
+                                                                        int zero_grad, const uint32_t* __restrict__ skip_flag) {
+    if (blockIdx.x < n_mlp) mlp_bwd_data_small_body(p, saved_h, dL_dout, dz, dfeature, dxyz, blockIdx.x);
+    else adam_chunk_body<ST>(t, blockIdx.x - n_mlp, threadIdx.x, b1, b2, eps, zero_grad, skip_flag);
 }

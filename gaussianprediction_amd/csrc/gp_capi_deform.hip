@@ -1,6 +1,7 @@
 // gp_capi_deform.hip -- extern "C" entry points of the deformation path (see include/gp_hip.h).
 #include "gp_common.h"
 #include "deform_kernels.h"
+#include "loss_adam_kernels.h"
 #include <stdlib.h>
 
 static int make_mlp(const gp_mlp_params* p, const gp_mlp_input* x, MlpDev& m) {
@@ -87,7 +88,17 @@ extern "C" int gp_mlp_backward(const gp_mlp_params* p, const gp_mlp_input* x, co
     const size_t dz_bytes = gp_align_up((size_t)4 * m.rows * 256 * sizeof(float), 256);
     float* dz = (float*)alloc(alloc_ctx, GP_BUF_TEMP, dz_bytes);
     if (!dz) GP_FAIL("allocator returned NULL for TEMP (%zu B)", dz_bytes);
-    { GpProfScope _p("mlp_bwd_data", s);
+    GpAdamRider* rider = gp_adam_rider_slot();
+    if (m.rows <= GP_MLP_SMALL_ROWS && rider->armed) {
+        // gp_train_step_run left an optimizer launch that needs nothing of this backward: its chunks ride in the data kernel's launch
+        // (deform_mlp_small.hip).  The scope carries the optimizer's name: its bytes are what the launch moves.
+        rider->armed = false;
+        const unsigned n_mlp = gp_blocks((size_t)m.rows, 16);
+        GpProfScope _p("adam", s);
+        hipLaunchKernelGGL(gp_mlp_bwd_data_small_adam_kernel, dim3(n_mlp + rider->chunks), dim3(512), 0, s, m, sh, dL_dout, dz, dL_dfeature,
+                           dL_dxyz, n_mlp, rider->t, rider->b1, rider->b2, rider->eps, rider->zero_grad, rider->skip_flag);
+        GP_LAUNCH_CHECK();
+    } else { GpProfScope _p("mlp_bwd_data", s);
         if (m.rows <= GP_MLP_SMALL_ROWS)
             hipLaunchKernelGGL(gp_mlp_bwd_data_small_kernel, dim3(gp_blocks((size_t)m.rows, 16)), dim3(512), 0, s, m, sh, dL_dout, dz,
                                dL_dfeature, dL_dxyz);

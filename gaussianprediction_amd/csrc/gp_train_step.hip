@@ -3,7 +3,7 @@
 // nothing is re-implemented here, so the fused step and the drop-in surfaces cannot drift apart.
 // [REF train.py:101-133, 196-197; scene/gaussian_model.py:251-273]
 #include "gp_common.h"
-#include <mutex>
+#include "loss_adam_kernels.h"
 
 // dst[i] += src[i]: the keypoint features take a gradient from the regulariser AND from the MLP's input (both "=" producers)
 __global__ __launch_bounds__(256) void gp_step_accumulate_kernel(float* __restrict__ dst, const float* __restrict__ src, int64_t n) {
@@ -11,34 +11,9 @@ __global__ __launch_bounds__(256) void gp_step_accumulate_kernel(float* __restri
     if (i < n) dst[i] += src[i];
 }
 
-// The second stream of the early optimizer launch (gp_step_update.adam_early_mask): one per device, created on first use, never destroyed.
-struct StepSide { hipStream_t s; hipEvent_t fork, join; bool ok; };
-static StepSide* step_side() {
-    static StepSide side[32];
-    static std::mutex mu;                       // (two host threads driving one device: the table is filled once, under the lock)
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32) return nullptr;
-    std::lock_guard<std::mutex> lock(mu);
-    StepSide& x = side[dev];
-    if (!x.ok) {
-        hipStream_t st = nullptr;
-        hipEvent_t f = nullptr, j = nullptr;
-        const bool good = hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess &&
-                          hipEventCreateWithFlags(&f, hipEventDisableTiming) == hipSuccess &&
-                          hipEventCreateWithFlags(&j, hipEventDisableTiming) == hipSuccess;
-        if (!good) {                            // nothing half-made is left behind
-            if (j) (void)hipEventDestroy(j);
-            if (f) (void)hipEventDestroy(f);
-            if (st) (void)hipStreamDestroy(st);
-            return nullptr;
-        }
-        x.s = st; x.fork = f; x.join = j; x.ok = true;
-    }
-    return &x;
-}
-
-// gp_adam_step_multi[_steps] over the tensors of `u`'s tables selected by `sel`
-static int step_adam(const gp_step_update* u, uint32_t sel, gp_stream_t stream) {
+// gp_adam_step_multi[_steps] over the tensors of `u`'s tables selected by `sel` -- launched on `stream`, or (ride) left in the rider
+// slot for the keypoint MLP's data backward to carry (loss_adam_kernels.h)
+static int step_adam(const gp_step_update* u, uint32_t sel, gp_stream_t stream, bool ride = false) {
     float *P[32], *G[32], *M[32], *V[32];
     int64_t NUM[32], ST[32];
     float LR[32];
@@ -48,14 +23,13 @@ static int step_adam(const gp_step_update* u, uint32_t sel, gp_stream_t stream) 
         if (!((sel >> k) & 1u)) continue;
         P[n] = u->adam_params[k]; G[n] = u->adam_grads[k]; M[n] = u->adam_exp_avgs[k]; V[n] = u->adam_exp_avg_sqs[k];
         NUM[n] = u->adam_numels[k]; LR[n] = u->adam_lrs[k];
-        if (u->adam_steps) ST[n] = u->adam_steps[k];
+        ST[n] = u->adam_steps ? u->adam_steps[k] : u->step;
         if ((u->keep_grad_mask >> k) & 1u) keep |= 1u << n;
         ++n;
     }
     if (n == 0) return 0;
-    if (u->adam_steps)
-        return gp_adam_step_multi_steps(n, P, G, M, V, NUM, LR, ST, u->beta1, u->beta2, u->eps, 1, keep, u->skip_flag, stream);
-    return gp_adam_step_multi(n, P, G, M, V, NUM, LR, u->beta1, u->beta2, u->eps, u->step, 1, keep, u->skip_flag, stream);
+    if (ride) return gp_adam_rider_arm(n, P, G, M, V, NUM, LR, ST, u->beta1, u->beta2, u->eps, 1, keep, u->skip_flag);
+    return gp_adam_step_multi_steps(n, P, G, M, V, NUM, LR, ST, u->beta1, u->beta2, u->eps, 1, keep, u->skip_flag, stream);
 }
 
 extern "C" int gp_train_step_run(const gp_step_plan* p, const gp_step_view* v, const gp_step_update* u, gp_alloc_fn alloc,
@@ -156,37 +130,25 @@ extern "C" int gp_train_step_run(const gp_step_plan* p, const gp_step_view* v, c
     if (gp_blend_backward(&ba, p->g_xyz_t, p->g_q_t, p->g_delta, nullptr, p->g_xyz, p->g_rotation, alloc, alloc_ctx, stream)) return 1;
     alloc(alloc_ctx, GP_BUF_TEMP_DONE, 0);
     // ---- optimizer, first part [REF train.py:196-197]: the per-Gaussian tensors' gradients are final here.  Their update (HBM-bound,
-    // every CU) runs on the second stream beside the keypoint MLP's backward (latency-bound, 16 CUs): neither touches the other's tensors.
+    // every CU) needs nothing the keypoint MLP's backward (latency-bound, 16 CUs) produces and touches none of its tensors: the tensors of
+    // adam_early_mask RIDE in the launch of that backward's data kernel (the rider of loss_adam_kernels.h; a row count the small-row
+    // kernels do not serve leaves the rider unconsumed: it is then launched right behind the MLP backward).
     const uint32_t all = u->adam_count >= 32 ? 0xFFFFFFFFu : ((1u << u->adam_count) - 1u);
-    uint32_t early = (u->hook || u->adam_count <= 0) ? 0u : (u->adam_early_mask & all);
-    StepSide* side = early ? step_side() : nullptr;
-    if (early && !side) early = 0u;         // (no second stream: one launch behind the backward, as without the mask)
-    // (an error behind the fork still joins the side stream: the caller sees ONE stream, whatever the return code)
-    auto join_side = [&]() { if (early) { (void)hipEventRecord(side->join, side->s); (void)hipStreamWaitEvent((hipStream_t)stream, side->join, 0); } };
-    if (early) {
-        GP_HIP_CHECK(hipEventRecord(side->fork, (hipStream_t)stream));
-        GP_HIP_CHECK(hipStreamWaitEvent(side->s, side->fork, 0));
-        if (step_adam(u, early, (gp_stream_t)side->s)) { join_side(); return 1; }
-        GP_HIP_CHECK(hipEventRecord(side->join, side->s));
-    }
+    const uint32_t early = (u->hook || u->adam_count <= 0) ? 0u : (u->adam_early_mask & all);
+    if (early && step_adam(u, early, stream, true)) return 1;
     gp_mlp_grads mg = p->g_mlp;
-    if (gp_mlp_backward(&p->mlp, &mi, p->acts, p->g_delta, &mg, reg ? p->g_feature_tmp : p->g_keypoint_features, p->g_keypoints, alloc,
-                        alloc_ctx, stream)) {
-        join_side();
-        return 1;
-    }
+    const int rc_mlp = gp_mlp_backward(&p->mlp, &mi, p->acts, p->g_delta, &mg, reg ? p->g_feature_tmp : p->g_keypoint_features, p->g_keypoints,
+                                       alloc, alloc_ctx, stream);
+    if (rc_mlp) { gp_adam_rider_slot()->armed = false; return 1; }
+    if (gp_adam_rider_flush((hipStream_t)stream)) return 1;
     if (reg) {
         hipLaunchKernelGGL(gp_step_accumulate_kernel, dim3(gp_blocks((size_t)nfeat, 256)), dim3(256), 0, (hipStream_t)stream,
                            p->g_keypoint_features, (const float*)p->g_feature_tmp, nfeat);
-        if (hipGetLastError() != hipSuccess) { join_side(); GP_FAIL("gp_train_step_run: launch failed"); }
+        GP_LAUNCH_CHECK();
     }
     if (u->hook) u->hook(u->hook_ctx, GP_STEP_AFTER_BACKWARD);
 
     // ---- optimizer [REF train.py:196-197, scene/gaussian_model.py:472]
-    if (u->adam_count > 0) {
-        const int rc = step_adam(u, all & ~early, stream);
-        if (early) GP_HIP_CHECK(hipStreamWaitEvent((hipStream_t)stream, side->join, 0));     // the caller sees ONE stream
-        if (rc) return 1;
-    }
+    if (u->adam_count > 0 && step_adam(u, all & ~early, stream)) return 1;
     return 0;
 }

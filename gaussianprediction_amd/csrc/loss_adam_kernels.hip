@@ -479,69 +479,10 @@ __global__ __launch_bounds__(256) void gp_adam_kernel(float* __restrict__ p, flo
     }
 }
 
-// multi-tensor form: ONE launch walks every parameter tensor (chunk table built by the host)
-#define ADAM_MAX_TENSORS 32
-#define ADAM_CHUNK 16384   // elements per workgroup-chunk
-struct AdamTable {
-    float* p[ADAM_MAX_TENSORS];
-    float* g[ADAM_MAX_TENSORS];
-    float* m[ADAM_MAX_TENSORS];
-    float* v[ADAM_MAX_TENSORS];
-    unsigned long long n[ADAM_MAX_TENSORS];
-    float step_size[ADAM_MAX_TENSORS];           // lr / (1 - beta1^t) with the TENSOR's step count t
-    float bc2_sqrt[ADAM_MAX_TENSORS];            // sqrt(1 - beta2^t)
-    unsigned keep_grad_mask;                     // bit k: leave tensor k's gradient as it is
-    unsigned chunk_begin[ADAM_MAX_TENSORS + 1];   // prefix of chunk counts
-    int count;
-};
+// multi-tensor form: ONE launch walks every parameter tensor (chunk table built by the host; table and chunk body: loss_adam_kernels.h)
 __global__ __launch_bounds__(256) void gp_adam_multi_kernel(AdamTable t, float b1, float b2, float eps, int zero_grad,
                                                            const uint32_t* __restrict__ skip_flag) {
-    const bool skip = skip_flag && *skip_flag != 0;      // the frame that produced these gradients was invalid: no update
-    const unsigned chunk = blockIdx.x;
-    int k = 0;
-    while (k + 1 < t.count && chunk >= t.chunk_begin[k + 1]) ++k;
-    const size_t base = (size_t)(chunk - t.chunk_begin[k]) * ADAM_CHUNK;
-    const size_t n = t.n[k];
-    float* __restrict__ p = t.p[k]; float* __restrict__ g = t.g[k]; float* __restrict__ m = t.m[k]; float* __restrict__ v = t.v[k];
-    const float step_size = t.step_size[k], bc2_sqrt = t.bc2_sqrt[k];
-    if ((t.keep_grad_mask >> k) & 1u) zero_grad = 0;
-    const size_t end = base + ADAM_CHUNK < n ? base + ADAM_CHUNK : n;
-    auto upd = [&](float4& pv, const float4& gv, float4& mv, float4& vv) {
-        float* pp = (float*)&pv; const float* gg = (const float*)&gv; float* mm = (float*)&mv; float* vq = (float*)&vv;
-#pragma unroll
-        for (int u = 0; u < 4; ++u) gp_adam_update(pp[u], gg[u], mm[u], vq[u], b1, b2, eps, step_size, bc2_sqrt);
-    };
-    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    size_t i = base + (size_t)threadIdx.x * 4;
-    if (skip) {             // discard the gradients (where this pass owns their zeroing), leave p / m / v untouched
-        if (zero_grad)
-            for (size_t j = base + threadIdx.x; j < end; j += 256) g[j] = 0.f;
-        return;
-    }
-    // two independent 16-byte streams per thread and iteration: 8 loads in flight per lane
-    for (; i + 1024 + 3 < end; i += 2048) {
-        const size_t j = i + 1024;
-        float4 pa = *(float4*)(p + i), ga = *(float4*)(g + i), ma = *(float4*)(m + i), va = *(float4*)(v + i);
-        float4 pb = *(float4*)(p + j), gb = *(float4*)(g + j), mb = *(float4*)(m + j), vb = *(float4*)(v + j);
-        upd(pa, ga, ma, va);
-        upd(pb, gb, mb, vb);
-        *(float4*)(p + i) = pa; *(float4*)(m + i) = ma; *(float4*)(v + i) = va;
-        *(float4*)(p + j) = pb; *(float4*)(m + j) = mb; *(float4*)(v + j) = vb;
-        if (zero_grad) { *(float4*)(g + i) = zero4; *(float4*)(g + j) = zero4; }
-    }
-    for (; i < end; i += 1024) {
-        if (i + 3 < n) {
-            float4 pv = *(float4*)(p + i), gv = *(float4*)(g + i), mv = *(float4*)(m + i), vv = *(float4*)(v + i);
-            upd(pv, gv, mv, vv);
-            *(float4*)(p + i) = pv; *(float4*)(m + i) = mv; *(float4*)(v + i) = vv;
-            if (zero_grad) *(float4*)(g + i) = zero4;
-        } else {
-            for (size_t j = i; j < n; ++j) {
-                gp_adam_update(p[j], g[j], m[j], v[j], b1, b2, eps, step_size, bc2_sqrt);
-                if (zero_grad) g[j] = 0.f;
-            }
-        }
-    }
+    adam_chunk_body<256>(t, blockIdx.x, threadIdx.x, b1, b2, eps, zero_grad, skip_flag);
 }
 
 // The slot totals in a fixed order: thread k walks slots k, k + 256, ..., xor-butterfly inside the wave, the four wave sums
@@ -733,15 +674,14 @@ extern "C" int gp_adam_step(float* param, float* grad, float* exp_avg, float* ex
 // torch.optim.Adam counts steps PER PARAMETER: a tensor whose .grad is None when step() runs is skipped and its count stays behind
 // (in the reference: the per-Gaussian tensors on every densify / prune iteration, train.py:164-197).  `steps` = the 1-based count of
 // each tensor's update; the bias corrections are formed per tensor on the host.
-extern "C" int gp_adam_step_multi_steps(int32_t count, float* const* params, float* const* grads, float* const* exp_avgs,
-                                        float* const* exp_avg_sqs, const int64_t* numels, const float* lrs, const int64_t* steps,
-                                        float beta1, float beta2, float eps, int32_t zero_grad, uint32_t keep_grad_mask,
-                                        const uint32_t* skip_flag, gp_stream_t stream_) {
-    hipStream_t s = (hipStream_t)stream_;
+// the chunk table of a launch and its number of chunks (0: nothing to update)
+static int adam_build_table(AdamTable& t, long& n_chunks, int32_t count, float* const* params, float* const* grads, float* const* exp_avgs,
+                            float* const* exp_avg_sqs, const int64_t* numels, const float* lrs, const int64_t* steps, float beta1,
+                            float beta2, uint32_t keep_grad_mask) {
+    n_chunks = 0;
     if (count < 0 || count > ADAM_MAX_TENSORS) GP_FAIL("adam: at most %d tensors per call (got %d)", ADAM_MAX_TENSORS, count);
     if (count == 0) return 0;
     if (!params || !grads || !exp_avgs || !exp_avg_sqs || !numels || !lrs || !steps) GP_FAIL("null argument");
-    AdamTable t;
     t.count = 0;
     t.keep_grad_mask = 0;
     unsigned chunks = 0;
@@ -760,9 +700,47 @@ extern "C" int gp_adam_step_multi_steps(int32_t count, float* const* params, flo
         chunks += (unsigned)((numels[k] + ADAM_CHUNK - 1) / ADAM_CHUNK);
     }
     t.chunk_begin[t.count] = chunks;
+    n_chunks = (long)chunks;
+    return 0;
+}
+
+extern "C" int gp_adam_step_multi_steps(int32_t count, float* const* params, float* const* grads, float* const* exp_avgs,
+                                        float* const* exp_avg_sqs, const int64_t* numels, const float* lrs, const int64_t* steps,
+                                        float beta1, float beta2, float eps, int32_t zero_grad, uint32_t keep_grad_mask,
+                                        const uint32_t* skip_flag, gp_stream_t stream_) {
+    hipStream_t s = (hipStream_t)stream_;
+    AdamTable t;
+    long chunks = 0;
+    if (adam_build_table(t, chunks, count, params, grads, exp_avgs, exp_avg_sqs, numels, lrs, steps, beta1, beta2, keep_grad_mask)) return 1;
     if (chunks == 0) return 0;
     GpProfScope _p("adam", s);
-    hipLaunchKernelGGL(gp_adam_multi_kernel, dim3(chunks), dim3(256), 0, s, t, beta1, beta2, eps, zero_grad, skip_flag);
+    hipLaunchKernelGGL(gp_adam_multi_kernel, dim3((unsigned)chunks), dim3(256), 0, s, t, beta1, beta2, eps, zero_grad, skip_flag);
+    GP_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- the rider (loss_adam_kernels.h)
+GpAdamRider* gp_adam_rider_slot() {
+    static thread_local GpAdamRider slot = {};
+    return &slot;
+}
+int gp_adam_rider_arm(int count, float* const* params, float* const* grads, float* const* exp_avgs, float* const* exp_avg_sqs,
+                      const int64_t* numels, const float* lrs, const int64_t* steps, float beta1, float beta2, float eps, int zero_grad,
+                      uint32_t keep_grad_mask, const uint32_t* skip_flag) {
+    GpAdamRider* r = gp_adam_rider_slot();
+    r->armed = false;
+    long chunks = 0;
+    if (adam_build_table(r->t, chunks, count, params, grads, exp_avgs, exp_avg_sqs, numels, lrs, steps, beta1, beta2, keep_grad_mask)) return 1;
+    r->b1 = beta1; r->b2 = beta2; r->eps = eps; r->zero_grad = zero_grad; r->skip_flag = skip_flag; r->chunks = (unsigned)chunks;
+    r->armed = chunks > 0;
+    return 0;
+}
+int gp_adam_rider_flush(hipStream_t s) {
+    GpAdamRider* r = gp_adam_rider_slot();
+    if (!r->armed) return 0;
+    r->armed = false;
+    GpProfScope _p("adam", s);
+    hipLaunchKernelGGL(gp_adam_multi_kernel, dim3(r->chunks), dim3(256), 0, s, r->t, r->b1, r->b2, r->eps, r->zero_grad, r->skip_flag);
     GP_LAUNCH_CHECK();
     return 0;
 }

@@ -266,9 +266,10 @@ class FusedStage3:
         for k, own in enumerate(opt.owner):
             if id(own) in keep_ids and tab["NUM"][k] != 0:
                 mask |= 1 << k
-        # the per-Gaussian tensors' gradients are final after the blend backward: their update runs beside the keypoint MLP's backward
-        # (gp_step_update.adam_early_mask; single-rank only -- a view-parallel step reduces the gradients first).  OFF by default: measured
-        # slower on the bench workload (profiles/r05_early_adam_ab.txt: the MLP backward slows down beside the HBM-bound Adam stream).
+        # the per-Gaussian tensors' gradients are final after the blend backward and the keypoint MLP's backward touches none of them: their
+        # update rides in the launch of that backward's data kernel (gp_step_update.adam_early_mask; single-rank only -- a view-parallel
+        # step reduces the gradients first).  Bit-identical to one launch; -0.015 ms per step on the bench workload
+        # (profiles/r06_adam_rider_ab.txt; round 5's two-stream form of the same idea measured slower and is gone).
         early = 0
         if not ts.reducer.enabled and getattr(ts, "early_adam", False):
             early_ids = {id(t) for t in (pc._xyz, pc._rotation, pc._scaling, pc._opacity, pc._features_dc, pc._features_rest)}

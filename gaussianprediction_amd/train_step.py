@@ -58,7 +58,7 @@ class TrainStep:
         self.factorised_sh = bool(factorised_sh)
         self._view_center = None
         self.fused = bool(fused)
-        self.early_adam = False                 # fused step: gp_step_update.adam_early_mask (measured slower, profiles/r05_early_adam_ab.txt)
+        self.early_adam = True                  # fused step: gp_step_update.adam_early_mask (the Adam rider of the MLP backward's launch)
         self._fused_plan = None
         self.fused_steps = 0
         self.lambda_dssim = lambda_dssim

@@ -454,10 +454,11 @@ typedef struct gp_step_update {
     /* the optimizer launch behind the backward: gp_adam_step_multi (steps == NULL) / gp_adam_step_multi_steps; count 0 = none */
     int32_t adam_count;
     /* bit k: tensor k's gradient is FINAL once the blend backward has run (the per-Gaussian tensors: nothing behind that point writes
-     * them) -- those updates are launched there, on a second stream of the library's own, and run beside the keypoint MLP's backward
-     * (three small, latency-bound kernels that occupy 16 CUs); the other tensors follow the MLP backward as before and the call's
-     * stream waits for the second one before the call returns, so a caller sees one stream.  0 = one launch behind the backward
-     * (what TrainStep passes: on the bench workload the overlap measured SLOWER, profiles/r05_early_adam_ab.txt).
+     * them) and the keypoint MLP's backward neither reads nor writes the tensor.  Those updates travel in the SAME LAUNCH as that
+     * backward's data kernel (a handful of workgroups, each bound for tens of microseconds by the rate at which one CU takes the
+     * layer weights in: the optimizer's HBM-bound chunks fill the rest of the part around them; round 6 -- round 5 used a second stream,
+     * whose fork / join events cost more than the overlap brought, profiles/r05_early_adam_ab.txt); the other tensors follow the MLP
+     * backward as before.  Element-wise arithmetic: the result is bit-identical to one launch.  0 = one launch behind the backward.
      * Ignored (one launch) when `hook` is set: a view-parallel caller reduces the gradients at GP_STEP_AFTER_BACKWARD first. */
     uint32_t adam_early_mask;
     float* const* adam_params; float* const* adam_grads; float* const* adam_exp_avgs; float* const* adam_exp_avg_sqs;

@@ -157,11 +157,11 @@ def test_two_rank_fused_step_equals_the_two_rank_graph_step(tmp_path):
         assert float(d.median()) <= 0.25 * lr + 1e-7 and float(d.max()) <= 2 * steps * lr + 1e-6, (k, float(d.median()), float(d.max()), lr)
 
 
-def test_early_optimizer_launch_on_the_second_stream_changes_nothing():
-    """gp_step_update.adam_early_mask: the per-Gaussian tensors' Adam update leaves on the library's second stream as soon as the blend
-    backward has run, beside the keypoint MLP's backward.  Same updates as the single launch behind the backward: parameters after
-    real steps agree as two runs of one path do, the step counts are equal, and the call returns with both streams joined (the
-    parameters read right after a step on the caller's stream are the updated ones)."""
+def test_adam_update_riding_in_the_mlp_backward_launch_changes_nothing():
+    """gp_step_update.adam_early_mask: the per-Gaussian tensors' Adam update rides in the launch of the keypoint MLP's data backward (the
+    rider of csrc/loss_adam_kernels.h; round 5: a second stream).  Same updates as the single launch behind the backward: parameters
+    after real steps agree as two runs of one path do, the step counts are equal, and the parameters read right after a step on the
+    caller's stream are the updated ones."""
     a = _run(True, None, 8, early_adam=True)
     b = _run(True, None, 8, early_adam=False)
     assert a["ts"]._fused_plan.upd.adam_early_mask != 0 and b["ts"]._fused_plan.upd.adam_early_mask == 0
