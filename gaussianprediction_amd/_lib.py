@@ -64,7 +64,7 @@ class AdamFuseC(C.Structure):
 
 class MlpParamsC(C.Structure):
     _fields_ = [("in_dim", C.c_int32), ("width", C.c_int32), ("depth", C.c_int32), ("out_dim", C.c_int32),
-                ("w", C.c_void_p * 5), ("b", C.c_void_p * 5), ("packed", C.c_void_p)]
+                ("w", C.c_void_p * 5), ("b", C.c_void_p * 5), ("packed", C.c_void_p), ("scratch", C.c_void_p)]
 
 
 class Mlp16ParamsC(C.Structure):
@@ -133,7 +133,7 @@ class ProfileEntryC(C.Structure):
 
 EXPORTS = [
     "gp_raster_forward", "gp_raster_backward", "gp_raster_mark_visible", "gp_raster_debug_binning",
-    "gp_mlp_forward", "gp_mlp_backward", "gp_mlp_pack", "gp_mlp_packed_floats", "gp_mlp16_forward", "gp_mlp16_backward", "gp_mlp16_pack", "gp_mlp16_packed_elems", "gp_blend_forward", "gp_blend_backward",
+    "gp_mlp_forward", "gp_mlp_backward", "gp_mlp_pack", "gp_mlp_packed_floats", "gp_mlp_scratch_bytes", "gp_mlp16_forward", "gp_mlp16_backward", "gp_mlp16_pack", "gp_mlp16_packed_elems", "gp_blend_forward", "gp_blend_backward",
     "gp_activations_forward", "gp_activations_backward", "gp_profile_enable", "gp_profile_collect",
     "gp_loss_l1_ssim_forward", "gp_loss_l1_ssim_finalize", "gp_loss_l1_ssim_backward", "gp_loss_l1_ssim_fused", "gp_adam_step",
     "gp_adam_step_multi", "gp_adam_step_multi_steps",
@@ -178,6 +178,7 @@ def lib() -> C.CDLL:
                 getattr(l, name).restype = C.c_int
         l.gp_hashgrid_table_entries.restype = C.c_int64
         l.gp_mlp_packed_floats.restype = C.c_int64
+        l.gp_mlp_scratch_bytes.restype = C.c_int64
         l.gp_mlp16_packed_elems.restype = C.c_int64
         if int(l.gp_abi_version()) != GP_ABI_VERSION:
             raise GpHipError(f"{LIB_PATH} implements ABI {int(l.gp_abi_version())}, this binding is written against ABI "

@@ -113,6 +113,10 @@ __global__ __launch_bounds__(512) void gp_mlp_bwd_data_small_kernel(MlpDev p, co
                                                                     const float* __restrict__ dL_dout, float* __restrict__ dz,
                                                                     float* __restrict__ dfeature, float* __restrict__ dxyz);
 
+__global__ __launch_bounds__(256) void gp_mlp_fwd_split_small_kernel(MlpDev p, float* __restrict__ out, float* __restrict__ saved_x, float* hx,
+                                                                     uint32_t* flags, uint32_t* err);
+__global__ __launch_bounds__(256) void gp_mlp_fwd_split_small_agent_kernel(MlpDev p, float* __restrict__ out, float* __restrict__ saved_x,
+                                                                           float* hx, uint32_t* flags, uint32_t* err);
 struct AdamTable;      // loss_adam_kernels.h
 __global__ __launch_bounds__(512) void gp_mlp_bwd_data_small_adam_kernel(MlpDev p, const float* __restrict__ saved_h,
                                                                          const float* __restrict__ dL_dout, float* __restrict__ dz,

@@ -23,14 +23,15 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ int pi16(int f) { return (f & ~15) | ((f & 3) << 2) | ((f >> 2) & 3); }
 __device__ __forceinline__ int sidx(int f, int n) { return pi16(f) * SR + n; }
 
+template <int NT = 512>
 __device__ __forceinline__ void build_input_s(float* buf, const MlpDev& p, long row0, int tid, int k16) {
     const int fd = p.feature_dim, xf = p.xyz_freq, tf = p.time_freq;
-    for (int e = tid; e < fd * SR; e += ST) {
+    for (int e = tid; e < fd * SR; e += NT) {
         const int jj = e / fd, f = e - jj * fd;
         const long row = row0 + jj;
         buf[sidx(f, jj)] = row < p.rows ? p.feature[row * fd + f] : 0.f;
     }
-    for (int e = tid; e < 3 * xf * SR; e += ST) {
+    for (int e = tid; e < 3 * xf * SR; e += NT) {
         const int jj = e % SR, cf = e / SR;  // cf = c*xf + fr
         const int c = cf / xf, fr = cf - c * xf;
         const long row = row0 + jj;
@@ -41,7 +42,7 @@ __device__ __forceinline__ void build_input_s(float* buf, const MlpDev& p, long 
         buf[sidx(f + 1, jj)] = cv;
     }
     const float tv = tf > 0 ? p.t[0] : 0.f;
-    for (int e = tid; e < tf * SR; e += ST) {
+    for (int e = tid; e < tf * SR; e += NT) {
         const int jj = e % SR, fr = e / SR;
         float sv, cv;
         sincosf(tv * (float)(1u << fr), &sv, &cv);
@@ -50,12 +51,13 @@ __device__ __forceinline__ void build_input_s(float* buf, const MlpDev& p, long 
         buf[sidx(f, jj)] = ok ? sv : 0.f;
         buf[sidx(f + 1, jj)] = ok ? cv : 0.f;
     }
-    for (int e = tid; e < (k16 - p.in_dim) * SR; e += ST) buf[sidx(p.in_dim + e / SR, e % SR)] = 0.f;
+    for (int e = tid; e < (k16 - p.in_dim) * SR; e += NT) buf[sidx(p.in_dim + e / SR, e % SR)] = 0.f;
 }
 
 // coalesced copy LDS act^T[0:nf][16] -> global dst[(row0+jj)*ld + f]
+template <int NT = 512>
 __device__ __forceinline__ void store_rows_s(const float* buf, float* dst, int nf, int nf_valid, int ld, long row0, long rows, int tid) {
-    for (int e = tid; e < nf * SR; e += ST) {
+    for (int e = tid; e < nf * SR; e += NT) {
         const int jj = e / nf, f = e - jj * nf;
         if (row0 + jj < rows) dst[(row0 + jj) * (long)ld + f] = f < nf_valid ? buf[sidx(f, jj)] : 0.f;
     }
@@ -477,4 +479,169 @@ __global__ __launch_bounds__(ST) void gp_mlp_bwd_data_small_adam_kernel(MlpDev p
                                                                         int zero_grad, const uint32_t* __restrict__ skip_flag) {
     if (blockIdx.x < n_mlp) mlp_bwd_data_small_body(p, saved_h, dL_dout, dz, dfeature, dxyz, blockIdx.x);
     else adam_chunk_body<ST>(t, blockIdx.x - n_mlp, threadIdx.x, b1, b2, eps, zero_grad, skip_flag);
+}
+
+// ------------------------------------------------------------------------------------------------
+// FEATURE-SPLIT forward for <= 512 rows (round 6).  What bounds the 16-row kernels above is the rate at which ONE CU takes the layer
+// weights in (~25 B/clk: 8.7 us per 256 x 256 layer, 4 layers), and every workgroup needs ALL the weights however few rows it owns: more
+// workgroups along the rows buy nothing.  Here the 16 row tiles are split along the FEATURES as well: workgroup (row tile rt, feature
+// tile ft) computes 16 rows x 16 features of every hidden layer -- 16 KB of weights per layer instead of 256 KB, requested for all
+// layers before the first product -- and the 16 workgroups of a row tile exchange the layer's activations through memory: the saved
+// activations of the training pass ARE the exchange buffer (the scratch's when nothing is saved).  Per layer: wait for the 16 arrivals of
+// the layer before (one counter per (row tile, layer) in the caller's scratch; agent-scope release / acquire around it), 4 x 16 B per lane
+// straight from memory as the MFMA's B operand, K split over the 4 waves (16 MFMAs each), the four partial tiles added in a fixed order
+// through LDS, bias + ReLU, 64 B per row to the exchange buffer, arrive.  The 16 workgroups of a row tile are placed on ONE XCD (blockIdx
+// & 7 = XCD: the exchange stays in that XCD's L2; correctness does not depend on it).  Feature tile 0 also writes the input tile and runs
+// the output layer; having passed the last counter it knows every partner has passed all of its own and zeroes the row tile's counters:
+// the scratch returns to its initial state at the end of every launch.  A counter that does not fill (partners not resident: the host
+// checks the occupancy before choosing this kernel) ends the wait after ~1 s and raises bit 0 of the scratch's error word instead of
+// hanging.  The XCD-local form of the exchange (ns_arrive / ns_wait below) NEEDS the one-XCD placement: every workgroup publishes its
+// XCC_ID, a row tile seen on two XCDs raises bit 1 of the error word, and the host validates the first launch on a device before it
+// trusts the form (gp_capi_deform.hip; otherwise the agent-scope form or the 16-row kernels).
+// Sums: K in four quarters, each over two accumulators, added as (w0 + w1) + (w2 + w3) + bias -- another order than the 16-row kernels'
+// single chain (agreement ~1e-7 relative; the golden-vector tests hold both).
+// ------------------------------------------------------------------------------------------------
+#define NS_T 256
+// LOCAL: the 16 workgroups of a row tile share an XCD, whose L2 is then the point of coherence -- stores are complete there once the
+// wave's counter has drained (the L1 writes through), the counter is an L2 atomic, and nothing has to be written back or invalidated
+// (the agent-scope form's L2 write-backs / invalidations serialise per XCD: 93 us at 256 workgroups, 177 us at 512).
+template <bool LOCAL>
+__device__ __forceinline__ void ns_arrive(uint32_t* flag) {          // every thread of the workgroup calls it, behind its stores
+    if constexpr (LOCAL) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_fetch_add(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            __hip_atomic_fetch_add(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+template <bool LOCAL>
+__device__ __forceinline__ void ns_wait(uint32_t* flag, uint32_t target, uint32_t* err) {
+    if (threadIdx.x == 0) {
+        unsigned spins = 0;
+        // (an agent-scope load: never answered by the CU's L1 -- a workgroup-scope read-modify-write of 0 was turned into a plain load
+        // and spun on the L1's copy until the limit below)
+        while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > (1u << 23)) { __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+        }
+        if constexpr (!LOCAL) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    __syncthreads();
+}
+// the 4 x 4 MFMAs of a wave's K quarter: A = 4 float4 of weights, B = 4 float4 of activations (lane (i, kg): k = 16 q + 4 kg + 0..3)
+__device__ __forceinline__ f32x4 ns_product(const float4 (&a)[4], const float4 (&b)[4]) {
+    f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = c0;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[g].x, b[g].x, c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[g].y, b[g].y, c1, 0, 0, 0);
+        c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[g].z, b[g].z, c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[g].w, b[g].w, c1, 0, 0, 0);
+    }
+    return c0 + c1;
+}
+
+template <bool LOCAL>
+__device__ __forceinline__ void mlp_fwd_split_small_body(const MlpDev& p, float* __restrict__ out, float* __restrict__ saved_x,
+                                                         float* hx /* [4][rows][256]: read AND written, by other CUs too */,
+                                                         uint32_t* flags, uint32_t* err) {
+    __shared__ float s_in[SW * SR];
+    __shared__ __attribute__((aligned(16))) float s_part[4][SR * 16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 15, kg = lane >> 4;
+    const unsigned slot = blockIdx.x >> 3;
+    const int rt = (int)((slot >> 4) * 8 + (blockIdx.x & 7)), ft = (int)(slot & 15);
+    const long row0 = (long)rt * SR;
+    if (row0 >= p.rows) return;
+    const int f0 = 16 * ft;
+    uint32_t* fl = flags + 32 * rt;         // a row tile's counters in a 128-byte line of their own (all tiles' in one line: every
+                                            // arrival and every poll of 256 workgroups met at the same address -- 22 us instead of 17 at 250 rows)
+    uint32_t* xm = fl + 4;                  // which XCDs the row tile's workgroups run on (LOCAL: it must be one)
+    if (LOCAL && tid == 0)
+        __hip_atomic_fetch_or(xm, 1u << (__builtin_amdgcn_s_getreg(20 | (3 << 11)) & 15u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // HW_REG_XCC_ID[3:0]
+    const size_t lstride = (size_t)p.rows * SW;
+    // every weight this workgroup will need, requested now
+    float4 wr[3][4], w4[4];
+#pragma unroll
+    for (int l = 1; l < 4; ++l)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) wr[l - 1][g] = *(const float4*)(p.w[l] + (size_t)(f0 + i) * SW + 16 * (4 * wave + g) + 4 * kg);
+    if (ft == 0) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) w4[g] = *(const float4*)(p.w[4] + (size_t)(i < p.out_dim ? i : 0) * SW + 16 * (4 * wave + g) + 4 * kg);
+    }
+    float bias[4];
+#pragma unroll
+    for (int l = 0; l < 4; ++l) bias[l] = p.b[l][f0 + (tid & 15)];
+    const int k16 = (p.in_dim + 15) & ~15, nq0 = k16 / 16;
+    float4 w0[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {           // layer 0: k-steps wave, wave + 4, ... (in_dim <= 256: at most four per wave)
+        const int k = 16 * (wave + 4 * g) + 4 * kg;
+        w0[g] = k < p.in_dim ? *(const float4*)(p.w[0] + (size_t)(f0 + i) * p.in_dim + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    build_input_s<NS_T>(s_in, p, row0, tid, k16);
+    __syncthreads();
+    if (ft == 0 && saved_x) store_rows_s<NS_T>(s_in, saved_x, p.in_pad, p.in_dim, p.in_pad, row0, p.rows, tid);
+    auto reduce = [&](const f32x4& acc) {       // the tile's element (row tid >> 4, feature tid & 15) without bias
+        *(float4*)&s_part[wave][i * 16 + 4 * kg] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        __syncthreads();
+        return (s_part[0][tid] + s_part[1][tid]) + (s_part[2][tid] + s_part[3][tid]);
+    };
+    const long my_row = row0 + (tid >> 4);
+    {   // layer 0: B from the LDS input tile (k >= in_dim: zero rows of the tile against zero weights)
+        float4 b[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int q = wave + 4 * g;
+            if (q < nq0) {
+                const float* bp = s_in + (16 * q + kg) * SR + i;        // row pi(16 q + 4 kg + u) = 16 q + 4 u + kg
+                b[g] = make_float4(bp[0], bp[4 * SR], bp[8 * SR], bp[12 * SR]);
+            } else b[g] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        const float v = fmaxf(reduce(ns_product(w0, b)) + bias[0], 0.f);
+        if (my_row < p.rows) hx[my_row * SW + f0 + (tid & 15)] = v;
+        ns_arrive<LOCAL>(fl + 0);
+    }
+    const long rowc = row0 + i < p.rows ? row0 + i : p.rows - 1;       // (rows beyond the input: a valid row's values, never stored)
+#pragma unroll
+    for (int l = 1; l < 4; ++l) {
+        ns_wait<LOCAL>(fl + l - 1, 16u, err);
+        const float* src = hx + (size_t)(l - 1) * lstride + rowc * SW + 64 * wave + 4 * kg;
+        float4 b[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) b[g] = *(const float4*)(src + 16 * g);
+        const float v = fmaxf(reduce(ns_product(wr[l - 1], b)) + bias[l], 0.f);
+        if (my_row < p.rows) hx[(size_t)l * lstride + my_row * SW + f0 + (tid & 15)] = v;
+        ns_arrive<LOCAL>(fl + l);
+    }
+    if (ft != 0) return;
+    ns_wait<LOCAL>(fl + 3, 16u, err);
+    if (tid < 4) fl[tid] = 0u;              // every partner has passed all of its waits: the counters return to zero for the next launch
+    if (LOCAL && tid == 0) {                // (every partner's bit is in: each set its own before its first arrival)
+        const uint32_t m = __hip_atomic_load(xm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (m & (m - 1u)) __hip_atomic_fetch_or(err, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *xm = 0u;
+    }
+    {
+        const float* src = hx + (size_t)3 * lstride + rowc * SW + 64 * wave + 4 * kg;
+        float4 b[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) b[g] = *(const float4*)(src + 16 * g);
+        const float v = reduce(ns_product(w4, b));
+        const int f = tid & 15;
+        if (f < p.out_dim && my_row < p.rows) out[my_row * p.out_dim + f] = v + p.b[4][f];
+    }
+}
+__global__ __launch_bounds__(NS_T) void gp_mlp_fwd_split_small_kernel(MlpDev p, float* __restrict__ out, float* __restrict__ saved_x, float* hx,
+                                                                      uint32_t* flags, uint32_t* err) {
+    mlp_fwd_split_small_body<true>(p, out, saved_x, hx, flags, err);
+}
+__global__ __launch_bounds__(NS_T) void gp_mlp_fwd_split_small_agent_kernel(MlpDev p, float* __restrict__ out, float* __restrict__ saved_x,
+                                                                            float* hx, uint32_t* flags, uint32_t* err) {
+    mlp_fwd_split_small_body<false>(p, out, saved_x, hx, flags, err);
 }

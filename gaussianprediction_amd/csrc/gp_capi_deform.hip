@@ -23,6 +23,7 @@ static int make_mlp(const gp_mlp_params* p, const gp_mlp_input* x, MlpDev& m) {
     m.feature = x->feature; m.xyz = x->xyz; m.t = x->t;
     m.pk = p->packed;
     if (m.pk && ((uintptr_t)m.pk & 15) != 0) GP_FAIL("gp_mlp_params.packed must be 16-byte aligned");
+    if (p->scratch && ((uintptr_t)p->scratch & 15) != 0) GP_FAIL("gp_mlp_params.scratch must be 16-byte aligned");
     return 0;
 }
 
@@ -52,6 +53,43 @@ static inline size_t acts_x_floats(const MlpDev& m) { return (size_t)m.rows * m.
 
 #define GP_MLP_SMALL_ROWS 2048
 #define GP_MLP_LARGE_ROWS 32768
+#define GP_MLP_SPLIT_ROWS 512       // the feature-split kernel's range (deform_mlp_small.hip): <= 32 row tiles x 16 feature tiles
+#define GP_MLP_SCRATCH_FLAG_BYTES 8192       // 32 row tiles x 128 B of counters, the error word at byte 4096
+#define GP_MLP_SCRATCH_ERR_WORD 1024
+
+extern "C" int64_t gp_mlp_scratch_bytes(int64_t rows) {
+    if (rows <= 0 || rows > GP_MLP_SPLIT_ROWS) return 0;
+    return GP_MLP_SCRATCH_FLAG_BYTES + (int64_t)4 * rows * 256 * (int64_t)sizeof(float);
+}
+
+// the feature-split forward's grid, or 0 where it cannot run: its workgroups wait for each other, so all of them must be resident.
+// mode: 1 = XCD-local exchange, validated on this device; 2 = XCD-local, FIRST launch (the caller validates it); 3 = agent-scope fences
+static unsigned mlp_split_grid(const MlpDev& m, const void* scratch, int& mode, int*& state_out) {
+    mode = 0; state_out = nullptr;
+    if (!scratch || m.rows > GP_MLP_SPLIT_ROWS || gp_debug_get(13) == 1) return 0;
+    const unsigned rt = (unsigned)((m.rows + 15) / 16), grid = 8u * 16u * ((rt + 7u) / 8u);
+    // per device: how many workgroups of the kernel the part holds at once (0: not asked yet), and what the first launch showed
+    // (0 not run, 1 XCD-local placement holds, -1 it does not: the 16-row kernels from then on)
+    static int resident[32] = {0}, state[32] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32) return 0;
+    if (__atomic_load_n(&resident[dev], __ATOMIC_RELAXED) == 0) {
+        int per_cu = 0, r = -1;
+        hipDeviceProp_t prop;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gp_mlp_fwd_split_small_kernel, 256, 0) == hipSuccess &&
+            hipGetDeviceProperties(&prop, dev) == hipSuccess && per_cu * prop.multiProcessorCount > 0)
+            r = per_cu * prop.multiProcessorCount;
+        else (void)hipGetLastError();
+        __atomic_store_n(&resident[dev], r, __ATOMIC_RELAXED);
+    }
+    if (__atomic_load_n(&resident[dev], __ATOMIC_RELAXED) < (int)grid) return 0;
+    if (gp_debug_get(13) == 2) { mode = 3; return grid; }
+    const int st = __atomic_load_n(&state[dev], __ATOMIC_ACQUIRE);
+    if (st < 0) return 0;
+    mode = st > 0 ? 1 : 2;
+    state_out = &state[dev];
+    return grid;
+}
 
 extern "C" int gp_mlp_forward(const gp_mlp_params* p, const gp_mlp_input* x, float* out, float* acts, gp_stream_t stream_) {
     MlpDev m;
@@ -62,7 +100,30 @@ extern "C" int gp_mlp_forward(const gp_mlp_params* p, const gp_mlp_input* x, flo
     float* sh = acts ? acts + gp_align_up(acts_x_floats(m), 64) : nullptr;
     { GpProfScope _p("mlp_fwd", (hipStream_t)stream_);
         // few rows (stage 2/3: the keypoints): 16-row workgroups on v_mfma_f32_16x16x4_f32 spread the work over twice the CUs
-        if (m.rows <= GP_MLP_SMALL_ROWS)
+        int mode = 0;
+        int* state = nullptr;
+        const unsigned split = mlp_split_grid(m, p->scratch, mode, state);
+        if (split) {    // <= 512 rows with a scratch: 16 feature tiles per row tile (the saved activations are the exchange buffer)
+            float* hx = sh ? sh : (float*)((char*)p->scratch + GP_MLP_SCRATCH_FLAG_BYTES);
+            uint32_t* flags = (uint32_t*)p->scratch;
+            hipLaunchKernelGGL(mode == 3 ? gp_mlp_fwd_split_small_agent_kernel : gp_mlp_fwd_split_small_kernel, dim3(split), dim3(256), 0,
+                               (hipStream_t)stream_, m, out, sx, hx, flags, flags + GP_MLP_SCRATCH_ERR_WORD);
+            if (mode == 2) {
+                // The FIRST launch of the XCD-local form on this device is validated before the form is trusted: wait for it, read the
+                // scratch's error word (a counter that never filled; a row tile's workgroups on two XCDs).  A bad word: the word is
+                // cleared, the device is marked, and this call's result comes from the 16-row kernel -- as every later one's will.
+                uint32_t e = 1;
+                if (hipGetLastError() != hipSuccess || hipStreamSynchronize((hipStream_t)stream_) != hipSuccess ||
+                    hipMemcpy(&e, flags + GP_MLP_SCRATCH_ERR_WORD, sizeof(e), hipMemcpyDeviceToHost) != hipSuccess) e = 1;
+                if (e != 0) {
+                    (void)hipGetLastError();
+                    __atomic_store_n(state, -1, __ATOMIC_RELEASE);
+                    GP_HIP_CHECK(hipMemsetAsync(flags, 0, GP_MLP_SCRATCH_FLAG_BYTES, (hipStream_t)stream_));
+                    hipLaunchKernelGGL(gp_mlp_fwd_small_kernel, dim3(gp_blocks((size_t)m.rows, 16)), dim3(512), 0, (hipStream_t)stream_, m, out, sx, sh);
+                } else __atomic_store_n(state, 1, __ATOMIC_RELEASE);
+            }
+        }
+        else if (m.rows <= GP_MLP_SMALL_ROWS)
             hipLaunchKernelGGL(gp_mlp_fwd_small_kernel, dim3(gp_blocks((size_t)m.rows, 16)), dim3(512), 0, (hipStream_t)stream_, m, out, sx, sh);
         else if (m.rows >= GP_MLP_LARGE_ROWS)   // two row tiles per workgroup: half the weight traffic from L2
             hipLaunchKernelGGL(gp_mlp_fwd2_kernel, dim3(gp_blocks((size_t)m.rows, 64)), dim3(512), 0, (hipStream_t)stream_, m, out, sx, sh,

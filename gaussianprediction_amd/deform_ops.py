@@ -27,6 +27,7 @@ def _c(t):
 _PACK_CACHE = {}           # id(layer-0 weight) -> (key, packed tensor)
 SMALL_ROWS = 2048          # csrc/gp_capi_deform.hip: GP_MLP_SMALL_ROWS
 FORCE_PACKED = False       # (tests: use the packed copy under autograd too)
+FORCE_ROW_TILES = False    # (tests, A/B: the 16-row kernels where the feature-split forward would run)
 
 
 def packed_weights(wb, ws):
@@ -52,6 +53,29 @@ def packed_weights(wb, ws):
         _PACK_CACHE.clear()
     _PACK_CACHE[id(leaves[0])] = (key, pk)
     return pk
+
+
+SPLIT_ROWS = 512           # csrc/gp_capi_deform.hip: GP_MLP_SPLIT_ROWS
+_SCRATCH = {}              # (device index, stream) -> zero-initialised scratch of the feature-split small-row forward
+
+
+def mlp_scratch(dev, rows):
+    """gp_mlp_params.scratch for a pass over `rows` rows on the CURRENT stream of `dev` (None where the library would not use one): one
+    buffer per (device, stream) -- calls on one stream run one after the other, and the library returns the counters to zero at the end
+    of every call -- sized for the largest row count the feature-split kernel serves, zeroed once."""
+    if not (0 < rows <= SPLIT_ROWS):
+        return None
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), int(torch.cuda.current_stream(dev).cuda_stream))
+    t = _SCRATCH.get(key)
+    if t is None:
+        n = int(_lib.lib().gp_mlp_scratch_bytes(C.c_int64(SPLIT_ROWS)))
+        if n <= 0:
+            return None
+        t = torch.zeros((n + 3) // 4, dtype=torch.int32, device=dev)
+        if len(_SCRATCH) > 64:
+            _SCRATCH.clear()
+        _SCRATCH[key] = t
+    return t
 
 
 def _input_sink(leaf, shape):
@@ -89,8 +113,11 @@ class FusedMlp(torch.autograd.Function):
         # Used where the copy is free: passes without autograd (evaluation: the weights stand still, one pack serves every frame;
         # forward 0.040 -> 0.035 ms at 250 rows).  In training the weights change every step and the 0.9 MB repack (6 us, a launch
         # of its own) costs what the faster forward + backward save (measured: 5 + 2 us) -- there the kernels read w[] directly.
-        pk = packed_weights(wb, ws) if (0 < rows <= SMALL_ROWS and (not need_grad or FORCE_PACKED)) else None
+        # (rows <= 512: the feature-split kernel reads w[] -- 16 KB per layer and workgroup -- and needs no copy, only its scratch)
+        scratch = mlp_scratch(dev, rows) if not (FORCE_PACKED or FORCE_ROW_TILES) else None
+        pk = packed_weights(wb, ws) if (0 < rows <= SMALL_ROWS and scratch is None and (not need_grad or FORCE_PACKED)) else None
         params.packed = pk.data_ptr() if pk is not None else None
+        params.scratch = scratch.data_ptr() if scratch is not None else None
         inp = _lib.MlpInputC(rows, fd, int(xyz_freq), int(time_freq), feature_c.data_ptr(),
                              xyz_c.data_ptr() if xyz_c is not None else None, t_c.data_ptr() if t_c is not None else None)
         with _lib.on_device(dev):

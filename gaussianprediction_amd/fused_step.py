@@ -85,6 +85,11 @@ class FusedStage3:
         for l in range(5):
             P.mlp.w[l], P.mlp.b[l] = wb[2 * l].data_ptr(), wb[2 * l + 1].data_ptr()
             P.g_mlp.dw[l], P.g_mlp.db[l] = wb[2 * l].grad.data_ptr(), wb[2 * l + 1].grad.data_ptr()
+        # (K <= 512: the feature-split forward of the keypoint MLP; in the fused step the saved activations are its exchange buffer, the
+        # scratch holds the counters.  The plan runs on one stream: the scratch of that stream, deform_ops.mlp_scratch)
+        from .deform_ops import mlp_scratch
+        self.mlp_scratch = mlp_scratch(dev, K)
+        P.mlp.scratch = self.mlp_scratch.data_ptr() if self.mlp_scratch is not None else None
         P.feature_dim, P.xyz_freq, P.time_freq = fd, xyz_freq, time_freq
         P.raw_w, P.knn_idx = self.raw_w.data_ptr(), self.knn.data_ptr()
         P.knn_idx16 = self.idx16.data_ptr() if self.idx16 is not None else None

@@ -184,7 +184,16 @@ typedef struct gp_mlp_params {
     const float* packed; /* optional (NULL = read w[] as they are): gp_mlp_pack's fragment-ordered copy of w[0..3]; used by the
                           * passes over <= 2048 rows (stage 2/3: the rows are the keypoints), which are bound by the rate at which a
                           * single CU takes the weights in.  Must describe the CURRENT values of w[0..3]. */
+    void* scratch;       /* optional (NULL = the 16-row kernels): gp_mlp_scratch_bytes(rows) bytes of device memory, ZEROED ONCE by the caller
+                          * and then left to the library -- for passes over <= 512 rows gp_mlp_forward then splits every row tile along
+                          * the features over 16 workgroups that exchange the activations through memory (counters in the scratch, back
+                          * at zero when the call's kernel ends; the hidden activations too when `acts` is NULL): the weights each CU has to
+                          * take in drop 16-fold.  ONE scratch per stream: calls that may run at the same time need their own.  The 32-bit word
+                          * at byte 4096 is raised if a counter never filled (bit 0) or a row tile's workgroups ran on two XCDs (bit 1):
+                          * the result is then undefined (the library validates the first launch on a device and falls back by itself). */
 } gp_mlp_params;
+/* 0 where the scratch is not used (rows > 512) */
+int64_t gp_mlp_scratch_bytes(int64_t rows);
 
 /* fragment-ordered copy of w[0..3] (both the forward's and the backward's operand order; gp_mlp_packed_floats(in_dim) floats,
  * 16-byte aligned): one contiguous kilobyte per wavefront operand load instead of sixteen 64-byte pieces.  Repack whenever the

@@ -230,8 +230,8 @@ def test_small_row_mlp_with_fragment_ordered_weights_is_bit_identical():
     the arithmetic: same result, bit for bit, forward and backward, and it follows the weights when they change."""
     from gaussianprediction_amd import deform_ops
     net, _ = _net(3, 108, 7)
-    feat = (torch.rand(250, 32, device="cuda") - 0.5)
-    xyz = torch.rand(250, 3, device="cuda") * 2 - 1
+    feat = (torch.rand(600, 32, device="cuda") - 0.5)               # (> 512 rows: up to there the feature-split forward runs, below)
+    xyz = torch.rand(600, 3, device="cuda") * 2 - 1
     t = torch.tensor([0.37], device="cuda")
     f1 = feat.clone().requires_grad_(True)
     y_plain = net.forward_fused(f1, xyz, t, 10, 8)                   # autograd on: w[] read directly
@@ -260,6 +260,74 @@ def test_small_row_mlp_with_fragment_ordered_weights_is_bit_identical():
     assert torch.equal(y3.detach(), y2)
     for a, b in zip([p.grad for p in net.parameters()] + [f2.grad], g_ref):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("rows", [1, 17, 250, 400, 512])
+def test_feature_split_small_row_forward(rows):
+    """Round 6: up to 512 rows gp_mlp_forward splits every 16-row tile along the features over 16 workgroups that exchange the layer
+    activations through memory (gp_mlp_params.scratch; csrc/deform_mlp_small.hip).  Against the 16-row kernels (another summation
+    order: ~1e-7): the output, the saved input tile (identical) and the saved activations; the gradients of the backward that reads what
+    the forward saved -- on the rows where the two forms agree about every ReLU (a hidden unit whose pre-activation lies within rounding
+    of zero is on in one order and off in the other: seen, e.g. 1.1e-8 against 0 at 400 rows; such rows are counted and bounded, the
+    weight gradients are compared when there is none).  The XCD-local and the agent-scope form of the exchange are the same arithmetic
+    (bit-identical); a pass without saved activations gives the same values; the scratch is back at zero after every call, error word clear."""
+    from gaussianprediction_amd import _lib, deform_ops
+    net, _ = _net(5, 104, 7)
+    g = torch.Generator("cuda").manual_seed(rows)
+    feat = (torch.rand(rows, 32, device="cuda", generator=g) - 0.5) * 3
+    xyz = torch.rand(rows, 3, device="cuda", generator=g) * 2.6 - 1.3
+    gy = torch.randn(rows, 7, device="cuda", generator=g)
+    t = torch.tensor([0.41], device="cuda")
+    in_pad, x_floats = 104, (rows * 104 + 63) // 64 * 64
+
+    class Ctx:
+        def save_for_backward(self, *a):
+            self.saved = a
+
+    def run(row_tiles, grad=True):
+        deform_ops.FORCE_ROW_TILES = row_tiles
+        try:
+            f = feat.clone().requires_grad_(grad)
+            x = xyz.clone().requires_grad_(grad)
+            net.zero_grad(set_to_none=True)
+            if not grad:
+                with torch.no_grad():
+                    return [net.forward_fused(f, x, t, 10, 6).clone()]
+            ctx = Ctx()
+            deform_ops.FusedMlp.forward(ctx, f, x, t, 10, 6, *net._wb())      # (the saved record of this form)
+            acts = ctx.saved[3]
+            y = net.forward_fused(f, x, t, 10, 6)
+            y.backward(gy)
+            return [y.detach().clone(), acts[:rows * in_pad].clone(), acts[x_floats:x_floats + 4 * rows * 256].view(4, rows, 256).clone(),
+                    f.grad.clone(), x.grad.clone()] + [p.grad.clone() for p in net.parameters()]
+        finally:
+            deform_ops.FORCE_ROW_TILES = False
+
+    close = lambda u, v: float((u - v).abs().max()) <= 2e-6 * max(1.0, float(v.abs().max()))
+    a, b = run(False), run(True)
+    assert close(a[0], b[0]) and torch.equal(a[1], b[1]) and close(a[2], b[2])
+    flipped = ((a[2] > 0) != (b[2] > 0)).any(dim=2).any(dim=0)     # rows on which the forms disagree about a ReLU
+    assert int(flipped.sum()) <= 2, int(flipped.sum())
+    keep = ~flipped
+    assert close(a[3][keep], b[3][keep]) and close(a[4][keep], b[4][keep])
+    if not bool(flipped.any()):
+        for u, v in zip(a[5:], b[5:]):
+            assert close(u, v)
+    assert torch.equal(run(False, grad=False)[0], a[0])             # without saved activations: the scratch's exchange region, same values
+    L = _lib.lib()
+    _lib.check(L.gp_debug_option(13, 2), "opt")                     # the agent-scope form of the exchange
+    try:
+        c = run(False)
+    finally:
+        _lib.check(L.gp_debug_option(13, 0), "opt")
+    for u, v in zip(a, c):
+        assert torch.equal(u, v)
+    for _ in range(20):                                             # back to back on one stream: every call finds the counters at zero
+        y = run(False, grad=False)[0]
+    assert torch.equal(y, a[0])
+    sc = deform_ops.mlp_scratch(feat.device, rows)
+    torch.cuda.synchronize()
+    assert int((sc[:2048] != 0).sum()) == 0, "counters / error word of the scratch"
 
 
 # ---- the range guard of precision="fp32s" (round-4 verdict: hi = fp16(x) saturates at 65504, silently) ----------------------------------

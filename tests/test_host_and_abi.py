@@ -29,7 +29,7 @@ def test_struct_sizes_match_header_layout():
     assert C.sizeof(_lib.RasterSavedC) == 7 * 8
     assert C.sizeof(_lib.RasterGradsC) == 9 * 8 + 8 + 8     # + accumulate_shs (padded) + adam_shs
     assert C.sizeof(_lib.AdamFuseC) == 4 * 8 + 5 * 4 + 4 + 8 + 8   # 4 pointers, 5 floats + pad, step, skip_flag
-    assert C.sizeof(_lib.MlpParamsC) == 4 * 4 + 11 * 8
+    assert C.sizeof(_lib.MlpParamsC) == 4 * 4 + 12 * 8      # 4 dims, w[5], b[5], packed, scratch (round 6)
     assert C.sizeof(_lib.MlpInputC) == 8 + 3 * 4 + 4 + 3 * 8
     assert C.sizeof(_lib.BlendArgsC) == 2 * 8 + 3 * 4 + 4 + 6 * 8
 
