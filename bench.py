@@ -343,7 +343,8 @@ def main():
                          "fused step (gp_train_step_run): the A/B of TrainStep(fused=...)")
     ap.add_argument("--no-early-adam", action="store_true",
                     help="fused step: ONE optimizer launch behind the backward instead of the per-Gaussian tensors' Adam update riding in the "
-                         "launch of the keypoint MLP's data backward (gp_step_update.adam_early_mask; A/B: profiles/r06_adam_rider_ab.txt)")
+                         "launch of the keypoint MLP's data backward (gp_step_update.adam_early_mask; A/B: profiles/r06_adam_rider_ab.txt).  The "
+                         "rider travels with the 16-row MLP kernels only (more than 512 keypoints, or --debug-option 13=1)")
     ap.add_argument("--debug-option", action="append", default=[], metavar="KEY=VALUE",
                     help="gp_debug_option(KEY, VALUE) before the run (the library's A/B knobs, e.g. 8=2: the three-pass 11-bit depth sort); repeatable")
     ap.add_argument("--render-only", action="store_true", help="time eval-style forward renders instead of train steps")
@@ -656,7 +657,7 @@ def main():
                        "step_driver": (f"one library call per step (gp_train_step_run): {getattr(ts, 'fused_steps', 0)} of the steps since the set-up"
                                        + ("; the per-Gaussian tensors' Adam update rides in the launch of the keypoint MLP's data backward "
                                           "(kernels_ms.adam = that launch + the MLP tensors' update; no mlp_bwd_data entry)"
-                                          if (getattr(ts, "early_adam", False) and world == 1) else "")
+                                          if (getattr(getattr(getattr(ts, "_fused_plan", None), "upd", None), "adam_early_mask", 0) and world == 1) else "")
                                        if getattr(ts, "fused_steps", 0) else "autograd graph (render -> loss -> backward -> FusedAdam.step)"),
                        "binning": "exact (R read back every step)" if args.exact_binning else
                                   f"capacity mode in warm-up and timed steps (no host sync; {preroll} exact-mode set-up steps before the "

@@ -645,3 +645,144 @@ __global__ __launch_bounds__(NS_T) void gp_mlp_fwd_split_small_agent_kernel(MlpD
                                                                             float* hx, uint32_t* flags, uint32_t* err) {
     mlp_fwd_split_small_body<false>(p, out, saved_x, hx, flags, err);
 }
+
+// ------------------------------------------------------------------------------------------------
+// FEATURE-SPLIT data backward for <= 512 rows (round 6): the forward's scheme run backwards.  Workgroup (row tile, feature tile ft) owns
+// 16 of the 256 columns of every dZ buffer (which the weight-gradient kernel needs in memory anyway: they are the exchange buffers):
+//   step 0: dZ_4 = gate(W_4^T dL/dout)            (K = out_dim: one wave)        -> arrive 0
+//   step s = 1..3: wait s - 1; dZ_{4-s} = gate(W_{4-s}^T dZ_{5-s}), K over the 4 waves -> arrive s
+//   feature tiles below ceil(in_dim / 16): wait 3; dX = W_0^T dZ_1; d feature written by its owners; the encoding's part of dX goes
+//   through the scratch's exchange region (free in a training pass: the forward exchanged through the saved activations) -> arrive 4;
+//   feature tile 0: wait 4, counters back to zero, d xyz through the encoding's derivative.
+// Counters: words 8..12 of the row tile's line in gp_mlp_params.scratch, XCC mask in word 13.  Same sums as the forward's remark: K in
+// four quarters over two accumulators each -- another order than the 16-row kernel's.
+// ------------------------------------------------------------------------------------------------
+template <bool LOCAL>
+__device__ __forceinline__ void mlp_bwd_data_split_small_body(const MlpDev& p, const float* __restrict__ saved_h, const float* __restrict__ dL_dout,
+                                                              float* dz /* [4][rows][256]: exchange */, float* __restrict__ dfeature,
+                                                              float* __restrict__ dxyz, float* gx /* [rows][in_pad]: exchange */,
+                                                              uint32_t* flags, uint32_t* err, unsigned block) {
+    __shared__ __attribute__((aligned(16))) float s_part[4][SR * 16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 15, kg = lane >> 4;
+    const unsigned slot = block >> 3;
+    const int rt = (int)((slot >> 4) * 8 + (block & 7)), ft = (int)(slot & 15);
+    const long row0 = (long)rt * SR;
+    if (row0 >= p.rows) return;
+    const int f0 = 16 * ft, nft0 = (p.in_dim + 15) / 16;
+    uint32_t* fl = flags + 32 * rt + 8;
+    uint32_t* xm = fl + 5;
+    if (LOCAL && tid == 0)
+        __hip_atomic_fetch_or(xm, 1u << (__builtin_amdgcn_s_getreg(20 | (3 << 11)) & 15u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // HW_REG_XCC_ID[3:0]
+    const size_t lstride = (size_t)p.rows * SW;
+    const bool want_dx = (dfeature || dxyz) && ft < nft0;
+    // every operand that does not come out of the exchange, requested now
+    float4 a4 = make_float4(0.f, 0.f, 0.f, 0.f), b4 = a4, wt[3][4], a0[4];
+    const long rowc = row0 + i < p.rows ? row0 + i : p.rows - 1;
+    if (wave == 0) {
+        float* av = (float*)&a4; float* bv = (float*)&b4;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int k = 4 * kg + u;
+            av[u] = k < p.out_dim ? p.w[4][(size_t)k * SW + f0 + i] : 0.f;
+            bv[u] = k < p.out_dim ? dL_dout[rowc * p.out_dim + k] : 0.f;
+        }
+    }
+#pragma unroll
+    for (int l = 3; l >= 1; --l)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float* w = p.w[l] + (size_t)(16 * (4 * wave + g) + 4 * kg) * SW + f0 + i;
+            wt[l - 1][g] = make_float4(w[0], w[SW], w[2 * SW], w[3 * SW]);
+        }
+    if (want_dx) {
+        const int c = f0 + i;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float* w = p.w[0] + (size_t)(16 * (4 * wave + g) + 4 * kg) * p.in_dim + (c < p.in_dim ? c : 0);
+            a0[g] = c < p.in_dim ? make_float4(w[0], w[p.in_dim], w[2 * p.in_dim], w[3 * p.in_dim]) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    const long my_row = row0 + (tid >> 4), my_rowc = my_row < p.rows ? my_row : p.rows - 1;
+    float hv[4];
+#pragma unroll
+    for (int l = 0; l < 4; ++l) hv[l] = saved_h[(size_t)l * lstride + my_rowc * SW + f0 + (tid & 15)];
+    auto reduce = [&](const f32x4& acc) {       // the tile's element (row tid >> 4, feature tid & 15)
+        *(float4*)&s_part[wave][i * 16 + 4 * kg] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        __syncthreads();
+        return (s_part[0][tid] + s_part[1][tid]) + (s_part[2][tid] + s_part[3][tid]);
+    };
+    {   // step 0
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        if (wave == 0) {
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, b4.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, b4.y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, b4.z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, b4.w, acc, 0, 0, 0);
+        }
+        const float v = reduce(acc);
+        if (my_row < p.rows) dz[(size_t)3 * lstride + my_row * SW + f0 + (tid & 15)] = hv[3] > 0.f ? v : 0.f;
+        ns_arrive<LOCAL>(fl + 0);
+    }
+#pragma unroll
+    for (int s = 1; s < 4; ++s) {
+        const int l = 4 - s;            // reads dZ buffer l, writes buffer l - 1 through W_l^T
+        ns_wait<LOCAL>(fl + s - 1, 16u, err);
+        const float* src = dz + (size_t)l * lstride + rowc * SW + 64 * wave + 4 * kg;
+        float4 b[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) b[g] = *(const float4*)(src + 16 * g);
+        const float v = reduce(ns_product(wt[l - 1], b));
+        if (my_row < p.rows) dz[(size_t)(l - 1) * lstride + my_row * SW + f0 + (tid & 15)] = hv[l - 1] > 0.f ? v : 0.f;
+        ns_arrive<LOCAL>(fl + s);
+    }
+    if (ft >= nft0) return;             // (feature tile 0 is below nft0: in_dim >= 1)
+    ns_wait<LOCAL>(fl + 3, 16u, err);
+    if (dfeature || dxyz) {
+        const float* src = dz + rowc * SW + 64 * wave + 4 * kg;
+        float4 b[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) b[g] = *(const float4*)(src + 16 * g);
+        const float v = reduce(ns_product(a0, b));
+        const int c = f0 + (tid & 15);
+        if (my_row < p.rows && c < p.in_dim) {
+            if (dfeature && c < p.feature_dim) dfeature[my_row * p.feature_dim + c] = v;
+            if (dxyz) gx[my_row * p.in_pad + c] = v;
+        }
+    }
+    ns_arrive<LOCAL>(fl + 4);
+    if (ft != 0) return;
+    ns_wait<LOCAL>(fl + 4, (uint32_t)nft0, err);
+    if (tid < 5) fl[tid] = 0u;          // every partner has passed all of its waits: the counters return to zero for the next launch
+    if (LOCAL && tid == 0) {
+        const uint32_t m = __hip_atomic_load(xm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (m & (m - 1u)) __hip_atomic_fetch_or(err, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *xm = 0u;
+    }
+    if (dxyz && tid < 3 * SR) {         // d/dx sin(x 2^f) = 2^f cos, d/dx cos(x 2^f) = -2^f sin
+        const int jj = tid / 3, c = tid % 3;
+        const long row = row0 + jj;
+        if (row < p.rows) {
+            const float x = p.xyz[row * 3 + c];
+            const float* grow = gx + row * p.in_pad;
+            float g = 0.f;
+            for (int fr = 0; fr < p.xyz_freq; ++fr) {
+                const float sc = (float)(1u << fr);
+                float sv, cv;
+                sincosf(x * sc, &sv, &cv);
+                const int f = p.feature_dim + 2 * (c * p.xyz_freq + fr);
+                g += sc * (cv * grow[f] - sv * grow[f + 1]);
+            }
+            dxyz[row * 3 + c] = g;
+        }
+    }
+}
+__global__ __launch_bounds__(NS_T) void gp_mlp_bwd_data_split_small_kernel(MlpDev p, const float* __restrict__ saved_h, const float* __restrict__ dL_dout,
+                                                                           float* dz, float* __restrict__ dfeature, float* __restrict__ dxyz, float* gx,
+                                                                           uint32_t* flags, uint32_t* err, int agent) {
+    if (agent) mlp_bwd_data_split_small_body<false>(p, saved_h, dL_dout, dz, dfeature, dxyz, gx, flags, err, blockIdx.x);
+    else mlp_bwd_data_split_small_body<true>(p, saved_h, dL_dout, dz, dfeature, dxyz, gx, flags, err, blockIdx.x);
+}
+// (Carrying the optimizer's rider in THIS launch, as gp_mlp_bwd_data_small_adam_kernel does for the 16-row form, was built and measured:
+// 0.092 ms for the fused launch against 0.019 + 0.054 ms for the two -- under the Adam chunks' HBM stream every one of the exchange's
+// dependent trips to memory takes several times as long, and the chain of five is the kernel's critical path.  The rider stays with
+// the 16-row form: profiles/r06_adam_rider_ab.txt.)

@@ -150,7 +150,21 @@ extern "C" int gp_mlp_backward(const gp_mlp_params* p, const gp_mlp_input* x, co
     float* dz = (float*)alloc(alloc_ctx, GP_BUF_TEMP, dz_bytes);
     if (!dz) GP_FAIL("allocator returned NULL for TEMP (%zu B)", dz_bytes);
     GpAdamRider* rider = gp_adam_rider_slot();
-    if (m.rows <= GP_MLP_SMALL_ROWS && rider->armed) {
+    int split_mode = 0;
+    int* split_state = nullptr;
+    // the feature-split form (deform_mlp_small.hip) once a forward has validated its XCD-local exchange on this device (mode 1), or in
+    // the agent-scope form (mode 3)
+    const unsigned split = mlp_split_grid(m, p->scratch, split_mode, split_state);
+    if (split && (split_mode == 1 || split_mode == 3)) {
+        float* gx = (float*)((char*)p->scratch + GP_MLP_SCRATCH_FLAG_BYTES);
+        uint32_t* flags = (uint32_t*)p->scratch;
+        // (an armed rider stays armed: beside this latency-chained kernel the optimizer's stream costs more than it hides -- it is
+        // launched behind the MLP backward by its owner, gp_adam_rider_flush)
+        GpProfScope _p("mlp_bwd_data", s);
+        hipLaunchKernelGGL(gp_mlp_bwd_data_split_small_kernel, dim3(split), dim3(256), 0, s, m, sh, dL_dout, dz, dL_dfeature, dL_dxyz, gx, flags,
+                           flags + GP_MLP_SCRATCH_ERR_WORD, split_mode == 3 ? 1 : 0);
+        GP_LAUNCH_CHECK();
+    } else if (m.rows <= GP_MLP_SMALL_ROWS && rider->armed) {
         // gp_train_step_run left an optimizer launch that needs nothing of this backward: its chunks ride in the data kernel's launch
         // (deform_mlp_small.hip).  The scope carries the optimizer's name: its bytes are what the launch moves.
         rider->armed = false;

@@ -63,7 +63,7 @@ def mlp_scratch(dev, rows):
     """gp_mlp_params.scratch for a pass over `rows` rows on the CURRENT stream of `dev` (None where the library would not use one): one
     buffer per (device, stream) -- calls on one stream run one after the other, and the library returns the counters to zero at the end
     of every call -- sized for the largest row count the feature-split kernel serves, zeroed once."""
-    if not (0 < rows <= SPLIT_ROWS):
+    if not (0 < rows <= SPLIT_ROWS) or FORCE_PACKED or FORCE_ROW_TILES:
         return None
     key = (dev.index if dev.index is not None else torch.cuda.current_device(), int(torch.cuda.current_stream(dev).cuda_stream))
     t = _SCRATCH.get(key)
@@ -114,7 +114,7 @@ class FusedMlp(torch.autograd.Function):
         # forward 0.040 -> 0.035 ms at 250 rows).  In training the weights change every step and the 0.9 MB repack (6 us, a launch
         # of its own) costs what the faster forward + backward save (measured: 5 + 2 us) -- there the kernels read w[] directly.
         # (rows <= 512: the feature-split kernel reads w[] -- 16 KB per layer and workgroup -- and needs no copy, only its scratch)
-        scratch = mlp_scratch(dev, rows) if not (FORCE_PACKED or FORCE_ROW_TILES) else None
+        scratch = mlp_scratch(dev, rows)
         pk = packed_weights(wb, ws) if (0 < rows <= SMALL_ROWS and scratch is None and (not need_grad or FORCE_PACKED)) else None
         params.packed = pk.data_ptr() if pk is not None else None
         params.scratch = scratch.data_ptr() if scratch is not None else None
@@ -131,6 +131,7 @@ class FusedMlp(torch.autograd.Function):
             ctx.wb_leaves = tuple(wb)
             ctx.in_leaves = (feature, xyz)      # (their .grad may take the input gradients directly: _input_sink)
             ctx.pk = pk              # (the weights do not change between a forward and its backward)
+            ctx.split = scratch is not None
         return out
 
     @staticmethod
@@ -160,6 +161,8 @@ class FusedMlp(torch.autograd.Function):
             grads.dw[l] = dws[l].data_ptr()
             grads.db[l] = dbs[l].data_ptr()
         params.packed = ctx.pk.data_ptr() if getattr(ctx, "pk", None) is not None else None
+        scratch = mlp_scratch(dev, rows) if getattr(ctx, "split", False) else None     # (the feature-split data backward, as the forward)
+        params.scratch = scratch.data_ptr() if scratch is not None else None
         inp = _lib.MlpInputC(rows, fd, xyz_freq, time_freq, feature_c.data_ptr(), xyz_c.data_ptr() if has_xyz else None,
                              t_c.data_ptr() if has_t else None)
         need_f, need_x = ctx.needs

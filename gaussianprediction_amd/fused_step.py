@@ -276,7 +276,9 @@ class FusedStage3:
         # step reduces the gradients first).  Bit-identical to one launch; -0.015 ms per step on the bench workload
         # (profiles/r06_adam_rider_ab.txt; round 5's two-stream form of the same idea measured slower and is gone).
         early = 0
-        if not ts.reducer.enabled and getattr(ts, "early_adam", False):
+        # (not beside the feature-split MLP kernels, K <= 512: their chain of dependent trips to memory slows down under the optimizer's
+        # stream by more than the overlap brings -- 0.092 ms fused against 0.019 + 0.054)
+        if not ts.reducer.enabled and getattr(ts, "early_adam", False) and self.mlp_scratch is None:
             early_ids = {id(t) for t in (pc._xyz, pc._rotation, pc._scaling, pc._opacity, pc._features_dc, pc._features_rest)}
             for k, own in enumerate(opt.owner):
                 if id(own) in early_ids and tab["NUM"][k] != 0:

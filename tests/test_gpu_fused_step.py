@@ -162,8 +162,13 @@ def test_adam_update_riding_in_the_mlp_backward_launch_changes_nothing():
     rider of csrc/loss_adam_kernels.h; round 5: a second stream).  Same updates as the single launch behind the backward: parameters
     after real steps agree as two runs of one path do, the step counts are equal, and the parameters read right after a step on the
     caller's stream are the updated ones."""
-    a = _run(True, None, 8, early_adam=True)
-    b = _run(True, None, 8, early_adam=False)
+    from gaussianprediction_amd import deform_ops
+    deform_ops.FORCE_ROW_TILES = True        # (the rider travels with the 16-row kernels only: beside the feature-split ones it measured slower)
+    try:
+        a = _run(True, None, 8, early_adam=True)
+        b = _run(True, None, 8, early_adam=False)
+    finally:
+        deform_ops.FORCE_ROW_TILES = False
     assert a["ts"]._fused_plan.upd.adam_early_mask != 0 and b["ts"]._fused_plan.upd.adam_early_mask == 0
     assert a["ts"].fused_steps == b["ts"].fused_steps == 8
     assert np.abs(np.array(a["loss"]) - np.array(b["loss"])).max() < 2e-4
