@@ -119,7 +119,7 @@ __global__ __launch_bounds__(256) void gp_mlp_fwd_split_small_agent_kernel(MlpDe
                                                                            float* hx, uint32_t* flags, uint32_t* err);
 __global__ __launch_bounds__(256) void gp_mlp_bwd_data_split_small_kernel(MlpDev p, const float* __restrict__ saved_h, const float* __restrict__ dL_dout,
                                                                           float* dz, float* __restrict__ dfeature, float* __restrict__ dxyz, float* gx,
-                                                                          uint32_t* flags, uint32_t* err, int agent);
+                                                                          uint32_t* flags, uint32_t* err, int form);
 struct AdamTable;      // loss_adam_kernels.h
 __global__ __launch_bounds__(512) void gp_mlp_bwd_data_small_adam_kernel(MlpDev p, const float* __restrict__ saved_h,
                                                                          const float* __restrict__ dL_dout, float* __restrict__ dz,

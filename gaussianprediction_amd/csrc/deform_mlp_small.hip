@@ -661,7 +661,7 @@ template <bool LOCAL>
 __device__ __forceinline__ void mlp_bwd_data_split_small_body(const MlpDev& p, const float* __restrict__ saved_h, const float* __restrict__ dL_dout,
                                                               float* dz /* [4][rows][256]: exchange */, float* __restrict__ dfeature,
                                                               float* __restrict__ dxyz, float* gx /* [rows][in_pad]: exchange */,
-                                                              uint32_t* flags, uint32_t* err, unsigned block) {
+                                                              uint32_t* flags, uint32_t* err, unsigned block, bool add_dfeature) {
     __shared__ __attribute__((aligned(16))) float s_part[4][SR * 16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 15, kg = lane >> 4;
     const unsigned slot = block >> 3;
@@ -745,7 +745,10 @@ __device__ __forceinline__ void mlp_bwd_data_split_small_body(const MlpDev& p, c
         const float v = reduce(ns_product(a0, b));
         const int c = f0 + (tid & 15);
         if (my_row < p.rows && c < p.in_dim) {
-            if (dfeature && c < p.feature_dim) dfeature[my_row * p.feature_dim + c] = v;
+            if (dfeature && c < p.feature_dim) {
+                float* d = dfeature + my_row * p.feature_dim + c;
+                *d = add_dfeature ? *d + v : v;
+            }
             if (dxyz) gx[my_row * p.in_pad + c] = v;
         }
     }
@@ -778,9 +781,9 @@ __device__ __forceinline__ void mlp_bwd_data_split_small_body(const MlpDev& p, c
 }
 __global__ __launch_bounds__(NS_T) void gp_mlp_bwd_data_split_small_kernel(MlpDev p, const float* __restrict__ saved_h, const float* __restrict__ dL_dout,
                                                                            float* dz, float* __restrict__ dfeature, float* __restrict__ dxyz, float* gx,
-                                                                           uint32_t* flags, uint32_t* err, int agent) {
-    if (agent) mlp_bwd_data_split_small_body<false>(p, saved_h, dL_dout, dz, dfeature, dxyz, gx, flags, err, blockIdx.x);
-    else mlp_bwd_data_split_small_body<true>(p, saved_h, dL_dout, dz, dfeature, dxyz, gx, flags, err, blockIdx.x);
+                                                                           uint32_t* flags, uint32_t* err, int form /* bit 0: agent-scope exchange, bit 1: dfeature += */) {
+    if (form & 1) mlp_bwd_data_split_small_body<false>(p, saved_h, dL_dout, dz, dfeature, dxyz, gx, flags, err, blockIdx.x, (form & 2) != 0);
+    else mlp_bwd_data_split_small_body<true>(p, saved_h, dL_dout, dz, dfeature, dxyz, gx, flags, err, blockIdx.x, (form & 2) != 0);
 }
 // (Carrying the optimizer's rider in THIS launch, as gp_mlp_bwd_data_small_adam_kernel does for the 16-row form, was built and measured:
 // 0.092 ms for the fused launch against 0.019 + 0.054 ms for the two -- under the Adam chunks' HBM stream every one of the exchange's

@@ -134,6 +134,21 @@ extern "C" int gp_mlp_forward(const gp_mlp_params* p, const gp_mlp_input* x, flo
     return 0;
 }
 
+// Internal (gp_train_step_run): would gp_mlp_backward take the feature-split data kernel for these arguments?  Only that kernel honours
+// a request to ADD the input-feature gradient into dL_dfeature (gp_mlp_backward_accumulate_dfeature_once: the keypoint features also take
+// the regulariser's gradient, which the loss kernel has already written there -- one launch less per step than "=" into a temporary + add).
+static thread_local int g_dfeature_accumulate = 0;
+bool gp_mlp_backward_splits(const gp_mlp_params* p, int64_t rows) {
+    if (!p) return false;
+    MlpDev m;
+    memset(&m, 0, sizeof(m));
+    m.rows = rows;
+    int mode = 0;
+    int* st = nullptr;
+    return mlp_split_grid(m, p->scratch, mode, st) != 0 && (mode == 1 || mode == 3);
+}
+void gp_mlp_backward_accumulate_dfeature_once() { g_dfeature_accumulate = 1; }
+
 extern "C" int gp_mlp_backward(const gp_mlp_params* p, const gp_mlp_input* x, const float* acts, const float* dL_dout,
                                gp_mlp_grads* g, float* dL_dfeature, float* dL_dxyz, gp_alloc_fn alloc, void* alloc_ctx,
                                gp_stream_t stream_) {
@@ -150,6 +165,7 @@ extern "C" int gp_mlp_backward(const gp_mlp_params* p, const gp_mlp_input* x, co
     float* dz = (float*)alloc(alloc_ctx, GP_BUF_TEMP, dz_bytes);
     if (!dz) GP_FAIL("allocator returned NULL for TEMP (%zu B)", dz_bytes);
     GpAdamRider* rider = gp_adam_rider_slot();
+    struct ClearAcc { ~ClearAcc() { g_dfeature_accumulate = 0; } } clear_acc;      // (a request is for THIS call, whichever path it takes)
     int split_mode = 0;
     int* split_state = nullptr;
     // the feature-split form (deform_mlp_small.hip) once a forward has validated its XCD-local exchange on this device (mode 1), or in
@@ -161,8 +177,10 @@ extern "C" int gp_mlp_backward(const gp_mlp_params* p, const gp_mlp_input* x, co
         // (an armed rider stays armed: beside this latency-chained kernel the optimizer's stream costs more than it hides -- it is
         // launched behind the MLP backward by its owner, gp_adam_rider_flush)
         GpProfScope _p("mlp_bwd_data", s);
+        const int acc = g_dfeature_accumulate;
+        g_dfeature_accumulate = 0;
         hipLaunchKernelGGL(gp_mlp_bwd_data_split_small_kernel, dim3(split), dim3(256), 0, s, m, sh, dL_dout, dz, dL_dfeature, dL_dxyz, gx, flags,
-                           flags + GP_MLP_SCRATCH_ERR_WORD, split_mode == 3 ? 1 : 0);
+                           flags + GP_MLP_SCRATCH_ERR_WORD, (split_mode == 3 ? 1 : 0) | (acc ? 2 : 0));
         GP_LAUNCH_CHECK();
     } else if (m.rows <= GP_MLP_SMALL_ROWS && rider->armed) {
         // gp_train_step_run left an optimizer launch that needs nothing of this backward: its chunks ride in the data kernel's launch

@@ -5,6 +5,9 @@
 #include "gp_common.h"
 #include "loss_adam_kernels.h"
 
+bool gp_mlp_backward_splits(const gp_mlp_params* p, int64_t rows);     // gp_capi_deform.hip (internal)
+void gp_mlp_backward_accumulate_dfeature_once();
+
 // dst[i] += src[i]: the keypoint features take a gradient from the regulariser AND from the MLP's input (both "=" producers)
 __global__ __launch_bounds__(256) void gp_step_accumulate_kernel(float* __restrict__ dst, const float* __restrict__ src, int64_t n) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -137,11 +140,15 @@ extern "C" int gp_train_step_run(const gp_step_plan* p, const gp_step_view* v, c
     const uint32_t early = (u->hook || u->adam_count <= 0) ? 0u : (u->adam_early_mask & all);
     if (early && step_adam(u, early, stream, true)) return 1;
     gp_mlp_grads mg = p->g_mlp;
-    const int rc_mlp = gp_mlp_backward(&p->mlp, &mi, p->acts, p->g_delta, &mg, reg ? p->g_feature_tmp : p->g_keypoint_features, p->g_keypoints,
-                                       alloc, alloc_ctx, stream);
+    // (the keypoint features take a gradient from the regulariser -- written by the loss kernel -- AND from the MLP's input: the
+    // feature-split data backward adds its part in place; the 16-row form writes a temporary that a launch of its own adds)
+    const bool add_in_place = reg && gp_mlp_backward_splits(&p->mlp, K);
+    if (add_in_place) gp_mlp_backward_accumulate_dfeature_once();
+    const int rc_mlp = gp_mlp_backward(&p->mlp, &mi, p->acts, p->g_delta, &mg, (reg && !add_in_place) ? p->g_feature_tmp : p->g_keypoint_features,
+                                       p->g_keypoints, alloc, alloc_ctx, stream);
     if (rc_mlp) { gp_adam_rider_slot()->armed = false; return 1; }
     if (gp_adam_rider_flush((hipStream_t)stream)) return 1;
-    if (reg) {
+    if (reg && !add_in_place) {
         hipLaunchKernelGGL(gp_step_accumulate_kernel, dim3(gp_blocks((size_t)nfeat, 256)), dim3(256), 0, (hipStream_t)stream,
                            p->g_keypoint_features, (const float*)p->g_feature_tmp, nfeat);
         GP_LAUNCH_CHECK();
