@@ -30,7 +30,8 @@ class RasterSettingsC(C.Structure):
                 ("sh_coeffs", C.c_int32), ("prefiltered", C.c_int32), ("debug", C.c_int32),
                 ("bg", C.c_void_p), ("viewmatrix", C.c_void_p), ("projmatrix", C.c_void_p), ("campos", C.c_void_p),
                 ("binning_capacity", C.c_int64), ("binning_status", C.c_void_p), ("sh_ready_event", C.c_void_p),
-                ("depth_key_bits", C.c_int32), ("depth_key_base", C.c_uint32), ("depth_key_range", C.c_void_p)]
+                ("depth_key_bits", C.c_int32), ("depth_key_base", C.c_uint32), ("depth_key_range", C.c_void_p),
+                ("raw_activations", C.c_int32), ("reserved0", C.c_int32)]
 
 
 class RasterInputsC(C.Structure):

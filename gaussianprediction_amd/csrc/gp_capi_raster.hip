@@ -51,6 +51,11 @@ static int make_dims(const gp_raster_settings* st, const gp_raster_inputs* in, R
     d.visible = nullptr; d.zero_words = nullptr; d.n_zero = 0;
     d.key_hi = 0u; d.key_base = 0u; d.key_culled = 0xFFFFFFFFu; d.key_flag = nullptr; d.key_tag = 0u;
     d.sb_side = nullptr;
+    d.raw_opacity = nullptr;
+    if (st->raw_activations) {
+        if (in->cov3D_precomp || !in->scales) GP_FAIL("raw_activations needs scales + rotations (not cov3D_precomp)");
+        d.raw_opacity = in->opacities;
+    }
     if (st->depth_key_bits != 0 && st->depth_key_bits != 32) {
         if (st->depth_key_bits < 8 || st->depth_key_bits > 31) GP_FAIL("depth_key_bits must be 0, 32 or 8 .. 31 (got %d)", st->depth_key_bits);
         if (!st->binning_status) GP_FAIL("depth_key_bits needs binning_status (the word a broken promise raises)");

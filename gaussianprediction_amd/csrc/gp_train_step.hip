@@ -69,7 +69,11 @@ extern "C" int gp_train_step_run(const gp_step_plan* p, const gp_step_view* v, c
     ba.num_gaussians = N; ba.num_keypoints = K; ba.nearest_num = p->nearest_num; ba.out_dim = od; ba.norm_rotation = p->norm_rotation;
     ba.delta = p->delta; ba.raw_w = p->raw_w; ba.knn_idx = p->knn_idx; ba.xyz = p->xyz; ba.rot = p->rotation; ba.knn_idx16 = p->knn_idx16;
     if (gp_blend_forward(&ba, p->xyz_t, p->q_t, stream)) return 1;
-    if (gp_activations_forward(N, p->scaling, p->opacity, nullptr, 0, 1.f, p->scale, p->opacity_t, stream)) return 1;
+    // (exp / sigmoid of the raw scales and opacities [REF scene/gaussian_model.py get_scaling, get_opacity] run INSIDE the projection
+    // kernel and its backward -- gp_raster_settings.raw_activations, the expressions of gp_activations_forward / _backward bit for bit:
+    // two launches and 64 B per Gaussian less per step; gp_debug_option(14, 1): the launches of their own, for A/B)
+    const bool raw_act = gp_debug_get(14) == 0;
+    if (!raw_act && gp_activations_forward(N, p->scaling, p->opacity, nullptr, 0, 1.f, p->scale, p->opacity_t, stream)) return 1;
 
     // ---- GaussianRasterizer [REF gaussian_renderer/__init__.py:37-52, 98-106]
     gp_raster_settings st;
@@ -79,10 +83,12 @@ extern "C" int gp_train_step_run(const gp_step_plan* p, const gp_step_view* v, c
     st.bg = v->bg; st.viewmatrix = v->viewmatrix; st.projmatrix = v->projmatrix; st.campos = v->campos;
     st.binning_capacity = u->binning_capacity; st.binning_status = u->binning_status; st.sh_ready_event = u->sh_ready_event;
     st.depth_key_bits = u->depth_key_bits; st.depth_key_base = u->depth_key_base;
+    st.raw_activations = raw_act ? 1 : 0;
     gp_raster_inputs in;
     memset(&in, 0, sizeof(in));
-    in.num_gaussians = N; in.means3D = p->xyz_t; in.shs = p->features_dc; in.shs_rest = p->features_rest; in.opacities = p->opacity_t;
-    in.scales = p->scale; in.rotations = p->q_t;
+    in.num_gaussians = N; in.means3D = p->xyz_t; in.shs = p->features_dc; in.shs_rest = p->features_rest;
+    in.opacities = raw_act ? p->opacity : p->opacity_t;
+    in.scales = raw_act ? p->scaling : p->scale; in.rotations = p->q_t;
     gp_raster_outputs out = p->out;
     gp_raster_saved saved;
     memset(&saved, 0, sizeof(saved));
@@ -124,11 +130,11 @@ extern "C" int gp_train_step_run(const gp_step_plan* p, const gp_step_view* v, c
     gp_raster_grads g;
     memset(&g, 0, sizeof(g));
     g.dL_dmeans3D = p->g_xyz_t; g.dL_dmeans2D = p->g_means2D; g.dL_dshs = p->g_features_dc; g.dL_dshs_rest = p->g_features_rest;
-    g.dL_dopacities = p->g_opacity_t; g.dL_dscales = p->g_scale; g.dL_drotations = p->g_q_t; g.accumulate_shs = 0; g.adam_shs = u->adam_shs;
+    g.dL_dopacities = raw_act ? p->g_opacity : p->g_opacity_t; g.dL_dscales = raw_act ? p->g_scaling : p->g_scale; g.dL_drotations = p->g_q_t; g.accumulate_shs = 0; g.adam_shs = u->adam_shs;
     if (gp_raster_backward(&st, &in, &out, &saved, dimg, nullptr, &g, alloc, alloc_ctx, stream)) return 1;
     alloc(alloc_ctx, GP_BUF_TEMP_DONE, 0);
     if (u->hook) u->hook(u->hook_ctx, GP_STEP_AFTER_RASTER_BACKWARD);
-    if (gp_activations_backward(N, p->scaling, p->opacity, nullptr, 0, 1.f, p->g_scale, p->g_opacity_t, p->g_scaling, p->g_opacity, nullptr, stream))
+    if (!raw_act && gp_activations_backward(N, p->scaling, p->opacity, nullptr, 0, 1.f, p->g_scale, p->g_opacity_t, p->g_scaling, p->g_opacity, nullptr, stream))
         return 1;
     if (gp_blend_backward(&ba, p->g_xyz_t, p->g_q_t, p->g_delta, nullptr, p->g_xyz, p->g_rotation, alloc, alloc_ctx, stream)) return 1;
     alloc(alloc_ctx, GP_BUF_TEMP_DONE, 0);

@@ -33,6 +33,9 @@ struct RasterDims {
     // per-Gaussian half of the composite forward's sub-block test (gp_sb_mask), written by the projection kernel: (dyr, inv_cx), inv_cx = NaN
     // for "do not cull" (degenerate conic).  The staging lanes computed these -- three rcp and a sqrt -- per tile-splat INSTANCE (R = 4 N)
     float2* sb_side;
+    // gp_raster_settings.raw_activations: != NULL = the `opacities` pointer, holding LOGITS (and `scales` log-scales): the projection
+    // applies sigmoid / exp, the backward chains through them
+    const float* raw_opacity;
 };
 __global__ __launch_bounds__(256) void gp_key_range_kernel(const uint32_t* __restrict__ keys, const int32_t* __restrict__ radii, int n,
                                                           uint32_t base, uint32_t* __restrict__ out2);

@@ -315,11 +315,16 @@ __device__ __forceinline__ void preprocess_fwd_body(RasterDims d, const float* _
 #pragma unroll
         for (int k = 0; k < 4; ++k) q4[k] = rotations[4 * ii + k];
     }
-    const float opac = opacities[ii];
+    float opac = opacities[ii];
     if (SH_MODE == 1 && use_sh && d.D > 0) stage_sh<48>(s_sh, shs + (size_t)base * 48, nblk, tid);
     if (SH_MODE == 2 && use_sh && d.D > 0) stage_sh<45>(s_sh, shs_rest + (size_t)base * 45, nblk, tid);
     if (SH_MODE != 0) __syncthreads();
     asm volatile("" ::"v"(px), "v"(py), "v"(pz), "v"(sc3[0]), "v"(sc3[1]), "v"(sc3[2]), "v"(q4[0]), "v"(q4[1]), "v"(q4[2]), "v"(q4[3]), "v"(opac));
+    if (d.raw_opacity) {            // (gp_raster_settings.raw_activations: gp_act_fwd_kernel's expressions)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) sc3[k] = expf(sc3[k]);
+        opac = 1.f / (1.f + expf(-opac));
+    }
     if (i >= d.N) return;
     if (i < d.n_zero) d.zero_words[i] = 0u;              // (only handed over when N >= n_zero)
     radii[i] = 0;
@@ -1986,6 +1991,7 @@ __device__ __forceinline__ void preprocess_bwd_body(
 #pragma unroll
         for (int k = 0; k < 4; ++k) q4[k] = rotations[4 * ii + k];
     }
+    const float raw_o = d.raw_opacity ? d.raw_opacity[ii] : 0.f;
     const uint8_t cl = dL_dcolors ? (uint8_t)0 : clamped[ii];
     const float acc_mean2D[2] = {A0.x, A0.y}, acc_conic[3] = {A0.z, A0.w, A1.x}, acc_opacity = A1.y,
                 acc_color[3] = {A1.z, A1.w, A2.x}, acc_depth = A2.y;
@@ -2002,7 +2008,15 @@ __device__ __forceinline__ void preprocess_bwd_body(
     dL_dmeans2D[3 * i] = vis ? acc_mean2D[0] : 0.f;
     dL_dmeans2D[3 * i + 1] = vis ? acc_mean2D[1] : 0.f;
     dL_dmeans2D[3 * i + 2] = 0.f;
-    dL_dopacities[i] = vis ? acc_opacity : 0.f;
+    {
+        const float go = vis ? acc_opacity : 0.f;
+        float out = go;
+        if (d.raw_opacity) {        // gp_act_bwd_kernel's expression (life = 1)
+            const float so = 1.f / (1.f + expf(-raw_o));
+            out = go * 1.f * so * (1.f - so);
+        }
+        dL_dopacities[i] = out;
+    }
     // A culled Gaussian (radii = 0: 0.4 % of the bench scene) runs the same arithmetic on whatever its position gives -- its
     // accumulator line is zero, so every colour / SH term is an exact zero -- and `vis` SELECTS zeros where a division by a
     // non-positive depth could have produced NaN.  (As an early-out branch it let the compiler sink the loads of scales, rotations
@@ -2013,6 +2027,10 @@ __device__ __forceinline__ void preprocess_bwd_body(
 #pragma unroll
         for (int k = 0; k < 6; ++k) c6[k] = cov3D_precomp[6 * i + k];
     } else {
+        if (d.raw_opacity) {        // (log-scales: gp_act_fwd_kernel's exp; applied here, behind the loads' and the SH staging's round trips)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) sc3[k] = expf(sc3[k]);
+        }
         compute_cov3D(sc3, d.scale_mod, q4, c6);
     }
     float abc[3];
@@ -2180,7 +2198,8 @@ __device__ __forceinline__ void preprocess_bwd_body(
             float acc = 0.f;
 #pragma unroll
             for (int r = 0; r < 3; ++r) { acc += dLm[3 * r + k] * Rm[3 * r + k]; dR[3 * r + k] = dLm[3 * r + k] * s[k]; }
-            dL_dscales[3 * i + k] = vis ? acc * d.scale_mod : 0.f;
+            const float gs = vis ? acc * d.scale_mod : 0.f;
+            dL_dscales[3 * i + k] = d.raw_opacity ? gs * sc3[k] : gs;        // (raw: gp_act_bwd_kernel's g exp(s))
         }
         const float r = q[0], x = q[1], y = q[2], z = q[3];
         dL_drots[4 * i + 0] = vis ? 2.f * (-z * dR[1] + y * dR[2] + z * dR[3] - x * dR[5] - y * dR[6] + x * dR[7]) : 0.f;

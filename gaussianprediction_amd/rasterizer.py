@@ -55,6 +55,9 @@ class GaussianRasterizationSettings(NamedTuple):
     depth_key_bits: int = 0
     depth_key_base: int = 0
     depth_key_range: Optional[torch.Tensor] = None
+    # extension (gp_raster_settings.raw_activations): `scales` are the model's log-scales and `opacities` its logits -- the projection
+    # kernel applies exp / sigmoid (get_scaling / get_opacity) itself and the backward returns the gradients of the RAW tensors.
+    raw_activations: bool = False
 
 
 _bump_version = getattr(torch.autograd.graph, "increment_version", lambda t: None)
@@ -90,6 +93,7 @@ def _settings_c(rs: GaussianRasterizationSettings, device, sh_coeffs: int):
         if status is None or status.numel() < 3:
             raise RuntimeError("depth_key_bits needs a binning_status of >= 3 words")
         st.depth_key_bits, st.depth_key_base = kb, int(getattr(rs, "depth_key_base", 0)) & 0xFFFFFFFF
+    st.raw_activations = 1 if getattr(rs, "raw_activations", False) else 0
     kr = getattr(rs, "depth_key_range", None)
     if kr is not None:
         if kr.device != device or kr.dtype != torch.int32 or kr.numel() < 2 or not kr.is_contiguous():

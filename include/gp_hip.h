@@ -86,6 +86,13 @@ typedef struct gp_raster_settings {
     int32_t depth_key_bits;
     uint32_t depth_key_base;
     uint32_t* depth_key_range;
+    /* != 0 (round 6): `scales` are the model's LOG-scales and `opacities` its LOGITS [REF scene/gaussian_model.py: get_scaling = exp(_scaling),
+     * get_opacity = sigmoid(_opacity)] -- the projection kernel applies exp / sigmoid itself, and gp_raster_backward returns dL_dscales /
+     * dL_dopacities with respect to the RAW values (g exp(s); g sigma (1 - sigma)): the same expressions as gp_activations_forward /
+     * _backward without a lifecycle term, bit for bit, minus two launches and 64 B per Gaussian of traffic.  Needs scales + rotations
+     * (not cov3D_precomp). */
+    int32_t raw_activations;
+    int32_t reserved0;
 } gp_raster_settings;
 
 /* inputs of GaussianRasterizer.forward [REF gaussian_renderer/__init__.py:98-106] */

@@ -154,6 +154,43 @@ def test_scaling_modifier_forward_and_backward(mod):
         assert e < 1e-4, f"{k}: rel L2 {e:.3e}"
 
 
+@pytest.mark.parametrize("mod", [1.0, 1.3])
+def test_raw_activations_equal_the_activation_kernels_bit_for_bit(mod):
+    """gp_raster_settings.raw_activations (round 6): log-scales and opacity logits go to the rasterizer as they are -- the projection
+    kernel applies exp / sigmoid, its backward chains through them.  Same expressions as the activation kernels [REF scene/gaussian_model.py
+    get_scaling, get_opacity] in front of the plain rasterizer: image, radii, depth, and the gradients of the RAW tensors bit-identical
+    (the composite's accumulation order aside: compared on the discrete outputs exactly, on the gradients to atomics' noise)."""
+    from gaussianprediction_amd.deform_ops import Activations
+    scene, st, cam = small_scene(**CASES["dense_big_splats"])
+    st.scale_modifier = mod
+    st = f32_settings(st)
+    dev = scene_to_device(scene)
+    raw_s = torch.log(dev["scales"]).detach()
+    raw_o = torch.logit(dev["opacities"].clamp(1e-4, 1 - 1e-4)).detach()
+    gimg = torch.randn(3, st.image_height, st.image_width, device="cuda", generator=torch.Generator("cuda").manual_seed(1))
+
+    def run(raw):
+        rs_, ro_ = raw_s.clone().requires_grad_(True), raw_o.clone().requires_grad_(True)
+        leaves = {k: dev[k].detach().clone().requires_grad_(True) for k in ("means3D", "shs", "rotations")}
+        m2d = torch.zeros(dev["means3D"].shape[0], 3, device="cuda", requires_grad=True)
+        ts = torch_settings(st)._replace(raw_activations=raw)
+        if raw:
+            sc, op = rs_, ro_
+        else:
+            sc, op = Activations.apply(rs_, ro_, None, 0, 1.0)
+        img, radii, depth, tidx = gpa.GaussianRasterizer(ts)(means3D=leaves["means3D"], means2D=m2d, shs=leaves["shs"], colors_precomp=None,
+                                                             opacities=op, scales=sc, rotations=leaves["rotations"], cov3D_precomp=None)
+        (img * gimg).sum().backward()
+        torch.cuda.synchronize()
+        return img.detach(), radii, depth.detach(), tidx, [rs_.grad, ro_.grad, leaves["means3D"].grad, leaves["rotations"].grad, leaves["shs"].grad, m2d.grad]
+
+    a, b = run(True), run(False)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2]) and torch.equal(a[3], b[3])
+    for u, v in zip(a[4], b[4]):       # (two runs of ONE path differ by the order of the composite backward's atomic adds: that yardstick)
+        assert rel_l2(u.cpu().numpy(), v.cpu().numpy()) < 2e-6
+    assert float(a[4][0].abs().max()) > 0 and float(a[4][1].abs().max()) > 0
+
+
 def test_backward_precomputed_color_and_cov():
     g, L = _grads_case("small_partial_tiles", use_colors=True, use_cov=True)
     for k in ("means3D", "colors_precomp", "cov3D_precomp", "opacities"):

@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
 
 
 def test_struct_sizes_match_header_layout():
-    assert C.sizeof(_lib.RasterSettingsC) == 9 * 4 + 4 + 4 * 8 + 8 + 8 + 8 + 4 + 4 + 8   # 9 x 4-byte + pad + 4 pointers + capacity + status pointer + event + depth-key bits, base, range pointer
+    assert C.sizeof(_lib.RasterSettingsC) == 9 * 4 + 4 + 4 * 8 + 8 + 8 + 8 + 4 + 4 + 8 + 4 + 4   # 9 x 4-byte + pad + 4 pointers + capacity + status pointer + event + depth-key bits, base, range pointer + raw_activations + reserved
     assert C.sizeof(_lib.RasterInputsC) == 9 * 8
     assert C.sizeof(_lib.RasterSavedC) == 7 * 8
     assert C.sizeof(_lib.RasterGradsC) == 9 * 8 + 8 + 8     # + accumulate_shs (padded) + adam_shs
