@@ -33,7 +33,7 @@ __global__ __launch_bounds__(256) void gp_l1_ssim_fwd_kernel(const float* __rest
                                                             int H, int W, Win11 win, double* __restrict__ sums,
                                                             float* __restrict__ dmap) {
     __shared__ float s_a[LE][LP], s_b[LE][LP];
-    __shared__ float s_h[5][LE][LHP];
+    __shared__ float s_h[4][LE][LHP];
     __shared__ float s_red[4];
     const int tid = threadIdx.x;
     const int tx0 = blockIdx.x * LT, ty0 = blockIdx.y * LT, ch = blockIdx.z;
@@ -66,22 +66,24 @@ __global__ __launch_bounds__(256) void gp_l1_ssim_fwd_kernel(const float* __rest
     // (a sliding window in registers instead of 22 reads per output).  Row strides 43 / 33 keep every access conflict-free.
     if (tid < LE * 4) {
         const int y = tid >> 2, x0 = (tid & 3) * 8;
-        float a[18], b[18], aa[18], bb[18], ab[18];
+        // FOUR filtered maps, not five (round 6): SSIM reads sigma_a^2 + sigma_b^2 only as a sum [REF utils/loss_utils.py:94-98], and the
+        // window is linear -- conv(a^2) + conv(b^2) = conv(a^2 + b^2) up to rounding (~1e-7 of the sum; the loss golden vectors hold it)
+        float a[18], b[18], s2[18], ab[18];
 #pragma unroll
         for (int j = 0; j < 18; ++j) {
             a[j] = s_a[y][x0 + j]; b[j] = s_b[y][x0 + j];
-            aa[j] = a[j] * a[j]; bb[j] = b[j] * b[j]; ab[j] = a[j] * b[j];
+            s2[j] = a[j] * a[j] + b[j] * b[j]; ab[j] = a[j] * b[j];
         }
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            float m1 = 0.f, m2 = 0.f, saa = 0.f, sbb = 0.f, sab = 0.f;
+            float m1 = 0.f, m2 = 0.f, ss2 = 0.f, sab = 0.f;
 #pragma unroll
             for (int k = 0; k < 11; ++k) {
                 const float w = win.w[k];
                 m1 = fmaf(w, a[e + k], m1); m2 = fmaf(w, b[e + k], m2);
-                saa = fmaf(w, aa[e + k], saa); sbb = fmaf(w, bb[e + k], sbb); sab = fmaf(w, ab[e + k], sab);
+                ss2 = fmaf(w, s2[e + k], ss2); sab = fmaf(w, ab[e + k], sab);
             }
-            s_h[0][y][x0 + e] = m1; s_h[1][y][x0 + e] = m2; s_h[2][y][x0 + e] = saa; s_h[3][y][x0 + e] = sbb; s_h[4][y][x0 + e] = sab;
+            s_h[0][y][x0 + e] = m1; s_h[1][y][x0 + e] = m2; s_h[2][y][x0 + e] = ss2; s_h[3][y][x0 + e] = sab;
         }
     }
     __syncthreads();
@@ -90,9 +92,9 @@ __global__ __launch_bounds__(256) void gp_l1_ssim_fwd_kernel(const float* __rest
     const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
     {
         const int x = tid & 31, y0 = (tid >> 5) * 4;
-        float o[5][4];
+        float o[4][4];
 #pragma unroll
-        for (int q = 0; q < 5; ++q) {
+        for (int q = 0; q < 4; ++q) {
             float v[14];
 #pragma unroll
             for (int j = 0; j < 14; ++j) v[j] = s_h[q][y0 + j][x];
@@ -109,10 +111,10 @@ __global__ __launch_bounds__(256) void gp_l1_ssim_fwd_kernel(const float* __rest
         for (int e = 0; e < 4; ++e) {
             const int y = y0 + e, gy = ty0 + y;
             if (gy >= H || gx >= W) continue;
-            const float mu1 = o[0][e], mu2 = o[1][e], aa = o[2][e], bb = o[3][e], ab = o[4][e];
+            const float mu1 = o[0][e], mu2 = o[1][e], s2f = o[2][e], ab = o[3][e];
             const float mu1s = mu1 * mu1, mu2s = mu2 * mu2, mu12 = mu1 * mu2;
-            const float s11 = aa - mu1s, s22 = bb - mu2s, s12 = ab - mu12;
-            const float N1 = 2.f * mu12 + C1, N2 = 2.f * s12 + C2, D1 = mu1s + mu2s + C1, D2 = s11 + s22 + C2;
+            const float s12 = ab - mu12;
+            const float N1 = 2.f * mu12 + C1, N2 = 2.f * s12 + C2, D1 = mu1s + mu2s + C1, D2 = ((s2f - mu1s) - mu2s) + C2;
             const float inv = 1.f / (D1 * D2);
             const float ssim = N1 * N2 * inv;
             ss += ssim;
@@ -295,73 +297,52 @@ __global__ __launch_bounds__(256) void gp_l1_ssim_fused_kernel(const float* __re
     f2 pab[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) pab[e] = s_ab[oy0 + e + 2 * LH][ox + 2 * LH];
-    // ---- statistics on 42 x 42: five maps in three rounds -- (a, b), (a^2, b^2) as the halves of packed fp32 operations (v_pk_fma_f32:
-    // one instruction per tap and output for BOTH maps), then a b alone.  Horizontal: an item = 11 consecutive outputs of one staged row
-    // (52 rows x 4 groups = 208 items: one pass over the threads); vertical: a thread = 7 consecutive rows of one column (42 columns x 6
-    // groups = 252 threads).
+    // ---- statistics on 42 x 42: FOUR maps in two rounds -- (a, b), then (a^2 + b^2, a b), each pair the halves of packed fp32 operations
+    // (v_pk_fma_f32: one instruction per tap and output for BOTH maps).  Round 6: SSIM reads sigma_a^2 + sigma_b^2 only as a sum [REF
+    // utils/loss_utils.py:94-98] and the window is linear, so conv(a^2 + b^2) replaces conv(a^2) + conv(b^2) (rounding aside) -- a
+    // fifth of the statistics' filter work; gp_l1_ssim_fwd_kernel does the same, bit for bit.  Horizontal: an item = 11 consecutive
+    // outputs of one staged row (52 rows x 4 groups = 208 items: one pass over the threads); vertical: a thread = 7 consecutive rows of
+    // one column (42 columns x 6 groups = 252 threads).
     const int vx = tid % LE, vy0 = (tid / LE) * 7;
     const bool vert = tid < LE * 6;
-    float st[5][7];
+    float st[4][7];
 #pragma unroll
-    for (int round = 0; round < 3; ++round) {
+    for (int round = 0; round < 2; ++round) {
         if (tid < LF * 4) {
             const int y = tid >> 2, x0 = (tid & 3) * 11;
             f2 v[21];           // (columns beyond the staged 52 feed outputs beyond 42 only: discarded)
 #pragma unroll
             for (int j = 0; j < 21; ++j) v[j] = s_ab[y][x0 + j];
-            if (round < 2) {
-                if (round == 1) {
+            if (round == 1) {
 #pragma unroll
-                    for (int j = 0; j < 21; ++j) v[j] = v[j] * v[j];
+                for (int j = 0; j < 21; ++j) {
+                    const f2 sq = v[j] * v[j];
+                    v[j] = f2{sq[0] + sq[1], v[j][0] * v[j][1]};
                 }
+            }
 #pragma unroll
-                for (int e = 0; e < 11; ++e) {
-                    f2 m = {0.f, 0.f};
+            for (int e = 0; e < 11; ++e) {
+                f2 m = {0.f, 0.f};
 #pragma unroll
-                    for (int k = 0; k < 11; ++k) m = __builtin_elementwise_fma(f2{win.w[k], win.w[k]}, v[e + k], m);
-                    if (x0 + e < LE) s_h[y][x0 + e] = m;
-                }
-            } else {
-                float p[21];
-#pragma unroll
-                for (int j = 0; j < 21; ++j) p[j] = v[j][0] * v[j][1];
-#pragma unroll
-                for (int e = 0; e < 11; ++e) {
-                    float m = 0.f;
-#pragma unroll
-                    for (int k = 0; k < 11; ++k) m = fmaf(win.w[k], p[e + k], m);
-                    if (x0 + e < LE) s_h[y][x0 + e][0] = m;
-                }
+                for (int k = 0; k < 11; ++k) m = __builtin_elementwise_fma(f2{win.w[k], win.w[k]}, v[e + k], m);
+                if (x0 + e < LE) s_h[y][x0 + e] = m;
             }
         }
         __syncthreads();
         if (vert) {
-            if (round < 2) {
-                f2 v[17];
+            f2 v[17];
 #pragma unroll
-                for (int j = 0; j < 17; ++j) v[j] = s_h[vy0 + j][vx];
+            for (int j = 0; j < 17; ++j) v[j] = s_h[vy0 + j][vx];
 #pragma unroll
-                for (int e = 0; e < 7; ++e) {
-                    f2 acc = {0.f, 0.f};
+            for (int e = 0; e < 7; ++e) {
+                f2 acc = {0.f, 0.f};
 #pragma unroll
-                    for (int k = 0; k < 11; ++k) acc = __builtin_elementwise_fma(f2{win.w[k], win.w[k]}, v[e + k], acc);
-                    st[2 * round][e] = acc[0];
-                    st[2 * round + 1][e] = acc[1];
-                }
-            } else {
-                float v[17];
-#pragma unroll
-                for (int j = 0; j < 17; ++j) v[j] = s_h[vy0 + j][vx][0];
-#pragma unroll
-                for (int e = 0; e < 7; ++e) {
-                    float acc = 0.f;
-#pragma unroll
-                    for (int k = 0; k < 11; ++k) acc = fmaf(win.w[k], v[e + k], acc);
-                    st[4][e] = acc;
-                }
+                for (int k = 0; k < 11; ++k) acc = __builtin_elementwise_fma(f2{win.w[k], win.w[k]}, v[e + k], acc);
+                st[2 * round][e] = acc[0];
+                st[2 * round + 1][e] = acc[1];
             }
         }
-        if (round < 2) __syncthreads();         // (after the last round nobody reads the image planes again: the maps may overwrite them)
+        if (round < 1) __syncthreads();         // (after the last round nobody reads the image planes again: the maps may overwrite them)
     }
     // ---- SSIM and its three derivative maps on 42 x 42 (zero outside the image, as the backward's staging had them)
     float l1 = 0.f, ss = 0.f;
@@ -373,10 +354,10 @@ __global__ __launch_bounds__(256) void gp_l1_ssim_fused_kernel(const float* __re
             const int y = vy0 + e, gy = ty0 - LH + y;
             float d0 = 0.f, d1 = 0.f, d2 = 0.f;
             if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
-                const float mu1 = st[0][e], mu2 = st[1][e], aa = st[2][e], bb = st[3][e], ab = st[4][e];
+                const float mu1 = st[0][e], mu2 = st[1][e], s2f = st[2][e], ab = st[3][e];
                 const float mu1s = mu1 * mu1, mu2s = mu2 * mu2, mu12 = mu1 * mu2;
-                const float s11 = aa - mu1s, s22 = bb - mu2s, s12 = ab - mu12;
-                const float N1 = 2.f * mu12 + C1, N2 = 2.f * s12 + C2, D1 = mu1s + mu2s + C1, D2 = s11 + s22 + C2;
+                const float s12 = ab - mu12;
+                const float N1 = 2.f * mu12 + C1, N2 = 2.f * s12 + C2, D1 = mu1s + mu2s + C1, D2 = ((s2f - mu1s) - mu2s) + C2;
                 const float inv = 1.f / (D1 * D2);
                 const float ssim = N1 * N2 * inv;
                 if (vx >= LH && vx < LH + LT && y >= LH && y < LH + LT) ss += ssim;        // this workgroup's own 32 x 32
