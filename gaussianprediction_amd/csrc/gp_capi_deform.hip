@@ -153,6 +153,7 @@ extern "C" int gp_mlp_backward(const gp_mlp_params* p, const gp_mlp_input* x, co
                                gp_mlp_grads* g, float* dL_dfeature, float* dL_dxyz, gp_alloc_fn alloc, void* alloc_ctx,
                                gp_stream_t stream_) {
     hipStream_t s = (hipStream_t)stream_;
+    struct ClearAcc { ~ClearAcc() { g_dfeature_accumulate = 0; } } clear_acc;      // (a "+=" request is for THIS call, however it returns)
     MlpDev m;
     if (make_mlp(p, x, m)) return 1;
     if (m.rows == 0) return 0;
@@ -165,7 +166,6 @@ extern "C" int gp_mlp_backward(const gp_mlp_params* p, const gp_mlp_input* x, co
     float* dz = (float*)alloc(alloc_ctx, GP_BUF_TEMP, dz_bytes);
     if (!dz) GP_FAIL("allocator returned NULL for TEMP (%zu B)", dz_bytes);
     GpAdamRider* rider = gp_adam_rider_slot();
-    struct ClearAcc { ~ClearAcc() { g_dfeature_accumulate = 0; } } clear_acc;      // (a request is for THIS call, whichever path it takes)
     int split_mode = 0;
     int* split_state = nullptr;
     // the feature-split form (deform_mlp_small.hip) once a forward has validated its XCD-local exchange on this device (mode 1), or in

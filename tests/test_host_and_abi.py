@@ -34,6 +34,15 @@ def test_struct_sizes_match_header_layout():
     assert C.sizeof(_lib.BlendArgsC) == 2 * 8 + 3 * 4 + 4 + 6 * 8
 
 
+def test_mlp_scratch_size_query():
+    """gp_mlp_scratch_bytes (round 6): 8 KB of counters (32 row tiles x 128 B + the error word at byte 4096) + the exchange region of
+    four hidden layers; 0 where the feature-split kernels do not run (more than 512 rows)."""
+    l = _lib.lib()
+    assert int(l.gp_mlp_scratch_bytes(C.c_int64(250))) == 8192 + 4 * 250 * 256 * 4
+    assert int(l.gp_mlp_scratch_bytes(C.c_int64(512))) == 8192 + 4 * 512 * 256 * 4
+    assert int(l.gp_mlp_scratch_bytes(C.c_int64(513))) == 0 and int(l.gp_mlp_scratch_bytes(C.c_int64(0))) == 0
+
+
 def test_abi_validation_errors_are_reported_not_thrown():
     l = _lib.lib()
     st = _lib.RasterSettingsC(0, 0, 1.0, 1.0, 1.0, 3, 16, 0, 0, None, None, None, None)
