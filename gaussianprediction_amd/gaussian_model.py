@@ -300,12 +300,18 @@ class GaussianModel(TrainingMixin, nn.Module):
             self.set_superKeypoints()
             self.training2stage_setup()
 
-    def forward(self, t, iteration, return_weights=False, reference_rng=None):
+    raw_activations_ok = True      # forward(raw_activations=True) exists (renderer.render asks before it passes the keyword)
+
+    def forward(self, t, iteration, return_weights=False, reference_rng=None, raw_activations=False):
         """`reference_rng` (default: the model's `reference_rng` attribute, False): draw `torch.randn_like` on EVERY stage-1 / stage-2/3
         pass, also once the noise's scale has decayed to zero, as the reference does [REF scene/gaussian_model.py:241,254] -- a seeded
         training run then consumes the random stream exactly like the reference's (matters for bit-reproducible training
         comparisons, not for render parity).  Off: the draw is skipped once its factor is zero (one launch less per step); the fused
         train step is not taken with it on."""
+        # `raw_activations` (extension, passes without autograd: renderer.render): where no lifecycle term applies, return the RAW
+        # _scaling / _opacity in the places of the activated tensors and set `_forward_raw` -- the rasterizer applies exp / sigmoid
+        # itself (GaussianRasterizationSettings.raw_activations: same values, one launch less per frame)
+        self._forward_raw = False
         if torch.is_tensor(iteration):
             iteration = iteration.item()
         a = self.args
@@ -370,5 +376,8 @@ class GaussianModel(TrainingMixin, nn.Module):
             if weights:                              # the reference returns the PLAIN opacity beside the weights [REF :299-300]
                 return (xyz_t, q_t, s, self.get_opacity) + tuple(weights)
             return xyz_t, q_t, s, o
+        if raw_activations and not torch.is_grad_enabled():
+            self._forward_raw = True
+            return (xyz_t, q_t, self._scaling, self._opacity) + tuple(weights)
         s, o = Activations.apply(self._scaling, self._opacity, None, 0, 1.0)
         return (xyz_t, q_t, s, o) + tuple(weights)

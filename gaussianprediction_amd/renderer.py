@@ -33,9 +33,10 @@ def _sh_to_rgb_python(deg, feats, dirs):
     return torch.clamp_min(res + 0.5, 0.0)
 
 
-def _settings(viewpoint_camera, pc, bg_color, scaling_modifier, binning=None, sh_ready_event=None, visible_out=None):
+def _settings(viewpoint_camera, pc, bg_color, scaling_modifier, binning=None, sh_ready_event=None, visible_out=None, raw_activations=False):
     return GaussianRasterizationSettings(
         visible_out=visible_out,
+        raw_activations=bool(raw_activations),
         binning_capacity=int(binning[0]) if binning else 0,
         binning_status=binning[1] if binning else None,
         depth_key_bits=int(binning[2][0]) if (binning and len(binning) > 2 and binning[2]) else 0,
@@ -88,6 +89,7 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=
     of the rasterizer's capacity mode / depth-key speculation -- see GaussianRasterizationSettings.binning_capacity, .depth_key_bits."""
     screenspace_points = _screenspace_points(pc)
     cov3D_precomp = None
+    raw_act = False
     if time is None:
         means3D = pc.get_xyz + delta if delta is not None else pc.get_xyz
         opacity = pc.get_opacity
@@ -96,7 +98,12 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=
         else:
             scales, rotations = pc.get_scaling, pc.get_rotation
     else:
-        means3D, rotations, scales, opacity = pc(time, it)
+        # (a pass without autograd over a model that offers it: the raw scales / opacities go to the rasterizer as they are)
+        if not torch.is_grad_enabled() and getattr(pc, "raw_activations_ok", False):
+            means3D, rotations, scales, opacity = pc(time, it, raw_activations=True)[:4]
+            raw_act = bool(getattr(pc, "_forward_raw", False))
+        else:
+            means3D, rotations, scales, opacity = pc(time, it)
     shs, shs_rest, colors_precomp = None, None, None
     # (after the deformation was enqueued: it does not read the tensors a harness updates late.)  The SH coefficients are read by
     # the rasterizer alone, and only in front of its composite: a view-parallel harness hands over an EVENT for their all-gather
@@ -108,7 +115,7 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=
     if late is None:
         _wait_params(pc)
     vis = torch.empty(means3D.shape[0], dtype=torch.uint8, device=means3D.device)     # filled by the projection kernel (radii > 0)
-    rasterizer = GaussianRasterizer(raster_settings=_settings(viewpoint_camera, pc, bg_color, scaling_modifier, binning, sh_ready, vis))
+    rasterizer = GaussianRasterizer(raster_settings=_settings(viewpoint_camera, pc, bg_color, scaling_modifier, binning, sh_ready, vis, raw_act))
     if override_color is None:
         if getattr(pipe, "convert_SHs_python", False):
             base = means3D.detach() if time is not None else pc.get_xyz + (delta if delta is not None else 0)
