@@ -145,7 +145,7 @@ EXPORTS = [
     "gp_mlp_input_forward", "gp_mlp_input_backward", "gp_linear_forward", "gp_linear_backward", "gp_softmax_forward", "gp_softmax_backward",
     "gp_last_error", "gp_version", "gp_abi_version",
 ]
-GP_ABI_VERSION = 6         # include/gp_hip.h: the struct layouts / signatures / buffer-size macros this binding was written against
+GP_ABI_VERSION = 7         # include/gp_hip.h: the struct layouts / signatures / buffer-size macros this binding was written against
 
 _lib = None
 _lock = threading.Lock()

@@ -602,8 +602,9 @@ int gp_sh_factor_gradient(int64_t n, int32_t world, const float* factors, int32_
  * does: gaussianprediction_amd/_lib.py).  History: 1 = rounds 1-2; 2 = round 3 (gp_raster_settings.sh_ready_event / visible,
  * gp_knn_keypoints' `order`, GP_LOSS_SUM_SLOTS per image size); 3 = round 4 (gp_abi_version itself); 4 = round 4 (gp_mlp_params.packed, gp_blend_args.knn_idx16, gp_knn_keypoints' signature,
  * gp_adam_step_multi_steps); 5 = round 5 (gp_train_step_run and its three structs);
- * 6 = round 6 (gp_mlp16_pack / gp_mlp16_packed_elems, gp_loss_l1_ssim_fused, gp_sh_factor_gradient; the ReLU words gp_mlp16_forward hands to gp_mlp16_backward changed layout). */
-#define GP_ABI_VERSION 6
+ * 6 = round 6 (gp_mlp16_pack / gp_mlp16_packed_elems, gp_loss_l1_ssim_fused, gp_sh_factor_gradient; the ReLU words gp_mlp16_forward hands to gp_mlp16_backward changed layout);
+ * 7 = round 6, last session (gp_mlp_params.scratch + gp_mlp_scratch_bytes, gp_raster_settings.raw_activations, the saved 16-bit tensors' extent padded to 128 rows). */
+#define GP_ABI_VERSION 7
 int gp_abi_version(void);
 
 #ifdef __cplusplus
