@@ -147,3 +147,83 @@ def render_motion(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_mo
                                                     scales=pc.get_scaling, rotations=r_t, cov3D_precomp=None)
     return {"render": rendered_image, "viewspace_points": screenspace_points, "visibility_filter": radii > 0,
             "radii": radii}
+
+
+class SpeculativeRenderer:
+    """render() for inference loops WITHOUT a host synchronisation per frame (extension; the eval harness's form of TrainStep's
+    speculative binning).  The reference's rasterizer -- and render() in its exact mode -- reads the number of tile-splat instances back
+    to the host in the middle of every frame [REF eval.py:208-215 times exactly that]; here the first frame is exact and reports R,
+    later frames run in capacity mode with `margin` x the largest R seen and write {R, overflow} into a slot of a ring of status
+    words; `flush()` (and a full ring) reads the slots back in ONE synchronisation, re-renders the frames that overflowed exactly and
+    raises the high-water mark.  `__call__` returns the render dict; the image of a frame that later turns out to have overflowed is
+    replaced IN PLACE by the exact re-render (same tensor object), so results collected before flush() are valid after it."""
+
+    KEY_BITS = 24               # the depth-key window promised to capacity-mode frames (three sort passes instead of four)
+    KEY_MIN_MARGIN = 1 << 19    # keys of room demanded on either side of the range seen so far
+
+    def __init__(self, pc, pipe, bg_color, margin=1.25, slots=32, depth_key_speculation=True):
+        self.pc, self.pipe, self.bg = pc, pipe, bg_color
+        self.margin, self.slots = float(margin), int(slots)
+        self.capacity = 0
+        self.depth_key_speculation = bool(depth_key_speculation)
+        self._key_lo, self._key_hi = None, None
+        self._status = None
+        self._pending = []          # (slot, camera, time, it, pkg)
+        self.rerendered = 0
+
+    def _exact(self, viewpoint_camera, time, it):
+        """An exact-mode frame (one host synchronisation inside) that reports R and the visible depth keys' range."""
+        st = self._status[self.slots]               # (the row behind the ring)
+        st[4:6].copy_(self._key_none, non_blocking=True)
+        pkg = render(viewpoint_camera, self.pc, self.pipe, self.bg, time=time, it=it, binning=(0, st[0:3], None, st[4:6]))
+        h = st.cpu()
+        r, lo, hi = int(h[0]), int(h[4]) & 0xFFFFFFFF, int(h[5]) & 0xFFFFFFFF
+        self.capacity = max(self.capacity, 1024, int(self.margin * max(1, r)))
+        if lo <= hi:
+            self._key_lo = lo if self._key_lo is None else min(self._key_lo, lo)
+            self._key_hi = hi if self._key_hi is None else max(self._key_hi, hi)
+        return pkg
+
+    def _promise(self):
+        if not self.depth_key_speculation or self._key_lo is None:
+            return None
+        slack = (1 << self.KEY_BITS) - 1 - (self._key_hi - self._key_lo)
+        if slack < 2 * self.KEY_MIN_MARGIN:
+            return None
+        return self.KEY_BITS, max(1, self._key_lo - slack // 2)
+
+    def __call__(self, viewpoint_camera, time=None, it=1):
+        dev = self.bg.device
+        if self._status is None:
+            self._status = torch.zeros(self.slots + 1, 8, dtype=torch.int32, device=dev)
+            self._key_none = torch.tensor([-1, 0], dtype=torch.int32, device=dev)      # {0xFFFFFFFF, 0}: nothing reported
+        if self.capacity <= 0:                      # exact frame: learns R and the key range (the call synchronises anyway)
+            return self._exact(viewpoint_camera, time, it)
+        if len(self._pending) >= self.slots:
+            self.flush()
+        slot = len(self._pending)
+        pkg = render(viewpoint_camera, self.pc, self.pipe, self.bg, time=time, it=it,
+                     binning=(self.capacity, self._status[slot][0:3], self._promise()))
+        self._pending.append((slot, viewpoint_camera, time, it, pkg))
+        return pkg
+
+    def flush(self):
+        """One synchronisation for all frames since the last flush; returns the number of frames that had to be rendered again (instance
+        count beyond the capacity, or a visible depth key outside the promised window: both raise the frame's overflow word)."""
+        if not self._pending:
+            return 0
+        st = self._status[:len(self._pending)].cpu()          # (waits for the frames)
+        again = 0
+        hi = 0
+        pending, self._pending = self._pending, []
+        for slot, cam, time, it, pkg in pending:
+            hi = max(hi, int(st[slot, 0]))
+            if int(st[slot, 1]) != 0:
+                exact = self._exact(cam, time, it)
+                for k, v in exact.items():
+                    if torch.is_tensor(v) and torch.is_tensor(pkg.get(k)) and pkg[k].shape == v.shape:
+                        pkg[k].copy_(v)
+                again += 1
+        self.capacity = max(self.capacity, int(self.margin * hi))
+        self.rerendered += again
+        return again

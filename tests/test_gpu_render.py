@@ -201,3 +201,26 @@ def test_reference_rng_draws_the_decayed_noise_like_the_reference(it):
         s1 = torch.cuda.get_rng_state()
         pc(t, it)
         assert not torch.equal(torch.cuda.get_rng_state(), s1)
+
+
+def test_speculative_renderer_equals_render_frame_by_frame():
+    """SpeculativeRenderer (round 6): capacity-mode frames without a host synchronisation give render()'s own images bit for bit; a frame
+    whose instance count exceeds the capacity is found at flush() and replaced in place by the exact re-render."""
+    from gaussianprediction_amd.renderer import SpeculativeRenderer
+    pc = build(N=4000)[0]
+    cams = orbit_cameras(6, 4.0, 0.6911, 120, 90, device="cuda")
+    times = [torch.tensor([0.1 + 0.15 * v], device="cuda") for v in range(len(cams))]
+    pipe = SimpleNamespace(convert_SHs_python=False, compute_cov3D_python=False, debug=False)
+    bg = torch.tensor([0.0, 0.0, 0.0], device="cuda")
+    with torch.no_grad():
+        ref = [gpa.render(cams[v], pc, pipe, bg, time=times[v], it=50000)["render"].clone() for v in range(len(cams))]
+        sr = SpeculativeRenderer(pc, pipe, bg)
+        got = [sr(cams[v], time=times[v], it=50000) for v in range(len(cams))]
+        assert sr.flush() == 0
+        for a, b in zip(got, ref):
+            assert torch.equal(a["render"], b)
+        tight = SpeculativeRenderer(pc, pipe, bg, margin=0.5)       # every capacity-mode frame overflows
+        got = [tight(cams[v], time=times[v], it=50000) for v in range(len(cams))]
+        assert tight.flush() == len(cams) - 1
+        for a, b in zip(got, ref):
+            assert torch.equal(a["render"], b)
