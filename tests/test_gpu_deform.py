@@ -330,6 +330,32 @@ def test_feature_split_small_row_forward(rows):
     assert int((sc[:2048] != 0).sum()) == 0, "counters / error word of the scratch"
 
 
+def test_feature_split_forward_on_two_streams_at_once():
+    """One scratch per (device, stream): passes enqueued on two streams may run at the same time -- each finds its own counters."""
+    from gaussianprediction_amd import deform_ops
+    net, _ = _net(9, 104, 7)
+    t = torch.tensor([0.2], device="cuda")
+    feats = [(torch.rand(250, 32, device="cuda") - 0.5) for _ in range(2)]
+    xyzs = [torch.rand(250, 3, device="cuda") * 2 - 1 for _ in range(2)]
+    with torch.no_grad():
+        want = [net.forward_fused(f, x, t, 10, 6).clone() for f, x in zip(feats, xyzs)]
+        streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+        torch.cuda.synchronize()
+        got = [[], []]
+        for rep in range(30):
+            for k, st in enumerate(streams):
+                with torch.cuda.stream(st):
+                    got[k].append(net.forward_fused(feats[k], xyzs[k], t, 10, 6))
+        torch.cuda.synchronize()
+    for k in range(2):
+        for y in got[k]:
+            assert torch.equal(y, want[k])
+    keys = [k for k in deform_ops._SCRATCH if k[1] in (int(streams[0].cuda_stream), int(streams[1].cuda_stream))]
+    assert len(keys) == 2
+    for k in keys:
+        assert int((deform_ops._SCRATCH[k][:2048] != 0).sum()) == 0
+
+
 # ---- the range guard of precision="fp32s" (round-4 verdict: hi = fp16(x) saturates at 65504, silently) ----------------------------------
 def _scaled_net(scale, seed=3):
     net, _ = _net(seed, 104, 7)
