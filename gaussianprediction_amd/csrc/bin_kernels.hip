@@ -239,7 +239,7 @@ __global__ __launch_bounds__(BIN_THREADS) void gp_bin_scatter_kernel(int N, int 
     __shared__ BinWave s_w[BIN_WAVES];
     __shared__ uint32_t s_wsum[BIN_WAVES];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if ((int)blockIdx.x == n_chunks) {
+    if (blockIdx.x == gridDim.x - 1 && order) {
         // One workgroup more than there are chunks: the composite forward's heavy-first launch order (gp_tile_order_kernel's job:
         // a counting sort of the tiles by a logarithm of their list length = the tile totals this kernel reads anyway), computed
         // BESIDE the scatter instead of in a 9 us launch of its own behind it.
@@ -269,8 +269,15 @@ __global__ __launch_bounds__(BIN_THREADS) void gp_bin_scatter_kernel(int N, int 
         for (int t = tid; t < T; t += BIN_THREADS) order[atomicAdd(&s_baseb[s_bk[t]], 1u)] = (uint32_t)t;
         return;
     }
+    // XCD-aware chunk order: workgroups go to the 8 XCDs round-robin by id, and consecutive slots of a tile's list are written by
+    // CONSECUTIVE chunks of the depth-ordered Gaussians (1.5 instances per tile and chunk at configs[2]) -- with chunk = blockIdx they
+    // came from eight different L2s, every 4-byte store a partially written 64-byte line of its own on the way to HBM.  Here XCD x
+    // owns a contiguous eighth of the chunks: a tile's slots fill up inside ONE L2 and leave it as whole lines.
+    const int per_xcd = (n_chunks + 7) / 8;
+    const int blk = (int)(blockIdx.x & 7u) * per_xcd + (int)(blockIdx.x >> 3);
+    if ((int)(blockIdx.x >> 3) >= per_xcd || blk >= n_chunks) return;
     constexpr int G = CH * 64 * BIN_WAVES;
-    const int i_begin = blockIdx.x * G + wave * (CH * 64);
+    const int i_begin = blk * G + wave * (CH * 64);
     uint32_t rx[CH], ry[CH], rid[CH];           // this wave's Gaussians: tile rectangle and id, the only global loads of the walks
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
@@ -289,7 +296,7 @@ __global__ __launch_bounds__(BIN_THREADS) void gp_bin_scatter_kernel(int N, int 
     constexpr int PRE = GP_BIN_MAX_TILES / BIN_THREADS;
     uint32_t tv[PRE], rv[PRE];
     {
-        const uint32_t* row = hist_scanned + (size_t)blockIdx.x * T;
+        const uint32_t* row = hist_scanned + (size_t)blk * T;
 #pragma unroll
         for (int k = 0; k < PRE; ++k) {
             const int t = tid + k * BIN_THREADS;
@@ -303,7 +310,7 @@ __global__ __launch_bounds__(BIN_THREADS) void gp_bin_scatter_kernel(int N, int 
         if (t < T) s_base[t] = tv[k];
     }
     {   // the per-(wave, tile) counts of this chunk, counted by gp_bin_count_kernel (coalesced copy)
-        const uint32_t* wrow = wave_cnt + (size_t)blockIdx.x * BIN_WAVES * words;
+        const uint32_t* wrow = wave_cnt + (size_t)blk * BIN_WAVES * words;
         const int nw = BIN_WAVES * words;
         for (int i0 = 0; i0 < nw; i0 += 16 * BIN_THREADS) {            // 16 loads in flight per thread, then 16 LDS stores
             uint32_t v[16];
@@ -332,7 +339,7 @@ __global__ __launch_bounds__(BIN_THREADS) void gp_bin_scatter_kernel(int N, int 
             s_base[t] = run;
             run += c;
         }
-        if (blockIdx.x == 0 && tid == BIN_THREADS - 1 && status) {      // (the last thread's running sum is the grand total R)
+        if (blk == 0 && tid == BIN_THREADS - 1 && status) {      // (the last thread's running sum is the grand total R)
             status[0] = run;
             status[1] = (run > capacity || (key_tag && status[2] == key_tag)) ? 1u : 0u;      // (key_tag: gp_raster_settings.depth_key_bits)
         }
@@ -343,7 +350,7 @@ __global__ __launch_bounds__(BIN_THREADS) void gp_bin_scatter_kernel(int N, int 
         const int t = tid + k * BIN_THREADS;
         if (t < T) {
             const uint32_t st = s_base[t];
-            if (blockIdx.x == 0) {              // per-tile [start, end) -- cut at the capacity (capacity mode, overflow: flagged above)
+            if (blk == 0) {              // per-tile [start, end) -- cut at the capacity (capacity mode, overflow: flagged above)
                 const uint32_t c = tv[k];
                 const uint32_t lo = st < capacity ? st : capacity, hi = st + c < capacity ? st + c : capacity;
                 ranges[t] = c ? make_int2((int)lo, (int)hi) : make_int2(0, 0);
@@ -489,7 +496,7 @@ static int bin_scatter_launch(const GpBinPlan& p, size_t N, int gx, size_t T, co
         GP_HIP_CHECK(hipFuncSetAttribute((const void*)gp_bin_scatter_kernel<CH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         lds_set = lds;
     }
-    hipLaunchKernelGGL(gp_bin_scatter_kernel<CH>, dim3((unsigned)p.NB + (order ? 1u : 0u)), dim3(BIN_THREADS), lds, s, (int)N, gx, (int)T, sorted_ids,
+    hipLaunchKernelGGL(gp_bin_scatter_kernel<CH>, dim3(8u * (((unsigned)p.NB + 7u) / 8u) + (order ? 1u : 0u)), dim3(BIN_THREADS), lds, s, (int)N, gx, (int)T, sorted_ids,
                        rect_sorted, hist, totals, wave_cnt, point_list, capacity, ranges, status, gp_debug_get(6), order, p.NB, key_tag);
     GP_LAUNCH_CHECK();
     return 0;
