@@ -88,6 +88,14 @@ size_t gp_sort_hist_elems(size_t n) {
     return 256 * ((n + tile - 1) / tile) + 64;
 }
 
+// XCD-aware block order (round 6): workgroups go to the 8 XCDs round-robin by id; with block = blockIdx the adjacent runs of one digit
+// (32 bytes per block at 2048 keys and 256 digits) were written from different L2s, every 64-byte line twice and partially.  XCD x owns
+// a contiguous eighth of the blocks: the launches below use 8 ceil(nblocks / 8) workgroups, ids beyond nblocks leave at once.
+__device__ __forceinline__ uint32_t rs_logical_block(uint32_t b, uint32_t nblocks) {
+    const uint32_t per = (nblocks + 7u) / 8u;
+    return (b >> 3) < per ? (b & 7u) * per + (b >> 3) : nblocks;
+}
+static inline unsigned rs_grid(uint32_t nblocks) { return 8u * ((nblocks + 7u) / 8u); }
 // per-block digit histogram, written digit-major: hist[digit * nblocks + block]
 template <int RS_ITEMS>
 __global__ __launch_bounds__(RS_BLOCK) void gp_radix_hist_kernel(const uint32_t* __restrict__ keys, size_t n, int shift,
@@ -96,9 +104,11 @@ __global__ __launch_bounds__(RS_BLOCK) void gp_radix_hist_kernel(const uint32_t*
     constexpr int RS_TILE = RS_ITEMS * RS_BLOCK;
     __shared__ uint32_t s_hist[256];
     const int tid = threadIdx.x;
+    const uint32_t blk = rs_logical_block(blockIdx.x, nblocks);
+    if (blk >= nblocks) return;
     s_hist[tid] = 0;
     __syncthreads();
-    const size_t base = (size_t)blockIdx.x * RS_TILE;
+    const size_t base = (size_t)blk * RS_TILE;
     uint32_t k[RS_ITEMS];
 #pragma unroll
     for (int it = 0; it < RS_ITEMS; ++it) {        // every load in flight before the first use (as `if (idx < n) atomicAdd(.. keys[idx] ..)`
@@ -109,7 +119,7 @@ __global__ __launch_bounds__(RS_BLOCK) void gp_radix_hist_kernel(const uint32_t*
     for (int it = 0; it < RS_ITEMS; ++it)
         if (base + (size_t)it * RS_BLOCK + tid < n) atomicAdd(&s_hist[(k[it] >> shift) & mask], 1u);
     __syncthreads();
-    hist[(size_t)tid * nblocks + blockIdx.x] = s_hist[tid];
+    hist[(size_t)tid * nblocks + blk] = s_hist[tid];
 }
 
 // exclusive scan of every digit's row  hist[digit][0..nblocks)  in place (one workgroup per digit) + the row totals.
@@ -176,10 +186,12 @@ __global__ __launch_bounds__(RS_BLOCK) void gp_radix_scatter_kernel(const uint32
     __shared__ uint32_t s_dbase[256], s_dw[4];
     __shared__ uint32_t s_k[RS_TILE], s_v[RS_TILE];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t blk = rs_logical_block(blockIdx.x, nblocks);
+    if (blk >= nblocks) return;
 #pragma unroll
     for (int w = 0; w < RS_BLOCK / GP_WAVE; ++w) s_cnt[w][tid] = 0;
     __syncthreads();
-    const size_t base = (size_t)blockIdx.x * RS_TILE + (size_t)wave * (GP_WAVE * RS_ITEMS);
+    const size_t base = (size_t)blk * RS_TILE + (size_t)wave * (GP_WAVE * RS_ITEMS);
     uint32_t k[RS_ITEMS], v[RS_ITEMS], r[RS_ITEMS];
     // every global load of the block up front (clamped addresses): inside the ranking loop each pair was waited for before its
     // eight ballots -- RS_ITEMS dependent round trips per block, plus one each for the two scan inputs below
@@ -191,7 +203,7 @@ __global__ __launch_bounds__(RS_BLOCK) void gp_radix_scatter_kernel(const uint32
         v[it] = vals_in ? vals_in[ic] : (uint32_t)idx;                       // vals_in == NULL: the values are the indices (first pass)
     }
     const uint32_t tv_pre = totals[tid];
-    const uint32_t hs_pre = hist_scanned[(size_t)tid * nblocks + blockIdx.x];
+    const uint32_t hs_pre = hist_scanned[(size_t)tid * nblocks + blk];
 #pragma unroll
     for (int it = 0; it < RS_ITEMS; ++it) {
         const size_t idx = base + (size_t)it * GP_WAVE + lane;
@@ -261,7 +273,7 @@ __global__ __launch_bounds__(RS_BLOCK) void gp_radix_scatter_kernel(const uint32
         }
     }
     __syncthreads();
-    const size_t bbase = (size_t)blockIdx.x * RS_TILE;
+    const size_t bbase = (size_t)blk * RS_TILE;
     const uint32_t bn = (uint32_t)(n - bbase < RS_TILE ? n - bbase : RS_TILE);
     if (!ep.by_value) {
         for (uint32_t p = tid; p < bn; p += RS_BLOCK) {
@@ -311,25 +323,25 @@ int gp_radix_sort_pairs(GpSortBufs& b, size_t n, int nbits, hipStream_t s, bool 
         GpSortEpilogue ep = {nullptr, nullptr, nullptr};
         if (epilogue && shift + per >= nbits) ep = *epilogue;      // (last pass)
         if (items == RS_ITEMS_SMALL)
-            hipLaunchKernelGGL((gp_radix_hist_kernel<RS_ITEMS_SMALL>), dim3(nblocks), dim3(RS_BLOCK), 0, s, b.k[cur], n, shift, mask,
+            hipLaunchKernelGGL((gp_radix_hist_kernel<RS_ITEMS_SMALL>), dim3(rs_grid(nblocks)), dim3(RS_BLOCK), 0, s, b.k[cur], n, shift, mask,
                                b.hist, nblocks);
         else if (items == RS_ITEMS_MID)
-            hipLaunchKernelGGL((gp_radix_hist_kernel<RS_ITEMS_MID>), dim3(nblocks), dim3(RS_BLOCK), 0, s, b.k[cur], n, shift, mask,
+            hipLaunchKernelGGL((gp_radix_hist_kernel<RS_ITEMS_MID>), dim3(rs_grid(nblocks)), dim3(RS_BLOCK), 0, s, b.k[cur], n, shift, mask,
                                b.hist, nblocks);
         else
-            hipLaunchKernelGGL((gp_radix_hist_kernel<RS_ITEMS_LARGE>), dim3(nblocks), dim3(RS_BLOCK), 0, s, b.k[cur], n, shift, mask,
+            hipLaunchKernelGGL((gp_radix_hist_kernel<RS_ITEMS_LARGE>), dim3(rs_grid(nblocks)), dim3(RS_BLOCK), 0, s, b.k[cur], n, shift, mask,
                                b.hist, nblocks);
         if (hipGetLastError() != hipSuccess) { snprintf(gp_err_buf, sizeof(gp_err_buf), "radix hist launch failed"); return -1; }
         if (b.scan_tmp_elems < 256) { snprintf(gp_err_buf, sizeof(gp_err_buf), "radix sort: temp storage too small"); return -1; }
         hipLaunchKernelGGL(gp_radix_rowscan_kernel, dim3(256), dim3(256), 0, s, b.hist, nblocks, b.scan_tmp);
         if (items == RS_ITEMS_SMALL)
-            hipLaunchKernelGGL((gp_radix_scatter_kernel<RS_ITEMS_SMALL>), dim3(nblocks), dim3(RS_BLOCK), 0, s, b.k[cur], vin,
+            hipLaunchKernelGGL((gp_radix_scatter_kernel<RS_ITEMS_SMALL>), dim3(rs_grid(nblocks)), dim3(RS_BLOCK), 0, s, b.k[cur], vin,
                                b.k[cur ^ 1], b.v[cur ^ 1], b.hist, b.scan_tmp, n, shift, mask, nblocks, ep);
         else if (items == RS_ITEMS_MID)
-            hipLaunchKernelGGL((gp_radix_scatter_kernel<RS_ITEMS_MID>), dim3(nblocks), dim3(RS_BLOCK), 0, s, b.k[cur], vin,
+            hipLaunchKernelGGL((gp_radix_scatter_kernel<RS_ITEMS_MID>), dim3(rs_grid(nblocks)), dim3(RS_BLOCK), 0, s, b.k[cur], vin,
                                b.k[cur ^ 1], b.v[cur ^ 1], b.hist, b.scan_tmp, n, shift, mask, nblocks, ep);
         else
-            hipLaunchKernelGGL((gp_radix_scatter_kernel<RS_ITEMS_LARGE>), dim3(nblocks), dim3(RS_BLOCK), 0, s, b.k[cur], vin,
+            hipLaunchKernelGGL((gp_radix_scatter_kernel<RS_ITEMS_LARGE>), dim3(rs_grid(nblocks)), dim3(RS_BLOCK), 0, s, b.k[cur], vin,
                                b.k[cur ^ 1], b.v[cur ^ 1], b.hist, b.scan_tmp, n, shift, mask, nblocks, ep);
         if (hipGetLastError() != hipSuccess) { snprintf(gp_err_buf, sizeof(gp_err_buf), "radix scatter launch failed"); return -1; }
         cur ^= 1;
