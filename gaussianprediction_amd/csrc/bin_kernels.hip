@@ -546,7 +546,10 @@ __global__ __launch_bounds__(DS_THREADS) void gp_dsort_count_kernel(const uint32
                                                                     uint32_t* __restrict__ hist) {
     __shared__ uint32_t s_hist[DS_BINS];
     const int tid = threadIdx.x;
-    const int base = blockIdx.x * (IT * DS_THREADS);
+    const int nb_all = (n + IT * DS_THREADS - 1) / (IT * DS_THREADS), per_xcd = (nb_all + 7) / 8;
+    const int blk = (int)(blockIdx.x & 7u) * per_xcd + (int)(blockIdx.x >> 3);      // XCD x owns a contiguous eighth of the blocks (see gp_bin_scatter_kernel)
+    if ((int)(blockIdx.x >> 3) >= per_xcd || blk >= nb_all) return;
+    const int base = blk * (IT * DS_THREADS);
     uint32_t k[IT];
 #pragma unroll
     for (int it = 0; it < IT; ++it) {
@@ -559,7 +562,7 @@ __global__ __launch_bounds__(DS_THREADS) void gp_dsort_count_kernel(const uint32
     for (int it = 0; it < IT; ++it)
         if (base + it * DS_THREADS + tid < n) atomicAdd(&s_hist[(k[it] >> shift) & mask], 1u);
     __syncthreads();
-    uint32_t* row = hist + (size_t)blockIdx.x * DS_BINS;
+    uint32_t* row = hist + (size_t)blk * DS_BINS;
     for (int d = tid; d < DS_BINS; d += DS_THREADS) row[d] = s_hist[d];
 }
 
@@ -574,7 +577,10 @@ __global__ __launch_bounds__(DS_THREADS) void gp_dsort_scatter_kernel(const uint
     __shared__ uint32_t s_wsum[DS_WAVES];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     constexpr int PER_WAVE = IT * 64;
-    const int wbase = blockIdx.x * (IT * DS_THREADS) + wave * PER_WAVE;       // wave w owns keys [w * PER_WAVE, (w + 1) * PER_WAVE)
+    const int nb_all = (n + IT * DS_THREADS - 1) / (IT * DS_THREADS), per_xcd = (nb_all + 7) / 8;
+    const int blk = (int)(blockIdx.x & 7u) * per_xcd + (int)(blockIdx.x >> 3);      // XCD x owns a contiguous eighth of the blocks
+    if ((int)(blockIdx.x >> 3) >= per_xcd || blk >= nb_all) return;
+    const int wbase = blk * (IT * DS_THREADS) + wave * PER_WAVE;       // wave w owns keys [w * PER_WAVE, (w + 1) * PER_WAVE)
     uint32_t k[IT], v[IT];
 #pragma unroll
     for (int it = 0; it < IT; ++it) {
@@ -586,7 +592,7 @@ __global__ __launch_bounds__(DS_THREADS) void gp_dsort_scatter_kernel(const uint
     constexpr int PB = DS_BINS / DS_THREADS;                  // 8 digits per thread
     uint32_t tv[PB], rv[PB];
     {
-        const uint32_t* row = hist_scanned + (size_t)blockIdx.x * DS_BINS;
+        const uint32_t* row = hist_scanned + (size_t)blk * DS_BINS;
 #pragma unroll
         for (int j = 0; j < PB; ++j) { tv[j] = totals[tid * PB + j]; rv[j] = row[tid * PB + j]; }
     }
@@ -666,6 +672,7 @@ __global__ __launch_bounds__(DS_THREADS) void gp_dsort_scatter_kernel(const uint
 // (profiles/r04_depth_sort_ab.txt).  Nine launches instead of twelve do not pay for a scatter that is twice as long: with 2048 bins
 // and 2048 keys per block every key is its own digit run (no coalescing to stage for), and the kernel is one latency chain -- key
 // loads, a 2048-entry prefix, eight counter round trips per wave -- at two workgroups per CU.
+// (Round 6: with the XCD-aware block order of both sorts -- profiles/r06_xcd_locality_ab.txt -- 0.090 ms against 0.080 for the four radix passes: still off.)
 bool gp_dsort_supported(size_t n) { return n > 0 && n <= 512u * 8192u && gp_debug_get(8) == 2; }
 size_t gp_dsort_hist_elems(size_t n) {
     size_t kpb = 2048;
@@ -678,11 +685,11 @@ static int dsort_pass(const uint32_t* kin, const uint32_t* vin, uint32_t* kout, 
                       const GpSortEpilogue& ep, hipStream_t s) {
     const uint32_t mask = (1u << bits) - 1u;
     uint32_t* totals = hist + (size_t)nb * DS_BINS;
-    hipLaunchKernelGGL(gp_dsort_count_kernel<IT>, dim3((unsigned)nb), dim3(DS_THREADS), 0, s, kin, n, shift, mask, hist);
+    hipLaunchKernelGGL(gp_dsort_count_kernel<IT>, dim3(8u * (((unsigned)nb + 7u) / 8u)), dim3(DS_THREADS), 0, s, kin, n, shift, mask, hist);
     GP_LAUNCH_CHECK();
     hipLaunchKernelGGL(gp_bin_scan_kernel, dim3(DS_BINS / 64), dim3(64 * BIN_SEGS), 0, s, hist, nb, DS_BINS, totals);
     GP_LAUNCH_CHECK();
-    hipLaunchKernelGGL(gp_dsort_scatter_kernel<IT>, dim3((unsigned)nb), dim3(DS_THREADS), 0, s, kin, vin, kout, vout, (const uint32_t*)hist,
+    hipLaunchKernelGGL(gp_dsort_scatter_kernel<IT>, dim3(8u * (((unsigned)nb + 7u) / 8u)), dim3(DS_THREADS), 0, s, kin, vin, kout, vout, (const uint32_t*)hist,
                        (const uint32_t*)totals, n, shift, mask, bits, ep);
     GP_LAUNCH_CHECK();
     return 0;
