@@ -580,8 +580,10 @@ int gp_microbench_gather(const void* src, int rec_bytes, int stride_bytes, const
  * split-mode weight-gradient kernel; key 4: workgroup cap of the fused weights-model forward;
  * key 5: 1 = tile binning by duplicate + radix sort instead of by counting, csrc/bin_kernels.hip; key 6: ablation bits of the
  * binning scatter kernel; key 8: 2 = depth sort in three 11-bit counting passes instead of four 8-bit radix passes -- measured slower, kept for the A/B;
- * key 9: ablation bits of the 16-bit MLP forward, tools/probe/mlp16_ablate.py).  Never needed by a caller of the
- * render path. */
+ * key 9: ablation bits of the 16-bit MLP forward, tools/probe/mlp16_ablate.py; key 10: 16-row blocks per slab of the 16-bit weight gradient;
+ * key 11: 1 = the pair of loss kernels in gp_train_step_run; key 13: 1 = the 16-row kernels where the feature-split small-row MLP would run,
+ * 2 = its agent-scope form of the exchange; key 14: 1 = activation launches of their own in gp_train_step_run instead of raw_activations).
+ * Never needed by a caller of the render path. */
 int gp_debug_option(int key, int value);
 /* Diagnostics: with gp_debug_option(0, 3) the composite forward counts, over all launches since the last call, out4[0] = the
  * (pixel, splat) pairs that contribute (alpha >= 1/255, pixel not yet saturated) and out4[1] = the pairs its sub-block lists make
