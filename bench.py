@@ -497,11 +497,15 @@ def main():
             # (b) back-to-back renders, one synchronisation at the end -- pipelined throughput.  render() in its exact mode still reads
             # the instance count back in the middle of every frame (as the reference's rasterizer does); SpeculativeRenderer is the
             # harness-side form without it: capacity mode from the first frame's count, overflow words checked once at the end
-            te = time.perf_counter()
-            for i in range(n_eval):
-                ev(i)
-            torch.cuda.synchronize()
-            eval_fps_exact = n_eval / (time.perf_counter() - te)
+            # (both back-to-back loops: the median of three repetitions -- a single 50-frame loop is ~20 ms, one host hiccup is half of that)
+            reps = []
+            for _ in range(3):
+                te = time.perf_counter()
+                for i in range(n_eval):
+                    ev(i)
+                torch.cuda.synchronize()
+                reps.append(n_eval / (time.perf_counter() - te))
+            eval_fps_exact = sorted(reps)[1]
             from gaussianprediction_amd.renderer import SpeculativeRenderer
             sr = SpeculativeRenderer(pc, ts.pipe, ts.bg)
             evs = lambda i: sr(cams[(i * world + rank) % len(cams)], time=ts.times[(i * world + rank) % len(cams)], it=args.iteration)   # noqa: E731
@@ -509,12 +513,15 @@ def main():
                 evs(i)
             sr.flush()
             torch.cuda.synchronize()
-            te = time.perf_counter()
-            for i in range(n_eval):
-                evs(i)
-            eval_again = sr.flush()
-            torch.cuda.synchronize()
-            eval_fps = n_eval / (time.perf_counter() - te)
+            reps, eval_again = [], 0
+            for _ in range(3):
+                te = time.perf_counter()
+                for i in range(n_eval):
+                    evs(i)
+                eval_again += sr.flush()
+                torch.cuda.synchronize()
+                reps.append(n_eval / (time.perf_counter() - te))
+            eval_fps = sorted(reps)[1]
     _lib.profile_enable(2)                      # untimed pass for the per-kernel table
     for i in range(min(args.steps, 5)):
         one_step(preroll + args.warmup + args.steps + i)
