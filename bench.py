@@ -348,6 +348,9 @@ def main():
     ap.add_argument("--debug-option", action="append", default=[], metavar="KEY=VALUE",
                     help="gp_debug_option(KEY, VALUE) before the run (the library's A/B knobs, e.g. 8=2: the three-pass 11-bit depth sort); repeatable")
     ap.add_argument("--render-only", action="store_true", help="time eval-style forward renders instead of train steps")
+    ap.add_argument("--roofline-sample-period", type=int, default=8,
+                    help="the roofline kernel is bracketed by hipEvents at every P-th step of the timed region (a bracket is a ~10 us bubble "
+                         "on the stream; 1 = every step)")
     ap.add_argument("--no-chain-sh", action="store_true",
                     help="N > 1, sharded exchange: keep the SH regions' Adam + all-gather on the compute stream (A/B of TrainStep._chain_sh)")
     ap.add_argument("--replicated-adam", action="store_true",
@@ -425,6 +428,7 @@ def main():
         dist.barrier()
     # timed region: only the roofline kernel (composite forward) is bracketed by hipEvents -- every
     # bracket costs ~10 us of stream bubble, so the full per-kernel table is taken in a separate pass
+    _lib.check(_lib.lib().gp_debug_option(12, int(args.roofline_sample_period)), "gp_debug_option")
     _lib.profile_enable(1)
     _lib.profile_collect()
     if args.time_waits and getattr(ts.reducer, "exposed_wait_ms", None):
@@ -446,6 +450,7 @@ def main():
         ts.reducer.time_waits = False
     prof = _lib.profile_collect()
     _lib.profile_enable(0)
+    _lib.check(_lib.lib().gp_debug_option(12, 0), "gp_debug_option")
     # the headline's depth sort runs three passes under a promise about the key range, which holds for scenes whose visible depths span less
     # than a factor of four (config.depth_sort): the same step WITHOUT the promise (four passes, what a deeper scene pays), 10 untimed-for-
     # the-headline steps, so that the scene-dependent part of the number is visible in the record
@@ -560,6 +565,8 @@ def main():
             roof = {"kernel": "composite_fwd", "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
                     "algorithmic_bytes": bytes_alg, "avg_ms": round(avg_ms, 4),
+                    # hipEvent pairs around the kernel's launches INSIDE the timed region: every `event_sample_period`-th step
+                    "event_samples": int(prof["composite_fwd"][0]), "event_sample_period": int(args.roofline_sample_period),
                     # `bound` is the contract's roofline (SURVEY 8d prices the kernel in bytes); what the kernel WAITS for is the vector ALU
                     # (valu_issue_frac / valu_busy below): the fraction of the HBM roof is therefore capped by instructions, not by traffic
                     "binding_resource": "valu"}

@@ -24,6 +24,14 @@ bool gp_prof_on() { return g_level > 0; }
 void* gp_prof_begin(const char* name, hipStream_t s, int level) {
     if (g_level < level) return nullptr;
     std::lock_guard<std::mutex> lk(g_mu);
+    // level 1 (one tagged kernel inside a timed region): every P-th launch only, P = gp_debug_option(12, P) -- an event pair is a
+    // ~10 us bubble on the stream, and the region being timed should not pay it at every step for an average that 1 / P of the
+    // launches give as well (the count of bracketed launches comes back in gp_profile_entry.launches)
+    if (g_level == 1) {
+        static unsigned seen = 0;
+        const int period = gp_debug_get(12);
+        if (period > 1 && (seen++ % (unsigned)period) != 0) return nullptr;
+    }
     ProfRec r{name, take_event(), take_event()};
     if (!r.a || !r.b) return nullptr;
     (void)hipEventRecord(r.a, s);

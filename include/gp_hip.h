@@ -581,7 +581,7 @@ int gp_microbench_gather(const void* src, int rec_bytes, int stride_bytes, const
  * key 5: 1 = tile binning by duplicate + radix sort instead of by counting, csrc/bin_kernels.hip; key 6: ablation bits of the
  * binning scatter kernel; key 8: 2 = depth sort in three 11-bit counting passes instead of four 8-bit radix passes -- measured slower, kept for the A/B;
  * key 9: ablation bits of the 16-bit MLP forward, tools/probe/mlp16_ablate.py; key 10: 16-row blocks per slab of the 16-bit weight gradient;
- * key 11: 1 = the pair of loss kernels in gp_train_step_run; key 13: 1 = the 16-row kernels where the feature-split small-row MLP would run,
+ * key 11: 1 = the pair of loss kernels in gp_train_step_run; key 12: P > 1 = gp_profile_enable(1) brackets every P-th launch only; key 13: 1 = the 16-row kernels where the feature-split small-row MLP would run,
  * 2 = its agent-scope form of the exchange; key 14: 1 = activation launches of their own in gp_train_step_run instead of raw_activations).
  * Never needed by a caller of the render path. */
 int gp_debug_option(int key, int value);
