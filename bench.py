@@ -161,6 +161,28 @@ def cpu_baseline(args, pc, cams, gts, margs, seconds_budget=30.0):
 import contextlib
 
 
+def no_gc():
+    """Timed loops run behind `gc.freeze()`: the process's long-lived heap (torch, numpy, the scene) moves to the
+    permanent generation, so a generation-2 pass that falls into a timed loop walks only what the loop itself allocated.  Without it
+    such a pass is ~100 ms here -- one of them inside the 20-step loop of the host-bound graph path doubled that leg's reading (a
+    step of 98 ms among steps of 4.8 ms: GP_BENCH_DEBUG=1), and inside the headline's region it would drain the launch queue.  The
+    collector itself stays ON: switched off (as `timeit` does) the cyclic garbage of the steps keeps its device buffers, the caching
+    allocator hands out fresh blocks, and the steps get slower (dense variant 1.05 -> 1.10 ms; GP_BENCH_GC=1 leaves everything alone)."""
+    import gc
+
+    @contextlib.contextmanager
+    def cm():
+        if os.environ.get("GP_BENCH_GC") == "1":      # (A/B: leave the collector alone)
+            yield
+            return
+        gc.freeze()         # (no collect() in front: it changes which cached blocks the next allocations get, and with them the step time)
+        try:
+            yield
+        finally:
+            gc.unfreeze()
+    return cm()
+
+
 @contextlib.contextmanager
 def stdout_to_stderr():
     """Communicator start-up prints banners on the C library's stdout (RCCL's version line, gloo's "[Gloo] Rank ..."); stdout
@@ -254,11 +276,12 @@ def dense_variant(args, device, steps=20):
     for i in range(pre):
         ts.step(i)
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(steps):
-        ts.step(pre + i)
-    torch.cuda.synchronize()
-    ms = 1000.0 * (time.perf_counter() - t0) / steps
+    with no_gc():
+        t0 = time.perf_counter()
+        for i in range(steps):
+            ts.step(pre + i)
+        torch.cuda.synchronize()
+        ms = 1000.0 * (time.perf_counter() - t0) / steps
     _lib.profile_enable(2)
     _lib.profile_collect()
     for i in range(5):
@@ -435,16 +458,17 @@ def main():
         ts.reducer.time_waits = True
         ts.reducer.exposed_wait_ms(1)                  # (drop what the warm-up recorded)
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    pkg = None
-    for i in range(args.steps):
-        out = one_step(preroll + args.warmup + i)
-        pkg = out if args.render_only else out[1]
-    ts.sync_params()                            # (N > 1: the last step's parameter all-gather belongs to the timed work)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
+    with no_gc():
+        t0 = time.perf_counter()
+        pkg = None
+        for i in range(args.steps):
+            out = one_step(preroll + args.warmup + i)
+            pkg = out if args.render_only else out[1]
+        ts.sync_params()                            # (N > 1: the last step's parameter all-gather belongs to the timed work)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        elapsed = time.perf_counter() - t0
     waits = ts.reducer.exposed_wait_ms(args.steps) if (args.time_waits and getattr(ts.reducer, "exposed_wait_ms", None)) else None
     if waits is not None:
         ts.reducer.time_waits = False
@@ -484,7 +508,7 @@ def main():
     if not args.render_only:
         from gaussianprediction_amd.renderer import render as _render
         n_eval = max(10, min(args.steps, 50))
-        with torch.no_grad():
+        with torch.no_grad(), no_gc():
             ev = lambda i: _render(cams[(i * world + rank) % len(cams)], pc, ts.pipe, ts.bg,              # noqa: E731
                                    time=ts.times[(i * world + rank) % len(cams)], it=args.iteration)
             for i in range(3):
@@ -742,11 +766,20 @@ def main():
                 for i in range(5):
                     ts2.step(i)
                 torch.cuda.synchronize()
-                t1 = time.perf_counter()
-                for i in range(20):
-                    ts2.step(5 + i)
-                torch.cuda.synchronize()
-                result["train_step_with_weights_model_ms"] = round(1000.0 * (time.perf_counter() - t1) / 20, 3)
+                host = []
+                with no_gc():
+                    t1 = time.perf_counter()
+                    for i in range(20):
+                        th = time.perf_counter()
+                        ts2.step(5 + i)
+                        host.append(time.perf_counter() - th)
+                    torch.cuda.synchronize()
+                    result["train_step_with_weights_model_ms"] = round(1000.0 * (time.perf_counter() - t1) / 20, 3)
+                if os.environ.get("GP_BENCH_DEBUG"):
+                    ms = torch.cuda.memory_stats()
+                    print("[weights-model leg] host ms per step:", [round(1e3 * h, 2) for h in host], "reserved GB",
+                          round(torch.cuda.memory_reserved() / 2**30, 2), "alloc retries", ms.get("num_alloc_retries"),
+                          "device mallocs", ms.get("num_device_alloc"), "device frees", ms.get("num_device_free"), file=sys.stderr, flush=True)
             except Exception as e:
                 result["train_step_with_weights_model_ms"] = f"failed: {e}"
         print(json.dumps(result), flush=True)
