@@ -166,8 +166,8 @@ def no_gc():
     permanent generation, so a generation-2 pass that falls into a timed loop walks only what the loop itself allocated.  Without it
     such a pass is ~100 ms here -- one of them inside the 20-step loop of the host-bound graph path doubled that leg's reading (a
     step of 98 ms among steps of 4.8 ms: GP_BENCH_DEBUG=1), and inside the headline's region it would drain the launch queue.  The
-    collector itself stays ON: switched off (as `timeit` does) the cyclic garbage of the steps keeps its device buffers, the caching
-    allocator hands out fresh blocks, and the steps get slower (dense variant 1.05 -> 1.10 ms; GP_BENCH_GC=1 leaves everything alone)."""
+    collector itself stays ON and nothing is collected in front of a loop (either way the 20-step dense variant read 1.10 instead of
+    1.04 ms per step; GP_BENCH_GC=1 leaves everything alone)."""
     import gc
 
     @contextlib.contextmanager
@@ -175,7 +175,7 @@ def no_gc():
         if os.environ.get("GP_BENCH_GC") == "1":      # (A/B: leave the collector alone)
             yield
             return
-        gc.freeze()         # (no collect() in front: it changes which cached blocks the next allocations get, and with them the step time)
+        gc.freeze()         # (no collect() in front: measured, it costs the loop behind it ~1 ms once -- 20-step dense variant 1.04 -> 1.10 ms per step)
         try:
             yield
         finally:
