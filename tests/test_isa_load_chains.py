@@ -20,14 +20,17 @@ pytestmark = pytest.mark.skipif(shutil.which(HIPCC) is None and not os.path.exis
     ("sort_scan.hip", ["gp_radix_hist_kernelILi8E", "gp_radix_scatter_kernelILi8E", "gp_radix_hist_kernelILi16E"]),
     ("deform_kernels.hip", ["gp_blend_fwd6_kernel", "gp_blend_bwd6_kernel", "gp_blend_fwd6_i16_kernel", "gp_blend_bwd6_i16_kernel", "gp_act_fwd_kernel", "gp_act_bwd_kernel"]),
     ("weights_kernels.hip", ["gp_knn_kernelILi35ELi6E"]),
-    ("raster_kernels.hip", ["gp_tile_ranges_kernel", "gp_preprocess_fwd_split_kernel"]),
+    # (the projection forward: a FULL workgroup stages its SH span with all twelve loads in flight -- stage_sh_full; the rolled form with its
+    # one-load tail is left for the last, partial workgroup only and accounts for one more wait behind a load)
+    ("raster_kernels.hip", ["gp_tile_ranges_kernel", ("gp_preprocess_fwd_split_kernel", 3)]),
     ("bin_kernels.hip", ["gp_bin_count_kernelILi2E", "gp_bin_scan_kernel", "gp_bin_scatter_kernelILi8E"]),
 ])
 def test_hot_kernels_keep_their_loads_batched(src, kernels):
     from isa_load_audit import CSRC, audit
     stats = audit(os.path.join(CSRC, src), HIPCC)
     for want in kernels:
+        want, limit = want if isinstance(want, tuple) else (want, 2)
         hits = [(k, v) for k, v in stats.items() if want in k]
         assert hits, f"{want} not found in {src}"
         for k, (loads, waits, tight) in hits:
-            assert loads >= 2 and tight <= 2, f"{k}: {tight} of {waits} full waits sit right behind one of its {loads} loads (serialized loads?)"
+            assert loads >= 2 and tight <= limit, f"{k}: {tight} of {waits} full waits sit right behind one of its {loads} loads (serialized loads?)"
