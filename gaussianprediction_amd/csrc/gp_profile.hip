@@ -9,6 +9,7 @@
 struct ProfRec { const char* name; hipEvent_t a, b; };
 static std::mutex g_mu;
 static int g_level = 0;   // 0 off, 1 = only the kernels tagged level 1 (roofline kernel), 2 = every kernel
+static unsigned g_seen = 0;   // level-1 launches since gp_profile_enable (the first one is always bracketed)
 static std::vector<ProfRec> g_recs;
 static std::vector<hipEvent_t> g_pool;
 
@@ -28,9 +29,8 @@ void* gp_prof_begin(const char* name, hipStream_t s, int level) {
     // ~10 us bubble on the stream, and the region being timed should not pay it at every step for an average that 1 / P of the
     // launches give as well (the count of bracketed launches comes back in gp_profile_entry.launches)
     if (g_level == 1) {
-        static unsigned seen = 0;
         const int period = gp_debug_get(12);
-        if (period > 1 && (seen++ % (unsigned)period) != 0) return nullptr;
+        if (period > 1 && (g_seen++ % (unsigned)period) != 0) return nullptr;
     }
     ProfRec r{name, take_event(), take_event()};
     if (!r.a || !r.b) return nullptr;
@@ -48,6 +48,7 @@ void gp_prof_end(void* h, hipStream_t s) {
 extern "C" int gp_profile_enable(int on) {
     std::lock_guard<std::mutex> lk(g_mu);
     g_level = on < 0 ? 0 : on;
+    g_seen = 0;
     return 0;
 }
 
