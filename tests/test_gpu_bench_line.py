@@ -42,7 +42,9 @@ def test_bench_prints_one_well_formed_line():
     ks = d["kernels_ms"]
     for name in ("composite_fwd", "composite_bwd", "preprocess_fwd", "preprocess_bwd", "depth_sort", "adam", "l1_ssim_fused"):
         assert ks[name]["ms_per_step"] > 0, name
-    assert sum(v["ms_per_step"] for v in ks.values()) <= 1.15 * d["ms_per_step"]                           # one stream: the kernels fit in the step
+    # one stream: the kernels fit in the step.  (Each entry of the table carries its hipEvent bracket, ~3 us x 27 launches -- a quarter of
+    # this small scene's step, which itself is timed with one bracket per eight steps: hence the margin.)
+    assert sum(v["ms_per_step"] for v in ks.values()) <= 1.35 * d["ms_per_step"]
     assert d["dense_variant"]["R_per_gaussian"] > d["config"]["R_per_gaussian"]
     assert d["dense_variant"]["contributing_pairs"] > 0 and d["dense_variant"]["evaluated_pairs"] >= d["dense_variant"]["contributing_pairs"]
     assert r["binding_resource"] == "valu"
